@@ -1,0 +1,195 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see pgo_common.h header).
+//
+// Plain-C entry points for ctypes (tests/, __graft_entry__.smoke(), bench.py cpu_baseline).
+#include <chrono>
+#include <cstdio>
+#include <thread>
+
+#include "pgo_env.h"
+
+using pgo::Env;
+
+extern "C" {
+
+// Registers a decoded RGBA8 texture under the reference's asset path.
+void pgo_put_texture(const char* name, int w, int h, const uint8_t* rgba) {
+    pgo::TextureBank::global().put(name, w, h, rgba);
+}
+
+int pgo_texture_count() { return static_cast<int>(pgo::TextureBank::global().size()); }
+
+// game: "coinrun" | "maze".  Returns nullptr for unknown games.
+void* pgo_make(const char* game, uint32_t seed, int render_enabled) {
+    std::string g(game);
+    Env* e = nullptr;
+    if (g == "coinrun")
+        e = pgo::new_coinrun();
+    else if (g == "maze")
+        e = pgo::new_maze();
+    if (!e) return nullptr;
+    e->set_render_enabled(render_enabled != 0);
+    e->make(seed);
+    return e;
+}
+
+void pgo_close(void* h) { delete static_cast<Env*>(h); }
+
+void pgo_reset(void* h, int reseed, int32_t seed) { static_cast<Env*>(h)->reset(reseed != 0, seed); }
+
+void pgo_step(void* h, int action) { static_cast<Env*>(h)->step(action); }
+
+float pgo_reward(void* h) { return static_cast<Env*>(h)->reward; }
+int pgo_terminated(void* h) { return static_cast<Env*>(h)->terminated ? 1 : 0; }
+int pgo_truncated(void* h) { return static_cast<Env*>(h)->truncated ? 1 : 0; }
+const uint8_t* pgo_obs(void* h) { return static_cast<Env*>(h)->obs; }
+int pgo_dump_state(void* h, float* out, int cap) { return static_cast<Env*>(h)->dump_state(out, cap); }
+int pgo_dump_tiles(void* h, uint8_t* out, int cap) { return static_cast<Env*>(h)->dump_tiles(out, cap); }
+uint32_t pgo_rng_peek(void* h) { return static_cast<Env*>(h)->rng_peek(); }
+
+// SURVEY.md Appendix C driver: make(seed) → reset → `steps` LCG actions, reset on terminated.
+// Fills crc of the (reward f32 LE, terminated u8) stream, episode count, reward sum and the
+// first `cap` episode lengths.  Rendering is off (the traces are raster-independent).
+int pgo_trace(const char* game, uint32_t seed, int steps, uint32_t* crc_out, int* episodes_out, double* reward_sum_out,
+              int* lengths_out, int cap) {
+    Env* e = static_cast<Env*>(pgo_make(game, seed, 0));
+    if (!e) return -1;
+    e->reset(false, 0);
+    pgo::Crc32 crc;
+    uint32_t s = 1;
+    int episodes = 0, len = 0;
+    double total = 0.0;
+    for (int i = 0; i < steps; i++) {
+        s = s * 1664525u + 1013904223u;
+        int action = static_cast<int>((s >> 16) % 15);
+        e->step(action);
+        len++;
+        float r = e->reward;
+        uint8_t t = e->terminated ? 1 : 0;
+        crc.feed(&r, 4);
+        crc.feed(&t, 1);
+        total += r;
+        if (t) {
+            if (episodes < cap) lengths_out[episodes] = len;
+            episodes++;
+            len = 0;
+            e->reset(false, 0);
+        }
+    }
+    *crc_out = crc.value();
+    *episodes_out = episodes;
+    *reward_sum_out = total;
+    delete e;
+    return 0;
+}
+
+// Vector rollout used for parity checks and the CPU baseline: N independent envs with seeds
+// seed_base + i (make, then one reset — exactly CEnv(lib, options={"seed": s}).reset()),
+// actions from the same counter hash the HIP engine uses (include/procgen2_vec.h), auto-reset
+// on the step after `terminated` (the reset replaces that step; reward 0, done 0).
+// obs_out: nullptr or [steps][n][12288]; rew_out [steps][n]; done_out [steps][n].
+struct pgo_vec;
+
+static inline uint32_t mix32(uint32_t x) {  // the action hash of include/procgen2_vec.h
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+
+int pgo_synthetic_action(uint32_t run_seed, uint32_t step, uint32_t env) {
+    uint32_t h = mix32(mix32(step * 0x9E3779B9u + run_seed) ^ (env * 0x85EBCA6Bu + 0xC2B2AE35u));
+    return static_cast<int>((static_cast<uint64_t>(h) * 15u) >> 32);
+}
+
+struct VecState {
+    std::vector<Env*> envs;
+    std::vector<uint8_t> pending_reset;
+    uint32_t step_counter = 0;
+};
+
+void* pgo_vec_make(const char* game, int n, uint32_t seed_base, int env_offset, int render_enabled) {
+    auto* v = new VecState();
+    for (int i = 0; i < n; i++) {
+        Env* e = static_cast<Env*>(pgo_make(game, seed_base + static_cast<uint32_t>(env_offset + i), render_enabled));
+        if (!e) {
+            delete v;
+            return nullptr;
+        }
+        e->reset(false, 0);
+        v->envs.push_back(e);
+    }
+    v->pending_reset.assign(n, 0);
+    return v;
+}
+
+void pgo_vec_close(void* h) {
+    auto* v = static_cast<VecState*>(h);
+    for (Env* e : v->envs) delete e;
+    delete v;
+}
+
+// One vector step over envs [lo, hi) with explicit actions (nullptr → synthetic hash with
+// run_seed and the global env index env_offset + i).
+static void vec_step_range(VecState* v, int lo, int hi, const int32_t* actions, uint32_t run_seed, int env_offset,
+                           uint8_t* obs_out, float* rew_out, uint8_t* done_out) {
+    for (int i = lo; i < hi; i++) {
+        Env* e = v->envs[i];
+        if (v->pending_reset[i]) {
+            e->reset(false, 0);
+            e->reward = 0.0f;
+            e->terminated = false;
+            v->pending_reset[i] = 0;
+        } else {
+            int a = actions ? actions[i] : pgo_synthetic_action(run_seed, v->step_counter, env_offset + i);
+            e->step(a);
+            if (e->terminated) v->pending_reset[i] = 1;
+        }
+        if (obs_out) std::memcpy(obs_out + size_t(i) * pgo::kObsBytes, e->obs, pgo::kObsBytes);
+        if (rew_out) rew_out[i] = e->reward;
+        if (done_out) done_out[i] = e->terminated ? 1 : 0;
+    }
+}
+
+void pgo_vec_step(void* h, const int32_t* actions, uint32_t run_seed, int env_offset, int threads, uint8_t* obs_out,
+                  float* rew_out, uint8_t* done_out) {
+    auto* v = static_cast<VecState*>(h);
+    const int n = static_cast<int>(v->envs.size());
+    if (threads <= 1) {
+        vec_step_range(v, 0, n, actions, run_seed, env_offset, obs_out, rew_out, done_out);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; t++) {
+            int lo = static_cast<int>(int64_t(n) * t / threads), hi = static_cast<int>(int64_t(n) * (t + 1) / threads);
+            pool.emplace_back(vec_step_range, v, lo, hi, actions, run_seed, env_offset, obs_out, rew_out, done_out);
+        }
+        for (auto& th : pool) th.join();
+    }
+    v->step_counter++;
+}
+
+void pgo_vec_obs(void* h, uint8_t* obs_out) {
+    auto* v = static_cast<VecState*>(h);
+    for (size_t i = 0; i < v->envs.size(); i++)
+        std::memcpy(obs_out + i * pgo::kObsBytes, v->envs[i]->obs, pgo::kObsBytes);
+}
+
+int pgo_vec_dump_state(void* h, int env, float* out, int cap) {
+    return static_cast<VecState*>(h)->envs[env]->dump_state(out, cap);
+}
+int pgo_vec_dump_tiles(void* h, int env, uint8_t* out, int cap) {
+    return static_cast<VecState*>(h)->envs[env]->dump_tiles(out, cap);
+}
+
+// Times `steps` vector steps (synthetic actions) and returns env-steps per second.
+double pgo_vec_bench(void* h, int steps, uint32_t run_seed, int threads) {
+    auto* v = static_cast<VecState*>(h);
+    auto t0 = std::chrono::steady_clock::now();
+    for (int s = 0; s < steps; s++) pgo_vec_step(h, nullptr, run_seed, 0, threads, nullptr, nullptr, nullptr);
+    auto t1 = std::chrono::steady_clock::now();
+    double sec = std::chrono::duration<double>(t1 - t0).count();
+    return double(steps) * double(v->envs.size()) / sec;
+}
+
+}  // extern "C"

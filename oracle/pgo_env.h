@@ -1,0 +1,76 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see pgo_common.h header).
+//
+// One env instance = what one loaded reference .so image holds in its globals
+// (SURVEY.md §0 fact 1).  Life cycle mirrors the cenv entry points:
+//   make(seed)  ≙ cenv_make   (games/<g>/<g>.cpp: seeds rng, builds level 0 which is never observed — D1)
+//   reset()     ≙ cenv_reset  (optional reseed, new level, render, pack)
+//   step(a)     ≙ cenv_step   (sub-steps, render, pack)
+#pragma once
+
+#include "pgo_raster.h"
+
+namespace pgo {
+
+constexpr int kObsW = 64;
+constexpr int kObsH = 64;
+constexpr int kObsBytes = kObsW * kObsH * 3;
+
+class Env {
+   public:
+    Env() : surface_(kObsW, kObsH) { painter_.target = &surface_; }
+    virtual ~Env() = default;
+
+    void make(uint32_t seed) {
+        rng_.seed(seed);
+        on_make();
+        new_level();
+    }
+    void reset(bool reseed, int32_t seed) {
+        // `rng.seed(options[i].value.i)`: int → unsigned long → mod 2^32 (coinrun.cpp:316)
+        if (reseed) rng_.seed(static_cast<uint32_t>(seed));
+        new_level();
+        observe();
+    }
+    void step(int action) {
+        advance(action);
+        observe();
+    }
+
+    void set_render_enabled(bool on) { painter_.enabled = on; }
+
+    float reward = 0.0f;
+    bool terminated = false;
+    bool truncated = false;
+    uint8_t obs[kObsBytes] = {0};
+
+    // Debug/parity taps: a flat float dump of the logical game state, game-defined layout.
+    virtual int dump_state(float* out, int cap) const = 0;
+    // Level dump: tile ids as the game stores them (column-major y + x*H), returns count.
+    virtual int dump_tiles(uint8_t* out, int cap) const = 0;
+    long draw_calls() const { return painter_.draw_calls; }
+    uint32_t rng_peek() {  // next raw output without consuming
+        std::mt19937 copy = rng_.eng;
+        return static_cast<uint32_t>(copy());
+    }
+
+   protected:
+    virtual void on_make() = 0;         // load textures, fixed setup
+    virtual void new_level() = 0;       // the game's reset()
+    virtual void advance(int action) = 0;  // the sub-step loop of cenv_step
+    virtual void paint() = 0;           // render_game(true)
+
+    void observe() {
+        if (!painter_.enabled) return;  // logic-only traces: no textures needed
+        paint();
+        pack_rgb(surface_, obs);
+    }
+
+    Rng rng_;
+    Surface surface_;
+    Painter painter_;
+};
+
+Env* new_coinrun();
+Env* new_maze();
+
+}  // namespace pgo

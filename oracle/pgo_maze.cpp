@@ -1,0 +1,264 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see pgo_common.h header).
+//
+// maze: CPU restatement of SURVEY.md row G2.
+//   step   games/maze/maze.cpp:279-330, common_systems.cpp:69-136
+//   render games/maze/maze.cpp:386-414, tilemap.cpp:111-133, common_systems.cpp:41-63,138-150
+//   reset  games/maze/maze.cpp:416-438, tilemap.cpp:31-109, maze_generator.cpp:55-139,183-195
+// Config is the reference's compile-time default: hard_mode (25×25 world, fixed camera).
+#include <algorithm>
+
+#include "pgo_env.h"
+
+namespace pgo {
+namespace {
+
+enum Cell : uint8_t { kOpen = 0, kWall = 1 };
+
+const char* const kFloors[9] = {  // maze.cpp:62-72
+    "topdown_backgrounds/floortiles.png",          "topdown_backgrounds/backgrounddetailed1.png",
+    "topdown_backgrounds/backgrounddetailed2.png", "topdown_backgrounds/backgrounddetailed3.png",
+    "topdown_backgrounds/backgrounddetailed4.png", "topdown_backgrounds/backgrounddetailed5.png",
+    "topdown_backgrounds/backgrounddetailed6.png", "topdown_backgrounds/backgrounddetailed7.png",
+    "topdown_backgrounds/backgrounddetailed8.png"};
+
+// Randomised Kruskal over a padded grid (maze_generator.h / maze_generator.cpp).
+struct Carver {
+    static constexpr int kPad = 1;
+    static constexpr int kInvalid = -1, kSpace = 0, kBrick = 1, kStartCellQuirk = 10;  // maze_generator.h:15-18
+    int mw = 0, mh = 0, aw = 0, ah = 0;
+    std::vector<int> grid, rank, parent, open_cells;
+    std::unordered_set<int> open_set;
+    int n_open = 0;
+
+    int idx(int x, int y) const { return y + ah * x; }
+    int get(int x, int y) const {
+        if (x < 0 || y < 0 || x >= aw || y >= ah) return 1;
+        return grid[idx(x, y)];
+    }
+    int root(int c) {  // maze_generator.cpp:47-53, path halving
+        int cur = c;
+        while (parent[cur] != cur) cur = parent[cur] = parent[parent[cur]];
+        return cur;
+    }
+    void open(int x, int y) {  // maze_generator.cpp:34-45
+        grid[idx(x + kPad, y + kPad)] = kSpace;
+        int cell = y + mh * x;
+        if (open_set.find(cell) == open_set.end()) {
+            open_cells[n_open] = cell;
+            open_set.insert(cell);
+            n_open++;
+        }
+    }
+    void carve(int w, int h, Rng& rng) {  // maze_generator.cpp:55-139
+        mw = w;
+        mh = h;
+        aw = w + 2 * kPad;
+        ah = h + 2 * kPad;
+        rank.assign(aw * ah, 0);
+        parent.assign(aw * ah, 0);
+        open_cells.assign(aw * ah, 0);
+        grid.assign(aw * ah, kBrick);
+        grid[idx(kPad, kPad)] = kSpace;
+        n_open = 0;
+        open_set.clear();
+        for (int i = 0; i < mw * mh; i++) parent[i] = i;
+
+        struct Seg {
+            int x1, y1, x2, y2;
+        };
+        std::vector<Seg> segs;
+        for (int i = 1; i < mw; i += 2)
+            for (int j = 0; j < mh; j += 2)
+                if (i > 0 && i < mw - 1) segs.push_back({i - 1, j, i + 1, j});
+        for (int i = 0; i < mw; i += 2)
+            for (int j = 1; j < mh; j += 2)
+                if (j > 0 && j < mh - 1) segs.push_back({i, j - 1, i, j + 1});
+
+        while (!segs.empty()) {
+            int n = rng.irange(0, static_cast<int>(segs.size()) - 1);
+            Seg s = segs[n];
+            int r0 = root(s.y1 + mh * s.x1);
+            int r1 = root(s.y2 + mh * s.x2);
+            int mx = (s.x1 + s.x2) / 2, my = (s.y1 + s.y2) / 2;
+            int centre = my + mh * mx;
+            if (get(mx + kPad, my + kPad) == kBrick && r0 != r1) {
+                open(s.x1, s.y1);
+                open(mx, my);
+                open(s.x2, s.y2);
+                if (rank[r0] > rank[r1]) {
+                    parent[r1] = r0;
+                    parent[centre] = r0;
+                } else {
+                    parent[r0] = r1;
+                    parent[centre] = r1;
+                    if (rank[r0] == rank[r1]) rank[r1]++;
+                }
+            }
+            segs.erase(segs.begin() + n);
+        }
+    }
+    void drop(int kind, Rng& rng) {  // maze_generator.cpp:183-195 (D7: compares the cell index with 10)
+        int k = rng.irange(0, n_open - 1);
+        while (open_cells[k] == kInvalid || open_cells[k] == kStartCellQuirk) k = rng.irange(0, n_open - 1);
+        int cell = open_cells[k];
+        open_cells[k] = kInvalid;
+        grid[idx(cell / mh + kPad, cell % mh + kPad)] = kind;
+    }
+};
+
+class Maze final : public Env {
+   public:
+    static constexpr int W = 25, H = 25, kTimeout = 500, kGoalMark = 2;
+
+    int dump_state(float* out, int cap) const override {
+        float v[8] = {a_pos.x, a_pos.y, static_cast<float>(a_forward), goal_pos.x, goal_pos.y,
+                      static_cast<float>(steps_), static_cast<float>(floor_), floor_shift_};
+        int n = std::min(cap, 8);
+        std::memcpy(out, v, n * sizeof(float));
+        return 8;
+    }
+    int dump_tiles(uint8_t* out, int cap) const override {
+        int n = std::min<int>(cap, W * H);
+        std::memcpy(out, tiles_.data(), n);
+        return n;
+    }
+
+   protected:
+    void on_make() override {
+        auto& bank = TextureBank::global();
+        tex_wall_ = bank.find("assets/kenney/Ground/Sand/sandCenter.png");
+        tex_cheese_ = bank.find("assets/misc_assets/cheese.png");
+        tex_mouse_ = bank.find("assets/kenney/Enemies/mouse_move.png");
+        for (int i = 0; i < 9; i++) tex_floor_[i] = bank.find(std::string("assets/") + kFloors[i]);
+    }
+
+    uint8_t at(int x, int y) const {
+        if (x < 0 || y < 0 || x >= W || y >= H) return kWall;
+        return tiles_[y + x * H];
+    }
+
+    void new_level() override {  // maze.cpp:416-438
+        ids_.refill();
+        in_sprite_.clear();
+        in_goal_.clear();
+        in_agent_.clear();
+        in_tilemap_.clear();
+
+        // tilemap.cpp:31-109
+        std::fill(tiles_.begin(), tiles_.end(), kWall);
+        const int dim = rng_.irange(0, (W - 1) / 2 - 1) * 2 + 3;
+        const int margin = (W - dim) / 2;
+        Carver carver;
+        carver.carve(dim, dim, rng_);
+        carver.drop(kGoalMark, rng_);
+        int gx = 0, gy = 0;
+        for (int i = 0; i < dim; i++)
+            for (int j = 0; j < dim; j++) {
+                int t = carver.get(i + Carver::kPad, j + Carver::kPad);
+                tiles_[(j + margin) + (i + margin) * H] = (t == Carver::kBrick) ? kWall : kOpen;
+                if (t == kGoalMark) {
+                    gx = i + margin;
+                    gy = j + margin;
+                }
+            }
+        int goal_id = ids_.take();
+        in_tilemap_.insert(goal_id);
+        in_sprite_.insert(goal_id);
+        in_goal_.insert(goal_id);
+        goal_pos = {static_cast<float>(gx) + 0.5f, static_cast<float>(H - 1 - gy) + 0.5f};
+
+        int agent_id = ids_.take();
+        in_tilemap_.insert(agent_id);
+        in_agent_.insert(agent_id);
+        a_pos = {static_cast<float>(margin) + 0.5f, static_cast<float>(H - 1 - margin) + 0.5f};
+        a_forward = true;
+
+        steps_ = 0;
+        floor_ = rng_.irange(0, 8);
+        floor_shift_ = rng_.unit();
+        goal_listed_ = false;  // sprite_render->clear_render()  (D2)
+        painter_.cam_pos = {W * 0.5f * kUnitPx, H * 0.5f * kUnitPx};
+    }
+
+    void advance(int action) override {  // maze.cpp:293-310, common_systems.cpp:69-136
+        int mx = action / 3 - 1;
+        int my = mx ? 0 : -(action % 3 - 1);
+        if (mx) {
+            if (at(static_cast<int>(a_pos.x + mx), H - 1 - static_cast<int>(a_pos.y)) == kOpen)
+                a_pos.x = static_cast<int>(a_pos.x + mx) + 0.5f;
+        } else if (my) {
+            if (at(static_cast<int>(a_pos.x), H - 1 - static_cast<int>(a_pos.y + my)) == kOpen)
+                a_pos.y = static_cast<int>(a_pos.y + my) + 0.5f;
+        }
+        Box body{a_pos.x - 0.5f, a_pos.y - 0.5f, 1.0f, 1.0f};
+        Box goal{goal_pos.x - 0.5f, goal_pos.y - 0.5f, 1.0f, 1.0f};
+        bool reached = boxes_touch(body, goal);
+        if (mx > 0.0f)
+            a_forward = true;
+        else if (mx < 0.0f)
+            a_forward = false;
+        goal_listed_ = true;  // sprite_render->update(dt): the draw list now holds the cheese
+
+        reward = reached * 10.0f;
+        terminated = reached;
+        truncated = false;
+        if (++steps_ >= kTimeout) terminated = true;
+    }
+
+    void paint() override {  // maze.cpp:386-414
+        surface_.clear_black();
+        float zoom = static_cast<float>(kObsW) / (kUnitPx * static_cast<float>(25));
+        painter_.cam_scale = zoom;
+        painter_.cam_size = {static_cast<float>(kObsW), static_cast<float>(kObsH)};
+
+        const Texture* bg = tex_floor_[floor_];
+        float aspect = static_cast<float>(bg->w) / static_cast<float>(bg->h);
+        float extra = aspect - 1.0f;
+        painter_.draw(bg, V2{-floor_shift_ * extra, 0.0f}, 64.0f * kUnitPx / bg->h);
+
+        {  // tilemap.cpp:111-133
+            const V2& cp = painter_.cam_pos;
+            const V2& cs = painter_.cam_size;
+            const float sc = painter_.cam_scale;
+            Box view{(cp.x - cs.x * 0.5f / sc) * kPxUnit, (cp.y - cs.y * 0.5f / sc) * kPxUnit, cs.x * kPxUnit / sc,
+                     cs.y * kPxUnit / sc};
+            int x0 = std::floor(view.x), y0 = std::floor(view.y);
+            int x1 = std::ceil(view.x + view.w), y1 = std::ceil(view.y + view.h);
+            for (int y = y0; y <= y1; y++)
+                for (int x = x0; x <= x1; x++) {
+                    if (at(x, H - 1 - y) == kOpen) continue;
+                    painter_.draw(tex_wall_, V2{x * kUnitPx, y * kUnitPx}, kUnitPx / tex_wall_->w);
+                }
+        }
+        if (goal_listed_) {  // cheese sprite: offset (-0.48,-0.5), scale 0.95, z=1 (tilemap.cpp:88)
+            float scale = 1.0f * 0.95f;
+            painter_.draw(tex_cheese_, V2{(goal_pos.x + -0.48f) * kUnitPx, (goal_pos.y + -0.5f) * kUnitPx},
+                          scale * kUnitPx / tex_cheese_->w, 1.0f, false);
+        }
+        {  // common_systems.cpp:138-150
+            float agent_scale = 1.0f;
+            V2 off{-0.5f, -0.5f};
+            painter_.draw(tex_mouse_, V2{(a_pos.x + off.x) * kUnitPx, (a_pos.y + off.y) * kUnitPx},
+                          kUnitPx / tex_mouse_->w * agent_scale, 1.0f, a_forward);
+        }
+    }
+
+   private:
+    std::vector<uint8_t> tiles_ = std::vector<uint8_t>(W * H, kWall);
+    IdPool ids_;
+    IdSet in_sprite_, in_goal_, in_agent_, in_tilemap_;
+    V2 a_pos, goal_pos;
+    bool a_forward = true, goal_listed_ = false;
+    int steps_ = 0, floor_ = 0;
+    float floor_shift_ = 0.0f;
+    const Texture* tex_wall_ = nullptr;
+    const Texture* tex_cheese_ = nullptr;
+    const Texture* tex_mouse_ = nullptr;
+    const Texture* tex_floor_[9] = {};
+};
+
+}  // namespace
+
+Env* new_maze() { return new Maze(); }
+
+}  // namespace pgo
