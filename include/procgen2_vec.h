@@ -1,0 +1,110 @@
+/* procgen2_vec.h — vector extension of the cenv ABI for the MI355X engine.
+ *
+ * The reference ABI (cenv/cenv.h:122-133) is single-env with process-global state and host buffers;
+ * at 65 536 envs one step's observations are 805 MB, which cannot cross PCIe at the target rate
+ * (SURVEY.md §7 hard part 5, §8b "Consequence for a vector engine").  This extension keeps the same
+ * life cycle — make / reset / step / close, games/<g>/<g>.cpp cenv_make:127, cenv_reset:308,
+ * cenv_step:341, cenv_close:413 — but for N envs at once, with explicit handles and DEVICE pointers.
+ *
+ * Plain C ABI: pointers and sizes only.  Pointers documented as "device" are HIP device pointers on
+ * the env's GPU.  All work is enqueued on the env's stream (its own, or the one given at make);
+ * pgv_sync waits for it.  Every function returns 0 on success; on failure the message is in
+ * pgv_last_error().  There is no CPU fallback: without a usable GPU pgv_make fails.
+ *
+ * Semantics that mirror the reference:
+ *   - env i is seeded with seed_base + env_offset + i and builds one level that is never observed
+ *     (cenv_make calls reset(), coinrun.cpp:235,303 — SURVEY.md D1);
+ *   - pgv_reset ≙ cenv_reset on the selected envs (optional reseed), renders the reset frame;
+ *   - pgv_step ≙ cenv_step.  An env that reported terminated performs its reset on the NEXT
+ *     pgv_step instead of stepping (action ignored, reward 0, done 0, observation = reset frame),
+ *     i.e. the observation sequence equals the reference caller's `if term: env.reset()` loop
+ *     (game_test.py:36-40) with the per-env mt19937 stream continuing;
+ *   - truncated is always false in the reference games (coinrun.cpp:367) and is not materialised.
+ */
+#ifndef PROCGEN2_VEC_H
+#define PROCGEN2_VEC_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#include <stdint.h>
+
+#define PGV_API __attribute__((__visibility__("default")))
+
+#define PGV_OBS_BYTES 12288 /* 64*64*3, coinrun.cpp:24-25,185 */
+#define PGV_NUM_ACTIONS 15  /* coinrun.cpp:26 */
+
+typedef struct pgv_env pgv_env;
+
+/* Games available in this build: 0 "coinrun", 1 "maze".  Returns NULL past the end. */
+PGV_API const char* pgv_game_name(int32_t game_id);
+PGV_API int32_t pgv_game_id(const char* name); /* -1 if unknown */
+
+/* Create N envs of `game` on HIP device `device`.  `stream` is a hipStream_t to enqueue on, or NULL
+ * for an internally created stream.  Asset root: $PROCGEN2_ASSETS, else <dir of the .so>/../assets. */
+PGV_API int32_t pgv_make(const char* game, int32_t num_envs, int32_t device, uint32_t seed_base, int32_t env_offset,
+                         void* stream, pgv_env** out);
+PGV_API void pgv_close(pgv_env* env);
+
+/* Reset the envs whose mask byte is non-zero (device u8[N]; NULL = all).  seeds: device int32[N] to
+ * reseed each selected env's mt19937 (coinrun.cpp:313-317), or NULL to keep the streams running. */
+PGV_API int32_t pgv_reset(pgv_env* env, const uint8_t* d_mask, const int32_t* d_seeds);
+
+/* One step of every env.  d_actions: device int32[N], values 0..14 (others are no-ops except in maze,
+ * SURVEY.md D6/D20). */
+PGV_API int32_t pgv_step(pgv_env* env, const int32_t* d_actions);
+
+/* Same, with actions generated on the device: a = (mix(run_seed, step_index, env_offset+i) * 15) >> 32
+ * where step_index counts pgv_step/pgv_step_synthetic calls since make.  Used by the benchmark so
+ * the CPU oracle sees identical streams without a host transfer. */
+PGV_API int32_t pgv_step_synthetic(pgv_env* env, uint32_t run_seed);
+PGV_API int32_t pgv_synthetic_action(uint32_t run_seed, uint32_t step_index, uint32_t global_env);
+
+/* Host-pointer conveniences (synchronous upload, then the calls above): for callers without device
+ * memory of their own, e.g. the cenv shim and the parity tests.  h_mask / h_seeds may be NULL. */
+PGV_API int32_t pgv_step_host(pgv_env* env, const int32_t* h_actions);
+PGV_API int32_t pgv_reset_host(pgv_env* env, const uint8_t* h_mask, const int32_t* h_seeds);
+
+/* PNG → RGBA8 through the engine's own decoder (host only, no GPU needed): lets tests compare the
+ * atlas loader with an independent decoder.  Returns 0 and fills w/h; copies min(cap, w*h*4) bytes. */
+PGV_API int32_t pgv_decode_png(const char* path, int32_t* w, int32_t* h, uint8_t* h_rgba, int64_t cap);
+
+PGV_API int32_t pgv_sync(pgv_env* env);
+
+/* Result buffers (device pointers, valid until pgv_close or the next pgv_bind_outputs):
+ *   obs    u8 [N][64][64][3]   row-major HWC, one contiguous slab
+ *   reward f32[N]
+ *   done   u8 [N]              terminated flag of the last step */
+PGV_API uint8_t* pgv_obs(pgv_env* env);
+PGV_API float* pgv_reward(pgv_env* env);
+PGV_API uint8_t* pgv_done(pgv_env* env);
+/* Let the caller own the result buffers (e.g. torch tensors): any pointer may be NULL to keep the
+ * engine's own allocation. */
+PGV_API int32_t pgv_bind_outputs(pgv_env* env, uint8_t* d_obs, float* d_reward, uint8_t* d_done);
+
+PGV_API int32_t pgv_num_envs(pgv_env* env);
+PGV_API int32_t pgv_device(pgv_env* env);
+PGV_API void* pgv_stream(pgv_env* env);
+
+/* Synchronous copies to host memory (any pointer may be NULL). */
+PGV_API int32_t pgv_copy_out(pgv_env* env, uint8_t* h_obs, float* h_reward, uint8_t* h_done);
+
+/* Measurement helper for bench.py: runs `steps` synthetic steps and returns, from HIP events recorded
+ * on the env's stream, the total time of the region and the summed time of the dominant (render)
+ * kernel launches inside it. */
+PGV_API int32_t pgv_timed_steps(pgv_env* env, int32_t steps, uint32_t run_seed, double* total_ms,
+                                double* render_kernel_ms);
+
+/* Parity taps (host pointers): game-defined state vector / tile ids of one env; return the full
+ * length, copy at most `cap` items. */
+PGV_API int32_t pgv_dump_state(pgv_env* env, int32_t index, float* h_out, int32_t cap);
+PGV_API int32_t pgv_dump_tiles(pgv_env* env, int32_t index, uint8_t* h_out, int32_t cap);
+
+PGV_API const char* pgv_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* PROCGEN2_VEC_H */

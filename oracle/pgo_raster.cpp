@@ -34,7 +34,8 @@ void Surface::clear_black() {
 }
 
 // Raster spec.
-//  S1  dst rect → integers by truncation toward zero of x, y, w, h; nothing is drawn if w<=0 or h<=0.
+//  S1  dst rect → integers by truncation toward zero of x, y, w, h; nothing is drawn unless 1 <= w,h < 32768
+//      and |x|,|y| < 32768 (NaN fails every comparison, so a non-finite rect draws nothing).
 //  S2  src rect → integers by truncation, then intersected with the texture; nothing is drawn if empty.
 //      The dst rect is NOT adjusted for the part of src that fell outside the texture.
 //  S3  nearest sampling at pixel centres in integer arithmetic:
@@ -51,9 +52,12 @@ void spec_blit(Surface& target, const Texture& tex, float fsx, float fsy, float 
         std::fprintf(stderr, "pgo::spec_blit: rotated blits are not part of the spec yet\n");
         std::abort();
     }
+    // S1: a destination that is not finite, narrower than one pixel or absurdly large draws nothing
+    // (the reference's crop arithmetic yields 0*inf = NaN for sprites that end exactly on the viewport edge).
+    if (!(fdw >= 1.0f && fdh >= 1.0f && fdw < 32768.0f && fdh < 32768.0f)) return;
+    if (!(fdx > -32768.0f && fdx < 32768.0f && fdy > -32768.0f && fdy < 32768.0f)) return;
     const int dx = static_cast<int>(fdx), dy = static_cast<int>(fdy);
     const int dw = static_cast<int>(fdw), dh = static_cast<int>(fdh);
-    if (dw <= 0 || dh <= 0) return;
 
     int sx0 = static_cast<int>(fsx), sy0 = static_cast<int>(fsy);
     int sx1 = sx0 + static_cast<int>(fsw), sy1 = sy0 + static_cast<int>(fsh);

@@ -1,0 +1,96 @@
+"""Build recipe for the HIP engine (gfx950 only) — explicit hipcc calls, outputs in-tree.
+
+    python -m procgen2_amd.build            # build what is stale
+    python -m procgen2_amd.build --force
+
+Produces, under procgen2_amd/lib/:
+    libprocgen2_hip.so   the engine: vector ABI (include/procgen2_vec.h) + cenv ABI (include/procgen2_cenv.h)
+    libCoinRun.so        same objects, cenv_make defaults to coinrun  (reference name: games/coinrun/CMakeLists.txt)
+    libMaze.so           same objects, cenv_make defaults to maze     (reference name: games/maze/CMakeLists.txt)
+
+hipcc cross-compiles for gfx950 without a GPU present.  -ffp-contract=off is mandatory: the reference
+x86-64 build forms no FMAs and every float result has to match it bit for bit.
+"""
+import argparse
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "lib")
+OBJ = os.path.join(HERE, "build")
+ARCH = "gfx950"
+
+COMMON = ["--offload-arch=" + ARCH, "-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
+          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-I" + CSRC]
+
+KERNEL_SOURCES = ["coinrun.hip", "maze.hip"]
+HOST_SOURCES = ["png_decode.cpp"]
+ENGINE = "engine.hip"
+ALIASES = {"libprocgen2_hip.so": 0, "libCoinRun.so": 0, "libMaze.so": 1}
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC)")
+
+
+def _stale(out, deps):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _headers():
+    inc = os.path.join(HERE, "..", "include")
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
+           [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
+
+
+def _run(cmd, verbose):
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIB, exist_ok=True)
+    os.makedirs(OBJ, exist_ok=True)
+    cc = hipcc()
+    hdrs = _headers()
+    objs = []
+    for src in KERNEL_SOURCES + HOST_SOURCES:
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+        if force or _stale(obj, [path] + hdrs):
+            _run([cc] + COMMON + ["-c", path, "-o", obj], verbose)
+        objs.append(obj)
+    outputs = []
+    for lib, game in ALIASES.items():
+        eng = os.path.join(OBJ, "engine_g%d.o" % game)
+        if force or _stale(eng, [os.path.join(CSRC, ENGINE)] + hdrs):
+            _run([cc] + COMMON + ["-DPG_DEFAULT_GAME=%d" % game, "-c", os.path.join(CSRC, ENGINE), "-o", eng], verbose)
+        out = os.path.join(LIB, lib)
+        if force or _stale(out, objs + [eng]):
+            _run([cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out] + objs + [eng, "-lz", "-ldl"], verbose)
+        outputs.append(out)
+    return outputs
+
+
+def library_path(name="libprocgen2_hip.so"):
+    return os.path.join(LIB, name)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--quiet", action="store_true")
+    a = ap.parse_args()
+    for o in build(force=a.force, verbose=not a.quiet):
+        print("built", os.path.relpath(o))
+    sys.exit(0)

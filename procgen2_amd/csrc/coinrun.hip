@@ -1,0 +1,857 @@
+// coinrun on gfx950: level generation, physics and rendering for N concurrent envs.
+//
+// Reference:
+//   step   games/coinrun/coinrun.cpp:341-391, common_systems.cpp:7-39,65-105,121-252,284-313
+//   render games/coinrun/coinrun.cpp:443-470, tilemap.cpp:294-321, common_systems.cpp:41-63,254-278,315-337
+//   reset  games/coinrun/coinrun.cpp:472-507, tilemap.cpp:52-94,97-292
+//
+// Mapping onto the machine:
+//   * logic (reset + the 4 physics sub-steps) is SIMT across envs — one lane per env, state laid out
+//     struct-of-arrays across envs so the 64 lanes of a wave touch 64 consecutive floats;
+//   * render is SIMD within an env — one wavefront per env, target in LDS (pg_render.h).
+// The ECS of the reference is gone: an entity is a slot index (= the id the reference's allocator hands
+// out: saws/mobs in creation order, then the coin; the agent is kept apart), and the iteration order of the
+// reference's std::unordered_set-based systems is recomputed at reset with pg_order.h and stored as two
+// small permutations (sprite draw order, particle-owner order).
+#include "pg_engine.h"
+#include "pg_geom.h"
+#include "pg_order.h"
+#include "pg_render.h"
+#include "pg_rng.h"
+
+namespace pg {
+namespace coinrun {
+
+constexpr int W = 64, H = 64;
+constexpr int kMaxEnt = 36;  // 5 sections × max 7-wide pit of saws/mobs + the coin (tilemap.cpp:126-131,176-186)
+constexpr int kSparks = 10;  // tilemap.cpp:91
+
+enum Tile : uint8_t { kEmpty = 0, kWallTop, kWallMid, kLavaTop, kLavaMid, kCrate };  // tilemap.h:13-21
+enum Solid { kPass = 0, kFull, kOneWay };                                            // tilemap.h:23-27
+enum Kind { kSaw = 0, kMob = 1, kCoin = 2 };
+
+// Atlas order (texture_names() below must match).
+enum Tex {
+    kTexTop = 0,                  // 6 themes: <theme>Mid.png    (tile wall_top)
+    kTexMid = 6,                  // 6 themes: <theme>Center.png (tile wall_mid)
+    kTexLavaTop = 12,
+    kTexLava = 13,
+    kTexCrate = 14,               // 4
+    kTexWalker = 18,              // 9 × {still, move}
+    kTexSaw = 36,                 // 2
+    kTexCoin = 38,
+    kTexStand = 39,               // 5 each
+    kTexJump = 44,
+    kTexWalk1 = 49,
+    kTexWalk2 = 54,
+    kTexSpark = 59,
+    kTexBackdrop = 60,            // 49
+    kTexCount = 109
+};
+
+// scalar float fields
+enum { F_AX, F_AY, F_AVX, F_AVY, F_APHASE, F_CAMX, F_CAMY, F_BGSHIFT, F_COUNT };
+// scalar int fields
+enum { I_FLAGS, I_THEMES, I_NENT, I_NMOB, I_HASH_SPRITE, I_HASH_SPARK, I_COUNT };
+constexpr int kFlagGround = 1, kFlagForward = 2, kFlagListed = 4;
+// per-entity float fields
+enum { EF_X, EF_Y, EF_VX, EF_ANIM_T, EF_SPAWN_T, EF_COUNT };
+// per-entity byte fields
+enum { EB_INFO, EB_TEX, EB_DRAW_ORDER, EB_SPARK_ORDER, EB_COUNT };
+// EB_INFO bits: kind (0-1) | frame (2) | flip_x (3) | texture assigned (4)
+constexpr int kInfoFrame = 4, kInfoFlip = 8, kInfoTexSet = 16;
+
+struct State {
+    int n;
+    uint32_t* mt;    // [n][625]
+    uint8_t* tiles;  // [n][4096]   tile id | crate kind << 4, column-major y + x*H (tilemap.h:62-85)
+    float* f;        // [F_COUNT][n]
+    int32_t* i;      // [I_COUNT][n]
+    float* ef;       // [EF_COUNT][kMaxEnt][n]
+    uint8_t* eb;     // [EB_COUNT][kMaxEnt][n]
+    float* spark;    // [3][kMaxEnt][kSparks][n]   x, y, life
+};
+
+PG_D float& SF(const State& s, int field, int env) { return s.f[size_t(field) * s.n + env]; }
+PG_D int32_t& SI(const State& s, int field, int env) { return s.i[size_t(field) * s.n + env]; }
+PG_D float& EF(const State& s, int field, int e, int env) { return s.ef[(size_t(field) * kMaxEnt + e) * s.n + env]; }
+PG_D uint8_t& EB(const State& s, int field, int e, int env) { return s.eb[(size_t(field) * kMaxEnt + e) * s.n + env]; }
+PG_D float& SP(const State& s, int comp, int e, int k, int env) {
+    return s.spark[((size_t(comp) * kMaxEnt + e) * kSparks + k) * s.n + env];
+}
+
+struct TileMap {
+    uint8_t* t;  // this env's 4096 cells
+    PG_D void put(int x, int y, int id) {
+        if (x < 0 || y < 0 || x >= W || y >= H) return;
+        t[y + x * H] = static_cast<uint8_t>(id);
+    }
+    PG_D int at(int x, int y) const {
+        if (x < 0 || y < 0 || x >= W || y >= H) return kWallMid;
+        return t[y + x * H] & 7;
+    }
+    PG_D void fill(int x, int y, int w, int h, int id) {
+        for (int a = 0; a < w; a++)
+            for (int b = 0; b < h; b++) put(x + a, y + b, id);
+    }
+    PG_D void fill_capped(int x, int y, int w, int h, int body, int cap) {
+        fill(x, y, w, h - 1, body);
+        fill(x, y + h - 1, w, 1, cap);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// reset: coinrun.cpp:472-507 + tilemap.cpp:97-292
+// ------------------------------------------------------------------------------------------------
+struct LevelBuilder {
+    const State& s;
+    int env;
+    uint32_t* mt;
+    TileMap map;
+    int n_ent = 0, n_mob = 0;
+
+    PG_D int spawn(float x, float y, int kind, int tex, float vx) {
+        const int e = n_ent++;
+        EF(s, EF_X, e, env) = x;
+        EF(s, EF_Y, e, env) = y;
+        EF(s, EF_VX, e, env) = vx;
+        EF(s, EF_ANIM_T, e, env) = 0.0f;
+        EF(s, EF_SPAWN_T, e, env) = 0.0f;
+        EB(s, EB_INFO, e, env) = static_cast<uint8_t>(kind | (kind == kCoin ? kInfoTexSet : 0));
+        EB(s, EB_TEX, e, env) = static_cast<uint8_t>(tex);
+        return e;
+    }
+    PG_D void add_saw(int x, int y) {  // tilemap.cpp:52-68
+        spawn(static_cast<float>(x) + 0.5f, static_cast<float>(H - 1 - y) + 0.5f, kSaw, kTexSaw, 0.0f);
+    }
+    PG_D void add_mob(int x, int y) {  // tilemap.cpp:70-94
+        const int which = rng_int(mt, 0, 8);
+        const float vx = 0.15f * ((rng_real(mt, 0.0f, 1.0f) < 0.5f) * 2.0f - 1.0f);
+        const int e = spawn(static_cast<float>(x) + 0.5f, static_cast<float>(H - 1 - y) + 0.5f, kMob,
+                            kTexWalker + 2 * which, vx);
+        for (int k = 0; k < kSparks; k++) {
+            SP(s, 0, e, k, env) = 0.0f;
+            SP(s, 1, e, k, env) = 0.0f;
+            SP(s, 2, e, k, env) = 0.0f;
+        }
+        EB(s, EB_SPARK_ORDER, n_mob, env) = static_cast<uint8_t>(e);  // creation order; permuted below
+        n_mob++;
+    }
+
+    PG_D void build() {
+        const float max_jump = 1.5f, gravity = 0.2f, max_speed = 0.5f;
+        for (int k = 0; k < W * H; k++) map.t[k] = kEmpty;
+        map.fill(0, 0, W, 1, kWallTop);
+        map.fill(0, 0, 1, H, kWallMid);
+        map.fill(W - 1, 0, 1, H, kWallMid);
+        map.fill(0, H - 1, W, 1, kWallMid);
+
+        const int difficulty = rng_int(mt, 1, 3);
+        const int sections = rng_int(mt, difficulty, 2 * difficulty - 1);
+        int cx = 5, cy = 1;
+        const int pit_thresh = difficulty;
+        const int danger = rng_int(mt, 0, 2);
+
+        const float reach_x = max_speed * 2.0f * max_jump / gravity;
+        const float reach_y = max_jump * max_jump / (2.0f * gravity);
+        const int max_dx = static_cast<int>(reach_x - 0.5f);
+        const int max_dy = static_cast<int>(reach_y - 0.5f);
+
+        for (int sec = 0; sec < sections; sec++) {
+            if (cx + 15 >= W) break;
+            const int bump = difficulty / 3;
+            int dy = rng_int(mt, 1 + bump, 4 + bump);
+            dy = dy < max_dy ? dy : max_dy;
+            if (cy >= 20 || (cy >= 5 && rng_real(mt, 0.0f, 1.0f) < 0.5f)) dy = -dy;
+            const int dx = rng_int(mt, 3 + bump, 2 * difficulty + 2 + bump);
+            cy = (cy + dy) > 1 ? (cy + dy) : 1;
+
+            const bool pit = (dx > 7) && (cy > 3) && (rng_int(mt, 0, 19) >= pit_thresh);
+            if (pit) {
+                int x1 = rng_int(mt, 1, 3);
+                int x2 = rng_int(mt, 1, 3);
+                int gap = dx - x1 - x2;
+                if (gap > max_dx) {
+                    gap = max_dx;
+                    x2 = dx - x1 - gap;
+                }
+                map.fill_capped(cx, 0, x1, cy, kWallMid, kWallTop);
+                map.fill_capped(cx + dx - x2, 0, x2, cy, kWallMid, kWallTop);
+                const int lava_h = rng_int(mt, 1, cy - 3);
+                if (danger == 0) {
+                    map.fill_capped(cx + x1, 1, gap, lava_h, kLavaMid, kLavaTop);
+                } else if (danger == 1) {
+                    for (int k = 0; k < gap; k++) add_saw(cx + x1 + k, 1);
+                } else {
+                    for (int k = 0; k < gap; k++) add_mob(cx + x1 + k, 1);
+                }
+                if (gap > 4) {
+                    int x3, w1;
+                    if (gap == 5) {
+                        x3 = rng_int(mt, 1, 2);
+                        w1 = rng_int(mt, 1, 2);
+                    } else if (gap == 6) {
+                        x3 = rng_int(mt, 1, 2) + 1;
+                        w1 = rng_int(mt, 1, 2);
+                    } else {
+                        x3 = rng_int(mt, 1, 2) + 1;
+                        const int x4 = rng_int(mt, 1, 2) + 1;
+                        w1 = gap - x3 - x4;
+                    }
+                    map.fill_capped(cx + x1 + x3, cy - 1, w1, 1, kWallMid, kWallTop);
+                }
+            } else {
+                map.fill_capped(cx, 0, dx, cy, kWallMid, kWallTop);
+                int ob1 = -1;
+                const int ob2 = -1;
+                if (rng_int(mt, 0, 9) < 2 * difficulty && dx > 3) {
+                    ob1 = cx + rng_int(mt, 1, dx - 2);
+                    add_saw(ob1, cy);
+                }
+                if (rng_int(mt, 0, 9) < difficulty && dx > 3 && max_dx >= 4) {
+                    ob1 = cx + rng_int(mt, 1, dx - 2);
+                    add_mob(ob1, cy);
+                }
+                for (int k = 0; k < 2; k++) {
+                    const int crate_x = cx + rng_int(mt, 1, dx - 2);
+                    if (rng_real(mt, 0.0f, 1.0f) < 0.5f && ob1 != crate_x && ob2 != crate_x) {
+                        const int pile = rng_int(mt, 1, 3);
+                        for (int j = 0; j < pile; j++) {
+                            const int kind = rng_int(mt, 0, 3);  // crate_dist is drawn for every pile cell (tilemap.cpp:263)
+                            map.put(crate_x, cy + j, kCrate | (kind << 4));
+                        }
+                    }
+                }
+            }
+            cx += dx;
+        }
+        spawn(static_cast<float>(cx) + 0.5f, static_cast<float>(H - 1 - cy) + 0.5f, kCoin, kTexCoin, 0.0f);
+        map.fill_capped(cx, 0, 1, cy, kWallMid, kWallTop);
+        map.fill(cx + 1, 0, W - cx, H, kWallMid);
+    }
+};
+
+// Iteration order of a System's std::unordered_set after inserting `ids[0..n)` in that order into a
+// set that was clear()ed but kept its bucket array (packed = buckets | next_resize << 16).
+PG_D void episode_order(int32_t& packed, const uint8_t* ids, int n, uint8_t* out) {
+    int16_t next[kMaxEnt];
+    int16_t before[64];
+    HashOrder h;
+    h.next = next;
+    h.before = before;
+    h.head = kNil;
+    h.buckets = packed & 0xffff;
+    h.next_resize = packed >> 16;
+    h.count = 0;
+    if (h.buckets == 0) h.buckets = 1;
+    for (int b = 0; b < h.buckets; b++) before[b] = kNil;
+    for (int k = 0; k < n; k++) hash_insert(h, ids[k]);
+    int16_t p = static_cast<int16_t>(h.head);
+    for (int k = 0; k < n; k++) {
+        out[k] = static_cast<uint8_t>(p);
+        p = next[p];
+    }
+    packed = h.buckets | (h.next_resize << 16);
+}
+
+PG_D void new_level(const State& s, int env) {
+    LevelBuilder lb{s, env, s.mt + size_t(env) * kMtWords, TileMap{s.tiles + size_t(env) * (W * H)}};
+    lb.build();
+    uint32_t* mt = lb.mt;
+    const int backdrop = rng_int(mt, 0, 48);
+    const float shift = rng_real(mt, 0.0f, 1.0f);
+    const int alien = rng_int(mt, 0, 4);
+    const int ground = rng_int(mt, 0, 5);
+
+    SF(s, F_AX, env) = 1.5f;
+    SF(s, F_AY, env) = H - 1 - 1.0f;
+    SF(s, F_AVX, env) = 0.0f;
+    SF(s, F_AVY, env) = 0.0f;
+    SF(s, F_APHASE, env) = 0.0f;
+    SF(s, F_BGSHIFT, env) = shift;
+    SI(s, I_FLAGS, env) = kFlagForward;  // on_ground=false, face_forward=true, draw list cleared (D2)
+    SI(s, I_THEMES, env) = backdrop | (alien << 8) | (ground << 16);
+    SI(s, I_NENT, env) = lb.n_ent;
+    SI(s, I_NMOB, env) = lb.n_mob;
+    // camera keeps the previous episode's value (D3)
+
+    // T3/T4: sprite set = every non-agent entity in creation order; particle set = the mobs.
+    uint8_t ids[kMaxEnt], order[kMaxEnt];
+    for (int k = 0; k < lb.n_ent; k++) ids[k] = static_cast<uint8_t>(k);
+    int32_t packed = SI(s, I_HASH_SPRITE, env);
+    episode_order(packed, ids, lb.n_ent, order);
+    SI(s, I_HASH_SPRITE, env) = packed;
+    ZItem items[kMaxEnt];
+    for (int k = 0; k < lb.n_ent; k++) items[k] = {1.0f, order[k]};  // every coinrun sprite has z = 1
+    sort_by_key(items, lb.n_ent);
+    for (int k = 0; k < lb.n_ent; k++) EB(s, EB_DRAW_ORDER, k, env) = static_cast<uint8_t>(items[k].id);
+
+    for (int k = 0; k < lb.n_mob; k++) ids[k] = EB(s, EB_SPARK_ORDER, k, env);
+    packed = SI(s, I_HASH_SPARK, env);
+    episode_order(packed, ids, lb.n_mob, order);
+    SI(s, I_HASH_SPARK, env) = packed;
+    for (int k = 0; k < lb.n_mob; k++) EB(s, EB_SPARK_ORDER, k, env) = order[k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// tile collision, variant A (tilemap.cpp:323-396)
+// ------------------------------------------------------------------------------------------------
+struct Hit {
+    float x, y;
+    bool any;
+};
+
+template <class Pred>
+PG_D Hit collide(const TileMap& map, Box r, Pred solid, bool fallthrough, float step_y) {
+    bool any = false;
+    const int x0 = static_cast<int>(floorf(r.x)), y0 = static_cast<int>(floorf(r.y));
+    const int x1 = static_cast<int>(ceilf(r.x + r.w)), y1 = static_cast<int>(ceilf(r.y + r.h));
+    const float mid_x = r.x + r.w * 0.5f, mid_y = r.y + r.h * 0.5f;
+    Box cell{0.0f, 0.0f, 1.0f, 1.0f};
+    for (int y = y0; y <= y1; y++)
+        for (int x = x0; x <= x1; x++) {
+            const int kind = solid(map.at(x, H - 1 - y));
+            if (kind == kPass) continue;
+            cell.x = static_cast<float>(x);
+            cell.y = static_cast<float>(y);
+            const Box o = box_overlap(r, cell);
+            if (o.w == 0.0f && o.h == 0.0f) continue;
+            const float oy = o.y + o.h * 0.5f;
+            if (o.w > o.h) {
+                if (kind == kOneWay) {
+                    const bool inside = (r.y + r.h - step_y > cell.y);
+                    if (step_y > 0.01f && !fallthrough && !inside) {
+                        r.y = (oy > mid_y ? cell.y - r.h : cell.y + cell.h);
+                        any = true;
+                    }
+                } else {
+                    r.y = (oy > mid_y ? cell.y - r.h : cell.y + cell.h);
+                    any = true;
+                }
+            }
+        }
+    for (int y = y0; y <= y1; y++)
+        for (int x = x0; x <= x1; x++) {
+            const int kind = solid(map.at(x, H - 1 - y));
+            if (kind == kPass) continue;
+            cell.x = static_cast<float>(x);
+            cell.y = static_cast<float>(y);
+            const Box o = box_overlap(r, cell);
+            if (o.w == 0.0f && o.h == 0.0f) continue;
+            const float ox = o.x + o.w * 0.5f;
+            if (o.w <= o.h && kind != kOneWay) {
+                r.x = (ox > mid_x ? cell.x - r.w : cell.x + cell.w);
+                any = true;
+            }
+        }
+    return {r.x, r.y, any};
+}
+
+// ------------------------------------------------------------------------------------------------
+// step: the sub-step loop of cenv_step (coinrun.cpp:356-371)
+// ------------------------------------------------------------------------------------------------
+PG_D void advance(const State& s, int env, int action, float& reward_out, bool& terminated_out) {
+    const TileMap map{s.tiles + size_t(env) * (W * H)};
+    const int n_ent = SI(s, I_NENT, env);
+    int flags = SI(s, I_FLAGS, env);
+    float ax = SF(s, F_AX, env), ay = SF(s, F_AY, env);
+    float avx = SF(s, F_AVX, env), avy = SF(s, F_AVY, env);
+    float phase = SF(s, F_APHASE, env);
+    bool ground = (flags & kFlagGround) != 0, forward = (flags & kFlagForward) != 0;
+    float camx = SF(s, F_CAMX, env), camy = SF(s, F_CAMY, env);
+
+    const float dt = 1.0f / 4;
+    const float max_jump = 1.55f, gravity = 0.2f, max_speed = 0.5f, mix = 0.2f, air_control = 0.15f;
+    const float move_x = static_cast<float>((action == 6 || action == 7 || action == 8) -
+                                            (action == 0 || action == 1 || action == 2));
+    const bool jump = (action == 2 || action == 5 || action == 8);
+    const bool drop = (action == 0 || action == 3 || action == 6);
+
+    float reward = 0.0f;
+    bool terminated = false;
+    for (int ss = 0; ss < 4; ss++) {
+        // --- System_Mob_AI::update (common_systems.cpp:65-105)
+        for (int e = 0; e < n_ent; e++) {
+            const int info = EB(s, EB_INFO, e, env);
+            if ((info & 3) != kMob) continue;
+            float x = EF(s, EF_X, e, env);
+            const float y = EF(s, EF_Y, e, env);
+            float vx = EF(s, EF_VX, e, env);
+            x += vx * dt;
+            const Box wall_probe{x - 0.5f, y - 0.6f, 1.0f, 0.5f};
+            const Box floor_probe{x - 0.5f, y + 0.6f, 1.0f, 0.5f};
+            const Hit wall = collide(
+                map, wall_probe, [](int t) { return (t == kWallMid || t == kWallTop) ? kFull : kPass; }, false, 0.0f);
+            const Hit gap = collide(
+                map, floor_probe, [](int t) { return t == kEmpty ? kFull : kPass; }, false, 0.0f);
+            float nx = wall.x + 0.5f;
+            if (gap.any) nx = gap.x + 0.5f;
+            x = nx;
+            if (wall.any || gap.any) vx *= -1.0f;
+            EF(s, EF_X, e, env) = x;
+            EF(s, EF_VX, e, env) = vx;
+            EB(s, EB_INFO, e, env) = static_cast<uint8_t>((info & ~kInfoFlip) | (vx > 0.0f ? kInfoFlip : 0));
+        }
+
+        // --- System_Agent::update (common_systems.cpp:121-252)
+        bool alive = true, got_coin = false;
+        {
+            const float mix_x = ground ? mix : (mix * air_control);
+            avx += mix_x * (max_speed * move_x - avx) * dt;
+            if (fabsf(avx) < mix_x * max_speed * dt) avx = 0.0f;
+            if (jump && ground) avy = -max_jump;
+            avy += gravity * dt;
+            if (fabsf(avy) > max_jump) avy = (avy > 0.0f ? 1.0f : -1.0f) * max_jump;
+            ax += avx * dt;
+            ay += avy * dt;
+
+            Box body{ax + -0.5f, ay + -1.0f, 1.0f, 1.0f};
+            const Hit h = collide(
+                map, body,
+                [](int t) { return (t == kWallMid || t == kWallTop) ? kFull : (t == kCrate ? kOneWay : kPass); }, drop,
+                avy * dt);
+            const float moved_x = h.x - body.x, moved_y = h.y - body.y;
+            ground = moved_y < 0.0f && h.any;
+            ax = h.x - -0.5f;
+            ay = h.y - -1.0f;
+            body.x = ax + -0.5f;
+            body.y = ay + -1.0f;
+            if (moved_x != 0.0f) avx = 0.0f;
+            if (ground) avy = 0.0f;
+
+            for (int e = 0; e < n_ent; e++) {  // hazards and the coin; a boolean OR, order-free (App. B)
+                const int kind = EB(s, EB_INFO, e, env) & 3;
+                const float x = EF(s, EF_X, e, env), y = EF(s, EF_Y, e, env);
+                Box hb;
+                if (kind == kMob)
+                    hb = Box{x + -0.5f, y + -0.48f, 1.0f, 0.98f};
+                else
+                    hb = Box{x + -0.5f, y + -0.5f, 1.0f, 1.0f};
+                if (box_hit(body, hb)) {
+                    if (kind == kCoin)
+                        got_coin = true;
+                    else
+                        alive = false;
+                }
+            }
+            const Hit lava = collide(
+                map, body, [](int t) { return (t == kLavaMid || t == kLavaTop) ? kFull : kPass; }, false, 0.0f);
+            if (lava.any) alive = false;
+
+            camx = ax * kUnitPx;
+            camy = (ay - 0.5f) * kUnitPx;
+            phase += 0.1f * dt;
+            phase = fmodf(phase, 1.0f);
+            if (move_x > 0.0f)
+                forward = true;
+            else if (move_x < 0.0f)
+                forward = false;
+        }
+
+        // --- System_Particles::update (common_systems.cpp:284-313) and
+        // --- System_Sprite_Render::update animation advance (common_systems.cpp:7-39)
+        for (int e = 0; e < n_ent; e++) {
+            int info = EB(s, EB_INFO, e, env);
+            const int kind = info & 3;
+            if (kind == kMob) {
+                int dead = -1;
+                for (int k = 0; k < kSparks; k++) {
+                    float life = SP(s, 2, e, k, env);
+                    life -= dt;
+                    SP(s, 2, e, k, env) = life;
+                    if (life <= 0.0f) dead = k;
+                }
+                float timer = EF(s, EF_SPAWN_T, e, env) + dt;
+                if (dead != -1 && timer >= 0.5f) {
+                    timer = fmodf(timer, 0.5f);
+                    SP(s, 2, e, dead, env) = 5.0f;
+                    SP(s, 0, e, dead, env) = EF(s, EF_X, e, env) + 0.0f;
+                    SP(s, 1, e, dead, env) = EF(s, EF_Y, e, env) + 0.34f;
+                }
+                EF(s, EF_SPAWN_T, e, env) = timer;
+            }
+            if (kind != kCoin) {
+                const float rate = (kind == kSaw) ? 1.0f : 0.2f;
+                float t = EF(s, EF_ANIM_T, e, env) + dt;
+                const int adv = static_cast<int>(t * rate);
+                t -= adv / rate;
+                const int frame = (((info & kInfoFrame) ? 1 : 0) + adv) % 2;
+                info = (info & ~kInfoFrame) | (frame ? kInfoFrame : 0) | kInfoTexSet;
+                EF(s, EF_ANIM_T, e, env) = t;
+                EB(s, EB_INFO, e, env) = static_cast<uint8_t>(info);
+            }
+        }
+        flags |= kFlagListed;
+
+        reward = got_coin * 10.0f;
+        terminated = !alive || got_coin;
+        if (terminated) break;
+    }
+
+    SF(s, F_AX, env) = ax;
+    SF(s, F_AY, env) = ay;
+    SF(s, F_AVX, env) = avx;
+    SF(s, F_AVY, env) = avy;
+    SF(s, F_APHASE, env) = phase;
+    SF(s, F_CAMX, env) = camx;
+    SF(s, F_CAMY, env) = camy;
+    SI(s, I_FLAGS, env) = (flags & kFlagListed) | (ground ? kFlagGround : 0) | (forward ? kFlagForward : 0);
+    reward_out = reward;
+    terminated_out = terminated;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) make_kernel(State s, uint32_t seed_base, int env_offset) {
+    const int env = blockIdx.x * 64 + threadIdx.x;
+    if (env >= s.n) return;
+    mt_seed(s.mt + size_t(env) * kMtWords, seed_base + static_cast<uint32_t>(env_offset + env));
+    SI(s, I_HASH_SPRITE, env) = 1;  // empty unordered_set: one bucket, next_resize 0
+    SI(s, I_HASH_SPARK, env) = 1;
+    SF(s, F_CAMX, env) = 0.0f;  // Renderer::camera_position{0} (renderer.h:18)
+    SF(s, F_CAMY, env) = 0.0f;
+    new_level(s, env);  // level 0, never observed (D1)
+}
+
+__global__ void __launch_bounds__(64) reset_kernel(State s, const uint8_t* mask, const int32_t* seeds, StepIO io) {
+    const int env = blockIdx.x * 64 + threadIdx.x;
+    if (env >= s.n) return;
+    if (mask && !mask[env]) return;
+    if (seeds) mt_seed(s.mt + size_t(env) * kMtWords, static_cast<uint32_t>(seeds[env]));
+    new_level(s, env);
+    io.reward[env] = 0.0f;
+    io.done[env] = 0;
+    io.pending[env] = 0;
+}
+
+__global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actions, uint32_t run_seed,
+                                                   uint32_t step_index, int env_offset, StepIO io) {
+    const int env = blockIdx.x * 64 + threadIdx.x;
+    if (env >= s.n) return;
+    if (io.pending[env]) {  // the caller's `if term: env.reset()` (game_test.py:38-40), RNG stream continues
+        new_level(s, env);
+        io.reward[env] = 0.0f;
+        io.done[env] = 0;
+        io.pending[env] = 0;
+        return;
+    }
+    const int action =
+        actions ? actions[env] : synthetic_action(run_seed, step_index, static_cast<uint32_t>(env_offset + env));
+    float reward;
+    bool terminated;
+    advance(s, env, action, reward, terminated);
+    io.reward[env] = reward;
+    io.done[env] = terminated ? 1 : 0;
+    io.pending[env] = terminated ? 1 : 0;
+}
+
+// render_game(true) (coinrun.cpp:443-470): one wavefront per env.
+__global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io) {
+    const int env = blockIdx.x;
+    if (mask && !mask[env]) return;
+    const int lane = threadIdx.x;
+    __shared__ uint32_t fb[kFbWords];
+    wave_clear(fb, lane);
+
+    const Camera cam{SF(s, F_CAMX, env), SF(s, F_CAMY, env), 64.0f, 64.0f, 0.3f * 64.0f / 64.0f};
+    const int themes = SI(s, I_THEMES, env);
+    const int flags = SI(s, I_FLAGS, env);
+    const int backdrop = themes & 0xff, alien = (themes >> 8) & 0xff, ground_theme = (themes >> 16) & 0xff;
+    const int n_ent = SI(s, I_NENT, env);
+    const int n_mob = SI(s, I_NMOB, env);
+    const uint8_t* tiles = s.tiles + size_t(env) * (W * H);
+    Blit mine;
+
+    {  // background (coinrun.cpp:459-464)
+        const int4 d = atlas.desc[kTexBackdrop + backdrop];
+        const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
+        const float extra = aspect - 1.0f;
+        const bool ok = resolve_draw(cam, d.y, d.z, kTexBackdrop + backdrop, -SF(s, F_BGSHIFT, env) * extra, 0.0f,
+                                     64.0f * kUnitPx / d.z, 1.0f, false, false, mine);
+        wave_replay(fb, atlas, mine, ok ? 1ull : 0ull, lane);
+    }
+    // negative-z sprites: none — every coinrun sprite has z = 1 (tilemap.cpp:63,88,283)
+
+    {  // tiles (tilemap.cpp:294-321)
+        const float vx = (cam.px - cam.sw * 0.5f / cam.scale) * kPxUnit;
+        const float vy = (cam.py - cam.sh * 0.5f / cam.scale) * kPxUnit;
+        const float vw = cam.sw * kPxUnit / cam.scale, vh = cam.sh * kPxUnit / cam.scale;
+        const int x0 = static_cast<int>(floorf(vx)), y0 = static_cast<int>(floorf(vy));
+        const int x1 = static_cast<int>(ceilf(vx + vw)), y1 = static_cast<int>(ceilf(vy + vh));
+        const int cols = x1 - x0 + 1, cells = cols * (y1 - y0 + 1);
+        for (int base = 0; base < cells; base += 64) {
+            const int cell = base + lane;
+            bool has = false;
+            if (cell < cells) {
+                const int row = cell / cols;
+                const int x = x0 + (cell - row * cols), y = y0 + row;
+                const int ty = H - 1 - y;
+                int t = kWallMid, crate = 0;
+                if (x >= 0 && ty >= 0 && x < W && ty < H) {
+                    const int raw = tiles[ty + x * H];
+                    t = raw & 7;
+                    crate = raw >> 4;
+                }
+                if (t != kEmpty) {
+                    int tex;
+                    if (t == kWallMid)
+                        tex = kTexMid + ground_theme;
+                    else if (t == kWallTop)
+                        tex = kTexTop + ground_theme;
+                    else if (t == kLavaMid)
+                        tex = kTexLava;
+                    else if (t == kLavaTop)
+                        tex = kTexLavaTop;
+                    else
+                        tex = kTexCrate + crate;
+                    const int4 d = atlas.desc[tex];
+                    has = resolve_draw(cam, d.y, d.z, tex, x * kUnitPx, y * kUnitPx, kUnitPx / d.y, 1.0f, false, false,
+                                       mine);
+                }
+            }
+            wave_replay(fb, atlas, mine, __ballot(has), lane);
+        }
+    }
+
+    {  // particles (common_systems.cpp:315-337): owners in the particle system's set order
+        const int4 d = atlas.desc[kTexSpark];
+        const int total = n_mob * kSparks;
+        for (int base = 0; base < total; base += 64) {
+            const int idx = base + lane;
+            bool has = false;
+            if (idx < total) {
+                const int m = idx / kSparks, k = idx - m * kSparks;
+                const int e = EB(s, EB_SPARK_ORDER, m, env);
+                const float life = SP(s, 2, e, k, env);
+                if (!(life <= 0.0f)) {
+                    const float px = SP(s, 0, e, k, env), py = SP(s, 1, e, k, env);
+                    const float lr = (5.0f - life) / 5.0f;
+                    const float alpha = 0.5f * (1.0f - lr);
+                    const float scale = 0.45f * (0.4f * lr + 0.6f);
+                    const float oy = -lr * 0.17f;
+                    has = resolve_draw(cam, d.y, d.z, kTexSpark, px * kUnitPx - 0.5f * d.y * scale,
+                                       (py + oy) * kUnitPx - 0.5f * d.z * scale, scale * kUnitPx / d.y, alpha, false,
+                                       false, mine);
+                }
+            }
+            wave_replay(fb, atlas, mine, __ballot(has), lane);
+        }
+    }
+
+    if (flags & kFlagListed) {  // sprites, positive z (common_systems.cpp:41-63); empty until the first update (D2)
+        bool has = false;
+        if (lane < n_ent) {
+            const int e = EB(s, EB_DRAW_ORDER, lane, env);
+            const int info = EB(s, EB_INFO, e, env);
+            if (info & kInfoTexSet) {
+                const int tex = EB(s, EB_TEX, e, env) + ((info & kInfoFrame) ? 1 : 0);
+                const int4 d = atlas.desc[tex];
+                const float scale = 1.0f * 1.0f;
+                has = resolve_draw(cam, d.y, d.z, tex, (EF(s, EF_X, e, env) + -0.5f) * kUnitPx,
+                                   (EF(s, EF_Y, e, env) + -0.5f) * kUnitPx, scale * kUnitPx / d.y, 1.0f,
+                                   (info & kInfoFlip) != 0, false, mine);
+            }
+        }
+        wave_replay(fb, atlas, mine, __ballot(has), lane);
+    }
+
+    {  // agent (common_systems.cpp:254-278)
+        const float avx = SF(s, F_AVX, env);
+        const bool ground = (flags & kFlagGround) != 0;
+        int tex;
+        if (fabsf(avx) < 0.01f && ground)
+            tex = kTexStand + alien;
+        else if (!ground)
+            tex = kTexJump + alien;
+        else if (SF(s, F_APHASE, env) > 0.5f)
+            tex = kTexWalk2 + alien;
+        else
+            tex = kTexWalk1 + alien;
+        const int4 d = atlas.desc[tex];
+        const float px = SF(s, F_AX, env) - 0.5f, py = SF(s, F_AY, env) - 2.0f;
+        const bool ok = resolve_draw(cam, d.y, d.z, tex, px * kUnitPx, py * kUnitPx, kUnitPx / d.y, 1.0f,
+                                     (flags & kFlagForward) == 0, false, mine);
+        wave_replay(fb, atlas, mine, ok ? 1ull : 0ull, lane);
+    }
+
+    wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+class CoinrunGame final : public Game {
+   public:
+    const char* name() const override { return "coinrun"; }
+
+    std::vector<std::string> texture_names() const override {
+        static const char* themes[6] = {"Dirt", "Grass", "Planet", "Sand", "Snow", "Stone"};
+        static const char* walkers[9] = {"slimeBlock", "slimePurple", "slimeBlue", "slimeGreen", "mouse",
+                                         "snail",      "ladybug",     "wormGreen", "wormPink"};
+        static const char* crates[4] = {"boxCrate", "boxCrate_double", "boxCrate_single", "boxCrate_warning"};
+        static const char* aliens[5] = {"Beige", "Blue", "Green", "Pink", "Yellow"};
+        std::vector<std::string> v;
+        auto lower = [](std::string t) {
+            for (auto& ch : t) ch = static_cast<char>(tolower(ch));
+            return t;
+        };
+        for (auto t : themes) v.push_back(std::string("kenney/Ground/") + t + "/" + lower(t) + "Mid.png");
+        for (auto t : themes) v.push_back(std::string("kenney/Ground/") + t + "/" + lower(t) + "Center.png");
+        v.push_back("kenney/Tiles/lavaTop_low.png");
+        v.push_back("kenney/Tiles/lava.png");
+        for (auto c : crates) v.push_back(std::string("kenney/Tiles/") + c + ".png");
+        for (auto w : walkers) {
+            v.push_back(std::string("kenney/Enemies/") + w + ".png");
+            v.push_back(std::string("kenney/Enemies/") + w + "_move.png");
+        }
+        v.push_back("kenney/Enemies/sawHalf.png");
+        v.push_back("kenney/Enemies/sawHalf_move.png");
+        v.push_back("kenney/Items/coinGold.png");
+        for (auto pose : {"_stand.png", "_jump.png", "_walk1.png", "_walk2.png"})
+            for (auto a : aliens) v.push_back(std::string("kenney/Players/128x256/") + a + "/alien" + a + pose);
+        v.push_back("misc_assets/iconCircle_white.png");
+        static const char* backdrops[49] = {
+            "platform_backgrounds/alien_bg.png", "platform_backgrounds/another_world_bg.png",
+            "platform_backgrounds/back_cave.png", "platform_backgrounds/caverns.png",
+            "platform_backgrounds/cyberpunk_bg.png", "platform_backgrounds/parallax_forest.png",
+            "platform_backgrounds/scifi_bg.png", "platform_backgrounds/scifi2_bg.png",
+            "platform_backgrounds/living_tissue_bg.png", "platform_backgrounds/airadventurelevel1.png",
+            "platform_backgrounds/airadventurelevel2.png", "platform_backgrounds/airadventurelevel3.png",
+            "platform_backgrounds/airadventurelevel4.png", "platform_backgrounds/cave_background.png",
+            "platform_backgrounds/blue_desert.png", "platform_backgrounds/blue_grass.png",
+            "platform_backgrounds/blue_land.png", "platform_backgrounds/blue_shroom.png",
+            "platform_backgrounds/colored_desert.png", "platform_backgrounds/colored_grass.png",
+            "platform_backgrounds/colored_land.png", "platform_backgrounds/colored_shroom.png",
+            "platform_backgrounds/landscape1.png", "platform_backgrounds/landscape2.png",
+            "platform_backgrounds/landscape3.png", "platform_backgrounds/landscape4.png",
+            "platform_backgrounds/battleback1.png", "platform_backgrounds/battleback2.png",
+            "platform_backgrounds/battleback3.png", "platform_backgrounds/battleback4.png",
+            "platform_backgrounds/battleback5.png", "platform_backgrounds/battleback6.png",
+            "platform_backgrounds/battleback7.png", "platform_backgrounds/battleback8.png",
+            "platform_backgrounds/battleback9.png", "platform_backgrounds/battleback10.png",
+            "platform_backgrounds/sunrise.png", "platform_backgrounds_2/beach1.png",
+            "platform_backgrounds_2/beach2.png", "platform_backgrounds_2/beach3.png",
+            "platform_backgrounds_2/beach4.png", "platform_backgrounds_2/fantasy1.png",
+            "platform_backgrounds_2/fantasy2.png", "platform_backgrounds_2/fantasy3.png",
+            "platform_backgrounds_2/fantasy4.png", "platform_backgrounds_2/candy1.png",
+            "platform_backgrounds_2/candy2.png", "platform_backgrounds_2/candy3.png",
+            "platform_backgrounds_2/candy4.png"};
+        for (auto b : backdrops) v.push_back(b);
+        return v;
+    }
+
+    static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+    size_t state_bytes(int n) const override {
+        size_t total = 0;
+        total += align256(size_t(n) * kMtWords * 4);
+        total += align256(size_t(n) * W * H);
+        total += align256(size_t(F_COUNT) * n * 4);
+        total += align256(size_t(I_COUNT) * n * 4);
+        total += align256(size_t(EF_COUNT) * kMaxEnt * n * 4);
+        total += align256(size_t(EB_COUNT) * kMaxEnt * n);
+        total += align256(size_t(3) * kMaxEnt * kSparks * n * 4);
+        return total;
+    }
+    void bind(void* d_state, int n, AtlasView atlas) override {
+        uint8_t* p = static_cast<uint8_t*>(d_state);
+        auto take = [&](size_t bytes) {
+            uint8_t* q = p;
+            p += align256(bytes);
+            return q;
+        };
+        s_.n = n;
+        s_.mt = reinterpret_cast<uint32_t*>(take(size_t(n) * kMtWords * 4));
+        s_.tiles = take(size_t(n) * W * H);
+        s_.f = reinterpret_cast<float*>(take(size_t(F_COUNT) * n * 4));
+        s_.i = reinterpret_cast<int32_t*>(take(size_t(I_COUNT) * n * 4));
+        s_.ef = reinterpret_cast<float*>(take(size_t(EF_COUNT) * kMaxEnt * n * 4));
+        s_.eb = take(size_t(EB_COUNT) * kMaxEnt * n);
+        s_.spark = reinterpret_cast<float*>(take(size_t(3) * kMaxEnt * kSparks * n * 4));
+        atlas_ = atlas;
+    }
+    int blocks() const { return (s_.n + 63) / 64; }
+    void launch_make(hipStream_t st, uint32_t seed_base, int env_offset) override {
+        hipLaunchKernelGGL(make_kernel, dim3(blocks()), dim3(64), 0, st, s_, seed_base, env_offset);
+    }
+    void launch_reset(hipStream_t st, const uint8_t* mask, const int32_t* seeds, StepIO io) override {
+        hipLaunchKernelGGL(reset_kernel, dim3(blocks()), dim3(64), 0, st, s_, mask, seeds, io);
+    }
+    void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
+                      StepIO io) override {
+        hipLaunchKernelGGL(logic_kernel, dim3(blocks()), dim3(64), 0, st, s_, actions, run_seed, step_index,
+                           env_offset, io);
+    }
+    void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
+        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(64), 0, st, s_, atlas_, mask, io);
+    }
+
+    // Same layout as oracle/pgo_coinrun.cpp Coinrun::dump_state.
+    int dump_state(hipStream_t st, int env, float* out, int cap) override {
+        hipStreamSynchronize(st);
+        auto f = [&](int field) {
+            float v;
+            hipMemcpy(&v, s_.f + size_t(field) * s_.n + env, 4, hipMemcpyDeviceToHost);
+            return v;
+        };
+        auto iv = [&](int field) {
+            int32_t v;
+            hipMemcpy(&v, s_.i + size_t(field) * s_.n + env, 4, hipMemcpyDeviceToHost);
+            return v;
+        };
+        auto ef = [&](int field, int e) {
+            float v;
+            hipMemcpy(&v, s_.ef + (size_t(field) * kMaxEnt + e) * s_.n + env, 4, hipMemcpyDeviceToHost);
+            return v;
+        };
+        auto eb = [&](int field, int e) {
+            uint8_t v;
+            hipMemcpy(&v, s_.eb + (size_t(field) * kMaxEnt + e) * s_.n + env, 1, hipMemcpyDeviceToHost);
+            return v;
+        };
+        std::vector<float> v;
+        const int flags = iv(I_FLAGS), themes = iv(I_THEMES), n_ent = iv(I_NENT);
+        v.push_back(f(F_AX));
+        v.push_back(f(F_AY));
+        v.push_back(f(F_AVX));
+        v.push_back(f(F_AVY));
+        v.push_back((flags & kFlagGround) ? 1.0f : 0.0f);
+        v.push_back((flags & kFlagForward) ? 1.0f : 0.0f);
+        v.push_back(f(F_APHASE));
+        v.push_back(f(F_CAMX));
+        v.push_back(f(F_CAMY));
+        v.push_back(static_cast<float>(themes & 0xff));
+        v.push_back(f(F_BGSHIFT));
+        v.push_back(static_cast<float>((themes >> 8) & 0xff));
+        v.push_back(static_cast<float>((themes >> 16) & 0xff));
+        v.push_back(static_cast<float>(n_ent));
+        for (int e = 0; e < n_ent; e++) {
+            const int info = eb(EB_INFO, e);
+            v.push_back(ef(EF_X, e));
+            v.push_back(ef(EF_Y, e));
+            v.push_back((info & 3) == kMob ? ef(EF_VX, e) : 0.0f);
+            v.push_back((info & kInfoFrame) ? 1.0f : 0.0f);
+            v.push_back(ef(EF_ANIM_T, e));
+        }
+        const int m = cap < static_cast<int>(v.size()) ? cap : static_cast<int>(v.size());
+        for (int k = 0; k < m; k++) out[k] = v[k];
+        return static_cast<int>(v.size());
+    }
+    int dump_tiles(hipStream_t st, int env, uint8_t* out, int cap) override {
+        hipStreamSynchronize(st);
+        const int m = cap < W * H ? cap : W * H;
+        hipMemcpy(out, s_.tiles + size_t(env) * W * H, m, hipMemcpyDeviceToHost);
+        for (int k = 0; k < m; k++) out[k] &= 7;
+        return m;
+    }
+
+   private:
+    State s_{};
+    AtlasView atlas_{};
+};
+
+}  // namespace coinrun
+
+std::unique_ptr<Game> make_coinrun() { return std::make_unique<coinrun::CoinrunGame>(); }
+
+}  // namespace pg

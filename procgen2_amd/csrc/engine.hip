@@ -1,0 +1,595 @@
+// Vector env engine + the two C ABIs (include/procgen2_vec.h, include/procgen2_cenv.h).
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "../../include/procgen2_cenv.h"
+#include "../../include/procgen2_vec.h"
+#include "pg_engine.h"
+#include "png_decode.h"
+
+#ifndef PG_DEFAULT_GAME
+#define PG_DEFAULT_GAME 0
+#endif
+
+namespace pg {
+
+static thread_local std::string g_error;
+
+static int fail(const std::string& msg) {
+    g_error = msg;
+    return 1;
+}
+
+#define PG_HIP(call)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) return fail(std::string(#call) + ": " + hipGetErrorString(e_));    \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// Atlas
+// ------------------------------------------------------------------------------------------------
+Atlas::~Atlas() {
+    if (d_texels_) hipFree(d_texels_);
+    if (d_desc_) hipFree(d_desc_);
+}
+
+bool Atlas::load(const std::string& root, const std::vector<std::string>& names, std::string& err) {
+    texels_.clear();
+    desc_.clear();
+    for (const auto& name : names) {
+        Image img;
+        if (!decode_png_file(root + "/" + name, img, err)) return false;
+        int4 d;
+        d.x = static_cast<int>(texels_.size());
+        d.y = img.w;
+        d.z = img.h;
+        d.w = 0;
+        desc_.push_back(d);
+        size_t base = texels_.size();
+        texels_.resize(base + size_t(img.w) * img.h);
+        std::memcpy(&texels_[base], img.rgba.data(), size_t(img.w) * img.h * 4);
+    }
+    return true;
+}
+
+bool Atlas::upload(std::string& err) {
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_texels_), texels_.size() * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_desc_), desc_.size() * sizeof(int4));
+    if (e == hipSuccess) e = hipMemcpy(d_texels_, texels_.data(), texels_.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_desc_, desc_.data(), desc_.size() * sizeof(int4), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        err = std::string("atlas upload: ") + hipGetErrorString(e);
+        return false;
+    }
+    return true;
+}
+
+static std::string asset_root() {
+    if (const char* env = std::getenv("PROCGEN2_ASSETS")) return env;
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void*>(&asset_root), &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        size_t slash = p.rfind('/');
+        std::string dir = slash == std::string::npos ? "." : p.substr(0, slash);
+        return dir + "/../assets";
+    }
+    return "assets";
+}
+
+static const char* const kGameNames[kNumGames] = {"coinrun", "maze"};
+
+static std::unique_ptr<Game> make_game(int id) {
+    switch (id) {
+        case kGameCoinrun: return make_coinrun();
+        case kGameMaze: return make_maze();
+        default: return nullptr;
+    }
+}
+
+}  // namespace pg
+
+// ------------------------------------------------------------------------------------------------
+// The vector env object
+// ------------------------------------------------------------------------------------------------
+struct pgv_env {
+    int n = 0, device = 0, env_offset = 0;
+    uint32_t step_index = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::unique_ptr<pg::Game> game;
+    pg::Atlas atlas;
+    void* d_state = nullptr;
+    uint8_t* d_obs = nullptr;
+    float* d_reward = nullptr;
+    uint8_t* d_done = nullptr;
+    uint8_t* d_pending = nullptr;
+    int32_t* d_host_i32 = nullptr;  // staging for the *_host entry points
+    uint8_t* d_host_u8 = nullptr;
+    bool own_obs = false, own_reward = false, own_done = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+
+    pg::StepIO io() const { return {d_obs, d_reward, d_done, d_pending}; }
+};
+
+using pg::fail;
+
+extern "C" {
+
+const char* pgv_last_error(void) { return pg::g_error.c_str(); }
+
+const char* pgv_game_name(int32_t id) { return (id >= 0 && id < pg::kNumGames) ? pg::kGameNames[id] : nullptr; }
+
+int32_t pgv_game_id(const char* name) {
+    for (int i = 0; i < pg::kNumGames; i++)
+        if (name && !std::strcmp(name, pg::kGameNames[i])) return i;
+    return -1;
+}
+
+int32_t pgv_synthetic_action(uint32_t run_seed, uint32_t step_index, uint32_t global_env) {
+    return pg::synthetic_action(run_seed, step_index, global_env);
+}
+
+void pgv_close(pgv_env* e) {
+    if (!e) return;
+    hipSetDevice(e->device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    for (auto& ev : e->ev)
+        if (ev) hipEventDestroy(ev);
+    if (e->d_state) hipFree(e->d_state);
+    if (e->own_obs && e->d_obs) hipFree(e->d_obs);
+    if (e->own_reward && e->d_reward) hipFree(e->d_reward);
+    if (e->own_done && e->d_done) hipFree(e->d_done);
+    if (e->d_pending) hipFree(e->d_pending);
+    if (e->d_host_i32) hipFree(e->d_host_i32);
+    if (e->d_host_u8) hipFree(e->d_host_u8);
+    if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int32_t pgv_make(const char* game, int32_t num_envs, int32_t device, uint32_t seed_base, int32_t env_offset,
+                 void* stream, pgv_env** out) {
+    if (!out) return fail("pgv_make: out is NULL");
+    *out = nullptr;
+    const int gid = pgv_game_id(game);
+    if (gid < 0) return fail(std::string("pgv_make: unknown game '") + (game ? game : "(null)") + "'");
+    if (num_envs <= 0) return fail("pgv_make: num_envs must be positive");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail("pgv_make: no HIP device available (the engine has no CPU path)");
+    if (device < 0 || device >= count) return fail("pgv_make: device index out of range");
+    PG_HIP(hipSetDevice(device));
+
+    std::unique_ptr<pgv_env> e(new pgv_env());
+    e->n = num_envs;
+    e->device = device;
+    e->env_offset = env_offset;
+    e->game = pg::make_game(gid);
+    if (stream) {
+        e->stream = static_cast<hipStream_t>(stream);
+    } else {
+        PG_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        e->own_stream = true;
+    }
+    for (auto& ev : e->ev) PG_HIP(hipEventCreate(&ev));
+
+    std::string err;
+    if (!e->atlas.load(pg::asset_root(), e->game->texture_names(), err)) {
+        pgv_env* raw = e.release();
+        pgv_close(raw);
+        return fail("pgv_make: " + err);
+    }
+    if (!e->atlas.upload(err)) {
+        pgv_env* raw = e.release();
+        pgv_close(raw);
+        return fail("pgv_make: " + err);
+    }
+    const size_t sb = e->game->state_bytes(num_envs);
+    PG_HIP(hipMalloc(&e->d_state, sb));
+    PG_HIP(hipMemsetAsync(e->d_state, 0, sb, e->stream));
+    PG_HIP(hipMalloc(reinterpret_cast<void**>(&e->d_obs), size_t(num_envs) * pg::kObsBytes));
+    PG_HIP(hipMalloc(reinterpret_cast<void**>(&e->d_reward), size_t(num_envs) * 4));
+    PG_HIP(hipMalloc(reinterpret_cast<void**>(&e->d_done), size_t(num_envs)));
+    PG_HIP(hipMalloc(reinterpret_cast<void**>(&e->d_pending), size_t(num_envs)));
+    e->own_obs = e->own_reward = e->own_done = true;
+    PG_HIP(hipMemsetAsync(e->d_obs, 0, size_t(num_envs) * pg::kObsBytes, e->stream));
+    PG_HIP(hipMemsetAsync(e->d_reward, 0, size_t(num_envs) * 4, e->stream));
+    PG_HIP(hipMemsetAsync(e->d_done, 0, size_t(num_envs), e->stream));
+    PG_HIP(hipMemsetAsync(e->d_pending, 0, size_t(num_envs), e->stream));
+
+    e->game->bind(e->d_state, num_envs, e->atlas.view());
+    e->game->launch_make(e->stream, seed_base, env_offset);
+    PG_HIP(hipGetLastError());
+    PG_HIP(hipStreamSynchronize(e->stream));
+    *out = e.release();
+    return 0;
+}
+
+int32_t pgv_reset(pgv_env* e, const uint8_t* d_mask, const int32_t* d_seeds) {
+    if (!e) return fail("pgv_reset: env is NULL");
+    PG_HIP(hipSetDevice(e->device));
+    e->game->launch_reset(e->stream, d_mask, d_seeds, e->io());
+    e->game->launch_render(e->stream, d_mask, e->io());
+    PG_HIP(hipGetLastError());
+    return 0;
+}
+
+static int32_t step_impl(pgv_env* e, const int32_t* d_actions, uint32_t run_seed) {
+    e->game->launch_logic(e->stream, d_actions, run_seed, e->step_index, e->env_offset, e->io());
+    e->game->launch_render(e->stream, nullptr, e->io());
+    e->step_index++;
+    return 0;
+}
+
+int32_t pgv_step(pgv_env* e, const int32_t* d_actions) {
+    if (!e) return fail("pgv_step: env is NULL");
+    if (!d_actions) return fail("pgv_step: actions is NULL");
+    PG_HIP(hipSetDevice(e->device));
+    step_impl(e, d_actions, 0);
+    PG_HIP(hipGetLastError());
+    return 0;
+}
+
+int32_t pgv_step_synthetic(pgv_env* e, uint32_t run_seed) {
+    if (!e) return fail("pgv_step_synthetic: env is NULL");
+    PG_HIP(hipSetDevice(e->device));
+    step_impl(e, nullptr, run_seed);
+    PG_HIP(hipGetLastError());
+    return 0;
+}
+
+static int32_t ensure_staging(pgv_env* e) {
+    if (!e->d_host_i32) PG_HIP(hipMalloc(reinterpret_cast<void**>(&e->d_host_i32), size_t(e->n) * 4));
+    if (!e->d_host_u8) PG_HIP(hipMalloc(reinterpret_cast<void**>(&e->d_host_u8), size_t(e->n)));
+    return 0;
+}
+
+int32_t pgv_step_host(pgv_env* e, const int32_t* h_actions) {
+    if (!e) return fail("pgv_step_host: env is NULL");
+    if (!h_actions) return fail("pgv_step_host: actions is NULL");
+    PG_HIP(hipSetDevice(e->device));
+    if (ensure_staging(e)) return 1;
+    PG_HIP(hipMemcpyAsync(e->d_host_i32, h_actions, size_t(e->n) * 4, hipMemcpyHostToDevice, e->stream));
+    PG_HIP(hipStreamSynchronize(e->stream));  // the host buffer is the caller's: do not keep reading it
+    return pgv_step(e, e->d_host_i32);
+}
+
+int32_t pgv_reset_host(pgv_env* e, const uint8_t* h_mask, const int32_t* h_seeds) {
+    if (!e) return fail("pgv_reset_host: env is NULL");
+    PG_HIP(hipSetDevice(e->device));
+    if (ensure_staging(e)) return 1;
+    if (h_mask) PG_HIP(hipMemcpyAsync(e->d_host_u8, h_mask, size_t(e->n), hipMemcpyHostToDevice, e->stream));
+    if (h_seeds) PG_HIP(hipMemcpyAsync(e->d_host_i32, h_seeds, size_t(e->n) * 4, hipMemcpyHostToDevice, e->stream));
+    PG_HIP(hipStreamSynchronize(e->stream));
+    int rc = pgv_reset(e, h_mask ? e->d_host_u8 : nullptr, h_seeds ? e->d_host_i32 : nullptr);
+    if (rc) return rc;
+    PG_HIP(hipStreamSynchronize(e->stream));  // staging buffers are reused by the next *_host call
+    return 0;
+}
+
+int32_t pgv_decode_png(const char* path, int32_t* w, int32_t* h, uint8_t* h_rgba, int64_t cap) {
+    pg::Image img;
+    std::string err;
+    if (!path || !pg::decode_png_file(path, img, err)) return fail("pgv_decode_png: " + err);
+    if (w) *w = img.w;
+    if (h) *h = img.h;
+    if (h_rgba && cap > 0) {
+        size_t nbytes = img.rgba.size() < static_cast<size_t>(cap) ? img.rgba.size() : static_cast<size_t>(cap);
+        std::memcpy(h_rgba, img.rgba.data(), nbytes);
+    }
+    return 0;
+}
+
+int32_t pgv_sync(pgv_env* e) {
+    if (!e) return fail("pgv_sync: env is NULL");
+    PG_HIP(hipSetDevice(e->device));
+    PG_HIP(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+uint8_t* pgv_obs(pgv_env* e) { return e ? e->d_obs : nullptr; }
+float* pgv_reward(pgv_env* e) { return e ? e->d_reward : nullptr; }
+uint8_t* pgv_done(pgv_env* e) { return e ? e->d_done : nullptr; }
+int32_t pgv_num_envs(pgv_env* e) { return e ? e->n : 0; }
+int32_t pgv_device(pgv_env* e) { return e ? e->device : -1; }
+void* pgv_stream(pgv_env* e) { return e ? static_cast<void*>(e->stream) : nullptr; }
+
+int32_t pgv_bind_outputs(pgv_env* e, uint8_t* d_obs, float* d_reward, uint8_t* d_done) {
+    if (!e) return fail("pgv_bind_outputs: env is NULL");
+    PG_HIP(hipSetDevice(e->device));
+    PG_HIP(hipStreamSynchronize(e->stream));
+    if (d_obs) {
+        PG_HIP(hipMemcpy(d_obs, e->d_obs, size_t(e->n) * pg::kObsBytes, hipMemcpyDeviceToDevice));
+        if (e->own_obs) hipFree(e->d_obs);
+        e->d_obs = d_obs;
+        e->own_obs = false;
+    }
+    if (d_reward) {
+        PG_HIP(hipMemcpy(d_reward, e->d_reward, size_t(e->n) * 4, hipMemcpyDeviceToDevice));
+        if (e->own_reward) hipFree(e->d_reward);
+        e->d_reward = d_reward;
+        e->own_reward = false;
+    }
+    if (d_done) {
+        PG_HIP(hipMemcpy(d_done, e->d_done, size_t(e->n), hipMemcpyDeviceToDevice));
+        if (e->own_done) hipFree(e->d_done);
+        e->d_done = d_done;
+        e->own_done = false;
+    }
+    return 0;
+}
+
+int32_t pgv_copy_out(pgv_env* e, uint8_t* h_obs, float* h_reward, uint8_t* h_done) {
+    if (!e) return fail("pgv_copy_out: env is NULL");
+    PG_HIP(hipSetDevice(e->device));
+    PG_HIP(hipStreamSynchronize(e->stream));
+    if (h_obs) PG_HIP(hipMemcpy(h_obs, e->d_obs, size_t(e->n) * pg::kObsBytes, hipMemcpyDeviceToHost));
+    if (h_reward) PG_HIP(hipMemcpy(h_reward, e->d_reward, size_t(e->n) * 4, hipMemcpyDeviceToHost));
+    if (h_done) PG_HIP(hipMemcpy(h_done, e->d_done, size_t(e->n), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int32_t pgv_timed_steps(pgv_env* e, int32_t steps, uint32_t run_seed, double* total_ms, double* render_kernel_ms) {
+    if (!e) return fail("pgv_timed_steps: env is NULL");
+    PG_HIP(hipSetDevice(e->device));
+    // Whole region on the env's stream.
+    PG_HIP(hipEventRecord(e->ev[0], e->stream));
+    double render_sum = 0.0;
+    // Per-launch render timing: events bracket each render launch; they are read back after the region
+    // so the host never stalls the stream inside it.  Events are recycled in pairs every 64 steps.
+    std::vector<hipEvent_t> pairs(size_t(steps) * 2, nullptr);
+    for (auto& p : pairs) PG_HIP(hipEventCreate(&p));
+    for (int s = 0; s < steps; s++) {
+        e->game->launch_logic(e->stream, nullptr, run_seed, e->step_index, e->env_offset, e->io());
+        PG_HIP(hipEventRecord(pairs[2 * s], e->stream));
+        e->game->launch_render(e->stream, nullptr, e->io());
+        PG_HIP(hipEventRecord(pairs[2 * s + 1], e->stream));
+        e->step_index++;
+    }
+    PG_HIP(hipEventRecord(e->ev[1], e->stream));
+    PG_HIP(hipEventSynchronize(e->ev[1]));
+    PG_HIP(hipGetLastError());
+    float ms = 0.0f;
+    PG_HIP(hipEventElapsedTime(&ms, e->ev[0], e->ev[1]));
+    if (total_ms) *total_ms = ms;
+    for (int s = 0; s < steps; s++) {
+        float k = 0.0f;
+        PG_HIP(hipEventElapsedTime(&k, pairs[2 * s], pairs[2 * s + 1]));
+        render_sum += k;
+    }
+    for (auto& p : pairs) hipEventDestroy(p);
+    if (render_kernel_ms) *render_kernel_ms = render_sum;
+    return 0;
+}
+
+int32_t pgv_dump_state(pgv_env* e, int32_t index, float* h_out, int32_t cap) {
+    if (!e || index < 0 || index >= e->n) return -1;
+    hipSetDevice(e->device);
+    return e->game->dump_state(e->stream, index, h_out, cap);
+}
+
+int32_t pgv_dump_tiles(pgv_env* e, int32_t index, uint8_t* h_out, int32_t cap) {
+    if (!e || index < 0 || index >= e->n) return -1;
+    hipSetDevice(e->device);
+    return e->game->dump_tiles(e->stream, index, h_out, cap);
+}
+
+// ------------------------------------------------------------------------------------------------
+// cenv ABI (include/procgen2_cenv.h) on top of one process-global vector env.
+// ------------------------------------------------------------------------------------------------
+cenv_make_data make_data;
+cenv_reset_data reset_data;
+cenv_step_data step_data;
+cenv_render_data render_data;
+
+}  // extern "C"
+
+namespace {
+
+struct CenvGlobal {
+    pgv_env* env = nullptr;
+    int n = 0;
+    int window_w = 512, window_h = 512;  // coinrun.cpp:29-30
+    cenv_key_value obs_space{}, act_space{};
+    cenv_key_value observations[3]{};
+    float box_bounds[2] = {0.0f, 255.0f};
+    int32_t nvec[1] = {pg::kNumActions};
+    std::vector<uint8_t> h_obs, h_done, h_frame;
+    std::vector<float> h_reward;
+    int32_t* d_actions = nullptr;
+    int32_t* d_seeds = nullptr;
+    std::vector<int32_t> h_actions;
+};
+CenvGlobal g;
+
+const int kVersion = 100;  // coinrun.cpp:9
+
+int opt_int(const cenv_option& o, int* out) {
+    if (o.value_type == CENV_VALUE_TYPE_INT) {
+        *out = o.value.i;
+        return 0;
+    }
+    if (o.value_type == CENV_VALUE_TYPE_DOUBLE) {  // python float → DOUBLE (cenv.py:39-42)
+        *out = static_cast<int>(o.value.d);
+        return 0;
+    }
+    return 1;
+}
+
+void publish_results(bool from_step) {
+    pgv_copy_out(g.env, g.h_obs.data(), g.h_reward.data(), g.h_done.data());
+    if (from_step) {
+        double sum = 0.0;
+        bool all = true;
+        for (int i = 0; i < g.n; i++) {
+            sum += g.h_reward[i];
+            all = all && g.h_done[i];
+        }
+        step_data.reward.f = static_cast<float>(g.n == 1 ? g.h_reward[0] : sum / g.n);
+        step_data.terminated = g.n == 1 ? (g.h_done[0] != 0) : all;
+        step_data.truncated = false;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t cenv_get_env_version(void) { return kVersion; }
+
+int32_t cenv_make(const char* render_mode, cenv_option* options, int32_t options_size) {
+    (void)render_mode;
+    if (g.env) cenv_close();
+    int seed = static_cast<int>(time(nullptr));  // coinrun.cpp:130
+    int num_envs = 1, game = PG_DEFAULT_GAME, device = 0, env_offset = 0;
+    for (int i = 0; i < options_size; i++) {
+        const std::string name(options[i].name ? options[i].name : "");
+        int v = 0;
+        if (name == "seed" || name == "width" || name == "height" || name == "num_envs" || name == "game" ||
+            name == "device" || name == "env_offset") {
+            if (opt_int(options[i], &v)) return fail("cenv_make: option '" + name + "' must be INT");
+        }
+        if (name == "seed")
+            seed = v;
+        else if (name == "width")
+            g.window_w = v;
+        else if (name == "height")
+            g.window_h = v;
+        else if (name == "num_envs")
+            num_envs = v;
+        else if (name == "game")
+            game = v;
+        else if (name == "device")
+            device = v;
+        else if (name == "env_offset")
+            env_offset = v;
+    }
+    const char* gname = pgv_game_name(game);
+    if (!gname) return fail("cenv_make: unknown game id");
+    int rc = pgv_make(gname, num_envs, device, static_cast<uint32_t>(seed), env_offset, nullptr, &g.env);
+    if (rc) return rc;
+    g.n = num_envs;
+    g.h_obs.assign(size_t(num_envs) * pg::kObsBytes, 0);
+    g.h_reward.assign(num_envs, 0.0f);
+    g.h_done.assign(num_envs, 0);
+    g.h_actions.assign(num_envs, 0);
+    g.h_frame.assign(size_t(g.window_w) * g.window_h * 3, 0);
+    if (hipMalloc(reinterpret_cast<void**>(&g.d_actions), size_t(num_envs) * 4) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&g.d_seeds), size_t(num_envs) * 4) != hipSuccess)
+        return fail("cenv_make: hipMalloc failed");
+
+    // Spaces (coinrun.cpp:154-172): "screen" Box(0,255), "action" MultiDiscrete([15]).
+    g.obs_space.key = "screen";
+    g.obs_space.value_type = CENV_SPACE_TYPE_BOX;
+    g.obs_space.value_buffer_size = 2;
+    g.obs_space.value_buffer.f = g.box_bounds;
+    g.act_space.key = "action";
+    g.act_space.value_type = CENV_SPACE_TYPE_MULTI_DISCRETE;
+    g.act_space.value_buffer_size = 1;
+    g.act_space.value_buffer.i = g.nvec;
+    make_data.observation_spaces_size = 1;
+    make_data.observation_spaces = &g.obs_space;
+    make_data.action_spaces_size = 1;
+    make_data.action_spaces = &g.act_space;
+
+    g.observations[0].key = "screen";
+    g.observations[0].value_type = CENV_VALUE_TYPE_BYTE;
+    g.observations[0].value_buffer_size = num_envs * pg::kObsBytes;
+    g.observations[0].value_buffer.b = g.h_obs.data();
+    g.observations[1].key = "reward";
+    g.observations[1].value_type = CENV_VALUE_TYPE_FLOAT;
+    g.observations[1].value_buffer_size = num_envs;
+    g.observations[1].value_buffer.f = g.h_reward.data();
+    g.observations[2].key = "terminated";
+    g.observations[2].value_type = CENV_VALUE_TYPE_BYTE;
+    g.observations[2].value_buffer_size = num_envs;
+    g.observations[2].value_buffer.b = g.h_done.data();
+    const int nobs = num_envs == 1 ? 1 : 3;
+    reset_data.observations_size = nobs;
+    reset_data.observations = g.observations;
+    reset_data.infos_size = 0;
+    reset_data.infos = nullptr;
+    step_data.observations_size = nobs;
+    step_data.observations = g.observations;
+    step_data.reward.f = 0.0f;
+    step_data.terminated = false;
+    step_data.truncated = false;
+    step_data.infos_size = 0;
+    step_data.infos = nullptr;
+    render_data.value_type = CENV_VALUE_TYPE_BYTE;
+    render_data.value_buffer_width = g.window_w;
+    render_data.value_buffer_height = g.window_h;
+    render_data.value_buffer_channels = 3;
+    render_data.value_buffer.b = g.h_frame.data();
+    return 0;
+}
+
+int32_t cenv_reset(cenv_option* options, int32_t options_size) {
+    if (!g.env) return fail("cenv_reset: cenv_make has not been called");
+    const int32_t* seeds = nullptr;
+    for (int i = 0; i < options_size; i++) {
+        const std::string name(options[i].name ? options[i].name : "");
+        if (name == "seed") {
+            int v = 0;
+            if (opt_int(options[i], &v)) return fail("cenv_reset: option 'seed' must be INT");
+            for (int k = 0; k < g.n; k++) g.h_actions[k] = v + k;
+            if (hipMemcpy(g.d_seeds, g.h_actions.data(), size_t(g.n) * 4, hipMemcpyHostToDevice) != hipSuccess)
+                return fail("cenv_reset: seed upload failed");
+            seeds = g.d_seeds;
+        }
+    }
+    int rc = pgv_reset(g.env, nullptr, seeds);
+    if (rc) return rc;
+    publish_results(false);
+    return 0;
+}
+
+int32_t cenv_step(cenv_key_value* actions, int32_t actions_size) {
+    if (!g.env) return fail("cenv_step: cenv_make has not been called");
+    for (int k = 0; k < g.n; k++) g.h_actions[k] = 0;  // `int action = 0;` (coinrun.cpp:342)
+    for (int i = 0; i < actions_size; i++) {
+        if (!actions[i].key || std::strcmp(actions[i].key, "action")) continue;
+        if (actions[i].value_type != CENV_VALUE_TYPE_INT) return fail("cenv_step: 'action' must be INT");
+        const int m = actions[i].value_buffer_size < g.n ? actions[i].value_buffer_size : g.n;
+        for (int k = 0; k < m; k++) g.h_actions[k] = actions[i].value_buffer.i[k];
+    }
+    if (hipMemcpy(g.d_actions, g.h_actions.data(), size_t(g.n) * 4, hipMemcpyHostToDevice) != hipSuccess)
+        return fail("cenv_step: action upload failed");
+    if (g.n == 1) {
+        // Reference semantics: no auto-reset — stepping a terminated env keeps stepping it.  The vector
+        // engine's pending flag is cleared so the single-env path never resets on its own.
+        uint8_t zero = 0;
+        hipMemcpy(g.env->d_pending, &zero, 1, hipMemcpyHostToDevice);
+    }
+    int rc = pgv_step(g.env, g.d_actions);
+    if (rc) return rc;
+    publish_results(true);
+    return 0;
+}
+
+int32_t cenv_render(void) {
+    // Human-size frame (coinrun.cpp:393-411).  The W×H render path is SURVEY.md §8f item 2 ("next");
+    // until it lands the frame is the 64×64 observation of env 0, nearest-neighbour enlarged.
+    if (!g.env) return fail("cenv_render: cenv_make has not been called");
+    for (int y = 0; y < g.window_h; y++)
+        for (int x = 0; x < g.window_w; x++) {
+            const int sx = x * pg::kObsW / g.window_w, sy = y * pg::kObsH / g.window_h;
+            for (int c = 0; c < 3; c++) g.h_frame[c + 3 * (x + g.window_w * y)] = g.h_obs[c + 3 * (sx + pg::kObsW * sy)];
+        }
+    return 0;
+}
+
+void cenv_close(void) {
+    if (!g.env) return;
+    if (g.d_actions) hipFree(g.d_actions);
+    if (g.d_seeds) hipFree(g.d_seeds);
+    g.d_actions = g.d_seeds = nullptr;
+    pgv_close(g.env);
+    g.env = nullptr;
+}
+
+}  // extern "C"

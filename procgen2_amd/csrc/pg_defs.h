@@ -1,0 +1,33 @@
+// Shared definitions for the procgen2_amd engine (host + gfx950 device code).
+//
+// Every arithmetic helper that must be bit-exact against the reference lives in a header of
+// `PG_HD` inline functions, so the same source is compiled by hipcc for the kernels and by g++
+// for the CPU unit tests that compare it with the real libstdc++ / glibc behaviour
+// (tests/test_primitives.py).  The product path only ever runs the device instantiation.
+#pragma once
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define PG_HD __host__ __device__ __forceinline__
+#define PG_D __device__ __forceinline__
+#else
+#define PG_HD inline
+#define PG_D inline
+#endif
+
+namespace pg {
+
+constexpr int kObsW = 64;
+constexpr int kObsH = 64;
+constexpr int kObsBytes = kObsW * kObsH * 3;  // coinrun.cpp:24-25,185 — 64×64×3 uint8
+constexpr int kNumActions = 15;               // coinrun.cpp:26
+
+// helpers.h:8-9
+constexpr float kUnitPx = 16.0f;
+constexpr float kPxUnit = 1.0f / 16.0f;
+
+enum GameId : int32_t { kGameCoinrun = 0, kGameMaze = 1, kNumGames = 2 };
+
+}  // namespace pg

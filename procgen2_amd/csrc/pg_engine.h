@@ -1,0 +1,86 @@
+// Engine-internal interfaces: device sprite atlas, per-game kernel launchers, and the vector env
+// object behind the C ABI of include/procgen2_vec.h.  Nothing here is exported.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "pg_defs.h"
+
+namespace pg {
+
+// Device view of the atlas: all textures of one game packed into one RGBA8 array in HBM.
+// desc[t] = {texel offset, width, height, 0}.  Replaces Asset_Texture / manager_texture
+// (games/*/common_assets.h, asset_manager.h) — SURVEY.md rows A1, E4.
+struct AtlasView {
+    const uint32_t* texels;
+    const int4* desc;
+    int count;
+};
+
+class Atlas {
+   public:
+    ~Atlas();
+    // names are reference asset paths relative to the asset root ("kenney/Items/coinGold.png").
+    bool load(const std::string& root, const std::vector<std::string>& names, std::string& err);
+    bool upload(std::string& err);
+    AtlasView view() const { return {d_texels_, d_desc_, static_cast<int>(desc_.size())}; }
+    size_t texel_bytes() const { return texels_.size() * 4; }
+
+   private:
+    std::vector<uint32_t> texels_;
+    std::vector<int4> desc_;
+    uint32_t* d_texels_ = nullptr;
+    int4* d_desc_ = nullptr;
+};
+
+// Buffers every game writes: the contiguous observation slab and the per-env scalars.
+struct StepIO {
+    uint8_t* obs;      // [n][64][64][3]
+    float* reward;     // [n]
+    uint8_t* done;     // [n]  terminated (truncated is always false in the reference: coinrun.cpp:367)
+    uint8_t* pending;  // [n]  env terminated last step → next step performs the reset instead
+};
+
+class Game {
+   public:
+    virtual ~Game() = default;
+    virtual const char* name() const = 0;
+    virtual std::vector<std::string> texture_names() const = 0;
+    virtual size_t state_bytes(int n) const = 0;
+    virtual void bind(void* d_state, int n, AtlasView atlas) = 0;
+    // cenv_make: seed rng with seed_base + env_offset + i, build and discard level 0 (D1).
+    virtual void launch_make(hipStream_t s, uint32_t seed_base, int env_offset) = 0;
+    // cenv_reset for envs where mask != 0 (nullptr = all); seeds nullptr = keep the stream (no reseed).
+    virtual void launch_reset(hipStream_t s, const uint8_t* mask, const int32_t* seeds, StepIO io) = 0;
+    // cenv_step with next-step auto-reset; actions nullptr = synthetic hash(run_seed, step, env).
+    virtual void launch_logic(hipStream_t s, const int32_t* actions, uint32_t run_seed, uint32_t step_index,
+                              int env_offset, StepIO io) = 0;
+    // render_game(true) + RGB pack into io.obs for envs where mask != 0 (nullptr = all).
+    virtual void launch_render(hipStream_t s, const uint8_t* mask, StepIO io) = 0;
+    // Debug tap used by the parity tests: game-defined float dump of one env (host pointer).
+    virtual int dump_state(hipStream_t s, int env, float* out, int cap) = 0;
+    virtual int dump_tiles(hipStream_t s, int env, uint8_t* out, int cap) = 0;
+};
+
+std::unique_ptr<Game> make_coinrun();
+std::unique_ptr<Game> make_maze();
+
+// Counter-based synthetic action shared with the oracle (oracle/pgo_api.cpp pgo_synthetic_action).
+PG_HD uint32_t mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+PG_HD int synthetic_action(uint32_t run_seed, uint32_t step, uint32_t env) {
+    uint32_t h = mix32(mix32(step * 0x9E3779B9u + run_seed) ^ (env * 0x85EBCA6Bu + 0xC2B2AE35u));
+    return static_cast<int>((static_cast<uint64_t>(h) * 15u) >> 32);
+}
+
+}  // namespace pg

@@ -1,0 +1,80 @@
+// Per-env random stream: MT19937 plus the two libstdc++ 11 distributions the games use.
+//
+// Reference: every game owns one `std::mt19937 rng` for its whole life (games/coinrun/coinrun.cpp:34,235,316)
+// and draws through std::uniform_int_distribution<int> / std::uniform_real_distribution<float>
+// (SURVEY.md rows T1, T2).  Results are bit-exact against libstdc++ 11:
+//   * uniform_int(a,b): Lemire's nearly-divisionless method on 32-bit draws
+//     (/usr/include/c++/11/bits/uniform_int_dist.h:246-270,311-317);
+//   * uniform_real<float>(a,b): generate_canonical<float,24> = one draw, u32→float (RNE) / 2^32,
+//     clamped below 1, then c*(b-a)+a with separate roundings (bits/random.tcc:3348-3380, random.h:1865-1871).
+// State layout: 624 × u32 words + one index word, wherever the caller keeps them (LDS in the kernels).
+#pragma once
+
+#include "pg_defs.h"
+
+namespace pg {
+
+constexpr int kMtN = 624;
+constexpr int kMtM = 397;
+constexpr int kMtWords = kMtN + 1;  // state + index, the per-env footprint in HBM (2500 B)
+
+// mt19937::seed(value): x[0]=value, x[i]=1812433253*(x[i-1]^(x[i-1]>>30))+i; index = 624.
+PG_HD void mt_seed(uint32_t* x, uint32_t seed) {
+    x[0] = seed;
+    for (int i = 1; i < kMtN; i++) x[i] = 1812433253u * (x[i - 1] ^ (x[i - 1] >> 30)) + static_cast<uint32_t>(i);
+    x[kMtN] = kMtN;
+}
+
+PG_HD uint32_t mt_mix(uint32_t hi, uint32_t lo) {
+    uint32_t y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
+    return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+// In-place regeneration of all 624 words (one lane; amortised over 624 draws).
+PG_HD void mt_twist(uint32_t* x) {
+    for (int i = 0; i < kMtN - kMtM; i++) x[i] = x[i + kMtM] ^ mt_mix(x[i], x[i + 1]);
+    for (int i = kMtN - kMtM; i < kMtN - 1; i++) x[i] = x[i + kMtM - kMtN] ^ mt_mix(x[i], x[i + 1]);
+    x[kMtN - 1] = x[kMtM - 1] ^ mt_mix(x[kMtN - 1], x[0]);
+}
+
+PG_HD uint32_t mt_next(uint32_t* x) {
+    uint32_t idx = x[kMtN];
+    if (idx >= static_cast<uint32_t>(kMtN)) {
+        mt_twist(x);
+        idx = 0;
+    }
+    uint32_t y = x[idx];
+    x[kMtN] = idx + 1;
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+// std::uniform_int_distribution<int>(lo, hi)(rng), lo <= hi, hi - lo < 2^32 - 1.
+PG_HD int rng_int(uint32_t* x, int lo, int hi) {
+    const uint32_t range = static_cast<uint32_t>(hi) - static_cast<uint32_t>(lo) + 1u;
+    uint64_t product = static_cast<uint64_t>(mt_next(x)) * range;
+    uint32_t low = static_cast<uint32_t>(product);
+    if (low < range) {
+        const uint32_t threshold = (0u - range) % range;
+        while (low < threshold) {
+            product = static_cast<uint64_t>(mt_next(x)) * range;
+            low = static_cast<uint32_t>(product);
+        }
+    }
+    return lo + static_cast<int>(product >> 32);
+}
+
+// std::generate_canonical<float, 24>(rng)
+PG_HD float rng_canonical(uint32_t* x) {
+    float c = static_cast<float>(mt_next(x)) / 4294967296.0f;
+    if (c >= 1.0f) c = 0.99999994f;  // nextafter(1.0f, 0.0f) = 0x3f7fffff
+    return c;
+}
+
+// std::uniform_real_distribution<float>(a, b)(rng)
+PG_HD float rng_real(uint32_t* x, float a, float b) { return rng_canonical(x) * (b - a) + a; }
+
+}  // namespace pg

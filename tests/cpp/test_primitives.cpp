@@ -1,0 +1,198 @@
+// CPU check of the engine's host/device primitives (procgen2_amd/csrc/pg_*.h compiled for the host)
+// against the genuine libstdc++ behaviour the reference depends on (SURVEY.md rows T1–T4).
+// Built and run by tests/test_primitives.py; prints "OK <name>" per section, exits non-zero on failure.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <unordered_set>
+#include <vector>
+
+#include "pg_order.h"
+#include "pg_rng.h"
+
+static int fails = 0;
+#define CHECK(cond, ...)                 \
+    do {                                 \
+        if (!(cond)) {                   \
+            std::printf("FAIL: " __VA_ARGS__); \
+            std::printf("\n");           \
+            if (++fails > 10) std::exit(1); \
+        }                                \
+    } while (0)
+
+static void test_mt() {
+    // SURVEY.md T1 known answers
+    uint32_t st[pg::kMtWords];
+    pg::mt_seed(st, 123u);
+    CHECK(pg::mt_next(st) == 2991312382u, "mt seed 123 #0");
+    CHECK(pg::mt_next(st) == 3062119789u, "mt seed 123 #1");
+    CHECK(pg::mt_next(st) == 1228959102u, "mt seed 123 #2");
+    pg::mt_seed(st, static_cast<uint32_t>(-5));
+    CHECK(pg::mt_next(st) == 1844333030u, "mt seed -5 #0");
+    pg::mt_seed(st, 1u);
+    uint32_t v = 0;
+    for (int i = 0; i < 624; i++) v = pg::mt_next(st);  // the 624th draw (1-based), last before the first re-twist
+    CHECK(v == 2006116153u, "mt seed 1 #624 got %u", v);
+    CHECK(pg::mt_next(st) == 1104314680u, "mt seed 1 #625");
+
+    for (uint32_t seed : {0u, 1u, 7u, 123u, 4294967291u, 0xdeadbeefu}) {
+        std::mt19937 ref(seed);
+        pg::mt_seed(st, seed);
+        for (int i = 0; i < 3000; i++) {
+            uint32_t a = static_cast<uint32_t>(ref()), b = pg::mt_next(st);
+            CHECK(a == b, "mt stream seed %u draw %d: %u vs %u", seed, i, a, b);
+        }
+    }
+    std::printf("OK mt19937\n");
+}
+
+static void test_distributions() {
+    // SURVEY.md T2 known answers (seed 123, in this order)
+    uint32_t st[pg::kMtWords];
+    pg::mt_seed(st, 123u);
+    CHECK(pg::rng_int(st, 1, 3) == 3, "kat int(1,3)");
+    CHECK(pg::rng_int(st, 0, 48) == 34, "kat int(0,48)");
+    CHECK(pg::rng_int(st, 0, 19) == 5, "kat int(0,19)");
+    auto bits = [](float f) {
+        uint32_t u;
+        std::memcpy(&u, &f, 4);
+        return u;
+    };
+    CHECK(bits(pg::rng_real(st, 0.0f, 1.0f)) == 0x3edb608bu, "kat real(0,1)");
+    CHECK(bits(pg::rng_real(st, -1.0f, 1.0f)) == 0xbf0bda20u, "kat real(-1,1)");
+    CHECK(bits(pg::rng_real(st, 0.7f, 1.2f)) == 0x3f85d10fu, "kat real(0.7,1.2)");
+
+    std::mt19937 meta(99);
+    for (int round = 0; round < 200; round++) {
+        uint32_t seed = static_cast<uint32_t>(meta());
+        std::mt19937 ref(seed);
+        pg::mt_seed(st, seed);
+        for (int i = 0; i < 400; i++) {
+            int kind = static_cast<int>(meta() % 4);
+            if (kind < 2) {
+                int lo = static_cast<int>(meta() % 50) - 10;
+                int span = (kind == 0) ? static_cast<int>(meta() % 8) : static_cast<int>(meta() % 3000);
+                std::uniform_int_distribution<int> d(lo, lo + span);
+                int a = d(ref), b = pg::rng_int(st, lo, lo + span);
+                CHECK(a == b, "uniform_int(%d,%d): %d vs %d", lo, lo + span, a, b);
+            } else {
+                float lo = (kind == 2) ? 0.0f : -1.0f - static_cast<float>(meta() % 7) * 0.3f;
+                float hi = (kind == 2) ? 1.0f : 1.2f + static_cast<float>(meta() % 5) * 0.7f;
+                std::uniform_real_distribution<float> d(lo, hi);
+                float a = d(ref), b = pg::rng_real(st, lo, hi);
+                CHECK(bits(a) == bits(b), "uniform_real(%g,%g): %08x vs %08x", lo, hi, bits(a), bits(b));
+            }
+        }
+    }
+    std::printf("OK distributions\n");
+}
+
+static bool same_order(const std::unordered_set<int>& ref, const pg::HashOrder& h) {
+    int16_t p = static_cast<int16_t>(h.head);
+    for (int k : ref) {
+        if (p != k) return false;
+        p = h.next[p];
+    }
+    return p == pg::kNil && static_cast<int>(ref.size()) == h.count && static_cast<int>(ref.bucket_count()) == h.buckets;
+}
+
+static void test_hash_order() {
+    std::vector<int16_t> next(2400), before(2400);
+    // SURVEY.md T3 known answers
+    {
+        std::unordered_set<int> ref;
+        pg::HashOrder h;
+        pg::hash_init(h, next.data(), before.data());
+        for (int i = 0; i < 30; i++) {
+            ref.insert(i);
+            pg::hash_insert(h, i);
+            CHECK(same_order(ref, h), "ascending insert %d", i);
+        }
+        int expect[30] = {29, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28};
+        int16_t p = static_cast<int16_t>(h.head);
+        for (int i = 0; i < 30; i++) {
+            CHECK(p == expect[i], "T3 order at %d", i);
+            p = h.next[p];
+        }
+    }
+    std::mt19937 meta(4242);
+    for (int round = 0; round < 300; round++) {
+        std::unordered_set<int> ref;
+        pg::HashOrder h;
+        pg::hash_init(h, next.data(), before.data());
+        int universe = 5 + static_cast<int>(meta() % (round < 250 ? 120 : 1000));
+        int ops = 50 + static_cast<int>(meta() % 400);
+        for (int i = 0; i < ops; i++) {
+            int r = static_cast<int>(meta() % 100);
+            int key = static_cast<int>(meta() % universe);
+            if (r < 60) {
+                ref.insert(key);
+                pg::hash_insert(h, key);
+            } else if (r < 95) {
+                ref.erase(key);
+                pg::hash_erase(h, key);
+            } else if (r < 98) {
+                ref.clear();
+                pg::hash_clear(h);
+            } else {  // an "episode": clear then ascending ids, the ECS pattern
+                ref.clear();
+                pg::hash_clear(h);
+                int n = static_cast<int>(meta() % universe);
+                for (int k = 0; k < n; k++) {
+                    ref.insert(k);
+                    pg::hash_insert(h, k);
+                }
+            }
+            CHECK(same_order(ref, h), "random ops round %d op %d", round, i);
+            CHECK(pg::hash_contains(h, key) == (ref.count(key) != 0), "contains");
+        }
+    }
+    std::printf("OK hash_order\n");
+}
+
+static void test_sort() {
+    // SURVEY.md T4 known answers: all-equal keys
+    {
+        int expect17[17] = {8, 16, 15, 14, 13, 12, 11, 10, 9, 0, 7, 6, 5, 4, 3, 2, 1};
+        pg::ZItem a[17];
+        for (int i = 0; i < 17; i++) a[i] = {1.0f, i};
+        pg::sort_by_key(a, 17);
+        for (int i = 0; i < 17; i++) CHECK(a[i].id == expect17[i], "T4 n=17 at %d: %d", i, a[i].id);
+    }
+    std::mt19937 meta(777);
+    for (int round = 0; round < 3000; round++) {
+        int n = static_cast<int>(meta() % (round < 2500 ? 80 : 700));
+        int distinct = 1 + static_cast<int>(meta() % 4);
+        if (round % 7 == 0) distinct = 1000;
+        std::vector<std::pair<float, int>> ref(n);
+        std::vector<pg::ZItem> mine(n);
+        for (int i = 0; i < n; i++) {
+            float z = static_cast<float>(static_cast<int>(meta() % distinct)) - 1.0f;
+            ref[i] = {z, i};
+            mine[i] = {z, i};
+        }
+        if (round % 11 == 0)  // adversarial-ish: organ pipe to push partition depth
+            for (int i = 0; i < n; i++) ref[i].first = mine[i].z = static_cast<float>(i < n / 2 ? i : n - i);
+        std::sort(ref.begin(), ref.end(),
+                  [](const std::pair<float, int>& l, const std::pair<float, int>& r) { return l.first < r.first; });
+        pg::sort_by_key(mine.data(), n);
+        for (int i = 0; i < n; i++)
+            CHECK(ref[i].second == mine[i].id, "sort round %d n=%d distinct=%d at %d", round, n, distinct, i);
+    }
+    std::printf("OK sort\n");
+}
+
+int main() {
+    test_mt();
+    test_distributions();
+    test_hash_order();
+    test_sort();
+    if (fails) {
+        std::printf("%d failure(s)\n", fails);
+        return 1;
+    }
+    std::printf("ALL OK\n");
+    return 0;
+}

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Copy the sprite/background PNGs a game needs from the reference tree into procgen2_amd/assets/.
+
+Assets are *data* (MIT-licensed art shipped with the reference, see procgen2_amd/assets/NOTICE);
+the GPU box only receives this repo, so the PNGs the engine loads have to live in it.  Run in
+the build container (needs /root/reference); the result is committed.
+
+The per-game lists restate the literal asset paths in the reference sources:
+  coinrun  games/coinrun/coinrun.cpp:60-110, tilemap.cpp:3-38, common_systems.cpp:107-119,280-282
+  maze     games/maze/maze.cpp:62-72, tilemap.cpp:20-29, common_systems.cpp:65-67
+"""
+import argparse
+import os
+import shutil
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEST = os.path.join(HERE, "..", "procgen2_amd", "assets")
+
+GROUND = ["Dirt", "Grass", "Planet", "Sand", "Snow", "Stone"]
+WALKERS = ["slimeBlock", "slimePurple", "slimeBlue", "slimeGreen", "mouse", "snail", "ladybug", "wormGreen",
+           "wormPink"]
+CRATES = ["boxCrate", "boxCrate_double", "boxCrate_single", "boxCrate_warning"]
+ALIENS = ["Beige", "Blue", "Green", "Pink", "Yellow"]
+
+PLATFORM_BACKDROPS = [
+    "platform_backgrounds/alien_bg.png", "platform_backgrounds/another_world_bg.png",
+    "platform_backgrounds/back_cave.png", "platform_backgrounds/caverns.png",
+    "platform_backgrounds/cyberpunk_bg.png", "platform_backgrounds/parallax_forest.png",
+    "platform_backgrounds/scifi_bg.png", "platform_backgrounds/scifi2_bg.png",
+    "platform_backgrounds/living_tissue_bg.png", "platform_backgrounds/airadventurelevel1.png",
+    "platform_backgrounds/airadventurelevel2.png", "platform_backgrounds/airadventurelevel3.png",
+    "platform_backgrounds/airadventurelevel4.png", "platform_backgrounds/cave_background.png",
+    "platform_backgrounds/blue_desert.png", "platform_backgrounds/blue_grass.png",
+    "platform_backgrounds/blue_land.png", "platform_backgrounds/blue_shroom.png",
+    "platform_backgrounds/colored_desert.png", "platform_backgrounds/colored_grass.png",
+    "platform_backgrounds/colored_land.png", "platform_backgrounds/colored_shroom.png",
+    "platform_backgrounds/landscape1.png", "platform_backgrounds/landscape2.png",
+    "platform_backgrounds/landscape3.png", "platform_backgrounds/landscape4.png",
+] + ["platform_backgrounds/battleback%d.png" % i for i in range(1, 11)] + [
+    "platform_backgrounds/sunrise.png",
+] + ["platform_backgrounds_2/%s%d.png" % (k, i) for k in ("beach", "fantasy", "candy") for i in range(1, 5)]
+
+TOPDOWN_BACKDROPS = ["topdown_backgrounds/floortiles.png"] + [
+    "topdown_backgrounds/backgrounddetailed%d.png" % i for i in range(1, 9)]
+
+
+def coinrun():
+    out = []
+    for t in GROUND:
+        out += ["kenney/Ground/%s/%sMid.png" % (t, t.lower()), "kenney/Ground/%s/%sCenter.png" % (t, t.lower())]
+    out += ["kenney/Tiles/lavaTop_low.png", "kenney/Tiles/lava.png"]
+    out += ["kenney/Tiles/%s.png" % c for c in CRATES]
+    for w in WALKERS:
+        out += ["kenney/Enemies/%s.png" % w, "kenney/Enemies/%s_move.png" % w]
+    out += ["kenney/Enemies/sawHalf.png", "kenney/Enemies/sawHalf_move.png", "kenney/Items/coinGold.png",
+            "misc_assets/iconCircle_white.png"]
+    for a in ALIENS:
+        out += ["kenney/Players/128x256/%s/alien%s_%s.png" % (a, a, s) for s in ("stand", "jump", "walk1", "walk2")]
+    return out + PLATFORM_BACKDROPS
+
+
+def maze():
+    return ["kenney/Ground/Sand/sandCenter.png", "misc_assets/cheese.png",
+            "kenney/Enemies/mouse_move.png"] + TOPDOWN_BACKDROPS
+
+
+GAMES = {"coinrun": coinrun, "maze": maze}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference", default="/root/reference")
+    ap.add_argument("games", nargs="*", default=sorted(GAMES))
+    args = ap.parse_args()
+    n = 0
+    for g in args.games:
+        for rel in GAMES[g]():
+            src = os.path.join(args.reference, "assets", rel)
+            dst = os.path.join(DEST, rel)
+            os.makedirs(os.path.dirname(dst), exist_ok=True)
+            if not os.path.exists(dst):
+                shutil.copyfile(src, dst)
+                n += 1
+    print("copied %d files into %s" % (n, os.path.normpath(DEST)))
+
+
+if __name__ == "__main__":
+    main()
