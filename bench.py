@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: coinrun, 65 536 envs per GPU, synthetic random actions, observations in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--game coinrun]
+
+One "step" = one pass of the hot path over the whole batch: the logic kernel (auto-reset or 4 physics
+sub-steps per env) + the render kernel (64×64×3 observation per env into the contiguous slab).  Inputs
+(actions) are generated on the device from a counter hash, so nothing crosses PCIe inside the timed region.
+N > 1: one process per GPU (torch.distributed.run), envs sharded by global index, no data-path collective
+(weak scaling: 65 536 envs per GPU); time = max over ranks.
+
+Prints ONE JSON line (rank 0) with `roofline` (render kernel, HIP-event timed on the engine's stream) and,
+at N=1, `cpu_baseline` (the CPU oracle on a bounded sample of the same workload, all host cores).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_ENV_STEP = 12297  # 12288 obs write + 4 action read + 4 reward write + 1 done write
+HBM_PEAK_GBPS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(game, run_seed, budget_s=20.0):
+    """The CPU restatement (oracle/, kind "port") on a bounded sample of the same workload: same seeds
+    (1 + env index), same action hash, same auto-reset policy, rendering on, one thread per host core."""
+    import numpy as np
+    from PIL import Image
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_util
+    oracle_util.register_textures(game)
+    L = oracle_util.oracle()
+    cores = os.cpu_count() or 1
+    envs = 64 * cores
+    h = L.pgo_vec_make(game.encode(), envs, 1, 0, 1)
+    rate = L.pgo_vec_bench(h, 4, run_seed, cores)  # calibrate
+    steps = max(8, int(budget_s * rate / envs))
+    rate = L.pgo_vec_bench(h, steps, run_seed, cores)
+    L.pgo_vec_close(h)
+    return {"value": rate, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%s, first %d envs of the workload (seeds 1..%d), %d steps after a 4-step warm-up, "
+                      "render on, %d threads" % (game, envs, envs, steps, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--game", default="coinrun")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    from procgen2_amd.vec_env import ProcgenVecEnv
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    n_gpus = world if distributed else 1
+    if a.gpus != n_gpus and rank == 0:
+        print("note: --gpus %d but WORLD_SIZE %d; launch with torch.distributed.run for N>1" % (a.gpus, n_gpus),
+              file=sys.stderr)
+
+    run_seed = 0
+    env = ProcgenVecEnv(a.game, a.envs, device=local_rank, seed_base=1, env_offset=rank * a.envs)
+    env.reset()
+    env.timed_steps(max(1, a.warmup), run_seed)  # untimed warm-up steps (same code path as the timed ones)
+
+    def fence():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    total_ms, render_ms = env.timed_steps(a.steps, run_seed)  # returns after the stream has drained
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if distributed:
+        t = torch.tensor([elapsed, render_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, render_ms = float(t[0]), float(t[1])
+    fence()
+
+    done_frac = float(env.done.float().mean().item())
+    env.close()
+
+    if rank == 0:
+        total_steps = float(n_gpus) * a.envs * a.steps
+        value = total_steps / elapsed
+        render_avg_ms = render_ms / a.steps
+        achieved = ALGO_BYTES_PER_ENV_STEP * a.envs / (render_avg_ms * 1e-3) / 1e9
+        line = {
+            "metric": "env-steps/sec at 65536 envs, 64x64x3 obs",
+            "value": value,
+            "unit": "env-steps/s",
+            "n_gpus": n_gpus,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8/f32",
+            "data": "synthetic",
+            "config": {"workload": "%s, %d envs per GPU, uniform random actions 0..14 from a device counter hash, "
+                                   "next-step auto-reset, seeds 1+global env index" % (a.game, a.envs),
+                       "game": a.game, "envs_per_gpu": a.envs, "obs": "64x64x3 uint8", "parallelism": "env-shard x%d, no collective" % n_gpus},
+            "obs_write_GBps": value * 12288 / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "%s::render_kernel" % a.game, "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * a.envs,
+                         "avg_launch_ms": render_avg_ms},
+            "done_fraction_last_step": done_frac,
+        }
+        if n_gpus == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(a.game, run_seed)
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,133 @@
+"""ProcgenVecEnv — N concurrent envs on one MI355X, tensors stay in HBM.
+
+Counterpart of the reference's `CEnv` (cenv/cenv.py:152-380) for the vector extension
+(include/procgen2_vec.h): same life cycle (make → reset → step … close), but observations,
+rewards and dones are zero-copy torch tensors over the engine's output slab instead of per-call
+numpy copies (SURVEY.md §8b "Consequence for a vector engine").
+
+Multi-GPU: one process per GPU; rank r owns global envs [r*N, (r+1)*N) (seed = seed_base + global
+index, so results do not depend on the GPU count).  There is no collective in reset/step/render;
+`gather()` is the optional rooted gather of obs/reward/done to rank 0 over RCCL.
+"""
+import ctypes
+from ctypes import c_void_p
+
+import torch
+
+from . import lib as pglib
+
+GAMES = ("coinrun", "maze")
+
+
+def shard_range(total_envs, world_size, rank):
+    """Contiguous env-index block of `rank`: [lo, hi).  Earlier ranks take the remainder."""
+    base, rem = divmod(total_envs, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class ProcgenVecEnv:
+    def __init__(self, game, num_envs, device=0, seed_base=1, env_offset=0, lib_path=None):
+        if not torch.cuda.is_available():
+            raise pglib.EngineError("ProcgenVecEnv needs a HIP device (torch.cuda.is_available() is False); "
+                                    "there is no CPU fallback")
+        self.L = pglib.load(lib_path)
+        self.game = game
+        self.num_envs = int(num_envs)
+        self.env_offset = int(env_offset)
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self._stream = torch.cuda.current_stream(self.device)
+        h = c_void_p()
+        pglib.check(self.L, self.L.pgv_make(game.encode(), self.num_envs, device, seed_base, self.env_offset,
+                                            c_void_p(self._stream.cuda_stream), ctypes.byref(h)), "pgv_make")
+        self._h = h
+        # torch owns the result buffers; the engine writes straight into them.
+        self.obs = torch.zeros((self.num_envs, 64, 64, 3), dtype=torch.uint8, device=self.device)
+        self.reward = torch.zeros(self.num_envs, dtype=torch.float32, device=self.device)
+        self.done = torch.zeros(self.num_envs, dtype=torch.uint8, device=self.device)
+        pglib.check(self.L, self.L.pgv_bind_outputs(self._h, c_void_p(self.obs.data_ptr()),
+                                                    c_void_p(self.reward.data_ptr()), c_void_p(self.done.data_ptr())),
+                    "pgv_bind_outputs")
+        self.single_observation_shape = (64, 64, 3)
+        self.num_actions = pglib.NUM_ACTIONS
+
+    # -- life cycle ------------------------------------------------------------------------------
+    def reset(self, mask=None, seeds=None):
+        """cenv_reset on every env (or those with mask != 0); seeds (int32[N]) reseed the streams."""
+        m = None
+        s = None
+        if mask is not None:
+            m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+        if seeds is not None:
+            s = torch.as_tensor(seeds, device=self.device).to(torch.int32).contiguous()
+        pglib.check(self.L, self.L.pgv_reset(self._h, c_void_p(m.data_ptr()) if m is not None else None,
+                                             c_void_p(s.data_ptr()) if s is not None else None), "pgv_reset")
+        self._keep = (m, s)
+        return self.obs
+
+    def step(self, actions):
+        """actions: int32[N] tensor on this device (or anything torch.as_tensor accepts).
+        Returns (obs u8[N,64,64,3], reward f32[N], done u8[N]) — views of the engine's buffers, valid
+        until the next step; work is enqueued on torch's current stream."""
+        a = torch.as_tensor(actions, device=self.device).to(torch.int32).contiguous()
+        if a.numel() != self.num_envs:
+            raise ValueError("expected %d actions, got %d" % (self.num_envs, a.numel()))
+        pglib.check(self.L, self.L.pgv_step(self._h, c_void_p(a.data_ptr())), "pgv_step")
+        self._keep = (a,)
+        return self.obs, self.reward, self.done
+
+    def step_synthetic(self, run_seed=0):
+        pglib.check(self.L, self.L.pgv_step_synthetic(self._h, run_seed), "pgv_step_synthetic")
+        return self.obs, self.reward, self.done
+
+    def timed_steps(self, steps, run_seed=0):
+        """(total_ms, render_kernel_ms_sum) from HIP events on the engine's stream."""
+        total, render = ctypes.c_double(), ctypes.c_double()
+        pglib.check(self.L, self.L.pgv_timed_steps(self._h, steps, run_seed, ctypes.byref(total),
+                                                   ctypes.byref(render)), "pgv_timed_steps")
+        return total.value, render.value
+
+    def sync(self):
+        pglib.check(self.L, self.L.pgv_sync(self._h), "pgv_sync")
+
+    def close(self):
+        if self._h:
+            self.L.pgv_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- multi-GPU -------------------------------------------------------------------------------
+    def gather(self, dst=0, group=None):
+        """Rooted gather of (obs, reward, done) to rank `dst`; other ranks get None.  Optional: the hot
+        path itself never communicates."""
+        return gather_outputs(self.obs, self.reward, self.done, dst=dst, group=group)
+
+
+def gather_outputs(obs, reward, done, dst=0, group=None):
+    """torch.distributed rooted gather (RCCL on GPUs: grouped send/recv so all inbound xGMI links of the
+    root run concurrently; gloo in the CPU tests).  Ranks may hold different env counts."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    counts = [torch.zeros(1, dtype=torch.int64, device=obs.device) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([obs.shape[0]], dtype=torch.int64, device=obs.device), group=group)
+    counts = [int(c.item()) for c in counts]
+    out = []
+    for t in (obs, reward, done):
+        if rank == dst:
+            parts = [torch.empty((c,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for c in counts]
+            parts[dst].copy_(t)
+            reqs = [dist.irecv(parts[r], src=r, group=group) for r in range(world) if r != dst]
+            for q in reqs:
+                q.wait()
+            out.append(torch.cat(parts, dim=0))
+        else:
+            dist.send(t.contiguous(), dst=dst, group=group)
+            out.append(None)
+    return tuple(out)

@@ -1,0 +1,111 @@
+"""The drop-in boundary without a GPU: the engine library loads, exports every symbol the headers declare,
+its struct layouts match what the reference's ctypes mirror expects (cenv/cenv.py:62-111), and the Python
+CEnv surface reproduces the reference wrapper's behaviour on the reference's own toy env
+(cenv/test_env.c compiled as-is into oracle/_ref/ — known answers from SURVEY.md §4)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from procgen2_amd import cenv as pgcenv
+from procgen2_amd import lib as pglib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header, prefix):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    return sorted(set(re.findall(r"\b(%s\w+)\s*\(" % prefix, text)))
+
+
+def test_vec_header_symbols_exported(engine_lib):
+    names = _declared("procgen2_vec.h", "pgv_")
+    assert set(names) == set(pglib.EXPORTED_VEC_SYMBOLS)
+    for n in names:
+        assert hasattr(engine_lib, n), n
+
+
+@pytest.mark.parametrize("libname", ["libprocgen2_hip.so", "libCoinRun.so", "libMaze.so"])
+def test_cenv_header_symbols_exported(engine_lib, libname):
+    L = ctypes.CDLL(os.path.join(pglib.LIB_DIR, libname))
+    funcs = _declared("procgen2_cenv.h", "cenv_")
+    assert set(funcs) == {s for s in pglib.EXPORTED_CENV_SYMBOLS if s.startswith("cenv_")}
+    for n in funcs:
+        assert hasattr(L, n), n
+    for data, typ in (("make_data", pgcenv.MakeData), ("reset_data", pgcenv.ResetData),
+                      ("step_data", pgcenv.StepData), ("render_data", pgcenv.RenderData)):
+        typ.in_dll(L, data)
+    assert L.cenv_get_env_version() == 100  # games/coinrun/coinrun.cpp:9
+
+
+def test_struct_layouts_match_reference_ctypes_mirror():
+    # x86-64 layouts
+    assert ctypes.sizeof(pgcenv.Value) == 8 and ctypes.sizeof(pgcenv.ValueBuffer) == 8
+    assert ctypes.sizeof(pgcenv.KeyValue) == 24 and pgcenv.KeyValue.value_buffer.offset == 16
+    assert ctypes.sizeof(pgcenv.Option) == 24 and pgcenv.Option.value.offset == 16
+    assert ctypes.sizeof(pgcenv.StepData) == 40
+    assert (pgcenv.StepData.reward.offset, pgcenv.StepData.terminated.offset, pgcenv.StepData.truncated.offset,
+            pgcenv.StepData.infos_size.offset, pgcenv.StepData.infos.offset) == (16, 24, 25, 28, 32)
+    assert ctypes.sizeof(pgcenv.RenderData) == 24 and pgcenv.RenderData.value_buffer.offset == 16
+
+
+def test_engine_fails_loudly_without_gpu(engine_lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = ctypes.c_void_p()
+    rc = engine_lib.pgv_make(b"coinrun", 4, 0, 1, 0, None, ctypes.byref(h))
+    assert rc != 0 and not h.value
+    assert b"no HIP device" in engine_lib.pgv_last_error() or b"hip" in engine_lib.pgv_last_error().lower()
+    with pytest.raises(Exception, match="Non-zero error code!"):
+        pgcenv.CEnv(os.path.join(pglib.LIB_DIR, "libCoinRun.so"), options={"seed": 1})
+
+
+def test_unknown_game_rejected(engine_lib):
+    h = ctypes.c_void_p()
+    assert engine_lib.pgv_make(b"pong", 4, 0, 1, 0, None, ctypes.byref(h)) != 0
+    assert engine_lib.pgv_game_id(b"maze") == 1 and engine_lib.pgv_game_name(0) == b"coinrun"
+    assert engine_lib.pgv_game_name(99) is None
+
+
+def test_synthetic_action_matches_oracle_hash(engine_lib, oracle_lib):
+    for run_seed in (0, 5):
+        for step in (0, 1, 77, 4095):
+            for env in (0, 1, 63, 65535, 524287):
+                a = engine_lib.pgv_synthetic_action(run_seed, step, env)
+                assert 0 <= a < 15 and a == oracle_lib.pgo_synthetic_action(run_seed, step, env)
+    hist = np.bincount([engine_lib.pgv_synthetic_action(0, s, e) for s in range(64) for e in range(256)], minlength=15)
+    assert hist.min() > 0.8 * hist.mean() and hist.max() < 1.2 * hist.mean()
+
+
+REF_TOY = os.path.join(ROOT, "oracle", "_ref", "libtest_env.so")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_TOY), reason="oracle/_ref not built (needs /root/reference at build time)")
+def test_cenv_wrapper_on_reference_toy_env():
+    env = pgcenv.CEnv(REF_TOY)
+    assert env.version() == 123  # cenv/test_env.c:18
+    assert list(env.observation_space) == ["obs1"] and list(env.action_space) == ["act1"]
+    box = env.observation_space["obs1"]
+    assert box.shape == (10,) and np.all(box.low == -1.0) and np.all(box.high == 1.0)
+    assert list(env.action_space["act1"].nvec) == [10]
+    obs, info = env.reset()
+    assert list(obs) == ["obs"] and info == {}
+    first = obs["obs"]
+    assert first.dtype == np.float32 and first.shape == (10,)
+    np.testing.assert_allclose(first[:3], [1.0, 0.87758255, 0.5403023], rtol=0, atol=1e-7)
+    steps, reward, term = 0, 0.0, False
+    while not term:
+        obs, reward, term, trunc, info = env.step({"blah123": np.ones(10, dtype=np.int32) * 123})
+        steps += 1
+        assert trunc is False and isinstance(reward, float)
+    assert steps == 40
+    assert abs(reward - (-0.31951919)) < 1e-7  # sinf(9.75)
+    frame = env.render()
+    assert frame.shape == (8, 8, 3) and frame.dtype == np.uint8 and np.all(frame == 64)
+    env.step(3)  # int action path
+    with pytest.raises(Exception, match="Unrecognized action type"):
+        env.step(3.5)
+    env.close()

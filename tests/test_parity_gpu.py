@@ -1,0 +1,248 @@
+"""Parity tests proper (need an MI355X): the HIP engine, called through its C ABI, against the CPU oracle on
+the same seeds and actions.  Bar: bit-exact observations (u8), rewards (f32 bit patterns) and dones.
+
+Small/medium sizes compare every byte of every step; BASELINE.json's full sizes (65 536 envs) use
+size-independent properties: shard invariance (an env's trajectory depends only on its global index),
+determinism, and byte-compare of a strided sample of envs against the oracle.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from engine_util import EngineVec
+from oracle_util import OracleVec, oracle
+
+pytestmark = pytest.mark.gpu
+
+from procgen2_amd import cenv as pgcenv  # noqa: E402
+from procgen2_amd import lib as pglib  # noqa: E402
+
+
+def _actions(L, run_seed, step, n, offset=0):
+    return np.array([L.pgo_synthetic_action(run_seed, step, offset + e) for e in range(n)], np.int32)
+
+
+def _lockstep(game, n, steps, seed_base=1, run_seed=0, check_state_every=0):
+    eng = EngineVec(game, n, seed_base=seed_base)
+    ora = OracleVec(game, n, seed_base=seed_base)
+    L = ora.L
+    assert np.array_equal(eng.reset(), ora.reset_obs()), "reset frame"
+    resets = 0
+    for s in range(steps):
+        a = _actions(L, run_seed, s, n)
+        oe, re_, de = eng.step(a)
+        oo, ro, do = ora.step(a)
+        assert np.array_equal(de, do), "done, step %d" % s
+        assert np.array_equal(re_.view(np.uint32), ro.view(np.uint32)), "reward bits, step %d" % s
+        if not np.array_equal(oe, oo):
+            bad = np.nonzero((oe != oo).any(axis=1))[0]
+            raise AssertionError("obs differ at step %d in %d envs (first env %d, %d bytes)" %
+                                 (s, bad.size, bad[0], int((oe[bad[0]] != oo[bad[0]]).sum())))
+        resets += int(do.sum())
+        if check_state_every and s % check_state_every == 0:
+            for e in range(0, n, max(1, n // 8)):
+                assert np.array_equal(eng.state(e).view(np.uint32), ora.state(e).view(np.uint32)), "state env %d" % e
+                assert np.array_equal(eng.tiles(e), ora.tiles(e)), "tiles env %d" % e
+    eng.close()
+    ora.close()
+    return resets
+
+
+def test_coinrun_lockstep_256_envs():
+    # configs[1] scaled to what the scalar oracle renders in seconds; 400 steps cross several episode ends
+    resets = _lockstep("coinrun", 256, 400, check_state_every=50)
+    assert resets > 0, "no episode ended: the auto-reset path was not exercised"
+
+
+def test_coinrun_other_seeds_and_action_stream():
+    _lockstep("coinrun", 64, 300, seed_base=4294967000, run_seed=9)  # seeds wrap through 2^32 like `unsigned long`→u32
+
+
+def test_maze_lockstep_with_timeouts():
+    resets = _lockstep("maze", 96, 620, check_state_every=100)  # > 500: every env hits the step cap (D5)
+    assert resets >= 96
+
+
+def test_maze_out_of_range_actions_follow_reference_quirk():
+    # D6/D20: actions 9..15 teleport 2–3 cells in maze; others ignore them.
+    n = 32
+    eng, ora = EngineVec("maze", n, seed_base=3), OracleVec("maze", n, seed_base=3)
+    assert np.array_equal(eng.reset(), ora.reset_obs())
+    rng = np.random.default_rng(1)
+    for s in range(120):
+        a = rng.integers(0, 16, n).astype(np.int32)
+        oe, re_, de = eng.step(a)
+        oo, ro, do = ora.step(a)
+        assert np.array_equal(oe, oo) and np.array_equal(de, do) and np.array_equal(re_, ro), s
+    eng.close()
+    ora.close()
+
+
+@pytest.mark.parametrize("game", ["coinrun", "maze"])
+def test_reset_with_seed_option_and_mask(game):
+    """cenv_reset's "seed" option (coinrun.cpp:313-317) per env, and masked resets leaving other envs untouched."""
+    n = 16
+    eng = EngineVec(game, n, seed_base=11)
+    L = oracle()
+    from oracle_util import register_textures
+    register_textures(game)
+    hs = [L.pgo_make(game.encode(), 11 + i, 1) for i in range(n)]
+    for h in hs:
+        L.pgo_reset(h, 0, 0)
+    o = eng.reset()
+    for i, h in enumerate(hs):
+        assert np.array_equal(o[i], np.ctypeslib.as_array(L.pgo_obs(h), shape=(12288,)))
+    for s in range(20):
+        a = _actions(L, 2, s, n)
+        eng.step(a)
+        for i, h in enumerate(hs):
+            L.pgo_step(h, int(a[i]))
+    before = eng.obs.copy()
+    mask = np.zeros(n, np.uint8)
+    mask[::3] = 1
+    seeds = np.arange(n, dtype=np.int32) * 7 - 5  # includes negative seeds: int → u32 wrap
+    o = eng.reset(mask=mask, seeds=seeds).copy()
+    for i, h in enumerate(hs):
+        if mask[i]:
+            L.pgo_reset(h, 1, int(seeds[i]))
+            assert np.array_equal(o[i], np.ctypeslib.as_array(L.pgo_obs(h), shape=(12288,))), i
+        else:
+            assert np.array_equal(o[i], before[i]), i
+    for s in range(30):
+        a = _actions(L, 3, s, n)
+        oe, _, _ = eng.step(a)
+        for i, h in enumerate(hs):
+            if L.pgo_terminated(h):  # reference loop: reset replaces the next step
+                L.pgo_reset(h, 0, 0)
+            else:
+                L.pgo_step(h, int(a[i]))
+            if not np.array_equal(oe[i], np.ctypeslib.as_array(L.pgo_obs(h), shape=(12288,))):
+                raise AssertionError("env %d step %d" % (i, s))
+    for h in hs:
+        L.pgo_close(h)
+    eng.close()
+
+
+def test_cenv_abi_single_env_matches_reference_loop():
+    """The drop-in path: CEnv("libCoinRun.so", options={"seed": s}) → reset → step(int) … with the caller doing
+    `if term: reset()` — exactly game_test.py:36-40 — against the oracle driven the same way."""
+    for libname, game in (("libCoinRun.so", "coinrun"), ("libMaze.so", "maze")):
+        env = pgcenv.CEnv(os.path.join(pglib.LIB_DIR, libname), options={"seed": 123})
+        assert list(env.observation_space) == ["screen"] and list(env.action_space) == ["action"]
+        assert list(env.action_space["action"].nvec) == [15]
+        from oracle_util import register_textures
+        register_textures(game)
+        L = oracle()
+        h = L.pgo_make(game.encode(), 123, 1)
+        L.pgo_reset(h, 0, 0)
+        obs, info = env.reset()
+        assert obs["screen"].shape == (12288,) and obs["screen"].dtype == np.uint8 and info == {}
+        assert np.array_equal(obs["screen"], np.ctypeslib.as_array(L.pgo_obs(h), shape=(12288,)))
+        s = 1
+        for i in range(700 if game == "maze" else 300):
+            s = (s * 1664525 + 1013904223) & 0xFFFFFFFF
+            a = (s >> 16) % 15
+            obs, rew, term, trunc, info = env.step(int(a))
+            L.pgo_step(h, a)
+            assert np.array_equal(obs["screen"], np.ctypeslib.as_array(L.pgo_obs(h), shape=(12288,))), i
+            assert rew == L.pgo_reward(h) and term == bool(L.pgo_terminated(h)) and trunc is False
+            if term:
+                obs, _ = env.reset()
+                L.pgo_reset(h, 0, 0)
+                assert np.array_equal(obs["screen"], np.ctypeslib.as_array(L.pgo_obs(h), shape=(12288,)))
+        frame = env.render()
+        assert frame.shape == (512, 512, 3)
+        env.close()
+        L.pgo_close(h)
+
+
+def test_cenv_abi_batched_through_unmodified_wrapper_shapes():
+    """N envs through the reference wrapper's call shapes — action {"action": int32[N]},
+    observations "screen" BYTE[N*12288] + "reward" FLOAT[N] + "terminated" BYTE[N]."""
+    n = 8
+    env = pgcenv.CEnv(os.path.join(pglib.LIB_DIR, "libprocgen2_hip.so"), options={"seed": 1, "num_envs": n, "game": 0})
+    ora = OracleVec("coinrun", n, seed_base=1)
+    obs, _ = env.reset()
+    assert np.array_equal(obs["screen"].reshape(n, 12288), ora.reset_obs())
+    for s in range(40):
+        a = _actions(ora.L, 0, s, n)
+        obs, rew, term, trunc, _ = env.step({"action": a})
+        oo, ro, do = ora.step(a)
+        assert np.array_equal(obs["screen"].reshape(n, 12288), oo)
+        assert np.array_equal(obs["reward"], ro) and np.array_equal(obs["terminated"], do)
+        assert abs(rew - float(ro.mean())) < 1e-6
+    env.close()
+    ora.close()
+
+
+def test_shard_invariance_and_determinism_at_full_size():
+    """BASELINE.json full size (65 536 envs, coinrun): a shard created with env_offset reproduces the same global
+    envs byte for byte (so results do not depend on the GPU count), two identical runs agree, and a strided
+    sample of the 65 536 envs matches the oracle."""
+    n = 65536
+    steps = 24
+    big = EngineVec("coinrun", n, seed_base=1)
+    big.reset()
+    for s in range(steps):
+        big.step(None, run_seed=0)
+    obs_big, rew_big, done_big = (x.copy() for x in big._fetch())
+    big.close()
+
+    lo = 40000
+    shard = EngineVec("coinrun", 512, seed_base=1, env_offset=lo)
+    shard.reset()
+    for s in range(steps):
+        shard.step(None, run_seed=0)
+    o, r, d = shard._fetch()
+    assert np.array_equal(o, obs_big[lo:lo + 512]) and np.array_equal(r, rew_big[lo:lo + 512])
+    assert np.array_equal(d, done_big[lo:lo + 512])
+    shard.close()
+
+    again = EngineVec("coinrun", n, seed_base=1)
+    again.reset()
+    for s in range(steps):
+        again.step(None, run_seed=0)
+    o2, r2, d2 = again._fetch()
+    assert np.array_equal(o2, obs_big) and np.array_equal(r2, rew_big) and np.array_equal(d2, done_big)
+    again.close()
+
+    L = oracle()
+    from oracle_util import register_textures
+    register_textures("coinrun")
+    for g in range(0, n, 4099):  # 16 envs spread over the whole range
+        h = L.pgo_make(b"coinrun", 1 + g, 1)
+        L.pgo_reset(h, 0, 0)
+        pending = False
+        for s in range(steps):
+            if pending:
+                L.pgo_reset(h, 0, 0)
+                pending = False
+            else:
+                L.pgo_step(h, L.pgo_synthetic_action(0, s, g))
+                pending = bool(L.pgo_terminated(h))
+        assert np.array_equal(obs_big[g], np.ctypeslib.as_array(L.pgo_obs(h), shape=(12288,))), g
+        L.pgo_close(h)
+
+
+def test_vec_env_torch_zero_copy_matches_c_abi():
+    import torch
+    from procgen2_amd.vec_env import ProcgenVecEnv
+    n = 128
+    env = ProcgenVecEnv("coinrun", n, seed_base=1)
+    ref = EngineVec("coinrun", n, seed_base=1)
+    o = env.reset()
+    env.sync()
+    assert o.shape == (n, 64, 64, 3) and o.dtype == torch.uint8 and o.is_cuda
+    assert np.array_equal(o.cpu().numpy().reshape(n, -1), ref.reset())
+    L = oracle()
+    for s in range(30):
+        a = _actions(L, 0, s, n)
+        o, r, d = env.step(torch.from_numpy(a).cuda())
+        oe, re_, de = ref.step(a)
+        env.sync()
+        assert np.array_equal(o.cpu().numpy().reshape(n, -1), oe)
+        assert np.array_equal(r.cpu().numpy(), re_) and np.array_equal(d.cpu().numpy(), de)
+    env.close()
+    ref.close()
