@@ -110,14 +110,17 @@ def test_reset_with_seed_option_and_mask(game):
             assert np.array_equal(o[i], np.ctypeslib.as_array(L.pgo_obs(h), shape=(12288,))), i
         else:
             assert np.array_equal(o[i], before[i]), i
+    pending = [False] * n
     for s in range(30):
         a = _actions(L, 3, s, n)
         oe, _, _ = eng.step(a)
         for i, h in enumerate(hs):
-            if L.pgo_terminated(h):  # reference loop: reset replaces the next step
+            if pending[i]:  # reference loop: `if term: env.reset()` replaces the next step
                 L.pgo_reset(h, 0, 0)
+                pending[i] = False
             else:
                 L.pgo_step(h, int(a[i]))
+                pending[i] = bool(L.pgo_terminated(h))
             if not np.array_equal(oe[i], np.ctypeslib.as_array(L.pgo_obs(h), shape=(12288,))):
                 raise AssertionError("env %d step %d" % (i, s))
     for h in hs:
