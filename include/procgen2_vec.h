@@ -96,6 +96,10 @@ PGV_API int32_t pgv_copy_out(pgv_env* env, uint8_t* h_obs, float* h_reward, uint
 PGV_API int32_t pgv_timed_steps(pgv_env* env, int32_t steps, uint32_t run_seed, double* total_ms,
                                 double* render_kernel_ms);
 
+/* Debug switches (tests only).  Bit 0: render the background and tile layer by replaying the draw list
+ * one blit at a time instead of the fused row composer; results are identical, only slower. */
+PGV_API int32_t pgv_set_debug(pgv_env* env, int32_t flags);
+
 /* Parity taps (host pointers): game-defined state vector / tile ids of one env; return the full
  * length, copy at most `cap` items. */
 PGV_API int32_t pgv_dump_state(pgv_env* env, int32_t index, float* h_out, int32_t cap);

@@ -547,39 +547,86 @@ __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actio
 }
 
 // render_game(true) (coinrun.cpp:443-470): one wavefront per env.
-__global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io) {
+// flags bit 0: force the draw-list replay for background + tiles (fallback path; parity tests run both).
+__global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
+                                                    int flags) {
     const int env = blockIdx.x;
     if (mask && !mask[env]) return;
     const int lane = threadIdx.x;
     __shared__ uint32_t fb[kFbWords];
-    wave_clear(fb, lane);
+    constexpr int kGrid = 16;  // 64 px / 4.8 px per tile = 13.3 tiles → at most 15 columns/rows in view
+    __shared__ ComposeLds<kGrid> L;
 
     const Camera cam{SF(s, F_CAMX, env), SF(s, F_CAMY, env), 64.0f, 64.0f, 0.3f * 64.0f / 64.0f};
     const int themes = SI(s, I_THEMES, env);
-    const int flags = SI(s, I_FLAGS, env);
-    const int backdrop = themes & 0xff, alien = (themes >> 8) & 0xff, ground_theme = (themes >> 16) & 0xff;
+    const int sflags = SI(s, I_FLAGS, env);
+    const int backdrop = (flags & 16) ? 9 : (themes & 0xff);  // (bit 4: timing experiment — one shared background)
+    const int alien = (themes >> 8) & 0xff, ground_theme = (themes >> 16) & 0xff;
     const int n_ent = SI(s, I_NENT, env);
     const int n_mob = SI(s, I_NMOB, env);
     const uint8_t* tiles = s.tiles + size_t(env) * (W * H);
     Blit mine;
 
-    {  // background (coinrun.cpp:459-464)
+    // background (coinrun.cpp:459-464)
+    Blit bg;
+    bool has_bg;
+    {
         const int4 d = atlas.desc[kTexBackdrop + backdrop];
         const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
         const float extra = aspect - 1.0f;
-        const bool ok = resolve_draw(cam, d.y, d.z, kTexBackdrop + backdrop, -SF(s, F_BGSHIFT, env) * extra, 0.0f,
-                                     64.0f * kUnitPx / d.z, 1.0f, false, false, mine);
-        wave_replay(fb, atlas, mine, ok ? 1ull : 0ull, lane);
+        has_bg = resolve_draw(cam, d.y, d.z, d.x, -SF(s, F_BGSHIFT, env) * extra, 0.0f, 64.0f * kUnitPx / d.z, 1.0f,
+                              false, false, bg);
     }
     // negative-z sprites: none — every coinrun sprite has z = 1 (tilemap.cpp:63,88,283)
 
-    {  // tiles (tilemap.cpp:294-321)
-        const float vx = (cam.px - cam.sw * 0.5f / cam.scale) * kPxUnit;
-        const float vy = (cam.py - cam.sh * 0.5f / cam.scale) * kPxUnit;
-        const float vw = cam.sw * kPxUnit / cam.scale, vh = cam.sh * kPxUnit / cam.scale;
-        const int x0 = static_cast<int>(floorf(vx)), y0 = static_cast<int>(floorf(vy));
-        const int x1 = static_cast<int>(ceilf(vx + vw)), y1 = static_cast<int>(ceilf(vy + vh));
-        const int cols = x1 - x0 + 1, cells = cols * (y1 - y0 + 1);
+    // tile window (tilemap.cpp:294-304)
+    const float vx = (cam.px - cam.sw * 0.5f / cam.scale) * kPxUnit;
+    const float vy = (cam.py - cam.sh * 0.5f / cam.scale) * kPxUnit;
+    const float vw = cam.sw * kPxUnit / cam.scale, vh = cam.sh * kPxUnit / cam.scale;
+    const int x0 = static_cast<int>(floorf(vx)), y0 = static_cast<int>(floorf(vy));
+    const int x1 = static_cast<int>(ceilf(vx + vw)), y1 = static_cast<int>(ceilf(vy + vh));
+    const int cols = x1 - x0 + 1, rows = y1 - y0 + 1, cells = cols * rows;
+    const int4 tile_desc = atlas.desc[kTexMid];  // every tile texture is 128×128 (checked at make time)
+
+    bool composed = false;
+    if (!(flags & 5) && cols <= kGrid && rows <= kGrid) {
+        compose_spans(L, cam, x0, y0, cols, rows, tile_desc.y, tile_desc.z, kUnitPx / tile_desc.y, lane);
+        // Texel offset of each tile kind's texture, one per lane (0..7), looked up with a cross-lane read:
+        // lanes 0-3 = wall_top, wall_mid, lava_top, lava_mid (tile id - 1), lanes 4-7 = the four crates.
+        int kind_base = -1;
+        if (lane < 8) {
+            int tex;
+            if (lane == 0)
+                tex = kTexTop + ground_theme;
+            else if (lane == 1)
+                tex = kTexMid + ground_theme;
+            else if (lane == 2)
+                tex = kTexLavaTop;
+            else if (lane == 3)
+                tex = kTexLava;
+            else
+                tex = kTexCrate + (lane - 4);
+            kind_base = atlas.desc[tex].x;
+        }
+        for (int base = 0; base < cells; base += 64) {
+            const int cell = base + lane;
+            const int r = cell / cols, c = cell - r * cols;
+            const int x = x0 + c, ty = H - 1 - (y0 + r);
+            int raw = kWallMid;  // out of bounds is a wall (tilemap.h:80-81)
+            if (cell < cells && x >= 0 && ty >= 0 && x < W && ty < H) raw = tiles[ty + x * H];
+            const int t = raw & 7;
+            const int slot = t < kCrate ? t - 1 : 4 + (raw >> 4);
+            const int off = __shfl(kind_base, slot < 0 ? 0 : slot);
+            if (cell < cells) L.base[r * kGrid + c] = (t == kEmpty) ? -1 : off;
+        }
+        __syncthreads();
+        composed = compose_rows(fb, L, atlas, bg, has_bg, cols, rows, tile_desc.y, lane);
+    }
+    if (flags & 4) composed = true;  // (bit 2: timing ablation only — no background/tiles at all)
+    if (!composed) {  // draw-list replay of background and tiles (tilemap.cpp:294-321)
+        wave_clear(fb, lane);
+        mine = bg;
+        wave_replay(fb, atlas, mine, has_bg ? 1ull : 0ull, lane);
         for (int base = 0; base < cells; base += 64) {
             const int cell = base + lane;
             bool has = false;
@@ -606,7 +653,7 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
                     else
                         tex = kTexCrate + crate;
                     const int4 d = atlas.desc[tex];
-                    has = resolve_draw(cam, d.y, d.z, tex, x * kUnitPx, y * kUnitPx, kUnitPx / d.y, 1.0f, false, false,
+                    has = resolve_draw(cam, d.y, d.z, d.x, x * kUnitPx, y * kUnitPx, kUnitPx / d.y, 1.0f, false, false,
                                        mine);
                 }
             }
@@ -614,6 +661,7 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
         }
     }
 
+    if (!(flags & 2)) {  // (bit 1: timing ablation only — skips particles, sprites and the agent)
     {  // particles (common_systems.cpp:315-337): owners in the particle system's set order
         const int4 d = atlas.desc[kTexSpark];
         const int total = n_mob * kSparks;
@@ -630,7 +678,7 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
                     const float alpha = 0.5f * (1.0f - lr);
                     const float scale = 0.45f * (0.4f * lr + 0.6f);
                     const float oy = -lr * 0.17f;
-                    has = resolve_draw(cam, d.y, d.z, kTexSpark, px * kUnitPx - 0.5f * d.y * scale,
+                    has = resolve_draw(cam, d.y, d.z, d.x, px * kUnitPx - 0.5f * d.y * scale,
                                        (py + oy) * kUnitPx - 0.5f * d.z * scale, scale * kUnitPx / d.y, alpha, false,
                                        false, mine);
                 }
@@ -639,7 +687,7 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
         }
     }
 
-    if (flags & kFlagListed) {  // sprites, positive z (common_systems.cpp:41-63); empty until the first update (D2)
+    if (sflags & kFlagListed) {  // sprites, positive z (common_systems.cpp:41-63); empty until the first update (D2)
         bool has = false;
         if (lane < n_ent) {
             const int e = EB(s, EB_DRAW_ORDER, lane, env);
@@ -648,7 +696,7 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
                 const int tex = EB(s, EB_TEX, e, env) + ((info & kInfoFrame) ? 1 : 0);
                 const int4 d = atlas.desc[tex];
                 const float scale = 1.0f * 1.0f;
-                has = resolve_draw(cam, d.y, d.z, tex, (EF(s, EF_X, e, env) + -0.5f) * kUnitPx,
+                has = resolve_draw(cam, d.y, d.z, d.x, (EF(s, EF_X, e, env) + -0.5f) * kUnitPx,
                                    (EF(s, EF_Y, e, env) + -0.5f) * kUnitPx, scale * kUnitPx / d.y, 1.0f,
                                    (info & kInfoFlip) != 0, false, mine);
             }
@@ -658,7 +706,7 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
 
     {  // agent (common_systems.cpp:254-278)
         const float avx = SF(s, F_AVX, env);
-        const bool ground = (flags & kFlagGround) != 0;
+        const bool ground = (sflags & kFlagGround) != 0;
         int tex;
         if (fabsf(avx) < 0.01f && ground)
             tex = kTexStand + alien;
@@ -670,12 +718,13 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
             tex = kTexWalk1 + alien;
         const int4 d = atlas.desc[tex];
         const float px = SF(s, F_AX, env) - 0.5f, py = SF(s, F_AY, env) - 2.0f;
-        const bool ok = resolve_draw(cam, d.y, d.z, tex, px * kUnitPx, py * kUnitPx, kUnitPx / d.y, 1.0f,
-                                     (flags & kFlagForward) == 0, false, mine);
+        const bool ok = resolve_draw(cam, d.y, d.z, d.x, px * kUnitPx, py * kUnitPx, kUnitPx / d.y, 1.0f,
+                                     (sflags & kFlagForward) == 0, false, mine);
         wave_replay(fb, atlas, mine, ok ? 1ull : 0ull, lane);
     }
 
-    wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane);
+    }  // ablation
+    if (!(flags & 8)) wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -741,6 +790,13 @@ class CoinrunGame final : public Game {
         return v;
     }
 
+    std::string check_atlas(const std::vector<std::pair<int, int>>& sizes) const override {
+        if (static_cast<int>(sizes.size()) != kTexCount) return "coinrun: unexpected texture count";
+        for (int t = kTexTop; t < kTexWalker; t++)  // the row composer assumes one tile texture size
+            if (sizes[t] != sizes[kTexMid]) return "coinrun: tile textures differ in size";
+        return "";
+    }
+
     static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
     size_t state_bytes(int n) const override {
         size_t total = 0;
@@ -783,7 +839,7 @@ class CoinrunGame final : public Game {
                            env_offset, io);
     }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
-        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(64), 0, st, s_, atlas_, mask, io);
+        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(64), 0, st, s_, atlas_, mask, io, debug_flags);
     }
 
     // Same layout as oracle/pgo_coinrun.cpp Coinrun::dump_state.

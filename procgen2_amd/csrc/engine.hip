@@ -183,6 +183,12 @@ int32_t pgv_make(const char* game, int32_t num_envs, int32_t device, uint32_t se
         pgv_close(raw);
         return fail("pgv_make: " + err);
     }
+    err = e->game->check_atlas(e->atlas.sizes());
+    if (!err.empty()) {
+        pgv_env* raw = e.release();
+        pgv_close(raw);
+        return fail("pgv_make: " + err);
+    }
     if (!e->atlas.upload(err)) {
         pgv_env* raw = e.release();
         pgv_close(raw);
@@ -363,6 +369,12 @@ int32_t pgv_timed_steps(pgv_env* e, int32_t steps, uint32_t run_seed, double* to
     }
     for (auto& p : pairs) hipEventDestroy(p);
     if (render_kernel_ms) *render_kernel_ms = render_sum;
+    return 0;
+}
+
+int32_t pgv_set_debug(pgv_env* e, int32_t flags) {
+    if (!e) return fail("pgv_set_debug: env is NULL");
+    e->game->debug_flags = flags;
     return 0;
 }
 

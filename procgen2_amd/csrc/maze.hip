@@ -246,37 +246,55 @@ __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actio
     io.pending[env] = terminated ? 1 : 0;
 }
 
-__global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io) {
+// flags bit 0: force the draw-list replay for background + walls (fallback path).
+__global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
+                                                    int flags) {
     const int env = blockIdx.x;
     if (mask && !mask[env]) return;
     const int lane = threadIdx.x;
     __shared__ uint32_t fb[kFbWords];
-    wave_clear(fb, lane);
+    constexpr int kGrid = 32;  // 25 visible tiles + the border cells of the inclusive window
+    __shared__ ComposeLds<kGrid> L;
 
     // maze.cpp:397-400, 436-437: zoom = 64 / (16 * visible_width), camera at the world centre.
     const float zoom = 64.0f / (kUnitPx * 25.0f);
     const Camera cam{W * 0.5f * kUnitPx, H * 0.5f * kUnitPx, 64.0f, 64.0f, zoom};
-    const int flags = SI(s, I_FLAGS, env);
+    const int sflags = SI(s, I_FLAGS, env);
     const uint8_t* tiles = s.tiles + size_t(env) * kTileStride;
     Blit mine;
 
-    {  // background (maze.cpp:402-408)
-        const int tex = kTexFloor + SI(s, I_BG, env);
-        const int4 d = atlas.desc[tex];
+    Blit bg;  // background (maze.cpp:402-408)
+    bool has_bg;
+    {
+        const int4 d = atlas.desc[kTexFloor + SI(s, I_BG, env)];
         const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
         const float extra = aspect - 1.0f;
-        const bool ok = resolve_draw(cam, d.y, d.z, tex, -SF(s, F_BGSHIFT, env) * extra, 0.0f, 64.0f * kUnitPx / d.z,
-                                     1.0f, false, false, mine);
-        wave_replay(fb, atlas, mine, ok ? 1ull : 0ull, lane);
+        has_bg = resolve_draw(cam, d.y, d.z, d.x, -SF(s, F_BGSHIFT, env) * extra, 0.0f, 64.0f * kUnitPx / d.z, 1.0f,
+                              false, false, bg);
     }
-    {  // walls (tilemap.cpp:111-133)
-        const float vx = (cam.px - cam.sw * 0.5f / cam.scale) * kPxUnit;
-        const float vy = (cam.py - cam.sh * 0.5f / cam.scale) * kPxUnit;
-        const float vw = cam.sw * kPxUnit / cam.scale, vh = cam.sh * kPxUnit / cam.scale;
-        const int x0 = static_cast<int>(floorf(vx)), y0 = static_cast<int>(floorf(vy));
-        const int x1 = static_cast<int>(ceilf(vx + vw)), y1 = static_cast<int>(ceilf(vy + vh));
-        const int cols = x1 - x0 + 1, cells = cols * (y1 - y0 + 1);
-        const int4 d = atlas.desc[kTexWall];
+    // wall window (tilemap.cpp:111-121)
+    const float vx = (cam.px - cam.sw * 0.5f / cam.scale) * kPxUnit;
+    const float vy = (cam.py - cam.sh * 0.5f / cam.scale) * kPxUnit;
+    const float vw = cam.sw * kPxUnit / cam.scale, vh = cam.sh * kPxUnit / cam.scale;
+    const int x0 = static_cast<int>(floorf(vx)), y0 = static_cast<int>(floorf(vy));
+    const int x1 = static_cast<int>(ceilf(vx + vw)), y1 = static_cast<int>(ceilf(vy + vh));
+    const int cols = x1 - x0 + 1, rows = y1 - y0 + 1, cells = cols * rows;
+    const int4 wall = atlas.desc[kTexWall];
+
+    bool composed = false;
+    if (!(flags & 1) && cols <= kGrid && rows <= kGrid) {
+        compose_spans(L, cam, x0, y0, cols, rows, wall.y, wall.z, kUnitPx / wall.y, lane);
+        for (int cell = lane; cell < cells; cell += 64) {
+            const int r = cell / cols, c = cell - r * cols;
+            L.base[r * kGrid + c] = tile_at(tiles, x0 + c, H - 1 - (y0 + r)) == kOpen ? -1 : wall.x;
+        }
+        __syncthreads();
+        composed = compose_rows(fb, L, atlas, bg, has_bg, cols, rows, wall.y, lane);
+    }
+    if (!composed) {  // draw-list replay (tilemap.cpp:111-133)
+        wave_clear(fb, lane);
+        mine = bg;
+        wave_replay(fb, atlas, mine, has_bg ? 1ull : 0ull, lane);
         for (int base = 0; base < cells; base += 64) {
             const int cell = base + lane;
             bool has = false;
@@ -284,25 +302,25 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
                 const int row = cell / cols;
                 const int x = x0 + (cell - row * cols), y = y0 + row;
                 if (tile_at(tiles, x, H - 1 - y) != kOpen)
-                    has = resolve_draw(cam, d.y, d.z, kTexWall, x * kUnitPx, y * kUnitPx, kUnitPx / d.y, 1.0f, false,
-                                       false, mine);
+                    has = resolve_draw(cam, wall.y, wall.z, wall.x, x * kUnitPx, y * kUnitPx, kUnitPx / wall.y, 1.0f,
+                                       false, false, mine);
             }
             wave_replay(fb, atlas, mine, __ballot(has), lane);
         }
     }
-    if (flags & kFlagListed) {  // the cheese sprite (tilemap.cpp:88): offset (-0.48,-0.5), scale 0.95, z = 1
+    if (sflags & kFlagListed) {  // the cheese sprite (tilemap.cpp:88): offset (-0.48,-0.5), scale 0.95, z = 1
         const int4 d = atlas.desc[kTexCheese];
         const float scale = 1.0f * 0.95f;
-        const bool ok = resolve_draw(cam, d.y, d.z, kTexCheese, (SF(s, F_GX, env) + -0.48f) * kUnitPx,
+        const bool ok = resolve_draw(cam, d.y, d.z, d.x, (SF(s, F_GX, env) + -0.48f) * kUnitPx,
                                      (SF(s, F_GY, env) + -0.5f) * kUnitPx, scale * kUnitPx / d.y, 1.0f, false, false,
                                      mine);
         wave_replay(fb, atlas, mine, ok ? 1ull : 0ull, lane);
     }
     {  // the mouse (common_systems.cpp:138-150); flip = face_forward
         const int4 d = atlas.desc[kTexMouse];
-        const bool ok = resolve_draw(cam, d.y, d.z, kTexMouse, (SF(s, F_AX, env) + -0.5f) * kUnitPx,
+        const bool ok = resolve_draw(cam, d.y, d.z, d.x, (SF(s, F_AX, env) + -0.5f) * kUnitPx,
                                      (SF(s, F_AY, env) + -0.5f) * kUnitPx, kUnitPx / d.y * 1.0f, 1.0f,
-                                     (flags & kFlagForward) != 0, false, mine);
+                                     (sflags & kFlagForward) != 0, false, mine);
         wave_replay(fb, atlas, mine, ok ? 1ull : 0ull, lane);
     }
     wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane);
@@ -349,7 +367,7 @@ class MazeGame final : public Game {
                            env_offset, io);
     }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
-        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(64), 0, st, s_, atlas_, mask, io);
+        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(64), 0, st, s_, atlas_, mask, io, debug_flags);
     }
     // Same layout as oracle/pgo_maze.cpp Maze::dump_state.
     int dump_state(hipStream_t st, int env, float* out, int cap) override {

@@ -29,6 +29,11 @@ class Atlas {
     bool upload(std::string& err);
     AtlasView view() const { return {d_texels_, d_desc_, static_cast<int>(desc_.size())}; }
     size_t texel_bytes() const { return texels_.size() * 4; }
+    std::vector<std::pair<int, int>> sizes() const {
+        std::vector<std::pair<int, int>> v;
+        for (const auto& d : desc_) v.emplace_back(d.y, d.z);
+        return v;
+    }
 
    private:
     std::vector<uint32_t> texels_;
@@ -64,6 +69,11 @@ class Game {
     // Debug tap used by the parity tests: game-defined float dump of one env (host pointer).
     virtual int dump_state(hipStream_t s, int env, float* out, int cap) = 0;
     virtual int dump_tiles(hipStream_t s, int env, uint8_t* out, int cap) = 0;
+    // Host-side sanity check of the loaded atlas (sizes[i] = {w, h} of texture i); empty string = fine.
+    virtual std::string check_atlas(const std::vector<std::pair<int, int>>& sizes) const { return ""; }
+
+    // Bit 0: render background + tiles by draw-list replay instead of the row composer (fallback path).
+    int debug_flags = 0;
 };
 
 std::unique_ptr<Game> make_coinrun();

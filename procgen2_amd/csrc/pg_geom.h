@@ -41,11 +41,12 @@ PG_HD Box box_overlap(const Box& a, const Box& b) {
 }
 
 // One resolved draw call: destination rectangle in target pixels and the texel rectangle it
-// samples, both integer (raster spec S1/S2).  `dw <= 0` marks "nothing to draw".
+// samples, both integer (raster spec S1/S2).
 struct Blit {
     int32_t dx, dy, dw, dh;  // destination (may extend outside the 64×64 target; clipped per pixel)
     int32_t sx, sy, sw, sh;  // source texel rect, already intersected with the texture
-    int32_t tex;             // atlas texture index
+    int32_t tex_off;         // first texel of the texture in the atlas array
+    int32_t tex_w;           // texture width (row pitch in texels)
     int32_t flip_mod;        // bit 8: horizontal flip, bit 9: vertical flip, bits 0-7: alpha modulation
 };
 
@@ -58,81 +59,80 @@ struct Camera {
 constexpr int32_t kFlipH = 1 << 8;
 constexpr int32_t kFlipV = 1 << 9;
 
-// Renderer::render_texture (games/*/renderer.cpp:5-82) followed by raster-spec S1/S2.
-// tw/th: texture size; pos in world pixels.  Returns false when culled or empty.
-PG_HD bool resolve_draw(const Camera& cam, int tw, int th, int tex, float pos_x, float pos_y, float scale, float alpha,
-                        bool flip_h, bool flip_v, Blit& out) {
-    float sx = 0.0f, sy = 0.0f;
-    float sw = static_cast<float>(tw), sh = static_cast<float>(th);
-    float dx = (pos_x - cam.px) * cam.scale + cam.sw * 0.5f;
-    float dy = (pos_y - cam.py) * cam.scale + cam.sh * 0.5f;
-    float dw = tw * scale * cam.scale;
-    float dh = th * scale * cam.scale;
+// One axis of a resolved draw: destination span [d0, d0+dn) and source span [s0, s0+sn).
+struct Span {
+    int32_t d0, dn, s0, sn;
+};
 
-    if (dx > cam.sw || dy >= cam.sh || dx + dw < 0 || dy + dh < 0) return false;  // renderer.cpp:14
+// Renderer::render_texture (games/*/renderer.cpp:5-82) is separable: every x quantity depends only on
+// x inputs and every y quantity only on y inputs (the cull test is an OR of two x and two y conditions on
+// the untouched values).  This is one axis of it, followed by raster-spec S1/S2 for that axis.
+//   cam_pos/cam_len: camera position and viewport size on this axis; tsize: texture extent on this axis;
+//   strict_far: the far-side cull is `>=` on y and `>` on x (renderer.cpp:14).
+PG_HD bool resolve_axis(float cam_pos, float cam_len, float cam_scale, int tsize, float pos, float scale, bool flip,
+                        bool strict_far, Span& out) {
+    float s = 0.0f;
+    float sl = static_cast<float>(tsize);
+    float d = (pos - cam_pos) * cam_scale + cam_len * 0.5f;
+    float dl = tsize * scale * cam_scale;
 
-    if (dx < 0.0f) {  // renderer.cpp:18-26
-        float ratio = -dx / dw;
-        sx += sw * ratio;
-        sw -= sx;
-        dw += dx;
-        dx = 0.0f;
+    if ((strict_far ? d >= cam_len : d > cam_len) || d + dl < 0) return false;  // renderer.cpp:14
+
+    if (d < 0.0f) {  // renderer.cpp:18-26 / 36-44
+        float ratio = -d / dl;
+        s += sl * ratio;
+        sl -= s;
+        dl += d;
+        d = 0.0f;
     }
-    if (dx + dw > cam.sw) {  // renderer.cpp:28-34
-        float ratio = (dx + dw - cam.sw) / dw;
-        sw = sw * (1.0f - ratio);
-        dw = cam.sw - dx;
-    }
-    if (dy < 0.0f) {  // renderer.cpp:36-44
-        float ratio = -dy / dh;
-        sy += sh * ratio;
-        sh -= sy;
-        dh += dy;
-        dy = 0.0f;
-    }
-    if (dy + dh > cam.sh) {  // renderer.cpp:46-52
-        float ratio = (dy + dh - cam.sh) / dh;
-        sh = sh * (1.0f - ratio);
-        dh = cam.sh - dy;
+    if (d + dl > cam_len) {  // renderer.cpp:28-34 / 46-52
+        float ratio = (d + dl - cam_len) / dl;
+        sl = sl * (1.0f - ratio);
+        dl = cam_len - d;
     }
 
+    int padding = static_cast<int>(ceilf(1.0f / (scale * cam_scale)));  // renderer.cpp:59
+    int r0 = static_cast<int>(floorf(s));
+    int rl = static_cast<int>(ceilf(sl)) + padding;
+    float off = s - r0;  // renderer.cpp:64-70
+    float ratio = rl / sl;
+    dl *= ratio;
+    d -= off * (dl / sl);
+    if (flip) r0 = tsize - rl - r0;  // renderer.cpp:72-74 (the reference only flips x this way)
+
+    // S1: destination by truncation; non-finite, sub-pixel or absurd spans draw nothing.
+    if (!(dl >= 1.0f && dl < 32768.0f)) return false;
+    if (!(d > -32768.0f && d < 32768.0f)) return false;
+    out.d0 = static_cast<int>(d);
+    out.dn = static_cast<int>(dl);
+    // S2: source span intersected with the texture, destination untouched.
+    int a = r0, b = r0 + rl;
+    if (a < 0) a = 0;
+    if (b > tsize) b = tsize;
+    out.s0 = a;
+    out.sn = b - a;
+    return out.sn > 0;
+}
+
+// The full draw call = both axes.  tex_off/tw/th describe the texture; pos in world pixels.
+// Returns false when culled or empty.
+PG_HD bool resolve_draw(const Camera& cam, int tw, int th, int tex_off, float pos_x, float pos_y, float scale,
+                        float alpha, bool flip_h, bool flip_v, Blit& out) {
+    Span x, y;
+    if (!resolve_axis(cam.px, cam.sw, cam.scale, tw, pos_x, scale, flip_h, false, x)) return false;
+    if (!resolve_axis(cam.py, cam.sh, cam.scale, th, pos_y, scale, false, true, y)) return false;
     int mod = 255;
     if (alpha != 1.0f) mod = static_cast<int>(255 * alpha) & 0xff;  // Uint8 parameter (renderer.cpp:56-57)
-
-    int padding = static_cast<int>(ceilf(1.0f / (scale * cam.scale)));  // renderer.cpp:59
-    int rx = static_cast<int>(floorf(sx));
-    int ry = static_cast<int>(floorf(sy));
-    int rw = static_cast<int>(ceilf(sw)) + padding;
-    int rh = static_cast<int>(ceilf(sh)) + padding;
-
-    float off_x = sx - rx, off_y = sy - ry;  // renderer.cpp:64-70
-    float ratio_x = rw / sw, ratio_y = rh / sh;
-    dw *= ratio_x;
-    dh *= ratio_y;
-    dx -= off_x * (dw / sw);
-    dy -= off_y * (dh / sh);
-
-    if (flip_h) rx = tw - rw - rx;  // renderer.cpp:72-74
-
-    // S1: destination by truncation; non-finite, sub-pixel or absurd rectangles draw nothing.
-    if (!(dw >= 1.0f && dh >= 1.0f && dw < 32768.0f && dh < 32768.0f)) return false;
-    if (!(dx > -32768.0f && dx < 32768.0f && dy > -32768.0f && dy < 32768.0f)) return false;
-    out.dx = static_cast<int>(dx);
-    out.dy = static_cast<int>(dy);
-    out.dw = static_cast<int>(dw);
-    out.dh = static_cast<int>(dh);
-    // S2: source rect intersected with the texture, destination untouched.
-    int x0 = rx, y0 = ry, x1 = rx + rw, y1 = ry + rh;
-    if (x0 < 0) x0 = 0;
-    if (y0 < 0) y0 = 0;
-    if (x1 > tw) x1 = tw;
-    if (y1 > th) y1 = th;
-    out.sx = x0;
-    out.sy = y0;
-    out.sw = x1 - x0;
-    out.sh = y1 - y0;
-    if (out.sw <= 0 || out.sh <= 0) return false;
-    out.tex = tex;
+    out.dx = x.d0;
+    out.dw = x.dn;
+    out.sx = x.s0;
+    out.sw = x.sn;
+    out.dy = y.d0;
+    out.dh = y.dn;
+    out.sy = y.s0;
+    out.sh = y.sn;
+    out.tex_off = tex_off;
+    out.tex_w = tw;
     out.flip_mod = mod | (flip_h ? kFlipH : (flip_v ? kFlipV : 0));
     return true;
 }
@@ -140,20 +140,24 @@ PG_HD bool resolve_draw(const Camera& cam, int tw, int th, int tex, float pos_x,
 // Raster spec S3: nearest texel for destination column/row `i` of `n`, over `len` texels from `start`.
 PG_HD int sample_index(int start, int len, int i, int n) { return start + ((2 * i + 1) * len) / (2 * n); }
 
+// floor(x / 255) for 0 <= x < 65536 (exhaustively checked in tests/cpp/test_primitives.cpp).
+PG_HD uint32_t div255(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(x, 0x8081u) >> 23;
+#else
+    return (x * 0x8081u) >> 23;
+#endif
+}
+
 // Raster spec S4: straight-alpha blend with truncating /255 on one packed pixel (R | G<<8 | B<<16).
-// a is the source alpha after modulation; returns the new destination.
+// a is the source alpha after modulation (0..255); returns the new destination.  a = 0 leaves dst, a = 255
+// yields src — both fall out of the formula, no special cases needed.
 PG_HD uint32_t blend_px(uint32_t dst, uint32_t src, int a) {
-    if (a >= 255) return src & 0x00ffffffu;
-    const int ia = 255 - a;
-    uint32_t out = 0;
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        int s = static_cast<int>((src >> (8 * c)) & 0xffu);
-        int d = static_cast<int>((dst >> (8 * c)) & 0xffu);
-        int v = (s * a) / 255 + (ia * d) / 255;
-        out |= static_cast<uint32_t>(v) << (8 * c);
-    }
-    return out;
+    const uint32_t ua = static_cast<uint32_t>(a), ia = 255u - ua;
+    const uint32_t r = div255((src & 0xffu) * ua) + div255((dst & 0xffu) * ia);
+    const uint32_t g = div255(((src >> 8) & 0xffu) * ua) + div255(((dst >> 8) & 0xffu) * ia);
+    const uint32_t b = div255(((src >> 16) & 0xffu) * ua) + div255(((dst >> 16) & 0xffu) * ia);
+    return r | (g << 8) | (b << 16);
 }
 
 }  // namespace pg

@@ -1,10 +1,21 @@
 // Device-side rasteriser shared by the game render kernels (gfx950 only).
 //
-// One 64-lane wavefront owns one env: its 64×64 target lives in LDS as packed 0x00BBGGRR words
-// (16 KiB), draw calls are replayed back-to-front exactly in the reference's order (painter's
-// algorithm, so overdraw and blend order are right by construction), and the finished frame is
-// streamed to the observation slab as contiguous 768-byte wave stores (4 pixels → 3 dwords per lane).
-// Raster rules S1–S5: DESIGN.md §raster-spec (oracle twin: oracle/pgo_raster.cpp spec_blit).
+// One 64-lane wavefront owns one env; its 64×64 target lives in LDS as packed 0x00BBGGRR words (16 KiB).
+// Two ways of putting pixels there, both bit-identical to replaying the reference's draw list back to front
+// under raster rules S1–S5 (oracle twin: oracle/pgo_raster.cpp):
+//
+//  * compose_rows — background + the whole tile layer in ONE pass over the 64 rows, lane = pixel column.
+//    render_texture's arithmetic is separable per axis (pg_geom.h resolve_axis), and every tile of the layer
+//    shares one texture size and scale, so the layer is described by one span table per grid column and one per
+//    grid row.  A pixel is covered by at most two grid columns and two grid rows (tiles overlap their
+//    neighbours by the padding); the (row, column) candidates are blended in draw order
+//    (y-major, x-minor).  Cost is independent of the number of tiles, every lane is busy, and the texel
+//    gathers of several rows are issued together — unlike ~100–470 latency-serialised small blits.
+//    If any pixel had a third covering column/row the function reports it and the caller falls back.
+//  * wave_blit / wave_replay — one resolved draw executed by all lanes (flattened pixels), used for the few
+//    sprites, particles and the agent, and as the fallback for tiles.
+//
+// The finished frame is streamed to the observation slab as contiguous 768-byte wave stores.
 #pragma once
 
 #include "pg_engine.h"
@@ -18,6 +29,14 @@ struct __attribute__((packed, aligned(4))) Rgb4 {
     uint32_t a, b, c;
 };
 
+// LDS scratch of the row composer; GRID = max tile-grid columns / rows visible in one frame.
+template <int GRID>
+struct ComposeLds {
+    int4 col[GRID];             // per grid column: {d0, dn, s0, sn}; sn == 0 ⇒ nothing drawn
+    int4 row[GRID];             // per grid row
+    int32_t base[GRID * GRID];  // [row][col] texel offset of the cell's tile texture, -1 = no tile
+};
+
 // Broadcast a resolved draw from lane `src` (wave-uniform) into scalar registers.
 PG_D Blit blit_from_lane(const Blit& mine, int src) {
     Blit b;
@@ -29,14 +48,22 @@ PG_D Blit blit_from_lane(const Blit& mine, int src) {
     b.sy = __builtin_amdgcn_readlane(mine.sy, src);
     b.sw = __builtin_amdgcn_readlane(mine.sw, src);
     b.sh = __builtin_amdgcn_readlane(mine.sh, src);
-    b.tex = __builtin_amdgcn_readlane(mine.tex, src);
+    b.tex_off = __builtin_amdgcn_readlane(mine.tex_off, src);
+    b.tex_w = __builtin_amdgcn_readlane(mine.tex_w, src);
     b.flip_mod = __builtin_amdgcn_readlane(mine.flip_mod, src);
     return b;
 }
 
+// dst OVER-composited with one texel (raster spec S4).  Wave-level fast path: when every lane's alpha is 0 or
+// 255 (opaque walls, opaque backgrounds — the common case) the blend is a select; the formula gives the same.
+PG_D uint32_t over(uint32_t dst, uint32_t texel, int a) {
+    if (__ballot(a != 0 && a != 255) == 0) return a ? (texel & 0x00ffffffu) : dst;
+    return blend_px(dst, texel, a);
+}
+
 PG_D void blend_into(uint32_t* fb, int idx, uint32_t texel, int mod) {
     int a = static_cast<int>(texel >> 24);
-    if (mod != 255) a = a * mod / 255;
+    if (mod != 255) a = static_cast<int>(div255(static_cast<uint32_t>(a * mod)));
     if (a == 0) return;
     fb[idx] = blend_px(fb[idx], texel, a);
 }
@@ -48,14 +75,13 @@ PG_D void wave_blit(uint32_t* fb, const AtlasView& atlas, const Blit& b, int lan
     const int y1 = (b.dy + b.dh) < kObsH ? (b.dy + b.dh) : kObsH;
     const int cw = x1 - x0, ch = y1 - y0;
     if (cw <= 0 || ch <= 0) return;
-    const int4 d = atlas.desc[b.tex];
-    const uint32_t* tex = atlas.texels + d.x;
-    const int tw = d.y;
+    const uint32_t* tex = atlas.texels + b.tex_off;
+    const int tw = b.tex_w;
     const int mod = b.flip_mod & 0xff;
     const bool fh = (b.flip_mod & kFlipH) != 0, fv = (b.flip_mod & kFlipV) != 0;
 
     if (cw > 32) {
-        // Wide blit (backgrounds): lane = column, source column fixed per lane, one row per iteration.
+        // Wide blit (backgrounds on the fallback path): lane = column, one row per iteration.
         const int x = x0 + lane;
         const bool on = lane < cw;
         int i = x - b.dx;
@@ -99,6 +125,147 @@ PG_D void wave_clear(uint32_t* fb, int lane) {
     uint4* p = reinterpret_cast<uint4*>(fb);
     for (int k = lane; k < kFbWords / 4; k += 64) p[k] = make_uint4(0, 0, 0, 0);
     __syncthreads();
+}
+
+// Which of the `n` spans cover destination coordinate `p`?  Records the first two (ascending index) and the
+// texel coordinate each samples at p; returns false if a third one covers p.
+PG_D bool covering_spans(const int4* spans, int n, int p, int& ia, int& ib, int& ta, int& tb) {
+    ia = ib = -1;
+    ta = tb = 0;
+    bool ok = true;
+    for (int k = 0; k < n; k++) {
+        const int4 s = spans[k];
+        if (s.w > 0 && p >= s.x && p < s.x + s.y) {
+            const int t = sample_index(s.z, s.w, p - s.x, s.y);
+            if (ia < 0) {
+                ia = k;
+                ta = t;
+            } else if (ib < 0) {
+                ib = k;
+                tb = t;
+            } else {
+                ok = false;
+            }
+        }
+    }
+    return ok;
+}
+
+// Step 1 of the composer: the per-column / per-row span tables of the tile grid (lane c → column x0+c and
+// row y0+c).  Call before staging L.base; needs a __syncthreads() before compose_rows (which the staging
+// loop's own barrier provides).
+template <int GRID>
+PG_D void compose_spans(ComposeLds<GRID>& L, const Camera& cam, int x0, int y0, int cols, int rows, int tw, int th,
+                        float tile_scale, int lane) {
+    if (lane < cols) {
+        Span sp;
+        const bool ok = resolve_axis(cam.px, cam.sw, cam.scale, tw, (x0 + lane) * kUnitPx, tile_scale, false, false, sp);
+        L.col[lane] = ok ? make_int4(sp.d0, sp.dn, sp.s0, sp.sn) : make_int4(0, 0, 0, 0);
+    }
+    if (lane < rows) {
+        Span sp;
+        const bool ok = resolve_axis(cam.py, cam.sh, cam.scale, th, (y0 + lane) * kUnitPx, tile_scale, false, true, sp);
+        L.row[lane] = ok ? make_int4(sp.d0, sp.dn, sp.s0, sp.sn) : make_int4(0, 0, 0, 0);
+    }
+}
+
+// Background + tile layer in one pass.  Preconditions (set up by the game's render kernel, then a barrier):
+//   compose_spans() has run; L.base[r * GRID + c] = texel offset of the texture of grid cell (x0+c, y0+r) or -1;
+//   all tile textures are tw texels wide; bg / has_bg: the resolved background draw (wave-uniform).
+// Writes every pixel of fb (black where nothing is drawn).  Returns false — having written nothing — when the
+// layer does not fit the two-candidate scheme (caller falls back to wave_replay).
+template <int GRID>
+PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView& atlas, const Blit& bg, bool has_bg,
+                       int cols, int rows, int tw, int lane) {
+    // lane as pixel column: covering grid columns; lane as pixel row: covering grid rows.
+    int ca, cb, ua, ub, ra, rb, va, vb;
+    bool fits = covering_spans(L.col, cols, lane, ca, cb, ua, ub);
+    fits = covering_spans(L.row, rows, lane, ra, rb, va, vb) && fits;
+    if (__ballot(!fits)) return false;
+
+    // background sampling coordinates: column (this lane) and row (lane = row index)
+    const uint32_t* texels = atlas.texels;
+    int bg_u = -1, bg_v = -1;
+    if (has_bg) {
+        const bool fh = (bg.flip_mod & kFlipH) != 0, fv = (bg.flip_mod & kFlipV) != 0;
+        if (lane >= bg.dx && lane < bg.dx + bg.dw) {
+            int i = lane - bg.dx;
+            if (fh) i = bg.dw - 1 - i;
+            bg_u = sample_index(bg.sx, bg.sw, i, bg.dw);
+        }
+        if (lane >= bg.dy && lane < bg.dy + bg.dh) {
+            int j = lane - bg.dy;
+            if (fv) j = bg.dh - 1 - j;
+            bg_v = sample_index(bg.sy, bg.sh, j, bg.dh);
+        }
+    }
+    const int bg_mod = has_bg ? (bg.flip_mod & 0xff) : 255;
+    const int bg_off = has_bg ? bg.tex_off : 0, bg_w = has_bg ? bg.tex_w : 0;
+    // per-lane constants of the row loop
+    const int cia = ca >= 0 ? ca : 0, cib = cb >= 0 ? cb : 0;
+    const bool has_a = ca >= 0, has_b = cb >= 0, has_bgu = bg_u >= 0;
+
+    // Rows in batches: all texel gathers of a batch are issued before any blend (branch-free addresses; a
+    // candidate that does not exist reads texel 0 and is zeroed, i.e. alpha 0), so a batch costs one memory
+    // round trip instead of up to five per row.
+    constexpr int kBatch = 4;
+    for (int py0 = 0; py0 < kObsH; py0 += kBatch) {
+        uint32_t t[kBatch][5];
+        bool second_row[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) {
+            const int py = py0 + k;
+            const int r_a = __builtin_amdgcn_readlane(ra, py), r_b = __builtin_amdgcn_readlane(rb, py);
+            const int v_a = __builtin_amdgcn_readlane(va, py), v_b = __builtin_amdgcn_readlane(vb, py);
+            const int bv = __builtin_amdgcn_readlane(bg_v, py);
+            {
+                const bool ok = has_bgu && bv >= 0;
+                const uint32_t x = texels[ok ? bg_off + bv * bg_w + bg_u : 0];
+                t[k][0] = ok ? x : 0u;
+            }
+            {
+                const int32_t* br = L.base + (r_a >= 0 ? r_a : 0) * GRID;
+                const int base_a = br[cia], base_b = br[cib];
+                const bool ok_a = r_a >= 0 && has_a && base_a >= 0;
+                const bool ok_b = r_a >= 0 && has_b && base_b >= 0;
+                const uint32_t xa = texels[ok_a ? base_a + v_a * tw + ua : 0];
+                const uint32_t xb = texels[ok_b ? base_b + v_a * tw + ub : 0];
+                t[k][1] = ok_a ? xa : 0u;
+                t[k][2] = ok_b ? xb : 0u;
+            }
+            second_row[k] = r_b >= 0;  // wave-uniform
+            if (second_row[k]) {
+                const int32_t* br = L.base + r_b * GRID;
+                const int base_a = br[cia], base_b = br[cib];
+                const bool ok_a = has_a && base_a >= 0;
+                const bool ok_b = has_b && base_b >= 0;
+                const uint32_t xa = texels[ok_a ? base_a + v_b * tw + ua : 0];
+                const uint32_t xb = texels[ok_b ? base_b + v_b * tw + ub : 0];
+                t[k][3] = ok_a ? xa : 0u;
+                t[k][4] = ok_b ? xb : 0u;
+            } else {
+                t[k][3] = t[k][4] = 0u;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) {
+            uint32_t pix = 0;
+            {
+                int a = static_cast<int>(t[k][0] >> 24);
+                if (bg_mod != 255) a = static_cast<int>(div255(static_cast<uint32_t>(a * bg_mod)));
+                pix = over(pix, t[k][0], a);
+            }
+            pix = over(pix, t[k][1], static_cast<int>(t[k][1] >> 24));
+            pix = over(pix, t[k][2], static_cast<int>(t[k][2] >> 24));
+            if (second_row[k]) {
+                pix = over(pix, t[k][3], static_cast<int>(t[k][3] >> 24));
+                pix = over(pix, t[k][4], static_cast<int>(t[k][4] >> 24));
+            }
+            fb[(py0 + k) * kObsW + lane] = pix;
+        }
+    }
+    __syncthreads();
+    return true;
 }
 
 // RGB pack (coinrun.cpp:377-388): obs[3k+c] = pix[4k+c]; 4 pixels → 12 bytes per lane per pass,

@@ -9,6 +9,7 @@
 #include <unordered_set>
 #include <vector>
 
+#include "pg_geom.h"
 #include "pg_order.h"
 #include "pg_rng.h"
 
@@ -184,7 +185,30 @@ static void test_sort() {
     std::printf("OK sort\n");
 }
 
+static void test_blend() {
+    for (uint32_t x = 0; x < 65536; x++) CHECK(pg::div255(x) == x / 255, "div255(%u)", x);
+    // Raster spec S4 written out naively: s = a<255 ? C*a/255 : C;  D = s + (255-a)*D/255
+    for (int a = 0; a < 256; a++)
+        for (int s = 0; s < 256; s++)
+            for (int d = 0; d < 256; d += (a % 16 == 0 ? 1 : 5)) {
+                const int sc = (a < 255) ? s * a / 255 : s;
+                const int want = sc + (255 - a) * d / 255;
+                const uint32_t got = pg::blend_px(uint32_t(d) | uint32_t(d) << 8 | uint32_t(d) << 16,
+                                                  uint32_t(s) | uint32_t(s) << 8 | uint32_t(s) << 16 | 0xab000000u, a);
+                CHECK(got == (uint32_t(want) | uint32_t(want) << 8 | uint32_t(want) << 16), "blend a=%d s=%d d=%d", a, s, d);
+            }
+    // resolve_draw is the composition of its two axes and reproduces the known coinrun tile geometry:
+    // a 128-px tile at zoom 0.3 is 4.8 px, padded source 155 texels → destination trunc(5.8125) = 5 px.
+    pg::Camera cam{100.0f, 200.0f, 64.0f, 64.0f, 0.3f};
+    pg::Blit b;
+    CHECK(pg::resolve_draw(cam, 128, 128, 7, 96.0f, 192.0f, 0.125f, 1.0f, false, false, b), "tile visible");
+    CHECK(b.dw == 5 && b.dh == 5 && b.sx == 0 && b.sw == 128 && b.tex_off == 7 && b.tex_w == 128, "tile geometry");
+    CHECK(!pg::resolve_draw(cam, 128, 128, 7, 4000.0f, 192.0f, 0.125f, 1.0f, false, false, b), "culled");
+    std::printf("OK blend\n");
+}
+
 int main() {
+    test_blend();
     test_mt();
     test_distributions();
     test_hash_order();

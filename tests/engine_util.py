@@ -48,6 +48,9 @@ class EngineVec:
             pglib.check(self.L, self.L.pgv_step_host(self.h, a.ctypes.data_as(c_void_p)), "pgv_step_host")
         return self._fetch()
 
+    def set_debug(self, flags):
+        pglib.check(self.L, self.L.pgv_set_debug(self.h, flags), "pgv_set_debug")
+
     def state(self, env, cap=512):
         buf = (c_float * cap)()
         n = self.L.pgv_dump_state(self.h, env, buf, cap)
