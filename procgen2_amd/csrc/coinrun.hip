@@ -13,6 +13,16 @@
 // out: saws/mobs in creation order, then the coin; the agent is kept apart), and the iteration order of the
 // reference's std::unordered_set-based systems is recomputed at reset with pg_order.h and stored as two
 // small permutations (sprite draw order, particle-owner order).
+//
+// The logic kernel is latency-bound (one wave per SIMD at 65 536 envs), so a step is organised to expose as
+// few dependent memory round trips as possible while producing the reference's sub-step interleaving exactly:
+//   1. the agent's four sub-steps first — they depend on tiles only — keeping a snapshot per sub-step;
+//   2. ONE pass over the entities simulating all sub-steps of each (mob walk + particles + animation) with its
+//      state in registers, testing its box against the agent's box of the same sub-step; tile lookups of a
+//      whole collide() come from a 4×4 window fetched in one go and packed 3 bits per cell into a 64-bit word;
+//      results go to the *other* half of a double-buffered entity table;
+//   3. the first sub-step that terminates (hazard, lava, coin) decides how many sub-steps really happened; in
+//      the rare case that is fewer than four, pass 2 is redone from the untouched half with that limit.
 #include "pg_engine.h"
 #include "pg_geom.h"
 #include "pg_order.h"
@@ -32,20 +42,20 @@ enum Kind { kSaw = 0, kMob = 1, kCoin = 2 };
 
 // Atlas order (texture_names() below must match).
 enum Tex {
-    kTexTop = 0,                  // 6 themes: <theme>Mid.png    (tile wall_top)
-    kTexMid = 6,                  // 6 themes: <theme>Center.png (tile wall_mid)
+    kTexTop = 0,      // 6 themes: <theme>Mid.png    (tile wall_top)
+    kTexMid = 6,      // 6 themes: <theme>Center.png (tile wall_mid)
     kTexLavaTop = 12,
     kTexLava = 13,
-    kTexCrate = 14,               // 4
-    kTexWalker = 18,              // 9 × {still, move}
-    kTexSaw = 36,                 // 2
+    kTexCrate = 14,   // 4
+    kTexWalker = 18,  // 9 × {still, move}
+    kTexSaw = 36,     // 2
     kTexCoin = 38,
-    kTexStand = 39,               // 5 each
+    kTexStand = 39,   // 5 each
     kTexJump = 44,
     kTexWalk1 = 49,
     kTexWalk2 = 54,
     kTexSpark = 59,
-    kTexBackdrop = 60,            // 49
+    kTexBackdrop = 60,  // 49
     kTexCount = 109
 };
 
@@ -53,13 +63,13 @@ enum Tex {
 enum { F_AX, F_AY, F_AVX, F_AVY, F_APHASE, F_CAMX, F_CAMY, F_BGSHIFT, F_COUNT };
 // scalar int fields
 enum { I_FLAGS, I_THEMES, I_NENT, I_NMOB, I_HASH_SPRITE, I_HASH_SPARK, I_COUNT };
-constexpr int kFlagGround = 1, kFlagForward = 2, kFlagListed = 4;
-// per-entity float fields
-enum { EF_X, EF_Y, EF_VX, EF_ANIM_T, EF_SPAWN_T, EF_COUNT };
-// per-entity byte fields
-enum { EB_INFO, EB_TEX, EB_DRAW_ORDER, EB_SPARK_ORDER, EB_COUNT };
-// EB_INFO bits: kind (0-1) | frame (2) | flip_x (3) | texture assigned (4)
-constexpr int kInfoFrame = 4, kInfoFlip = 8, kInfoTexSet = 16;
+constexpr int kFlagGround = 1, kFlagForward = 2, kFlagListed = 4, kFlagBuf = 8;  // kFlagBuf: live half of the table
+// static per-entity bytes
+enum { EB_KIND, EB_TEX, EB_DRAW_ORDER, EB_SPARK_ORDER, EB_COUNT };
+// dynamic (double-buffered) per-entity floats
+enum { DF_X, DF_VX, DF_ANIM_T, DF_SPAWN_T, DF_COUNT };
+// dynamic per-entity byte: animation frame | flip_x | texture assigned
+constexpr int kDynFrame = 1, kDynFlip = 2, kDynTexSet = 4;
 
 struct State {
     int n;
@@ -67,17 +77,23 @@ struct State {
     uint8_t* tiles;  // [n][4096]   tile id | crate kind << 4, column-major y + x*H (tilemap.h:62-85)
     float* f;        // [F_COUNT][n]
     int32_t* i;      // [I_COUNT][n]
-    float* ef;       // [EF_COUNT][kMaxEnt][n]
+    float* ey;       // [kMaxEnt][n]                      entity y (never changes within an episode)
     uint8_t* eb;     // [EB_COUNT][kMaxEnt][n]
-    float* spark;    // [3][kMaxEnt][kSparks][n]   x, y, life
+    float* df;       // [2][DF_COUNT][kMaxEnt][n]         double-buffered
+    uint8_t* db;     // [2][kMaxEnt][n]
+    float* spark;    // [2][3][kMaxEnt][kSparks][n]       x, y, life
 };
 
 PG_D float& SF(const State& s, int field, int env) { return s.f[size_t(field) * s.n + env]; }
 PG_D int32_t& SI(const State& s, int field, int env) { return s.i[size_t(field) * s.n + env]; }
-PG_D float& EF(const State& s, int field, int e, int env) { return s.ef[(size_t(field) * kMaxEnt + e) * s.n + env]; }
+PG_D float& EY(const State& s, int e, int env) { return s.ey[size_t(e) * s.n + env]; }
 PG_D uint8_t& EB(const State& s, int field, int e, int env) { return s.eb[(size_t(field) * kMaxEnt + e) * s.n + env]; }
-PG_D float& SP(const State& s, int comp, int e, int k, int env) {
-    return s.spark[((size_t(comp) * kMaxEnt + e) * kSparks + k) * s.n + env];
+PG_D float& DF(const State& s, int buf, int field, int e, int env) {
+    return s.df[((size_t(buf) * DF_COUNT + field) * kMaxEnt + e) * s.n + env];
+}
+PG_D uint8_t& DB(const State& s, int buf, int e, int env) { return s.db[(size_t(buf) * kMaxEnt + e) * s.n + env]; }
+PG_D float& SP(const State& s, int buf, int comp, int e, int k, int env) {
+    return s.spark[(((size_t(buf) * 3 + comp) * kMaxEnt + e) * kSparks + k) * s.n + env];
 }
 
 struct TileMap {
@@ -85,10 +101,6 @@ struct TileMap {
     PG_D void put(int x, int y, int id) {
         if (x < 0 || y < 0 || x >= W || y >= H) return;
         t[y + x * H] = static_cast<uint8_t>(id);
-    }
-    PG_D int at(int x, int y) const {
-        if (x < 0 || y < 0 || x >= W || y >= H) return kWallMid;
-        return t[y + x * H] & 7;
     }
     PG_D void fill(int x, int y, int w, int h, int id) {
         for (int a = 0; a < w; a++)
@@ -106,19 +118,21 @@ struct TileMap {
 struct LevelBuilder {
     const State& s;
     int env;
+    int buf;  // live half of the dynamic table
     uint32_t* mt;
     TileMap map;
     int n_ent = 0, n_mob = 0;
 
     PG_D int spawn(float x, float y, int kind, int tex, float vx) {
         const int e = n_ent++;
-        EF(s, EF_X, e, env) = x;
-        EF(s, EF_Y, e, env) = y;
-        EF(s, EF_VX, e, env) = vx;
-        EF(s, EF_ANIM_T, e, env) = 0.0f;
-        EF(s, EF_SPAWN_T, e, env) = 0.0f;
-        EB(s, EB_INFO, e, env) = static_cast<uint8_t>(kind | (kind == kCoin ? kInfoTexSet : 0));
+        EY(s, e, env) = y;
+        EB(s, EB_KIND, e, env) = static_cast<uint8_t>(kind);
         EB(s, EB_TEX, e, env) = static_cast<uint8_t>(tex);
+        DF(s, buf, DF_X, e, env) = x;
+        DF(s, buf, DF_VX, e, env) = vx;
+        DF(s, buf, DF_ANIM_T, e, env) = 0.0f;
+        DF(s, buf, DF_SPAWN_T, e, env) = 0.0f;
+        DB(s, buf, e, env) = static_cast<uint8_t>(kind == kCoin ? kDynTexSet : 0);  // D10: animated sprites start unset
         return e;
     }
     PG_D void add_saw(int x, int y) {  // tilemap.cpp:52-68
@@ -130,9 +144,9 @@ struct LevelBuilder {
         const int e = spawn(static_cast<float>(x) + 0.5f, static_cast<float>(H - 1 - y) + 0.5f, kMob,
                             kTexWalker + 2 * which, vx);
         for (int k = 0; k < kSparks; k++) {
-            SP(s, 0, e, k, env) = 0.0f;
-            SP(s, 1, e, k, env) = 0.0f;
-            SP(s, 2, e, k, env) = 0.0f;
+            SP(s, buf, 0, e, k, env) = 0.0f;
+            SP(s, buf, 1, e, k, env) = 0.0f;
+            SP(s, buf, 2, e, k, env) = 0.0f;
         }
         EB(s, EB_SPARK_ORDER, n_mob, env) = static_cast<uint8_t>(e);  // creation order; permuted below
         n_mob++;
@@ -255,7 +269,8 @@ PG_D void episode_order(int32_t& packed, const uint8_t* ids, int n, uint8_t* out
 }
 
 PG_D void new_level(const State& s, int env) {
-    LevelBuilder lb{s, env, s.mt + size_t(env) * kMtWords, TileMap{s.tiles + size_t(env) * (W * H)}};
+    const int buf = (SI(s, I_FLAGS, env) & kFlagBuf) ? 1 : 0;
+    LevelBuilder lb{s, env, buf, s.mt + size_t(env) * kMtWords, TileMap{s.tiles + size_t(env) * (W * H)}};
     lb.build();
     uint32_t* mt = lb.mt;
     const int backdrop = rng_int(mt, 0, 48);
@@ -269,7 +284,8 @@ PG_D void new_level(const State& s, int env) {
     SF(s, F_AVY, env) = 0.0f;
     SF(s, F_APHASE, env) = 0.0f;
     SF(s, F_BGSHIFT, env) = shift;
-    SI(s, I_FLAGS, env) = kFlagForward;  // on_ground=false, face_forward=true, draw list cleared (D2)
+    // on_ground=false, face_forward=true, draw list cleared (D2); the live half of the table is unchanged
+    SI(s, I_FLAGS, env) = kFlagForward | (buf ? kFlagBuf : 0);
     SI(s, I_THEMES, env) = backdrop | (alien << 8) | (ground << 16);
     SI(s, I_NENT, env) = lb.n_ent;
     SI(s, I_NMOB, env) = lb.n_mob;
@@ -296,13 +312,43 @@ PG_D void new_level(const State& s, int env) {
 // ------------------------------------------------------------------------------------------------
 // tile collision, variant A (tilemap.cpp:323-396)
 // ------------------------------------------------------------------------------------------------
+// 4×4 window of tile ids in collide() coordinates (x, y ↦ tile (x, H-1-y)), 3 bits per cell in one 64-bit
+// word: the whole window is fetched with 16 independent byte loads (one memory round trip), after which every
+// lookup of a collide() is a shift and a mask.  Cells outside the window fall back to a direct load, so the
+// window's placement affects speed only.
+struct TileWin {
+    const uint8_t* tiles;
+    int ax, ay;
+    uint64_t bits;
+
+    PG_D static int direct(const uint8_t* tiles, int x, int y) {
+        const int ty = H - 1 - y;
+        if (x < 0 || ty < 0 || x >= W || ty >= H) return kWallMid;  // out of bounds is a wall (tilemap.h:80-81)
+        return tiles[ty + x * H] & 7;
+    }
+    PG_D static TileWin fetch(const uint8_t* tiles, int ax, int ay) {
+        TileWin w{tiles, ax, ay, 0};
+        int t[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) t[k] = direct(tiles, ax + (k & 3), ay + (k >> 2));
+#pragma unroll
+        for (int k = 0; k < 16; k++) w.bits |= static_cast<uint64_t>(t[k]) << (3 * k);
+        return w;
+    }
+    PG_D int at(int x, int y) const {
+        const unsigned dx = static_cast<unsigned>(x - ax), dy = static_cast<unsigned>(y - ay);
+        if (dx < 4u && dy < 4u) return static_cast<int>((bits >> (3 * (dx + 4 * dy))) & 7u);
+        return direct(tiles, x, y);
+    }
+};
+
 struct Hit {
     float x, y;
     bool any;
 };
 
 template <class Pred>
-PG_D Hit collide(const TileMap& map, Box r, Pred solid, bool fallthrough, float step_y) {
+PG_D Hit collide(const TileWin& win, Box r, Pred solid, bool fallthrough, float step_y) {
     bool any = false;
     const int x0 = static_cast<int>(floorf(r.x)), y0 = static_cast<int>(floorf(r.y));
     const int x1 = static_cast<int>(ceilf(r.x + r.w)), y1 = static_cast<int>(ceilf(r.y + r.h));
@@ -310,7 +356,7 @@ PG_D Hit collide(const TileMap& map, Box r, Pred solid, bool fallthrough, float 
     Box cell{0.0f, 0.0f, 1.0f, 1.0f};
     for (int y = y0; y <= y1; y++)
         for (int x = x0; x <= x1; x++) {
-            const int kind = solid(map.at(x, H - 1 - y));
+            const int kind = solid(win.at(x, y));
             if (kind == kPass) continue;
             cell.x = static_cast<float>(x);
             cell.y = static_cast<float>(y);
@@ -332,7 +378,7 @@ PG_D Hit collide(const TileMap& map, Box r, Pred solid, bool fallthrough, float 
         }
     for (int y = y0; y <= y1; y++)
         for (int x = x0; x <= x1; x++) {
-            const int kind = solid(map.at(x, H - 1 - y));
+            const int kind = solid(win.at(x, y));
             if (kind == kPass) continue;
             cell.x = static_cast<float>(x);
             cell.y = static_cast<float>(y);
@@ -350,15 +396,125 @@ PG_D Hit collide(const TileMap& map, Box r, Pred solid, bool fallthrough, float 
 // ------------------------------------------------------------------------------------------------
 // step: the sub-step loop of cenv_step (coinrun.cpp:356-371)
 // ------------------------------------------------------------------------------------------------
+struct AgentSnap {  // agent + camera after one sub-step
+    float ax, ay, avx, avy, phase, camx, camy;
+    bool ground, forward;
+};
+
+// One pass over the entities, `limit` sub-steps each, reading half `src` and writing half `1 - src` of the
+// dynamic table.  body[ss] = the agent's box after its sub-step ss; hazard[ss] accumulates "some hazard
+// overlaps the agent in sub-step ss" (a boolean OR, so the reference's set order is irrelevant — App. B).
+PG_D void entity_pass(const State& s, int env, int n_ent, int src, int limit, const Box (&body)[4], bool (&hazard)[4]) {
+    const uint8_t* tiles = s.tiles + size_t(env) * (W * H);
+    const int dst = 1 - src;
+    const float dt = 1.0f / 4;
+    for (int ss = 0; ss < 4; ss++) hazard[ss] = false;
+    for (int e = 0; e < n_ent; e++) {
+        const int kind = EB(s, EB_KIND, e, env);
+        if (kind == kCoin) {  // no dynamic state beyond the texture flag
+            DF(s, dst, DF_X, e, env) = DF(s, src, DF_X, e, env);
+            DB(s, dst, e, env) = DB(s, src, e, env);
+            continue;
+        }
+        float x = DF(s, src, DF_X, e, env);
+        const float y = EY(s, e, env);
+        float anim_t = DF(s, src, DF_ANIM_T, e, env);
+        int dyn = DB(s, src, e, env);
+        if (kind == kSaw) {
+            const Box hb{x + -0.5f, y + -0.5f, 1.0f, 1.0f};  // tilemap.cpp:66
+#pragma unroll
+            for (int ss = 0; ss < 4; ss++) {
+                if (ss >= limit) break;
+                if (box_hit(body[ss], hb)) hazard[ss] = true;
+                // System_Sprite_Render::update (common_systems.cpp:14-29), rate 1.0 (tilemap.cpp:60)
+                anim_t += dt;
+                const int adv = static_cast<int>(anim_t * 1.0f);
+                anim_t -= adv / 1.0f;
+                dyn = ((dyn & ~kDynFrame) | ((((dyn & kDynFrame) ? 1 : 0) + adv) % 2 ? kDynFrame : 0)) | kDynTexSet;
+            }
+            DF(s, dst, DF_X, e, env) = x;
+            DF(s, dst, DF_ANIM_T, e, env) = anim_t;
+            DB(s, dst, e, env) = static_cast<uint8_t>(dyn);
+            continue;
+        }
+        // --- mob: System_Mob_AI (common_systems.cpp:65-105) + System_Particles (:284-313) + animation, rate 0.2
+        float vx = DF(s, src, DF_VX, e, env);
+        float timer = DF(s, src, DF_SPAWN_T, e, env);
+        float sx[kSparks], sy[kSparks], sl[kSparks];
+#pragma unroll
+        for (int k = 0; k < kSparks; k++) {
+            sx[k] = SP(s, src, 0, e, k, env);
+            sy[k] = SP(s, src, 1, e, k, env);
+            sl[k] = SP(s, src, 2, e, k, env);
+        }
+        // both sensors of all sub-steps live inside this window (x drifts by at most 0.15 per step)
+        const TileWin win = TileWin::fetch(tiles, static_cast<int>(floorf(x - 0.66f)), static_cast<int>(floorf(y - 0.6f)));
+#pragma unroll
+        for (int ss = 0; ss < 4; ss++) {
+            if (ss >= limit) break;
+            x += vx * dt;
+            const Box wall_probe{x - 0.5f, y - 0.6f, 1.0f, 0.5f};
+            const Box floor_probe{x - 0.5f, y + 0.6f, 1.0f, 0.5f};
+            const Hit wall = collide(
+                win, wall_probe, [](int t) { return (t == kWallMid || t == kWallTop) ? kFull : kPass; }, false, 0.0f);
+            const Hit gap = collide(
+                win, floor_probe, [](int t) { return t == kEmpty ? kFull : kPass; }, false, 0.0f);
+            float nx = wall.x + 0.5f;
+            if (gap.any) nx = gap.x + 0.5f;
+            x = nx;
+            if (wall.any || gap.any) vx *= -1.0f;
+            dyn = (dyn & ~kDynFlip) | (vx > 0.0f ? kDynFlip : 0);
+
+            const Box hb{x + -0.5f, y + -0.48f, 1.0f, 0.98f};  // tilemap.cpp:89
+            if (box_hit(body[ss], hb)) hazard[ss] = true;
+
+            int dead = -1;
+#pragma unroll
+            for (int k = 0; k < kSparks; k++) {
+                sl[k] -= dt;
+                if (sl[k] <= 0.0f) dead = k;
+            }
+            timer += dt;
+            if (dead != -1 && timer >= 0.5f) {
+                timer = fmodf(timer, 0.5f);
+#pragma unroll
+                for (int k = 0; k < kSparks; k++)
+                    if (k == dead) {
+                        sl[k] = 5.0f;
+                        sx[k] = x + 0.0f;
+                        sy[k] = y + 0.34f;
+                    }
+            }
+            anim_t += dt;
+            const int adv = static_cast<int>(anim_t * 0.2f);
+            anim_t -= adv / 0.2f;
+            dyn = ((dyn & ~kDynFrame) | ((((dyn & kDynFrame) ? 1 : 0) + adv) % 2 ? kDynFrame : 0)) | kDynTexSet;
+        }
+        DF(s, dst, DF_X, e, env) = x;
+        DF(s, dst, DF_VX, e, env) = vx;
+        DF(s, dst, DF_ANIM_T, e, env) = anim_t;
+        DF(s, dst, DF_SPAWN_T, e, env) = timer;
+        DB(s, dst, e, env) = static_cast<uint8_t>(dyn);
+#pragma unroll
+        for (int k = 0; k < kSparks; k++) {
+            SP(s, dst, 0, e, k, env) = sx[k];
+            SP(s, dst, 1, e, k, env) = sy[k];
+            SP(s, dst, 2, e, k, env) = sl[k];
+        }
+    }
+}
+
 PG_D void advance(const State& s, int env, int action, float& reward_out, bool& terminated_out) {
-    const TileMap map{s.tiles + size_t(env) * (W * H)};
+    const uint8_t* tiles = s.tiles + size_t(env) * (W * H);
     const int n_ent = SI(s, I_NENT, env);
-    int flags = SI(s, I_FLAGS, env);
+    const int flags = SI(s, I_FLAGS, env);
+    const int src = (flags & kFlagBuf) ? 1 : 0;
     float ax = SF(s, F_AX, env), ay = SF(s, F_AY, env);
     float avx = SF(s, F_AVX, env), avy = SF(s, F_AVY, env);
     float phase = SF(s, F_APHASE, env);
     bool ground = (flags & kFlagGround) != 0, forward = (flags & kFlagForward) != 0;
-    float camx = SF(s, F_CAMX, env), camy = SF(s, F_CAMY, env);
+    // the coin is the last entity created before the agent (tilemap.cpp:277-287); it never moves
+    const Box coin_box{DF(s, src, DF_X, n_ent - 1, env) + -0.5f, EY(s, n_ent - 1, env) + -0.5f, 1.0f, 1.0f};
 
     const float dt = 1.0f / 4;
     const float max_jump = 1.55f, gravity = 0.2f, max_speed = 0.5f, mix = 0.2f, air_control = 0.15f;
@@ -367,137 +523,82 @@ PG_D void advance(const State& s, int env, int action, float& reward_out, bool& 
     const bool jump = (action == 2 || action == 5 || action == 8);
     const bool drop = (action == 0 || action == 3 || action == 6);
 
-    float reward = 0.0f;
-    bool terminated = false;
+    // --- 1. System_Agent::update ×4 (common_systems.cpp:121-252) minus the hazard loop, which needs the mobs
+    AgentSnap snap[4];
+    Box body[4];
+    bool lava[4], coin[4];
+#pragma unroll
     for (int ss = 0; ss < 4; ss++) {
-        // --- System_Mob_AI::update (common_systems.cpp:65-105)
-        for (int e = 0; e < n_ent; e++) {
-            const int info = EB(s, EB_INFO, e, env);
-            if ((info & 3) != kMob) continue;
-            float x = EF(s, EF_X, e, env);
-            const float y = EF(s, EF_Y, e, env);
-            float vx = EF(s, EF_VX, e, env);
-            x += vx * dt;
-            const Box wall_probe{x - 0.5f, y - 0.6f, 1.0f, 0.5f};
-            const Box floor_probe{x - 0.5f, y + 0.6f, 1.0f, 0.5f};
-            const Hit wall = collide(
-                map, wall_probe, [](int t) { return (t == kWallMid || t == kWallTop) ? kFull : kPass; }, false, 0.0f);
-            const Hit gap = collide(
-                map, floor_probe, [](int t) { return t == kEmpty ? kFull : kPass; }, false, 0.0f);
-            float nx = wall.x + 0.5f;
-            if (gap.any) nx = gap.x + 0.5f;
-            x = nx;
-            if (wall.any || gap.any) vx *= -1.0f;
-            EF(s, EF_X, e, env) = x;
-            EF(s, EF_VX, e, env) = vx;
-            EB(s, EB_INFO, e, env) = static_cast<uint8_t>((info & ~kInfoFlip) | (vx > 0.0f ? kInfoFlip : 0));
-        }
+        const float mix_x = ground ? mix : (mix * air_control);
+        avx += mix_x * (max_speed * move_x - avx) * dt;
+        if (fabsf(avx) < mix_x * max_speed * dt) avx = 0.0f;
+        if (jump && ground) avy = -max_jump;
+        avy += gravity * dt;
+        if (fabsf(avy) > max_jump) avy = (avy > 0.0f ? 1.0f : -1.0f) * max_jump;
+        ax += avx * dt;
+        ay += avy * dt;
 
-        // --- System_Agent::update (common_systems.cpp:121-252)
-        bool alive = true, got_coin = false;
-        {
-            const float mix_x = ground ? mix : (mix * air_control);
-            avx += mix_x * (max_speed * move_x - avx) * dt;
-            if (fabsf(avx) < mix_x * max_speed * dt) avx = 0.0f;
-            if (jump && ground) avy = -max_jump;
-            avy += gravity * dt;
-            if (fabsf(avy) > max_jump) avy = (avy > 0.0f ? 1.0f : -1.0f) * max_jump;
-            ax += avx * dt;
-            ay += avy * dt;
+        Box b{ax + -0.5f, ay + -1.0f, 1.0f, 1.0f};
+        const TileWin w1 = TileWin::fetch(tiles, static_cast<int>(floorf(b.x)), static_cast<int>(floorf(b.y)));
+        const Hit h = collide(
+            w1, b, [](int t) { return (t == kWallMid || t == kWallTop) ? kFull : (t == kCrate ? kOneWay : kPass); },
+            drop, avy * dt);
+        const float moved_x = h.x - b.x, moved_y = h.y - b.y;
+        ground = moved_y < 0.0f && h.any;
+        ax = h.x - -0.5f;
+        ay = h.y - -1.0f;
+        b.x = ax + -0.5f;
+        b.y = ay + -1.0f;
+        if (moved_x != 0.0f) avx = 0.0f;
+        if (ground) avy = 0.0f;
 
-            Box body{ax + -0.5f, ay + -1.0f, 1.0f, 1.0f};
-            const Hit h = collide(
-                map, body,
-                [](int t) { return (t == kWallMid || t == kWallTop) ? kFull : (t == kCrate ? kOneWay : kPass); }, drop,
-                avy * dt);
-            const float moved_x = h.x - body.x, moved_y = h.y - body.y;
-            ground = moved_y < 0.0f && h.any;
-            ax = h.x - -0.5f;
-            ay = h.y - -1.0f;
-            body.x = ax + -0.5f;
-            body.y = ay + -1.0f;
-            if (moved_x != 0.0f) avx = 0.0f;
-            if (ground) avy = 0.0f;
+        const TileWin w2 = TileWin::fetch(tiles, static_cast<int>(floorf(b.x)), static_cast<int>(floorf(b.y)));
+        const Hit lv = collide(
+            w2, b, [](int t) { return (t == kLavaMid || t == kLavaTop) ? kFull : kPass; }, false, 0.0f);
+        lava[ss] = lv.any;
+        coin[ss] = box_hit(b, coin_box);
+        body[ss] = b;
 
-            for (int e = 0; e < n_ent; e++) {  // hazards and the coin; a boolean OR, order-free (App. B)
-                const int kind = EB(s, EB_INFO, e, env) & 3;
-                const float x = EF(s, EF_X, e, env), y = EF(s, EF_Y, e, env);
-                Box hb;
-                if (kind == kMob)
-                    hb = Box{x + -0.5f, y + -0.48f, 1.0f, 0.98f};
-                else
-                    hb = Box{x + -0.5f, y + -0.5f, 1.0f, 1.0f};
-                if (box_hit(body, hb)) {
-                    if (kind == kCoin)
-                        got_coin = true;
-                    else
-                        alive = false;
-                }
-            }
-            const Hit lava = collide(
-                map, body, [](int t) { return (t == kLavaMid || t == kLavaTop) ? kFull : kPass; }, false, 0.0f);
-            if (lava.any) alive = false;
-
-            camx = ax * kUnitPx;
-            camy = (ay - 0.5f) * kUnitPx;
-            phase += 0.1f * dt;
-            phase = fmodf(phase, 1.0f);
-            if (move_x > 0.0f)
-                forward = true;
-            else if (move_x < 0.0f)
-                forward = false;
-        }
-
-        // --- System_Particles::update (common_systems.cpp:284-313) and
-        // --- System_Sprite_Render::update animation advance (common_systems.cpp:7-39)
-        for (int e = 0; e < n_ent; e++) {
-            int info = EB(s, EB_INFO, e, env);
-            const int kind = info & 3;
-            if (kind == kMob) {
-                int dead = -1;
-                for (int k = 0; k < kSparks; k++) {
-                    float life = SP(s, 2, e, k, env);
-                    life -= dt;
-                    SP(s, 2, e, k, env) = life;
-                    if (life <= 0.0f) dead = k;
-                }
-                float timer = EF(s, EF_SPAWN_T, e, env) + dt;
-                if (dead != -1 && timer >= 0.5f) {
-                    timer = fmodf(timer, 0.5f);
-                    SP(s, 2, e, dead, env) = 5.0f;
-                    SP(s, 0, e, dead, env) = EF(s, EF_X, e, env) + 0.0f;
-                    SP(s, 1, e, dead, env) = EF(s, EF_Y, e, env) + 0.34f;
-                }
-                EF(s, EF_SPAWN_T, e, env) = timer;
-            }
-            if (kind != kCoin) {
-                const float rate = (kind == kSaw) ? 1.0f : 0.2f;
-                float t = EF(s, EF_ANIM_T, e, env) + dt;
-                const int adv = static_cast<int>(t * rate);
-                t -= adv / rate;
-                const int frame = (((info & kInfoFrame) ? 1 : 0) + adv) % 2;
-                info = (info & ~kInfoFrame) | (frame ? kInfoFrame : 0) | kInfoTexSet;
-                EF(s, EF_ANIM_T, e, env) = t;
-                EB(s, EB_INFO, e, env) = static_cast<uint8_t>(info);
-            }
-        }
-        flags |= kFlagListed;
-
-        reward = got_coin * 10.0f;
-        terminated = !alive || got_coin;
-        if (terminated) break;
+        phase += 0.1f * dt;
+        phase = fmodf(phase, 1.0f);
+        if (move_x > 0.0f)
+            forward = true;
+        else if (move_x < 0.0f)
+            forward = false;
+        snap[ss] = {ax, ay, avx, avy, phase, ax * kUnitPx, (ay - 0.5f) * kUnitPx, ground, forward};
     }
 
-    SF(s, F_AX, env) = ax;
-    SF(s, F_AY, env) = ay;
-    SF(s, F_AVX, env) = avx;
-    SF(s, F_AVY, env) = avy;
-    SF(s, F_APHASE, env) = phase;
-    SF(s, F_CAMX, env) = camx;
-    SF(s, F_CAMY, env) = camy;
-    SI(s, I_FLAGS, env) = (flags & kFlagListed) | (ground ? kFlagGround : 0) | (forward ? kFlagForward : 0);
-    reward_out = reward;
-    terminated_out = terminated;
+    // --- 2./3. entities, then the first terminating sub-step decides how many sub-steps took place
+    bool hazard[4];
+    int limit = 4, last = 3;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        entity_pass(s, env, n_ent, src, limit, body, hazard);
+        last = limit - 1;
+        for (int ss = limit - 1; ss >= 0; ss--)
+            if (hazard[ss] || lava[ss] || coin[ss]) last = ss;
+        if (last + 1 == limit) break;
+        limit = last + 1;  // rare: redo from the untouched half with fewer sub-steps
+    }
+    bool alive = true, got_coin = false;
+    AgentSnap fin = snap[0];
+#pragma unroll
+    for (int ss = 0; ss < 4; ss++)
+        if (ss == last) {
+            fin = snap[ss];
+            alive = !(hazard[ss] || lava[ss]);
+            got_coin = coin[ss];
+        }
+    SF(s, F_AX, env) = fin.ax;
+    SF(s, F_AY, env) = fin.ay;
+    SF(s, F_AVX, env) = fin.avx;
+    SF(s, F_AVY, env) = fin.avy;
+    SF(s, F_APHASE, env) = fin.phase;
+    SF(s, F_CAMX, env) = fin.camx;
+    SF(s, F_CAMY, env) = fin.camy;
+    SI(s, I_FLAGS, env) =
+        kFlagListed | (fin.ground ? kFlagGround : 0) | (fin.forward ? kFlagForward : 0) | (src ? 0 : kFlagBuf);
+    reward_out = got_coin * 10.0f;        // coinrun.cpp:364, last executed sub-step only (D4)
+    terminated_out = !alive || got_coin;  // coinrun.cpp:366
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -507,6 +608,7 @@ __global__ void __launch_bounds__(64) make_kernel(State s, uint32_t seed_base, i
     const int env = blockIdx.x * 64 + threadIdx.x;
     if (env >= s.n) return;
     mt_seed(s.mt + size_t(env) * kMtWords, seed_base + static_cast<uint32_t>(env_offset + env));
+    SI(s, I_FLAGS, env) = 0;
     SI(s, I_HASH_SPRITE, env) = 1;  // empty unordered_set: one bucket, next_resize 0
     SI(s, I_HASH_SPARK, env) = 1;
     SF(s, F_CAMX, env) = 0.0f;  // Renderer::camera_position{0} (renderer.h:18)
@@ -548,6 +650,7 @@ __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actio
 
 // render_game(true) (coinrun.cpp:443-470): one wavefront per env.
 // flags bit 0: force the draw-list replay for background + tiles (fallback path; parity tests run both).
+// Higher bits are timing experiments only (tools/ablate_render.py) and change the picture.
 __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
                                                     int flags) {
     const int env = blockIdx.x;
@@ -560,6 +663,7 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
     const Camera cam{SF(s, F_CAMX, env), SF(s, F_CAMY, env), 64.0f, 64.0f, 0.3f * 64.0f / 64.0f};
     const int themes = SI(s, I_THEMES, env);
     const int sflags = SI(s, I_FLAGS, env);
+    const int buf = (sflags & kFlagBuf) ? 1 : 0;
     const int backdrop = (flags & 16) ? 9 : (themes & 0xff);  // (bit 4: timing experiment — one shared background)
     const int alien = (themes >> 8) & 0xff, ground_theme = (themes >> 16) & 0xff;
     const int n_ent = SI(s, I_NENT, env);
@@ -617,12 +721,12 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
             const int t = raw & 7;
             const int slot = t < kCrate ? t - 1 : 4 + (raw >> 4);
             const int off = __shfl(kind_base, slot < 0 ? 0 : slot);
-            if (cell < cells) L.base[r * kGrid + c] = (t == kEmpty) ? -1 : off;
+            if (cell < cells) L.base[r * kGrid + c] = (t == kEmpty) ? static_cast<int32_t>(kNoTexel) : off * 4;
         }
         __syncthreads();
-        composed = compose_rows(fb, L, atlas, bg, has_bg, cols, rows, tile_desc.y, lane);
+        composed = compose_rows(fb, L, atlas, bg, has_bg, cols, rows, tile_desc.y, lane, flags);
     }
-    if (flags & 4) composed = true;  // (bit 2: timing ablation only — no background/tiles at all)
+    if (flags & 4) composed = true;  // (bit 2: timing experiment — no background/tiles at all)
     if (!composed) {  // draw-list replay of background and tiles (tilemap.cpp:294-321)
         wave_clear(fb, lane);
         mine = bg;
@@ -661,69 +765,68 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
         }
     }
 
-    if (!(flags & 2)) {  // (bit 1: timing ablation only — skips particles, sprites and the agent)
-    {  // particles (common_systems.cpp:315-337): owners in the particle system's set order
-        const int4 d = atlas.desc[kTexSpark];
-        const int total = n_mob * kSparks;
-        for (int base = 0; base < total; base += 64) {
-            const int idx = base + lane;
+    if (!(flags & 2)) {  // (bit 1: timing experiment — skips particles, sprites and the agent)
+        {  // particles (common_systems.cpp:315-337): owners in the particle system's set order
+            const int4 d = atlas.desc[kTexSpark];
+            const int total = n_mob * kSparks;
+            for (int base = 0; base < total; base += 64) {
+                const int idx = base + lane;
+                bool has = false;
+                if (idx < total) {
+                    const int m = idx / kSparks, k = idx - m * kSparks;
+                    const int e = EB(s, EB_SPARK_ORDER, m, env);
+                    const float life = SP(s, buf, 2, e, k, env);
+                    if (!(life <= 0.0f)) {
+                        const float px = SP(s, buf, 0, e, k, env), py = SP(s, buf, 1, e, k, env);
+                        const float lr = (5.0f - life) / 5.0f;
+                        const float alpha = 0.5f * (1.0f - lr);
+                        const float scale = 0.45f * (0.4f * lr + 0.6f);
+                        const float oy = -lr * 0.17f;
+                        has = resolve_draw(cam, d.y, d.z, d.x, px * kUnitPx - 0.5f * d.y * scale,
+                                           (py + oy) * kUnitPx - 0.5f * d.z * scale, scale * kUnitPx / d.y, alpha,
+                                           false, false, mine);
+                    }
+                }
+                wave_replay(fb, atlas, mine, __ballot(has), lane);
+            }
+        }
+
+        if (sflags & kFlagListed) {  // sprites, positive z (common_systems.cpp:41-63); empty until the first update (D2)
             bool has = false;
-            if (idx < total) {
-                const int m = idx / kSparks, k = idx - m * kSparks;
-                const int e = EB(s, EB_SPARK_ORDER, m, env);
-                const float life = SP(s, 2, e, k, env);
-                if (!(life <= 0.0f)) {
-                    const float px = SP(s, 0, e, k, env), py = SP(s, 1, e, k, env);
-                    const float lr = (5.0f - life) / 5.0f;
-                    const float alpha = 0.5f * (1.0f - lr);
-                    const float scale = 0.45f * (0.4f * lr + 0.6f);
-                    const float oy = -lr * 0.17f;
-                    has = resolve_draw(cam, d.y, d.z, d.x, px * kUnitPx - 0.5f * d.y * scale,
-                                       (py + oy) * kUnitPx - 0.5f * d.z * scale, scale * kUnitPx / d.y, alpha, false,
-                                       false, mine);
+            if (lane < n_ent) {
+                const int e = EB(s, EB_DRAW_ORDER, lane, env);
+                const int dyn = DB(s, buf, e, env);
+                if (dyn & kDynTexSet) {
+                    const int tex = EB(s, EB_TEX, e, env) + ((dyn & kDynFrame) ? 1 : 0);
+                    const int4 d = atlas.desc[tex];
+                    const float scale = 1.0f * 1.0f;
+                    has = resolve_draw(cam, d.y, d.z, d.x, (DF(s, buf, DF_X, e, env) + -0.5f) * kUnitPx,
+                                       (EY(s, e, env) + -0.5f) * kUnitPx, scale * kUnitPx / d.y, 1.0f,
+                                       (dyn & kDynFlip) != 0, false, mine);
                 }
             }
             wave_replay(fb, atlas, mine, __ballot(has), lane);
         }
-    }
 
-    if (sflags & kFlagListed) {  // sprites, positive z (common_systems.cpp:41-63); empty until the first update (D2)
-        bool has = false;
-        if (lane < n_ent) {
-            const int e = EB(s, EB_DRAW_ORDER, lane, env);
-            const int info = EB(s, EB_INFO, e, env);
-            if (info & kInfoTexSet) {
-                const int tex = EB(s, EB_TEX, e, env) + ((info & kInfoFrame) ? 1 : 0);
-                const int4 d = atlas.desc[tex];
-                const float scale = 1.0f * 1.0f;
-                has = resolve_draw(cam, d.y, d.z, d.x, (EF(s, EF_X, e, env) + -0.5f) * kUnitPx,
-                                   (EF(s, EF_Y, e, env) + -0.5f) * kUnitPx, scale * kUnitPx / d.y, 1.0f,
-                                   (info & kInfoFlip) != 0, false, mine);
-            }
+        {  // agent (common_systems.cpp:254-278)
+            const float avx = SF(s, F_AVX, env);
+            const bool ground = (sflags & kFlagGround) != 0;
+            int tex;
+            if (fabsf(avx) < 0.01f && ground)
+                tex = kTexStand + alien;
+            else if (!ground)
+                tex = kTexJump + alien;
+            else if (SF(s, F_APHASE, env) > 0.5f)
+                tex = kTexWalk2 + alien;
+            else
+                tex = kTexWalk1 + alien;
+            const int4 d = atlas.desc[tex];
+            const float px = SF(s, F_AX, env) - 0.5f, py = SF(s, F_AY, env) - 2.0f;
+            const bool ok = resolve_draw(cam, d.y, d.z, d.x, px * kUnitPx, py * kUnitPx, kUnitPx / d.y, 1.0f,
+                                         (sflags & kFlagForward) == 0, false, mine);
+            wave_replay(fb, atlas, mine, ok ? 1ull : 0ull, lane);
         }
-        wave_replay(fb, atlas, mine, __ballot(has), lane);
     }
-
-    {  // agent (common_systems.cpp:254-278)
-        const float avx = SF(s, F_AVX, env);
-        const bool ground = (sflags & kFlagGround) != 0;
-        int tex;
-        if (fabsf(avx) < 0.01f && ground)
-            tex = kTexStand + alien;
-        else if (!ground)
-            tex = kTexJump + alien;
-        else if (SF(s, F_APHASE, env) > 0.5f)
-            tex = kTexWalk2 + alien;
-        else
-            tex = kTexWalk1 + alien;
-        const int4 d = atlas.desc[tex];
-        const float px = SF(s, F_AX, env) - 0.5f, py = SF(s, F_AY, env) - 2.0f;
-        const bool ok = resolve_draw(cam, d.y, d.z, d.x, px * kUnitPx, py * kUnitPx, kUnitPx / d.y, 1.0f,
-                                     (sflags & kFlagForward) == 0, false, mine);
-        wave_replay(fb, atlas, mine, ok ? 1ull : 0ull, lane);
-    }
-
-    }  // ablation
     if (!(flags & 8)) wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane);
 }
 
@@ -760,33 +863,17 @@ class CoinrunGame final : public Game {
         for (auto pose : {"_stand.png", "_jump.png", "_walk1.png", "_walk2.png"})
             for (auto a : aliens) v.push_back(std::string("kenney/Players/128x256/") + a + "/alien" + a + pose);
         v.push_back("misc_assets/iconCircle_white.png");
-        static const char* backdrops[49] = {
-            "platform_backgrounds/alien_bg.png", "platform_backgrounds/another_world_bg.png",
-            "platform_backgrounds/back_cave.png", "platform_backgrounds/caverns.png",
-            "platform_backgrounds/cyberpunk_bg.png", "platform_backgrounds/parallax_forest.png",
-            "platform_backgrounds/scifi_bg.png", "platform_backgrounds/scifi2_bg.png",
-            "platform_backgrounds/living_tissue_bg.png", "platform_backgrounds/airadventurelevel1.png",
-            "platform_backgrounds/airadventurelevel2.png", "platform_backgrounds/airadventurelevel3.png",
-            "platform_backgrounds/airadventurelevel4.png", "platform_backgrounds/cave_background.png",
-            "platform_backgrounds/blue_desert.png", "platform_backgrounds/blue_grass.png",
-            "platform_backgrounds/blue_land.png", "platform_backgrounds/blue_shroom.png",
-            "platform_backgrounds/colored_desert.png", "platform_backgrounds/colored_grass.png",
-            "platform_backgrounds/colored_land.png", "platform_backgrounds/colored_shroom.png",
-            "platform_backgrounds/landscape1.png", "platform_backgrounds/landscape2.png",
-            "platform_backgrounds/landscape3.png", "platform_backgrounds/landscape4.png",
-            "platform_backgrounds/battleback1.png", "platform_backgrounds/battleback2.png",
-            "platform_backgrounds/battleback3.png", "platform_backgrounds/battleback4.png",
-            "platform_backgrounds/battleback5.png", "platform_backgrounds/battleback6.png",
-            "platform_backgrounds/battleback7.png", "platform_backgrounds/battleback8.png",
-            "platform_backgrounds/battleback9.png", "platform_backgrounds/battleback10.png",
-            "platform_backgrounds/sunrise.png", "platform_backgrounds_2/beach1.png",
-            "platform_backgrounds_2/beach2.png", "platform_backgrounds_2/beach3.png",
-            "platform_backgrounds_2/beach4.png", "platform_backgrounds_2/fantasy1.png",
-            "platform_backgrounds_2/fantasy2.png", "platform_backgrounds_2/fantasy3.png",
-            "platform_backgrounds_2/fantasy4.png", "platform_backgrounds_2/candy1.png",
-            "platform_backgrounds_2/candy2.png", "platform_backgrounds_2/candy3.png",
-            "platform_backgrounds_2/candy4.png"};
-        for (auto b : backdrops) v.push_back(b);
+        for (const char* b : {"alien_bg", "another_world_bg", "back_cave", "caverns", "cyberpunk_bg", "parallax_forest",
+                              "scifi_bg", "scifi2_bg", "living_tissue_bg", "airadventurelevel1", "airadventurelevel2",
+                              "airadventurelevel3", "airadventurelevel4", "cave_background", "blue_desert",
+                              "blue_grass", "blue_land", "blue_shroom", "colored_desert", "colored_grass",
+                              "colored_land", "colored_shroom", "landscape1", "landscape2", "landscape3",
+                              "landscape4", "battleback1", "battleback2", "battleback3", "battleback4", "battleback5",
+                              "battleback6", "battleback7", "battleback8", "battleback9", "battleback10", "sunrise"})
+            v.push_back(std::string("platform_backgrounds/") + b + ".png");
+        for (const char* fam : {"beach", "fantasy", "candy"})
+            for (int k = 1; k <= 4; k++)
+                v.push_back(std::string("platform_backgrounds_2/") + fam + std::to_string(k) + ".png");
         return v;
     }
 
@@ -798,32 +885,43 @@ class CoinrunGame final : public Game {
     }
 
     static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
-    size_t state_bytes(int n) const override {
-        size_t total = 0;
-        total += align256(size_t(n) * kMtWords * 4);
-        total += align256(size_t(n) * W * H);
-        total += align256(size_t(F_COUNT) * n * 4);
-        total += align256(size_t(I_COUNT) * n * 4);
-        total += align256(size_t(EF_COUNT) * kMaxEnt * n * 4);
-        total += align256(size_t(EB_COUNT) * kMaxEnt * n);
-        total += align256(size_t(3) * kMaxEnt * kSparks * n * 4);
-        return total;
+    struct Layout {
+        size_t mt, tiles, f, i, ey, eb, df, db, spark, total;
+    };
+    static Layout layout(int n) {
+        Layout l{};
+        size_t off = 0;
+        auto take = [&](size_t bytes) {
+            size_t at = off;
+            off += align256(bytes);
+            return at;
+        };
+        l.mt = take(size_t(n) * kMtWords * 4);
+        l.tiles = take(size_t(n) * W * H);
+        l.f = take(size_t(F_COUNT) * n * 4);
+        l.i = take(size_t(I_COUNT) * n * 4);
+        l.ey = take(size_t(kMaxEnt) * n * 4);
+        l.eb = take(size_t(EB_COUNT) * kMaxEnt * n);
+        l.df = take(size_t(2) * DF_COUNT * kMaxEnt * n * 4);
+        l.db = take(size_t(2) * kMaxEnt * n);
+        l.spark = take(size_t(2) * 3 * kMaxEnt * kSparks * n * 4);
+        l.total = off;
+        return l;
     }
+    size_t state_bytes(int n) const override { return layout(n).total; }
     void bind(void* d_state, int n, AtlasView atlas) override {
         uint8_t* p = static_cast<uint8_t*>(d_state);
-        auto take = [&](size_t bytes) {
-            uint8_t* q = p;
-            p += align256(bytes);
-            return q;
-        };
+        const Layout l = layout(n);
         s_.n = n;
-        s_.mt = reinterpret_cast<uint32_t*>(take(size_t(n) * kMtWords * 4));
-        s_.tiles = take(size_t(n) * W * H);
-        s_.f = reinterpret_cast<float*>(take(size_t(F_COUNT) * n * 4));
-        s_.i = reinterpret_cast<int32_t*>(take(size_t(I_COUNT) * n * 4));
-        s_.ef = reinterpret_cast<float*>(take(size_t(EF_COUNT) * kMaxEnt * n * 4));
-        s_.eb = take(size_t(EB_COUNT) * kMaxEnt * n);
-        s_.spark = reinterpret_cast<float*>(take(size_t(3) * kMaxEnt * kSparks * n * 4));
+        s_.mt = reinterpret_cast<uint32_t*>(p + l.mt);
+        s_.tiles = p + l.tiles;
+        s_.f = reinterpret_cast<float*>(p + l.f);
+        s_.i = reinterpret_cast<int32_t*>(p + l.i);
+        s_.ey = reinterpret_cast<float*>(p + l.ey);
+        s_.eb = p + l.eb;
+        s_.df = reinterpret_cast<float*>(p + l.df);
+        s_.db = p + l.db;
+        s_.spark = reinterpret_cast<float*>(p + l.spark);
         atlas_ = atlas;
     }
     int blocks() const { return (s_.n + 63) / 64; }
@@ -845,28 +943,27 @@ class CoinrunGame final : public Game {
     // Same layout as oracle/pgo_coinrun.cpp Coinrun::dump_state.
     int dump_state(hipStream_t st, int env, float* out, int cap) override {
         hipStreamSynchronize(st);
-        auto f = [&](int field) {
+        auto rd_f = [&](const float* base, size_t idx) {
             float v;
-            hipMemcpy(&v, s_.f + size_t(field) * s_.n + env, 4, hipMemcpyDeviceToHost);
+            hipMemcpy(&v, base + idx, 4, hipMemcpyDeviceToHost);
             return v;
         };
-        auto iv = [&](int field) {
+        auto rd_i = [&](size_t idx) {
             int32_t v;
-            hipMemcpy(&v, s_.i + size_t(field) * s_.n + env, 4, hipMemcpyDeviceToHost);
+            hipMemcpy(&v, s_.i + idx, 4, hipMemcpyDeviceToHost);
             return v;
         };
-        auto ef = [&](int field, int e) {
-            float v;
-            hipMemcpy(&v, s_.ef + (size_t(field) * kMaxEnt + e) * s_.n + env, 4, hipMemcpyDeviceToHost);
-            return v;
-        };
-        auto eb = [&](int field, int e) {
+        auto rd_b = [&](const uint8_t* base, size_t idx) {
             uint8_t v;
-            hipMemcpy(&v, s_.eb + (size_t(field) * kMaxEnt + e) * s_.n + env, 1, hipMemcpyDeviceToHost);
+            hipMemcpy(&v, base + idx, 1, hipMemcpyDeviceToHost);
             return v;
         };
+        const size_t n = s_.n;
+        auto f = [&](int field) { return rd_f(s_.f, size_t(field) * n + env); };
+        const int flags = rd_i(size_t(I_FLAGS) * n + env), themes = rd_i(size_t(I_THEMES) * n + env);
+        const int n_ent = rd_i(size_t(I_NENT) * n + env);
+        const int buf = (flags & kFlagBuf) ? 1 : 0;
         std::vector<float> v;
-        const int flags = iv(I_FLAGS), themes = iv(I_THEMES), n_ent = iv(I_NENT);
         v.push_back(f(F_AX));
         v.push_back(f(F_AY));
         v.push_back(f(F_AVX));
@@ -882,12 +979,14 @@ class CoinrunGame final : public Game {
         v.push_back(static_cast<float>((themes >> 16) & 0xff));
         v.push_back(static_cast<float>(n_ent));
         for (int e = 0; e < n_ent; e++) {
-            const int info = eb(EB_INFO, e);
-            v.push_back(ef(EF_X, e));
-            v.push_back(ef(EF_Y, e));
-            v.push_back((info & 3) == kMob ? ef(EF_VX, e) : 0.0f);
-            v.push_back((info & kInfoFrame) ? 1.0f : 0.0f);
-            v.push_back(ef(EF_ANIM_T, e));
+            const int kind = rd_b(s_.eb, (size_t(EB_KIND) * kMaxEnt + e) * n + env);
+            const int dyn = rd_b(s_.db, (size_t(buf) * kMaxEnt + e) * n + env);
+            auto df = [&](int field) { return rd_f(s_.df, ((size_t(buf) * DF_COUNT + field) * kMaxEnt + e) * n + env); };
+            v.push_back(df(DF_X));
+            v.push_back(rd_f(s_.ey, size_t(e) * n + env));
+            v.push_back(kind == kMob ? df(DF_VX) : 0.0f);
+            v.push_back((dyn & kDynFrame) ? 1.0f : 0.0f);
+            v.push_back(kind == kCoin ? 0.0f : df(DF_ANIM_T));
         }
         const int m = cap < static_cast<int>(v.size()) ? cap : static_cast<int>(v.size());
         for (int k = 0; k < m; k++) out[k] = v[k];

@@ -58,6 +58,10 @@ bool Atlas::load(const std::string& root, const std::vector<std::string>& names,
 }
 
 bool Atlas::upload(std::string& err) {
+    if (texels_.size() * 4 >= 0x40000000ull) {
+        err = "atlas exceeds 1 GiB (pg_render.h kNoTexel)";
+        return false;
+    }
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_texels_), texels_.size() * 4);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_desc_), desc_.size() * sizeof(int4));
     if (e == hipSuccess) e = hipMemcpy(d_texels_, texels_.data(), texels_.size() * 4, hipMemcpyHostToDevice);

@@ -286,10 +286,11 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
         compose_spans(L, cam, x0, y0, cols, rows, wall.y, wall.z, kUnitPx / wall.y, lane);
         for (int cell = lane; cell < cells; cell += 64) {
             const int r = cell / cols, c = cell - r * cols;
-            L.base[r * kGrid + c] = tile_at(tiles, x0 + c, H - 1 - (y0 + r)) == kOpen ? -1 : wall.x;
+            L.base[r * kGrid + c] =
+                tile_at(tiles, x0 + c, H - 1 - (y0 + r)) == kOpen ? static_cast<int32_t>(kNoTexel) : wall.x * 4;
         }
         __syncthreads();
-        composed = compose_rows(fb, L, atlas, bg, has_bg, cols, rows, wall.y, lane);
+        composed = compose_rows(fb, L, atlas, bg, has_bg, cols, rows, wall.y, lane, flags);
     }
     if (!composed) {  // draw-list replay (tilemap.cpp:111-133)
         wave_clear(fb, lane);

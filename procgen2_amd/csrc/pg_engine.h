@@ -19,6 +19,7 @@ struct AtlasView {
     const uint32_t* texels;
     const int4* desc;
     int count;
+    uint32_t texel_bytes;  // size of `texels` in bytes (< 1 GiB: pg_render.h kNoTexel)
 };
 
 class Atlas {
@@ -27,7 +28,9 @@ class Atlas {
     // names are reference asset paths relative to the asset root ("kenney/Items/coinGold.png").
     bool load(const std::string& root, const std::vector<std::string>& names, std::string& err);
     bool upload(std::string& err);
-    AtlasView view() const { return {d_texels_, d_desc_, static_cast<int>(desc_.size())}; }
+    AtlasView view() const {
+        return {d_texels_, d_desc_, static_cast<int>(desc_.size()), static_cast<uint32_t>(texels_.size() * 4)};
+    }
     size_t texel_bytes() const { return texels_.size() * 4; }
     std::vector<std::pair<int, int>> sizes() const {
         std::vector<std::pair<int, int>> v;

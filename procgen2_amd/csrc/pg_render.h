@@ -169,99 +169,112 @@ PG_D void compose_spans(ComposeLds<GRID>& L, const Camera& cam, int x0, int y0, 
     }
 }
 
+// "No texel here" marker for the composer's byte offsets: adding it to any valid offset lands beyond the
+// atlas (which must stay below kNoTexel bytes — checked at make time), so the buffer load's hardware range
+// check returns 0 = alpha 0 = pixel untouched.  Two markers added together still do not wrap 32 bits.
+constexpr uint32_t kNoTexel = 0x40000000u;
+
 // Background + tile layer in one pass.  Preconditions (set up by the game's render kernel, then a barrier):
-//   compose_spans() has run; L.base[r * GRID + c] = texel offset of the texture of grid cell (x0+c, y0+r) or -1;
-//   all tile textures are tw texels wide; bg / has_bg: the resolved background draw (wave-uniform).
+//   compose_spans() has run; L.base[r * GRID + c] = BYTE offset of the texture of grid cell (x0+c, y0+r) in the
+//   atlas, or kNoTexel; all tile textures are tw texels wide; bg / has_bg: the resolved background draw
+//   (wave-uniform).
 // Writes every pixel of fb (black where nothing is drawn).  Returns false — having written nothing — when the
 // layer does not fit the two-candidate scheme (caller falls back to wave_replay).
 template <int GRID>
 PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView& atlas, const Blit& bg, bool has_bg,
-                       int cols, int rows, int tw, int lane) {
+                       int cols, int rows, int tw, int lane, int ablate = 0) {
+
     // lane as pixel column: covering grid columns; lane as pixel row: covering grid rows.
     int ca, cb, ua, ub, ra, rb, va, vb;
     bool fits = covering_spans(L.col, cols, lane, ca, cb, ua, ub);
     fits = covering_spans(L.row, rows, lane, ra, rb, va, vb) && fits;
     if (__ballot(!fits)) return false;
 
-    // background sampling coordinates: column (this lane) and row (lane = row index)
-    const uint32_t* texels = atlas.texels;
-    int bg_u = -1, bg_v = -1;
+    // All texel reads go through one buffer descriptor over the atlas: 32-bit byte offsets, and out-of-range
+    // (= "no candidate") reads return 0 without a branch.
+    // (`ablate` bits 5/6 are timing experiments: a descriptor with zero records drops every load through it.)
+    const __amdgpu_buffer_rsrc_t bg_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t*>(atlas.texels), 0, (ablate & 32) ? 0 : static_cast<int>(atlas.texel_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t atlas_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t*>(atlas.texels), 0, (ablate & 64) ? 0 : static_cast<int>(atlas.texel_bytes), 0x00020000);
+
+    // background: per-lane column byte offset, per-row (lane = row index) row byte offset
+    uint32_t bg_col = kNoTexel, bg_row = kNoTexel;
     if (has_bg) {
         const bool fh = (bg.flip_mod & kFlipH) != 0, fv = (bg.flip_mod & kFlipV) != 0;
         if (lane >= bg.dx && lane < bg.dx + bg.dw) {
             int i = lane - bg.dx;
             if (fh) i = bg.dw - 1 - i;
-            bg_u = sample_index(bg.sx, bg.sw, i, bg.dw);
+            bg_col = static_cast<uint32_t>(bg.tex_off + sample_index(bg.sx, bg.sw, i, bg.dw)) * 4u;
         }
         if (lane >= bg.dy && lane < bg.dy + bg.dh) {
             int j = lane - bg.dy;
             if (fv) j = bg.dh - 1 - j;
-            bg_v = sample_index(bg.sy, bg.sh, j, bg.dh);
+            bg_row = static_cast<uint32_t>(sample_index(bg.sy, bg.sh, j, bg.dh) * bg.tex_w) * 4u;
         }
     }
     const int bg_mod = has_bg ? (bg.flip_mod & 0xff) : 255;
-    const int bg_off = has_bg ? bg.tex_off : 0, bg_w = has_bg ? bg.tex_w : 0;
-    // per-lane constants of the row loop
+    // tile layer: per-lane column byte offsets and LDS column indices; per-row row byte offsets and LDS row bases
+    const uint32_t col_a = ca >= 0 ? static_cast<uint32_t>(ua) * 4u : kNoTexel;
+    const uint32_t col_b = cb >= 0 ? static_cast<uint32_t>(ub) * 4u : kNoTexel;
     const int cia = ca >= 0 ? ca : 0, cib = cb >= 0 ? cb : 0;
-    const bool has_a = ca >= 0, has_b = cb >= 0, has_bgu = bg_u >= 0;
+    const uint32_t row_a = ra >= 0 ? static_cast<uint32_t>(va * tw) * 4u : kNoTexel;
+    const uint32_t row_b = rb >= 0 ? static_cast<uint32_t>(vb * tw) * 4u : kNoTexel;
+    const int ria = (ra >= 0 ? ra : 0) * GRID, rib = (rb >= 0 ? rb : 0) * GRID;
+    const unsigned long long second_row = __ballot(rb >= 0);  // bit py: pixel row py is covered by two grid rows
 
-    // Rows in batches: all texel gathers of a batch are issued before any blend (branch-free addresses; a
-    // candidate that does not exist reads texel 0 and is zeroed, i.e. alpha 0), so a batch costs one memory
-    // round trip instead of up to five per row.
-    constexpr int kBatch = 4;
+    // Rows in batches: every texel gather of a batch is issued before any blend, so a batch costs one memory
+    // round trip.  Candidates in draw order: background, (row a, col a), (row a, col b), (row b, col a), (row b, col b).
+#ifndef PG_BATCH
+#define PG_BATCH 8
+#endif
+    constexpr int kBatch = PG_BATCH;
     for (int py0 = 0; py0 < kObsH; py0 += kBatch) {
         uint32_t t[kBatch][5];
-        bool second_row[kBatch];
 #pragma unroll
         for (int k = 0; k < kBatch; k++) {
             const int py = py0 + k;
-            const int r_a = __builtin_amdgcn_readlane(ra, py), r_b = __builtin_amdgcn_readlane(rb, py);
-            const int v_a = __builtin_amdgcn_readlane(va, py), v_b = __builtin_amdgcn_readlane(vb, py);
-            const int bv = __builtin_amdgcn_readlane(bg_v, py);
-            {
-                const bool ok = has_bgu && bv >= 0;
-                const uint32_t x = texels[ok ? bg_off + bv * bg_w + bg_u : 0];
-                t[k][0] = ok ? x : 0u;
-            }
-            {
-                const int32_t* br = L.base + (r_a >= 0 ? r_a : 0) * GRID;
-                const int base_a = br[cia], base_b = br[cib];
-                const bool ok_a = r_a >= 0 && has_a && base_a >= 0;
-                const bool ok_b = r_a >= 0 && has_b && base_b >= 0;
-                const uint32_t xa = texels[ok_a ? base_a + v_a * tw + ua : 0];
-                const uint32_t xb = texels[ok_b ? base_b + v_a * tw + ub : 0];
-                t[k][1] = ok_a ? xa : 0u;
-                t[k][2] = ok_b ? xb : 0u;
-            }
-            second_row[k] = r_b >= 0;  // wave-uniform
-            if (second_row[k]) {
-                const int32_t* br = L.base + r_b * GRID;
-                const int base_a = br[cia], base_b = br[cib];
-                const bool ok_a = has_a && base_a >= 0;
-                const bool ok_b = has_b && base_b >= 0;
-                const uint32_t xa = texels[ok_a ? base_a + v_b * tw + ua : 0];
-                const uint32_t xb = texels[ok_b ? base_b + v_b * tw + ub : 0];
-                t[k][3] = ok_a ? xa : 0u;
-                t[k][4] = ok_b ? xb : 0u;
+            const uint32_t s_bg = __builtin_amdgcn_readlane(bg_row, py);
+            const uint32_t s_a = __builtin_amdgcn_readlane(row_a, py);
+            const int l_a = __builtin_amdgcn_readlane(ria, py);
+            t[k][0] = __builtin_amdgcn_raw_buffer_load_b32(bg_rsrc, bg_col, s_bg, 0);
+            t[k][1] = __builtin_amdgcn_raw_buffer_load_b32(atlas_rsrc, static_cast<uint32_t>(L.base[l_a + cia]) + col_a, s_a, 0);
+            t[k][2] = __builtin_amdgcn_raw_buffer_load_b32(atlas_rsrc, static_cast<uint32_t>(L.base[l_a + cib]) + col_b, s_a, 0);
+            if ((second_row >> py) & 1ull) {
+                const uint32_t s_b = __builtin_amdgcn_readlane(row_b, py);
+                const int l_b = __builtin_amdgcn_readlane(rib, py);
+                t[k][3] = __builtin_amdgcn_raw_buffer_load_b32(atlas_rsrc, static_cast<uint32_t>(L.base[l_b + cia]) + col_a, s_b, 0);
+                t[k][4] = __builtin_amdgcn_raw_buffer_load_b32(atlas_rsrc, static_cast<uint32_t>(L.base[l_b + cib]) + col_b, s_b, 0);
             } else {
                 t[k][3] = t[k][4] = 0u;
             }
         }
+        // Is any fetched texel translucent (alpha not in {0, 255})?  (a + 1) & 0xFE is zero exactly for 0 and 255.
+        uint32_t translucent = 0;
 #pragma unroll
-        for (int k = 0; k < kBatch; k++) {
-            uint32_t pix = 0;
-            {
+        for (int k = 0; k < kBatch; k++)
+#pragma unroll
+            for (int j = 0; j < 5; j++) translucent |= ((t[k][j] >> 24) + 1u) & 0xFEu;
+        if (__ballot(translucent != 0) == 0 && bg_mod == 255) {
+            // Opaque-or-absent everywhere in the batch: OVER is "last drawn wins" (what S4 yields for a = 0 / 255).
+#pragma unroll
+            for (int k = 0; k < kBatch; k++) {
+                uint32_t pix = 0;
+#pragma unroll
+                for (int j = 0; j < 5; j++) pix = (t[k][j] >> 24) ? t[k][j] : pix;
+                fb[(py0 + k) * kObsW + lane] = pix & 0x00ffffffu;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kBatch; k++) {
+                uint32_t pix = 0;
                 int a = static_cast<int>(t[k][0] >> 24);
                 if (bg_mod != 255) a = static_cast<int>(div255(static_cast<uint32_t>(a * bg_mod)));
-                pix = over(pix, t[k][0], a);
+                pix = blend_px(pix, t[k][0], a);
+#pragma unroll
+                for (int j = 1; j < 5; j++) pix = blend_px(pix, t[k][j], static_cast<int>(t[k][j] >> 24));
+                fb[(py0 + k) * kObsW + lane] = pix;
             }
-            pix = over(pix, t[k][1], static_cast<int>(t[k][1] >> 24));
-            pix = over(pix, t[k][2], static_cast<int>(t[k][2] >> 24));
-            if (second_row[k]) {
-                pix = over(pix, t[k][3], static_cast<int>(t[k][3] >> 24));
-                pix = over(pix, t[k][4], static_cast<int>(t[k][4] >> 24));
-            }
-            fb[(py0 + k) * kObsW + lane] = pix;
         }
     }
     __syncthreads();

@@ -1,7 +1,7 @@
 import sys
 sys.path.insert(0,'tests')
 from engine_util import EngineVec
-for flags,name in ((0,'full'),(16,'one shared bg'),(2,'no sprites'),(4,'no bg/tiles'),(14,'nothing')):
+for flags,name in ((0,'full'),(32,'no bg loads'),(64,'no tile loads'),(96,'no loads'),(2,'no sprites'),(4,'no bg/tiles'),(14,'nothing')):
     e=EngineVec('coinrun',65536,seed_base=1); e.reset(); e.timed(40)
     e.set_debug(flags)
     tot,ren=e.timed(64)
