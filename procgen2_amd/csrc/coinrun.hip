@@ -14,15 +14,18 @@
 // reference's std::unordered_set-based systems is recomputed at reset with pg_order.h and stored as two
 // small permutations (sprite draw order, particle-owner order).
 //
-// The logic kernel is latency-bound (one wave per SIMD at 65 536 envs), so a step is organised to expose as
-// few dependent memory round trips as possible while producing the reference's sub-step interleaving exactly:
-//   1. the agent's four sub-steps first — they depend on tiles only — keeping a snapshot per sub-step;
-//   2. ONE pass over the entities simulating all sub-steps of each (mob walk + particles + animation) with its
-//      state in registers, testing its box against the agent's box of the same sub-step; tile lookups of a
-//      whole collide() come from a 4×4 window fetched in one go and packed 3 bits per cell into a 64-bit word;
-//      results go to the *other* half of a double-buffered entity table;
-//   3. the first sub-step that terminates (hazard, lava, coin) decides how many sub-steps really happened; in
-//      the rare case that is fewer than four, pass 2 is redone from the untouched half with that limit.
+// One lane per env gives only 1 024 waves at 65 536 envs (one per SIMD), so the step is cut into three launches
+// that expose more parallelism and few dependent memory round trips, while producing the reference's sub-step
+// interleaving exactly:
+//   A. agent_kernel (lane = env): the auto-reset, or the agent's four sub-steps — they depend on tiles only —
+//      leaving a snapshot per sub-step in a scratch table;
+//   B. entity_kernel (lane = env, blockIdx.y = entity slot): every entity simulates all its sub-steps (mob walk +
+//      particles + animation) with its state in registers and tests its box against the agent's box of the
+//      same sub-step; tile lookups of a whole collide() come from a 4×4 window fetched in one go and packed
+//      3 bits per cell into a 64-bit word; results go to the *other* half of a double-buffered entity table;
+//   C. resolve_kernel (lane = env): the first sub-step that terminates (hazard, lava, coin) decides how many
+//      sub-steps really happened; in the rare case that is fewer than four, that env's entities are redone from
+//      the untouched half with that limit.  Writes reward / done and commits the agent.
 #include "pg_engine.h"
 #include "pg_geom.h"
 #include "pg_order.h"
@@ -82,7 +85,14 @@ struct State {
     float* df;       // [2][DF_COUNT][kMaxEnt][n]         double-buffered
     uint8_t* db;     // [2][kMaxEnt][n]
     float* spark;    // [2][3][kMaxEnt][kSparks][n]       x, y, life
+    float* scratch;  // [SC_COUNT][n]                     hand-off between the three logic kernels of a step
 };
+
+// scratch rows: the agent after each of the 4 sub-steps, then one word of flags
+enum { SC_AX = 0, SC_AY = 4, SC_AVX = 8, SC_AVY = 12, SC_PHASE = 16, SC_BITS = 20, SC_HAZARD = 21, SC_COUNT = 22 };
+// SC_BITS (int): per sub-step ss: ground 1<<ss, forward 1<<(4+ss), lava 1<<(8+ss), coin 1<<(12+ss); bit 31: this env
+// stepped (as opposed to: performed its auto-reset) in the current vector step.
+// SC_HAZARD (int): bit ss set by entity_kernel when a hazard overlaps the agent in sub-step ss.
 
 PG_D float& SF(const State& s, int field, int env) { return s.f[size_t(field) * s.n + env]; }
 PG_D int32_t& SI(const State& s, int field, int env) { return s.i[size_t(field) * s.n + env]; }
@@ -92,6 +102,10 @@ PG_D float& DF(const State& s, int buf, int field, int e, int env) {
     return s.df[((size_t(buf) * DF_COUNT + field) * kMaxEnt + e) * s.n + env];
 }
 PG_D uint8_t& DB(const State& s, int buf, int e, int env) { return s.db[(size_t(buf) * kMaxEnt + e) * s.n + env]; }
+PG_D float& SC(const State& s, int row, int env) { return s.scratch[size_t(row) * s.n + env]; }
+PG_D int32_t& SCI(const State& s, int row, int env) {
+    return reinterpret_cast<int32_t*>(s.scratch)[size_t(row) * s.n + env];
+}
 PG_D float& SP(const State& s, int buf, int comp, int e, int k, int env) {
     return s.spark[(((size_t(buf) * 3 + comp) * kMaxEnt + e) * kSparks + k) * s.n + env];
 }
@@ -401,110 +415,111 @@ struct AgentSnap {  // agent + camera after one sub-step
     bool ground, forward;
 };
 
-// One pass over the entities, `limit` sub-steps each, reading half `src` and writing half `1 - src` of the
-// dynamic table.  body[ss] = the agent's box after its sub-step ss; hazard[ss] accumulates "some hazard
-// overlaps the agent in sub-step ss" (a boolean OR, so the reference's set order is irrelevant — App. B).
-PG_D void entity_pass(const State& s, int env, int n_ent, int src, int limit, const Box (&body)[4], bool (&hazard)[4]) {
+// One entity, `limit` sub-steps, reading half `src` and writing half `1 - src` of the dynamic table.
+// body_x/body_y[ss] = the agent's box origin after its sub-step ss.  Returns a bit per sub-step in which this
+// entity, a hazard, overlaps the agent (the reference ORs over its hazard set, so set order is irrelevant — App. B).
+PG_D int entity_step(const State& s, int env, int e, int src, int limit, const float (&body_x)[4],
+                     const float (&body_y)[4]) {
     const uint8_t* tiles = s.tiles + size_t(env) * (W * H);
     const int dst = 1 - src;
     const float dt = 1.0f / 4;
-    for (int ss = 0; ss < 4; ss++) hazard[ss] = false;
-    for (int e = 0; e < n_ent; e++) {
-        const int kind = EB(s, EB_KIND, e, env);
-        if (kind == kCoin) {  // no dynamic state beyond the texture flag
-            DF(s, dst, DF_X, e, env) = DF(s, src, DF_X, e, env);
-            DB(s, dst, e, env) = DB(s, src, e, env);
-            continue;
-        }
-        float x = DF(s, src, DF_X, e, env);
-        const float y = EY(s, e, env);
-        float anim_t = DF(s, src, DF_ANIM_T, e, env);
-        int dyn = DB(s, src, e, env);
-        if (kind == kSaw) {
-            const Box hb{x + -0.5f, y + -0.5f, 1.0f, 1.0f};  // tilemap.cpp:66
-#pragma unroll
-            for (int ss = 0; ss < 4; ss++) {
-                if (ss >= limit) break;
-                if (box_hit(body[ss], hb)) hazard[ss] = true;
-                // System_Sprite_Render::update (common_systems.cpp:14-29), rate 1.0 (tilemap.cpp:60)
-                anim_t += dt;
-                const int adv = static_cast<int>(anim_t * 1.0f);
-                anim_t -= adv / 1.0f;
-                dyn = ((dyn & ~kDynFrame) | ((((dyn & kDynFrame) ? 1 : 0) + adv) % 2 ? kDynFrame : 0)) | kDynTexSet;
-            }
-            DF(s, dst, DF_X, e, env) = x;
-            DF(s, dst, DF_ANIM_T, e, env) = anim_t;
-            DB(s, dst, e, env) = static_cast<uint8_t>(dyn);
-            continue;
-        }
-        // --- mob: System_Mob_AI (common_systems.cpp:65-105) + System_Particles (:284-313) + animation, rate 0.2
-        float vx = DF(s, src, DF_VX, e, env);
-        float timer = DF(s, src, DF_SPAWN_T, e, env);
-        float sx[kSparks], sy[kSparks], sl[kSparks];
-#pragma unroll
-        for (int k = 0; k < kSparks; k++) {
-            sx[k] = SP(s, src, 0, e, k, env);
-            sy[k] = SP(s, src, 1, e, k, env);
-            sl[k] = SP(s, src, 2, e, k, env);
-        }
-        // both sensors of all sub-steps live inside this window (x drifts by at most 0.15 per step)
-        const TileWin win = TileWin::fetch(tiles, static_cast<int>(floorf(x - 0.66f)), static_cast<int>(floorf(y - 0.6f)));
+    int hits = 0;
+    const int kind = EB(s, EB_KIND, e, env);
+    if (kind == kCoin) {  // no dynamic state beyond the texture flag
+        DF(s, dst, DF_X, e, env) = DF(s, src, DF_X, e, env);
+        DB(s, dst, e, env) = DB(s, src, e, env);
+        return 0;
+    }
+    float x = DF(s, src, DF_X, e, env);
+    const float y = EY(s, e, env);
+    float anim_t = DF(s, src, DF_ANIM_T, e, env);
+    int dyn = DB(s, src, e, env);
+    if (kind == kSaw) {
+        const Box hb{x + -0.5f, y + -0.5f, 1.0f, 1.0f};  // tilemap.cpp:66
 #pragma unroll
         for (int ss = 0; ss < 4; ss++) {
             if (ss >= limit) break;
-            x += vx * dt;
-            const Box wall_probe{x - 0.5f, y - 0.6f, 1.0f, 0.5f};
-            const Box floor_probe{x - 0.5f, y + 0.6f, 1.0f, 0.5f};
-            const Hit wall = collide(
-                win, wall_probe, [](int t) { return (t == kWallMid || t == kWallTop) ? kFull : kPass; }, false, 0.0f);
-            const Hit gap = collide(
-                win, floor_probe, [](int t) { return t == kEmpty ? kFull : kPass; }, false, 0.0f);
-            float nx = wall.x + 0.5f;
-            if (gap.any) nx = gap.x + 0.5f;
-            x = nx;
-            if (wall.any || gap.any) vx *= -1.0f;
-            dyn = (dyn & ~kDynFlip) | (vx > 0.0f ? kDynFlip : 0);
-
-            const Box hb{x + -0.5f, y + -0.48f, 1.0f, 0.98f};  // tilemap.cpp:89
-            if (box_hit(body[ss], hb)) hazard[ss] = true;
-
-            int dead = -1;
-#pragma unroll
-            for (int k = 0; k < kSparks; k++) {
-                sl[k] -= dt;
-                if (sl[k] <= 0.0f) dead = k;
-            }
-            timer += dt;
-            if (dead != -1 && timer >= 0.5f) {
-                timer = fmodf(timer, 0.5f);
-#pragma unroll
-                for (int k = 0; k < kSparks; k++)
-                    if (k == dead) {
-                        sl[k] = 5.0f;
-                        sx[k] = x + 0.0f;
-                        sy[k] = y + 0.34f;
-                    }
-            }
+            if (box_hit(Box{body_x[ss], body_y[ss], 1.0f, 1.0f}, hb)) hits |= 1 << ss;
+            // System_Sprite_Render::update (common_systems.cpp:14-29), rate 1.0 (tilemap.cpp:60)
             anim_t += dt;
-            const int adv = static_cast<int>(anim_t * 0.2f);
-            anim_t -= adv / 0.2f;
+            const int adv = static_cast<int>(anim_t * 1.0f);
+            anim_t -= adv / 1.0f;
             dyn = ((dyn & ~kDynFrame) | ((((dyn & kDynFrame) ? 1 : 0) + adv) % 2 ? kDynFrame : 0)) | kDynTexSet;
         }
         DF(s, dst, DF_X, e, env) = x;
-        DF(s, dst, DF_VX, e, env) = vx;
         DF(s, dst, DF_ANIM_T, e, env) = anim_t;
-        DF(s, dst, DF_SPAWN_T, e, env) = timer;
         DB(s, dst, e, env) = static_cast<uint8_t>(dyn);
+        return hits;
+    }
+    // --- mob: System_Mob_AI (common_systems.cpp:65-105) + System_Particles (:284-313) + animation, rate 0.2
+    float vx = DF(s, src, DF_VX, e, env);
+    float timer = DF(s, src, DF_SPAWN_T, e, env);
+    float sx[kSparks], sy[kSparks], sl[kSparks];
+#pragma unroll
+    for (int k = 0; k < kSparks; k++) {
+        sx[k] = SP(s, src, 0, e, k, env);
+        sy[k] = SP(s, src, 1, e, k, env);
+        sl[k] = SP(s, src, 2, e, k, env);
+    }
+    // both sensors of all sub-steps live inside this window (x drifts by at most 0.15 per step)
+    const TileWin win = TileWin::fetch(tiles, static_cast<int>(floorf(x - 0.66f)), static_cast<int>(floorf(y - 0.6f)));
+#pragma unroll
+    for (int ss = 0; ss < 4; ss++) {
+        if (ss >= limit) break;
+        x += vx * dt;
+        const Box wall_probe{x - 0.5f, y - 0.6f, 1.0f, 0.5f};
+        const Box floor_probe{x - 0.5f, y + 0.6f, 1.0f, 0.5f};
+        const Hit wall = collide(
+            win, wall_probe, [](int t) { return (t == kWallMid || t == kWallTop) ? kFull : kPass; }, false, 0.0f);
+        const Hit gap = collide(
+            win, floor_probe, [](int t) { return t == kEmpty ? kFull : kPass; }, false, 0.0f);
+        float nx = wall.x + 0.5f;
+        if (gap.any) nx = gap.x + 0.5f;
+        x = nx;
+        if (wall.any || gap.any) vx *= -1.0f;
+        dyn = (dyn & ~kDynFlip) | (vx > 0.0f ? kDynFlip : 0);
+
+        const Box hb{x + -0.5f, y + -0.48f, 1.0f, 0.98f};  // tilemap.cpp:89
+        if (box_hit(Box{body_x[ss], body_y[ss], 1.0f, 1.0f}, hb)) hits |= 1 << ss;
+
+        int dead = -1;
 #pragma unroll
         for (int k = 0; k < kSparks; k++) {
-            SP(s, dst, 0, e, k, env) = sx[k];
-            SP(s, dst, 1, e, k, env) = sy[k];
-            SP(s, dst, 2, e, k, env) = sl[k];
+            sl[k] -= dt;
+            if (sl[k] <= 0.0f) dead = k;
         }
+        timer += dt;
+        if (dead != -1 && timer >= 0.5f) {
+            timer = fmodf(timer, 0.5f);
+#pragma unroll
+            for (int k = 0; k < kSparks; k++)
+                if (k == dead) {
+                    sl[k] = 5.0f;
+                    sx[k] = x + 0.0f;
+                    sy[k] = y + 0.34f;
+                }
+        }
+        anim_t += dt;
+        const int adv = static_cast<int>(anim_t * 0.2f);
+        anim_t -= adv / 0.2f;
+        dyn = ((dyn & ~kDynFrame) | ((((dyn & kDynFrame) ? 1 : 0) + adv) % 2 ? kDynFrame : 0)) | kDynTexSet;
     }
+    DF(s, dst, DF_X, e, env) = x;
+    DF(s, dst, DF_VX, e, env) = vx;
+    DF(s, dst, DF_ANIM_T, e, env) = anim_t;
+    DF(s, dst, DF_SPAWN_T, e, env) = timer;
+    DB(s, dst, e, env) = static_cast<uint8_t>(dyn);
+#pragma unroll
+    for (int k = 0; k < kSparks; k++) {
+        SP(s, dst, 0, e, k, env) = sx[k];
+        SP(s, dst, 1, e, k, env) = sy[k];
+        SP(s, dst, 2, e, k, env) = sl[k];
+    }
+    return hits;
 }
 
-PG_D void advance(const State& s, int env, int action, float& reward_out, bool& terminated_out) {
+// A: System_Agent::update ×4 (common_systems.cpp:121-252) minus the hazard loop, which needs the mobs.
+PG_D void agent_substeps(const State& s, int env, int action) {
     const uint8_t* tiles = s.tiles + size_t(env) * (W * H);
     const int n_ent = SI(s, I_NENT, env);
     const int flags = SI(s, I_FLAGS, env);
@@ -523,10 +538,7 @@ PG_D void advance(const State& s, int env, int action, float& reward_out, bool& 
     const bool jump = (action == 2 || action == 5 || action == 8);
     const bool drop = (action == 0 || action == 3 || action == 6);
 
-    // --- 1. System_Agent::update ×4 (common_systems.cpp:121-252) minus the hazard loop, which needs the mobs
-    AgentSnap snap[4];
-    Box body[4];
-    bool lava[4], coin[4];
+    int bits = static_cast<int>(0x80000000u);
 #pragma unroll
     for (int ss = 0; ss < 4; ss++) {
         const float mix_x = ground ? mix : (mix * air_control);
@@ -555,9 +567,6 @@ PG_D void advance(const State& s, int env, int action, float& reward_out, bool& 
         const TileWin w2 = TileWin::fetch(tiles, static_cast<int>(floorf(b.x)), static_cast<int>(floorf(b.y)));
         const Hit lv = collide(
             w2, b, [](int t) { return (t == kLavaMid || t == kLavaTop) ? kFull : kPass; }, false, 0.0f);
-        lava[ss] = lv.any;
-        coin[ss] = box_hit(b, coin_box);
-        body[ss] = b;
 
         phase += 0.1f * dt;
         phase = fmodf(phase, 1.0f);
@@ -565,40 +574,17 @@ PG_D void advance(const State& s, int env, int action, float& reward_out, bool& 
             forward = true;
         else if (move_x < 0.0f)
             forward = false;
-        snap[ss] = {ax, ay, avx, avy, phase, ax * kUnitPx, (ay - 0.5f) * kUnitPx, ground, forward};
-    }
 
-    // --- 2./3. entities, then the first terminating sub-step decides how many sub-steps took place
-    bool hazard[4];
-    int limit = 4, last = 3;
-    for (int attempt = 0; attempt < 2; attempt++) {
-        entity_pass(s, env, n_ent, src, limit, body, hazard);
-        last = limit - 1;
-        for (int ss = limit - 1; ss >= 0; ss--)
-            if (hazard[ss] || lava[ss] || coin[ss]) last = ss;
-        if (last + 1 == limit) break;
-        limit = last + 1;  // rare: redo from the untouched half with fewer sub-steps
+        SC(s, SC_AX + ss, env) = ax;
+        SC(s, SC_AY + ss, env) = ay;
+        SC(s, SC_AVX + ss, env) = avx;
+        SC(s, SC_AVY + ss, env) = avy;
+        SC(s, SC_PHASE + ss, env) = phase;
+        bits |= (ground ? 1 << ss : 0) | (forward ? 1 << (4 + ss) : 0) | (lv.any ? 1 << (8 + ss) : 0) |
+                (box_hit(b, coin_box) ? 1 << (12 + ss) : 0);
     }
-    bool alive = true, got_coin = false;
-    AgentSnap fin = snap[0];
-#pragma unroll
-    for (int ss = 0; ss < 4; ss++)
-        if (ss == last) {
-            fin = snap[ss];
-            alive = !(hazard[ss] || lava[ss]);
-            got_coin = coin[ss];
-        }
-    SF(s, F_AX, env) = fin.ax;
-    SF(s, F_AY, env) = fin.ay;
-    SF(s, F_AVX, env) = fin.avx;
-    SF(s, F_AVY, env) = fin.avy;
-    SF(s, F_APHASE, env) = fin.phase;
-    SF(s, F_CAMX, env) = fin.camx;
-    SF(s, F_CAMY, env) = fin.camy;
-    SI(s, I_FLAGS, env) =
-        kFlagListed | (fin.ground ? kFlagGround : 0) | (fin.forward ? kFlagForward : 0) | (src ? 0 : kFlagBuf);
-    reward_out = got_coin * 10.0f;        // coinrun.cpp:364, last executed sub-step only (D4)
-    terminated_out = !alive || got_coin;  // coinrun.cpp:366
+    SCI(s, SC_BITS, env) = bits;
+    SCI(s, SC_HAZARD, env) = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -627,7 +613,8 @@ __global__ void __launch_bounds__(64) reset_kernel(State s, const uint8_t* mask,
     io.pending[env] = 0;
 }
 
-__global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actions, uint32_t run_seed,
+// A — lane = env: auto-reset, or the agent's sub-steps into the scratch table.
+__global__ void __launch_bounds__(64) agent_kernel(State s, const int32_t* actions, uint32_t run_seed,
                                                    uint32_t step_index, int env_offset, StepIO io) {
     const int env = blockIdx.x * 64 + threadIdx.x;
     if (env >= s.n) return;
@@ -636,14 +623,70 @@ __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actio
         io.reward[env] = 0.0f;
         io.done[env] = 0;
         io.pending[env] = 0;
+        SCI(s, SC_BITS, env) = 0;  // did not step: B and C leave this env alone
         return;
     }
     const int action =
         actions ? actions[env] : synthetic_action(run_seed, step_index, static_cast<uint32_t>(env_offset + env));
-    float reward;
-    bool terminated;
-    advance(s, env, action, reward, terminated);
-    io.reward[env] = reward;
+    agent_substeps(s, env, action);
+}
+
+// B — lane = env, blockIdx.y = entity slot: all four sub-steps of one entity (optimistic: no early termination).
+__global__ void __launch_bounds__(64) entity_kernel(State s) {
+    const int env = blockIdx.x * 64 + threadIdx.x;
+    const int e = blockIdx.y;
+    if (env >= s.n) return;
+    if (e >= SI(s, I_NENT, env)) return;
+    if (SCI(s, SC_BITS, env) >= 0) return;  // bit 31 clear: this env performed its reset instead
+    float bx[4], by[4];
+#pragma unroll
+    for (int ss = 0; ss < 4; ss++) {
+        bx[ss] = SC(s, SC_AX + ss, env) + -0.5f;
+        by[ss] = SC(s, SC_AY + ss, env) + -1.0f;
+    }
+    const int src = (SI(s, I_FLAGS, env) & kFlagBuf) ? 1 : 0;
+    const int hits = entity_step(s, env, e, src, 4, bx, by);
+    if (hits) atomicOr(&SCI(s, SC_HAZARD, env), hits);
+}
+
+// C — lane = env: which sub-step ended the step, rare redo, commit (coinrun.cpp:356-371).
+__global__ void __launch_bounds__(64) resolve_kernel(State s, StepIO io) {
+    const int env = blockIdx.x * 64 + threadIdx.x;
+    if (env >= s.n) return;
+    const int bits = SCI(s, SC_BITS, env);
+    if (bits >= 0) return;  // reset this step; agent_kernel already wrote reward/done/pending
+    const int flags = SI(s, I_FLAGS, env);
+    const int src = (flags & kFlagBuf) ? 1 : 0;
+    int hazard = SCI(s, SC_HAZARD, env);
+    const int lava = (bits >> 8) & 15, coin = (bits >> 12) & 15;
+    int ending = hazard | lava | coin;
+    int last = ending ? __builtin_ctz(ending) : 3;  // first terminating sub-step, or all four took place
+    if (last < 3) {
+        // rare: fewer than four sub-steps happened — redo this env's entities from the untouched half
+        float bx[4], by[4];
+#pragma unroll
+        for (int ss = 0; ss < 4; ss++) {
+            bx[ss] = SC(s, SC_AX + ss, env) + -0.5f;
+            by[ss] = SC(s, SC_AY + ss, env) + -1.0f;
+        }
+        const int n_ent = SI(s, I_NENT, env);
+        hazard = 0;
+        for (int e = 0; e < n_ent; e++) hazard |= entity_step(s, env, e, src, last + 1, bx, by);
+    }
+    const bool alive = !(((hazard | lava) >> last) & 1);
+    const bool got_coin = ((coin >> last) & 1) != 0;
+    const float ax = SC(s, SC_AX + last, env), ay = SC(s, SC_AY + last, env);
+    SF(s, F_AX, env) = ax;
+    SF(s, F_AY, env) = ay;
+    SF(s, F_AVX, env) = SC(s, SC_AVX + last, env);
+    SF(s, F_AVY, env) = SC(s, SC_AVY + last, env);
+    SF(s, F_APHASE, env) = SC(s, SC_PHASE + last, env);
+    SF(s, F_CAMX, env) = ax * kUnitPx;  // common_systems.cpp:238-239
+    SF(s, F_CAMY, env) = (ay - 0.5f) * kUnitPx;
+    SI(s, I_FLAGS, env) = kFlagListed | (((bits >> last) & 1) ? kFlagGround : 0) |
+                          (((bits >> (4 + last)) & 1) ? kFlagForward : 0) | (src ? 0 : kFlagBuf);
+    const bool terminated = !alive || got_coin;  // coinrun.cpp:366
+    io.reward[env] = got_coin * 10.0f;           // coinrun.cpp:364, last executed sub-step only (D4)
     io.done[env] = terminated ? 1 : 0;
     io.pending[env] = terminated ? 1 : 0;
 }
@@ -886,7 +929,7 @@ class CoinrunGame final : public Game {
 
     static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
     struct Layout {
-        size_t mt, tiles, f, i, ey, eb, df, db, spark, total;
+        size_t mt, tiles, f, i, ey, eb, df, db, spark, scratch, total;
     };
     static Layout layout(int n) {
         Layout l{};
@@ -905,6 +948,7 @@ class CoinrunGame final : public Game {
         l.df = take(size_t(2) * DF_COUNT * kMaxEnt * n * 4);
         l.db = take(size_t(2) * kMaxEnt * n);
         l.spark = take(size_t(2) * 3 * kMaxEnt * kSparks * n * 4);
+        l.scratch = take(size_t(SC_COUNT) * n * 4);
         l.total = off;
         return l;
     }
@@ -922,6 +966,7 @@ class CoinrunGame final : public Game {
         s_.df = reinterpret_cast<float*>(p + l.df);
         s_.db = p + l.db;
         s_.spark = reinterpret_cast<float*>(p + l.spark);
+        s_.scratch = reinterpret_cast<float*>(p + l.scratch);
         atlas_ = atlas;
     }
     int blocks() const { return (s_.n + 63) / 64; }
@@ -933,8 +978,10 @@ class CoinrunGame final : public Game {
     }
     void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
                       StepIO io) override {
-        hipLaunchKernelGGL(logic_kernel, dim3(blocks()), dim3(64), 0, st, s_, actions, run_seed, step_index,
+        hipLaunchKernelGGL(agent_kernel, dim3(blocks()), dim3(64), 0, st, s_, actions, run_seed, step_index,
                            env_offset, io);
+        hipLaunchKernelGGL(entity_kernel, dim3(blocks(), kMaxEnt), dim3(64), 0, st, s_);
+        hipLaunchKernelGGL(resolve_kernel, dim3(blocks()), dim3(64), 0, st, s_, io);
     }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
         hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(64), 0, st, s_, atlas_, mask, io, debug_flags);
