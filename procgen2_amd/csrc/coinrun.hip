@@ -755,16 +755,17 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
                 tex = kTexCrate + (lane - 4);
             kind_base = atlas.desc[tex].x;
         }
-        for (int base = 0; base < cells; base += 64) {
-            const int cell = base + lane;
-            const int r = cell / cols, c = cell - r * cols;
+#pragma unroll
+        for (int k = 0; k < kGrid * kGrid / 64; k++) {  // the whole kGrid×kGrid table, 64 cells per pass
+            const int cell = k * 64 + lane;
+            const int r = cell / kGrid, c = cell % kGrid;
             const int x = x0 + c, ty = H - 1 - (y0 + r);
             int raw = kWallMid;  // out of bounds is a wall (tilemap.h:80-81)
-            if (cell < cells && x >= 0 && ty >= 0 && x < W && ty < H) raw = tiles[ty + x * H];
+            if (x >= 0 && ty >= 0 && x < W && ty < H) raw = tiles[ty + x * H];
             const int t = raw & 7;
             const int slot = t < kCrate ? t - 1 : 4 + (raw >> 4);
             const int off = __shfl(kind_base, slot < 0 ? 0 : slot);
-            if (cell < cells) L.base[r * kGrid + c] = (t == kEmpty) ? static_cast<int32_t>(kNoTexel) : off * 4;
+            L.base[cell] = (t == kEmpty) ? static_cast<int32_t>(kNoTexel) : off * 4;
         }
         __syncthreads();
         composed = compose_rows(fb, L, atlas, bg, has_bg, cols, rows, tile_desc.y, lane, flags);

@@ -138,7 +138,22 @@ PG_HD bool resolve_draw(const Camera& cam, int tw, int th, int tex_off, float po
 }
 
 // Raster spec S3: nearest texel for destination column/row `i` of `n`, over `len` texels from `start`.
-PG_HD int sample_index(int start, int len, int i, int n) { return start + ((2 * i + 1) * len) / (2 * n); }
+// floor(a / b) for 0 <= a < 2^22, 1 <= b < 2^22.  On the device: one reciprocal estimate and a ±1 fix-up
+// instead of the ~30-instruction generic 32-bit division (a and b are exact in float, the estimate is off
+// by at most one; checked against `/` in tests/cpp/test_primitives.cpp for the host twin of this code).
+PG_HD int udiv_small(int a, int b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int q = static_cast<int>(static_cast<float>(a) * __builtin_amdgcn_rcpf(static_cast<float>(b)));
+#else
+    int q = static_cast<int>(static_cast<float>(a) * (1.0f / static_cast<float>(b)));
+#endif
+    int r = a - q * b;
+    if (r < 0) q--;
+    if (r >= b) q++;
+    return q;
+}
+
+PG_HD int sample_index(int start, int len, int i, int n) { return start + udiv_small((2 * i + 1) * len, 2 * n); }
 
 // floor(x / 255) for 0 <= x < 65536 (exhaustively checked in tests/cpp/test_primitives.cpp).
 PG_HD uint32_t div255(uint32_t x) {

@@ -34,8 +34,12 @@ template <int GRID>
 struct ComposeLds {
     int4 col[GRID];             // per grid column: {d0, dn, s0, sn}; sn == 0 ⇒ nothing drawn
     int4 row[GRID];             // per grid row
-    int32_t base[GRID * GRID];  // [row][col] texel offset of the cell's tile texture, -1 = no tile
+    int32_t base[GRID * GRID];  // [row][col] byte offset of the cell's tile texture in the atlas, kNoTexel = no tile
+    int32_t cover_n[2][64];     // [axis][pixel] how many grid columns (axis 0) / rows (axis 1) cover the pixel
+    int32_t cover[2][64][2];    // the first two of them: grid index | texel coordinate << 8
+    int32_t too_wide;           // some span is wider than kMaxSpan pixels → fall back
 };
+constexpr int kMaxSpan = 8;  // a tile of the layer covers at most this many pixels per axis (coinrun 5–6, maze 3)
 
 // Broadcast a resolved draw from lane `src` (wave-uniform) into scalar registers.
 PG_D Blit blit_from_lane(const Blit& mine, int src) {
@@ -110,13 +114,54 @@ PG_D void wave_blit(uint32_t* fb, const AtlasView& atlas, const Blit& b, int lan
 }
 
 // Replays the draws held by the lanes flagged in `mask`, in ascending lane order.
+// Small draws (≤ 64 visible pixels: every sprite, particle and the agent) are taken kGroup at a time: one pixel
+// per lane per draw, all texel fetches of the group issued before the first blend, so a group costs one memory
+// round trip; the blends then run in draw order.  A larger draw goes through wave_blit on its own.
 PG_D void wave_replay(uint32_t* fb, const AtlasView& atlas, const Blit& mine, unsigned long long mask, int lane) {
+    constexpr int kGroup = 4;
     while (mask) {
-        const int src = __builtin_ctzll(mask);
-        mask &= mask - 1;
-        const Blit b = blit_from_lane(mine, src);
-        wave_blit(fb, atlas, b, lane);
-        __syncthreads();  // single-wave workgroup: orders the LDS traffic of consecutive draws
+        uint32_t texel[kGroup];
+        int idx[kGroup], mod[kGroup];
+        bool stop = false;
+#pragma unroll
+        for (int g = 0; g < kGroup; g++) {
+            idx[g] = -1;
+            texel[g] = 0;
+            mod[g] = 255;
+            if (mask == 0 || stop) continue;
+            const Blit b = blit_from_lane(mine, __builtin_ctzll(mask));
+            const int x0 = b.dx > 0 ? b.dx : 0, y0 = b.dy > 0 ? b.dy : 0;
+            const int x1 = (b.dx + b.dw) < kObsW ? (b.dx + b.dw) : kObsW;
+            const int y1 = (b.dy + b.dh) < kObsH ? (b.dy + b.dh) : kObsH;
+            const int cw = x1 - x0, ch = y1 - y0;
+            if (cw > 0 && ch > 0 && cw * ch > 64) {  // a big one: alone, and only at the head of a group
+                stop = true;
+                if (g == 0) {
+                    mask &= mask - 1;
+                    wave_blit(fb, atlas, b, lane);
+                    __syncthreads();
+                }
+                continue;
+            }
+            mask &= mask - 1;
+            if (cw <= 0 || ch <= 0 || lane >= cw * ch) continue;
+            const int ry = udiv_small(lane, cw);
+            const int rx = lane - ry * cw;
+            const int x = x0 + rx, y = y0 + ry;
+            int i = x - b.dx, j = y - b.dy;
+            if (b.flip_mod & kFlipH) i = b.dw - 1 - i;
+            if (b.flip_mod & kFlipV) j = b.dh - 1 - j;
+            const int u = sample_index(b.sx, b.sw, i, b.dw);
+            const int v = sample_index(b.sy, b.sh, j, b.dh);
+            idx[g] = y * kObsW + x;
+            texel[g] = atlas.texels[b.tex_off + v * b.tex_w + u];
+            mod[g] = b.flip_mod & 0xff;
+        }
+#pragma unroll
+        for (int g = 0; g < kGroup; g++) {
+            if (idx[g] >= 0) blend_into(fb, idx[g], texel[g], mod[g]);
+            __syncthreads();  // single-wave workgroup: orders the LDS traffic of consecutive draws
+        }
     }
 }
 
@@ -127,46 +172,66 @@ PG_D void wave_clear(uint32_t* fb, int lane) {
     __syncthreads();
 }
 
-// Which of the `n` spans cover destination coordinate `p`?  Records the first two (ascending index) and the
-// texel coordinate each samples at p; returns false if a third one covers p.
-PG_D bool covering_spans(const int4* spans, int n, int p, int& ia, int& ib, int& ta, int& tb) {
-    ia = ib = -1;
-    ta = tb = 0;
-    bool ok = true;
-    for (int k = 0; k < n; k++) {
-        const int4 s = spans[k];
-        if (s.w > 0 && p >= s.x && p < s.x + s.y) {
-            const int t = sample_index(s.z, s.w, p - s.x, s.y);
-            if (ia < 0) {
-                ia = k;
-                ta = t;
-            } else if (ib < 0) {
-                ib = k;
-                tb = t;
-            } else {
-                ok = false;
-            }
-        }
-    }
-    return ok;
-}
-
-// Step 1 of the composer: the per-column / per-row span tables of the tile grid (lane c → column x0+c and
-// row y0+c).  Call before staging L.base; needs a __syncthreads() before compose_rows (which the staging
-// loop's own barrier provides).
+// Step 1 of the composer: the per-column / per-row span tables of the tile grid (lane c → column x0+c and row
+// y0+c), then — after a barrier — every (span, offset) pair scatters itself to the pixel it covers, so each pixel
+// column / row learns which grid columns / rows cover it and at which texel coordinate, without a search loop.
+// Leaves a __syncthreads() to the caller (the staging of L.base provides it) before compose_rows.
 template <int GRID>
 PG_D void compose_spans(ComposeLds<GRID>& L, const Camera& cam, int x0, int y0, int cols, int rows, int tw, int th,
                         float tile_scale, int lane) {
+    L.cover_n[0][lane] = 0;
+    L.cover_n[1][lane] = 0;
+    if (lane == 0) L.too_wide = 0;
+    bool wide = false;
     if (lane < cols) {
         Span sp;
         const bool ok = resolve_axis(cam.px, cam.sw, cam.scale, tw, (x0 + lane) * kUnitPx, tile_scale, false, false, sp);
         L.col[lane] = ok ? make_int4(sp.d0, sp.dn, sp.s0, sp.sn) : make_int4(0, 0, 0, 0);
+        wide = ok && sp.dn > kMaxSpan;
     }
     if (lane < rows) {
         Span sp;
         const bool ok = resolve_axis(cam.py, cam.sh, cam.scale, th, (y0 + lane) * kUnitPx, tile_scale, false, true, sp);
         L.row[lane] = ok ? make_int4(sp.d0, sp.dn, sp.s0, sp.sn) : make_int4(0, 0, 0, 0);
+        wide = wide || (ok && sp.dn > kMaxSpan);
     }
+    __syncthreads();
+    if (__ballot(wide)) {
+        if (lane == 0) L.too_wide = 1;
+        return;
+    }
+#pragma unroll
+    for (int axis = 0; axis < 2; axis++) {
+        const int4* spans = axis == 0 ? L.col : L.row;
+        const int count = axis == 0 ? cols : rows;
+        for (int q = lane; q < count * kMaxSpan; q += 64) {
+            const int g = q / kMaxSpan, i = q % kMaxSpan;
+            const int4 sp = spans[g];
+            const int p = sp.x + i;
+            if (sp.w > 0 && i < sp.y && p >= 0 && p < 64) {
+                const int slot = atomicAdd(&L.cover_n[axis][p], 1);
+                if (slot < 2) L.cover[axis][p][slot] = g | (sample_index(sp.z, sp.w, i, sp.y) << 8);
+            }
+        }
+    }
+}
+
+// The (at most two) covering grid indices of pixel `p` on `axis`, ascending = draw order.  Returns false when
+// more than two spans cover the pixel.
+template <int GRID>
+PG_D bool covering(const ComposeLds<GRID>& L, int axis, int p, int& ia, int& ib, int& ta, int& tb) {
+    const int n = L.cover_n[axis][p];
+    int c0 = L.cover[axis][p][0], c1 = L.cover[axis][p][1];
+    if (n >= 2 && (c0 & 0xff) > (c1 & 0xff)) {
+        const int t = c0;
+        c0 = c1;
+        c1 = t;
+    }
+    ia = n >= 1 ? (c0 & 0xff) : -1;
+    ta = c0 >> 8;
+    ib = n >= 2 ? (c1 & 0xff) : -1;
+    tb = c1 >> 8;
+    return n <= 2;
 }
 
 // "No texel here" marker for the composer's byte offsets: adding it to any valid offset lands beyond the
@@ -186,8 +251,9 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
 
     // lane as pixel column: covering grid columns; lane as pixel row: covering grid rows.
     int ca, cb, ua, ub, ra, rb, va, vb;
-    bool fits = covering_spans(L.col, cols, lane, ca, cb, ua, ub);
-    fits = covering_spans(L.row, rows, lane, ra, rb, va, vb) && fits;
+    if (L.too_wide) return false;
+    bool fits = covering(L, 0, lane, ca, cb, ua, ub);
+    fits = covering(L, 1, lane, ra, rb, va, vb) && fits;
     if (__ballot(!fits)) return false;
 
     // All texel reads go through one buffer descriptor over the atlas: 32-bit byte offsets, and out-of-range
@@ -229,6 +295,10 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
 #define PG_BATCH 8
 #endif
     constexpr int kBatch = PG_BATCH;
+    if (ablate & 128) {  // timing experiment: everything but the row loop
+        __syncthreads();
+        return true;
+    }
     for (int py0 = 0; py0 < kObsH; py0 += kBatch) {
         uint32_t t[kBatch][5];
 #pragma unroll

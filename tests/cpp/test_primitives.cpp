@@ -187,6 +187,12 @@ static void test_sort() {
 
 static void test_blend() {
     for (uint32_t x = 0; x < 65536; x++) CHECK(pg::div255(x) == x / 255, "div255(%u)", x);
+    for (int b = 1; b < 700; b++)
+        for (int a = 0; a < (1 << 22); a += (b < 140 ? 1 + a / 4096 : 997)) CHECK(pg::udiv_small(a, b) == a / b, "udiv_small(%d,%d)", a, b);
+    for (int n = 1; n <= 70; n++)  // every (column, width) pair a blit can see
+        for (int len = 1; len <= 2100; len += (len < 200 ? 1 : 13))
+            for (int i = 0; i < n; i++)
+                CHECK(pg::sample_index(3, len, i, n) == 3 + ((2 * i + 1) * len) / (2 * n), "sample_index(%d,%d,%d)", len, i, n);
     // Raster spec S4 written out naively: s = a<255 ? C*a/255 : C;  D = s + (255-a)*D/255
     for (int a = 0; a < 256; a++)
         for (int s = 0; s < 256; s++)
