@@ -712,13 +712,39 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
     const int n_ent = SI(s, I_NENT, env);
     const int n_mob = SI(s, I_NMOB, env);
     const uint8_t* tiles = s.tiles + size_t(env) * (W * H);
+    const DescRegs descs = DescRegs::load(atlas, lane);  // the whole descriptor table, two entries per lane
     Blit mine;
+
+    // The per-lane inputs of the sprite pass (one draw per lane: particles, then sprites, then the agent) are
+    // requested now so their memory latency hides behind the background/tile composition.
+    const int n_parts = n_mob * kSparks;
+    const int n_sprites = (sflags & kFlagListed) ? n_ent : 0;  // the draw list is empty until the first update (D2)
+    const bool one_pass = n_parts + n_sprites + 1 <= 64;
+    const int first_sprite = one_pass ? n_parts : 0;
+    const bool is_part = one_pass && lane < n_parts;
+    const bool is_sprite = lane >= first_sprite && lane < first_sprite + n_sprites;
+    const bool is_agent = lane == first_sprite + n_sprites;
+    int spr_e = 0, spr_dyn = 0, spr_tex = 0;
+    float spr_x = 0.0f, spr_y = 0.0f, part_life = 0.0f, part_x = 0.0f, part_y = 0.0f;
+    if (is_sprite) {
+        spr_e = EB(s, EB_DRAW_ORDER, lane - first_sprite, env);
+        spr_dyn = DB(s, buf, spr_e, env);
+        spr_tex = EB(s, EB_TEX, spr_e, env);
+        spr_x = DF(s, buf, DF_X, spr_e, env);
+        spr_y = EY(s, spr_e, env);
+    } else if (is_part) {
+        const int m = lane / kSparks, k = lane - m * kSparks;
+        const int e = EB(s, EB_SPARK_ORDER, m, env);
+        part_life = SP(s, buf, 2, e, k, env);
+        part_x = SP(s, buf, 0, e, k, env);
+        part_y = SP(s, buf, 1, e, k, env);
+    }
 
     // background (coinrun.cpp:459-464)
     Blit bg;
     bool has_bg;
     {
-        const int4 d = atlas.desc[kTexBackdrop + backdrop];
+        const int4 d = descs.uniform(kTexBackdrop + backdrop);
         const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
         const float extra = aspect - 1.0f;
         has_bg = resolve_draw(cam, d.y, d.z, d.x, -SF(s, F_BGSHIFT, env) * extra, 0.0f, 64.0f * kUnitPx / d.z, 1.0f,
@@ -733,28 +759,19 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
     const int x0 = static_cast<int>(floorf(vx)), y0 = static_cast<int>(floorf(vy));
     const int x1 = static_cast<int>(ceilf(vx + vw)), y1 = static_cast<int>(ceilf(vy + vh));
     const int cols = x1 - x0 + 1, rows = y1 - y0 + 1, cells = cols * rows;
-    const int4 tile_desc = atlas.desc[kTexMid];  // every tile texture is 128×128 (checked at make time)
+    const int4 tile_desc = descs.uniform(kTexMid);  // every tile texture is 128×128 (checked at make time)
 
     bool composed = false;
     if (!(flags & 5) && cols <= kGrid && rows <= kGrid) {
         compose_spans(L, cam, x0, y0, cols, rows, tile_desc.y, tile_desc.z, kUnitPx / tile_desc.y, lane);
         // Texel offset of each tile kind's texture, one per lane (0..7), looked up with a cross-lane read:
         // lanes 0-3 = wall_top, wall_mid, lava_top, lava_mid (tile id - 1), lanes 4-7 = the four crates.
-        int kind_base = -1;
-        if (lane < 8) {
-            int tex;
-            if (lane == 0)
-                tex = kTexTop + ground_theme;
-            else if (lane == 1)
-                tex = kTexMid + ground_theme;
-            else if (lane == 2)
-                tex = kTexLavaTop;
-            else if (lane == 3)
-                tex = kTexLava;
-            else
-                tex = kTexCrate + (lane - 4);
-            kind_base = atlas.desc[tex].x;
-        }
+        int kind_tex = kTexCrate + ((lane - 4) & 3);
+        if (lane == 0) kind_tex = kTexTop + ground_theme;
+        if (lane == 1) kind_tex = kTexMid + ground_theme;
+        if (lane == 2) kind_tex = kTexLavaTop;
+        if (lane == 3) kind_tex = kTexLava;
+        const int kind_base = descs.at(kind_tex).x;
 #pragma unroll
         for (int k = 0; k < kGrid * kGrid / 64; k++) {  // the whole kGrid×kGrid table, 64 cells per pass
             const int cell = k * 64 + lane;
@@ -800,7 +817,7 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
                         tex = kTexLavaTop;
                     else
                         tex = kTexCrate + crate;
-                    const int4 d = atlas.desc[tex];
+                    const int4 d = atlas.desc[tex];  // fallback path: plain global lookup
                     has = resolve_draw(cam, d.y, d.z, d.x, x * kUnitPx, y * kUnitPx, kUnitPx / d.y, 1.0f, false, false,
                                        mine);
                 }
@@ -810,66 +827,62 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
     }
 
     if (!(flags & 2)) {  // (bit 1: timing experiment — skips particles, sprites and the agent)
-        {  // particles (common_systems.cpp:315-337): owners in the particle system's set order
-            const int4 d = atlas.desc[kTexSpark];
-            const int total = n_mob * kSparks;
-            for (int base = 0; base < total; base += 64) {
-                const int idx = base + lane;
+        // One draw per lane, in the reference's order: particles (owners in the particle system's set order,
+        // common_systems.cpp:315-337), then the sprites of the draw list (positive z, :41-63; empty until the
+        // first update — D2), then the agent (:254-278).
+        const int4 spark_d = descs.uniform(kTexSpark);
+        auto particle = [&](float life, float px, float py, Blit& out) {
+            if (life <= 0.0f) return false;
+            const float lr = (5.0f - life) / 5.0f;
+            const float alpha = 0.5f * (1.0f - lr);
+            const float scale = 0.45f * (0.4f * lr + 0.6f);
+            const float oy = -lr * 0.17f;
+            return resolve_draw(cam, spark_d.y, spark_d.z, spark_d.x, px * kUnitPx - 0.5f * spark_d.y * scale,
+                                (py + oy) * kUnitPx - 0.5f * spark_d.z * scale, scale * kUnitPx / spark_d.y, alpha,
+                                false, false, out);
+        };
+        if (!one_pass) {  // many mobs: particles in rounds of 64 first
+            for (int base = 0; base < n_parts; base += 64) {
                 bool has = false;
-                if (idx < total) {
-                    const int m = idx / kSparks, k = idx - m * kSparks;
+                if (base + lane < n_parts) {
+                    const int idx = base + lane, m = idx / kSparks, k = idx - m * kSparks;
                     const int e = EB(s, EB_SPARK_ORDER, m, env);
-                    const float life = SP(s, buf, 2, e, k, env);
-                    if (!(life <= 0.0f)) {
-                        const float px = SP(s, buf, 0, e, k, env), py = SP(s, buf, 1, e, k, env);
-                        const float lr = (5.0f - life) / 5.0f;
-                        const float alpha = 0.5f * (1.0f - lr);
-                        const float scale = 0.45f * (0.4f * lr + 0.6f);
-                        const float oy = -lr * 0.17f;
-                        has = resolve_draw(cam, d.y, d.z, d.x, px * kUnitPx - 0.5f * d.y * scale,
-                                           (py + oy) * kUnitPx - 0.5f * d.z * scale, scale * kUnitPx / d.y, alpha,
-                                           false, false, mine);
-                    }
+                    has = particle(SP(s, buf, 2, e, k, env), SP(s, buf, 0, e, k, env), SP(s, buf, 1, e, k, env), mine);
                 }
                 wave_replay(fb, atlas, mine, __ballot(has), lane);
             }
         }
-
-        if (sflags & kFlagListed) {  // sprites, positive z (common_systems.cpp:41-63); empty until the first update (D2)
-            bool has = false;
-            if (lane < n_ent) {
-                const int e = EB(s, EB_DRAW_ORDER, lane, env);
-                const int dyn = DB(s, buf, e, env);
-                if (dyn & kDynTexSet) {
-                    const int tex = EB(s, EB_TEX, e, env) + ((dyn & kDynFrame) ? 1 : 0);
-                    const int4 d = atlas.desc[tex];
-                    const float scale = 1.0f * 1.0f;
-                    has = resolve_draw(cam, d.y, d.z, d.x, (DF(s, buf, DF_X, e, env) + -0.5f) * kUnitPx,
-                                       (EY(s, e, env) + -0.5f) * kUnitPx, scale * kUnitPx / d.y, 1.0f,
-                                       (dyn & kDynFlip) != 0, false, mine);
-                }
-            }
-            wave_replay(fb, atlas, mine, __ballot(has), lane);
-        }
-
-        {  // agent (common_systems.cpp:254-278)
-            const float avx = SF(s, F_AVX, env);
+        // every lane asks for the descriptor it needs with a cross-lane read, so do that outside the branches
+        int want_tex = 0;
+        if (is_sprite) {
+            want_tex = spr_tex + ((spr_dyn & kDynFrame) ? 1 : 0);
+        } else if (is_agent) {
             const bool ground = (sflags & kFlagGround) != 0;
-            int tex;
-            if (fabsf(avx) < 0.01f && ground)
-                tex = kTexStand + alien;
+            if (fabsf(SF(s, F_AVX, env)) < 0.01f && ground)
+                want_tex = kTexStand + alien;
             else if (!ground)
-                tex = kTexJump + alien;
+                want_tex = kTexJump + alien;
             else if (SF(s, F_APHASE, env) > 0.5f)
-                tex = kTexWalk2 + alien;
+                want_tex = kTexWalk2 + alien;
             else
-                tex = kTexWalk1 + alien;
-            const int4 d = atlas.desc[tex];
-            const float px = SF(s, F_AX, env) - 0.5f, py = SF(s, F_AY, env) - 2.0f;
-            const bool ok = resolve_draw(cam, d.y, d.z, d.x, px * kUnitPx, py * kUnitPx, kUnitPx / d.y, 1.0f,
-                                         (sflags & kFlagForward) == 0, false, mine);
-            wave_replay(fb, atlas, mine, ok ? 1ull : 0ull, lane);
+                want_tex = kTexWalk1 + alien;
         }
+        const int4 d = descs.at(want_tex);
+        bool has = false;
+        if (is_part) {
+            has = particle(part_life, part_x, part_y, mine);
+        } else if (is_sprite) {
+            if (spr_dyn & kDynTexSet) {
+                const float scale = 1.0f * 1.0f;
+                has = resolve_draw(cam, d.y, d.z, d.x, (spr_x + -0.5f) * kUnitPx, (spr_y + -0.5f) * kUnitPx,
+                                   scale * kUnitPx / d.y, 1.0f, (spr_dyn & kDynFlip) != 0, false, mine);
+            }
+        } else if (is_agent) {
+            const float px = SF(s, F_AX, env) - 0.5f, py = SF(s, F_AY, env) - 2.0f;
+            has = resolve_draw(cam, d.y, d.z, d.x, px * kUnitPx, py * kUnitPx, kUnitPx / d.y, 1.0f,
+                               (sflags & kFlagForward) == 0, false, mine);
+        }
+        wave_replay(fb, atlas, mine, __ballot(has), lane);
     }
     if (!(flags & 8)) wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane);
 }

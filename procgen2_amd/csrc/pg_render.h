@@ -41,6 +41,40 @@ struct ComposeLds {
 };
 constexpr int kMaxSpan = 8;  // a tile of the layer covers at most this many pixels per axis (coinrun 5–6, maze 3)
 
+// The atlas descriptor table held in registers, two entries per lane (tables up to 128 textures): one pair of
+// global loads at kernel start instead of a dependent global lookup in front of every draw.
+struct DescRegs {
+    int4 lo, hi;  // lane l: desc[l], desc[l + 64]
+    PG_D static DescRegs load(const AtlasView& atlas, int lane) {
+        DescRegs d;
+        d.lo = lane < atlas.count ? atlas.desc[lane] : make_int4(0, 1, 1, 0);
+        d.hi = lane + 64 < atlas.count ? atlas.desc[lane + 64] : make_int4(0, 1, 1, 0);
+        return d;
+    }
+    // per-lane index (every lane must call this: cross-lane reads)
+    PG_D int4 at(int t) const {
+        const int l = t & 63;
+        const bool up = t >= 64;
+        int4 r;
+        r.x = up ? __shfl(hi.x, l) : __shfl(lo.x, l);
+        r.y = up ? __shfl(hi.y, l) : __shfl(lo.y, l);
+        r.z = up ? __shfl(hi.z, l) : __shfl(lo.z, l);
+        r.w = 0;
+        return r;
+    }
+    // wave-uniform index
+    PG_D int4 uniform(int t) const {
+        const int l = __builtin_amdgcn_readfirstlane(t) & 63;
+        const bool up = __builtin_amdgcn_readfirstlane(t) >= 64;
+        int4 r;
+        r.x = up ? __builtin_amdgcn_readlane(hi.x, l) : __builtin_amdgcn_readlane(lo.x, l);
+        r.y = up ? __builtin_amdgcn_readlane(hi.y, l) : __builtin_amdgcn_readlane(lo.y, l);
+        r.z = up ? __builtin_amdgcn_readlane(hi.z, l) : __builtin_amdgcn_readlane(lo.z, l);
+        r.w = 0;
+        return r;
+    }
+};
+
 // Broadcast a resolved draw from lane `src` (wave-uniform) into scalar registers.
 PG_D Blit blit_from_lane(const Blit& mine, int src) {
     Blit b;
