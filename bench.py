@@ -26,6 +26,23 @@ ALGO_BYTES_PER_ENV_STEP = 12297  # 12288 obs write + 4 action read + 4 reward wr
 HBM_PEAK_GBPS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def measured_traffic(game):
+    """HBM bytes per render launch from the committed PMC passes (tools/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in
+    separate rocprofv3 --pmc runs of this same command at 65 536 envs; KB → bytes, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md §HBM prescribes for gfx950).  PMC counters cannot be read inside a timed run, so this is
+    the latest profile on record, or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic_pmc.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        data = json.load(f)
+    entry = data.get("pg::%s::render_kernel" % game)
+    if not entry:
+        return None, None
+    return entry["bytes_corrected"], os.path.relpath(files[-1], ROOT)
+
+
 def cpu_baseline(game, run_seed, budget_s=20.0):
     """The CPU restatement (oracle/, kind "port") on a bounded sample of the same workload: same seeds
     (1 + env index), same action hash, same auto-reset policy, rendering on, one thread per host core."""
@@ -105,6 +122,7 @@ def main():
         value = total_steps / elapsed
         render_avg_ms = render_ms / a.steps
         achieved = ALGO_BYTES_PER_ENV_STEP * a.envs / (render_avg_ms * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(a.game) if a.envs == 65536 else (None, None)
         line = {
             "metric": "env-steps/sec at 65536 envs, 64x64x3 obs",
             "value": value,
@@ -123,7 +141,8 @@ def main():
                        "game": a.game, "envs_per_gpu": a.envs, "obs": "64x64x3 uint8", "parallelism": "env-shard x%d, no collective" % n_gpus},
             "obs_write_GBps": value * 12288 / 1e9,
             "roofline": {"bound": "hbm", "kernel": "%s::render_kernel" % a.game, "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * a.envs,
                          "avg_launch_ms": render_avg_ms},
             "done_fraction_last_step": done_frac,
