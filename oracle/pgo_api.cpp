@@ -18,7 +18,7 @@ void pgo_put_texture(const char* name, int w, int h, const uint8_t* rgba) {
 
 int pgo_texture_count() { return static_cast<int>(pgo::TextureBank::global().size()); }
 
-// game: "coinrun" | "maze".  Returns nullptr for unknown games.
+// game: "coinrun" | "maze" | "bossfight".  Returns nullptr for unknown games.
 void* pgo_make(const char* game, uint32_t seed, int render_enabled) {
     std::string g(game);
     Env* e = nullptr;
@@ -26,6 +26,8 @@ void* pgo_make(const char* game, uint32_t seed, int render_enabled) {
         e = pgo::new_coinrun();
     else if (g == "maze")
         e = pgo::new_maze();
+    else if (g == "bossfight")
+        e = pgo::new_bossfight();
     if (!e) return nullptr;
     e->set_render_enabled(render_enabled != 0);
     e->make(seed);

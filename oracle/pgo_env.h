@@ -72,5 +72,6 @@ class Env {
 
 Env* new_coinrun();
 Env* new_maze();
+Env* new_bossfight();
 
 }  // namespace pgo

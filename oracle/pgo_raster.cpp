@@ -3,6 +3,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 
 namespace pgo {
 
@@ -45,12 +46,12 @@ void Surface::clear_black() {
 //        a = A;  if mod != 255: a = a*mod/255;   a == 0 → pixel untouched
 //        s = (a < 255) ? C*a/255 : C;   D = s + (255-a)*D/255     for C in R,G,B (and A likewise)
 //  S5  target clip: pixels outside the surface are dropped.
-//  S6  rotation (angle != 0): reserved for the rotated-sprite games; not reachable from coinrun/maze.
+//  S6  rotation (angle != 0, whole texture as source, no flip): see spec_blit_rotated below.
 void spec_blit(Surface& target, const Texture& tex, float fsx, float fsy, float fsw, float fsh, float fdx, float fdy,
                float fdw, float fdh, double angle_deg, int flip, int alpha_mod) {
     if (angle_deg != 0.0) {
-        std::fprintf(stderr, "pgo::spec_blit: rotated blits are not part of the spec yet\n");
-        std::abort();
+        spec_blit_rotated(target, tex, fdx, fdy, fdw, fdh, angle_deg, alpha_mod);
+        return;
     }
     // S1: a destination that is not finite, narrower than one pixel or absurdly large draws nothing
     // (the reference's crop arithmetic yields 0*inf = NaN for sprites that end exactly on the viewport edge).
@@ -83,6 +84,55 @@ void spec_blit(Surface& target, const Texture& tex, float fsx, float fsy, float 
             if (alpha_mod != 255) a = a * alpha_mod / 255;
             if (a == 0) continue;
             uint8_t* d = &target.px[(size_t(ty) * target.w + tx) * 4];
+            for (int c = 0; c < 3; c++) {
+                const int sc = (a < 255) ? s[c] * a / 255 : s[c];
+                d[c] = static_cast<uint8_t>(sc + (255 - a) * d[c] / 255);
+            }
+            d[3] = static_cast<uint8_t>(a + (255 - a) * d[3] / 255);
+        }
+    }
+}
+
+// S6.  The destination rectangle (truncated as in S1) is rotated clockwise by `angle_deg` about its centre and
+// every target pixel whose centre falls inside the rotated rectangle takes the texel that S3 assigns to the
+// un-rotated column/row it maps back to.  All arithmetic is integer once sine and cosine are fixed:
+//   theta  = (float)(angle_deg * (pi / 180))          (double product, rounded to float)
+//   sn, cs = round(sinf(theta) * 65536), round(cosf(theta) * 65536)   (glibc sinf/cosf; 16.16 fixed point)
+//   for a pixel (X, Y): px = 2*(X-dx) + 1 - dw, py = 2*(Y-dy) + 1 - dh        (doubled offsets from the centre)
+//     lx = px*cs + py*sn + dw*65536,  ly = -px*sn + py*cs + dh*65536          (doubled, 16.16)
+//     inside iff 0 <= lx < 2*dw*65536 and 0 <= ly < 2*dh*65536;  i = lx >> 17, j = ly >> 17
+//   pixels scanned: the square of half-side ceil(sqrt(dw*dw + dh*dh) / 2) + 1 around the centre, clipped (S5).
+void spec_blit_rotated(Surface& target, const Texture& tex, float fdx, float fdy, float fdw, float fdh, double angle_deg,
+                       int alpha_mod) {
+    if (!(fdw >= 1.0f && fdh >= 1.0f && fdw < 32768.0f && fdh < 32768.0f)) return;
+    if (!(fdx > -32768.0f && fdx < 32768.0f && fdy > -32768.0f && fdy < 32768.0f)) return;
+    const int dx = static_cast<int>(fdx), dy = static_cast<int>(fdy);
+    const int dw = static_cast<int>(fdw), dh = static_cast<int>(fdh);
+    const float theta = static_cast<float>(angle_deg * (3.14159265358979323846 / 180.0));
+    const int sn = static_cast<int>(std::floor(static_cast<double>(sinf(theta)) * 65536.0 + 0.5));
+    const int cs = static_cast<int>(std::floor(static_cast<double>(cosf(theta)) * 65536.0 + 0.5));
+    int reach = 1;
+    while (reach * reach * 4 < dw * dw + dh * dh) reach++;  // ceil(sqrt(dw²+dh²)/2)
+    reach += 1;
+    const int cx2 = 2 * dx + dw, cy2 = 2 * dy + dh;  // doubled centre
+    const int x_lo = (cx2 - 2 * reach) / 2 - 1, x_hi = (cx2 + 2 * reach) / 2 + 1;
+    const int y_lo = (cy2 - 2 * reach) / 2 - 1, y_hi = (cy2 + 2 * reach) / 2 + 1;
+    for (int Y = y_lo; Y <= y_hi; Y++) {
+        if (Y < 0 || Y >= target.h) continue;
+        for (int X = x_lo; X <= x_hi; X++) {
+            if (X < 0 || X >= target.w) continue;
+            const int px = 2 * (X - dx) + 1 - dw, py = 2 * (Y - dy) + 1 - dh;
+            const int64_t lx = int64_t(px) * cs + int64_t(py) * sn + int64_t(dw) * 65536;
+            const int64_t ly = -int64_t(px) * sn + int64_t(py) * cs + int64_t(dh) * 65536;
+            if (lx < 0 || ly < 0 || lx >= int64_t(2 * dw) * 65536 || ly >= int64_t(2 * dh) * 65536) continue;
+            const int i = static_cast<int>(lx >> 17), j = static_cast<int>(ly >> 17);
+            const int u = static_cast<int>((int64_t(2 * i + 1) * tex.w) / (2 * int64_t(dw)));
+            const int v = static_cast<int>((int64_t(2 * j + 1) * tex.h) / (2 * int64_t(dh)));
+            const uint8_t* s = &tex.rgba[(size_t(v) * tex.w + u) * 4];
+            int a = s[3];
+            if (alpha_mod != 255) a = a * alpha_mod / 255;
+            if (a == 0) continue;
+            uint8_t* d = &target.px[(size_t(Y) * target.w + X) * 4];
             for (int c = 0; c < 3; c++) {
                 const int sc = (a < 255) ? s[c] * a / 255 : s[c];
                 d[c] = static_cast<uint8_t>(sc + (255 - a) * d[c] / 255);

@@ -47,6 +47,9 @@ struct Surface {
 void spec_blit(Surface& target, const Texture& tex, float sx, float sy, float sw, float sh, float dx, float dy,
                float dw, float dh, double angle_deg, int flip, int alpha_mod);
 
+void spec_blit_rotated(Surface& target, const Texture& tex, float dx, float dy, float dw, float dh, double angle_deg,
+                       int alpha_mod);
+
 // renderer.h:9-31 — the global renderer's camera, one per env here.
 struct Painter {
     Surface* target = nullptr;

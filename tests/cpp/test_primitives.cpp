@@ -12,6 +12,7 @@
 #include "pg_geom.h"
 #include "pg_order.h"
 #include "pg_rng.h"
+#include "pg_sincos.h"
 
 static int fails = 0;
 #define CHECK(cond, ...)                 \
@@ -213,7 +214,41 @@ static void test_blend() {
     std::printf("OK blend\n");
 }
 
+static void test_sincos() {
+    // Against the sinf/cosf this process is linked with (glibc; the reference games call exactly these).
+    auto bits = [](float f) {
+        uint32_t u;
+        std::memcpy(&u, &f, 4);
+        return u;
+    };
+    auto check = [&](float x) {
+        CHECK(bits(pg::sc_sinf(x)) == bits(sinf(x)), "sinf(%a): %a vs %a", x, pg::sc_sinf(x), sinf(x));
+        CHECK(bits(pg::sc_cosf(x)) == bits(cosf(x)), "cosf(%a): %a vs %a", x, pg::sc_cosf(x), cosf(x));
+    };
+    // every float in [2^-13, 8) and its negative, stride 7 (≈ 21 M arguments): the games' angles live here
+    for (uint32_t u = 0x39000000u; u < 0x41000000u; u += 7) {
+        float x;
+        std::memcpy(&x, &u, 4);
+        check(x);
+        check(-x);
+    }
+    // sparser sweep of everything else that is finite, including the |x| >= 120 reduction
+    for (uint32_t u = 0; u < 0x7f800000u; u += 4099) {
+        float x;
+        std::memcpy(&x, &u, 4);
+        check(x);
+        check(-x);
+    }
+    std::mt19937 meta(31337);
+    for (int i = 0; i < 2000000; i++) {
+        float x = (static_cast<float>(meta() >> 8) / 16777216.0f - 0.5f) * 2000.0f;
+        check(x);
+    }
+    std::printf("OK sincos\n");
+}
+
 int main() {
+    test_sincos();
     test_blend();
     test_mt();
     test_distributions();

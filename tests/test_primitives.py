@@ -8,9 +8,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_primitives_match_libstdcxx(tmp_path):
     exe = str(tmp_path / "test_primitives")
-    subprocess.run(["g++", "-std=gnu++17", "-O2", "-ffp-contract=off", "-I" + os.path.join(ROOT, "procgen2_amd", "csrc"),
+    subprocess.run(["g++", "-std=gnu++17", "-O2", "-mfma", "-ffp-contract=off", "-I" + os.path.join(ROOT, "procgen2_amd", "csrc"),
                     os.path.join(ROOT, "tests", "cpp", "test_primitives.cpp"), "-o", exe], check=True)
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
-    for section in ("OK blend", "OK mt19937", "OK distributions", "OK hash_order", "OK sort", "ALL OK"):
+    for section in ("OK sincos", "OK blend", "OK mt19937", "OK distributions", "OK hash_order", "OK sort", "ALL OK"):
         assert section in out.stdout
