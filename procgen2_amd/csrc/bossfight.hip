@@ -1,0 +1,834 @@
+// bossfight on gfx950: a shooter without a tile map — boss phase machine, 64 + 32
+// bullets, 8 explosions, and the per-env mt19937 consumed INSIDE the step.
+//
+// Reference:
+//   step   games/bossfight/bossfight.cpp:294-345, common_systems.cpp:199-390 (boss), :494-683 (agent),
+//          :103-185 (fire_pattern), :187-197 (show_damage)
+//   render games/bossfight/bossfight.cpp:401-424, common_systems.cpp:392-450, :685-721, :22-48
+//   reset  games/bossfight/bossfight.cpp:426-504, common_systems.cpp:452-470, :724-737
+// Config = the reference's compile-time default, hard_mode (common_systems.h:63-65).
+//
+// Same machine mapping as coinrun.hip: logic one lane per env over struct-of-arrays state, render one wavefront
+// per env with the target in LDS.  std::cos/std::sin(float) are pg_sincos.h (bit-identical to the glibc the
+// reference links); every `M_PI` expression keeps the reference's float/double promotion points.
+//
+// Entity ids are fixed by creation order (player 0, boss 1, barriers 2..): the hazard set therefore iterates
+// barriers newest-first, then the boss (libstdc++ unordered_set with 13 buckets, one id per bucket, each insert
+// goes to the list head — SURVEY.md T3), which is the order first-hit tests below use.
+#include "pg_engine.h"
+#include "pg_geom.h"
+#include "pg_render.h"
+#include "pg_rng.h"
+#include "pg_sincos.h"
+
+namespace pg {
+namespace bossfight {
+
+constexpr int kAgentShots = 32, kBossShots = 64, kBooms = 8, kRocks = 4;
+constexpr double kPi = 3.14159265358979323846;  // M_PI
+
+enum Tex {
+    kTexSpace = 0,    // 13 backgrounds
+    kTexRock = 13,    // 8 barrier sprites
+    kTexBoss = 21,    // 4
+    kTexPlayer = 25,  // 4
+    kTexLaser = 29,   // 3
+    kTexBoom = 32,    // 5
+    kTexShield = 37,
+    kTexCount = 38
+};
+
+// per-env scalar floats
+enum {
+    F_AX, F_AY, F_AVX, F_AVY, F_ATIMER, F_BX, F_BY, F_BVX, F_BVY, F_PHASE_T, F_ATTACK_T, F_EXPLO_T, F_DAMAGE_T,
+    F_MOVE_T, F_COUNT
+};
+// per-env scalar ints
+enum {
+    I_FLAGS, I_A_NEXT, I_A_COUNT, I_PHASE, I_WEAPON, I_HP, I_B_NEXT, I_B_COUNT, I_X_NEXT, I_X_COUNT, I_SKINS, I_NROCKS,
+    I_COUNT
+};
+constexpr int kFlagAlive = 1, kFlagListed = 2;
+// I_SKINS: a_ship | a_laser<<4 | b_ship<<8 | b_laser<<12 | backdrop<<16
+// shot fields (floats); agent shots also have a "bouncing" byte
+enum { S_X, S_Y, S_VX, S_VY, S_ROT, S_FRAME, S_BOUNCE_T, S_COUNT };
+
+struct State {
+    int n;
+    uint32_t* mt;   // [n][625]
+    float* f;       // [F_COUNT][n]
+    int32_t* i;     // [I_COUNT][n]
+    float* ashot;   // [S_COUNT][32][n]
+    uint8_t* abnc;  // [32][n]  bouncing flag
+    float* bshot;   // [S_COUNT][64][n]   (S_BOUNCE_T unused)
+    float* boom;    // [3][8][n]  x, y, frame
+    float* rock;    // [3][4][n]  x, y, texture index
+};
+
+PG_D float& SF(const State& s, int field, int env) { return s.f[size_t(field) * s.n + env]; }
+PG_D int32_t& SI(const State& s, int field, int env) { return s.i[size_t(field) * s.n + env]; }
+PG_D float& AS(const State& s, int field, int k, int env) { return s.ashot[(size_t(field) * kAgentShots + k) * s.n + env]; }
+PG_D uint8_t& AB(const State& s, int k, int env) { return s.abnc[size_t(k) * s.n + env]; }
+PG_D float& BS(const State& s, int field, int k, int env) { return s.bshot[(size_t(field) * kBossShots + k) * s.n + env]; }
+PG_D float& BM(const State& s, int field, int k, int env) { return s.boom[(size_t(field) * kBooms + k) * s.n + env]; }
+PG_D float& RK(const State& s, int field, int k, int env) { return s.rock[(size_t(field) * kRocks + k) * s.n + env]; }
+
+// Observation camera: size 64, scale 1 (bossfight.cpp:413-414).  reset() and both update()s read these from the
+// renderer; for observation-only use they never change (D15).
+constexpr float kCamSize = 64.0f, kCamScale = 1.0f;
+
+PG_D Box screen_box() {  // common_systems.cpp:224-226, 513-515
+    return Box{-kCamSize / kCamScale * kPxUnit * 0.5f, -kCamSize / kCamScale * kPxUnit * 0.5f,
+               kCamSize / kCamScale * kPxUnit, kCamSize / kCamScale * kPxUnit};
+}
+
+// ------------------------------------------------------------------------------------------------
+// reset (bossfight.cpp:426-504)
+// ------------------------------------------------------------------------------------------------
+PG_D void new_level(const State& s, int env) {
+    uint32_t* mt = s.mt + size_t(env) * kMtWords;
+    SF(s, F_AX, env) = rng_real(mt, -1.0f, 1.0f) * kCamSize / kCamScale * kPxUnit * 0.5f;
+    SF(s, F_AY, env) = kCamSize / kCamScale * kPxUnit * 0.5f;
+    SF(s, F_AVX, env) = 0.0f;
+    SF(s, F_AVY, env) = 0.0f;
+    SF(s, F_BX, env) = 0.0f;
+    SF(s, F_BY, env) = 0.0f;
+    SF(s, F_BVX, env) = 0.0f;
+    SF(s, F_BVY, env) = 0.0f;
+    SF(s, F_PHASE_T, env) = 0.0f;
+    SF(s, F_ATTACK_T, env) = 0.0f;
+    SI(s, I_PHASE, env) = 0;
+    SI(s, I_WEAPON, env) = 0;
+    SI(s, I_HP, env) = 0;
+
+    const int want = rng_int(mt, 1, 4);
+    Box placed[kRocks];
+    int n_rocks = 0;
+    for (int k = 0; k < want; k++) {
+        const float px = rng_real(mt, -1.0f, 1.0f) * kCamSize / kCamScale * kPxUnit * 0.5f * 0.9f;
+        const float py = kCamSize / kCamScale * kPxUnit * 0.5f - rng_real(mt, 0.7f, 1.2f);
+        const Box wc{px + -0.1f, py + -0.1f, 0.2f, 0.2f};
+        bool clash = false;
+        for (int j = 0; j < k; j++)
+            if (box_hit(wc, placed[j])) {
+                clash = true;
+                break;
+            }
+        if (!clash) {
+            RK(s, 0, n_rocks, env) = px;
+            RK(s, 1, n_rocks, env) = py;
+            RK(s, 2, n_rocks, env) = static_cast<float>(rng_int(mt, 0, 7));
+            n_rocks++;
+            placed[k] = wc;
+        } else {
+            placed[k] = Box{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    }
+    SI(s, I_NROCKS, env) = n_rocks;
+    const int backdrop = rng_int(mt, 0, 12);
+    rng_real(mt, 0.0f, 1.0f);  // current_background_offset_x / _y: drawn, never used
+    rng_real(mt, 0.0f, 1.0f);
+    // System_Agent::reset, then System_Mob_AI::reset
+    SI(s, I_A_NEXT, env) = 0;
+    SI(s, I_A_COUNT, env) = 0;
+    SF(s, F_ATIMER, env) = 0.0f;
+    const int a_ship = rng_int(mt, 0, 3);
+    const int a_laser = rng_int(mt, 0, 2);
+    SI(s, I_B_NEXT, env) = 0;
+    SI(s, I_X_NEXT, env) = 0;
+    SI(s, I_B_COUNT, env) = 0;
+    SI(s, I_X_COUNT, env) = 0;
+    SF(s, F_EXPLO_T, env) = 0.0f;
+    SF(s, F_DAMAGE_T, env) = 0.0f;
+    SF(s, F_MOVE_T, env) = 0.0f;
+    const int b_ship = rng_int(mt, 0, 3);
+    const int b_laser = rng_int(mt, 0, 2);
+    SI(s, I_SKINS, env) = a_ship | (a_laser << 4) | (b_ship << 8) | (b_laser << 12) | (backdrop << 16);
+    SI(s, I_FLAGS, env) = kFlagAlive;  // agent alive; sprite draw list cleared (D2)
+}
+
+// ------------------------------------------------------------------------------------------------
+// step (bossfight.cpp:308-325)
+// ------------------------------------------------------------------------------------------------
+struct Live {  // the hot scalars of one env, kept in registers over the four sub-steps
+    float ax, ay, avx, avy, atimer;
+    float bx, by, bvx, bvy, phase_t, attack_t, explo_t, damage_t, move_t;
+    int a_next, a_count, phase, weapon, hp, b_next, b_count, x_next, x_count, n_rocks;
+    bool a_alive;
+};
+
+PG_D Box hazard_box(const State& s, int env, const Live& v, int h) {  // h: 0..n_rocks-1 barrier, n_rocks = boss
+    if (h == v.n_rocks) return Box{v.bx + -0.6f, v.by + -0.4f, 1.2f, 0.8f};
+    return Box{RK(s, 0, h, env) + -0.1f, RK(s, 1, h, env) + -0.1f, 0.2f, 0.2f};
+}
+
+PG_D void boss_fire(const State& s, int env, Live& v, float rotation, float speed) {  // common_systems.cpp:75-88
+    if (v.b_count < kBossShots) {
+        const int k = v.b_next;
+        BS(s, S_ROT, k, env) = rotation;
+        BS(s, S_VX, k, env) = sc_cosf(rotation) * speed;
+        BS(s, S_VY, k, env) = -sc_sinf(rotation) * speed;
+        BS(s, S_X, k, env) = v.bx;
+        BS(s, S_Y, k, env) = v.by;
+        BS(s, S_FRAME, k, env) = 0.0f;
+        v.b_next = (v.b_next + 1) % kBossShots;
+        v.b_count++;
+    }
+}
+
+PG_D void fire_pattern(const State& s, int env, Live& v, uint32_t* mt, int pattern, float dt) {  // :103-185
+    const float bullet_speed = 0.1f;  // hard_mode
+    float& timer = v.attack_t;
+    switch (pattern) {
+        case -1:
+            if (rng_real(mt, 0.0f, 1.0f) < 0.1f * dt)
+                boss_fire(s, env, v, static_cast<float>(kPi * (1.0f + rng_real(mt, 0.0f, 1.0f))), bullet_speed);
+            break;
+        case 0:
+            if (timer >= 8.0f) {
+                timer = 0.0f;
+                for (int k = 0; k < 5; k++)
+                    boss_fire(s, env, v, static_cast<float>(kPi * 1.5f + (k - 2) * kPi * 0.125f), bullet_speed);
+            } else
+                timer += dt;
+            break;
+        case 1:
+            if (timer >= 5.0f) {
+                timer = 0.0f;
+                int q = static_cast<int>(timer / 5.0f);
+                q = abs(8 - (q % 16));
+                for (int k = 0; k < 4; k++)
+                    boss_fire(s, env, v, static_cast<float>(kPi * (1.25f + q * 0.0625f) + k * kPi * 0.5f), bullet_speed);
+            } else
+                timer += dt;
+            break;
+        case 2:
+            if (timer >= 10.0f) {
+                timer = 0.0f;
+                const float offset = static_cast<float>(rng_real(mt, 0.0f, 1.0f) * 2.0f * kPi);
+                for (int k = 0; k < 8; k++)
+                    boss_fire(s, env, v, static_cast<float>(kPi * 0.25f * k + offset), bullet_speed);
+            } else
+                timer += dt;
+            break;
+        case 3:
+            if (timer >= 4.0f) {
+                timer = 0.0f;
+                boss_fire(s, env, v, static_cast<float>(kPi * (1.0f + rng_real(mt, 0.0f, 1.0f))), bullet_speed);
+            } else
+                timer += dt;
+            break;
+    }
+}
+
+PG_D bool agent_update(const State& s, int env, Live& v, uint32_t* mt, float dt, int action) {  // :494-683
+    const float mixrate = 0.5f, speed = 0.1f, bullet_time = 5.0f, bullet_speed = 0.1f;
+    const float bounce_speed = 0.05f, bounce_time = 10.0f, explosion_rate = 0.3f;
+    const Box scr = screen_box();
+    const float mx = static_cast<float>((action == 6 || action == 7 || action == 8) -
+                                        (action == 0 || action == 1 || action == 2));
+    const float my = static_cast<float>((action == 2 || action == 5 || action == 8) -
+                                        (action == 0 || action == 3 || action == 6));
+    const bool fire = action == 9;
+    v.avx += mixrate * (mx * speed - v.avx) * dt;
+    v.avy += mixrate * (-my * speed - v.avy) * dt;
+    v.ax += v.avx * dt;
+    v.ay += v.avy * dt;
+    Box wc{v.ax + -0.15f, v.ay + -0.1f, 0.3f, 0.2f};
+    if (wc.x < scr.x) {
+        v.ax += scr.x - wc.x;
+        v.avx = 0.0f;
+    } else if (wc.x + wc.w > scr.x + scr.w) {
+        v.ax += scr.x + scr.w - (wc.x + wc.w);
+        v.avx = 0.0f;
+    }
+    if (wc.y < scr.y) {
+        v.ay += scr.y - wc.y;
+        v.avy = 0.0f;
+    } else if (wc.y + wc.h > scr.y + scr.h) {
+        v.ay += scr.y + scr.h - (wc.y + wc.h);
+        v.avy = 0.0f;
+    }
+    wc = Box{v.ax + -0.15f, v.ay + -0.1f, 0.3f, 0.2f};
+    if (fire) {
+        if (v.atimer == 0.0f && v.a_count < kAgentShots) {
+            v.atimer = bullet_time;
+            const int k = v.a_next;
+            AS(s, S_ROT, k, env) = 0.0f;
+            AS(s, S_VX, k, env) = 0.0f;
+            AS(s, S_VY, k, env) = -bullet_speed;
+            AS(s, S_X, k, env) = v.ax;
+            AS(s, S_Y, k, env) = v.ay;
+            AS(s, S_FRAME, k, env) = 0.0f;
+            AS(s, S_BOUNCE_T, k, env) = 0.0f;
+            AB(s, k, env) = 0;
+            v.a_next = (v.a_next + 1) % kAgentShots;
+            v.a_count++;
+        } else {
+            v.atimer = fmaxf(0.0f, v.atimer - dt);
+        }
+    }
+    for (int h = 0; h <= v.n_rocks; h++)  // any hazard: a boolean, order-free
+        if (box_hit(wc, hazard_box(s, env, v, h))) {
+            v.a_alive = false;
+            break;
+        }
+    for (int i = 0; i < v.a_count; i++) {  // a_count shrinks inside the loop, as in the reference
+        const int k = (kAgentShots + v.a_next - 1 - i) % kAgentShots;
+        float frame = AS(s, S_FRAME, k, env);
+        if (frame == -1.0f) continue;
+        float px = AS(s, S_X, k, env), py = AS(s, S_Y, k, env);
+        float vx = AS(s, S_VX, k, env), vy = AS(s, S_VY, k, env);
+        float btimer = AS(s, S_BOUNCE_T, k, env);
+        bool bouncing = AB(s, k, env) != 0;
+        if (frame == 0.0f) {
+            const Box sb{px - 0.01f, py - 0.01f, 0.02f, 0.02f};
+            if (!box_hit(sb, scr)) {
+                vx = vy = 0.0f;
+                frame = 5.0f;
+            } else {
+                // hazard set order: barriers newest-first, then the boss
+                for (int step = 0; step <= v.n_rocks; step++) {
+                    const int h = step < v.n_rocks ? v.n_rocks - 1 - step : v.n_rocks;
+                    if (!box_hit(sb, hazard_box(s, env, v, h))) continue;
+                    if (h == v.n_rocks) {
+                        if (v.phase % 2 == 0) {  // shielded: bounce off
+                            vx = rng_real(mt, -1.0f, 1.0f) * bounce_speed;
+                            vy = bounce_speed;
+                            btimer = bounce_time;
+                            bouncing = true;
+                        } else {
+                            vx = vy = 0.0f;
+                            frame = 1.0f;
+                            if (v.hp > 0) v.hp--;
+                        }
+                    } else {
+                        vx = vy = 0.0f;
+                        frame = 1.0f;
+                    }
+                    break;
+                }
+            }
+        }
+        px += vx * dt;
+        py += vy * dt;
+        bool destroy = false;
+        if (frame >= 5.0f)
+            destroy = true;
+        else if (frame >= 1.0f)
+            frame += explosion_rate * dt;
+        if (bouncing) {
+            if (btimer > 0.0f)
+                btimer = fmaxf(0.0f, btimer - dt);
+            else
+                destroy = true;
+        }
+        if (destroy) {
+            v.a_count--;
+            frame = -1.0f;
+        }
+        AS(s, S_X, k, env) = px;
+        AS(s, S_Y, k, env) = py;
+        AS(s, S_VX, k, env) = vx;
+        AS(s, S_VY, k, env) = vy;
+        AS(s, S_FRAME, k, env) = frame;
+        AS(s, S_BOUNCE_T, k, env) = btimer;
+        AB(s, k, env) = bouncing ? 1 : 0;
+    }
+    return v.a_alive;
+}
+
+PG_D bool boss_update(const State& s, int env, Live& v, uint32_t* mt, float dt) {  // :199-390
+    const float shielded_time = 180.0f + rng_real(mt, 0.0f, 1.0f) * 80.0f;  // drawn every sub-step (D14)
+    const float unshielded_time = 300.0f, explosion_rate = 0.3f, move_time = 70.0f, damage_time = 80.0f;
+    const int boss_hp = 3;
+    bool alive = true;
+    const Box agent_rect{v.ax + -0.15f, v.ay + -0.1f, 0.3f, 0.2f};
+    const Box scr = screen_box();
+
+    if (v.phase_t == 0.0f) {
+        v.weapon = rng_int(mt, 0, 3);
+        v.attack_t = 0.0f;
+        v.hp = boss_hp;
+    }
+    if (v.phase % 2 == 0) {
+        if (v.phase_t >= shielded_time) {
+            v.phase_t = 0.0f;
+            v.phase++;
+        } else
+            v.phase_t += dt;
+        fire_pattern(s, env, v, mt, v.weapon, dt);
+    } else {
+        if (v.phase_t >= unshielded_time) {
+            v.phase_t = 0.0f;
+            v.phase++;
+        } else
+            v.phase_t += dt;
+        fire_pattern(s, env, v, mt, -1, dt);
+        if (v.hp == 0) {
+            if (v.explo_t >= 8.0f) {  // show_damage → explode (:187-197, :91-101)
+                v.explo_t = 0.0f;
+                const float ox = rng_real(mt, -0.5f, 0.5f) + v.bx;
+                const float oy = rng_real(mt, -0.5f, 0.5f) + v.by;
+                if (v.x_count < kBooms) {
+                    BM(s, 0, v.x_next, env) = ox;
+                    BM(s, 1, v.x_next, env) = oy;
+                    BM(s, 2, v.x_next, env) = 0.0f;
+                    v.x_next = (v.x_next + 1) % kBooms;
+                    v.x_count++;
+                }
+            } else
+                v.explo_t += dt;
+            if (v.damage_t >= damage_time) {
+                v.damage_t = 0.0f;
+                v.phase++;
+                v.hp = boss_hp;
+            } else
+                v.damage_t += dt;
+        }
+    }
+    if (v.move_t >= move_time) {
+        v.move_t = 0.0f;
+        const float tx = (rng_real(mt, 0.0f, 1.0f) * 2.0f - 1.0f) * 0.5f * scr.w * 0.7f;
+        const float ty = ((rng_real(mt, 0.0f, 1.0f) * 2.0f - 1.0f) * 0.5f - 0.3f) * scr.h * 0.5f;
+        v.bvx = (tx - v.bx) / move_time;
+        v.bvy = (ty - v.by) / move_time;
+    } else
+        v.move_t += dt;
+    v.bx += v.bvx * dt;
+    v.by += v.bvy * dt;
+
+    for (int i = 0; i < v.b_count; i++) {
+        const int k = (kBossShots + v.b_next - 1 - i) % kBossShots;
+        float frame = BS(s, S_FRAME, k, env);
+        if (frame == -1.0f) continue;
+        float px = BS(s, S_X, k, env), py = BS(s, S_Y, k, env);
+        float vx = BS(s, S_VX, k, env), vy = BS(s, S_VY, k, env);
+        if (frame == 0.0f) {
+            const Box sb{px - 0.01f, py - 0.01f, 0.02f, 0.02f};
+            if (!box_hit(sb, scr)) {
+                vx = vy = 0.0f;
+                frame = 5.0f;
+            } else {
+                if (box_hit(sb, agent_rect)) {
+                    BS(s, S_VX, k, env) = 0.0f;
+                    BS(s, S_VY, k, env) = 0.0f;
+                    BS(s, S_FRAME, k, env) = 1.0f;
+                    v.a_alive = false;
+                    break;  // later bullets skip this sub-step (D14)
+                }
+                for (int step = 0; step < v.n_rocks; step++) {  // barriers, newest first (the boss skips itself)
+                    const int h = v.n_rocks - 1 - step;
+                    if (box_hit(sb, hazard_box(s, env, v, h))) {
+                        vx = vy = 0.0f;
+                        frame = 1.0f;
+                        break;
+                    }
+                }
+            }
+        }
+        px += vx * dt;
+        py += vy * dt;
+        if (frame >= 5.0f) {
+            v.b_count--;
+            frame = -1.0f;
+        } else if (frame >= 1.0f)
+            frame += explosion_rate * dt;
+        BS(s, S_X, k, env) = px;
+        BS(s, S_Y, k, env) = py;
+        BS(s, S_VX, k, env) = vx;
+        BS(s, S_VY, k, env) = vy;
+        BS(s, S_FRAME, k, env) = frame;
+    }
+    for (int i = 0; i < v.x_count; i++) {
+        const int k = (kBooms + v.x_next - 1 - i) % kBooms;
+        float frame = BM(s, 2, k, env);
+        if (frame == -1.0f) continue;
+        if (frame >= 4.0f) {
+            v.x_count--;
+            frame = -1.0f;
+        } else if (frame >= 0.0f)
+            frame += explosion_rate * dt;
+        BM(s, 2, k, env) = frame;
+    }
+    if (v.phase >= 6) alive = false;
+    return alive;
+}
+
+PG_D void advance(const State& s, int env, int action, float& reward_out, bool& terminated_out) {
+    uint32_t* mt = s.mt + size_t(env) * kMtWords;
+    const int flags = SI(s, I_FLAGS, env);
+    Live v;
+    v.ax = SF(s, F_AX, env);
+    v.ay = SF(s, F_AY, env);
+    v.avx = SF(s, F_AVX, env);
+    v.avy = SF(s, F_AVY, env);
+    v.atimer = SF(s, F_ATIMER, env);
+    v.bx = SF(s, F_BX, env);
+    v.by = SF(s, F_BY, env);
+    v.bvx = SF(s, F_BVX, env);
+    v.bvy = SF(s, F_BVY, env);
+    v.phase_t = SF(s, F_PHASE_T, env);
+    v.attack_t = SF(s, F_ATTACK_T, env);
+    v.explo_t = SF(s, F_EXPLO_T, env);
+    v.damage_t = SF(s, F_DAMAGE_T, env);
+    v.move_t = SF(s, F_MOVE_T, env);
+    v.a_next = SI(s, I_A_NEXT, env);
+    v.a_count = SI(s, I_A_COUNT, env);
+    v.phase = SI(s, I_PHASE, env);
+    v.weapon = SI(s, I_WEAPON, env);
+    v.hp = SI(s, I_HP, env);
+    v.b_next = SI(s, I_B_NEXT, env);
+    v.b_count = SI(s, I_B_COUNT, env);
+    v.x_next = SI(s, I_X_NEXT, env);
+    v.x_count = SI(s, I_X_COUNT, env);
+    v.n_rocks = SI(s, I_NROCKS, env);
+    v.a_alive = (flags & kFlagAlive) != 0;
+
+    const float dt = 1.0f / 4;
+    float reward = 0.0f;
+    bool terminated = false;
+    for (int ss = 0; ss < 4; ss++) {
+        const bool agent_alive = agent_update(s, env, v, mt, dt, action);
+        const bool boss_alive = boss_update(s, env, v, mt, dt);
+        reward = (!agent_alive) * -10.0f + (!boss_alive) * 10.0f;
+        terminated = !agent_alive || !boss_alive;
+        if (terminated) break;
+    }
+
+    SF(s, F_AX, env) = v.ax;
+    SF(s, F_AY, env) = v.ay;
+    SF(s, F_AVX, env) = v.avx;
+    SF(s, F_AVY, env) = v.avy;
+    SF(s, F_ATIMER, env) = v.atimer;
+    SF(s, F_BX, env) = v.bx;
+    SF(s, F_BY, env) = v.by;
+    SF(s, F_BVX, env) = v.bvx;
+    SF(s, F_BVY, env) = v.bvy;
+    SF(s, F_PHASE_T, env) = v.phase_t;
+    SF(s, F_ATTACK_T, env) = v.attack_t;
+    SF(s, F_EXPLO_T, env) = v.explo_t;
+    SF(s, F_DAMAGE_T, env) = v.damage_t;
+    SF(s, F_MOVE_T, env) = v.move_t;
+    SI(s, I_A_NEXT, env) = v.a_next;
+    SI(s, I_A_COUNT, env) = v.a_count;
+    SI(s, I_PHASE, env) = v.phase;
+    SI(s, I_WEAPON, env) = v.weapon;
+    SI(s, I_HP, env) = v.hp;
+    SI(s, I_B_NEXT, env) = v.b_next;
+    SI(s, I_B_COUNT, env) = v.b_count;
+    SI(s, I_X_NEXT, env) = v.x_next;
+    SI(s, I_X_COUNT, env) = v.x_count;
+    SI(s, I_FLAGS, env) = (v.a_alive ? kFlagAlive : 0) | kFlagListed;  // sprite list built by the first update
+    reward_out = reward;
+    terminated_out = terminated;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) make_kernel(State s, uint32_t seed_base, int env_offset) {
+    const int env = blockIdx.x * 64 + threadIdx.x;
+    if (env >= s.n) return;
+    mt_seed(s.mt + size_t(env) * kMtWords, seed_base + static_cast<uint32_t>(env_offset + env));
+    for (int k = 0; k < kAgentShots; k++) {  // std::vector<Bullet>(32): frame = -1 ("dead"), rest zero
+        for (int f = 0; f < S_COUNT; f++) AS(s, f, k, env) = (f == S_FRAME) ? -1.0f : 0.0f;
+        AB(s, k, env) = 0;
+    }
+    for (int k = 0; k < kBossShots; k++)
+        for (int f = 0; f < S_COUNT; f++) BS(s, f, k, env) = (f == S_FRAME) ? -1.0f : 0.0f;
+    for (int k = 0; k < kBooms; k++) {
+        BM(s, 0, k, env) = 0.0f;
+        BM(s, 1, k, env) = 0.0f;
+        BM(s, 2, k, env) = -1.0f;
+    }
+    new_level(s, env);  // level 0, never observed (D1)
+}
+
+__global__ void __launch_bounds__(64) reset_kernel(State s, const uint8_t* mask, const int32_t* seeds, StepIO io) {
+    const int env = blockIdx.x * 64 + threadIdx.x;
+    if (env >= s.n) return;
+    if (mask && !mask[env]) return;
+    if (seeds) mt_seed(s.mt + size_t(env) * kMtWords, static_cast<uint32_t>(seeds[env]));
+    new_level(s, env);
+    io.reward[env] = 0.0f;
+    io.done[env] = 0;
+    io.pending[env] = 0;
+}
+
+__global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actions, uint32_t run_seed,
+                                                   uint32_t step_index, int env_offset, StepIO io) {
+    const int env = blockIdx.x * 64 + threadIdx.x;
+    if (env >= s.n) return;
+    if (io.pending[env]) {
+        new_level(s, env);
+        io.reward[env] = 0.0f;
+        io.done[env] = 0;
+        io.pending[env] = 0;
+        return;
+    }
+    const int action =
+        actions ? actions[env] : synthetic_action(run_seed, step_index, static_cast<uint32_t>(env_offset + env));
+    float reward;
+    bool terminated;
+    advance(s, env, action, reward, terminated);
+    io.reward[env] = reward;
+    io.done[env] = terminated ? 1 : 0;
+    io.pending[env] = terminated ? 1 : 0;
+}
+
+// render_game(true) (bossfight.cpp:401-424): one wavefront per env.
+__global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
+                                                    int flags) {
+    const int env = blockIdx.x;
+    if (mask && !mask[env]) return;
+    const int lane = threadIdx.x;
+    __shared__ uint32_t fb[kFbWords];
+    __shared__ ComposeLds<1> L;  // no tile layer: the composer only lays down the background
+
+    const Camera cam{0.0f, 0.0f, kCamSize, kCamSize, kCamScale};  // camera_position stays {0,0} (renderer.h:18)
+    const DescRegs descs = DescRegs::load(atlas, lane);
+    const int skins = SI(s, I_SKINS, env), sflags = SI(s, I_FLAGS, env);
+    const int a_ship = skins & 15, a_laser = (skins >> 4) & 15, b_ship = (skins >> 8) & 15, b_laser = (skins >> 12) & 15;
+    const int backdrop = (skins >> 16) & 255;
+    const int a_next = SI(s, I_A_NEXT, env), a_count = SI(s, I_A_COUNT, env);
+    const int b_next = SI(s, I_B_NEXT, env), b_count = SI(s, I_B_COUNT, env);
+    const int x_next = SI(s, I_X_NEXT, env), x_count = SI(s, I_X_COUNT, env);
+    const int n_rocks = SI(s, I_NROCKS, env), phase = SI(s, I_PHASE, env);
+    const float bx = SF(s, F_BX, env), by = SF(s, F_BY, env), ax = SF(s, F_AX, env), ay = SF(s, F_AY, env);
+    Blit mine;
+
+    Blit bg;  // bossfight.cpp:416-419
+    bool has_bg;
+    {
+        const int4 d = descs.uniform(kTexSpace + backdrop);
+        has_bg = resolve_draw(cam, d.y, d.z, d.x, -kCamSize / kCamScale * 0.5f, -kCamSize / kCamScale * 0.5f,
+                              1.0f / d.z * kCamSize / kCamScale, 1.0f, false, false, bg);
+    }
+    bool composed = false;
+    if (!(flags & 1)) {
+        compose_spans(L, cam, 0, 0, 0, 0, 1, 1, 1.0f, lane);
+        if (lane == 0) L.base[0] = static_cast<int32_t>(kNoTexel);
+        __syncthreads();
+        composed = compose_rows(fb, L, atlas, bg, has_bg, 0, 0, 1, lane, flags);
+    }
+    if (!composed) {
+        wave_clear(fb, lane);
+        mine = bg;
+        wave_replay(fb, atlas, mine, has_bg ? 1ull : 0ull, lane);
+    }
+
+    // negative-z sprites: none.  System_Mob_AI::render (common_systems.cpp:392-450): boss bullets, rotated
+    {
+        bool has = false;
+        int want_tex = kTexLaser + b_laser;
+        float px = 0.0f, py = 0.0f, rot = 0.0f;
+        if (lane < b_count) {
+            const int k = (kBossShots + b_next - 1 - lane) % kBossShots;
+            const float frame = BS(s, S_FRAME, k, env);
+            if (frame != -1.0f) {
+                has = true;
+                if (frame != 0.0f) want_tex = kTexBoom + static_cast<int>(frame - 1.0f);
+                px = BS(s, S_X, k, env);
+                py = BS(s, S_Y, k, env);
+                rot = BS(s, S_ROT, k, env);
+            }
+        }
+        const int4 d = descs.at(want_tex);
+        if (has) {
+            const float size = 0.1f;
+            has = resolve_rotated(cam, d.y, d.z, d.x, px * kUnitPx - size * d.y * 0.5f, py * kUnitPx - size * d.z * 0.5f,
+                                  static_cast<float>(rot + kPi * 0.5f), size, 1.0f, mine);
+        }
+        wave_replay(fb, atlas, mine, __ballot(has), lane);
+    }
+    // second list, one draw per lane: boss ship, shield, explosions, barriers (positive-z sprites), agent bullets, agent
+    {
+        const int first_boom = 2, first_rock = first_boom + x_count;
+        const int n_listed = (sflags & kFlagListed) ? n_rocks : 0;  // empty draw list right after a reset (D2)
+        const int first_shot = first_rock + n_listed, agent_lane = first_shot + a_count;
+        bool has = false;
+        int want_tex = 0;
+        float px = 0.0f, py = 0.0f, size = 0.0f, alpha = 1.0f;
+        bool sprite = false;
+        if (lane == 0) {
+            has = true;
+            want_tex = kTexBoss + b_ship;
+            px = bx;
+            py = by;
+            size = 0.25f;
+        } else if (lane == 1) {
+            has = (phase % 2 == 0);
+            want_tex = kTexShield;
+            px = bx;
+            py = by;
+            size = 0.25f;
+            alpha = 0.7f;
+        } else if (lane < first_rock) {
+            const int k = (kBooms + x_next - 1 - (lane - first_boom)) % kBooms;
+            const float frame = BM(s, 2, k, env);
+            if (frame != -1.0f) {
+                has = true;
+                want_tex = kTexBoom + static_cast<int>(frame);
+                px = BM(s, 0, k, env);
+                py = BM(s, 1, k, env);
+                size = 0.3f;
+            }
+        } else if (lane < first_shot) {
+            const int r = n_rocks - 1 - (lane - first_rock);  // sprite set order: newest barrier first
+            has = true;
+            sprite = true;
+            want_tex = kTexRock + static_cast<int>(RK(s, 2, r, env));
+            px = RK(s, 0, r, env);
+            py = RK(s, 1, r, env);
+        } else if (lane < agent_lane) {
+            const int k = (kAgentShots + a_next - 1 - (lane - first_shot)) % kAgentShots;
+            const float frame = AS(s, S_FRAME, k, env);
+            if (frame != -1.0f) {
+                has = true;
+                want_tex = (frame == 0.0f) ? kTexLaser + a_laser : kTexBoom + static_cast<int>(frame - 1.0f);
+                px = AS(s, S_X, k, env);
+                py = AS(s, S_Y, k, env);
+                size = 0.05f;
+            }
+        } else if (lane == agent_lane) {
+            has = true;
+            want_tex = kTexPlayer + a_ship;
+            px = ax;
+            py = ay;
+            size = 0.05f;
+        }
+        const int4 d = descs.at(want_tex);
+        if (has) {
+            if (sprite) {  // common_systems.cpp:22-48: offset (-0.15,-0.15), scale 0.3 (bossfight.cpp:479)
+                const float scale = 1.0f * 0.3f;
+                has = resolve_draw(cam, d.y, d.z, d.x, (px + -0.15f) * kUnitPx, (py + -0.15f) * kUnitPx,
+                                   scale * kUnitPx / d.y, 1.0f, false, false, mine);
+            } else {
+                has = resolve_draw(cam, d.y, d.z, d.x, px * kUnitPx - size * d.y * 0.5f, py * kUnitPx - size * d.z * 0.5f,
+                                   size, alpha, false, false, mine);
+            }
+        }
+        wave_replay(fb, atlas, mine, __ballot(has), lane);
+    }
+    wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+class BossfightGame final : public Game {
+   public:
+    const char* name() const override { return "bossfight"; }
+    std::vector<std::string> texture_names() const override {
+        std::vector<std::string> v;
+        for (const char* n : {"deep_space_01", "spacegen_01", "milky_way_01", "ez_space_lite_01", "meyespace_v1_01",
+                              "eye_nebula_01", "deep_sky_01", "space_nebula_01", "Background-1", "Background-2",
+                              "Background-3", "Background-4", "parallax-space-backgound"})
+            v.push_back(std::string("space_backgrounds/") + n + ".png");
+        for (const char* n : {"spaceMeteors_001", "spaceMeteors_002", "spaceMeteors_003", "spaceMeteors_004",
+                              "meteorGrey_big1", "meteorGrey_big2", "meteorGrey_big3", "meteorGrey_big4",
+                              "enemyShipBlack1", "enemyShipBlue2", "enemyShipGreen3", "enemyShipRed4",
+                              "playerShip1_blue", "playerShip1_green", "playerShip2_orange", "playerShip3_red",
+                              "laserGreen14", "laserRed11", "laserBlue09", "explosion1", "explosion2", "explosion3",
+                              "explosion4", "explosion5", "shield2"})
+            v.push_back(std::string("misc_assets/") + n + ".png");
+        return v;
+    }
+    std::string check_atlas(const std::vector<std::pair<int, int>>& sizes) const override {
+        return static_cast<int>(sizes.size()) == kTexCount ? "" : "bossfight: unexpected texture count";
+    }
+    static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+    struct Layout {
+        size_t mt, f, i, ashot, abnc, bshot, boom, rock, total;
+    };
+    static Layout layout(int n) {
+        Layout l{};
+        size_t off = 0;
+        auto take = [&](size_t bytes) {
+            size_t at = off;
+            off += align256(bytes);
+            return at;
+        };
+        l.mt = take(size_t(n) * kMtWords * 4);
+        l.f = take(size_t(F_COUNT) * n * 4);
+        l.i = take(size_t(I_COUNT) * n * 4);
+        l.ashot = take(size_t(S_COUNT) * kAgentShots * n * 4);
+        l.abnc = take(size_t(kAgentShots) * n);
+        l.bshot = take(size_t(S_COUNT) * kBossShots * n * 4);
+        l.boom = take(size_t(3) * kBooms * n * 4);
+        l.rock = take(size_t(3) * kRocks * n * 4);
+        l.total = off;
+        return l;
+    }
+    size_t state_bytes(int n) const override { return layout(n).total; }
+    void bind(void* d_state, int n, AtlasView atlas) override {
+        uint8_t* p = static_cast<uint8_t*>(d_state);
+        const Layout l = layout(n);
+        s_.n = n;
+        s_.mt = reinterpret_cast<uint32_t*>(p + l.mt);
+        s_.f = reinterpret_cast<float*>(p + l.f);
+        s_.i = reinterpret_cast<int32_t*>(p + l.i);
+        s_.ashot = reinterpret_cast<float*>(p + l.ashot);
+        s_.abnc = p + l.abnc;
+        s_.bshot = reinterpret_cast<float*>(p + l.bshot);
+        s_.boom = reinterpret_cast<float*>(p + l.boom);
+        s_.rock = reinterpret_cast<float*>(p + l.rock);
+        atlas_ = atlas;
+    }
+    int blocks() const { return (s_.n + 63) / 64; }
+    void launch_make(hipStream_t st, uint32_t seed_base, int env_offset) override {
+        hipLaunchKernelGGL(make_kernel, dim3(blocks()), dim3(64), 0, st, s_, seed_base, env_offset);
+    }
+    void launch_reset(hipStream_t st, const uint8_t* mask, const int32_t* seeds, StepIO io) override {
+        hipLaunchKernelGGL(reset_kernel, dim3(blocks()), dim3(64), 0, st, s_, mask, seeds, io);
+    }
+    void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
+                      StepIO io) override {
+        hipLaunchKernelGGL(logic_kernel, dim3(blocks()), dim3(64), 0, st, s_, actions, run_seed, step_index,
+                           env_offset, io);
+    }
+    void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
+        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(64), 0, st, s_, atlas_, mask, io, debug_flags);
+    }
+    // Same layout as oracle/pgo_bossfight.cpp Bossfight::dump_state.
+    int dump_state(hipStream_t st, int env, float* out, int cap) override {
+        hipStreamSynchronize(st);
+        const size_t n = s_.n;
+        auto rf = [&](const float* base, size_t idx) {
+            float v;
+            hipMemcpy(&v, base + idx, 4, hipMemcpyDeviceToHost);
+            return v;
+        };
+        auto f = [&](int field) { return rf(s_.f, size_t(field) * n + env); };
+        auto iv = [&](int field) {
+            int32_t v;
+            hipMemcpy(&v, s_.i + size_t(field) * n + env, 4, hipMemcpyDeviceToHost);
+            return static_cast<float>(v);
+        };
+        int32_t flags;
+        hipMemcpy(&flags, s_.i + size_t(I_FLAGS) * n + env, 4, hipMemcpyDeviceToHost);
+        std::vector<float> v = {f(F_AX), f(F_AY), f(F_AVX), f(F_AVY), (flags & kFlagAlive) ? 1.0f : 0.0f, f(F_ATIMER),
+                                iv(I_A_NEXT), iv(I_A_COUNT), f(F_BX), f(F_BY), f(F_BVX), f(F_BVY), f(F_PHASE_T),
+                                iv(I_PHASE), iv(I_WEAPON), f(F_ATTACK_T), iv(I_HP), iv(I_B_NEXT), iv(I_B_COUNT),
+                                iv(I_X_NEXT), iv(I_X_COUNT), f(F_EXPLO_T), f(F_DAMAGE_T), f(F_MOVE_T), iv(I_NROCKS)};
+        for (int k = 0; k < kAgentShots; k++)
+            for (int fld : {S_X, S_Y, S_FRAME}) v.push_back(rf(s_.ashot, (size_t(fld) * kAgentShots + k) * n + env));
+        for (int k = 0; k < kBossShots; k++)
+            for (int fld : {S_X, S_Y, S_FRAME}) v.push_back(rf(s_.bshot, (size_t(fld) * kBossShots + k) * n + env));
+        const int m = cap < static_cast<int>(v.size()) ? cap : static_cast<int>(v.size());
+        for (int k = 0; k < m; k++) out[k] = v[k];
+        return static_cast<int>(v.size());
+    }
+    int dump_tiles(hipStream_t, int, uint8_t*, int) override { return 0; }
+
+   private:
+    State s_{};
+    AtlasView atlas_{};
+};
+
+}  // namespace bossfight
+
+std::unique_ptr<Game> make_bossfight() { return std::make_unique<bossfight::BossfightGame>(); }
+
+}  // namespace pg

@@ -85,12 +85,13 @@ static std::string asset_root() {
     return "assets";
 }
 
-static const char* const kGameNames[kNumGames] = {"coinrun", "maze"};
+static const char* const kGameNames[kNumGames] = {"coinrun", "maze", "bossfight"};
 
 static std::unique_ptr<Game> make_game(int id) {
     switch (id) {
         case kGameCoinrun: return make_coinrun();
         case kGameMaze: return make_maze();
+        case kGameBossfight: return make_bossfight();
         default: return nullptr;
     }
 }

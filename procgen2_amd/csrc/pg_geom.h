@@ -47,7 +47,8 @@ struct Blit {
     int32_t sx, sy, sw, sh;  // source texel rect, already intersected with the texture
     int32_t tex_off;         // first texel of the texture in the atlas array
     int32_t tex_w;           // texture width (row pitch in texels)
-    int32_t flip_mod;        // bit 8: horizontal flip, bit 9: vertical flip, bits 0-7: alpha modulation
+    int32_t flip_mod;        // bit 8: horizontal flip, bit 9: vertical flip, bit 10: rotated, bits 0-7: alpha modulation
+    int32_t rot_sn, rot_cs;  // rotated draws (raster spec S6): sine / cosine of the angle in 16.16 fixed point
 };
 
 struct Camera {
@@ -58,6 +59,7 @@ struct Camera {
 
 constexpr int32_t kFlipH = 1 << 8;
 constexpr int32_t kFlipV = 1 << 9;
+constexpr int32_t kRotated = 1 << 10;
 
 // One axis of a resolved draw: destination span [d0, d0+dn) and source span [s0, s0+sn).
 struct Span {
@@ -134,6 +136,8 @@ PG_HD bool resolve_draw(const Camera& cam, int tw, int th, int tex_off, float po
     out.tex_off = tex_off;
     out.tex_w = tw;
     out.flip_mod = mod | (flip_h ? kFlipH : (flip_v ? kFlipV : 0));
+    out.rot_sn = 0;
+    out.rot_cs = 65536;
     return true;
 }
 

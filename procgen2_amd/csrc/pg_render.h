@@ -20,6 +20,7 @@
 
 #include "pg_engine.h"
 #include "pg_geom.h"
+#include "pg_sincos.h"
 
 namespace pg {
 
@@ -89,7 +90,73 @@ PG_D Blit blit_from_lane(const Blit& mine, int src) {
     b.tex_off = __builtin_amdgcn_readlane(mine.tex_off, src);
     b.tex_w = __builtin_amdgcn_readlane(mine.tex_w, src);
     b.flip_mod = __builtin_amdgcn_readlane(mine.flip_mod, src);
+    b.rot_sn = __builtin_amdgcn_readlane(mine.rot_sn, src);
+    b.rot_cs = __builtin_amdgcn_readlane(mine.rot_cs, src);
     return b;
+}
+
+PG_D void blend_into(uint32_t* fb, int idx, uint32_t texel, int mod);
+
+// Renderer::render_texture_rotated (games/*/renderer.cpp:84-101) followed by raster-spec S1 and S6: no cull, no
+// crop, whole texture as source, rotation about the centre of the destination rectangle.  `rotation` is the
+// float the reference passes; the angle handed to SDL is rotation * 180.0f / M_PI in double.  An angle of exactly
+// zero takes the un-rotated path (S3), like the oracle.
+PG_D bool resolve_rotated(const Camera& cam, int tw, int th, int tex_off, float pos_x, float pos_y, float rotation,
+                          float scale, float alpha, Blit& out) {
+    const float dx = (pos_x - cam.px) * cam.scale + cam.sw * 0.5f;
+    const float dy = (pos_y - cam.py) * cam.scale + cam.sh * 0.5f;
+    const float dw = tw * scale * cam.scale;
+    const float dh = th * scale * cam.scale;
+    int mod = 255;
+    if (alpha != 1.0f) mod = static_cast<int>(255 * alpha) & 0xff;
+    const double deg = rotation * 180.0f / 3.14159265358979323846;
+    if (!(dw >= 1.0f && dh >= 1.0f && dw < 32768.0f && dh < 32768.0f)) return false;
+    if (!(dx > -32768.0f && dx < 32768.0f && dy > -32768.0f && dy < 32768.0f)) return false;
+    out.dx = static_cast<int>(dx);
+    out.dy = static_cast<int>(dy);
+    out.dw = static_cast<int>(dw);
+    out.dh = static_cast<int>(dh);
+    out.sx = 0;
+    out.sy = 0;
+    out.sw = tw;
+    out.sh = th;
+    out.tex_off = tex_off;
+    out.tex_w = tw;
+    out.flip_mod = mod;
+    out.rot_sn = 0;
+    out.rot_cs = 65536;
+    if (deg != 0.0) {
+        const float theta = static_cast<float>(deg * (3.14159265358979323846 / 180.0));
+        out.rot_sn = static_cast<int>(floor(static_cast<double>(sc_sinf(theta)) * 65536.0 + 0.5));
+        out.rot_cs = static_cast<int>(floor(static_cast<double>(sc_cosf(theta)) * 65536.0 + 0.5));
+        out.flip_mod |= kRotated;
+    }
+    return true;
+}
+
+// Raster spec S6: all lanes execute one rotated draw (wave-uniform).  Scans the same square as the oracle.
+PG_D void wave_blit_rotated(uint32_t* fb, const AtlasView& atlas, const Blit& b, int lane) {
+    int reach = 1;
+    while (reach * reach * 4 < b.dw * b.dw + b.dh * b.dh) reach++;
+    reach += 1;
+    const int cx2 = 2 * b.dx + b.dw, cy2 = 2 * b.dy + b.dh;
+    const int x_lo = (cx2 - 2 * reach) / 2 - 1, x_hi = (cx2 + 2 * reach) / 2 + 1;
+    const int y_lo = (cy2 - 2 * reach) / 2 - 1, y_hi = (cy2 + 2 * reach) / 2 + 1;
+    const int bw = x_hi - x_lo + 1, bh = y_hi - y_lo + 1;
+    const uint32_t* tex = atlas.texels + b.tex_off;
+    const int mod = b.flip_mod & 0xff;
+    for (int p = lane; p < bw * bh; p += 64) {
+        const int ry = udiv_small(p, bw);
+        const int X = x_lo + (p - ry * bw), Y = y_lo + ry;
+        if (X < 0 || X >= kObsW || Y < 0 || Y >= kObsH) continue;
+        const int px = 2 * (X - b.dx) + 1 - b.dw, py = 2 * (Y - b.dy) + 1 - b.dh;
+        const long long lx = (long long)px * b.rot_cs + (long long)py * b.rot_sn + (long long)b.dw * 65536;
+        const long long ly = -(long long)px * b.rot_sn + (long long)py * b.rot_cs + (long long)b.dh * 65536;
+        if (lx < 0 || ly < 0 || lx >= (long long)(2 * b.dw) * 65536 || ly >= (long long)(2 * b.dh) * 65536) continue;
+        const int i = static_cast<int>(lx >> 17), j = static_cast<int>(ly >> 17);
+        const int u = sample_index(0, b.sw, i, b.dw), v = sample_index(0, b.sh, j, b.dh);
+        blend_into(fb, Y * kObsW + X, tex[v * b.tex_w + u], mod);
+    }
 }
 
 // dst OVER-composited with one texel (raster spec S4).  Wave-level fast path: when every lane's alpha is 0 or
@@ -168,11 +235,15 @@ PG_D void wave_replay(uint32_t* fb, const AtlasView& atlas, const Blit& mine, un
             const int x1 = (b.dx + b.dw) < kObsW ? (b.dx + b.dw) : kObsW;
             const int y1 = (b.dy + b.dh) < kObsH ? (b.dy + b.dh) : kObsH;
             const int cw = x1 - x0, ch = y1 - y0;
-            if (cw > 0 && ch > 0 && cw * ch > 64) {  // a big one: alone, and only at the head of a group
+            if ((b.flip_mod & kRotated) || (cw > 0 && ch > 0 && cw * ch > 64)) {
+                // a rotated or big one: alone, and only at the head of a group
                 stop = true;
                 if (g == 0) {
                     mask &= mask - 1;
-                    wave_blit(fb, atlas, b, lane);
+                    if (b.flip_mod & kRotated)
+                        wave_blit_rotated(fb, atlas, b, lane);
+                    else
+                        wave_blit(fb, atlas, b, lane);
                     __syncthreads();
                 }
                 continue;

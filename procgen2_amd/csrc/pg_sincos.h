@@ -14,10 +14,8 @@
 
 #include "pg_defs.h"
 
-#if !defined(__HIPCC__)
 #include <cmath>
 #include <cstring>
-#endif
 
 namespace pg {
 

@@ -16,7 +16,7 @@ import torch
 
 from . import lib as pglib
 
-GAMES = ("coinrun", "maze")
+GAMES = ("coinrun", "maze", "bossfight")
 
 
 def shard_range(total_envs, world_size, rank):

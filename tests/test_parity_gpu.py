@@ -56,7 +56,7 @@ def test_coinrun_lockstep_256_envs():
     assert resets > 0, "no episode ended: the auto-reset path was not exercised"
 
 
-@pytest.mark.parametrize("game", ["coinrun", "maze"])
+@pytest.mark.parametrize("game", ["coinrun", "maze", "bossfight"])
 def test_row_composer_equals_draw_list_replay(game):
     """The fused background+tile row composer (pg_render.h compose_rows) against the one-blit-at-a-time replay of
     the reference's draw list, the same engine in both modes, every byte of 512 envs over 150 steps."""
@@ -82,6 +82,31 @@ def test_maze_lockstep_with_timeouts():
     assert resets >= 96
 
 
+def test_bossfight_lockstep_many_episodes():
+    # BASELINE.json configs[3] game: ~87-step episodes under random actions, so 500 steps cross several resets per env;
+    # exercises the in-step RNG draws, the glibc-exact sin/cos twin and the rotated bullet blits (raster rule S6).
+    resets = _lockstep("bossfight", 192, 500, check_state_every=60)
+    assert resets >= 192
+
+
+def test_bossfight_fire_heavy_actions():
+    # action 9 = fire: agent bullets, shield bounces (RNG), boss hit points and the phase machine
+    n = 64
+    eng, ora = EngineVec("bossfight", n, seed_base=21), OracleVec("bossfight", n, seed_base=21)
+    assert np.array_equal(eng.reset(), ora.reset_obs())
+    rng = np.random.default_rng(5)
+    for s in range(700):
+        a = np.where(rng.random(n) < 0.6, 9, rng.integers(0, 15, n)).astype(np.int32)
+        oe, re_, de = eng.step(a)
+        oo, ro, do = ora.step(a)
+        assert np.array_equal(de, do) and np.array_equal(re_.view(np.uint32), ro.view(np.uint32)), s
+        assert np.array_equal(oe, oo), s
+    for e in range(0, n, 8):
+        assert np.array_equal(eng.state(e, 400).view(np.uint32), ora.state(e, 400).view(np.uint32)), e
+    eng.close()
+    ora.close()
+
+
 def test_maze_out_of_range_actions_follow_reference_quirk():
     # D6/D20: actions 9..15 teleport 2–3 cells in maze; others ignore them.
     n = 32
@@ -97,7 +122,7 @@ def test_maze_out_of_range_actions_follow_reference_quirk():
     ora.close()
 
 
-@pytest.mark.parametrize("game", ["coinrun", "maze"])
+@pytest.mark.parametrize("game", ["coinrun", "maze", "bossfight"])
 def test_reset_with_seed_option_and_mask(game):
     """cenv_reset's "seed" option (coinrun.cpp:313-317) per env, and masked resets leaving other envs untouched."""
     n = 16
@@ -148,7 +173,7 @@ def test_reset_with_seed_option_and_mask(game):
 def test_cenv_abi_single_env_matches_reference_loop():
     """The drop-in path: CEnv("libCoinRun.so", options={"seed": s}) → reset → step(int) … with the caller doing
     `if term: reset()` — exactly game_test.py:36-40 — against the oracle driven the same way."""
-    for libname, game in (("libCoinRun.so", "coinrun"), ("libMaze.so", "maze")):
+    for libname, game in (("libCoinRun.so", "coinrun"), ("libMaze.so", "maze"), ("libBossFight.so", "bossfight")):
         env = pgcenv.CEnv(os.path.join(pglib.LIB_DIR, libname), options={"seed": 123})
         assert list(env.observation_space) == ["screen"] and list(env.action_space) == ["action"]
         assert list(env.action_space["action"].nvec) == [15]

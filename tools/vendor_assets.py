@@ -64,7 +64,20 @@ def maze():
             "kenney/Enemies/mouse_move.png"] + TOPDOWN_BACKDROPS
 
 
-GAMES = {"coinrun": coinrun, "maze": maze}
+def bossfight():
+    # games/bossfight/bossfight.cpp:54-79, common_systems.cpp:52-68,474-488
+    space = ["deep_space_01", "spacegen_01", "milky_way_01", "ez_space_lite_01", "meyespace_v1_01", "eye_nebula_01",
+             "deep_sky_01", "space_nebula_01", "Background-1", "Background-2", "Background-3", "Background-4",
+             "parallax-space-backgound"]
+    misc = ["spaceMeteors_001", "spaceMeteors_002", "spaceMeteors_003", "spaceMeteors_004", "meteorGrey_big1",
+            "meteorGrey_big2", "meteorGrey_big3", "meteorGrey_big4", "enemyShipBlack1", "enemyShipBlue2",
+            "enemyShipGreen3", "enemyShipRed4", "playerShip1_blue", "playerShip1_green", "playerShip2_orange",
+            "playerShip3_red", "laserGreen14", "laserRed11", "laserBlue09", "shield2"] + \
+           ["explosion%d" % i for i in range(1, 6)]
+    return ["space_backgrounds/%s.png" % n for n in space] + ["misc_assets/%s.png" % n for n in misc]
+
+
+GAMES = {"coinrun": coinrun, "maze": maze, "bossfight": bossfight}
 
 
 def main():
