@@ -73,5 +73,6 @@ class Env {
 Env* new_coinrun();
 Env* new_maze();
 Env* new_bossfight();
+Env* new_climber();
 
 }  // namespace pgo

@@ -1,0 +1,578 @@
+// climber on gfx950: vertical platformer, patrol mobs, collectible crystals.
+//
+// Reference:
+//   step   games/climber/climber.cpp:323-376, common_systems.cpp:184-270 (agent), :109-168 (mobs), :66-107 (points),
+//          :8-39 (sprite list)
+//   render games/climber/climber.cpp:431-459, tilemap.cpp:172-198, common_systems.cpp:41-63, :272-298
+//   reset  games/climber/climber.cpp:461-497, tilemap.cpp:40-70, :75-170
+// Config = the reference's compile-time default (easy_mode = false, climber/tilemap.h:32-34).
+//
+// Machine mapping as in coinrun.hip: logic one lane per env over struct-of-arrays state, render one wavefront per
+// env.  Collected crystals are destroyed entities in the reference: they leave the sprite System's
+// std::unordered_set, and the z-sorted draw list is rebuilt from that set every sub-step.  Erasing from the
+// libstdc++ node list keeps the relative order of the survivors, so the device keeps the episode's insertion-built
+// order (pg_order.h, computed at reset) plus an alive bit per entity, and re-runs the introsort emulation over the
+// survivors whenever the set changed.
+#include "pg_engine.h"
+#include "pg_geom.h"
+#include "pg_order.h"
+#include "pg_render.h"
+#include "pg_rng.h"
+#include "pg_tiles.h"
+
+namespace pg {
+namespace climber {
+
+constexpr int W = 20, H = 64;
+constexpr int kMaxEnt = 34;  // ≤ 17 platforms (difficulty 3), each at most one mob and one crystal (tilemap.cpp:98-105)
+enum Tile : uint8_t { kEmpty = 0, kWallTop, kWallMid };  // tilemap.h:12-17
+
+enum Tex {
+    kTexTop = 0,    // 4 themes
+    kTexMid = 4,    // 4 themes
+    kTexStand = 8,  // 4 suits each
+    kTexJump = 12,
+    kTexWalk1 = 16,
+    kTexWalk2 = 20,
+    kTexFish = 24,  // 2 frames
+    kTexGem = 26,
+    kTexBackdrop = 27,  // 10
+    kTexCount = 37
+};
+
+enum { F_AX, F_AY, F_AVX, F_AVY, F_APHASE, F_CAMY, F_BGSHIFT, F_COUNT };
+enum { I_FLAGS, I_THEMES, I_NENT, I_NDRAW, I_HASH_SPRITE, I_COUNT };
+constexpr int kFlagGround = 1, kFlagForward = 2, kFlagListed = 4;
+enum { EF_X, EF_Y, EF_VX, EF_ANIM_T, EF_COUNT };
+enum { EB_INFO, EB_SPAWN_X, EB_ORDER, EB_DRAW, EB_COUNT };
+// EB_INFO bits
+constexpr int kMob = 1, kAlive = 2, kFrame = 4, kFlip = 8, kTexSet = 16;
+
+struct State {
+    int n;
+    uint32_t* mt;    // [n][625]
+    uint8_t* tiles;  // [n][1280]  column-major y + x*H
+    float* f;        // [F_COUNT][n]
+    int32_t* i;      // [I_COUNT][n]
+    float* ef;       // [EF_COUNT][kMaxEnt][n]
+    uint8_t* eb;     // [EB_COUNT][kMaxEnt][n]
+};
+
+PG_D float& SF(const State& s, int field, int env) { return s.f[size_t(field) * s.n + env]; }
+PG_D int32_t& SI(const State& s, int field, int env) { return s.i[size_t(field) * s.n + env]; }
+PG_D float& EF(const State& s, int field, int e, int env) { return s.ef[(size_t(field) * kMaxEnt + e) * s.n + env]; }
+PG_D uint8_t& EB(const State& s, int field, int e, int env) { return s.eb[(size_t(field) * kMaxEnt + e) * s.n + env]; }
+
+using Win = TileWinT<W, H, kWallMid>;  // out of bounds is a wall (tilemap.h:66-68)
+
+PG_D void put(uint8_t* t, int x, int y, int id) {
+    if (x < 0 || y < 0 || x >= W || y >= H) return;
+    t[y + x * H] = static_cast<uint8_t>(id);
+}
+PG_D void fill(uint8_t* t, int x, int y, int w, int h, int id) {
+    for (int a = 0; a < w; a++)
+        for (int b = 0; b < h; b++) put(t, x + a, y + b, id);
+}
+PG_D void fill_capped(uint8_t* t, int x, int y, int w, int h, int body, int cap) {
+    fill(t, x, y, w, h - 1, body);
+    fill(t, x, y + h - 1, w, 1, cap);
+}
+
+// The sprite System's set order for this episode: ids 0..n-1 inserted in creation order into a set that kept its
+// bucket array across clear() (packed = buckets | next_resize << 16).
+PG_D void episode_order(int32_t& packed, int n, uint8_t* out) {
+    int16_t next[kMaxEnt];
+    int16_t before[64];
+    HashOrder h;
+    h.next = next;
+    h.before = before;
+    h.head = kNil;
+    h.buckets = packed & 0xffff;
+    h.next_resize = packed >> 16;
+    h.count = 0;
+    if (h.buckets == 0) h.buckets = 1;
+    for (int b = 0; b < h.buckets; b++) before[b] = kNil;
+    for (int k = 0; k < n; k++) hash_insert(h, k);
+    int16_t p = static_cast<int16_t>(h.head);
+    for (int k = 0; k < n; k++) {
+        out[k] = static_cast<uint8_t>(p);
+        p = next[p];
+    }
+    packed = h.buckets | (h.next_resize << 16);
+}
+
+// System_Sprite_Render::update's list: the surviving sprites in set order, then std::sort on z (all 1.0).
+PG_D void rebuild_draw_list(const State& s, int env, int n_ent) {
+    ZItem items[kMaxEnt];
+    int n = 0;
+    for (int k = 0; k < n_ent; k++) {
+        const int e = EB(s, EB_ORDER, k, env);
+        if (EB(s, EB_INFO, e, env) & kAlive) items[n++] = {1.0f, e};
+    }
+    sort_by_key(items, n);
+    for (int k = 0; k < n; k++) EB(s, EB_DRAW, k, env) = static_cast<uint8_t>(items[k].id);
+    SI(s, I_NDRAW, env) = n;
+}
+
+PG_D void new_level(const State& s, int env) {  // climber.cpp:461-497 + tilemap.cpp:75-170
+    uint32_t* mt = s.mt + size_t(env) * kMtWords;
+    uint8_t* tiles = s.tiles + size_t(env) * (W * H);
+    const float max_jump = 1.5f, gravity = 0.2f;
+    for (int k = 0; k < W * H; k++) tiles[k] = kEmpty;
+    fill_capped(tiles, 0, 0, W, 1, kWallMid, kWallTop);
+    fill(tiles, 0, 0, 1, H, kWallMid);
+    fill(tiles, W - 1, 0, 1, H, kWallMid);
+    fill(tiles, 0, H - 1, W, 1, kWallMid);
+    const int difficulty = rng_int(mt, 1, 3);
+    const int platforms = rng_int(mt, difficulty * difficulty + 1, (difficulty + 1) * (difficulty + 1) + 1);
+    int cx = rng_int(mt, 2, W - 3), cy = 1;
+    const int margin = 3;
+    const float enemy_prob = 0.5f;
+    const float reach_y = max_jump * max_jump / (2.0f * gravity);
+    const int max_dy = static_cast<int>(reach_y - 0.5f);
+    int n_ent = 0;
+    auto spawn = [&](int x, int y, int info, float vx) {
+        const int e = n_ent++;
+        EF(s, EF_X, e, env) = static_cast<float>(x) + 0.5f;
+        EF(s, EF_Y, e, env) = static_cast<float>(H - 1 - y) + 0.5f;
+        EF(s, EF_VX, e, env) = vx;
+        EF(s, EF_ANIM_T, e, env) = 0.0f;
+        EB(s, EB_INFO, e, env) = static_cast<uint8_t>(info | kAlive);
+        EB(s, EB_SPAWN_X, e, env) = static_cast<uint8_t>(x);
+    };
+    for (int p = 0; p < platforms; p++) {
+        const int dy = rng_int(mt, 3, max_dy - 1);
+        const bool roomy = (cx >= margin) && (cx <= W - 1 - margin);
+        if (roomy && (rng_real(mt, 0.0f, 1.0f) < enemy_prob)) {
+            const int my = cy + rng_int(mt, 0, 1) + 2;
+            const float vx = 0.15f * (rng_int(mt, 0, 1) * 2.0f - 1.0f);  // tilemap.cpp:55
+            spawn(cx, my, kMob, vx);
+        }
+        cy += dy;
+        const int len = 2 + rng_int(mt, 0, 9);
+        int vx = rng_int(mt, 0, 1) * 2 - 1;
+        if (cx < margin) vx = 1;
+        if (cx > W - margin) vx = -1;
+        int spots[12];
+        int n_spots = 0;
+        for (int j = 0; j < len; j++) {
+            const int nx = cx + (j + 1) * vx;
+            if (nx <= 0 || nx >= W - 1) break;
+            spots[n_spots++] = nx;
+            fill_capped(tiles, nx, cy, 1, 1, kWallMid, kWallTop);
+        }
+        if (rng_real(mt, 0.0f, 1.0f) < 0.5f || p == platforms - 1)
+            spawn(spots[rng_int(mt, 0, n_spots - 1)], cy + 1, kTexSet, 0.0f);  // crystal: textured from the start
+        cx = spots[rng_int(mt, 0, n_spots - 1)];
+    }
+    const int backdrop = rng_int(mt, 0, 9);
+    SF(s, F_BGSHIFT, env) = rng_real(mt, 0.0f, 1.0f);
+    SF(s, F_AX, env) = 1.5f;
+    SF(s, F_AY, env) = H - 2 + 1.0f;
+    SF(s, F_AVX, env) = 0.0f;
+    SF(s, F_AVY, env) = 0.0f;
+    SF(s, F_APHASE, env) = 0.0f;
+    const int suit = rng_int(mt, 0, 3);
+    const int theme = rng_int(mt, 0, 3);
+    SI(s, I_FLAGS, env) = kFlagForward;  // on_ground = false, face_forward = true, draw list cleared (D2)
+    SI(s, I_THEMES, env) = backdrop | (suit << 8) | (theme << 16);
+    SI(s, I_NENT, env) = n_ent;
+    SI(s, I_NDRAW, env) = 0;
+    // camera x is fixed (climber.cpp:466); camera y keeps the previous episode's value (D3)
+
+    uint8_t order[kMaxEnt];
+    int32_t packed = SI(s, I_HASH_SPRITE, env);
+    episode_order(packed, n_ent, order);
+    SI(s, I_HASH_SPRITE, env) = packed;
+    for (int k = 0; k < n_ent; k++) EB(s, EB_ORDER, k, env) = order[k];
+}
+
+PG_D bool is_wall(int t) { return t == kWallMid || t == kWallTop; }
+
+PG_D void advance(const State& s, int env, int action, float& reward_out, bool& terminated_out) {
+    const uint8_t* tiles = s.tiles + size_t(env) * (W * H);
+    const int n_ent = SI(s, I_NENT, env);
+    int flags = SI(s, I_FLAGS, env);
+    float ax = SF(s, F_AX, env), ay = SF(s, F_AY, env);
+    float avx = SF(s, F_AVX, env), avy = SF(s, F_AVY, env);
+    float phase = SF(s, F_APHASE, env), camy = SF(s, F_CAMY, env);
+    bool ground = (flags & kFlagGround) != 0, forward = (flags & kFlagForward) != 0;
+    const float dt = 1.0f / 4;
+    const float max_jump = 1.55f, gravity = 0.2f, max_speed = 0.5f, mix = 0.2f, air_control = 0.15f;
+    const float move_x = static_cast<float>((action == 6 || action == 7 || action == 8) -
+                                            (action == 0 || action == 1 || action == 2));
+    const bool jump = (action == 2 || action == 5 || action == 8);
+
+    float reward = 0.0f;
+    bool terminated = false, set_changed = (flags & kFlagListed) == 0;
+    for (int ss = 0; ss < 4; ss++) {
+        // --- System_Agent::update (common_systems.cpp:184-270)
+        {
+            const float mix_x = ground ? mix : (mix * air_control);
+            avx += mix_x * (max_speed * move_x - avx) * dt;
+            if (fabsf(avx) < mix_x * max_speed * dt) avx = 0.0f;
+            if (jump && ground) avy = -max_jump;
+            avy += gravity * dt;
+            if (fabsf(avy) > max_jump) avy = (avy > 0.0f ? 1.0f : -1.0f) * max_jump;
+            ax += avx * dt;
+            ay += avy * dt;
+            const Box body{ax + -0.5f, ay + -1.0f, 1.0f, 1.0f};
+            const Win win = Win::fetch(tiles, static_cast<int>(floorf(body.x)), static_cast<int>(floorf(body.y)));
+            const TileHit h = collide_plain(win, body, is_wall);
+            const float moved_x = h.x - body.x, moved_y = h.y - body.y;
+            ground = moved_y < 0.0f && h.any;
+            ax = h.x - -0.5f;
+            ay = h.y - -1.0f;
+            if (moved_x != 0.0f) avx = 0.0f;
+            if (ground) avy = 0.0f;
+            camy = (ay - 8 - 0.5f) * kUnitPx;
+            phase += 0.1f * dt;
+            phase = fmodf(phase, 1.0f);
+            if (move_x > 0.0f)
+                forward = true;
+            else if (move_x < 0.0f)
+                forward = false;
+        }
+        const Box agent{ax + -0.5f, ay + -1.0f, 1.0f, 1.0f};
+        // --- mobs (common_systems.cpp:109-168), points (:66-107), animation (:8-39); all order-free per entity
+        bool dead = false;
+        int delta = 0, available = 0;
+        for (int e = 0; e < n_ent; e++) {
+            int info = EB(s, EB_INFO, e, env);
+            if (!(info & kAlive)) continue;
+            float x = EF(s, EF_X, e, env);
+            const float y = EF(s, EF_Y, e, env);
+            if (info & kMob) {
+                float vx = EF(s, EF_VX, e, env);
+                x += vx * dt;
+                const Box probe{x - 0.5f, y - 0.6f, 1.0f, 0.5f};
+                const Win win = Win::fetch(tiles, static_cast<int>(floorf(probe.x)), static_cast<int>(floorf(probe.y)));
+                const TileHit w = collide_plain(win, probe, is_wall);
+                x = w.x + 0.5f;
+                if (box_hit(agent, Box{x + -0.4f, y + -0.4f, 0.8f, 0.8f})) dead = true;
+                const int spawn_x = EB(s, EB_SPAWN_X, e, env);
+                const bool end_patrol = x > spawn_x + 4 || x < spawn_x - 4;
+                if (w.any || end_patrol) vx *= -1.0f;
+                info = (info & ~kFlip) | (vx < 0.0f ? kFlip : 0);
+                float t = EF(s, EF_ANIM_T, e, env) + dt;
+                const int adv = static_cast<int>(t * 0.2f);
+                t -= adv / 0.2f;
+                const int frame = (((info & kFrame) ? 1 : 0) + adv) % 2;
+                info = (info & ~kFrame) | (frame ? kFrame : 0) | kTexSet;
+                EF(s, EF_X, e, env) = x;
+                EF(s, EF_VX, e, env) = vx;
+                EF(s, EF_ANIM_T, e, env) = t;
+                EB(s, EB_INFO, e, env) = static_cast<uint8_t>(info);
+            } else {
+                if (box_hit(agent, Box{x + -0.5f, y + -0.5f, 1.0f, 1.0f})) {
+                    delta++;
+                    EB(s, EB_INFO, e, env) = static_cast<uint8_t>(info & ~kAlive);  // destroy_entity
+                    set_changed = true;
+                } else {
+                    available++;
+                }
+            }
+        }
+        reward = delta + (available == 0) * 10.0f;
+        terminated = dead || (available == 0);
+        if (terminated) break;
+    }
+    // Note: in the reference the mob loop runs before the point loop within a sub-step; the two never read each
+    // other's data, so one fused pass per sub-step yields the same state.
+    SF(s, F_AX, env) = ax;
+    SF(s, F_AY, env) = ay;
+    SF(s, F_AVX, env) = avx;
+    SF(s, F_AVY, env) = avy;
+    SF(s, F_APHASE, env) = phase;
+    SF(s, F_CAMY, env) = camy;
+    SI(s, I_FLAGS, env) = kFlagListed | (ground ? kFlagGround : 0) | (forward ? kFlagForward : 0);
+    if (set_changed) rebuild_draw_list(s, env, n_ent);
+    reward_out = reward;
+    terminated_out = terminated;
+}
+
+__global__ void __launch_bounds__(64) make_kernel(State s, uint32_t seed_base, int env_offset) {
+    const int env = blockIdx.x * 64 + threadIdx.x;
+    if (env >= s.n) return;
+    mt_seed(s.mt + size_t(env) * kMtWords, seed_base + static_cast<uint32_t>(env_offset + env));
+    SI(s, I_HASH_SPRITE, env) = 1;
+    SF(s, F_CAMY, env) = 0.0f;  // Renderer::camera_position{0} (renderer.h:18)
+    new_level(s, env);
+}
+
+__global__ void __launch_bounds__(64) reset_kernel(State s, const uint8_t* mask, const int32_t* seeds, StepIO io) {
+    const int env = blockIdx.x * 64 + threadIdx.x;
+    if (env >= s.n) return;
+    if (mask && !mask[env]) return;
+    if (seeds) mt_seed(s.mt + size_t(env) * kMtWords, static_cast<uint32_t>(seeds[env]));
+    new_level(s, env);
+    io.reward[env] = 0.0f;
+    io.done[env] = 0;
+    io.pending[env] = 0;
+}
+
+__global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actions, uint32_t run_seed,
+                                                   uint32_t step_index, int env_offset, StepIO io) {
+    const int env = blockIdx.x * 64 + threadIdx.x;
+    if (env >= s.n) return;
+    if (io.pending[env]) {
+        new_level(s, env);
+        io.reward[env] = 0.0f;
+        io.done[env] = 0;
+        io.pending[env] = 0;
+        return;
+    }
+    const int action =
+        actions ? actions[env] : synthetic_action(run_seed, step_index, static_cast<uint32_t>(env_offset + env));
+    float reward;
+    bool terminated;
+    advance(s, env, action, reward, terminated);
+    io.reward[env] = reward;
+    io.done[env] = terminated ? 1 : 0;
+    io.pending[env] = terminated ? 1 : 0;
+}
+
+// render_game(true) (climber.cpp:431-459): one wavefront per env.
+__global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
+                                                    int flags) {
+    const int env = blockIdx.x;
+    if (mask && !mask[env]) return;
+    const int lane = threadIdx.x;
+    __shared__ uint32_t fb[kFbWords];
+    constexpr int kGrid = 32;  // 64 px / 3.2 px per tile = 20 tiles → at most 22 columns/rows in view
+    __shared__ ComposeLds<kGrid> L;
+
+    const Camera cam{W / 2.0f * kUnitPx, SF(s, F_CAMY, env), 64.0f, 64.0f, 0.2f * 64.0f / 64.0f};
+    const int themes = SI(s, I_THEMES, env), sflags = SI(s, I_FLAGS, env);
+    const int backdrop = themes & 0xff, suit = (themes >> 8) & 0xff, theme = (themes >> 16) & 0xff;
+    const int n_draw = (sflags & kFlagListed) ? SI(s, I_NDRAW, env) : 0;  // empty right after a reset (D2)
+    const uint8_t* tiles = s.tiles + size_t(env) * (W * H);
+    const DescRegs descs = DescRegs::load(atlas, lane);
+    Blit mine;
+
+    // sprite-pass inputs, requested early
+    const bool is_sprite = lane < n_draw, is_agent = lane == n_draw;
+    int spr_info = 0;
+    float spr_x = 0.0f, spr_y = 0.0f;
+    if (is_sprite) {
+        const int e = EB(s, EB_DRAW, lane, env);
+        spr_info = EB(s, EB_INFO, e, env);
+        spr_x = EF(s, EF_X, e, env);
+        spr_y = EF(s, EF_Y, e, env);
+    }
+
+    Blit bg;  // climber.cpp:447-452
+    bool has_bg;
+    {
+        const int4 d = descs.uniform(kTexBackdrop + backdrop);
+        const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
+        const float extra = aspect - 1.0f;
+        has_bg = resolve_draw(cam, d.y, d.z, d.x, -SF(s, F_BGSHIFT, env) * extra, 0.0f, 64.0f * kUnitPx / d.z, 1.0f,
+                              false, false, bg);
+    }
+    // tile window (tilemap.cpp:172-181)
+    const float vx = (cam.px - cam.sw * 0.5f / cam.scale) * kPxUnit;
+    const float vy = (cam.py - cam.sh * 0.5f / cam.scale) * kPxUnit;
+    const float vw = cam.sw * kPxUnit / cam.scale, vh = cam.sh * kPxUnit / cam.scale;
+    const int x0 = static_cast<int>(floorf(vx)), y0 = static_cast<int>(floorf(vy));
+    const int x1 = static_cast<int>(ceilf(vx + vw)), y1 = static_cast<int>(ceilf(vy + vh));
+    const int cols = x1 - x0 + 1, rows = y1 - y0 + 1, cells = cols * rows;
+    const int4 top_d = descs.uniform(kTexTop + theme), mid_d = descs.uniform(kTexMid + theme);
+
+    bool composed = false;
+    // The row composer needs one tile size for the whole layer; the brown theme's top tile is 64×53
+    // (assets/platformer/tileBrown_06.png), so that theme takes the draw-list replay.
+    if (!(flags & 1) && cols <= kGrid && rows <= kGrid && top_d.y == mid_d.y && top_d.z == mid_d.z) {
+        compose_spans(L, cam, x0, y0, cols, rows, mid_d.y, mid_d.z, kUnitPx / mid_d.y, lane);
+#pragma unroll
+        for (int k = 0; k < kGrid * kGrid / 64; k++) {
+            const int cell = k * 64 + lane;
+            const int r = cell / kGrid, c = cell % kGrid;
+            const int t = (c < cols && r < rows) ? Win::direct(tiles, x0 + c, y0 + r) : kEmpty;
+            L.base[cell] = (t == kEmpty) ? static_cast<int32_t>(kNoTexel) : (t == kWallTop ? top_d.x : mid_d.x) * 4;
+        }
+        __syncthreads();
+        composed = compose_rows(fb, L, atlas, bg, has_bg, cols, rows, mid_d.y, lane, flags);
+    }
+    if (!composed) {  // draw-list replay (tilemap.cpp:172-198)
+        wave_clear(fb, lane);
+        mine = bg;
+        wave_replay(fb, atlas, mine, has_bg ? 1ull : 0ull, lane);
+        for (int base = 0; base < cells; base += 64) {
+            const int cell = base + lane;
+            bool has = false;
+            if (cell < cells) {
+                const int row = cell / cols;
+                const int x = x0 + (cell - row * cols), y = y0 + row;
+                const int t = Win::direct(tiles, x, y);
+                if (t != kEmpty) {
+                    const int4 d = (t == kWallTop) ? top_d : mid_d;
+                    has = resolve_draw(cam, d.y, d.z, d.x, x * kUnitPx, y * kUnitPx, kUnitPx / d.y, 1.0f, false, false,
+                                       mine);
+                }
+            }
+            wave_replay(fb, atlas, mine, __ballot(has), lane);
+        }
+    }
+
+    {  // positive-z sprites (common_systems.cpp:41-63), then the agent (:272-298): one draw per lane
+        int want_tex = 0;
+        if (is_sprite) {
+            want_tex = (spr_info & kMob) ? kTexFish + ((spr_info & kFrame) ? 1 : 0) : kTexGem;
+        } else if (is_agent) {
+            const bool ground = (sflags & kFlagGround) != 0;
+            if (fabsf(SF(s, F_AVX, env)) < 0.01f && ground)
+                want_tex = kTexStand + suit;
+            else if (!ground)
+                want_tex = kTexJump + suit;
+            else if (SF(s, F_APHASE, env) > 0.5f)
+                want_tex = kTexWalk2 + suit;
+            else
+                want_tex = kTexWalk1 + suit;
+        }
+        const int4 d = descs.at(want_tex);
+        bool has = false;
+        if (is_sprite) {
+            if (spr_info & kTexSet) {
+                const float off = (spr_info & kMob) ? -0.4f : -0.5f;  // tilemap.cpp:53,66
+                const float scale = 1.0f * 1.0f;
+                has = resolve_draw(cam, d.y, d.z, d.x, (spr_x + off) * kUnitPx, (spr_y + off) * kUnitPx,
+                                   scale * kUnitPx / d.y, 1.0f, (spr_info & kFlip) != 0, false, mine);
+            }
+        } else if (is_agent) {
+            const float px = SF(s, F_AX, env) - 0.5f, py = SF(s, F_AY, env) - 1.0f;
+            has = resolve_draw(cam, d.y, d.z, d.x, px * kUnitPx, py * kUnitPx, 0.8f * kUnitPx / d.y, 1.0f,
+                               (sflags & kFlagForward) == 0, false, mine);
+        }
+        wave_replay(fb, atlas, mine, __ballot(has), lane);
+    }
+    wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane);
+}
+
+class ClimberGame final : public Game {
+   public:
+    const char* name() const override { return "climber"; }
+    std::vector<std::string> texture_names() const override {
+        std::vector<std::string> v;
+        for (const char* t : {"tileBlue_05", "tileGreen_05", "tileYellow_06", "tileBrown_06", "tileBlue_08",
+                              "tileGreen_08", "tileYellow_09", "tileBrown_09"})
+            v.push_back(std::string("platformer/") + t + ".png");
+        for (const char* pose : {"_stand", "_walk4", "_walk1", "_walk2"})  // jump = walk4 (common_systems.cpp:178)
+            for (const char* suit : {"Blue", "Green", "Grey", "Red"})
+                v.push_back(std::string("platformer/player") + suit + pose + ".png");
+        v.push_back("platformer/enemySwimming_1.png");
+        v.push_back("platformer/enemySwimming_2.png");
+        v.push_back("misc_assets/yellowCrystal.png");
+        for (const char* b : {"platform_backgrounds/alien_bg", "platform_backgrounds/another_world_bg",
+                              "platform_backgrounds_2/fantasy1", "platform_backgrounds_2/fantasy2",
+                              "platform_backgrounds_2/fantasy3", "platform_backgrounds_2/fantasy4",
+                              "platform_backgrounds_2/candy1", "platform_backgrounds_2/candy2",
+                              "platform_backgrounds_2/candy3", "platform_backgrounds_2/candy4"})
+            v.push_back(std::string(b) + ".png");
+        return v;
+    }
+    std::string check_atlas(const std::vector<std::pair<int, int>>& sizes) const override {
+        return static_cast<int>(sizes.size()) == kTexCount ? "" : "climber: unexpected texture count";
+    }
+    static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+    struct Layout {
+        size_t mt, tiles, f, i, ef, eb, total;
+    };
+    static Layout layout(int n) {
+        Layout l{};
+        size_t off = 0;
+        auto take = [&](size_t bytes) {
+            size_t at = off;
+            off += align256(bytes);
+            return at;
+        };
+        l.mt = take(size_t(n) * kMtWords * 4);
+        l.tiles = take(size_t(n) * W * H);
+        l.f = take(size_t(F_COUNT) * n * 4);
+        l.i = take(size_t(I_COUNT) * n * 4);
+        l.ef = take(size_t(EF_COUNT) * kMaxEnt * n * 4);
+        l.eb = take(size_t(EB_COUNT) * kMaxEnt * n);
+        l.total = off;
+        return l;
+    }
+    size_t state_bytes(int n) const override { return layout(n).total; }
+    void bind(void* d_state, int n, AtlasView atlas) override {
+        uint8_t* p = static_cast<uint8_t*>(d_state);
+        const Layout l = layout(n);
+        s_.n = n;
+        s_.mt = reinterpret_cast<uint32_t*>(p + l.mt);
+        s_.tiles = p + l.tiles;
+        s_.f = reinterpret_cast<float*>(p + l.f);
+        s_.i = reinterpret_cast<int32_t*>(p + l.i);
+        s_.ef = reinterpret_cast<float*>(p + l.ef);
+        s_.eb = p + l.eb;
+        atlas_ = atlas;
+    }
+    int blocks() const { return (s_.n + 63) / 64; }
+    void launch_make(hipStream_t st, uint32_t seed_base, int env_offset) override {
+        hipLaunchKernelGGL(make_kernel, dim3(blocks()), dim3(64), 0, st, s_, seed_base, env_offset);
+    }
+    void launch_reset(hipStream_t st, const uint8_t* mask, const int32_t* seeds, StepIO io) override {
+        hipLaunchKernelGGL(reset_kernel, dim3(blocks()), dim3(64), 0, st, s_, mask, seeds, io);
+    }
+    void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
+                      StepIO io) override {
+        hipLaunchKernelGGL(logic_kernel, dim3(blocks()), dim3(64), 0, st, s_, actions, run_seed, step_index,
+                           env_offset, io);
+    }
+    void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
+        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(64), 0, st, s_, atlas_, mask, io, debug_flags);
+    }
+    // Same layout as oracle/pgo_climber.cpp Climber::dump_state.
+    int dump_state(hipStream_t st, int env, float* out, int cap) override {
+        hipStreamSynchronize(st);
+        const size_t n = s_.n;
+        auto rf = [&](const float* base, size_t idx) {
+            float v;
+            hipMemcpy(&v, base + idx, 4, hipMemcpyDeviceToHost);
+            return v;
+        };
+        auto ri = [&](int field) {
+            int32_t v;
+            hipMemcpy(&v, s_.i + size_t(field) * n + env, 4, hipMemcpyDeviceToHost);
+            return v;
+        };
+        auto f = [&](int field) { return rf(s_.f, size_t(field) * n + env); };
+        const int flags = ri(I_FLAGS), themes = ri(I_THEMES), n_ent = ri(I_NENT);
+        std::vector<float> v = {f(F_AX), f(F_AY), f(F_AVX), f(F_AVY), (flags & kFlagGround) ? 1.0f : 0.0f,
+                                (flags & kFlagForward) ? 1.0f : 0.0f, f(F_APHASE), W / 2.0f * kUnitPx, f(F_CAMY),
+                                static_cast<float>(themes & 0xff), f(F_BGSHIFT),
+                                static_cast<float>((themes >> 8) & 0xff), static_cast<float>((themes >> 16) & 0xff),
+                                static_cast<float>(n_ent)};
+        for (int e = 0; e < n_ent; e++) {
+            uint8_t info;
+            hipMemcpy(&info, s_.eb + (size_t(EB_INFO) * kMaxEnt + e) * n + env, 1, hipMemcpyDeviceToHost);
+            auto ef = [&](int field) { return rf(s_.ef, (size_t(field) * kMaxEnt + e) * n + env); };
+            v.push_back((info & kAlive) ? 1.0f : 0.0f);
+            v.push_back(ef(EF_X));
+            v.push_back(ef(EF_Y));
+            v.push_back((info & kMob) ? ef(EF_VX) : 0.0f);
+            v.push_back((info & kFrame) ? 1.0f : 0.0f);
+            v.push_back(ef(EF_ANIM_T));
+        }
+        const int m = cap < static_cast<int>(v.size()) ? cap : static_cast<int>(v.size());
+        for (int k = 0; k < m; k++) out[k] = v[k];
+        return static_cast<int>(v.size());
+    }
+    int dump_tiles(hipStream_t st, int env, uint8_t* out, int cap) override {
+        hipStreamSynchronize(st);
+        const int m = cap < W * H ? cap : W * H;
+        hipMemcpy(out, s_.tiles + size_t(env) * W * H, m, hipMemcpyDeviceToHost);
+        return m;
+    }
+
+   private:
+    State s_{};
+    AtlasView atlas_{};
+};
+
+}  // namespace climber
+
+std::unique_ptr<Game> make_climber() { return std::make_unique<climber::ClimberGame>(); }
+
+}  // namespace pg

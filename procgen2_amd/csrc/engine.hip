@@ -85,13 +85,14 @@ static std::string asset_root() {
     return "assets";
 }
 
-static const char* const kGameNames[kNumGames] = {"coinrun", "maze", "bossfight"};
+static const char* const kGameNames[kNumGames] = {"coinrun", "maze", "bossfight", "climber"};
 
 static std::unique_ptr<Game> make_game(int id) {
     switch (id) {
         case kGameCoinrun: return make_coinrun();
         case kGameMaze: return make_maze();
         case kGameBossfight: return make_bossfight();
+        case kGameClimber: return make_climber();
         default: return nullptr;
     }
 }

@@ -56,7 +56,7 @@ def test_coinrun_lockstep_256_envs():
     assert resets > 0, "no episode ended: the auto-reset path was not exercised"
 
 
-@pytest.mark.parametrize("game", ["coinrun", "maze", "bossfight"])
+@pytest.mark.parametrize("game", ["coinrun", "maze", "bossfight", "climber"])
 def test_row_composer_equals_draw_list_replay(game):
     """The fused background+tile row composer (pg_render.h compose_rows) against the one-blit-at-a-time replay of
     the reference's draw list, the same engine in both modes, every byte of 512 envs over 150 steps."""
@@ -107,6 +107,32 @@ def test_bossfight_fire_heavy_actions():
     ora.close()
 
 
+def test_climber_lockstep_jump_heavy_actions():
+    # Uniform random actions rarely leave the floor; biasing towards the jump actions (2, 5, 8) makes agents climb,
+    # collect crystals (entity destruction -> draw-list rebuild) and die on mobs (auto-reset, new level).
+    n = 192
+    eng, ora = EngineVec("climber", n, seed_base=31), OracleVec("climber", n, seed_base=31)
+    assert np.array_equal(eng.reset(), ora.reset_obs())
+    idx = np.arange(n)
+    ends, rew = 0, 0.0
+    for s in range(900):
+        a = _actions(ora.L, 2, s, n)
+        a = np.where((idx + s) % 5 < 3, (a % 3) * 3 + 2, a).astype(np.int32)
+        oe, re_, de = eng.step(a)
+        oo, ro, do = ora.step(a)
+        assert np.array_equal(de, do) and np.array_equal(re_.view(np.uint32), ro.view(np.uint32)), s
+        assert np.array_equal(oe, oo), s
+        ends += int(do.sum())
+        rew += float(ro.sum())
+        if s % 150 == 0:
+            for e in range(0, n, 24):
+                assert np.array_equal(eng.state(e).view(np.uint32), ora.state(e).view(np.uint32)), (s, e)
+                assert np.array_equal(eng.tiles(e), ora.tiles(e)), (s, e)
+    assert ends > 50 and rew > 10.0, (ends, rew)
+    eng.close()
+    ora.close()
+
+
 def test_maze_out_of_range_actions_follow_reference_quirk():
     # D6/D20: actions 9..15 teleport 2–3 cells in maze; others ignore them.
     n = 32
@@ -122,7 +148,7 @@ def test_maze_out_of_range_actions_follow_reference_quirk():
     ora.close()
 
 
-@pytest.mark.parametrize("game", ["coinrun", "maze", "bossfight"])
+@pytest.mark.parametrize("game", ["coinrun", "maze", "bossfight", "climber"])
 def test_reset_with_seed_option_and_mask(game):
     """cenv_reset's "seed" option (coinrun.cpp:313-317) per env, and masked resets leaving other envs untouched."""
     n = 16
@@ -136,11 +162,17 @@ def test_reset_with_seed_option_and_mask(game):
     o = eng.reset()
     for i, h in enumerate(hs):
         assert np.array_equal(o[i], np.ctypeslib.as_array(L.pgo_obs(h), shape=(12288,)))
+    pending = [False] * n
     for s in range(20):
         a = _actions(L, 2, s, n)
         eng.step(a)
         for i, h in enumerate(hs):
-            L.pgo_step(h, int(a[i]))
+            if pending[i]:  # reference loop: `if term: env.reset()` replaces the next step
+                L.pgo_reset(h, 0, 0)
+                pending[i] = False
+            else:
+                L.pgo_step(h, int(a[i]))
+                pending[i] = bool(L.pgo_terminated(h))
     before = eng.obs.copy()
     mask = np.zeros(n, np.uint8)
     mask[::3] = 1
@@ -152,7 +184,7 @@ def test_reset_with_seed_option_and_mask(game):
             assert np.array_equal(o[i], np.ctypeslib.as_array(L.pgo_obs(h), shape=(12288,))), i
         else:
             assert np.array_equal(o[i], before[i]), i
-    pending = [False] * n
+    pending = [p and not mask[i] for i, p in enumerate(pending)]  # an explicit reset clears a pending one
     for s in range(30):
         a = _actions(L, 3, s, n)
         oe, _, _ = eng.step(a)
@@ -173,7 +205,8 @@ def test_reset_with_seed_option_and_mask(game):
 def test_cenv_abi_single_env_matches_reference_loop():
     """The drop-in path: CEnv("libCoinRun.so", options={"seed": s}) → reset → step(int) … with the caller doing
     `if term: reset()` — exactly game_test.py:36-40 — against the oracle driven the same way."""
-    for libname, game in (("libCoinRun.so", "coinrun"), ("libMaze.so", "maze"), ("libBossFight.so", "bossfight")):
+    for libname, game in (("libCoinRun.so", "coinrun"), ("libMaze.so", "maze"), ("libBossFight.so", "bossfight"),
+                          ("libClimber.so", "climber")):
         env = pgcenv.CEnv(os.path.join(pglib.LIB_DIR, libname), options={"seed": 123})
         assert list(env.observation_space) == ["screen"] and list(env.action_space) == ["action"]
         assert list(env.action_space["action"].nvec) == [15]

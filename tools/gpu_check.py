@@ -20,10 +20,12 @@ from engine_util import EngineVec  # noqa: E402
 from oracle_util import OracleVec  # noqa: E402
 
 
-def compare(game, n, steps, seed_base, run_seed):
+def compare(game, n, steps, seed_base, run_seed, jumpy=False):
     eng = EngineVec(game, n, seed_base=seed_base)
     ora = OracleVec(game, n, seed_base=seed_base)
     bad = 0
+    n_done = 0
+    rew_sum = 0.0
 
     def diff(tag, step):
         nonlocal bad
@@ -54,8 +56,13 @@ def compare(game, n, steps, seed_base, run_seed):
         bad += 1
     for s in range(steps):
         acts = np.array([ora.L.pgo_synthetic_action(run_seed, s, e) for e in range(n)], np.int32)
+        if jumpy:  # bias towards the jump actions (2, 5, 8) so platformer agents climb and meet hazards
+            idx = np.arange(n)
+            acts = np.where((idx + s) % 5 < 3, (acts % 3) * 3 + 2, acts).astype(np.int32)
         oe, re_, de = eng.step(acts)
         oo, ro, do = ora.step(acts)
+        n_done += int(do.sum())
+        rew_sum += float(ro.sum())
         rew_ok = np.array_equal(re_.view(np.uint32), ro.view(np.uint32))
         done_ok = np.array_equal(de, do)
         obs_ok = np.array_equal(oe, oo)
@@ -72,8 +79,8 @@ def compare(game, n, steps, seed_base, run_seed):
             diff("step", s)
             if bad >= 3:
                 break
-    print("%s: %d envs x %d steps: %s (%d resets seen)" %
-          (game, n, steps, "PARITY OK" if bad == 0 else "MISMATCH", int(0)))
+    print("%s: %d envs x %d steps: %s (%d episode ends, reward sum %.1f)" %
+          (game, n, steps, "PARITY OK" if bad == 0 else "MISMATCH", n_done, rew_sum))
     eng.close()
     ora.close()
     return bad == 0
@@ -96,11 +103,12 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--seed-base", type=int, default=1)
     ap.add_argument("--run-seed", type=int, default=0)
+    ap.add_argument("--jumpy", action="store_true")
     ap.add_argument("--time-envs", type=int, default=0)
     ap.add_argument("--time-steps", type=int, default=64)
     a = ap.parse_args()
     t0 = time.time()
-    ok = compare(a.game, a.envs, a.steps, a.seed_base, a.run_seed)
+    ok = compare(a.game, a.envs, a.steps, a.seed_base, a.run_seed, a.jumpy)
     print("compare took %.1fs" % (time.time() - t0))
     if a.time_envs:
         timing(a.game, a.time_envs, a.time_steps)

@@ -77,7 +77,18 @@ def bossfight():
     return ["space_backgrounds/%s.png" % n for n in space] + ["misc_assets/%s.png" % n for n in misc]
 
 
-GAMES = {"coinrun": coinrun, "maze": maze, "bossfight": bossfight}
+def climber():
+    # games/climber/climber.cpp:60-71, tilemap.cpp:3-27, common_systems.cpp:170-182
+    tiles = ["tileBlue_05", "tileGreen_05", "tileYellow_06", "tileBrown_06", "tileBlue_08", "tileGreen_08",
+             "tileYellow_09", "tileBrown_09", "enemySwimming_1", "enemySwimming_2"]
+    players = ["player%s_%s" % (c, p) for c in ("Blue", "Green", "Grey", "Red")
+               for p in ("stand", "walk4", "walk1", "walk2")]
+    backs = ["platform_backgrounds/alien_bg.png", "platform_backgrounds/another_world_bg.png"] + \
+            ["platform_backgrounds_2/%s%d.png" % (k, i) for k in ("fantasy", "candy") for i in range(1, 5)]
+    return ["platformer/%s.png" % n for n in tiles + players] + ["misc_assets/yellowCrystal.png"] + backs
+
+
+GAMES = {"coinrun": coinrun, "maze": maze, "bossfight": bossfight, "climber": climber}
 
 
 def main():
