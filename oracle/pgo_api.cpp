@@ -30,6 +30,8 @@ void* pgo_make(const char* game, uint32_t seed, int render_enabled) {
         e = pgo::new_bossfight();
     else if (g == "climber")
         e = pgo::new_climber();
+    else if (g == "caveflyer")
+        e = pgo::new_caveflyer();
     if (!e) return nullptr;
     e->set_render_enabled(render_enabled != 0);
     e->make(seed);

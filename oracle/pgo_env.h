@@ -74,5 +74,6 @@ Env* new_coinrun();
 Env* new_maze();
 Env* new_bossfight();
 Env* new_climber();
+Env* new_caveflyer();
 
 }  // namespace pgo

@@ -1,0 +1,891 @@
+// caveflyer on gfx950 (BASELINE.json configs[2]): free-flight ship with rotation
+// and bullets in a cellular-automaton cave.
+//
+// Reference:
+//   step   games/caveflyer/caveflyer.cpp:301-357, common_systems.cpp:90-289 (agent + bullets), :50-75 (enemies),
+//          :333-372 (exhaust particles), :7-24 (sprite list)
+//   render games/caveflyer/caveflyer.cpp:413-440, tilemap.cpp:280-303, common_systems.cpp:26-48, :291-327, :374-397
+//   reset  games/caveflyer/caveflyer.cpp:442-460, tilemap.cpp:118-278, room_generator.cpp:4-202
+// Config = the reference's compile-time default, hard_mode (40×40, pruned; caveflyer/tilemap.h:43-45).
+//
+// Machine mapping:
+//   * logic  — one lane per env over struct-of-arrays state (agent, 32 bullets, ≤60 objects, 10 particles);
+//   * render — one wavefront per env (pg_render.h), tiles through the row composer, the rotated sprites
+//              (particles, bullets, ship) as whole-wave rotated blits;
+//   * level generation — one wavefront per env with a 23 KiB LDS workspace.  The generator's result depends on
+//              the iteration order of a std::unordered_set<int> holding up to 1600 cells (the largest room,
+//              tilemap.cpp:158-169), so the libstdc++ hashtable is replayed (pg_order.h) — inherently serial, hence
+//              on LDS rather than HBM: the dependent-access latency is what bounds it.  Episodes are long
+//              (thousands of steps), so this kernel touches a handful of envs per step.
+#include "pg_engine.h"
+#include "pg_geom.h"
+#include "pg_order.h"
+#include "pg_render.h"
+#include "pg_rng.h"
+#include "pg_sincos.h"
+#include "pg_tiles.h"
+
+namespace pg {
+namespace caveflyer {
+
+constexpr int W = 40, H = 40, kCells = W * H;
+constexpr int kMaxEnt = 62;  // ids: 0 goal, 1 ship, 2.. objects; 3·(free/80) ≤ 60 objects (tilemap.cpp:232-233)
+constexpr int kShots = 32, kPuffs = 10;
+constexpr double kPi = 3.14159265358979323846;  // M_PI
+enum Tile : uint8_t { kEmpty = 0, kWall = 1 };
+enum Kind { kMeteor = 0, kTarget = 1, kEnemy = 2, kGoal = 3 };
+
+enum Tex {
+    kTexWall = 0,
+    kTexKind = 1,  // meteor, target, enemy, goal
+    kTexShip = 5,
+    kTexLaser = 6,
+    kTexBoom = 7,  // 5
+    kTexPuff = 12,
+    kTexSpace = 13,  // 13
+    kTexCount = 26
+};
+
+enum { F_AX, F_AY, F_AVX, F_AVY, F_ROT, F_CAMX, F_CAMY, F_BGSHIFT, F_STIMER, F_PTIMER, F_COUNT };
+enum { I_FLAGS, I_BACKDROP, I_NENT, I_NDRAW, I_SNEXT, I_SCOUNT, I_HASH_SPRITE, I_HASH_HAZARD, I_COUNT };
+constexpr int kFlagListed = 1, kFlagPuffOn = 2;
+enum { EF_X, EF_Y, EF_VX, EF_VY, EF_COUNT };
+enum { EB_INFO, EB_ORDER_S, EB_ORDER_H, EB_DRAW, EB_COUNT };
+constexpr int kKindMask = 3, kAlive = 4;
+enum { SH_X, SH_Y, SH_VX, SH_VY, SH_ROT, SH_FRAME, SH_COUNT };
+enum { PF_X, PF_Y, PF_DX, PF_DY, PF_ROT, PF_LIFE, PF_COUNT };
+
+struct State {
+    int n;
+    uint32_t* mt;    // [n][625]
+    uint8_t* tiles;  // [n][1600]  column-major y + x*H
+    float* f;        // [F_COUNT][n]
+    int32_t* i;      // [I_COUNT][n]
+    float* ef;       // [EF_COUNT][kMaxEnt][n]
+    uint8_t* eb;     // [EB_COUNT][kMaxEnt][n]
+    float* sh;       // [SH_COUNT][kShots][n]
+    float* pf;       // [PF_COUNT][kPuffs][n]
+};
+
+PG_D float& SF(const State& s, int field, int env) { return s.f[size_t(field) * s.n + env]; }
+PG_D int32_t& SI(const State& s, int field, int env) { return s.i[size_t(field) * s.n + env]; }
+PG_D float& EF(const State& s, int field, int e, int env) { return s.ef[(size_t(field) * kMaxEnt + e) * s.n + env]; }
+PG_D uint8_t& EB(const State& s, int field, int e, int env) { return s.eb[(size_t(field) * kMaxEnt + e) * s.n + env]; }
+PG_D float& SH(const State& s, int field, int k, int env) { return s.sh[(size_t(field) * kShots + k) * s.n + env]; }
+PG_D float& PF(const State& s, int field, int k, int env) { return s.pf[(size_t(field) * kPuffs + k) * s.n + env]; }
+
+using Win = TileWinT<W, H, kWall>;  // out of bounds is a wall (tilemap.h:78-83)
+PG_D bool is_wall(int t) { return t == kWall; }
+
+// ------------------------------------------------------------------------------------------------
+// level generation (one wavefront per env; the serial parts run on lane 0)
+// ------------------------------------------------------------------------------------------------
+struct GenLds {
+    uint32_t mt[kMtWords];
+    uint8_t grid[kCells];    // Room_Generator::grid after the two automaton iterations
+    uint8_t aux[kCells];     // automaton double buffer → room membership → path `covered` → widened set (2 = on the path)
+    int16_t next[kCells];    // hashtable node links, later the goal path
+    int16_t before[2368];    // hashtable buckets (≤ 2357)
+    int16_t queue[kCells + 4];   // BFS queue / `expanded` / widening layer A
+    int16_t parent[kCells + 4];  // `parents` / widening layer B
+    int16_t cells[kCells];   // free_cells
+};
+
+PG_D int cell_of(int x, int y) { return y + H * x; }
+
+// Room_Generator::update (room_generator.cpp:20-35): ≥5 walls among the 9 Moore cells (out of bounds = wall).
+PG_D void automaton(const uint8_t* src, uint8_t* dst, int lane) {
+    for (int c = lane; c < kCells; c += 64) {
+        const int x = c / H, y = c % H;
+        int n = 0;
+        for (int a = -1; a <= 1; a++)
+            for (int b = -1; b <= 1; b++) {
+                const int nx = x + a, ny = y + b;
+                n += (nx < 0 || ny < 0 || nx >= W || ny >= H) ? 1 : src[cell_of(nx, ny)];
+            }
+        dst[c] = n >= 5 ? 1 : 0;
+    }
+}
+
+// The order of a System's entity set for this episode: `keys` inserted in creation order into a set that kept its
+// bucket array across clear() (packed = buckets | next_resize << 16).
+PG_D void episode_order(int32_t& packed, const uint8_t* keys, int n, uint8_t* out, int16_t* next, int16_t* before) {
+    HashOrder h;
+    h.next = next;
+    h.before = before;
+    h.head = kNil;
+    h.buckets = packed & 0xffff;
+    h.next_resize = packed >> 16;
+    h.count = 0;
+    for (int b = 0; b < h.buckets; b++) before[b] = kNil;
+    for (int k = 0; k < n; k++) hash_insert(h, keys[k]);
+    int16_t p = static_cast<int16_t>(h.head);
+    for (int k = 0; k < n; k++) {
+        out[k] = static_cast<uint8_t>(p);
+        p = next[p];
+    }
+    packed = h.buckets | (h.next_resize << 16);
+}
+
+// Lane 0: Room_Generator::find_best_room (room_generator.cpp:138-160) with the real container's iteration order,
+// written to L.cells; returns the room's size.  L.aux must be zero on entry and holds the union of rooms on exit.
+PG_D int best_room(GenLds& L) {
+    int best_size = -1, best_n = 0;
+    for (int start = 0; start < kCells; start++) {
+        if (L.grid[start] != 0 || L.aux[start]) continue;
+        HashOrder room;
+        hash_init(room, L.next, L.before);
+        int qh = 0, qt = 0;
+        L.queue[qt++] = static_cast<int16_t>(start);
+        while (qh < qt) {  // build_room (:37-75); the start cell joins when a neighbour looks back at it
+            const int cur = L.queue[qh++];
+            const int x = cur / H, y = cur % H;
+            for (int d = 0; d < 4; d++) {  // (i, j) = (-1,0) (0,-1) (0,1) (1,0)
+                const int nx = x + (d == 0 ? -1 : d == 3 ? 1 : 0), ny = y + (d == 1 ? -1 : d == 2 ? 1 : 0);
+                if (nx < 0 || ny < 0 || nx >= W || ny >= H) continue;
+                const int ni = cell_of(nx, ny);
+                if (!L.aux[ni] && L.grid[ni] == 0) {
+                    L.queue[qt++] = static_cast<int16_t>(ni);
+                    L.aux[ni] = 1;
+                    hash_insert(room, ni);
+                }
+            }
+        }
+        if (room.count > best_size) {  // `best_room = next_room`: the copy keeps the iteration order
+            best_size = room.count;
+            best_n = room.count;
+            int16_t p = static_cast<int16_t>(room.head);
+            for (int k = 0; k < best_n; k++) {
+                L.cells[k] = p;
+                p = L.next[p];
+            }
+        }
+    }
+    return best_n;
+}
+
+// Lane 0: Room_Generator::find_path (:77-136).  Path cells go to L.next[0..len); returns len.  L.aux = `covered`.
+PG_D int goal_path(GenLds& L, int src, int dst) {
+    int n = 0, at = 0;
+    L.queue[n] = static_cast<int16_t>(src);
+    L.parent[n] = -1;
+    n++;
+    while (at < n) {
+        const int cur = L.queue[at];
+        if (cur == dst) break;
+        const int x = cur / H, y = cur % H;
+        for (int d = 0; d < 4; d++) {
+            const int nx = x + (d == 0 ? -1 : d == 3 ? 1 : 0), ny = y + (d == 1 ? -1 : d == 2 ? 1 : 0);
+            if (nx < 0 || ny < 0 || nx >= W || ny >= H) continue;
+            const int ni = cell_of(nx, ny);
+            if (!L.aux[ni] && L.grid[ni] == 0) {  // the source is not `covered`: it is expanded a second time
+                L.queue[n] = static_cast<int16_t>(ni);
+                L.parent[n] = static_cast<int16_t>(at);
+                n++;
+                L.aux[ni] = 1;
+            }
+        }
+        at++;
+    }
+    int len = 0;
+    for (int k = at; k >= 0; k = L.parent[k]) len++;
+    int w = len;
+    for (int k = at; k >= 0; k = L.parent[k]) L.next[--w] = L.queue[k];
+    return len;
+}
+
+PG_D void put_thing(const State& s, int env, int id, int kind, int cell, float vx, float vy) {
+    const int x = cell / H, y = cell % H;
+    EF(s, EF_X, id, env) = static_cast<float>(x) + 0.5f;
+    EF(s, EF_Y, id, env) = static_cast<float>(H - 1 - y) + 0.5f;
+    EF(s, EF_VX, id, env) = vx;
+    EF(s, EF_VY, id, env) = vy;
+    EB(s, EB_INFO, id, env) = static_cast<uint8_t>(kind | kAlive);
+}
+
+PG_D int check_neighbors(float x0, float y0, float x1, float y1) {  // tilemap.cpp:103-115
+    const float neighborhood = 2.0f, epsilon = 0.001f;
+    if (fabsf(x0 - x1) <= epsilon && fabsf(y0 - y1) <= neighborhood) return 1;
+    if (fabsf(x0 - x1) <= neighborhood && fabsf(y0 - y1) <= epsilon) return 2;
+    return 0;
+}
+
+// reset() (caveflyer.cpp:442-460) for one env by one wavefront.
+PG_D void new_level(const State& s, int env, GenLds& L, bool reseed, uint32_t seed, int lane) {
+    uint32_t* gmt = s.mt + size_t(env) * kMtWords;
+    if (reseed) {
+        if (lane == 0) mt_seed(L.mt, seed);
+    } else {
+        for (int k = lane; k < kMtWords; k += 64) L.mt[k] = gmt[k];
+    }
+    __syncthreads();
+    uint32_t* mt = L.mt;
+    if (lane == 0)  // tilemap.cpp:139-140
+        for (int c = 0; c < kCells; c++) L.grid[c] = rng_real(mt, 0.0f, 1.0f) < 0.5f ? 1 : 0;
+    __syncthreads();
+    automaton(L.grid, L.aux, lane);
+    __syncthreads();
+    automaton(L.aux, L.grid, lane);
+    __syncthreads();
+    for (int c = lane; c < kCells; c += 64) L.aux[c] = 0;
+    __syncthreads();
+
+    int path_len = 0, agent_cell = 0, goal_cell = 0;
+    if (lane == 0) {
+        const int n_free = best_room(L);
+        const int goal_index = rng_int(mt, 0, n_free - 1);
+        int agent_index = rng_int(mt, 0, n_free - 1);
+        if (agent_index == goal_index) agent_index = (agent_index + 1) % n_free;
+        goal_cell = L.cells[goal_index];
+        agent_cell = L.cells[agent_index];
+    }
+    __syncthreads();
+    for (int c = lane; c < kCells; c += 64) L.aux[c] = 0;
+    __syncthreads();
+    if (lane == 0) path_len = goal_path(L, agent_cell, goal_cell);
+    __syncthreads();
+    for (int c = lane; c < kCells; c += 64) L.aux[c] = 0;
+    __syncthreads();
+    if (lane == 0) {
+        // expand_room(wide_path, 4) (room_generator.cpp:162-202): four layers of 8-neighbour growth through open
+        // cells; only membership matters downstream.
+        int16_t* cur = L.queue;
+        int16_t* nxt = L.parent;
+        int n_cur = 0;
+        for (int k = 0; k < path_len; k++) {
+            const int c = L.next[k];
+            if (!L.aux[c]) {
+                L.aux[c] = 2;
+                cur[n_cur++] = static_cast<int16_t>(c);
+            }
+        }
+        for (int loop = 0; loop < 4; loop++) {
+            int n_nxt = 0;
+            for (int k = 0; k < n_cur; k++) {
+                const int c = cur[k];
+                const int x = c / H, y = c % H;
+                for (int a = -1; a <= 1; a++)
+                    for (int b = -1; b <= 1; b++) {
+                        if (a == 0 && b == 0) continue;
+                        const int nx = x + a, ny = y + b;
+                        if (nx < 0 || ny < 0 || nx >= W || ny >= H) continue;
+                        const int ni = cell_of(nx, ny);
+                        if (!L.aux[ni] && L.grid[ni] == 0) {
+                            L.aux[ni] = 1;
+                            nxt[n_nxt++] = static_cast<int16_t>(ni);
+                        }
+                    }
+            }
+            int16_t* t = cur;
+            cur = nxt;
+            nxt = t;
+            n_cur = n_nxt;
+        }
+        // the four further automaton iterations (tilemap.cpp:217-222) never reach tile_ids (D13)
+
+        // goal (id 0), ship (id 1)
+        put_thing(s, env, 0, kGoal, goal_cell, 0.0f, 0.0f);
+        const float ax = static_cast<float>(agent_cell / H) + 0.5f;
+        const float ay = static_cast<float>(H - 1 - (agent_cell % H));  // no +0.5 (tilemap.cpp:189)
+        SF(s, F_AX, env) = ax;
+        SF(s, F_AY, env) = ay;
+        SF(s, F_AVX, env) = 0.0f;
+        SF(s, F_AVY, env) = 0.0f;
+        SF(s, F_ROT, env) = 0.0f;
+        EB(s, EB_INFO, 1, env) = 0;
+
+        // objects on the open cells off the path, in index order (tilemap.cpp:224-272)
+        int n_free = 0;
+        for (int c = 0; c < kCells; c++)
+            if (L.aux[c] == 1) L.cells[n_free++] = static_cast<int16_t>(c);
+        const int chunk = n_free / 80, num_objects = 3 * chunk;
+        int16_t* picked = L.next;  // the path is no longer needed
+        for (int i = 0; i < num_objects; i++) {
+            int index = rng_int(mt, 0, n_free - 1);
+            bool repeat;
+            do {
+                repeat = false;
+                for (int j = 0; j < i; j++)
+                    if (picked[j] == index) {
+                        index = (index + 1) % n_free;
+                        repeat = true;
+                        break;
+                    }
+            } while (repeat);
+            picked[i] = static_cast<int16_t>(index);
+            const int cell = L.cells[index];
+            const int id = 2 + i;
+            if (i < chunk)
+                put_thing(s, env, id, kMeteor, cell, 0.0f, 0.0f);
+            else if (i < 2 * chunk)
+                put_thing(s, env, id, kTarget, cell, 0.0f, 0.0f);
+            else {  // spawn_enemy (tilemap.cpp:68-101)
+                const float magnitude = 0.1f * rng_real(mt, 0.0f, 1.0f) + 0.1f;
+                const float vel = magnitude * (rng_real(mt, 0.0f, 1.0f) < 0.5f ? 1.0f : -1.0f);
+                const float ex = static_cast<float>(cell / H) + 0.5f, ey = static_cast<float>(H - 1 - cell % H) + 0.5f;
+                const int clash = check_neighbors(ex, ey, ax, ay);
+                bool along_x;
+                if (clash == 0)
+                    along_x = rng_real(mt, 0.0f, 1.0f) < 0.5f;
+                else
+                    along_x = clash == 1;
+                put_thing(s, env, id, kEnemy, cell, along_x ? vel : 0.0f, along_x ? 0.0f : vel);
+            }
+        }
+        const int n_ent = 2 + num_objects;
+        SI(s, I_NENT, env) = n_ent;
+        SI(s, I_BACKDROP, env) = rng_int(mt, 0, 12);
+        SF(s, F_BGSHIFT, env) = rng_real(mt, 0.0f, 1.0f);
+        SI(s, I_FLAGS, env) = kFlagPuffOn;  // draw list cleared; Component_Particles::enabled = true
+        SI(s, I_NDRAW, env) = 0;
+        SI(s, I_SNEXT, env) = 0;  // System_Agent::reset (common_systems.h:83-87); the 32 slots keep their contents
+        SI(s, I_SCOUNT, env) = 0;
+        SF(s, F_STIMER, env) = 0.0f;
+        SF(s, F_PTIMER, env) = 0.0f;
+        for (int k = 0; k < kPuffs; k++)
+            for (int f = 0; f < PF_COUNT; f++) PF(s, f, k, env) = 0.0f;
+        // camera keeps the previous episode's value (D3)
+
+        // entity-set orders of the episode: sprites = goal + objects, hazards = objects
+        uint8_t keys[kMaxEnt], order[kMaxEnt];
+        int nk = 0;
+        keys[nk++] = 0;
+        for (int id = 2; id < n_ent; id++) keys[nk++] = static_cast<uint8_t>(id);
+        int32_t packed = SI(s, I_HASH_SPRITE, env);
+        episode_order(packed, keys, nk, order, L.queue, L.before);
+        SI(s, I_HASH_SPRITE, env) = packed;
+        for (int k = 0; k < nk; k++) EB(s, EB_ORDER_S, k, env) = order[k];
+        packed = SI(s, I_HASH_HAZARD, env);
+        episode_order(packed, keys + 1, nk - 1, order, L.queue, L.before);
+        SI(s, I_HASH_HAZARD, env) = packed;
+        for (int k = 0; k < nk - 1; k++) EB(s, EB_ORDER_H, k, env) = order[k];
+    }
+    __syncthreads();
+    uint8_t* tiles = s.tiles + size_t(env) * kCells;
+    for (int c = lane; c < kCells; c += 64) tiles[c] = L.aux[c] ? kEmpty : kWall;
+    for (int k = lane; k < kMtWords; k += 64) gmt[k] = L.mt[k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// step
+// ------------------------------------------------------------------------------------------------
+PG_D Box thing_box(const State& s, int e, int env, int kind) {
+    const float x = EF(s, EF_X, e, env), y = EF(s, EF_Y, e, env);
+    if (kind == kEnemy || kind == kGoal) return Box{x + -0.4f, y + -0.4f, 0.8f, 0.8f};
+    return Box{x + -0.25f, y + -0.25f, 0.5f, 0.5f};
+}
+
+// System_Sprite_Render::update's list: the surviving sprites in set order, then std::sort on z (all 1.0).
+PG_D void rebuild_draw_list(const State& s, int env, int n_ent) {
+    ZItem items[kMaxEnt];
+    int n = 0;
+    for (int k = 0; k < n_ent - 1; k++) {
+        const int e = EB(s, EB_ORDER_S, k, env);
+        if (EB(s, EB_INFO, e, env) & kAlive) items[n++] = {1.0f, e};
+    }
+    sort_by_key(items, n);
+    for (int k = 0; k < n; k++) EB(s, EB_DRAW, k, env) = static_cast<uint8_t>(items[k].id);
+    SI(s, I_NDRAW, env) = n;
+}
+
+PG_D void advance(const State& s, int env, int action, float& reward_out, bool& terminated_out) {
+    const uint8_t* tiles = s.tiles + size_t(env) * kCells;
+    const int n_ent = SI(s, I_NENT, env);
+    const int flags = SI(s, I_FLAGS, env);
+    float ax = SF(s, F_AX, env), ay = SF(s, F_AY, env), avx = SF(s, F_AVX, env), avy = SF(s, F_AVY, env);
+    float rot = SF(s, F_ROT, env), s_timer = SF(s, F_STIMER, env), p_timer = SF(s, F_PTIMER, env);
+    int s_next = SI(s, I_SNEXT, env), s_count = SI(s, I_SCOUNT, env);
+    bool puff_on = (flags & kFlagPuffOn) != 0;
+    bool set_changed = (flags & kFlagListed) == 0;
+
+    const float dt = 1.0f / 4;
+    const float accel = 0.05f, spin_rate = 0.05f, vel_decay = 0.1f, reverse_mul = 0.5f, bullet_time = 0.5f,
+                bullet_speed = 1.0f, explosion_rate = 0.5f;
+    const float movement_x = static_cast<float>((action == 6 || action == 7 || action == 8) -
+                                                (action == 0 || action == 1 || action == 2));
+    float movement_y = static_cast<float>((action == 2 || action == 5 || action == 8) -
+                                          (action == 0 || action == 3 || action == 6));
+    const bool fire = action == 9;
+    if (movement_y < 0.0f) movement_y *= reverse_mul;
+
+    float reward = 0.0f;
+    bool terminated = false;
+    for (int ss = 0; ss < 4; ss++) {
+        // --- System_Agent::update (common_systems.cpp:90-289)
+        bool alive = true, achieved_goal = false;
+        int targets_destroyed = 0;
+        rot += movement_x * spin_rate * dt;
+        const float dir_x = sc_cosf(rot), dir_y = sc_sinf(rot);
+        if (fire) {
+            if (s_timer == 0.0f && s_count < kShots) {
+                s_timer = bullet_time;
+                SH(s, SH_ROT, s_next, env) = rot;
+                SH(s, SH_VX, s_next, env) = dir_x * bullet_speed;
+                SH(s, SH_VY, s_next, env) = dir_y * bullet_speed;
+                SH(s, SH_X, s_next, env) = ax;
+                SH(s, SH_Y, s_next, env) = ay;
+                SH(s, SH_FRAME, s_next, env) = 0.0f;
+                s_next = (s_next + 1) % kShots;
+                s_count++;
+            } else {
+                s_timer = fmaxf(0.0f, s_timer - dt);
+            }
+        }
+        const float acc_x = dir_x * movement_y * accel, acc_y = dir_y * movement_y * accel;
+        avx += (acc_x - avx * vel_decay) * dt;
+        avy += (acc_y - avy * vel_decay) * dt;
+        ax += avx * dt;
+        ay += avy * dt;
+        Box body{ax + -0.4f, ay + -0.4f, 0.8f, 0.8f};
+        {
+            const Win win = Win::fetch(tiles, static_cast<int>(floorf(body.x)), static_cast<int>(floorf(body.y)));
+            const TileHit h = collide_plain(win, body, is_wall);
+            const float moved_x = h.x - body.x, moved_y = h.y - body.y;
+            ax = h.x - -0.4f;
+            ay = h.y - -0.4f;
+            body.x = ax + -0.4f;
+            body.y = ay + -0.4f;
+            if (moved_x != 0.0f) avx = 0.0f;
+            if (moved_y != 0.0f) avy = 0.0f;
+        }
+        for (int e = 2; e < n_ent; e++) {  // hazards: any hit kills, order-free
+            const int info = EB(s, EB_INFO, e, env);
+            if ((info & kAlive) && box_hit(body, thing_box(s, e, env, info & kKindMask))) alive = false;
+        }
+        if (box_hit(body, thing_box(s, 0, env, kGoal))) achieved_goal = true;
+        const float cam_x = ax * kUnitPx, cam_y = ay * kUnitPx;
+
+        for (int i = 0; i < s_count; i++) {  // bullets, newest first
+            const int k = (kShots + s_next - 1 - i) % kShots;
+            float frame = SH(s, SH_FRAME, k, env);
+            if (frame == -1.0f) continue;
+            float bx = SH(s, SH_X, k, env), by = SH(s, SH_Y, k, env);
+            float bvx = SH(s, SH_VX, k, env), bvy = SH(s, SH_VY, k, env);
+            if (frame == 0.0f) {
+                const Box sb{bx - 0.01f, by - 0.01f, 0.02f, 0.02f};
+                const Win win = Win::fetch(tiles, static_cast<int>(floorf(sb.x)), static_cast<int>(floorf(sb.y)));
+                if (collide_plain(win, sb, is_wall).any) {
+                    bvx = 0.0f;
+                    bvy = 0.0f;
+                    frame = 1.0f;
+                }
+                for (int q = 0; q < n_ent - 2; q++) {  // first hit in the hazard set's iteration order
+                    const int e = EB(s, EB_ORDER_H, q, env);
+                    const int info = EB(s, EB_INFO, e, env);
+                    if (!(info & kAlive)) continue;
+                    if (box_hit(sb, thing_box(s, e, env, info & kKindMask))) {
+                        bvx = 0.0f;
+                        bvy = 0.0f;
+                        frame = 1.0f;
+                        if ((info & kKindMask) == kTarget) {
+                            EB(s, EB_INFO, e, env) = static_cast<uint8_t>(info & ~kAlive);  // destroy_entity
+                            set_changed = true;
+                            targets_destroyed++;
+                        }
+                        break;
+                    }
+                }
+            }
+            bx += bvx * dt;
+            by += bvy * dt;
+            if (frame >= 5.0f) {
+                s_count--;
+                frame = -1.0f;
+            } else if (frame >= 1.0f) {
+                frame += explosion_rate * dt;
+            }
+            SH(s, SH_X, k, env) = bx;
+            SH(s, SH_Y, k, env) = by;
+            SH(s, SH_VX, k, env) = bvx;
+            SH(s, SH_VY, k, env) = bvy;
+            SH(s, SH_FRAME, k, env) = frame;
+        }
+        puff_on = movement_y > 0.0f;
+
+        // --- System_Mob_AI::update (common_systems.cpp:50-75)
+        for (int e = 2; e < n_ent; e++) {
+            const int info = EB(s, EB_INFO, e, env);
+            if ((info & kKindMask) != kEnemy) continue;
+            float vx = EF(s, EF_VX, e, env), vy = EF(s, EF_VY, e, env);
+            const float x = EF(s, EF_X, e, env) + vx * dt, y = EF(s, EF_Y, e, env) + vy * dt;
+            const Box box{x + -0.4f, y + -0.4f, 0.8f, 0.8f};
+            const Win win = Win::fetch(tiles, static_cast<int>(floorf(box.x)), static_cast<int>(floorf(box.y)));
+            if (collide_plain(win, box, is_wall).any) {
+                vx = -vx;
+                vy = -vy;
+            }
+            EF(s, EF_X, e, env) = x;
+            EF(s, EF_Y, e, env) = y;
+            EF(s, EF_VX, e, env) = vx;
+            EF(s, EF_VY, e, env) = vy;
+        }
+
+        // --- System_Particles::update (common_systems.cpp:333-372)
+        {
+            const float lifespan = 3.0f, spawn_time = 0.3f, off_x = 0.0f, off_y = 0.3f;
+            int dead_index = -1;
+            for (int k = 0; k < kPuffs; k++) {
+                const float life = PF(s, PF_LIFE, k, env) - dt;
+                PF(s, PF_LIFE, k, env) = life;
+                if (life <= 0.0f) dead_index = k;
+            }
+            p_timer += dt;
+            if (dead_index != -1 && p_timer >= spawn_time && puff_on) {
+                p_timer = fmodf(p_timer, spawn_time);
+                const float prot = static_cast<float>(rot + kPi * 0.5f);
+                const float c = sc_cosf(prot), sn = sc_sinf(prot);
+                PF(s, PF_LIFE, dead_index, env) = lifespan;
+                PF(s, PF_ROT, dead_index, env) = prot;
+                PF(s, PF_DX, dead_index, env) = -sc_cosf(rot);
+                PF(s, PF_DY, dead_index, env) = -sc_sinf(rot);
+                PF(s, PF_X, dead_index, env) = ax + (c * off_x - sn * off_y);
+                PF(s, PF_Y, dead_index, env) = ay + (sn * off_x + c * off_y);
+            }
+        }
+        SF(s, F_CAMX, env) = cam_x;
+        SF(s, F_CAMY, env) = cam_y;
+
+        reward = achieved_goal * 10.0f + targets_destroyed * 3.0f;
+        terminated = !alive || achieved_goal;
+        if (terminated) break;
+    }
+    SF(s, F_AX, env) = ax;
+    SF(s, F_AY, env) = ay;
+    SF(s, F_AVX, env) = avx;
+    SF(s, F_AVY, env) = avy;
+    SF(s, F_ROT, env) = rot;
+    SF(s, F_STIMER, env) = s_timer;
+    SF(s, F_PTIMER, env) = p_timer;
+    SI(s, I_SNEXT, env) = s_next;
+    SI(s, I_SCOUNT, env) = s_count;
+    SI(s, I_FLAGS, env) = kFlagListed | (puff_on ? kFlagPuffOn : 0);
+    if (set_changed) rebuild_draw_list(s, env, n_ent);
+    reward_out = reward;
+    terminated_out = terminated;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) make_kernel(State s, uint32_t seed_base, int env_offset) {
+    const int env = blockIdx.x * 64 + threadIdx.x;
+    if (env >= s.n) return;
+    SI(s, I_HASH_SPRITE, env) = 1;
+    SI(s, I_HASH_HAZARD, env) = 1;
+    SF(s, F_CAMX, env) = 0.0f;  // Renderer::camera_position{0} (renderer.h:18)
+    SF(s, F_CAMY, env) = 0.0f;
+    for (int k = 0; k < kShots; k++)  // std::vector<Bullet>(32): frame = -1 ("dead"), rest zero
+        for (int f = 0; f < SH_COUNT; f++) SH(s, f, k, env) = (f == SH_FRAME) ? -1.0f : 0.0f;
+}
+
+// mode 0: cenv_make (seed = seed_base + env index); 1: explicit reset (mask, optional seeds); 2: the envs whose
+// previous step terminated (auto-reset: this vector step is their reset, StepIO::pending → 2 tells the logic kernel).
+__global__ void __launch_bounds__(64) level_kernel(State s, int mode, uint32_t seed_base, int env_offset,
+                                                   const uint8_t* mask, const int32_t* seeds, StepIO io) {
+    const int env = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (mode == 1 && mask && !mask[env]) return;
+    if (mode == 2 && io.pending[env] != 1) return;
+    __shared__ GenLds L;
+    const bool reseed = mode == 0 || (mode == 1 && seeds != nullptr);
+    const uint32_t seed =
+        mode == 0 ? seed_base + static_cast<uint32_t>(env_offset + env) : (seeds ? static_cast<uint32_t>(seeds[env]) : 0u);
+    new_level(s, env, L, reseed, seed, lane);
+    if (mode != 0 && lane == 0) {
+        io.reward[env] = 0.0f;
+        io.done[env] = 0;
+        io.pending[env] = mode == 2 ? 2 : 0;
+    }
+}
+
+__global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actions, uint32_t run_seed,
+                                                   uint32_t step_index, int env_offset, StepIO io) {
+    const int env = blockIdx.x * 64 + threadIdx.x;
+    if (env >= s.n) return;
+    if (io.pending[env] == 2) {  // reset by level_kernel in this step
+        io.pending[env] = 0;
+        return;
+    }
+    const int action =
+        actions ? actions[env] : synthetic_action(run_seed, step_index, static_cast<uint32_t>(env_offset + env));
+    float reward;
+    bool terminated;
+    advance(s, env, action, reward, terminated);
+    io.reward[env] = reward;
+    io.done[env] = terminated ? 1 : 0;
+    io.pending[env] = terminated ? 1 : 0;
+}
+
+// render_game(true) (caveflyer.cpp:413-440): one wavefront per env.
+__global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
+                                                    int flags) {
+    const int env = blockIdx.x;
+    if (mask && !mask[env]) return;
+    const int lane = threadIdx.x;
+    __shared__ uint32_t fb[kFbWords];
+    constexpr int kGrid = 16;  // 64 px / 8 px per tile → at most 10 columns/rows in view
+    __shared__ ComposeLds<kGrid> L;
+
+    const Camera cam{SF(s, F_CAMX, env), SF(s, F_CAMY, env), 64.0f, 64.0f, 0.5f * 64.0f / 64.0f};
+    const int sflags = SI(s, I_FLAGS, env);
+    const int n_draw = (sflags & kFlagListed) ? SI(s, I_NDRAW, env) : 0;  // empty right after a reset
+    const int s_next = SI(s, I_SNEXT, env), s_count = SI(s, I_SCOUNT, env);
+    const uint8_t* tiles = s.tiles + size_t(env) * kCells;
+    const DescRegs descs = DescRegs::load(atlas, lane);
+    Blit mine;
+
+    // inputs of the sprite passes, requested early
+    float puff_life = 0.0f, puff_x = 0.0f, puff_y = 0.0f, puff_dx = 0.0f, puff_dy = 0.0f, puff_rot = 0.0f;
+    if (lane < kPuffs) {
+        puff_life = PF(s, PF_LIFE, lane, env);
+        puff_x = PF(s, PF_X, lane, env);
+        puff_y = PF(s, PF_Y, lane, env);
+        puff_dx = PF(s, PF_DX, lane, env);
+        puff_dy = PF(s, PF_DY, lane, env);
+        puff_rot = PF(s, PF_ROT, lane, env);
+    }
+    int spr_kind = 0;
+    float spr_x = 0.0f, spr_y = 0.0f;
+    if (lane < n_draw) {
+        const int e = EB(s, EB_DRAW, lane, env);
+        spr_kind = EB(s, EB_INFO, e, env) & kKindMask;
+        spr_x = EF(s, EF_X, e, env);
+        spr_y = EF(s, EF_Y, e, env);
+    }
+    float shot_frame = -1.0f, shot_x = 0.0f, shot_y = 0.0f, shot_rot = 0.0f;
+    if (lane < s_count) {
+        const int k = (kShots + s_next - 1 - lane) % kShots;
+        shot_frame = SH(s, SH_FRAME, k, env);
+        shot_x = SH(s, SH_X, k, env);
+        shot_y = SH(s, SH_Y, k, env);
+        shot_rot = SH(s, SH_ROT, k, env);
+    } else if (lane == s_count) {
+        shot_x = SF(s, F_AX, env);
+        shot_y = SF(s, F_AY, env);
+        shot_rot = SF(s, F_ROT, env);
+    }
+
+    Blit bg;  // caveflyer.cpp:427-432
+    bool has_bg;
+    {
+        const int4 d = descs.uniform(kTexSpace + SI(s, I_BACKDROP, env));
+        const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
+        const float extra = aspect - 1.0f;
+        has_bg = resolve_draw(cam, d.y, d.z, d.x, -SF(s, F_BGSHIFT, env) * extra, 0.0f, 64.0f * kUnitPx / d.z, 1.0f,
+                              false, false, bg);
+    }
+    // tile window (tilemap.cpp:280-289)
+    const float vx = (cam.px - cam.sw * 0.5f / cam.scale) * kPxUnit;
+    const float vy = (cam.py - cam.sh * 0.5f / cam.scale) * kPxUnit;
+    const float vw = cam.sw * kPxUnit / cam.scale, vh = cam.sh * kPxUnit / cam.scale;
+    const int x0 = static_cast<int>(floorf(vx)), y0 = static_cast<int>(floorf(vy));
+    const int x1 = static_cast<int>(ceilf(vx + vw)), y1 = static_cast<int>(ceilf(vy + vh));
+    const int cols = x1 - x0 + 1, rows = y1 - y0 + 1, cells = cols * rows;
+    const int4 wall_d = descs.uniform(kTexWall);
+
+    bool composed = false;
+    if (!(flags & 1) && cols <= kGrid && rows <= kGrid) {
+        compose_spans<kGrid, 16>(L, cam, x0, y0, cols, rows, wall_d.y, wall_d.z, kUnitPx / wall_d.y, lane);
+#pragma unroll
+        for (int k = 0; k < kGrid * kGrid / 64; k++) {
+            const int cell = k * 64 + lane;
+            const int r = cell / kGrid, c = cell % kGrid;
+            const int t = (c < cols && r < rows) ? Win::direct(tiles, x0 + c, y0 + r) : kEmpty;
+            L.base[cell] = (t == kEmpty) ? static_cast<int32_t>(kNoTexel) : wall_d.x * 4;
+        }
+        __syncthreads();
+        composed = compose_rows(fb, L, atlas, bg, has_bg, cols, rows, wall_d.y, lane, flags);
+    }
+    if (!composed) {  // draw-list replay (tilemap.cpp:291-302)
+        wave_clear(fb, lane);
+        mine = bg;
+        wave_replay(fb, atlas, mine, has_bg ? 1ull : 0ull, lane);
+        for (int base = 0; base < cells; base += 64) {
+            const int cell = base + lane;
+            bool has = false;
+            if (cell < cells) {
+                const int row = cell / cols;
+                const int x = x0 + (cell - row * cols), y = y0 + row;
+                if (Win::direct(tiles, x, y) != kEmpty)
+                    has = resolve_draw(cam, wall_d.y, wall_d.z, wall_d.x, x * kUnitPx, y * kUnitPx, kUnitPx / wall_d.y,
+                                       1.0f, false, false, mine);
+            }
+            wave_replay(fb, atlas, mine, __ballot(has), lane);
+        }
+    }
+
+    {  // System_Particles::render (common_systems.cpp:374-397): rotated, fading
+        const int4 d = descs.uniform(kTexPuff);
+        bool has = false;
+        if (lane < kPuffs && puff_life > 0.0f) {
+            const float lifespan = 3.0f;
+            const float life_ratio = (lifespan - puff_life) / lifespan;
+            const float alpha = 0.5f * (1.0f - life_ratio);
+            const float scale = 1.0f * (0.4f * life_ratio + 0.6f);
+            const float shift = life_ratio * 2.0f;
+            const float size = scale * kUnitPx / d.y;
+            has = resolve_rotated(cam, d.y, d.z, d.x, (puff_x + puff_dx * shift) * kUnitPx - size * d.y * 0.5f,
+                                  (puff_y + puff_dy * shift) * kUnitPx - size * d.z * 0.5f, puff_rot, size, alpha, mine);
+        }
+        wave_replay(fb, atlas, mine, __ballot(has), lane);
+    }
+    {  // positive-z sprites (common_systems.cpp:26-48): goal, meteors, targets, enemies
+        const int4 d = descs.at(kTexKind + spr_kind);
+        bool has = false;
+        if (lane < n_draw) {
+            const float scale = 1.0f * 0.8f;
+            has = resolve_draw(cam, d.y, d.z, d.x, (spr_x + -0.4f) * kUnitPx, (spr_y + -0.4f) * kUnitPx,
+                               scale * kUnitPx / d.y, 1.0f, false, false, mine);
+        }
+        wave_replay(fb, atlas, mine, __ballot(has), lane);
+    }
+    {  // System_Agent::render (common_systems.cpp:291-327): bullets newest first, then the ship
+        int want_tex = kTexShip;
+        bool has = lane == s_count;
+        float size = 0.15f;
+        if (lane < s_count && shot_frame != -1.0f) {
+            has = true;
+            size = 0.1f;
+            want_tex = (shot_frame == 0.0f) ? kTexLaser : kTexBoom + static_cast<int>(shot_frame - 1.0f);
+        }
+        const int4 d = descs.at(want_tex);
+        if (has)
+            has = resolve_rotated(cam, d.y, d.z, d.x, shot_x * kUnitPx - size * d.y * 0.5f,
+                                  shot_y * kUnitPx - size * d.z * 0.5f, static_cast<float>(shot_rot + kPi * 0.5f), size,
+                                  1.0f, mine);
+        wave_replay(fb, atlas, mine, __ballot(has), lane);
+    }
+    wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane);
+}
+
+class CaveflyerGame final : public Game {
+   public:
+    const char* name() const override { return "caveflyer"; }
+    std::vector<std::string> texture_names() const override {
+        std::vector<std::string> v;
+        for (const char* t : {"groundA", "meteorBrown_big1", "ufoRed2", "enemyShipBlue4", "ufoGreen2", "playerShip1_red",
+                              "laserBlue02", "explosion1", "explosion2", "explosion3", "explosion4", "explosion5",
+                              "towerDefense_tile295"})
+            v.push_back(std::string("misc_assets/") + t + ".png");
+        for (const char* b : {"deep_space_01", "spacegen_01", "milky_way_01", "ez_space_lite_01", "meyespace_v1_01",
+                              "eye_nebula_01", "deep_sky_01", "space_nebula_01", "Background-1", "Background-2",
+                              "Background-3", "Background-4", "parallax-space-backgound"})
+            v.push_back(std::string("space_backgrounds/") + b + ".png");
+        return v;
+    }
+    std::string check_atlas(const std::vector<std::pair<int, int>>& sizes) const override {
+        return static_cast<int>(sizes.size()) == kTexCount ? "" : "caveflyer: unexpected texture count";
+    }
+    static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+    struct Layout {
+        size_t mt, tiles, f, i, ef, eb, sh, pf, total;
+    };
+    static Layout layout(int n) {
+        Layout l{};
+        size_t off = 0;
+        auto take = [&](size_t bytes) {
+            size_t at = off;
+            off += align256(bytes);
+            return at;
+        };
+        l.mt = take(size_t(n) * kMtWords * 4);
+        l.tiles = take(size_t(n) * kCells);
+        l.f = take(size_t(F_COUNT) * n * 4);
+        l.i = take(size_t(I_COUNT) * n * 4);
+        l.ef = take(size_t(EF_COUNT) * kMaxEnt * n * 4);
+        l.eb = take(size_t(EB_COUNT) * kMaxEnt * n);
+        l.sh = take(size_t(SH_COUNT) * kShots * n * 4);
+        l.pf = take(size_t(PF_COUNT) * kPuffs * n * 4);
+        l.total = off;
+        return l;
+    }
+    size_t state_bytes(int n) const override { return layout(n).total; }
+    void bind(void* d_state, int n, AtlasView atlas) override {
+        uint8_t* p = static_cast<uint8_t*>(d_state);
+        const Layout l = layout(n);
+        s_.n = n;
+        s_.mt = reinterpret_cast<uint32_t*>(p + l.mt);
+        s_.tiles = p + l.tiles;
+        s_.f = reinterpret_cast<float*>(p + l.f);
+        s_.i = reinterpret_cast<int32_t*>(p + l.i);
+        s_.ef = reinterpret_cast<float*>(p + l.ef);
+        s_.eb = p + l.eb;
+        s_.sh = reinterpret_cast<float*>(p + l.sh);
+        s_.pf = reinterpret_cast<float*>(p + l.pf);
+        atlas_ = atlas;
+    }
+    int blocks() const { return (s_.n + 63) / 64; }
+    void launch_make(hipStream_t st, uint32_t seed_base, int env_offset) override {
+        hipLaunchKernelGGL(make_kernel, dim3(blocks()), dim3(64), 0, st, s_, seed_base, env_offset);
+        hipLaunchKernelGGL(level_kernel, dim3(s_.n), dim3(64), 0, st, s_, 0, seed_base, env_offset, nullptr, nullptr,
+                           StepIO{});
+    }
+    void launch_reset(hipStream_t st, const uint8_t* mask, const int32_t* seeds, StepIO io) override {
+        hipLaunchKernelGGL(level_kernel, dim3(s_.n), dim3(64), 0, st, s_, 1, 0u, 0, mask, seeds, io);
+    }
+    void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
+                      StepIO io) override {
+        hipLaunchKernelGGL(level_kernel, dim3(s_.n), dim3(64), 0, st, s_, 2, 0u, 0, nullptr, nullptr, io);
+        hipLaunchKernelGGL(logic_kernel, dim3(blocks()), dim3(64), 0, st, s_, actions, run_seed, step_index,
+                           env_offset, io);
+    }
+    void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
+        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(64), 0, st, s_, atlas_, mask, io, debug_flags);
+    }
+    // Same layout as oracle/pgo_caveflyer.cpp Caveflyer::dump_state.
+    int dump_state(hipStream_t st, int env, float* out, int cap) override {
+        hipStreamSynchronize(st);
+        const size_t n = s_.n;
+        auto rf = [&](const float* base, size_t idx) {
+            float v;
+            hipMemcpy(&v, base + idx, 4, hipMemcpyDeviceToHost);
+            return v;
+        };
+        auto ri = [&](int field) {
+            int32_t v;
+            hipMemcpy(&v, s_.i + size_t(field) * n + env, 4, hipMemcpyDeviceToHost);
+            return v;
+        };
+        auto f = [&](int field) { return rf(s_.f, size_t(field) * n + env); };
+        const int flags = ri(I_FLAGS), n_ent = ri(I_NENT);
+        std::vector<float> v = {f(F_AX), f(F_AY), f(F_AVX), f(F_AVY), f(F_ROT), f(F_CAMX), f(F_CAMY),
+                                static_cast<float>(ri(I_BACKDROP)), f(F_BGSHIFT), static_cast<float>(ri(I_SNEXT)),
+                                static_cast<float>(ri(I_SCOUNT)), f(F_STIMER), f(F_PTIMER),
+                                (flags & kFlagPuffOn) ? 1.0f : 0.0f, static_cast<float>(n_ent)};
+        for (int k = 0; k < kShots; k++)
+            for (int fld : {SH_X, SH_Y, SH_FRAME}) v.push_back(rf(s_.sh, (size_t(fld) * kShots + k) * n + env));
+        for (int k = 0; k < kPuffs; k++)
+            for (int fld : {PF_X, PF_Y, PF_LIFE}) v.push_back(rf(s_.pf, (size_t(fld) * kPuffs + k) * n + env));
+        for (int e = 0; e < n_ent; e++) {
+            if (e == 1) continue;
+            uint8_t info;
+            hipMemcpy(&info, s_.eb + (size_t(EB_INFO) * kMaxEnt + e) * n + env, 1, hipMemcpyDeviceToHost);
+            auto ef = [&](int field) { return rf(s_.ef, (size_t(field) * kMaxEnt + e) * n + env); };
+            v.push_back((info & kAlive) ? 1.0f : 0.0f);
+            v.push_back(static_cast<float>(info & kKindMask));
+            v.push_back(ef(EF_X));
+            v.push_back(ef(EF_Y));
+            v.push_back(ef(EF_VX));
+            v.push_back(ef(EF_VY));
+        }
+        const int m = cap < static_cast<int>(v.size()) ? cap : static_cast<int>(v.size());
+        for (int k = 0; k < m; k++) out[k] = v[k];
+        return static_cast<int>(v.size());
+    }
+    int dump_tiles(hipStream_t st, int env, uint8_t* out, int cap) override {
+        hipStreamSynchronize(st);
+        const int m = cap < kCells ? cap : kCells;
+        hipMemcpy(out, s_.tiles + size_t(env) * kCells, m, hipMemcpyDeviceToHost);
+        return m;
+    }
+
+   private:
+    State s_{};
+    AtlasView atlas_{};
+};
+
+}  // namespace caveflyer
+
+std::unique_ptr<Game> make_caveflyer() { return std::make_unique<caveflyer::CaveflyerGame>(); }
+
+}  // namespace pg

@@ -85,7 +85,7 @@ static std::string asset_root() {
     return "assets";
 }
 
-static const char* const kGameNames[kNumGames] = {"coinrun", "maze", "bossfight", "climber"};
+static const char* const kGameNames[kNumGames] = {"coinrun", "maze", "bossfight", "climber", "caveflyer"};
 
 static std::unique_ptr<Game> make_game(int id) {
     switch (id) {
@@ -93,6 +93,7 @@ static std::unique_ptr<Game> make_game(int id) {
         case kGameMaze: return make_maze();
         case kGameBossfight: return make_bossfight();
         case kGameClimber: return make_climber();
+        case kGameCaveflyer: return make_caveflyer();
         default: return nullptr;
     }
 }

@@ -40,7 +40,7 @@ struct ComposeLds {
     int32_t cover[2][64][2];    // the first two of them: grid index | texel coordinate << 8
     int32_t too_wide;           // some span is wider than kMaxSpan pixels → fall back
 };
-constexpr int kMaxSpan = 8;  // a tile of the layer covers at most this many pixels per axis (coinrun 5–6, maze 3)
+constexpr int kMaxSpan = 8;  // default bound on the pixels one tile covers per axis (coinrun 5–6, maze 3); caveflyer passes 16
 
 // The atlas descriptor table held in registers, two entries per lane (tables up to 128 textures): one pair of
 // global loads at kernel start instead of a dependent global lookup in front of every draw.
@@ -281,7 +281,7 @@ PG_D void wave_clear(uint32_t* fb, int lane) {
 // y0+c), then — after a barrier — every (span, offset) pair scatters itself to the pixel it covers, so each pixel
 // column / row learns which grid columns / rows cover it and at which texel coordinate, without a search loop.
 // Leaves a __syncthreads() to the caller (the staging of L.base provides it) before compose_rows.
-template <int GRID>
+template <int GRID, int MAXSPAN = kMaxSpan>
 PG_D void compose_spans(ComposeLds<GRID>& L, const Camera& cam, int x0, int y0, int cols, int rows, int tw, int th,
                         float tile_scale, int lane) {
     L.cover_n[0][lane] = 0;
@@ -292,13 +292,13 @@ PG_D void compose_spans(ComposeLds<GRID>& L, const Camera& cam, int x0, int y0, 
         Span sp;
         const bool ok = resolve_axis(cam.px, cam.sw, cam.scale, tw, (x0 + lane) * kUnitPx, tile_scale, false, false, sp);
         L.col[lane] = ok ? make_int4(sp.d0, sp.dn, sp.s0, sp.sn) : make_int4(0, 0, 0, 0);
-        wide = ok && sp.dn > kMaxSpan;
+        wide = ok && sp.dn > MAXSPAN;
     }
     if (lane < rows) {
         Span sp;
         const bool ok = resolve_axis(cam.py, cam.sh, cam.scale, th, (y0 + lane) * kUnitPx, tile_scale, false, true, sp);
         L.row[lane] = ok ? make_int4(sp.d0, sp.dn, sp.s0, sp.sn) : make_int4(0, 0, 0, 0);
-        wide = wide || (ok && sp.dn > kMaxSpan);
+        wide = wide || (ok && sp.dn > MAXSPAN);
     }
     __syncthreads();
     if (__ballot(wide)) {
@@ -309,8 +309,8 @@ PG_D void compose_spans(ComposeLds<GRID>& L, const Camera& cam, int x0, int y0, 
     for (int axis = 0; axis < 2; axis++) {
         const int4* spans = axis == 0 ? L.col : L.row;
         const int count = axis == 0 ? cols : rows;
-        for (int q = lane; q < count * kMaxSpan; q += 64) {
-            const int g = q / kMaxSpan, i = q % kMaxSpan;
+        for (int q = lane; q < count * MAXSPAN; q += 64) {
+            const int g = q / MAXSPAN, i = q % MAXSPAN;
             const int4 sp = spans[g];
             const int p = sp.x + i;
             if (sp.w > 0 && i < sp.y && p >= 0 && p < 64) {

@@ -56,7 +56,7 @@ def test_coinrun_lockstep_256_envs():
     assert resets > 0, "no episode ended: the auto-reset path was not exercised"
 
 
-@pytest.mark.parametrize("game", ["coinrun", "maze", "bossfight", "climber"])
+@pytest.mark.parametrize("game", ["coinrun", "maze", "bossfight", "climber", "caveflyer"])
 def test_row_composer_equals_draw_list_replay(game):
     """The fused background+tile row composer (pg_render.h compose_rows) against the one-blit-at-a-time replay of
     the reference's draw list, the same engine in both modes, every byte of 512 envs over 150 steps."""
@@ -107,6 +107,33 @@ def test_bossfight_fire_heavy_actions():
     ora.close()
 
 
+def test_caveflyer_lockstep_with_fire():
+    # BASELINE.json configs[2] game.  40% fire / thrust-heavy actions: bullets, target destruction (+3, entity sets
+    # shrink and the draw list is rebuilt), exhaust particles (rotated + alpha blits), deaths -> the level generator
+    # (hashtable-ordered largest room, BFS path, widening) runs for the auto-resets.
+    n = 160
+    eng, ora = EngineVec("caveflyer", n, seed_base=41), OracleVec("caveflyer", n, seed_base=41)
+    assert np.array_equal(eng.reset(), ora.reset_obs())
+    rng = np.random.default_rng(8)
+    ends, rew = 0, 0.0
+    for s in range(700):
+        u = rng.random(n)
+        a = np.where(u < 0.25, 9, np.where(u < 0.55, rng.choice([2, 5, 8], n), rng.integers(0, 15, n))).astype(np.int32)
+        oe, re_, de = eng.step(a)
+        oo, ro, do = ora.step(a)
+        assert np.array_equal(de, do) and np.array_equal(re_.view(np.uint32), ro.view(np.uint32)), s
+        assert np.array_equal(oe, oo), s
+        ends += int(do.sum())
+        rew += float(ro.sum())
+        if s % 100 == 0:
+            for e in range(0, n, 20):
+                assert np.array_equal(eng.state(e).view(np.uint32), ora.state(e).view(np.uint32)), (s, e)
+                assert np.array_equal(eng.tiles(e), ora.tiles(e)), (s, e)
+    assert ends > 10 and rew > 0.0, (ends, rew)
+    eng.close()
+    ora.close()
+
+
 def test_climber_lockstep_jump_heavy_actions():
     # Uniform random actions rarely leave the floor; biasing towards the jump actions (2, 5, 8) makes agents climb,
     # collect crystals (entity destruction -> draw-list rebuild) and die on mobs (auto-reset, new level).
@@ -148,7 +175,7 @@ def test_maze_out_of_range_actions_follow_reference_quirk():
     ora.close()
 
 
-@pytest.mark.parametrize("game", ["coinrun", "maze", "bossfight", "climber"])
+@pytest.mark.parametrize("game", ["coinrun", "maze", "bossfight", "climber", "caveflyer"])
 def test_reset_with_seed_option_and_mask(game):
     """cenv_reset's "seed" option (coinrun.cpp:313-317) per env, and masked resets leaving other envs untouched."""
     n = 16
@@ -206,7 +233,7 @@ def test_cenv_abi_single_env_matches_reference_loop():
     """The drop-in path: CEnv("libCoinRun.so", options={"seed": s}) → reset → step(int) … with the caller doing
     `if term: reset()` — exactly game_test.py:36-40 — against the oracle driven the same way."""
     for libname, game in (("libCoinRun.so", "coinrun"), ("libMaze.so", "maze"), ("libBossFight.so", "bossfight"),
-                          ("libClimber.so", "climber")):
+                          ("libClimber.so", "climber"), ("libCaveFlyer.so", "caveflyer")):
         env = pgcenv.CEnv(os.path.join(pglib.LIB_DIR, libname), options={"seed": 123})
         assert list(env.observation_space) == ["screen"] and list(env.action_space) == ["action"]
         assert list(env.action_space["action"].nvec) == [15]

@@ -88,7 +88,17 @@ def climber():
     return ["platformer/%s.png" % n for n in tiles + players] + ["misc_assets/yellowCrystal.png"] + backs
 
 
-GAMES = {"coinrun": coinrun, "maze": maze, "bossfight": bossfight, "climber": climber}
+def caveflyer():
+    # games/caveflyer/caveflyer.cpp:58-72, tilemap.cpp:6-20, common_systems.cpp:77-88, :329-331
+    misc = ["groundA", "meteorBrown_big1", "ufoRed2", "enemyShipBlue4", "ufoGreen2", "playerShip1_red", "laserBlue02",
+            "towerDefense_tile295"] + ["explosion%d" % i for i in range(1, 6)]
+    space = ["deep_space_01", "spacegen_01", "milky_way_01", "ez_space_lite_01", "meyespace_v1_01", "eye_nebula_01",
+             "deep_sky_01", "space_nebula_01", "Background-1", "Background-2", "Background-3", "Background-4",
+             "parallax-space-backgound"]
+    return ["misc_assets/%s.png" % n for n in misc] + ["space_backgrounds/%s.png" % n for n in space]
+
+
+GAMES = {"coinrun": coinrun, "maze": maze, "bossfight": bossfight, "climber": climber, "caveflyer": caveflyer}
 
 
 def main():
