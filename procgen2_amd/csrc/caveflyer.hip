@@ -15,11 +15,14 @@
 //   * level generation — one wavefront per env with a 23 KiB LDS workspace.  The generator's result depends on
 //              the iteration order of a std::unordered_set<int> holding up to 1600 cells (the largest room,
 //              tilemap.cpp:158-169), so the libstdc++ hashtable is replayed (pg_order.h) — inherently serial, hence
-//              on LDS rather than HBM: the dependent-access latency is what bounds it.  Episodes are long
-//              (thousands of steps), so this kernel touches a handful of envs per step.
+//              on LDS rather than HBM: the dependent-access latency is what bounds it (≈2 ms for one env, ≈1 µs per
+//              env in bulk).  The game draws no random numbers during an episode, so the NEXT level of every env is
+//              generated ahead of time on a side stream into a shadow slot and merely copied in when the episode
+//              ends (pg_prefetch.h); the synchronous path remains as the fallback and for reseeding resets.
 #include "pg_engine.h"
 #include "pg_geom.h"
 #include "pg_order.h"
+#include "pg_prefetch.h"
 #include "pg_render.h"
 #include "pg_rng.h"
 #include "pg_sincos.h"
@@ -55,9 +58,22 @@ constexpr int kKindMask = 3, kAlive = 4;
 enum { SH_X, SH_Y, SH_VX, SH_VY, SH_ROT, SH_FRAME, SH_COUNT };
 enum { PF_X, PF_Y, PF_DX, PF_DY, PF_ROT, PF_LIFE, PF_COUNT };
 
+// One generated level, as the generator leaves it in LDS and as it waits in the shadow slot.
+struct Level {
+    uint8_t tiles[W * H];
+    float ax, ay, bgshift;
+    int32_t n_ent, backdrop;
+    float ex[kMaxEnt], ey[kMaxEnt], evx[kMaxEnt], evy[kMaxEnt];
+    uint8_t info[kMaxEnt], order_s[kMaxEnt], order_h[kMaxEnt];
+    uint8_t pad[2];
+};
+static_assert(sizeof(Level) % 4 == 0, "Level is copied as 32-bit words");
+
 struct State {
     int n;
-    uint32_t* mt;    // [n][625]
+    Level* shadow;   // [n]  next level of each env (pg_prefetch.h)
+    int32_t* slot;   // [n]  SlotState
+    uint32_t* mt;    // [n][625]  generator chain: the stream position after the newest generated level
     uint8_t* tiles;  // [n][1600]  column-major y + x*H
     float* f;        // [F_COUNT][n]
     int32_t* i;      // [I_COUNT][n]
@@ -83,12 +99,21 @@ PG_D bool is_wall(int t) { return t == kWall; }
 struct GenLds {
     uint32_t mt[kMtWords];
     uint8_t grid[kCells];    // Room_Generator::grid after the two automaton iterations
-    uint8_t aux[kCells];     // automaton double buffer → room membership → path `covered` → widened set (2 = on the path)
-    int16_t next[kCells];    // hashtable node links, later the goal path
-    int16_t before[2368];    // hashtable buckets (≤ 2357)
+    uint8_t aux[kCells];     // automaton double buffer → room membership → path `covered` → widening layer + 1 (1 = path)
+    union {
+        int32_t claim[kCells];  // flood(): lowest (parent slot, direction) reaching a cell within one chunk
+        int32_t tail_sum[kCells + 8];  // set_order(): elements listed before the bucket first touched at [p]
+        struct {
+            int16_t next[kCells];  // small hashtable replays (entity sets); the picked object indices
+            int16_t before[128];
+        };
+    };
+    int32_t touch[2368];  // set_order(): first insertion index per bucket (≤ 2357 buckets)
+    int32_t chain[2368];  // set_order(): per-bucket chain of insertion indices (head; links in L.parent)
     int16_t queue[kCells + 4];   // BFS queue / `expanded` / widening layer A
     int16_t parent[kCells + 4];  // `parents` / widening layer B
-    int16_t cells[kCells];   // free_cells
+    int16_t cells[kCells];   // free_cells / the goal path
+    int32_t path_len, goal_cell, agent_cell;
 };
 
 PG_D int cell_of(int x, int y) { return y + H * x; }
@@ -127,80 +152,206 @@ PG_D void episode_order(int32_t& packed, const uint8_t* keys, int n, uint8_t* ou
     packed = h.buckets | (h.next_resize << 16);
 }
 
-// Lane 0: Room_Generator::find_best_room (room_generator.cpp:138-160) with the real container's iteration order,
-// written to L.cells; returns the room's size.  L.aux must be zero on entry and holds the union of rooms on exit.
-PG_D int best_room(GenLds& L) {
-    int best_size = -1, best_n = 0;
-    for (int start = 0; start < kCells; start++) {
-        if (L.grid[start] != 0 || L.aux[start]) continue;
-        HashOrder room;
-        hash_init(room, L.next, L.before);
-        int qh = 0, qt = 0;
-        L.queue[qt++] = static_cast<int16_t>(start);
-        while (qh < qt) {  // build_room (:37-75); the start cell joins when a neighbour looks back at it
-            const int cur = L.queue[qh++];
+// Breadth-first flood from `start` over open cells by the whole wavefront, reproducing the reference's queue exactly
+// (room_generator.cpp:37-75 build_room and :77-136 find_path share it): the FIFO is consumed in chunks of up to 64
+// entries, lane j expanding entry j; a cell reached by several (entry, direction) pairs of one chunk goes to the
+// lowest pair — the one the serial loop would have reached first — and the winners are appended in (entry,
+// direction) order by a wave prefix sum.  L.queue receives the FIFO (entry 0 = start; a start with open neighbours
+// appears a second time, as in the reference, because it is not marked when pushed), L.parent the queue slot each
+// entry was discovered from when `parents` is set.  L.aux marks discovered cells; L.claim must be all-ones.
+// Stops early once `stop_cell` has been discovered.  Returns the FIFO length.
+PG_D int flood(GenLds& L, int start, bool parents, int stop_cell, int lane) {
+    int qh = 0, qt = 1;
+    if (lane == 0) {
+        L.queue[0] = static_cast<int16_t>(start);
+        L.parent[0] = -1;
+    }
+    __syncthreads();
+    while (qh < qt) {
+        const int take = (qt - qh) < 64 ? (qt - qh) : 64;
+        int reach[4] = {-1, -1, -1, -1};
+        if (lane < take) {
+            const int cur = L.queue[qh + lane];
             const int x = cur / H, y = cur % H;
+#pragma unroll
             for (int d = 0; d < 4; d++) {  // (i, j) = (-1,0) (0,-1) (0,1) (1,0)
                 const int nx = x + (d == 0 ? -1 : d == 3 ? 1 : 0), ny = y + (d == 1 ? -1 : d == 2 ? 1 : 0);
                 if (nx < 0 || ny < 0 || nx >= W || ny >= H) continue;
                 const int ni = cell_of(nx, ny);
                 if (!L.aux[ni] && L.grid[ni] == 0) {
-                    L.queue[qt++] = static_cast<int16_t>(ni);
-                    L.aux[ni] = 1;
-                    hash_insert(room, ni);
+                    reach[d] = ni;
+                    atomicMin(&L.claim[ni], lane * 4 + d);
                 }
             }
         }
-        if (room.count > best_size) {  // `best_room = next_room`: the copy keeps the iteration order
-            best_size = room.count;
-            best_n = room.count;
-            int16_t p = static_cast<int16_t>(room.head);
-            for (int k = 0; k < best_n; k++) {
-                L.cells[k] = p;
-                p = L.next[p];
+        __syncthreads();
+        bool win[4];
+        int mine = 0;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            win[d] = reach[d] >= 0 && L.claim[reach[d]] == lane * 4 + d;
+            mine += win[d] ? 1 : 0;
+        }
+        int upto = mine;  // inclusive prefix sum over lanes
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(upto, off);
+            if (lane >= off) upto += t;
+        }
+        const int total = __shfl(upto, 63);
+        __syncthreads();
+        int w = qt + upto - mine;
+        bool found = false;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            if (reach[d] >= 0) L.claim[reach[d]] = 0x7fffffff;
+            if (win[d]) {
+                L.queue[w] = static_cast<int16_t>(reach[d]);
+                if (parents) L.parent[w] = static_cast<int16_t>(qh + lane);
+                L.aux[reach[d]] = 1;
+                found = found || reach[d] == stop_cell;
+                w++;
             }
         }
+        qh += take;
+        qt += total;
+        __syncthreads();
+        if (__ballot(found)) break;
     }
+    return qt;
+}
+
+// Iteration order of a fresh std::unordered_set<int> after inserting the n distinct keys L.cells[0..n) one by one
+// (libstdc++ 11, pg_order.h), computed without replaying the node list.  With B buckets fixed, the list is: buckets
+// in order of their FIRST insertion, latest first; inside a bucket, latest insertion first.  A rehash re-inserts
+// the nodes in list order under the new B, i.e. it is the same rule applied to (current order ++ later keys).
+// Single inserts grow B 13→29→59→…→2357 just before the (B+1)-th key, so the result is at most eight rounds of
+// "rank by (first touch of my bucket, my position), both descending".  The rank of element i is
+//     (elements in buckets first touched after mine) + (elements of my bucket inserted after me),
+// a suffix sum over first-touch positions plus a walk of my bucket's short chain — all lanes busy, a handful of
+// LDS operations per element, instead of ~2n dependent pointer-chasing steps on one lane.  Result in L.cells.
+PG_D void set_order(GenLds& L, int n, int lane) {
+    const int growth[8] = {13, 29, 59, 127, 257, 541, 1109, 2357};
+    int have = 0;
+    for (int g = 0; g < 8 && have < n; g++) {
+        const int B = growth[g];
+        const int m = n < B ? n : B;  // L.cells[0..have) in list order, [have..m) still in insertion order
+        for (int b = lane; b < B; b += 64) {
+            L.touch[b] = 0x7fffffff;
+            L.chain[b] = -1;
+        }
+        __syncthreads();
+        for (int i = lane; i < m; i += 64) {
+            const int b = hash_mod(L.cells[i], B);
+            atomicMin(&L.touch[b], i);
+            L.parent[i] = static_cast<int16_t>(atomicExch(&L.chain[b], i));
+        }
+        __syncthreads();
+        // per element: its bucket's population and how many of it came later; first-touch positions carry the
+        // population into the suffix sum
+        int later[25], first_touch[25];
+        for (int r = 0, i = lane; i < m; i += 64, r++) {
+            const int b = hash_mod(L.cells[i], B);
+            int all = 0, after = 0;
+            for (int q = L.chain[b]; q >= 0; q = L.parent[q]) {
+                all++;
+                after += q > i ? 1 : 0;
+            }
+            later[r] = after;
+            first_touch[r] = L.touch[b];
+            L.tail_sum[i] = first_touch[r] == i ? all : 0;
+        }
+        if (lane == 0) L.tail_sum[m] = 0;
+        __syncthreads();
+        {   // tail_sum[p] ← Σ_{q ≥ p} tail_sum[q]: each lane owns a contiguous strip, strips combined by a wave scan
+            const int strip = (m + 63) / 64;
+            const int lo = lane * strip, hi = (lo + strip) < m ? (lo + strip) : m;
+            int mine = 0;
+            for (int p = lo; p < hi; p++) mine += L.tail_sum[p];
+            int above = mine;  // inclusive suffix over lanes
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_down(above, off);
+                if (lane + off < 64) above += t;
+            }
+            int run = above - mine;  // everything in higher strips
+            for (int p = hi - 1; p >= lo; p--) {
+                run += L.tail_sum[p];
+                L.tail_sum[p] = run;
+            }
+        }
+        __syncthreads();
+        for (int r = 0, i = lane; i < m; i += 64, r++)
+            L.queue[L.tail_sum[first_touch[r] + 1] + later[r]] = L.cells[i];
+        __syncthreads();
+        for (int i = lane; i < m; i += 64) L.cells[i] = L.queue[i];
+        __syncthreads();
+        have = m;
+    }
+}
+
+// Room_Generator::find_best_room (room_generator.cpp:138-160): the largest 4-connected room (the first one on
+// ties), its cells in the iteration order of the reference's std::unordered_set (`best_room = next_room` keeps
+// it): the FIFO's discovery order is the insertion order.  Result in L.cells; returns the size.  A lone open cell
+// forms a room of size zero (it is never inserted).
+PG_D int best_room(GenLds& L, int lane) {
+    for (int c = lane; c < kCells; c += 64) {
+        L.aux[c] = 0;
+        L.claim[c] = 0x7fffffff;
+    }
+    __syncthreads();
+    int best_n = -1, from = 0;
+    for (;;) {
+        // next start: the lowest open cell ≥ from that no room holds yet
+        int first = kCells;
+        for (int c = from + lane; c < kCells && first == kCells; c += 64)
+            if (L.grid[c] == 0 && !L.aux[c]) first = c;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const int t = __shfl_xor(first, off);
+            first = t < first ? t : first;
+        }
+        if (first >= kCells) break;
+        const int n = flood(L, first, false, -1, lane) - 1;
+        if (n > best_n) {
+            best_n = n;
+            for (int k = lane; k < n; k += 64) L.cells[k] = L.queue[1 + k];
+        }
+        from = first + 1;
+        __syncthreads();
+    }
+    __syncthreads();
+    set_order(L, best_n, lane);  // overwrites L.claim: the floods are done
     return best_n;
 }
 
-// Lane 0: Room_Generator::find_path (:77-136).  Path cells go to L.next[0..len); returns len.  L.aux = `covered`.
-PG_D int goal_path(GenLds& L, int src, int dst) {
-    int n = 0, at = 0;
-    L.queue[n] = static_cast<int16_t>(src);
-    L.parent[n] = -1;
-    n++;
-    while (at < n) {
-        const int cur = L.queue[at];
-        if (cur == dst) break;
-        const int x = cur / H, y = cur % H;
-        for (int d = 0; d < 4; d++) {
-            const int nx = x + (d == 0 ? -1 : d == 3 ? 1 : 0), ny = y + (d == 1 ? -1 : d == 2 ? 1 : 0);
-            if (nx < 0 || ny < 0 || nx >= W || ny >= H) continue;
-            const int ni = cell_of(nx, ny);
-            if (!L.aux[ni] && L.grid[ni] == 0) {  // the source is not `covered`: it is expanded a second time
-                L.queue[n] = static_cast<int16_t>(ni);
-                L.parent[n] = static_cast<int16_t>(at);
-                n++;
-                L.aux[ni] = 1;
-            }
-        }
-        at++;
+// Room_Generator::find_path (:77-136): the BFS tree's path src → dst into L.cells; length in L.path_len.
+PG_D void goal_path(GenLds& L, int src, int dst, int lane) {
+    for (int c = lane; c < kCells; c += 64) {
+        L.aux[c] = 0;  // `covered`; the source is not in it, so it is reached (and expanded) a second time
+        L.claim[c] = 0x7fffffff;
     }
-    int len = 0;
-    for (int k = at; k >= 0; k = L.parent[k]) len++;
-    int w = len;
-    for (int k = at; k >= 0; k = L.parent[k]) L.next[--w] = L.queue[k];
-    return len;
+    __syncthreads();
+    const int n = flood(L, src, true, dst, lane);
+    if (lane == 0) {
+        int at = n - 1;
+        while (L.queue[at] != dst) at--;  // dst ≠ src has exactly one entry
+        int len = 0;
+        for (int k = at; k >= 0; k = L.parent[k]) len++;
+        int w = len;
+        for (int k = at; k >= 0; k = L.parent[k]) L.cells[--w] = L.queue[k];
+        L.path_len = len;
+    }
+    __syncthreads();
 }
 
-PG_D void put_thing(const State& s, int env, int id, int kind, int cell, float vx, float vy) {
+PG_D void put_thing(Level& lv, int id, int kind, int cell, float vx, float vy) {
     const int x = cell / H, y = cell % H;
-    EF(s, EF_X, id, env) = static_cast<float>(x) + 0.5f;
-    EF(s, EF_Y, id, env) = static_cast<float>(H - 1 - y) + 0.5f;
-    EF(s, EF_VX, id, env) = vx;
-    EF(s, EF_VY, id, env) = vy;
-    EB(s, EB_INFO, id, env) = static_cast<uint8_t>(kind | kAlive);
+    lv.ex[id] = static_cast<float>(x) + 0.5f;
+    lv.ey[id] = static_cast<float>(H - 1 - y) + 0.5f;
+    lv.evx[id] = vx;
+    lv.evy[id] = vy;
+    lv.info[id] = static_cast<uint8_t>(kind | kAlive);
 }
 
 PG_D int check_neighbors(float x0, float y0, float x1, float y1) {  // tilemap.cpp:103-115
@@ -210,8 +361,9 @@ PG_D int check_neighbors(float x0, float y0, float x1, float y1) {  // tilemap.c
     return 0;
 }
 
-// reset() (caveflyer.cpp:442-460) for one env by one wavefront.
-PG_D void new_level(const State& s, int env, GenLds& L, bool reseed, uint32_t seed, int lane) {
+// reset() (caveflyer.cpp:442-460) for one env by one wavefront: advances the env's generator chain (s.mt, the two
+// bucket-count words) and leaves the level in `lv` (LDS).
+PG_D void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, uint32_t seed, int lane) {
     uint32_t* gmt = s.mt + size_t(env) * kMtWords;
     if (reseed) {
         if (lane == 0) mt_seed(L.mt, seed);
@@ -220,150 +372,163 @@ PG_D void new_level(const State& s, int env, GenLds& L, bool reseed, uint32_t se
     }
     __syncthreads();
     uint32_t* mt = L.mt;
-    if (lane == 0)  // tilemap.cpp:139-140
-        for (int c = 0; c < kCells; c++) L.grid[c] = rng_real(mt, 0.0f, 1.0f) < 0.5f ? 1 : 0;
-    __syncthreads();
+    wave_coin_flips(mt, L.grid, kCells, lane);  // tilemap.cpp:139-140: grid[i] = dist01(rng) < 0.5f
     automaton(L.grid, L.aux, lane);
     __syncthreads();
     automaton(L.aux, L.grid, lane);
     __syncthreads();
-    for (int c = lane; c < kCells; c += 64) L.aux[c] = 0;
-    __syncthreads();
-
-    int path_len = 0, agent_cell = 0, goal_cell = 0;
-    if (lane == 0) {
-        const int n_free = best_room(L);
-        const int goal_index = rng_int(mt, 0, n_free - 1);
-        int agent_index = rng_int(mt, 0, n_free - 1);
-        if (agent_index == goal_index) agent_index = (agent_index + 1) % n_free;
-        goal_cell = L.cells[goal_index];
-        agent_cell = L.cells[agent_index];
+    {
+        const int n_free = best_room(L, lane);
+        if (lane == 0) {  // tilemap.cpp:163-172
+            const int goal_index = rng_int(mt, 0, n_free - 1);
+            int agent_index = rng_int(mt, 0, n_free - 1);
+            if (agent_index == goal_index) agent_index = (agent_index + 1) % n_free;
+            L.goal_cell = L.cells[goal_index];
+            L.agent_cell = L.cells[agent_index];
+        }
+        __syncthreads();
     }
-    __syncthreads();
+    goal_path(L, L.agent_cell, L.goal_cell, lane);
     for (int c = lane; c < kCells; c += 64) L.aux[c] = 0;
     __syncthreads();
-    if (lane == 0) path_len = goal_path(L, agent_cell, goal_cell);
+    // expand_room(wide_path, 4) (room_generator.cpp:162-202): four layers of 8-neighbour growth through open cells.
+    // Only membership matters downstream, so each layer is one data-parallel pass: a cell joins layer k+1 when a
+    // neighbour sits in layer k (a concurrent write can only turn a 0 into k+1, which no lane of this pass matches).
+    for (int k = lane; k < L.path_len; k += 64) L.aux[L.cells[k]] = 1;
     __syncthreads();
-    for (int c = lane; c < kCells; c += 64) L.aux[c] = 0;
-    __syncthreads();
+    for (int layer = 1; layer <= 4; layer++) {
+        for (int c = lane; c < kCells; c += 64) {
+            if (L.aux[c] || L.grid[c]) continue;
+            const int x = c / H, y = c % H;
+            bool hit = false;
+            for (int a = -1; a <= 1; a++)
+                for (int b = -1; b <= 1; b++) {
+                    const int nx = x + a, ny = y + b;
+                    if ((a | b) == 0 || nx < 0 || ny < 0 || nx >= W || ny >= H) continue;
+                    hit = hit || L.aux[cell_of(nx, ny)] == layer;
+                }
+            if (hit) L.aux[c] = static_cast<uint8_t>(layer + 1);
+        }
+        __syncthreads();
+    }
     if (lane == 0) {
-        // expand_room(wide_path, 4) (room_generator.cpp:162-202): four layers of 8-neighbour growth through open
-        // cells; only membership matters downstream.
-        int16_t* cur = L.queue;
-        int16_t* nxt = L.parent;
-        int n_cur = 0;
-        for (int k = 0; k < path_len; k++) {
-            const int c = L.next[k];
-            if (!L.aux[c]) {
-                L.aux[c] = 2;
-                cur[n_cur++] = static_cast<int16_t>(c);
-            }
-        }
-        for (int loop = 0; loop < 4; loop++) {
-            int n_nxt = 0;
-            for (int k = 0; k < n_cur; k++) {
-                const int c = cur[k];
-                const int x = c / H, y = c % H;
-                for (int a = -1; a <= 1; a++)
-                    for (int b = -1; b <= 1; b++) {
-                        if (a == 0 && b == 0) continue;
-                        const int nx = x + a, ny = y + b;
-                        if (nx < 0 || ny < 0 || nx >= W || ny >= H) continue;
-                        const int ni = cell_of(nx, ny);
-                        if (!L.aux[ni] && L.grid[ni] == 0) {
-                            L.aux[ni] = 1;
-                            nxt[n_nxt++] = static_cast<int16_t>(ni);
-                        }
-                    }
-            }
-            int16_t* t = cur;
-            cur = nxt;
-            nxt = t;
-            n_cur = n_nxt;
-        }
         // the four further automaton iterations (tilemap.cpp:217-222) never reach tile_ids (D13)
 
         // goal (id 0), ship (id 1)
-        put_thing(s, env, 0, kGoal, goal_cell, 0.0f, 0.0f);
+        const int goal_cell = L.goal_cell, agent_cell = L.agent_cell;
+        put_thing(lv, 0, kGoal, goal_cell, 0.0f, 0.0f);
         const float ax = static_cast<float>(agent_cell / H) + 0.5f;
         const float ay = static_cast<float>(H - 1 - (agent_cell % H));  // no +0.5 (tilemap.cpp:189)
-        SF(s, F_AX, env) = ax;
-        SF(s, F_AY, env) = ay;
-        SF(s, F_AVX, env) = 0.0f;
-        SF(s, F_AVY, env) = 0.0f;
-        SF(s, F_ROT, env) = 0.0f;
-        EB(s, EB_INFO, 1, env) = 0;
+        lv.ax = ax;
+        lv.ay = ay;
+        lv.info[1] = 0;
 
-        // objects on the open cells off the path, in index order (tilemap.cpp:224-272)
-        int n_free = 0;
-        for (int c = 0; c < kCells; c++)
-            if (L.aux[c] == 1) L.cells[n_free++] = static_cast<int16_t>(c);
-        const int chunk = n_free / 80, num_objects = 3 * chunk;
-        int16_t* picked = L.next;  // the path is no longer needed
+    }
+    // objects on the open cells off the path, in index order (tilemap.cpp:224-272).  The whole wave walks the loop:
+    // lane 0 owns the random stream, lane j remembers the j-th picked index so that "already taken?" is one ballot.
+    int n_free = 0;
+    for (int c0 = 0; c0 < kCells; c0 += 64) {
+        const bool open = L.aux[c0 + lane] >= 2;
+        const unsigned long long m = __ballot(open);
+        if (open) L.cells[n_free + __popcll(m & ((1ull << lane) - 1ull))] = static_cast<int16_t>(c0 + lane);
+        n_free += __popcll(m);
+    }
+    __syncthreads();
+    const int chunk = n_free / 80, num_objects = 3 * chunk;
+    {
+        const float ax = lv.ax, ay = lv.ay;
+        int picked = -1;
         for (int i = 0; i < num_objects; i++) {
-            int index = rng_int(mt, 0, n_free - 1);
-            bool repeat;
-            do {
-                repeat = false;
-                for (int j = 0; j < i; j++)
-                    if (picked[j] == index) {
-                        index = (index + 1) % n_free;
-                        repeat = true;
-                        break;
-                    }
-            } while (repeat);
-            picked[i] = static_cast<int16_t>(index);
-            const int cell = L.cells[index];
-            const int id = 2 + i;
-            if (i < chunk)
-                put_thing(s, env, id, kMeteor, cell, 0.0f, 0.0f);
-            else if (i < 2 * chunk)
-                put_thing(s, env, id, kTarget, cell, 0.0f, 0.0f);
-            else {  // spawn_enemy (tilemap.cpp:68-101)
-                const float magnitude = 0.1f * rng_real(mt, 0.0f, 1.0f) + 0.1f;
-                const float vel = magnitude * (rng_real(mt, 0.0f, 1.0f) < 0.5f ? 1.0f : -1.0f);
-                const float ex = static_cast<float>(cell / H) + 0.5f, ey = static_cast<float>(H - 1 - cell % H) + 0.5f;
-                const int clash = check_neighbors(ex, ey, ax, ay);
-                bool along_x;
-                if (clash == 0)
-                    along_x = rng_real(mt, 0.0f, 1.0f) < 0.5f;
-                else
-                    along_x = clash == 1;
-                put_thing(s, env, id, kEnemy, cell, along_x ? vel : 0.0f, along_x ? 0.0f : vel);
+            int index = 0;
+            if (lane == 0) index = rng_int(mt, 0, n_free - 1);
+            index = __shfl(index, 0);
+            while (__ballot(picked == index)) index = (index + 1) % n_free;
+            if (lane == i) picked = index;
+            if (lane == 0) {
+                const int cell = L.cells[index];
+                const int id = 2 + i;
+                if (i < chunk)
+                    put_thing(lv, id, kMeteor, cell, 0.0f, 0.0f);
+                else if (i < 2 * chunk)
+                    put_thing(lv, id, kTarget, cell, 0.0f, 0.0f);
+                else {  // spawn_enemy (tilemap.cpp:68-101)
+                    const float magnitude = 0.1f * rng_real(mt, 0.0f, 1.0f) + 0.1f;
+                    const float vel = magnitude * (rng_real(mt, 0.0f, 1.0f) < 0.5f ? 1.0f : -1.0f);
+                    const float ex = static_cast<float>(cell / H) + 0.5f;
+                    const float ey = static_cast<float>(H - 1 - cell % H) + 0.5f;
+                    const int clash = check_neighbors(ex, ey, ax, ay);
+                    bool along_x;
+                    if (clash == 0)
+                        along_x = rng_real(mt, 0.0f, 1.0f) < 0.5f;
+                    else
+                        along_x = clash == 1;
+                    put_thing(lv, id, kEnemy, cell, along_x ? vel : 0.0f, along_x ? 0.0f : vel);
+                }
             }
         }
+    }
+    if (lane == 0) {
         const int n_ent = 2 + num_objects;
-        SI(s, I_NENT, env) = n_ent;
-        SI(s, I_BACKDROP, env) = rng_int(mt, 0, 12);
-        SF(s, F_BGSHIFT, env) = rng_real(mt, 0.0f, 1.0f);
-        SI(s, I_FLAGS, env) = kFlagPuffOn;  // draw list cleared; Component_Particles::enabled = true
-        SI(s, I_NDRAW, env) = 0;
-        SI(s, I_SNEXT, env) = 0;  // System_Agent::reset (common_systems.h:83-87); the 32 slots keep their contents
-        SI(s, I_SCOUNT, env) = 0;
-        SF(s, F_STIMER, env) = 0.0f;
-        SF(s, F_PTIMER, env) = 0.0f;
-        for (int k = 0; k < kPuffs; k++)
-            for (int f = 0; f < PF_COUNT; f++) PF(s, f, k, env) = 0.0f;
-        // camera keeps the previous episode's value (D3)
+        lv.n_ent = n_ent;
+        lv.backdrop = rng_int(mt, 0, 12);
+        lv.bgshift = rng_real(mt, 0.0f, 1.0f);
 
         // entity-set orders of the episode: sprites = goal + objects, hazards = objects
-        uint8_t keys[kMaxEnt], order[kMaxEnt];
+        uint8_t keys[kMaxEnt];
         int nk = 0;
         keys[nk++] = 0;
         for (int id = 2; id < n_ent; id++) keys[nk++] = static_cast<uint8_t>(id);
         int32_t packed = SI(s, I_HASH_SPRITE, env);
-        episode_order(packed, keys, nk, order, L.queue, L.before);
+        episode_order(packed, keys, nk, lv.order_s, L.queue, L.before);
         SI(s, I_HASH_SPRITE, env) = packed;
-        for (int k = 0; k < nk; k++) EB(s, EB_ORDER_S, k, env) = order[k];
         packed = SI(s, I_HASH_HAZARD, env);
-        episode_order(packed, keys + 1, nk - 1, order, L.queue, L.before);
+        episode_order(packed, keys + 1, nk - 1, lv.order_h, L.queue, L.before);
         SI(s, I_HASH_HAZARD, env) = packed;
-        for (int k = 0; k < nk - 1; k++) EB(s, EB_ORDER_H, k, env) = order[k];
     }
     __syncthreads();
-    uint8_t* tiles = s.tiles + size_t(env) * kCells;
-    for (int c = lane; c < kCells; c += 64) tiles[c] = L.aux[c] ? kEmpty : kWall;
+    for (int c = lane; c < kCells; c += 64) lv.tiles[c] = L.aux[c] ? kEmpty : kWall;
     for (int k = lane; k < kMtWords; k += 64) gmt[k] = L.mt[k];
+    __syncthreads();
+}
+
+// The level becomes the env's live state (everything reset() and the component constructors initialise).
+PG_D void install(const State& s, int env, const Level& lv, int lane) {
+    uint32_t* tiles = reinterpret_cast<uint32_t*>(s.tiles + size_t(env) * kCells);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(lv.tiles);
+    for (int k = lane; k < kCells / 4; k += 64) tiles[k] = src[k];
+    const int n_ent = lv.n_ent;
+    if (lane < n_ent) {
+        EF(s, EF_X, lane, env) = lv.ex[lane];
+        EF(s, EF_Y, lane, env) = lv.ey[lane];
+        EF(s, EF_VX, lane, env) = lv.evx[lane];
+        EF(s, EF_VY, lane, env) = lv.evy[lane];
+        EB(s, EB_INFO, lane, env) = lv.info[lane];
+        if (lane < n_ent - 1) EB(s, EB_ORDER_S, lane, env) = lv.order_s[lane];
+        if (lane < n_ent - 2) EB(s, EB_ORDER_H, lane, env) = lv.order_h[lane];
+    }
+    if (lane < kPuffs)
+        for (int f = 0; f < PF_COUNT; f++) PF(s, f, lane, env) = 0.0f;
+    if (lane == 0) {
+        SF(s, F_AX, env) = lv.ax;
+        SF(s, F_AY, env) = lv.ay;
+        SF(s, F_AVX, env) = 0.0f;
+        SF(s, F_AVY, env) = 0.0f;
+        SF(s, F_ROT, env) = 0.0f;
+        SF(s, F_BGSHIFT, env) = lv.bgshift;
+        SF(s, F_STIMER, env) = 0.0f;
+        SF(s, F_PTIMER, env) = 0.0f;
+        SI(s, I_NENT, env) = n_ent;
+        SI(s, I_BACKDROP, env) = lv.backdrop;
+        SI(s, I_FLAGS, env) = kFlagPuffOn;  // draw list cleared; Component_Particles::enabled = true
+        SI(s, I_NDRAW, env) = 0;
+        SI(s, I_SNEXT, env) = 0;  // System_Agent::reset (common_systems.h:83-87); the 32 slots keep their contents
+        SI(s, I_SCOUNT, env) = 0;
+        // camera keeps the previous episode's value (D3)
+    }
+}
+
+PG_D void copy_level(uint32_t* dst, const uint32_t* src, int lane) {
+    for (int k = lane; k < static_cast<int>(sizeof(Level) / 4); k += 64) dst[k] = src[k];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -578,23 +743,86 @@ __global__ void __launch_bounds__(64) make_kernel(State s, uint32_t seed_base, i
         for (int f = 0; f < SH_COUNT; f++) SH(s, f, k, env) = (f == SH_FRAME) ? -1.0f : 0.0f;
 }
 
-// mode 0: cenv_make (seed = seed_base + env index); 1: explicit reset (mask, optional seeds); 2: the envs whose
-// previous step terminated (auto-reset: this vector step is their reset, StepIO::pending → 2 tells the logic kernel).
-__global__ void __launch_bounds__(64) level_kernel(State s, int mode, uint32_t seed_base, int env_offset,
-                                                   const uint8_t* mask, const int32_t* seeds, StepIO io) {
-    const int env = blockIdx.x;
+// The level kernel serves the envs [blockIdx·span, +span) that need a level, one wavefront at a time:
+//   mode 0  cenv_make: seed = seed_base + env index, level 0 generated synchronously;
+//   mode 1  explicit reset (mask, optional seeds; a seed restarts the env's generator chain);
+//   mode 2  auto-reset of the envs whose previous step terminated (StepIO::pending 1 → 2 tells the logic kernel);
+//   mode 3  side stream: fill the shadow slots that are kSlotQueued.
+// `prefetch` = whether a served env queues its next level (pg_prefetch.h).
+__global__ void __launch_bounds__(64) level_kernel(State s, int mode, int span, int prefetch, uint32_t seed_base,
+                                                   int env_offset, const uint8_t* mask, const int32_t* seeds,
+                                                   StepIO io) {
     const int lane = threadIdx.x;
-    if (mode == 1 && mask && !mask[env]) return;
-    if (mode == 2 && io.pending[env] != 1) return;
+    const int base = blockIdx.x * span;
+    bool want = false;
+    if (lane < span && base + lane < s.n) {
+        const int e = base + lane;
+        if (mode == 0)
+            want = true;
+        else if (mode == 1)
+            want = !mask || mask[e];
+        else if (mode == 2)
+            want = io.pending[e] == 1;
+        else
+            want = __hip_atomic_load(&s.slot[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kSlotQueued;
+    }
+    unsigned long long todo = __ballot(want);
+    if (!todo) return;
     __shared__ GenLds L;
-    const bool reseed = mode == 0 || (mode == 1 && seeds != nullptr);
-    const uint32_t seed =
-        mode == 0 ? seed_base + static_cast<uint32_t>(env_offset + env) : (seeds ? static_cast<uint32_t>(seeds[env]) : 0u);
-    new_level(s, env, L, reseed, seed, lane);
-    if (mode != 0 && lane == 0) {
-        io.reward[env] = 0.0f;
-        io.done[env] = 0;
-        io.pending[env] = mode == 2 ? 2 : 0;
+    __shared__ Level lv;
+    __shared__ int32_t verdict;
+    while (todo) {
+        const int env = base + __builtin_ctzll(todo);
+        todo &= todo - 1;
+        if (mode == 3) {
+            if (lane == 0) verdict = slot_cas(&s.slot[env], kSlotQueued, kSlotBusy) ? 1 : 0;
+            __syncthreads();
+            const bool mine = verdict != 0;
+            __syncthreads();
+            if (!mine) continue;
+            generate(s, env, L, lv, false, 0u, lane);
+            copy_level(reinterpret_cast<uint32_t*>(&s.shadow[env]), reinterpret_cast<const uint32_t*>(&lv), lane);
+            __threadfence();
+            __syncthreads();
+            if (lane == 0) slot_store(&s.slot[env], kSlotReady);
+            continue;
+        }
+        const bool reseed = mode == 0 || (mode == 1 && seeds != nullptr);
+        if (lane == 0) {
+            if (mode == 0) {
+                verdict = kSlotSync;
+            } else {
+                int32_t got = slot_acquire_for_install(&s.slot[env]);
+                if (got == kSlotReady && reseed) {  // the prepared level belongs to the abandoned chain
+                    slot_store(&s.slot[env], kSlotSync);
+                    got = kSlotSync;
+                }
+                verdict = got;
+            }
+        }
+        __syncthreads();
+        const int32_t how = verdict;
+        __threadfence();
+        if (how == kSlotReady) {
+            copy_level(reinterpret_cast<uint32_t*>(&lv), reinterpret_cast<const uint32_t*>(&s.shadow[env]), lane);
+            __syncthreads();
+        } else {
+            const uint32_t seed = mode == 0 ? seed_base + static_cast<uint32_t>(env_offset + env)
+                                            : (seeds ? static_cast<uint32_t>(seeds[env]) : 0u);
+            generate(s, env, L, lv, reseed, seed, lane);
+        }
+        install(s, env, lv, lane);
+        __threadfence();
+        __syncthreads();
+        if (lane == 0) {
+            slot_store(&s.slot[env], prefetch ? kSlotQueued : kSlotIdle);
+            if (mode != 0) {
+                io.reward[env] = 0.0f;
+                io.done[env] = 0;
+                io.pending[env] = mode == 2 ? 2 : 0;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -778,7 +1006,7 @@ class CaveflyerGame final : public Game {
     }
     static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
     struct Layout {
-        size_t mt, tiles, f, i, ef, eb, sh, pf, total;
+        size_t shadow, slot, mt, tiles, f, i, ef, eb, sh, pf, total;
     };
     static Layout layout(int n) {
         Layout l{};
@@ -788,6 +1016,8 @@ class CaveflyerGame final : public Game {
             off += align256(bytes);
             return at;
         };
+        l.shadow = take(size_t(n) * sizeof(Level));
+        l.slot = take(size_t(n) * 4);
         l.mt = take(size_t(n) * kMtWords * 4);
         l.tiles = take(size_t(n) * kCells);
         l.f = take(size_t(F_COUNT) * n * 4);
@@ -804,6 +1034,8 @@ class CaveflyerGame final : public Game {
         uint8_t* p = static_cast<uint8_t*>(d_state);
         const Layout l = layout(n);
         s_.n = n;
+        s_.shadow = reinterpret_cast<Level*>(p + l.shadow);
+        s_.slot = reinterpret_cast<int32_t*>(p + l.slot);
         s_.mt = reinterpret_cast<uint32_t*>(p + l.mt);
         s_.tiles = p + l.tiles;
         s_.f = reinterpret_cast<float*>(p + l.f);
@@ -817,15 +1049,24 @@ class CaveflyerGame final : public Game {
     int blocks() const { return (s_.n + 63) / 64; }
     void launch_make(hipStream_t st, uint32_t seed_base, int env_offset) override {
         hipLaunchKernelGGL(make_kernel, dim3(blocks()), dim3(64), 0, st, s_, seed_base, env_offset);
-        hipLaunchKernelGGL(level_kernel, dim3(s_.n), dim3(64), 0, st, s_, 0, seed_base, env_offset, nullptr, nullptr,
-                           StepIO{});
+        hipLaunchKernelGGL(level_kernel, dim3(s_.n), dim3(64), 0, st, s_, 0, 1, prefetch(), seed_base, env_offset,
+                           nullptr, nullptr, StepIO{});
     }
     void launch_reset(hipStream_t st, const uint8_t* mask, const int32_t* seeds, StepIO io) override {
-        hipLaunchKernelGGL(level_kernel, dim3(s_.n), dim3(64), 0, st, s_, 1, 0u, 0, mask, seeds, io);
+        hipLaunchKernelGGL(level_kernel, dim3(s_.n), dim3(64), 0, st, s_, 1, 1, prefetch(), 0u, 0, mask, seeds, io);
     }
+    bool launch_pregen(hipStream_t side, bool bulk) override {
+        if (!prefetch()) return false;
+        const int span = bulk ? 1 : 8;  // few envs per wave: queued envs of one wave are served one after the other
+        hipLaunchKernelGGL(level_kernel, dim3((s_.n + span - 1) / span), dim3(64), 0, side, s_, 3, span, 1, 0u, 0,
+                           nullptr, nullptr, StepIO{});
+        return true;
+    }
+    int prefetch() const { return (debug_flags & kDebugNoPrefetch) ? 0 : 1; }
     void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
                       StepIO io) override {
-        hipLaunchKernelGGL(level_kernel, dim3(s_.n), dim3(64), 0, st, s_, 2, 0u, 0, nullptr, nullptr, io);
+        hipLaunchKernelGGL(level_kernel, dim3(blocks()), dim3(64), 0, st, s_, 2, 64, prefetch(), 0u, 0, nullptr, nullptr,
+                           io);
         hipLaunchKernelGGL(logic_kernel, dim3(blocks()), dim3(64), 0, st, s_, actions, run_seed, step_index,
                            env_offset, io);
     }

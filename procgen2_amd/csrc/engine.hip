@@ -119,9 +119,30 @@ struct pgv_env {
     uint8_t* d_host_u8 = nullptr;
     bool own_obs = false, own_reward = false, own_done = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // level prefetch (pg_prefetch.h): generator launches on a side stream, ordered behind the main stream by events
+    hipStream_t side = nullptr;
+    hipEvent_t side_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int side_ev_next = 0, since_pregen = 0;
 
     pg::StepIO io() const { return {d_obs, d_reward, d_done, d_pending}; }
 };
+
+// Queue one generator launch behind everything the main stream holds so far.  In the step loop: whenever the side
+// stream is idle, otherwise every 4th step — one launch serves every slot queued by then, and a launch costs its
+// single-env latency (ms) even for one env, so launching per step would only pile launches up.
+static void pregen(pgv_env* e, bool bulk, bool force) {
+    if (!e->side) return;
+    e->since_pregen++;
+    if (!force && e->since_pregen < 4 && hipStreamQuery(e->side) != hipSuccess) return;
+    hipEvent_t ev = e->side_ev[e->side_ev_next];
+    e->side_ev_next = (e->side_ev_next + 1) % 8;
+    if (hipEventRecord(ev, e->stream) != hipSuccess || hipStreamWaitEvent(e->side, ev, 0) != hipSuccess) return;
+    if (!e->game->launch_pregen(e->side, bulk)) {
+        hipStreamDestroy(e->side);  // this game generates its levels inside the step
+        e->side = nullptr;
+    }
+    e->since_pregen = 0;
+}
 
 using pg::fail;
 
@@ -145,6 +166,12 @@ void pgv_close(pgv_env* e) {
     if (!e) return;
     hipSetDevice(e->device);
     if (e->stream) hipStreamSynchronize(e->stream);
+    if (e->side) {
+        hipStreamSynchronize(e->side);
+        hipStreamDestroy(e->side);
+    }
+    for (auto& ev : e->side_ev)
+        if (ev) hipEventDestroy(ev);
     for (auto& ev : e->ev)
         if (ev) hipEventDestroy(ev);
     if (e->d_state) hipFree(e->d_state);
@@ -183,6 +210,8 @@ int32_t pgv_make(const char* game, int32_t num_envs, int32_t device, uint32_t se
         e->own_stream = true;
     }
     for (auto& ev : e->ev) PG_HIP(hipEventCreate(&ev));
+    PG_HIP(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+    for (auto& ev : e->side_ev) PG_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 
     std::string err;
     if (!e->atlas.load(pg::asset_root(), e->game->texture_names(), err)) {
@@ -218,6 +247,7 @@ int32_t pgv_make(const char* game, int32_t num_envs, int32_t device, uint32_t se
     e->game->launch_make(e->stream, seed_base, env_offset);
     PG_HIP(hipGetLastError());
     PG_HIP(hipStreamSynchronize(e->stream));
+    pregen(e.get(), true, true);
     *out = e.release();
     return 0;
 }
@@ -227,12 +257,14 @@ int32_t pgv_reset(pgv_env* e, const uint8_t* d_mask, const int32_t* d_seeds) {
     PG_HIP(hipSetDevice(e->device));
     e->game->launch_reset(e->stream, d_mask, d_seeds, e->io());
     e->game->launch_render(e->stream, d_mask, e->io());
+    pregen(e, true, true);
     PG_HIP(hipGetLastError());
     return 0;
 }
 
 static int32_t step_impl(pgv_env* e, const int32_t* d_actions, uint32_t run_seed) {
     e->game->launch_logic(e->stream, d_actions, run_seed, e->step_index, e->env_offset, e->io());
+    pregen(e, false, false);  // before the render launch: the generator overlaps it
     e->game->launch_render(e->stream, nullptr, e->io());
     e->step_index++;
     return 0;
@@ -358,6 +390,7 @@ int32_t pgv_timed_steps(pgv_env* e, int32_t steps, uint32_t run_seed, double* to
     for (auto& p : pairs) PG_HIP(hipEventCreate(&p));
     for (int s = 0; s < steps; s++) {
         e->game->launch_logic(e->stream, nullptr, run_seed, e->step_index, e->env_offset, e->io());
+        pregen(e, false, false);
         PG_HIP(hipEventRecord(pairs[2 * s], e->stream));
         e->game->launch_render(e->stream, nullptr, e->io());
         PG_HIP(hipEventRecord(pairs[2 * s + 1], e->stream));
@@ -381,6 +414,7 @@ int32_t pgv_timed_steps(pgv_env* e, int32_t steps, uint32_t run_seed, double* to
 
 int32_t pgv_set_debug(pgv_env* e, int32_t flags) {
     if (!e) return fail("pgv_set_debug: env is NULL");
+    if (e->side) hipStreamSynchronize(e->side);
     e->game->debug_flags = flags;
     return 0;
 }

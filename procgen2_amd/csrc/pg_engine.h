@@ -69,6 +69,9 @@ class Game {
                               int env_offset, StepIO io) = 0;
     // render_game(true) + RGB pack into io.obs for envs where mask != 0 (nullptr = all).
     virtual void launch_render(hipStream_t s, const uint8_t* mask, StepIO io) = 0;
+    // Level prefetch (pg_prefetch.h): launch the generator that fills queued shadow slots on the side stream.
+    // bulk = most envs are expected to be queued (after make / a full reset).  False = game has no prefetch.
+    virtual bool launch_pregen(hipStream_t side, bool bulk) { return false; }
     // Debug tap used by the parity tests: game-defined float dump of one env (host pointer).
     virtual int dump_state(hipStream_t s, int env, float* out, int cap) = 0;
     virtual int dump_tiles(hipStream_t s, int env, uint8_t* out, int cap) = 0;
@@ -76,8 +79,11 @@ class Game {
     virtual std::string check_atlas(const std::vector<std::pair<int, int>>& sizes) const { return ""; }
 
     // Bit 0: render background + tiles by draw-list replay instead of the row composer (fallback path).
+    // Bit 8: no level prefetch — every reset generates its level synchronously inside the step.
     int debug_flags = 0;
 };
+
+constexpr int kDebugNoPrefetch = 1 << 8;
 
 std::unique_ptr<Game> make_coinrun();
 std::unique_ptr<Game> make_maze();

@@ -47,6 +47,20 @@ PG_HD int32_t hash_next_bkt(int32_t want) {
     return 2357;
 }
 
+// key % b for 0 ≤ key < 2^15, 1 ≤ b < 2^12.  The device has no integer divider: a 32-bit `%` is a ~40-instruction
+// dependent chain, and the replay does several per node; one reciprocal multiply plus a fix-up is exact here.
+PG_HD int32_t hash_mod(int32_t key, int32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int32_t q = static_cast<int32_t>(static_cast<float>(key) * __builtin_amdgcn_rcpf(static_cast<float>(b)));
+    int32_t r = key - q * b;
+    if (r < 0) r += b;
+    if (r >= b) r -= b;
+    return r;
+#else
+    return key % b;
+#endif
+}
+
 PG_HD void hash_init(HashOrder& h, int16_t* next, int16_t* before) {
     h.next = next;
     h.before = before;
@@ -79,7 +93,7 @@ PG_HD void hash_rehash(HashOrder& h, int32_t nb) {  // _M_rehash_aux(n, true_typ
     int32_t bbegin_bkt = 0;
     while (p != kNil) {
         int16_t nxt = h.next[p];
-        int32_t b = p % nb;
+        int32_t b = hash_mod(p, nb);
         if (h.before[b] == kNil) {
             h.next[p] = static_cast<int16_t>(h.head);
             h.head = p;
@@ -98,14 +112,14 @@ PG_HD void hash_rehash(HashOrder& h, int32_t nb) {  // _M_rehash_aux(n, true_typ
 
 // Returns the node before `key` in its bucket, or kNil when absent (_M_find_before_node).
 PG_HD int16_t hash_find_before(const HashOrder& h, int32_t key) {
-    int32_t b = key % h.buckets;
+    int32_t b = hash_mod(key, h.buckets);
     int16_t prev = h.before[b];
     if (prev == kNil) return kNil;
     int16_t p = hash_get_next(h, prev);
     for (;;) {
         if (p == key) return prev;
         int16_t nx = h.next[p];
-        if (nx == kNil || (nx % h.buckets) != b) return kNil;
+        if (nx == kNil || hash_mod(nx, h.buckets) != b) return kNil;
         prev = p;
         p = nx;
     }
@@ -113,9 +127,9 @@ PG_HD int16_t hash_find_before(const HashOrder& h, int32_t key) {
 
 PG_HD bool hash_contains(const HashOrder& h, int32_t key) { return h.count > 0 && hash_find_before(h, key) != kNil; }
 
-// unordered_set::insert(key) for a key not necessarily absent.
-PG_HD void hash_insert(HashOrder& h, int32_t key) {
-    if (h.count > 0 && hash_find_before(h, key) != kNil) return;
+// unordered_set::insert(key); `known_absent` skips the lookup when the caller has its own membership test.
+PG_HD void hash_insert(HashOrder& h, int32_t key, bool known_absent = false) {
+    if (!known_absent && h.count > 0 && hash_find_before(h, key) != kNil) return;
     // _Prime_rehash_policy::_M_need_rehash(B, count, 1), max_load_factor = 1
     if (h.count + 1 > h.next_resize) {
         int32_t floor_min = h.count + 1;
@@ -131,7 +145,7 @@ PG_HD void hash_insert(HashOrder& h, int32_t key) {
         }
     }
     // _M_insert_bucket_begin
-    int32_t b = key % h.buckets;
+    int32_t b = hash_mod(key, h.buckets);
     int16_t k = static_cast<int16_t>(key);
     if (h.before[b] != kNil) {
         int16_t prev = h.before[b];
@@ -140,7 +154,7 @@ PG_HD void hash_insert(HashOrder& h, int32_t key) {
     } else {
         h.next[k] = static_cast<int16_t>(h.head);
         h.head = k;
-        if (h.next[k] != kNil) h.before[h.next[k] % h.buckets] = k;
+        if (h.next[k] != kNil) h.before[hash_mod(h.next[k], h.buckets)] = k;
         h.before[b] = kHead;
     }
     h.count++;
@@ -151,19 +165,19 @@ PG_HD void hash_erase(HashOrder& h, int32_t key) {
     if (h.count == 0) return;
     int16_t prev = hash_find_before(h, key);
     if (prev == kNil) return;
-    int32_t b = key % h.buckets;
+    int32_t b = hash_mod(key, h.buckets);
     int16_t n = static_cast<int16_t>(key);
     int16_t nx = h.next[n];
     if (prev == h.before[b]) {
         // _M_remove_bucket_begin
-        int32_t nb = (nx != kNil) ? (nx % h.buckets) : 0;
+        int32_t nb = (nx != kNil) ? hash_mod(nx, h.buckets) : 0;
         if (nx == kNil || nb != b) {
             if (nx != kNil) h.before[nb] = h.before[b];
             if (h.before[b] == kHead) h.head = nx;
             h.before[b] = kNil;
         }
     } else if (nx != kNil) {
-        int32_t nb = nx % h.buckets;
+        int32_t nb = hash_mod(nx, h.buckets);
         if (nb != b) h.before[nb] = prev;
     }
     hash_set_next(h, prev, nx);

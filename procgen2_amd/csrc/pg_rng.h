@@ -37,19 +37,23 @@ PG_HD void mt_twist(uint32_t* x) {
     x[kMtN - 1] = x[kMtM - 1] ^ mt_mix(x[kMtN - 1], x[0]);
 }
 
+PG_HD uint32_t mt_temper(uint32_t y) {
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
 PG_HD uint32_t mt_next(uint32_t* x) {
     uint32_t idx = x[kMtN];
     if (idx >= static_cast<uint32_t>(kMtN)) {
         mt_twist(x);
         idx = 0;
     }
-    uint32_t y = x[idx];
+    const uint32_t y = x[idx];
     x[kMtN] = idx + 1;
-    y ^= y >> 11;
-    y ^= (y << 7) & 0x9d2c5680u;
-    y ^= (y << 15) & 0xefc60000u;
-    y ^= y >> 18;
-    return y;
+    return mt_temper(y);
 }
 
 // std::uniform_int_distribution<int>(lo, hi)(rng), lo <= hi, hi - lo < 2^32 - 1.
@@ -67,14 +71,62 @@ PG_HD int rng_int(uint32_t* x, int lo, int hi) {
     return lo + static_cast<int>(product >> 32);
 }
 
-// std::generate_canonical<float, 24>(rng)
-PG_HD float rng_canonical(uint32_t* x) {
-    float c = static_cast<float>(mt_next(x)) / 4294967296.0f;
+// std::generate_canonical<float, 24>(rng) for one engine output
+PG_HD float canonical_of(uint32_t word) {
+    float c = static_cast<float>(word) / 4294967296.0f;
     if (c >= 1.0f) c = 0.99999994f;  // nextafter(1.0f, 0.0f) = 0x3f7fffff
     return c;
 }
+PG_HD float rng_canonical(uint32_t* x) { return canonical_of(mt_next(x)); }
 
 // std::uniform_real_distribution<float>(a, b)(rng)
 PG_HD float rng_real(uint32_t* x, float a, float b) { return rng_canonical(x) * (b - a) + a; }
+
+#if defined(__HIPCC__)
+// mt_twist by one wavefront (x in LDS): the recurrence x[i] ← x[i+397 mod 624] ^ mix(x[i], x[i+1]) reads, within
+// each of the index ranges [0,227) [227,454) [454,623), only words that range does not write — except its own
+// x[i] / x[i+1] neighbours, hence read-all, barrier, write-all per range.  Same words as mt_twist.
+__device__ inline void mt_twist_wave(uint32_t* x, int lane) {
+    const int lo[3] = {0, kMtN - kMtM, 2 * (kMtN - kMtM)};
+    const int hi[3] = {kMtN - kMtM, 2 * (kMtN - kMtM), kMtN - 1};
+    for (int ph = 0; ph < 3; ph++) {
+        uint32_t v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int i = lo[ph] + lane + 64 * r;
+            if (i < hi[ph]) v[r] = x[ph == 0 ? i + kMtM : i + kMtM - kMtN] ^ mt_mix(x[i], x[i + 1]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int i = lo[ph] + lane + 64 * r;
+            if (i < hi[ph]) x[i] = v[r];
+        }
+        __syncthreads();
+    }
+    if (lane == 0) x[kMtN - 1] = x[kMtM - 1] ^ mt_mix(x[kMtN - 1], x[0]);
+    __syncthreads();
+}
+
+// `count` consecutive draws of uniform_real_distribution<float>(0,1)(rng) < 0.5f by one wavefront: out[k] = 1 when
+// the k-th draw is below one half.  Leaves the stream where `count` calls of rng_real would.
+__device__ inline void wave_coin_flips(uint32_t* x, uint8_t* out, int count, int lane) {
+    int done = 0;
+    while (done < count) {
+        int idx = static_cast<int>(x[kMtN]);
+        __syncthreads();
+        if (idx >= kMtN) {
+            mt_twist_wave(x, lane);
+            idx = 0;
+        }
+        const int take = (kMtN - idx) < (count - done) ? (kMtN - idx) : (count - done);
+        for (int k = lane; k < take; k += 64)
+            out[done + k] = (canonical_of(mt_temper(x[idx + k])) * (1.0f - 0.0f) + 0.0f) < 0.5f ? 1 : 0;
+        if (lane == 0) x[kMtN] = static_cast<uint32_t>(idx + take);
+        __syncthreads();
+        done += take;
+    }
+}
+#endif
 
 }  // namespace pg
