@@ -527,9 +527,6 @@ PG_D void install(const State& s, int env, const Level& lv, int lane) {
     }
 }
 
-PG_D void copy_level(uint32_t* dst, const uint32_t* src, int lane) {
-    for (int k = lane; k < static_cast<int>(sizeof(Level) / 4); k += 64) dst[k] = src[k];
-}
 
 // ------------------------------------------------------------------------------------------------
 // step
@@ -743,88 +740,17 @@ __global__ void __launch_bounds__(64) make_kernel(State s, uint32_t seed_base, i
         for (int f = 0; f < SH_COUNT; f++) SH(s, f, k, env) = (f == SH_FRAME) ? -1.0f : 0.0f;
 }
 
-// The level kernel serves the envs [blockIdx·span, +span) that need a level, one wavefront at a time:
-//   mode 0  cenv_make: seed = seed_base + env index, level 0 generated synchronously;
-//   mode 1  explicit reset (mask, optional seeds; a seed restarts the env's generator chain);
-//   mode 2  auto-reset of the envs whose previous step terminated (StepIO::pending 1 → 2 tells the logic kernel);
-//   mode 3  side stream: fill the shadow slots that are kSlotQueued.
-// `prefetch` = whether a served env queues its next level (pg_prefetch.h).
-__global__ void __launch_bounds__(64) level_kernel(State s, int mode, int span, int prefetch, uint32_t seed_base,
-                                                   int env_offset, const uint8_t* mask, const int32_t* seeds,
-                                                   StepIO io) {
-    const int lane = threadIdx.x;
-    const int base = blockIdx.x * span;
-    bool want = false;
-    if (lane < span && base + lane < s.n) {
-        const int e = base + lane;
-        if (mode == 0)
-            want = true;
-        else if (mode == 1)
-            want = !mask || mask[e];
-        else if (mode == 2)
-            want = io.pending[e] == 1;
-        else
-            want = __hip_atomic_load(&s.slot[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kSlotQueued;
+struct Gen {  // pg_prefetch.h level_kernel<Gen>
+    using State = caveflyer::State;
+    using Level = caveflyer::Level;
+    using GenLds = caveflyer::GenLds;
+    PG_D static void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, uint32_t seed, int lane) {
+        caveflyer::generate(s, env, L, lv, reseed, seed, lane);
     }
-    unsigned long long todo = __ballot(want);
-    if (!todo) return;
-    __shared__ GenLds L;
-    __shared__ Level lv;
-    __shared__ int32_t verdict;
-    while (todo) {
-        const int env = base + __builtin_ctzll(todo);
-        todo &= todo - 1;
-        if (mode == 3) {
-            if (lane == 0) verdict = slot_cas(&s.slot[env], kSlotQueued, kSlotBusy) ? 1 : 0;
-            __syncthreads();
-            const bool mine = verdict != 0;
-            __syncthreads();
-            if (!mine) continue;
-            generate(s, env, L, lv, false, 0u, lane);
-            copy_level(reinterpret_cast<uint32_t*>(&s.shadow[env]), reinterpret_cast<const uint32_t*>(&lv), lane);
-            __threadfence();
-            __syncthreads();
-            if (lane == 0) slot_store(&s.slot[env], kSlotReady);
-            continue;
-        }
-        const bool reseed = mode == 0 || (mode == 1 && seeds != nullptr);
-        if (lane == 0) {
-            if (mode == 0) {
-                verdict = kSlotSync;
-            } else {
-                int32_t got = slot_acquire_for_install(&s.slot[env]);
-                if (got == kSlotReady && reseed) {  // the prepared level belongs to the abandoned chain
-                    slot_store(&s.slot[env], kSlotSync);
-                    got = kSlotSync;
-                }
-                verdict = got;
-            }
-        }
-        __syncthreads();
-        const int32_t how = verdict;
-        __threadfence();
-        if (how == kSlotReady) {
-            copy_level(reinterpret_cast<uint32_t*>(&lv), reinterpret_cast<const uint32_t*>(&s.shadow[env]), lane);
-            __syncthreads();
-        } else {
-            const uint32_t seed = mode == 0 ? seed_base + static_cast<uint32_t>(env_offset + env)
-                                            : (seeds ? static_cast<uint32_t>(seeds[env]) : 0u);
-            generate(s, env, L, lv, reseed, seed, lane);
-        }
-        install(s, env, lv, lane);
-        __threadfence();
-        __syncthreads();
-        if (lane == 0) {
-            slot_store(&s.slot[env], prefetch ? kSlotQueued : kSlotIdle);
-            if (mode != 0) {
-                io.reward[env] = 0.0f;
-                io.done[env] = 0;
-                io.pending[env] = mode == 2 ? 2 : 0;
-            }
-        }
-        __syncthreads();
+    PG_D static void install(const State& s, int env, const Level& lv, int lane) {
+        caveflyer::install(s, env, lv, lane);
     }
-}
+};
 
 __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actions, uint32_t run_seed,
                                                    uint32_t step_index, int env_offset, StepIO io) {
@@ -1049,24 +975,20 @@ class CaveflyerGame final : public Game {
     int blocks() const { return (s_.n + 63) / 64; }
     void launch_make(hipStream_t st, uint32_t seed_base, int env_offset) override {
         hipLaunchKernelGGL(make_kernel, dim3(blocks()), dim3(64), 0, st, s_, seed_base, env_offset);
-        hipLaunchKernelGGL(level_kernel, dim3(s_.n), dim3(64), 0, st, s_, 0, 1, prefetch(), seed_base, env_offset,
-                           nullptr, nullptr, StepIO{});
+        LevelLaunch<Gen>::make(st, s_, prefetch(), seed_base, env_offset);
     }
     void launch_reset(hipStream_t st, const uint8_t* mask, const int32_t* seeds, StepIO io) override {
-        hipLaunchKernelGGL(level_kernel, dim3(s_.n), dim3(64), 0, st, s_, 1, 1, prefetch(), 0u, 0, mask, seeds, io);
+        LevelLaunch<Gen>::reset(st, s_, prefetch(), mask, seeds, io);
     }
     bool launch_pregen(hipStream_t side, bool bulk) override {
         if (!prefetch()) return false;
-        const int span = bulk ? 1 : 8;  // few envs per wave: queued envs of one wave are served one after the other
-        hipLaunchKernelGGL(level_kernel, dim3((s_.n + span - 1) / span), dim3(64), 0, side, s_, 3, span, 1, 0u, 0,
-                           nullptr, nullptr, StepIO{});
+        LevelLaunch<Gen>::pregen(side, s_, bulk);
         return true;
     }
     int prefetch() const { return (debug_flags & kDebugNoPrefetch) ? 0 : 1; }
     void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
                       StepIO io) override {
-        hipLaunchKernelGGL(level_kernel, dim3(blocks()), dim3(64), 0, st, s_, 2, 64, prefetch(), 0u, 0, nullptr, nullptr,
-                           io);
+        LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io);
         hipLaunchKernelGGL(logic_kernel, dim3(blocks()), dim3(64), 0, st, s_, actions, run_seed, step_index,
                            env_offset, io);
     }

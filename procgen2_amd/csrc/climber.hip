@@ -16,6 +16,7 @@
 #include "pg_engine.h"
 #include "pg_geom.h"
 #include "pg_order.h"
+#include "pg_prefetch.h"
 #include "pg_render.h"
 #include "pg_rng.h"
 #include "pg_tiles.h"
@@ -48,9 +49,25 @@ enum { EB_INFO, EB_SPAWN_X, EB_ORDER, EB_DRAW, EB_COUNT };
 // EB_INFO bits
 constexpr int kMob = 1, kAlive = 2, kFrame = 4, kFlip = 8, kTexSet = 16;
 
+// One generated level, as the generator leaves it in LDS and as it waits in the shadow slot (pg_prefetch.h).
+struct Level {
+    uint8_t tiles[W * H];
+    float bgshift;
+    int32_t themes, n_ent;
+    float ex[kMaxEnt], ey[kMaxEnt], evx[kMaxEnt];
+    uint8_t info[kMaxEnt], spawn_x[kMaxEnt], order[kMaxEnt];
+    uint8_t pad[2];
+};
+
+struct GenLds {
+    uint32_t mt[kMtWords];
+};
+
 struct State {
     int n;
-    uint32_t* mt;    // [n][625]
+    Level* shadow;   // [n]  next level of each env
+    int32_t* slot;   // [n]  SlotState
+    uint32_t* mt;    // [n][625]  generator chain: the stream position after the newest generated level
     uint8_t* tiles;  // [n][1280]  column-major y + x*H
     float* f;        // [F_COUNT][n]
     int32_t* i;      // [I_COUNT][n]
@@ -65,17 +82,20 @@ PG_D uint8_t& EB(const State& s, int field, int e, int env) { return s.eb[(size_
 
 using Win = TileWinT<W, H, kWallMid>;  // out of bounds is a wall (tilemap.h:66-68)
 
-PG_D void put(uint8_t* t, int x, int y, int id) {
-    if (x < 0 || y < 0 || x >= W || y >= H) return;
-    t[y + x * H] = static_cast<uint8_t>(id);
+// Tile writes by the whole wavefront into the map under construction (LDS); later fills overwrite earlier ones, so
+// each ends with a barrier.
+PG_D void fill(uint8_t* t, int x, int y, int w, int h, int id, int lane) {
+    const int total = (w > 0 && h > 0) ? w * h : 0;
+    for (int k = lane; k < total; k += 64) {
+        const int a = udiv_small(k, h), b = k - a * h;
+        const int px = x + a, py = y + b;
+        if (!(px < 0 || py < 0 || px >= W || py >= H)) t[py + px * H] = static_cast<uint8_t>(id);
+    }
+    __syncthreads();
 }
-PG_D void fill(uint8_t* t, int x, int y, int w, int h, int id) {
-    for (int a = 0; a < w; a++)
-        for (int b = 0; b < h; b++) put(t, x + a, y + b, id);
-}
-PG_D void fill_capped(uint8_t* t, int x, int y, int w, int h, int body, int cap) {
-    fill(t, x, y, w, h - 1, body);
-    fill(t, x, y + h - 1, w, 1, cap);
+PG_D void fill_capped(uint8_t* t, int x, int y, int w, int h, int body, int cap, int lane) {
+    fill(t, x, y, w, h - 1, body, lane);
+    fill(t, x, y + h - 1, w, 1, cap, lane);
 }
 
 // The sprite System's set order for this episode: ids 0..n-1 inserted in creation order into a set that kept its
@@ -114,18 +134,28 @@ PG_D void rebuild_draw_list(const State& s, int env, int n_ent) {
     SI(s, I_NDRAW, env) = n;
 }
 
-PG_D void new_level(const State& s, int env) {  // climber.cpp:461-497 + tilemap.cpp:75-170
-    uint32_t* mt = s.mt + size_t(env) * kMtWords;
-    uint8_t* tiles = s.tiles + size_t(env) * (W * H);
+// reset() (climber.cpp:461-497 + tilemap.cpp:75-170) for one env by one wavefront: every lane walks the generator
+// (the draws are wave-uniform), lane 0 records the entities.  Advances the env's generator chain (s.mt, the sprite
+// set's bucket count) and leaves the level in `lv` (LDS).
+PG_D void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, uint32_t seed, int lane) {
+    uint32_t* gmt = s.mt + size_t(env) * kMtWords;
+    if (reseed) {
+        if (lane == 0) mt_seed(L.mt, seed);
+    } else {
+        for (int k = lane; k < kMtWords; k += 64) L.mt[k] = gmt[k];
+    }
+    __syncthreads();
+    uint32_t* mt = L.mt;
+    uint8_t* tiles = lv.tiles;
     const float max_jump = 1.5f, gravity = 0.2f;
-    for (int k = 0; k < W * H; k++) tiles[k] = kEmpty;
-    fill_capped(tiles, 0, 0, W, 1, kWallMid, kWallTop);
-    fill(tiles, 0, 0, 1, H, kWallMid);
-    fill(tiles, W - 1, 0, 1, H, kWallMid);
-    fill(tiles, 0, H - 1, W, 1, kWallMid);
-    const int difficulty = rng_int(mt, 1, 3);
-    const int platforms = rng_int(mt, difficulty * difficulty + 1, (difficulty + 1) * (difficulty + 1) + 1);
-    int cx = rng_int(mt, 2, W - 3), cy = 1;
+    fill(tiles, 0, 0, W, H, kEmpty, lane);
+    fill_capped(tiles, 0, 0, W, 1, kWallMid, kWallTop, lane);
+    fill(tiles, 0, 0, 1, H, kWallMid, lane);
+    fill(tiles, W - 1, 0, 1, H, kWallMid, lane);
+    fill(tiles, 0, H - 1, W, 1, kWallMid, lane);
+    const int difficulty = wave_rng_int(mt, 1, 3, lane);
+    const int platforms = wave_rng_int(mt, difficulty * difficulty + 1, (difficulty + 1) * (difficulty + 1) + 1, lane);
+    int cx = wave_rng_int(mt, 2, W - 3, lane), cy = 1;
     const int margin = 3;
     const float enemy_prob = 0.5f;
     const float reach_y = max_jump * max_jump / (2.0f * gravity);
@@ -133,24 +163,25 @@ PG_D void new_level(const State& s, int env) {  // climber.cpp:461-497 + tilemap
     int n_ent = 0;
     auto spawn = [&](int x, int y, int info, float vx) {
         const int e = n_ent++;
-        EF(s, EF_X, e, env) = static_cast<float>(x) + 0.5f;
-        EF(s, EF_Y, e, env) = static_cast<float>(H - 1 - y) + 0.5f;
-        EF(s, EF_VX, e, env) = vx;
-        EF(s, EF_ANIM_T, e, env) = 0.0f;
-        EB(s, EB_INFO, e, env) = static_cast<uint8_t>(info | kAlive);
-        EB(s, EB_SPAWN_X, e, env) = static_cast<uint8_t>(x);
+        if (lane == 0) {
+            lv.ex[e] = static_cast<float>(x) + 0.5f;
+            lv.ey[e] = static_cast<float>(H - 1 - y) + 0.5f;
+            lv.evx[e] = vx;
+            lv.info[e] = static_cast<uint8_t>(info | kAlive);
+            lv.spawn_x[e] = static_cast<uint8_t>(x);
+        }
     };
     for (int p = 0; p < platforms; p++) {
-        const int dy = rng_int(mt, 3, max_dy - 1);
+        const int dy = wave_rng_int(mt, 3, max_dy - 1, lane);
         const bool roomy = (cx >= margin) && (cx <= W - 1 - margin);
-        if (roomy && (rng_real(mt, 0.0f, 1.0f) < enemy_prob)) {
-            const int my = cy + rng_int(mt, 0, 1) + 2;
-            const float vx = 0.15f * (rng_int(mt, 0, 1) * 2.0f - 1.0f);  // tilemap.cpp:55
+        if (roomy && (wave_rng_real(mt, 0.0f, 1.0f, lane) < enemy_prob)) {
+            const int my = cy + wave_rng_int(mt, 0, 1, lane) + 2;
+            const float vx = 0.15f * (wave_rng_int(mt, 0, 1, lane) * 2.0f - 1.0f);  // tilemap.cpp:55
             spawn(cx, my, kMob, vx);
         }
         cy += dy;
-        const int len = 2 + rng_int(mt, 0, 9);
-        int vx = rng_int(mt, 0, 1) * 2 - 1;
+        const int len = 2 + wave_rng_int(mt, 0, 9, lane);
+        int vx = wave_rng_int(mt, 0, 1, lane) * 2 - 1;
         if (cx < margin) vx = 1;
         if (cx > W - margin) vx = -1;
         int spots[12];
@@ -159,33 +190,68 @@ PG_D void new_level(const State& s, int env) {  // climber.cpp:461-497 + tilemap
             const int nx = cx + (j + 1) * vx;
             if (nx <= 0 || nx >= W - 1) break;
             spots[n_spots++] = nx;
-            fill_capped(tiles, nx, cy, 1, 1, kWallMid, kWallTop);
+            fill_capped(tiles, nx, cy, 1, 1, kWallMid, kWallTop, lane);
         }
-        if (rng_real(mt, 0.0f, 1.0f) < 0.5f || p == platforms - 1)
-            spawn(spots[rng_int(mt, 0, n_spots - 1)], cy + 1, kTexSet, 0.0f);  // crystal: textured from the start
-        cx = spots[rng_int(mt, 0, n_spots - 1)];
+        if (wave_rng_real(mt, 0.0f, 1.0f, lane) < 0.5f || p == platforms - 1)
+            spawn(spots[wave_rng_int(mt, 0, n_spots - 1, lane)], cy + 1, kTexSet, 0.0f);  // crystal: textured from the start
+        cx = spots[wave_rng_int(mt, 0, n_spots - 1, lane)];
     }
-    const int backdrop = rng_int(mt, 0, 9);
-    SF(s, F_BGSHIFT, env) = rng_real(mt, 0.0f, 1.0f);
-    SF(s, F_AX, env) = 1.5f;
-    SF(s, F_AY, env) = H - 2 + 1.0f;
-    SF(s, F_AVX, env) = 0.0f;
-    SF(s, F_AVY, env) = 0.0f;
-    SF(s, F_APHASE, env) = 0.0f;
-    const int suit = rng_int(mt, 0, 3);
-    const int theme = rng_int(mt, 0, 3);
-    SI(s, I_FLAGS, env) = kFlagForward;  // on_ground = false, face_forward = true, draw list cleared (D2)
-    SI(s, I_THEMES, env) = backdrop | (suit << 8) | (theme << 16);
-    SI(s, I_NENT, env) = n_ent;
-    SI(s, I_NDRAW, env) = 0;
-    // camera x is fixed (climber.cpp:466); camera y keeps the previous episode's value (D3)
-
-    uint8_t order[kMaxEnt];
-    int32_t packed = SI(s, I_HASH_SPRITE, env);
-    episode_order(packed, n_ent, order);
-    SI(s, I_HASH_SPRITE, env) = packed;
-    for (int k = 0; k < n_ent; k++) EB(s, EB_ORDER, k, env) = order[k];
+    const int backdrop = wave_rng_int(mt, 0, 9, lane);
+    const float shift = wave_rng_real(mt, 0.0f, 1.0f, lane);
+    const int suit = wave_rng_int(mt, 0, 3, lane);
+    const int theme = wave_rng_int(mt, 0, 3, lane);
+    if (lane == 0) {
+        lv.bgshift = shift;
+        lv.themes = backdrop | (suit << 8) | (theme << 16);
+        lv.n_ent = n_ent;
+        int32_t packed = SI(s, I_HASH_SPRITE, env);
+        episode_order(packed, n_ent, lv.order);
+        SI(s, I_HASH_SPRITE, env) = packed;
+    }
+    __syncthreads();
+    for (int k = lane; k < kMtWords; k += 64) gmt[k] = L.mt[k];
+    __syncthreads();
 }
+
+// The level becomes the env's live state (what reset() and the component constructors initialise).
+PG_D void install(const State& s, int env, const Level& lv, int lane) {
+    uint32_t* tiles = reinterpret_cast<uint32_t*>(s.tiles + size_t(env) * (W * H));
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(lv.tiles);
+    for (int k = lane; k < W * H / 4; k += 64) tiles[k] = src[k];
+    const int n_ent = lv.n_ent;
+    if (lane < n_ent) {
+        EF(s, EF_X, lane, env) = lv.ex[lane];
+        EF(s, EF_Y, lane, env) = lv.ey[lane];
+        EF(s, EF_VX, lane, env) = lv.evx[lane];
+        EF(s, EF_ANIM_T, lane, env) = 0.0f;
+        EB(s, EB_INFO, lane, env) = lv.info[lane];
+        EB(s, EB_SPAWN_X, lane, env) = lv.spawn_x[lane];
+        EB(s, EB_ORDER, lane, env) = lv.order[lane];
+    }
+    if (lane == 0) {
+        SF(s, F_BGSHIFT, env) = lv.bgshift;
+        SF(s, F_AX, env) = 1.5f;
+        SF(s, F_AY, env) = H - 2 + 1.0f;
+        SF(s, F_AVX, env) = 0.0f;
+        SF(s, F_AVY, env) = 0.0f;
+        SF(s, F_APHASE, env) = 0.0f;
+        SI(s, I_FLAGS, env) = kFlagForward;  // on_ground = false, face_forward = true, draw list cleared (D2)
+        SI(s, I_THEMES, env) = lv.themes;
+        SI(s, I_NENT, env) = n_ent;
+        SI(s, I_NDRAW, env) = 0;
+        // camera x is fixed (climber.cpp:466); camera y keeps the previous episode's value (D3)
+    }
+}
+
+struct Gen {  // pg_prefetch.h level_kernel<Gen>
+    using State = climber::State;
+    using Level = climber::Level;
+    using GenLds = climber::GenLds;
+    PG_D static void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, uint32_t seed, int lane) {
+        climber::generate(s, env, L, lv, reseed, seed, lane);
+    }
+    PG_D static void install(const State& s, int env, const Level& lv, int lane) { climber::install(s, env, lv, lane); }
+};
 
 PG_D bool is_wall(int t) { return t == kWallMid || t == kWallTop; }
 
@@ -294,31 +360,15 @@ PG_D void advance(const State& s, int env, int action, float& reward_out, bool& 
 __global__ void __launch_bounds__(64) make_kernel(State s, uint32_t seed_base, int env_offset) {
     const int env = blockIdx.x * 64 + threadIdx.x;
     if (env >= s.n) return;
-    mt_seed(s.mt + size_t(env) * kMtWords, seed_base + static_cast<uint32_t>(env_offset + env));
     SI(s, I_HASH_SPRITE, env) = 1;
     SF(s, F_CAMY, env) = 0.0f;  // Renderer::camera_position{0} (renderer.h:18)
-    new_level(s, env);
-}
-
-__global__ void __launch_bounds__(64) reset_kernel(State s, const uint8_t* mask, const int32_t* seeds, StepIO io) {
-    const int env = blockIdx.x * 64 + threadIdx.x;
-    if (env >= s.n) return;
-    if (mask && !mask[env]) return;
-    if (seeds) mt_seed(s.mt + size_t(env) * kMtWords, static_cast<uint32_t>(seeds[env]));
-    new_level(s, env);
-    io.reward[env] = 0.0f;
-    io.done[env] = 0;
-    io.pending[env] = 0;
 }
 
 __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actions, uint32_t run_seed,
                                                    uint32_t step_index, int env_offset, StepIO io) {
     const int env = blockIdx.x * 64 + threadIdx.x;
     if (env >= s.n) return;
-    if (io.pending[env]) {
-        new_level(s, env);
-        io.reward[env] = 0.0f;
-        io.done[env] = 0;
+    if (io.pending[env] == 2) {  // reset by the level kernel in this step
         io.pending[env] = 0;
         return;
     }
@@ -476,7 +526,7 @@ class ClimberGame final : public Game {
     }
     static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
     struct Layout {
-        size_t mt, tiles, f, i, ef, eb, total;
+        size_t shadow, slot, mt, tiles, f, i, ef, eb, total;
     };
     static Layout layout(int n) {
         Layout l{};
@@ -486,6 +536,8 @@ class ClimberGame final : public Game {
             off += align256(bytes);
             return at;
         };
+        l.shadow = take(size_t(n) * sizeof(Level));
+        l.slot = take(size_t(n) * 4);
         l.mt = take(size_t(n) * kMtWords * 4);
         l.tiles = take(size_t(n) * W * H);
         l.f = take(size_t(F_COUNT) * n * 4);
@@ -500,6 +552,8 @@ class ClimberGame final : public Game {
         uint8_t* p = static_cast<uint8_t*>(d_state);
         const Layout l = layout(n);
         s_.n = n;
+        s_.shadow = reinterpret_cast<Level*>(p + l.shadow);
+        s_.slot = reinterpret_cast<int32_t*>(p + l.slot);
         s_.mt = reinterpret_cast<uint32_t*>(p + l.mt);
         s_.tiles = p + l.tiles;
         s_.f = reinterpret_cast<float*>(p + l.f);
@@ -511,12 +565,20 @@ class ClimberGame final : public Game {
     int blocks() const { return (s_.n + 63) / 64; }
     void launch_make(hipStream_t st, uint32_t seed_base, int env_offset) override {
         hipLaunchKernelGGL(make_kernel, dim3(blocks()), dim3(64), 0, st, s_, seed_base, env_offset);
+        LevelLaunch<Gen>::make(st, s_, prefetch(), seed_base, env_offset);
     }
     void launch_reset(hipStream_t st, const uint8_t* mask, const int32_t* seeds, StepIO io) override {
-        hipLaunchKernelGGL(reset_kernel, dim3(blocks()), dim3(64), 0, st, s_, mask, seeds, io);
+        LevelLaunch<Gen>::reset(st, s_, prefetch(), mask, seeds, io);
     }
+    bool launch_pregen(hipStream_t side, bool bulk) override {
+        if (!prefetch()) return false;
+        LevelLaunch<Gen>::pregen(side, s_, bulk);
+        return true;
+    }
+    int prefetch() const { return (debug_flags & kDebugNoPrefetch) ? 0 : 1; }
     void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
                       StepIO io) override {
+        LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io);
         hipLaunchKernelGGL(logic_kernel, dim3(blocks()), dim3(64), 0, st, s_, actions, run_seed, step_index,
                            env_offset, io);
     }

@@ -29,6 +29,7 @@
 #include "pg_engine.h"
 #include "pg_geom.h"
 #include "pg_order.h"
+#include "pg_prefetch.h"
 #include "pg_render.h"
 #include "pg_rng.h"
 
@@ -74,9 +75,20 @@ enum { DF_X, DF_VX, DF_ANIM_T, DF_SPAWN_T, DF_COUNT };
 // dynamic per-entity byte: animation frame | flip_x | texture assigned
 constexpr int kDynFrame = 1, kDynFlip = 2, kDynTexSet = 4;
 
+// One generated level, as the generator leaves it in LDS and as it waits in the shadow slot (pg_prefetch.h).
+struct Level {
+    uint8_t tiles[W * H];
+    float bgshift;
+    int32_t themes, n_ent, n_mob;
+    float ey[kMaxEnt], x[kMaxEnt], vx[kMaxEnt];
+    uint8_t kind[kMaxEnt], tex[kMaxEnt], draw_order[kMaxEnt], spark_order[kMaxEnt];
+};
+
 struct State {
     int n;
-    uint32_t* mt;    // [n][625]
+    Level* shadow;   // [n]  next level of each env
+    int32_t* slot;   // [n]  SlotState
+    uint32_t* mt;    // [n][625]  generator chain: the stream position after the newest generated level
     uint8_t* tiles;  // [n][4096]   tile id | crate kind << 4, column-major y + x*H (tilemap.h:62-85)
     float* f;        // [F_COUNT][n]
     int32_t* i;      // [I_COUNT][n]
@@ -110,15 +122,23 @@ PG_D float& SP(const State& s, int buf, int comp, int e, int k, int env) {
     return s.spark[(((size_t(buf) * 3 + comp) * kMaxEnt + e) * kSparks + k) * s.n + env];
 }
 
+// The tile map under construction (in LDS), written by the whole wavefront: a rectangle fill is spread over the
+// lanes, and since later fills overwrite earlier ones every operation ends with a barrier.
 struct TileMap {
-    uint8_t* t;  // this env's 4096 cells
+    uint8_t* t;  // 4096 cells
+    int lane;
     PG_D void put(int x, int y, int id) {
-        if (x < 0 || y < 0 || x >= W || y >= H) return;
-        t[y + x * H] = static_cast<uint8_t>(id);
+        if (lane == 0 && !(x < 0 || y < 0 || x >= W || y >= H)) t[y + x * H] = static_cast<uint8_t>(id);
+        __syncthreads();
     }
     PG_D void fill(int x, int y, int w, int h, int id) {
-        for (int a = 0; a < w; a++)
-            for (int b = 0; b < h; b++) put(x + a, y + b, id);
+        const int total = (w > 0 && h > 0) ? w * h : 0;
+        for (int k = lane; k < total; k += 64) {
+            const int a = udiv_small(k, h), b = k - a * h;
+            const int px = x + a, py = y + b;
+            if (!(px < 0 || py < 0 || px >= W || py >= H)) t[py + px * H] = static_cast<uint8_t>(id);
+        }
+        __syncthreads();
     }
     PG_D void fill_capped(int x, int y, int w, int h, int body, int cap) {
         fill(x, y, w, h - 1, body);
@@ -126,59 +146,57 @@ struct TileMap {
     }
 };
 
+struct GenLds {
+    uint32_t mt[kMtWords];
+};
+
 // ------------------------------------------------------------------------------------------------
-// reset: coinrun.cpp:472-507 + tilemap.cpp:97-292
+// reset: coinrun.cpp:472-507 + tilemap.cpp:97-292.  Every lane walks the builder (the draws are wave-uniform), lane 0
+// records the entities.
 // ------------------------------------------------------------------------------------------------
 struct LevelBuilder {
-    const State& s;
-    int env;
-    int buf;  // live half of the dynamic table
+    Level& lv;
     uint32_t* mt;
+    int lane;
     TileMap map;
     int n_ent = 0, n_mob = 0;
 
     PG_D int spawn(float x, float y, int kind, int tex, float vx) {
         const int e = n_ent++;
-        EY(s, e, env) = y;
-        EB(s, EB_KIND, e, env) = static_cast<uint8_t>(kind);
-        EB(s, EB_TEX, e, env) = static_cast<uint8_t>(tex);
-        DF(s, buf, DF_X, e, env) = x;
-        DF(s, buf, DF_VX, e, env) = vx;
-        DF(s, buf, DF_ANIM_T, e, env) = 0.0f;
-        DF(s, buf, DF_SPAWN_T, e, env) = 0.0f;
-        DB(s, buf, e, env) = static_cast<uint8_t>(kind == kCoin ? kDynTexSet : 0);  // D10: animated sprites start unset
+        if (lane == 0) {
+            lv.ey[e] = y;
+            lv.kind[e] = static_cast<uint8_t>(kind);
+            lv.tex[e] = static_cast<uint8_t>(tex);
+            lv.x[e] = x;
+            lv.vx[e] = vx;
+        }
         return e;
     }
     PG_D void add_saw(int x, int y) {  // tilemap.cpp:52-68
         spawn(static_cast<float>(x) + 0.5f, static_cast<float>(H - 1 - y) + 0.5f, kSaw, kTexSaw, 0.0f);
     }
     PG_D void add_mob(int x, int y) {  // tilemap.cpp:70-94
-        const int which = rng_int(mt, 0, 8);
-        const float vx = 0.15f * ((rng_real(mt, 0.0f, 1.0f) < 0.5f) * 2.0f - 1.0f);
+        const int which = wave_rng_int(mt, 0, 8, lane);
+        const float vx = 0.15f * ((wave_rng_real(mt, 0.0f, 1.0f, lane) < 0.5f) * 2.0f - 1.0f);
         const int e = spawn(static_cast<float>(x) + 0.5f, static_cast<float>(H - 1 - y) + 0.5f, kMob,
                             kTexWalker + 2 * which, vx);
-        for (int k = 0; k < kSparks; k++) {
-            SP(s, buf, 0, e, k, env) = 0.0f;
-            SP(s, buf, 1, e, k, env) = 0.0f;
-            SP(s, buf, 2, e, k, env) = 0.0f;
-        }
-        EB(s, EB_SPARK_ORDER, n_mob, env) = static_cast<uint8_t>(e);  // creation order; permuted below
+        if (lane == 0) lv.spark_order[n_mob] = static_cast<uint8_t>(e);  // creation order; permuted below
         n_mob++;
     }
 
     PG_D void build() {
         const float max_jump = 1.5f, gravity = 0.2f, max_speed = 0.5f;
-        for (int k = 0; k < W * H; k++) map.t[k] = kEmpty;
+        map.fill(0, 0, W, H, kEmpty);
         map.fill(0, 0, W, 1, kWallTop);
         map.fill(0, 0, 1, H, kWallMid);
         map.fill(W - 1, 0, 1, H, kWallMid);
         map.fill(0, H - 1, W, 1, kWallMid);
 
-        const int difficulty = rng_int(mt, 1, 3);
-        const int sections = rng_int(mt, difficulty, 2 * difficulty - 1);
+        const int difficulty = wave_rng_int(mt, 1, 3, lane);
+        const int sections = wave_rng_int(mt, difficulty, 2 * difficulty - 1, lane);
         int cx = 5, cy = 1;
         const int pit_thresh = difficulty;
-        const int danger = rng_int(mt, 0, 2);
+        const int danger = wave_rng_int(mt, 0, 2, lane);
 
         const float reach_x = max_speed * 2.0f * max_jump / gravity;
         const float reach_y = max_jump * max_jump / (2.0f * gravity);
@@ -188,16 +206,16 @@ struct LevelBuilder {
         for (int sec = 0; sec < sections; sec++) {
             if (cx + 15 >= W) break;
             const int bump = difficulty / 3;
-            int dy = rng_int(mt, 1 + bump, 4 + bump);
+            int dy = wave_rng_int(mt, 1 + bump, 4 + bump, lane);
             dy = dy < max_dy ? dy : max_dy;
-            if (cy >= 20 || (cy >= 5 && rng_real(mt, 0.0f, 1.0f) < 0.5f)) dy = -dy;
-            const int dx = rng_int(mt, 3 + bump, 2 * difficulty + 2 + bump);
+            if (cy >= 20 || (cy >= 5 && wave_rng_real(mt, 0.0f, 1.0f, lane) < 0.5f)) dy = -dy;
+            const int dx = wave_rng_int(mt, 3 + bump, 2 * difficulty + 2 + bump, lane);
             cy = (cy + dy) > 1 ? (cy + dy) : 1;
 
-            const bool pit = (dx > 7) && (cy > 3) && (rng_int(mt, 0, 19) >= pit_thresh);
+            const bool pit = (dx > 7) && (cy > 3) && (wave_rng_int(mt, 0, 19, lane) >= pit_thresh);
             if (pit) {
-                int x1 = rng_int(mt, 1, 3);
-                int x2 = rng_int(mt, 1, 3);
+                int x1 = wave_rng_int(mt, 1, 3, lane);
+                int x2 = wave_rng_int(mt, 1, 3, lane);
                 int gap = dx - x1 - x2;
                 if (gap > max_dx) {
                     gap = max_dx;
@@ -205,7 +223,7 @@ struct LevelBuilder {
                 }
                 map.fill_capped(cx, 0, x1, cy, kWallMid, kWallTop);
                 map.fill_capped(cx + dx - x2, 0, x2, cy, kWallMid, kWallTop);
-                const int lava_h = rng_int(mt, 1, cy - 3);
+                const int lava_h = wave_rng_int(mt, 1, cy - 3, lane);
                 if (danger == 0) {
                     map.fill_capped(cx + x1, 1, gap, lava_h, kLavaMid, kLavaTop);
                 } else if (danger == 1) {
@@ -216,14 +234,14 @@ struct LevelBuilder {
                 if (gap > 4) {
                     int x3, w1;
                     if (gap == 5) {
-                        x3 = rng_int(mt, 1, 2);
-                        w1 = rng_int(mt, 1, 2);
+                        x3 = wave_rng_int(mt, 1, 2, lane);
+                        w1 = wave_rng_int(mt, 1, 2, lane);
                     } else if (gap == 6) {
-                        x3 = rng_int(mt, 1, 2) + 1;
-                        w1 = rng_int(mt, 1, 2);
+                        x3 = wave_rng_int(mt, 1, 2, lane) + 1;
+                        w1 = wave_rng_int(mt, 1, 2, lane);
                     } else {
-                        x3 = rng_int(mt, 1, 2) + 1;
-                        const int x4 = rng_int(mt, 1, 2) + 1;
+                        x3 = wave_rng_int(mt, 1, 2, lane) + 1;
+                        const int x4 = wave_rng_int(mt, 1, 2, lane) + 1;
                         w1 = gap - x3 - x4;
                     }
                     map.fill_capped(cx + x1 + x3, cy - 1, w1, 1, kWallMid, kWallTop);
@@ -232,20 +250,21 @@ struct LevelBuilder {
                 map.fill_capped(cx, 0, dx, cy, kWallMid, kWallTop);
                 int ob1 = -1;
                 const int ob2 = -1;
-                if (rng_int(mt, 0, 9) < 2 * difficulty && dx > 3) {
-                    ob1 = cx + rng_int(mt, 1, dx - 2);
+                if (wave_rng_int(mt, 0, 9, lane) < 2 * difficulty && dx > 3) {
+                    ob1 = cx + wave_rng_int(mt, 1, dx - 2, lane);
                     add_saw(ob1, cy);
                 }
-                if (rng_int(mt, 0, 9) < difficulty && dx > 3 && max_dx >= 4) {
-                    ob1 = cx + rng_int(mt, 1, dx - 2);
+                if (wave_rng_int(mt, 0, 9, lane) < difficulty && dx > 3 && max_dx >= 4) {
+                    ob1 = cx + wave_rng_int(mt, 1, dx - 2, lane);
                     add_mob(ob1, cy);
                 }
                 for (int k = 0; k < 2; k++) {
-                    const int crate_x = cx + rng_int(mt, 1, dx - 2);
-                    if (rng_real(mt, 0.0f, 1.0f) < 0.5f && ob1 != crate_x && ob2 != crate_x) {
-                        const int pile = rng_int(mt, 1, 3);
+                    const int crate_x = cx + wave_rng_int(mt, 1, dx - 2, lane);
+                    if (wave_rng_real(mt, 0.0f, 1.0f, lane) < 0.5f && ob1 != crate_x && ob2 != crate_x) {
+                        const int pile = wave_rng_int(mt, 1, 3, lane);
                         for (int j = 0; j < pile; j++) {
-                            const int kind = rng_int(mt, 0, 3);  // crate_dist is drawn for every pile cell (tilemap.cpp:263)
+                            // crate_dist is drawn for every pile cell (tilemap.cpp:263)
+                            const int kind = wave_rng_int(mt, 0, 3, lane);
                             map.put(crate_x, cy + j, kCrate | (kind << 4));
                         }
                     }
@@ -282,46 +301,103 @@ PG_D void episode_order(int32_t& packed, const uint8_t* ids, int n, uint8_t* out
     packed = h.buckets | (h.next_resize << 16);
 }
 
-PG_D void new_level(const State& s, int env) {
-    const int buf = (SI(s, I_FLAGS, env) & kFlagBuf) ? 1 : 0;
-    LevelBuilder lb{s, env, buf, s.mt + size_t(env) * kMtWords, TileMap{s.tiles + size_t(env) * (W * H)}};
+// reset() for one env by one wavefront: advances the env's generator chain (s.mt, the two bucket-count words) and
+// leaves the level in `lv` (LDS).
+PG_D void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, uint32_t seed, int lane) {
+    uint32_t* gmt = s.mt + size_t(env) * kMtWords;
+    if (reseed) {
+        if (lane == 0) mt_seed(L.mt, seed);
+    } else {
+        for (int k = lane; k < kMtWords; k += 64) L.mt[k] = gmt[k];
+    }
+    __syncthreads();
+    uint32_t* mt = L.mt;
+    LevelBuilder lb{lv, mt, lane, TileMap{lv.tiles, lane}};
     lb.build();
-    uint32_t* mt = lb.mt;
-    const int backdrop = rng_int(mt, 0, 48);
-    const float shift = rng_real(mt, 0.0f, 1.0f);
-    const int alien = rng_int(mt, 0, 4);
-    const int ground = rng_int(mt, 0, 5);
+    const int backdrop = wave_rng_int(mt, 0, 48, lane);
+    const float shift = wave_rng_real(mt, 0.0f, 1.0f, lane);
+    const int alien = wave_rng_int(mt, 0, 4, lane);
+    const int ground = wave_rng_int(mt, 0, 5, lane);
+    if (lane == 0) {
+        lv.bgshift = shift;
+        lv.themes = backdrop | (alien << 8) | (ground << 16);
+        lv.n_ent = lb.n_ent;
+        lv.n_mob = lb.n_mob;
+        // T3/T4: sprite set = every non-agent entity in creation order; particle set = the mobs.
+        uint8_t ids[kMaxEnt], order[kMaxEnt];
+        for (int k = 0; k < lb.n_ent; k++) ids[k] = static_cast<uint8_t>(k);
+        int32_t packed = SI(s, I_HASH_SPRITE, env);
+        episode_order(packed, ids, lb.n_ent, order);
+        SI(s, I_HASH_SPRITE, env) = packed;
+        ZItem items[kMaxEnt];
+        for (int k = 0; k < lb.n_ent; k++) items[k] = {1.0f, order[k]};  // every coinrun sprite has z = 1
+        sort_by_key(items, lb.n_ent);
+        for (int k = 0; k < lb.n_ent; k++) lv.draw_order[k] = static_cast<uint8_t>(items[k].id);
 
-    SF(s, F_AX, env) = 1.5f;
-    SF(s, F_AY, env) = H - 1 - 1.0f;
-    SF(s, F_AVX, env) = 0.0f;
-    SF(s, F_AVY, env) = 0.0f;
-    SF(s, F_APHASE, env) = 0.0f;
-    SF(s, F_BGSHIFT, env) = shift;
-    // on_ground=false, face_forward=true, draw list cleared (D2); the live half of the table is unchanged
-    SI(s, I_FLAGS, env) = kFlagForward | (buf ? kFlagBuf : 0);
-    SI(s, I_THEMES, env) = backdrop | (alien << 8) | (ground << 16);
-    SI(s, I_NENT, env) = lb.n_ent;
-    SI(s, I_NMOB, env) = lb.n_mob;
-    // camera keeps the previous episode's value (D3)
-
-    // T3/T4: sprite set = every non-agent entity in creation order; particle set = the mobs.
-    uint8_t ids[kMaxEnt], order[kMaxEnt];
-    for (int k = 0; k < lb.n_ent; k++) ids[k] = static_cast<uint8_t>(k);
-    int32_t packed = SI(s, I_HASH_SPRITE, env);
-    episode_order(packed, ids, lb.n_ent, order);
-    SI(s, I_HASH_SPRITE, env) = packed;
-    ZItem items[kMaxEnt];
-    for (int k = 0; k < lb.n_ent; k++) items[k] = {1.0f, order[k]};  // every coinrun sprite has z = 1
-    sort_by_key(items, lb.n_ent);
-    for (int k = 0; k < lb.n_ent; k++) EB(s, EB_DRAW_ORDER, k, env) = static_cast<uint8_t>(items[k].id);
-
-    for (int k = 0; k < lb.n_mob; k++) ids[k] = EB(s, EB_SPARK_ORDER, k, env);
-    packed = SI(s, I_HASH_SPARK, env);
-    episode_order(packed, ids, lb.n_mob, order);
-    SI(s, I_HASH_SPARK, env) = packed;
-    for (int k = 0; k < lb.n_mob; k++) EB(s, EB_SPARK_ORDER, k, env) = order[k];
+        for (int k = 0; k < lb.n_mob; k++) ids[k] = lv.spark_order[k];
+        packed = SI(s, I_HASH_SPARK, env);
+        episode_order(packed, ids, lb.n_mob, order);
+        SI(s, I_HASH_SPARK, env) = packed;
+        for (int k = 0; k < lb.n_mob; k++) lv.spark_order[k] = order[k];
+    }
+    __syncthreads();
+    for (int k = lane; k < kMtWords; k += 64) gmt[k] = L.mt[k];
+    __syncthreads();
 }
+
+// The level becomes the env's live state (what reset() and the component constructors initialise).
+PG_D void install(const State& s, int env, const Level& lv, int lane) {
+    uint32_t* tiles = reinterpret_cast<uint32_t*>(s.tiles + size_t(env) * (W * H));
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(lv.tiles);
+    for (int k = lane; k < W * H / 4; k += 64) tiles[k] = src[k];
+    const int buf = (SI(s, I_FLAGS, env) & kFlagBuf) ? 1 : 0;  // the live half of the dynamic table stays where it is
+    const int n_ent = lv.n_ent, n_mob = lv.n_mob;
+    if (lane < n_ent) {
+        const int e = lane;
+        const int kind = lv.kind[e];
+        EY(s, e, env) = lv.ey[e];
+        EB(s, EB_KIND, e, env) = static_cast<uint8_t>(kind);
+        EB(s, EB_TEX, e, env) = lv.tex[e];
+        EB(s, EB_DRAW_ORDER, e, env) = lv.draw_order[e];
+        DF(s, buf, DF_X, e, env) = lv.x[e];
+        DF(s, buf, DF_VX, e, env) = lv.vx[e];
+        DF(s, buf, DF_ANIM_T, e, env) = 0.0f;
+        DF(s, buf, DF_SPAWN_T, e, env) = 0.0f;
+        DB(s, buf, e, env) = static_cast<uint8_t>(kind == kCoin ? kDynTexSet : 0);  // D10: animated sprites start unset
+        if (kind == kMob)
+            for (int k = 0; k < kSparks; k++) {
+                SP(s, buf, 0, e, k, env) = 0.0f;
+                SP(s, buf, 1, e, k, env) = 0.0f;
+                SP(s, buf, 2, e, k, env) = 0.0f;
+            }
+    }
+    if (lane < n_mob) EB(s, EB_SPARK_ORDER, lane, env) = lv.spark_order[lane];
+    __syncthreads();  // I_FLAGS is read above by every lane
+    if (lane == 0) {
+        SF(s, F_AX, env) = 1.5f;
+        SF(s, F_AY, env) = H - 1 - 1.0f;
+        SF(s, F_AVX, env) = 0.0f;
+        SF(s, F_AVY, env) = 0.0f;
+        SF(s, F_APHASE, env) = 0.0f;
+        SF(s, F_BGSHIFT, env) = lv.bgshift;
+        // on_ground=false, face_forward=true, draw list cleared (D2); the live half of the table is unchanged
+        SI(s, I_FLAGS, env) = kFlagForward | (buf ? kFlagBuf : 0);
+        SI(s, I_THEMES, env) = lv.themes;
+        SI(s, I_NENT, env) = n_ent;
+        SI(s, I_NMOB, env) = n_mob;
+        // camera keeps the previous episode's value (D3)
+    }
+}
+
+struct Gen {  // pg_prefetch.h level_kernel<Gen>
+    using State = coinrun::State;
+    using Level = coinrun::Level;
+    using GenLds = coinrun::GenLds;
+    PG_D static void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, uint32_t seed, int lane) {
+        coinrun::generate(s, env, L, lv, reseed, seed, lane);
+    }
+    PG_D static void install(const State& s, int env, const Level& lv, int lane) { coinrun::install(s, env, lv, lane); }
+};
 
 // ------------------------------------------------------------------------------------------------
 // tile collision, variant A (tilemap.cpp:323-396)
@@ -593,35 +669,20 @@ PG_D void agent_substeps(const State& s, int env, int action) {
 __global__ void __launch_bounds__(64) make_kernel(State s, uint32_t seed_base, int env_offset) {
     const int env = blockIdx.x * 64 + threadIdx.x;
     if (env >= s.n) return;
-    mt_seed(s.mt + size_t(env) * kMtWords, seed_base + static_cast<uint32_t>(env_offset + env));
     SI(s, I_FLAGS, env) = 0;
     SI(s, I_HASH_SPRITE, env) = 1;  // empty unordered_set: one bucket, next_resize 0
     SI(s, I_HASH_SPARK, env) = 1;
     SF(s, F_CAMX, env) = 0.0f;  // Renderer::camera_position{0} (renderer.h:18)
     SF(s, F_CAMY, env) = 0.0f;
-    new_level(s, env);  // level 0, never observed (D1)
+    // level 0 (never observed, D1) follows from the level kernel
 }
 
-__global__ void __launch_bounds__(64) reset_kernel(State s, const uint8_t* mask, const int32_t* seeds, StepIO io) {
-    const int env = blockIdx.x * 64 + threadIdx.x;
-    if (env >= s.n) return;
-    if (mask && !mask[env]) return;
-    if (seeds) mt_seed(s.mt + size_t(env) * kMtWords, static_cast<uint32_t>(seeds[env]));
-    new_level(s, env);
-    io.reward[env] = 0.0f;
-    io.done[env] = 0;
-    io.pending[env] = 0;
-}
-
-// A — lane = env: auto-reset, or the agent's sub-steps into the scratch table.
+// A — lane = env: the agent's sub-steps into the scratch table (envs that reset in this step sit it out).
 __global__ void __launch_bounds__(64) agent_kernel(State s, const int32_t* actions, uint32_t run_seed,
                                                    uint32_t step_index, int env_offset, StepIO io) {
     const int env = blockIdx.x * 64 + threadIdx.x;
     if (env >= s.n) return;
-    if (io.pending[env]) {  // the caller's `if term: env.reset()` (game_test.py:38-40), RNG stream continues
-        new_level(s, env);
-        io.reward[env] = 0.0f;
-        io.done[env] = 0;
+    if (io.pending[env] == 2) {  // the caller's `if term: env.reset()` (game_test.py:38-40): done by the level kernel
         io.pending[env] = 0;
         SCI(s, SC_BITS, env) = 0;  // did not step: B and C leave this env alone
         return;
@@ -943,7 +1004,7 @@ class CoinrunGame final : public Game {
 
     static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
     struct Layout {
-        size_t mt, tiles, f, i, ey, eb, df, db, spark, scratch, total;
+        size_t shadow, slot, mt, tiles, f, i, ey, eb, df, db, spark, scratch, total;
     };
     static Layout layout(int n) {
         Layout l{};
@@ -953,6 +1014,8 @@ class CoinrunGame final : public Game {
             off += align256(bytes);
             return at;
         };
+        l.shadow = take(size_t(n) * sizeof(Level));
+        l.slot = take(size_t(n) * 4);
         l.mt = take(size_t(n) * kMtWords * 4);
         l.tiles = take(size_t(n) * W * H);
         l.f = take(size_t(F_COUNT) * n * 4);
@@ -971,6 +1034,8 @@ class CoinrunGame final : public Game {
         uint8_t* p = static_cast<uint8_t*>(d_state);
         const Layout l = layout(n);
         s_.n = n;
+        s_.shadow = reinterpret_cast<Level*>(p + l.shadow);
+        s_.slot = reinterpret_cast<int32_t*>(p + l.slot);
         s_.mt = reinterpret_cast<uint32_t*>(p + l.mt);
         s_.tiles = p + l.tiles;
         s_.f = reinterpret_cast<float*>(p + l.f);
@@ -986,12 +1051,20 @@ class CoinrunGame final : public Game {
     int blocks() const { return (s_.n + 63) / 64; }
     void launch_make(hipStream_t st, uint32_t seed_base, int env_offset) override {
         hipLaunchKernelGGL(make_kernel, dim3(blocks()), dim3(64), 0, st, s_, seed_base, env_offset);
+        LevelLaunch<Gen>::make(st, s_, prefetch(), seed_base, env_offset);
     }
     void launch_reset(hipStream_t st, const uint8_t* mask, const int32_t* seeds, StepIO io) override {
-        hipLaunchKernelGGL(reset_kernel, dim3(blocks()), dim3(64), 0, st, s_, mask, seeds, io);
+        LevelLaunch<Gen>::reset(st, s_, prefetch(), mask, seeds, io);
     }
+    bool launch_pregen(hipStream_t side, bool bulk) override {
+        if (!prefetch()) return false;
+        LevelLaunch<Gen>::pregen(side, s_, bulk);
+        return true;
+    }
+    int prefetch() const { return (debug_flags & kDebugNoPrefetch) ? 0 : 1; }
     void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
                       StepIO io) override {
+        LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io);
         hipLaunchKernelGGL(agent_kernel, dim3(blocks()), dim3(64), 0, st, s_, actions, run_seed, step_index,
                            env_offset, io);
         hipLaunchKernelGGL(entity_kernel, dim3(blocks(), kMaxEnt), dim3(64), 0, st, s_);

@@ -6,9 +6,13 @@
 //   reset  games/maze/maze.cpp:416-438, tilemap.cpp:31-109, maze_generator.cpp:55-139,183-195
 // Config = the reference's compile-time default, hard_mode: 25×25 world, all visible, fixed camera
 // (maze/tilemap.h:40-42, tilemap.cpp:35-38).
-// Same machine mapping as coinrun.hip: logic one lane per env (SoA across envs), render one wave per env.
+// Machine mapping: logic one lane per env (SoA across envs), render one wave per env, level generation one wave per
+// env on LDS.  The game draws no random numbers during an episode and every episode ends within 500 steps, so
+// resets are frequent and bursty; the next maze of every env is carved ahead of time on a side stream and copied
+// in at reset (pg_prefetch.h).
 #include "pg_engine.h"
 #include "pg_geom.h"
+#include "pg_prefetch.h"
 #include "pg_render.h"
 #include "pg_rng.h"
 
@@ -26,9 +30,18 @@ enum { F_AX, F_AY, F_GX, F_GY, F_BGSHIFT, F_COUNT };
 enum { I_FLAGS, I_STEPS, I_BG, I_COUNT };
 constexpr int kFlagForward = 1, kFlagListed = 2;
 
+// One generated level, as the generator leaves it in LDS and as it waits in the shadow slot.
+struct Level {
+    uint8_t tiles[kTileStride];
+    float ax, ay, gx, gy, bgshift;
+    int32_t bg;
+};
+
 struct State {
     int n;
-    uint32_t* mt;    // [n][625]
+    Level* shadow;   // [n]  next level of each env (pg_prefetch.h)
+    int32_t* slot;   // [n]  SlotState
+    uint32_t* mt;    // [n][625]  generator chain: the stream position after the newest generated level
     uint8_t* tiles;  // [n][640], column-major y + x*H
     float* f;        // [F_COUNT][n]
     int32_t* i;      // [I_COUNT][n]
@@ -42,140 +55,209 @@ PG_D int tile_at(const uint8_t* t, int x, int y) {
     return t[y + x * H];
 }
 
-// Randomised Kruskal with union by rank + path halving over a 1-cell padded grid
-// (maze_generator.cpp:55-139).  Scratch lives in private memory; types are narrowed to keep it small.
-struct Carver {
+// Randomised Kruskal with union by rank + path halving over a 1-cell padded grid (maze_generator.cpp:55-139), on
+// LDS.  The reference erases the drawn wall from a std::vector (`walls.erase(walls.begin() + n)`), i.e. the draw
+// selects the n-th wall still present in construction order: kept here as a 320-bit presence mask and a
+// select-the-n-th-set-bit, instead of moving the tail of the array 312 times.
+struct GenLds {
     static constexpr int kMaxDim = 25, kPadDim = kMaxDim + 2;
-    int mw, mh, aw, ah;
-    uint8_t grid[kPadDim * kPadDim];
-    uint8_t rank[kMaxDim * kMaxDim];
-    int16_t parent[kMaxDim * kMaxDim];
-    int16_t open_cells[kPadDim * kPadDim];
-    uint8_t seen[(kMaxDim * kMaxDim + 7) / 8];
+    uint32_t mt[kMtWords];
+    uint64_t present[5];
+    uint8_t grid[kPadDim * kPadDim + 3];
+    uint8_t rank[kMaxDim * kMaxDim + 3];
+    int16_t parent[kMaxDim * kMaxDim + 1];
+    int16_t open_cells[kPadDim * kPadDim + 1];
+    uint8_t seen[kMaxDim * kMaxDim + 3];
     uint8_t segs[312][4];  // walls between cells, 2 * 12 * 13 for a 25×25 maze
-    int n_open, n_segs;
+    int32_t n_open, drop_cell;
+};
+
+struct Carver {
+    GenLds& L;
+    int mw, mh, aw, ah;
 
     PG_D int idx(int x, int y) const { return y + ah * x; }
     PG_D int get(int x, int y) const {
         if (x < 0 || y < 0 || x >= aw || y >= ah) return 1;
-        return grid[idx(x, y)];
+        return L.grid[idx(x, y)];
     }
     PG_D int root(int c) {
         int cur = c;
-        while (parent[cur] != cur) {
-            parent[cur] = parent[parent[cur]];
-            cur = parent[cur];
+        while (L.parent[cur] != cur) {
+            L.parent[cur] = L.parent[L.parent[cur]];
+            cur = L.parent[cur];
         }
         return cur;
     }
     PG_D void open(int x, int y) {  // maze_generator.cpp:34-45
-        grid[idx(x + 1, y + 1)] = 0;
+        L.grid[idx(x + 1, y + 1)] = 0;
         const int cell = y + mh * x;
-        if (!(seen[cell >> 3] & (1 << (cell & 7)))) {
-            open_cells[n_open++] = static_cast<int16_t>(cell);
-            seen[cell >> 3] |= static_cast<uint8_t>(1 << (cell & 7));
+        if (!L.seen[cell]) {
+            L.open_cells[L.n_open++] = static_cast<int16_t>(cell);
+            L.seen[cell] = 1;
         }
     }
-    PG_D void carve(int dim, uint32_t* mt) {
+    PG_D int nth_present(int n) const {
+        int w = 0;
+        for (;; w++) {
+            const int c = __popcll(L.present[w]);
+            if (n < c) break;
+            n -= c;
+        }
+        uint64_t v = L.present[w];
+        for (int k = 0; k < n; k++) v &= v - 1;
+        return w * 64 + __builtin_ctzll(v);
+    }
+    // All lanes call; the draws are wave-uniform, the union-find runs on lane 0.
+    PG_D void carve(int dim, uint32_t* mt, int lane) {
         mw = mh = dim;
         aw = ah = dim + 2;
-        for (int k = 0; k < aw * ah; k++) {
-            grid[k] = 1;
-            open_cells[k] = 0;
+        for (int k = lane; k < aw * ah; k += 64) {
+            L.grid[k] = 1;
+            L.open_cells[k] = 0;
         }
-        grid[idx(1, 1)] = 0;
-        for (int k = 0; k < mw * mh; k++) {
-            parent[k] = static_cast<int16_t>(k);
-            rank[k] = 0;
+        for (int k = lane; k < mw * mh; k += 64) {
+            L.parent[k] = static_cast<int16_t>(k);
+            L.rank[k] = 0;
+            L.seen[k] = 0;
         }
-        for (int k = 0; k < static_cast<int>(sizeof(seen)); k++) seen[k] = 0;
-        n_open = 0;
-        n_segs = 0;
-        for (int a = 1; a < mw; a += 2)
-            for (int b = 0; b < mh; b += 2)
-                if (a > 0 && a < mw - 1) {
-                    segs[n_segs][0] = static_cast<uint8_t>(a - 1);
-                    segs[n_segs][1] = static_cast<uint8_t>(b);
-                    segs[n_segs][2] = static_cast<uint8_t>(a + 1);
-                    segs[n_segs][3] = static_cast<uint8_t>(b);
-                    n_segs++;
-                }
-        for (int a = 0; a < mw; a += 2)
-            for (int b = 1; b < mh; b += 2)
-                if (b > 0 && b < mh - 1) {
-                    segs[n_segs][0] = static_cast<uint8_t>(a);
-                    segs[n_segs][1] = static_cast<uint8_t>(b - 1);
-                    segs[n_segs][2] = static_cast<uint8_t>(a);
-                    segs[n_segs][3] = static_cast<uint8_t>(b + 1);
-                    n_segs++;
-                }
-        while (n_segs > 0) {
-            const int pick = rng_int(mt, 0, n_segs - 1);
-            const int x1 = segs[pick][0], y1 = segs[pick][1], x2 = segs[pick][2], y2 = segs[pick][3];
-            const int r0 = root(y1 + mh * x1);
-            const int r1 = root(y2 + mh * x2);
-            const int mx = (x1 + x2) / 2, my = (y1 + y2) / 2;
-            const int centre = my + mh * mx;
-            if (get(mx + 1, my + 1) == 1 && r0 != r1) {
-                open(x1, y1);
-                open(mx, my);
-                open(x2, y2);
-                if (rank[r0] > rank[r1]) {
-                    parent[r1] = static_cast<int16_t>(r0);
-                    parent[centre] = static_cast<int16_t>(r0);
-                } else {
-                    parent[r0] = static_cast<int16_t>(r1);
-                    parent[centre] = static_cast<int16_t>(r1);
-                    if (rank[r0] == rank[r1]) rank[r1]++;
+        __syncthreads();
+        int n_segs = 0;
+        if (lane == 0) {
+            L.grid[idx(1, 1)] = 0;
+            L.n_open = 0;
+            for (int a = 1; a < mw; a += 2)
+                for (int b = 0; b < mh; b += 2)
+                    if (a > 0 && a < mw - 1) {
+                        L.segs[n_segs][0] = static_cast<uint8_t>(a - 1);
+                        L.segs[n_segs][1] = static_cast<uint8_t>(b);
+                        L.segs[n_segs][2] = static_cast<uint8_t>(a + 1);
+                        L.segs[n_segs][3] = static_cast<uint8_t>(b);
+                        n_segs++;
+                    }
+            for (int a = 0; a < mw; a += 2)
+                for (int b = 1; b < mh; b += 2)
+                    if (b > 0 && b < mh - 1) {
+                        L.segs[n_segs][0] = static_cast<uint8_t>(a);
+                        L.segs[n_segs][1] = static_cast<uint8_t>(b - 1);
+                        L.segs[n_segs][2] = static_cast<uint8_t>(a);
+                        L.segs[n_segs][3] = static_cast<uint8_t>(b + 1);
+                        n_segs++;
+                    }
+            for (int w = 0; w < 5; w++) {
+                const int left = n_segs - 64 * w;
+                L.present[w] = left >= 64 ? ~0ull : (left > 0 ? ((1ull << left) - 1ull) : 0ull);
+            }
+        }
+        n_segs = (dim / 2) * ((dim + 1) / 2) * 2;  // (dim odd) both loops: (dim-1)/2 · (dim+1)/2 walls
+        __syncthreads();
+        for (; n_segs > 0; n_segs--) {
+            const int pick = wave_rng_int(mt, 0, n_segs - 1, lane);
+            if (lane == 0) {
+                const int at = nth_present(pick);
+                L.present[at >> 6] &= ~(1ull << (at & 63));
+                const int x1 = L.segs[at][0], y1 = L.segs[at][1], x2 = L.segs[at][2], y2 = L.segs[at][3];
+                const int r0 = root(y1 + mh * x1);
+                const int r1 = root(y2 + mh * x2);
+                const int mx = (x1 + x2) / 2, my = (y1 + y2) / 2;
+                const int centre = my + mh * mx;
+                if (get(mx + 1, my + 1) == 1 && r0 != r1) {
+                    open(x1, y1);
+                    open(mx, my);
+                    open(x2, y2);
+                    if (L.rank[r0] > L.rank[r1]) {
+                        L.parent[r1] = static_cast<int16_t>(r0);
+                        L.parent[centre] = static_cast<int16_t>(r0);
+                    } else {
+                        L.parent[r0] = static_cast<int16_t>(r1);
+                        L.parent[centre] = static_cast<int16_t>(r1);
+                        if (L.rank[r0] == L.rank[r1]) L.rank[r1]++;
+                    }
                 }
             }
-            for (int k = pick; k < n_segs - 1; k++) {  // walls.erase(walls.begin() + n)
-                segs[k][0] = segs[k + 1][0];
-                segs[k][1] = segs[k + 1][1];
-                segs[k][2] = segs[k + 1][2];
-                segs[k][3] = segs[k + 1][3];
-            }
-            n_segs--;
         }
+        __syncthreads();
     }
     // maze_generator.cpp:183-195; START_CELL = 10 is compared with the cell index (D7).
-    PG_D void drop(int kind, uint32_t* mt) {
-        int k = rng_int(mt, 0, n_open - 1);
-        while (open_cells[k] == -1 || open_cells[k] == 10) k = rng_int(mt, 0, n_open - 1);
-        const int cell = open_cells[k];
-        open_cells[k] = -1;
-        grid[idx(cell / mh + 1, cell % mh + 1)] = static_cast<uint8_t>(kind);
+    PG_D void drop(int kind, uint32_t* mt, int lane) {
+        const int n_open = L.n_open;
+        int k = wave_rng_int(mt, 0, n_open - 1, lane);
+        while (L.open_cells[k] == -1 || L.open_cells[k] == 10) k = wave_rng_int(mt, 0, n_open - 1, lane);
+        __syncthreads();
+        if (lane == 0) {
+            const int cell = L.open_cells[k];
+            L.open_cells[k] = -1;
+            L.grid[idx(cell / mh + 1, cell % mh + 1)] = static_cast<uint8_t>(kind);
+        }
+        __syncthreads();
     }
 };
 
-PG_D void new_level(const State& s, int env) {  // maze.cpp:416-438 + tilemap.cpp:31-109
-    uint32_t* mt = s.mt + size_t(env) * kMtWords;
-    uint8_t* tiles = s.tiles + size_t(env) * kTileStride;
-    for (int k = 0; k < kCells; k++) tiles[k] = kWall;
-    const int dim = rng_int(mt, 0, (W - 1) / 2 - 1) * 2 + 3;
+// reset() (maze.cpp:416-438 + tilemap.cpp:31-109) for one env by one wavefront: advances the env's generator chain
+// (s.mt) and leaves the level in `lv` (LDS).
+PG_D void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, uint32_t seed, int lane) {
+    uint32_t* gmt = s.mt + size_t(env) * kMtWords;
+    if (reseed) {
+        if (lane == 0) mt_seed(L.mt, seed);
+    } else {
+        for (int k = lane; k < kMtWords; k += 64) L.mt[k] = gmt[k];
+    }
+    for (int k = lane; k < kTileStride; k += 64) lv.tiles[k] = kWall;
+    __syncthreads();
+    uint32_t* mt = L.mt;
+    const int dim = wave_rng_int(mt, 0, (W - 1) / 2 - 1, lane) * 2 + 3;
     const int margin = (W - dim) / 2;
-    Carver carver;
-    carver.carve(dim, mt);
-    carver.drop(2, mt);
-    int gx = 0, gy = 0;
-    for (int a = 0; a < dim; a++)
-        for (int b = 0; b < dim; b++) {
-            const int t = carver.get(a + 1, b + 1);
-            tiles[(b + margin) + (a + margin) * H] = (t == 1) ? kWall : kOpen;
-            if (t == 2) {
-                gx = a + margin;
-                gy = b + margin;
-            }
+    Carver carver{L, 0, 0, 0, 0};
+    carver.carve(dim, mt, lane);
+    carver.drop(2, mt, lane);
+    for (int c = lane; c < dim * dim; c += 64) {
+        const int a = c / dim, b = c % dim;
+        const int t = carver.get(a + 1, b + 1);
+        lv.tiles[(b + margin) + (a + margin) * H] = (t == 1) ? kWall : kOpen;
+        if (t == 2) {
+            lv.gx = static_cast<float>(a + margin) + 0.5f;
+            lv.gy = static_cast<float>(H - 1 - (b + margin)) + 0.5f;
         }
-    SF(s, F_GX, env) = static_cast<float>(gx) + 0.5f;
-    SF(s, F_GY, env) = static_cast<float>(H - 1 - gy) + 0.5f;
-    SF(s, F_AX, env) = static_cast<float>(margin) + 0.5f;
-    SF(s, F_AY, env) = static_cast<float>(H - 1 - margin) + 0.5f;
-    SI(s, I_STEPS, env) = 0;
-    SI(s, I_BG, env) = rng_int(mt, 0, 8);
-    SF(s, F_BGSHIFT, env) = rng_real(mt, 0.0f, 1.0f);
-    SI(s, I_FLAGS, env) = kFlagForward;  // face_forward = true; draw list cleared (D2)
+    }
+    const int bg = wave_rng_int(mt, 0, 8, lane);
+    const float shift = wave_rng_real(mt, 0.0f, 1.0f, lane);
+    if (lane == 0) {
+        lv.ax = static_cast<float>(margin) + 0.5f;
+        lv.ay = static_cast<float>(H - 1 - margin) + 0.5f;
+        lv.bg = bg;
+        lv.bgshift = shift;
+    }
+    __syncthreads();
+    for (int k = lane; k < kMtWords; k += 64) gmt[k] = L.mt[k];
+    __syncthreads();
 }
+
+// The level becomes the env's live state.
+PG_D void install(const State& s, int env, const Level& lv, int lane) {
+    uint32_t* tiles = reinterpret_cast<uint32_t*>(s.tiles + size_t(env) * kTileStride);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(lv.tiles);
+    for (int k = lane; k < kTileStride / 4; k += 64) tiles[k] = src[k];
+    if (lane == 0) {
+        SF(s, F_GX, env) = lv.gx;
+        SF(s, F_GY, env) = lv.gy;
+        SF(s, F_AX, env) = lv.ax;
+        SF(s, F_AY, env) = lv.ay;
+        SI(s, I_STEPS, env) = 0;
+        SI(s, I_BG, env) = lv.bg;
+        SF(s, F_BGSHIFT, env) = lv.bgshift;
+        SI(s, I_FLAGS, env) = kFlagForward;  // face_forward = true; draw list cleared (D2)
+    }
+}
+
+struct Gen {  // pg_prefetch.h level_kernel<Gen>
+    using State = maze::State;
+    using Level = maze::Level;
+    using GenLds = maze::GenLds;
+    PG_D static void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, uint32_t seed, int lane) {
+        maze::generate(s, env, L, lv, reseed, seed, lane);
+    }
+    PG_D static void install(const State& s, int env, const Level& lv, int lane) { maze::install(s, env, lv, lane); }
+};
 
 PG_D void advance(const State& s, int env, int action, float& reward_out, bool& terminated_out) {
     const uint8_t* tiles = s.tiles + size_t(env) * kTileStride;
@@ -207,32 +289,11 @@ PG_D void advance(const State& s, int env, int action, float& reward_out, bool& 
     terminated_out = reached || steps >= kTimeout;  // maze.cpp:302-310: the cap sets `terminated` (D5)
 }
 
-__global__ void __launch_bounds__(64) make_kernel(State s, uint32_t seed_base, int env_offset) {
-    const int env = blockIdx.x * 64 + threadIdx.x;
-    if (env >= s.n) return;
-    mt_seed(s.mt + size_t(env) * kMtWords, seed_base + static_cast<uint32_t>(env_offset + env));
-    new_level(s, env);
-}
-
-__global__ void __launch_bounds__(64) reset_kernel(State s, const uint8_t* mask, const int32_t* seeds, StepIO io) {
-    const int env = blockIdx.x * 64 + threadIdx.x;
-    if (env >= s.n) return;
-    if (mask && !mask[env]) return;
-    if (seeds) mt_seed(s.mt + size_t(env) * kMtWords, static_cast<uint32_t>(seeds[env]));
-    new_level(s, env);
-    io.reward[env] = 0.0f;
-    io.done[env] = 0;
-    io.pending[env] = 0;
-}
-
 __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actions, uint32_t run_seed,
                                                    uint32_t step_index, int env_offset, StepIO io) {
     const int env = blockIdx.x * 64 + threadIdx.x;
     if (env >= s.n) return;
-    if (io.pending[env]) {
-        new_level(s, env);
-        io.reward[env] = 0.0f;
-        io.done[env] = 0;
+    if (io.pending[env] == 2) {  // reset by the level kernel in this step
         io.pending[env] = 0;
         return;
     }
@@ -338,7 +399,8 @@ class MazeGame final : public Game {
     }
     static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
     size_t state_bytes(int n) const override {
-        return align256(size_t(n) * kMtWords * 4) + align256(size_t(n) * kTileStride) +
+        return align256(size_t(n) * sizeof(Level)) + align256(size_t(n) * 4) + align256(size_t(n) * kMtWords * 4) +
+               align256(size_t(n) * kTileStride) +
                align256(size_t(F_COUNT) * n * 4) + align256(size_t(I_COUNT) * n * 4);
     }
     void bind(void* d_state, int n, AtlasView atlas) override {
@@ -349,6 +411,8 @@ class MazeGame final : public Game {
             return q;
         };
         s_.n = n;
+        s_.shadow = reinterpret_cast<Level*>(take(size_t(n) * sizeof(Level)));
+        s_.slot = reinterpret_cast<int32_t*>(take(size_t(n) * 4));
         s_.mt = reinterpret_cast<uint32_t*>(take(size_t(n) * kMtWords * 4));
         s_.tiles = take(size_t(n) * kTileStride);
         s_.f = reinterpret_cast<float*>(take(size_t(F_COUNT) * n * 4));
@@ -357,13 +421,20 @@ class MazeGame final : public Game {
     }
     int blocks() const { return (s_.n + 63) / 64; }
     void launch_make(hipStream_t st, uint32_t seed_base, int env_offset) override {
-        hipLaunchKernelGGL(make_kernel, dim3(blocks()), dim3(64), 0, st, s_, seed_base, env_offset);
+        LevelLaunch<Gen>::make(st, s_, prefetch(), seed_base, env_offset);
     }
     void launch_reset(hipStream_t st, const uint8_t* mask, const int32_t* seeds, StepIO io) override {
-        hipLaunchKernelGGL(reset_kernel, dim3(blocks()), dim3(64), 0, st, s_, mask, seeds, io);
+        LevelLaunch<Gen>::reset(st, s_, prefetch(), mask, seeds, io);
     }
+    bool launch_pregen(hipStream_t side, bool bulk) override {
+        if (!prefetch()) return false;
+        LevelLaunch<Gen>::pregen(side, s_, bulk);
+        return true;
+    }
+    int prefetch() const { return (debug_flags & kDebugNoPrefetch) ? 0 : 1; }
     void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
                       StepIO io) override {
+        LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io);
         hipLaunchKernelGGL(logic_kernel, dim3(blocks()), dim3(64), 0, st, s_, actions, run_seed, step_index,
                            env_offset, io);
     }

@@ -20,6 +20,7 @@
 #pragma once
 
 #include "pg_defs.h"
+#include "pg_engine.h"
 
 namespace pg {
 
@@ -43,7 +44,7 @@ PG_D bool slot_cas(int32_t* p, int32_t expect, int32_t want) {
 // slot) or kSlotSync (generate it yourself; the slot is yours).  A kBusy generator is a resident wave that needs
 // nothing from the caller, so waiting for it cannot deadlock; the spin is bounded anyway and falls back to a trap.
 PG_D int32_t slot_acquire_for_install(int32_t* p) {
-    for (long spin = 0; spin < (1L << 34); spin++) {
+    for (long spin = 0; spin < (1L << 22); spin++) {  // ≈ seconds
         const int32_t st = slot_load(p);
         if (st == kSlotReady) return kSlotReady;
         if (st == kSlotQueued || st == kSlotIdle) {
@@ -55,6 +56,124 @@ PG_D int32_t slot_acquire_for_install(int32_t* p) {
     __builtin_trap();
     return kSlotSync;
 }
+
+// The level kernel shared by the prefetching games.  G supplies
+//     State  (members: int n; Level* shadow; int32_t* slot),  Level (POD, size a multiple of 4),  GenLds (scratch),
+//     generate(s, env, L, lv, reseed, seed, lane)  — one wavefront advances env's generator chain, level into lv (LDS)
+//     install(s, env, lv, lane)                     — lv becomes env's live state.
+// A block serves the envs [blockIdx·span, +span) that need a level, one after the other:
+//   mode 0  cenv_make: seed = seed_base + env index, level 0 generated synchronously;
+//   mode 1  explicit reset (mask, optional seeds; a seed restarts the env's generator chain);
+//   mode 2  auto-reset of the envs whose previous step terminated (StepIO::pending 1 → 2 tells the logic kernel);
+//   mode 3  side stream: fill the shadow slots that are kSlotQueued.
+// `prefetch` = whether a served env queues its next level.
+template <class G>
+__global__ void __launch_bounds__(64) level_kernel(typename G::State s, int mode, int span, int prefetch,
+                                                   uint32_t seed_base, int env_offset, const uint8_t* mask,
+                                                   const int32_t* seeds, StepIO io) {
+    using Level = typename G::Level;
+    const int lane = threadIdx.x;
+    const int base = blockIdx.x * span;
+    bool want = false;
+    if (lane < span && base + lane < s.n) {
+        const int e = base + lane;
+        if (mode == 0)
+            want = true;
+        else if (mode == 1)
+            want = !mask || mask[e];
+        else if (mode == 2)
+            want = io.pending[e] == 1;
+        else
+            want = __hip_atomic_load(&s.slot[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kSlotQueued;
+    }
+    unsigned long long todo = __ballot(want);
+    if (!todo) return;
+    __shared__ typename G::GenLds L;
+    __shared__ Level lv;
+    __shared__ int32_t verdict;
+    constexpr int kWords = static_cast<int>(sizeof(Level) / 4);
+    static_assert(sizeof(Level) % 4 == 0, "Level is copied as 32-bit words");
+    while (todo) {
+        const int env = base + __builtin_ctzll(todo);
+        todo &= todo - 1;
+        uint32_t* shadow = reinterpret_cast<uint32_t*>(&s.shadow[env]);
+        uint32_t* local = reinterpret_cast<uint32_t*>(&lv);
+        if (mode == 3) {
+            if (lane == 0) verdict = slot_cas(&s.slot[env], kSlotQueued, kSlotBusy) ? 1 : 0;
+            __syncthreads();
+            const bool mine = verdict != 0;
+            __syncthreads();
+            if (!mine) continue;
+            G::generate(s, env, L, lv, false, 0u, lane);
+            __syncthreads();
+            for (int k = lane; k < kWords; k += 64) shadow[k] = local[k];
+            __threadfence();
+            __syncthreads();
+            if (lane == 0) slot_store(&s.slot[env], kSlotReady);
+            continue;
+        }
+        const bool reseed = mode == 0 || (mode == 1 && seeds != nullptr);
+        if (lane == 0) {
+            if (mode == 0) {
+                verdict = kSlotSync;
+            } else {
+                int32_t got = slot_acquire_for_install(&s.slot[env]);
+                if (got == kSlotReady && reseed) {  // the prepared level belongs to the abandoned chain
+                    slot_store(&s.slot[env], kSlotSync);
+                    got = kSlotSync;
+                }
+                verdict = got;
+            }
+        }
+        __syncthreads();
+        const int32_t how = verdict;
+        __threadfence();
+        if (how == kSlotReady) {
+            for (int k = lane; k < kWords; k += 64) local[k] = shadow[k];
+        } else {
+            const uint32_t seed = mode == 0 ? seed_base + static_cast<uint32_t>(env_offset + env)
+                                            : (seeds ? static_cast<uint32_t>(seeds[env]) : 0u);
+            G::generate(s, env, L, lv, reseed, seed, lane);
+        }
+        __syncthreads();
+        G::install(s, env, lv, lane);
+        __threadfence();
+        __syncthreads();
+        if (lane == 0) {
+            slot_store(&s.slot[env], prefetch ? kSlotQueued : kSlotIdle);
+            if (mode != 0) {
+                io.reward[env] = 0.0f;
+                io.done[env] = 0;
+                io.pending[env] = mode == 2 ? 2 : 0;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Host side of the same: the four launches a prefetching game needs.
+template <class G>
+struct LevelLaunch {
+    static void make(hipStream_t st, const typename G::State& s, int prefetch, uint32_t seed_base, int env_offset) {
+        hipLaunchKernelGGL(level_kernel<G>, dim3(s.n), dim3(64), 0, st, s, 0, 1, prefetch, seed_base, env_offset,
+                           nullptr, nullptr, StepIO{});
+    }
+    static void reset(hipStream_t st, const typename G::State& s, int prefetch, const uint8_t* mask,
+                      const int32_t* seeds, StepIO io) {
+        hipLaunchKernelGGL(level_kernel<G>, dim3(s.n), dim3(64), 0, st, s, 1, 1, prefetch, 0u, 0, mask, seeds, io);
+    }
+    static void auto_reset(hipStream_t st, const typename G::State& s, int prefetch, StepIO io) {
+        hipLaunchKernelGGL(level_kernel<G>, dim3((s.n + 63) / 64), dim3(64), 0, st, s, 2, 64, prefetch, 0u, 0, nullptr,
+                           nullptr, io);
+    }
+    // bulk: most slots are queued (after make / a full reset) → a wavefront per env; otherwise few envs per wave,
+    // because the queued envs of one wave are served one after the other.
+    static void pregen(hipStream_t side, const typename G::State& s, bool bulk) {
+        const int span = bulk ? 1 : 8;
+        hipLaunchKernelGGL(level_kernel<G>, dim3((s.n + span - 1) / span), dim3(64), 0, side, s, 3, span, 1, 0u, 0,
+                           nullptr, nullptr, StepIO{});
+    }
+};
 #endif
 
 }  // namespace pg

@@ -108,6 +108,38 @@ __device__ inline void mt_twist_wave(uint32_t* x, int lane) {
     __syncthreads();
 }
 
+// Wave-uniform draws from a stream held in LDS: every lane calls them together and gets the same value; the
+// regeneration of the 624 words, when due, is done by all lanes (mt_twist_wave) instead of by one.
+__device__ inline uint32_t wave_mt_next(uint32_t* x, int lane) {
+    int idx = static_cast<int>(x[kMtN]);
+    if (idx >= kMtN) {
+        __syncthreads();
+        mt_twist_wave(x, lane);
+        idx = 0;
+    }
+    const uint32_t y = x[idx];
+    __syncthreads();  // everyone has read the index
+    if (lane == 0) x[kMtN] = static_cast<uint32_t>(idx + 1);
+    __syncthreads();
+    return mt_temper(y);
+}
+__device__ inline int wave_rng_int(uint32_t* x, int lo, int hi, int lane) {  // = rng_int
+    const uint32_t range = static_cast<uint32_t>(hi) - static_cast<uint32_t>(lo) + 1u;
+    uint64_t product = static_cast<uint64_t>(wave_mt_next(x, lane)) * range;
+    uint32_t low = static_cast<uint32_t>(product);
+    if (low < range) {
+        const uint32_t threshold = (0u - range) % range;
+        while (low < threshold) {
+            product = static_cast<uint64_t>(wave_mt_next(x, lane)) * range;
+            low = static_cast<uint32_t>(product);
+        }
+    }
+    return lo + static_cast<int>(product >> 32);
+}
+__device__ inline float wave_rng_real(uint32_t* x, float a, float b, int lane) {  // = rng_real
+    return canonical_of(wave_mt_next(x, lane)) * (b - a) + a;
+}
+
 // `count` consecutive draws of uniform_real_distribution<float>(0,1)(rng) < 0.5f by one wavefront: out[k] = 1 when
 // the k-th draw is below one half.  Leaves the stream where `count` calls of rng_real would.
 __device__ inline void wave_coin_flips(uint32_t* x, uint8_t* out, int count, int lane) {
