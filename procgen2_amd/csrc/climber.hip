@@ -430,19 +430,22 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
     const int4 top_d = descs.uniform(kTexTop + theme), mid_d = descs.uniform(kTexMid + theme);
 
     bool composed = false;
-    // The row composer needs one tile size for the whole layer; the brown theme's top tile is 64×53
-    // (assets/platformer/tileBrown_06.png), so that theme takes the draw-list replay.
-    if (!(flags & 1) && cols <= kGrid && rows <= kGrid && top_d.y == mid_d.y && top_d.z == mid_d.z) {
-        compose_spans(L, cam, x0, y0, cols, rows, mid_d.y, mid_d.z, kUnitPx / mid_d.y, lane);
+    // The brown theme's cap tile is 64×53 next to 64×64 bodies (assets/platformer/tileBrown_06.png): the composer's
+    // two-texture mode; a cap taller than the body, or of another width, would take the draw-list replay.
+    const bool two = top_d.z != mid_d.z;
+    if (!(flags & 1) && cols <= kGrid && rows <= kGrid && top_d.y == mid_d.y && top_d.z <= mid_d.z) {
+        compose_spans(L, cam, x0, y0, cols, rows, mid_d.y, mid_d.z, kUnitPx / mid_d.y, lane, two ? top_d.z : 0);
 #pragma unroll
         for (int k = 0; k < kGrid * kGrid / 64; k++) {
             const int cell = k * 64 + lane;
             const int r = cell / kGrid, c = cell % kGrid;
             const int t = (c < cols && r < rows) ? Win::direct(tiles, x0 + c, y0 + r) : kEmpty;
-            L.base[cell] = (t == kEmpty) ? static_cast<int32_t>(kNoTexel) : (t == kWallTop ? top_d.x : mid_d.x) * 4;
+            L.base[cell] = (t == kEmpty) ? static_cast<int32_t>(kNoTexel)
+                                         : (t == kWallTop ? (top_d.x * 4) | (two ? 1 : 0) : mid_d.x * 4);
         }
         __syncthreads();
-        composed = compose_rows(fb, L, atlas, bg, has_bg, cols, rows, mid_d.y, lane, flags);
+        composed = two ? compose_rows<kGrid, true>(fb, L, atlas, bg, has_bg, cols, rows, mid_d.y, lane, flags)
+                       : compose_rows<kGrid, false>(fb, L, atlas, bg, has_bg, cols, rows, mid_d.y, lane, flags);
     }
     if (!composed) {  // draw-list replay (tilemap.cpp:172-198)
         wave_clear(fb, lane);

@@ -35,6 +35,7 @@ template <int GRID>
 struct ComposeLds {
     int4 col[GRID];             // per grid column: {d0, dn, s0, sn}; sn == 0 ⇒ nothing drawn
     int4 row[GRID];             // per grid row
+    int4 row2[GRID];            // per grid row for the layer's second, shorter tile texture (sn == 0 ⇒ none)
     int32_t base[GRID * GRID];  // [row][col] byte offset of the cell's tile texture in the atlas, kNoTexel = no tile
     int32_t cover_n[2][64];     // [axis][pixel] how many grid columns (axis 0) / rows (axis 1) cover the pixel
     int32_t cover[2][64][2];    // the first two of them: grid index | texel coordinate << 8
@@ -281,9 +282,12 @@ PG_D void wave_clear(uint32_t* fb, int lane) {
 // y0+c), then — after a barrier — every (span, offset) pair scatters itself to the pixel it covers, so each pixel
 // column / row learns which grid columns / rows cover it and at which texel coordinate, without a search loop.
 // Leaves a __syncthreads() to the caller (the staging of L.base provides it) before compose_rows.
+// th2 > 0: some cells of the layer use a second texture of the same width but height th2 < th (climber's 64×53
+// cap tile next to 64×64 bodies).  Its rows start where the tall ones start and end earlier, so the covering grid
+// rows of a pixel stay the tall texture's; only the texel row differs per cell (compose_rows<GRID, true>).
 template <int GRID, int MAXSPAN = kMaxSpan>
 PG_D void compose_spans(ComposeLds<GRID>& L, const Camera& cam, int x0, int y0, int cols, int rows, int tw, int th,
-                        float tile_scale, int lane) {
+                        float tile_scale, int lane, int th2 = 0) {
     L.cover_n[0][lane] = 0;
     L.cover_n[1][lane] = 0;
     if (lane == 0) L.too_wide = 0;
@@ -299,6 +303,13 @@ PG_D void compose_spans(ComposeLds<GRID>& L, const Camera& cam, int x0, int y0, 
         const bool ok = resolve_axis(cam.py, cam.sh, cam.scale, th, (y0 + lane) * kUnitPx, tile_scale, false, true, sp);
         L.row[lane] = ok ? make_int4(sp.d0, sp.dn, sp.s0, sp.sn) : make_int4(0, 0, 0, 0);
         wide = wide || (ok && sp.dn > MAXSPAN);
+        if (th2 > 0) {
+            Span s2;
+            const bool ok2 =
+                resolve_axis(cam.py, cam.sh, cam.scale, th2, (y0 + lane) * kUnitPx, tile_scale, false, true, s2);
+            L.row2[lane] = ok2 ? make_int4(s2.d0, s2.dn, s2.s0, s2.sn) : make_int4(0, 0, 0, 0);
+            wide = wide || (ok2 && (!ok || s2.d0 != sp.d0 || s2.dn > sp.dn));  // not nested: take the fallback
+        }
     }
     __syncthreads();
     if (__ballot(wide)) {
@@ -350,7 +361,9 @@ constexpr uint32_t kNoTexel = 0x40000000u;
 //   (wave-uniform).
 // Writes every pixel of fb (black where nothing is drawn).  Returns false — having written nothing — when the
 // layer does not fit the two-candidate scheme (caller falls back to wave_replay).
-template <int GRID>
+// TWO: cells whose L.base has bit 0 set use the second tile texture (compose_spans th2); their texel row comes from
+// L.row2 and is chosen per lane, at the price of a select and an add in front of every tile load.
+template <int GRID, bool TWO = false>
 PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView& atlas, const Blit& bg, bool has_bg,
                        int cols, int rows, int tw, int lane, int ablate = 0) {
 
@@ -392,6 +405,27 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
     const uint32_t row_a = ra >= 0 ? static_cast<uint32_t>(va * tw) * 4u : kNoTexel;
     const uint32_t row_b = rb >= 0 ? static_cast<uint32_t>(vb * tw) * 4u : kNoTexel;
     const int ria = (ra >= 0 ? ra : 0) * GRID, rib = (rb >= 0 ? rb : 0) * GRID;
+    uint32_t row_a2 = kNoTexel, row_b2 = kNoTexel;  // lane = pixel row: texel rows of the second texture
+    if (TWO) {
+        if (ra >= 0) {
+            const int4 sp = L.row2[ra];
+            const int i = lane - sp.x;
+            if (sp.w > 0 && i >= 0 && i < sp.y) row_a2 = static_cast<uint32_t>(sample_index(sp.z, sp.w, i, sp.y) * tw) * 4u;
+        }
+        if (rb >= 0) {
+            const int4 sp = L.row2[rb];
+            const int i = lane - sp.x;
+            if (sp.w > 0 && i >= 0 && i < sp.y) row_b2 = static_cast<uint32_t>(sample_index(sp.z, sp.w, i, sp.y) * tw) * 4u;
+        }
+    }
+    // one tile texel: cell base (bit 0 = second texture) + column offset + the row offset of the cell's texture
+    auto tile_texel = [&](uint32_t base, uint32_t col, uint32_t row_first, uint32_t row_second) {
+        if (TWO) {
+            const uint32_t row = (base & 1u) ? row_second : row_first;
+            return __builtin_amdgcn_raw_buffer_load_b32(atlas_rsrc, (base & ~3u) + col + row, 0, 0);
+        }
+        return __builtin_amdgcn_raw_buffer_load_b32(atlas_rsrc, base + col, row_first, 0);
+    };
     const unsigned long long second_row = __ballot(rb >= 0);  // bit py: pixel row py is covered by two grid rows
 
     // Rows in batches: every texel gather of a batch is issued before any blend, so a batch costs one memory
@@ -413,13 +447,15 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
             const uint32_t s_a = __builtin_amdgcn_readlane(row_a, py);
             const int l_a = __builtin_amdgcn_readlane(ria, py);
             t[k][0] = __builtin_amdgcn_raw_buffer_load_b32(bg_rsrc, bg_col, s_bg, 0);
-            t[k][1] = __builtin_amdgcn_raw_buffer_load_b32(atlas_rsrc, static_cast<uint32_t>(L.base[l_a + cia]) + col_a, s_a, 0);
-            t[k][2] = __builtin_amdgcn_raw_buffer_load_b32(atlas_rsrc, static_cast<uint32_t>(L.base[l_a + cib]) + col_b, s_a, 0);
+            const uint32_t s_a2 = TWO ? __builtin_amdgcn_readlane(row_a2, py) : 0u;
+            t[k][1] = tile_texel(static_cast<uint32_t>(L.base[l_a + cia]), col_a, s_a, s_a2);
+            t[k][2] = tile_texel(static_cast<uint32_t>(L.base[l_a + cib]), col_b, s_a, s_a2);
             if ((second_row >> py) & 1ull) {
                 const uint32_t s_b = __builtin_amdgcn_readlane(row_b, py);
                 const int l_b = __builtin_amdgcn_readlane(rib, py);
-                t[k][3] = __builtin_amdgcn_raw_buffer_load_b32(atlas_rsrc, static_cast<uint32_t>(L.base[l_b + cia]) + col_a, s_b, 0);
-                t[k][4] = __builtin_amdgcn_raw_buffer_load_b32(atlas_rsrc, static_cast<uint32_t>(L.base[l_b + cib]) + col_b, s_b, 0);
+                const uint32_t s_b2 = TWO ? __builtin_amdgcn_readlane(row_b2, py) : 0u;
+                t[k][3] = tile_texel(static_cast<uint32_t>(L.base[l_b + cia]), col_a, s_b, s_b2);
+                t[k][4] = tile_texel(static_cast<uint32_t>(L.base[l_b + cib]), col_b, s_b, s_b2);
             } else {
                 t[k][3] = t[k][4] = 0u;
             }
