@@ -32,6 +32,8 @@ void* pgo_make(const char* game, uint32_t seed, int render_enabled) {
         e = pgo::new_climber();
     else if (g == "caveflyer")
         e = pgo::new_caveflyer();
+    else if (g == "chaser")
+        e = pgo::new_chaser();
     if (!e) return nullptr;
     e->set_render_enabled(render_enabled != 0);
     e->make(seed);

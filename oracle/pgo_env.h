@@ -75,5 +75,6 @@ Env* new_maze();
 Env* new_bossfight();
 Env* new_climber();
 Env* new_caveflyer();
+Env* new_chaser();
 
 }  // namespace pgo

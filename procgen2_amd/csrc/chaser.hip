@@ -1,0 +1,799 @@
+// chaser on gfx950: pac-man-like on an 11×11 maze, three egg-born enemies, orbs and points.
+//
+// Reference:
+//   step   games/chaser/chaser.cpp:282-334, common_systems.cpp:305-444 (agent), :117-295 (enemies), :66-106 (points),
+//          :8-39 (sprite list)
+//   render games/chaser/chaser.cpp:390-416, tilemap.cpp:245-267, common_systems.cpp:41-63, :446-460
+//   reset  games/chaser/chaser.cpp:418-443, tilemap.cpp:80-243, maze_generator.cpp:47-130
+// Config = the reference's compile-time default, easy_mode (11×11, 3 enemies; chaser/tilemap.h:39-41).
+//
+// Quirk kept on purpose (D21, oracle/pgo_chaser.cpp): the reference's `abs(<float>)` calls in common_systems.cpp
+// compile to glibc's `int abs(int)` — the argument is truncated first — so the "close to the cell centre" tests always
+// pass and the chase heuristic compares sums of truncated integers.  iabs() below is that.
+//
+// Machine mapping: logic one lane per env (SoA across envs) — the enemies draw from the env's mt19937 inside the step,
+// in the iteration order of the enemy System's std::unordered_set; render one wavefront per env; level generation one
+// wavefront per env.  Because of the in-step draws the next level cannot be generated ahead of time (pg_prefetch.h
+// is used with prefetch off: every reset carves its maze inside the step).
+#include "pg_engine.h"
+#include "pg_geom.h"
+#include "pg_kruskal.h"
+#include "pg_order.h"
+#include "pg_prefetch.h"
+#include "pg_render.h"
+#include "pg_rng.h"
+
+namespace pg {
+namespace chaser {
+
+constexpr int W = 11, H = 11, kCells = W * H, kTileStride = 128;
+constexpr int kMobs = 3, kOrbs = 4, kFirstPoint = kOrbs + kMobs;
+constexpr int kMaxEnt = 72;  // 4 orbs + 3 eggs + ≤ 63 points (71 open cells − 4 − 1 − 3)
+enum Tile : uint8_t { kEmpty = 0, kWall = 1, kMarker = 2 };
+enum Kind { kOrb = 0, kPoint = 1, kEgg = 2 };
+
+enum Tex {
+    kTexWall = 0,
+    kTexOrb = 1,
+    kTexPoint = 2,
+    kTexEnemy = 3,  // egg, flying 1-3, walking
+    kTexAgent = 8,
+    kTexFloor = 9,  // 9
+    kTexCount = 18
+};
+
+enum { F_AX, F_AY, F_AVX, F_AVY, F_NVX, F_NVY, F_INPUT_T, F_ANIM_T, F_EAT_T, F_BGSHIFT, F_COUNT };
+enum { I_FLAGS, I_ANIM_I, I_BG, I_NENT, I_NDRAW, I_HASH_SPRITE, I_HASH_MOB, I_COUNT };
+constexpr int kFlagListed = 1;
+enum { MF_X, MF_Y, MF_VX, MF_VY, MF_HATCH, MF_COUNT };
+enum { EB_INFO, EB_CELL, EB_ORDER, EB_DRAW, EB_COUNT };
+constexpr int kKindMask = 3, kAlive = 4;
+
+// One generated level (LDS → live state; the shadow slots stay unused in this game).
+struct Level {
+    uint8_t tiles[kTileStride];
+    float ax, ay, bgshift;
+    int32_t bg, n_ent;
+    uint8_t cell[kMaxEnt], order[kMaxEnt];
+    uint8_t mob_order[4];
+};
+
+struct GenLds {
+    uint32_t mt[kMtWords];
+    KruskalLds k;
+    int16_t next[128];
+    int16_t before[128];
+    uint8_t free_cells[kCells + 7];
+};
+
+struct State {
+    int n;
+    Level* shadow;   // [n]  (pg_prefetch.h interface; never filled)
+    int32_t* slot;   // [n]
+    uint32_t* mt;    // [n][625]
+    uint8_t* tiles;  // [n][128]  column-major y + x*H
+    float* f;        // [F_COUNT][n]
+    int32_t* i;      // [I_COUNT][n]
+    float* mf;       // [MF_COUNT][kMobs][n]
+    uint8_t* mb;     // [2][kMobs][n]   texture index (0 egg, 1-3 flying, 4 walking), iteration order of the enemy set
+    uint8_t* eb;     // [EB_COUNT][kMaxEnt][n]
+};
+
+PG_D float& SF(const State& s, int field, int env) { return s.f[size_t(field) * s.n + env]; }
+PG_D int32_t& SI(const State& s, int field, int env) { return s.i[size_t(field) * s.n + env]; }
+PG_D float& MF(const State& s, int field, int m, int env) { return s.mf[(size_t(field) * kMobs + m) * s.n + env]; }
+PG_D uint8_t& MB(const State& s, int field, int m, int env) { return s.mb[(size_t(field) * kMobs + m) * s.n + env]; }
+PG_D uint8_t& EB(const State& s, int field, int e, int env) { return s.eb[(size_t(field) * kMaxEnt + e) * s.n + env]; }
+
+PG_D int tile_at(const uint8_t* t, int x, int y) {  // tilemap.h:79-84: out of bounds is neither empty nor wall
+    if (x < 0 || y < 0 || x >= W || y >= H) return -1;
+    return t[y + x * H];
+}
+PG_D int iabs(float v) {  // D21
+    const int t = static_cast<int>(v);
+    return t < 0 ? -t : t;
+}
+PG_D int sign_of(float x) { return x == 0.0f ? 0 : (x > 0.0f) * 2 - 1; }  // helpers.h:31-36
+
+// Iteration order of a std::unordered_set<int> that kept its bucket array across clear() after inserting keys[0..n)
+// (packed = buckets | next_resize << 16; a fresh set is packed = 1).
+PG_D void set_order(int32_t& packed, const uint8_t* keys, int n, uint8_t* out, int16_t* next, int16_t* before) {
+    HashOrder h;
+    h.next = next;
+    h.before = before;
+    h.head = kNil;
+    h.buckets = packed & 0xffff;
+    h.next_resize = packed >> 16;
+    h.count = 0;
+    for (int b = 0; b < h.buckets; b++) before[b] = kNil;
+    for (int k = 0; k < n; k++) hash_insert(h, keys[k]);
+    int16_t p = static_cast<int16_t>(h.head);
+    for (int k = 0; k < n; k++) {
+        out[k] = static_cast<uint8_t>(p);
+        p = next[p];
+    }
+    packed = h.buckets | (h.next_resize << 16);
+}
+
+// reset() (chaser.cpp:418-443 + tilemap.cpp:80-243) for one env by one wavefront; the level is left in `lv` (LDS).
+PG_D void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, uint32_t seed, int lane) {
+    uint32_t* gmt = s.mt + size_t(env) * kMtWords;
+    if (reseed) {
+        if (lane == 0) mt_seed(L.mt, seed);
+    } else {
+        for (int k = lane; k < kMtWords; k += 64) L.mt[k] = gmt[k];
+    }
+    __syncthreads();
+    uint32_t* mt = L.mt;
+    Carver carver{L.k, 0, 0, 0, 0};
+    carver.carve(W, mt, lane);
+    wave_rng_int(mt, 0, 3, lane);  // extra_quad: drawn, without effect in easy mode (extra_orb_sign = 0)
+    for (int c = lane; c < kTileStride; c += 64) {
+        const int x = c / H, y = c % H;
+        lv.tiles[c] = (c < kCells && carver.get(x + 1, y + 1) == 0) ? kEmpty : kWall;
+    }
+    __syncthreads();
+    // one orb per quadrant (tilemap.cpp:121-170): the drawn-th open cell of the quadrant in x-major order
+    for (int q = 0; q < 4; q++) {
+        int count = 0;
+        for (int c = 0; c < kCells; c++) {
+            const int x = c / H, y = c % H;
+            if (lv.tiles[c] != kWall && ((x >= W / 2) * 2 + (y >= H / 2)) == q) count++;  // markers were open cells
+        }
+        const int pos = wave_rng_int(mt, 0, count - 1, lane);
+        if (lane == 0) {
+            int seen = 0;
+            for (int c = 0; c < kCells; c++) {
+                const int x = c / H, y = c % H;
+                if (lv.tiles[c] != kWall && ((x >= W / 2) * 2 + (y >= H / 2)) == q) {
+                    if (seen == pos) {
+                        lv.cell[q] = static_cast<uint8_t>(c);
+                        lv.tiles[c] = kMarker;
+                        break;
+                    }
+                    seen++;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // the agent's cell and the three eggs (tilemap.cpp:172-213): four distinct free cells, taken from a
+    // std::unordered_set<int> in ITS iteration order — first the agent, then the eggs
+    int n_free = 0;
+    for (int c = 0; c < kCells; c++)
+        if (lv.tiles[c] == kEmpty) {
+            if (lane == 0) L.free_cells[n_free] = static_cast<uint8_t>(c);
+            n_free++;
+        }
+    __syncthreads();
+    uint8_t picked[4];
+    for (int j = 0; j < kMobs + 1; j++) {
+        int pos = wave_rng_int(mt, 0, n_free - 1, lane);
+        for (bool again = true; again;) {
+            again = false;
+            for (int k = 0; k < j; k++)
+                if (picked[k] == pos) {
+                    pos = (pos + 1) % n_free;
+                    again = true;
+                    break;
+                }
+        }
+        picked[j] = static_cast<uint8_t>(pos);
+    }
+    if (lane == 0) {
+        uint8_t order[4];
+        int32_t fresh = 1;
+        set_order(fresh, picked, kMobs + 1, order, L.next, L.before);
+        const int start = L.free_cells[order[0]];
+        lv.tiles[start] = kMarker;
+        lv.ax = static_cast<float>(start / H) + 0.5f;
+        lv.ay = static_cast<float>(H - 1 - start % H) + 0.5f;
+        for (int m = 0; m < kMobs; m++) {
+            const int cell = L.free_cells[order[1 + m]];
+            lv.cell[kOrbs + m] = static_cast<uint8_t>(cell);
+            lv.tiles[cell] = kMarker;
+        }
+        int n_ent = kFirstPoint;  // a point on every cell still free (tilemap.cpp:215-225)
+        for (int c = 0; c < kCells; c++)
+            if (lv.tiles[c] == kEmpty) lv.cell[n_ent++] = static_cast<uint8_t>(c);
+        lv.n_ent = n_ent;
+        for (int c = 0; c < kCells; c++)
+            if (lv.tiles[c] == kMarker) lv.tiles[c] = kEmpty;
+    }
+    __syncthreads();
+    const int bg = wave_rng_int(mt, 0, 8, lane);
+    const float shift = wave_rng_real(mt, 0.0f, 1.0f, lane);
+    if (lane == 0) {
+        lv.bg = bg;
+        lv.bgshift = shift;
+        // entity-set orders of the episode: sprites = every non-agent entity, enemies = the eggs
+        uint8_t keys[kMaxEnt];
+        const int n_ent = lv.n_ent;
+        for (int k = 0; k < n_ent; k++) keys[k] = static_cast<uint8_t>(k);
+        int32_t packed = SI(s, I_HASH_SPRITE, env);
+        set_order(packed, keys, n_ent, lv.order, L.next, L.before);
+        SI(s, I_HASH_SPRITE, env) = packed;
+        packed = SI(s, I_HASH_MOB, env);
+        set_order(packed, keys + kOrbs, kMobs, lv.mob_order, L.next, L.before);
+        SI(s, I_HASH_MOB, env) = packed;
+    }
+    __syncthreads();
+    for (int k = lane; k < kMtWords; k += 64) gmt[k] = L.mt[k];
+    __syncthreads();
+}
+
+PG_D float cell_x(int cell) { return static_cast<float>(cell / H) + 0.5f; }
+PG_D float cell_y(int cell) { return static_cast<float>(H - 1 - cell % H) + 0.5f; }
+
+// The level becomes the env's live state (what reset() and the component constructors initialise).
+PG_D void install(const State& s, int env, const Level& lv, int lane) {
+    uint32_t* tiles = reinterpret_cast<uint32_t*>(s.tiles + size_t(env) * kTileStride);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(lv.tiles);
+    if (lane < kTileStride / 4) tiles[lane] = src[lane];
+    const int n_ent = lv.n_ent;
+    for (int e = lane; e < n_ent; e += 64) {
+        const int kind = e < kOrbs ? kOrb : (e < kFirstPoint ? kEgg : kPoint);
+        EB(s, EB_INFO, e, env) = static_cast<uint8_t>(kind | kAlive);
+        EB(s, EB_CELL, e, env) = lv.cell[e];
+        EB(s, EB_ORDER, e, env) = lv.order[e];
+    }
+    if (lane < kMobs) {
+        const int cell = lv.cell[kOrbs + lane];
+        MF(s, MF_X, lane, env) = cell_x(cell);
+        MF(s, MF_Y, lane, env) = cell_y(cell);
+        MF(s, MF_VX, lane, env) = 0.0f;
+        MF(s, MF_VY, lane, env) = 0.0f;
+        MF(s, MF_HATCH, lane, env) = 0.0f;
+        MB(s, 0, lane, env) = 0;
+        MB(s, 1, lane, env) = lv.mob_order[lane];
+    }
+    if (lane == 0) {
+        SF(s, F_AX, env) = lv.ax;
+        SF(s, F_AY, env) = lv.ay;
+        SF(s, F_AVX, env) = 0.0f;
+        SF(s, F_AVY, env) = 0.0f;
+        SF(s, F_NVX, env) = 0.0f;
+        SF(s, F_NVY, env) = 0.0f;
+        SF(s, F_INPUT_T, env) = 0.0f;
+        SF(s, F_ANIM_T, env) = 0.0f;
+        SF(s, F_EAT_T, env) = 0.0f;
+        SF(s, F_BGSHIFT, env) = lv.bgshift;
+        SI(s, I_FLAGS, env) = 0;  // draw list cleared
+        SI(s, I_ANIM_I, env) = 0;
+        SI(s, I_BG, env) = lv.bg;
+        SI(s, I_NENT, env) = n_ent;
+        SI(s, I_NDRAW, env) = 0;
+    }
+}
+
+struct Gen {  // pg_prefetch.h level_kernel<Gen>
+    using State = chaser::State;
+    using Level = chaser::Level;
+    using GenLds = chaser::GenLds;
+    PG_D static void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, uint32_t seed, int lane) {
+        chaser::generate(s, env, L, lv, reseed, seed, lane);
+    }
+    PG_D static void install(const State& s, int env, const Level& lv, int lane) { chaser::install(s, env, lv, lane); }
+};
+
+// System_Sprite_Render::update's list: the surviving sprites in set order, then std::sort on z (all 0.0).
+PG_D void rebuild_draw_list(const State& s, int env, int n_ent) {
+    ZItem items[kMaxEnt];
+    int n = 0;
+    for (int k = 0; k < n_ent; k++) {
+        const int e = EB(s, EB_ORDER, k, env);
+        if (EB(s, EB_INFO, e, env) & kAlive) items[n++] = {0.0f, e};
+    }
+    sort_by_key(items, n);
+    for (int k = 0; k < n; k++) EB(s, EB_DRAW, k, env) = static_cast<uint8_t>(items[k].id);
+    SI(s, I_NDRAW, env) = n;
+}
+
+PG_D void advance(const State& s, int env, int action, float& reward_out, bool& terminated_out) {
+    const uint8_t* tiles = s.tiles + size_t(env) * kTileStride;
+    uint32_t* mt = s.mt + size_t(env) * kMtWords;
+    const int n_ent = SI(s, I_NENT, env);
+    float ax = SF(s, F_AX, env), ay = SF(s, F_AY, env), avx = SF(s, F_AVX, env), avy = SF(s, F_AVY, env);
+    float nvx = SF(s, F_NVX, env), nvy = SF(s, F_NVY, env);
+    float input_t = SF(s, F_INPUT_T, env), anim_t = SF(s, F_ANIM_T, env), eat_t = SF(s, F_EAT_T, env);
+    int anim_i = SI(s, I_ANIM_I, env);
+    bool set_changed = (SI(s, I_FLAGS, env) & kFlagListed) == 0;
+    const float dt = 1.0f / 4;
+
+    float movement_x = static_cast<float>((action == 7) - (action == 1));
+    float movement_y = static_cast<float>((action == 3) - (action == 5));
+    if (movement_x != 0.0f && movement_y != 0.0f) movement_y = 0.0f;
+
+    float reward = 0.0f;
+    bool terminated = false;
+    for (int ss = 0; ss < 4; ss++) {
+        {  // --- System_Agent::update (common_systems.cpp:305-444)
+            const float speed = 0.2f;
+            const float input_reset_time = 1.0f / speed * 0.5f;
+            if (movement_x != 0.0f || movement_y != 0.0f) {
+                nvx = movement_x;
+                nvy = movement_y;
+                input_t = 0.0f;
+            }
+            if (nvx > 0.0f) {
+                if (iabs(ay - (static_cast<int>(ay) + 0.5f)) <= speed * dt &&
+                    tile_at(tiles, static_cast<int>(ax) + 1, H - 1 - static_cast<int>(ay)) == kEmpty) {
+                    ay = static_cast<int>(ay) + 0.5f;
+                    avx = nvx;
+                    avy = nvy;
+                }
+            } else if (nvx < 0.0f) {
+                if (iabs(ay - (static_cast<int>(ay) + 0.5f)) <= speed * dt &&
+                    tile_at(tiles, static_cast<int>(ax) - 1, H - 1 - static_cast<int>(ay)) == kEmpty) {
+                    ay = static_cast<int>(ay) + 0.5f;
+                    avx = nvx;
+                    avy = nvy;
+                }
+            }
+            if (nvy > 0.0f) {
+                if (iabs(ax - (static_cast<int>(ax) + 0.5f)) <= speed * dt &&
+                    tile_at(tiles, static_cast<int>(ax), H - 1 - (static_cast<int>(ay) + 1)) == kEmpty) {
+                    ax = static_cast<int>(ax) + 0.5f;
+                    avx = nvx;
+                    avy = nvy;
+                }
+            } else if (nvy < 0.0f) {
+                if (iabs(ax - (static_cast<int>(ax) + 0.5f)) <= speed * dt &&
+                    tile_at(tiles, static_cast<int>(ax), H - 1 - (static_cast<int>(ay) - 1)) == kEmpty) {
+                    ax = static_cast<int>(ax) + 0.5f;
+                    avx = nvx;
+                    avy = nvy;
+                }
+            }
+            if (avx < 0.0f) {
+                if (iabs(ax - (static_cast<int>(ax) + 0.5f)) <= speed * dt &&
+                    tile_at(tiles, static_cast<int>(ax) - 1, H - 1 - static_cast<int>(ay)) != kEmpty) {
+                    ax = static_cast<int>(ax) + 0.5f;
+                    avx = 0.0f;
+                }
+            } else if (avx > 0.0f) {
+                if (iabs(ax - (static_cast<int>(ax) + 0.5f)) <= speed * dt &&
+                    tile_at(tiles, static_cast<int>(ax) + 1, H - 1 - static_cast<int>(ay)) != kEmpty) {
+                    ax = static_cast<int>(ax) + 0.5f;
+                    avx = 0.0f;
+                }
+            }
+            if (avy < 0.0f) {
+                if (iabs(ay - (static_cast<int>(ay) + 0.5f)) <= speed * dt &&
+                    tile_at(tiles, static_cast<int>(ax), H - 1 - (static_cast<int>(ay) - 1)) != kEmpty) {
+                    ay = static_cast<int>(ay) + 0.5f;
+                    avy = 0.0f;
+                }
+            } else if (avy > 0.0f) {
+                if (iabs(ay - (static_cast<int>(ay) + 0.5f)) <= speed * dt &&
+                    tile_at(tiles, static_cast<int>(ax), H - 1 - (static_cast<int>(ay) + 1)) != kEmpty) {
+                    ay = static_cast<int>(ay) + 0.5f;
+                    avy = 0.0f;
+                }
+            }
+            ax += avx * speed * dt;
+            ay += avy * speed * dt;
+            if (input_t >= input_reset_time) {
+                nvx = 0.0f;
+                nvy = 0.0f;
+            } else {
+                input_t += dt;
+            }
+        }
+        const Box agent_rect{-0.5f + ax, -0.5f + ay, 1.0f, 1.0f};
+
+        // --- System_Mob_AI::update (common_systems.cpp:117-295), enemies in the set's iteration order
+        bool player_hit = false;
+        {
+            const float hatch_time = 50.0f, anim_time = 1.0f, speed_low = 0.125f, speed_high = 0.25f;
+            for (int q = 0; q < kMobs; q++) {
+                const int m = MB(s, 1, q, env) - kOrbs;
+                float hatch = MF(s, MF_HATCH, m, env);
+                if (hatch >= hatch_time) {
+                    float px = MF(s, MF_X, m, env), py = MF(s, MF_Y, m, env);
+                    float vx = MF(s, MF_VX, m, env), vy = MF(s, MF_VY, m, env);
+                    float speed;
+                    int tex;
+                    if (eat_t == 0.0f) {
+                        tex = anim_i < 3 ? 1 + anim_i : 1 + (5 - anim_i);
+                        speed = speed_high;
+                    } else {
+                        tex = 4;
+                        speed = speed_low;
+                    }
+                    const int fx = iabs(px - (static_cast<int>(px) + 0.5f)), fy = iabs(py - (static_cast<int>(py) + 0.5f));
+                    const bool at_junction = static_cast<float>(fx > fy ? fx : fy) < speed * dt;
+                    if ((vx == 0.0f && vy == 0.0f) || at_junction) {
+                        bool possible[4];
+                        int n_possible = 0;
+#pragma unroll
+                        for (int k = 0; k < 2; k++) {
+                            const int dx = 2 * k - 1;
+                            const int id = tile_at(tiles, static_cast<int>(px) + dx, H - 1 - static_cast<int>(py));
+                            possible[k] = (id == kEmpty && dx != -sign_of(vx));
+                            n_possible += possible[k] ? 1 : 0;
+                        }
+#pragma unroll
+                        for (int k = 0; k < 2; k++) {
+                            const int dy = 2 * k - 1;
+                            const int id = tile_at(tiles, static_cast<int>(px), H - 1 - (static_cast<int>(py) + dy));
+                            possible[2 + k] = (id == kEmpty && dy != -sign_of(vy));
+                            n_possible += possible[2 + k] ? 1 : 0;
+                        }
+                        const bool be_aggressive = rng_real(mt, 0.0f, 1.0f) < 0.5f;
+                        int select = 0;
+                        if (be_aggressive) {
+                            float min_dist = 999999.0f;
+#pragma unroll
+                            for (int k = 0; k < 4; k++)
+                                if (possible[k]) {
+                                    const float dir_x = k == 0 ? -1.0f : (k == 1 ? 1.0f : 0.0f);
+                                    const float dir_y = k == 2 ? -1.0f : (k == 3 ? 1.0f : 0.0f);
+                                    float d = static_cast<float>(iabs(px + dir_x - ax) + iabs(py + dir_y - ay));
+                                    if (eat_t > 0.0f) d = -d;
+                                    if (d < min_dist) {
+                                        min_dist = d;
+                                        select = k;
+                                    }
+                                }
+                        } else if (n_possible > 0) {
+                            const int cusp = rng_int(mt, 0, n_possible - 1);
+                            int sum = 0;
+                            bool found = false;
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                sum += possible[k] ? 1 : 0;
+                                if (!found && sum > cusp) {
+                                    select = k;
+                                    found = true;
+                                }
+                            }
+                        }
+                        const float dir_x = select == 0 ? -1.0f : (select == 1 ? 1.0f : 0.0f);
+                        const float dir_y = select == 2 ? -1.0f : (select == 3 ? 1.0f : 0.0f);
+                        vx = dir_x * speed;
+                        vy = dir_y * speed;
+                        if (dir_x == 0.0f) px = static_cast<int>(px) + 0.5f;
+                        if (dir_y == 0.0f) py = static_cast<int>(py) + 0.5f;
+                    }
+                    px += vx * dt;
+                    py += vy * dt;
+                    if (box_hit(agent_rect, Box{-0.5f + px, -0.5f + py, 1.0f, 1.0f})) {
+                        if (eat_t == 0.0f) {
+                            player_hit = true;
+                        } else {  // back to an egg on a random point cell, without the world-y flip (D16)
+                            hatch = 0.0f;
+                            const int n_free = n_ent - kFirstPoint;
+                            const int cell = EB(s, EB_CELL, kFirstPoint + rng_int(mt, 0, n_free - 1), env);
+                            px = cell / H + 0.5f;
+                            py = cell % H + 0.5f;
+                            tex = 0;
+                        }
+                    }
+                    MF(s, MF_X, m, env) = px;
+                    MF(s, MF_Y, m, env) = py;
+                    MF(s, MF_VX, m, env) = vx;
+                    MF(s, MF_VY, m, env) = vy;
+                    MF(s, MF_HATCH, m, env) = hatch;
+                    MB(s, 0, m, env) = static_cast<uint8_t>(tex);
+                } else {
+                    MF(s, MF_HATCH, m, env) = hatch + dt;
+                }
+            }
+            if (anim_t < anim_time) {
+                anim_t += dt;
+            } else {
+                anim_t -= anim_time;
+                anim_i = (anim_i + 1) % 6;
+            }
+            if (eat_t > 0.0f) eat_t = fmaxf(0.0f, eat_t - dt);
+        }
+
+        // --- System_Point::update (common_systems.cpp:66-106): order-free
+        int delta = 0, available = 0;
+        for (int e = 0; e < n_ent; e++) {
+            if (e >= kOrbs && e < kFirstPoint) continue;
+            const int info = EB(s, EB_INFO, e, env);
+            if (!(info & kAlive)) continue;
+            const int cell = EB(s, EB_CELL, e, env);
+            const float x = cell_x(cell), y = cell_y(cell);
+            const bool orb = e < kOrbs;
+            const Box rect = orb ? Box{-0.5f + x, -0.5f + y, 1.0f, 1.0f} : Box{-0.3f + x, -0.3f + y, 0.6f, 0.6f};
+            if (box_hit(agent_rect, rect)) {
+                if (orb) eat_t = 75.0f;
+                delta++;
+                EB(s, EB_INFO, e, env) = static_cast<uint8_t>(info & ~kAlive);  // destroy_entity
+                set_changed = true;
+            } else {
+                available++;
+            }
+        }
+        reward = delta * 0.04f + (available == 0) * 10.0f;
+        terminated = player_hit || (available == 0);
+        if (terminated) break;
+    }
+    SF(s, F_AX, env) = ax;
+    SF(s, F_AY, env) = ay;
+    SF(s, F_AVX, env) = avx;
+    SF(s, F_AVY, env) = avy;
+    SF(s, F_NVX, env) = nvx;
+    SF(s, F_NVY, env) = nvy;
+    SF(s, F_INPUT_T, env) = input_t;
+    SF(s, F_ANIM_T, env) = anim_t;
+    SF(s, F_EAT_T, env) = eat_t;
+    SI(s, I_ANIM_I, env) = anim_i;
+    SI(s, I_FLAGS, env) = kFlagListed;
+    if (set_changed) rebuild_draw_list(s, env, n_ent);
+    reward_out = reward;
+    terminated_out = terminated;
+}
+
+__global__ void __launch_bounds__(64) make_kernel(State s) {
+    const int env = blockIdx.x * 64 + threadIdx.x;
+    if (env >= s.n) return;
+    SI(s, I_HASH_SPRITE, env) = 1;  // empty unordered_set: one bucket, next_resize 0
+    SI(s, I_HASH_MOB, env) = 1;
+}
+
+__global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actions, uint32_t run_seed,
+                                                   uint32_t step_index, int env_offset, StepIO io) {
+    const int env = blockIdx.x * 64 + threadIdx.x;
+    if (env >= s.n) return;
+    if (io.pending[env] == 2) {  // reset by the level kernel in this step
+        io.pending[env] = 0;
+        return;
+    }
+    const int action =
+        actions ? actions[env] : synthetic_action(run_seed, step_index, static_cast<uint32_t>(env_offset + env));
+    float reward;
+    bool terminated;
+    advance(s, env, action, reward, terminated);
+    io.reward[env] = reward;
+    io.done[env] = terminated ? 1 : 0;
+    io.pending[env] = terminated ? 1 : 0;
+}
+
+// render_game(true) (chaser.cpp:390-416): one wavefront per env.
+__global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
+                                                    int flags) {
+    const int env = blockIdx.x;
+    if (mask && !mask[env]) return;
+    const int lane = threadIdx.x;
+    __shared__ uint32_t fb[kFbWords];
+    constexpr int kGrid = 16;  // 11 tiles + the border cells of the inclusive window
+    __shared__ ComposeLds<kGrid> L;
+
+    const float zoom = 64.0f * kPxUnit / static_cast<float>(W);  // chaser.cpp:401
+    const Camera cam{W * 0.5f * kUnitPx, H * 0.5f * kUnitPx, 64.0f, 64.0f, zoom};
+    const int sflags = SI(s, I_FLAGS, env);
+    const int n_draw = (sflags & kFlagListed) ? SI(s, I_NDRAW, env) : 0;  // empty right after a reset
+    const uint8_t* tiles = s.tiles + size_t(env) * kTileStride;
+    const DescRegs descs = DescRegs::load(atlas, lane);
+    Blit mine;
+
+    Blit bg;  // chaser.cpp:404-409
+    bool has_bg;
+    {
+        const int4 d = descs.uniform(kTexFloor + SI(s, I_BG, env));
+        const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
+        const float extra = aspect - 1.0f;
+        has_bg = resolve_draw(cam, d.y, d.z, d.x, -SF(s, F_BGSHIFT, env) * extra, 0.0f, 64.0f * kUnitPx / d.z, 1.0f,
+                              false, false, bg);
+    }
+    // wall window (tilemap.cpp:245-254)
+    const float vx = (cam.px - cam.sw * 0.5f / cam.scale) * kPxUnit;
+    const float vy = (cam.py - cam.sh * 0.5f / cam.scale) * kPxUnit;
+    const float vw = cam.sw * kPxUnit / cam.scale, vh = cam.sh * kPxUnit / cam.scale;
+    const int x0 = static_cast<int>(floorf(vx)), y0 = static_cast<int>(floorf(vy));
+    const int x1 = static_cast<int>(ceilf(vx + vw)), y1 = static_cast<int>(ceilf(vy + vh));
+    const int cols = x1 - x0 + 1, rows = y1 - y0 + 1, cells = cols * rows;
+    const int4 wall_d = descs.uniform(kTexWall);
+
+    bool composed = false;
+    if (!(flags & 1) && cols <= kGrid && rows <= kGrid) {
+        compose_spans<kGrid, 16>(L, cam, x0, y0, cols, rows, wall_d.y, wall_d.z, kUnitPx / wall_d.y, lane);
+#pragma unroll
+        for (int k = 0; k < kGrid * kGrid / 64; k++) {
+            const int cell = k * 64 + lane;
+            const int r = cell / kGrid, c = cell % kGrid;
+            const bool wall = c < cols && r < rows && tile_at(tiles, x0 + c, H - 1 - (y0 + r)) == kWall;
+            L.base[cell] = wall ? wall_d.x * 4 : static_cast<int32_t>(kNoTexel);
+        }
+        __syncthreads();
+        composed = compose_rows(fb, L, atlas, bg, has_bg, cols, rows, wall_d.y, lane, flags);
+    }
+    if (!composed) {  // draw-list replay (tilemap.cpp:256-266)
+        wave_clear(fb, lane);
+        mine = bg;
+        wave_replay(fb, atlas, mine, has_bg ? 1ull : 0ull, lane);
+        for (int base = 0; base < cells; base += 64) {
+            const int cell = base + lane;
+            bool has = false;
+            if (cell < cells) {
+                const int row = cell / cols;
+                const int x = x0 + (cell - row * cols), y = y0 + row;
+                if (tile_at(tiles, x, H - 1 - y) == kWall)
+                    has = resolve_draw(cam, wall_d.y, wall_d.z, wall_d.x, x * kUnitPx, y * kUnitPx, kUnitPx / wall_d.y,
+                                       1.0f, false, false, mine);
+            }
+            wave_replay(fb, atlas, mine, __ballot(has), lane);
+        }
+    }
+    // every sprite has z = 0: the positive pass (common_systems.cpp:41-63), then the agent (:446-460)
+    for (int first = 0; first < n_draw + 1; first += 64) {
+        const int k = first + lane;
+        int want_tex = kTexAgent;
+        float x = 0.0f, y = 0.0f;
+        bool has = false;
+        if (k < n_draw) {
+            const int e = EB(s, EB_DRAW, k, env);
+            const int kind = EB(s, EB_INFO, e, env) & kKindMask;
+            has = true;
+            if (kind == kEgg) {
+                const int m = e - kOrbs;
+                want_tex = kTexEnemy + MB(s, 0, m, env);
+                x = MF(s, MF_X, m, env);
+                y = MF(s, MF_Y, m, env);
+            } else {
+                const int cell = EB(s, EB_CELL, e, env);
+                want_tex = kind == kOrb ? kTexOrb : kTexPoint;
+                x = cell_x(cell);
+                y = cell_y(cell);
+            }
+        } else if (k == n_draw) {
+            has = true;
+            x = SF(s, F_AX, env);
+            y = SF(s, F_AY, env);
+        }
+        const int4 d = descs.at(want_tex);
+        if (has) {
+            const float scale = (k == n_draw) ? kUnitPx / d.y * 1.0f : (1.0f * 1.0f) * kUnitPx / d.y;
+            has = resolve_draw(cam, d.y, d.z, d.x, (x + -0.5f) * kUnitPx, (y + -0.5f) * kUnitPx, scale, 1.0f, false, false,
+                               mine);
+        }
+        wave_replay(fb, atlas, mine, __ballot(has), lane);
+    }
+    wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane);
+}
+
+class ChaserGame final : public Game {
+   public:
+    const char* name() const override { return "chaser"; }
+    std::vector<std::string> texture_names() const override {
+        std::vector<std::string> v = {"misc_assets/tileStone_slope.png", "misc_assets/yellowCrystal.png",
+                                      "custom/chaser_point.png",         "misc_assets/enemySpikey_1b.png",
+                                      "misc_assets/enemyFlying_1.png",   "misc_assets/enemyFlying_2.png",
+                                      "misc_assets/enemyFlying_3.png",   "misc_assets/enemyWalking_1b.png",
+                                      "misc_assets/enemyFloating_1b.png", "topdown_backgrounds/floortiles.png"};
+        for (int k = 1; k <= 8; k++) v.push_back("topdown_backgrounds/backgrounddetailed" + std::to_string(k) + ".png");
+        return v;
+    }
+    std::string check_atlas(const std::vector<std::pair<int, int>>& sizes) const override {
+        return static_cast<int>(sizes.size()) == kTexCount ? "" : "chaser: unexpected texture count";
+    }
+    static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+    struct Layout {
+        size_t shadow, slot, mt, tiles, f, i, mf, mb, eb, total;
+    };
+    static Layout layout(int n) {
+        Layout l{};
+        size_t off = 0;
+        auto take = [&](size_t bytes) {
+            size_t at = off;
+            off += align256(bytes);
+            return at;
+        };
+        l.shadow = take(sizeof(Level));  // unused: this game never prefetches
+        l.slot = take(size_t(n) * 4);
+        l.mt = take(size_t(n) * kMtWords * 4);
+        l.tiles = take(size_t(n) * kTileStride);
+        l.f = take(size_t(F_COUNT) * n * 4);
+        l.i = take(size_t(I_COUNT) * n * 4);
+        l.mf = take(size_t(MF_COUNT) * kMobs * n * 4);
+        l.mb = take(size_t(2) * kMobs * n);
+        l.eb = take(size_t(EB_COUNT) * kMaxEnt * n);
+        l.total = off;
+        return l;
+    }
+    size_t state_bytes(int n) const override { return layout(n).total; }
+    void bind(void* d_state, int n, AtlasView atlas) override {
+        uint8_t* p = static_cast<uint8_t*>(d_state);
+        const Layout l = layout(n);
+        s_.n = n;
+        s_.shadow = reinterpret_cast<Level*>(p + l.shadow);
+        s_.slot = reinterpret_cast<int32_t*>(p + l.slot);
+        s_.mt = reinterpret_cast<uint32_t*>(p + l.mt);
+        s_.tiles = p + l.tiles;
+        s_.f = reinterpret_cast<float*>(p + l.f);
+        s_.i = reinterpret_cast<int32_t*>(p + l.i);
+        s_.mf = reinterpret_cast<float*>(p + l.mf);
+        s_.mb = p + l.mb;
+        s_.eb = p + l.eb;
+        atlas_ = atlas;
+    }
+    int blocks() const { return (s_.n + 63) / 64; }
+    void launch_make(hipStream_t st, uint32_t seed_base, int env_offset) override {
+        hipLaunchKernelGGL(make_kernel, dim3(blocks()), dim3(64), 0, st, s_);
+        LevelLaunch<Gen>::make(st, s_, 0, seed_base, env_offset);
+    }
+    void launch_reset(hipStream_t st, const uint8_t* mask, const int32_t* seeds, StepIO io) override {
+        LevelLaunch<Gen>::reset(st, s_, 0, mask, seeds, io);
+    }
+    void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
+                      StepIO io) override {
+        LevelLaunch<Gen>::auto_reset(st, s_, 0, io);
+        hipLaunchKernelGGL(logic_kernel, dim3(blocks()), dim3(64), 0, st, s_, actions, run_seed, step_index,
+                           env_offset, io);
+    }
+    void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
+        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(64), 0, st, s_, atlas_, mask, io, debug_flags);
+    }
+    // Same layout as oracle/pgo_chaser.cpp Chaser::dump_state.
+    int dump_state(hipStream_t st, int env, float* out, int cap) override {
+        hipStreamSynchronize(st);
+        const size_t n = s_.n;
+        auto rf = [&](const float* base, size_t idx) {
+            float v;
+            hipMemcpy(&v, base + idx, 4, hipMemcpyDeviceToHost);
+            return v;
+        };
+        auto rb = [&](const uint8_t* base, size_t idx) {
+            uint8_t v;
+            hipMemcpy(&v, base + idx, 1, hipMemcpyDeviceToHost);
+            return v;
+        };
+        auto ri = [&](int field) {
+            int32_t v;
+            hipMemcpy(&v, s_.i + size_t(field) * n + env, 4, hipMemcpyDeviceToHost);
+            return v;
+        };
+        auto f = [&](int field) { return rf(s_.f, size_t(field) * n + env); };
+        const int n_ent = ri(I_NENT);
+        std::vector<float> v = {f(F_AX), f(F_AY), f(F_AVX), f(F_AVY), f(F_NVX), f(F_NVY), f(F_INPUT_T), f(F_ANIM_T),
+                                static_cast<float>(ri(I_ANIM_I)), f(F_EAT_T), static_cast<float>(ri(I_BG)), f(F_BGSHIFT),
+                                static_cast<float>(n_ent)};
+        for (int e = 0; e < n_ent; e++) {
+            const int info = rb(s_.eb, (size_t(EB_INFO) * kMaxEnt + e) * n + env);
+            const int cell = rb(s_.eb, (size_t(EB_CELL) * kMaxEnt + e) * n + env);
+            const int kind = info & kKindMask;
+            v.push_back((info & kAlive) ? 1.0f : 0.0f);
+            v.push_back(static_cast<float>(kind));
+            if (kind == kEgg) {
+                const int m = e - kOrbs;
+                auto mf = [&](int field) { return rf(s_.mf, (size_t(field) * kMobs + m) * n + env); };
+                v.push_back(mf(MF_X));
+                v.push_back(mf(MF_Y));
+                v.push_back(mf(MF_VX));
+                v.push_back(mf(MF_VY));
+                v.push_back(mf(MF_HATCH));
+                v.push_back(static_cast<float>(rb(s_.mb, (size_t(0) * kMobs + m) * n + env)));
+            } else {
+                v.push_back(static_cast<float>(cell / H) + 0.5f);
+                v.push_back(static_cast<float>(H - 1 - cell % H) + 0.5f);
+                v.push_back(0.0f);
+                v.push_back(0.0f);
+                v.push_back(0.0f);
+                v.push_back(0.0f);
+            }
+        }
+        const int m = cap < static_cast<int>(v.size()) ? cap : static_cast<int>(v.size());
+        for (int k = 0; k < m; k++) out[k] = v[k];
+        return static_cast<int>(v.size());
+    }
+    int dump_tiles(hipStream_t st, int env, uint8_t* out, int cap) override {
+        hipStreamSynchronize(st);
+        const int m = cap < kCells ? cap : kCells;
+        hipMemcpy(out, s_.tiles + size_t(env) * kTileStride, m, hipMemcpyDeviceToHost);
+        return m;
+    }
+
+   private:
+    State s_{};
+    AtlasView atlas_{};
+};
+
+}  // namespace chaser
+
+std::unique_ptr<Game> make_chaser() { return std::make_unique<chaser::ChaserGame>(); }
+
+}  // namespace pg

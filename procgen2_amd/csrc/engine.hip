@@ -85,7 +85,7 @@ static std::string asset_root() {
     return "assets";
 }
 
-static const char* const kGameNames[kNumGames] = {"coinrun", "maze", "bossfight", "climber", "caveflyer"};
+static const char* const kGameNames[kNumGames] = {"coinrun", "maze", "bossfight", "climber", "caveflyer", "chaser"};
 
 static std::unique_ptr<Game> make_game(int id) {
     switch (id) {
@@ -94,6 +94,7 @@ static std::unique_ptr<Game> make_game(int id) {
         case kGameBossfight: return make_bossfight();
         case kGameClimber: return make_climber();
         case kGameCaveflyer: return make_caveflyer();
+        case kGameChaser: return make_chaser();
         default: return nullptr;
     }
 }

@@ -56,7 +56,7 @@ def test_coinrun_lockstep_256_envs():
     assert resets > 0, "no episode ended: the auto-reset path was not exercised"
 
 
-@pytest.mark.parametrize("game", ["coinrun", "maze", "bossfight", "climber", "caveflyer"])
+@pytest.mark.parametrize("game", ["coinrun", "maze", "bossfight", "climber", "caveflyer", "chaser"])
 def test_row_composer_equals_draw_list_replay(game):
     """The fused background+tile row composer (pg_render.h compose_rows) against the one-blit-at-a-time replay of
     the reference's draw list, the same engine in both modes, every byte of 512 envs over 150 steps."""
@@ -155,6 +155,35 @@ def test_level_prefetch_equals_synchronous_generation(game, steps):
     sync.close()
 
 
+def test_chaser_lockstep_steering_actions():
+    # Only actions 1, 3, 5, 7 steer in chaser; with mostly those the agent roams, eats points (entity sets shrink, draw
+    # list rebuilt through the introsort twin on up to 70 equal keys), takes orbs (enemies flee, get eaten, respawn as
+    # eggs: in-step RNG) and is caught (auto-reset: Kruskal maze + unordered_set-ordered spawn cells).
+    n = 192
+    eng, ora = EngineVec("chaser", n, seed_base=51), OracleVec("chaser", n, seed_base=51)
+    assert np.array_equal(eng.reset(), ora.reset_obs())
+    rng = np.random.default_rng(11)
+    ends, rew = 0, 0.0
+    hold = rng.choice([1, 3, 5, 7], n)
+    for s in range(700):
+        turn = rng.random(n) < 0.15
+        hold = np.where(turn, rng.choice([1, 3, 5, 7], n), hold)
+        a = np.where(rng.random(n) < 0.1, rng.integers(0, 15, n), hold).astype(np.int32)
+        oe, re_, de = eng.step(a)
+        oo, ro, do = ora.step(a)
+        assert np.array_equal(de, do) and np.array_equal(re_.view(np.uint32), ro.view(np.uint32)), s
+        assert np.array_equal(oe, oo), s
+        ends += int(do.sum())
+        rew += float(ro.sum())
+        if s % 100 == 0:
+            for e in range(0, n, 24):
+                assert np.array_equal(eng.state(e, 1024).view(np.uint32), ora.state(e, 1024).view(np.uint32)), (s, e)
+                assert np.array_equal(eng.tiles(e), ora.tiles(e)), (s, e)
+    assert ends > 50 and rew > 50.0, (ends, rew)
+    eng.close()
+    ora.close()
+
+
 def test_climber_lockstep_jump_heavy_actions():
     # Uniform random actions rarely leave the floor; biasing towards the jump actions (2, 5, 8) makes agents climb,
     # collect crystals (entity destruction -> draw-list rebuild) and die on mobs (auto-reset, new level).
@@ -196,7 +225,7 @@ def test_maze_out_of_range_actions_follow_reference_quirk():
     ora.close()
 
 
-@pytest.mark.parametrize("game", ["coinrun", "maze", "bossfight", "climber", "caveflyer"])
+@pytest.mark.parametrize("game", ["coinrun", "maze", "bossfight", "climber", "caveflyer", "chaser"])
 def test_reset_with_seed_option_and_mask(game):
     """cenv_reset's "seed" option (coinrun.cpp:313-317) per env, and masked resets leaving other envs untouched."""
     n = 16
@@ -254,7 +283,8 @@ def test_cenv_abi_single_env_matches_reference_loop():
     """The drop-in path: CEnv("libCoinRun.so", options={"seed": s}) → reset → step(int) … with the caller doing
     `if term: reset()` — exactly game_test.py:36-40 — against the oracle driven the same way."""
     for libname, game in (("libCoinRun.so", "coinrun"), ("libMaze.so", "maze"), ("libBossFight.so", "bossfight"),
-                          ("libClimber.so", "climber"), ("libCaveFlyer.so", "caveflyer")):
+                          ("libClimber.so", "climber"), ("libCaveFlyer.so", "caveflyer"),
+                          ("libChaser.so", "chaser")):
         env = pgcenv.CEnv(os.path.join(pglib.LIB_DIR, libname), options={"seed": 123})
         assert list(env.observation_space) == ["screen"] and list(env.action_space) == ["action"]
         assert list(env.action_space["action"].nvec) == [15]

@@ -98,7 +98,17 @@ def caveflyer():
     return ["misc_assets/%s.png" % n for n in misc] + ["space_backgrounds/%s.png" % n for n in space]
 
 
-GAMES = {"coinrun": coinrun, "maze": maze, "bossfight": bossfight, "climber": climber, "caveflyer": caveflyer}
+def chaser():
+    # games/chaser/chaser.cpp:57-67, tilemap.cpp:6-16, common_systems.cpp:108-115, :297-299
+    misc = ["tileStone_slope", "yellowCrystal", "enemySpikey_1b", "enemyFlying_1", "enemyFlying_2", "enemyFlying_3",
+            "enemyWalking_1b", "enemyFloating_1b"]
+    floors = ["floortiles"] + ["backgrounddetailed%d" % i for i in range(1, 9)]
+    return ["misc_assets/%s.png" % n for n in misc] + ["custom/chaser_point.png"] + \
+           ["topdown_backgrounds/%s.png" % n for n in floors]
+
+
+GAMES = {"coinrun": coinrun, "maze": maze, "bossfight": bossfight, "climber": climber, "caveflyer": caveflyer,
+         "chaser": chaser}
 
 
 def main():
