@@ -119,7 +119,7 @@ CENV_API extern cenv_render_data render_data;
 
 /* cenv.h:128-133.
  * cenv_make options (games/coinrun/coinrun.cpp:133-151): "seed" INT, "width"/"height" INT (human frame
- * size); engine additions, INT: "num_envs", "game" (0 coinrun, 1 maze, 2 bossfight, 3 climber, 4 caveflyer, 5 chaser), "device", "env_offset".
+ * size); engine additions, INT: "num_envs", "game" (0 coinrun, 1 maze, 2 bossfight, 3 climber, 4 caveflyer, 5 chaser, 6 jumper), "device", "env_offset".
  * cenv_reset options (coinrun.cpp:310-318): "seed" INT (env i reseeds with seed + i). */
 CENV_API int32_t cenv_get_env_version(void);
 CENV_API int32_t cenv_make(const char* render_mode, cenv_option* options, int32_t options_size);

@@ -37,7 +37,7 @@ extern "C" {
 
 typedef struct pgv_env pgv_env;
 
-/* Games available in this build: 0 "coinrun", 1 "maze", 2 "bossfight", 3 "climber", 4 "caveflyer", 5 "chaser".  Returns NULL past the end. */
+/* Games available in this build: 0 "coinrun", 1 "maze", 2 "bossfight", 3 "climber", 4 "caveflyer", 5 "chaser", 6 "jumper".  Returns NULL past the end. */
 PGV_API const char* pgv_game_name(int32_t game_id);
 PGV_API int32_t pgv_game_id(const char* name); /* -1 if unknown */
 

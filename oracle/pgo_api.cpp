@@ -34,6 +34,8 @@ void* pgo_make(const char* game, uint32_t seed, int render_enabled) {
         e = pgo::new_caveflyer();
     else if (g == "chaser")
         e = pgo::new_chaser();
+    else if (g == "jumper")
+        e = pgo::new_jumper();
     if (!e) return nullptr;
     e->set_render_enabled(render_enabled != 0);
     e->make(seed);

@@ -76,5 +76,6 @@ Env* new_bossfight();
 Env* new_climber();
 Env* new_caveflyer();
 Env* new_chaser();
+Env* new_jumper();
 
 }  // namespace pgo

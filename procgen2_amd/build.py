@@ -26,11 +26,12 @@ ARCH = "gfx950"
 COMMON = ["--offload-arch=" + ARCH, "-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
           "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-I" + CSRC]
 
-KERNEL_SOURCES = ["coinrun.hip", "maze.hip", "bossfight.hip", "climber.hip", "caveflyer.hip", "chaser.hip"]
+KERNEL_SOURCES = ["coinrun.hip", "maze.hip", "bossfight.hip", "climber.hip", "caveflyer.hip", "chaser.hip", "jumper.hip"]
 HOST_SOURCES = ["png_decode.cpp"]
 ENGINE = "engine.hip"
 ALIASES = {"libprocgen2_hip.so": 0, "libCoinRun.so": 0, "libMaze.so": 1, "libBossFight.so": 2, "libClimber.so": 3,
-           "libCaveFlyer.so": 4, "libChaser.so": 5}
+           "libCaveFlyer.so": 4, "libChaser.so": 5,
+           "libJumper.so": 6}
 
 
 def hipcc():

@@ -85,7 +85,7 @@ static std::string asset_root() {
     return "assets";
 }
 
-static const char* const kGameNames[kNumGames] = {"coinrun", "maze", "bossfight", "climber", "caveflyer", "chaser"};
+static const char* const kGameNames[kNumGames] = {"coinrun", "maze", "bossfight", "climber", "caveflyer", "chaser", "jumper"};
 
 static std::unique_ptr<Game> make_game(int id) {
     switch (id) {
@@ -95,6 +95,7 @@ static std::unique_ptr<Game> make_game(int id) {
         case kGameClimber: return make_climber();
         case kGameCaveflyer: return make_caveflyer();
         case kGameChaser: return make_chaser();
+        case kGameJumper: return make_jumper();
         default: return nullptr;
     }
 }

@@ -1,0 +1,825 @@
+// jumper on gfx950: double-jumping bunny in a cave, spikes, a carrot, and a compass HUD.
+//
+// Reference:
+//   step   games/jumper/jumper.cpp:340-389, common_systems.cpp:57-202 (agent), :255-283 (particles), :7-24 (sprites)
+//   render games/jumper/jumper.cpp:445-509 (incl. the compass), tilemap.cpp:255-281, common_systems.cpp:26-48,
+//          :204-247 (agent), :285-308 (particles)
+//   reset  games/jumper/jumper.cpp:511-533, tilemap.cpp:79-253, maze_generator.cpp:47-173, room_generator.cpp:4-202
+// Config = the reference's compile-time default, hard_mode (40×40, pruned; jumper/tilemap.h:44-46).
+//
+// Machine mapping: logic one lane per env, render one wavefront per env, level generation one wavefront per env on
+// LDS (pg_kruskal.h maze → noisy 3× upscale → pg_rooms.h cave/room/path → spikes and wall trimming as column bit
+// masks).  No random draws during an episode, so the next level is generated ahead of time (pg_prefetch.h).
+// The compass needle's angle is std::atan2(float, float): pg_atan2.h is glibc's atan2f bit for bit.
+// D21 (oracle/pgo_chaser.cpp) applies to one line: `abs(velocity.x) > 0.01f` (common_systems.cpp:198) is the int abs.
+#include "pg_atan2.h"
+#include "pg_engine.h"
+#include "pg_geom.h"
+#include "pg_kruskal.h"
+#include "pg_order.h"
+#include "pg_prefetch.h"
+#include "pg_render.h"
+#include "pg_rng.h"
+#include "pg_rooms.h"
+#include "pg_tiles.h"
+
+namespace pg {
+namespace jumper {
+
+constexpr int W = 40, H = 40, kCells = W * H;
+constexpr int kMaxSpikes = 126;             // entity ids: 0 carrot, 1 bunny, 2.. spikes
+constexpr int kMaxSprites = kMaxSpikes + 1;  // carrot + spikes
+constexpr int kPuffs = 10;
+enum Tile : uint8_t { kEmpty = 0, kWallTop = 1, kWallMid = 2, kSpike = 3 };  // tilemap.h:19-26
+
+enum Tex {
+    kTexTop = 0,  // 4 themes
+    kTexMid = 4,  // 4 themes
+    kTexSpike = 8,
+    kTexCarrot = 9,
+    kTexStand = 10,
+    kTexJump = 11,
+    kTexWalk1 = 12,
+    kTexWalk2 = 13,
+    kTexPuff = 14,
+    kTexCircle = 15,
+    kTexNeedle = 16,
+    kTexBar = 17,
+    kTexBackdrop = 18,  // 49
+    kTexCount = 67
+};
+
+enum {
+    F_AX, F_AY, F_AVX, F_AVY, F_APHASE, F_JUMP_T, F_CAMX, F_CAMY, F_TOGX, F_TOGY, F_GX, F_GY, F_BGSHIFT, F_PTIMER,
+    F_COUNT
+};
+enum { I_FLAGS, I_THEMES, I_NSPIKES, I_JUMPS, I_HASH_SPRITE, I_COUNT };
+constexpr int kFlagGround = 1, kFlagForward = 2, kFlagListed = 4, kFlagPuffOn = 8;
+enum { PF_X, PF_Y, PF_LIFE, PF_COUNT };
+
+// One generated level, as the generator leaves it in LDS and as it waits in the shadow slot (pg_prefetch.h).
+struct Level {
+    uint8_t tiles[kCells];
+    float ax, ay, gx, gy, bgshift;
+    int32_t themes, n_spikes;
+    uint16_t spike_cell[kMaxSpikes];
+    uint8_t draw[kMaxSprites + 1];  // entity ids in draw order (0 = carrot, k + 2 = spike k)
+};
+static_assert(sizeof(Level) % 4 == 0, "Level is copied as 32-bit words");
+
+struct GenLds {
+    rooms::RoomsLds r;  // r.mt is the stream
+    KruskalLds k;
+    unsigned long long mid[W + 2], open[W + 2];  // per column (index x + 1): wall_mid cells / empty cells, bit = y
+    float draws[64];
+};
+
+struct State {
+    int n;
+    Level* shadow;   // [n]  next level of each env
+    int32_t* slot;   // [n]  SlotState
+    uint32_t* mt;    // [n][625]  generator chain
+    uint8_t* tiles;  // [n][1600]  column-major y + x*H
+    float* f;        // [F_COUNT][n]
+    int32_t* i;      // [I_COUNT][n]
+    float* pf;       // [PF_COUNT][kPuffs][n]
+    uint16_t* spike_cell;  // [kMaxSpikes][n]
+    uint8_t* draw;         // [kMaxSprites][n]
+};
+
+PG_D float& SF(const State& s, int field, int env) { return s.f[size_t(field) * s.n + env]; }
+PG_D int32_t& SI(const State& s, int field, int env) { return s.i[size_t(field) * s.n + env]; }
+PG_D float& PF(const State& s, int field, int k, int env) { return s.pf[(size_t(field) * kPuffs + k) * s.n + env]; }
+
+using Win = TileWinT<W, H, kWallMid>;  // out of bounds is a wall (tilemap.h:84-89)
+PG_D bool is_wall(int t) { return t == kWallMid || t == kWallTop; }
+PG_D float cell_x(int cell) { return static_cast<float>(cell / H) + 0.5f; }
+PG_D float cell_y(int cell) { return static_cast<float>(H - 1 - cell % H) + 0.5f; }
+
+// ------------------------------------------------------------------------------------------------
+// level generation
+// ------------------------------------------------------------------------------------------------
+// Maze_Generator::generate_maze_no_dead_ends, second half (maze_generator.cpp:132-173): every open cell of the padded
+// grid with exactly one open neighbour gets one more opening, chosen — quirk kept — among the first `walls` entries of
+// its neighbour list (−x, +x, −y, +y), not among its wall neighbours.  The scan mutates the grid it reads.
+PG_D void open_dead_ends(KruskalLds& K, int dim, uint32_t* mt, int lane) {
+    const int ah = dim + 2;
+    for (int i = 0; i < ah * ah; i++) {
+        if (K.grid[i] != 0) continue;
+        const int x = i / ah, y = i % ah;
+        const int nb[4] = {y + ah * (x - 1), y + ah * (x + 1), (y - 1) + ah * x, (y + 1) + ah * x};
+        int spaces = 0, walls = 0;
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+            const int g = K.grid[nb[n]];
+            spaces += g == 0 ? 1 : 0;
+            walls += g == 1 ? 1 : 0;
+        }
+        if (spaces == 1 && walls > 0) {
+            const int pick = wave_rng_int(mt, 0, walls - 1, lane);
+            if (lane == 0) {
+                for (int n = 0; n < 4; n++) {
+                    const int cell = nb[(pick + n) % walls];
+                    const int cx = cell / ah, cy = cell % ah;
+                    if (cx >= 1 && cy >= 1 && cx < ah - 1 && cy < ah - 1 && K.grid[cell] == 1) {
+                        K.grid[cell] = 0;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Column masks of the tile map under construction (bit y of column x): lane = column.
+PG_D void masks_from_tiles(GenLds& L, const uint8_t* tiles, int lane) {
+    if (lane < W + 2) {
+        unsigned long long m = 0, o = 0;
+        const int x = lane - 1;
+        if (x >= 0 && x < W)
+            for (int y = 0; y < H; y++) {
+                const int t = tiles[y + x * H];
+                m |= static_cast<unsigned long long>(t == kWallMid) << y;
+                o |= static_cast<unsigned long long>(t == kEmpty) << y;
+            }
+        L.mid[lane] = m;  // columns −1 and W: no wall_mid bit and no empty bit — at() there is wall_mid, which only
+        L.open[lane] = o;  // ever matters through "is it empty" (no) and "is the cell below a wall" (handled below)
+    }
+    __syncthreads();
+}
+
+// is_space_on_ground for a whole column (tilemap.cpp:52-62): empty, empty above, wall below.  Row −1 is out of
+// bounds = wall, row H is out of bounds = not empty.  Only wall_mid and empty exist at this point.
+PG_D unsigned long long ground_mask(unsigned long long mid, unsigned long long open) {
+    const unsigned long long below_is_wall = (mid << 1) | 1ull;
+    return open & (open >> 1) & below_is_wall & ((1ull << H) - 1ull);
+}
+
+PG_D void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, uint32_t seed, int lane) {
+    rooms::RoomsLds& R = L.r;
+    uint32_t* gmt = s.mt + size_t(env) * kMtWords;
+    if (reseed) {
+        if (lane == 0) mt_seed(R.mt, seed);
+    } else {
+        for (int k = lane; k < kMtWords; k += 64) R.mt[k] = gmt[k];
+    }
+    __syncthreads();
+    uint32_t* mt = R.mt;
+    // tilemap.cpp:95-123: 13×13 maze without dead ends, blown up ×3 with noise
+    constexpr int kScale = 3, kDim = W / kScale;
+    Carver carver{L.k, 0, 0, 0, 0};
+    carver.carve(kDim, mt, lane);
+    open_dead_ends(L.k, kDim, mt, lane);
+    wave_draws(mt, kCells, lane, [&](int i, float v) {
+        const int obj = L.k.grid[((i % H) / kScale + 1) + (kDim + 2) * ((i / H) / kScale + 1)];
+        R.grid[i] = v < (obj == 1 ? 0.8f : 0.2f) ? 1 : 0;
+    });
+    __syncthreads();
+    rooms::automaton(R.grid, R.aux, lane);
+    __syncthreads();
+    rooms::automaton(R.aux, R.grid, lane);
+    __syncthreads();
+    for (int c = lane; c < kCells; c += 64) {  // border cells become wall (tilemap.cpp:125-141)
+        const int x = c / H, y = c % H;
+        if (x == 0 || y == 0 || x == W - 1 || y == H - 1) R.grid[c] = 1;
+    }
+    __syncthreads();
+    const int n_room = rooms::best_room(R, lane);  // R.cells: the room in the reference's iteration order
+    const int goal_cell = R.cells[wave_rng_int(mt, 0, n_room - 1, lane)];
+    // tiles: everything wall_mid except the best room (tilemap.cpp:146-155); lv.tiles is the working map
+    for (int c = lane; c < kCells; c += 64) lv.tiles[c] = kWallMid;
+    __syncthreads();
+    for (int k = lane; k < n_room; k += 64) lv.tiles[R.cells[k]] = kEmpty;
+    __syncthreads();
+    masks_from_tiles(L, lv.tiles, lane);
+    // agent candidates in x-major order (tilemap.cpp:161-171): the drawn-th ground cell that is not the goal
+    int agent_cell;
+    {
+        unsigned long long g = 0;
+        if (lane < W) g = ground_mask(L.mid[lane + 1], L.open[lane + 1]);
+        if (lane == goal_cell / H) g &= ~(1ull << (goal_cell % H));
+        int before = __popcll(g);  // exclusive prefix over columns
+        int upto = before;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(upto, off);
+            if (lane >= off) upto += t;
+        }
+        const int total = __shfl(upto, 63);
+        before = upto - before;
+        const int pick = wave_rng_int(mt, 0, total - 1, lane);
+        int found = -1;
+        if (pick >= before && pick < upto) {
+            unsigned long long v = g;
+            for (int k = 0; k < pick - before; k++) v &= v - 1;
+            found = __builtin_ctzll(v) + lane * H;
+        }
+        const unsigned long long who = __ballot(found >= 0);
+        agent_cell = __shfl(found, __builtin_ctzll(who));
+    }
+    if (lane == 0) {
+        R.agent_cell = agent_cell;
+        R.goal_cell = goal_cell;
+    }
+    __syncthreads();
+    rooms::goal_path(R, agent_cell, goal_cell, lane);
+    rooms::widen(R, lane);
+    for (int c = lane; c < kCells; c += 64) lv.tiles[c] = R.aux[c] ? kEmpty : kWallMid;  // pruned to the wide path
+    __syncthreads();
+    masks_from_tiles(L, lv.tiles, lane);
+
+    // spikes (tilemap.cpp:203-211): x-major scan; a cell takes a draw when it and both horizontal neighbours are
+    // ground cells — and a spike placed in the previous column makes that neighbour "not empty".  Column by column,
+    // the rows of a column in one go: the k-th eligible row takes the k-th draw.
+    {
+        unsigned long long spikes_prev = 0;
+        for (int x = 0; x < W; x++) {
+            const unsigned long long here = ground_mask(L.mid[x + 1], L.open[x + 1]);
+            const unsigned long long left = ground_mask(L.mid[x], L.open[x]) & ~spikes_prev;
+            const unsigned long long right = ground_mask(L.mid[x + 2], L.open[x + 2]);
+            const unsigned long long eligible = here & left & right;  // columns −1 and W have no ground bits
+            unsigned long long placed = 0;
+            const int count = __popcll(eligible);
+            if (count > 0) {
+                wave_draws(mt, count, lane, [&](int k, float v) { L.draws[k] = v; });
+                __syncthreads();
+                bool spike = false;
+                if (lane < H && ((eligible >> lane) & 1ull))
+                    spike = L.draws[__popcll(eligible & ((1ull << lane) - 1ull))] < 0.2f;
+                placed = __ballot(spike);
+                __syncthreads();
+            }
+            spikes_prev = placed;
+            if (lane == 0) L.open[x + 1] &= ~placed;  // a spike is neither empty nor wall
+            if (lane < H && ((placed >> lane) & 1ull)) lv.tiles[lane + x * H] = kSpike;
+            __syncthreads();
+        }
+    }
+    // no long vertical walls (tilemap.cpp:213-224): strictly sequential (every removal changes later tests), but on
+    // column masks it is a few bit operations per cell; all lanes walk it together, the draws are wave-uniform.
+    for (int x = 0; x < W; x++) {
+        unsigned long long mid = L.mid[x + 1], open = L.open[x + 1];
+        const unsigned long long open_left = L.open[x], open_right = L.open[x + 2];
+        for (int y = 0; y < H; y++) {
+            if ((((mid & open_right) >> y) & 7ull) == 7ull) {  // is_left_wall(x, y .. y+2)
+                const int k = y + wave_rng_int(mt, 0, 2, lane);
+                mid &= ~(1ull << k);
+                open |= 1ull << k;
+            }
+            if ((((mid & open_left) >> y) & 7ull) == 7ull) {  // is_right_wall(x, y .. y+2)
+                const int k = y + wave_rng_int(mt, 0, 2, lane);
+                mid &= ~(1ull << k);
+                open |= 1ull << k;
+            }
+        }
+        if (lane == 0) {
+            L.mid[x + 1] = mid;
+            L.open[x + 1] = open;
+        }
+        __syncthreads();
+    }
+    // write the masks back, collect the spikes in index order (tilemap.cpp:236-245), cap the walls (:247-253)
+    int n_spikes = 0;
+    for (int c0 = 0; c0 < kCells; c0 += 64) {
+        const int c = c0 + lane;
+        const int x = c / H, y = c % H;
+        const bool was_spike = lv.tiles[c] == kSpike;
+        const bool mid = (L.mid[x + 1] >> y) & 1ull;
+        // is_top_wall: wall_mid with an empty cell above; the spike tiles have turned back into empty cells by then
+        const bool empty_above = y + 1 < H && !((L.mid[x + 1] >> (y + 1)) & 1ull);
+        const bool keep = was_spike && c != agent_cell && c != goal_cell;
+        const unsigned long long m = __ballot(keep);
+        if (keep) {
+            const int at = n_spikes + __popcll(m & ((1ull << lane) - 1ull));
+            if (at < kMaxSpikes) lv.spike_cell[at] = static_cast<uint16_t>(c);
+        }
+        n_spikes += __popcll(m);
+        __syncthreads();
+        lv.tiles[c] = mid ? (empty_above ? kWallTop : kWallMid) : kEmpty;
+    }
+    if (n_spikes > kMaxSpikes) __builtin_trap();  // far beyond anything the generator produces
+    __syncthreads();
+    const int backdrop = wave_rng_int(mt, 0, 48, lane);
+    const float shift = wave_rng_real(mt, 0.0f, 1.0f, lane);
+    const int theme = wave_rng_int(mt, 0, 3, lane);
+    if (lane == 0) {
+        lv.ax = static_cast<float>(agent_cell / H) + 0.5f;
+        lv.ay = static_cast<float>(H - 1 - (agent_cell % H));  // no +0.5 (tilemap.cpp:226)
+        lv.gx = cell_x(goal_cell);
+        lv.gy = cell_y(goal_cell);
+        lv.bgshift = shift;
+        lv.themes = backdrop | (theme << 8);
+        lv.n_spikes = n_spikes;
+        // draw order of the episode: the sprite set (carrot id 0, spikes ids 2..) in its iteration order, then
+        // std::sort on z (all 1.0); nothing is destroyed during an episode, so it is fixed here
+        int32_t packed = SI(s, I_HASH_SPRITE, env);
+        HashOrder h;
+        h.next = R.queue;
+        h.before = reinterpret_cast<int16_t*>(R.touch);
+        h.head = kNil;
+        h.buckets = packed & 0xffff;
+        h.next_resize = packed >> 16;
+        h.count = 0;
+        for (int b = 0; b < h.buckets; b++) h.before[b] = kNil;
+        hash_insert(h, 0);
+        for (int k = 0; k < n_spikes; k++) hash_insert(h, 2 + k);
+        SI(s, I_HASH_SPRITE, env) = h.buckets | (h.next_resize << 16);
+        ZItem* items = reinterpret_cast<ZItem*>(R.chain);
+        int n = 0;
+        for (int16_t p = static_cast<int16_t>(h.head); p != kNil; p = h.next[p]) items[n++] = {1.0f, p};
+        sort_by_key(items, n);
+        for (int k = 0; k < n; k++) lv.draw[k] = static_cast<uint8_t>(items[k].id);
+    }
+    __syncthreads();
+    for (int k = lane; k < kMtWords; k += 64) gmt[k] = R.mt[k];
+    __syncthreads();
+}
+
+// The level becomes the env's live state (what reset() and the component constructors initialise).
+PG_D void install(const State& s, int env, const Level& lv, int lane) {
+    uint32_t* tiles = reinterpret_cast<uint32_t*>(s.tiles + size_t(env) * kCells);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(lv.tiles);
+    for (int k = lane; k < kCells / 4; k += 64) tiles[k] = src[k];
+    const int n_spikes = lv.n_spikes;
+    for (int k = lane; k < n_spikes; k += 64) s.spike_cell[size_t(k) * s.n + env] = lv.spike_cell[k];
+    for (int k = lane; k < n_spikes + 1; k += 64) s.draw[size_t(k) * s.n + env] = lv.draw[k];
+    if (lane < kPuffs)
+        for (int f = 0; f < PF_COUNT; f++) PF(s, f, lane, env) = 0.0f;
+    if (lane == 0) {
+        SF(s, F_AX, env) = lv.ax;
+        SF(s, F_AY, env) = lv.ay;
+        SF(s, F_AVX, env) = 0.0f;
+        SF(s, F_AVY, env) = 0.0f;
+        SF(s, F_APHASE, env) = 0.0f;
+        SF(s, F_JUMP_T, env) = 0.0f;
+        SF(s, F_GX, env) = lv.gx;
+        SF(s, F_GY, env) = lv.gy;
+        SF(s, F_BGSHIFT, env) = lv.bgshift;
+        SF(s, F_PTIMER, env) = 0.0f;
+        // on_ground = false, face_forward = true, particles enabled, draw list cleared
+        SI(s, I_FLAGS, env) = kFlagForward | kFlagPuffOn;
+        SI(s, I_THEMES, env) = lv.themes;
+        SI(s, I_NSPIKES, env) = n_spikes;
+        SI(s, I_JUMPS, env) = 2;
+        // camera and System_Agent::info.to_goal keep the previous episode's values until the first update (D3)
+    }
+}
+
+struct Gen {  // pg_prefetch.h level_kernel<Gen>
+    using State = jumper::State;
+    using Level = jumper::Level;
+    using GenLds = jumper::GenLds;
+    PG_D static void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, uint32_t seed, int lane) {
+        jumper::generate(s, env, L, lv, reseed, seed, lane);
+    }
+    PG_D static void install(const State& s, int env, const Level& lv, int lane) { jumper::install(s, env, lv, lane); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// step
+// ------------------------------------------------------------------------------------------------
+PG_D void advance(const State& s, int env, int action, float& reward_out, bool& terminated_out) {
+    const uint8_t* tiles = s.tiles + size_t(env) * kCells;
+    const int n_spikes = SI(s, I_NSPIKES, env);
+    int flags = SI(s, I_FLAGS, env), jumps = SI(s, I_JUMPS, env);
+    float ax = SF(s, F_AX, env), ay = SF(s, F_AY, env), avx = SF(s, F_AVX, env), avy = SF(s, F_AVY, env);
+    float phase = SF(s, F_APHASE, env), jump_t = SF(s, F_JUMP_T, env), p_timer = SF(s, F_PTIMER, env);
+    const float gx = SF(s, F_GX, env), gy = SF(s, F_GY, env);
+    bool ground = (flags & kFlagGround) != 0, forward = (flags & kFlagForward) != 0, puff_on = (flags & kFlagPuffOn) != 0;
+    const float dt = 1.0f / 4;
+    const float max_jump = 0.92f, gravity = 0.1f, max_speed = 0.5f, mix = 0.2f, air_control = 1.0f, jump_cooldown = 3.0f;
+    const float movement_x = static_cast<float>((action == 6 || action == 7 || action == 8) -
+                                                (action == 0 || action == 1 || action == 2));
+    const bool jump = (action == 2 || action == 5 || action == 8);
+
+    float reward = 0.0f;
+    bool terminated = false;
+    for (int ss = 0; ss < 4; ss++) {
+        bool alive = true, achieved_goal = false;
+        // --- System_Agent::update (common_systems.cpp:57-202)
+        const float mix_x = ground ? mix : (mix * air_control);
+        avx += mix_x * (max_speed * movement_x - avx) * dt;
+        if (fabsf(avx) < mix_x * max_speed * dt) avx = 0.0f;
+        if (ground) jumps = 2;
+        if (jump && jumps > 0 && jump_t == 0.0f) {
+            avy = -max_jump;
+            jumps--;
+            jump_t = jump_cooldown;
+        }
+        if (jump_t > 0.0f) jump_t = fmaxf(0.0f, jump_t - dt);
+        avy += gravity * dt;
+        if (fabsf(avy) > max_jump) avy = (avy > 0.0f ? 1.0f : -1.0f) * max_jump;
+        ax += avx * dt;
+        ay += avy * dt;
+        Box body{ax + -0.25f, ay + -0.8f, 0.5f, 0.8f};
+        {
+            const Win win = Win::fetch(tiles, static_cast<int>(floorf(body.x)), static_cast<int>(floorf(body.y)));
+            const TileHit h = collide_plain(win, body, is_wall);
+            const float moved_x = h.x - body.x, moved_y = h.y - body.y;
+            ground = moved_y < 0.0f && h.any;
+            ax = h.x - -0.25f;
+            ay = h.y - -0.8f;
+            body.x = ax + -0.25f;
+            body.y = ay + -0.8f;
+            if (moved_x != 0.0f) avx = 0.0f;
+            if (moved_y > 0.0f && h.any) avy = 0.0f;
+            if (ground) avy = 0.0f;
+        }
+        for (int k = 0; k < n_spikes; k++) {  // hazards: any hit kills, order-free
+            const int cell = s.spike_cell[size_t(k) * s.n + env];
+            if (box_hit(body, Box{cell_x(cell) + -0.25f, cell_y(cell) + -0.25f, 0.5f, 0.5f})) alive = false;
+        }
+        if (box_hit(body, Box{gx + -0.5f, gy + -0.5f, 1.0f, 1.0f})) achieved_goal = true;
+        phase += 0.1f * dt;
+        phase = fmodf(phase, 1.0f);
+        if (movement_x > 0.0f)
+            forward = true;
+        else if (movement_x < 0.0f)
+            forward = false;
+        {
+            const int truncated = static_cast<int>(avx);  // `abs` = int abs(int) there (D21)
+            puff_on = !ground || static_cast<float>(truncated < 0 ? -truncated : truncated) > 0.01f;
+        }
+        // --- System_Particles::update (common_systems.cpp:255-283)
+        {
+            const float lifespan = 5.0f, spawn_time = 0.5f;
+            int dead_index = -1;
+            for (int k = 0; k < kPuffs; k++) {
+                const float life = PF(s, PF_LIFE, k, env) - dt;
+                PF(s, PF_LIFE, k, env) = life;
+                if (life <= 0.0f) dead_index = k;
+            }
+            p_timer += dt;
+            if (dead_index != -1 && p_timer >= spawn_time && puff_on) {
+                p_timer = fmodf(p_timer, spawn_time);
+                PF(s, PF_LIFE, dead_index, env) = lifespan;
+                PF(s, PF_X, dead_index, env) = ax + 0.0f;
+                PF(s, PF_Y, dead_index, env) = ay + -0.2f;
+            }
+        }
+        reward = achieved_goal * 10.0f;
+        terminated = !alive || achieved_goal;
+        if (terminated) break;
+    }
+    SF(s, F_AX, env) = ax;
+    SF(s, F_AY, env) = ay;
+    SF(s, F_AVX, env) = avx;
+    SF(s, F_AVY, env) = avy;
+    SF(s, F_APHASE, env) = phase;
+    SF(s, F_JUMP_T, env) = jump_t;
+    SF(s, F_PTIMER, env) = p_timer;
+    SF(s, F_CAMX, env) = ax * kUnitPx;  // common_systems.cpp:179-180
+    SF(s, F_CAMY, env) = (ay - 0.5f) * kUnitPx;
+    SF(s, F_TOGX, env) = gx - ax;
+    SF(s, F_TOGY, env) = gy - ay;
+    SI(s, I_JUMPS, env) = jumps;
+    SI(s, I_FLAGS, env) = kFlagListed | (ground ? kFlagGround : 0) | (forward ? kFlagForward : 0) |
+                          (puff_on ? kFlagPuffOn : 0);
+    reward_out = reward;
+    terminated_out = terminated;
+}
+
+__global__ void __launch_bounds__(64) make_kernel(State s) {
+    const int env = blockIdx.x * 64 + threadIdx.x;
+    if (env >= s.n) return;
+    SI(s, I_HASH_SPRITE, env) = 1;  // empty unordered_set: one bucket, next_resize 0
+    SF(s, F_CAMX, env) = 0.0f;      // Renderer::camera_position{0} (renderer.h:18)
+    SF(s, F_CAMY, env) = 0.0f;
+    SF(s, F_TOGX, env) = 0.0f;  // Agent_Info::to_goal{0, 0} (common_systems.h:57-59)
+    SF(s, F_TOGY, env) = 0.0f;
+}
+
+__global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actions, uint32_t run_seed,
+                                                   uint32_t step_index, int env_offset, StepIO io) {
+    const int env = blockIdx.x * 64 + threadIdx.x;
+    if (env >= s.n) return;
+    if (io.pending[env] == 2) {  // reset by the level kernel in this step
+        io.pending[env] = 0;
+        return;
+    }
+    const int action =
+        actions ? actions[env] : synthetic_action(run_seed, step_index, static_cast<uint32_t>(env_offset + env));
+    float reward;
+    bool terminated;
+    advance(s, env, action, reward, terminated);
+    io.reward[env] = reward;
+    io.done[env] = terminated ? 1 : 0;
+    io.pending[env] = terminated ? 1 : 0;
+}
+
+// render_game(true) (jumper.cpp:445-509): one wavefront per env.
+__global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
+                                                    int flags) {
+    const int env = blockIdx.x;
+    if (mask && !mask[env]) return;
+    const int lane = threadIdx.x;
+    __shared__ uint32_t fb[kFbWords];
+    constexpr int kGrid = 16;  // 64 px / 4.8 px per tile → at most 16 columns/rows in view
+    __shared__ ComposeLds<kGrid> L;
+
+    const float game_zoom = 0.3f;
+    const Camera cam{SF(s, F_CAMX, env), SF(s, F_CAMY, env), 64.0f, 64.0f, game_zoom * 64.0f / 64.0f};
+    const int themes = SI(s, I_THEMES, env), sflags = SI(s, I_FLAGS, env);
+    const int backdrop = themes & 0xff, theme = (themes >> 8) & 0xff;
+    const int n_draw = (sflags & kFlagListed) ? SI(s, I_NSPIKES, env) + 1 : 0;  // empty right after a reset
+    const uint8_t* tiles = s.tiles + size_t(env) * kCells;
+    const DescRegs descs = DescRegs::load(atlas, lane);
+    Blit mine;
+
+    float puff_life = 0.0f, puff_x = 0.0f, puff_y = 0.0f;
+    if (lane < kPuffs) {
+        puff_life = PF(s, PF_LIFE, lane, env);
+        puff_x = PF(s, PF_X, lane, env);
+        puff_y = PF(s, PF_Y, lane, env);
+    }
+
+    Blit bg;  // jumper.cpp:459-464
+    bool has_bg;
+    {
+        const int4 d = descs.uniform(kTexBackdrop + backdrop);
+        const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
+        const float extra = aspect - 1.0f;
+        has_bg = resolve_draw(cam, d.y, d.z, d.x, -SF(s, F_BGSHIFT, env) * extra, 0.0f, 64.0f * kUnitPx / d.z, 1.0f,
+                              false, false, bg);
+    }
+    // tile window (tilemap.cpp:255-264)
+    const float vx = (cam.px - cam.sw * 0.5f / cam.scale) * kPxUnit;
+    const float vy = (cam.py - cam.sh * 0.5f / cam.scale) * kPxUnit;
+    const float vw = cam.sw * kPxUnit / cam.scale, vh = cam.sh * kPxUnit / cam.scale;
+    const int x0 = static_cast<int>(floorf(vx)), y0 = static_cast<int>(floorf(vy));
+    const int x1 = static_cast<int>(ceilf(vx + vw)), y1 = static_cast<int>(ceilf(vy + vh));
+    const int cols = x1 - x0 + 1, rows = y1 - y0 + 1, cells = cols * rows;
+    const int4 top_d = descs.uniform(kTexTop + theme), mid_d = descs.uniform(kTexMid + theme);
+
+    bool composed = false;
+    const bool two = top_d.z != mid_d.z;  // the brown cap tile is 64×53 (see climber.hip)
+    if (!(flags & 1) && cols <= kGrid && rows <= kGrid && top_d.y == mid_d.y && top_d.z <= mid_d.z) {
+        compose_spans(L, cam, x0, y0, cols, rows, mid_d.y, mid_d.z, kUnitPx / mid_d.y, lane, two ? top_d.z : 0);
+#pragma unroll
+        for (int k = 0; k < kGrid * kGrid / 64; k++) {
+            const int cell = k * 64 + lane;
+            const int r = cell / kGrid, c = cell % kGrid;
+            const int t = (c < cols && r < rows) ? Win::direct(tiles, x0 + c, y0 + r) : kEmpty;
+            L.base[cell] = !is_wall(t) ? static_cast<int32_t>(kNoTexel)
+                                       : (t == kWallTop ? (top_d.x * 4) | (two ? 1 : 0) : mid_d.x * 4);
+        }
+        __syncthreads();
+        composed = two ? compose_rows<kGrid, true>(fb, L, atlas, bg, has_bg, cols, rows, mid_d.y, lane, flags)
+                       : compose_rows<kGrid, false>(fb, L, atlas, bg, has_bg, cols, rows, mid_d.y, lane, flags);
+    }
+    if (!composed) {  // draw-list replay (tilemap.cpp:266-280)
+        wave_clear(fb, lane);
+        mine = bg;
+        wave_replay(fb, atlas, mine, has_bg ? 1ull : 0ull, lane);
+        for (int base = 0; base < cells; base += 64) {
+            const int cell = base + lane;
+            bool has = false;
+            if (cell < cells) {
+                const int row = cell / cols;
+                const int x = x0 + (cell - row * cols), y = y0 + row;
+                const int t = Win::direct(tiles, x, y);
+                if (is_wall(t)) {
+                    const int4 d = (t == kWallTop) ? top_d : mid_d;
+                    has = resolve_draw(cam, d.y, d.z, d.x, x * kUnitPx, y * kUnitPx, kUnitPx / d.y, 1.0f, false, false,
+                                       mine);
+                }
+            }
+            wave_replay(fb, atlas, mine, __ballot(has), lane);
+        }
+    }
+    {  // System_Particles::render (common_systems.cpp:285-308)
+        const int4 d = descs.uniform(kTexPuff);
+        bool has = false;
+        if (lane < kPuffs && puff_life > 0.0f) {
+            const float lifespan = 5.0f;
+            const float life_ratio = (lifespan - puff_life) / lifespan;
+            const float alpha = 0.5f * (1.0f - life_ratio);
+            const float scale = 0.45f * (0.4f * life_ratio + 0.6f);
+            const float offset_y = -life_ratio * 0.17f;
+            has = resolve_draw(cam, d.y, d.z, d.x, puff_x * kUnitPx - 0.5f * d.y * scale,
+                               (puff_y + offset_y) * kUnitPx - 0.5f * d.z * scale, scale * kUnitPx / d.y, alpha, false,
+                               false, mine);
+        }
+        wave_replay(fb, atlas, mine, __ballot(has), lane);
+    }
+    // positive-z sprites (common_systems.cpp:26-48): carrot and spikes in draw order
+    for (int first = 0; first < n_draw; first += 64) {
+        const int k = first + lane;
+        bool has = false;
+        int id = 0;
+        if (k < n_draw) {
+            id = s.draw[size_t(k) * s.n + env];
+            has = true;
+        }
+        const int4 d = descs.at(id == 0 ? kTexCarrot : kTexSpike);
+        if (has) {
+            if (id == 0) {
+                const float scale = 1.0f * 1.0f;
+                has = resolve_draw(cam, d.y, d.z, d.x, (SF(s, F_GX, env) + -0.5f) * kUnitPx,
+                                   (SF(s, F_GY, env) + -0.5f) * kUnitPx, scale * kUnitPx / d.y, 1.0f, false, false, mine);
+            } else {
+                const int cell = s.spike_cell[size_t(id - 2) * s.n + env];
+                const float scale = 1.0f * 0.4f;
+                has = resolve_draw(cam, d.y, d.z, d.x, (cell_x(cell) + -0.25f) * kUnitPx,
+                                   (cell_y(cell) + -0.25f) * kUnitPx, scale * kUnitPx / d.y, 1.0f, false, false, mine);
+            }
+        }
+        wave_replay(fb, atlas, mine, __ballot(has), lane);
+    }
+    {  // lane 0: the bunny (common_systems.cpp:204-247); lanes 1-3: the compass (jumper.cpp:473-509)
+        const float avx = SF(s, F_AVX, env), phase = SF(s, F_APHASE, env);
+        const bool ground = (sflags & kFlagGround) != 0;
+        int want_tex;
+        float agent_scale = 0.5f, off_x = 0.0f, off_y = 0.2f;
+        if (fabsf(avx) < 0.01f && ground) {
+            want_tex = kTexStand;
+        } else if (!ground) {
+            want_tex = kTexJump;
+            agent_scale = 0.6f;
+            off_x = -0.05f;
+            off_y = 0.25f;
+        } else if (phase > 0.5f) {
+            want_tex = kTexWalk2;
+        } else {
+            want_tex = kTexWalk1;
+        }
+        if (lane >= 1 && lane <= 3) want_tex = kTexCircle + (lane - 1);
+        const int4 d = descs.at(want_tex);
+        bool has = false;
+        if (lane == 0) {
+            const float px = SF(s, F_AX, env) - 0.25f, py = SF(s, F_AY, env) - 1.0f;
+            has = resolve_draw(cam, d.y, d.z, d.x, (px + off_x) * kUnitPx, (py + off_y) * kUnitPx,
+                               kUnitPx / d.y * agent_scale, 1.0f, (sflags & kFlagForward) == 0, false, mine);
+        } else if (lane <= 3) {
+            const float width = 64.0f, compass_size = 200.0f, offset_x = -32.0f, offset_y = 32.0f;
+            const float tx = SF(s, F_TOGX, env), ty = SF(s, F_TOGY, env);
+            const float angle = static_cast<float>(at_atan2f(ty, tx) * 180.0f / 3.14159265358979323846);
+            const float dist = __fsqrt_rn(tx * tx + ty * ty);
+            const float dist_inv = 1.0f / fmaxf(0.0001f, dist);
+            const float dir_x = tx * dist_inv, dir_y = ty * dist_inv;
+            const float ratio = fminf(1.0f, dist / (W * 1.414f));
+            if (lane == 1) {
+                has = resolve_screen(d.y, d.z, d.x, width - compass_size * game_zoom + offset_x * game_zoom,
+                                     offset_y * game_zoom, compass_size * game_zoom, compass_size * game_zoom, 0.0, mine);
+            } else if (lane == 2) {
+                float dx = width - compass_size * 0.75f * game_zoom + offset_x * game_zoom;
+                float dy = compass_size * 0.5f * game_zoom + offset_y * game_zoom;
+                dx += compass_size * 0.25f * dir_x * game_zoom;
+                dy += compass_size * 0.25f * dir_y * game_zoom;
+                has = resolve_screen(d.y, d.z, d.x, dx, dy, compass_size * 0.5f * game_zoom,
+                                     compass_size * 0.1f * game_zoom, static_cast<double>(angle), mine);
+            } else {
+                has = resolve_screen(d.y, d.z, d.x, width - compass_size * game_zoom + offset_x * game_zoom,
+                                     compass_size * game_zoom + offset_y * game_zoom, compass_size * game_zoom * ratio,
+                                     compass_size * 0.15f * game_zoom, 0.0, mine);
+            }
+        }
+        wave_replay(fb, atlas, mine, __ballot(has), lane);
+    }
+    wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane);
+}
+
+class JumperGame final : public Game {
+   public:
+    const char* name() const override { return "jumper"; }
+    std::vector<std::string> texture_names() const override {
+        std::vector<std::string> v;
+        for (const char* t : {"tileBlue_05", "tileGreen_05", "tileYellow_06", "tileBrown_06", "tileBlue_08",
+                              "tileGreen_08", "tileYellow_09", "tileBrown_09"})
+            v.push_back(std::string("platformer/") + t + ".png");
+        for (const char* t : {"spikeMan_stand", "carrot", "bunny2_ready", "bunny2_jump", "bunny2_walk1", "bunny2_walk2",
+                              "iconCircle_white"})
+            v.push_back(std::string("misc_assets/") + t + ".png");
+        for (const char* t : {"jumper_compass_circle", "jumper_compass_needle", "jumper_compass_bar"})
+            v.push_back(std::string("custom/") + t + ".png");
+        for (const char* b :
+             {"alien_bg", "another_world_bg", "back_cave", "caverns", "cyberpunk_bg", "parallax_forest", "scifi_bg",
+              "scifi2_bg", "living_tissue_bg", "airadventurelevel1", "airadventurelevel2", "airadventurelevel3",
+              "airadventurelevel4", "cave_background", "blue_desert", "blue_grass", "blue_land", "blue_shroom",
+              "colored_desert", "colored_grass", "colored_land", "colored_shroom", "landscape1", "landscape2",
+              "landscape3", "landscape4", "battleback1", "battleback2", "battleback3", "battleback4", "battleback5",
+              "battleback6", "battleback7", "battleback8", "battleback9", "battleback10", "sunrise"})
+            v.push_back(std::string("platform_backgrounds/") + b + ".png");
+        for (const char* b : {"beach1", "beach2", "beach3", "beach4", "fantasy1", "fantasy2", "fantasy3", "fantasy4",
+                              "candy1", "candy2", "candy3", "candy4"})
+            v.push_back(std::string("platform_backgrounds_2/") + b + ".png");
+        return v;
+    }
+    std::string check_atlas(const std::vector<std::pair<int, int>>& sizes) const override {
+        return static_cast<int>(sizes.size()) == kTexCount ? "" : "jumper: unexpected texture count";
+    }
+    static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+    struct Layout {
+        size_t shadow, slot, mt, tiles, f, i, pf, spike, draw, total;
+    };
+    static Layout layout(int n) {
+        Layout l{};
+        size_t off = 0;
+        auto take = [&](size_t bytes) {
+            size_t at = off;
+            off += align256(bytes);
+            return at;
+        };
+        l.shadow = take(size_t(n) * sizeof(Level));
+        l.slot = take(size_t(n) * 4);
+        l.mt = take(size_t(n) * kMtWords * 4);
+        l.tiles = take(size_t(n) * kCells);
+        l.f = take(size_t(F_COUNT) * n * 4);
+        l.i = take(size_t(I_COUNT) * n * 4);
+        l.pf = take(size_t(PF_COUNT) * kPuffs * n * 4);
+        l.spike = take(size_t(kMaxSpikes) * n * 2);
+        l.draw = take(size_t(kMaxSprites) * n);
+        l.total = off;
+        return l;
+    }
+    size_t state_bytes(int n) const override { return layout(n).total; }
+    void bind(void* d_state, int n, AtlasView atlas) override {
+        uint8_t* p = static_cast<uint8_t*>(d_state);
+        const Layout l = layout(n);
+        s_.n = n;
+        s_.shadow = reinterpret_cast<Level*>(p + l.shadow);
+        s_.slot = reinterpret_cast<int32_t*>(p + l.slot);
+        s_.mt = reinterpret_cast<uint32_t*>(p + l.mt);
+        s_.tiles = p + l.tiles;
+        s_.f = reinterpret_cast<float*>(p + l.f);
+        s_.i = reinterpret_cast<int32_t*>(p + l.i);
+        s_.pf = reinterpret_cast<float*>(p + l.pf);
+        s_.spike_cell = reinterpret_cast<uint16_t*>(p + l.spike);
+        s_.draw = p + l.draw;
+        atlas_ = atlas;
+    }
+    int blocks() const { return (s_.n + 63) / 64; }
+    int prefetch() const { return (debug_flags & kDebugNoPrefetch) ? 0 : 1; }
+    void launch_make(hipStream_t st, uint32_t seed_base, int env_offset) override {
+        hipLaunchKernelGGL(make_kernel, dim3(blocks()), dim3(64), 0, st, s_);
+        LevelLaunch<Gen>::make(st, s_, prefetch(), seed_base, env_offset);
+    }
+    void launch_reset(hipStream_t st, const uint8_t* mask, const int32_t* seeds, StepIO io) override {
+        LevelLaunch<Gen>::reset(st, s_, prefetch(), mask, seeds, io);
+    }
+    bool launch_pregen(hipStream_t side, bool bulk) override {
+        if (!prefetch()) return false;
+        LevelLaunch<Gen>::pregen(side, s_, bulk);
+        return true;
+    }
+    void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
+                      StepIO io) override {
+        LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io);
+        hipLaunchKernelGGL(logic_kernel, dim3(blocks()), dim3(64), 0, st, s_, actions, run_seed, step_index,
+                           env_offset, io);
+    }
+    void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
+        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(64), 0, st, s_, atlas_, mask, io, debug_flags);
+    }
+    // Same layout as oracle/pgo_jumper.cpp Jumper::dump_state.
+    int dump_state(hipStream_t st, int env, float* out, int cap) override {
+        hipStreamSynchronize(st);
+        const size_t n = s_.n;
+        auto rf = [&](const float* base, size_t idx) {
+            float v;
+            hipMemcpy(&v, base + idx, 4, hipMemcpyDeviceToHost);
+            return v;
+        };
+        auto ri = [&](int field) {
+            int32_t v;
+            hipMemcpy(&v, s_.i + size_t(field) * n + env, 4, hipMemcpyDeviceToHost);
+            return v;
+        };
+        auto f = [&](int field) { return rf(s_.f, size_t(field) * n + env); };
+        const int flags = ri(I_FLAGS), themes = ri(I_THEMES), n_spikes = ri(I_NSPIKES);
+        std::vector<float> v = {f(F_AX), f(F_AY), f(F_AVX), f(F_AVY), (flags & kFlagGround) ? 1.0f : 0.0f,
+                                (flags & kFlagForward) ? 1.0f : 0.0f, f(F_APHASE), f(F_JUMP_T),
+                                static_cast<float>(ri(I_JUMPS)), f(F_CAMX), f(F_CAMY), f(F_TOGX), f(F_TOGY),
+                                static_cast<float>(themes & 0xff), f(F_BGSHIFT), static_cast<float>((themes >> 8) & 0xff),
+                                f(F_PTIMER), (flags & kFlagPuffOn) ? 1.0f : 0.0f, f(F_GX), f(F_GY),
+                                static_cast<float>(n_spikes)};
+        for (int k = 0; k < kPuffs; k++)
+            for (int fld : {PF_X, PF_Y, PF_LIFE}) v.push_back(rf(s_.pf, (size_t(fld) * kPuffs + k) * n + env));
+        for (int k = 0; k < n_spikes; k++) {
+            uint16_t cell;
+            hipMemcpy(&cell, s_.spike_cell + size_t(k) * n + env, 2, hipMemcpyDeviceToHost);
+            v.push_back(static_cast<float>(cell / H) + 0.5f);
+            v.push_back(static_cast<float>(H - 1 - cell % H) + 0.5f);
+        }
+        const int m = cap < static_cast<int>(v.size()) ? cap : static_cast<int>(v.size());
+        for (int k = 0; k < m; k++) out[k] = v[k];
+        return static_cast<int>(v.size());
+    }
+    int dump_tiles(hipStream_t st, int env, uint8_t* out, int cap) override {
+        hipStreamSynchronize(st);
+        const int m = cap < kCells ? cap : kCells;
+        hipMemcpy(out, s_.tiles + size_t(env) * kCells, m, hipMemcpyDeviceToHost);
+        return m;
+    }
+
+   private:
+    State s_{};
+    AtlasView atlas_{};
+};
+
+}  // namespace jumper
+
+std::unique_ptr<Game> make_jumper() { return std::make_unique<jumper::JumperGame>(); }
+
+}  // namespace pg

@@ -28,6 +28,6 @@ constexpr int kNumActions = 15;               // coinrun.cpp:26
 constexpr float kUnitPx = 16.0f;
 constexpr float kPxUnit = 1.0f / 16.0f;
 
-enum GameId : int32_t { kGameCoinrun = 0, kGameMaze = 1, kGameBossfight = 2, kGameClimber = 3, kGameCaveflyer = 4, kGameChaser = 5, kNumGames = 6 };
+enum GameId : int32_t { kGameCoinrun = 0, kGameMaze = 1, kGameBossfight = 2, kGameClimber = 3, kGameCaveflyer = 4, kGameChaser = 5, kGameJumper = 6, kNumGames = 7 };
 
 }  // namespace pg

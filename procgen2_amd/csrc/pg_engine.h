@@ -91,6 +91,7 @@ std::unique_ptr<Game> make_bossfight();
 std::unique_ptr<Game> make_climber();
 std::unique_ptr<Game> make_caveflyer();
 std::unique_ptr<Game> make_chaser();
+std::unique_ptr<Game> make_jumper();
 
 // Counter-based synthetic action shared with the oracle (oracle/pgo_api.cpp pgo_synthetic_action).
 PG_HD uint32_t mix32(uint32_t x) {

@@ -135,6 +135,33 @@ PG_D bool resolve_rotated(const Camera& cam, int tw, int th, int tex_off, float 
     return true;
 }
 
+// A raw SDL_RenderTextureRotated(renderer, texture, NULL, &dst, angle, NULL, SDL_FLIP_NONE) in screen space (jumper's
+// compass, jumper.cpp:485-508): whole texture as source, float destination rectangle, `deg` degrees about its centre.
+PG_D bool resolve_screen(int tw, int th, int tex_off, float dx, float dy, float dw, float dh, double deg, Blit& out) {
+    if (!(dw >= 1.0f && dh >= 1.0f && dw < 32768.0f && dh < 32768.0f)) return false;
+    if (!(dx > -32768.0f && dx < 32768.0f && dy > -32768.0f && dy < 32768.0f)) return false;
+    out.dx = static_cast<int>(dx);
+    out.dy = static_cast<int>(dy);
+    out.dw = static_cast<int>(dw);
+    out.dh = static_cast<int>(dh);
+    out.sx = 0;
+    out.sy = 0;
+    out.sw = tw;
+    out.sh = th;
+    out.tex_off = tex_off;
+    out.tex_w = tw;
+    out.flip_mod = 255;
+    out.rot_sn = 0;
+    out.rot_cs = 65536;
+    if (deg != 0.0) {
+        const float theta = static_cast<float>(deg * (3.14159265358979323846 / 180.0));
+        out.rot_sn = static_cast<int>(floor(static_cast<double>(sc_sinf(theta)) * 65536.0 + 0.5));
+        out.rot_cs = static_cast<int>(floor(static_cast<double>(sc_cosf(theta)) * 65536.0 + 0.5));
+        out.flip_mod |= kRotated;
+    }
+    return true;
+}
+
 // Raster spec S6: all lanes execute one rotated draw (wave-uniform).  Scans the same square as the oracle.
 PG_D void wave_blit_rotated(uint32_t* fb, const AtlasView& atlas, const Blit& b, int lane) {
     int reach = 1;

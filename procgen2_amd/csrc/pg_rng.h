@@ -140,9 +140,11 @@ __device__ inline float wave_rng_real(uint32_t* x, float a, float b, int lane) {
     return canonical_of(wave_mt_next(x, lane)) * (b - a) + a;
 }
 
-// `count` consecutive draws of uniform_real_distribution<float>(0,1)(rng) < 0.5f by one wavefront: out[k] = 1 when
-// the k-th draw is below one half.  Leaves the stream where `count` calls of rng_real would.
-__device__ inline void wave_coin_flips(uint32_t* x, uint8_t* out, int count, int lane) {
+// `count` consecutive draws of uniform_real_distribution<float>(0,1)(rng) by one wavefront: f(k, value) is called
+// once for every k in [0, count) by whichever lane owns that draw.  Leaves the stream where `count` calls of
+// rng_real(x, 0, 1) would.  The caller needs a barrier before other lanes read what f stored.
+template <class F>
+__device__ inline void wave_draws(uint32_t* x, int count, int lane, F f) {
     int done = 0;
     while (done < count) {
         int idx = static_cast<int>(x[kMtN]);
@@ -152,12 +154,16 @@ __device__ inline void wave_coin_flips(uint32_t* x, uint8_t* out, int count, int
             idx = 0;
         }
         const int take = (kMtN - idx) < (count - done) ? (kMtN - idx) : (count - done);
-        for (int k = lane; k < take; k += 64)
-            out[done + k] = (canonical_of(mt_temper(x[idx + k])) * (1.0f - 0.0f) + 0.0f) < 0.5f ? 1 : 0;
+        for (int k = lane; k < take; k += 64) f(done + k, canonical_of(mt_temper(x[idx + k])) * (1.0f - 0.0f) + 0.0f);
         if (lane == 0) x[kMtN] = static_cast<uint32_t>(idx + take);
         __syncthreads();
         done += take;
     }
+}
+
+// out[k] = 1 when the k-th of `count` draws is below one half.
+__device__ inline void wave_coin_flips(uint32_t* x, uint8_t* out, int count, int lane) {
+    wave_draws(x, count, lane, [&](int k, float v) { out[k] = v < 0.5f ? 1 : 0; });
 }
 #endif
 

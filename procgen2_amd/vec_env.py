@@ -16,7 +16,7 @@ import torch
 
 from . import lib as pglib
 
-GAMES = ("coinrun", "maze", "bossfight", "climber", "caveflyer", "chaser")
+GAMES = ("coinrun", "maze", "bossfight", "climber", "caveflyer", "chaser", "jumper")
 
 
 def shard_range(total_envs, world_size, rank):

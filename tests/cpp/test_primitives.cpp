@@ -12,6 +12,7 @@
 #include "pg_geom.h"
 #include "pg_order.h"
 #include "pg_rng.h"
+#include "pg_atan2.h"
 #include "pg_sincos.h"
 
 static int fails = 0;
@@ -247,8 +248,56 @@ static void test_sincos() {
     std::printf("OK sincos\n");
 }
 
+// pg_atan2.h against the process's libm (what the reference's std::atan2(float, float) calls).
+static void test_atan2() {
+    std::mt19937 rng(99);
+    auto bits = [](float f) {
+        uint32_t u;
+        std::memcpy(&u, &f, 4);
+        return u;
+    };
+    long checked = 0;
+    auto check = [&](float y, float x) {
+        const float want = atan2f(y, x), got = pg::at_atan2f(y, x);
+        if (bits(want) != bits(got) && !(want != want && got != got)) {
+            std::printf("FAIL atan2f(%a, %a): libm %a twin %a\n", y, x, want, got);
+            std::exit(1);
+        }
+        checked++;
+    };
+    std::uniform_real_distribution<float> world(-40.0f, 40.0f);
+    for (int i = 0; i < 4000000; i++) check(world(rng), world(rng));  // to_goal vectors of a 40×40 level
+    for (int i = 0; i < 4000000; i++) {  // arbitrary bit patterns: every branch incl. inf / nan / denormals
+        uint32_t a = rng(), b = rng();
+        float y, x;
+        std::memcpy(&y, &a, 4);
+        std::memcpy(&x, &b, 4);
+        check(y, x);
+    }
+    const float specials[] = {0.0f, -0.0f, 1.0f, -1.0f, 0.4375f, 0.6875f, 1.1875f, 2.4375f, 1e-10f, 3e38f, 1e-40f,
+                              INFINITY, -INFINITY, 0.5f, 2.0f, 33554432.0f, 67108864.0f};
+    for (float y : specials)
+        for (float x : specials) {
+            check(y, x);
+            check(-y, x);
+            check(y, -x);
+        }
+    for (int i = 0; i < 2000000; i++) {  // atanf alone, dense around the interval boundaries
+        uint32_t a = rng();
+        float v;
+        std::memcpy(&v, &a, 4);
+        const float want = atanf(v), got = pg::at_atanf(v);
+        if (bits(want) != bits(got) && !(want != want && got != got)) {
+            std::printf("FAIL atanf(%a): libm %a twin %a\n", v, want, got);
+            std::exit(1);
+        }
+    }
+    std::printf("OK atan2 (%ld pairs)\n", checked);
+}
+
 int main() {
     test_sincos();
+    test_atan2();
     test_blend();
     test_mt();
     test_distributions();

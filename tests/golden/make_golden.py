@@ -18,7 +18,8 @@ CASES = {"coinrun": [(123, 96), (7, 96), (4294967291, 48)], "maze": [(123, 96), 
          "bossfight": [(123, 120), (7, 120)],
          "climber": [(123, 120), (7, 120)],
          "caveflyer": [(123, 120), (7, 120)],
-         "chaser": [(123, 120), (7, 120)]}
+         "chaser": [(123, 120), (7, 120)],
+         "jumper": [(123, 120), (7, 120)]}
 
 if __name__ == "__main__":
     out = {g: {"%d:%d" % (seed, steps): _frame_crcs(g, seed, steps) for seed, steps in cases}

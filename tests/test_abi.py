@@ -27,7 +27,7 @@ def test_vec_header_symbols_exported(engine_lib):
         assert hasattr(engine_lib, n), n
 
 
-@pytest.mark.parametrize("libname", ["libprocgen2_hip.so", "libCoinRun.so", "libMaze.so", "libBossFight.so", "libClimber.so", "libCaveFlyer.so", "libChaser.so"])
+@pytest.mark.parametrize("libname", ["libprocgen2_hip.so", "libCoinRun.so", "libMaze.so", "libBossFight.so", "libClimber.so", "libCaveFlyer.so", "libChaser.so", "libJumper.so"])
 def test_cenv_header_symbols_exported(engine_lib, libname):
     L = ctypes.CDLL(os.path.join(pglib.LIB_DIR, libname))
     funcs = _declared("procgen2_cenv.h", "cenv_")
@@ -71,6 +71,7 @@ def test_unknown_game_rejected(engine_lib):
     assert engine_lib.pgv_game_id(b"climber") == 3
     assert engine_lib.pgv_game_id(b"caveflyer") == 4
     assert engine_lib.pgv_game_id(b"chaser") == 5
+    assert engine_lib.pgv_game_id(b"jumper") == 6
     assert engine_lib.pgv_game_name(99) is None
 
 

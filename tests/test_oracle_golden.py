@@ -12,7 +12,7 @@ import pytest
 import oracle_util
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
-IMPLEMENTED = ("coinrun", "maze", "bossfight", "climber", "caveflyer", "chaser")
+IMPLEMENTED = ("coinrun", "maze", "bossfight", "climber", "caveflyer", "chaser", "jumper")
 
 with open(os.path.join(GOLDEN, "appendix_c.json")) as f:
     APPENDIX_C = json.load(f)

@@ -56,7 +56,7 @@ def test_coinrun_lockstep_256_envs():
     assert resets > 0, "no episode ended: the auto-reset path was not exercised"
 
 
-@pytest.mark.parametrize("game", ["coinrun", "maze", "bossfight", "climber", "caveflyer", "chaser"])
+@pytest.mark.parametrize("game", ["coinrun", "maze", "bossfight", "climber", "caveflyer", "chaser", "jumper"])
 def test_row_composer_equals_draw_list_replay(game):
     """The fused background+tile row composer (pg_render.h compose_rows) against the one-blit-at-a-time replay of
     the reference's draw list, the same engine in both modes, every byte of 512 envs over 150 steps."""
@@ -134,7 +134,8 @@ def test_caveflyer_lockstep_with_fire():
     ora.close()
 
 
-@pytest.mark.parametrize("game,steps", [("caveflyer", 200), ("maze", 560), ("coinrun", 260), ("climber", 200)])
+@pytest.mark.parametrize("game,steps", [("caveflyer", 200), ("maze", 560), ("coinrun", 260), ("climber", 200),
+                                        ("jumper", 200)])
 def test_level_prefetch_equals_synchronous_generation(game, steps):
     """pg_prefetch.h: levels generated ahead of time on the side stream and installed at reset against the same engine
     with prefetch off (every reset generates inside the step) — every byte of 2048 envs, over enough steps that both
@@ -150,7 +151,7 @@ def test_level_prefetch_equals_synchronous_generation(game, steps):
         assert np.array_equal(da, ds) and np.array_equal(ra, rs), s
         assert np.array_equal(oa, os_), s
         ends += int(da.sum())
-    assert ends > 100 or game == "climber", ends
+    assert ends > 100 or game in ("climber", "jumper"), ends
     ahead.close()
     sync.close()
 
@@ -180,6 +181,32 @@ def test_chaser_lockstep_steering_actions():
                 assert np.array_equal(eng.state(e, 1024).view(np.uint32), ora.state(e, 1024).view(np.uint32)), (s, e)
                 assert np.array_equal(eng.tiles(e), ora.tiles(e)), (s, e)
     assert ends > 50 and rew > 50.0, (ends, rew)
+    eng.close()
+    ora.close()
+
+
+def test_jumper_lockstep_jump_heavy_actions():
+    # Jump-biased actions: double jumps with cooldown, spikes (deaths -> maze/cave generator on the auto-reset),
+    # carrots (+10), dust particles (alpha blits) and the compass HUD (screen-space blits, glibc-exact atan2f).
+    n = 160
+    eng, ora = EngineVec("jumper", n, seed_base=61), OracleVec("jumper", n, seed_base=61)
+    assert np.array_equal(eng.reset(), ora.reset_obs())
+    idx = np.arange(n)
+    ends, rew = 0, 0.0
+    for s in range(800):
+        a = _actions(ora.L, 5, s, n)
+        a = np.where((idx + s) % 5 < 3, (a % 3) * 3 + 2, a).astype(np.int32)
+        oe, re_, de = eng.step(a)
+        oo, ro, do = ora.step(a)
+        assert np.array_equal(de, do) and np.array_equal(re_.view(np.uint32), ro.view(np.uint32)), s
+        assert np.array_equal(oe, oo), s
+        ends += int(do.sum())
+        rew += float(ro.sum())
+        if s % 160 == 0:
+            for e in range(0, n, 20):
+                assert np.array_equal(eng.state(e).view(np.uint32), ora.state(e).view(np.uint32)), (s, e)
+                assert np.array_equal(eng.tiles(e), ora.tiles(e)), (s, e)
+    assert ends > 40, (ends, rew)
     eng.close()
     ora.close()
 
@@ -225,7 +252,7 @@ def test_maze_out_of_range_actions_follow_reference_quirk():
     ora.close()
 
 
-@pytest.mark.parametrize("game", ["coinrun", "maze", "bossfight", "climber", "caveflyer", "chaser"])
+@pytest.mark.parametrize("game", ["coinrun", "maze", "bossfight", "climber", "caveflyer", "chaser", "jumper"])
 def test_reset_with_seed_option_and_mask(game):
     """cenv_reset's "seed" option (coinrun.cpp:313-317) per env, and masked resets leaving other envs untouched."""
     n = 16
@@ -284,7 +311,7 @@ def test_cenv_abi_single_env_matches_reference_loop():
     `if term: reset()` — exactly game_test.py:36-40 — against the oracle driven the same way."""
     for libname, game in (("libCoinRun.so", "coinrun"), ("libMaze.so", "maze"), ("libBossFight.so", "bossfight"),
                           ("libClimber.so", "climber"), ("libCaveFlyer.so", "caveflyer"),
-                          ("libChaser.so", "chaser")):
+                          ("libChaser.so", "chaser"), ("libJumper.so", "jumper")):
         env = pgcenv.CEnv(os.path.join(pglib.LIB_DIR, libname), options={"seed": 123})
         assert list(env.observation_space) == ["screen"] and list(env.action_space) == ["action"]
         assert list(env.action_space["action"].nvec) == [15]

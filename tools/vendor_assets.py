@@ -107,8 +107,19 @@ def chaser():
            ["topdown_backgrounds/%s.png" % n for n in floors]
 
 
+def jumper():
+    # games/jumper/jumper.cpp:59-109 (= coinrun's backdrops), :297-299, tilemap.cpp:13-25, common_systems.cpp:50-55, :250
+    tiles = ["tileBlue_05", "tileGreen_05", "tileYellow_06", "tileBrown_06", "tileBlue_08", "tileGreen_08",
+             "tileYellow_09", "tileBrown_09"]
+    misc = ["spikeMan_stand", "carrot", "bunny2_ready", "bunny2_jump", "bunny2_walk1", "bunny2_walk2", "iconCircle_white"]
+    custom = ["jumper_compass_circle", "jumper_compass_needle", "jumper_compass_bar"]
+    backs = [p for p in coinrun() if p.startswith("platform_backgrounds")]
+    return ["platformer/%s.png" % n for n in tiles] + ["misc_assets/%s.png" % n for n in misc] + \
+           ["custom/%s.png" % n for n in custom] + backs
+
+
 GAMES = {"coinrun": coinrun, "maze": maze, "bossfight": bossfight, "climber": climber, "caveflyer": caveflyer,
-         "chaser": chaser}
+         "chaser": chaser, "jumper": jumper}
 
 
 def main():
