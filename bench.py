@@ -2,6 +2,7 @@
 """Benchmark of the hot path: coinrun, 65 536 envs per GPU, synthetic random actions, observations in HBM.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--game coinrun]
+    python bench.py --workload mixed [--gather]      # BASELINE.json configs[4]: all seven games, envs split 7 ways
 
 One "step" = one pass of the hot path over the whole batch: the logic kernel (auto-reset or 4 physics
 sub-steps per env) + the render kernel (64×64×3 observation per env into the contiguous slab).  Inputs
@@ -72,6 +73,11 @@ def main():
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--game", default="coinrun")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["single", "mixed"], default="single",
+                    help="mixed = all seven games on every GPU, --envs split seven ways (the last game takes the "
+                         "remainder), one HIP stream per game")
+    ap.add_argument("--gather", action="store_true",
+                    help="mixed workload only: rooted RCCL gather of obs/reward/done to rank 0 after every step")
     a = ap.parse_args()
 
     import torch
@@ -92,6 +98,8 @@ def main():
               file=sys.stderr)
 
     run_seed = 0
+    if a.workload == "mixed":
+        return mixed(a, torch, ProcgenVecEnv, distributed, world, rank, local_rank, n_gpus, run_seed)
     env = ProcgenVecEnv(a.game, a.envs, device=local_rank, seed_base=1, env_offset=rank * a.envs)
     env.reset()
     env.timed_steps(max(1, a.warmup), run_seed)  # untimed warm-up steps (same code path as the timed ones)
@@ -150,6 +158,74 @@ def main():
         if n_gpus == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.game, run_seed)
         print(json.dumps(line), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+def mixed(a, torch, ProcgenVecEnv, distributed, world, rank, local_rank, n_gpus, run_seed):
+    """BASELINE.json configs[4]: the seven games side by side on every GPU.  Each game is its own vector env on its own
+    HIP stream (they overlap on the device); the envs of a game are sharded over the ranks by global index like the
+    single-game workload.  No collective unless --gather."""
+    from procgen2_amd.vec_env import GAMES
+    if distributed:
+        import torch.distributed as dist
+    base = a.envs // len(GAMES)
+    counts = [base] * (len(GAMES) - 1) + [a.envs - base * (len(GAMES) - 1)]
+    envs = []
+    for game, count in zip(GAMES, counts):
+        with torch.cuda.stream(torch.cuda.Stream(device=local_rank)):
+            envs.append(ProcgenVecEnv(game, count, device=local_rank, seed_base=1, env_offset=rank * count))
+    for e in envs:
+        e.reset()
+
+    def run(steps):
+        for _ in range(steps):
+            for e in envs:
+                e.step_synthetic(run_seed)
+            if a.gather and distributed:
+                for e in envs:
+                    e.sync()
+                    e.gather(dst=0)
+        for e in envs:
+            e.sync()
+
+    def fence():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run(max(1, a.warmup))
+    fence()
+    t0 = time.perf_counter()
+    run(a.steps)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    fence()
+    for e in envs:
+        e.close()
+    if rank == 0:
+        value = float(n_gpus) * a.envs * a.steps / elapsed
+        achieved = ALGO_BYTES_PER_ENV_STEP * a.envs / (elapsed / a.steps) / 1e9
+        print(json.dumps({
+            "metric": "env-steps/sec, all 7 games mixed, 64x64x3 obs",
+            "value": value, "unit": "env-steps/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/f32", "data": "synthetic",
+            "config": {"workload": "all seven games, %d envs per GPU split %s, one stream per game, uniform random "
+                                   "actions from a device counter hash, next-step auto-reset" % (a.envs, counts),
+                       "games": list(GAMES), "envs_per_gpu": a.envs, "obs": "64x64x3 uint8",
+                       "parallelism": "env-shard x%d, %s" % (n_gpus, "rooted RCCL gather to rank 0 every step"
+                                                             if a.gather and distributed else "no collective")},
+            "obs_write_GBps": value * 12288 / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "whole step, all games (wall clock, not one kernel)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": None},
+        }), flush=True)
     if distributed:
         dist.destroy_process_group()
 

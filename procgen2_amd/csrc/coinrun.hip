@@ -101,10 +101,14 @@ struct State {
 };
 
 // scratch rows: the agent after each of the 4 sub-steps, then one word of flags
-enum { SC_AX = 0, SC_AY = 4, SC_AVX = 8, SC_AVY = 12, SC_PHASE = 16, SC_BITS = 20, SC_HAZARD = 21, SC_COUNT = 22 };
+enum {
+    SC_AX = 0, SC_AY = 4, SC_AVX = 8, SC_AVY = 12, SC_PHASE = 16, SC_BITS = 20, SC_HAZARD = 21, SC_REDO = 22, SC_COUNT = 23
+};
 // SC_BITS (int): per sub-step ss: ground 1<<ss, forward 1<<(4+ss), lava 1<<(8+ss), coin 1<<(12+ss); bit 31: this env
 // stepped (as opposed to: performed its auto-reset) in the current vector step.
 // SC_HAZARD (int): bit ss set by entity_kernel when a hazard overlaps the agent in sub-step ss.
+// SC_REDO (int): n > 0 — the step ended after n < 4 sub-steps; the entities (advanced by four, optimistically) are
+// recomputed for n sub-steps from the untouched half of the table by the env's render wavefront, one lane per entity.
 
 PG_D float& SF(const State& s, int field, int env) { return s.f[size_t(field) * s.n + env]; }
 PG_D int32_t& SI(const State& s, int field, int env) { return s.i[size_t(field) * s.n + env]; }
@@ -718,22 +722,14 @@ __global__ void __launch_bounds__(64) resolve_kernel(State s, StepIO io) {
     if (bits >= 0) return;  // reset this step; agent_kernel already wrote reward/done/pending
     const int flags = SI(s, I_FLAGS, env);
     const int src = (flags & kFlagBuf) ? 1 : 0;
-    int hazard = SCI(s, SC_HAZARD, env);
+    const int hazard = SCI(s, SC_HAZARD, env);
     const int lava = (bits >> 8) & 15, coin = (bits >> 12) & 15;
-    int ending = hazard | lava | coin;
-    int last = ending ? __builtin_ctz(ending) : 3;  // first terminating sub-step, or all four took place
-    if (last < 3) {
-        // rare: fewer than four sub-steps happened — redo this env's entities from the untouched half
-        float bx[4], by[4];
-#pragma unroll
-        for (int ss = 0; ss < 4; ss++) {
-            bx[ss] = SC(s, SC_AX + ss, env) + -0.5f;
-            by[ss] = SC(s, SC_AY + ss, env) + -1.0f;
-        }
-        const int n_ent = SI(s, I_NENT, env);
-        hazard = 0;
-        for (int e = 0; e < n_ent; e++) hazard |= entity_step(s, env, e, src, last + 1, bx, by);
-    }
+    const int ending = hazard | lava | coin;
+    const int last = ending ? __builtin_ctz(ending) : 3;  // first terminating sub-step, or all four took place
+    // Rare: fewer than four sub-steps happened.  The hazard bits of the sub-steps that did happen are already right
+    // (entities do not react to the agent), so reward/done need nothing more; the entity table does, and that is left
+    // to the render wavefront of this env (SC_REDO) instead of 36 serial entity updates on this one lane.
+    SCI(s, SC_REDO, env) = last < 3 ? last + 1 : 0;
     const bool alive = !(((hazard | lava) >> last) & 1);
     const bool got_coin = ((coin >> last) & 1) != 0;
     const float ax = SC(s, SC_AX + last, env), ay = SC(s, SC_AY + last, env);
@@ -775,6 +771,25 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
     const uint8_t* tiles = s.tiles + size_t(env) * (W * H);
     const DescRegs descs = DescRegs::load(atlas, lane);  // the whole descriptor table, two entries per lane
     Blit mine;
+
+    {   // the step ended after fewer than four sub-steps (resolve_kernel): bring the entity table to that sub-step,
+        // one lane per entity, from the half of the table the optimistic pass left untouched
+        const int redo = SCI(s, SC_REDO, env);
+        if (redo) {
+            if (lane < n_ent) {
+                float bx[4], by[4];
+#pragma unroll
+                for (int ss = 0; ss < 4; ss++) {
+                    bx[ss] = SC(s, SC_AX + ss, env) + -0.5f;
+                    by[ss] = SC(s, SC_AY + ss, env) + -1.0f;
+                }
+                entity_step(s, env, lane, 1 - buf, redo, bx, by);
+            }
+            if (lane == 0) SCI(s, SC_REDO, env) = 0;
+            __threadfence();
+            __syncthreads();
+        }
+    }
 
     // The per-lane inputs of the sprite pass (one draw per lane: particles, then sprites, then the agent) are
     // requested now so their memory latency hides behind the background/tile composition.
