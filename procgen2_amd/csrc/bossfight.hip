@@ -578,11 +578,12 @@ __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actio
 }
 
 // render_game(true) (bossfight.cpp:401-424): one wavefront per env.
-__global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
+__global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
                                                     int flags) {
     const int env = blockIdx.x;
     if (mask && !mask[env]) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, half = threadIdx.x >> 6;  // two wavefronts per env (pg_render.h)
+    constexpr int halves = 2;
     __shared__ uint32_t fb[kFbWords];
     __shared__ ComposeLds<1> L;  // no tile layer: the composer only lays down the background
 
@@ -607,15 +608,15 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
     }
     bool composed = false;
     if (!(flags & 1)) {
-        compose_spans(L, cam, 0, 0, 0, 0, 1, 1, 1.0f, lane);
+        compose_spans(L, cam, 0, 0, 0, 0, 1, 1, 1.0f, lane, 0, half, halves);
         if (lane == 0) L.base[0] = static_cast<int32_t>(kNoTexel);
         __syncthreads();
-        composed = compose_rows(fb, L, atlas, bg, has_bg, 0, 0, 1, lane, flags);
+        composed = compose_rows(fb, L, atlas, bg, has_bg, 0, 0, 1, lane, flags, half, halves);
     }
     if (!composed) {
-        wave_clear(fb, lane);
+        wave_clear(fb, lane, half, halves);
         mine = bg;
-        wave_replay(fb, atlas, mine, has_bg ? 1ull : 0ull, lane);
+        wave_replay(fb, atlas, mine, has_bg ? 1ull : 0ull, lane, half, halves);
     }
 
     // negative-z sprites: none.  System_Mob_AI::render (common_systems.cpp:392-450): boss bullets, rotated
@@ -640,7 +641,7 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
             has = resolve_rotated(cam, d.y, d.z, d.x, px * kUnitPx - size * d.y * 0.5f, py * kUnitPx - size * d.z * 0.5f,
                                   static_cast<float>(rot + kPi * 0.5f), size, 1.0f, mine);
         }
-        wave_replay(fb, atlas, mine, __ballot(has), lane);
+        wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
     }
     // second list, one draw per lane: boss ship, shield, explosions, barriers (positive-z sprites), agent bullets, agent
     {
@@ -709,9 +710,10 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
                                    size, alpha, false, false, mine);
             }
         }
-        wave_replay(fb, atlas, mine, __ballot(has), lane);
+        wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
     }
-    wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane);
+    __syncthreads();
+    wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane, half, halves);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -789,7 +791,7 @@ class BossfightGame final : public Game {
                            env_offset, io);
     }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
-        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(64), 0, st, s_, atlas_, mask, io, debug_flags);
+        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags);
     }
     // Same layout as oracle/pgo_bossfight.cpp Bossfight::dump_state.
     int dump_state(hipStream_t st, int env, float* out, int cap) override {

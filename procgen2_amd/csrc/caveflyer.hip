@@ -510,11 +510,12 @@ __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actio
 }
 
 // render_game(true) (caveflyer.cpp:413-440): one wavefront per env.
-__global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
+__global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
                                                     int flags) {
     const int env = blockIdx.x;
     if (mask && !mask[env]) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, half = threadIdx.x >> 6;  // two wavefronts per env (pg_render.h)
+    constexpr int halves = 2;
     __shared__ uint32_t fb[kFbWords];
     constexpr int kGrid = 16;  // 64 px / 8 px per tile → at most 10 columns/rows in view
     __shared__ ComposeLds<kGrid> L;
@@ -578,21 +579,21 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
 
     bool composed = false;
     if (!(flags & 1) && cols <= kGrid && rows <= kGrid) {
-        compose_spans<kGrid, 16>(L, cam, x0, y0, cols, rows, wall_d.y, wall_d.z, kUnitPx / wall_d.y, lane);
+        compose_spans<kGrid, 16>(L, cam, x0, y0, cols, rows, wall_d.y, wall_d.z, kUnitPx / wall_d.y, lane, 0, half, halves);
 #pragma unroll
-        for (int k = 0; k < kGrid * kGrid / 64; k++) {
+        for (int k = half; k < kGrid * kGrid / 64; k += halves) {
             const int cell = k * 64 + lane;
             const int r = cell / kGrid, c = cell % kGrid;
             const int t = (c < cols && r < rows) ? Win::direct(tiles, x0 + c, y0 + r) : kEmpty;
             L.base[cell] = (t == kEmpty) ? static_cast<int32_t>(kNoTexel) : wall_d.x * 4;
         }
         __syncthreads();
-        composed = compose_rows(fb, L, atlas, bg, has_bg, cols, rows, wall_d.y, lane, flags);
+        composed = compose_rows(fb, L, atlas, bg, has_bg, cols, rows, wall_d.y, lane, flags, half, halves);
     }
     if (!composed) {  // draw-list replay (tilemap.cpp:291-302)
-        wave_clear(fb, lane);
+        wave_clear(fb, lane, half, halves);
         mine = bg;
-        wave_replay(fb, atlas, mine, has_bg ? 1ull : 0ull, lane);
+        wave_replay(fb, atlas, mine, has_bg ? 1ull : 0ull, lane, half, halves);
         for (int base = 0; base < cells; base += 64) {
             const int cell = base + lane;
             bool has = false;
@@ -603,7 +604,7 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
                     has = resolve_draw(cam, wall_d.y, wall_d.z, wall_d.x, x * kUnitPx, y * kUnitPx, kUnitPx / wall_d.y,
                                        1.0f, false, false, mine);
             }
-            wave_replay(fb, atlas, mine, __ballot(has), lane);
+            wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
         }
     }
 
@@ -620,7 +621,7 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
             has = resolve_rotated(cam, d.y, d.z, d.x, (puff_x + puff_dx * shift) * kUnitPx - size * d.y * 0.5f,
                                   (puff_y + puff_dy * shift) * kUnitPx - size * d.z * 0.5f, puff_rot, size, alpha, mine);
         }
-        wave_replay(fb, atlas, mine, __ballot(has), lane);
+        wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
     }
     {  // positive-z sprites (common_systems.cpp:26-48): goal, meteors, targets, enemies
         const int4 d = descs.at(kTexKind + spr_kind);
@@ -630,7 +631,7 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
             has = resolve_draw(cam, d.y, d.z, d.x, (spr_x + -0.4f) * kUnitPx, (spr_y + -0.4f) * kUnitPx,
                                scale * kUnitPx / d.y, 1.0f, false, false, mine);
         }
-        wave_replay(fb, atlas, mine, __ballot(has), lane);
+        wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
     }
     {  // System_Agent::render (common_systems.cpp:291-327): bullets newest first, then the ship
         int want_tex = kTexShip;
@@ -646,9 +647,10 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
             has = resolve_rotated(cam, d.y, d.z, d.x, shot_x * kUnitPx - size * d.y * 0.5f,
                                   shot_y * kUnitPx - size * d.z * 0.5f, static_cast<float>(shot_rot + kPi * 0.5f), size,
                                   1.0f, mine);
-        wave_replay(fb, atlas, mine, __ballot(has), lane);
+        wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
     }
-    wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane);
+    __syncthreads();
+    wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane, half, halves);
 }
 
 class CaveflyerGame final : public Game {
@@ -732,7 +734,7 @@ class CaveflyerGame final : public Game {
                            env_offset, io);
     }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
-        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(64), 0, st, s_, atlas_, mask, io, debug_flags);
+        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags);
     }
     // Same layout as oracle/pgo_caveflyer.cpp Caveflyer::dump_state.
     int dump_state(hipStream_t st, int env, float* out, int cap) override {

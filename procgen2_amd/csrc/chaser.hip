@@ -554,11 +554,12 @@ __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actio
 }
 
 // render_game(true) (chaser.cpp:390-416): one wavefront per env.
-__global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
+__global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
                                                     int flags) {
     const int env = blockIdx.x;
     if (mask && !mask[env]) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, half = threadIdx.x >> 6;  // two wavefronts per env (pg_render.h)
+    constexpr int halves = 2;
     __shared__ uint32_t fb[kFbWords];
     constexpr int kGrid = 16;  // 11 tiles + the border cells of the inclusive window
     __shared__ ComposeLds<kGrid> L;
@@ -591,21 +592,21 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
 
     bool composed = false;
     if (!(flags & 1) && cols <= kGrid && rows <= kGrid) {
-        compose_spans<kGrid, 16>(L, cam, x0, y0, cols, rows, wall_d.y, wall_d.z, kUnitPx / wall_d.y, lane);
+        compose_spans<kGrid, 16>(L, cam, x0, y0, cols, rows, wall_d.y, wall_d.z, kUnitPx / wall_d.y, lane, 0, half, halves);
 #pragma unroll
-        for (int k = 0; k < kGrid * kGrid / 64; k++) {
+        for (int k = half; k < kGrid * kGrid / 64; k += halves) {
             const int cell = k * 64 + lane;
             const int r = cell / kGrid, c = cell % kGrid;
             const bool wall = c < cols && r < rows && tile_at(tiles, x0 + c, H - 1 - (y0 + r)) == kWall;
             L.base[cell] = wall ? wall_d.x * 4 : static_cast<int32_t>(kNoTexel);
         }
         __syncthreads();
-        composed = compose_rows(fb, L, atlas, bg, has_bg, cols, rows, wall_d.y, lane, flags);
+        composed = compose_rows(fb, L, atlas, bg, has_bg, cols, rows, wall_d.y, lane, flags, half, halves);
     }
     if (!composed) {  // draw-list replay (tilemap.cpp:256-266)
-        wave_clear(fb, lane);
+        wave_clear(fb, lane, half, halves);
         mine = bg;
-        wave_replay(fb, atlas, mine, has_bg ? 1ull : 0ull, lane);
+        wave_replay(fb, atlas, mine, has_bg ? 1ull : 0ull, lane, half, halves);
         for (int base = 0; base < cells; base += 64) {
             const int cell = base + lane;
             bool has = false;
@@ -616,7 +617,7 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
                     has = resolve_draw(cam, wall_d.y, wall_d.z, wall_d.x, x * kUnitPx, y * kUnitPx, kUnitPx / wall_d.y,
                                        1.0f, false, false, mine);
             }
-            wave_replay(fb, atlas, mine, __ballot(has), lane);
+            wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
         }
     }
     // every sprite has z = 0: the positive pass (common_systems.cpp:41-63), then the agent (:446-460)
@@ -651,9 +652,10 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
             has = resolve_draw(cam, d.y, d.z, d.x, (x + -0.5f) * kUnitPx, (y + -0.5f) * kUnitPx, scale, 1.0f, false, false,
                                mine);
         }
-        wave_replay(fb, atlas, mine, __ballot(has), lane);
+        wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
     }
-    wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane);
+    __syncthreads();
+    wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane, half, halves);
 }
 
 class ChaserGame final : public Game {
@@ -726,7 +728,7 @@ class ChaserGame final : public Game {
                            env_offset, io);
     }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
-        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(64), 0, st, s_, atlas_, mask, io, debug_flags);
+        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags);
     }
     // Same layout as oracle/pgo_chaser.cpp Chaser::dump_state.
     int dump_state(hipStream_t st, int env, float* out, int cap) override {

@@ -383,11 +383,12 @@ __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actio
 }
 
 // render_game(true) (climber.cpp:431-459): one wavefront per env.
-__global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
+__global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
                                                     int flags) {
     const int env = blockIdx.x;
     if (mask && !mask[env]) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, half = threadIdx.x >> 6;  // two wavefronts per env (pg_render.h)
+    constexpr int halves = 2;
     __shared__ uint32_t fb[kFbWords];
     constexpr int kGrid = 32;  // 64 px / 3.2 px per tile = 20 tiles → at most 22 columns/rows in view
     __shared__ ComposeLds<kGrid> L;
@@ -434,9 +435,9 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
     // two-texture mode; a cap taller than the body, or of another width, would take the draw-list replay.
     const bool two = top_d.z != mid_d.z;
     if (!(flags & 1) && cols <= kGrid && rows <= kGrid && top_d.y == mid_d.y && top_d.z <= mid_d.z) {
-        compose_spans(L, cam, x0, y0, cols, rows, mid_d.y, mid_d.z, kUnitPx / mid_d.y, lane, two ? top_d.z : 0);
+        compose_spans(L, cam, x0, y0, cols, rows, mid_d.y, mid_d.z, kUnitPx / mid_d.y, lane, two ? top_d.z : 0, half, halves);
 #pragma unroll
-        for (int k = 0; k < kGrid * kGrid / 64; k++) {
+        for (int k = half; k < kGrid * kGrid / 64; k += halves) {
             const int cell = k * 64 + lane;
             const int r = cell / kGrid, c = cell % kGrid;
             const int t = (c < cols && r < rows) ? Win::direct(tiles, x0 + c, y0 + r) : kEmpty;
@@ -444,13 +445,13 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
                                          : (t == kWallTop ? (top_d.x * 4) | (two ? 1 : 0) : mid_d.x * 4);
         }
         __syncthreads();
-        composed = two ? compose_rows<kGrid, true>(fb, L, atlas, bg, has_bg, cols, rows, mid_d.y, lane, flags)
-                       : compose_rows<kGrid, false>(fb, L, atlas, bg, has_bg, cols, rows, mid_d.y, lane, flags);
+        composed = two ? compose_rows<kGrid, true>(fb, L, atlas, bg, has_bg, cols, rows, mid_d.y, lane, flags, half, halves)
+                       : compose_rows<kGrid, false>(fb, L, atlas, bg, has_bg, cols, rows, mid_d.y, lane, flags, half, halves);
     }
     if (!composed) {  // draw-list replay (tilemap.cpp:172-198)
-        wave_clear(fb, lane);
+        wave_clear(fb, lane, half, halves);
         mine = bg;
-        wave_replay(fb, atlas, mine, has_bg ? 1ull : 0ull, lane);
+        wave_replay(fb, atlas, mine, has_bg ? 1ull : 0ull, lane, half, halves);
         for (int base = 0; base < cells; base += 64) {
             const int cell = base + lane;
             bool has = false;
@@ -464,7 +465,7 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
                                        mine);
                 }
             }
-            wave_replay(fb, atlas, mine, __ballot(has), lane);
+            wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
         }
     }
 
@@ -497,9 +498,10 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
             has = resolve_draw(cam, d.y, d.z, d.x, px * kUnitPx, py * kUnitPx, 0.8f * kUnitPx / d.y, 1.0f,
                                (sflags & kFlagForward) == 0, false, mine);
         }
-        wave_replay(fb, atlas, mine, __ballot(has), lane);
+        wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
     }
-    wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane);
+    __syncthreads();
+    wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane, half, halves);
 }
 
 class ClimberGame final : public Game {
@@ -586,7 +588,7 @@ class ClimberGame final : public Game {
                            env_offset, io);
     }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
-        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(64), 0, st, s_, atlas_, mask, io, debug_flags);
+        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags);
     }
     // Same layout as oracle/pgo_climber.cpp Climber::dump_state.
     int dump_state(hipStream_t st, int env, float* out, int cap) override {

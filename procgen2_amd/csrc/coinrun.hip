@@ -751,11 +751,14 @@ __global__ void __launch_bounds__(64) resolve_kernel(State s, StepIO io) {
 // render_game(true) (coinrun.cpp:443-470): one wavefront per env.
 // flags bit 0: force the draw-list replay for background + tiles (fallback path; parity tests run both).
 // Higher bits are timing experiments only (tools/ablate_render.py) and change the picture.
-__global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
-                                                    int flags) {
+constexpr int kRenderWaves = 2;  // wavefronts per env (pg_render.h: two waves share one frame's LDS target)
+
+__global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, AtlasView atlas, const uint8_t* mask,
+                                                                   StepIO io, int flags) {
     const int env = blockIdx.x;
     if (mask && !mask[env]) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, half = threadIdx.x >> 6;
+    constexpr int halves = kRenderWaves;
     __shared__ uint32_t fb[kFbWords];
     constexpr int kGrid = 16;  // 64 px / 4.8 px per tile = 13.3 tiles → at most 15 columns/rows in view
     __shared__ ComposeLds<kGrid> L;
@@ -775,8 +778,9 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
     {   // the step ended after fewer than four sub-steps (resolve_kernel): bring the entity table to that sub-step,
         // one lane per entity, from the half of the table the optimistic pass left untouched
         const int redo = SCI(s, SC_REDO, env);
+        __syncthreads();  // every wave has read the flag before it is cleared
         if (redo) {
-            if (lane < n_ent) {
+            if (half == 0 && lane < n_ent) {
                 float bx[4], by[4];
 #pragma unroll
                 for (int ss = 0; ss < 4; ss++) {
@@ -785,7 +789,7 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
                 }
                 entity_step(s, env, lane, 1 - buf, redo, bx, by);
             }
-            if (lane == 0) SCI(s, SC_REDO, env) = 0;
+            if (threadIdx.x == 0) SCI(s, SC_REDO, env) = 0;
             __threadfence();
             __syncthreads();
         }
@@ -839,7 +843,7 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
 
     bool composed = false;
     if (!(flags & 5) && cols <= kGrid && rows <= kGrid) {
-        compose_spans(L, cam, x0, y0, cols, rows, tile_desc.y, tile_desc.z, kUnitPx / tile_desc.y, lane);
+        compose_spans(L, cam, x0, y0, cols, rows, tile_desc.y, tile_desc.z, kUnitPx / tile_desc.y, lane, 0, half, halves);
         // Texel offset of each tile kind's texture, one per lane (0..7), looked up with a cross-lane read:
         // lanes 0-3 = wall_top, wall_mid, lava_top, lava_mid (tile id - 1), lanes 4-7 = the four crates.
         int kind_tex = kTexCrate + ((lane - 4) & 3);
@@ -849,7 +853,7 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
         if (lane == 3) kind_tex = kTexLava;
         const int kind_base = descs.at(kind_tex).x;
 #pragma unroll
-        for (int k = 0; k < kGrid * kGrid / 64; k++) {  // the whole kGrid×kGrid table, 64 cells per pass
+        for (int k = half; k < kGrid * kGrid / 64; k += halves) {  // the whole kGrid×kGrid table, 64 cells per pass
             const int cell = k * 64 + lane;
             const int r = cell / kGrid, c = cell % kGrid;
             const int x = x0 + c, ty = H - 1 - (y0 + r);
@@ -861,13 +865,13 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
             L.base[cell] = (t == kEmpty) ? static_cast<int32_t>(kNoTexel) : off * 4;
         }
         __syncthreads();
-        composed = compose_rows(fb, L, atlas, bg, has_bg, cols, rows, tile_desc.y, lane, flags);
+        composed = compose_rows(fb, L, atlas, bg, has_bg, cols, rows, tile_desc.y, lane, flags, half, halves);
     }
     if (flags & 4) composed = true;  // (bit 2: timing experiment — no background/tiles at all)
     if (!composed) {  // draw-list replay of background and tiles (tilemap.cpp:294-321)
-        wave_clear(fb, lane);
+        wave_clear(fb, lane, half, halves);
         mine = bg;
-        wave_replay(fb, atlas, mine, has_bg ? 1ull : 0ull, lane);
+        wave_replay(fb, atlas, mine, has_bg ? 1ull : 0ull, lane, half, halves);
         for (int base = 0; base < cells; base += 64) {
             const int cell = base + lane;
             bool has = false;
@@ -898,7 +902,7 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
                                        mine);
                 }
             }
-            wave_replay(fb, atlas, mine, __ballot(has), lane);
+            wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
         }
     }
 
@@ -925,7 +929,7 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
                     const int e = EB(s, EB_SPARK_ORDER, m, env);
                     has = particle(SP(s, buf, 2, e, k, env), SP(s, buf, 0, e, k, env), SP(s, buf, 1, e, k, env), mine);
                 }
-                wave_replay(fb, atlas, mine, __ballot(has), lane);
+                wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
             }
         }
         // every lane asks for the descriptor it needs with a cross-lane read, so do that outside the branches
@@ -958,9 +962,10 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
             has = resolve_draw(cam, d.y, d.z, d.x, px * kUnitPx, py * kUnitPx, kUnitPx / d.y, 1.0f,
                                (sflags & kFlagForward) == 0, false, mine);
         }
-        wave_replay(fb, atlas, mine, __ballot(has), lane);
+        wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
     }
-    if (!(flags & 8)) wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane);
+    __syncthreads();
+    if (!(flags & 8)) wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane, half, halves);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1086,7 +1091,8 @@ class CoinrunGame final : public Game {
         hipLaunchKernelGGL(resolve_kernel, dim3(blocks()), dim3(64), 0, st, s_, io);
     }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
-        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(64), 0, st, s_, atlas_, mask, io, debug_flags);
+        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(64 * kRenderWaves), 0, st, s_, atlas_, mask, io,
+                           debug_flags);
     }
 
     // Same layout as oracle/pgo_coinrun.cpp Coinrun::dump_state.

@@ -509,11 +509,12 @@ __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actio
 }
 
 // render_game(true) (jumper.cpp:445-509): one wavefront per env.
-__global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
+__global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
                                                     int flags) {
     const int env = blockIdx.x;
     if (mask && !mask[env]) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, half = threadIdx.x >> 6;  // two wavefronts per env (pg_render.h)
+    constexpr int halves = 2;
     __shared__ uint32_t fb[kFbWords];
     constexpr int kGrid = 16;  // 64 px / 4.8 px per tile → at most 16 columns/rows in view
     __shared__ ComposeLds<kGrid> L;
@@ -555,9 +556,9 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
     bool composed = false;
     const bool two = top_d.z != mid_d.z;  // the brown cap tile is 64×53 (see climber.hip)
     if (!(flags & 1) && cols <= kGrid && rows <= kGrid && top_d.y == mid_d.y && top_d.z <= mid_d.z) {
-        compose_spans(L, cam, x0, y0, cols, rows, mid_d.y, mid_d.z, kUnitPx / mid_d.y, lane, two ? top_d.z : 0);
+        compose_spans(L, cam, x0, y0, cols, rows, mid_d.y, mid_d.z, kUnitPx / mid_d.y, lane, two ? top_d.z : 0, half, halves);
 #pragma unroll
-        for (int k = 0; k < kGrid * kGrid / 64; k++) {
+        for (int k = half; k < kGrid * kGrid / 64; k += halves) {
             const int cell = k * 64 + lane;
             const int r = cell / kGrid, c = cell % kGrid;
             const int t = (c < cols && r < rows) ? Win::direct(tiles, x0 + c, y0 + r) : kEmpty;
@@ -565,13 +566,13 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
                                        : (t == kWallTop ? (top_d.x * 4) | (two ? 1 : 0) : mid_d.x * 4);
         }
         __syncthreads();
-        composed = two ? compose_rows<kGrid, true>(fb, L, atlas, bg, has_bg, cols, rows, mid_d.y, lane, flags)
-                       : compose_rows<kGrid, false>(fb, L, atlas, bg, has_bg, cols, rows, mid_d.y, lane, flags);
+        composed = two ? compose_rows<kGrid, true>(fb, L, atlas, bg, has_bg, cols, rows, mid_d.y, lane, flags, half, halves)
+                       : compose_rows<kGrid, false>(fb, L, atlas, bg, has_bg, cols, rows, mid_d.y, lane, flags, half, halves);
     }
     if (!composed) {  // draw-list replay (tilemap.cpp:266-280)
-        wave_clear(fb, lane);
+        wave_clear(fb, lane, half, halves);
         mine = bg;
-        wave_replay(fb, atlas, mine, has_bg ? 1ull : 0ull, lane);
+        wave_replay(fb, atlas, mine, has_bg ? 1ull : 0ull, lane, half, halves);
         for (int base = 0; base < cells; base += 64) {
             const int cell = base + lane;
             bool has = false;
@@ -585,7 +586,7 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
                                        mine);
                 }
             }
-            wave_replay(fb, atlas, mine, __ballot(has), lane);
+            wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
         }
     }
     {  // System_Particles::render (common_systems.cpp:285-308)
@@ -601,7 +602,7 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
                                (puff_y + offset_y) * kUnitPx - 0.5f * d.z * scale, scale * kUnitPx / d.y, alpha, false,
                                false, mine);
         }
-        wave_replay(fb, atlas, mine, __ballot(has), lane);
+        wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
     }
     // positive-z sprites (common_systems.cpp:26-48): carrot and spikes in draw order
     for (int first = 0; first < n_draw; first += 64) {
@@ -625,7 +626,7 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
                                    (cell_y(cell) + -0.25f) * kUnitPx, scale * kUnitPx / d.y, 1.0f, false, false, mine);
             }
         }
-        wave_replay(fb, atlas, mine, __ballot(has), lane);
+        wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
     }
     {  // lane 0: the bunny (common_systems.cpp:204-247); lanes 1-3: the compass (jumper.cpp:473-509)
         const float avx = SF(s, F_AVX, env), phase = SF(s, F_APHASE, env);
@@ -675,9 +676,10 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
                                      compass_size * 0.15f * game_zoom, 0.0, mine);
             }
         }
-        wave_replay(fb, atlas, mine, __ballot(has), lane);
+        wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
     }
-    wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane);
+    __syncthreads();
+    wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane, half, halves);
 }
 
 class JumperGame final : public Game {
@@ -770,7 +772,7 @@ class JumperGame final : public Game {
                            env_offset, io);
     }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
-        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(64), 0, st, s_, atlas_, mask, io, debug_flags);
+        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags);
     }
     // Same layout as oracle/pgo_jumper.cpp Jumper::dump_state.
     int dump_state(hipStream_t st, int env, float* out, int cap) override {

@@ -176,11 +176,12 @@ __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actio
 }
 
 // flags bit 0: force the draw-list replay for background + walls (fallback path).
-__global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
+__global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
                                                     int flags) {
     const int env = blockIdx.x;
     if (mask && !mask[env]) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, half = threadIdx.x >> 6;  // two wavefronts per env (pg_render.h)
+    constexpr int halves = 2;
     __shared__ uint32_t fb[kFbWords];
     constexpr int kGrid = 32;  // 25 visible tiles + the border cells of the inclusive window
     __shared__ ComposeLds<kGrid> L;
@@ -212,19 +213,19 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
 
     bool composed = false;
     if (!(flags & 1) && cols <= kGrid && rows <= kGrid) {
-        compose_spans(L, cam, x0, y0, cols, rows, wall.y, wall.z, kUnitPx / wall.y, lane);
-        for (int cell = lane; cell < cells; cell += 64) {
+        compose_spans(L, cam, x0, y0, cols, rows, wall.y, wall.z, kUnitPx / wall.y, lane, 0, half, halves);
+        for (int cell = lane + 64 * half; cell < cells; cell += 64 * halves) {
             const int r = cell / cols, c = cell - r * cols;
             L.base[r * kGrid + c] =
                 tile_at(tiles, x0 + c, H - 1 - (y0 + r)) == kOpen ? static_cast<int32_t>(kNoTexel) : wall.x * 4;
         }
         __syncthreads();
-        composed = compose_rows(fb, L, atlas, bg, has_bg, cols, rows, wall.y, lane, flags);
+        composed = compose_rows(fb, L, atlas, bg, has_bg, cols, rows, wall.y, lane, flags, half, halves);
     }
     if (!composed) {  // draw-list replay (tilemap.cpp:111-133)
-        wave_clear(fb, lane);
+        wave_clear(fb, lane, half, halves);
         mine = bg;
-        wave_replay(fb, atlas, mine, has_bg ? 1ull : 0ull, lane);
+        wave_replay(fb, atlas, mine, has_bg ? 1ull : 0ull, lane, half, halves);
         for (int base = 0; base < cells; base += 64) {
             const int cell = base + lane;
             bool has = false;
@@ -235,7 +236,7 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
                     has = resolve_draw(cam, wall.y, wall.z, wall.x, x * kUnitPx, y * kUnitPx, kUnitPx / wall.y, 1.0f,
                                        false, false, mine);
             }
-            wave_replay(fb, atlas, mine, __ballot(has), lane);
+            wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
         }
     }
     if (sflags & kFlagListed) {  // the cheese sprite (tilemap.cpp:88): offset (-0.48,-0.5), scale 0.95, z = 1
@@ -244,16 +245,17 @@ __global__ void __launch_bounds__(64) render_kernel(State s, AtlasView atlas, co
         const bool ok = resolve_draw(cam, d.y, d.z, d.x, (SF(s, F_GX, env) + -0.48f) * kUnitPx,
                                      (SF(s, F_GY, env) + -0.5f) * kUnitPx, scale * kUnitPx / d.y, 1.0f, false, false,
                                      mine);
-        wave_replay(fb, atlas, mine, ok ? 1ull : 0ull, lane);
+        wave_replay(fb, atlas, mine, ok ? 1ull : 0ull, lane, half, halves);
     }
     {  // the mouse (common_systems.cpp:138-150); flip = face_forward
         const int4 d = atlas.desc[kTexMouse];
         const bool ok = resolve_draw(cam, d.y, d.z, d.x, (SF(s, F_AX, env) + -0.5f) * kUnitPx,
                                      (SF(s, F_AY, env) + -0.5f) * kUnitPx, kUnitPx / d.y * 1.0f, 1.0f,
                                      (sflags & kFlagForward) != 0, false, mine);
-        wave_replay(fb, atlas, mine, ok ? 1ull : 0ull, lane);
+        wave_replay(fb, atlas, mine, ok ? 1ull : 0ull, lane, half, halves);
     }
-    wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane);
+    __syncthreads();
+    wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane, half, halves);
 }
 
 class MazeGame final : public Game {
@@ -307,7 +309,7 @@ class MazeGame final : public Game {
                            env_offset, io);
     }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
-        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(64), 0, st, s_, atlas_, mask, io, debug_flags);
+        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags);
     }
     // Same layout as oracle/pgo_maze.cpp Maze::dump_state.
     int dump_state(hipStream_t st, int env, float* out, int cap) override {

@@ -16,6 +16,12 @@
 //    sprites, particles and the agent, and as the fallback for tiles.
 //
 // The finished frame is streamed to the observation slab as contiguous 768-byte wave stores.
+//
+// One or two wavefronts per env.  With one, a frame's 16 KiB LDS target caps a CU at 8 resident waves (2 per SIMD),
+// too few to hide the gather latency this kernel lives on.  Every helper therefore takes (half, halves): with
+// halves = 2 the workgroup is two waves sharing one target — wave h composes, blends and stores the pixel rows
+// [32h, 32h+32), the span tables are built one axis per wave — which doubles the waves per CU and halves the time a
+// frame occupies its LDS.  Both waves run the same control flow on the same inputs, so every barrier is met by both.
 #pragma once
 
 #include "pg_engine.h"
@@ -163,7 +169,7 @@ PG_D bool resolve_screen(int tw, int th, int tex_off, float dx, float dy, float 
 }
 
 // Raster spec S6: all lanes execute one rotated draw (wave-uniform).  Scans the same square as the oracle.
-PG_D void wave_blit_rotated(uint32_t* fb, const AtlasView& atlas, const Blit& b, int lane) {
+PG_D void wave_blit_rotated(uint32_t* fb, const AtlasView& atlas, const Blit& b, int lane, int stride = 64) {
     int reach = 1;
     while (reach * reach * 4 < b.dw * b.dw + b.dh * b.dh) reach++;
     reach += 1;
@@ -173,7 +179,7 @@ PG_D void wave_blit_rotated(uint32_t* fb, const AtlasView& atlas, const Blit& b,
     const int bw = x_hi - x_lo + 1, bh = y_hi - y_lo + 1;
     const uint32_t* tex = atlas.texels + b.tex_off;
     const int mod = b.flip_mod & 0xff;
-    for (int p = lane; p < bw * bh; p += 64) {
+    for (int p = lane; p < bw * bh; p += stride) {
         const int ry = udiv_small(p, bw);
         const int X = x_lo + (p - ry * bw), Y = y_lo + ry;
         if (X < 0 || X >= kObsW || Y < 0 || Y >= kObsH) continue;
@@ -202,7 +208,7 @@ PG_D void blend_into(uint32_t* fb, int idx, uint32_t texel, int mod) {
 }
 
 // All 64 lanes execute one (wave-uniform) blit into the LDS target.
-PG_D void wave_blit(uint32_t* fb, const AtlasView& atlas, const Blit& b, int lane) {
+PG_D void wave_blit(uint32_t* fb, const AtlasView& atlas, const Blit& b, int lane, int half = 0, int halves = 1) {
     const int x0 = b.dx > 0 ? b.dx : 0, y0 = b.dy > 0 ? b.dy : 0;
     const int x1 = (b.dx + b.dw) < kObsW ? (b.dx + b.dw) : kObsW;
     const int y1 = (b.dy + b.dh) < kObsH ? (b.dy + b.dh) : kObsH;
@@ -220,7 +226,7 @@ PG_D void wave_blit(uint32_t* fb, const AtlasView& atlas, const Blit& b, int lan
         int i = x - b.dx;
         if (fh) i = b.dw - 1 - i;
         const int u = on ? sample_index(b.sx, b.sw, i, b.dw) : b.sx;
-        for (int y = y0; y < y1; y++) {
+        for (int y = y0 + half; y < y1; y += halves) {
             int j = y - b.dy;
             if (fv) j = b.dh - 1 - j;
             const int v = sample_index(b.sy, b.sh, j, b.dh);
@@ -228,7 +234,7 @@ PG_D void wave_blit(uint32_t* fb, const AtlasView& atlas, const Blit& b, int lan
         }
     } else {
         const int total = cw * ch;
-        for (int p = lane; p < total; p += 64) {
+        for (int p = lane + 64 * half; p < total; p += 64 * halves) {
             const int ry = p / cw;
             const int rx = p - ry * cw;
             const int x = x0 + rx, y = y0 + ry;
@@ -246,7 +252,8 @@ PG_D void wave_blit(uint32_t* fb, const AtlasView& atlas, const Blit& b, int lan
 // Small draws (≤ 64 visible pixels: every sprite, particle and the agent) are taken kGroup at a time: one pixel
 // per lane per draw, all texel fetches of the group issued before the first blend, so a group costs one memory
 // round trip; the blends then run in draw order.  A larger draw goes through wave_blit on its own.
-PG_D void wave_replay(uint32_t* fb, const AtlasView& atlas, const Blit& mine, unsigned long long mask, int lane) {
+PG_D void wave_replay(uint32_t* fb, const AtlasView& atlas, const Blit& mine, unsigned long long mask, int lane,
+                      int half = 0, int halves = 1) {
     constexpr int kGroup = 4;
     while (mask) {
         uint32_t texel[kGroup];
@@ -269,9 +276,9 @@ PG_D void wave_replay(uint32_t* fb, const AtlasView& atlas, const Blit& mine, un
                 if (g == 0) {
                     mask &= mask - 1;
                     if (b.flip_mod & kRotated)
-                        wave_blit_rotated(fb, atlas, b, lane);
+                        wave_blit_rotated(fb, atlas, b, lane + 64 * half, 64 * halves);
                     else
-                        wave_blit(fb, atlas, b, lane);
+                        wave_blit(fb, atlas, b, lane, half, halves);
                     __syncthreads();
                 }
                 continue;
@@ -281,6 +288,7 @@ PG_D void wave_replay(uint32_t* fb, const AtlasView& atlas, const Blit& mine, un
             const int ry = udiv_small(lane, cw);
             const int rx = lane - ry * cw;
             const int x = x0 + rx, y = y0 + ry;
+            if (halves == 2 && (y >> 5) != half) continue;  // the other wave's rows
             int i = x - b.dx, j = y - b.dy;
             if (b.flip_mod & kFlipH) i = b.dw - 1 - i;
             if (b.flip_mod & kFlipV) j = b.dh - 1 - j;
@@ -299,9 +307,9 @@ PG_D void wave_replay(uint32_t* fb, const AtlasView& atlas, const Blit& mine, un
 }
 
 // SDL_RenderClear with (0,0,0,255): coinrun.cpp:447-448.
-PG_D void wave_clear(uint32_t* fb, int lane) {
+PG_D void wave_clear(uint32_t* fb, int lane, int half = 0, int halves = 1) {
     uint4* p = reinterpret_cast<uint4*>(fb);
-    for (int k = lane; k < kFbWords / 4; k += 64) p[k] = make_uint4(0, 0, 0, 0);
+    for (int k = lane + 64 * half; k < kFbWords / 4; k += 64 * halves) p[k] = make_uint4(0, 0, 0, 0);
     __syncthreads();
 }
 
@@ -314,18 +322,22 @@ PG_D void wave_clear(uint32_t* fb, int lane) {
 // rows of a pixel stay the tall texture's; only the texel row differs per cell (compose_rows<GRID, true>).
 template <int GRID, int MAXSPAN = kMaxSpan>
 PG_D void compose_spans(ComposeLds<GRID>& L, const Camera& cam, int x0, int y0, int cols, int rows, int tw, int th,
-                        float tile_scale, int lane, int th2 = 0) {
-    L.cover_n[0][lane] = 0;
-    L.cover_n[1][lane] = 0;
-    if (lane == 0) L.too_wide = 0;
+                        float tile_scale, int lane, int th2 = 0, int half = 0, int halves = 1) {
+    if (half == 0) {
+        L.cover_n[0][lane] = 0;
+        L.cover_n[1][lane] = 0;
+        if (lane == 0) L.too_wide = 0;
+    }
+    __syncthreads();
     bool wide = false;
-    if (lane < cols) {
+    const bool do_cols = halves == 1 || half == 0, do_rows = halves == 1 || half == 1;  // one axis per wave
+    if (do_cols && lane < cols) {
         Span sp;
         const bool ok = resolve_axis(cam.px, cam.sw, cam.scale, tw, (x0 + lane) * kUnitPx, tile_scale, false, false, sp);
         L.col[lane] = ok ? make_int4(sp.d0, sp.dn, sp.s0, sp.sn) : make_int4(0, 0, 0, 0);
         wide = ok && sp.dn > MAXSPAN;
     }
-    if (lane < rows) {
+    if (do_rows && lane < rows) {
         Span sp;
         const bool ok = resolve_axis(cam.py, cam.sh, cam.scale, th, (y0 + lane) * kUnitPx, tile_scale, false, true, sp);
         L.row[lane] = ok ? make_int4(sp.d0, sp.dn, sp.s0, sp.sn) : make_int4(0, 0, 0, 0);
@@ -338,13 +350,12 @@ PG_D void compose_spans(ComposeLds<GRID>& L, const Camera& cam, int x0, int y0, 
             wide = wide || (ok2 && (!ok || s2.d0 != sp.d0 || s2.dn > sp.dn));  // not nested: take the fallback
         }
     }
+    if (wide) L.too_wide = 1;
     __syncthreads();
-    if (__ballot(wide)) {
-        if (lane == 0) L.too_wide = 1;
-        return;
-    }
+    if (L.too_wide) return;
 #pragma unroll
     for (int axis = 0; axis < 2; axis++) {
+        if (halves == 2 && axis != half) continue;
         const int4* spans = axis == 0 ? L.col : L.row;
         const int count = axis == 0 ? cols : rows;
         for (int q = lane; q < count * MAXSPAN; q += 64) {
@@ -392,7 +403,7 @@ constexpr uint32_t kNoTexel = 0x40000000u;
 // L.row2 and is chosen per lane, at the price of a select and an add in front of every tile load.
 template <int GRID, bool TWO = false>
 PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView& atlas, const Blit& bg, bool has_bg,
-                       int cols, int rows, int tw, int lane, int ablate = 0) {
+                       int cols, int rows, int tw, int lane, int ablate = 0, int half = 0, int halves = 1) {
 
     // lane as pixel column: covering grid columns; lane as pixel row: covering grid rows.
     int ca, cb, ua, ub, ra, rb, va, vb;
@@ -465,7 +476,8 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
         __syncthreads();
         return true;
     }
-    for (int py0 = 0; py0 < kObsH; py0 += kBatch) {
+    const int py_begin = half * (kObsH / halves), py_end = py_begin + kObsH / halves;
+    for (int py0 = py_begin; py0 < py_end; py0 += kBatch) {
         uint32_t t[kBatch][5];
 #pragma unroll
         for (int k = 0; k < kBatch; k++) {
@@ -521,10 +533,10 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
 
 // RGB pack (coinrun.cpp:377-388): obs[3k+c] = pix[4k+c]; 4 pixels → 12 bytes per lane per pass,
 // 768 contiguous bytes per wave store.
-PG_D void wave_store_obs(const uint32_t* fb, uint8_t* obs_env, int lane) {
+PG_D void wave_store_obs(const uint32_t* fb, uint8_t* obs_env, int lane, int half = 0, int halves = 1) {
     Rgb4* out = reinterpret_cast<Rgb4*>(obs_env);
     const uint4* in = reinterpret_cast<const uint4*>(fb);
-    for (int g = lane; g < kFbWords / 4; g += 64) {
+    for (int g = lane + 64 * half; g < kFbWords / 4; g += 64 * halves) {
         const uint4 p = in[g];
         Rgb4 o;
         o.a = p.x | (p.y << 24);
