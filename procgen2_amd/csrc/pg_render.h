@@ -204,6 +204,10 @@ PG_D void blend_into(uint32_t* fb, int idx, uint32_t texel, int mod) {
     int a = static_cast<int>(texel >> 24);
     if (mod != 255) a = static_cast<int>(div255(static_cast<uint32_t>(a * mod)));
     if (a == 0) return;
+    if (a == 255) {  // what the blend yields for an opaque texel, without the read-modify-write
+        fb[idx] = texel & 0x00ffffffu;
+        return;
+    }
     fb[idx] = blend_px(fb[idx], texel, a);
 }
 
