@@ -823,8 +823,10 @@ __global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, Atla
     // background (coinrun.cpp:459-464)
     Blit bg;
     bool has_bg;
+    int4 bg_d;
     {
         const int4 d = descs.uniform(kTexBackdrop + backdrop);
+        bg_d = d;
         const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
         const float extra = aspect - 1.0f;
         has_bg = resolve_draw(cam, d.y, d.z, d.x, -SF(s, F_BGSHIFT, env) * extra, 0.0f, 64.0f * kUnitPx / d.z, 1.0f,
@@ -851,7 +853,9 @@ __global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, Atla
         if (lane == 1) kind_tex = kTexMid + ground_theme;
         if (lane == 2) kind_tex = kTexLavaTop;
         if (lane == 3) kind_tex = kTexLava;
-        const int kind_base = descs.at(kind_tex).x;
+        const int4 kind_d = descs.at(kind_tex);
+        const int kind_base = kind_d.x;
+        bool blendy = threadIdx.x == 0 && bg_d.w != 0;  // a visible texture with translucent texels (descriptor .w)
 #pragma unroll
         for (int k = half; k < kGrid * kGrid / 64; k += halves) {  // the whole kGrid×kGrid table, 64 cells per pass
             const int cell = k * 64 + lane;
@@ -862,10 +866,16 @@ __global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, Atla
             const int t = raw & 7;
             const int slot = t < kCrate ? t - 1 : 4 + (raw >> 4);
             const int off = __shfl(kind_base, slot < 0 ? 0 : slot);
+            const int soft = __shfl(kind_d.w, slot < 0 ? 0 : slot);
             L.base[cell] = (t == kEmpty) ? static_cast<int32_t>(kNoTexel) : off * 4;
+            blendy = blendy || (t != kEmpty && soft != 0);
         }
+        if (blendy) L.blendy = 1;
         __syncthreads();
-        composed = compose_rows(fb, L, atlas, bg, has_bg, cols, rows, tile_desc.y, lane, flags, half, halves);
+        // no translucent texel in the background nor in any tile texture in view (most frames: crates and lava caps are
+        // the only soft-edged tiles) → the composer skips its per-texel translucency scan
+        const bool may_blend = L.blendy != 0;
+        composed = compose_rows(fb, L, atlas, bg, has_bg, cols, rows, tile_desc.y, lane, flags, half, halves, may_blend);
     }
     if (flags & 4) composed = true;  // (bit 2: timing experiment — no background/tiles at all)
     if (!composed) {  // draw-list replay of background and tiles (tilemap.cpp:294-321)

@@ -48,7 +48,12 @@ bool Atlas::load(const std::string& root, const std::vector<std::string>& names,
         d.x = static_cast<int>(texels_.size());
         d.y = img.w;
         d.z = img.h;
-        d.w = 0;
+        d.w = 0;  // 1 = some texel is translucent (alpha neither 0 nor 255): the row composer's blend path can be needed
+        for (size_t k = 3; k < img.rgba.size(); k += 4)
+            if (img.rgba[k] != 0 && img.rgba[k] != 255) {
+                d.w = 1;
+                break;
+            }
         desc_.push_back(d);
         size_t base = texels_.size();
         texels_.resize(base + size_t(img.w) * img.h);

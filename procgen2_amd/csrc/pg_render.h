@@ -46,6 +46,7 @@ struct ComposeLds {
     int32_t cover_n[2][64];     // [axis][pixel] how many grid columns (axis 0) / rows (axis 1) cover the pixel
     int32_t cover[2][64][2];    // the first two of them: grid index | texel coordinate << 8
     int32_t too_wide;           // some span is wider than kMaxSpan pixels → fall back
+    int32_t blendy;             // set by the caller's staging pass when a visible texture has translucent texels
 };
 constexpr int kMaxSpan = 8;  // default bound on the pixels one tile covers per axis (coinrun 5–6, maze 3); caveflyer passes 16
 
@@ -67,7 +68,7 @@ struct DescRegs {
         r.x = up ? __shfl(hi.x, l) : __shfl(lo.x, l);
         r.y = up ? __shfl(hi.y, l) : __shfl(lo.y, l);
         r.z = up ? __shfl(hi.z, l) : __shfl(lo.z, l);
-        r.w = 0;
+        r.w = up ? __shfl(hi.w, l) : __shfl(lo.w, l);
         return r;
     }
     // wave-uniform index
@@ -78,7 +79,7 @@ struct DescRegs {
         r.x = up ? __builtin_amdgcn_readlane(hi.x, l) : __builtin_amdgcn_readlane(lo.x, l);
         r.y = up ? __builtin_amdgcn_readlane(hi.y, l) : __builtin_amdgcn_readlane(lo.y, l);
         r.z = up ? __builtin_amdgcn_readlane(hi.z, l) : __builtin_amdgcn_readlane(lo.z, l);
-        r.w = 0;
+        r.w = up ? __builtin_amdgcn_readlane(hi.w, l) : __builtin_amdgcn_readlane(lo.w, l);
         return r;
     }
 };
@@ -330,7 +331,10 @@ PG_D void compose_spans(ComposeLds<GRID>& L, const Camera& cam, int x0, int y0, 
     if (half == 0) {
         L.cover_n[0][lane] = 0;
         L.cover_n[1][lane] = 0;
-        if (lane == 0) L.too_wide = 0;
+        if (lane == 0) {
+            L.too_wide = 0;
+            L.blendy = 0;
+        }
     }
     __syncthreads();
     bool wide = false;
@@ -407,7 +411,8 @@ constexpr uint32_t kNoTexel = 0x40000000u;
 // L.row2 and is chosen per lane, at the price of a select and an add in front of every tile load.
 template <int GRID, bool TWO = false>
 PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView& atlas, const Blit& bg, bool has_bg,
-                       int cols, int rows, int tw, int lane, int ablate = 0, int half = 0, int halves = 1) {
+                       int cols, int rows, int tw, int lane, int ablate = 0, int half = 0, int halves = 1,
+                       bool may_blend = true) {
 
     // lane as pixel column: covering grid columns; lane as pixel row: covering grid rows.
     int ca, cb, ua, ub, ra, rb, va, vb;
@@ -504,18 +509,22 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
             }
         }
         // Is any fetched texel translucent (alpha not in {0, 255})?  (a + 1) & 0xFE is zero exactly for 0 and 255.
+        // `may_blend` false = the caller vouches (descriptor flags, set when the atlas is loaded) that no texture of
+        // this layer has such a texel: the scan — a third of this loop's vector instructions — is skipped.
         uint32_t translucent = 0;
+        if (may_blend) {
 #pragma unroll
-        for (int k = 0; k < kBatch; k++)
+            for (int k = 0; k < kBatch; k++)
 #pragma unroll
-            for (int j = 0; j < 5; j++) translucent |= ((t[k][j] >> 24) + 1u) & 0xFEu;
-        if (__ballot(translucent != 0) == 0 && bg_mod == 255) {
+                for (int j = 0; j < 5; j++) translucent |= ((t[k][j] >> 24) + 1u) & 0xFEu;
+        }
+        if (bg_mod == 255 && (!may_blend || __ballot(translucent != 0) == 0)) {
             // Opaque-or-absent everywhere in the batch: OVER is "last drawn wins" (what S4 yields for a = 0 / 255).
 #pragma unroll
             for (int k = 0; k < kBatch; k++) {
                 uint32_t pix = 0;
 #pragma unroll
-                for (int j = 0; j < 5; j++) pix = (t[k][j] >> 24) ? t[k][j] : pix;
+                for (int j = 0; j < 5; j++) pix = (t[k][j] > 0x00ffffffu) ? t[k][j] : pix;  // alpha ≠ 0
                 fb[(py0 + k) * kObsW + lane] = pix & 0x00ffffffu;
             }
         } else {
