@@ -22,6 +22,7 @@
 #include "pg_prefetch.h"
 #include "pg_render.h"
 #include "pg_rng.h"
+#include "pg_setorder.h"
 
 namespace pg {
 namespace chaser {
@@ -61,8 +62,8 @@ struct Level {
 struct GenLds {
     uint32_t mt[kMtWords];
     KruskalLds k;
-    int16_t next[128];
-    int16_t before[128];
+    int32_t touch[260], chain[260], tail_sum[132];  // pg_setorder.h scratch (≤ 257 buckets, ≤ 128 keys)
+    int16_t link[128], tmp[128], keys[128];
     uint8_t free_cells[kCells + 7];
 };
 
@@ -95,24 +96,12 @@ PG_D int iabs(float v) {  // D21
 }
 PG_D int sign_of(float x) { return x == 0.0f ? 0 : (x > 0.0f) * 2 - 1; }  // helpers.h:31-36
 
-// Iteration order of a std::unordered_set<int> that kept its bucket array across clear() after inserting keys[0..n)
-// (packed = buckets | next_resize << 16; a fresh set is packed = 1).
-PG_D void set_order(int32_t& packed, const uint8_t* keys, int n, uint8_t* out, int16_t* next, int16_t* before) {
-    HashOrder h;
-    h.next = next;
-    h.before = before;
-    h.head = kNil;
-    h.buckets = packed & 0xffff;
-    h.next_resize = packed >> 16;
-    h.count = 0;
-    for (int b = 0; b < h.buckets; b++) before[b] = kNil;
-    for (int k = 0; k < n; k++) hash_insert(h, keys[k]);
-    int16_t p = static_cast<int16_t>(h.head);
-    for (int k = 0; k < n; k++) {
-        out[k] = static_cast<uint8_t>(p);
-        p = next[p];
-    }
-    packed = h.buckets | (h.next_resize << 16);
+// Iteration order of a std::unordered_set<int> that kept its bucket array across clear() after inserting
+// L.keys[0..n) (packed = buckets | next_resize << 16; a fresh set is packed = 1).  Result in L.keys.  All lanes.
+PG_D void set_order(GenLds& L, int32_t& packed, int n, int lane) {
+    int32_t buckets = packed & 0xffff, next_resize = packed >> 16;
+    wave_set_order(L.keys, n, buckets, next_resize, SetOrderScratch{L.touch, L.chain, L.link, L.tail_sum, L.tmp}, lane);
+    packed = buckets | (next_resize << 16);
 }
 
 // reset() (chaser.cpp:418-443 + tilemap.cpp:80-243) for one env by one wavefront; the level is left in `lv` (LDS).
@@ -181,9 +170,14 @@ PG_D void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, u
         picked[j] = static_cast<uint8_t>(pos);
     }
     if (lane == 0) {
-        uint8_t order[4];
-        int32_t fresh = 1;
-        set_order(fresh, picked, kMobs + 1, order, L.next, L.before);
+#pragma unroll
+        for (int j = 0; j < kMobs + 1; j++) L.keys[j] = picked[j];
+    }
+    __syncthreads();
+    int32_t fresh = 1;
+    set_order(L, fresh, kMobs + 1, lane);
+    if (lane == 0) {
+        const int16_t* order = L.keys;
         const int start = L.free_cells[order[0]];
         lv.tiles[start] = kMarker;
         lv.ax = static_cast<float>(start / H) + 0.5f;
@@ -206,16 +200,22 @@ PG_D void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, u
     if (lane == 0) {
         lv.bg = bg;
         lv.bgshift = shift;
-        // entity-set orders of the episode: sprites = every non-agent entity, enemies = the eggs
-        uint8_t keys[kMaxEnt];
+    }
+    {   // entity-set orders of the episode: sprites = every non-agent entity, enemies = the eggs
         const int n_ent = lv.n_ent;
-        for (int k = 0; k < n_ent; k++) keys[k] = static_cast<uint8_t>(k);
+        for (int k = lane; k < n_ent; k += 64) L.keys[k] = static_cast<int16_t>(k);
+        __syncthreads();
         int32_t packed = SI(s, I_HASH_SPRITE, env);
-        set_order(packed, keys, n_ent, lv.order, L.next, L.before);
-        SI(s, I_HASH_SPRITE, env) = packed;
+        set_order(L, packed, n_ent, lane);
+        if (lane == 0) SI(s, I_HASH_SPRITE, env) = packed;
+        for (int k = lane; k < n_ent; k += 64) lv.order[k] = static_cast<uint8_t>(L.keys[k]);
+        __syncthreads();
+        if (lane < kMobs) L.keys[lane] = static_cast<int16_t>(kOrbs + lane);
+        __syncthreads();
         packed = SI(s, I_HASH_MOB, env);
-        set_order(packed, keys + kOrbs, kMobs, lv.mob_order, L.next, L.before);
-        SI(s, I_HASH_MOB, env) = packed;
+        set_order(L, packed, kMobs, lane);
+        if (lane == 0) SI(s, I_HASH_MOB, env) = packed;
+        if (lane < kMobs) lv.mob_order[lane] = static_cast<uint8_t>(L.keys[lane]);
     }
     __syncthreads();
     for (int k = lane; k < kMtWords; k += 64) gmt[k] = L.mt[k];

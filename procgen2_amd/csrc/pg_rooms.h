@@ -13,6 +13,7 @@
 #include "pg_defs.h"
 #include "pg_order.h"
 #include "pg_rng.h"
+#include "pg_setorder.h"
 
 namespace pg {
 namespace rooms {
@@ -144,73 +145,12 @@ PG_D int flood(RoomsLds& L, int start, bool parents, int stop_cell, int lane) {
     return qt;
 }
 
-// Iteration order of a fresh std::unordered_set<int> after inserting the n distinct keys L.cells[0..n) one by one
-// (libstdc++ 11, pg_order.h), computed without replaying the node list.  With B buckets fixed, the list is: buckets
-// in order of their FIRST insertion, latest first; inside a bucket, latest insertion first.  A rehash re-inserts
-// the nodes in list order under the new B, i.e. it is the same rule applied to (current order ++ later keys).
-// Single inserts grow B 13→29→59→…→2357 just before the (B+1)-th key, so the result is at most eight rounds of
-// "rank by (first touch of my bucket, my position), both descending".  The rank of element i is
-//     (elements in buckets first touched after mine) + (elements of my bucket inserted after me),
-// a suffix sum over first-touch positions plus a walk of my bucket's short chain — all lanes busy, a handful of
-// LDS operations per element, instead of ~2n dependent pointer-chasing steps on one lane.  Result in L.cells.
+// Iteration order of a fresh std::unordered_set<int> after inserting the n distinct keys L.cells[0..n) one by one:
+// pg_setorder.h (closed-form ranks per rehash round instead of replaying up to 1600 dependent insertions).
 PG_D void set_order(RoomsLds& L, int n, int lane) {
-    const int growth[8] = {13, 29, 59, 127, 257, 541, 1109, 2357};
-    int have = 0;
-    for (int g = 0; g < 8 && have < n; g++) {
-        const int B = growth[g];
-        const int m = n < B ? n : B;  // L.cells[0..have) in list order, [have..m) still in insertion order
-        for (int b = lane; b < B; b += 64) {
-            L.touch[b] = 0x7fffffff;
-            L.chain[b] = -1;
-        }
-        __syncthreads();
-        for (int i = lane; i < m; i += 64) {
-            const int b = hash_mod(L.cells[i], B);
-            atomicMin(&L.touch[b], i);
-            L.parent[i] = static_cast<int16_t>(atomicExch(&L.chain[b], i));
-        }
-        __syncthreads();
-        // per element: its bucket's population and how many of it came later; first-touch positions carry the
-        // population into the suffix sum
-        int later[25], first_touch[25];
-        for (int r = 0, i = lane; i < m; i += 64, r++) {
-            const int b = hash_mod(L.cells[i], B);
-            int all = 0, after = 0;
-            for (int q = L.chain[b]; q >= 0; q = L.parent[q]) {
-                all++;
-                after += q > i ? 1 : 0;
-            }
-            later[r] = after;
-            first_touch[r] = L.touch[b];
-            L.tail_sum[i] = first_touch[r] == i ? all : 0;
-        }
-        if (lane == 0) L.tail_sum[m] = 0;
-        __syncthreads();
-        {   // tail_sum[p] ← Σ_{q ≥ p} tail_sum[q]: each lane owns a contiguous strip, strips combined by a wave scan
-            const int strip = (m + 63) / 64;
-            const int lo = lane * strip, hi = (lo + strip) < m ? (lo + strip) : m;
-            int mine = 0;
-            for (int p = lo; p < hi; p++) mine += L.tail_sum[p];
-            int above = mine;  // inclusive suffix over lanes
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int t = __shfl_down(above, off);
-                if (lane + off < 64) above += t;
-            }
-            int run = above - mine;  // everything in higher strips
-            for (int p = hi - 1; p >= lo; p--) {
-                run += L.tail_sum[p];
-                L.tail_sum[p] = run;
-            }
-        }
-        __syncthreads();
-        for (int r = 0, i = lane; i < m; i += 64, r++)
-            L.queue[L.tail_sum[first_touch[r] + 1] + later[r]] = L.cells[i];
-        __syncthreads();
-        for (int i = lane; i < m; i += 64) L.cells[i] = L.queue[i];
-        __syncthreads();
-        have = m;
-    }
+    int32_t buckets = 1, next_resize = 0;
+    wave_set_order(L.cells, n, buckets, next_resize, SetOrderScratch{L.touch, L.chain, L.parent, L.tail_sum, L.queue},
+                   lane);
 }
 
 // Room_Generator::find_best_room (room_generator.cpp:138-160): the largest 4-connected room (the first one on
