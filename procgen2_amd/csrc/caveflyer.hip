@@ -82,6 +82,7 @@ struct State {
     uint8_t* eb;     // [EB_COUNT][kMaxEnt][n]
     float* sh;       // [SH_COUNT][kShots][n]
     float* pf;       // [PF_COUNT][kPuffs][n]
+    const uint8_t* ranks;  // pg_order.h equal-key sort ranks
 };
 
 PG_D float& SF(const State& s, int field, int env) { return s.f[size_t(field) * s.n + env]; }
@@ -278,14 +279,14 @@ PG_D Box thing_box(const State& s, int e, int env, int kind) {
 
 // System_Sprite_Render::update's list: the surviving sprites in set order, then std::sort on z (all 1.0).
 PG_D void rebuild_draw_list(const State& s, int env, int n_ent) {
-    ZItem items[kMaxEnt];
     int n = 0;
+    for (int k = 0; k < n_ent - 1; k++) n += (EB(s, EB_INFO, EB(s, EB_ORDER_S, k, env), env) & kAlive) ? 1 : 0;
+    const uint8_t* rank = s.ranks + rank_offset(n);  // equal keys: the sort is a fixed permutation for each n
+    int r = 0;
     for (int k = 0; k < n_ent - 1; k++) {
         const int e = EB(s, EB_ORDER_S, k, env);
-        if (EB(s, EB_INFO, e, env) & kAlive) items[n++] = {1.0f, e};
+        if (EB(s, EB_INFO, e, env) & kAlive) EB(s, EB_DRAW, rank[r++], env) = static_cast<uint8_t>(e);
     }
-    sort_by_key(items, n);
-    for (int k = 0; k < n; k++) EB(s, EB_DRAW, k, env) = static_cast<uint8_t>(items[k].id);
     SI(s, I_NDRAW, env) = n;
 }
 
@@ -711,6 +712,7 @@ class CaveflyerGame final : public Game {
         s_.eb = p + l.eb;
         s_.sh = reinterpret_cast<float*>(p + l.sh);
         s_.pf = reinterpret_cast<float*>(p + l.pf);
+        s_.ranks = atlas.sort_ranks;
         atlas_ = atlas;
     }
     int blocks() const { return (s_.n + 63) / 64; }

@@ -73,6 +73,7 @@ struct State {
     int32_t* i;      // [I_COUNT][n]
     float* ef;       // [EF_COUNT][kMaxEnt][n]
     uint8_t* eb;     // [EB_COUNT][kMaxEnt][n]
+    const uint8_t* ranks;  // pg_order.h equal-key sort ranks
 };
 
 PG_D float& SF(const State& s, int field, int env) { return s.f[size_t(field) * s.n + env]; }
@@ -123,14 +124,14 @@ PG_D void episode_order(int32_t& packed, int n, uint8_t* out) {
 
 // System_Sprite_Render::update's list: the surviving sprites in set order, then std::sort on z (all 1.0).
 PG_D void rebuild_draw_list(const State& s, int env, int n_ent) {
-    ZItem items[kMaxEnt];
     int n = 0;
+    for (int k = 0; k < n_ent; k++) n += (EB(s, EB_INFO, EB(s, EB_ORDER, k, env), env) & kAlive) ? 1 : 0;
+    const uint8_t* rank = s.ranks + rank_offset(n);  // equal keys: the sort is a fixed permutation for each n
+    int r = 0;
     for (int k = 0; k < n_ent; k++) {
         const int e = EB(s, EB_ORDER, k, env);
-        if (EB(s, EB_INFO, e, env) & kAlive) items[n++] = {1.0f, e};
+        if (EB(s, EB_INFO, e, env) & kAlive) EB(s, EB_DRAW, rank[r++], env) = static_cast<uint8_t>(e);
     }
-    sort_by_key(items, n);
-    for (int k = 0; k < n; k++) EB(s, EB_DRAW, k, env) = static_cast<uint8_t>(items[k].id);
     SI(s, I_NDRAW, env) = n;
 }
 
@@ -565,6 +566,7 @@ class ClimberGame final : public Game {
         s_.i = reinterpret_cast<int32_t*>(p + l.i);
         s_.ef = reinterpret_cast<float*>(p + l.ef);
         s_.eb = p + l.eb;
+        s_.ranks = atlas.sort_ranks;
         atlas_ = atlas;
     }
     int blocks() const { return (s_.n + 63) / 64; }

@@ -9,6 +9,7 @@
 #include "../../include/procgen2_cenv.h"
 #include "../../include/procgen2_vec.h"
 #include "pg_engine.h"
+#include "pg_order.h"
 #include "png_decode.h"
 
 #ifndef PG_DEFAULT_GAME
@@ -36,6 +37,7 @@ static int fail(const std::string& msg) {
 Atlas::~Atlas() {
     if (d_texels_) hipFree(d_texels_);
     if (d_desc_) hipFree(d_desc_);
+    if (d_ranks_) hipFree(d_ranks_);
 }
 
 bool Atlas::load(const std::string& root, const std::vector<std::string>& names, std::string& err) {
@@ -71,6 +73,10 @@ bool Atlas::upload(std::string& err) {
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_desc_), desc_.size() * sizeof(int4));
     if (e == hipSuccess) e = hipMemcpy(d_texels_, texels_.data(), texels_.size() * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_desc_, desc_.data(), desc_.size() * sizeof(int4), hipMemcpyHostToDevice);
+    std::vector<uint8_t> ranks(kRankTableBytes);
+    build_equal_key_ranks(ranks.data());
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_ranks_), ranks.size());
+    if (e == hipSuccess) e = hipMemcpy(d_ranks_, ranks.data(), ranks.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         err = std::string("atlas upload: ") + hipGetErrorString(e);
         return false;

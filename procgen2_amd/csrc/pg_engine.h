@@ -20,6 +20,7 @@ struct AtlasView {
     const int4* desc;
     int count;
     uint32_t texel_bytes;  // size of `texels` in bytes (< 1 GiB: pg_render.h kNoTexel)
+    const uint8_t* sort_ranks;  // pg_order.h equal_key_ranks table (kRankTableBytes), uploaded with the atlas
 };
 
 class Atlas {
@@ -29,7 +30,7 @@ class Atlas {
     bool load(const std::string& root, const std::vector<std::string>& names, std::string& err);
     bool upload(std::string& err);
     AtlasView view() const {
-        return {d_texels_, d_desc_, static_cast<int>(desc_.size()), static_cast<uint32_t>(texels_.size() * 4)};
+        return {d_texels_, d_desc_, static_cast<int>(desc_.size()), static_cast<uint32_t>(texels_.size() * 4), d_ranks_};
     }
     size_t texel_bytes() const { return texels_.size() * 4; }
     std::vector<std::pair<int, int>> sizes() const {
@@ -43,6 +44,7 @@ class Atlas {
     std::vector<int4> desc_;
     uint32_t* d_texels_ = nullptr;
     int4* d_desc_ = nullptr;
+    uint8_t* d_ranks_ = nullptr;
 };
 
 // Buffers every game writes: the contiguous observation slab and the per-env scalars.

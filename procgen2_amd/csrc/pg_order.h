@@ -328,4 +328,24 @@ PG_HD void sort_by_key(ZItem* a, int n) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Every game gives all its sprites the same z, so std::sort never sees `a < b` hold and its
+// result is a fixed permutation of its input that depends on the element count alone.  equal_key_ranks[n][r] = the
+// position sort_by_key gives to the r-th of n equal-key elements; with it a draw list is rebuilt by scattering the
+// surviving sprites (in set order) instead of re-running the introsort twin on a private array in every lane whose
+// sprite set changed.  Table: rank_offset(n) + r, n ≤ kRankMax; built on the host from sort_by_key itself.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRankMax = 128;
+PG_HD int rank_offset(int n) { return n * (n - 1) / 2; }
+constexpr int kRankTableBytes = (kRankMax + 1) * kRankMax / 2;
+
+inline void build_equal_key_ranks(uint8_t* out) {
+    for (int n = 1; n <= kRankMax; n++) {
+        ZItem items[kRankMax];
+        for (int k = 0; k < n; k++) items[k] = {1.0f, k};
+        sort_by_key(items, n);
+        for (int k = 0; k < n; k++) out[rank_offset(n) + items[k].id] = static_cast<uint8_t>(k);
+    }
+}
+
 }  // namespace pg
