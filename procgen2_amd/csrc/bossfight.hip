@@ -528,7 +528,7 @@ PG_D void advance(const State& s, int env, int action, float& reward_out, bool& 
 // kernels
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) make_kernel(State s, uint32_t seed_base, int env_offset) {
-    const int env = blockIdx.x * 64 + threadIdx.x;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= s.n) return;
     mt_seed(s.mt + size_t(env) * kMtWords, seed_base + static_cast<uint32_t>(env_offset + env));
     for (int k = 0; k < kAgentShots; k++) {  // std::vector<Bullet>(32): frame = -1 ("dead"), rest zero
@@ -546,7 +546,7 @@ __global__ void __launch_bounds__(64) make_kernel(State s, uint32_t seed_base, i
 }
 
 __global__ void __launch_bounds__(64) reset_kernel(State s, const uint8_t* mask, const int32_t* seeds, StepIO io) {
-    const int env = blockIdx.x * 64 + threadIdx.x;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= s.n) return;
     if (mask && !mask[env]) return;
     if (seeds) mt_seed(s.mt + size_t(env) * kMtWords, static_cast<uint32_t>(seeds[env]));
@@ -558,7 +558,7 @@ __global__ void __launch_bounds__(64) reset_kernel(State s, const uint8_t* mask,
 
 __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actions, uint32_t run_seed,
                                                    uint32_t step_index, int env_offset, StepIO io) {
-    const int env = blockIdx.x * 64 + threadIdx.x;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= s.n) return;
     if (io.pending[env]) {
         new_level(s, env);
@@ -787,7 +787,7 @@ class BossfightGame final : public Game {
     }
     void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
                       StepIO io) override {
-        hipLaunchKernelGGL(logic_kernel, dim3(blocks()), dim3(64), 0, st, s_, actions, run_seed, step_index,
+        hipLaunchKernelGGL(logic_kernel, dim3(logic_blocks(s_.n)), dim3(logic_lanes()), 0, st, s_, actions, run_seed, step_index,
                            env_offset, io);
     }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {

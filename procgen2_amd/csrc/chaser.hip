@@ -530,7 +530,7 @@ PG_D void advance(const State& s, int env, int action, float& reward_out, bool& 
 }
 
 __global__ void __launch_bounds__(64) make_kernel(State s) {
-    const int env = blockIdx.x * 64 + threadIdx.x;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= s.n) return;
     SI(s, I_HASH_SPRITE, env) = 1;  // empty unordered_set: one bucket, next_resize 0
     SI(s, I_HASH_MOB, env) = 1;
@@ -538,7 +538,7 @@ __global__ void __launch_bounds__(64) make_kernel(State s) {
 
 __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actions, uint32_t run_seed,
                                                    uint32_t step_index, int env_offset, StepIO io) {
-    const int env = blockIdx.x * 64 + threadIdx.x;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= s.n) return;
     if (io.pending[env] == 2) {  // reset by the level kernel in this step
         io.pending[env] = 0;
@@ -726,7 +726,7 @@ class ChaserGame final : public Game {
     void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
                       StepIO io) override {
         LevelLaunch<Gen>::auto_reset(st, s_, 0, io);
-        hipLaunchKernelGGL(logic_kernel, dim3(blocks()), dim3(64), 0, st, s_, actions, run_seed, step_index,
+        hipLaunchKernelGGL(logic_kernel, dim3(logic_blocks(s_.n)), dim3(logic_lanes()), 0, st, s_, actions, run_seed, step_index,
                            env_offset, io);
     }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {

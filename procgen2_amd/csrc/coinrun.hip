@@ -671,7 +671,7 @@ PG_D void agent_substeps(const State& s, int env, int action) {
 // kernels
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) make_kernel(State s, uint32_t seed_base, int env_offset) {
-    const int env = blockIdx.x * 64 + threadIdx.x;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= s.n) return;
     SI(s, I_FLAGS, env) = 0;
     SI(s, I_HASH_SPRITE, env) = 1;  // empty unordered_set: one bucket, next_resize 0
@@ -684,7 +684,7 @@ __global__ void __launch_bounds__(64) make_kernel(State s, uint32_t seed_base, i
 // A — lane = env: the agent's sub-steps into the scratch table (envs that reset in this step sit it out).
 __global__ void __launch_bounds__(64) agent_kernel(State s, const int32_t* actions, uint32_t run_seed,
                                                    uint32_t step_index, int env_offset, StepIO io) {
-    const int env = blockIdx.x * 64 + threadIdx.x;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= s.n) return;
     if (io.pending[env] == 2) {  // the caller's `if term: env.reset()` (game_test.py:38-40): done by the level kernel
         io.pending[env] = 0;
@@ -698,7 +698,7 @@ __global__ void __launch_bounds__(64) agent_kernel(State s, const int32_t* actio
 
 // B — lane = env, blockIdx.y = entity slot: all four sub-steps of one entity (optimistic: no early termination).
 __global__ void __launch_bounds__(64) entity_kernel(State s) {
-    const int env = blockIdx.x * 64 + threadIdx.x;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = blockIdx.y;
     if (env >= s.n) return;
     if (e >= SI(s, I_NENT, env)) return;
@@ -716,7 +716,7 @@ __global__ void __launch_bounds__(64) entity_kernel(State s) {
 
 // C — lane = env: which sub-step ended the step, rare redo, commit (coinrun.cpp:356-371).
 __global__ void __launch_bounds__(64) resolve_kernel(State s, StepIO io) {
-    const int env = blockIdx.x * 64 + threadIdx.x;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= s.n) return;
     const int bits = SCI(s, SC_BITS, env);
     if (bits >= 0) return;  // reset this step; agent_kernel already wrote reward/done/pending
@@ -1095,10 +1095,10 @@ class CoinrunGame final : public Game {
     void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
                       StepIO io) override {
         LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io);
-        hipLaunchKernelGGL(agent_kernel, dim3(blocks()), dim3(64), 0, st, s_, actions, run_seed, step_index,
+        hipLaunchKernelGGL(agent_kernel, dim3(logic_blocks(s_.n)), dim3(logic_lanes()), 0, st, s_, actions, run_seed, step_index,
                            env_offset, io);
-        hipLaunchKernelGGL(entity_kernel, dim3(blocks(), kMaxEnt), dim3(64), 0, st, s_);
-        hipLaunchKernelGGL(resolve_kernel, dim3(blocks()), dim3(64), 0, st, s_, io);
+        hipLaunchKernelGGL(entity_kernel, dim3(logic_blocks(s_.n), kMaxEnt), dim3(logic_lanes()), 0, st, s_);
+        hipLaunchKernelGGL(resolve_kernel, dim3(logic_blocks(s_.n)), dim3(logic_lanes()), 0, st, s_, io);
     }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
         hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(64 * kRenderWaves), 0, st, s_, atlas_, mask, io,

@@ -31,6 +31,15 @@ static int fail(const std::string& msg) {
         if (e_ != hipSuccess) return fail(std::string(#call) + ": " + hipGetErrorString(e_));    \
     } while (0)
 
+int logic_lanes() {
+    static const int lanes = [] {
+        const char* e = std::getenv("PG_LOGIC_LANES");
+        const int v = e ? std::atoi(e) : 64;
+        return (v == 8 || v == 16 || v == 32 || v == 64) ? v : 64;
+    }();
+    return lanes;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Atlas
 // ------------------------------------------------------------------------------------------------

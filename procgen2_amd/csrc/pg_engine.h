@@ -87,6 +87,10 @@ class Game {
 
 constexpr int kDebugNoPrefetch = 1 << 8;
 
+// Lanes per workgroup of the lane-per-env logic kernels: fewer envs per wave = more waves.
+int logic_lanes();
+inline int logic_blocks(int n) { return (n + logic_lanes() - 1) / logic_lanes(); }
+
 std::unique_ptr<Game> make_coinrun();
 std::unique_ptr<Game> make_maze();
 std::unique_ptr<Game> make_bossfight();

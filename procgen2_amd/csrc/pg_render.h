@@ -256,10 +256,22 @@ PG_D void wave_blit(uint32_t* fb, const AtlasView& atlas, const Blit& b, int lan
 // Replays the draws held by the lanes flagged in `mask`, in ascending lane order.
 // Small draws (≤ 64 visible pixels: every sprite, particle and the agent) are taken kGroup at a time: one pixel
 // per lane per draw, all texel fetches of the group issued before the first blend, so a group costs one memory
-// round trip; the blends then run in draw order.  A larger draw goes through wave_blit on its own.
+// round trip; the blends then run in draw order.  A larger draw goes through wave_blit on its own.  With two waves
+// the small draws of a group alternate between them (per-draw work is mostly fixed-cost vector instructions — these
+// kernels are VALU-bound — so executing every draw in both waves would double it).
 PG_D void wave_replay(uint32_t* fb, const AtlasView& atlas, const Blit& mine, unsigned long long mask, int lane,
                       int half = 0, int halves = 1) {
     constexpr int kGroup = 4;
+    // Which draws go alone (rotated, or more visible pixels than a wave has lanes): every lane judges its own draw,
+    // so the group loop below can steer on a mask without broadcasting a draw it is not going to execute.
+    bool lone = false;
+    if ((mask >> lane) & 1ull) {
+        const int x0 = mine.dx > 0 ? mine.dx : 0, y0 = mine.dy > 0 ? mine.dy : 0;
+        const int x1 = (mine.dx + mine.dw) < kObsW ? (mine.dx + mine.dw) : kObsW;
+        const int y1 = (mine.dy + mine.dh) < kObsH ? (mine.dy + mine.dh) : kObsH;
+        lone = (mine.flip_mod & kRotated) || (x1 > x0 && y1 > y0 && (x1 - x0) * (y1 - y0) > 64);
+    }
+    const unsigned long long lones = __ballot(lone);
     while (mask) {
         uint32_t texel[kGroup];
         int idx[kGroup], mod[kGroup];
@@ -270,16 +282,13 @@ PG_D void wave_replay(uint32_t* fb, const AtlasView& atlas, const Blit& mine, un
             texel[g] = 0;
             mod[g] = 255;
             if (mask == 0 || stop) continue;
-            const Blit b = blit_from_lane(mine, __builtin_ctzll(mask));
-            const int x0 = b.dx > 0 ? b.dx : 0, y0 = b.dy > 0 ? b.dy : 0;
-            const int x1 = (b.dx + b.dw) < kObsW ? (b.dx + b.dw) : kObsW;
-            const int y1 = (b.dy + b.dh) < kObsH ? (b.dy + b.dh) : kObsH;
-            const int cw = x1 - x0, ch = y1 - y0;
-            if ((b.flip_mod & kRotated) || (cw > 0 && ch > 0 && cw * ch > 64)) {
-                // a rotated or big one: alone, and only at the head of a group
+            const int src = __builtin_ctzll(mask);
+            if ((lones >> src) & 1ull) {
+                // a rotated or big one: alone, only at the head of a group, by the whole workgroup
                 stop = true;
                 if (g == 0) {
                     mask &= mask - 1;
+                    const Blit b = blit_from_lane(mine, src);
                     if (b.flip_mod & kRotated)
                         wave_blit_rotated(fb, atlas, b, lane + 64 * half, 64 * halves);
                     else
@@ -289,11 +298,16 @@ PG_D void wave_replay(uint32_t* fb, const AtlasView& atlas, const Blit& mine, un
                 continue;
             }
             mask &= mask - 1;
+            if (halves == 2 && (g & 1) != half) continue;  // with two waves the small draws of a group alternate
+            const Blit b = blit_from_lane(mine, src);
+            const int x0 = b.dx > 0 ? b.dx : 0, y0 = b.dy > 0 ? b.dy : 0;
+            const int x1 = (b.dx + b.dw) < kObsW ? (b.dx + b.dw) : kObsW;
+            const int y1 = (b.dy + b.dh) < kObsH ? (b.dy + b.dh) : kObsH;
+            const int cw = x1 - x0, ch = y1 - y0;
             if (cw <= 0 || ch <= 0 || lane >= cw * ch) continue;
             const int ry = udiv_small(lane, cw);
             const int rx = lane - ry * cw;
             const int x = x0 + rx, y = y0 + ry;
-            if (halves == 2 && (y >> 5) != half) continue;  // the other wave's rows
             int i = x - b.dx, j = y - b.dy;
             if (b.flip_mod & kFlipH) i = b.dw - 1 - i;
             if (b.flip_mod & kFlipV) j = b.dh - 1 - j;
@@ -306,7 +320,7 @@ PG_D void wave_replay(uint32_t* fb, const AtlasView& atlas, const Blit& mine, un
 #pragma unroll
         for (int g = 0; g < kGroup; g++) {
             if (idx[g] >= 0) blend_into(fb, idx[g], texel[g], mod[g]);
-            __syncthreads();  // single-wave workgroup: orders the LDS traffic of consecutive draws
+            __syncthreads();  // orders the LDS traffic of consecutive draws (they may overlap)
         }
     }
 }
