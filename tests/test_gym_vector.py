@@ -1,0 +1,129 @@
+"""procgen2_amd.gym_vector: the Gymnasium VectorEnv-shaped wrapper, exercised on the CPU over an
+oracle-backed stand-in engine (the wrapper only needs reset/step/close/num_envs), and on the GPU over the real one."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle_util
+from procgen2_amd.gym_vector import GymVectorAdapter, NUM_ACTIONS, make_spaces
+
+
+class OracleEngine:
+    """The engine's contract on the CPU: N single-env oracle objects, next-step auto-reset, reseeding masked resets."""
+
+    def __init__(self, game, n, seed_base=1):
+        oracle_util.register_textures(game)
+        self.L = oracle_util.oracle()
+        self.game = game
+        self.num_envs = n
+        self.h = [self.L.pgo_make(game.encode(), seed_base + i, 1) for i in range(n)]
+        self.pending = [False] * n
+        self.obs = np.zeros((n, 64, 64, 3), np.uint8)
+        self.reward = np.zeros(n, np.float32)
+        self.done = np.zeros(n, np.uint8)
+
+    def _grab(self, i):
+        self.obs[i] = np.ctypeslib.as_array(self.L.pgo_obs(self.h[i]), shape=(12288,)).reshape(64, 64, 3)
+
+    def reset(self, mask=None, seeds=None):
+        for i, h in enumerate(self.h):
+            if mask is not None and not mask[i]:
+                continue
+            self.L.pgo_reset(h, 0 if seeds is None else 1, 0 if seeds is None else int(seeds[i]))
+            self.pending[i] = False
+            self.reward[i] = 0.0
+            self.done[i] = 0
+            self._grab(i)
+        return self.obs
+
+    def step(self, actions):
+        actions = np.asarray(actions)
+        for i, h in enumerate(self.h):
+            if self.pending[i]:
+                self.L.pgo_reset(h, 0, 0)
+                self.pending[i] = False
+                self.reward[i], self.done[i] = 0.0, 0
+            else:
+                self.L.pgo_step(h, int(actions[i]))
+                self.reward[i] = self.L.pgo_reward(h)
+                self.done[i] = 1 if self.L.pgo_terminated(h) else 0
+                self.pending[i] = bool(self.done[i])
+            self._grab(i)
+        return self.obs, self.reward, self.done
+
+    def close(self):
+        for h in self.h:
+            self.L.pgo_close(h)
+        self.h = []
+
+
+def test_spaces_have_the_vector_env_shapes():
+    single_obs, single_act, obs, act = make_spaces(5)
+    assert single_obs.shape == (64, 64, 3) and single_obs.dtype == np.uint8
+    assert int(single_obs.low.min()) == 0 and int(single_obs.high.max()) == 255
+    assert single_act.n == NUM_ACTIONS
+    assert obs.shape == (5, 64, 64, 3)
+    assert act.shape == (5,) and int(np.asarray(act.nvec)[0]) == NUM_ACTIONS
+    assert single_act.contains(single_act.sample())
+    assert act.contains(np.asarray(act.sample()))
+
+
+def test_wrapper_over_the_oracle_engine_reset_step_autoreset():
+    n = 6
+    env = GymVectorAdapter(OracleEngine("maze", n), output="numpy")
+    assert env.num_envs == n and env.observation_space.shape == (n, 64, 64, 3)
+    obs, info = env.reset(seed=40)
+    assert obs.shape == (n, 64, 64, 3) and obs.dtype == np.uint8 and info == {}
+    first = obs.copy()
+    rng = np.random.default_rng(0)
+    ended_at = {}
+    for s in range(520):  # maze episodes end by step 500 at the latest (timeout counts as terminated, D5)
+        obs, reward, terminated, truncated, info = env.step(rng.integers(0, NUM_ACTIONS, n))
+        assert reward.shape == (n,) and terminated.dtype == bool and not truncated.any()
+        for i in np.nonzero(terminated)[0]:
+            ended_at.setdefault(int(i), s)
+        for i, t in ended_at.items():
+            if s == t + 1:  # NEXT_STEP autoreset: reward 0, not terminated, a fresh level
+                assert reward[i] == 0.0 and not terminated[i]
+    assert len(ended_at) == n
+    # same seeds → same first frames; scalar seed = seed + i, explicit list accepted
+    again, _ = env.reset(seed=40)
+    assert np.array_equal(again, first)
+    listed, _ = env.reset(seed=[40 + i for i in range(n)])
+    assert np.array_equal(listed, first)
+    # masked reset leaves the other envs' observations alone
+    obs, *_ = env.step(np.zeros(n, np.int64))
+    before = obs.copy()
+    mask = np.array([1, 0, 0, 1, 0, 0], bool)
+    after, _ = env.reset(seed=7, options={"reset_mask": mask})
+    assert np.array_equal(after[~mask], before[~mask])
+    with pytest.raises(ValueError):
+        env.step(np.zeros(n + 1, np.int64))
+    with pytest.raises(ValueError):
+        env.reset(options={"nonsense": 1})
+    env.close()
+    env.close()  # idempotent
+
+
+@pytest.mark.gpu
+def test_wrapper_over_the_hip_engine_matches_the_oracle_engine():
+    import torch
+    from procgen2_amd.gym_vector import ProcgenGymVectorEnv
+    n = 8
+    gpu = ProcgenGymVectorEnv("coinrun", n, seed=1)
+    cpu = GymVectorAdapter(OracleEngine("coinrun", n), output="numpy")
+    o_g, _ = gpu.reset(seed=900)
+    o_c, _ = cpu.reset(seed=900)
+    assert isinstance(o_g, torch.Tensor) and o_g.is_cuda and tuple(o_g.shape) == (n, 64, 64, 3)
+    assert np.array_equal(o_g.cpu().numpy(), o_c)
+    rng = np.random.default_rng(3)
+    for s in range(120):
+        a = rng.integers(0, NUM_ACTIONS, n)
+        og, rg, tg, ug, _ = gpu.step(torch.as_tensor(a, dtype=torch.int32, device="cuda"))
+        oc, rc, tc, uc, _ = cpu.step(a)
+        assert np.array_equal(og.cpu().numpy(), oc), s
+        assert np.array_equal(rg.cpu().numpy(), rc) and np.array_equal(tg.cpu().numpy(), tc)
+        assert not bool(ug.any())
+    gpu.close()
+    cpu.close()
