@@ -173,15 +173,14 @@ def mixed(a, torch, ProcgenVecEnv, distributed, world, rank, local_rank, n_gpus,
     counts = [base] * (len(GAMES) - 1) + [a.envs - base * (len(GAMES) - 1)]
     envs = []
     for game, count in zip(GAMES, counts):
-        with torch.cuda.stream(torch.cuda.Stream(device=local_rank)):
-            envs.append(ProcgenVecEnv(game, count, device=local_rank, seed_base=1, env_offset=rank * count))
+        envs.append(ProcgenVecEnv(game, count, device=local_rank, seed_base=1, env_offset=rank * count))  # own stream each
     for e in envs:
         e.reset()
 
     def run(steps):
         for _ in range(steps):
             for e in envs:
-                e.step_synthetic(run_seed)
+                e.step_synthetic(run_seed, ordered=False)
             if a.gather and distributed:
                 for e in envs:
                     e.sync()

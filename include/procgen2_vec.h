@@ -90,6 +90,10 @@ PGV_API void* pgv_stream(pgv_env* env);
 /* Synchronous copies to host memory (any pointer may be NULL). */
 PGV_API int32_t pgv_copy_out(pgv_env* env, uint8_t* h_obs, float* h_reward, uint8_t* h_done);
 
+/* cenv_render for one env of the batch (games/coinrun/coinrun.cpp:393-411, render_game(false)): the human-size frame,
+ * width x height x 3 bytes row-major RGB into a HOST buffer.  Synchronises the env's stream.  Debug / viewer path. */
+PGV_API int32_t pgv_render_frame(pgv_env* env, int32_t index, int32_t width, int32_t height, uint8_t* h_rgb);
+
 /* Measurement helper for bench.py: runs `steps` synthetic steps and returns, from HIP events recorded
  * on the env's stream, the total time of the region and the summed time of the dominant (render)
  * kernel launches inside it. */

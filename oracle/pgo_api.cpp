@@ -44,6 +44,9 @@ void* pgo_make(const char* game, uint32_t seed, int render_enabled) {
 
 void pgo_close(void* h) { delete static_cast<Env*>(h); }
 
+void pgo_render_frame(void* h, int width, int height, uint8_t* out_rgb) {
+    static_cast<Env*>(h)->render_frame(width, height, out_rgb);
+}
 void pgo_reset(void* h, int reseed, int32_t seed) { static_cast<Env*>(h)->reset(reseed != 0, seed); }
 
 void pgo_step(void* h, int action) { static_cast<Env*>(h)->step(action); }

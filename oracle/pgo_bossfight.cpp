@@ -440,9 +440,9 @@ class Bossfight final : public Env {
     }
 
     void paint() override {  // bossfight.cpp:401-424
-        surface_.clear_black();
-        painter_.cam_scale = 1.0f * static_cast<float>(kObsW) / static_cast<float>(kObsW);
-        painter_.cam_size = {static_cast<float>(kObsW), static_cast<float>(kObsH)};
+        painter_.target->clear_black();
+        painter_.cam_scale = 1.0f * static_cast<float>(view_w_) / static_cast<float>(kObsW);
+        painter_.cam_size = {static_cast<float>(view_w_), static_cast<float>(view_h_)};
         const V2 cs = painter_.cam_size;
         const float sc = painter_.cam_scale;
         const Texture* bg = tex_space_[backdrop_];

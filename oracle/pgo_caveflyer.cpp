@@ -436,9 +436,9 @@ class Caveflyer final : public Env {
     }
 
     void paint() override {  // caveflyer.cpp:413-440
-        surface_.clear_black();
-        painter_.cam_scale = 0.5f * static_cast<float>(kObsW) / static_cast<float>(kObsW);
-        painter_.cam_size = {static_cast<float>(kObsW), static_cast<float>(kObsH)};
+        painter_.target->clear_black();
+        painter_.cam_scale = 0.5f * static_cast<float>(view_w_) / static_cast<float>(kObsW);
+        painter_.cam_size = {static_cast<float>(view_w_), static_cast<float>(view_h_)};
         const Texture* bg = tex_space_[backdrop_];
         const float aspect = static_cast<float>(bg->w) / static_cast<float>(bg->h);
         const float extra = aspect - 1.0f;

@@ -432,9 +432,9 @@ class Chaser final : public Env {
     }
 
     void paint() override {  // chaser.cpp:390-416
-        surface_.clear_black();
-        painter_.cam_scale = static_cast<float>(kObsW) * kPxUnit / static_cast<float>(W);
-        painter_.cam_size = {static_cast<float>(kObsW), static_cast<float>(kObsH)};
+        painter_.target->clear_black();
+        painter_.cam_scale = static_cast<float>(view_w_) * kPxUnit / static_cast<float>(W);
+        painter_.cam_size = {static_cast<float>(view_w_), static_cast<float>(view_h_)};
         const Texture* bg = tex_floor_[backdrop_];
         const float aspect = static_cast<float>(bg->w) / static_cast<float>(bg->h);
         const float extra = aspect - 1.0f;

@@ -338,9 +338,9 @@ class Climber final : public Env {
     }
 
     void paint() override {  // climber.cpp:431-459
-        surface_.clear_black();
-        painter_.cam_scale = 0.2f * static_cast<float>(kObsW) / static_cast<float>(kObsW);
-        painter_.cam_size = {static_cast<float>(kObsW), static_cast<float>(kObsH)};
+        painter_.target->clear_black();
+        painter_.cam_scale = 0.2f * static_cast<float>(view_w_) / static_cast<float>(kObsW);
+        painter_.cam_size = {static_cast<float>(view_w_), static_cast<float>(view_h_)};
         const Texture* bg = tex_backdrop_[backdrop_];
         float aspect = static_cast<float>(bg->w) / static_cast<float>(bg->h);
         float extra = aspect - 1.0f;

@@ -546,9 +546,9 @@ void Coinrun::advance(int action) {  // coinrun.cpp:356-371
 }
 
 void Coinrun::paint() {  // coinrun.cpp:443-470
-    surface_.clear_black();
-    painter_.cam_scale = 0.3f * static_cast<float>(kObsW) / static_cast<float>(kObsW);
-    painter_.cam_size = {static_cast<float>(kObsW), static_cast<float>(kObsH)};
+    painter_.target->clear_black();
+    painter_.cam_scale = 0.3f * static_cast<float>(view_w_) / static_cast<float>(kObsW);
+    painter_.cam_size = {static_cast<float>(view_w_), static_cast<float>(view_h_)};
 
     const Texture* bg = tex_backdrop_[backdrop_];
     float aspect = static_cast<float>(bg->w) / static_cast<float>(bg->h);

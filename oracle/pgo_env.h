@@ -38,6 +38,26 @@ class Env {
 
     void set_render_enabled(bool on) { painter_.enabled = on; }
 
+    // cenv_render (coinrun.cpp:393-411): render_game(false) into a width×height target, packed RGB.  The reference
+    // leaves its global camera scale/size at the window's values afterwards (only bossfight's reset reads them, D15);
+    // this restatement puts them back, i.e. it models a caller that never mixes human frames into a rollout.
+    void render_frame(int width, int height, uint8_t* out_rgb) {
+        Surface big(width, height);
+        Surface* keep_target = painter_.target;
+        const V2 keep_size = painter_.cam_size;
+        const float keep_scale = painter_.cam_scale;
+        painter_.target = &big;
+        view_w_ = width;
+        view_h_ = height;
+        paint();
+        pack_rgb(big, out_rgb);
+        painter_.target = keep_target;
+        painter_.cam_size = keep_size;
+        painter_.cam_scale = keep_scale;
+        view_w_ = kObsW;
+        view_h_ = kObsH;
+    }
+
     float reward = 0.0f;
     bool terminated = false;
     bool truncated = false;
@@ -65,6 +85,7 @@ class Env {
         pack_rgb(surface_, obs);
     }
 
+    int view_w_ = kObsW, view_h_ = kObsH;  // `width`, `height` of render_game(is_obs): the target being painted
     Rng rng_;
     Surface surface_;
     Painter painter_;

@@ -408,10 +408,10 @@ class Jumper final : public Env {
     }
 
     void paint() override {  // jumper.cpp:445-509
-        surface_.clear_black();
+        painter_.target->clear_black();
         const float game_zoom = 0.3f;
-        painter_.cam_scale = game_zoom * static_cast<float>(kObsW) / static_cast<float>(kObsW);
-        painter_.cam_size = {static_cast<float>(kObsW), static_cast<float>(kObsH)};
+        painter_.cam_scale = game_zoom * static_cast<float>(view_w_) / static_cast<float>(kObsW);
+        painter_.cam_size = {static_cast<float>(view_w_), static_cast<float>(view_h_)};
         const Texture* bg = tex_backdrop_[backdrop_];
         const float aspect = static_cast<float>(bg->w) / static_cast<float>(bg->h);
         const float extra = aspect - 1.0f;
@@ -487,7 +487,7 @@ class Jumper final : public Env {
         }
         if (!painter_.enabled) return;
         // compass HUD: raw SDL_RenderTextureRotated calls in screen space (jumper.cpp:473-509)
-        const float width = static_cast<float>(kObsW);
+        const float width = static_cast<float>(view_w_);
         const float compass_size = 200.0f;
         const V2 compass_offset{-32.0f, 32.0f};
         float angle = std::atan2(to_goal.y, to_goal.x) * 180.0f / M_PI;
@@ -497,7 +497,7 @@ class Jumper final : public Env {
         float ratio = std::min(1.0f, dist / (W * 1.414f));
         auto whole = [&](const Texture* t, float dx, float dy, float dw, float dh, double deg) {
             painter_.draw_calls++;
-            spec_blit(surface_, *t, 0.0f, 0.0f, static_cast<float>(t->w), static_cast<float>(t->h), dx, dy, dw, dh, deg,
+            spec_blit(*painter_.target, *t, 0.0f, 0.0f, static_cast<float>(t->w), static_cast<float>(t->h), dx, dy, dw, dh, deg,
                       kFlipNone, 255);
         };
         whole(tex_circle_, width - compass_size * game_zoom + compass_offset.x * game_zoom, compass_offset.y * game_zoom,

@@ -206,10 +206,10 @@ class Maze final : public Env {
     }
 
     void paint() override {  // maze.cpp:386-414
-        surface_.clear_black();
-        float zoom = static_cast<float>(kObsW) / (kUnitPx * static_cast<float>(25));
+        painter_.target->clear_black();
+        float zoom = static_cast<float>(view_w_) / (kUnitPx * static_cast<float>(25));
         painter_.cam_scale = zoom;
-        painter_.cam_size = {static_cast<float>(kObsW), static_cast<float>(kObsH)};
+        painter_.cam_size = {static_cast<float>(view_w_), static_cast<float>(view_h_)};
 
         const Texture* bg = tex_floor_[floor_];
         float aspect = static_cast<float>(bg->w) / static_cast<float>(bg->h);

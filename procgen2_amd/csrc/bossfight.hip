@@ -16,6 +16,7 @@
 // barriers newest-first, then the boss (libstdc++ unordered_set with 13 buckets, one id per bucket, each insert
 // goes to the list head — SURVEY.md T3), which is the order first-hit tests below use.
 #include "pg_engine.h"
+#include "pg_frame.h"
 #include "pg_geom.h"
 #include "pg_render.h"
 #include "pg_rng.h"
@@ -719,6 +720,79 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// cenv_render's frame (render_game(false)) for one env: pg_frame.h; the draw list of render_kernel, one draw at a time.
+__global__ void __launch_bounds__(kFrameThreads) frame_kernel(State s, AtlasView atlas, int env, FrameTarget t) {
+    const float fw = static_cast<float>(t.w), fh = static_cast<float>(t.h);
+    const float sc = 1.0f * fw / 64.0f;
+    FramePainter P{t, atlas, Camera{0.0f, 0.0f, fw, fh, sc}, static_cast<int>(threadIdx.x), kFrameThreads};
+    const int skins = SI(s, I_SKINS, env), sflags = SI(s, I_FLAGS, env);
+    const int a_ship = skins & 15, a_laser = (skins >> 4) & 15, b_ship = (skins >> 8) & 15, b_laser = (skins >> 12) & 15;
+    const int backdrop = (skins >> 16) & 255;
+    const int a_next = SI(s, I_A_NEXT, env), a_count = SI(s, I_A_COUNT, env);
+    const int b_next = SI(s, I_B_NEXT, env), b_count = SI(s, I_B_COUNT, env);
+    const int x_next = SI(s, I_X_NEXT, env), x_count = SI(s, I_X_COUNT, env);
+    const int n_rocks = SI(s, I_NROCKS, env), phase = SI(s, I_PHASE, env);
+    const float bx = SF(s, F_BX, env), by = SF(s, F_BY, env), ax = SF(s, F_AX, env), ay = SF(s, F_AY, env);
+    P.clear();
+    {
+        const int tex = kTexSpace + backdrop;
+        P.draw(tex, -fw / sc * 0.5f, -fh / sc * 0.5f, 1.0f / P.desc(tex).z * fh / sc);
+    }
+    for (int i = 0; i < b_count; i++) {
+        const int k = (kBossShots + b_next - 1 - i) % kBossShots;
+        const float frame = BS(s, S_FRAME, k, env);
+        if (frame == -1.0f) continue;
+        const int tex = (frame == 0.0f) ? kTexLaser + b_laser : kTexBoom + static_cast<int>(frame - 1.0f);
+        const int4 d = P.desc(tex);
+        const float size = 0.1f;
+        P.draw_rotated(tex, BS(s, S_X, k, env) * kUnitPx - size * d.y * 0.5f, BS(s, S_Y, k, env) * kUnitPx - size * d.z * 0.5f,
+                       static_cast<float>(BS(s, S_ROT, k, env) + kPi * 0.5f), size);
+    }
+    {
+        const int tex = kTexBoss + b_ship;
+        const int4 d = P.desc(tex);
+        const float size = 0.25f;
+        P.draw(tex, bx * kUnitPx - size * d.y * 0.5f, by * kUnitPx - size * d.z * 0.5f, size);
+    }
+    if (phase % 2 == 0) {
+        const int4 d = P.desc(kTexShield);
+        const float size = 0.25f;
+        P.draw(kTexShield, bx * kUnitPx - size * d.y * 0.5f, by * kUnitPx - size * d.z * 0.5f, size, 0.7f);
+    }
+    for (int i = 0; i < x_count; i++) {
+        const int k = (kBooms + x_next - 1 - i) % kBooms;
+        const float frame = BM(s, 2, k, env);
+        if (frame == -1.0f) continue;
+        const int tex = kTexBoom + static_cast<int>(frame);
+        const int4 d = P.desc(tex);
+        const float size = 0.3f;
+        P.draw(tex, BM(s, 0, k, env) * kUnitPx - size * d.y * 0.5f, BM(s, 1, k, env) * kUnitPx - size * d.z * 0.5f, size);
+    }
+    if (sflags & kFlagListed)
+        for (int k = 0; k < n_rocks; k++) {
+            const int r = n_rocks - 1 - k;  // sprite set order: newest barrier first
+            const int tex = kTexRock + static_cast<int>(RK(s, 2, r, env));
+            const float scale = 1.0f * 0.3f;
+            P.draw(tex, (RK(s, 0, r, env) + -0.15f) * kUnitPx, (RK(s, 1, r, env) + -0.15f) * kUnitPx,
+                   scale * kUnitPx / P.desc(tex).y);
+        }
+    for (int i = 0; i < a_count; i++) {
+        const int k = (kAgentShots + a_next - 1 - i) % kAgentShots;
+        const float frame = AS(s, S_FRAME, k, env);
+        if (frame == -1.0f) continue;
+        const int tex = (frame == 0.0f) ? kTexLaser + a_laser : kTexBoom + static_cast<int>(frame - 1.0f);
+        const int4 d = P.desc(tex);
+        const float size = 0.05f;
+        P.draw(tex, AS(s, S_X, k, env) * kUnitPx - size * d.y * 0.5f, AS(s, S_Y, k, env) * kUnitPx - size * d.z * 0.5f, size);
+    }
+    {
+        const int tex = kTexPlayer + a_ship;
+        const int4 d = P.desc(tex);
+        const float size = 0.05f;
+        P.draw(tex, ax * kUnitPx - size * d.y * 0.5f, ay * kUnitPx - size * d.z * 0.5f, size);
+    }
+}
+
 class BossfightGame final : public Game {
    public:
     const char* name() const override { return "bossfight"; }
@@ -789,6 +863,10 @@ class BossfightGame final : public Game {
                       StepIO io) override {
         hipLaunchKernelGGL(logic_kernel, dim3(logic_blocks(s_.n)), dim3(logic_lanes()), 0, st, s_, actions, run_seed, step_index,
                            env_offset, io);
+    }
+    bool launch_frame(hipStream_t st, int env, uint32_t* d_px, int w, int h) override {
+        hipLaunchKernelGGL(frame_kernel, dim3(1), dim3(kFrameThreads), 0, st, s_, atlas_, env, FrameTarget{d_px, w, h});
+        return true;
     }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
         hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags);

@@ -20,6 +20,7 @@
 //              generated ahead of time on a side stream into a shadow slot and merely copied in when the episode
 //              ends (pg_prefetch.h); the synchronous path remains as the fallback and for reseeding resets.
 #include "pg_engine.h"
+#include "pg_frame.h"
 #include "pg_geom.h"
 #include "pg_order.h"
 #include "pg_prefetch.h"
@@ -654,6 +655,66 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
     wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane, half, halves);
 }
 
+// cenv_render's frame (render_game(false)) for one env: pg_frame.h; the draw list of render_kernel, one draw at a time.
+__global__ void __launch_bounds__(kFrameThreads) frame_kernel(State s, AtlasView atlas, int env, FrameTarget t) {
+    const float fw = static_cast<float>(t.w), fh = static_cast<float>(t.h);
+    FramePainter P{t, atlas, Camera{SF(s, F_CAMX, env), SF(s, F_CAMY, env), fw, fh, 0.5f * fw / 64.0f},
+                   static_cast<int>(threadIdx.x), kFrameThreads};
+    const int sflags = SI(s, I_FLAGS, env);
+    const int n_draw = (sflags & kFlagListed) ? SI(s, I_NDRAW, env) : 0;
+    const int s_next = SI(s, I_SNEXT, env), s_count = SI(s, I_SCOUNT, env);
+    const uint8_t* tiles = s.tiles + size_t(env) * kCells;
+    P.clear();
+    {
+        const int4 d = P.desc(kTexSpace + SI(s, I_BACKDROP, env));
+        const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
+        const float extra = aspect - 1.0f;
+        P.draw(kTexSpace + SI(s, I_BACKDROP, env), -SF(s, F_BGSHIFT, env) * extra, 0.0f, 64.0f * kUnitPx / d.z);
+    }
+    int x0, y0, x1, y1;
+    P.window(x0, y0, x1, y1);
+    for (int y = y0; y <= y1; y++)
+        for (int x = x0; x <= x1; x++)
+            if (Win::direct(tiles, x, y) != kEmpty) P.draw(kTexWall, x * kUnitPx, y * kUnitPx, kUnitPx / P.desc(kTexWall).y);
+    for (int k = 0; k < kPuffs; k++) {
+        const float life = PF(s, PF_LIFE, k, env);
+        if (life <= 0.0f) continue;
+        const int4 d = P.desc(kTexPuff);
+        const float lifespan = 3.0f;
+        const float life_ratio = (lifespan - life) / lifespan;
+        const float alpha = 0.5f * (1.0f - life_ratio);
+        const float scale = 1.0f * (0.4f * life_ratio + 0.6f);
+        const float shift = life_ratio * 2.0f;
+        const float size = scale * kUnitPx / d.y;
+        P.draw_rotated(kTexPuff, (PF(s, PF_X, k, env) + PF(s, PF_DX, k, env) * shift) * kUnitPx - size * d.y * 0.5f,
+                       (PF(s, PF_Y, k, env) + PF(s, PF_DY, k, env) * shift) * kUnitPx - size * d.z * 0.5f,
+                       PF(s, PF_ROT, k, env), size, alpha);
+    }
+    for (int k = 0; k < n_draw; k++) {
+        const int e = EB(s, EB_DRAW, k, env);
+        const int tex = kTexKind + (EB(s, EB_INFO, e, env) & kKindMask);
+        const float scale = 1.0f * 0.8f;
+        P.draw(tex, (EF(s, EF_X, e, env) + -0.4f) * kUnitPx, (EF(s, EF_Y, e, env) + -0.4f) * kUnitPx,
+               scale * kUnitPx / P.desc(tex).y);
+    }
+    for (int i = 0; i < s_count; i++) {
+        const int k = (kShots + s_next - 1 - i) % kShots;
+        const float frame = SH(s, SH_FRAME, k, env);
+        if (frame == -1.0f) continue;
+        const int tex = (frame == 0.0f) ? kTexLaser : kTexBoom + static_cast<int>(frame - 1.0f);
+        const int4 d = P.desc(tex);
+        const float size = 0.1f;
+        P.draw_rotated(tex, SH(s, SH_X, k, env) * kUnitPx - size * d.y * 0.5f, SH(s, SH_Y, k, env) * kUnitPx - size * d.z * 0.5f,
+                       static_cast<float>(SH(s, SH_ROT, k, env) + kPi * 0.5f), size);
+    }
+    {
+        const int4 d = P.desc(kTexShip);
+        const float size = 0.15f;
+        P.draw_rotated(kTexShip, SF(s, F_AX, env) * kUnitPx - size * d.y * 0.5f, SF(s, F_AY, env) * kUnitPx - size * d.z * 0.5f,
+                       static_cast<float>(SF(s, F_ROT, env) + kPi * 0.5f), size);
+    }
+}
+
 class CaveflyerGame final : public Game {
    public:
     const char* name() const override { return "caveflyer"; }
@@ -734,6 +795,10 @@ class CaveflyerGame final : public Game {
         LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io);
         hipLaunchKernelGGL(logic_kernel, dim3(logic_blocks(s_.n)), dim3(logic_lanes()), 0, st, s_, actions, run_seed, step_index,
                            env_offset, io);
+    }
+    bool launch_frame(hipStream_t st, int env, uint32_t* d_px, int w, int h) override {
+        hipLaunchKernelGGL(frame_kernel, dim3(1), dim3(kFrameThreads), 0, st, s_, atlas_, env, FrameTarget{d_px, w, h});
+        return true;
     }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
         hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags);

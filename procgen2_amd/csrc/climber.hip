@@ -14,6 +14,7 @@
 // order (pg_order.h, computed at reset) plus an alive bit per entity, and re-runs the introsort emulation over the
 // survivors whenever the set changed.
 #include "pg_engine.h"
+#include "pg_frame.h"
 #include "pg_geom.h"
 #include "pg_order.h"
 #include "pg_prefetch.h"
@@ -505,6 +506,57 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
     wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane, half, halves);
 }
 
+// cenv_render's frame (render_game(false)) for one env: pg_frame.h; the draw list of render_kernel, one draw at a time.
+__global__ void __launch_bounds__(kFrameThreads) frame_kernel(State s, AtlasView atlas, int env, FrameTarget t) {
+    const float fw = static_cast<float>(t.w), fh = static_cast<float>(t.h);
+    FramePainter P{t, atlas, Camera{W / 2.0f * kUnitPx, SF(s, F_CAMY, env), fw, fh, 0.2f * fw / 64.0f},
+                   static_cast<int>(threadIdx.x), kFrameThreads};
+    const int themes = SI(s, I_THEMES, env), sflags = SI(s, I_FLAGS, env);
+    const int backdrop = themes & 0xff, suit = (themes >> 8) & 0xff, theme = (themes >> 16) & 0xff;
+    const int n_draw = (sflags & kFlagListed) ? SI(s, I_NDRAW, env) : 0;
+    const uint8_t* tiles = s.tiles + size_t(env) * (W * H);
+    P.clear();
+    {
+        const int4 d = P.desc(kTexBackdrop + backdrop);
+        const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
+        const float extra = aspect - 1.0f;
+        P.draw(kTexBackdrop + backdrop, -SF(s, F_BGSHIFT, env) * extra, 0.0f, 64.0f * kUnitPx / d.z);
+    }
+    int x0, y0, x1, y1;
+    P.window(x0, y0, x1, y1);
+    for (int y = y0; y <= y1; y++)
+        for (int x = x0; x <= x1; x++) {
+            const int tile = Win::direct(tiles, x, y);
+            if (tile == kEmpty) continue;
+            const int tex = (tile == kWallTop ? kTexTop : kTexMid) + theme;
+            P.draw(tex, x * kUnitPx, y * kUnitPx, kUnitPx / P.desc(tex).y);
+        }
+    for (int k = 0; k < n_draw; k++) {
+        const int e = EB(s, EB_DRAW, k, env);
+        const int info = EB(s, EB_INFO, e, env);
+        if (!(info & kTexSet)) continue;
+        const int tex = (info & kMob) ? kTexFish + ((info & kFrame) ? 1 : 0) : kTexGem;
+        const float off = (info & kMob) ? -0.4f : -0.5f;
+        const float scale = 1.0f * 1.0f;
+        P.draw(tex, (EF(s, EF_X, e, env) + off) * kUnitPx, (EF(s, EF_Y, e, env) + off) * kUnitPx,
+               scale * kUnitPx / P.desc(tex).y, 1.0f, (info & kFlip) != 0);
+    }
+    {
+        const bool ground = (sflags & kFlagGround) != 0;
+        int tex;
+        if (fabsf(SF(s, F_AVX, env)) < 0.01f && ground)
+            tex = kTexStand + suit;
+        else if (!ground)
+            tex = kTexJump + suit;
+        else if (SF(s, F_APHASE, env) > 0.5f)
+            tex = kTexWalk2 + suit;
+        else
+            tex = kTexWalk1 + suit;
+        const float px = SF(s, F_AX, env) - 0.5f, py = SF(s, F_AY, env) - 1.0f;
+        P.draw(tex, px * kUnitPx, py * kUnitPx, 0.8f * kUnitPx / P.desc(tex).y, 1.0f, (sflags & kFlagForward) == 0);
+    }
+}
+
 class ClimberGame final : public Game {
    public:
     const char* name() const override { return "climber"; }
@@ -588,6 +640,10 @@ class ClimberGame final : public Game {
         LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io);
         hipLaunchKernelGGL(logic_kernel, dim3(logic_blocks(s_.n)), dim3(logic_lanes()), 0, st, s_, actions, run_seed, step_index,
                            env_offset, io);
+    }
+    bool launch_frame(hipStream_t st, int env, uint32_t* d_px, int w, int h) override {
+        hipLaunchKernelGGL(frame_kernel, dim3(1), dim3(kFrameThreads), 0, st, s_, atlas_, env, FrameTarget{d_px, w, h});
+        return true;
     }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
         hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags);

@@ -27,6 +27,7 @@
 //      sub-steps really happened; in the rare case that is fewer than four, that env's entities are redone from
 //      the untouched half with that limit.  Writes reward / done and commits the agent.
 #include "pg_engine.h"
+#include "pg_frame.h"
 #include "pg_geom.h"
 #include "pg_order.h"
 #include "pg_prefetch.h"
@@ -978,6 +979,83 @@ __global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, Atla
     if (!(flags & 8)) wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane, half, halves);
 }
 
+// cenv_render's frame (coinrun.cpp:393-411 → render_game(false), :443-470) for one env: pg_frame.h.
+__global__ void __launch_bounds__(kFrameThreads) frame_kernel(State s, AtlasView atlas, int env, FrameTarget t) {
+    FramePainter P{t, atlas,
+                   Camera{SF(s, F_CAMX, env), SF(s, F_CAMY, env), static_cast<float>(t.w), static_cast<float>(t.h),
+                          0.3f * static_cast<float>(t.w) / 64.0f},
+                   static_cast<int>(threadIdx.x), kFrameThreads};
+    const int themes = SI(s, I_THEMES, env), sflags = SI(s, I_FLAGS, env);
+    const int buf = (sflags & kFlagBuf) ? 1 : 0;
+    const int backdrop = themes & 0xff, alien = (themes >> 8) & 0xff, ground_theme = (themes >> 16) & 0xff;
+    const uint8_t* tiles = s.tiles + size_t(env) * (W * H);
+    P.clear();
+    {
+        const int4 d = P.desc(kTexBackdrop + backdrop);
+        const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
+        const float extra = aspect - 1.0f;
+        P.draw(kTexBackdrop + backdrop, -SF(s, F_BGSHIFT, env) * extra, 0.0f, 64.0f * kUnitPx / d.z);
+    }
+    int x0, y0, x1, y1;
+    P.window(x0, y0, x1, y1);
+    for (int y = y0; y <= y1; y++)
+        for (int x = x0; x <= x1; x++) {
+            const int ty = H - 1 - y;
+            int t_id = kWallMid, crate = 0;
+            if (x >= 0 && ty >= 0 && x < W && ty < H) {
+                const int raw = tiles[ty + x * H];
+                t_id = raw & 7;
+                crate = raw >> 4;
+            }
+            if (t_id == kEmpty) continue;
+            const int tex = t_id == kWallMid   ? kTexMid + ground_theme
+                            : t_id == kWallTop ? kTexTop + ground_theme
+                            : t_id == kLavaMid ? kTexLava
+                            : t_id == kLavaTop ? kTexLavaTop
+                                               : kTexCrate + crate;
+            P.draw(tex, x * kUnitPx, y * kUnitPx, kUnitPx / P.desc(tex).y);
+        }
+    const int n_mob = SI(s, I_NMOB, env);
+    for (int m = 0; m < n_mob; m++) {  // particles, owners in the particle system's set order
+        const int e = EB(s, EB_SPARK_ORDER, m, env);
+        for (int k = 0; k < kSparks; k++) {
+            const float life = SP(s, buf, 2, e, k, env);
+            if (life <= 0.0f) continue;
+            const int4 d = P.desc(kTexSpark);
+            const float lr = (5.0f - life) / 5.0f;
+            const float alpha = 0.5f * (1.0f - lr);
+            const float scale = 0.45f * (0.4f * lr + 0.6f);
+            const float oy = -lr * 0.17f;
+            P.draw(kTexSpark, SP(s, buf, 0, e, k, env) * kUnitPx - 0.5f * d.y * scale,
+                   (SP(s, buf, 1, e, k, env) + oy) * kUnitPx - 0.5f * d.z * scale, scale * kUnitPx / d.y, alpha);
+        }
+    }
+    const int n_sprites = (sflags & kFlagListed) ? SI(s, I_NENT, env) : 0;
+    for (int k = 0; k < n_sprites; k++) {
+        const int e = EB(s, EB_DRAW_ORDER, k, env);
+        const int dyn = DB(s, buf, e, env);
+        if (!(dyn & kDynTexSet)) continue;
+        const int tex = EB(s, EB_TEX, e, env) + ((dyn & kDynFrame) ? 1 : 0);
+        const float scale = 1.0f * 1.0f;
+        P.draw(tex, (DF(s, buf, DF_X, e, env) + -0.5f) * kUnitPx, (EY(s, e, env) + -0.5f) * kUnitPx,
+               scale * kUnitPx / P.desc(tex).y, 1.0f, (dyn & kDynFlip) != 0);
+    }
+    {
+        const bool ground = (sflags & kFlagGround) != 0;
+        int tex;
+        if (fabsf(SF(s, F_AVX, env)) < 0.01f && ground)
+            tex = kTexStand + alien;
+        else if (!ground)
+            tex = kTexJump + alien;
+        else if (SF(s, F_APHASE, env) > 0.5f)
+            tex = kTexWalk2 + alien;
+        else
+            tex = kTexWalk1 + alien;
+        const float px = SF(s, F_AX, env) - 0.5f, py = SF(s, F_AY, env) - 2.0f;
+        P.draw(tex, px * kUnitPx, py * kUnitPx, kUnitPx / P.desc(tex).y, 1.0f, (sflags & kFlagForward) == 0);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -1099,6 +1177,10 @@ class CoinrunGame final : public Game {
                            env_offset, io);
         hipLaunchKernelGGL(entity_kernel, dim3(logic_blocks(s_.n), kMaxEnt), dim3(logic_lanes()), 0, st, s_);
         hipLaunchKernelGGL(resolve_kernel, dim3(logic_blocks(s_.n)), dim3(logic_lanes()), 0, st, s_, io);
+    }
+    bool launch_frame(hipStream_t st, int env, uint32_t* d_px, int w, int h) override {
+        hipLaunchKernelGGL(frame_kernel, dim3(1), dim3(kFrameThreads), 0, st, s_, atlas_, env, FrameTarget{d_px, w, h});
+        return true;
     }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
         hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(64 * kRenderWaves), 0, st, s_, atlas_, mask, io,

@@ -434,6 +434,33 @@ int32_t pgv_timed_steps(pgv_env* e, int32_t steps, uint32_t run_seed, double* to
     return 0;
 }
 
+int32_t pgv_render_frame(pgv_env* e, int32_t index, int32_t width, int32_t height, uint8_t* h_rgb) {
+    if (!e) return fail("pgv_render_frame: env is NULL");
+    if (index < 0 || index >= e->n) return fail("pgv_render_frame: env index out of range");
+    if (width < 1 || height < 1 || width > 4096 || height > 4096 || !h_rgb)
+        return fail("pgv_render_frame: bad frame size or NULL buffer");
+    PG_HIP(hipSetDevice(e->device));
+    const size_t px = size_t(width) * height;
+    uint32_t* d_px = nullptr;
+    PG_HIP(hipMalloc(reinterpret_cast<void**>(&d_px), px * 4));
+    if (!e->game->launch_frame(e->stream, index, d_px, width, height)) {
+        hipFree(d_px);
+        return fail(std::string("pgv_render_frame: not implemented for ") + e->game->name());
+    }
+    std::vector<uint32_t> host(px);
+    hipError_t err = hipGetLastError();
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    if (err == hipSuccess) err = hipMemcpy(host.data(), d_px, px * 4, hipMemcpyDeviceToHost);
+    hipFree(d_px);
+    if (err != hipSuccess) return fail(std::string("pgv_render_frame: ") + hipGetErrorString(err));
+    for (size_t k = 0; k < px; k++) {  // RGBA → RGB, row-major (coinrun.cpp:401-407)
+        h_rgb[3 * k + 0] = static_cast<uint8_t>(host[k]);
+        h_rgb[3 * k + 1] = static_cast<uint8_t>(host[k] >> 8);
+        h_rgb[3 * k + 2] = static_cast<uint8_t>(host[k] >> 16);
+    }
+    return 0;
+}
+
 int32_t pgv_set_debug(pgv_env* e, int32_t flags) {
     if (!e) return fail("pgv_set_debug: env is NULL");
     if (e->side) hipStreamSynchronize(e->side);
@@ -647,9 +674,10 @@ int32_t cenv_step(cenv_key_value* actions, int32_t actions_size) {
 }
 
 int32_t cenv_render(void) {
-    // Human-size frame (coinrun.cpp:393-411).  The W×H render path is SURVEY.md §8f item 2 ("next");
-    // until it lands the frame is the 64×64 observation of env 0, nearest-neighbour enlarged.
+    // Human-size frame (coinrun.cpp:393-411): render_game(false) of env 0 on the GPU (pg_frame.h).
     if (!g.env) return fail("cenv_render: cenv_make has not been called");
+    if (pgv_render_frame(g.env, 0, g.window_w, g.window_h, g.h_frame.data()) == 0) return 0;
+    // a game without a frame kernel: the 64×64 observation of env 0, nearest-neighbour enlarged
     for (int y = 0; y < g.window_h; y++)
         for (int x = 0; x < g.window_w; x++) {
             const int sx = x * pg::kObsW / g.window_w, sy = y * pg::kObsH / g.window_h;

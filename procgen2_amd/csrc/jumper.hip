@@ -14,6 +14,7 @@
 // D21 (oracle/pgo_chaser.cpp) applies to one line: `abs(velocity.x) > 0.01f` (common_systems.cpp:198) is the int abs.
 #include "pg_atan2.h"
 #include "pg_engine.h"
+#include "pg_frame.h"
 #include "pg_geom.h"
 #include "pg_kruskal.h"
 #include "pg_order.h"
@@ -682,6 +683,100 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
     wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane, half, halves);
 }
 
+// cenv_render's frame (render_game(false)) for one env: pg_frame.h; the draw list of render_kernel, one draw at a time.
+__global__ void __launch_bounds__(kFrameThreads) frame_kernel(State s, AtlasView atlas, int env, FrameTarget t) {
+    const float fw = static_cast<float>(t.w), fh = static_cast<float>(t.h);
+    const float game_zoom = 0.3f;
+    FramePainter P{t, atlas, Camera{SF(s, F_CAMX, env), SF(s, F_CAMY, env), fw, fh, game_zoom * fw / 64.0f},
+                   static_cast<int>(threadIdx.x), kFrameThreads};
+    const int themes = SI(s, I_THEMES, env), sflags = SI(s, I_FLAGS, env);
+    const int backdrop = themes & 0xff, theme = (themes >> 8) & 0xff;
+    const int n_draw = (sflags & kFlagListed) ? SI(s, I_NSPIKES, env) + 1 : 0;
+    const uint8_t* tiles = s.tiles + size_t(env) * kCells;
+    P.clear();
+    {
+        const int4 d = P.desc(kTexBackdrop + backdrop);
+        const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
+        const float extra = aspect - 1.0f;
+        P.draw(kTexBackdrop + backdrop, -SF(s, F_BGSHIFT, env) * extra, 0.0f, 64.0f * kUnitPx / d.z);
+    }
+    int x0, y0, x1, y1;
+    P.window(x0, y0, x1, y1);
+    for (int y = y0; y <= y1; y++)
+        for (int x = x0; x <= x1; x++) {
+            const int tile = Win::direct(tiles, x, y);
+            if (!is_wall(tile)) continue;
+            const int tex = (tile == kWallTop ? kTexTop : kTexMid) + theme;
+            P.draw(tex, x * kUnitPx, y * kUnitPx, kUnitPx / P.desc(tex).y);
+        }
+    for (int k = 0; k < kPuffs; k++) {
+        const float life = PF(s, PF_LIFE, k, env);
+        if (life <= 0.0f) continue;
+        const int4 d = P.desc(kTexPuff);
+        const float lifespan = 5.0f;
+        const float life_ratio = (lifespan - life) / lifespan;
+        const float alpha = 0.5f * (1.0f - life_ratio);
+        const float scale = 0.45f * (0.4f * life_ratio + 0.6f);
+        const float offset_y = -life_ratio * 0.17f;
+        P.draw(kTexPuff, PF(s, PF_X, k, env) * kUnitPx - 0.5f * d.y * scale,
+               (PF(s, PF_Y, k, env) + offset_y) * kUnitPx - 0.5f * d.z * scale, scale * kUnitPx / d.y, alpha);
+    }
+    for (int k = 0; k < n_draw; k++) {
+        const int id = s.draw[size_t(k) * s.n + env];
+        if (id == 0) {
+            const float scale = 1.0f * 1.0f;
+            P.draw(kTexCarrot, (SF(s, F_GX, env) + -0.5f) * kUnitPx, (SF(s, F_GY, env) + -0.5f) * kUnitPx,
+                   scale * kUnitPx / P.desc(kTexCarrot).y);
+        } else {
+            const int cell = s.spike_cell[size_t(id - 2) * s.n + env];
+            const float scale = 1.0f * 0.4f;
+            P.draw(kTexSpike, (cell_x(cell) + -0.25f) * kUnitPx, (cell_y(cell) + -0.25f) * kUnitPx,
+                   scale * kUnitPx / P.desc(kTexSpike).y);
+        }
+    }
+    {
+        const float avx = SF(s, F_AVX, env), phase = SF(s, F_APHASE, env);
+        const bool ground = (sflags & kFlagGround) != 0;
+        int tex;
+        float agent_scale = 0.5f, off_x = 0.0f, off_y = 0.2f;
+        if (fabsf(avx) < 0.01f && ground) {
+            tex = kTexStand;
+        } else if (!ground) {
+            tex = kTexJump;
+            agent_scale = 0.6f;
+            off_x = -0.05f;
+            off_y = 0.25f;
+        } else if (phase > 0.5f) {
+            tex = kTexWalk2;
+        } else {
+            tex = kTexWalk1;
+        }
+        const float px = SF(s, F_AX, env) - 0.25f, py = SF(s, F_AY, env) - 1.0f;
+        P.draw(tex, (px + off_x) * kUnitPx, (py + off_y) * kUnitPx, kUnitPx / P.desc(tex).y * agent_scale, 1.0f,
+               (sflags & kFlagForward) == 0);
+    }
+    {   // compass (jumper.cpp:473-509): sized by the base zoom, not by the window
+        const float width = fw, compass_size = 200.0f, offset_x = -32.0f, offset_y = 32.0f;
+        const float tx = SF(s, F_TOGX, env), ty = SF(s, F_TOGY, env);
+        const float angle = static_cast<float>(at_atan2f(ty, tx) * 180.0f / 3.14159265358979323846);
+        const float dist = __fsqrt_rn(tx * tx + ty * ty);
+        const float dist_inv = 1.0f / fmaxf(0.0001f, dist);
+        const float dir_x = tx * dist_inv, dir_y = ty * dist_inv;
+        const float ratio = fminf(1.0f, dist / (W * 1.414f));
+        P.screen(kTexCircle, width - compass_size * game_zoom + offset_x * game_zoom, offset_y * game_zoom,
+                 compass_size * game_zoom, compass_size * game_zoom, 0.0);
+        float dx = width - compass_size * 0.75f * game_zoom + offset_x * game_zoom;
+        float dy = compass_size * 0.5f * game_zoom + offset_y * game_zoom;
+        dx += compass_size * 0.25f * dir_x * game_zoom;
+        dy += compass_size * 0.25f * dir_y * game_zoom;
+        P.screen(kTexNeedle, dx, dy, compass_size * 0.5f * game_zoom, compass_size * 0.1f * game_zoom,
+                 static_cast<double>(angle));
+        P.screen(kTexBar, width - compass_size * game_zoom + offset_x * game_zoom,
+                 compass_size * game_zoom + offset_y * game_zoom, compass_size * game_zoom * ratio,
+                 compass_size * 0.15f * game_zoom, 0.0);
+    }
+}
+
 class JumperGame final : public Game {
    public:
     const char* name() const override { return "jumper"; }
@@ -770,6 +865,10 @@ class JumperGame final : public Game {
         LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io);
         hipLaunchKernelGGL(logic_kernel, dim3(logic_blocks(s_.n)), dim3(logic_lanes()), 0, st, s_, actions, run_seed, step_index,
                            env_offset, io);
+    }
+    bool launch_frame(hipStream_t st, int env, uint32_t* d_px, int w, int h) override {
+        hipLaunchKernelGGL(frame_kernel, dim3(1), dim3(kFrameThreads), 0, st, s_, atlas_, env, FrameTarget{d_px, w, h});
+        return true;
     }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
         hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags);

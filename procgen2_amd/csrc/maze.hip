@@ -11,6 +11,7 @@
 // resets are frequent and bursty; the next maze of every env is carved ahead of time on a side stream and copied
 // in at reset (pg_prefetch.h).
 #include "pg_engine.h"
+#include "pg_frame.h"
 #include "pg_geom.h"
 #include "pg_kruskal.h"
 #include "pg_prefetch.h"
@@ -258,6 +259,35 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
     wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane, half, halves);
 }
 
+// cenv_render's frame (render_game(false)) for one env: pg_frame.h; the draw list of render_kernel, one draw at a time.
+__global__ void __launch_bounds__(kFrameThreads) frame_kernel(State s, AtlasView atlas, int env, FrameTarget t) {
+    const float fw = static_cast<float>(t.w), fh = static_cast<float>(t.h);
+    const float zoom = fw / (kUnitPx * 25.0f);  // maze.cpp:397-400
+    FramePainter P{t, atlas, Camera{W * 0.5f * kUnitPx, H * 0.5f * kUnitPx, fw, fh, zoom}, static_cast<int>(threadIdx.x),
+                   kFrameThreads};
+    const int sflags = SI(s, I_FLAGS, env);
+    const uint8_t* tiles = s.tiles + size_t(env) * kTileStride;
+    P.clear();
+    {
+        const int4 d = P.desc(kTexFloor + SI(s, I_BG, env));
+        const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
+        const float extra = aspect - 1.0f;
+        P.draw(kTexFloor + SI(s, I_BG, env), -SF(s, F_BGSHIFT, env) * extra, 0.0f, 64.0f * kUnitPx / d.z);
+    }
+    int x0, y0, x1, y1;
+    P.window(x0, y0, x1, y1);
+    for (int y = y0; y <= y1; y++)
+        for (int x = x0; x <= x1; x++)
+            if (tile_at(tiles, x, H - 1 - y) != kOpen) P.draw(kTexWall, x * kUnitPx, y * kUnitPx, kUnitPx / P.desc(kTexWall).y);
+    if (sflags & kFlagListed) {
+        const float scale = 1.0f * 0.95f;
+        P.draw(kTexCheese, (SF(s, F_GX, env) + -0.48f) * kUnitPx, (SF(s, F_GY, env) + -0.5f) * kUnitPx,
+               scale * kUnitPx / P.desc(kTexCheese).y);
+    }
+    P.draw(kTexMouse, (SF(s, F_AX, env) + -0.5f) * kUnitPx, (SF(s, F_AY, env) + -0.5f) * kUnitPx,
+           kUnitPx / P.desc(kTexMouse).y * 1.0f, 1.0f, (sflags & kFlagForward) != 0);
+}
+
 class MazeGame final : public Game {
    public:
     const char* name() const override { return "maze"; }
@@ -307,6 +337,10 @@ class MazeGame final : public Game {
         LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io);
         hipLaunchKernelGGL(logic_kernel, dim3(logic_blocks(s_.n)), dim3(logic_lanes()), 0, st, s_, actions, run_seed, step_index,
                            env_offset, io);
+    }
+    bool launch_frame(hipStream_t st, int env, uint32_t* d_px, int w, int h) override {
+        hipLaunchKernelGGL(frame_kernel, dim3(1), dim3(kFrameThreads), 0, st, s_, atlas_, env, FrameTarget{d_px, w, h});
+        return true;
     }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
         hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags);

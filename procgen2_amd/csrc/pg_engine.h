@@ -74,6 +74,9 @@ class Game {
     // Level prefetch (pg_prefetch.h): launch the generator that fills queued shadow slots on the side stream.
     // bulk = most envs are expected to be queued (after make / a full reset).  False = game has no prefetch.
     virtual bool launch_pregen(hipStream_t side, bool bulk) { return false; }
+    // cenv_render's human-size frame (render_game(false)) of one env into a w×h target of 0x00BBGGRR words in device
+    // memory (pg_frame.h).  False = not implemented for this game.
+    virtual bool launch_frame(hipStream_t s, int env, uint32_t* d_px, int w, int h) { return false; }
     // Debug tap used by the parity tests: game-defined float dump of one env (host pointer).
     virtual int dump_state(hipStream_t s, int env, float* out, int cap) = 0;
     virtual int dump_tiles(hipStream_t s, int env, uint8_t* out, int cap) = 0;

@@ -37,7 +37,11 @@ class ProcgenVecEnv:
         self.env_offset = int(env_offset)
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
-        self._stream = torch.cuda.current_stream(self.device)
+        # The engine gets a stream of its own (a torch stream, so torch can order against it): torch's default stream
+        # has handle 0, which the C ABI reads as "create one", and work on an unrelated stream would race with the
+        # caller's.  Every call below makes the engine's stream wait for the caller's current stream (actions, masks)
+        # and the caller's current stream wait for the engine's (obs, reward, done).
+        self._stream = torch.cuda.Stream(device=self.device)
         h = c_void_p()
         pglib.check(self.L, self.L.pgv_make(game.encode(), self.num_envs, device, seed_base, self.env_offset,
                                             c_void_p(self._stream.cuda_stream), ctypes.byref(h)), "pgv_make")
@@ -61,8 +65,10 @@ class ProcgenVecEnv:
             m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
         if seeds is not None:
             s = torch.as_tensor(seeds, device=self.device).to(torch.int32).contiguous()
+        self._before()
         pglib.check(self.L, self.L.pgv_reset(self._h, c_void_p(m.data_ptr()) if m is not None else None,
                                              c_void_p(s.data_ptr()) if s is not None else None), "pgv_reset")
+        self._after()
         self._keep = (m, s)
         return self.obs
 
@@ -73,13 +79,27 @@ class ProcgenVecEnv:
         a = torch.as_tensor(actions, device=self.device).to(torch.int32).contiguous()
         if a.numel() != self.num_envs:
             raise ValueError("expected %d actions, got %d" % (self.num_envs, a.numel()))
+        self._before()
         pglib.check(self.L, self.L.pgv_step(self._h, c_void_p(a.data_ptr())), "pgv_step")
+        self._after()
         self._keep = (a,)
         return self.obs, self.reward, self.done
 
-    def step_synthetic(self, run_seed=0):
+    def step_synthetic(self, run_seed=0, ordered=True):
+        """One step with device-generated actions.  ordered=False skips the stream hand-shake with the caller's current
+        stream (several envs stepping side by side on their own streams; call sync() before reading the outputs)."""
+        if ordered:
+            self._before()
         pglib.check(self.L, self.L.pgv_step_synthetic(self._h, run_seed), "pgv_step_synthetic")
+        if ordered:
+            self._after()
         return self.obs, self.reward, self.done
+
+    def _before(self):
+        self._stream.wait_stream(torch.cuda.current_stream(self.device))
+
+    def _after(self):
+        torch.cuda.current_stream(self.device).wait_stream(self._stream)
 
     def timed_steps(self, steps, run_seed=0):
         """(total_ms, render_kernel_ms_sum) from HIP events on the engine's stream."""
@@ -87,6 +107,14 @@ class ProcgenVecEnv:
         pglib.check(self.L, self.L.pgv_timed_steps(self._h, steps, run_seed, ctypes.byref(total),
                                                    ctypes.byref(render)), "pgv_timed_steps")
         return total.value, render.value
+
+    def render_frame(self, index=0, width=512, height=512):
+        """The human-size frame of env `index` (cenv_render, render_game(false)): uint8 [height, width, 3] on the host."""
+        import numpy as np
+        out = np.zeros((height, width, 3), np.uint8)
+        pglib.check(self.L, self.L.pgv_render_frame(self._h, index, width, height, c_void_p(out.ctypes.data)),
+                    "pgv_render_frame")
+        return out
 
     def sync(self):
         pglib.check(self.L, self.L.pgv_sync(self._h), "pgv_sync")

@@ -48,6 +48,12 @@ class EngineVec:
             pglib.check(self.L, self.L.pgv_step_host(self.h, a.ctypes.data_as(c_void_p)), "pgv_step_host")
         return self._fetch()
 
+    def frame(self, env, width, height):
+        out = np.zeros((height, width, 3), np.uint8)
+        pglib.check(self.L, self.L.pgv_render_frame(self.h, env, width, height, out.ctypes.data_as(c_void_p)),
+                    "pgv_render_frame")
+        return out
+
     def set_debug(self, flags):
         pglib.check(self.L, self.L.pgv_set_debug(self.h, flags), "pgv_set_debug")
 

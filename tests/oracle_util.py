@@ -43,6 +43,7 @@ def oracle():
     L.pgo_truncated.argtypes = [c_void_p]
     L.pgo_obs.restype = POINTER(c_uint8)
     L.pgo_obs.argtypes = [c_void_p]
+    L.pgo_render_frame.argtypes = [c_void_p, c_int, c_int, c_void_p]
     L.pgo_dump_state.argtypes = [c_void_p, POINTER(c_float), c_int]
     L.pgo_dump_tiles.argtypes = [c_void_p, POINTER(c_uint8), c_int]
     L.pgo_trace.argtypes = [c_char_p, c_uint32, c_int, POINTER(c_uint32), POINTER(c_int), POINTER(c_double),

@@ -211,6 +211,53 @@ def test_jumper_lockstep_jump_heavy_actions():
     ora.close()
 
 
+FRAME_GAMES = ["coinrun", "maze", "bossfight", "climber", "caveflyer", "chaser", "jumper"]
+
+
+@pytest.mark.parametrize("game", FRAME_GAMES)
+def test_human_frame_matches_the_oracle(game):
+    """cenv_render's W×H frame (render_game(false)): the GPU frame kernel (pg_frame.h) against the
+    oracle's paint() at the same size — the default 512×512 window, a small and a non-square one — after a reset and
+    along a rollout, for several envs."""
+    from oracle_util import register_textures
+    n = 6
+    eng = EngineVec(game, n, seed_base=71)
+    L = oracle()
+    register_textures(game)
+    hs = [L.pgo_make(game.encode(), 71 + i, 1) for i in range(n)]
+    for h in hs:
+        L.pgo_reset(h, 0, 0)
+    eng.reset()
+
+    def check(tag):
+        for env, (w, h) in ((0, (512, 512)), (1, (160, 160)), (2, (200, 120)), (5, (64, 64))):
+            want = np.zeros((h, w, 3), np.uint8)
+            L.pgo_render_frame(hs[env], w, h, want.ctypes.data_as(ctypes.c_void_p))
+            got = eng.frame(env, w, h)
+            if not np.array_equal(got, want):
+                bad = np.argwhere((got != want).any(axis=2))
+                raise AssertionError("%s: env %d %dx%d: %d pixels differ, first at (y=%d, x=%d)" %
+                                     (tag, env, w, h, len(bad), bad[0][0], bad[0][1]))
+
+    check("reset")
+    pending = [False] * n
+    for s in range(90):
+        a = _actions(L, 4, s, n)
+        eng.step(a)
+        for i, h in enumerate(hs):
+            if pending[i]:
+                L.pgo_reset(h, 0, 0)
+                pending[i] = False
+            else:
+                L.pgo_step(h, int(a[i]))
+                pending[i] = bool(L.pgo_terminated(h))
+        if s % 30 == 29:
+            check("step %d" % s)
+    for h in hs:
+        L.pgo_close(h)
+    eng.close()
+
+
 def test_climber_lockstep_jump_heavy_actions():
     # Uniform random actions rarely leave the floor; biasing towards the jump actions (2, 5, 8) makes agents climb,
     # collect crystals (entity destruction -> draw-list rebuild) and die on mobs (auto-reset, new level).
