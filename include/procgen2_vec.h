@@ -90,6 +90,14 @@ PGV_API void* pgv_stream(pgv_env* env);
 /* Synchronous copies to host memory (any pointer may be NULL). */
 PGV_API int32_t pgv_copy_out(pgv_env* env, uint8_t* h_obs, float* h_reward, uint8_t* h_done);
 
+/* Whole-batch snapshot / restore: game state (incl. RNG streams and prefetched levels), reward, done, the pending
+ * auto-resets, the step counter and the observations, as one HOST buffer of pgv_snapshot_bytes().  A snapshot loads
+ * only into an env made with the same game, num_envs and env_offset.  The reference has no counterpart (its state
+ * lives in process globals, games/coinrun/coinrun.cpp:22-70); this is the vector engine's checkpoint/resume. */
+PGV_API int64_t pgv_snapshot_bytes(pgv_env* env);
+PGV_API int32_t pgv_save_state(pgv_env* env, void* h_buffer, int64_t capacity);
+PGV_API int32_t pgv_load_state(pgv_env* env, const void* h_buffer, int64_t size);
+
 /* cenv_render for one env of the batch (games/coinrun/coinrun.cpp:393-411, render_game(false)): the human-size frame,
  * width x height x 3 bytes row-major RGB into a HOST buffer.  Synchronises the env's stream.  Debug / viewer path. */
 PGV_API int32_t pgv_render_frame(pgv_env* env, int32_t index, int32_t width, int32_t height, uint8_t* h_rgb);

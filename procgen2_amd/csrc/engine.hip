@@ -358,6 +358,74 @@ int32_t pgv_sync(pgv_env* e) {
     return 0;
 }
 
+// Whole-batch snapshot / restore (SURVEY.md §8f-4, §5 checkpoint/resume): everything a rollout depends on — the game
+// state blob (live state, generator chains, prefetched levels and their slot words), reward / done / pending, the
+// step counter and the observation slab — as one host buffer.  Both streams are drained first, so no slot is busy.
+struct SnapshotHeader {
+    uint32_t magic, game;
+    int32_t n, env_offset;
+    uint64_t state_bytes;
+    uint32_t step_index, reserved;
+};
+static constexpr uint32_t kSnapshotMagic = 0x50474e32u;  // "PGN2"
+
+static size_t snapshot_bytes(const pgv_env* e) {
+    return sizeof(SnapshotHeader) + e->game->state_bytes(e->n) + size_t(e->n) * (4 + 1 + 1) +
+           size_t(e->n) * pg::kObsBytes;
+}
+
+int64_t pgv_snapshot_bytes(pgv_env* e) { return e ? static_cast<int64_t>(snapshot_bytes(e)) : -1; }
+
+int32_t pgv_save_state(pgv_env* e, void* h_buffer, int64_t capacity) {
+    if (!e || !h_buffer) return fail("pgv_save_state: NULL argument");
+    if (capacity < static_cast<int64_t>(snapshot_bytes(e))) return fail("pgv_save_state: buffer too small");
+    PG_HIP(hipSetDevice(e->device));
+    PG_HIP(hipStreamSynchronize(e->stream));
+    if (e->side) PG_HIP(hipStreamSynchronize(e->side));
+    uint8_t* out = static_cast<uint8_t*>(h_buffer);
+    SnapshotHeader hd{kSnapshotMagic, static_cast<uint32_t>(pgv_game_id(e->game->name())), e->n, e->env_offset,
+                      e->game->state_bytes(e->n), e->step_index, 0};
+    std::memcpy(out, &hd, sizeof(hd));
+    out += sizeof(hd);
+    PG_HIP(hipMemcpy(out, e->d_state, hd.state_bytes, hipMemcpyDeviceToHost));
+    out += hd.state_bytes;
+    PG_HIP(hipMemcpy(out, e->d_reward, size_t(e->n) * 4, hipMemcpyDeviceToHost));
+    out += size_t(e->n) * 4;
+    PG_HIP(hipMemcpy(out, e->d_done, size_t(e->n), hipMemcpyDeviceToHost));
+    out += size_t(e->n);
+    PG_HIP(hipMemcpy(out, e->d_pending, size_t(e->n), hipMemcpyDeviceToHost));
+    out += size_t(e->n);
+    PG_HIP(hipMemcpy(out, e->d_obs, size_t(e->n) * pg::kObsBytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int32_t pgv_load_state(pgv_env* e, const void* h_buffer, int64_t size) {
+    if (!e || !h_buffer) return fail("pgv_load_state: NULL argument");
+    if (size < static_cast<int64_t>(snapshot_bytes(e))) return fail("pgv_load_state: buffer too small for this env");
+    const uint8_t* in = static_cast<const uint8_t*>(h_buffer);
+    SnapshotHeader hd;
+    std::memcpy(&hd, in, sizeof(hd));
+    if (hd.magic != kSnapshotMagic || hd.game != static_cast<uint32_t>(pgv_game_id(e->game->name())) || hd.n != e->n ||
+        hd.env_offset != e->env_offset || hd.state_bytes != e->game->state_bytes(e->n))
+        return fail("pgv_load_state: snapshot of a different env (game, size or shard)");
+    PG_HIP(hipSetDevice(e->device));
+    PG_HIP(hipStreamSynchronize(e->stream));
+    if (e->side) PG_HIP(hipStreamSynchronize(e->side));
+    in += sizeof(hd);
+    PG_HIP(hipMemcpy(e->d_state, in, hd.state_bytes, hipMemcpyHostToDevice));
+    in += hd.state_bytes;
+    PG_HIP(hipMemcpy(e->d_reward, in, size_t(e->n) * 4, hipMemcpyHostToDevice));
+    in += size_t(e->n) * 4;
+    PG_HIP(hipMemcpy(e->d_done, in, size_t(e->n), hipMemcpyHostToDevice));
+    in += size_t(e->n);
+    PG_HIP(hipMemcpy(e->d_pending, in, size_t(e->n), hipMemcpyHostToDevice));
+    in += size_t(e->n);
+    PG_HIP(hipMemcpy(e->d_obs, in, size_t(e->n) * pg::kObsBytes, hipMemcpyHostToDevice));
+    e->step_index = hd.step_index;
+    pregen(e, true, true);  // queued shadow slots of the snapshot get their generator launch
+    return 0;
+}
+
 uint8_t* pgv_obs(pgv_env* e) { return e ? e->d_obs : nullptr; }
 float* pgv_reward(pgv_env* e) { return e ? e->d_reward : nullptr; }
 uint8_t* pgv_done(pgv_env* e) { return e ? e->d_done : nullptr; }

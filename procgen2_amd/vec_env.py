@@ -116,6 +116,19 @@ class ProcgenVecEnv:
                     "pgv_render_frame")
         return out
 
+    def save_state(self):
+        """Snapshot of the whole batch (state, RNG streams, prefetched levels, outputs) as a numpy byte array."""
+        import numpy as np
+        n = self.L.pgv_snapshot_bytes(self._h)
+        buf = np.empty(n, np.uint8)
+        pglib.check(self.L, self.L.pgv_save_state(self._h, c_void_p(buf.ctypes.data), n), "pgv_save_state")
+        return buf
+
+    def load_state(self, buf):
+        import numpy as np
+        buf = np.ascontiguousarray(buf, np.uint8)
+        pglib.check(self.L, self.L.pgv_load_state(self._h, c_void_p(buf.ctypes.data), buf.size), "pgv_load_state")
+
     def sync(self):
         pglib.check(self.L, self.L.pgv_sync(self._h), "pgv_sync")
 

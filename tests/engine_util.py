@@ -54,6 +54,15 @@ class EngineVec:
                     "pgv_render_frame")
         return out
 
+    def save_state(self):
+        n = self.L.pgv_snapshot_bytes(self.h)
+        buf = np.empty(n, np.uint8)
+        pglib.check(self.L, self.L.pgv_save_state(self.h, buf.ctypes.data_as(c_void_p), n), "pgv_save_state")
+        return buf
+
+    def load_state(self, buf):
+        pglib.check(self.L, self.L.pgv_load_state(self.h, buf.ctypes.data_as(c_void_p), buf.size), "pgv_load_state")
+
     def set_debug(self, flags):
         pglib.check(self.L, self.L.pgv_set_debug(self.h, flags), "pgv_set_debug")
 

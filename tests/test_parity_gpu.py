@@ -211,6 +211,33 @@ def test_jumper_lockstep_jump_heavy_actions():
     ora.close()
 
 
+@pytest.mark.parametrize("game", ["coinrun", "caveflyer", "bossfight", "chaser"])
+def test_snapshot_restore_replays_the_same_rollout(game):
+    """pgv_save_state / pgv_load_state: after a restore the batch continues exactly as it did the first time —
+    observations, rewards, dones — across auto-resets, prefetched levels (coinrun, caveflyer) and in-step RNG draws
+    (bossfight, chaser); a snapshot is refused by an env of another size."""
+    n = 192
+    eng = EngineVec(game, n, seed_base=5)
+    eng.reset()
+    for s in range(40):
+        eng.step(None, run_seed=8)
+    snap = eng.save_state()
+    first = []
+    for s in range(120):
+        o, r, d = eng.step(None, run_seed=8)
+        first.append((o.copy(), r.copy(), d.copy()))
+    assert sum(int(d.sum()) for _, _, d in first) > 0
+    eng.load_state(snap)
+    for s in range(120):
+        o, r, d = eng.step(None, run_seed=8)
+        assert np.array_equal(o, first[s][0]) and np.array_equal(r, first[s][1]) and np.array_equal(d, first[s][2]), s
+    other = EngineVec(game, n + 1, seed_base=5)
+    with pytest.raises(pglib.EngineError):
+        other.load_state(snap)
+    other.close()
+    eng.close()
+
+
 FRAME_GAMES = ["coinrun", "maze", "bossfight", "climber", "caveflyer", "chaser", "jumper"]
 
 
