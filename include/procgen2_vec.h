@@ -45,6 +45,15 @@ PGV_API int32_t pgv_game_id(const char* name); /* -1 if unknown */
  * for an internally created stream.  Asset root: $PROCGEN2_ASSETS, else <dir of the .so>/../assets. */
 PGV_API int32_t pgv_make(const char* game, int32_t num_envs, int32_t device, uint32_t seed_base, int32_t env_offset,
                          void* stream, pgv_env** out);
+/* Same with a finite level set (the reference has no such option, the semantics follow the
+ * original procgen's num_levels / start_level).  num_levels = 0 is pgv_make: every level is new.  With
+ * num_levels > 0 the k-th level an env builds since it was made / reseeded is level number
+ *     start_level + mix32(mix32(seed of the env) + k) % num_levels      (mix32: the hash of pgv_synthetic_action)
+ * and level number L is exactly what a fresh cenv_make(seed = L) of the reference builds as its level 0 (fresh
+ * containers and camera, rng.seed(L): coinrun.cpp:130-152,219-262), so equal numbers give equal levels. */
+PGV_API int32_t pgv_make_levels(const char* game, int32_t num_envs, int32_t device, uint32_t seed_base,
+                                int32_t env_offset, void* stream, int32_t num_levels, int32_t start_level,
+                                pgv_env** out);
 PGV_API void pgv_close(pgv_env* env);
 
 /* Reset the envs whose mask byte is non-zero (device u8[N]; NULL = all).  seeds: device int32[N] to

@@ -47,6 +47,7 @@ void pgo_close(void* h) { delete static_cast<Env*>(h); }
 void pgo_render_frame(void* h, int width, int height, uint8_t* out_rgb) {
     static_cast<Env*>(h)->render_frame(width, height, out_rgb);
 }
+void pgo_present(void* h) { static_cast<Env*>(h)->present(); }
 void pgo_reset(void* h, int reseed, int32_t seed) { static_cast<Env*>(h)->reset(reseed != 0, seed); }
 
 void pgo_step(void* h, int action) { static_cast<Env*>(h)->step(action); }
@@ -120,21 +121,70 @@ struct VecState {
     std::vector<Env*> envs;
     std::vector<uint8_t> pending_reset;
     uint32_t step_counter = 0;
+    // level-seed mode (include/procgen2_vec.h pgv_make_levels); num_levels 0 = off
+    std::string game;
+    int render = 0, num_levels = 0, start_level = 0;
+    std::vector<uint32_t> chain_seed, drawn;
 };
 
-void* pgo_vec_make(const char* game, int n, uint32_t seed_base, int env_offset, int render_enabled) {
+// One new level for env i.  Level-seed mode: level number L = what a fresh cenv_make(seed = L) builds as its
+// level 0 — so the env object is literally made anew.
+static void vec_new_level(VecState* v, int i, bool restart, uint32_t seed) {
+    if (restart) {
+        v->chain_seed[i] = seed;
+        v->drawn[i] = 0;
+    }
+    if (v->num_levels > 0) {
+        const uint32_t k = v->drawn[i]++;
+        const uint32_t number = static_cast<uint32_t>(v->start_level) +
+                                mix32(mix32(v->chain_seed[i]) + k) % static_cast<uint32_t>(v->num_levels);
+        delete v->envs[i];
+        v->envs[i] = static_cast<Env*>(pgo_make(v->game.c_str(), number, v->render));
+        v->envs[i]->present();
+    } else {
+        v->envs[i]->reset(restart, static_cast<int32_t>(seed));
+    }
+}
+
+void* pgo_vec_make_levels(const char* game, int n, uint32_t seed_base, int env_offset, int render_enabled,
+                          int num_levels, int start_level) {
     auto* v = new VecState();
+    v->game = game;
+    v->render = render_enabled;
+    v->num_levels = num_levels;
+    v->start_level = start_level;
+    v->chain_seed.assign(n, 0);
+    v->drawn.assign(n, 0);
     for (int i = 0; i < n; i++) {
-        Env* e = static_cast<Env*>(pgo_make(game, seed_base + static_cast<uint32_t>(env_offset + i), render_enabled));
+        const uint32_t seed = seed_base + static_cast<uint32_t>(env_offset + i);
+        Env* e = static_cast<Env*>(pgo_make(game, seed, render_enabled));  // level 0, never observed (D1)
         if (!e) {
             delete v;
             return nullptr;
         }
-        e->reset(false, 0);
         v->envs.push_back(e);
+        v->chain_seed[i] = seed;
+        v->drawn[i] = num_levels > 0 ? 1 : 0;  // the engine's make draws a level number for its hidden level too
+        vec_new_level(v, i, false, 0);
     }
     v->pending_reset.assign(n, 0);
     return v;
+}
+
+void* pgo_vec_make(const char* game, int n, uint32_t seed_base, int env_offset, int render_enabled) {
+    return pgo_vec_make_levels(game, n, seed_base, env_offset, render_enabled, 0, 0);
+}
+
+// cenv_reset of the envs with mask[i] != 0 (nullptr = all); seeds nullptr = keep the streams.
+void pgo_vec_reset(void* h, const uint8_t* mask, const int32_t* seeds) {
+    auto* v = static_cast<VecState*>(h);
+    for (size_t i = 0; i < v->envs.size(); i++) {
+        if (mask && !mask[i]) continue;
+        vec_new_level(v, static_cast<int>(i), seeds != nullptr, seeds ? static_cast<uint32_t>(seeds[i]) : 0u);
+        v->envs[i]->reward = 0.0f;
+        v->envs[i]->terminated = false;
+        v->pending_reset[i] = 0;
+    }
 }
 
 void pgo_vec_close(void* h) {
@@ -150,7 +200,8 @@ static void vec_step_range(VecState* v, int lo, int hi, const int32_t* actions, 
     for (int i = lo; i < hi; i++) {
         Env* e = v->envs[i];
         if (v->pending_reset[i]) {
-            e->reset(false, 0);
+            vec_new_level(v, i, false, 0);
+            e = v->envs[i];
             e->reward = 0.0f;
             e->terminated = false;
             v->pending_reset[i] = 0;
@@ -208,7 +259,8 @@ double pgo_vec_bench(void* h, int steps, uint32_t run_seed, int threads) {
             for (int i = lo; i < hi; i++) {
                 Env* e = v->envs[i];
                 if (v->pending_reset[i]) {
-                    e->reset(false, 0);
+                    vec_new_level(v, i, false, 0);
+                    e = v->envs[i];
                     e->reward = 0.0f;
                     e->terminated = false;
                     v->pending_reset[i] = 0;

@@ -36,6 +36,10 @@ class Env {
         observe();
     }
 
+    // Level-seed mode (include/procgen2_vec.h pgv_make_levels): the level make() built is the one that is played, so it
+    // gets presented without the reset() that normally follows.
+    void present() { observe(); }
+
     void set_render_enabled(bool on) { painter_.enabled = on; }
 
     // cenv_render (coinrun.cpp:393-411): render_game(false) into a width×height target, packed RGB.  The reference

@@ -528,10 +528,8 @@ PG_D void advance(const State& s, int env, int action, float& reward_out, bool& 
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) make_kernel(State s, uint32_t seed_base, int env_offset) {
-    const int env = blockIdx.x * blockDim.x + threadIdx.x;
-    if (env >= s.n) return;
-    mt_seed(s.mt + size_t(env) * kMtWords, seed_base + static_cast<uint32_t>(env_offset + env));
+// What cenv_make leaves in an env besides the seeded RNG: the three bullet pools, all "dead".
+PG_D void fresh_env(const State& s, int env) {
     for (int k = 0; k < kAgentShots; k++) {  // std::vector<Bullet>(32): frame = -1 ("dead"), rest zero
         for (int f = 0; f < S_COUNT; f++) AS(s, f, k, env) = (f == S_FRAME) ? -1.0f : 0.0f;
         AB(s, k, env) = 0;
@@ -543,26 +541,51 @@ __global__ void __launch_bounds__(64) make_kernel(State s, uint32_t seed_base, i
         BM(s, 1, k, env) = 0.0f;
         BM(s, 2, k, env) = -1.0f;
     }
-    new_level(s, env);  // level 0, never observed (D1)
 }
 
-__global__ void __launch_bounds__(64) reset_kernel(State s, const uint8_t* mask, const int32_t* seeds, StepIO io) {
+// One new level for env.  restart: the env's RNG stream starts over from chain_seed.  Level-seed mode
+// (pg_engine.h LevelPlan) instead rebuilds the env as a fresh cenv_make(seed = level number) would.
+PG_D void begin_level(const State& s, const LevelPlan& plan, int env, bool restart, uint32_t chain_seed) {
+    uint32_t* mt = s.mt + size_t(env) * kMtWords;
+    if (restart) {
+        plan.chain_seed[env] = chain_seed;
+        plan.drawn[env] = 0;
+    }
+    if (plan.num_levels > 0) {
+        const uint32_t k = plan.drawn[env];
+        plan.drawn[env] = k + 1;
+        mt_seed(mt, level_number(plan.num_levels, plan.start_level, plan.chain_seed[env], k));
+        fresh_env(s, env);
+    } else if (restart) {
+        mt_seed(mt, chain_seed);
+    }
+    new_level(s, env);
+}
+
+__global__ void __launch_bounds__(64) make_kernel(State s, uint32_t seed_base, int env_offset, LevelPlan plan) {
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= s.n) return;
+    fresh_env(s, env);
+    begin_level(s, plan, env, true, seed_base + static_cast<uint32_t>(env_offset + env));  // level 0, never observed (D1)
+}
+
+__global__ void __launch_bounds__(64) reset_kernel(State s, const uint8_t* mask, const int32_t* seeds, StepIO io,
+                                                   LevelPlan plan) {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= s.n) return;
     if (mask && !mask[env]) return;
-    if (seeds) mt_seed(s.mt + size_t(env) * kMtWords, static_cast<uint32_t>(seeds[env]));
-    new_level(s, env);
+    begin_level(s, plan, env, seeds != nullptr, seeds ? static_cast<uint32_t>(seeds[env]) : 0u);
     io.reward[env] = 0.0f;
     io.done[env] = 0;
     io.pending[env] = 0;
 }
 
 __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actions, uint32_t run_seed,
-                                                   uint32_t step_index, int env_offset, StepIO io) {
+                                                   uint32_t step_index, int env_offset, StepIO io, LevelPlan plan) {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= s.n) return;
     if (io.pending[env]) {
-        new_level(s, env);
+        begin_level(s, plan, env, false, 0u);
         io.reward[env] = 0.0f;
         io.done[env] = 0;
         io.pending[env] = 0;
@@ -854,15 +877,15 @@ class BossfightGame final : public Game {
     }
     int blocks() const { return (s_.n + 63) / 64; }
     void launch_make(hipStream_t st, uint32_t seed_base, int env_offset) override {
-        hipLaunchKernelGGL(make_kernel, dim3(blocks()), dim3(64), 0, st, s_, seed_base, env_offset);
+        hipLaunchKernelGGL(make_kernel, dim3(blocks()), dim3(64), 0, st, s_, seed_base, env_offset, plan);
     }
     void launch_reset(hipStream_t st, const uint8_t* mask, const int32_t* seeds, StepIO io) override {
-        hipLaunchKernelGGL(reset_kernel, dim3(blocks()), dim3(64), 0, st, s_, mask, seeds, io);
+        hipLaunchKernelGGL(reset_kernel, dim3(blocks()), dim3(64), 0, st, s_, mask, seeds, io, plan);
     }
     void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
                       StepIO io) override {
         hipLaunchKernelGGL(logic_kernel, dim3(logic_blocks(s_.n)), dim3(logic_lanes()), 0, st, s_, actions, run_seed, step_index,
-                           env_offset, io);
+                           env_offset, io, plan);
     }
     bool launch_frame(hipStream_t st, int env, uint32_t* d_px, int w, int h) override {
         hipLaunchKernelGGL(frame_kernel, dim3(1), dim3(kFrameThreads), 0, st, s_, atlas_, env, FrameTarget{d_px, w, h});

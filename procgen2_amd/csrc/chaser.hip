@@ -268,6 +268,16 @@ PG_D void install(const State& s, int env, const Level& lv, int lane) {
     }
 }
 
+// What cenv_make leaves in an env besides the seeded RNG, split by owner: the generator chain (bucket counts of
+// the sets that survive clear()) and the live state.  Level-seed mode (pg_engine.h LevelPlan) rebuilds every
+// level from here.
+PG_D void fresh_chain(const State& s, int env) {
+    SI(s, I_HASH_SPRITE, env) = 1;  // empty unordered_set: one bucket, next_resize 0
+    SI(s, I_HASH_MOB, env) = 1;
+}
+PG_D void fresh_live(const State& s, int env) {
+}
+
 struct Gen {  // pg_prefetch.h level_kernel<Gen>
     using State = chaser::State;
     using Level = chaser::Level;
@@ -276,6 +286,8 @@ struct Gen {  // pg_prefetch.h level_kernel<Gen>
         chaser::generate(s, env, L, lv, reseed, seed, lane);
     }
     PG_D static void install(const State& s, int env, const Level& lv, int lane) { chaser::install(s, env, lv, lane); }
+    PG_D static void fresh_chain(const State& s, int env) { chaser::fresh_chain(s, env); }
+    PG_D static void fresh_live(const State& s, int env) { chaser::fresh_live(s, env); }
 };
 
 // System_Sprite_Render::update's list: the surviving sprites in set order, then std::sort on z (all 0.0).
@@ -533,8 +545,8 @@ PG_D void advance(const State& s, int env, int action, float& reward_out, bool& 
 __global__ void __launch_bounds__(64) make_kernel(State s) {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= s.n) return;
-    SI(s, I_HASH_SPRITE, env) = 1;  // empty unordered_set: one bucket, next_resize 0
-    SI(s, I_HASH_MOB, env) = 1;
+    fresh_chain(s, env);
+    fresh_live(s, env);
 }
 
 __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actions, uint32_t run_seed,
@@ -763,14 +775,14 @@ class ChaserGame final : public Game {
     int blocks() const { return (s_.n + 63) / 64; }
     void launch_make(hipStream_t st, uint32_t seed_base, int env_offset) override {
         hipLaunchKernelGGL(make_kernel, dim3(blocks()), dim3(64), 0, st, s_);
-        LevelLaunch<Gen>::make(st, s_, 0, seed_base, env_offset);
+        LevelLaunch<Gen>::make(st, s_, 0, seed_base, env_offset, plan);
     }
     void launch_reset(hipStream_t st, const uint8_t* mask, const int32_t* seeds, StepIO io) override {
-        LevelLaunch<Gen>::reset(st, s_, 0, mask, seeds, io);
+        LevelLaunch<Gen>::reset(st, s_, 0, mask, seeds, io, plan);
     }
     void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
                       StepIO io) override {
-        LevelLaunch<Gen>::auto_reset(st, s_, 0, io);
+        LevelLaunch<Gen>::auto_reset(st, s_, 0, io, plan);
         hipLaunchKernelGGL(logic_kernel, dim3(logic_blocks(s_.n)), dim3(logic_lanes()), 0, st, s_, actions, run_seed, step_index,
                            env_offset, io);
     }

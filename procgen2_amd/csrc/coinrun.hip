@@ -394,6 +394,19 @@ PG_D void install(const State& s, int env, const Level& lv, int lane) {
     }
 }
 
+// What cenv_make leaves in an env besides the seeded RNG, split by owner: the generator chain (bucket counts of
+// the sets that survive clear()) and the live state.  Level-seed mode (pg_engine.h LevelPlan) rebuilds every
+// level from here.
+PG_D void fresh_chain(const State& s, int env) {
+    SI(s, I_HASH_SPRITE, env) = 1;  // empty unordered_set: one bucket, next_resize 0
+    SI(s, I_HASH_SPARK, env) = 1;
+}
+PG_D void fresh_live(const State& s, int env) {
+    SI(s, I_FLAGS, env) = 0;
+    SF(s, F_CAMX, env) = 0.0f;  // Renderer::camera_position{0} (renderer.h:18)
+    SF(s, F_CAMY, env) = 0.0f;
+}
+
 struct Gen {  // pg_prefetch.h level_kernel<Gen>
     using State = coinrun::State;
     using Level = coinrun::Level;
@@ -402,6 +415,8 @@ struct Gen {  // pg_prefetch.h level_kernel<Gen>
         coinrun::generate(s, env, L, lv, reseed, seed, lane);
     }
     PG_D static void install(const State& s, int env, const Level& lv, int lane) { coinrun::install(s, env, lv, lane); }
+    PG_D static void fresh_chain(const State& s, int env) { coinrun::fresh_chain(s, env); }
+    PG_D static void fresh_live(const State& s, int env) { coinrun::fresh_live(s, env); }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -674,12 +689,8 @@ PG_D void agent_substeps(const State& s, int env, int action) {
 __global__ void __launch_bounds__(64) make_kernel(State s, uint32_t seed_base, int env_offset) {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= s.n) return;
-    SI(s, I_FLAGS, env) = 0;
-    SI(s, I_HASH_SPRITE, env) = 1;  // empty unordered_set: one bucket, next_resize 0
-    SI(s, I_HASH_SPARK, env) = 1;
-    SF(s, F_CAMX, env) = 0.0f;  // Renderer::camera_position{0} (renderer.h:18)
-    SF(s, F_CAMY, env) = 0.0f;
-    // level 0 (never observed, D1) follows from the level kernel
+    fresh_chain(s, env);
+    fresh_live(s, env);
 }
 
 // A — lane = env: the agent's sub-steps into the scratch table (envs that reset in this step sit it out).
@@ -1159,20 +1170,20 @@ class CoinrunGame final : public Game {
     int blocks() const { return (s_.n + 63) / 64; }
     void launch_make(hipStream_t st, uint32_t seed_base, int env_offset) override {
         hipLaunchKernelGGL(make_kernel, dim3(blocks()), dim3(64), 0, st, s_, seed_base, env_offset);
-        LevelLaunch<Gen>::make(st, s_, prefetch(), seed_base, env_offset);
+        LevelLaunch<Gen>::make(st, s_, prefetch(), seed_base, env_offset, plan);
     }
     void launch_reset(hipStream_t st, const uint8_t* mask, const int32_t* seeds, StepIO io) override {
-        LevelLaunch<Gen>::reset(st, s_, prefetch(), mask, seeds, io);
+        LevelLaunch<Gen>::reset(st, s_, prefetch(), mask, seeds, io, plan);
     }
     bool launch_pregen(hipStream_t side, bool bulk) override {
         if (!prefetch()) return false;
-        LevelLaunch<Gen>::pregen(side, s_, bulk);
+        LevelLaunch<Gen>::pregen(side, s_, bulk, plan);
         return true;
     }
     int prefetch() const { return (debug_flags & kDebugNoPrefetch) ? 0 : 1; }
     void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
                       StepIO io) override {
-        LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io);
+        LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io, plan);
         hipLaunchKernelGGL(agent_kernel, dim3(logic_blocks(s_.n)), dim3(logic_lanes()), 0, st, s_, actions, run_seed, step_index,
                            env_offset, io);
         hipLaunchKernelGGL(entity_kernel, dim3(logic_blocks(s_.n), kMaxEnt), dim3(logic_lanes()), 0, st, s_);

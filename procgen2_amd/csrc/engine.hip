@@ -207,9 +207,20 @@ void pgv_close(pgv_env* e) {
     delete e;
 }
 
+// The device state blob: the game's SoA state followed by the level plan's two per-env words (pg_engine.h
+// LevelPlan), so that a snapshot of the blob carries them.
+static size_t game_state_bytes(const pgv_env* e) { return (e->game->state_bytes(e->n) + 255) / 256 * 256; }
+static size_t state_blob_bytes(const pgv_env* e) { return game_state_bytes(e) + size_t(e->n) * 8; }
+
 int32_t pgv_make(const char* game, int32_t num_envs, int32_t device, uint32_t seed_base, int32_t env_offset,
                  void* stream, pgv_env** out) {
+    return pgv_make_levels(game, num_envs, device, seed_base, env_offset, stream, 0, 0, out);
+}
+
+int32_t pgv_make_levels(const char* game, int32_t num_envs, int32_t device, uint32_t seed_base, int32_t env_offset,
+                        void* stream, int32_t num_levels, int32_t start_level, pgv_env** out) {
     if (!out) return fail("pgv_make: out is NULL");
+    if (num_levels < 0) return fail("pgv_make: num_levels must be >= 0 (0 = every level is new)");
     *out = nullptr;
     const int gid = pgv_game_id(game);
     if (gid < 0) return fail(std::string("pgv_make: unknown game '") + (game ? game : "(null)") + "'");
@@ -252,7 +263,7 @@ int32_t pgv_make(const char* game, int32_t num_envs, int32_t device, uint32_t se
         pgv_close(raw);
         return fail("pgv_make: " + err);
     }
-    const size_t sb = e->game->state_bytes(num_envs);
+    const size_t sb = state_blob_bytes(e.get());
     PG_HIP(hipMalloc(&e->d_state, sb));
     PG_HIP(hipMemsetAsync(e->d_state, 0, sb, e->stream));
     PG_HIP(hipMalloc(reinterpret_cast<void**>(&e->d_obs), size_t(num_envs) * pg::kObsBytes));
@@ -266,6 +277,10 @@ int32_t pgv_make(const char* game, int32_t num_envs, int32_t device, uint32_t se
     PG_HIP(hipMemsetAsync(e->d_pending, 0, size_t(num_envs), e->stream));
 
     e->game->bind(e->d_state, num_envs, e->atlas.view());
+    {
+        uint32_t* words = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(e->d_state) + game_state_bytes(e.get()));
+        e->game->plan = pg::LevelPlan{num_levels, start_level, words, words + num_envs};
+    }
     e->game->launch_make(e->stream, seed_base, env_offset);
     PG_HIP(hipGetLastError());
     PG_HIP(hipStreamSynchronize(e->stream));
@@ -365,12 +380,13 @@ struct SnapshotHeader {
     uint32_t magic, game;
     int32_t n, env_offset;
     uint64_t state_bytes;
-    uint32_t step_index, reserved;
+    uint32_t step_index;
+    int32_t num_levels, start_level, reserved;
 };
 static constexpr uint32_t kSnapshotMagic = 0x50474e32u;  // "PGN2"
 
 static size_t snapshot_bytes(const pgv_env* e) {
-    return sizeof(SnapshotHeader) + e->game->state_bytes(e->n) + size_t(e->n) * (4 + 1 + 1) +
+    return sizeof(SnapshotHeader) + state_blob_bytes(e) + size_t(e->n) * (4 + 1 + 1) +
            size_t(e->n) * pg::kObsBytes;
 }
 
@@ -384,7 +400,7 @@ int32_t pgv_save_state(pgv_env* e, void* h_buffer, int64_t capacity) {
     if (e->side) PG_HIP(hipStreamSynchronize(e->side));
     uint8_t* out = static_cast<uint8_t*>(h_buffer);
     SnapshotHeader hd{kSnapshotMagic, static_cast<uint32_t>(pgv_game_id(e->game->name())), e->n, e->env_offset,
-                      e->game->state_bytes(e->n), e->step_index, 0};
+                      state_blob_bytes(e), e->step_index, e->game->plan.num_levels, e->game->plan.start_level, 0};
     std::memcpy(out, &hd, sizeof(hd));
     out += sizeof(hd);
     PG_HIP(hipMemcpy(out, e->d_state, hd.state_bytes, hipMemcpyDeviceToHost));
@@ -406,8 +422,9 @@ int32_t pgv_load_state(pgv_env* e, const void* h_buffer, int64_t size) {
     SnapshotHeader hd;
     std::memcpy(&hd, in, sizeof(hd));
     if (hd.magic != kSnapshotMagic || hd.game != static_cast<uint32_t>(pgv_game_id(e->game->name())) || hd.n != e->n ||
-        hd.env_offset != e->env_offset || hd.state_bytes != e->game->state_bytes(e->n))
-        return fail("pgv_load_state: snapshot of a different env (game, size or shard)");
+        hd.env_offset != e->env_offset || hd.state_bytes != state_blob_bytes(e) ||
+        hd.num_levels != e->game->plan.num_levels || hd.start_level != e->game->plan.start_level)
+        return fail("pgv_load_state: snapshot of a different env (game, size, shard or level set)");
     PG_HIP(hipSetDevice(e->device));
     PG_HIP(hipStreamSynchronize(e->stream));
     if (e->side) PG_HIP(hipStreamSynchronize(e->side));
@@ -615,12 +632,12 @@ int32_t cenv_make(const char* render_mode, cenv_option* options, int32_t options
     (void)render_mode;
     if (g.env) cenv_close();
     int seed = static_cast<int>(time(nullptr));  // coinrun.cpp:130
-    int num_envs = 1, game = PG_DEFAULT_GAME, device = 0, env_offset = 0;
+    int num_envs = 1, game = PG_DEFAULT_GAME, device = 0, env_offset = 0, num_levels = 0, start_level = 0;
     for (int i = 0; i < options_size; i++) {
         const std::string name(options[i].name ? options[i].name : "");
         int v = 0;
         if (name == "seed" || name == "width" || name == "height" || name == "num_envs" || name == "game" ||
-            name == "device" || name == "env_offset") {
+            name == "device" || name == "env_offset" || name == "num_levels" || name == "start_level") {
             if (opt_int(options[i], &v)) return fail("cenv_make: option '" + name + "' must be INT");
         }
         if (name == "seed")
@@ -637,10 +654,15 @@ int32_t cenv_make(const char* render_mode, cenv_option* options, int32_t options
             device = v;
         else if (name == "env_offset")
             env_offset = v;
+        else if (name == "num_levels")
+            num_levels = v;
+        else if (name == "start_level")
+            start_level = v;
     }
     const char* gname = pgv_game_name(game);
     if (!gname) return fail("cenv_make: unknown game id");
-    int rc = pgv_make(gname, num_envs, device, static_cast<uint32_t>(seed), env_offset, nullptr, &g.env);
+    int rc = pgv_make_levels(gname, num_envs, device, static_cast<uint32_t>(seed), env_offset, nullptr, num_levels,
+                             start_level, &g.env);
     if (rc) return rc;
     g.n = num_envs;
     g.h_obs.assign(size_t(num_envs) * pg::kObsBytes, 0);

@@ -367,6 +367,19 @@ PG_D void install(const State& s, int env, const Level& lv, int lane) {
     }
 }
 
+// What cenv_make leaves in an env besides the seeded RNG, split by owner: the generator chain (bucket counts of
+// the sets that survive clear()) and the live state.  Level-seed mode (pg_engine.h LevelPlan) rebuilds every
+// level from here.
+PG_D void fresh_chain(const State& s, int env) {
+    SI(s, I_HASH_SPRITE, env) = 1;  // empty unordered_set: one bucket, next_resize 0
+}
+PG_D void fresh_live(const State& s, int env) {
+    SF(s, F_CAMX, env) = 0.0f;  // Renderer::camera_position{0} (renderer.h:18)
+    SF(s, F_CAMY, env) = 0.0f;
+    SF(s, F_TOGX, env) = 0.0f;  // Agent_Info::to_goal{0, 0} (common_systems.h:57-59)
+    SF(s, F_TOGY, env) = 0.0f;
+}
+
 struct Gen {  // pg_prefetch.h level_kernel<Gen>
     using State = jumper::State;
     using Level = jumper::Level;
@@ -375,6 +388,8 @@ struct Gen {  // pg_prefetch.h level_kernel<Gen>
         jumper::generate(s, env, L, lv, reseed, seed, lane);
     }
     PG_D static void install(const State& s, int env, const Level& lv, int lane) { jumper::install(s, env, lv, lane); }
+    PG_D static void fresh_chain(const State& s, int env) { jumper::fresh_chain(s, env); }
+    PG_D static void fresh_live(const State& s, int env) { jumper::fresh_live(s, env); }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -484,11 +499,8 @@ PG_D void advance(const State& s, int env, int action, float& reward_out, bool& 
 __global__ void __launch_bounds__(64) make_kernel(State s) {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= s.n) return;
-    SI(s, I_HASH_SPRITE, env) = 1;  // empty unordered_set: one bucket, next_resize 0
-    SF(s, F_CAMX, env) = 0.0f;      // Renderer::camera_position{0} (renderer.h:18)
-    SF(s, F_CAMY, env) = 0.0f;
-    SF(s, F_TOGX, env) = 0.0f;  // Agent_Info::to_goal{0, 0} (common_systems.h:57-59)
-    SF(s, F_TOGY, env) = 0.0f;
+    fresh_chain(s, env);
+    fresh_live(s, env);
 }
 
 __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actions, uint32_t run_seed,
@@ -850,19 +862,19 @@ class JumperGame final : public Game {
     int prefetch() const { return (debug_flags & kDebugNoPrefetch) ? 0 : 1; }
     void launch_make(hipStream_t st, uint32_t seed_base, int env_offset) override {
         hipLaunchKernelGGL(make_kernel, dim3(blocks()), dim3(64), 0, st, s_);
-        LevelLaunch<Gen>::make(st, s_, prefetch(), seed_base, env_offset);
+        LevelLaunch<Gen>::make(st, s_, prefetch(), seed_base, env_offset, plan);
     }
     void launch_reset(hipStream_t st, const uint8_t* mask, const int32_t* seeds, StepIO io) override {
-        LevelLaunch<Gen>::reset(st, s_, prefetch(), mask, seeds, io);
+        LevelLaunch<Gen>::reset(st, s_, prefetch(), mask, seeds, io, plan);
     }
     bool launch_pregen(hipStream_t side, bool bulk) override {
         if (!prefetch()) return false;
-        LevelLaunch<Gen>::pregen(side, s_, bulk);
+        LevelLaunch<Gen>::pregen(side, s_, bulk, plan);
         return true;
     }
     void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
                       StepIO io) override {
-        LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io);
+        LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io, plan);
         hipLaunchKernelGGL(logic_kernel, dim3(logic_blocks(s_.n)), dim3(logic_lanes()), 0, st, s_, actions, run_seed, step_index,
                            env_offset, io);
     }

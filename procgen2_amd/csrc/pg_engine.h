@@ -55,6 +55,19 @@ struct StepIO {
     uint8_t* pending;  // [n]  env terminated last step → next step performs the reset instead
 };
 
+// Level-seed mode (absent from the reference, modelled on the original procgen's
+// num_levels / start_level).  num_levels = 0: the reference's behaviour — one RNG stream per env, every level is new.
+// num_levels > 0: the k-th level an env builds since it was (re)seeded is level number
+//     start_level + mix32(mix32(chain_seed) + k) % num_levels,
+// and "level number L" means exactly what a fresh `cenv_make(seed = L)` builds as its level 0 — fresh containers,
+// fresh camera, rng.seed(L) — so the same number always gives the same level, whatever the env played before.
+struct LevelPlan {
+    int32_t num_levels;    // 0 = off
+    int32_t start_level;
+    uint32_t* chain_seed;  // [n]  the seed the env was made / last reseeded with
+    uint32_t* drawn;       // [n]  k: levels built since then
+};
+
 class Game {
    public:
     virtual ~Game() = default;
@@ -86,6 +99,7 @@ class Game {
     // Bit 0: render background + tiles by draw-list replay instead of the row composer (fallback path).
     // Bit 8: no level prefetch — every reset generates its level synchronously inside the step.
     int debug_flags = 0;
+    LevelPlan plan{0, 0, nullptr, nullptr};  // set by the engine after bind()
 };
 
 constexpr int kDebugNoPrefetch = 1 << 8;
@@ -110,6 +124,9 @@ PG_HD uint32_t mix32(uint32_t x) {
     x *= 0x846ca68bu;
     x ^= x >> 16;
     return x;
+}
+PG_HD uint32_t level_number(int32_t num_levels, int32_t start_level, uint32_t chain_seed, uint32_t k) {
+    return static_cast<uint32_t>(start_level) + mix32(mix32(chain_seed) + k) % static_cast<uint32_t>(num_levels);
 }
 PG_HD int synthetic_action(uint32_t run_seed, uint32_t step, uint32_t env) {
     uint32_t h = mix32(mix32(step * 0x9E3779B9u + run_seed) ^ (env * 0x85EBCA6Bu + 0xC2B2AE35u));

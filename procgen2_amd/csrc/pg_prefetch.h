@@ -60,7 +60,10 @@ PG_D int32_t slot_acquire_for_install(int32_t* p) {
 // The level kernel shared by the prefetching games.  G supplies
 //     State  (members: int n; Level* shadow; int32_t* slot),  Level (POD, size a multiple of 4),  GenLds (scratch),
 //     generate(s, env, L, lv, reseed, seed, lane)  — one wavefront advances env's generator chain, level into lv (LDS)
-//     install(s, env, lv, lane)                     — lv becomes env's live state.
+//     install(s, env, lv, lane)                     — lv becomes env's live state
+//     fresh_chain(s, env), fresh_live(s, env)       — what cenv_make leaves in the generator chain besides the RNG
+//                                                     (hashtable bucket counts) / in the live state (camera, pools):
+//                                                     level-seed mode rebuilds every level from that (LevelPlan).
 // A block serves the envs [blockIdx·span, +span) that need a level, one after the other:
 //   mode 0  cenv_make: seed = seed_base + env index, level 0 generated synchronously;
 //   mode 1  explicit reset (mask, optional seeds; a seed restarts the env's generator chain);
@@ -70,7 +73,7 @@ PG_D int32_t slot_acquire_for_install(int32_t* p) {
 template <class G>
 __global__ void __launch_bounds__(64) level_kernel(typename G::State s, int mode, int span, int prefetch,
                                                    uint32_t seed_base, int env_offset, const uint8_t* mask,
-                                                   const int32_t* seeds, StepIO io) {
+                                                   const int32_t* seeds, StepIO io, LevelPlan plan) {
     using Level = typename G::Level;
     const int lane = threadIdx.x;
     const int base = blockIdx.x * span;
@@ -91,6 +94,24 @@ __global__ void __launch_bounds__(64) level_kernel(typename G::State s, int mode
     __shared__ typename G::GenLds L;
     __shared__ Level lv;
     __shared__ int32_t verdict;
+    __shared__ uint32_t numbered;  // level-seed mode: the level number this env builds next
+    const bool levels = plan.num_levels > 0;
+    // lane 0: (re)start the env's level sequence if asked, and in level-seed mode draw its next level number
+    auto next_level = [&](int env, bool restart, uint32_t chain_seed) {
+        if (lane == 0) {
+            if (restart) {
+                plan.chain_seed[env] = chain_seed;
+                plan.drawn[env] = 0;
+            }
+            if (levels) {
+                const uint32_t k = plan.drawn[env];
+                plan.drawn[env] = k + 1;
+                numbered = level_number(plan.num_levels, plan.start_level, plan.chain_seed[env], k);
+                G::fresh_chain(s, env);
+            }
+        }
+        __syncthreads();
+    };
     constexpr int kWords = static_cast<int>(sizeof(Level) / 4);
     static_assert(sizeof(Level) % 4 == 0, "Level is copied as 32-bit words");
     while (todo) {
@@ -104,7 +125,8 @@ __global__ void __launch_bounds__(64) level_kernel(typename G::State s, int mode
             const bool mine = verdict != 0;
             __syncthreads();
             if (!mine) continue;
-            G::generate(s, env, L, lv, false, 0u, lane);
+            next_level(env, false, 0u);
+            G::generate(s, env, L, lv, levels, numbered, lane);
             __syncthreads();
             for (int k = lane; k < kWords; k += 64) shadow[k] = local[k];
             __threadfence();
@@ -133,8 +155,11 @@ __global__ void __launch_bounds__(64) level_kernel(typename G::State s, int mode
         } else {
             const uint32_t seed = mode == 0 ? seed_base + static_cast<uint32_t>(env_offset + env)
                                             : (seeds ? static_cast<uint32_t>(seeds[env]) : 0u);
-            G::generate(s, env, L, lv, reseed, seed, lane);
+            next_level(env, reseed, seed);
+            G::generate(s, env, L, lv, reseed || levels, levels ? numbered : seed, lane);
         }
+        __syncthreads();
+        if (levels && lane == 0) G::fresh_live(s, env);
         __syncthreads();
         G::install(s, env, lv, lane);
         __threadfence();
@@ -154,24 +179,26 @@ __global__ void __launch_bounds__(64) level_kernel(typename G::State s, int mode
 // Host side of the same: the four launches a prefetching game needs.
 template <class G>
 struct LevelLaunch {
-    static void make(hipStream_t st, const typename G::State& s, int prefetch, uint32_t seed_base, int env_offset) {
+    static void make(hipStream_t st, const typename G::State& s, int prefetch, uint32_t seed_base, int env_offset,
+                     LevelPlan plan) {
         hipLaunchKernelGGL(level_kernel<G>, dim3(s.n), dim3(64), 0, st, s, 0, 1, prefetch, seed_base, env_offset,
-                           nullptr, nullptr, StepIO{});
+                           nullptr, nullptr, StepIO{}, plan);
     }
     static void reset(hipStream_t st, const typename G::State& s, int prefetch, const uint8_t* mask,
-                      const int32_t* seeds, StepIO io) {
-        hipLaunchKernelGGL(level_kernel<G>, dim3(s.n), dim3(64), 0, st, s, 1, 1, prefetch, 0u, 0, mask, seeds, io);
+                      const int32_t* seeds, StepIO io, LevelPlan plan) {
+        hipLaunchKernelGGL(level_kernel<G>, dim3(s.n), dim3(64), 0, st, s, 1, 1, prefetch, 0u, 0, mask, seeds, io,
+                           plan);
     }
-    static void auto_reset(hipStream_t st, const typename G::State& s, int prefetch, StepIO io) {
+    static void auto_reset(hipStream_t st, const typename G::State& s, int prefetch, StepIO io, LevelPlan plan) {
         hipLaunchKernelGGL(level_kernel<G>, dim3((s.n + 63) / 64), dim3(64), 0, st, s, 2, 64, prefetch, 0u, 0, nullptr,
-                           nullptr, io);
+                           nullptr, io, plan);
     }
     // bulk: most slots are queued (after make / a full reset) → a wavefront per env; otherwise few envs per wave,
     // because the queued envs of one wave are served one after the other.
-    static void pregen(hipStream_t side, const typename G::State& s, bool bulk) {
+    static void pregen(hipStream_t side, const typename G::State& s, bool bulk, LevelPlan plan) {
         const int span = bulk ? 1 : 8;
         hipLaunchKernelGGL(level_kernel<G>, dim3((s.n + span - 1) / span), dim3(64), 0, side, s, 3, span, 1, 0u, 0,
-                           nullptr, nullptr, StepIO{});
+                           nullptr, nullptr, StepIO{}, plan);
     }
 };
 #endif

@@ -200,7 +200,8 @@ class GymVectorAdapter(_VectorBase):
 class ProcgenGymVectorEnv(GymVectorAdapter):
     """`GymVectorAdapter` over the HIP engine.  Raises if there is no HIP device (no CPU fallback)."""
 
-    def __init__(self, game, num_envs, device=0, seed=1, env_offset=0, output="torch"):
+    def __init__(self, game, num_envs, device=0, seed=1, env_offset=0, output="torch", num_levels=0, start_level=0):
         from .vec_env import ProcgenVecEnv
-        super().__init__(ProcgenVecEnv(game, num_envs, device=device, seed_base=seed, env_offset=env_offset), output=output)
+        super().__init__(ProcgenVecEnv(game, num_envs, device=device, seed_base=seed, env_offset=env_offset,
+                                       num_levels=num_levels, start_level=start_level), output=output)
         self.game = game

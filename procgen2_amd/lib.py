@@ -37,6 +37,7 @@ def load(path=None):
         "pgv_game_name": (c_char_p, [c_int32]),
         "pgv_game_id": (c_int32, [c_char_p]),
         "pgv_make": (c_int32, [c_char_p, c_int32, c_int32, c_uint32, c_int32, P, POINTER(P)]),
+        "pgv_make_levels": (c_int32, [c_char_p, c_int32, c_int32, c_uint32, c_int32, P, c_int32, c_int32, POINTER(P)]),
         "pgv_close": (None, [P]),
         "pgv_reset": (c_int32, [P, P, P]),
         "pgv_step": (c_int32, [P, P]),
@@ -79,7 +80,7 @@ def check(lib, rc, what):
 
 
 EXPORTED_VEC_SYMBOLS = [
-    "pgv_game_name", "pgv_game_id", "pgv_make", "pgv_close", "pgv_reset", "pgv_step", "pgv_step_synthetic",
+    "pgv_game_name", "pgv_game_id", "pgv_make", "pgv_make_levels", "pgv_close", "pgv_reset", "pgv_step", "pgv_step_synthetic",
     "pgv_synthetic_action", "pgv_step_host", "pgv_reset_host", "pgv_decode_png", "pgv_sync", "pgv_obs", "pgv_reward", "pgv_done", "pgv_bind_outputs", "pgv_num_envs",
     "pgv_device", "pgv_stream", "pgv_copy_out", "pgv_render_frame", "pgv_snapshot_bytes", "pgv_save_state", "pgv_load_state", "pgv_timed_steps", "pgv_set_debug", "pgv_dump_state", "pgv_dump_tiles",
     "pgv_last_error",

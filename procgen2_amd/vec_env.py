@@ -27,7 +27,8 @@ def shard_range(total_envs, world_size, rank):
 
 
 class ProcgenVecEnv:
-    def __init__(self, game, num_envs, device=0, seed_base=1, env_offset=0, lib_path=None):
+    def __init__(self, game, num_envs, device=0, seed_base=1, env_offset=0, lib_path=None, num_levels=0,
+                 start_level=0):
         if not torch.cuda.is_available():
             raise pglib.EngineError("ProcgenVecEnv needs a HIP device (torch.cuda.is_available() is False); "
                                     "there is no CPU fallback")
@@ -43,8 +44,11 @@ class ProcgenVecEnv:
         # and the caller's current stream wait for the engine's (obs, reward, done).
         self._stream = torch.cuda.Stream(device=self.device)
         h = c_void_p()
-        pglib.check(self.L, self.L.pgv_make(game.encode(), self.num_envs, device, seed_base, self.env_offset,
-                                            c_void_p(self._stream.cuda_stream), ctypes.byref(h)), "pgv_make")
+        # num_levels > 0: a finite level set (include/procgen2_vec.h pgv_make_levels); 0 = every level is new
+        pglib.check(self.L, self.L.pgv_make_levels(game.encode(), self.num_envs, device, seed_base, self.env_offset,
+                                                   c_void_p(self._stream.cuda_stream), int(num_levels),
+                                                   int(start_level), ctypes.byref(h)), "pgv_make")
+        self.num_levels, self.start_level = int(num_levels), int(start_level)
         self._h = h
         # torch owns the result buffers; the engine writes straight into them.
         self.obs = torch.zeros((self.num_envs, 64, 64, 3), dtype=torch.uint8, device=self.device)

@@ -51,6 +51,9 @@ def oracle():
     L.pgo_synthetic_action.argtypes = [c_uint32, c_uint32, c_uint32]
     L.pgo_vec_make.restype = c_void_p
     L.pgo_vec_make.argtypes = [c_char_p, c_int, c_uint32, c_int, c_int]
+    L.pgo_vec_make_levels.restype = c_void_p
+    L.pgo_vec_make_levels.argtypes = [c_char_p, c_int, c_uint32, c_int, c_int, c_int, c_int]
+    L.pgo_vec_reset.argtypes = [c_void_p, c_void_p, c_void_p]
     L.pgo_vec_close.argtypes = [c_void_p]
     L.pgo_vec_step.argtypes = [c_void_p, c_void_p, c_uint32, c_int, c_int, c_void_p, c_void_p, c_void_p]
     L.pgo_vec_obs.argtypes = [c_void_p, c_void_p]
@@ -87,17 +90,29 @@ def register_textures(game):
 class OracleVec:
     """N oracle envs stepped in lock-step with the engine's auto-reset policy (oracle/pgo_api.cpp)."""
 
-    def __init__(self, game, n, seed_base=1, env_offset=0, render=True):
+    def __init__(self, game, n, seed_base=1, env_offset=0, render=True, num_levels=0, start_level=0):
         if render:
             register_textures(game)
         self.L = oracle()
         self.n = n
         self.env_offset = env_offset
-        self.h = self.L.pgo_vec_make(game.encode(), n, seed_base, env_offset, 1 if render else 0)
+        self.h = self.L.pgo_vec_make_levels(game.encode(), n, seed_base, env_offset, 1 if render else 0, num_levels,
+                                            start_level)
         assert self.h, "oracle does not know game %r" % game
         self.obs = np.zeros((n, OBS_BYTES), np.uint8)
         self.reward = np.zeros(n, np.float32)
         self.done = np.zeros(n, np.uint8)
+
+    def reset(self, mask=None, seeds=None):
+        m = s = None
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, dtype=np.uint8)
+            m = mask.ctypes.data_as(c_void_p)
+        if seeds is not None:
+            seeds = np.ascontiguousarray(seeds, dtype=np.int32)
+            s = seeds.ctypes.data_as(c_void_p)
+        self.L.pgo_vec_reset(self.h, m, s)
+        return self.reset_obs()
 
     def reset_obs(self):
         self.L.pgo_vec_obs(self.h, self.obs.ctypes.data_as(c_void_p))
