@@ -54,6 +54,30 @@ PGV_API int32_t pgv_make(const char* game, int32_t num_envs, int32_t device, uin
 PGV_API int32_t pgv_make_levels(const char* game, int32_t num_envs, int32_t device, uint32_t seed_base,
                                 int32_t env_offset, void* stream, int32_t num_levels, int32_t start_level,
                                 pgv_env** out);
+
+/* The general form.  Distribution modes are compile-time `System_Tilemap::Config` constants in the
+ * reference (e.g. maze/tilemap.h:13-17,40-42, chaser/tilemap.cpp:85-99, climber/tilemap.h:33); PGV_MODE_DEFAULT is the
+ * one each reference game is compiled with.  pgv_game_modes(game_id) = bit mask (1 << mode) of what a game offers;
+ * asking for anything else fails.  Zero-initialise the struct and set struct_size = sizeof(pgv_config). */
+#define PGV_MODE_DEFAULT 0
+#define PGV_MODE_EASY 1
+#define PGV_MODE_HARD 2
+#define PGV_MODE_MEMORY 3
+#define PGV_MODE_EXTREME 4
+typedef struct pgv_config {
+    uint32_t struct_size;
+    int32_t num_envs;
+    const char* game;
+    void* stream; /* hipStream_t or NULL */
+    int32_t device;
+    uint32_t seed_base;
+    int32_t env_offset;
+    int32_t num_levels, start_level; /* pgv_make_levels */
+    int32_t mode;                    /* PGV_MODE_* */
+} pgv_config;
+PGV_API int32_t pgv_make_config(const pgv_config* config, pgv_env** out);
+PGV_API uint32_t pgv_game_modes(int32_t game_id);
+PGV_API int32_t pgv_mode(pgv_env* env); /* the resolved mode (never PGV_MODE_DEFAULT) */
 PGV_API void pgv_close(pgv_env* env);
 
 /* Reset the envs whose mask byte is non-zero (device u8[N]; NULL = all).  seeds: device int32[N] to

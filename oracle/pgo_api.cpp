@@ -18,9 +18,28 @@ void pgo_put_texture(const char* name, int w, int h, const uint8_t* rgba) {
 
 int pgo_texture_count() { return static_cast<int>(pgo::TextureBank::global().size()); }
 
-// game: "coinrun" | "maze" | "bossfight".  Returns nullptr for unknown games.
-void* pgo_make(const char* game, uint32_t seed, int render_enabled) {
+// (game, PGV_MODE_*) → the mode the env runs in, -1 if the game has no such mode.  0 = the reference's compile-time
+// default (SURVEY.md §5 "config / flags").
+int pgo_resolve_mode(const char* game, int mode) {
+    const std::string g(game);
+    const bool plain = g == "coinrun" || g == "climber" || g == "bossfight";      // easy | hard
+    const bool mem = g == "maze" || g == "caveflyer" || g == "jumper";           // easy | hard | memory
+    if (mode == 0) return g == "chaser" ? Env::kEasy : Env::kHard;
+    if (mode == Env::kEasy || mode == Env::kHard) return (plain || mem || g == "chaser") ? mode : -1;
+    if (mode == Env::kMemory) return mem ? mode : -1;
+    if (mode == Env::kExtreme) return g == "chaser" ? mode : -1;
+    return -1;
+}
+
+void* pgo_make_mode(const char* game, uint32_t seed, int render_enabled, int mode);
+
+// game: one of the seven names.  Returns nullptr for unknown games.
+void* pgo_make(const char* game, uint32_t seed, int render_enabled) { return pgo_make_mode(game, seed, render_enabled, 0); }
+
+void* pgo_make_mode(const char* game, uint32_t seed, int render_enabled, int mode) {
     std::string g(game);
+    const int resolved = pgo_resolve_mode(game, mode);
+    if (resolved < 0) return nullptr;
     Env* e = nullptr;
     if (g == "coinrun")
         e = pgo::new_coinrun();
@@ -38,6 +57,7 @@ void* pgo_make(const char* game, uint32_t seed, int render_enabled) {
         e = pgo::new_jumper();
     if (!e) return nullptr;
     e->set_render_enabled(render_enabled != 0);
+    e->set_mode(resolved);
     e->make(seed);
     return e;
 }
@@ -123,7 +143,7 @@ struct VecState {
     uint32_t step_counter = 0;
     // level-seed mode (include/procgen2_vec.h pgv_make_levels); num_levels 0 = off
     std::string game;
-    int render = 0, num_levels = 0, start_level = 0;
+    int render = 0, num_levels = 0, start_level = 0, mode = 0;
     std::vector<uint32_t> chain_seed, drawn;
 };
 
@@ -139,17 +159,18 @@ static void vec_new_level(VecState* v, int i, bool restart, uint32_t seed) {
         const uint32_t number = static_cast<uint32_t>(v->start_level) +
                                 mix32(mix32(v->chain_seed[i]) + k) % static_cast<uint32_t>(v->num_levels);
         delete v->envs[i];
-        v->envs[i] = static_cast<Env*>(pgo_make(v->game.c_str(), number, v->render));
+        v->envs[i] = static_cast<Env*>(pgo_make_mode(v->game.c_str(), number, v->render, v->mode));
         v->envs[i]->present();
     } else {
         v->envs[i]->reset(restart, static_cast<int32_t>(seed));
     }
 }
 
-void* pgo_vec_make_levels(const char* game, int n, uint32_t seed_base, int env_offset, int render_enabled,
-                          int num_levels, int start_level) {
+void* pgo_vec_make_config(const char* game, int n, uint32_t seed_base, int env_offset, int render_enabled,
+                          int num_levels, int start_level, int mode) {
     auto* v = new VecState();
     v->game = game;
+    v->mode = mode;
     v->render = render_enabled;
     v->num_levels = num_levels;
     v->start_level = start_level;
@@ -157,7 +178,7 @@ void* pgo_vec_make_levels(const char* game, int n, uint32_t seed_base, int env_o
     v->drawn.assign(n, 0);
     for (int i = 0; i < n; i++) {
         const uint32_t seed = seed_base + static_cast<uint32_t>(env_offset + i);
-        Env* e = static_cast<Env*>(pgo_make(game, seed, render_enabled));  // level 0, never observed (D1)
+        Env* e = static_cast<Env*>(pgo_make_mode(game, seed, render_enabled, mode));  // level 0, never observed (D1)
         if (!e) {
             delete v;
             return nullptr;
@@ -171,8 +192,12 @@ void* pgo_vec_make_levels(const char* game, int n, uint32_t seed_base, int env_o
     return v;
 }
 
+void* pgo_vec_make_levels(const char* game, int n, uint32_t seed_base, int env_offset, int render_enabled,
+                          int num_levels, int start_level) {
+    return pgo_vec_make_config(game, n, seed_base, env_offset, render_enabled, num_levels, start_level, 0);
+}
 void* pgo_vec_make(const char* game, int n, uint32_t seed_base, int env_offset, int render_enabled) {
-    return pgo_vec_make_levels(game, n, seed_base, env_offset, render_enabled, 0, 0);
+    return pgo_vec_make_config(game, n, seed_base, env_offset, render_enabled, 0, 0, 0);
 }
 
 // cenv_reset of the envs with mask[i] != 0 (nullptr = all); seeds nullptr = keep the streams.

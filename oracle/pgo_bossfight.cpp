@@ -263,7 +263,7 @@ class Bossfight final : public Env {
         }
     }
     void fire_pattern(V2 pos, int pattern, float& timer, float dt) {  // common_systems.cpp:103-185
-        const float bullet_speed = 0.1f;  // hard_mode
+        const float bullet_speed = mode_ == kHard ? 0.1f : 0.05f;  // common_systems.cpp:104
         switch (pattern) {
             case -1:
                 if (rng_.unit() < 0.1f * dt) boss_fire(pos, M_PI * (1.0f + rng_.unit()), bullet_speed);
@@ -320,7 +320,8 @@ class Bossfight final : public Env {
     }
 
     bool boss_update(float dt) {  // common_systems.cpp:199-390
-        const float shielded_time = 180.0f + rng_.unit() * 80.0f;  // drawn every sub-step (D14)
+        const float shielded_time =
+            180.0f + rng_.unit() * (mode_ == kHard ? 80.0f : 30.0f);  // drawn every sub-step (D14); common_systems.cpp:202
         const float unshielded_time = 300.0f, explosion_rate = 0.3f, move_time = 70.0f, damage_time = 80.0f;
         const int boss_hp = 3;
         bool alive = true;

@@ -155,7 +155,7 @@ class Climber final : public Env {
         const int platforms = rng_.irange(lo, hi);
         int cx = rng_.irange(2, W - 3), cy = 1;
         const int margin = 3;
-        const float enemy_prob = .5;
+        const float enemy_prob = mode_ == kEasy ? .2 : .5;  // tilemap.cpp:118
         float reach_y = max_jump * max_jump / (2.0f * gravity);
         const int max_dy = reach_y - 0.5f;
         for (int p = 0; p < platforms; p++) {

@@ -42,6 +42,11 @@ class Env {
 
     void set_render_enabled(bool on) { painter_.enabled = on; }
 
+    // Distribution mode = the reference's compile-time `System_Tilemap::Config` / `Distribution_Mode` of the game
+    // (include/procgen2_vec.h PGV_MODE_*; always a resolved value here, never "default").  Set before make().
+    enum Mode { kEasy = 1, kHard = 2, kMemory = 3, kExtreme = 4 };
+    void set_mode(int mode) { mode_ = mode; }
+
     // cenv_render (coinrun.cpp:393-411): render_game(false) into a width×height target, packed RGB.  The reference
     // leaves its global camera scale/size at the window's values afterwards (only bossfight's reset reads them, D15);
     // this restatement puts them back, i.e. it models a caller that never mixes human frames into a rollout.
@@ -89,6 +94,7 @@ class Env {
         pack_rgb(surface_, obs);
     }
 
+    int mode_ = kHard;
     int view_w_ = kObsW, view_h_ = kObsH;  // `width`, `height` of render_game(is_obs): the target being painted
     Rng rng_;
     Surface surface_;

@@ -27,6 +27,10 @@ COMMON = ["--offload-arch=" + ARCH, "-std=c++17", "-O3", "-fPIC", "-ffp-contract
           "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-I" + CSRC]
 
 KERNEL_SOURCES = ["coinrun.hip", "maze.hip", "bossfight.hip", "climber.hip", "caveflyer.hip", "chaser.hip", "jumper.hip"]
+# Distribution modes: a game's source is compiled once per variant (-DPG_VARIANT=k, csrc/pg_defs.h); variant 0 is the
+# reference's compile-time default.  engine.hip's kVariants table maps (game, mode) to these.
+VARIANTS = {"coinrun.hip": 1, "maze.hip": 1, "bossfight.hip": 2, "climber.hip": 2, "caveflyer.hip": 1, "chaser.hip": 1,
+            "jumper.hip": 1}
 HOST_SOURCES = ["png_decode.cpp"]
 ENGINE = "engine.hip"
 ALIASES = {"libprocgen2_hip.so": 0, "libCoinRun.so": 0, "libMaze.so": 1, "libBossFight.so": 2, "libClimber.so": 3,
@@ -60,27 +64,44 @@ def _run(cmd, verbose):
     subprocess.run(cmd, check=True)
 
 
+def _parallel(jobs, verbose):
+    """Independent compiler invocations, a few at a time (each hipcc is single-threaded and takes ~1 GiB)."""
+    if not jobs:
+        return
+    from concurrent.futures import ThreadPoolExecutor
+    workers = max(1, min(len(jobs), int(os.environ.get("PG_BUILD_JOBS", "0")) or min(6, os.cpu_count() or 1)))
+    with ThreadPoolExecutor(workers) as pool:
+        for f in [pool.submit(_run, cmd, verbose) for cmd in jobs]:
+            f.result()
+
+
 def build(force=False, verbose=True):
     os.makedirs(LIB, exist_ok=True)
     os.makedirs(OBJ, exist_ok=True)
     cc = hipcc()
     hdrs = _headers()
-    objs = []
+    objs, jobs = [], []
     for src in KERNEL_SOURCES + HOST_SOURCES:
         path = os.path.join(CSRC, src)
-        obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
-        if force or _stale(obj, [path] + hdrs):
-            _run([cc] + COMMON + ["-c", path, "-o", obj], verbose)
-        objs.append(obj)
-    outputs = []
+        for k in range(VARIANTS.get(src, 1)):
+            obj = os.path.join(OBJ, os.path.splitext(src)[0] + ("_v%d.o" % k if src in VARIANTS else ".o"))
+            if force or _stale(obj, [path] + hdrs):
+                jobs.append([cc] + COMMON + ["-DPG_VARIANT=%d" % k, "-c", path, "-o", obj])
+            objs.append(obj)
+    engines = {}
     for lib, game in ALIASES.items():
         eng = os.path.join(OBJ, "engine_g%d.o" % game)
-        if force or _stale(eng, [os.path.join(CSRC, ENGINE)] + hdrs):
-            _run([cc] + COMMON + ["-DPG_DEFAULT_GAME=%d" % game, "-c", os.path.join(CSRC, ENGINE), "-o", eng], verbose)
+        if eng not in engines.values() and (force or _stale(eng, [os.path.join(CSRC, ENGINE)] + hdrs)):
+            jobs.append([cc] + COMMON + ["-DPG_DEFAULT_GAME=%d" % game, "-c", os.path.join(CSRC, ENGINE), "-o", eng])
+        engines[lib] = eng
+    _parallel(jobs, verbose)
+    outputs, links = [], []
+    for lib, eng in engines.items():
         out = os.path.join(LIB, lib)
-        if force or _stale(out, objs + [eng]):
-            _run([cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out] + objs + [eng, "-lz", "-ldl"], verbose)
+        if force or jobs or _stale(out, objs + [eng]):
+            links.append([cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out] + objs + [eng, "-lz", "-ldl"])
         outputs.append(out)
+    _parallel(links, verbose)
     return outputs
 
 

@@ -23,7 +23,17 @@
 #include "pg_sincos.h"
 
 namespace pg {
+namespace PG_VARIANT_NS {
 namespace bossfight {
+
+// common_systems.cpp:104,202 (`config.mode == hard_mode ? … : …`; common_systems.h:64: hard_mode is the default)
+#if PG_VARIANT == 0
+constexpr float kBossBulletSpeed = 0.1f, kShieldedSpread = 80.0f;
+#elif PG_VARIANT == 1  // easy_mode
+constexpr float kBossBulletSpeed = 0.05f, kShieldedSpread = 30.0f;
+#else
+#error "bossfight: unknown PG_VARIANT"
+#endif
 
 constexpr int kAgentShots = 32, kBossShots = 64, kBooms = 8, kRocks = 4;
 constexpr double kPi = 3.14159265358979323846;  // M_PI
@@ -178,7 +188,7 @@ PG_D void boss_fire(const State& s, int env, Live& v, float rotation, float spee
 }
 
 PG_D void fire_pattern(const State& s, int env, Live& v, uint32_t* mt, int pattern, float dt) {  // :103-185
-    const float bullet_speed = 0.1f;  // hard_mode
+    const float bullet_speed = kBossBulletSpeed;
     float& timer = v.attack_t;
     switch (pattern) {
         case -1:
@@ -340,7 +350,7 @@ PG_D bool agent_update(const State& s, int env, Live& v, uint32_t* mt, float dt,
 }
 
 PG_D bool boss_update(const State& s, int env, Live& v, uint32_t* mt, float dt) {  // :199-390
-    const float shielded_time = 180.0f + rng_real(mt, 0.0f, 1.0f) * 80.0f;  // drawn every sub-step (D14)
+    const float shielded_time = 180.0f + rng_real(mt, 0.0f, 1.0f) * kShieldedSpread;  // drawn every sub-step (D14)
     const float unshielded_time = 300.0f, explosion_rate = 0.3f, move_time = 70.0f, damage_time = 80.0f;
     const int boss_hp = 3;
     bool alive = true;
@@ -932,6 +942,8 @@ class BossfightGame final : public Game {
 
 }  // namespace bossfight
 
-std::unique_ptr<Game> make_bossfight() { return std::make_unique<bossfight::BossfightGame>(); }
+}  // namespace PG_VARIANT_NS
+
+std::unique_ptr<Game> PG_FACTORY(make_bossfight)() { return std::make_unique<PG_VARIANT_NS::bossfight::BossfightGame>(); }
 
 }  // namespace pg

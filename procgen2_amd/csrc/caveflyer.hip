@@ -31,6 +31,7 @@
 #include "pg_tiles.h"
 
 namespace pg {
+namespace PG_VARIANT_NS {
 namespace caveflyer {
 
 constexpr int W = 40, H = 40, kCells = W * H;
@@ -869,6 +870,8 @@ class CaveflyerGame final : public Game {
 
 }  // namespace caveflyer
 
-std::unique_ptr<Game> make_caveflyer() { return std::make_unique<caveflyer::CaveflyerGame>(); }
+}  // namespace PG_VARIANT_NS
+
+std::unique_ptr<Game> PG_FACTORY(make_caveflyer)() { return std::make_unique<PG_VARIANT_NS::caveflyer::CaveflyerGame>(); }
 
 }  // namespace pg

@@ -26,6 +26,7 @@
 #include "pg_setorder.h"
 
 namespace pg {
+namespace PG_VARIANT_NS {
 namespace chaser {
 
 constexpr int W = 11, H = 11, kCells = W * H, kTileStride = 128;
@@ -859,6 +860,8 @@ class ChaserGame final : public Game {
 
 }  // namespace chaser
 
-std::unique_ptr<Game> make_chaser() { return std::make_unique<chaser::ChaserGame>(); }
+}  // namespace PG_VARIANT_NS
+
+std::unique_ptr<Game> PG_FACTORY(make_chaser)() { return std::make_unique<PG_VARIANT_NS::chaser::ChaserGame>(); }
 
 }  // namespace pg

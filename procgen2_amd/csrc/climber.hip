@@ -23,7 +23,17 @@
 #include "pg_tiles.h"
 
 namespace pg {
+namespace PG_VARIANT_NS {
 namespace climber {
+
+// climber/tilemap.cpp:118 `enemy_prob = cfg.easy_mode ? .2 : .5` (tilemap.h:33: easy_mode = false is the default)
+#if PG_VARIANT == 0
+constexpr float kEnemyProb = 0.5f;
+#elif PG_VARIANT == 1  // easy_mode
+constexpr float kEnemyProb = 0.2f;
+#else
+#error "climber: unknown PG_VARIANT"
+#endif
 
 constexpr int W = 20, H = 64;
 constexpr int kMaxEnt = 34;  // ≤ 17 platforms (difficulty 3), each at most one mob and one crystal (tilemap.cpp:98-105)
@@ -159,7 +169,7 @@ PG_D void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, u
     const int platforms = wave_rng_int(mt, difficulty * difficulty + 1, (difficulty + 1) * (difficulty + 1) + 1, lane);
     int cx = wave_rng_int(mt, 2, W - 3, lane), cy = 1;
     const int margin = 3;
-    const float enemy_prob = 0.5f;
+    const float enemy_prob = kEnemyProb;
     const float reach_y = max_jump * max_jump / (2.0f * gravity);
     const int max_dy = static_cast<int>(reach_y - 0.5f);
     int n_ent = 0;
@@ -710,6 +720,8 @@ class ClimberGame final : public Game {
 
 }  // namespace climber
 
-std::unique_ptr<Game> make_climber() { return std::make_unique<climber::ClimberGame>(); }
+}  // namespace PG_VARIANT_NS
+
+std::unique_ptr<Game> PG_FACTORY(make_climber)() { return std::make_unique<PG_VARIANT_NS::climber::ClimberGame>(); }
 
 }  // namespace pg

@@ -35,6 +35,7 @@
 #include "pg_rng.h"
 
 namespace pg {
+namespace PG_VARIANT_NS {
 namespace coinrun {
 
 constexpr int W = 64, H = 64;
@@ -1265,6 +1266,8 @@ class CoinrunGame final : public Game {
 
 }  // namespace coinrun
 
-std::unique_ptr<Game> make_coinrun() { return std::make_unique<coinrun::CoinrunGame>(); }
+}  // namespace PG_VARIANT_NS
+
+std::unique_ptr<Game> PG_FACTORY(make_coinrun)() { return std::make_unique<PG_VARIANT_NS::coinrun::CoinrunGame>(); }
 
 }  // namespace pg

@@ -107,17 +107,27 @@ static std::string asset_root() {
 
 static const char* const kGameNames[kNumGames] = {"coinrun", "maze", "bossfight", "climber", "caveflyer", "chaser", "jumper"};
 
-static std::unique_ptr<Game> make_game(int id) {
-    switch (id) {
-        case kGameCoinrun: return make_coinrun();
-        case kGameMaze: return make_maze();
-        case kGameBossfight: return make_bossfight();
-        case kGameClimber: return make_climber();
-        case kGameCaveflyer: return make_caveflyer();
-        case kGameChaser: return make_chaser();
-        case kGameJumper: return make_jumper();
-        default: return nullptr;
-    }
+// (game, distribution mode) → compiled variant.  The first row of a game is its PGV_MODE_DEFAULT, i.e. the reference's
+// compile-time `Config` (SURVEY.md §5 "config / flags").  coinrun: `easy_mode` only feeds `allow_monsters`, which
+// nothing reads (coinrun/tilemap.cpp:148), so both modes are the same game.
+struct Variant {
+    int game, mode;
+    std::unique_ptr<Game> (*make)();
+};
+static const Variant kVariants[] = {
+    {kGameCoinrun, PGV_MODE_HARD, make_coinrun_v0},     {kGameCoinrun, PGV_MODE_EASY, make_coinrun_v0},
+    {kGameMaze, PGV_MODE_HARD, make_maze_v0},
+    {kGameBossfight, PGV_MODE_HARD, make_bossfight_v0}, {kGameBossfight, PGV_MODE_EASY, make_bossfight_v1},
+    {kGameClimber, PGV_MODE_HARD, make_climber_v0},     {kGameClimber, PGV_MODE_EASY, make_climber_v1},
+    {kGameCaveflyer, PGV_MODE_HARD, make_caveflyer_v0},
+    {kGameChaser, PGV_MODE_EASY, make_chaser_v0},
+    {kGameJumper, PGV_MODE_HARD, make_jumper_v0},
+};
+
+static const Variant* find_variant(int game, int mode) {
+    for (const Variant& v : kVariants)
+        if (v.game == game && (mode == PGV_MODE_DEFAULT || v.mode == mode)) return &v;
+    return nullptr;
 }
 
 }  // namespace pg
@@ -126,7 +136,7 @@ static std::unique_ptr<Game> make_game(int id) {
 // The vector env object
 // ------------------------------------------------------------------------------------------------
 struct pgv_env {
-    int n = 0, device = 0, env_offset = 0;
+    int n = 0, device = 0, env_offset = 0, mode = 0;
     uint32_t step_index = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -219,11 +229,45 @@ int32_t pgv_make(const char* game, int32_t num_envs, int32_t device, uint32_t se
 
 int32_t pgv_make_levels(const char* game, int32_t num_envs, int32_t device, uint32_t seed_base, int32_t env_offset,
                         void* stream, int32_t num_levels, int32_t start_level, pgv_env** out) {
+    pgv_config cfg{};
+    cfg.struct_size = sizeof(pgv_config);
+    cfg.game = game;
+    cfg.num_envs = num_envs;
+    cfg.device = device;
+    cfg.seed_base = seed_base;
+    cfg.env_offset = env_offset;
+    cfg.stream = stream;
+    cfg.num_levels = num_levels;
+    cfg.start_level = start_level;
+    cfg.mode = PGV_MODE_DEFAULT;
+    return pgv_make_config(&cfg, out);
+}
+
+uint32_t pgv_game_modes(int32_t game_id) {
+    uint32_t bits = 0;
+    for (const pg::Variant& v : pg::kVariants)
+        if (v.game == game_id) bits |= 1u << v.mode;
+    return bits;
+}
+
+int32_t pgv_mode(pgv_env* e) { return e ? e->mode : -1; }
+
+int32_t pgv_make_config(const pgv_config* cfg, pgv_env** out) {
     if (!out) return fail("pgv_make: out is NULL");
-    if (num_levels < 0) return fail("pgv_make: num_levels must be >= 0 (0 = every level is new)");
     *out = nullptr;
+    if (!cfg || cfg->struct_size < sizeof(pgv_config)) return fail("pgv_make_config: config is NULL or struct_size too small");
+    const char* game = cfg->game;
+    const int32_t num_envs = cfg->num_envs, device = cfg->device, env_offset = cfg->env_offset;
+    const uint32_t seed_base = cfg->seed_base;
+    void* stream = cfg->stream;
+    const int32_t num_levels = cfg->num_levels, start_level = cfg->start_level;
+    if (num_levels < 0) return fail("pgv_make: num_levels must be >= 0 (0 = every level is new)");
     const int gid = pgv_game_id(game);
     if (gid < 0) return fail(std::string("pgv_make: unknown game '") + (game ? game : "(null)") + "'");
+    const pg::Variant* variant = pg::find_variant(gid, cfg->mode);
+    if (!variant)
+        return fail(std::string("pgv_make: game '") + game + "' has no distribution mode " + std::to_string(cfg->mode) +
+                    " (see pgv_game_modes)");
     if (num_envs <= 0) return fail("pgv_make: num_envs must be positive");
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
@@ -235,7 +279,8 @@ int32_t pgv_make_levels(const char* game, int32_t num_envs, int32_t device, uint
     e->n = num_envs;
     e->device = device;
     e->env_offset = env_offset;
-    e->game = pg::make_game(gid);
+    e->game = variant->make();
+    e->mode = variant->mode;
     if (stream) {
         e->stream = static_cast<hipStream_t>(stream);
     } else {
@@ -381,7 +426,7 @@ struct SnapshotHeader {
     int32_t n, env_offset;
     uint64_t state_bytes;
     uint32_t step_index;
-    int32_t num_levels, start_level, reserved;
+    int32_t num_levels, start_level, mode;
 };
 static constexpr uint32_t kSnapshotMagic = 0x50474e32u;  // "PGN2"
 
@@ -400,7 +445,7 @@ int32_t pgv_save_state(pgv_env* e, void* h_buffer, int64_t capacity) {
     if (e->side) PG_HIP(hipStreamSynchronize(e->side));
     uint8_t* out = static_cast<uint8_t*>(h_buffer);
     SnapshotHeader hd{kSnapshotMagic, static_cast<uint32_t>(pgv_game_id(e->game->name())), e->n, e->env_offset,
-                      state_blob_bytes(e), e->step_index, e->game->plan.num_levels, e->game->plan.start_level, 0};
+                      state_blob_bytes(e), e->step_index, e->game->plan.num_levels, e->game->plan.start_level, e->mode};
     std::memcpy(out, &hd, sizeof(hd));
     out += sizeof(hd);
     PG_HIP(hipMemcpy(out, e->d_state, hd.state_bytes, hipMemcpyDeviceToHost));
@@ -423,8 +468,8 @@ int32_t pgv_load_state(pgv_env* e, const void* h_buffer, int64_t size) {
     std::memcpy(&hd, in, sizeof(hd));
     if (hd.magic != kSnapshotMagic || hd.game != static_cast<uint32_t>(pgv_game_id(e->game->name())) || hd.n != e->n ||
         hd.env_offset != e->env_offset || hd.state_bytes != state_blob_bytes(e) ||
-        hd.num_levels != e->game->plan.num_levels || hd.start_level != e->game->plan.start_level)
-        return fail("pgv_load_state: snapshot of a different env (game, size, shard or level set)");
+        hd.num_levels != e->game->plan.num_levels || hd.start_level != e->game->plan.start_level || hd.mode != e->mode)
+        return fail("pgv_load_state: snapshot of a different env (game, mode, size, shard or level set)");
     PG_HIP(hipSetDevice(e->device));
     PG_HIP(hipStreamSynchronize(e->stream));
     if (e->side) PG_HIP(hipStreamSynchronize(e->side));
@@ -632,12 +677,13 @@ int32_t cenv_make(const char* render_mode, cenv_option* options, int32_t options
     (void)render_mode;
     if (g.env) cenv_close();
     int seed = static_cast<int>(time(nullptr));  // coinrun.cpp:130
-    int num_envs = 1, game = PG_DEFAULT_GAME, device = 0, env_offset = 0, num_levels = 0, start_level = 0;
+    int num_envs = 1, game = PG_DEFAULT_GAME, device = 0, env_offset = 0, num_levels = 0, start_level = 0, mode = 0;
     for (int i = 0; i < options_size; i++) {
         const std::string name(options[i].name ? options[i].name : "");
         int v = 0;
         if (name == "seed" || name == "width" || name == "height" || name == "num_envs" || name == "game" ||
-            name == "device" || name == "env_offset" || name == "num_levels" || name == "start_level") {
+            name == "device" || name == "env_offset" || name == "num_levels" || name == "start_level" ||
+            name == "distribution_mode") {
             if (opt_int(options[i], &v)) return fail("cenv_make: option '" + name + "' must be INT");
         }
         if (name == "seed")
@@ -658,11 +704,22 @@ int32_t cenv_make(const char* render_mode, cenv_option* options, int32_t options
             num_levels = v;
         else if (name == "start_level")
             start_level = v;
+        else if (name == "distribution_mode")
+            mode = v;
     }
     const char* gname = pgv_game_name(game);
     if (!gname) return fail("cenv_make: unknown game id");
-    int rc = pgv_make_levels(gname, num_envs, device, static_cast<uint32_t>(seed), env_offset, nullptr, num_levels,
-                             start_level, &g.env);
+    pgv_config cfg{};
+    cfg.struct_size = sizeof(pgv_config);
+    cfg.game = gname;
+    cfg.num_envs = num_envs;
+    cfg.device = device;
+    cfg.seed_base = static_cast<uint32_t>(seed);
+    cfg.env_offset = env_offset;
+    cfg.num_levels = num_levels;
+    cfg.start_level = start_level;
+    cfg.mode = mode;
+    int rc = pgv_make_config(&cfg, &g.env);
     if (rc) return rc;
     g.n = num_envs;
     g.h_obs.assign(size_t(num_envs) * pg::kObsBytes, 0);

@@ -25,6 +25,7 @@
 #include "pg_tiles.h"
 
 namespace pg {
+namespace PG_VARIANT_NS {
 namespace jumper {
 
 constexpr int W = 40, H = 40, kCells = W * H;
@@ -933,6 +934,8 @@ class JumperGame final : public Game {
 
 }  // namespace jumper
 
-std::unique_ptr<Game> make_jumper() { return std::make_unique<jumper::JumperGame>(); }
+}  // namespace PG_VARIANT_NS
+
+std::unique_ptr<Game> PG_FACTORY(make_jumper)() { return std::make_unique<PG_VARIANT_NS::jumper::JumperGame>(); }
 
 }  // namespace pg

@@ -19,6 +19,7 @@
 #include "pg_rng.h"
 
 namespace pg {
+namespace PG_VARIANT_NS {
 namespace maze {
 
 constexpr int W = 25, H = 25, kCells = W * H;
@@ -387,6 +388,8 @@ class MazeGame final : public Game {
 
 }  // namespace maze
 
-std::unique_ptr<Game> make_maze() { return std::make_unique<maze::MazeGame>(); }
+}  // namespace PG_VARIANT_NS
+
+std::unique_ptr<Game> PG_FACTORY(make_maze)() { return std::make_unique<PG_VARIANT_NS::maze::MazeGame>(); }
 
 }  // namespace pg

@@ -17,6 +17,17 @@
 #define PG_D inline
 #endif
 
+// Distribution modes are compile-time constants in the reference (`System_Tilemap::Config`); here a
+// game's source is compiled once per mode it offers, with PG_VARIANT selecting the constants, each copy in its own
+// namespace with its own factory (build.py VARIANTS; engine.hip make_game maps (game, mode) → factory).
+#ifndef PG_VARIANT
+#define PG_VARIANT 0
+#endif
+#define PG_CAT2(a, b) a##b
+#define PG_CAT(a, b) PG_CAT2(a, b)
+#define PG_VARIANT_NS PG_CAT(variant, PG_VARIANT)
+#define PG_FACTORY(name) PG_CAT(PG_CAT(name, _v), PG_VARIANT)
+
 namespace pg {
 
 constexpr int kObsW = 64;

@@ -108,13 +108,16 @@ constexpr int kDebugNoPrefetch = 1 << 8;
 int logic_lanes();
 inline int logic_blocks(int n) { return (n + logic_lanes() - 1) / logic_lanes(); }
 
-std::unique_ptr<Game> make_coinrun();
-std::unique_ptr<Game> make_maze();
-std::unique_ptr<Game> make_bossfight();
-std::unique_ptr<Game> make_climber();
-std::unique_ptr<Game> make_caveflyer();
-std::unique_ptr<Game> make_chaser();
-std::unique_ptr<Game> make_jumper();
+// Factories, one per compiled variant of a game (pg_defs.h PG_VARIANT; v0 = the reference's compile-time default).
+std::unique_ptr<Game> make_coinrun_v0();
+std::unique_ptr<Game> make_maze_v0();
+std::unique_ptr<Game> make_bossfight_v0();
+std::unique_ptr<Game> make_bossfight_v1();
+std::unique_ptr<Game> make_climber_v0();
+std::unique_ptr<Game> make_climber_v1();
+std::unique_ptr<Game> make_caveflyer_v0();
+std::unique_ptr<Game> make_chaser_v0();
+std::unique_ptr<Game> make_jumper_v0();
 
 // Counter-based synthetic action shared with the oracle (oracle/pgo_api.cpp pgo_synthetic_action).
 PG_HD uint32_t mix32(uint32_t x) {

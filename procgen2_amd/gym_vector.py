@@ -200,8 +200,10 @@ class GymVectorAdapter(_VectorBase):
 class ProcgenGymVectorEnv(GymVectorAdapter):
     """`GymVectorAdapter` over the HIP engine.  Raises if there is no HIP device (no CPU fallback)."""
 
-    def __init__(self, game, num_envs, device=0, seed=1, env_offset=0, output="torch", num_levels=0, start_level=0):
+    def __init__(self, game, num_envs, device=0, seed=1, env_offset=0, output="torch", num_levels=0, start_level=0,
+                 distribution_mode=None):
         from .vec_env import ProcgenVecEnv
         super().__init__(ProcgenVecEnv(game, num_envs, device=device, seed_base=seed, env_offset=env_offset,
-                                       num_levels=num_levels, start_level=start_level), output=output)
+                                       num_levels=num_levels, start_level=start_level,
+                                       distribution_mode=distribution_mode), output=output)
         self.game = game

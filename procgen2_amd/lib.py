@@ -15,6 +15,36 @@ OBS_BYTES = 12288
 OBS_SHAPE = (64, 64, 3)
 NUM_ACTIONS = 15
 
+# include/procgen2_vec.h PGV_MODE_*
+MODES = {"default": 0, "easy": 1, "hard": 2, "memory": 3, "extreme": 4}
+
+
+class Config(ctypes.Structure):
+    """include/procgen2_vec.h `pgv_config`."""
+    _fields_ = [("struct_size", c_uint32), ("num_envs", c_int32), ("game", c_char_p), ("stream", c_void_p),
+                ("device", c_int32), ("seed_base", c_uint32), ("env_offset", c_int32), ("num_levels", c_int32),
+                ("start_level", c_int32), ("mode", c_int32)]
+
+
+def mode_id(mode):
+    if mode is None:
+        return 0
+    if isinstance(mode, str):
+        if mode not in MODES:
+            raise ValueError("unknown distribution mode %r (one of %s)" % (mode, ", ".join(MODES)))
+        return MODES[mode]
+    return int(mode)
+
+
+def make(lib, game, num_envs, device=0, seed_base=1, env_offset=0, stream=None, num_levels=0, start_level=0, mode=None):
+    """pgv_make_config → env handle (c_void_p)."""
+    cfg = Config(ctypes.sizeof(Config), int(num_envs), game.encode(), stream, int(device), int(seed_base) & 0xFFFFFFFF,
+                 int(env_offset), int(num_levels), int(start_level), mode_id(mode))
+    h = c_void_p()
+    check(lib, lib.pgv_make_config(ctypes.byref(cfg), ctypes.byref(h)), "pgv_make")
+    return h
+
+
 _cached = {}
 
 
@@ -38,6 +68,9 @@ def load(path=None):
         "pgv_game_id": (c_int32, [c_char_p]),
         "pgv_make": (c_int32, [c_char_p, c_int32, c_int32, c_uint32, c_int32, P, POINTER(P)]),
         "pgv_make_levels": (c_int32, [c_char_p, c_int32, c_int32, c_uint32, c_int32, P, c_int32, c_int32, POINTER(P)]),
+        "pgv_make_config": (c_int32, [POINTER(Config), POINTER(P)]),
+        "pgv_game_modes": (c_uint32, [c_int32]),
+        "pgv_mode": (c_int32, [P]),
         "pgv_close": (None, [P]),
         "pgv_reset": (c_int32, [P, P, P]),
         "pgv_step": (c_int32, [P, P]),
@@ -80,7 +113,7 @@ def check(lib, rc, what):
 
 
 EXPORTED_VEC_SYMBOLS = [
-    "pgv_game_name", "pgv_game_id", "pgv_make", "pgv_make_levels", "pgv_close", "pgv_reset", "pgv_step", "pgv_step_synthetic",
+    "pgv_game_name", "pgv_game_id", "pgv_make", "pgv_make_levels", "pgv_make_config", "pgv_game_modes", "pgv_mode", "pgv_close", "pgv_reset", "pgv_step", "pgv_step_synthetic",
     "pgv_synthetic_action", "pgv_step_host", "pgv_reset_host", "pgv_decode_png", "pgv_sync", "pgv_obs", "pgv_reward", "pgv_done", "pgv_bind_outputs", "pgv_num_envs",
     "pgv_device", "pgv_stream", "pgv_copy_out", "pgv_render_frame", "pgv_snapshot_bytes", "pgv_save_state", "pgv_load_state", "pgv_timed_steps", "pgv_set_debug", "pgv_dump_state", "pgv_dump_tiles",
     "pgv_last_error",

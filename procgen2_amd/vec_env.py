@@ -28,7 +28,7 @@ def shard_range(total_envs, world_size, rank):
 
 class ProcgenVecEnv:
     def __init__(self, game, num_envs, device=0, seed_base=1, env_offset=0, lib_path=None, num_levels=0,
-                 start_level=0):
+                 start_level=0, distribution_mode=None):
         if not torch.cuda.is_available():
             raise pglib.EngineError("ProcgenVecEnv needs a HIP device (torch.cuda.is_available() is False); "
                                     "there is no CPU fallback")
@@ -43,12 +43,14 @@ class ProcgenVecEnv:
         # caller's.  Every call below makes the engine's stream wait for the caller's current stream (actions, masks)
         # and the caller's current stream wait for the engine's (obs, reward, done).
         self._stream = torch.cuda.Stream(device=self.device)
-        h = c_void_p()
-        # num_levels > 0: a finite level set (include/procgen2_vec.h pgv_make_levels); 0 = every level is new
-        pglib.check(self.L, self.L.pgv_make_levels(game.encode(), self.num_envs, device, seed_base, self.env_offset,
-                                                   c_void_p(self._stream.cuda_stream), int(num_levels),
-                                                   int(start_level), ctypes.byref(h)), "pgv_make")
+        # num_levels > 0: a finite level set (include/procgen2_vec.h pgv_make_levels); 0 = every level is new.
+        # distribution_mode: None / "default" = the reference's compile-time config, or "easy" | "hard" | "memory" |
+        # "extreme" where the game has it (pgv_game_modes).
+        h = pglib.make(self.L, game, self.num_envs, device=device, seed_base=seed_base, env_offset=self.env_offset,
+                       stream=c_void_p(self._stream.cuda_stream), num_levels=num_levels, start_level=start_level,
+                       mode=distribution_mode)
         self.num_levels, self.start_level = int(num_levels), int(start_level)
+        self.distribution_mode = {v: k for k, v in pglib.MODES.items()}[self.L.pgv_mode(h)]
         self._h = h
         # torch owns the result buffers; the engine writes straight into them.
         self.obs = torch.zeros((self.num_envs, 64, 64, 3), dtype=torch.uint8, device=self.device)
