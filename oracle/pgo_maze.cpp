@@ -4,7 +4,8 @@
 //   step   games/maze/maze.cpp:279-330, common_systems.cpp:69-136
 //   render games/maze/maze.cpp:386-414, tilemap.cpp:111-133, common_systems.cpp:41-63,138-150
 //   reset  games/maze/maze.cpp:416-438, tilemap.cpp:31-109, maze_generator.cpp:55-139,183-195
-// Config is the reference's compile-time default: hard_mode (25×25 world, fixed camera).
+// Config: mode_ picks the reference's `Distribution_Mode` (tilemap.cpp:31-48); hard_mode (25×25 world, all visible,
+// fixed camera) is its compile-time default.
 #include <algorithm>
 
 #include "pgo_env.h"
@@ -108,14 +109,17 @@ struct Carver {
 
 class Maze final : public Env {
    public:
-    static constexpr int W = 25, H = 25, kTimeout = 500, kGoalMark = 2;
+    static constexpr int kTimeout = 500, kGoalMark = 2;
+    int W = 25, H = 25, visible_ = 25;  // tilemap.cpp:31-48
+    bool centred_ = false;
 
     int dump_state(float* out, int cap) const override {
-        float v[8] = {a_pos.x, a_pos.y, static_cast<float>(a_forward), goal_pos.x, goal_pos.y,
-                      static_cast<float>(steps_), static_cast<float>(floor_), floor_shift_};
-        int n = std::min(cap, 8);
+        float v[10] = {a_pos.x, a_pos.y, static_cast<float>(a_forward), goal_pos.x, goal_pos.y,
+                       static_cast<float>(steps_), static_cast<float>(floor_), floor_shift_, painter_.cam_pos.x,
+                       painter_.cam_pos.y};
+        int n = std::min(cap, 10);
         std::memcpy(out, v, n * sizeof(float));
-        return 8;
+        return 10;
     }
     int dump_tiles(uint8_t* out, int cap) const override {
         int n = std::min<int>(cap, W * H);
@@ -125,6 +129,14 @@ class Maze final : public Env {
 
    protected:
     void on_make() override {
+        if (mode_ == kMemory) {
+            W = H = 31;
+            visible_ = 8;
+            centred_ = true;
+        } else if (mode_ == kEasy) {
+            W = H = visible_ = 15;
+        }
+        tiles_.assign(W * H, kWall);
         auto& bank = TextureBank::global();
         tex_wall_ = bank.find("assets/kenney/Ground/Sand/sandCenter.png");
         tex_cheese_ = bank.find("assets/misc_assets/cheese.png");
@@ -193,6 +205,7 @@ class Maze final : public Env {
         Box body{a_pos.x - 0.5f, a_pos.y - 0.5f, 1.0f, 1.0f};
         Box goal{goal_pos.x - 0.5f, goal_pos.y - 0.5f, 1.0f, 1.0f};
         bool reached = boxes_touch(body, goal);
+        if (centred_) painter_.cam_pos = {a_pos.x * kUnitPx, a_pos.y * kUnitPx};  // common_systems.cpp:119-123
         if (mx > 0.0f)
             a_forward = true;
         else if (mx < 0.0f)
@@ -207,7 +220,7 @@ class Maze final : public Env {
 
     void paint() override {  // maze.cpp:386-414
         painter_.target->clear_black();
-        float zoom = static_cast<float>(view_w_) / (kUnitPx * static_cast<float>(25));
+        float zoom = static_cast<float>(view_w_) / (kUnitPx * static_cast<float>(visible_));
         painter_.cam_scale = zoom;
         painter_.cam_size = {static_cast<float>(view_w_), static_cast<float>(view_h_)};
 
@@ -244,7 +257,7 @@ class Maze final : public Env {
     }
 
    private:
-    std::vector<uint8_t> tiles_ = std::vector<uint8_t>(W * H, kWall);
+    std::vector<uint8_t> tiles_;
     IdPool ids_;
     IdSet in_sprite_, in_goal_, in_agent_, in_tilemap_;
     V2 a_pos, goal_pos;

@@ -116,7 +116,8 @@ struct Variant {
 };
 static const Variant kVariants[] = {
     {kGameCoinrun, PGV_MODE_HARD, make_coinrun_v0},     {kGameCoinrun, PGV_MODE_EASY, make_coinrun_v0},
-    {kGameMaze, PGV_MODE_HARD, make_maze_v0},
+    {kGameMaze, PGV_MODE_HARD, make_maze_v0},           {kGameMaze, PGV_MODE_EASY, make_maze_v1},
+    {kGameMaze, PGV_MODE_MEMORY, make_maze_v2},
     {kGameBossfight, PGV_MODE_HARD, make_bossfight_v0}, {kGameBossfight, PGV_MODE_EASY, make_bossfight_v1},
     {kGameClimber, PGV_MODE_HARD, make_climber_v0},     {kGameClimber, PGV_MODE_EASY, make_climber_v1},
     {kGameCaveflyer, PGV_MODE_HARD, make_caveflyer_v0},

@@ -4,7 +4,8 @@
 //   step   games/maze/maze.cpp:279-330, common_systems.cpp:69-136
 //   render games/maze/maze.cpp:386-414, tilemap.cpp:111-133, common_systems.cpp:41-63,138-150
 //   reset  games/maze/maze.cpp:416-438, tilemap.cpp:31-109, maze_generator.cpp:55-139,183-195
-// Config = the reference's compile-time default, hard_mode: 25×25 world, all visible, fixed camera
+// Config: one compiled variant per distribution mode (below); variant 0 = the reference's compile-time default,
+// hard_mode: 25×25 world, all visible, fixed camera
 // (maze/tilemap.h:40-42, tilemap.cpp:35-38).
 // Machine mapping: logic one lane per env (SoA across envs), render one wave per env, level generation one wave per
 // env on LDS.  The game draws no random numbers during an episode and every episode ends within 500 steps, so
@@ -22,14 +23,27 @@ namespace pg {
 namespace PG_VARIANT_NS {
 namespace maze {
 
-constexpr int W = 25, H = 25, kCells = W * H;
-constexpr int kTileStride = 640;  // 625 padded to a 128-byte multiple
+// tilemap.cpp:31-48: world side, visible side (the zoom, maze.cpp:397), camera on the agent or on the world centre
+#if PG_VARIANT == 0  // hard_mode — the reference's compile-time default (tilemap.h:41)
+constexpr int W = 25, kVisible = 25;
+constexpr bool kCentred = false;
+#elif PG_VARIANT == 1  // easy_mode
+constexpr int W = 15, kVisible = 15;
+constexpr bool kCentred = false;
+#elif PG_VARIANT == 2  // memory_mode
+constexpr int W = 31, kVisible = 8;
+constexpr bool kCentred = true;
+#else
+#error "maze: unknown PG_VARIANT"
+#endif
+constexpr int H = W, kCells = W * H;
+constexpr int kTileStride = (kCells + 127) / 128 * 128;  // 625 → 640
 constexpr int kTimeout = 500;     // maze.cpp:49
 enum Cell : uint8_t { kOpen = 0, kWall = 1 };
 
 enum Tex { kTexWall = 0, kTexCheese = 1, kTexMouse = 2, kTexFloor = 3, kTexCount = 12 };
 
-enum { F_AX, F_AY, F_GX, F_GY, F_BGSHIFT, F_COUNT };
+enum { F_AX, F_AY, F_GX, F_GY, F_BGSHIFT, F_CAMX, F_CAMY, F_COUNT };
 enum { I_FLAGS, I_STEPS, I_BG, I_COUNT };
 constexpr int kFlagForward = 1, kFlagListed = 2;
 
@@ -45,7 +59,7 @@ struct State {
     Level* shadow;   // [n]  next level of each env (pg_prefetch.h)
     int32_t* slot;   // [n]  SlotState
     uint32_t* mt;    // [n][625]  generator chain: the stream position after the newest generated level
-    uint8_t* tiles;  // [n][640], column-major y + x*H
+    uint8_t* tiles;  // [n][kTileStride], column-major y + x*H
     float* f;        // [F_COUNT][n]
     int32_t* i;      // [I_COUNT][n]
 };
@@ -58,9 +72,10 @@ PG_D int tile_at(const uint8_t* t, int x, int y) {
     return t[y + x * H];
 }
 
+using MazeLds = KruskalLdsT<(W > 25 ? W : 25)>;
 struct GenLds {
     uint32_t mt[kMtWords];
-    KruskalLds k;
+    MazeLds k;
 };
 
 // reset() (maze.cpp:416-438 + tilemap.cpp:31-109) for one env by one wavefront: advances the env's generator chain
@@ -77,7 +92,7 @@ PG_D void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, u
     uint32_t* mt = L.mt;
     const int dim = wave_rng_int(mt, 0, (W - 1) / 2 - 1, lane) * 2 + 3;
     const int margin = (W - dim) / 2;
-    Carver carver{L.k, 0, 0, 0, 0};
+    CarverT<MazeLds> carver{L.k, 0, 0, 0, 0};
     carver.carve(dim, mt, lane);
     carver.drop(2, mt, lane);
     for (int c = lane; c < dim * dim; c += 64) {
@@ -116,6 +131,8 @@ PG_D void install(const State& s, int env, const Level& lv, int lane) {
         SI(s, I_BG, env) = lv.bg;
         SF(s, F_BGSHIFT, env) = lv.bgshift;
         SI(s, I_FLAGS, env) = kFlagForward;  // face_forward = true; draw list cleared (D2)
+        SF(s, F_CAMX, env) = W * 0.5f * kUnitPx;  // maze.cpp:436-437
+        SF(s, F_CAMY, env) = H * 0.5f * kUnitPx;
     }
 }
 
@@ -163,6 +180,10 @@ PG_D void advance(const State& s, int env, int action, float& reward_out, bool& 
     const int steps = SI(s, I_STEPS, env) + 1;
     SF(s, F_AX, env) = ax;
     SF(s, F_AY, env) = ay;
+    if (kCentred) {  // common_systems.cpp:119-123: the camera follows the agent
+        SF(s, F_CAMX, env) = ax * kUnitPx;
+        SF(s, F_CAMY, env) = ay * kUnitPx;
+    }
     SI(s, I_FLAGS, env) = flags;
     SI(s, I_STEPS, env) = steps;
     reward_out = reached * 10.0f;
@@ -195,12 +216,12 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
     const int lane = threadIdx.x & 63, half = threadIdx.x >> 6;  // two wavefronts per env (pg_render.h)
     constexpr int halves = 2;
     __shared__ uint32_t fb[kFbWords];
-    constexpr int kGrid = 32;  // 25 visible tiles + the border cells of the inclusive window
+    constexpr int kGrid = 32;  // ≤ 25 visible tiles + the border cells of the inclusive window
     __shared__ ComposeLds<kGrid> L;
 
-    // maze.cpp:397-400, 436-437: zoom = 64 / (16 * visible_width), camera at the world centre.
-    const float zoom = 64.0f / (kUnitPx * 25.0f);
-    const Camera cam{W * 0.5f * kUnitPx, H * 0.5f * kUnitPx, 64.0f, 64.0f, zoom};
+    // maze.cpp:397-400, 436-437: zoom = 64 / (16 * visible_width); camera at the world centre, or on the agent
+    const float zoom = 64.0f / (kUnitPx * static_cast<float>(kVisible));
+    const Camera cam{SF(s, F_CAMX, env), SF(s, F_CAMY, env), 64.0f, 64.0f, zoom};
     const int sflags = SI(s, I_FLAGS, env);
     const uint8_t* tiles = s.tiles + size_t(env) * kTileStride;
     Blit mine;
@@ -273,8 +294,8 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
 // cenv_render's frame (render_game(false)) for one env: pg_frame.h; the draw list of render_kernel, one draw at a time.
 __global__ void __launch_bounds__(kFrameThreads) frame_kernel(State s, AtlasView atlas, int env, FrameTarget t) {
     const float fw = static_cast<float>(t.w), fh = static_cast<float>(t.h);
-    const float zoom = fw / (kUnitPx * 25.0f);  // maze.cpp:397-400
-    FramePainter P{t, atlas, Camera{W * 0.5f * kUnitPx, H * 0.5f * kUnitPx, fw, fh, zoom}, static_cast<int>(threadIdx.x),
+    const float zoom = fw / (kUnitPx * static_cast<float>(kVisible));  // maze.cpp:397-400
+    FramePainter P{t, atlas, Camera{SF(s, F_CAMX, env), SF(s, F_CAMY, env), fw, fh, zoom}, static_cast<int>(threadIdx.x),
                    kFrameThreads};
     const int sflags = SI(s, I_FLAGS, env);
     const uint8_t* tiles = s.tiles + size_t(env) * kTileStride;
@@ -369,10 +390,11 @@ class MazeGame final : public Game {
             hipMemcpy(&v, s_.i + size_t(field) * s_.n + env, 4, hipMemcpyDeviceToHost);
             return v;
         };
-        const float v[8] = {f(F_AX), f(F_AY), (iv(I_FLAGS) & kFlagForward) ? 1.0f : 0.0f, f(F_GX), f(F_GY),
-                            static_cast<float>(iv(I_STEPS)), static_cast<float>(iv(I_BG)), f(F_BGSHIFT)};
-        for (int k = 0; k < 8 && k < cap; k++) out[k] = v[k];
-        return 8;
+        const float v[10] = {f(F_AX), f(F_AY), (iv(I_FLAGS) & kFlagForward) ? 1.0f : 0.0f, f(F_GX), f(F_GY),
+                             static_cast<float>(iv(I_STEPS)), static_cast<float>(iv(I_BG)), f(F_BGSHIFT), f(F_CAMX),
+                             f(F_CAMY)};
+        for (int k = 0; k < 10 && k < cap; k++) out[k] = v[k];
+        return 10;
     }
     int dump_tiles(hipStream_t st, int env, uint8_t* out, int cap) override {
         hipStreamSynchronize(st);

@@ -111,6 +111,8 @@ inline int logic_blocks(int n) { return (n + logic_lanes() - 1) / logic_lanes();
 // Factories, one per compiled variant of a game (pg_defs.h PG_VARIANT; v0 = the reference's compile-time default).
 std::unique_ptr<Game> make_coinrun_v0();
 std::unique_ptr<Game> make_maze_v0();
+std::unique_ptr<Game> make_maze_v1();
+std::unique_ptr<Game> make_maze_v2();
 std::unique_ptr<Game> make_bossfight_v0();
 std::unique_ptr<Game> make_bossfight_v1();
 std::unique_ptr<Game> make_climber_v0();

@@ -14,21 +14,26 @@ namespace pg {
 // Randomised Kruskal with union by rank + path halving over a 1-cell padded grid (maze_generator.cpp:55-139), on
 // LDS.  The reference erases the drawn wall from a std::vector (`walls.erase(walls.begin() + n)`), i.e. the draw
 // selects the n-th wall still present in construction order: kept here as a 320-bit presence mask and a
-// select-the-n-th-set-bit, instead of moving the tail of the array 312 times.
-struct KruskalLds {
-    static constexpr int kMaxDim = 25, kPadDim = kMaxDim + 2;
-    uint64_t present[5];
+// select-the-n-th-set-bit, instead of moving the tail of the array 312 times.  MAXDIM = the largest (odd) maze side.
+template <int MAXDIM>
+struct KruskalLdsT {
+    static constexpr int kMaxDim = MAXDIM, kPadDim = kMaxDim + 2;
+    static constexpr int kMaxSegs = 2 * (kMaxDim / 2) * ((kMaxDim + 1) / 2);  // 312 walls between cells at 25×25
+    static constexpr int kPresentWords = (kMaxSegs + 63) / 64;
+    uint64_t present[kPresentWords];
     uint8_t grid[kPadDim * kPadDim + 3];
     uint8_t rank[kMaxDim * kMaxDim + 3];
     int16_t parent[kMaxDim * kMaxDim + 1];
     int16_t open_cells[kPadDim * kPadDim + 1];
     uint8_t seen[kMaxDim * kMaxDim + 3];
-    uint8_t segs[312][4];  // walls between cells, 2 * 12 * 13 for a 25×25 maze
+    uint8_t segs[kMaxSegs][4];
     int32_t n_open, drop_cell;
 };
+using KruskalLds = KruskalLdsT<25>;
 
-struct Carver {
-    KruskalLds& L;
+template <class LDS>
+struct CarverT {
+    LDS& L;
     int mw, mh, aw, ah;
 
     PG_D int idx(int x, int y) const { return y + ah * x; }
@@ -99,7 +104,7 @@ struct Carver {
                         L.segs[n_segs][3] = static_cast<uint8_t>(b + 1);
                         n_segs++;
                     }
-            for (int w = 0; w < 5; w++) {
+            for (int w = 0; w < LDS::kPresentWords; w++) {
                 const int left = n_segs - 64 * w;
                 L.present[w] = left >= 64 ? ~0ull : (left > 0 ? ((1ull << left) - 1ull) : 0ull);
             }
@@ -147,5 +152,6 @@ struct Carver {
         __syncthreads();
     }
 };
+using Carver = CarverT<KruskalLds>;
 
 }  // namespace pg

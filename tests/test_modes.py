@@ -14,7 +14,7 @@ EASY, HARD, MEMORY, EXTREME = 1, 2, 3, 4
 # game → (default, every mode it offers)
 TABLE = {
     "coinrun": (HARD, {EASY, HARD}),
-    "maze": (HARD, {HARD}),
+    "maze": (HARD, {EASY, HARD, MEMORY}),
     "bossfight": (HARD, {EASY, HARD}),
     "climber": (HARD, {EASY, HARD}),
     "caveflyer": (HARD, {HARD}),
