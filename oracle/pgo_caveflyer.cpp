@@ -48,7 +48,7 @@ struct Hit {
 
 class Caveflyer final : public Env {
    public:
-    static constexpr int W = 40, H = 40;
+    int W = 40, H = 40;  // tilemap.cpp world_dim: hard 40 (the default), easy 20
     enum Tile : uint8_t { kEmpty = 0, kWall = 1, kMarker = 2 };
 
     int dump_state(float* out, int cap) const override {
@@ -88,6 +88,8 @@ class Caveflyer final : public Env {
 
    protected:
     void on_make() override {
+        if (mode_ == kEasy) W = H = 20;  // tilemap.cpp: world_dim by Distribution_Mode (memory_mode 45 is not built)
+        tiles_.assign(W * H, 0);
         auto& bank = TextureBank::global();
         auto T = [&](const std::string& n) { return bank.find("assets/" + n + ".png"); };
         for (int i = 0; i < 13; i++) tex_space_[i] = T(std::string("space_backgrounds/") + kSpace[i]);
@@ -500,7 +502,7 @@ class Caveflyer final : public Env {
     }
 
    private:
-    std::vector<uint8_t> tiles_ = std::vector<uint8_t>(W * H, 0);
+    std::vector<uint8_t> tiles_;
     std::vector<Thing> things_ = std::vector<Thing>(IdPool::kMax);
     int n_things_ = 0;
     int goal_id_ = 0;

@@ -57,7 +57,7 @@ struct Puff {  // common_components.h:54-57
 
 class Jumper final : public Env {
    public:
-    static constexpr int W = 40, H = 40;
+    int W = 40, H = 40;  // tilemap.cpp world_dim: hard 40 (the default), easy 20
     enum Tile : uint8_t { kEmpty = 0, kWallTop = 1, kWallMid = 2, kSpike = 3 };  // tilemap.h:19-26
 
     int dump_state(float* out, int cap) const override {
@@ -88,6 +88,8 @@ class Jumper final : public Env {
 
    protected:
     void on_make() override {
+        if (mode_ == kEasy) W = H = 20;  // tilemap.cpp: world_dim by Distribution_Mode (memory_mode 45 is not built)
+        tiles_.assign(W * H, 0);
         auto& bank = TextureBank::global();
         auto T = [&](const std::string& n) { return bank.find("assets/" + n + ".png"); };
         for (int i = 0; i < 49; i++) tex_backdrop_[i] = T(kBackdrops[i]);
@@ -515,7 +517,7 @@ class Jumper final : public Env {
     }
 
    private:
-    std::vector<uint8_t> tiles_ = std::vector<uint8_t>(W * H, 0);
+    std::vector<uint8_t> tiles_;
     std::vector<V2> spikes_;  // entity id − 2
     IdPool ids_;
     IdSet in_sprite_;

@@ -26,6 +26,16 @@
 #include "pg_prefetch.h"
 #include "pg_render.h"
 #include "pg_rng.h"
+#include "pg_defs.h"
+// caveflyer/tilemap.cpp: world_dim by Distribution_Mode — hard_mode 40 (the reference's compile-time default, tilemap.h),
+// easy_mode 20.  memory_mode (45, no pruning) is not built.
+#if PG_VARIANT == 0
+#define PG_ROOMS_DIM 40
+#elif PG_VARIANT == 1
+#define PG_ROOMS_DIM 20
+#else
+#error "caveflyer: unknown PG_VARIANT"
+#endif
 #include "pg_rooms.h"
 #include "pg_sincos.h"
 #include "pg_tiles.h"
@@ -34,7 +44,8 @@ namespace pg {
 namespace PG_VARIANT_NS {
 namespace caveflyer {
 
-constexpr int W = 40, H = 40, kCells = W * H;
+constexpr int W = rooms::W, H = rooms::H, kCells = W * H;
+static_assert(kCells % 4 == 0, "tiles are copied as 32-bit words");
 constexpr int kMaxEnt = 62;  // ids: 0 goal, 1 ship, 2.. objects; 3·(free/80) ≤ 60 objects (tilemap.cpp:232-233)
 constexpr int kShots = 32, kPuffs = 10;
 constexpr double kPi = 3.14159265358979323846;  // M_PI
@@ -77,7 +88,7 @@ struct State {
     Level* shadow;   // [n]  next level of each env (pg_prefetch.h)
     int32_t* slot;   // [n]  SlotState
     uint32_t* mt;    // [n][625]  generator chain: the stream position after the newest generated level
-    uint8_t* tiles;  // [n][1600]  column-major y + x*H
+    uint8_t* tiles;  // [n][kCells]  column-major y + x*H
     float* f;        // [F_COUNT][n]
     int32_t* i;      // [I_COUNT][n]
     float* ef;       // [EF_COUNT][kMaxEnt][n]
@@ -170,7 +181,7 @@ PG_D void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, u
     // lane 0 owns the random stream, lane j remembers the j-th picked index so that "already taken?" is one ballot.
     int n_free = 0;
     for (int c0 = 0; c0 < kCells; c0 += 64) {
-        const bool open = L.aux[c0 + lane] >= 2;
+        const bool open = c0 + lane < kCells && L.aux[c0 + lane] >= 2;
         const unsigned long long m = __ballot(open);
         if (open) L.cells[n_free + __popcll(m & ((1ull << lane) - 1ull))] = static_cast<int16_t>(c0 + lane);
         n_free += __popcll(m);

@@ -120,9 +120,9 @@ static const Variant kVariants[] = {
     {kGameMaze, PGV_MODE_MEMORY, make_maze_v2},
     {kGameBossfight, PGV_MODE_HARD, make_bossfight_v0}, {kGameBossfight, PGV_MODE_EASY, make_bossfight_v1},
     {kGameClimber, PGV_MODE_HARD, make_climber_v0},     {kGameClimber, PGV_MODE_EASY, make_climber_v1},
-    {kGameCaveflyer, PGV_MODE_HARD, make_caveflyer_v0},
+    {kGameCaveflyer, PGV_MODE_HARD, make_caveflyer_v0}, {kGameCaveflyer, PGV_MODE_EASY, make_caveflyer_v1},
     {kGameChaser, PGV_MODE_EASY, make_chaser_v0},
-    {kGameJumper, PGV_MODE_HARD, make_jumper_v0},
+    {kGameJumper, PGV_MODE_HARD, make_jumper_v0},       {kGameJumper, PGV_MODE_EASY, make_jumper_v1},
 };
 
 static const Variant* find_variant(int game, int mode) {

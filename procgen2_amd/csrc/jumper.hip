@@ -21,6 +21,16 @@
 #include "pg_prefetch.h"
 #include "pg_render.h"
 #include "pg_rng.h"
+#include "pg_defs.h"
+// jumper/tilemap.cpp: world_dim by Distribution_Mode — hard_mode 40 (the reference's compile-time default, tilemap.h),
+// easy_mode 20.  memory_mode (45, no pruning) is not built.
+#if PG_VARIANT == 0
+#define PG_ROOMS_DIM 40
+#elif PG_VARIANT == 1
+#define PG_ROOMS_DIM 20
+#else
+#error "jumper: unknown PG_VARIANT"
+#endif
 #include "pg_rooms.h"
 #include "pg_tiles.h"
 
@@ -28,7 +38,8 @@ namespace pg {
 namespace PG_VARIANT_NS {
 namespace jumper {
 
-constexpr int W = 40, H = 40, kCells = W * H;
+constexpr int W = rooms::W, H = rooms::H, kCells = W * H;
+static_assert(kCells % 4 == 0, "tiles are copied as 32-bit words");
 constexpr int kMaxSpikes = 126;             // entity ids: 0 carrot, 1 bunny, 2.. spikes
 constexpr int kMaxSprites = kMaxSpikes + 1;  // carrot + spikes
 constexpr int kPuffs = 10;
@@ -81,7 +92,7 @@ struct State {
     Level* shadow;   // [n]  next level of each env
     int32_t* slot;   // [n]  SlotState
     uint32_t* mt;    // [n][625]  generator chain
-    uint8_t* tiles;  // [n][1600]  column-major y + x*H
+    uint8_t* tiles;  // [n][kCells]  column-major y + x*H
     float* f;        // [F_COUNT][n]
     int32_t* i;      // [I_COUNT][n]
     float* pf;       // [PF_COUNT][kPuffs][n]
@@ -168,7 +179,7 @@ PG_D void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, u
     }
     __syncthreads();
     uint32_t* mt = R.mt;
-    // tilemap.cpp:95-123: 13×13 maze without dead ends, blown up ×3 with noise
+    // tilemap.cpp:95-123: a (W/3)² maze (13×13 by default) without dead ends, blown up ×3 with noise
     constexpr int kScale = 3, kDim = W / kScale;
     Carver carver{L.k, 0, 0, 0, 0};
     carver.carve(kDim, mt, lane);
@@ -285,8 +296,9 @@ PG_D void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, u
     int n_spikes = 0;
     for (int c0 = 0; c0 < kCells; c0 += 64) {
         const int c = c0 + lane;
-        const int x = c / H, y = c % H;
-        const bool was_spike = lv.tiles[c] == kSpike;
+        const bool inside = c < kCells;
+        const int x = inside ? c / H : 0, y = inside ? c % H : 0;
+        const bool was_spike = inside && lv.tiles[c] == kSpike;
         const bool mid = (L.mid[x + 1] >> y) & 1ull;
         // is_top_wall: wall_mid with an empty cell above; the spike tiles have turned back into empty cells by then
         const bool empty_above = y + 1 < H && !((L.mid[x + 1] >> (y + 1)) & 1ull);
@@ -298,7 +310,7 @@ PG_D void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, u
         }
         n_spikes += __popcll(m);
         __syncthreads();
-        lv.tiles[c] = mid ? (empty_above ? kWallTop : kWallMid) : kEmpty;
+        if (inside) lv.tiles[c] = mid ? (empty_above ? kWallTop : kWallMid) : kEmpty;
     }
     if (n_spikes > kMaxSpikes) __builtin_trap();  // far beyond anything the generator produces
     __syncthreads();

@@ -118,8 +118,10 @@ std::unique_ptr<Game> make_bossfight_v1();
 std::unique_ptr<Game> make_climber_v0();
 std::unique_ptr<Game> make_climber_v1();
 std::unique_ptr<Game> make_caveflyer_v0();
+std::unique_ptr<Game> make_caveflyer_v1();
 std::unique_ptr<Game> make_chaser_v0();
 std::unique_ptr<Game> make_jumper_v0();
+std::unique_ptr<Game> make_jumper_v1();
 
 // Counter-based synthetic action shared with the oracle (oracle/pgo_api.cpp pgo_synthetic_action).
 PG_HD uint32_t mix32(uint32_t x) {

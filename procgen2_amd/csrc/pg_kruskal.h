@@ -18,7 +18,7 @@ namespace pg {
 template <int MAXDIM>
 struct KruskalLdsT {
     static constexpr int kMaxDim = MAXDIM, kPadDim = kMaxDim + 2;
-    static constexpr int kMaxSegs = 2 * (kMaxDim / 2) * ((kMaxDim + 1) / 2);  // 312 walls between cells at 25×25
+    static constexpr int kMaxSegs = 2 * ((kMaxDim - 1) / 2) * ((kMaxDim + 1) / 2);  // 312 walls between cells at 25×25
     static constexpr int kPresentWords = (kMaxSegs + 63) / 64;
     uint64_t present[kPresentWords];
     uint8_t grid[kPadDim * kPadDim + 3];
@@ -109,7 +109,7 @@ struct CarverT {
                 L.present[w] = left >= 64 ? ~0ull : (left > 0 ? ((1ull << left) - 1ull) : 0ull);
             }
         }
-        n_segs = (dim / 2) * ((dim + 1) / 2) * 2;  // (dim odd) both loops: (dim-1)/2 · (dim+1)/2 walls
+        n_segs = ((dim - 1) / 2) * ((dim + 1) / 2) * 2;  // both loops: odd a in [1, dim-2] × even b in [0, dim-1]
         __syncthreads();
         for (; n_segs > 0; n_segs--) {
             const int pick = wave_rng_int(mt, 0, n_segs - 1, lane);

@@ -1,5 +1,5 @@
 // Room_Generator on the device, shared by caveflyer and jumper (games/caveflyer/room_generator.{h,cpp}; jumper's copy
-// is identical): a 40×40 cellular-automaton cave, its largest 4-connected room in the iteration order of the
+// is identical): a W×W (40×40 by default) cellular-automaton cave, its largest 4-connected room in the iteration order of the
 // reference's std::unordered_set<int>, the BFS path between two cells.  One wavefront per level, all state in LDS.
 //
 // What is serial in the reference and what is done about it:
@@ -15,10 +15,16 @@
 #include "pg_rng.h"
 #include "pg_setorder.h"
 
+// World side: the including game defines PG_ROOMS_DIM per distribution mode (pg_defs.h PG_VARIANT) before this header.
+#ifndef PG_ROOMS_DIM
+#define PG_ROOMS_DIM 40
+#endif
+
 namespace pg {
+namespace PG_VARIANT_NS {
 namespace rooms {
 
-constexpr int W = 40, H = 40, kCells = W * H;
+constexpr int W = PG_ROOMS_DIM, H = PG_ROOMS_DIM, kCells = W * H;
 
 struct RoomsLds {
     uint32_t mt[kMtWords];
@@ -237,4 +243,5 @@ PG_D void widen(RoomsLds& L, int lane) {
 }
 
 }  // namespace rooms
+}  // namespace PG_VARIANT_NS
 }  // namespace pg

@@ -17,9 +17,9 @@ TABLE = {
     "maze": (HARD, {EASY, HARD, MEMORY}),
     "bossfight": (HARD, {EASY, HARD}),
     "climber": (HARD, {EASY, HARD}),
-    "caveflyer": (HARD, {HARD}),
+    "caveflyer": (HARD, {EASY, HARD}),
     "chaser": (EASY, {EASY}),
-    "jumper": (HARD, {HARD}),
+    "jumper": (HARD, {EASY, HARD}),
 }
 NON_DEFAULT = sorted((g, m) for g, (d, ms) in TABLE.items() for m in ms if m != d)
 
