@@ -43,7 +43,7 @@ int sign(float x) {  // helpers.h:31-36
 
 class Chaser final : public Env {
    public:
-    static constexpr int W = 11, H = 11;
+    int W = 11, H = 11, total_enemies_ = 3, extra_orb_sign_ = 0;  // tilemap.cpp:85-99, easy_mode is the default
     enum Tile : uint8_t { kEmpty = 0, kWall = 1, kMarker = 2 };
 
     int dump_state(float* out, int cap) const override {
@@ -73,6 +73,15 @@ class Chaser final : public Env {
 
    protected:
     void on_make() override {
+        if (mode_ == kHard) {  // tilemap.cpp:85-94
+            W = H = 13;
+            extra_orb_sign_ = -1;
+        } else if (mode_ == kExtreme) {
+            W = H = 19;
+            total_enemies_ = 5;
+            extra_orb_sign_ = 1;
+        }
+        tiles_.assign(W * H, 0);
         auto& bank = TextureBank::global();
         auto T = [&](const std::string& n) { return bank.find("assets/" + n + ".png"); };
         for (int i = 0; i < 9; i++) tex_floor_[i] = T(std::string("topdown_backgrounds/") + kFloors[i]);
@@ -152,7 +161,7 @@ class Chaser final : public Env {
         n_things_ = 0;
 
         // tilemap.cpp:80-243
-        const int total_enemies = 3, extra_orb_sign = 0;
+        const int total_enemies = total_enemies_, extra_orb_sign = extra_orb_sign_;
         std::fill(tiles_.begin(), tiles_.end(), static_cast<uint8_t>(kEmpty));
         std::vector<int> grid;
         carve(W, grid);
@@ -465,7 +474,7 @@ class Chaser final : public Env {
     }
 
    private:
-    std::vector<uint8_t> tiles_ = std::vector<uint8_t>(W * H, 0);
+    std::vector<uint8_t> tiles_;
     std::vector<Thing> things_ = std::vector<Thing>(IdPool::kMax);
     std::vector<int> free_cells_;
     int n_things_ = 0;

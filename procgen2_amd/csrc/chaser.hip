@@ -29,9 +29,24 @@ namespace pg {
 namespace PG_VARIANT_NS {
 namespace chaser {
 
-constexpr int W = 11, H = 11, kCells = W * H, kTileStride = 128;
-constexpr int kMobs = 3, kOrbs = 4, kFirstPoint = kOrbs + kMobs;
-constexpr int kMaxEnt = 72;  // 4 orbs + 3 eggs + ≤ 63 points (71 open cells − 4 − 1 − 3)
+// tilemap.cpp:85-99: world side, enemies, and the orb count of one random quadrant (1 + extra_orb_sign)
+#if PG_VARIANT == 0  // easy_mode — the reference's compile-time default (tilemap.h:40)
+constexpr int W = 11, kMobs = 3, kExtraOrbSign = 0;
+#elif PG_VARIANT == 1  // hard_mode
+constexpr int W = 13, kMobs = 3, kExtraOrbSign = -1;
+#elif PG_VARIANT == 2  // extreme_mode
+constexpr int W = 19, kMobs = 5, kExtraOrbSign = 1;
+#else
+#error "chaser: unknown PG_VARIANT"
+#endif
+constexpr int H = W, kCells = W * H, kTileStride = (kCells + 127) / 128 * 128;
+constexpr int kOrbs = 4 + kExtraOrbSign, kFirstPoint = kOrbs + kMobs;
+// a perfect maze on the even-even cells of an odd side has 2·((W+1)/2)² − 1 open cells (71 at 11×11); every one of
+// them but the agent's holds an entity: orbs, eggs, and a point on the rest
+constexpr int kOpenCells = 2 * ((W + 1) / 2) * ((W + 1) / 2) - 1;
+constexpr int kMaxEnt = (kOpenCells - 1 + 7) / 8 * 8;
+constexpr bool kWideCells = kCells > 256;  // cell indices need a second byte
+static_assert(kMaxEnt <= 255 && kMaxEnt <= kRankMax, "entity ids are bytes; draw lists use the equal-key rank table");
 enum Tile : uint8_t { kEmpty = 0, kWall = 1, kMarker = 2 };
 enum Kind { kOrb = 0, kPoint = 1, kEgg = 2 };
 
@@ -49,7 +64,7 @@ enum { F_AX, F_AY, F_AVX, F_AVY, F_NVX, F_NVY, F_INPUT_T, F_ANIM_T, F_EAT_T, F_B
 enum { I_FLAGS, I_ANIM_I, I_BG, I_NENT, I_NDRAW, I_HASH_SPRITE, I_HASH_MOB, I_COUNT };
 constexpr int kFlagListed = 1;
 enum { MF_X, MF_Y, MF_VX, MF_VY, MF_HATCH, MF_COUNT };
-enum { EB_INFO, EB_CELL, EB_ORDER, EB_DRAW, EB_COUNT };
+enum { EB_INFO, EB_CELL, EB_ORDER, EB_DRAW, EB_CELL_HI, EB_COUNT };
 constexpr int kKindMask = 3, kAlive = 4;
 
 // One generated level (LDS → live state; the shadow slots stay unused in this game).
@@ -57,16 +72,18 @@ struct Level {
     uint8_t tiles[kTileStride];
     float ax, ay, bgshift;
     int32_t bg, n_ent;
-    uint8_t cell[kMaxEnt], order[kMaxEnt];
-    uint8_t mob_order[4];
+    uint16_t cell[kMaxEnt];
+    uint8_t order[kMaxEnt];
+    uint8_t mob_order[8];
 };
+static_assert(sizeof(Level) % 4 == 0, "Level is copied as 32-bit words");
 
 struct GenLds {
     uint32_t mt[kMtWords];
     KruskalLds k;
-    int32_t touch[260], chain[260], tail_sum[132];  // pg_setorder.h scratch (≤ 257 buckets, ≤ 128 keys)
-    int16_t link[128], tmp[128], keys[128];
-    uint8_t free_cells[kCells + 7];
+    int32_t touch[260], chain[260], tail_sum[kMaxEnt + 4];  // pg_setorder.h scratch (≤ 257 buckets, ≤ kMaxEnt keys)
+    int16_t link[kMaxEnt], tmp[kMaxEnt], keys[kMaxEnt];
+    uint16_t free_cells[kCells + 7];
 };
 
 struct State {
@@ -88,6 +105,11 @@ PG_D int32_t& SI(const State& s, int field, int env) { return s.i[size_t(field) 
 PG_D float& MF(const State& s, int field, int m, int env) { return s.mf[(size_t(field) * kMobs + m) * s.n + env]; }
 PG_D uint8_t& MB(const State& s, int field, int m, int env) { return s.mb[(size_t(field) * kMobs + m) * s.n + env]; }
 PG_D uint8_t& EB(const State& s, int field, int e, int env) { return s.eb[(size_t(field) * kMaxEnt + e) * s.n + env]; }
+PG_D int ent_cell(const State& s, int e, int env) {
+    int c = EB(s, EB_CELL, e, env);
+    if (kWideCells) c |= EB(s, EB_CELL_HI, e, env) << 8;
+    return c;
+}
 
 PG_D int tile_at(const uint8_t* t, int x, int y) {  // tilemap.h:79-84: out of bounds is neither empty nor wall
     if (x < 0 || y < 0 || x >= W || y >= H) return -1;
@@ -119,34 +141,50 @@ PG_D void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, u
     uint32_t* mt = L.mt;
     Carver carver{L.k, 0, 0, 0, 0};
     carver.carve(W, mt, lane);
-    wave_rng_int(mt, 0, 3, lane);  // extra_quad: drawn, without effect in easy mode (extra_orb_sign = 0)
+    const int extra_quad = wave_rng_int(mt, 0, 3, lane);  // tilemap.cpp:121-122; without effect when the sign is 0
     for (int c = lane; c < kTileStride; c += 64) {
         const int x = c / H, y = c % H;
         lv.tiles[c] = (c < kCells && carver.get(x + 1, y + 1) == 0) ? kEmpty : kWall;
     }
     __syncthreads();
-    // one orb per quadrant (tilemap.cpp:121-170): the drawn-th open cell of the quadrant in x-major order
+    // orbs per quadrant (tilemap.cpp:124-170): 1, or 1 + extra_orb_sign in the extra quadrant; positions are drawn
+    // among the quadrant's open cells (x-major) with linear probing, collected in a fresh std::unordered_set<int> and
+    // spawned in ITS iteration order — for two elements always the second insertion first.
+    int n_orbs = 0;
     for (int q = 0; q < 4; q++) {
+        const int want = 1 + (q == extra_quad ? kExtraOrbSign : 0);
+        if (want == 0) continue;  // the distribution is constructed, nothing is drawn
         int count = 0;
         for (int c = 0; c < kCells; c++) {
             const int x = c / H, y = c % H;
             if (lv.tiles[c] != kWall && ((x >= W / 2) * 2 + (y >= H / 2)) == q) count++;  // markers were open cells
         }
-        const int pos = wave_rng_int(mt, 0, count - 1, lane);
+        int pos[2];
+        pos[0] = wave_rng_int(mt, 0, count - 1, lane);
+        pos[1] = -1;
+        if (want == 2) {
+            int p = wave_rng_int(mt, 0, count - 1, lane);
+            while (p == pos[0]) p = (p + 1) % count;
+            pos[1] = pos[0];  // iteration order: the second insertion, then the first
+            pos[0] = p;
+        }
         if (lane == 0) {
+            int cells_at[2] = {-1, -1};
             int seen = 0;
             for (int c = 0; c < kCells; c++) {
                 const int x = c / H, y = c % H;
                 if (lv.tiles[c] != kWall && ((x >= W / 2) * 2 + (y >= H / 2)) == q) {
-                    if (seen == pos) {
-                        lv.cell[q] = static_cast<uint8_t>(c);
-                        lv.tiles[c] = kMarker;
-                        break;
-                    }
+                    if (seen == pos[0]) cells_at[0] = c;
+                    if (seen == pos[1]) cells_at[1] = c;
                     seen++;
                 }
             }
+            for (int k = 0; k < want; k++) {
+                lv.cell[n_orbs + k] = static_cast<uint16_t>(cells_at[k]);
+                lv.tiles[cells_at[k]] = kMarker;
+            }
         }
+        n_orbs += want;
         __syncthreads();
     }
     // the agent's cell and the three eggs (tilemap.cpp:172-213): four distinct free cells, taken from a
@@ -154,11 +192,12 @@ PG_D void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, u
     int n_free = 0;
     for (int c = 0; c < kCells; c++)
         if (lv.tiles[c] == kEmpty) {
-            if (lane == 0) L.free_cells[n_free] = static_cast<uint8_t>(c);
+            if (lane == 0) L.free_cells[n_free] = static_cast<uint16_t>(c);
             n_free++;
         }
     __syncthreads();
-    uint8_t picked[4];
+    int16_t picked[kMobs + 1];
+#pragma unroll
     for (int j = 0; j < kMobs + 1; j++) {
         int pos = wave_rng_int(mt, 0, n_free - 1, lane);
         for (bool again = true; again;) {
@@ -170,7 +209,7 @@ PG_D void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, u
                     break;
                 }
         }
-        picked[j] = static_cast<uint8_t>(pos);
+        picked[j] = static_cast<int16_t>(pos);
     }
     if (lane == 0) {
 #pragma unroll
@@ -187,12 +226,12 @@ PG_D void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, u
         lv.ay = static_cast<float>(H - 1 - start % H) + 0.5f;
         for (int m = 0; m < kMobs; m++) {
             const int cell = L.free_cells[order[1 + m]];
-            lv.cell[kOrbs + m] = static_cast<uint8_t>(cell);
+            lv.cell[kOrbs + m] = static_cast<uint16_t>(cell);
             lv.tiles[cell] = kMarker;
         }
         int n_ent = kFirstPoint;  // a point on every cell still free (tilemap.cpp:215-225)
         for (int c = 0; c < kCells; c++)
-            if (lv.tiles[c] == kEmpty) lv.cell[n_ent++] = static_cast<uint8_t>(c);
+            if (lv.tiles[c] == kEmpty) lv.cell[n_ent++] = static_cast<uint16_t>(c);
         lv.n_ent = n_ent;
         for (int c = 0; c < kCells; c++)
             if (lv.tiles[c] == kMarker) lv.tiles[c] = kEmpty;
@@ -232,12 +271,13 @@ PG_D float cell_y(int cell) { return static_cast<float>(H - 1 - cell % H) + 0.5f
 PG_D void install(const State& s, int env, const Level& lv, int lane) {
     uint32_t* tiles = reinterpret_cast<uint32_t*>(s.tiles + size_t(env) * kTileStride);
     const uint32_t* src = reinterpret_cast<const uint32_t*>(lv.tiles);
-    if (lane < kTileStride / 4) tiles[lane] = src[lane];
+    for (int k = lane; k < kTileStride / 4; k += 64) tiles[k] = src[k];
     const int n_ent = lv.n_ent;
     for (int e = lane; e < n_ent; e += 64) {
         const int kind = e < kOrbs ? kOrb : (e < kFirstPoint ? kEgg : kPoint);
         EB(s, EB_INFO, e, env) = static_cast<uint8_t>(kind | kAlive);
-        EB(s, EB_CELL, e, env) = lv.cell[e];
+        EB(s, EB_CELL, e, env) = static_cast<uint8_t>(lv.cell[e] & 0xff);
+        if (kWideCells) EB(s, EB_CELL_HI, e, env) = static_cast<uint8_t>(lv.cell[e] >> 8);
         EB(s, EB_ORDER, e, env) = lv.order[e];
     }
     if (lane < kMobs) {
@@ -479,7 +519,7 @@ PG_D void advance(const State& s, int env, int action, float& reward_out, bool& 
                         } else {  // back to an egg on a random point cell, without the world-y flip (D16)
                             hatch = 0.0f;
                             const int n_free = n_ent - kFirstPoint;
-                            const int cell = EB(s, EB_CELL, kFirstPoint + rng_int(mt, 0, n_free - 1), env);
+                            const int cell = ent_cell(s, kFirstPoint + rng_int(mt, 0, n_free - 1), env);
                             px = cell / H + 0.5f;
                             py = cell % H + 0.5f;
                             tex = 0;
@@ -510,7 +550,7 @@ PG_D void advance(const State& s, int env, int action, float& reward_out, bool& 
             if (e >= kOrbs && e < kFirstPoint) continue;
             const int info = EB(s, EB_INFO, e, env);
             if (!(info & kAlive)) continue;
-            const int cell = EB(s, EB_CELL, e, env);
+            const int cell = ent_cell(s, e, env);
             const float x = cell_x(cell), y = cell_y(cell);
             const bool orb = e < kOrbs;
             const Box rect = orb ? Box{-0.5f + x, -0.5f + y, 1.0f, 1.0f} : Box{-0.3f + x, -0.3f + y, 0.6f, 0.6f};
@@ -576,7 +616,8 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
     const int lane = threadIdx.x & 63, half = threadIdx.x >> 6;  // two wavefronts per env (pg_render.h)
     constexpr int halves = 2;
     __shared__ uint32_t fb[kFbWords];
-    constexpr int kGrid = 16;  // 11 tiles + the border cells of the inclusive window
+    constexpr int kGrid = W + 2 <= 16 ? 16 : 24;  // W tiles + the border cells of the inclusive window
+    static_assert(W + 2 <= kGrid && (kGrid * kGrid) % 64 == 0, "composer grid");
     __shared__ ComposeLds<kGrid> L;
 
     const float zoom = 64.0f * kPxUnit / static_cast<float>(W);  // chaser.cpp:401
@@ -651,7 +692,7 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
                 x = MF(s, MF_X, m, env);
                 y = MF(s, MF_Y, m, env);
             } else {
-                const int cell = EB(s, EB_CELL, e, env);
+                const int cell = ent_cell(s, e, env);
                 want_tex = kind == kOrb ? kTexOrb : kTexPoint;
                 x = cell_x(cell);
                 y = cell_y(cell);
@@ -705,7 +746,7 @@ __global__ void __launch_bounds__(kFrameThreads) frame_kernel(State s, AtlasView
             x = MF(s, MF_X, m, env);
             y = MF(s, MF_Y, m, env);
         } else {
-            const int cell = EB(s, EB_CELL, e, env);
+            const int cell = ent_cell(s, e, env);
             tex = kind == kOrb ? kTexOrb : kTexPoint;
             x = cell_x(cell);
             y = cell_y(cell);
@@ -820,7 +861,8 @@ class ChaserGame final : public Game {
                                 static_cast<float>(n_ent)};
         for (int e = 0; e < n_ent; e++) {
             const int info = rb(s_.eb, (size_t(EB_INFO) * kMaxEnt + e) * n + env);
-            const int cell = rb(s_.eb, (size_t(EB_CELL) * kMaxEnt + e) * n + env);
+            const int cell = rb(s_.eb, (size_t(EB_CELL) * kMaxEnt + e) * n + env) |
+                             (kWideCells ? rb(s_.eb, (size_t(EB_CELL_HI) * kMaxEnt + e) * n + env) << 8 : 0);
             const int kind = info & kKindMask;
             v.push_back((info & kAlive) ? 1.0f : 0.0f);
             v.push_back(static_cast<float>(kind));

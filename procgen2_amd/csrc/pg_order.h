@@ -335,7 +335,7 @@ PG_HD void sort_by_key(ZItem* a, int n) {
 // surviving sprites (in set order) instead of re-running the introsort twin on a private array in every lane whose
 // sprite set changed.  Table: rank_offset(n) + r, n ≤ kRankMax; built on the host from sort_by_key itself.
 // ---------------------------------------------------------------------------------------------
-constexpr int kRankMax = 128;
+constexpr int kRankMax = 208;  // chaser extreme_mode: 198 sprites
 PG_HD int rank_offset(int n) { return n * (n - 1) / 2; }
 constexpr int kRankTableBytes = (kRankMax + 1) * kRankMax / 2;
 

@@ -18,7 +18,7 @@ TABLE = {
     "bossfight": (HARD, {EASY, HARD}),
     "climber": (HARD, {EASY, HARD}),
     "caveflyer": (HARD, {EASY, HARD}),
-    "chaser": (EASY, {EASY}),
+    "chaser": (EASY, {EASY, HARD, EXTREME}),
     "jumper": (HARD, {EASY, HARD}),
 }
 NON_DEFAULT = sorted((g, m) for g, (d, ms) in TABLE.items() for m in ms if m != d)
