@@ -88,7 +88,8 @@ class Jumper final : public Env {
 
    protected:
     void on_make() override {
-        if (mode_ == kEasy) W = H = 20;  // tilemap.cpp: world_dim by Distribution_Mode (memory_mode 45 is not built)
+        if (mode_ == kEasy) W = H = 20;  // tilemap.cpp:82-87: world_dim by Distribution_Mode
+        if (mode_ == kMemory) W = H = 45;
         tiles_.assign(W * H, 0);
         auto& bank = TextureBank::global();
         auto T = [&](const std::string& n) { return bank.find("assets/" + n + ".png"); };
@@ -232,7 +233,7 @@ class Jumper final : public Env {
         const int agent_cell = candidates[rng_.irange(0, static_cast<int>(candidates.size()) - 1)];
         std::vector<int> goal_path;
         rooms.find_path(agent_cell, goal_cell, goal_path);
-        {
+        if (mode_ != kMemory) {  // should_prune (tilemap.cpp:176-187)
             std::unordered_set<int> wide;
             wide.insert(goal_path.begin(), goal_path.end());
             rooms.expand_room(wide, 4);
@@ -243,7 +244,7 @@ class Jumper final : public Env {
         in_sprite_.insert(goal_id);
         goal_pos = {static_cast<float>(goal_cell / H) + 0.5f, static_cast<float>(H - 1 - goal_cell % H) + 0.5f};
 
-        const float spike_prob = 0.2f;
+        const float spike_prob = mode_ == kMemory ? 0.0f : 0.2f;  // tilemap.cpp:205
         for (int x = 0; x < W; x++)
             for (int y = 0; y < H; y++)
                 if (space_on_ground(x, y) && space_on_ground(x - 1, y) && space_on_ground(x + 1, y))

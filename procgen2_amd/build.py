@@ -30,7 +30,7 @@ KERNEL_SOURCES = ["coinrun.hip", "maze.hip", "bossfight.hip", "climber.hip", "ca
 # Distribution modes: a game's source is compiled once per variant (-DPG_VARIANT=k, csrc/pg_defs.h); variant 0 is the
 # reference's compile-time default.  engine.hip's kVariants table maps (game, mode) to these.
 VARIANTS = {"coinrun.hip": 1, "maze.hip": 3, "bossfight.hip": 2, "climber.hip": 2, "caveflyer.hip": 2, "chaser.hip": 3,
-            "jumper.hip": 2}
+            "jumper.hip": 3}
 HOST_SOURCES = ["png_decode.cpp"]
 ENGINE = "engine.hip"
 ALIASES = {"libprocgen2_hip.so": 0, "libCoinRun.so": 0, "libMaze.so": 1, "libBossFight.so": 2, "libClimber.so": 3,

@@ -124,6 +124,7 @@ static const Variant kVariants[] = {
     {kGameChaser, PGV_MODE_EASY, make_chaser_v0},       {kGameChaser, PGV_MODE_HARD, make_chaser_v1},
     {kGameChaser, PGV_MODE_EXTREME, make_chaser_v2},
     {kGameJumper, PGV_MODE_HARD, make_jumper_v0},       {kGameJumper, PGV_MODE_EASY, make_jumper_v1},
+    {kGameJumper, PGV_MODE_MEMORY, make_jumper_v2},
 };
 
 static const Variant* find_variant(int game, int mode) {

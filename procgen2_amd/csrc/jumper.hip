@@ -23,11 +23,13 @@
 #include "pg_rng.h"
 #include "pg_defs.h"
 // jumper/tilemap.cpp: world_dim by Distribution_Mode — hard_mode 40 (the reference's compile-time default, tilemap.h),
-// easy_mode 20.  memory_mode (45, no pruning) is not built.
+// easy_mode 20, memory_mode 45 (no pruning to the goal path, no spikes).
 #if PG_VARIANT == 0
 #define PG_ROOMS_DIM 40
 #elif PG_VARIANT == 1
 #define PG_ROOMS_DIM 20
+#elif PG_VARIANT == 2
+#define PG_ROOMS_DIM 45
 #else
 #error "jumper: unknown PG_VARIANT"
 #endif
@@ -39,7 +41,9 @@ namespace PG_VARIANT_NS {
 namespace jumper {
 
 constexpr int W = rooms::W, H = rooms::H, kCells = W * H;
-static_assert(kCells % 4 == 0, "tiles are copied as 32-bit words");
+constexpr int kTileStride = (kCells + 3) / 4 * 4;  // tiles are copied as 32-bit words
+constexpr bool kPrune = PG_VARIANT != 2;              // tilemap.cpp:176 should_prune = mode != memory_mode
+constexpr float kSpikeProb = PG_VARIANT == 2 ? 0.0f : 0.2f;  // tilemap.cpp:205
 constexpr int kMaxSpikes = 126;             // entity ids: 0 carrot, 1 bunny, 2.. spikes
 constexpr int kMaxSprites = kMaxSpikes + 1;  // carrot + spikes
 constexpr int kPuffs = 10;
@@ -72,7 +76,7 @@ enum { PF_X, PF_Y, PF_LIFE, PF_COUNT };
 
 // One generated level, as the generator leaves it in LDS and as it waits in the shadow slot (pg_prefetch.h).
 struct Level {
-    uint8_t tiles[kCells];
+    uint8_t tiles[kTileStride];
     float ax, ay, gx, gy, bgshift;
     int32_t themes, n_spikes;
     uint16_t spike_cell[kMaxSpikes];
@@ -92,7 +96,7 @@ struct State {
     Level* shadow;   // [n]  next level of each env
     int32_t* slot;   // [n]  SlotState
     uint32_t* mt;    // [n][625]  generator chain
-    uint8_t* tiles;  // [n][kCells]  column-major y + x*H
+    uint8_t* tiles;  // [n][kTileStride]  column-major y + x*H
     float* f;        // [F_COUNT][n]
     int32_t* i;      // [I_COUNT][n]
     float* pf;       // [PF_COUNT][kPuffs][n]
@@ -201,7 +205,7 @@ PG_D void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, u
     const int n_room = rooms::best_room(R, lane);  // R.cells: the room in the reference's iteration order
     const int goal_cell = R.cells[wave_rng_int(mt, 0, n_room - 1, lane)];
     // tiles: everything wall_mid except the best room (tilemap.cpp:146-155); lv.tiles is the working map
-    for (int c = lane; c < kCells; c += 64) lv.tiles[c] = kWallMid;
+    for (int c = lane; c < kTileStride; c += 64) lv.tiles[c] = kWallMid;
     __syncthreads();
     for (int k = lane; k < n_room; k += 64) lv.tiles[R.cells[k]] = kEmpty;
     __syncthreads();
@@ -236,11 +240,13 @@ PG_D void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, u
         R.goal_cell = goal_cell;
     }
     __syncthreads();
-    rooms::goal_path(R, agent_cell, goal_cell, lane);
-    rooms::widen(R, lane);
-    for (int c = lane; c < kCells; c += 64) lv.tiles[c] = R.aux[c] ? kEmpty : kWallMid;  // pruned to the wide path
-    __syncthreads();
-    masks_from_tiles(L, lv.tiles, lane);
+    if (kPrune) {  // find_path has no side effects, so memory_mode skips it with the pruning
+        rooms::goal_path(R, agent_cell, goal_cell, lane);
+        rooms::widen(R, lane);
+        for (int c = lane; c < kCells; c += 64) lv.tiles[c] = R.aux[c] ? kEmpty : kWallMid;  // pruned to the wide path
+        __syncthreads();
+        masks_from_tiles(L, lv.tiles, lane);
+    }
 
     // spikes (tilemap.cpp:203-211): x-major scan; a cell takes a draw when it and both horizontal neighbours are
     // ground cells — and a spike placed in the previous column makes that neighbour "not empty".  Column by column,
@@ -259,7 +265,7 @@ PG_D void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, u
                 __syncthreads();
                 bool spike = false;
                 if (lane < H && ((eligible >> lane) & 1ull))
-                    spike = L.draws[__popcll(eligible & ((1ull << lane) - 1ull))] < 0.2f;
+                    spike = L.draws[__popcll(eligible & ((1ull << lane) - 1ull))] < kSpikeProb;
                 placed = __ballot(spike);
                 __syncthreads();
             }
@@ -352,9 +358,9 @@ PG_D void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, u
 
 // The level becomes the env's live state (what reset() and the component constructors initialise).
 PG_D void install(const State& s, int env, const Level& lv, int lane) {
-    uint32_t* tiles = reinterpret_cast<uint32_t*>(s.tiles + size_t(env) * kCells);
+    uint32_t* tiles = reinterpret_cast<uint32_t*>(s.tiles + size_t(env) * kTileStride);
     const uint32_t* src = reinterpret_cast<const uint32_t*>(lv.tiles);
-    for (int k = lane; k < kCells / 4; k += 64) tiles[k] = src[k];
+    for (int k = lane; k < kTileStride / 4; k += 64) tiles[k] = src[k];
     const int n_spikes = lv.n_spikes;
     for (int k = lane; k < n_spikes; k += 64) s.spike_cell[size_t(k) * s.n + env] = lv.spike_cell[k];
     for (int k = lane; k < n_spikes + 1; k += 64) s.draw[size_t(k) * s.n + env] = lv.draw[k];
@@ -409,7 +415,7 @@ struct Gen {  // pg_prefetch.h level_kernel<Gen>
 // step
 // ------------------------------------------------------------------------------------------------
 PG_D void advance(const State& s, int env, int action, float& reward_out, bool& terminated_out) {
-    const uint8_t* tiles = s.tiles + size_t(env) * kCells;
+    const uint8_t* tiles = s.tiles + size_t(env) * kTileStride;
     const int n_spikes = SI(s, I_NSPIKES, env);
     int flags = SI(s, I_FLAGS, env), jumps = SI(s, I_JUMPS, env);
     float ax = SF(s, F_AX, env), ay = SF(s, F_AY, env), avx = SF(s, F_AVX, env), avy = SF(s, F_AVY, env);
@@ -550,7 +556,7 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
     const int themes = SI(s, I_THEMES, env), sflags = SI(s, I_FLAGS, env);
     const int backdrop = themes & 0xff, theme = (themes >> 8) & 0xff;
     const int n_draw = (sflags & kFlagListed) ? SI(s, I_NSPIKES, env) + 1 : 0;  // empty right after a reset
-    const uint8_t* tiles = s.tiles + size_t(env) * kCells;
+    const uint8_t* tiles = s.tiles + size_t(env) * kTileStride;
     const DescRegs descs = DescRegs::load(atlas, lane);
     Blit mine;
 
@@ -717,7 +723,7 @@ __global__ void __launch_bounds__(kFrameThreads) frame_kernel(State s, AtlasView
     const int themes = SI(s, I_THEMES, env), sflags = SI(s, I_FLAGS, env);
     const int backdrop = themes & 0xff, theme = (themes >> 8) & 0xff;
     const int n_draw = (sflags & kFlagListed) ? SI(s, I_NSPIKES, env) + 1 : 0;
-    const uint8_t* tiles = s.tiles + size_t(env) * kCells;
+    const uint8_t* tiles = s.tiles + size_t(env) * kTileStride;
     P.clear();
     {
         const int4 d = P.desc(kTexBackdrop + backdrop);
@@ -846,7 +852,7 @@ class JumperGame final : public Game {
         l.shadow = take(size_t(n) * sizeof(Level));
         l.slot = take(size_t(n) * 4);
         l.mt = take(size_t(n) * kMtWords * 4);
-        l.tiles = take(size_t(n) * kCells);
+        l.tiles = take(size_t(n) * kTileStride);
         l.f = take(size_t(F_COUNT) * n * 4);
         l.i = take(size_t(I_COUNT) * n * 4);
         l.pf = take(size_t(PF_COUNT) * kPuffs * n * 4);
@@ -935,7 +941,7 @@ class JumperGame final : public Game {
     int dump_tiles(hipStream_t st, int env, uint8_t* out, int cap) override {
         hipStreamSynchronize(st);
         const int m = cap < kCells ? cap : kCells;
-        hipMemcpy(out, s_.tiles + size_t(env) * kCells, m, hipMemcpyDeviceToHost);
+        hipMemcpy(out, s_.tiles + size_t(env) * kTileStride, m, hipMemcpyDeviceToHost);
         return m;
     }
 

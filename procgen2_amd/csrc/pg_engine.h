@@ -124,6 +124,7 @@ std::unique_ptr<Game> make_chaser_v1();
 std::unique_ptr<Game> make_chaser_v2();
 std::unique_ptr<Game> make_jumper_v0();
 std::unique_ptr<Game> make_jumper_v1();
+std::unique_ptr<Game> make_jumper_v2();
 
 // Counter-based synthetic action shared with the oracle (oracle/pgo_api.cpp pgo_synthetic_action).
 PG_HD uint32_t mix32(uint32_t x) {

@@ -19,7 +19,7 @@ TABLE = {
     "climber": (HARD, {EASY, HARD}),
     "caveflyer": (HARD, {EASY, HARD}),
     "chaser": (EASY, {EASY, HARD, EXTREME}),
-    "jumper": (HARD, {EASY, HARD}),
+    "jumper": (HARD, {EASY, HARD, MEMORY}),
 }
 NON_DEFAULT = sorted((g, m) for g, (d, ms) in TABLE.items() for m in ms if m != d)
 
