@@ -22,8 +22,8 @@ int pgo_texture_count() { return static_cast<int>(pgo::TextureBank::global().siz
 // default (SURVEY.md §5 "config / flags").
 int pgo_resolve_mode(const char* game, int mode) {
     const std::string g(game);
-    const bool plain = g == "coinrun" || g == "climber" || g == "bossfight" || g == "caveflyer";  // easy | hard
-    const bool mem = g == "maze" || g == "jumper";                                              // + memory
+    const bool plain = g == "coinrun" || g == "climber" || g == "bossfight";  // easy | hard
+    const bool mem = g == "maze" || g == "jumper" || g == "caveflyer";      // + memory
     if (mode == 0) return g == "chaser" ? Env::kEasy : Env::kHard;
     if (mode == Env::kEasy || mode == Env::kHard) return (plain || mem || g == "chaser") ? mode : -1;
     if (mode == Env::kMemory) return mem ? mode : -1;

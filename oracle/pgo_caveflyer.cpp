@@ -88,7 +88,8 @@ class Caveflyer final : public Env {
 
    protected:
     void on_make() override {
-        if (mode_ == kEasy) W = H = 20;  // tilemap.cpp: world_dim by Distribution_Mode (memory_mode 45 is not built)
+        if (mode_ == kEasy) W = H = 20;  // tilemap.cpp:121-126: world_dim by Distribution_Mode
+        if (mode_ == kMemory) W = H = 45;
         tiles_.assign(W * H, 0);
         auto& bank = TextureBank::global();
         auto T = [&](const std::string& n) { return bank.find("assets/" + n + ".png"); };
@@ -183,7 +184,7 @@ class Caveflyer final : public Env {
 
         std::vector<int> goal_path;
         rooms.find_path(agent_cell, goal_cell, goal_path);
-        {
+        if (mode_ != kMemory) {  // should_prune (tilemap.cpp:203-215)
             std::unordered_set<int> wide;
             wide.insert(goal_path.begin(), goal_path.end());
             rooms.expand_room(wide, 4);

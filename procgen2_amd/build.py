@@ -29,7 +29,7 @@ COMMON = ["--offload-arch=" + ARCH, "-std=c++17", "-O3", "-fPIC", "-ffp-contract
 KERNEL_SOURCES = ["coinrun.hip", "maze.hip", "bossfight.hip", "climber.hip", "caveflyer.hip", "chaser.hip", "jumper.hip"]
 # Distribution modes: a game's source is compiled once per variant (-DPG_VARIANT=k, csrc/pg_defs.h); variant 0 is the
 # reference's compile-time default.  engine.hip's kVariants table maps (game, mode) to these.
-VARIANTS = {"coinrun.hip": 1, "maze.hip": 3, "bossfight.hip": 2, "climber.hip": 2, "caveflyer.hip": 2, "chaser.hip": 3,
+VARIANTS = {"coinrun.hip": 1, "maze.hip": 3, "bossfight.hip": 2, "climber.hip": 2, "caveflyer.hip": 3, "chaser.hip": 3,
             "jumper.hip": 3}
 HOST_SOURCES = ["png_decode.cpp"]
 ENGINE = "engine.hip"

@@ -28,11 +28,13 @@
 #include "pg_rng.h"
 #include "pg_defs.h"
 // caveflyer/tilemap.cpp: world_dim by Distribution_Mode — hard_mode 40 (the reference's compile-time default, tilemap.h),
-// easy_mode 20.  memory_mode (45, no pruning) is not built.
+// easy_mode 20, memory_mode 45 (the whole cave stays, not just the widened goal path).
 #if PG_VARIANT == 0
 #define PG_ROOMS_DIM 40
 #elif PG_VARIANT == 1
 #define PG_ROOMS_DIM 20
+#elif PG_VARIANT == 2
+#define PG_ROOMS_DIM 45
 #else
 #error "caveflyer: unknown PG_VARIANT"
 #endif
@@ -45,8 +47,11 @@ namespace PG_VARIANT_NS {
 namespace caveflyer {
 
 constexpr int W = rooms::W, H = rooms::H, kCells = W * H;
-static_assert(kCells % 4 == 0, "tiles are copied as 32-bit words");
-constexpr int kMaxEnt = 62;  // ids: 0 goal, 1 ship, 2.. objects; 3·(free/80) ≤ 60 objects (tilemap.cpp:232-233)
+constexpr int kTileStride = (kCells + 3) / 4 * 4;  // tiles are copied as 32-bit words
+constexpr bool kPrune = PG_VARIANT != 2;              // tilemap.cpp:203 should_prune = mode != memory_mode
+// ids: 0 goal, 1 ship, 2.. objects; 3·(free/80) objects (tilemap.cpp:232-233): ≤ 60 at 40×40, ≤ 75 at 45×45
+constexpr int kMaxEnt = 2 + 3 * ((kCells > 1600 ? kCells : 1600) / 80) + (kCells > 1600 ? 1 : 0);
+static_assert(kMaxEnt <= 128, "two wave passes cover the sprites");
 constexpr int kShots = 32, kPuffs = 10;
 constexpr double kPi = 3.14159265358979323846;  // M_PI
 enum Tile : uint8_t { kEmpty = 0, kWall = 1 };
@@ -74,7 +79,7 @@ enum { PF_X, PF_Y, PF_DX, PF_DY, PF_ROT, PF_LIFE, PF_COUNT };
 
 // One generated level, as the generator leaves it in LDS and as it waits in the shadow slot.
 struct Level {
-    uint8_t tiles[W * H];
+    uint8_t tiles[kTileStride];
     float ax, ay, bgshift;
     int32_t n_ent, backdrop;
     float ex[kMaxEnt], ey[kMaxEnt], evx[kMaxEnt], evy[kMaxEnt];
@@ -163,7 +168,14 @@ PG_D void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, u
         __syncthreads();
     }
     goal_path(L, L.agent_cell, L.goal_cell, lane);
-    rooms::widen(L, lane);
+    if (kPrune) {
+        rooms::widen(L, lane);
+    } else {  // memory_mode: every open cell of the cave stays; same encoding as widen(): 0 wall, 1 path, ≥ 2 free
+        for (int c = lane; c < kCells; c += 64) L.aux[c] = L.grid[c] ? 0 : 2;
+        __syncthreads();
+        for (int k = lane; k < L.path_len; k += 64) L.aux[L.cells[k]] = 1;
+        __syncthreads();
+    }
     if (lane == 0) {
         // the four further automaton iterations (tilemap.cpp:217-222) never reach tile_ids (D13)
 
@@ -190,13 +202,14 @@ PG_D void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, u
     const int chunk = n_free / 80, num_objects = 3 * chunk;
     {
         const float ax = lv.ax, ay = lv.ay;
-        int picked = -1;
+        int picked = -1, picked_hi = -1;  // lane j: the j-th and the (64 + j)-th picked index
         for (int i = 0; i < num_objects; i++) {
             int index = 0;
             if (lane == 0) index = rng_int(mt, 0, n_free - 1);
             index = __shfl(index, 0);
-            while (__ballot(picked == index)) index = (index + 1) % n_free;
+            while (__ballot(picked == index || picked_hi == index)) index = (index + 1) % n_free;
             if (lane == i) picked = index;
+            if (lane + 64 == i) picked_hi = index;
             if (lane == 0) {
                 const int cell = L.cells[index];
                 const int id = 2 + i;
@@ -239,25 +252,25 @@ PG_D void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, u
         SI(s, I_HASH_HAZARD, env) = packed;
     }
     __syncthreads();
-    for (int c = lane; c < kCells; c += 64) lv.tiles[c] = L.aux[c] ? kEmpty : kWall;
+    for (int c = lane; c < kTileStride; c += 64) lv.tiles[c] = (c < kCells && L.aux[c]) ? kEmpty : kWall;
     for (int k = lane; k < kMtWords; k += 64) gmt[k] = L.mt[k];
     __syncthreads();
 }
 
 // The level becomes the env's live state (everything reset() and the component constructors initialise).
 PG_D void install(const State& s, int env, const Level& lv, int lane) {
-    uint32_t* tiles = reinterpret_cast<uint32_t*>(s.tiles + size_t(env) * kCells);
+    uint32_t* tiles = reinterpret_cast<uint32_t*>(s.tiles + size_t(env) * kTileStride);
     const uint32_t* src = reinterpret_cast<const uint32_t*>(lv.tiles);
-    for (int k = lane; k < kCells / 4; k += 64) tiles[k] = src[k];
+    for (int k = lane; k < kTileStride / 4; k += 64) tiles[k] = src[k];
     const int n_ent = lv.n_ent;
-    if (lane < n_ent) {
-        EF(s, EF_X, lane, env) = lv.ex[lane];
-        EF(s, EF_Y, lane, env) = lv.ey[lane];
-        EF(s, EF_VX, lane, env) = lv.evx[lane];
-        EF(s, EF_VY, lane, env) = lv.evy[lane];
-        EB(s, EB_INFO, lane, env) = lv.info[lane];
-        if (lane < n_ent - 1) EB(s, EB_ORDER_S, lane, env) = lv.order_s[lane];
-        if (lane < n_ent - 2) EB(s, EB_ORDER_H, lane, env) = lv.order_h[lane];
+    for (int e = lane; e < n_ent; e += 64) {
+        EF(s, EF_X, e, env) = lv.ex[e];
+        EF(s, EF_Y, e, env) = lv.ey[e];
+        EF(s, EF_VX, e, env) = lv.evx[e];
+        EF(s, EF_VY, e, env) = lv.evy[e];
+        EB(s, EB_INFO, e, env) = lv.info[e];
+        if (e < n_ent - 1) EB(s, EB_ORDER_S, e, env) = lv.order_s[e];
+        if (e < n_ent - 2) EB(s, EB_ORDER_H, e, env) = lv.order_h[e];
     }
     if (lane < kPuffs)
         for (int f = 0; f < PF_COUNT; f++) PF(s, f, lane, env) = 0.0f;
@@ -304,7 +317,7 @@ PG_D void rebuild_draw_list(const State& s, int env, int n_ent) {
 }
 
 PG_D void advance(const State& s, int env, int action, float& reward_out, bool& terminated_out) {
-    const uint8_t* tiles = s.tiles + size_t(env) * kCells;
+    const uint8_t* tiles = s.tiles + size_t(env) * kTileStride;
     const int n_ent = SI(s, I_NENT, env);
     const int flags = SI(s, I_FLAGS, env);
     float ax = SF(s, F_AX, env), ay = SF(s, F_AY, env), avx = SF(s, F_AVX, env), avy = SF(s, F_AVY, env);
@@ -550,7 +563,7 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
     const int sflags = SI(s, I_FLAGS, env);
     const int n_draw = (sflags & kFlagListed) ? SI(s, I_NDRAW, env) : 0;  // empty right after a reset
     const int s_next = SI(s, I_SNEXT, env), s_count = SI(s, I_SCOUNT, env);
-    const uint8_t* tiles = s.tiles + size_t(env) * kCells;
+    const uint8_t* tiles = s.tiles + size_t(env) * kTileStride;
     const DescRegs descs = DescRegs::load(atlas, lane);
     Blit mine;
 
@@ -658,6 +671,25 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
                                scale * kUnitPx / d.y, 1.0f, false, false, mine);
         }
         wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
+        if (kMaxEnt > 64 && n_draw > 64) {  // memory_mode: up to 76 sprites, the rest in a second pass
+            const int k = 64 + lane;
+            int kind2 = 0;
+            float x2 = 0.0f, y2 = 0.0f;
+            if (k < n_draw) {
+                const int e = EB(s, EB_DRAW, k, env);
+                kind2 = EB(s, EB_INFO, e, env) & kKindMask;
+                x2 = EF(s, EF_X, e, env);
+                y2 = EF(s, EF_Y, e, env);
+            }
+            const int4 d2 = descs.at(kTexKind + kind2);
+            bool has2 = false;
+            if (k < n_draw) {
+                const float scale = 1.0f * 0.8f;
+                has2 = resolve_draw(cam, d2.y, d2.z, d2.x, (x2 + -0.4f) * kUnitPx, (y2 + -0.4f) * kUnitPx,
+                                    scale * kUnitPx / d2.y, 1.0f, false, false, mine);
+            }
+            wave_replay(fb, atlas, mine, __ballot(has2), lane, half, halves);
+        }
     }
     {  // System_Agent::render (common_systems.cpp:291-327): bullets newest first, then the ship
         int want_tex = kTexShip;
@@ -687,7 +719,7 @@ __global__ void __launch_bounds__(kFrameThreads) frame_kernel(State s, AtlasView
     const int sflags = SI(s, I_FLAGS, env);
     const int n_draw = (sflags & kFlagListed) ? SI(s, I_NDRAW, env) : 0;
     const int s_next = SI(s, I_SNEXT, env), s_count = SI(s, I_SCOUNT, env);
-    const uint8_t* tiles = s.tiles + size_t(env) * kCells;
+    const uint8_t* tiles = s.tiles + size_t(env) * kTileStride;
     P.clear();
     {
         const int4 d = P.desc(kTexSpace + SI(s, I_BACKDROP, env));
@@ -772,7 +804,7 @@ class CaveflyerGame final : public Game {
         l.shadow = take(size_t(n) * sizeof(Level));
         l.slot = take(size_t(n) * 4);
         l.mt = take(size_t(n) * kMtWords * 4);
-        l.tiles = take(size_t(n) * kCells);
+        l.tiles = take(size_t(n) * kTileStride);
         l.f = take(size_t(F_COUNT) * n * 4);
         l.i = take(size_t(I_COUNT) * n * 4);
         l.ef = take(size_t(EF_COUNT) * kMaxEnt * n * 4);
@@ -870,7 +902,7 @@ class CaveflyerGame final : public Game {
     int dump_tiles(hipStream_t st, int env, uint8_t* out, int cap) override {
         hipStreamSynchronize(st);
         const int m = cap < kCells ? cap : kCells;
-        hipMemcpy(out, s_.tiles + size_t(env) * kCells, m, hipMemcpyDeviceToHost);
+        hipMemcpy(out, s_.tiles + size_t(env) * kTileStride, m, hipMemcpyDeviceToHost);
         return m;
     }
 

@@ -121,6 +121,7 @@ static const Variant kVariants[] = {
     {kGameBossfight, PGV_MODE_HARD, make_bossfight_v0}, {kGameBossfight, PGV_MODE_EASY, make_bossfight_v1},
     {kGameClimber, PGV_MODE_HARD, make_climber_v0},     {kGameClimber, PGV_MODE_EASY, make_climber_v1},
     {kGameCaveflyer, PGV_MODE_HARD, make_caveflyer_v0}, {kGameCaveflyer, PGV_MODE_EASY, make_caveflyer_v1},
+    {kGameCaveflyer, PGV_MODE_MEMORY, make_caveflyer_v2},
     {kGameChaser, PGV_MODE_EASY, make_chaser_v0},       {kGameChaser, PGV_MODE_HARD, make_chaser_v1},
     {kGameChaser, PGV_MODE_EXTREME, make_chaser_v2},
     {kGameJumper, PGV_MODE_HARD, make_jumper_v0},       {kGameJumper, PGV_MODE_EASY, make_jumper_v1},

@@ -119,6 +119,7 @@ std::unique_ptr<Game> make_climber_v0();
 std::unique_ptr<Game> make_climber_v1();
 std::unique_ptr<Game> make_caveflyer_v0();
 std::unique_ptr<Game> make_caveflyer_v1();
+std::unique_ptr<Game> make_caveflyer_v2();
 std::unique_ptr<Game> make_chaser_v0();
 std::unique_ptr<Game> make_chaser_v1();
 std::unique_ptr<Game> make_chaser_v2();

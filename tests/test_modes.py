@@ -17,7 +17,7 @@ TABLE = {
     "maze": (HARD, {EASY, HARD, MEMORY}),
     "bossfight": (HARD, {EASY, HARD}),
     "climber": (HARD, {EASY, HARD}),
-    "caveflyer": (HARD, {EASY, HARD}),
+    "caveflyer": (HARD, {EASY, HARD, MEMORY}),
     "chaser": (EASY, {EASY, HARD, EXTREME}),
     "jumper": (HARD, {EASY, HARD, MEMORY}),
 }
