@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--game", default="coinrun")
+    ap.add_argument("--mode", default=None, choices=["easy", "hard", "memory", "extreme"],
+                    help="distribution mode of the game (default: the reference's compile-time one, which is what "
+                         "BASELINE.json's metric is quoted on; other modes are reported without a CPU baseline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["single", "mixed"], default="single",
                     help="mixed = all seven games on every GPU, --envs split seven ways (the last game takes the "
@@ -100,7 +103,8 @@ def main():
     run_seed = 0
     if a.workload == "mixed":
         return mixed(a, torch, ProcgenVecEnv, distributed, world, rank, local_rank, n_gpus, run_seed)
-    env = ProcgenVecEnv(a.game, a.envs, device=local_rank, seed_base=1, env_offset=rank * a.envs)
+    env = ProcgenVecEnv(a.game, a.envs, device=local_rank, seed_base=1, env_offset=rank * a.envs,
+                        distribution_mode=a.mode)
     env.reset()
     env.timed_steps(max(1, a.warmup), run_seed)  # untimed warm-up steps (same code path as the timed ones)
 
@@ -130,7 +134,7 @@ def main():
         value = total_steps / elapsed
         render_avg_ms = render_ms / a.steps
         achieved = ALGO_BYTES_PER_ENV_STEP * a.envs / (render_avg_ms * 1e-3) / 1e9
-        traffic, traffic_src = measured_traffic(a.game) if a.envs == 65536 else (None, None)
+        traffic, traffic_src = measured_traffic(a.game) if a.envs == 65536 and not a.mode else (None, None)
         line = {
             "metric": "env-steps/sec at 65536 envs, 64x64x3 obs",
             "value": value,
@@ -146,7 +150,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s, %d envs per GPU, uniform random actions 0..14 from a device counter hash, "
                                    "next-step auto-reset, seeds 1+global env index" % (a.game, a.envs),
-                       "game": a.game, "envs_per_gpu": a.envs, "obs": "64x64x3 uint8", "parallelism": "env-shard x%d, no collective" % n_gpus},
+                       "game": a.game, "distribution_mode": a.mode or "default", "envs_per_gpu": a.envs, "obs": "64x64x3 uint8", "parallelism": "env-shard x%d, no collective" % n_gpus},
             "obs_write_GBps": value * 12288 / 1e9,
             "roofline": {"bound": "hbm", "kernel": "%s::render_kernel" % a.game, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
@@ -155,7 +159,7 @@ def main():
                          "avg_launch_ms": render_avg_ms},
             "done_fraction_last_step": done_frac,
         }
-        if n_gpus == 1 and not a.no_cpu_baseline:
+        if n_gpus == 1 and not a.no_cpu_baseline and not a.mode:
             line["cpu_baseline"] = cpu_baseline(a.game, run_seed)
         print(json.dumps(line), flush=True)
     if distributed:

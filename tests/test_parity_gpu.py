@@ -238,20 +238,23 @@ def test_snapshot_restore_replays_the_same_rollout(game):
     eng.close()
 
 
-FRAME_GAMES = ["coinrun", "maze", "bossfight", "climber", "caveflyer", "chaser", "jumper"]
+FRAME_GAMES = [("coinrun", 0), ("maze", 0), ("bossfight", 0), ("climber", 0), ("caveflyer", 0), ("chaser", 0),
+               ("jumper", 0),
+               # non-default distribution modes with their own camera / world size (include/procgen2_vec.h PGV_MODE_*)
+               ("maze", 3), ("chaser", 4), ("jumper", 3), ("caveflyer", 1)]
 
 
-@pytest.mark.parametrize("game", FRAME_GAMES)
-def test_human_frame_matches_the_oracle(game):
+@pytest.mark.parametrize("game,mode", FRAME_GAMES)
+def test_human_frame_matches_the_oracle(game, mode):
     """cenv_render's W×H frame (render_game(false)): the GPU frame kernel (pg_frame.h) against the
     oracle's paint() at the same size — the default 512×512 window, a small and a non-square one — after a reset and
     along a rollout, for several envs."""
     from oracle_util import register_textures
     n = 6
-    eng = EngineVec(game, n, seed_base=71)
+    eng = EngineVec(game, n, seed_base=71, mode=mode)
     L = oracle()
     register_textures(game)
-    hs = [L.pgo_make(game.encode(), 71 + i, 1) for i in range(n)]
+    hs = [L.pgo_make_mode(game.encode(), 71 + i, 1, mode) for i in range(n)]
     for h in hs:
         L.pgo_reset(h, 0, 0)
     eng.reset()
