@@ -169,28 +169,52 @@ PG_D bool resolve_screen(int tw, int th, int tex_off, float dx, float dy, float 
     return true;
 }
 
-// Raster spec S6: all lanes execute one rotated draw (wave-uniform).  Scans the same square as the oracle.
+// Raster spec S6: all lanes execute one rotated draw (wave-uniform).  The oracle scans the square of the rectangle's
+// half-diagonal around its centre; a pixel is drawn only if it maps back inside the un-rotated rectangle, so any
+// superset of those pixels gives the same frame.  Here: the bounding box of the rotated rectangle — in doubled
+// coordinates its corners (±dw, ±dh) turn into |x| ≤ (dw·|cs| + dh·|sn|) / 65536, likewise y — widened by a pixel
+// for the rounding of sn/cs, and clipped to the target.  For a needle-shaped sprite that is a fraction of the square.
+// The texel fetches of four pixels per lane are issued before the first blend (one memory round trip per batch).
 PG_D void wave_blit_rotated(uint32_t* fb, const AtlasView& atlas, const Blit& b, int lane, int stride = 64) {
-    int reach = 1;
-    while (reach * reach * 4 < b.dw * b.dw + b.dh * b.dh) reach++;
-    reach += 1;
-    const int cx2 = 2 * b.dx + b.dw, cy2 = 2 * b.dy + b.dh;
-    const int x_lo = (cx2 - 2 * reach) / 2 - 1, x_hi = (cx2 + 2 * reach) / 2 + 1;
-    const int y_lo = (cy2 - 2 * reach) / 2 - 1, y_hi = (cy2 + 2 * reach) / 2 + 1;
+    const int acs = b.rot_cs < 0 ? -b.rot_cs : b.rot_cs, asn = b.rot_sn < 0 ? -b.rot_sn : b.rot_sn;
+    const int ex = static_cast<int>((static_cast<long long>(b.dw) * acs + static_cast<long long>(b.dh) * asn) >> 16) + 1;
+    const int ey = static_cast<int>((static_cast<long long>(b.dw) * asn + static_cast<long long>(b.dh) * acs) >> 16) + 1;
+    // pixel X has doubled offset px = 2(X − dx) + 1 − dw; |px| ≤ ex  ⇐  X within the bounds below (floor/ceil + 1)
+    int x_lo = b.dx + ((b.dw - 1 - ex) >> 1) - 1, x_hi = b.dx + ((b.dw - 1 + ex + 1) >> 1) + 1;
+    int y_lo = b.dy + ((b.dh - 1 - ey) >> 1) - 1, y_hi = b.dy + ((b.dh - 1 + ey + 1) >> 1) + 1;
+    x_lo = x_lo < 0 ? 0 : x_lo;
+    y_lo = y_lo < 0 ? 0 : y_lo;
+    x_hi = x_hi > kObsW - 1 ? kObsW - 1 : x_hi;
+    y_hi = y_hi > kObsH - 1 ? kObsH - 1 : y_hi;
     const int bw = x_hi - x_lo + 1, bh = y_hi - y_lo + 1;
+    if (bw <= 0 || bh <= 0) return;
     const uint32_t* tex = atlas.texels + b.tex_off;
     const int mod = b.flip_mod & 0xff;
-    for (int p = lane; p < bw * bh; p += stride) {
-        const int ry = udiv_small(p, bw);
-        const int X = x_lo + (p - ry * bw), Y = y_lo + ry;
-        if (X < 0 || X >= kObsW || Y < 0 || Y >= kObsH) continue;
-        const int px = 2 * (X - b.dx) + 1 - b.dw, py = 2 * (Y - b.dy) + 1 - b.dh;
-        const long long lx = (long long)px * b.rot_cs + (long long)py * b.rot_sn + (long long)b.dw * 65536;
-        const long long ly = -(long long)px * b.rot_sn + (long long)py * b.rot_cs + (long long)b.dh * 65536;
-        if (lx < 0 || ly < 0 || lx >= (long long)(2 * b.dw) * 65536 || ly >= (long long)(2 * b.dh) * 65536) continue;
-        const int i = static_cast<int>(lx >> 17), j = static_cast<int>(ly >> 17);
-        const int u = sample_index(0, b.sw, i, b.dw), v = sample_index(0, b.sh, j, b.dh);
-        blend_into(fb, Y * kObsW + X, tex[v * b.tex_w + u], mod);
+    const int total = bw * bh;
+    constexpr int kBatch = 4;
+    for (int p0 = lane; p0 < total; p0 += stride * kBatch) {
+        int idx[kBatch];
+        uint32_t texel[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) {
+            idx[k] = -1;
+            texel[k] = 0;
+            const int p = p0 + k * stride;
+            if (p >= total) continue;
+            const int ry = udiv_small(p, bw);
+            const int X = x_lo + (p - ry * bw), Y = y_lo + ry;
+            const int px = 2 * (X - b.dx) + 1 - b.dw, py = 2 * (Y - b.dy) + 1 - b.dh;
+            const long long lx = (long long)px * b.rot_cs + (long long)py * b.rot_sn + (long long)b.dw * 65536;
+            const long long ly = -(long long)px * b.rot_sn + (long long)py * b.rot_cs + (long long)b.dh * 65536;
+            if (lx < 0 || ly < 0 || lx >= (long long)(2 * b.dw) * 65536 || ly >= (long long)(2 * b.dh) * 65536) continue;
+            const int i = static_cast<int>(lx >> 17), j = static_cast<int>(ly >> 17);
+            const int u = sample_index(0, b.sw, i, b.dw), v = sample_index(0, b.sh, j, b.dh);
+            idx[k] = Y * kObsW + X;
+            texel[k] = tex[v * b.tex_w + u];
+        }
+#pragma unroll
+        for (int k = 0; k < kBatch; k++)
+            if (idx[k] >= 0) blend_into(fb, idx[k], texel[k], mod);
     }
 }
 
@@ -224,31 +248,58 @@ PG_D void wave_blit(uint32_t* fb, const AtlasView& atlas, const Blit& b, int lan
     const int mod = b.flip_mod & 0xff;
     const bool fh = (b.flip_mod & kFlipH) != 0, fv = (b.flip_mod & kFlipV) != 0;
 
+    constexpr int kBatch = 4;  // texel fetches in flight per lane: a batch costs one memory round trip
     if (cw > 32) {
-        // Wide blit (backgrounds on the fallback path): lane = column, one row per iteration.
+        // Wide blit (backgrounds on the fallback path, jumper's compass): lane = column, kBatch rows per iteration.
         const int x = x0 + lane;
         const bool on = lane < cw;
         int i = x - b.dx;
         if (fh) i = b.dw - 1 - i;
         const int u = on ? sample_index(b.sx, b.sw, i, b.dw) : b.sx;
-        for (int y = y0 + half; y < y1; y += halves) {
-            int j = y - b.dy;
-            if (fv) j = b.dh - 1 - j;
-            const int v = sample_index(b.sy, b.sh, j, b.dh);
-            if (on) blend_into(fb, y * kObsW + x, tex[v * tw + u], mod);
+        for (int yb = y0 + half; yb < y1; yb += halves * kBatch) {
+            uint32_t texel[kBatch];
+#pragma unroll
+            for (int k = 0; k < kBatch; k++) {
+                const int y = yb + k * halves;
+                texel[k] = 0;
+                if (y >= y1) continue;
+                int j = y - b.dy;
+                if (fv) j = b.dh - 1 - j;
+                const int v = sample_index(b.sy, b.sh, j, b.dh);
+                if (on) texel[k] = tex[v * tw + u];
+            }
+#pragma unroll
+            for (int k = 0; k < kBatch; k++) {
+                const int y = yb + k * halves;
+                if (on && y < y1) blend_into(fb, y * kObsW + x, texel[k], mod);
+            }
         }
     } else {
         const int total = cw * ch;
-        for (int p = lane + 64 * half; p < total; p += 64 * halves) {
-            const int ry = p / cw;
-            const int rx = p - ry * cw;
-            const int x = x0 + rx, y = y0 + ry;
-            int i = x - b.dx, j = y - b.dy;
-            if (fh) i = b.dw - 1 - i;
-            if (fv) j = b.dh - 1 - j;
-            const int u = sample_index(b.sx, b.sw, i, b.dw);
-            const int v = sample_index(b.sy, b.sh, j, b.dh);
-            blend_into(fb, y * kObsW + x, tex[v * tw + u], mod);
+        const int step = 64 * halves;
+        for (int p0 = lane + 64 * half; p0 < total; p0 += step * kBatch) {
+            uint32_t texel[kBatch];
+            int idx[kBatch];
+#pragma unroll
+            for (int k = 0; k < kBatch; k++) {
+                const int p = p0 + k * step;
+                idx[k] = -1;
+                texel[k] = 0;
+                if (p >= total) continue;
+                const int ry = udiv_small(p, cw);
+                const int rx = p - ry * cw;
+                const int x = x0 + rx, y = y0 + ry;
+                int i = x - b.dx, j = y - b.dy;
+                if (fh) i = b.dw - 1 - i;
+                if (fv) j = b.dh - 1 - j;
+                const int u = sample_index(b.sx, b.sw, i, b.dw);
+                const int v = sample_index(b.sy, b.sh, j, b.dh);
+                idx[k] = y * kObsW + x;
+                texel[k] = tex[v * tw + u];
+            }
+#pragma unroll
+            for (int k = 0; k < kBatch; k++)
+                if (idx[k] >= 0) blend_into(fb, idx[k], texel[k], mod);
         }
     }
 }
@@ -298,7 +349,7 @@ PG_D void wave_replay(uint32_t* fb, const AtlasView& atlas, const Blit& mine, un
                 continue;
             }
             mask &= mask - 1;
-            if (halves == 2 && (g & 1) != half) continue;  // with two waves the small draws of a group alternate
+            if (halves >= 2 && (g % halves) != half) continue;  // the small draws of a group go round the waves
             const Blit b = blit_from_lane(mine, src);
             const int x0 = b.dx > 0 ? b.dx : 0, y0 = b.dy > 0 ? b.dy : 0;
             const int x1 = (b.dx + b.dw) < kObsW ? (b.dx + b.dw) : kObsW;
@@ -377,7 +428,7 @@ PG_D void compose_spans(ComposeLds<GRID>& L, const Camera& cam, int x0, int y0, 
     if (L.too_wide) return;
 #pragma unroll
     for (int axis = 0; axis < 2; axis++) {
-        if (halves == 2 && axis != half) continue;
+        if (halves >= 2 && axis != half) continue;
         const int4* spans = axis == 0 ? L.col : L.row;
         const int count = axis == 0 ? cols : rows;
         for (int q = lane; q < count * MAXSPAN; q += 64) {
@@ -532,6 +583,7 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
 #pragma unroll
                 for (int j = 0; j < 5; j++) translucent |= ((t[k][j] >> 24) + 1u) & 0xFEu;
         }
+        if (ablate & 512) translucent = 0;  // timing experiment: never take the blending path
         if (bg_mod == 255 && (!may_blend || __ballot(translucent != 0) == 0)) {
             // Opaque-or-absent everywhere in the batch: OVER is "last drawn wins" (what S4 yields for a = 0 / 255).
 #pragma unroll

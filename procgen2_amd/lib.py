@@ -61,6 +61,14 @@ def load(path=None):
         raise EngineError(
             "HIP engine library not found at %s — run `python -m procgen2_amd.build` (hipcc, gfx950). "
             "There is no CPU fallback." % path)
+    # One HIP runtime per process.  torch ships its own libamdhip64 under the same SONAME as /opt/rocm's, and the
+    # dynamic loader hands whichever was loaded first to everyone who asks later.  The engine shares device pointers
+    # and streams with torch (vec_env.py), so they must be the same runtime instance, and torch refuses to see a
+    # device when it finds a foreign runtime already resident: load torch's first whenever torch is installed.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = ctypes.CDLL(path)
     P = c_void_p
     proto = {

@@ -1,7 +1,7 @@
 import sys
 sys.path.insert(0,'tests')
 from engine_util import EngineVec
-for flags,name in ((0,'full'),(128,'no row loop'),(128+2,'no rows/sprites'),(128+2+8,'no rows/spr/store'),(4+2+8,'nothing')):
+for flags,name in ((0,'full'),(512,'rows never blend'),(128,'no row loop'),(128+2,'no rows/sprites'),(128+2+8,'no rows/spr/store'),(4+2+8,'nothing')):
     e=EngineVec('coinrun',65536,seed_base=1); e.reset(); e.timed(40)
     e.set_debug(flags)
     tot,ren=e.timed(64)
