@@ -12,7 +12,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_LIB = os.path.join(ORACLE_DIR, "libpgoracle.so")
+ORACLE_LIB = os.environ.get("PGO_ORACLE_LIB") or os.path.join(ORACLE_DIR, "libpgoracle.so")  # (sanitizer builds)
 ASSETS = os.path.join(ROOT, "procgen2_amd", "assets")
 OBS_BYTES = 12288
 
