@@ -118,17 +118,20 @@ def make_spaces(num_envs):
 class GymVectorAdapter(_VectorBase):
     """The wrapper logic over any engine object (see module docstring)."""
 
-    metadata = {"render_modes": [], "autoreset_mode": "next_step"}
+    metadata = {"render_modes": ["rgb_array"], "autoreset_mode": "next_step"}
 
-    def __init__(self, engine, output="torch"):
+    def __init__(self, engine, output="torch", render_mode=None, render_size=(512, 512)):
         if output not in ("torch", "numpy"):
             raise ValueError("output must be 'torch' or 'numpy'")
+        if render_mode not in (None, "rgb_array"):
+            raise ValueError("render_mode must be None or 'rgb_array'")
         self.engine = engine
         self.num_envs = int(engine.num_envs)
         self.output = output
+        self.render_size = (int(render_size[0]), int(render_size[1]))
         (self.single_observation_space, self.single_action_space, self.observation_space,
          self.action_space) = make_spaces(self.num_envs)
-        self.render_mode = None
+        self.render_mode = render_mode
         self.closed = False
         if _gym is not None:
             try:
@@ -179,6 +182,14 @@ class GymVectorAdapter(_VectorBase):
         truncated = np.zeros(self.num_envs, dtype=bool) if self.output == "numpy" else (done != done)
         return self._out(obs), self._out(reward), self._out(terminated, bool), truncated, {}
 
+    def render(self, index=0):
+        """The human-size frame of one env (the reference's `cenv_render`, coinrun.cpp:393-411; default 512×512 as its
+        window): uint8 [H, W, 3].  None unless the env was made with render_mode="rgb_array"."""
+        if self.render_mode != "rgb_array":
+            return None
+        w, h = self.render_size
+        return self.engine.render_frame(int(index), w, h)
+
     def close(self, **kwargs):
         if not self.closed:
             self.engine.close()
@@ -201,9 +212,10 @@ class ProcgenGymVectorEnv(GymVectorAdapter):
     """`GymVectorAdapter` over the HIP engine.  Raises if there is no HIP device (no CPU fallback)."""
 
     def __init__(self, game, num_envs, device=0, seed=1, env_offset=0, output="torch", num_levels=0, start_level=0,
-                 distribution_mode=None):
+                 distribution_mode=None, render_mode=None, render_size=(512, 512)):
         from .vec_env import ProcgenVecEnv
         super().__init__(ProcgenVecEnv(game, num_envs, device=device, seed_base=seed, env_offset=env_offset,
                                        num_levels=num_levels, start_level=start_level,
-                                       distribution_mode=distribution_mode), output=output)
+                                       distribution_mode=distribution_mode), output=output, render_mode=render_mode,
+                         render_size=render_size)
         self.game = game

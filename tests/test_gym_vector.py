@@ -52,6 +52,11 @@ class OracleEngine:
             self._grab(i)
         return self.obs, self.reward, self.done
 
+    def render_frame(self, index=0, width=512, height=512):
+        out = np.zeros((height, width, 3), np.uint8)
+        self.L.pgo_render_frame(self.h[index], width, height, out.ctypes.data_as(ctypes.c_void_p))
+        return out
+
     def close(self):
         for h in self.h:
             self.L.pgo_close(h)
@@ -127,3 +132,21 @@ def test_wrapper_over_the_hip_engine_matches_the_oracle_engine():
         assert not bool(ug.any())
     gpu.close()
     cpu.close()
+
+
+def test_render_returns_the_human_frame_only_in_rgb_array_mode():
+    env = GymVectorAdapter(OracleEngine("maze", 2), output="numpy")
+    env.reset()
+    assert env.render() is None
+    env.close()
+    env = GymVectorAdapter(OracleEngine("maze", 2), output="numpy", render_mode="rgb_array", render_size=(96, 80))
+    obs, _ = env.reset()
+    frame = env.render(index=1)
+    assert frame.shape == (80, 96, 3) and frame.dtype == np.uint8 and frame.any()
+    small = GymVectorAdapter(OracleEngine("maze", 2), output="numpy", render_mode="rgb_array", render_size=(64, 64))
+    obs2, _ = small.reset()
+    assert np.array_equal(small.render(index=0), obs2[0])  # at 64×64 the human frame is the observation
+    with pytest.raises(ValueError):
+        GymVectorAdapter(OracleEngine("maze", 1), render_mode="human")
+    env.close()
+    small.close()
