@@ -624,7 +624,12 @@ PG_D void wave_store_obs(const uint32_t* fb, uint8_t* obs_env, int lane, int hal
         o.a = p.x | (p.y << 24);
         o.b = (p.y >> 8) | (p.z << 16);
         o.c = (p.z >> 16) | (p.w << 8);
-        out[g] = o;
+        // Streaming stores (`global_store_dwordx3 … nt`): the 12 KB of an observation are written once and not read
+        // again by this launch; keeping them out of the L2's way leaves it to the atlas and the state (measured:
+        // render 0.728 → 0.681 ms, coinrun 66.5 → 70.6 M env-steps/s).
+        __builtin_nontemporal_store(o.a, &out[g].a);
+        __builtin_nontemporal_store(o.b, &out[g].b);
+        __builtin_nontemporal_store(o.c, &out[g].c);
     }
 }
 
