@@ -38,7 +38,10 @@ def measured_traffic(game):
         return None, None
     with open(files[-1]) as f:
         data = json.load(f)
-    entry = data.get("pg::%s::render_kernel" % game)
+    entry = None
+    for name, value in data.items():  # "pg::variant0::<game>::render_kernel" (default distribution mode)
+        if name.endswith("::%s::render_kernel" % game) and ("variant" not in name or "variant0::" in name):
+            entry = value
     if not entry:
         return None, None
     return entry["bytes_corrected"], os.path.relpath(files[-1], ROOT)

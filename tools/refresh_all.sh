@@ -1,0 +1,20 @@
+#!/bin/bash
+# Round-end refresh on the GPU box: bench lines of every game + mixed, rocprof kernel stats and PMC traffic of the
+# headline run.  Everything lands in gpurun_out/<tag>_*.
+R=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=${1:-r01_final}
+cd $R
+for G in coinrun maze bossfight climber caveflyer chaser jumper; do
+  python bench.py --game $G 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_$G.json
+done
+python bench.py --workload mixed 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_mixed.json
+( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/ks_final && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_final -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/${TAG}_rocprof.log 2>&1; cp $(ls /tmp/ks_final/*/*kernel_stats.csv | head -1) $R/gpurun_out/${TAG}_coinrun_kernel_stats.csv )
+tools/pmc_traffic.sh ${TAG} > gpurun_out/${TAG}_pmc.log 2>&1
+for f in gpurun_out/${TAG}_bench_*.json; do python - "$f" <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1])); c=d["config"]
+print(c.get("game","mixed"), round(d["value"]/1e6,1), "M env-steps/s", round(d["ms_per_step"],3), "ms", "roofline", round(d.get("roofline",{}).get("frac",0),3))
+PY
+done
+head -4 gpurun_out/${TAG}_coinrun_kernel_stats.csv | cut -c1-200
+cat gpurun_out/${TAG}_traffic.json | head -20
