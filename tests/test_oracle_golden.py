@@ -32,10 +32,10 @@ def test_reference_reward_done_trace(oracle_lib, trace):
     assert list(lens)[:len(want)] == want
 
 
-def _frame_crcs(game, seed, steps):
+def _frame_crcs(game, seed, steps, mode=0):
     oracle_util.register_textures(game)
     L = oracle_util.oracle()
-    h = L.pgo_make(game.encode(), seed, 1)
+    h = L.pgo_make_mode(game.encode(), seed, 1, mode)
     L.pgo_reset(h, 0, 0)
     out = []
     s = 1
@@ -57,6 +57,17 @@ def test_oracle_frame_checksums(game):
     for key, want in gold[game].items():
         seed, steps = (int(v) for v in key.split(":"))
         assert _frame_crcs(game, seed, steps) == want, "%s seed %d" % (game, seed)
+
+
+def test_oracle_frame_checksums_in_every_distribution_mode():
+    """The non-default distribution modes (tests/test_modes.py) have no reference trace; these checksums of the
+    oracle's own frames at least keep its reading of them from drifting unnoticed."""
+    with open(os.path.join(GOLDEN, "oracle_mode_frames.json")) as f:
+        gold = json.load(f)
+    assert len(gold) == 12
+    for key, want in gold.items():
+        game, mode, seed, steps = key.split(":")
+        assert _frame_crcs(game, int(seed), int(steps), int(mode)) == want, key
 
 
 def test_oracle_reset_frame_has_no_sprites_and_reseed_repeats():
