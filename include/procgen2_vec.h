@@ -74,7 +74,14 @@ typedef struct pgv_config {
     int32_t env_offset;
     int32_t num_levels, start_level; /* pgv_make_levels */
     int32_t mode;                    /* PGV_MODE_* */
+    uint32_t game_flags;             /* game-specific generator switches, 0 = the reference's defaults (below) */
 } pgv_config;
+/* coinrun: System_Tilemap::Config's allow_pit / allow_crate / allow_dy / allow_mobs (coinrun/tilemap.h:42-45, all true
+ * in the reference; tilemap.cpp:158,174,250,258), as switches that turn a feature OFF.  Other games take 0 only. */
+#define PGV_COINRUN_NO_PIT 1u
+#define PGV_COINRUN_NO_CRATE 2u
+#define PGV_COINRUN_NO_DY 4u
+#define PGV_COINRUN_NO_MOBS 8u
 PGV_API int32_t pgv_make_config(const pgv_config* config, pgv_env** out);
 PGV_API uint32_t pgv_game_modes(int32_t game_id);
 PGV_API int32_t pgv_mode(pgv_env* env); /* the resolved mode (never PGV_MODE_DEFAULT) */

@@ -32,12 +32,18 @@ int pgo_resolve_mode(const char* game, int mode) {
 }
 
 void* pgo_make_mode(const char* game, uint32_t seed, int render_enabled, int mode);
+void* pgo_make_config(const char* game, uint32_t seed, int render_enabled, int mode, uint32_t flags);
 
 // game: one of the seven names.  Returns nullptr for unknown games.
 void* pgo_make(const char* game, uint32_t seed, int render_enabled) { return pgo_make_mode(game, seed, render_enabled, 0); }
 
 void* pgo_make_mode(const char* game, uint32_t seed, int render_enabled, int mode) {
+    return pgo_make_config(game, seed, render_enabled, mode, 0);
+}
+
+void* pgo_make_config(const char* game, uint32_t seed, int render_enabled, int mode, uint32_t flags) {
     std::string g(game);
+    if (flags != 0 && (g != "coinrun" || (flags & ~15u))) return nullptr;  // PGV_COINRUN_NO_* only
     const int resolved = pgo_resolve_mode(game, mode);
     if (resolved < 0) return nullptr;
     Env* e = nullptr;
@@ -58,6 +64,7 @@ void* pgo_make_mode(const char* game, uint32_t seed, int render_enabled, int mod
     if (!e) return nullptr;
     e->set_render_enabled(render_enabled != 0);
     e->set_mode(resolved);
+    e->set_flags(flags);
     e->make(seed);
     return e;
 }
@@ -144,6 +151,7 @@ struct VecState {
     // level-seed mode (include/procgen2_vec.h pgv_make_levels); num_levels 0 = off
     std::string game;
     int render = 0, num_levels = 0, start_level = 0, mode = 0;
+    uint32_t flags = 0;
     std::vector<uint32_t> chain_seed, drawn;
 };
 
@@ -159,18 +167,19 @@ static void vec_new_level(VecState* v, int i, bool restart, uint32_t seed) {
         const uint32_t number = static_cast<uint32_t>(v->start_level) +
                                 mix32(mix32(v->chain_seed[i]) + k) % static_cast<uint32_t>(v->num_levels);
         delete v->envs[i];
-        v->envs[i] = static_cast<Env*>(pgo_make_mode(v->game.c_str(), number, v->render, v->mode));
+        v->envs[i] = static_cast<Env*>(pgo_make_config(v->game.c_str(), number, v->render, v->mode, v->flags));
         v->envs[i]->present();
     } else {
         v->envs[i]->reset(restart, static_cast<int32_t>(seed));
     }
 }
 
-void* pgo_vec_make_config(const char* game, int n, uint32_t seed_base, int env_offset, int render_enabled,
-                          int num_levels, int start_level, int mode) {
+void* pgo_vec_make_flags(const char* game, int n, uint32_t seed_base, int env_offset, int render_enabled,
+                         int num_levels, int start_level, int mode, uint32_t flags) {
     auto* v = new VecState();
     v->game = game;
     v->mode = mode;
+    v->flags = flags;
     v->render = render_enabled;
     v->num_levels = num_levels;
     v->start_level = start_level;
@@ -178,7 +187,7 @@ void* pgo_vec_make_config(const char* game, int n, uint32_t seed_base, int env_o
     v->drawn.assign(n, 0);
     for (int i = 0; i < n; i++) {
         const uint32_t seed = seed_base + static_cast<uint32_t>(env_offset + i);
-        Env* e = static_cast<Env*>(pgo_make_mode(game, seed, render_enabled, mode));  // level 0, never observed (D1)
+        Env* e = static_cast<Env*>(pgo_make_config(game, seed, render_enabled, mode, flags));  // level 0, never observed (D1)
         if (!e) {
             delete v;
             return nullptr;
@@ -192,6 +201,10 @@ void* pgo_vec_make_config(const char* game, int n, uint32_t seed_base, int env_o
     return v;
 }
 
+void* pgo_vec_make_config(const char* game, int n, uint32_t seed_base, int env_offset, int render_enabled,
+                          int num_levels, int start_level, int mode) {
+    return pgo_vec_make_flags(game, n, seed_base, env_offset, render_enabled, num_levels, start_level, mode, 0);
+}
 void* pgo_vec_make_levels(const char* game, int n, uint32_t seed_base, int env_offset, int render_enabled,
                           int num_levels, int start_level) {
     return pgo_vec_make_config(game, n, seed_base, env_offset, render_enabled, num_levels, start_level, 0);

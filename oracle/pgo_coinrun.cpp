@@ -260,13 +260,13 @@ void Coinrun::build_level() {  // tilemap.cpp:97-292
     for (int s = 0; s < sections; s++) {
         if (cx + 15 >= W) break;
         const int bump = difficulty / 3;
-        int dy = rng_.irange(1 + bump, 4 + bump);
+        int dy = (flags_ & 4u) ? 0 : rng_.irange(1 + bump, 4 + bump);  // cfg.allow_dy ? dy_dist(rng) : 0 (tilemap.cpp:158)
         dy = std::min(dy, max_dy);
         if (cy >= 20 || (cy >= 5 && rng_.unit() < 0.5f)) dy = -dy;
         const int dx = rng_.irange(3 + bump, 2 * difficulty + 2 + bump);
         cy = std::max(1, cy + dy);
 
-        const bool pit = (dx > 7) && (cy > 3) && (rng_.irange(0, 19) >= pit_thresh);
+        const bool pit = !(flags_ & 1u) && (dx > 7) && (cy > 3) && (rng_.irange(0, 19) >= pit_thresh);  // allow_pit (:174)
         if (pit) {
             int x1 = rng_.irange(1, 3);
             int x2 = rng_.irange(1, 3);
@@ -307,11 +307,11 @@ void Coinrun::build_level() {  // tilemap.cpp:97-292
                 ob1 = cx + rng_.irange(1, dx - 2);
                 add_saw(ob1, cy);
             }
-            if (rng_.irange(0, 9) < difficulty && dx > 3 && max_dx >= 4) {
+            if (!(flags_ & 8u) && rng_.irange(0, 9) < difficulty && dx > 3 && max_dx >= 4) {  // allow_mobs (:250)
                 ob1 = cx + rng_.irange(1, dx - 2);
                 add_mob(ob1, cy);
             }
-            for (int i = 0; i < 2; i++) {
+            for (int i = 0; i < ((flags_ & 2u) ? 0 : 2); i++) {  // allow_crate (:258)
                 int crate_x = cx + rng_.irange(1, dx - 2);
                 if (rng_.unit() < 0.5f && ob1 != crate_x && ob2 != crate_x) {
                     int pile = rng_.irange(1, 3);

@@ -46,6 +46,8 @@ class Env {
     // (include/procgen2_vec.h PGV_MODE_*; always a resolved value here, never "default").  Set before make().
     enum Mode { kEasy = 1, kHard = 2, kMemory = 3, kExtreme = 4 };
     void set_mode(int mode) { mode_ = mode; }
+    // include/procgen2_vec.h pgv_config.game_flags (coinrun: PGV_COINRUN_NO_*).  Set before make().
+    void set_flags(uint32_t flags) { flags_ = flags; }
 
     // cenv_render (coinrun.cpp:393-411): render_game(false) into a width×height target, packed RGB.  The reference
     // leaves its global camera scale/size at the window's values afterwards (only bossfight's reset reads them, D15);
@@ -95,6 +97,7 @@ class Env {
     }
 
     int mode_ = kHard;
+    uint32_t flags_ = 0;
     int view_w_ = kObsW, view_h_ = kObsH;  // `width`, `height` of render_game(is_obs): the target being painted
     Rng rng_;
     Surface surface_;

@@ -26,6 +26,7 @@
 //   C. resolve_kernel (lane = env): the first sub-step that terminates (hazard, lava, coin) decides how many
 //      sub-steps really happened; in the rare case that is fewer than four, that env's entities are redone from
 //      the untouched half with that limit.  Writes reward / done and commits the agent.
+#include "../../include/procgen2_vec.h"
 #include "pg_engine.h"
 #include "pg_frame.h"
 #include "pg_geom.h"
@@ -100,6 +101,7 @@ struct State {
     uint8_t* db;     // [2][kMaxEnt][n]
     float* spark;    // [2][3][kMaxEnt][kSparks][n]       x, y, life
     float* scratch;  // [SC_COUNT][n]                     hand-off between the three logic kernels of a step
+    uint32_t no;     // generator switches turned off (PGV_COINRUN_NO_*: coinrun/tilemap.h:42-45 allow_* = false)
 };
 
 // scratch rows: the agent after each of the 4 sub-steps, then one word of flags
@@ -165,6 +167,7 @@ struct LevelBuilder {
     uint32_t* mt;
     int lane;
     TileMap map;
+    uint32_t no;  // PGV_COINRUN_NO_* (wave-uniform); a switched-off feature also skips its draws, as `&&` / `?:` do
     int n_ent = 0, n_mob = 0;
 
     PG_D int spawn(float x, float y, int kind, int tex, float vx) {
@@ -212,13 +215,14 @@ struct LevelBuilder {
         for (int sec = 0; sec < sections; sec++) {
             if (cx + 15 >= W) break;
             const int bump = difficulty / 3;
-            int dy = wave_rng_int(mt, 1 + bump, 4 + bump, lane);
+            int dy = (no & PGV_COINRUN_NO_DY) ? 0 : wave_rng_int(mt, 1 + bump, 4 + bump, lane);  // tilemap.cpp:158
             dy = dy < max_dy ? dy : max_dy;
             if (cy >= 20 || (cy >= 5 && wave_rng_real(mt, 0.0f, 1.0f, lane) < 0.5f)) dy = -dy;
             const int dx = wave_rng_int(mt, 3 + bump, 2 * difficulty + 2 + bump, lane);
             cy = (cy + dy) > 1 ? (cy + dy) : 1;
 
-            const bool pit = (dx > 7) && (cy > 3) && (wave_rng_int(mt, 0, 19, lane) >= pit_thresh);
+            const bool pit = !(no & PGV_COINRUN_NO_PIT) && (dx > 7) && (cy > 3) &&  // tilemap.cpp:174
+                             (wave_rng_int(mt, 0, 19, lane) >= pit_thresh);
             if (pit) {
                 int x1 = wave_rng_int(mt, 1, 3, lane);
                 int x2 = wave_rng_int(mt, 1, 3, lane);
@@ -260,11 +264,12 @@ struct LevelBuilder {
                     ob1 = cx + wave_rng_int(mt, 1, dx - 2, lane);
                     add_saw(ob1, cy);
                 }
-                if (wave_rng_int(mt, 0, 9, lane) < difficulty && dx > 3 && max_dx >= 4) {
+                if (!(no & PGV_COINRUN_NO_MOBS) && wave_rng_int(mt, 0, 9, lane) < difficulty && dx > 3 &&  // :250
+                    max_dx >= 4) {
                     ob1 = cx + wave_rng_int(mt, 1, dx - 2, lane);
                     add_mob(ob1, cy);
                 }
-                for (int k = 0; k < 2; k++) {
+                for (int k = 0; k < ((no & PGV_COINRUN_NO_CRATE) ? 0 : 2); k++) {  // tilemap.cpp:258
                     const int crate_x = cx + wave_rng_int(mt, 1, dx - 2, lane);
                     if (wave_rng_real(mt, 0.0f, 1.0f, lane) < 0.5f && ob1 != crate_x && ob2 != crate_x) {
                         const int pile = wave_rng_int(mt, 1, 3, lane);
@@ -318,7 +323,7 @@ PG_D void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, u
     }
     __syncthreads();
     uint32_t* mt = L.mt;
-    LevelBuilder lb{lv, mt, lane, TileMap{lv.tiles, lane}};
+    LevelBuilder lb{lv, mt, lane, TileMap{lv.tiles, lane}, s.no};
     lb.build();
     const int backdrop = wave_rng_int(mt, 0, 48, lane);
     const float shift = wave_rng_real(mt, 0.0f, 1.0f, lane);
@@ -1074,6 +1079,11 @@ __global__ void __launch_bounds__(kFrameThreads) frame_kernel(State s, AtlasView
 class CoinrunGame final : public Game {
    public:
     const char* name() const override { return "coinrun"; }
+    bool set_game_flags(uint32_t flags) override {
+        const uint32_t known = PGV_COINRUN_NO_PIT | PGV_COINRUN_NO_CRATE | PGV_COINRUN_NO_DY | PGV_COINRUN_NO_MOBS;
+        s_.no = flags & known;
+        return (flags & ~known) == 0;
+    }
 
     std::vector<std::string> texture_names() const override {
         static const char* themes[6] = {"Dirt", "Grass", "Planet", "Sand", "Snow", "Stone"};

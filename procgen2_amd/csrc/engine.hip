@@ -141,6 +141,7 @@ static const Variant* find_variant(int game, int mode) {
 // ------------------------------------------------------------------------------------------------
 struct pgv_env {
     int n = 0, device = 0, env_offset = 0, mode = 0;
+    uint32_t game_flags = 0;
     uint32_t step_index = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -285,6 +286,9 @@ int32_t pgv_make_config(const pgv_config* cfg, pgv_env** out) {
     e->env_offset = env_offset;
     e->game = variant->make();
     e->mode = variant->mode;
+    e->game_flags = cfg->game_flags;
+    if (!e->game->set_game_flags(cfg->game_flags))
+        return fail(std::string("pgv_make: game '") + game + "' does not take game_flags " + std::to_string(cfg->game_flags));
     if (stream) {
         e->stream = static_cast<hipStream_t>(stream);
     } else {
@@ -431,6 +435,7 @@ struct SnapshotHeader {
     uint64_t state_bytes;
     uint32_t step_index;
     int32_t num_levels, start_level, mode;
+    uint32_t game_flags, reserved;
 };
 static constexpr uint32_t kSnapshotMagic = 0x50474e32u;  // "PGN2"
 
@@ -449,7 +454,7 @@ int32_t pgv_save_state(pgv_env* e, void* h_buffer, int64_t capacity) {
     if (e->side) PG_HIP(hipStreamSynchronize(e->side));
     uint8_t* out = static_cast<uint8_t*>(h_buffer);
     SnapshotHeader hd{kSnapshotMagic, static_cast<uint32_t>(pgv_game_id(e->game->name())), e->n, e->env_offset,
-                      state_blob_bytes(e), e->step_index, e->game->plan.num_levels, e->game->plan.start_level, e->mode};
+                      state_blob_bytes(e), e->step_index, e->game->plan.num_levels, e->game->plan.start_level, e->mode, e->game_flags, 0};
     std::memcpy(out, &hd, sizeof(hd));
     out += sizeof(hd);
     PG_HIP(hipMemcpy(out, e->d_state, hd.state_bytes, hipMemcpyDeviceToHost));
@@ -472,7 +477,8 @@ int32_t pgv_load_state(pgv_env* e, const void* h_buffer, int64_t size) {
     std::memcpy(&hd, in, sizeof(hd));
     if (hd.magic != kSnapshotMagic || hd.game != static_cast<uint32_t>(pgv_game_id(e->game->name())) || hd.n != e->n ||
         hd.env_offset != e->env_offset || hd.state_bytes != state_blob_bytes(e) ||
-        hd.num_levels != e->game->plan.num_levels || hd.start_level != e->game->plan.start_level || hd.mode != e->mode)
+        hd.num_levels != e->game->plan.num_levels || hd.start_level != e->game->plan.start_level || hd.mode != e->mode ||
+        hd.game_flags != e->game_flags)
         return fail("pgv_load_state: snapshot of a different env (game, mode, size, shard or level set)");
     PG_HIP(hipSetDevice(e->device));
     PG_HIP(hipStreamSynchronize(e->stream));
@@ -681,13 +687,13 @@ int32_t cenv_make(const char* render_mode, cenv_option* options, int32_t options
     (void)render_mode;
     if (g.env) cenv_close();
     int seed = static_cast<int>(time(nullptr));  // coinrun.cpp:130
-    int num_envs = 1, game = PG_DEFAULT_GAME, device = 0, env_offset = 0, num_levels = 0, start_level = 0, mode = 0;
+    int num_envs = 1, game = PG_DEFAULT_GAME, device = 0, env_offset = 0, num_levels = 0, start_level = 0, mode = 0, game_flags = 0;
     for (int i = 0; i < options_size; i++) {
         const std::string name(options[i].name ? options[i].name : "");
         int v = 0;
         if (name == "seed" || name == "width" || name == "height" || name == "num_envs" || name == "game" ||
             name == "device" || name == "env_offset" || name == "num_levels" || name == "start_level" ||
-            name == "distribution_mode") {
+            name == "distribution_mode" || name == "game_flags") {
             if (opt_int(options[i], &v)) return fail("cenv_make: option '" + name + "' must be INT");
         }
         if (name == "seed")
@@ -710,6 +716,8 @@ int32_t cenv_make(const char* render_mode, cenv_option* options, int32_t options
             start_level = v;
         else if (name == "distribution_mode")
             mode = v;
+        else if (name == "game_flags")
+            game_flags = v;
     }
     const char* gname = pgv_game_name(game);
     if (!gname) return fail("cenv_make: unknown game id");
@@ -723,6 +731,7 @@ int32_t cenv_make(const char* render_mode, cenv_option* options, int32_t options
     cfg.num_levels = num_levels;
     cfg.start_level = start_level;
     cfg.mode = mode;
+    cfg.game_flags = static_cast<uint32_t>(game_flags);
     int rc = pgv_make_config(&cfg, &g.env);
     if (rc) return rc;
     g.n = num_envs;

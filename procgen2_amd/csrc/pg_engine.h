@@ -93,6 +93,8 @@ class Game {
     // Debug tap used by the parity tests: game-defined float dump of one env (host pointer).
     virtual int dump_state(hipStream_t s, int env, float* out, int cap) = 0;
     virtual int dump_tiles(hipStream_t s, int env, uint8_t* out, int cap) = 0;
+    // pgv_config.game_flags (include/procgen2_vec.h); false = this game does not know these switches.
+    virtual bool set_game_flags(uint32_t flags) { return flags == 0; }
     // Host-side sanity check of the loaded atlas (sizes[i] = {w, h} of texture i); empty string = fine.
     virtual std::string check_atlas(const std::vector<std::pair<int, int>>& sizes) const { return ""; }
 

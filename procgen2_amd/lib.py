@@ -23,7 +23,7 @@ class Config(ctypes.Structure):
     """include/procgen2_vec.h `pgv_config`."""
     _fields_ = [("struct_size", c_uint32), ("num_envs", c_int32), ("game", c_char_p), ("stream", c_void_p),
                 ("device", c_int32), ("seed_base", c_uint32), ("env_offset", c_int32), ("num_levels", c_int32),
-                ("start_level", c_int32), ("mode", c_int32)]
+                ("start_level", c_int32), ("mode", c_int32), ("game_flags", c_uint32)]
 
 
 def mode_id(mode):
@@ -36,10 +36,15 @@ def mode_id(mode):
     return int(mode)
 
 
-def make(lib, game, num_envs, device=0, seed_base=1, env_offset=0, stream=None, num_levels=0, start_level=0, mode=None):
+# include/procgen2_vec.h PGV_COINRUN_NO_*
+COINRUN_NO_PIT, COINRUN_NO_CRATE, COINRUN_NO_DY, COINRUN_NO_MOBS = 1, 2, 4, 8
+
+
+def make(lib, game, num_envs, device=0, seed_base=1, env_offset=0, stream=None, num_levels=0, start_level=0, mode=None,
+         game_flags=0):
     """pgv_make_config → env handle (c_void_p)."""
     cfg = Config(ctypes.sizeof(Config), int(num_envs), game.encode(), stream, int(device), int(seed_base) & 0xFFFFFFFF,
-                 int(env_offset), int(num_levels), int(start_level), mode_id(mode))
+                 int(env_offset), int(num_levels), int(start_level), mode_id(mode), int(game_flags))
     h = c_void_p()
     check(lib, lib.pgv_make_config(ctypes.byref(cfg), ctypes.byref(h)), "pgv_make")
     return h

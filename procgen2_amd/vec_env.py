@@ -28,7 +28,7 @@ def shard_range(total_envs, world_size, rank):
 
 class ProcgenVecEnv:
     def __init__(self, game, num_envs, device=0, seed_base=1, env_offset=0, lib_path=None, num_levels=0,
-                 start_level=0, distribution_mode=None):
+                 start_level=0, distribution_mode=None, game_flags=0):
         if not torch.cuda.is_available():
             raise pglib.EngineError("ProcgenVecEnv needs a HIP device (torch.cuda.is_available() is False); "
                                     "there is no CPU fallback")
@@ -48,7 +48,7 @@ class ProcgenVecEnv:
         # "extreme" where the game has it (pgv_game_modes).
         h = pglib.make(self.L, game, self.num_envs, device=device, seed_base=seed_base, env_offset=self.env_offset,
                        stream=c_void_p(self._stream.cuda_stream), num_levels=num_levels, start_level=start_level,
-                       mode=distribution_mode)
+                       mode=distribution_mode, game_flags=game_flags)
         self.num_levels, self.start_level = int(num_levels), int(start_level)
         self.distribution_mode = {v: k for k, v in pglib.MODES.items()}[self.L.pgv_mode(h)]
         self._h = h

@@ -16,11 +16,11 @@ OBS_BYTES = pglib.OBS_BYTES
 
 
 class EngineVec:
-    def __init__(self, game, n, seed_base=1, env_offset=0, device=0, lib_path=None, num_levels=0, start_level=0, mode=None):
+    def __init__(self, game, n, seed_base=1, env_offset=0, device=0, lib_path=None, num_levels=0, start_level=0, mode=None, game_flags=0):
         self.L = pglib.load(lib_path)
         self.n = n
         self.h = pglib.make(self.L, game, n, device=device, seed_base=seed_base, env_offset=env_offset,
-                            num_levels=num_levels, start_level=start_level, mode=mode)
+                            num_levels=num_levels, start_level=start_level, mode=mode, game_flags=game_flags)
         self.obs = np.zeros((n, OBS_BYTES), np.uint8)
         self.reward = np.zeros(n, np.float32)
         self.done = np.zeros(n, np.uint8)

@@ -55,6 +55,8 @@ def oracle():
     L.pgo_vec_make_levels.argtypes = [c_char_p, c_int, c_uint32, c_int, c_int, c_int, c_int]
     L.pgo_vec_make_config.restype = c_void_p
     L.pgo_vec_make_config.argtypes = [c_char_p, c_int, c_uint32, c_int, c_int, c_int, c_int, c_int]
+    L.pgo_vec_make_flags.restype = c_void_p
+    L.pgo_vec_make_flags.argtypes = [c_char_p, c_int, c_uint32, c_int, c_int, c_int, c_int, c_int, c_uint32]
     L.pgo_make_mode.restype = c_void_p
     L.pgo_make_mode.argtypes = [c_char_p, c_uint32, c_int, c_int]
     L.pgo_resolve_mode.argtypes = [c_char_p, c_int]
@@ -96,14 +98,14 @@ def register_textures(game):
 class OracleVec:
     """N oracle envs stepped in lock-step with the engine's auto-reset policy (oracle/pgo_api.cpp)."""
 
-    def __init__(self, game, n, seed_base=1, env_offset=0, render=True, num_levels=0, start_level=0, mode=0):
+    def __init__(self, game, n, seed_base=1, env_offset=0, render=True, num_levels=0, start_level=0, mode=0, game_flags=0):
         if render:
             register_textures(game)
         self.L = oracle()
         self.n = n
         self.env_offset = env_offset
-        self.h = self.L.pgo_vec_make_config(game.encode(), n, seed_base, env_offset, 1 if render else 0, num_levels,
-                                            start_level, mode)
+        self.h = self.L.pgo_vec_make_flags(game.encode(), n, seed_base, env_offset, 1 if render else 0, num_levels,
+                                           start_level, mode, game_flags)
         assert self.h, "oracle does not know game %r" % game
         self.obs = np.zeros((n, OBS_BYTES), np.uint8)
         self.reward = np.zeros(n, np.float32)
