@@ -714,13 +714,48 @@ __global__ void __launch_bounds__(64) agent_kernel(State s, const int32_t* actio
     agent_substeps(s, env, action);
 }
 
-// B — lane = env, blockIdx.y = entity slot: all four sub-steps of one entity (optimistic: no early termination).
+// B — the entities of a step.  One workgroup = one wavefront = a block of 64 envs.
+//   blockIdx.y ≥ kMaxEnt: lane = env, entity id y − kMaxEnt unless it is a mob (saws and coins: cheap, coalesced).
+//   blockIdx.y < kMaxEnt: the mobs.  Their path is ~5 000 instructions (tile window, two collision probes per
+//     sub-step, sparks) and a level has between none and a dozen of them, so "row y = the y-th mob of every env" ran
+//     that path max-over-the-block times with mostly idle lanes (SQ counters: 78 M wave instructions per launch, the
+//     kernel is issue-bound).  Instead the (env, mob) pairs of the block are numbered densely — a wave prefix sum over
+//     the 64 mob counts — and row y takes pairs [64y, 64y + 64): full waves, about mean-instead-of-max many of them.
 __global__ void __launch_bounds__(64) entity_kernel(State s) {
-    const int env = blockIdx.x * blockDim.x + threadIdx.x;
-    const int e = blockIdx.y;
-    if (env >= s.n) return;
-    if (e >= SI(s, I_NENT, env)) return;
-    if (SCI(s, SC_BITS, env) >= 0) return;  // bit 31 clear: this env performed its reset instead
+    const int lane = threadIdx.x;
+    int env = blockIdx.x * 64 + lane;
+    int e;
+    if (blockIdx.y < kMaxEnt) {
+        const bool stepping = env < s.n && SCI(s, SC_BITS, env) < 0;  // bit 31 clear: the env reset instead
+        const int count = stepping ? SI(s, I_NMOB, env) : 0;
+        int upto = count;  // inclusive prefix sum over the block
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(upto, off);
+            if (lane >= off) upto += t;
+        }
+        const int total = __shfl(upto, 63);
+        const int pair = static_cast<int>(blockIdx.y) * 64 + lane;
+        if (static_cast<int>(blockIdx.y) * 64 >= total) return;  // wave-uniform
+        int lo = 0, hi = 63;  // owner of `pair`: the first lane whose inclusive sum exceeds it
+#pragma unroll
+        for (int it = 0; it < 6; it++) {
+            const int mid = (lo + hi) >> 1;
+            const bool right = __shfl(upto, mid) <= pair;
+            lo = right ? mid + 1 : lo;
+            hi = right ? hi : mid;
+        }
+        const int before = __shfl(upto, lo) - __shfl(count, lo);
+        if (pair >= total) return;
+        env = blockIdx.x * 64 + lo;
+        e = EB(s, EB_SPARK_ORDER, pair - before, env);
+    } else {
+        if (env >= s.n) return;
+        e = blockIdx.y - kMaxEnt;
+        if (e >= SI(s, I_NENT, env)) return;
+        if (EB(s, EB_KIND, e, env) == kMob) return;
+        if (SCI(s, SC_BITS, env) >= 0) return;  // bit 31 clear: this env performed its reset instead
+    }
     float bx[4], by[4];
 #pragma unroll
     for (int ss = 0; ss < 4; ss++) {
@@ -1197,7 +1232,7 @@ class CoinrunGame final : public Game {
         LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io, plan);
         hipLaunchKernelGGL(agent_kernel, dim3(logic_blocks(s_.n)), dim3(logic_lanes()), 0, st, s_, actions, run_seed, step_index,
                            env_offset, io);
-        hipLaunchKernelGGL(entity_kernel, dim3(logic_blocks(s_.n), kMaxEnt), dim3(logic_lanes()), 0, st, s_);
+        hipLaunchKernelGGL(entity_kernel, dim3((s_.n + 63) / 64, 2 * kMaxEnt), dim3(64), 0, st, s_);
         hipLaunchKernelGGL(resolve_kernel, dim3(logic_blocks(s_.n)), dim3(logic_lanes()), 0, st, s_, io);
     }
     bool launch_frame(hipStream_t st, int env, uint32_t* d_px, int w, int h) override {

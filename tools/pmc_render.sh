@@ -13,7 +13,7 @@ for fn in f:
         k=r["Kernel_Name"].split("(")[0]
         agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); cnt[(k,r["Counter_Name"])]+=1
 for k in agg:
-    if "render" in k or "logic" in k:
+    if "render" in k or "logic" in k or "entity" in k or "agent_kernel" in k:
         print(k)
         for c,v in sorted(agg[k].items()): print("   %-24s %.4g per launch"%(c, v/cnt[(k,c)]))
 PY
