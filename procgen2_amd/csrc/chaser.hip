@@ -46,6 +46,10 @@ constexpr int kOrbs = 4 + kExtraOrbSign, kFirstPoint = kOrbs + kMobs;
 constexpr int kOpenCells = 2 * ((W + 1) / 2) * ((W + 1) / 2) - 1;
 constexpr int kMaxEnt = (kOpenCells - 1 + 7) / 8 * 8;
 constexpr bool kWideCells = kCells > 256;  // cell indices need a second byte
+#ifndef PG_CHASER_SPAN
+#define PG_CHASER_SPAN 1
+#endif
+constexpr int kResetSpan = PG_CHASER_SPAN;  // envs per wavefront of the in-step level kernel (pg_prefetch.h auto_reset)
 static_assert(kMaxEnt <= 255 && kMaxEnt <= kRankMax, "entity ids are bytes; draw lists use the equal-key rank table");
 enum Tile : uint8_t { kEmpty = 0, kWall = 1, kMarker = 2 };
 enum Kind { kOrb = 0, kPoint = 1, kEgg = 2 };
@@ -824,7 +828,7 @@ class ChaserGame final : public Game {
     }
     void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
                       StepIO io) override {
-        LevelLaunch<Gen>::auto_reset(st, s_, 0, io, plan);
+        LevelLaunch<Gen>::auto_reset(st, s_, 0, io, plan, kResetSpan);
         hipLaunchKernelGGL(logic_kernel, dim3(logic_blocks(s_.n)), dim3(logic_lanes()), 0, st, s_, actions, run_seed, step_index,
                            env_offset, io);
     }

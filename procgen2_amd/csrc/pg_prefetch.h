@@ -189,9 +189,13 @@ struct LevelLaunch {
         hipLaunchKernelGGL(level_kernel<G>, dim3(s.n), dim3(64), 0, st, s, 1, 1, prefetch, 0u, 0, mask, seeds, io,
                            plan);
     }
-    static void auto_reset(hipStream_t st, const typename G::State& s, int prefetch, StepIO io, LevelPlan plan) {
-        hipLaunchKernelGGL(level_kernel<G>, dim3((s.n + 63) / 64), dim3(64), 0, st, s, 2, 64, prefetch, 0u, 0, nullptr,
-                           nullptr, io, plan);
+    // span = envs per wavefront, served one after the other.  With prefetch a served env costs a copy, so 64 per wave
+    // is right; a game that generates inside the step (chaser) wants few, or the step waits for the unluckiest wave:
+    // (number of its envs that reset in this step) × (one generation).
+    static void auto_reset(hipStream_t st, const typename G::State& s, int prefetch, StepIO io, LevelPlan plan,
+                           int span = 64) {
+        hipLaunchKernelGGL(level_kernel<G>, dim3((s.n + span - 1) / span), dim3(64), 0, st, s, 2, span, prefetch, 0u, 0,
+                           nullptr, nullptr, io, plan);
     }
     // bulk: most slots are queued (after make / a full reset) → a wavefront per env; otherwise few envs per wave,
     // because the queued envs of one wave are served one after the other.
