@@ -1025,20 +1025,43 @@ __global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, Atla
                 want_tex = kTexWalk1 + alien;
         }
         const int4 d = descs.at(want_tex);
-        bool has = false;
-        if (is_part) {
-            has = particle(part_life, part_x, part_y, mine);
+        // The three kinds of draw differ only in their parameters: pick them per lane, then resolve once.  (One
+        // resolve_draw per kind in its own branch made every wave run its ~180 vector instructions three times.)
+        bool go = false, flip = false;
+        int tw = d.y, th = d.z, tex_at = d.x;
+        float wx = 0.0f, wy = 0.0f, scale_num = kUnitPx, alpha = 1.0f;
+        if (is_part) {  // System_Particles::render (common_systems.cpp:315-337), as `particle` above
+            if (part_life > 0.0f) {
+                const float lr = (5.0f - part_life) / 5.0f;
+                alpha = 0.5f * (1.0f - lr);
+                const float scale = 0.45f * (0.4f * lr + 0.6f);
+                const float oy = -lr * 0.17f;
+                tw = spark_d.y;
+                th = spark_d.z;
+                tex_at = spark_d.x;
+                wx = part_x * kUnitPx - 0.5f * spark_d.y * scale;
+                wy = (part_y + oy) * kUnitPx - 0.5f * spark_d.z * scale;
+                scale_num = scale * kUnitPx;
+                go = true;
+            }
         } else if (is_sprite) {
             if (spr_dyn & kDynTexSet) {
                 const float scale = 1.0f * 1.0f;
-                has = resolve_draw(cam, d.y, d.z, d.x, (spr_x + -0.5f) * kUnitPx, (spr_y + -0.5f) * kUnitPx,
-                                   scale * kUnitPx / d.y, 1.0f, (spr_dyn & kDynFlip) != 0, false, mine);
+                wx = (spr_x + -0.5f) * kUnitPx;
+                wy = (spr_y + -0.5f) * kUnitPx;
+                scale_num = scale * kUnitPx;
+                flip = (spr_dyn & kDynFlip) != 0;
+                go = true;
             }
         } else if (is_agent) {
             const float px = SF(s, F_AX, env) - 0.5f, py = SF(s, F_AY, env) - 2.0f;
-            has = resolve_draw(cam, d.y, d.z, d.x, px * kUnitPx, py * kUnitPx, kUnitPx / d.y, 1.0f,
-                               (sflags & kFlagForward) == 0, false, mine);
+            wx = px * kUnitPx;
+            wy = py * kUnitPx;
+            flip = (sflags & kFlagForward) == 0;
+            go = true;
         }
+        bool has = false;
+        if (go) has = resolve_draw(cam, tw, th, tex_at, wx, wy, scale_num / static_cast<float>(tw), alpha, flip, false, mine);
         wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
     }
     __syncthreads();
