@@ -873,7 +873,9 @@ __global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, Atla
     const bool is_agent = lane == first_sprite + n_sprites;
     int spr_e = 0, spr_dyn = 0, spr_tex = 0;
     float spr_x = 0.0f, spr_y = 0.0f, part_life = 0.0f, part_x = 0.0f, part_y = 0.0f;
-    if (is_sprite) {
+    if (half != 0) {
+        // wave 0 resolves the 64 draws of the sprite pass and hands them over (pg_render.h blit_share)
+    } else if (is_sprite) {
         spr_e = EB(s, EB_DRAW_ORDER, lane - first_sprite, env);
         spr_dyn = DB(s, buf, spr_e, env);
         spr_tex = EB(s, EB_TEX, spr_e, env);
@@ -1009,59 +1011,70 @@ __global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, Atla
                 wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
             }
         }
-        // every lane asks for the descriptor it needs with a cross-lane read, so do that outside the branches
-        int want_tex = 0;
-        if (is_sprite) {
-            want_tex = spr_tex + ((spr_dyn & kDynFrame) ? 1 : 0);
-        } else if (is_agent) {
-            const bool ground = (sflags & kFlagGround) != 0;
-            if (fabsf(SF(s, F_AVX, env)) < 0.01f && ground)
-                want_tex = kTexStand + alien;
-            else if (!ground)
-                want_tex = kTexJump + alien;
-            else if (SF(s, F_APHASE, env) > 0.5f)
-                want_tex = kTexWalk2 + alien;
-            else
-                want_tex = kTexWalk1 + alien;
-        }
-        const int4 d = descs.at(want_tex);
-        // The three kinds of draw differ only in their parameters: pick them per lane, then resolve once.  (One
-        // resolve_draw per kind in its own branch made every wave run its ~180 vector instructions three times.)
-        bool go = false, flip = false;
-        int tw = d.y, th = d.z, tex_at = d.x;
-        float wx = 0.0f, wy = 0.0f, scale_num = kUnitPx, alpha = 1.0f;
-        if (is_part) {  // System_Particles::render (common_systems.cpp:315-337), as `particle` above
-            if (part_life > 0.0f) {
-                const float lr = (5.0f - part_life) / 5.0f;
-                alpha = 0.5f * (1.0f - lr);
-                const float scale = 0.45f * (0.4f * lr + 0.6f);
-                const float oy = -lr * 0.17f;
-                tw = spark_d.y;
-                th = spark_d.z;
-                tex_at = spark_d.x;
-                wx = part_x * kUnitPx - 0.5f * spark_d.y * scale;
-                wy = (part_y + oy) * kUnitPx - 0.5f * spark_d.z * scale;
-                scale_num = scale * kUnitPx;
-                go = true;
-            }
-        } else if (is_sprite) {
-            if (spr_dyn & kDynTexSet) {
-                const float scale = 1.0f * 1.0f;
-                wx = (spr_x + -0.5f) * kUnitPx;
-                wy = (spr_y + -0.5f) * kUnitPx;
-                scale_num = scale * kUnitPx;
-                flip = (spr_dyn & kDynFlip) != 0;
-                go = true;
-            }
-        } else if (is_agent) {
-            const float px = SF(s, F_AX, env) - 0.5f, py = SF(s, F_AY, env) - 2.0f;
-            wx = px * kUnitPx;
-            wy = py * kUnitPx;
-            flip = (sflags & kFlagForward) == 0;
-            go = true;
-        }
+        // The composer's tables are dead by now (its last barrier is behind both waves): their LDS carries the resolved
+        // draws from wave 0 to wave 1.
+        static_assert(sizeof(ComposeLds<kGrid>) >= kBlitWords * 64 * 4, "blit hand-over reuses the composer's LDS");
+        uint32_t* slots = reinterpret_cast<uint32_t*>(&L);
         bool has = false;
-        if (go) has = resolve_draw(cam, tw, th, tex_at, wx, wy, scale_num / static_cast<float>(tw), alpha, flip, false, mine);
+        if (half == 0) {
+            // every lane asks for the descriptor it needs with a cross-lane read, so do that outside the branches
+            int want_tex = 0;
+            if (is_sprite) {
+                want_tex = spr_tex + ((spr_dyn & kDynFrame) ? 1 : 0);
+            } else if (is_agent) {
+                const bool ground = (sflags & kFlagGround) != 0;
+                if (fabsf(SF(s, F_AVX, env)) < 0.01f && ground)
+                    want_tex = kTexStand + alien;
+                else if (!ground)
+                    want_tex = kTexJump + alien;
+                else if (SF(s, F_APHASE, env) > 0.5f)
+                    want_tex = kTexWalk2 + alien;
+                else
+                    want_tex = kTexWalk1 + alien;
+            }
+            const int4 d = descs.at(want_tex);
+            // The three kinds of draw differ only in their parameters: pick them per lane, then resolve once.  (One
+            // resolve_draw per kind in its own branch made every wave run its ~180 vector instructions three times.)
+            bool go = false, flip = false;
+            int tw = d.y, th = d.z, tex_at = d.x;
+            float wx = 0.0f, wy = 0.0f, scale_num = kUnitPx, alpha = 1.0f;
+            if (is_part) {  // System_Particles::render (common_systems.cpp:315-337), as `particle` above
+                if (part_life > 0.0f) {
+                    const float lr = (5.0f - part_life) / 5.0f;
+                    alpha = 0.5f * (1.0f - lr);
+                    const float scale = 0.45f * (0.4f * lr + 0.6f);
+                    const float oy = -lr * 0.17f;
+                    tw = spark_d.y;
+                    th = spark_d.z;
+                    tex_at = spark_d.x;
+                    wx = part_x * kUnitPx - 0.5f * spark_d.y * scale;
+                    wy = (part_y + oy) * kUnitPx - 0.5f * spark_d.z * scale;
+                    scale_num = scale * kUnitPx;
+                    go = true;
+                }
+            } else if (is_sprite) {
+                if (spr_dyn & kDynTexSet) {
+                    const float scale = 1.0f * 1.0f;
+                    wx = (spr_x + -0.5f) * kUnitPx;
+                    wy = (spr_y + -0.5f) * kUnitPx;
+                    scale_num = scale * kUnitPx;
+                    flip = (spr_dyn & kDynFlip) != 0;
+                    go = true;
+                }
+            } else if (is_agent) {
+                const float px = SF(s, F_AX, env) - 0.5f, py = SF(s, F_AY, env) - 2.0f;
+                wx = px * kUnitPx;
+                wy = py * kUnitPx;
+                flip = (sflags & kFlagForward) == 0;
+                go = true;
+            }
+            if (go)
+                has = resolve_draw(cam, tw, th, tex_at, wx, wy, scale_num / static_cast<float>(tw), alpha, flip, false,
+                                   mine);
+            blit_share(slots, lane, mine, has);
+        }
+        __syncthreads();
+        if (half != 0) has = blit_take(slots, lane, mine);
         wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
     }
     __syncthreads();

@@ -105,6 +105,38 @@ PG_D Blit blit_from_lane(const Blit& mine, int src) {
 
 PG_D void blend_into(uint32_t* fb, int idx, uint32_t texel, int mod);
 
+// A resolved, un-rotated draw as six words per lane ([word][lane], 1536 B for a wave): the two wavefronts of an env
+// need the same 64 resolved draws, and resolving them (≈ 180 vector instructions of exact float division) once and
+// handing them over through LDS is cheaper than both doing it.  S1 bounds destination coordinates to ±32767 and
+// texture extents are far below 32768, so halves of a word hold them; word 1 = 0 means "nothing to draw".
+constexpr int kBlitWords = 6;
+PG_D void blit_share(uint32_t* slots, int lane, const Blit& b, bool has) {
+    slots[0 * 64 + lane] = (static_cast<uint32_t>(b.dx) & 0xffffu) | (static_cast<uint32_t>(b.dy) << 16);
+    slots[1 * 64 + lane] = has ? (static_cast<uint32_t>(b.dw) | (static_cast<uint32_t>(b.dh) << 16)) : 0u;
+    slots[2 * 64 + lane] = static_cast<uint32_t>(b.sx) | (static_cast<uint32_t>(b.sy) << 16);
+    slots[3 * 64 + lane] = static_cast<uint32_t>(b.sw) | (static_cast<uint32_t>(b.sh) << 16);
+    slots[4 * 64 + lane] = static_cast<uint32_t>(b.tex_off);
+    slots[5 * 64 + lane] = static_cast<uint32_t>(b.tex_w) | (static_cast<uint32_t>(b.flip_mod) << 16);
+}
+PG_D bool blit_take(const uint32_t* slots, int lane, Blit& b) {
+    const uint32_t w0 = slots[0 * 64 + lane], w1 = slots[1 * 64 + lane], w2 = slots[2 * 64 + lane];
+    const uint32_t w3 = slots[3 * 64 + lane], w4 = slots[4 * 64 + lane], w5 = slots[5 * 64 + lane];
+    b.dx = static_cast<int32_t>(w0 << 16) >> 16;
+    b.dy = static_cast<int32_t>(w0) >> 16;
+    b.dw = static_cast<int32_t>(w1 & 0xffffu);
+    b.dh = static_cast<int32_t>(w1 >> 16);
+    b.sx = static_cast<int32_t>(w2 & 0xffffu);
+    b.sy = static_cast<int32_t>(w2 >> 16);
+    b.sw = static_cast<int32_t>(w3 & 0xffffu);
+    b.sh = static_cast<int32_t>(w3 >> 16);
+    b.tex_off = static_cast<int32_t>(w4);
+    b.tex_w = static_cast<int32_t>(w5 & 0xffffu);
+    b.flip_mod = static_cast<int32_t>(w5 >> 16);
+    b.rot_sn = 0;
+    b.rot_cs = 65536;
+    return w1 != 0u;
+}
+
 // Renderer::render_texture_rotated (games/*/renderer.cpp:84-101) followed by raster-spec S1 and S6: no cull, no
 // crop, whole texture as source, rotation about the centre of the destination rectangle.  `rotation` is the
 // float the reference passes; the angle handed to SDL is rotation * 180.0f / M_PI in double.  An angle of exactly
