@@ -734,15 +734,21 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
             size = 0.05f;
         }
         const int4 d = descs.at(want_tex);
-        if (has) {
+        if (has) {  // the two kinds of draw differ in their parameters only: pick per lane, resolve once
+            float wx, wy, sc, al;
             if (sprite) {  // common_systems.cpp:22-48: offset (-0.15,-0.15), scale 0.3 (bossfight.cpp:479)
                 const float scale = 1.0f * 0.3f;
-                has = resolve_draw(cam, d.y, d.z, d.x, (px + -0.15f) * kUnitPx, (py + -0.15f) * kUnitPx,
-                                   scale * kUnitPx / d.y, 1.0f, false, false, mine);
+                wx = (px + -0.15f) * kUnitPx;
+                wy = (py + -0.15f) * kUnitPx;
+                sc = scale * kUnitPx / d.y;
+                al = 1.0f;
             } else {
-                has = resolve_draw(cam, d.y, d.z, d.x, px * kUnitPx - size * d.y * 0.5f, py * kUnitPx - size * d.z * 0.5f,
-                                   size, alpha, false, false, mine);
+                wx = px * kUnitPx - size * d.y * 0.5f;
+                wy = py * kUnitPx - size * d.z * 0.5f;
+                sc = size;
+                al = alpha;
             }
+            has = resolve_draw(cam, d.y, d.z, d.x, wx, wy, sc, al, false, false, mine);
         }
         wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
     }

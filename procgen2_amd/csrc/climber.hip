@@ -509,19 +509,29 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
                 want_tex = kTexWalk1 + suit;
         }
         const int4 d = descs.at(want_tex);
-        bool has = false;
+        // sprites and the agent differ in their parameters only: pick per lane, resolve once (a resolve_draw per kind
+        // in its own branch is executed by the whole wave once per kind)
+        bool has = false, go = false, flip = false;
+        float wx = 0.0f, wy = 0.0f, scale_num = kUnitPx;
         if (is_sprite) {
             if (spr_info & kTexSet) {
                 const float off = (spr_info & kMob) ? -0.4f : -0.5f;  // tilemap.cpp:53,66
                 const float scale = 1.0f * 1.0f;
-                has = resolve_draw(cam, d.y, d.z, d.x, (spr_x + off) * kUnitPx, (spr_y + off) * kUnitPx,
-                                   scale * kUnitPx / d.y, 1.0f, (spr_info & kFlip) != 0, false, mine);
+                wx = (spr_x + off) * kUnitPx;
+                wy = (spr_y + off) * kUnitPx;
+                scale_num = scale * kUnitPx;
+                flip = (spr_info & kFlip) != 0;
+                go = true;
             }
         } else if (is_agent) {
             const float px = SF(s, F_AX, env) - 0.5f, py = SF(s, F_AY, env) - 1.0f;
-            has = resolve_draw(cam, d.y, d.z, d.x, px * kUnitPx, py * kUnitPx, 0.8f * kUnitPx / d.y, 1.0f,
-                               (sflags & kFlagForward) == 0, false, mine);
+            wx = px * kUnitPx;
+            wy = py * kUnitPx;
+            scale_num = 0.8f * kUnitPx;
+            flip = (sflags & kFlagForward) == 0;
+            go = true;
         }
+        if (go) has = resolve_draw(cam, d.y, d.z, d.x, wx, wy, scale_num / d.y, 1.0f, flip, false, mine);
         wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
     }
     __syncthreads();

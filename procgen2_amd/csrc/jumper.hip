@@ -646,17 +646,19 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
             has = true;
         }
         const int4 d = descs.at(id == 0 ? kTexCarrot : kTexSpike);
-        if (has) {
+        if (has) {  // carrot and spikes differ in their parameters only: pick per lane, resolve once
+            float wx, wy, scale;
             if (id == 0) {
-                const float scale = 1.0f * 1.0f;
-                has = resolve_draw(cam, d.y, d.z, d.x, (SF(s, F_GX, env) + -0.5f) * kUnitPx,
-                                   (SF(s, F_GY, env) + -0.5f) * kUnitPx, scale * kUnitPx / d.y, 1.0f, false, false, mine);
+                scale = 1.0f * 1.0f;
+                wx = (SF(s, F_GX, env) + -0.5f) * kUnitPx;
+                wy = (SF(s, F_GY, env) + -0.5f) * kUnitPx;
             } else {
                 const int cell = s.spike_cell[size_t(id - 2) * s.n + env];
-                const float scale = 1.0f * 0.4f;
-                has = resolve_draw(cam, d.y, d.z, d.x, (cell_x(cell) + -0.25f) * kUnitPx,
-                                   (cell_y(cell) + -0.25f) * kUnitPx, scale * kUnitPx / d.y, 1.0f, false, false, mine);
+                scale = 1.0f * 0.4f;
+                wx = (cell_x(cell) + -0.25f) * kUnitPx;
+                wy = (cell_y(cell) + -0.25f) * kUnitPx;
             }
+            has = resolve_draw(cam, d.y, d.z, d.x, wx, wy, scale * kUnitPx / d.y, 1.0f, false, false, mine);
         }
         wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
     }
