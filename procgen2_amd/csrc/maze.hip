@@ -216,7 +216,8 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
     const int lane = threadIdx.x & 63, half = threadIdx.x >> 6;  // two wavefronts per env (pg_render.h)
     constexpr int halves = 2;
     __shared__ uint32_t fb[kFbWords];
-    constexpr int kGrid = 32;  // ≤ 25 visible tiles + the border cells of the inclusive window
+    constexpr int kGrid = kVisible + 3 <= 20 ? 20 : 28;  // visible tiles + the border cells of the inclusive window; as small as it
+    // may be: the composer tables are LDS, and LDS decides how many envs a CU holds (28: 7 per CU, 32: 6)
     __shared__ ComposeLds<kGrid> L;
 
     // maze.cpp:397-400, 436-437: zoom = 64 / (16 * visible_width); camera at the world centre, or on the agent
