@@ -207,7 +207,10 @@ PG_D bool resolve_screen(int tw, int th, int tex_off, float dx, float dy, float 
 // coordinates its corners (±dw, ±dh) turn into |x| ≤ (dw·|cs| + dh·|sn|) / 65536, likewise y — widened by a pixel
 // for the rounding of sn/cs, and clipped to the target.  For a needle-shaped sprite that is a fraction of the square.
 // The texel fetches of four pixels per lane are issued before the first blend (one memory round trip per batch).
-PG_D void wave_blit_rotated(uint32_t* fb, const AtlasView& atlas, const Blit& b, int lane, int stride = 64) {
+struct RotBox {
+    int x_lo, y_lo, bw, bh;  // bw or bh ≤ 0: nothing on the target
+};
+PG_D RotBox rot_box(const Blit& b) {
     const int acs = b.rot_cs < 0 ? -b.rot_cs : b.rot_cs, asn = b.rot_sn < 0 ? -b.rot_sn : b.rot_sn;
     const int ex = static_cast<int>((static_cast<long long>(b.dw) * acs + static_cast<long long>(b.dh) * asn) >> 16) + 1;
     const int ey = static_cast<int>((static_cast<long long>(b.dw) * asn + static_cast<long long>(b.dh) * acs) >> 16) + 1;
@@ -218,7 +221,12 @@ PG_D void wave_blit_rotated(uint32_t* fb, const AtlasView& atlas, const Blit& b,
     y_lo = y_lo < 0 ? 0 : y_lo;
     x_hi = x_hi > kObsW - 1 ? kObsW - 1 : x_hi;
     y_hi = y_hi > kObsH - 1 ? kObsH - 1 : y_hi;
-    const int bw = x_hi - x_lo + 1, bh = y_hi - y_lo + 1;
+    return RotBox{x_lo, y_lo, x_hi - x_lo + 1, y_hi - y_lo + 1};
+}
+
+PG_D void wave_blit_rotated(uint32_t* fb, const AtlasView& atlas, const Blit& b, const RotBox& box, int lane,
+                            int stride = 64) {
+    const int x_lo = box.x_lo, y_lo = box.y_lo, bw = box.bw, bh = box.bh;
     if (bw <= 0 || bh <= 0) return;
     const uint32_t* tex = atlas.texels + b.tex_off;
     const int mod = b.flip_mod & 0xff;
@@ -358,6 +366,7 @@ PG_D void wave_replay(uint32_t* fb, const AtlasView& atlas, const Blit& mine, un
         lone = (mine.flip_mod & kRotated) || (x1 > x0 && y1 > y0 && (x1 - x0) * (y1 - y0) > 64);
     }
     const unsigned long long lones = __ballot(lone);
+    int lone_turn = 0;
     while (mask) {
         uint32_t texel[kGroup];
         int idx[kGroup], mod[kGroup];
@@ -375,10 +384,19 @@ PG_D void wave_replay(uint32_t* fb, const AtlasView& atlas, const Blit& mine, un
                 if (g == 0) {
                     mask &= mask - 1;
                     const Blit b = blit_from_lane(mine, src);
-                    if (b.flip_mod & kRotated)
-                        wave_blit_rotated(fb, atlas, b, lane + 64 * half, 64 * halves);
-                    else
+                    if (b.flip_mod & kRotated) {
+                        // A box that one wave covers in a single sweep (bullets, puffs) is left to one wave, the two
+                        // taking turns: the other would run the same instructions with every lane idle.
+                        const RotBox box = rot_box(b);
+                        if (halves == 2 && box.bw * box.bh <= 64) {
+                            if ((lone_turn & 1) == half) wave_blit_rotated(fb, atlas, b, box, lane, 64);
+                            lone_turn++;
+                        } else {
+                            wave_blit_rotated(fb, atlas, b, box, lane + 64 * half, 64 * halves);
+                        }
+                    } else {
                         wave_blit(fb, atlas, b, lane, half, halves);
+                    }
                     __syncthreads();
                 }
                 continue;
