@@ -39,6 +39,17 @@ struct TileWinT {
         if (dx < 4u && dy < 4u) return static_cast<int>((bits >> (3 * (dx + 4 * dy))) & 7u);
         return direct(tiles, x, y);
     }
+    // Does the window hold every tile collide_plain() scans for box r (floor(x)..ceil(x+w) × floor(y)..ceil(y+h))?
+    PG_D bool holds(const Box& r) const {
+        const int x0 = static_cast<int>(floorf(r.x)), y0 = static_cast<int>(floorf(r.y));
+        const int x1 = static_cast<int>(ceilf(r.x + r.w)), y1 = static_cast<int>(ceilf(r.y + r.h));
+        return x0 >= ax && y0 >= ay && x1 < ax + 4 && y1 < ay + 4;
+    }
+    // The window for box r with its spare column / row on the side the box is heading (dir: velocity signs).
+    PG_D static TileWinT around(const uint8_t* tiles, const Box& r, float dir_x, float dir_y) {
+        const int x0 = static_cast<int>(floorf(r.x)), y0 = static_cast<int>(floorf(r.y));
+        return fetch(tiles, x0 - (dir_x < 0.0f ? 1 : 0), y0 - (dir_y < 0.0f ? 1 : 0));
+    }
 };
 
 struct TileHit {
