@@ -604,6 +604,35 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
         return true;
     }
     const int py_begin = half * (kObsH / halves), py_end = py_begin + kObsH / halves;
+    if (cols == 0 || rows == 0) {
+        // No tile layer at all (bossfight): the frame is the background over black — one candidate per pixel instead
+        // of five, none of the tile tables touched.  Same arithmetic as the general loop with four absent candidates.
+        for (int py0 = py_begin; py0 < py_end; py0 += kBatch) {
+            uint32_t t[kBatch];
+#pragma unroll
+            for (int k = 0; k < kBatch; k++) {
+                const uint32_t s_bg = __builtin_amdgcn_readlane(bg_row, py0 + k);
+                t[k] = __builtin_amdgcn_raw_buffer_load_b32(bg_rsrc, bg_col, s_bg, 0);
+            }
+            uint32_t translucent = 0;
+#pragma unroll
+            for (int k = 0; k < kBatch; k++) translucent |= ((t[k] >> 24) + 1u) & 0xFEu;
+            if (bg_mod == 255 && __ballot(translucent != 0) == 0) {
+#pragma unroll
+                for (int k = 0; k < kBatch; k++)
+                    fb[(py0 + k) * kObsW + lane] = (t[k] > 0x00ffffffu) ? (t[k] & 0x00ffffffu) : 0u;
+            } else {
+#pragma unroll
+                for (int k = 0; k < kBatch; k++) {
+                    int a = static_cast<int>(t[k] >> 24);
+                    if (bg_mod != 255) a = static_cast<int>(div255(static_cast<uint32_t>(a * bg_mod)));
+                    fb[(py0 + k) * kObsW + lane] = blend_px(0u, t[k], a);
+                }
+            }
+        }
+        __syncthreads();
+        return true;
+    }
     for (int py0 = py_begin; py0 < py_end; py0 += kBatch) {
         uint32_t t[kBatch][5];
 #pragma unroll
