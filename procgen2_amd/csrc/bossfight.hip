@@ -619,7 +619,6 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
     const int lane = threadIdx.x & 63, half = threadIdx.x >> 6;  // two wavefronts per env (pg_render.h)
     constexpr int halves = 2;
     __shared__ uint32_t fb[kFbWords];
-    __shared__ ComposeLds<1> L;  // no tile layer: the composer only lays down the background
 
     const Camera cam{0.0f, 0.0f, kCamSize, kCamSize, kCamScale};  // camera_position stays {0,0} (renderer.h:18)
     const DescRegs descs = DescRegs::load(atlas, lane);
@@ -641,11 +640,9 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
                               1.0f / d.z * kCamSize / kCamScale, 1.0f, false, false, bg);
     }
     bool composed = false;
-    if (!(flags & 1)) {
-        compose_spans(L, cam, 0, 0, 0, 0, 1, 1, 1.0f, lane, 0, half, halves);
-        if (lane == 0) L.base[0] = static_cast<int32_t>(kNoTexel);
-        __syncthreads();
-        composed = compose_rows(fb, L, atlas, bg, has_bg, 0, 0, 1, lane, flags, half, halves);
+    if (!(flags & 1)) {  // no tile layer in this game: the background over black (pg_render.h)
+        compose_background(fb, atlas, bg, has_bg, lane, half, halves);
+        composed = true;
     }
     if (!composed) {
         wave_clear(fb, lane, half, halves);

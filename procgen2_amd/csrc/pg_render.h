@@ -527,6 +527,55 @@ constexpr uint32_t kNoTexel = 0x40000000u;
 // layer does not fit the two-candidate scheme (caller falls back to wave_replay).
 // TWO: cells whose L.base has bit 0 set use the second tile texture (compose_spans th2); their texel row comes from
 // L.row2 and is chosen per lane, at the price of a select and an add in front of every tile load.
+// The frame of a game without a tile layer (bossfight): the background over black, nothing else — one candidate per
+// pixel instead of the composer's five, no span tables.  Same arithmetic as compose_rows with four absent candidates.
+PG_D void compose_background(uint32_t* fb, const AtlasView& atlas, const Blit& bg, bool has_bg, int lane, int half = 0,
+                             int halves = 1) {
+    const __amdgpu_buffer_rsrc_t bg_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t*>(atlas.texels), 0, static_cast<int>(atlas.texel_bytes), 0x00020000);
+    uint32_t bg_col = kNoTexel, bg_row = kNoTexel;
+    if (has_bg) {
+        const bool fh = (bg.flip_mod & kFlipH) != 0, fv = (bg.flip_mod & kFlipV) != 0;
+        if (lane >= bg.dx && lane < bg.dx + bg.dw) {
+            int i = lane - bg.dx;
+            if (fh) i = bg.dw - 1 - i;
+            bg_col = static_cast<uint32_t>(bg.tex_off + sample_index(bg.sx, bg.sw, i, bg.dw)) * 4u;
+        }
+        if (lane >= bg.dy && lane < bg.dy + bg.dh) {
+            int j = lane - bg.dy;
+            if (fv) j = bg.dh - 1 - j;
+            bg_row = static_cast<uint32_t>(sample_index(bg.sy, bg.sh, j, bg.dh) * bg.tex_w) * 4u;
+        }
+    }
+    const int bg_mod = has_bg ? (bg.flip_mod & 0xff) : 255;
+    constexpr int kBatch = 8;
+    const int py_begin = half * (kObsH / halves), py_end = py_begin + kObsH / halves;
+    for (int py0 = py_begin; py0 < py_end; py0 += kBatch) {
+        uint32_t t[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) {
+            const uint32_t s_bg = __builtin_amdgcn_readlane(bg_row, py0 + k);
+            t[k] = __builtin_amdgcn_raw_buffer_load_b32(bg_rsrc, bg_col, s_bg, 0);
+        }
+        uint32_t translucent = 0;
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) translucent |= ((t[k] >> 24) + 1u) & 0xFEu;
+        if (bg_mod == 255 && __ballot(translucent != 0) == 0) {
+#pragma unroll
+            for (int k = 0; k < kBatch; k++)
+                fb[(py0 + k) * kObsW + lane] = (t[k] > 0x00ffffffu) ? (t[k] & 0x00ffffffu) : 0u;
+        } else {
+#pragma unroll
+            for (int k = 0; k < kBatch; k++) {
+                int a = static_cast<int>(t[k] >> 24);
+                if (bg_mod != 255) a = static_cast<int>(div255(static_cast<uint32_t>(a * bg_mod)));
+                fb[(py0 + k) * kObsW + lane] = blend_px(0u, t[k], a);
+            }
+        }
+    }
+    __syncthreads();
+}
+
 template <int GRID, bool TWO = false>
 PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView& atlas, const Blit& bg, bool has_bg,
                        int cols, int rows, int tw, int lane, int ablate = 0, int half = 0, int halves = 1,
@@ -604,35 +653,6 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
         return true;
     }
     const int py_begin = half * (kObsH / halves), py_end = py_begin + kObsH / halves;
-    if (cols == 0 || rows == 0) {
-        // No tile layer at all (bossfight): the frame is the background over black — one candidate per pixel instead
-        // of five, none of the tile tables touched.  Same arithmetic as the general loop with four absent candidates.
-        for (int py0 = py_begin; py0 < py_end; py0 += kBatch) {
-            uint32_t t[kBatch];
-#pragma unroll
-            for (int k = 0; k < kBatch; k++) {
-                const uint32_t s_bg = __builtin_amdgcn_readlane(bg_row, py0 + k);
-                t[k] = __builtin_amdgcn_raw_buffer_load_b32(bg_rsrc, bg_col, s_bg, 0);
-            }
-            uint32_t translucent = 0;
-#pragma unroll
-            for (int k = 0; k < kBatch; k++) translucent |= ((t[k] >> 24) + 1u) & 0xFEu;
-            if (bg_mod == 255 && __ballot(translucent != 0) == 0) {
-#pragma unroll
-                for (int k = 0; k < kBatch; k++)
-                    fb[(py0 + k) * kObsW + lane] = (t[k] > 0x00ffffffu) ? (t[k] & 0x00ffffffu) : 0u;
-            } else {
-#pragma unroll
-                for (int k = 0; k < kBatch; k++) {
-                    int a = static_cast<int>(t[k] >> 24);
-                    if (bg_mod != 255) a = static_cast<int>(div255(static_cast<uint32_t>(a * bg_mod)));
-                    fb[(py0 + k) * kObsW + lane] = blend_px(0u, t[k], a);
-                }
-            }
-        }
-        __syncthreads();
-        return true;
-    }
     for (int py0 = py_begin; py0 < py_end; py0 += kBatch) {
         uint32_t t[kBatch][5];
 #pragma unroll
