@@ -297,8 +297,17 @@ PG_D void install(const State& s, int env, const Level& lv, int lane) {
 // ------------------------------------------------------------------------------------------------
 // step
 // ------------------------------------------------------------------------------------------------
-PG_D Box thing_box(const State& s, int e, int env, int kind) {
-    const float x = EF(s, EF_X, e, env), y = EF(s, EF_Y, e, env);
+// The entity table of the 64 envs of a logic wavefront, staged in LDS for the step ([entity][lane]): a sub-step walks
+// the hazards for the ship and again, in the hazard set's order, for every flying bullet — from global memory three
+// dependent loads per visit on a wave with nothing to hide them behind.  Staged once (four entities at a time, all
+// loads in flight); enemy positions and destroyed targets are written through to global memory.
+struct StepLds {
+    float x[kMaxEnt][64], y[kMaxEnt][64];
+    uint8_t info[kMaxEnt][64], order_h[kMaxEnt][64];
+};
+
+PG_D Box thing_box(const StepLds& L, int lane, int e, int kind) {
+    const float x = L.x[e][lane], y = L.y[e][lane];
     if (kind == kEnemy || kind == kGoal) return Box{x + -0.4f, y + -0.4f, 0.8f, 0.8f};
     return Box{x + -0.25f, y + -0.25f, 0.5f, 0.5f};
 }
@@ -316,9 +325,35 @@ PG_D void rebuild_draw_list(const State& s, int env, int n_ent) {
     SI(s, I_NDRAW, env) = n;
 }
 
-PG_D void advance(const State& s, int env, int action, float& reward_out, bool& terminated_out) {
+// Every lane of the wave goes in (the staging loop is wave-wide); `active` = this lane's env takes a step.
+PG_D void advance(const State& s, StepLds& L, int lane, bool active, int env, int action, float& reward_out,
+                  bool& terminated_out) {
+    const int n_ent = active ? SI(s, I_NENT, env) : 0;
+    for (int e0 = 0; __ballot(e0 < n_ent); e0 += 4) {
+        int info[4], order[4];
+        float x[4], y[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int e = e0 + k;
+            const bool ok = e < n_ent;
+            info[k] = ok ? EB(s, EB_INFO, e, env) : 0;
+            order[k] = (ok && e < n_ent - 2) ? EB(s, EB_ORDER_H, e, env) : 0;
+            x[k] = ok ? EF(s, EF_X, e, env) : 0.0f;
+            y[k] = ok ? EF(s, EF_Y, e, env) : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int e = e0 + k;
+            if (e < n_ent) {
+                L.info[e][lane] = static_cast<uint8_t>(info[k]);
+                L.order_h[e][lane] = static_cast<uint8_t>(order[k]);
+                L.x[e][lane] = x[k];
+                L.y[e][lane] = y[k];
+            }
+        }
+    }
+    if (!active) return;
     const uint8_t* tiles = s.tiles + size_t(env) * kTileStride;
-    const int n_ent = SI(s, I_NENT, env);
     const int flags = SI(s, I_FLAGS, env);
     float ax = SF(s, F_AX, env), ay = SF(s, F_AY, env), avx = SF(s, F_AVX, env), avy = SF(s, F_AVY, env);
     float rot = SF(s, F_ROT, env), s_timer = SF(s, F_STIMER, env), p_timer = SF(s, F_PTIMER, env);
@@ -377,10 +412,10 @@ PG_D void advance(const State& s, int env, int action, float& reward_out, bool& 
             if (moved_y != 0.0f) avy = 0.0f;
         }
         for (int e = 2; e < n_ent; e++) {  // hazards: any hit kills, order-free
-            const int info = EB(s, EB_INFO, e, env);
-            if ((info & kAlive) && box_hit(body, thing_box(s, e, env, info & kKindMask))) alive = false;
+            const int info = L.info[e][lane];
+            if ((info & kAlive) && box_hit(body, thing_box(L, lane, e, info & kKindMask))) alive = false;
         }
-        if (box_hit(body, thing_box(s, 0, env, kGoal))) achieved_goal = true;
+        if (box_hit(body, thing_box(L, lane, 0, kGoal))) achieved_goal = true;
         const float cam_x = ax * kUnitPx, cam_y = ay * kUnitPx;
 
         for (int i = 0; i < s_count; i++) {  // bullets, newest first
@@ -398,15 +433,16 @@ PG_D void advance(const State& s, int env, int action, float& reward_out, bool& 
                     frame = 1.0f;
                 }
                 for (int q = 0; q < n_ent - 2; q++) {  // first hit in the hazard set's iteration order
-                    const int e = EB(s, EB_ORDER_H, q, env);
-                    const int info = EB(s, EB_INFO, e, env);
+                    const int e = L.order_h[q][lane];
+                    const int info = L.info[e][lane];
                     if (!(info & kAlive)) continue;
-                    if (box_hit(sb, thing_box(s, e, env, info & kKindMask))) {
+                    if (box_hit(sb, thing_box(L, lane, e, info & kKindMask))) {
                         bvx = 0.0f;
                         bvy = 0.0f;
                         frame = 1.0f;
                         if ((info & kKindMask) == kTarget) {
-                            EB(s, EB_INFO, e, env) = static_cast<uint8_t>(info & ~kAlive);  // destroy_entity
+                            L.info[e][lane] = static_cast<uint8_t>(info & ~kAlive);  // destroy_entity
+                            EB(s, EB_INFO, e, env) = static_cast<uint8_t>(info & ~kAlive);
                             set_changed = true;
                             targets_destroyed++;
                         }
@@ -432,16 +468,18 @@ PG_D void advance(const State& s, int env, int action, float& reward_out, bool& 
 
         // --- System_Mob_AI::update (common_systems.cpp:50-75)
         for (int e = 2; e < n_ent; e++) {
-            const int info = EB(s, EB_INFO, e, env);
+            const int info = L.info[e][lane];
             if ((info & kKindMask) != kEnemy) continue;
             float vx = EF(s, EF_VX, e, env), vy = EF(s, EF_VY, e, env);
-            const float x = EF(s, EF_X, e, env) + vx * dt, y = EF(s, EF_Y, e, env) + vy * dt;
+            const float x = L.x[e][lane] + vx * dt, y = L.y[e][lane] + vy * dt;
             const Box box{x + -0.4f, y + -0.4f, 0.8f, 0.8f};
             const Win win = Win::fetch(tiles, static_cast<int>(floorf(box.x)), static_cast<int>(floorf(box.y)));
             if (collide_plain(win, box, is_wall).any) {
                 vx = -vx;
                 vy = -vy;
             }
+            L.x[e][lane] = x;
+            L.y[e][lane] = y;
             EF(s, EF_X, e, env) = x;
             EF(s, EF_Y, e, env) = y;
             EF(s, EF_VX, e, env) = vx;
@@ -532,21 +570,26 @@ struct Gen {  // pg_prefetch.h level_kernel<Gen>
 
 __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actions, uint32_t run_seed,
                                                    uint32_t step_index, int env_offset, StepIO io) {
-    const int env = blockIdx.x * blockDim.x + threadIdx.x;
-    if (env >= s.n) return;
-    if (io.pending[env] == 2) {  // reset by level_kernel in this step
+    __shared__ StepLds L;
+    const int lane = threadIdx.x;
+    const int env = blockIdx.x * 64 + lane;
+    bool active = env < s.n;
+    if (active && io.pending[env] == 2) {  // reset by the level kernel in this step
         io.pending[env] = 0;
-        return;
+        active = false;
     }
-    const int action =
-        actions ? actions[env] : synthetic_action(run_seed, step_index, static_cast<uint32_t>(env_offset + env));
-    float reward;
-    bool terminated;
-    advance(s, env, action, reward, terminated);
+    const int action = !active ? 0
+                       : actions ? actions[env]
+                                 : synthetic_action(run_seed, step_index, static_cast<uint32_t>(env_offset + env));
+    float reward = 0.0f;
+    bool terminated = false;
+    advance(s, L, lane, active, env, action, reward, terminated);
+    if (!active) return;
     io.reward[env] = reward;
     io.done[env] = terminated ? 1 : 0;
     io.pending[env] = terminated ? 1 : 0;
 }
+
 
 // render_game(true) (caveflyer.cpp:413-440): one wavefront per env.
 __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
@@ -849,7 +892,7 @@ class CaveflyerGame final : public Game {
     void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
                       StepIO io) override {
         LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io, plan);
-        hipLaunchKernelGGL(logic_kernel, dim3(logic_blocks(s_.n)), dim3(logic_lanes()), 0, st, s_, actions, run_seed, step_index,
+        hipLaunchKernelGGL(logic_kernel, dim3((s_.n + 63) / 64), dim3(64), 0, st, s_, actions, run_seed, step_index,
                            env_offset, io);
     }
     bool launch_frame(hipStream_t st, int env, uint32_t* d_px, int w, int h) override {
