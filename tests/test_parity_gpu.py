@@ -506,3 +506,41 @@ def test_vec_env_torch_zero_copy_matches_c_abi():
         assert np.array_equal(r.cpu().numpy(), re_) and np.array_equal(d.cpu().numpy(), de)
     env.close()
     ref.close()
+
+
+def _appendix_c():
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "appendix_c.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("trace", _appendix_c()["traces"], ids=lambda t: "%s-%d" % (t["game"], t["seed"]))
+def test_engine_reproduces_the_reference_reward_done_traces(trace):
+    """The HIP engine against the reference itself, without the oracle in between: SURVEY.md Appendix C recorded the
+    CRC-32 of the (reward f32, terminated u8) stream of the UNMODIFIED reference sources for make(seed) → reset →
+    20 000 LCG actions with `if terminated: reset()`.  One engine env with that seed, the same actions, an explicit
+    reset after every terminal step (which is what the caller's loop does; it replaces the engine's auto-reset)."""
+    import struct
+    import zlib
+    steps = _appendix_c()["steps"]
+    eng = EngineVec(trace["game"], 1, seed_base=trace["seed"])
+    eng.reset()
+    s, crc, episodes, total, length, lengths = 1, 0, 0, 0.0, 0, []
+    one = np.ones(1, np.uint8)
+    for _ in range(steps):
+        s = (s * 1664525 + 1013904223) & 0xFFFFFFFF
+        _, r, d = eng.step(np.array([(s >> 16) % 15], np.int32))
+        crc = zlib.crc32(struct.pack("<fB", float(r[0]), int(d[0])), crc)
+        total += float(r[0])
+        length += 1
+        if d[0]:
+            episodes += 1
+            lengths.append(length)
+            length = 0
+            eng.reset(mask=one)
+    eng.close()
+    assert "%08x" % crc == trace["crc"]
+    assert episodes == trace["episodes"]
+    assert abs(total - trace["reward_sum"]) < 1e-3
+    want = trace["first_lengths"]
+    assert lengths[:len(want)] == want
