@@ -437,21 +437,25 @@ def test_cenv_abi_batched_through_unmodified_wrapper_shapes():
     ora.close()
 
 
-def test_shard_invariance_and_determinism_at_full_size():
-    """BASELINE.json full size (65 536 envs, coinrun): a shard created with env_offset reproduces the same global
-    envs byte for byte (so results do not depend on the GPU count), two identical runs agree, and a strided
-    sample of the 65 536 envs matches the oracle."""
-    n = 65536
-    steps = 24
-    big = EngineVec("coinrun", n, seed_base=1)
+@pytest.mark.parametrize("game,n,steps", [("coinrun", 65536, 24), ("bossfight", 65536, 100), ("caveflyer", 32768, 40)])
+def test_shard_invariance_and_determinism_at_full_size(game, n, steps):
+    """BASELINE.json's full sizes (configs: coinrun 65 536, bossfight 65 536, caveflyer 32 768 envs): a shard created
+    with env_offset reproduces the same global envs byte for byte (so results do not depend on the GPU count), two
+    identical runs agree, and a strided sample of the envs matches the oracle.  (bossfight runs long enough for a large
+    share of its envs to have ended an episode and drawn their next level inside the step.)"""
+    big = EngineVec(game, n, seed_base=1)
     big.reset()
+    ends = 0
     for s in range(steps):
-        big.step(None, run_seed=0)
+        _, _, d = big.step(None, run_seed=0)
+        ends += int(d.sum())
     obs_big, rew_big, done_big = (x.copy() for x in big._fetch())
     big.close()
+    if game == "bossfight":
+        assert ends > n // 4, ends
 
-    lo = 40000
-    shard = EngineVec("coinrun", 512, seed_base=1, env_offset=lo)
+    lo = (n * 5) // 8
+    shard = EngineVec(game, 512, seed_base=1, env_offset=lo)
     shard.reset()
     for s in range(steps):
         shard.step(None, run_seed=0)
@@ -460,7 +464,7 @@ def test_shard_invariance_and_determinism_at_full_size():
     assert np.array_equal(d, done_big[lo:lo + 512])
     shard.close()
 
-    again = EngineVec("coinrun", n, seed_base=1)
+    again = EngineVec(game, n, seed_base=1)
     again.reset()
     for s in range(steps):
         again.step(None, run_seed=0)
@@ -470,9 +474,9 @@ def test_shard_invariance_and_determinism_at_full_size():
 
     L = oracle()
     from oracle_util import register_textures
-    register_textures("coinrun")
-    for g in range(0, n, 4099):  # 16 envs spread over the whole range
-        h = L.pgo_make(b"coinrun", 1 + g, 1)
+    register_textures(game)
+    for g in range(0, n, n // 16 + 3):  # 16 envs spread over the whole range
+        h = L.pgo_make(game.encode(), 1 + g, 1)
         L.pgo_reset(h, 0, 0)
         pending = False
         for s in range(steps):
