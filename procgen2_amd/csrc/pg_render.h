@@ -291,11 +291,20 @@ PG_D void wave_blit(uint32_t* fb, const AtlasView& atlas, const Blit& b, int lan
     constexpr int kBatch = 4;  // texel fetches in flight per lane: a batch costs one memory round trip
     if (cw > 32) {
         // Wide blit (backgrounds on the fallback path, jumper's compass): lane = column, kBatch rows per iteration.
+        // The texel row of target row y0 + r is the same for every lane: lane r works it out once for all of them
+        // (the target has 64 rows) and the row loop picks it up with a cross-lane read instead of every lane redoing
+        // the division for every row.
         const int x = x0 + lane;
         const bool on = lane < cw;
         int i = x - b.dx;
         if (fh) i = b.dw - 1 - i;
         const int u = on ? sample_index(b.sx, b.sw, i, b.dw) : b.sx;
+        int row_at = 0;
+        if (y0 + lane < y1) {
+            int j = y0 + lane - b.dy;
+            if (fv) j = b.dh - 1 - j;
+            row_at = sample_index(b.sy, b.sh, j, b.dh) * tw;
+        }
         for (int yb = y0 + half; yb < y1; yb += halves * kBatch) {
             uint32_t texel[kBatch];
 #pragma unroll
@@ -303,10 +312,8 @@ PG_D void wave_blit(uint32_t* fb, const AtlasView& atlas, const Blit& b, int lan
                 const int y = yb + k * halves;
                 texel[k] = 0;
                 if (y >= y1) continue;
-                int j = y - b.dy;
-                if (fv) j = b.dh - 1 - j;
-                const int v = sample_index(b.sy, b.sh, j, b.dh);
-                if (on) texel[k] = tex[v * tw + u];
+                const int v_tw = __builtin_amdgcn_readlane(row_at, y - y0);
+                if (on) texel[k] = tex[v_tw + u];
             }
 #pragma unroll
             for (int k = 0; k < kBatch; k++) {
