@@ -694,21 +694,31 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
             const float dist_inv = 1.0f / fmaxf(0.0001f, dist);
             const float dir_x = tx * dist_inv, dir_y = ty * dist_inv;
             const float ratio = fminf(1.0f, dist / (W * 1.414f));
+            // circle, needle and bar differ in their parameters only: pick per lane, resolve once
+            float sx, sy, sw, sh;
+            double deg = 0.0;
             if (lane == 1) {
-                has = resolve_screen(d.y, d.z, d.x, width - compass_size * game_zoom + offset_x * game_zoom,
-                                     offset_y * game_zoom, compass_size * game_zoom, compass_size * game_zoom, 0.0, mine);
+                sx = width - compass_size * game_zoom + offset_x * game_zoom;
+                sy = offset_y * game_zoom;
+                sw = compass_size * game_zoom;
+                sh = compass_size * game_zoom;
             } else if (lane == 2) {
                 float dx = width - compass_size * 0.75f * game_zoom + offset_x * game_zoom;
                 float dy = compass_size * 0.5f * game_zoom + offset_y * game_zoom;
                 dx += compass_size * 0.25f * dir_x * game_zoom;
                 dy += compass_size * 0.25f * dir_y * game_zoom;
-                has = resolve_screen(d.y, d.z, d.x, dx, dy, compass_size * 0.5f * game_zoom,
-                                     compass_size * 0.1f * game_zoom, static_cast<double>(angle), mine);
+                sx = dx;
+                sy = dy;
+                sw = compass_size * 0.5f * game_zoom;
+                sh = compass_size * 0.1f * game_zoom;
+                deg = static_cast<double>(angle);
             } else {
-                has = resolve_screen(d.y, d.z, d.x, width - compass_size * game_zoom + offset_x * game_zoom,
-                                     compass_size * game_zoom + offset_y * game_zoom, compass_size * game_zoom * ratio,
-                                     compass_size * 0.15f * game_zoom, 0.0, mine);
+                sx = width - compass_size * game_zoom + offset_x * game_zoom;
+                sy = compass_size * game_zoom + offset_y * game_zoom;
+                sw = compass_size * game_zoom * ratio;
+                sh = compass_size * 0.15f * game_zoom;
             }
+            has = resolve_screen(d.y, d.z, d.x, sx, sy, sw, sh, deg, mine);
         }
         wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
     }
