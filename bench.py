@@ -47,6 +47,31 @@ def measured_traffic(game):
     return entry["bytes_corrected"], os.path.relpath(files[-1], ROOT)
 
 
+def usable_cores():
+    """Host cores this process may actually use: the scheduler affinity, capped by the cgroup CPU quota (a GPU box
+    shows 256 logical CPUs with a 16-CPU quota; 256 threads there only queue behind each other)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                quota = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            if quota > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(game, run_seed, budget_s=20.0):
     """The CPU restatement (oracle/, kind "port") on a bounded sample of the same workload: same seeds
     (1 + env index), same action hash, same auto-reset policy, rendering on, one thread per host core."""
@@ -56,7 +81,7 @@ def cpu_baseline(game, run_seed, budget_s=20.0):
     import oracle_util
     oracle_util.register_textures(game)
     L = oracle_util.oracle()
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     envs = 64 * cores
     h = L.pgo_vec_make(game.encode(), envs, 1, 0, 1)
     rate = L.pgo_vec_bench(h, 4, run_seed, cores)  # calibrate
