@@ -10,7 +10,7 @@
 //
 // Machine mapping:
 //   * logic  — one lane per env over struct-of-arrays state (agent, 32 bullets, ≤60 objects, 10 particles);
-//   * render — one wavefront per env (pg_render.h), tiles through the row composer, the rotated sprites
+//   * render — two wavefronts per env sharing an LDS target (pg_render.h), tiles through the row composer, the rotated sprites
 //              (particles, bullets, ship) as whole-wave rotated blits;
 //   * level generation — one wavefront per env with a 23 KiB LDS workspace.  The generator's result depends on
 //              the iteration order of a std::unordered_set<int> holding up to 1600 cells (the largest room,
@@ -591,7 +591,7 @@ __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actio
 }
 
 
-// render_game(true) (caveflyer.cpp:413-440): one wavefront per env.
+// render_game(true) (caveflyer.cpp:413-440): one workgroup of two wavefronts per env (pg_render.h).
 __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
                                                     int flags) {
     const int env = blockIdx.x;

@@ -12,7 +12,7 @@
 // pass and the chase heuristic compares sums of truncated integers.  iabs() below is that.
 //
 // Machine mapping: logic one lane per env (SoA across envs) — the enemies draw from the env's mt19937 inside the step,
-// in the iteration order of the enemy System's std::unordered_set; render one wavefront per env; level generation one
+// in the iteration order of the enemy System's std::unordered_set; render two wavefronts per env; level generation one
 // wavefront per env.  Because of the in-step draws the next level cannot be generated ahead of time (pg_prefetch.h
 // is used with prefetch off: every reset carves its maze inside the step).
 #include "pg_engine.h"
@@ -650,7 +650,7 @@ __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actio
     io.pending[env] = terminated ? 1 : 0;
 }
 
-// render_game(true) (chaser.cpp:390-416): one wavefront per env.
+// render_game(true) (chaser.cpp:390-416): one workgroup of two wavefronts per env (pg_render.h).
 __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
                                                     int flags) {
     const int env = blockIdx.x;

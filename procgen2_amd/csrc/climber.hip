@@ -507,7 +507,7 @@ __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actio
     io.pending[env] = terminated ? 1 : 0;
 }
 
-// render_game(true) (climber.cpp:431-459): one wavefront per env.
+// render_game(true) (climber.cpp:431-459): one workgroup of two wavefronts per env (pg_render.h).
 __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
                                                     int flags) {
     const int env = blockIdx.x;

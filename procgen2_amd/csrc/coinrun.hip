@@ -8,7 +8,7 @@
 // Mapping onto the machine:
 //   * logic (reset + the 4 physics sub-steps) is SIMT across envs — one lane per env, state laid out
 //     struct-of-arrays across envs so the 64 lanes of a wave touch 64 consecutive floats;
-//   * render is SIMD within an env — one wavefront per env, target in LDS (pg_render.h).
+//   * render is SIMD within an env — two wavefronts per env sharing a 64×64 target in LDS (pg_render.h).
 // The ECS of the reference is gone: an entity is a slot index (= the id the reference's allocator hands
 // out: saws/mobs in creation order, then the coin; the agent is kept apart), and the iteration order of the
 // reference's std::unordered_set-based systems is recomputed at reset with pg_order.h and stored as two
@@ -815,7 +815,7 @@ __global__ void __launch_bounds__(64) resolve_kernel(State s, StepIO io) {
     io.pending[env] = terminated ? 1 : 0;
 }
 
-// render_game(true) (coinrun.cpp:443-470): one wavefront per env.
+// render_game(true) (coinrun.cpp:443-470): one workgroup of two wavefronts per env (pg_render.h).
 // flags bit 0: force the draw-list replay for background + tiles (fallback path; parity tests run both).
 // Higher bits are timing experiments only (tools/ablate_render.py) and change the picture.
 constexpr int kRenderWaves = 2;  // wavefronts per env (pg_render.h: two waves share one frame's LDS target)
