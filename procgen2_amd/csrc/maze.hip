@@ -7,7 +7,7 @@
 // Config: one compiled variant per distribution mode (below); variant 0 = the reference's compile-time default,
 // hard_mode: 25×25 world, all visible, fixed camera
 // (maze/tilemap.h:40-42, tilemap.cpp:35-38).
-// Machine mapping: logic one lane per env (SoA across envs), render one wave per env, level generation one wave per
+// Machine mapping: logic one lane per env (SoA across envs), render two waves per env, level generation one wave per
 // env on LDS.  The game draws no random numbers during an episode and every episode ends within 500 steps, so
 // resets are frequent and bursty; the next maze of every env is carved ahead of time on a side stream and copied
 // in at reset (pg_prefetch.h).
