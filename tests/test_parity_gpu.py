@@ -548,3 +548,35 @@ def test_engine_reproduces_the_reference_reward_done_traces(trace):
     assert abs(total - trace["reward_sum"]) < 1e-3
     want = trace["first_lengths"]
     assert lengths[:len(want)] == want
+
+
+@pytest.mark.parametrize("game,steps", [("coinrun", 3000), ("chaser", 1200), ("climber", 2000)])
+def test_long_rollout_at_full_size_stays_on_the_oracle(game, steps):
+    """Soak: 65 536 envs for thousands of steps — every env goes through many episodes, prefetched levels, synchronous
+    fallbacks and (chaser) in-step generation — then a strided sample of envs must still be where the oracle is:
+    last observation, reward, done."""
+    from oracle_util import register_textures
+    n = 65536
+    eng = EngineVec(game, n, seed_base=1)
+    eng.reset()
+    for s in range(steps):
+        pglib.check(eng.L, eng.L.pgv_step_synthetic(eng.h, 5), "pgv_step_synthetic")
+    obs, rew, done = (x.copy() for x in eng._fetch())
+    eng.close()
+    L = oracle()
+    register_textures(game)
+    for g in range(0, n, n // 12 + 7):
+        h = L.pgo_make(game.encode(), 1 + g, 1)
+        L.pgo_reset(h, 0, 0)
+        pending, r, d = False, 0.0, 0
+        for s in range(steps):
+            if pending:
+                L.pgo_reset(h, 0, 0)
+                pending, r, d = False, 0.0, 0
+            else:
+                L.pgo_step(h, L.pgo_synthetic_action(5, s, g))
+                r, d = L.pgo_reward(h), int(L.pgo_terminated(h))
+                pending = bool(d)
+        assert np.array_equal(obs[g], np.ctypeslib.as_array(L.pgo_obs(h), shape=(12288,))), g
+        assert np.float32(r) == rew[g] and d == done[g], g
+        L.pgo_close(h)
