@@ -690,7 +690,7 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
 
     bool composed = false;
     if (!(flags & 1) && cols <= kGrid && rows <= kGrid) {
-        compose_spans<kGrid, 16>(L, cam, x0, y0, cols, rows, wall_d.y, wall_d.z, kUnitPx / wall_d.y, lane, 0, half, halves);
+        compose_spans<kGrid, 16>(fb, L, cam, x0, y0, cols, rows, wall_d.y, wall_d.z, kUnitPx / wall_d.y, lane, 0, half, halves);
 #pragma unroll
         for (int k = half; k < kGrid * kGrid / 64; k += halves) {
             const int cell = k * 64 + lane;

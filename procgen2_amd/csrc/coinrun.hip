@@ -828,7 +828,12 @@ __global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, Atla
     constexpr int halves = kRenderWaves;
     __shared__ uint32_t fb[kFbWords];
     constexpr int kGrid = 16;  // 64 px / 4.8 px per tile = 13.3 tiles → at most 15 columns/rows in view
-    __shared__ ComposeLds<kGrid> L;
+    // the composer's cell table, and — once it is dead — the 64 resolved draws wave 0 hands to wave 1
+    __shared__ union {
+        ComposeLds<kGrid> compose;
+        uint32_t slots[kBlitWords * 64];
+    } shared;
+    ComposeLds<kGrid>& L = shared.compose;
 
     const Camera cam{SF(s, F_CAMX, env), SF(s, F_CAMY, env), 64.0f, 64.0f, 0.3f * 64.0f / 64.0f};
     const int themes = SI(s, I_THEMES, env);
@@ -914,7 +919,7 @@ __global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, Atla
 
     bool composed = false;
     if (!(flags & 5) && cols <= kGrid && rows <= kGrid) {
-        compose_spans(L, cam, x0, y0, cols, rows, tile_desc.y, tile_desc.z, kUnitPx / tile_desc.y, lane, 0, half, halves);
+        compose_spans(fb, L, cam, x0, y0, cols, rows, tile_desc.y, tile_desc.z, kUnitPx / tile_desc.y, lane, 0, half, halves);
         // Texel offset of each tile kind's texture, one per lane (0..7), looked up with a cross-lane read:
         // lanes 0-3 = wall_top, wall_mid, lava_top, lava_mid (tile id - 1), lanes 4-7 = the four crates.
         int kind_tex = kTexCrate + ((lane - 4) & 3);
@@ -1013,8 +1018,7 @@ __global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, Atla
         }
         // The composer's tables are dead by now (its last barrier is behind both waves): their LDS carries the resolved
         // draws from wave 0 to wave 1.
-        static_assert(sizeof(ComposeLds<kGrid>) >= kBlitWords * 64 * 4, "blit hand-over reuses the composer's LDS");
-        uint32_t* slots = reinterpret_cast<uint32_t*>(&L);
+        uint32_t* slots = shared.slots;
         bool has = false;
         if (half == 0) {
             // every lane asks for the descriptor it needs with a cross-lane read, so do that outside the branches

@@ -588,7 +588,7 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
     bool composed = false;
     const bool two = top_d.z != mid_d.z;  // the brown cap tile is 64×53 (see climber.hip)
     if (!(flags & 1) && cols <= kGrid && rows <= kGrid && top_d.y == mid_d.y && top_d.z <= mid_d.z) {
-        compose_spans(L, cam, x0, y0, cols, rows, mid_d.y, mid_d.z, kUnitPx / mid_d.y, lane, two ? top_d.z : 0, half, halves);
+        compose_spans(fb, L, cam, x0, y0, cols, rows, mid_d.y, mid_d.z, kUnitPx / mid_d.y, lane, two ? top_d.z : 0, half, halves);
 #pragma unroll
         for (int k = half; k < kGrid * kGrid / 64; k += halves) {
             const int cell = k * 64 + lane;

@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
     bool composed = false;
     if (!(flags & 1) && cols <= kGrid && rows <= kGrid) {
         constexpr int kSpan = 64 / kVisible + 2 <= kMaxSpan ? kMaxSpan : 16;  // pixels a tile covers (+ seam padding)
-        compose_spans<kGrid, kSpan>(L, cam, x0, y0, cols, rows, wall.y, wall.z, kUnitPx / wall.y, lane, 0, half, halves);
+        compose_spans<kGrid, kSpan>(fb, L, cam, x0, y0, cols, rows, wall.y, wall.z, kUnitPx / wall.y, lane, 0, half, halves);
         for (int cell = lane + 64 * half; cell < cells; cell += 64 * halves) {
             const int r = cell / cols, c = cell - r * cols;
             L.base[r * kGrid + c] =

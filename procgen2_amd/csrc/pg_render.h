@@ -37,17 +37,28 @@ struct __attribute__((packed, aligned(4))) Rgb4 {
 };
 
 // LDS scratch of the row composer; GRID = max tile-grid columns / rows visible in one frame.
+// LDS decides how many envs a CU holds (measured: one workgroup less per CU costs 9 %), so only what the row loop
+// itself reads stays in ComposeLds; the set-up tables (ComposeTmp) are read into registers before the first pixel is
+// written and live in the frame target's own memory until then (compose_rows puts a barrier between the two uses).
 template <int GRID>
 struct ComposeLds {
-    int4 col[GRID];             // per grid column: {d0, dn, s0, sn}; sn == 0 ⇒ nothing drawn
-    int4 row[GRID];             // per grid row
-    int4 row2[GRID];            // per grid row for the layer's second, shorter tile texture (sn == 0 ⇒ none)
     int32_t base[GRID * GRID];  // [row][col] byte offset of the cell's tile texture in the atlas, kNoTexel = no tile
-    int32_t cover_n[2][64];     // [axis][pixel] how many grid columns (axis 0) / rows (axis 1) cover the pixel
-    int32_t cover[2][64][2];    // the first two of them: grid index | texel coordinate << 8
     int32_t too_wide;           // some span is wider than kMaxSpan pixels → fall back
     int32_t blendy;             // set by the caller's staging pass when a visible texture has translucent texels
 };
+template <int GRID>
+struct ComposeTmp {
+    int4 col[GRID];           // per grid column: {d0, dn, s0, sn}; sn == 0 ⇒ nothing drawn
+    int4 row[GRID];           // per grid row
+    int4 row2[GRID];          // per grid row for the layer's second, shorter tile texture (sn == 0 ⇒ none)
+    int32_t cover_n[2][64];   // [axis][pixel] how many grid columns (axis 0) / rows (axis 1) cover the pixel
+    int32_t cover[2][64][2];  // the first two of them: grid index | texel coordinate << 8
+};
+template <int GRID>
+PG_D ComposeTmp<GRID>& compose_tmp(uint32_t* fb) {
+    static_assert(sizeof(ComposeTmp<GRID>) <= 64 * 64 * 4, "the set-up tables borrow the frame target's memory");
+    return *reinterpret_cast<ComposeTmp<GRID>*>(fb);
+}
 constexpr int kMaxSpan = 8;  // default bound on the pixels one tile covers per axis (coinrun 5–6, maze 3); caveflyer passes 16
 
 // The atlas descriptor table held in registers, two entries per lane (tables up to 128 textures): one pair of
@@ -451,11 +462,12 @@ PG_D void wave_clear(uint32_t* fb, int lane, int half = 0, int halves = 1) {
 // cap tile next to 64×64 bodies).  Its rows start where the tall ones start and end earlier, so the covering grid
 // rows of a pixel stay the tall texture's; only the texel row differs per cell (compose_rows<GRID, true>).
 template <int GRID, int MAXSPAN = kMaxSpan>
-PG_D void compose_spans(ComposeLds<GRID>& L, const Camera& cam, int x0, int y0, int cols, int rows, int tw, int th,
-                        float tile_scale, int lane, int th2 = 0, int half = 0, int halves = 1) {
+PG_D void compose_spans(uint32_t* fb, ComposeLds<GRID>& L, const Camera& cam, int x0, int y0, int cols, int rows, int tw,
+                        int th, float tile_scale, int lane, int th2 = 0, int half = 0, int halves = 1) {
+    ComposeTmp<GRID>& T = compose_tmp<GRID>(fb);
     if (half == 0) {
-        L.cover_n[0][lane] = 0;
-        L.cover_n[1][lane] = 0;
+        T.cover_n[0][lane] = 0;
+        T.cover_n[1][lane] = 0;
         if (lane == 0) {
             L.too_wide = 0;
             L.blendy = 0;
@@ -467,19 +479,19 @@ PG_D void compose_spans(ComposeLds<GRID>& L, const Camera& cam, int x0, int y0, 
     if (do_cols && lane < cols) {
         Span sp;
         const bool ok = resolve_axis(cam.px, cam.sw, cam.scale, tw, (x0 + lane) * kUnitPx, tile_scale, false, false, sp);
-        L.col[lane] = ok ? make_int4(sp.d0, sp.dn, sp.s0, sp.sn) : make_int4(0, 0, 0, 0);
+        T.col[lane] = ok ? make_int4(sp.d0, sp.dn, sp.s0, sp.sn) : make_int4(0, 0, 0, 0);
         wide = ok && sp.dn > MAXSPAN;
     }
     if (do_rows && lane < rows) {
         Span sp;
         const bool ok = resolve_axis(cam.py, cam.sh, cam.scale, th, (y0 + lane) * kUnitPx, tile_scale, false, true, sp);
-        L.row[lane] = ok ? make_int4(sp.d0, sp.dn, sp.s0, sp.sn) : make_int4(0, 0, 0, 0);
+        T.row[lane] = ok ? make_int4(sp.d0, sp.dn, sp.s0, sp.sn) : make_int4(0, 0, 0, 0);
         wide = wide || (ok && sp.dn > MAXSPAN);
         if (th2 > 0) {
             Span s2;
             const bool ok2 =
                 resolve_axis(cam.py, cam.sh, cam.scale, th2, (y0 + lane) * kUnitPx, tile_scale, false, true, s2);
-            L.row2[lane] = ok2 ? make_int4(s2.d0, s2.dn, s2.s0, s2.sn) : make_int4(0, 0, 0, 0);
+            T.row2[lane] = ok2 ? make_int4(s2.d0, s2.dn, s2.s0, s2.sn) : make_int4(0, 0, 0, 0);
             wide = wide || (ok2 && (!ok || s2.d0 != sp.d0 || s2.dn > sp.dn));  // not nested: take the fallback
         }
     }
@@ -489,15 +501,15 @@ PG_D void compose_spans(ComposeLds<GRID>& L, const Camera& cam, int x0, int y0, 
 #pragma unroll
     for (int axis = 0; axis < 2; axis++) {
         if (halves >= 2 && axis != half) continue;
-        const int4* spans = axis == 0 ? L.col : L.row;
+        const int4* spans = axis == 0 ? T.col : T.row;
         const int count = axis == 0 ? cols : rows;
         for (int q = lane; q < count * MAXSPAN; q += 64) {
             const int g = q / MAXSPAN, i = q % MAXSPAN;
             const int4 sp = spans[g];
             const int p = sp.x + i;
             if (sp.w > 0 && i < sp.y && p >= 0 && p < 64) {
-                const int slot = atomicAdd(&L.cover_n[axis][p], 1);
-                if (slot < 2) L.cover[axis][p][slot] = g | (sample_index(sp.z, sp.w, i, sp.y) << 8);
+                const int slot = atomicAdd(&T.cover_n[axis][p], 1);
+                if (slot < 2) T.cover[axis][p][slot] = g | (sample_index(sp.z, sp.w, i, sp.y) << 8);
             }
         }
     }
@@ -506,9 +518,9 @@ PG_D void compose_spans(ComposeLds<GRID>& L, const Camera& cam, int x0, int y0, 
 // The (at most two) covering grid indices of pixel `p` on `axis`, ascending = draw order.  Returns false when
 // more than two spans cover the pixel.
 template <int GRID>
-PG_D bool covering(const ComposeLds<GRID>& L, int axis, int p, int& ia, int& ib, int& ta, int& tb) {
-    const int n = L.cover_n[axis][p];
-    int c0 = L.cover[axis][p][0], c1 = L.cover[axis][p][1];
+PG_D bool covering(const ComposeTmp<GRID>& T, int axis, int p, int& ia, int& ib, int& ta, int& tb) {
+    const int n = T.cover_n[axis][p];
+    int c0 = T.cover[axis][p][0], c1 = T.cover[axis][p][1];
     if (n >= 2 && (c0 & 0xff) > (c1 & 0xff)) {
         const int t = c0;
         c0 = c1;
@@ -591,8 +603,9 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
     // lane as pixel column: covering grid columns; lane as pixel row: covering grid rows.
     int ca, cb, ua, ub, ra, rb, va, vb;
     if (L.too_wide) return false;
-    bool fits = covering(L, 0, lane, ca, cb, ua, ub);
-    fits = covering(L, 1, lane, ra, rb, va, vb) && fits;
+    const ComposeTmp<GRID>& T = compose_tmp<GRID>(fb);
+    bool fits = covering(T, 0, lane, ca, cb, ua, ub);
+    fits = covering(T, 1, lane, ra, rb, va, vb) && fits;
     if (__ballot(!fits)) return false;
 
     // All texel reads go through one buffer descriptor over the atlas: 32-bit byte offsets, and out-of-range
@@ -629,12 +642,12 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
     uint32_t row_a2 = kNoTexel, row_b2 = kNoTexel;  // lane = pixel row: texel rows of the second texture
     if (TWO) {
         if (ra >= 0) {
-            const int4 sp = L.row2[ra];
+            const int4 sp = T.row2[ra];
             const int i = lane - sp.x;
             if (sp.w > 0 && i >= 0 && i < sp.y) row_a2 = static_cast<uint32_t>(sample_index(sp.z, sp.w, i, sp.y) * tw) * 4u;
         }
         if (rb >= 0) {
-            const int4 sp = L.row2[rb];
+            const int4 sp = T.row2[rb];
             const int i = lane - sp.x;
             if (sp.w > 0 && i >= 0 && i < sp.y) row_b2 = static_cast<uint32_t>(sample_index(sp.z, sp.w, i, sp.y) * tw) * 4u;
         }
@@ -648,6 +661,7 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
         return __builtin_amdgcn_raw_buffer_load_b32(atlas_rsrc, base + col, row_first, 0);
     };
     const unsigned long long second_row = __ballot(rb >= 0);  // bit py: pixel row py is covered by two grid rows
+    __syncthreads();  // everybody has read the set-up tables out of the frame target's memory: it may be written now
 
     // Rows in batches: every texel gather of a batch is issued before any blend, so a batch costs one memory
     // round trip.  Candidates in draw order: background, (row a, col a), (row a, col b), (row b, col a), (row b, col b).
