@@ -7,8 +7,16 @@
 One "step" = one pass of the hot path over the whole batch: the logic kernel (auto-reset or 4 physics
 sub-steps per env) + the render kernel (64×64×3 observation per env into the contiguous slab).  Inputs
 (actions) are generated on the device from a counter hash, so nothing crosses PCIe inside the timed region.
-N > 1: one process per GPU (torch.distributed.run), envs sharded by global index, no data-path collective
-(weak scaling: 65 536 envs per GPU); time = max over ranks.
+N > 1: one process per GPU, envs sharded by global index, no data-path collective (weak scaling: 65 536 envs per
+GPU); time = max over ranks.  Started under torch.distributed.run (WORLD_SIZE set) this process is one rank; started
+plainly with --gpus N > 1 it launches the N ranks itself — `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 …` as a CHILD, before this process has imported torch or touched HIP —
+and relays rank 0's line.  --dry-launch prints that command instead of running it.
+
+The timed region is preceded by --warmup steps AND --settle steps (default 512, untimed, reported): all envs are
+made in the same step, and the first few hundred steps after that have almost no resets in them, so a short run would
+time a transient that is ≈ 8 % faster than steady state.  The roofline leg is always measured on its own window of
+≥ 256 steps after the timed region (`roofline.window`), whatever --steps says.
 
 Prints ONE JSON line (rank 0) with `roofline` (render kernel, HIP-event timed on the engine's stream) and,
 at N=1, `cpu_baseline` (the CPU oracle on a bounded sample of the same workload, all host cores).
@@ -93,6 +101,28 @@ def cpu_baseline(game, run_seed, budget_s=20.0):
                       "render on, %d threads" % (game, envs, envs, steps, cores)}
 
 
+def launch_ranks(a):
+    """--gpus N > 1 without a launcher: start the N ranks as children (one per GPU, RCCL rendezvous on 127.0.0.1).
+    Nothing in this process has touched the GPU — torch is not even imported — so no initialised HIP runtime is ever
+    replaced; the parent only waits and passes the children's output and exit code on."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    args = [x for x in sys.argv[1:] if x != "--dry-launch"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + args
+    if a.dry_launch:
+        print(json.dumps({"launch": cmd, "n_gpus": a.gpus}), flush=True)
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,7 +139,18 @@ def main():
                          "remainder), one HIP stream per game")
     ap.add_argument("--gather", action="store_true",
                     help="mixed workload only: rooted RCCL gather of obs/reward/done to rank 0 after every step")
+    ap.add_argument("--settle", type=int, default=512,
+                    help="untimed steps before the warm-up so that episode ends are spread out (steady state)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="with --gpus N > 1 and no WORLD_SIZE: print the torch.distributed.run command and exit")
     a = ap.parse_args()
+    if a.steps < 1:
+        ap.error("--steps must be >= 1")
+    if a.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(a)
 
     import torch
     from procgen2_amd.vec_env import ProcgenVecEnv
@@ -124,9 +165,8 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     n_gpus = world if distributed else 1
-    if a.gpus != n_gpus and rank == 0:
-        print("note: --gpus %d but WORLD_SIZE %d; launch with torch.distributed.run for N>1" % (a.gpus, n_gpus),
-              file=sys.stderr)
+    if a.gpus != n_gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d" % (a.gpus, n_gpus))
 
     run_seed = 0
     if a.workload == "mixed":
@@ -134,6 +174,8 @@ def main():
     env = ProcgenVecEnv(a.game, a.envs, device=local_rank, seed_base=1, env_offset=rank * a.envs,
                         distribution_mode=a.mode)
     env.reset()
+    if a.settle > 0:
+        env.timed_steps(a.settle, run_seed)      # untimed: spreads the episode ends out (see the module docstring)
     env.timed_steps(max(1, a.warmup), run_seed)  # untimed warm-up steps (same code path as the timed ones)
 
     def fence():
@@ -144,14 +186,20 @@ def main():
 
     fence()
     t0 = time.perf_counter()
-    total_ms, render_ms = env.timed_steps(a.steps, run_seed)  # returns after the stream has drained
+    env.timed_steps(a.steps, run_seed)  # returns after the stream has drained
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     elapsed = t1 - t0
+    fence()
+    # Roofline leg: the dominant kernel's average launch duration over its own steady-state window (HIP events around
+    # every render launch, on the engine's stream), independent of how short the timed region was asked to be.
+    window = max(256, a.steps)
+    _, render_ms = env.timed_steps(window, run_seed)
+    render_avg_ms = render_ms / window
     if distributed:
-        t = torch.tensor([elapsed, render_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, render_avg_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, render_ms = float(t[0]), float(t[1])
+        elapsed, render_avg_ms = float(t[0]), float(t[1])
     fence()
 
     done_frac = float(env.done.float().mean().item())
@@ -160,7 +208,6 @@ def main():
     if rank == 0:
         total_steps = float(n_gpus) * a.envs * a.steps
         value = total_steps / elapsed
-        render_avg_ms = render_ms / a.steps
         achieved = ALGO_BYTES_PER_ENV_STEP * a.envs / (render_avg_ms * 1e-3) / 1e9
         traffic, traffic_src = measured_traffic(a.game) if a.envs == 65536 and not a.mode else (None, None)
         line = {
@@ -170,6 +217,7 @@ def main():
             "n_gpus": n_gpus,
             "steps": a.steps,
             "warmup": a.warmup,
+            "settle_steps": a.settle,
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
@@ -184,7 +232,10 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * a.envs,
-                         "avg_launch_ms": render_avg_ms},
+                         "avg_launch_ms": render_avg_ms,
+                         "window": "%d launches after the timed region (steps %d..%d since make), HIP events on the "
+                                   "engine's stream" % (window, a.settle + max(1, a.warmup) + a.steps,
+                                                        a.settle + max(1, a.warmup) + a.steps + window - 1)},
             "done_fraction_last_step": done_frac,
         }
         if n_gpus == 1 and not a.no_cpu_baseline and not a.mode:
@@ -215,7 +266,7 @@ def mixed(a, torch, ProcgenVecEnv, distributed, world, rank, local_rank, n_gpus,
                 e.step_synthetic(run_seed, ordered=False)
             if a.gather and distributed:
                 for e in envs:
-                    e.sync()
+                    e.publish()  # torch's current stream waits for the engine's stream: no host synchronisation
                     e.gather(dst=0)
         for e in envs:
             e.sync()
@@ -226,6 +277,8 @@ def mixed(a, torch, ProcgenVecEnv, distributed, world, rank, local_rank, n_gpus,
             dist.barrier()
             torch.cuda.synchronize()
 
+    if a.settle > 0:
+        run(a.settle)
     run(max(1, a.warmup))
     fence()
     t0 = time.perf_counter()
@@ -245,6 +298,7 @@ def mixed(a, torch, ProcgenVecEnv, distributed, world, rank, local_rank, n_gpus,
         print(json.dumps({
             "metric": "env-steps/sec, all 7 games mixed, 64x64x3 obs",
             "value": value, "unit": "env-steps/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
+            "settle_steps": a.settle,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/f32", "data": "synthetic",
             "config": {"workload": "all seven games, %d envs per GPU split %s, one stream per game, uniform random "
@@ -262,4 +316,4 @@ def mixed(a, torch, ProcgenVecEnv, distributed, world, rank, local_rank, n_gpus,
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -148,8 +148,9 @@ PGV_API int32_t pgv_render_frame(pgv_env* env, int32_t index, int32_t width, int
 PGV_API int32_t pgv_timed_steps(pgv_env* env, int32_t steps, uint32_t run_seed, double* total_ms,
                                 double* render_kernel_ms);
 
-/* Debug switches (tests only).  Bit 0: render the background and tile layer by replaying the draw list
- * one blit at a time instead of the fused row composer; results are identical, only slower. */
+/* Debug switches (tests only); neither changes a result.  Bit 0: render the background and tile layer by replaying the
+ * draw list one blit at a time instead of the fused row composer.  Bit 8: no level prefetch — every reset generates its
+ * level inside the step.  Any other bit is refused. */
 PGV_API int32_t pgv_set_debug(pgv_env* env, int32_t flags);
 
 /* Parity taps (host pointers): game-defined state vector / tile ids of one env; return the full

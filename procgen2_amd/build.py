@@ -75,7 +75,18 @@ def _parallel(jobs, verbose):
             f.result()
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, ablate=False):
+    """ablate=True: the timing-experiment build (-DPG_ABLATE, csrc/pg_render.h) of the engine alone, as
+    lib/libprocgen2_hip_ablate.so with its objects in build_ablate/ — for tools/ablate_render.py, never the product."""
+    common, aliases, obj_dir = COMMON, ALIASES, OBJ
+    if ablate:
+        common = COMMON + ["-DPG_ABLATE"]
+        aliases = {"libprocgen2_hip_ablate.so": 0}
+        obj_dir = OBJ + "_ablate"
+    return _build(force, verbose, common, aliases, obj_dir)
+
+
+def _build(force, verbose, COMMON, ALIASES, OBJ):
     os.makedirs(LIB, exist_ok=True)
     os.makedirs(OBJ, exist_ok=True)
     cc = hipcc()
@@ -113,7 +124,8 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--quiet", action="store_true")
+    ap.add_argument("--ablate", action="store_true", help="build lib/libprocgen2_hip_ablate.so (-DPG_ABLATE) instead")
     a = ap.parse_args()
-    for o in build(force=a.force, verbose=not a.quiet):
+    for o in build(force=a.force, verbose=not a.quiet, ablate=a.ablate):
         print("built", os.path.relpath(o))
     sys.exit(0)

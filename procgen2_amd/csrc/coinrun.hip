@@ -817,7 +817,7 @@ __global__ void __launch_bounds__(64) resolve_kernel(State s, StepIO io) {
 
 // render_game(true) (coinrun.cpp:443-470): one workgroup of two wavefronts per env (pg_render.h).
 // flags bit 0: force the draw-list replay for background + tiles (fallback path; parity tests run both).
-// Higher bits are timing experiments only (tools/ablate_render.py) and change the picture.
+// Higher bits are timing experiments (tools/ablate_render.py), compiled in only with -DPG_ABLATE (pg_render.h PG_ABL).
 constexpr int kRenderWaves = 2;  // wavefronts per env (pg_render.h: two waves share one frame's LDS target)
 
 __global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, AtlasView atlas, const uint8_t* mask,
@@ -839,7 +839,7 @@ __global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, Atla
     const int themes = SI(s, I_THEMES, env);
     const int sflags = SI(s, I_FLAGS, env);
     const int buf = (sflags & kFlagBuf) ? 1 : 0;
-    const int backdrop = (flags & 16) ? 9 : (themes & 0xff);  // (bit 4: timing experiment — one shared background)
+    const int backdrop = PG_ABL(flags, 16) ? 9 : (themes & 0xff);  // (bit 4: timing experiment — one shared background)
     const int alien = (themes >> 8) & 0xff, ground_theme = (themes >> 16) & 0xff;
     const int n_ent = SI(s, I_NENT, env);
     const int n_mob = SI(s, I_NMOB, env);
@@ -918,7 +918,7 @@ __global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, Atla
     const int4 tile_desc = descs.uniform(kTexMid);  // every tile texture is 128×128 (checked at make time)
 
     bool composed = false;
-    if (!(flags & 5) && cols <= kGrid && rows <= kGrid) {
+    if (!(flags & 1) && !PG_ABL(flags, 4) && cols <= kGrid && rows <= kGrid) {
         compose_spans(fb, L, cam, x0, y0, cols, rows, tile_desc.y, tile_desc.z, kUnitPx / tile_desc.y, lane, 0, half, halves);
         // Texel offset of each tile kind's texture, one per lane (0..7), looked up with a cross-lane read:
         // lanes 0-3 = wall_top, wall_mid, lava_top, lava_mid (tile id - 1), lanes 4-7 = the four crates.
@@ -951,7 +951,7 @@ __global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, Atla
         const bool may_blend = L.blendy != 0;
         composed = compose_rows(fb, L, atlas, bg, has_bg, cols, rows, tile_desc.y, lane, flags, half, halves, may_blend);
     }
-    if (flags & 4) composed = true;  // (bit 2: timing experiment — no background/tiles at all)
+    if (PG_ABL(flags, 4)) composed = true;  // (bit 2: timing experiment — no background/tiles at all)
     if (!composed) {  // draw-list replay of background and tiles (tilemap.cpp:294-321)
         wave_clear(fb, lane, half, halves);
         mine = bg;
@@ -990,7 +990,7 @@ __global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, Atla
         }
     }
 
-    if (!(flags & 2)) {  // (bit 1: timing experiment — skips particles, sprites and the agent)
+    if (!PG_ABL(flags, 2)) {  // (bit 1: timing experiment — skips particles, sprites and the agent)
         // One draw per lane, in the reference's order: particles (owners in the particle system's set order,
         // common_systems.cpp:315-337), then the sprites of the draw list (positive z, :41-63; empty until the
         // first update — D2), then the agent (:254-278).
@@ -1082,7 +1082,7 @@ __global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, Atla
         wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
     }
     __syncthreads();
-    if (!(flags & 8)) wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane, half, halves);
+    if (!PG_ABL(flags, 8)) wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane, half, halves);
 }
 
 // cenv_render's frame (coinrun.cpp:393-411 → render_game(false), :443-470) for one env: pg_frame.h.

@@ -280,7 +280,8 @@ int32_t pgv_make_config(const pgv_config* cfg, pgv_env** out) {
     if (device < 0 || device >= count) return fail("pgv_make: device index out of range");
     PG_HIP(hipSetDevice(device));
 
-    std::unique_ptr<pgv_env> e(new pgv_env());
+    // every failure path below releases what was created so far (streams, events, atlas, device memory)
+    std::unique_ptr<pgv_env, void (*)(pgv_env*)> e(new pgv_env(), pgv_close);
     e->n = num_envs;
     e->device = device;
     e->env_offset = env_offset;
@@ -300,22 +301,10 @@ int32_t pgv_make_config(const pgv_config* cfg, pgv_env** out) {
     for (auto& ev : e->side_ev) PG_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 
     std::string err;
-    if (!e->atlas.load(pg::asset_root(), e->game->texture_names(), err)) {
-        pgv_env* raw = e.release();
-        pgv_close(raw);
-        return fail("pgv_make: " + err);
-    }
+    if (!e->atlas.load(pg::asset_root(), e->game->texture_names(), err)) return fail("pgv_make: " + err);
     err = e->game->check_atlas(e->atlas.sizes());
-    if (!err.empty()) {
-        pgv_env* raw = e.release();
-        pgv_close(raw);
-        return fail("pgv_make: " + err);
-    }
-    if (!e->atlas.upload(err)) {
-        pgv_env* raw = e.release();
-        pgv_close(raw);
-        return fail("pgv_make: " + err);
-    }
+    if (!err.empty()) return fail("pgv_make: " + err);
+    if (!e->atlas.upload(err)) return fail("pgv_make: " + err);
     const size_t sb = state_blob_bytes(e.get());
     PG_HIP(hipMalloc(&e->d_state, sb));
     PG_HIP(hipMemsetAsync(e->d_state, 0, sb, e->stream));
@@ -352,10 +341,18 @@ int32_t pgv_reset(pgv_env* e, const uint8_t* d_mask, const int32_t* d_seeds) {
     return 0;
 }
 
-static int32_t step_impl(pgv_env* e, const int32_t* d_actions, uint32_t run_seed) {
+// One step's launches.  The launch status is read after each group of launches: hipGetLastError reports (and clears)
+// only the most recent error, and pregen's hipStreamQuery legitimately leaves hipErrorNotReady behind.
+static int32_t step_impl(pgv_env* e, const int32_t* d_actions, uint32_t run_seed, hipEvent_t before_render = nullptr,
+                         hipEvent_t after_render = nullptr) {
     e->game->launch_logic(e->stream, d_actions, run_seed, e->step_index, e->env_offset, e->io());
+    PG_HIP(hipGetLastError());
     pregen(e, false, false);  // before the render launch: the generator overlaps it
+    (void)hipGetLastError();  // hipErrorNotReady of the stream query is not an error
+    if (before_render) PG_HIP(hipEventRecord(before_render, e->stream));
     e->game->launch_render(e->stream, nullptr, e->io());
+    PG_HIP(hipGetLastError());
+    if (after_render) PG_HIP(hipEventRecord(after_render, e->stream));
     e->step_index++;
     return 0;
 }
@@ -364,17 +361,13 @@ int32_t pgv_step(pgv_env* e, const int32_t* d_actions) {
     if (!e) return fail("pgv_step: env is NULL");
     if (!d_actions) return fail("pgv_step: actions is NULL");
     PG_HIP(hipSetDevice(e->device));
-    step_impl(e, d_actions, 0);
-    PG_HIP(hipGetLastError());
-    return 0;
+    return step_impl(e, d_actions, 0);
 }
 
 int32_t pgv_step_synthetic(pgv_env* e, uint32_t run_seed) {
     if (!e) return fail("pgv_step_synthetic: env is NULL");
     PG_HIP(hipSetDevice(e->device));
-    step_impl(e, nullptr, run_seed);
-    PG_HIP(hipGetLastError());
-    return 0;
+    return step_impl(e, nullptr, run_seed);
 }
 
 static int32_t ensure_staging(pgv_env* e) {
@@ -542,34 +535,33 @@ int32_t pgv_copy_out(pgv_env* e, uint8_t* h_obs, float* h_reward, uint8_t* h_don
 
 int32_t pgv_timed_steps(pgv_env* e, int32_t steps, uint32_t run_seed, double* total_ms, double* render_kernel_ms) {
     if (!e) return fail("pgv_timed_steps: env is NULL");
+    if (steps < 1 || steps > (1 << 20)) return fail("pgv_timed_steps: steps must be in 1..1048576");
     PG_HIP(hipSetDevice(e->device));
-    // Whole region on the env's stream.
-    PG_HIP(hipEventRecord(e->ev[0], e->stream));
-    double render_sum = 0.0;
-    // Per-launch render timing: events bracket each render launch; they are read back after the region
-    // so the host never stalls the stream inside it.  Events are recycled in pairs every 64 steps.
-    std::vector<hipEvent_t> pairs(size_t(steps) * 2, nullptr);
-    for (auto& p : pairs) PG_HIP(hipEventCreate(&p));
-    for (int s = 0; s < steps; s++) {
-        e->game->launch_logic(e->stream, nullptr, run_seed, e->step_index, e->env_offset, e->io());
-        pregen(e, false, false);
-        PG_HIP(hipEventRecord(pairs[2 * s], e->stream));
-        e->game->launch_render(e->stream, nullptr, e->io());
-        PG_HIP(hipEventRecord(pairs[2 * s + 1], e->stream));
-        e->step_index++;
-    }
+    // One event pair per render launch, created before the region starts and destroyed on every way out; they are read
+    // back after the region so the host never stalls the stream inside it.
+    struct Events {
+        std::vector<hipEvent_t> v;
+        ~Events() {
+            for (hipEvent_t p : v)
+                if (p) hipEventDestroy(p);
+        }
+    } pairs;
+    pairs.v.assign(size_t(steps) * 2, nullptr);
+    for (auto& p : pairs.v) PG_HIP(hipEventCreate(&p));
+    PG_HIP(hipEventRecord(e->ev[0], e->stream));  // whole region on the env's stream
+    for (int s = 0; s < steps; s++)
+        if (step_impl(e, nullptr, run_seed, pairs.v[2 * s], pairs.v[2 * s + 1])) return 1;
     PG_HIP(hipEventRecord(e->ev[1], e->stream));
     PG_HIP(hipEventSynchronize(e->ev[1]));
-    PG_HIP(hipGetLastError());
     float ms = 0.0f;
     PG_HIP(hipEventElapsedTime(&ms, e->ev[0], e->ev[1]));
     if (total_ms) *total_ms = ms;
+    double render_sum = 0.0;
     for (int s = 0; s < steps; s++) {
         float k = 0.0f;
-        PG_HIP(hipEventElapsedTime(&k, pairs[2 * s], pairs[2 * s + 1]));
+        PG_HIP(hipEventElapsedTime(&k, pairs.v[2 * s], pairs.v[2 * s + 1]));
         render_sum += k;
     }
-    for (auto& p : pairs) hipEventDestroy(p);
     if (render_kernel_ms) *render_kernel_ms = render_sum;
     return 0;
 }
@@ -603,6 +595,10 @@ int32_t pgv_render_frame(pgv_env* e, int32_t index, int32_t width, int32_t heigh
 
 int32_t pgv_set_debug(pgv_env* e, int32_t flags) {
     if (!e) return fail("pgv_set_debug: env is NULL");
+#ifndef PG_ABLATE
+    if (flags & ~(1 | pg::kDebugNoPrefetch))
+        return fail("pgv_set_debug: only bit 0 (draw-list replay) and bit 8 (no level prefetch) exist in this build");
+#endif
     if (e->side) hipStreamSynchronize(e->side);
     e->game->debug_flags = flags;
     return 0;
@@ -686,6 +682,7 @@ int32_t cenv_get_env_version(void) { return kVersion; }
 int32_t cenv_make(const char* render_mode, cenv_option* options, int32_t options_size) {
     (void)render_mode;
     if (g.env) cenv_close();
+    g.window_w = g.window_h = 512;               // coinrun.cpp:29-30; a previous make's size does not carry over
     int seed = static_cast<int>(time(nullptr));  // coinrun.cpp:130
     int num_envs = 1, game = PG_DEFAULT_GAME, device = 0, env_offset = 0, num_levels = 0, start_level = 0, mode = 0, game_flags = 0;
     for (int i = 0; i < options_size; i++) {
@@ -741,8 +738,10 @@ int32_t cenv_make(const char* render_mode, cenv_option* options, int32_t options
     g.h_actions.assign(num_envs, 0);
     g.h_frame.assign(size_t(g.window_w) * g.window_h * 3, 0);
     if (hipMalloc(reinterpret_cast<void**>(&g.d_actions), size_t(num_envs) * 4) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&g.d_seeds), size_t(num_envs) * 4) != hipSuccess)
+        hipMalloc(reinterpret_cast<void**>(&g.d_seeds), size_t(num_envs) * 4) != hipSuccess) {
+        cenv_close();
         return fail("cenv_make: hipMalloc failed");
+    }
 
     // Spaces (coinrun.cpp:154-172): "screen" Box(0,255), "action" MultiDiscrete([15]).
     g.obs_space.key = "screen";

@@ -28,6 +28,15 @@
 #include "pg_geom.h"
 #include "pg_sincos.h"
 
+// Timing experiments (tools/ablate_render.py) change the picture; they exist only in the -DPG_ABLATE build
+// (`python -m procgen2_amd.build --ablate` → lib/libprocgen2_hip_ablate.so).  In the product build every test on an
+// ablation bit is the constant 0 and the compiler drops the branch.
+#ifdef PG_ABLATE
+#define PG_ABL(flags, bits) ((flags) & (bits))
+#else
+#define PG_ABL(flags, bits) 0
+#endif
+
 namespace pg {
 
 constexpr int kFbWords = kObsW * kObsH;
@@ -612,9 +621,9 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
     // (= "no candidate") reads return 0 without a branch.
     // (`ablate` bits 5/6 are timing experiments: a descriptor with zero records drops every load through it.)
     const __amdgpu_buffer_rsrc_t bg_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint32_t*>(atlas.texels), 0, (ablate & 32) ? 0 : static_cast<int>(atlas.texel_bytes), 0x00020000);
+        const_cast<uint32_t*>(atlas.texels), 0, PG_ABL(ablate, 32) ? 0 : static_cast<int>(atlas.texel_bytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t atlas_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint32_t*>(atlas.texels), 0, (ablate & 64) ? 0 : static_cast<int>(atlas.texel_bytes), 0x00020000);
+        const_cast<uint32_t*>(atlas.texels), 0, PG_ABL(ablate, 64) ? 0 : static_cast<int>(atlas.texel_bytes), 0x00020000);
 
     // background: per-lane column byte offset, per-row (lane = row index) row byte offset
     uint32_t bg_col = kNoTexel, bg_row = kNoTexel;
@@ -669,7 +678,7 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
 #define PG_BATCH 8
 #endif
     constexpr int kBatch = PG_BATCH;
-    if (ablate & 128) {  // timing experiment: everything but the row loop
+    if (PG_ABL(ablate, 128)) {  // timing experiment: everything but the row loop
         __syncthreads();
         return true;
     }
@@ -706,7 +715,7 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
 #pragma unroll
                 for (int j = 0; j < 5; j++) translucent |= ((t[k][j] >> 24) + 1u) & 0xFEu;
         }
-        if (ablate & 512) translucent = 0;  // timing experiment: never take the blending path
+        if (PG_ABL(ablate, 512)) translucent = 0;  // timing experiment: never take the blending path
         if (bg_mod == 255 && (!may_blend || __ballot(translucent != 0) == 0)) {
             // Opaque-or-absent everywhere in the batch: OVER is "last drawn wins" (what S4 yields for a = 0 / 255).
 #pragma unroll

@@ -138,6 +138,11 @@ class ProcgenVecEnv:
     def sync(self):
         pglib.check(self.L, self.L.pgv_sync(self._h), "pgv_sync")
 
+    def publish(self):
+        """Order torch's current stream behind the engine's stream (after step_synthetic(ordered=False)), without
+        blocking the host: whatever is enqueued on the current stream next sees the step's outputs."""
+        self._after()
+
     def close(self):
         if self._h:
             self.L.pgv_close(self._h)
@@ -151,30 +156,71 @@ class ProcgenVecEnv:
 
     # -- multi-GPU -------------------------------------------------------------------------------
     def gather(self, dst=0, group=None):
-        """Rooted gather of (obs, reward, done) to rank `dst`; other ranks get None.  Optional: the hot
-        path itself never communicates."""
-        return gather_outputs(self.obs, self.reward, self.done, dst=dst, group=group)
+        """Rooted gather of (obs, reward, done) to rank `dst` (a rank of `group`); other ranks get None.  Optional: the
+        hot path itself never communicates.  The plan (per-rank env counts, the root's slabs) is made on the first call
+        and reused: a call is then one batch of point-to-point transfers and no host synchronisation."""
+        key = (dst, id(group))
+        plan = self._gathers.get(key) if hasattr(self, "_gathers") else None
+        if plan is None:
+            if not hasattr(self, "_gathers"):
+                self._gathers = {}
+            plan = self._gathers[key] = RootGather((self.obs, self.reward, self.done), dst=dst, group=group)
+        return plan()
+
+
+class RootGather:
+    """Rooted gather of a tuple of per-rank tensors `[n_r, ...]` into `[sum n_r, ...]` slabs on rank `dst` of `group`
+    (SURVEY.md §8e).  Ranks may hold different env counts.
+
+    Built once: the counts are exchanged once (one all_gather of an int per rank) and the root allocates one slab per
+    tensor.  Every call is one `batch_isend_irecv`: the root receives each peer's block STRAIGHT into its slice of the
+    slab (no temporaries, no concatenation) while copying its own block, every peer sends its tensors as they are.  On
+    GPUs this is RCCL grouped send/recv, so the root's inbound xGMI links (one per peer, point to point) all run at
+    once; the CPU tests run the same code over gloo.  The returned slabs are reused by the next call."""
+
+    def __init__(self, tensors, dst=0, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.tensors = tuple(tensors)
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)  # rank inside `group`, like dst
+        self.dst = dst
+        # P2P ops address peers by GLOBAL rank.
+        self.global_rank = [dist.get_global_rank(group, r) if group is not None else r for r in range(self.world)]
+        n = self.tensors[0].shape[0]
+        counts = [None] * self.world
+        dist.all_gather_object(counts, int(n), group=group)  # once, on the host: no device sync per call later
+        self.counts = [int(c) for c in counts]
+        self.offsets = [0]
+        for c in self.counts:
+            self.offsets.append(self.offsets[-1] + c)
+        self.slabs = None
+        if self.rank == dst:
+            total = self.offsets[-1]
+            self.slabs = tuple(torch.empty((total,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+                               for t in self.tensors)
+
+    def __call__(self):
+        dist = self.dist
+        ops = []
+        if self.rank == self.dst:
+            for t, slab in zip(self.tensors, self.slabs):
+                for r in range(self.world):
+                    part = slab[self.offsets[r]:self.offsets[r + 1]]  # contiguous: a block of leading indices
+                    if r == self.rank:
+                        part.copy_(t)
+                    elif self.counts[r]:
+                        ops.append(dist.P2POp(dist.irecv, part, self.global_rank[r], group=self.group))
+        elif self.counts[self.rank]:
+            for t in self.tensors:
+                ops.append(dist.P2POp(dist.isend, t.contiguous(), self.global_rank[self.dst], group=self.group))
+        if ops:
+            for q in dist.batch_isend_irecv(ops):
+                q.wait()
+        return self.slabs if self.rank == self.dst else tuple(None for _ in self.tensors)
 
 
 def gather_outputs(obs, reward, done, dst=0, group=None):
-    """torch.distributed rooted gather (RCCL on GPUs: grouped send/recv so all inbound xGMI links of the
-    root run concurrently; gloo in the CPU tests).  Ranks may hold different env counts."""
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    counts = [torch.zeros(1, dtype=torch.int64, device=obs.device) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([obs.shape[0]], dtype=torch.int64, device=obs.device), group=group)
-    counts = [int(c.item()) for c in counts]
-    out = []
-    for t in (obs, reward, done):
-        if rank == dst:
-            parts = [torch.empty((c,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for c in counts]
-            parts[dst].copy_(t)
-            reqs = [dist.irecv(parts[r], src=r, group=group) for r in range(world) if r != dst]
-            for q in reqs:
-                q.wait()
-            out.append(torch.cat(parts, dim=0))
-        else:
-            dist.send(t.contiguous(), dst=dst, group=group)
-            out.append(None)
-    return tuple(out)
+    """One-shot form of RootGather (builds the plan, runs it once)."""
+    return RootGather((obs, reward, done), dst=dst, group=group)()

@@ -114,3 +114,23 @@ def test_cenv_wrapper_on_reference_toy_env():
     with pytest.raises(Exception, match="Unrecognized action type"):
         env.step(3.5)
     env.close()
+
+
+def test_bench_launches_n_ranks_itself_before_touching_the_gpu():
+    """`python bench.py --gpus N` without a launcher starts N ranks as children; --dry-launch shows the
+    command.  The parent must not have imported torch (nothing may initialise HIP before the children exist)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    code = ("import sys, runpy; sys.argv = ['bench.py', '--gpus', '2', '--steps', '3', '--warmup', '1', '--dry-launch'];"
+            "\ntry:\n    runpy.run_path(%r, run_name='__main__')\nexcept SystemExit as e:\n    assert not e.code, e.code\n"
+            "assert 'torch' not in sys.modules, 'the launcher imported torch'\n" % os.path.join(root, "bench.py"))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
+    line = json.loads(out.strip().splitlines()[-1])
+    cmd = line["launch"]
+    assert line["n_gpus"] == 2
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "2" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"] and "--dry-launch" not in cmd

@@ -42,20 +42,29 @@ def _worker(rank, world, port, total, steps, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle_util import OracleVec
+    from procgen2_amd.vec_env import RootGather
     lo, hi = shard_range(total, world, rank)
-    ora = OracleVec("maze", hi - lo, seed_base=1, env_offset=lo, render=False)
+    ora = OracleVec("maze", hi - lo, seed_base=1, env_offset=lo, render=True)
+    ora.reset()
+    # the tensors a ProcgenVecEnv owns: obs u8 [n,64,64,3], reward f32 [n], done u8 [n]; the plan is built once
+    obs = torch.zeros((hi - lo, 64, 64, 3), dtype=torch.uint8)
+    rew = torch.zeros(hi - lo, dtype=torch.float32)
+    done = torch.zeros(hi - lo, dtype=torch.uint8)
+    plan = RootGather((obs, rew, done), dst=0)
     for s in range(steps):
-        ora.step(None, run_seed=0)
-    obs = torch.from_numpy(np.tile(ora.reward[:, None], (1, 4)).astype(np.float32))  # stand-in payload [n,4]
-    rew = torch.from_numpy(ora.reward.copy())
-    done = torch.from_numpy(ora.done.copy())
-    g_obs, g_rew, g_done = gather_outputs(obs, rew, done, dst=0)
+        o, r, d = ora.step(None, run_seed=0)
+        obs.copy_(torch.from_numpy(o.reshape(-1, 64, 64, 3)))
+        rew.copy_(torch.from_numpy(r))
+        done.copy_(torch.from_numpy(d))
+        g_obs, g_rew, g_done = plan()  # every step, like bench.py --gather
+        if rank == 0 and s in (0, steps - 1):
+            np.save(os.path.join(out_dir, "obs%d.npy" % s), g_obs.numpy())
+            np.save(os.path.join(out_dir, "rew%d.npy" % s), g_rew.numpy())
+            np.save(os.path.join(out_dir, "done%d.npy" % s), g_done.numpy())
+        if rank != 0:
+            assert g_obs is None and g_rew is None and g_done is None
     if rank == 0:
-        np.save(os.path.join(out_dir, "rew.npy"), g_rew.numpy())
-        np.save(os.path.join(out_dir, "done.npy"), g_done.numpy())
-        np.save(os.path.join(out_dir, "obs.npy"), g_obs.numpy())
-    else:
-        assert g_obs is None and g_rew is None and g_done is None
+        assert plan.slabs[0].shape == (total, 64, 64, 3) and plan.slabs[0].dtype == torch.uint8
     ora.close()
     dist.barrier()
     dist.destroy_process_group()
@@ -65,10 +74,39 @@ def test_two_rank_sharded_rollout_equals_single_process(tmp_path):
     total, steps, world = 21, 40, 2  # odd total: ranks hold different env counts
     mp.spawn(_worker, args=(world, _free_port(), total, steps, str(tmp_path)), nprocs=world, join=True)
     from oracle_util import OracleVec
-    whole = OracleVec("maze", total, seed_base=1, env_offset=0, render=False)
+    whole = OracleVec("maze", total, seed_base=1, env_offset=0, render=True)
+    whole.reset()
     for s in range(steps):
-        whole.step(None, run_seed=0)
-    assert np.array_equal(np.load(tmp_path / "rew.npy"), whole.reward)
-    assert np.array_equal(np.load(tmp_path / "done.npy"), whole.done)
-    assert np.load(tmp_path / "obs.npy").shape == (total, 4)
+        o, r, d = whole.step(None, run_seed=0)
+        if s in (0, steps - 1):  # the root's slab == the single-process batch, every observation byte
+            assert np.array_equal(np.load(tmp_path / ("obs%d.npy" % s)).reshape(total, -1), o)
+            assert np.array_equal(np.load(tmp_path / ("rew%d.npy" % s)), r)
+            assert np.array_equal(np.load(tmp_path / ("done%d.npy" % s)), d)
     whole.close()
+
+
+def _subgroup_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    group = dist.new_group([1, 2])  # group rank 0 = global rank 1: the two numberings differ
+    if rank in (1, 2):
+        n = 3 if rank == 1 else 5
+        obs = torch.full((n, 64, 64, 3), rank, dtype=torch.uint8)
+        rew = torch.full((n,), float(rank))
+        done = torch.full((n,), rank, dtype=torch.uint8)
+        g_obs, g_rew, g_done = gather_outputs(obs, rew, done, dst=0, group=group)  # dst is a GROUP rank
+        if rank == 1:
+            assert g_obs.shape == (8, 64, 64, 3)
+            assert (g_obs[:3] == 1).all() and (g_obs[3:] == 2).all()
+            assert g_rew.tolist() == [1.0] * 3 + [2.0] * 5 and g_done.tolist() == [1] * 3 + [2] * 5
+            open(os.path.join(out_dir, "ok"), "w").write("1")
+        else:
+            assert g_obs is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_inside_a_subgroup_translates_ranks(tmp_path):
+    mp.spawn(_subgroup_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    assert (tmp_path / "ok").exists()

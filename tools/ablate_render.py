@@ -1,8 +1,17 @@
+"""Timing experiments on coinrun's render kernel: needs the -DPG_ABLATE build (python -m procgen2_amd.build --ablate).
+The product library refuses these debug bits (include/procgen2_vec.h pgv_set_debug)."""
+import os
 import sys
-sys.path.insert(0,'tests')
-from engine_util import EngineVec
-for flags,name in ((0,'full'),(512,'rows never blend'),(128,'no row loop'),(128+2,'no rows/sprites'),(128+2+8,'no rows/spr/store'),(4+2+8,'nothing')):
-    e=EngineVec('coinrun',65536,seed_base=1); e.reset(); e.timed(40)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from engine_util import EngineVec  # noqa: E402
+LIB = os.path.join(ROOT, "procgen2_amd", "lib", "libprocgen2_hip_ablate.so")
+for flags, name in ((0, "full"), (512, "rows never blend"), (128, "no row loop"), (128 + 2, "no rows/sprites"),
+                    (128 + 2 + 8, "no rows/spr/store"), (4 + 2 + 8, "nothing")):
+    e = EngineVec("coinrun", 65536, seed_base=1, lib_path=LIB)
+    e.reset()
+    e.timed(40)
     e.set_debug(flags)
-    tot,ren=e.timed(64)
-    print('%-18s render %.3f ms  total %.3f ms'%(name,ren/64,tot/64)); e.close()
+    tot, ren = e.timed(64)
+    print("%-18s render %.3f ms  total %.3f ms" % (name, ren / 64, tot / 64))
+    e.close()
