@@ -16,6 +16,7 @@
 #include <cmath>
 
 #include "pgo_env.h"
+#include "pgo_kruskal.h"
 
 namespace pgo {
 namespace {
@@ -118,41 +119,6 @@ class Chaser final : public Env {
         return id;
     }
 
-    // maze_generator.cpp:47-130: Kruskal over per-cell sets; only the set labels matter for the result.
-    void carve(int dim, std::vector<int>& grid) {
-        const int ah = dim + 2;
-        grid.assign(ah * ah, 1);
-        grid[1 + ah * 1] = 0;
-        std::vector<int> label(dim * dim);
-        for (int i = 0; i < dim * dim; i++) label[i] = i;
-        struct Seg {
-            int x1, y1, x2, y2;
-        };
-        std::vector<Seg> walls;
-        for (int i = 1; i < dim; i += 2)
-            for (int j = 0; j < dim; j += 2)
-                if (i > 0 && i < dim - 1) walls.push_back({i - 1, j, i + 1, j});
-        for (int i = 0; i < dim; i += 2)
-            for (int j = 1; j < dim; j += 2)
-                if (j > 0 && j < dim - 1) walls.push_back({i, j - 1, i, j + 1});
-        while (!walls.empty()) {
-            const int n = rng_.irange(0, static_cast<int>(walls.size()) - 1);
-            const Seg w = walls[n];
-            const int s0 = label[w.y1 + dim * w.x1], s1 = label[w.y2 + dim * w.x2];
-            const int x0 = (w.x1 + w.x2) / 2, y0 = (w.y1 + w.y2) / 2;
-            const int centre = y0 + dim * x0;
-            if (grid[(y0 + 1) + ah * (x0 + 1)] == 1 && s0 != s1) {
-                grid[(w.y1 + 1) + ah * (w.x1 + 1)] = 0;
-                grid[(y0 + 1) + ah * (x0 + 1)] = 0;
-                grid[(w.y2 + 1) + ah * (w.x2 + 1)] = 0;
-                for (int& l : label)
-                    if (l == s0) l = s1;
-                label[centre] = s1;
-            }
-            walls.erase(walls.begin() + n);
-        }
-    }
-
     void new_level() override {  // chaser.cpp:418-443
         ids_.refill();
         in_sprite_.clear();
@@ -164,7 +130,7 @@ class Chaser final : public Env {
         const int total_enemies = total_enemies_, extra_orb_sign = extra_orb_sign_;
         std::fill(tiles_.begin(), tiles_.end(), static_cast<uint8_t>(kEmpty));
         std::vector<int> grid;
-        carve(W, grid);
+        carve_merged(W, grid, rng_);  // maze_generator.cpp:47-130 (pgo_kruskal.h)
         const int extra_quad = rng_.irange(0, 3);
         std::vector<std::vector<int>> quadrants(4);
         int orbs_for[4];

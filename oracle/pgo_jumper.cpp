@@ -12,6 +12,7 @@
 #include <cmath>
 
 #include "pgo_env.h"
+#include "pgo_kruskal.h"
 #include "pgo_rooms.h"
 
 namespace pgo {
@@ -127,63 +128,6 @@ class Jumper final : public Env {
     bool left_wall(int x, int y) const { return at(x, y) == kWallMid && at(x + 1, y) == kEmpty; }
     bool right_wall(int x, int y) const { return at(x, y) == kWallMid && at(x - 1, y) == kEmpty; }
 
-    // maze_generator.cpp:47-173 (generate_maze + the dead-end removal pass); grid is (dim+2)², padded with walls.
-    void carve_no_dead_ends(int dim, std::vector<int>& grid) {
-        const int ah = dim + 2;
-        grid.assign(ah * ah, 1);
-        grid[1 + ah * 1] = 0;
-        std::vector<int> label(dim * dim);
-        for (int i = 0; i < dim * dim; i++) label[i] = i;
-        struct Seg {
-            int x1, y1, x2, y2;
-        };
-        std::vector<Seg> walls;
-        for (int i = 1; i < dim; i += 2)
-            for (int j = 0; j < dim; j += 2)
-                if (i > 0 && i < dim - 1) walls.push_back({i - 1, j, i + 1, j});
-        for (int i = 0; i < dim; i += 2)
-            for (int j = 1; j < dim; j += 2)
-                if (j > 0 && j < dim - 1) walls.push_back({i, j - 1, i, j + 1});
-        while (!walls.empty()) {
-            const int n = rng_.irange(0, static_cast<int>(walls.size()) - 1);
-            const Seg w = walls[n];
-            const int s0 = label[w.y1 + dim * w.x1], s1 = label[w.y2 + dim * w.x2];
-            const int x0 = (w.x1 + w.x2) / 2, y0 = (w.y1 + w.y2) / 2;
-            if (grid[(y0 + 1) + ah * (x0 + 1)] == 1 && s0 != s1) {
-                grid[(w.y1 + 1) + ah * (w.x1 + 1)] = 0;
-                grid[(y0 + 1) + ah * (x0 + 1)] = 0;
-                grid[(w.y2 + 1) + ah * (w.x2 + 1)] = 0;
-                for (int& l : label)
-                    if (l == s0) l = s1;
-                label[y0 + dim * x0] = s1;
-            }
-            walls.erase(walls.begin() + n);
-        }
-        for (int i = 0; i < ah * ah; i++) {  // :132-173
-            if (grid[i] != 0) continue;
-            const int x = i / ah, y = i % ah;
-            const int nb[4] = {y + ah * (x - 1), y + ah * (x + 1), (y - 1) + ah * x, (y + 1) + ah * x};
-            int spaces = 0, wallsn = 0;
-            for (int n = 0; n < 4; n++) {
-                if (grid[nb[n]] == 0)
-                    spaces++;
-                else if (grid[nb[n]] == 1)
-                    wallsn++;
-            }
-            if (spaces == 1 && wallsn > 0) {
-                const int pick = rng_.irange(0, wallsn - 1);
-                for (int n = 0; n < 4; n++) {
-                    const int cell = nb[(pick + n) % wallsn];  // indexes the neighbour list, not the walls (kept)
-                    const int cx = cell / ah, cy = cell % ah;
-                    if (cx >= 1 && cy >= 1 && cx < ah - 1 && cy < ah - 1 && grid[cell] == 1) {
-                        grid[cell] = 0;
-                        break;
-                    }
-                }
-            }
-        }
-    }
-
     void new_level() override {  // jumper.cpp:511-533
         spikes_.clear();
         in_sprite_.clear();
@@ -195,7 +139,8 @@ class Jumper final : public Env {
         std::fill(tiles_.begin(), tiles_.end(), static_cast<uint8_t>(kEmpty));
         const int maze_scale = 3, maze_dim = W / maze_scale;
         std::vector<int> maze;
-        carve_no_dead_ends(maze_dim, maze);
+        carve_merged(maze_dim, maze, rng_);  // generate_maze_no_dead_ends = generate_maze + the dead-end pass
+        open_dead_ends(maze_dim, maze, rng_);  // (maze_generator.cpp:47-173, pgo_kruskal.h)
         Rooms rooms;
         rooms.gw = W;
         rooms.gh = H;

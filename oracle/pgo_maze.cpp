@@ -9,6 +9,7 @@
 #include <algorithm>
 
 #include "pgo_env.h"
+#include "pgo_kruskal.h"
 
 namespace pgo {
 namespace {
@@ -21,91 +22,6 @@ const char* const kFloors[9] = {  // maze.cpp:62-72
     "topdown_backgrounds/backgrounddetailed4.png", "topdown_backgrounds/backgrounddetailed5.png",
     "topdown_backgrounds/backgrounddetailed6.png", "topdown_backgrounds/backgrounddetailed7.png",
     "topdown_backgrounds/backgrounddetailed8.png"};
-
-// Randomised Kruskal over a padded grid (maze_generator.h / maze_generator.cpp).
-struct Carver {
-    static constexpr int kPad = 1;
-    static constexpr int kInvalid = -1, kSpace = 0, kBrick = 1, kStartCellQuirk = 10;  // maze_generator.h:15-18
-    int mw = 0, mh = 0, aw = 0, ah = 0;
-    std::vector<int> grid, rank, parent, open_cells;
-    std::unordered_set<int> open_set;
-    int n_open = 0;
-
-    int idx(int x, int y) const { return y + ah * x; }
-    int get(int x, int y) const {
-        if (x < 0 || y < 0 || x >= aw || y >= ah) return 1;
-        return grid[idx(x, y)];
-    }
-    int root(int c) {  // maze_generator.cpp:47-53, path halving
-        int cur = c;
-        while (parent[cur] != cur) cur = parent[cur] = parent[parent[cur]];
-        return cur;
-    }
-    void open(int x, int y) {  // maze_generator.cpp:34-45
-        grid[idx(x + kPad, y + kPad)] = kSpace;
-        int cell = y + mh * x;
-        if (open_set.find(cell) == open_set.end()) {
-            open_cells[n_open] = cell;
-            open_set.insert(cell);
-            n_open++;
-        }
-    }
-    void carve(int w, int h, Rng& rng) {  // maze_generator.cpp:55-139
-        mw = w;
-        mh = h;
-        aw = w + 2 * kPad;
-        ah = h + 2 * kPad;
-        rank.assign(aw * ah, 0);
-        parent.assign(aw * ah, 0);
-        open_cells.assign(aw * ah, 0);
-        grid.assign(aw * ah, kBrick);
-        grid[idx(kPad, kPad)] = kSpace;
-        n_open = 0;
-        open_set.clear();
-        for (int i = 0; i < mw * mh; i++) parent[i] = i;
-
-        struct Seg {
-            int x1, y1, x2, y2;
-        };
-        std::vector<Seg> segs;
-        for (int i = 1; i < mw; i += 2)
-            for (int j = 0; j < mh; j += 2)
-                if (i > 0 && i < mw - 1) segs.push_back({i - 1, j, i + 1, j});
-        for (int i = 0; i < mw; i += 2)
-            for (int j = 1; j < mh; j += 2)
-                if (j > 0 && j < mh - 1) segs.push_back({i, j - 1, i, j + 1});
-
-        while (!segs.empty()) {
-            int n = rng.irange(0, static_cast<int>(segs.size()) - 1);
-            Seg s = segs[n];
-            int r0 = root(s.y1 + mh * s.x1);
-            int r1 = root(s.y2 + mh * s.x2);
-            int mx = (s.x1 + s.x2) / 2, my = (s.y1 + s.y2) / 2;
-            int centre = my + mh * mx;
-            if (get(mx + kPad, my + kPad) == kBrick && r0 != r1) {
-                open(s.x1, s.y1);
-                open(mx, my);
-                open(s.x2, s.y2);
-                if (rank[r0] > rank[r1]) {
-                    parent[r1] = r0;
-                    parent[centre] = r0;
-                } else {
-                    parent[r0] = r1;
-                    parent[centre] = r1;
-                    if (rank[r0] == rank[r1]) rank[r1]++;
-                }
-            }
-            segs.erase(segs.begin() + n);
-        }
-    }
-    void drop(int kind, Rng& rng) {  // maze_generator.cpp:183-195 (D7: compares the cell index with 10)
-        int k = rng.irange(0, n_open - 1);
-        while (open_cells[k] == kInvalid || open_cells[k] == kStartCellQuirk) k = rng.irange(0, n_open - 1);
-        int cell = open_cells[k];
-        open_cells[k] = kInvalid;
-        grid[idx(cell / mh + kPad, cell % mh + kPad)] = kind;
-    }
-};
 
 class Maze final : public Env {
    public:
