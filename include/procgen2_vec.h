@@ -77,11 +77,19 @@ typedef struct pgv_config {
     uint32_t game_flags;             /* game-specific generator switches, 0 = the reference's defaults (below) */
 } pgv_config;
 /* coinrun: System_Tilemap::Config's allow_pit / allow_crate / allow_dy / allow_mobs (coinrun/tilemap.h:42-45, all true
- * in the reference; tilemap.cpp:158,174,250,258), as switches that turn a feature OFF.  Other games take 0 only. */
+ * in the reference; tilemap.cpp:158,174,250,258), as switches that turn a feature OFF. */
 #define PGV_COINRUN_NO_PIT 1u
 #define PGV_COINRUN_NO_CRATE 2u
 #define PGV_COINRUN_NO_DY 4u
 #define PGV_COINRUN_NO_MOBS 8u
+/* chaser, jumper: how the reference's unqualified `abs(<float>)` calls resolve (games/chaser/common_systems.cpp:165-166,
+ * 206,346-420; games/jumper/common_systems.cpp:198).  0 (default): glibc's `int abs(int)` — the argument is truncated
+ * first — which is what g++/libstdc++ picks when no header of the translation unit includes <stdlib.h> or <math.h>
+ * (SDL3's SDL_stdinc.h stopped including them).  1: `float std::abs(float)`, what the same sources mean as soon as any
+ * header pulls libstdc++'s <stdlib.h> wrapper in, and on libc++ / MSVC always.  Both readings have recorded traces of
+ * the unmodified reference (tests/golden/appendix_c.json). */
+#define PGV_CHASER_FLOAT_ABS 1u
+#define PGV_JUMPER_FLOAT_ABS 1u
 PGV_API int32_t pgv_make_config(const pgv_config* config, pgv_env** out);
 PGV_API uint32_t pgv_game_modes(int32_t game_id);
 PGV_API int32_t pgv_mode(pgv_env* env); /* the resolved mode (never PGV_MODE_DEFAULT) */

@@ -43,7 +43,9 @@ void* pgo_make_mode(const char* game, uint32_t seed, int render_enabled, int mod
 
 void* pgo_make_config(const char* game, uint32_t seed, int render_enabled, int mode, uint32_t flags) {
     std::string g(game);
-    if (flags != 0 && (g != "coinrun" || (flags & ~15u))) return nullptr;  // PGV_COINRUN_NO_* only
+    // include/procgen2_vec.h: coinrun PGV_COINRUN_NO_* (bits 0-3), chaser / jumper PGV_*_FLOAT_ABS (bit 0)
+    const uint32_t known = g == "coinrun" ? 15u : (g == "chaser" || g == "jumper") ? 1u : 0u;
+    if (flags & ~known) return nullptr;
     const int resolved = pgo_resolve_mode(game, mode);
     if (resolved < 0) return nullptr;
     Env* e = nullptr;
@@ -90,9 +92,15 @@ uint32_t pgo_rng_peek(void* h) { return static_cast<Env*>(h)->rng_peek(); }
 // SURVEY.md Appendix C driver: make(seed) → reset → `steps` LCG actions, reset on terminated.
 // Fills crc of the (reward f32 LE, terminated u8) stream, episode count, reward sum and the
 // first `cap` episode lengths.  Rendering is off (the traces are raster-independent).
+int pgo_trace_flags(const char* game, uint32_t seed, int steps, uint32_t flags, uint32_t* crc_out, int* episodes_out,
+                    double* reward_sum_out, int* lengths_out, int cap);
 int pgo_trace(const char* game, uint32_t seed, int steps, uint32_t* crc_out, int* episodes_out, double* reward_sum_out,
               int* lengths_out, int cap) {
-    Env* e = static_cast<Env*>(pgo_make(game, seed, 0));
+    return pgo_trace_flags(game, seed, steps, 0, crc_out, episodes_out, reward_sum_out, lengths_out, cap);
+}
+int pgo_trace_flags(const char* game, uint32_t seed, int steps, uint32_t flags, uint32_t* crc_out, int* episodes_out,
+                    double* reward_sum_out, int* lengths_out, int cap) {
+    Env* e = static_cast<Env*>(pgo_make_config(game, seed, 0, 0, flags));
     if (!e) return -1;
     e->reset(false, 0);
     pgo::Crc32 crc;

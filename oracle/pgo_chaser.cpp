@@ -35,7 +35,6 @@ struct Thing {
     int tex = 0;  // eggs/enemies: 0 egg, 1..3 flying frames, 4 walking
 };
 
-int iabs(float v) { return std::abs(static_cast<int>(v)); }  // what `abs(<float>)` compiles to there (D21)
 
 int sign(float x) {  // helpers.h:31-36
     if (x == 0.0f) return 0;
@@ -44,6 +43,16 @@ int sign(float x) {  // helpers.h:31-36
 
 class Chaser final : public Env {
    public:
+    // What the unqualified `abs(<float>)` of common_systems.cpp:165-166,206,346-420 computes (D21).  Default: glibc's
+    // `int abs(int)` — the argument is truncated first — as g++/libstdc++ resolves it when nothing in the translation
+    // unit includes <stdlib.h> / <math.h> (the result is a small integer, exact as a float).  With game_flags bit 0
+    // (PGV_CHASER_FLOAT_ABS): `float std::abs(float)`, what the same sources give once any header brings libstdc++'s
+    // <stdlib.h> wrapper in (`using std::abs;`), and what libc++ / MSVC give always.  Both are "the reference";
+    // tests/golden/appendix_c.json holds traces of the unmodified sources for each.
+    float qabs(float v) const {
+        return (flags_ & 1u) ? std::fabs(v) : static_cast<float>(std::abs(static_cast<int>(v)));
+    }
+
     int W = 11, H = 11, total_enemies_ = 3, extra_orb_sign_ = 0;  // tilemap.cpp:85-99, easy_mode is the default
     enum Tile : uint8_t { kEmpty = 0, kWall = 1, kMarker = 2 };
 
@@ -214,8 +223,8 @@ class Chaser final : public Env {
             input_timer = 0.0f;
         }
         V2& p = a_pos;
-        auto frac_x = [&] { return iabs(p.x - (static_cast<int>(p.x) + 0.5f)); };
-        auto frac_y = [&] { return iabs(p.y - (static_cast<int>(p.y) + 0.5f)); };
+        auto frac_x = [&] { return qabs(p.x - (static_cast<int>(p.x) + 0.5f)); };
+        auto frac_y = [&] { return qabs(p.y - (static_cast<int>(p.y) + 0.5f)); };
         if (a_next.x > 0.0f) {
             if (frac_y() <= speed * dt && at(static_cast<int>(p.x) + 1, H - 1 - static_cast<int>(p.y)) == kEmpty) {
                 p.y = static_cast<int>(p.y) + 0.5f;
@@ -285,8 +294,8 @@ class Chaser final : public Env {
                     t.tex = 4;
                     speed = speed_low;
                 }
-                const bool at_junction = std::max(iabs(t.pos.x - (static_cast<int>(t.pos.x) + 0.5f)),
-                                                  iabs(t.pos.y - (static_cast<int>(t.pos.y) + 0.5f))) < speed * dt;
+                const bool at_junction = std::max(qabs(t.pos.x - (static_cast<int>(t.pos.x) + 0.5f)),
+                                                  qabs(t.pos.y - (static_cast<int>(t.pos.y) + 0.5f))) < speed * dt;
                 if ((t.vel.x == 0.0f && t.vel.y == 0.0f) || at_junction) {
                     bool possible[4];
                     int k = 0, n_possible = 0;
@@ -308,8 +317,8 @@ class Chaser final : public Env {
                         float min_dist = 999999.0f;
                         for (int i = 0; i < 4; i++)
                             if (possible[i]) {
-                                float d = iabs(t.pos.x + directions[i].x - a_pos.x) +
-                                          iabs(t.pos.y + directions[i].y - a_pos.y);
+                                float d = qabs(t.pos.x + directions[i].x - a_pos.x) +
+                                          qabs(t.pos.y + directions[i].y - a_pos.y);
                                 if (eat_timer > 0.0f) d = -d;
                                 if (d < min_dist) {
                                     min_dist = d;

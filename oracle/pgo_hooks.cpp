@@ -169,3 +169,79 @@ HOOK int pgo_hook_ecs_script(int n_ops, const int* ops, const int* args, int* ou
     }
     return w;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The genuine libstdc++ articles for the device-side primitive sweep (tests/hip/selftest.hip,
+// tests/test_primitives_gpu.py): same shapes as the pgst_* entry points.
+// ---------------------------------------------------------------------------------------------------------------
+#include <algorithm>
+
+HOOK void pgo_hook_mt(int n_seeds, const uint32_t* seeds, int n, uint32_t* out) {
+    for (int s = 0; s < n_seeds; s++) {
+        std::mt19937 e;
+        e.seed(seeds[s]);
+        for (int i = 0; i < n; i++) out[static_cast<size_t>(s) * n + i] = static_cast<uint32_t>(e());
+    }
+}
+
+HOOK void pgo_hook_draws(uint32_t seed, int n, const uint8_t* kind, const int* lo, const int* hi, const float* fa,
+                         const float* fb, int* iout, float* fout) {
+    std::mt19937 e;
+    e.seed(seed);
+    for (int i = 0; i < n; i++) {
+        iout[i] = 0;
+        fout[i] = 0.0f;
+        if (kind[i] == 0) {
+            std::uniform_int_distribution<int> d(lo[i], hi[i]);
+            iout[i] = d(e);
+        } else {
+            std::uniform_real_distribution<float> d(fa[i], fb[i]);
+            fout[i] = d(e);
+        }
+    }
+}
+
+HOOK void pgo_hook_bulk(uint32_t seed, int skip, int count, float* out, uint32_t* next) {
+    std::mt19937 e;
+    e.seed(seed);
+    for (int i = 0; i < skip; i++) e();
+    std::uniform_real_distribution<float> d(0.0f, 1.0f);
+    for (int i = 0; i < count; i++) out[i] = d(e);
+    *next = static_cast<uint32_t>(e());
+}
+
+static uint32_t fnv(uint32_t h, uint32_t v) { return (h ^ v) * 16777619u; }
+
+HOOK void pgo_hook_hash_script(int n_ops, const int* ops, const int* keys, uint32_t* hashes) {
+    std::unordered_set<int> set;
+    for (int k = 0; k < n_ops; k++) {
+        if (ops[k] == 0)
+            set.insert(keys[k]);
+        else if (ops[k] == 1)
+            set.erase(keys[k]);
+        else
+            set.clear();
+        uint32_t f = fnv(2166136261u, static_cast<uint32_t>(set.size()));
+        for (int v : set) f = fnv(f, static_cast<uint32_t>(v));
+        hashes[k] = f;
+    }
+}
+
+HOOK void pgo_hook_set_rounds(int n_rounds, const int* counts, const int16_t* keys_in, int16_t* keys_out) {
+    std::unordered_set<int> set;
+    size_t at = 0;
+    for (int r = 0; r < n_rounds; r++) {
+        set.clear();  // keeps the bucket array
+        for (int i = 0; i < counts[r]; i++) set.insert(keys_in[at + i]);
+        size_t w = at;
+        for (int v : set) keys_out[w++] = static_cast<int16_t>(v);
+        at += counts[r];
+    }
+}
+
+HOOK void pgo_hook_sort_equal(int n, int* out) {
+    std::vector<std::pair<float, int>> v(n);
+    for (int i = 0; i < n; i++) v[i] = {1.0f, i};
+    std::sort(v.begin(), v.end(), [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.first < b.first; });
+    for (int i = 0; i < n; i++) out[i] = v[i].second;
+}

@@ -313,7 +313,8 @@ class Jumper final : public Env {
         else if (movement_x < 0.0f)
             a_forward = false;
         to_goal = {goal_pos.x - a_pos.x, goal_pos.y - a_pos.y};
-        puff_on = !a_ground || std::abs(static_cast<int>(a_vel.x)) > 0.01f;  // `abs` = int abs(int) here (D21)
+        // `abs` = int abs(int) here (D21); game_flags bit 0 (PGV_JUMPER_FLOAT_ABS): the float overload (see pgo_chaser.cpp)
+        puff_on = !a_ground || ((flags_ & 1u) ? std::fabs(a_vel.x) : static_cast<float>(std::abs(static_cast<int>(a_vel.x)))) > 0.01f;
     }
 
     void puffs_update(float dt) {  // common_systems.cpp:255-283

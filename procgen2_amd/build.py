@@ -113,7 +113,19 @@ def _build(force, verbose, COMMON, ALIASES, OBJ):
             links.append([cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out] + objs + [eng, "-lz", "-ldl"])
         outputs.append(out)
     _parallel(links, verbose)
+    if "libprocgen2_hip.so" in ALIASES:
+        outputs.append(_build_selftest(force, verbose, cc, hdrs, COMMON))
     return outputs
+
+
+def _build_selftest(force, verbose, cc, hdrs, common):
+    """tests/hip/selftest.hip → lib/libpg_selftest.so: the device-side sweep of the bit-exact primitives (test
+    infrastructure, loaded only by tests/test_primitives_gpu.py; in lib/ so that it travels to the GPU box)."""
+    src = os.path.join(HERE, "..", "tests", "hip", "selftest.hip")
+    out = os.path.join(LIB, "libpg_selftest.so")
+    if os.path.exists(src) and (force or _stale(out, [src] + hdrs)):
+        _run([cc] + common + ["-shared", src, "-o", out], verbose)
+    return out
 
 
 def library_path(name="libprocgen2_hip.so"):

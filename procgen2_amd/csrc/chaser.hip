@@ -9,12 +9,13 @@
 //
 // Quirk kept on purpose (D21, oracle/pgo_chaser.cpp): the reference's `abs(<float>)` calls in common_systems.cpp
 // compile to glibc's `int abs(int)` — the argument is truncated first — so the "close to the cell centre" tests always
-// pass and the chase heuristic compares sums of truncated integers.  iabs() below is that.
+// pass and the chase heuristic compares sums of truncated integers.  qabs(s, ) below is that.
 //
 // Machine mapping: logic one lane per env (SoA across envs) — the enemies draw from the env's mt19937 inside the step,
 // in the iteration order of the enemy System's std::unordered_set; render two wavefronts per env; level generation one
 // wavefront per env.  Because of the in-step draws the next level cannot be generated ahead of time (pg_prefetch.h
 // is used with prefetch off: every reset carves its maze inside the step).
+#include "../../include/procgen2_vec.h"
 #include "pg_engine.h"
 #include "pg_frame.h"
 #include "pg_geom.h"
@@ -102,6 +103,7 @@ struct State {
     uint8_t* mb;     // [2][kMobs][n]   texture index (0 egg, 1-3 flying, 4 walking), iteration order of the enemy set
     uint8_t* eb;     // [EB_COUNT][kMaxEnt][n]
     const uint8_t* ranks;  // pg_order.h equal-key sort ranks
+    int float_abs;         // game_flags PGV_CHASER_FLOAT_ABS: which `abs` the reference's abs(<float>) calls are (D21)
 };
 
 PG_D float& SF(const State& s, int field, int env) { return s.f[size_t(field) * s.n + env]; }
@@ -119,9 +121,12 @@ PG_D int tile_at(const uint8_t* t, int x, int y) {  // tilemap.h:79-84: out of b
     if (x < 0 || y < 0 || x >= W || y >= H) return -1;
     return t[y + x * H];
 }
-PG_D int iabs(float v) {  // D21
+// D21: the unqualified abs(<float>) of common_systems.cpp:165-166,206,346-420.  Default: glibc's int abs(int) on the
+// truncated argument (a small integer, exact as a float); with PGV_CHASER_FLOAT_ABS: float std::abs(float).
+// See oracle/pgo_chaser.cpp qabs and tests/golden/appendix_c.json for why both exist.
+PG_D float qabs(const State& s, float v) {
     const int t = static_cast<int>(v);
-    return t < 0 ? -t : t;
+    return s.float_abs ? fabsf(v) : static_cast<float>(t < 0 ? -t : t);
 }
 PG_D int sign_of(float x) { return x == 0.0f ? 0 : (x > 0.0f) * 2 - 1; }  // helpers.h:31-36
 
@@ -408,14 +413,14 @@ PG_D void advance(const State& s, StepLds& L, int lane, bool active, int env, in
                 input_t = 0.0f;
             }
             if (nvx > 0.0f) {
-                if (iabs(ay - (static_cast<int>(ay) + 0.5f)) <= speed * dt &&
+                if (qabs(s, ay - (static_cast<int>(ay) + 0.5f)) <= speed * dt &&
                     tile_at(tiles, static_cast<int>(ax) + 1, H - 1 - static_cast<int>(ay)) == kEmpty) {
                     ay = static_cast<int>(ay) + 0.5f;
                     avx = nvx;
                     avy = nvy;
                 }
             } else if (nvx < 0.0f) {
-                if (iabs(ay - (static_cast<int>(ay) + 0.5f)) <= speed * dt &&
+                if (qabs(s, ay - (static_cast<int>(ay) + 0.5f)) <= speed * dt &&
                     tile_at(tiles, static_cast<int>(ax) - 1, H - 1 - static_cast<int>(ay)) == kEmpty) {
                     ay = static_cast<int>(ay) + 0.5f;
                     avx = nvx;
@@ -423,14 +428,14 @@ PG_D void advance(const State& s, StepLds& L, int lane, bool active, int env, in
                 }
             }
             if (nvy > 0.0f) {
-                if (iabs(ax - (static_cast<int>(ax) + 0.5f)) <= speed * dt &&
+                if (qabs(s, ax - (static_cast<int>(ax) + 0.5f)) <= speed * dt &&
                     tile_at(tiles, static_cast<int>(ax), H - 1 - (static_cast<int>(ay) + 1)) == kEmpty) {
                     ax = static_cast<int>(ax) + 0.5f;
                     avx = nvx;
                     avy = nvy;
                 }
             } else if (nvy < 0.0f) {
-                if (iabs(ax - (static_cast<int>(ax) + 0.5f)) <= speed * dt &&
+                if (qabs(s, ax - (static_cast<int>(ax) + 0.5f)) <= speed * dt &&
                     tile_at(tiles, static_cast<int>(ax), H - 1 - (static_cast<int>(ay) - 1)) == kEmpty) {
                     ax = static_cast<int>(ax) + 0.5f;
                     avx = nvx;
@@ -438,26 +443,26 @@ PG_D void advance(const State& s, StepLds& L, int lane, bool active, int env, in
                 }
             }
             if (avx < 0.0f) {
-                if (iabs(ax - (static_cast<int>(ax) + 0.5f)) <= speed * dt &&
+                if (qabs(s, ax - (static_cast<int>(ax) + 0.5f)) <= speed * dt &&
                     tile_at(tiles, static_cast<int>(ax) - 1, H - 1 - static_cast<int>(ay)) != kEmpty) {
                     ax = static_cast<int>(ax) + 0.5f;
                     avx = 0.0f;
                 }
             } else if (avx > 0.0f) {
-                if (iabs(ax - (static_cast<int>(ax) + 0.5f)) <= speed * dt &&
+                if (qabs(s, ax - (static_cast<int>(ax) + 0.5f)) <= speed * dt &&
                     tile_at(tiles, static_cast<int>(ax) + 1, H - 1 - static_cast<int>(ay)) != kEmpty) {
                     ax = static_cast<int>(ax) + 0.5f;
                     avx = 0.0f;
                 }
             }
             if (avy < 0.0f) {
-                if (iabs(ay - (static_cast<int>(ay) + 0.5f)) <= speed * dt &&
+                if (qabs(s, ay - (static_cast<int>(ay) + 0.5f)) <= speed * dt &&
                     tile_at(tiles, static_cast<int>(ax), H - 1 - (static_cast<int>(ay) - 1)) != kEmpty) {
                     ay = static_cast<int>(ay) + 0.5f;
                     avy = 0.0f;
                 }
             } else if (avy > 0.0f) {
-                if (iabs(ay - (static_cast<int>(ay) + 0.5f)) <= speed * dt &&
+                if (qabs(s, ay - (static_cast<int>(ay) + 0.5f)) <= speed * dt &&
                     tile_at(tiles, static_cast<int>(ax), H - 1 - (static_cast<int>(ay) + 1)) != kEmpty) {
                     ay = static_cast<int>(ay) + 0.5f;
                     avy = 0.0f;
@@ -493,8 +498,8 @@ PG_D void advance(const State& s, StepLds& L, int lane, bool active, int env, in
                         tex = 4;
                         speed = speed_low;
                     }
-                    const int fx = iabs(px - (static_cast<int>(px) + 0.5f)), fy = iabs(py - (static_cast<int>(py) + 0.5f));
-                    const bool at_junction = static_cast<float>(fx > fy ? fx : fy) < speed * dt;
+                    const float fx = qabs(s, px - (static_cast<int>(px) + 0.5f)), fy = qabs(s, py - (static_cast<int>(py) + 0.5f));
+                    const bool at_junction = (fx < fy ? fy : fx) < speed * dt;  // std::max
                     if ((vx == 0.0f && vy == 0.0f) || at_junction) {
                         bool possible[4];
                         int n_possible = 0;
@@ -521,7 +526,7 @@ PG_D void advance(const State& s, StepLds& L, int lane, bool active, int env, in
                                 if (possible[k]) {
                                     const float dir_x = k == 0 ? -1.0f : (k == 1 ? 1.0f : 0.0f);
                                     const float dir_y = k == 2 ? -1.0f : (k == 3 ? 1.0f : 0.0f);
-                                    float d = static_cast<float>(iabs(px + dir_x - ax) + iabs(py + dir_y - ay));
+                                    float d = qabs(s, px + dir_x - ax) + qabs(s, py + dir_y - ay);
                                     if (eat_t > 0.0f) d = -d;
                                     if (d < min_dist) {
                                         min_dist = d;
@@ -840,6 +845,10 @@ class ChaserGame final : public Game {
         return l;
     }
     size_t state_bytes(int n) const override { return layout(n).total; }
+    bool set_game_flags(uint32_t flags) override {  // include/procgen2_vec.h PGV_CHASER_FLOAT_ABS
+        s_.float_abs = (flags & PGV_CHASER_FLOAT_ABS) ? 1 : 0;
+        return (flags & ~PGV_CHASER_FLOAT_ABS) == 0;
+    }
     void bind(void* d_state, int n, AtlasView atlas) override {
         uint8_t* p = static_cast<uint8_t*>(d_state);
         const Layout l = layout(n);

@@ -13,6 +13,7 @@
 // The compass needle's angle is std::atan2(float, float): pg_atan2.h is glibc's atan2f bit for bit.
 // D21 (oracle/pgo_chaser.cpp) applies to one line: `abs(velocity.x) > 0.01f` (common_systems.cpp:198) is the int abs.
 #include "pg_atan2.h"
+#include "../../include/procgen2_vec.h"
 #include "pg_engine.h"
 #include "pg_frame.h"
 #include "pg_geom.h"
@@ -102,6 +103,7 @@ struct State {
     float* pf;       // [PF_COUNT][kPuffs][n]
     uint16_t* spike_cell;  // [kMaxSpikes][n]
     uint8_t* draw;         // [kMaxSprites][n]
+    int float_abs;         // game_flags PGV_JUMPER_FLOAT_ABS (D21)
 };
 
 PG_D float& SF(const State& s, int field, int env) { return s.f[size_t(field) * s.n + env]; }
@@ -473,8 +475,10 @@ PG_D void advance(const State& s, int env, int action, float& reward_out, bool& 
         else if (movement_x < 0.0f)
             forward = false;
         {
-            const int truncated = static_cast<int>(avx);  // `abs` = int abs(int) there (D21)
-            puff_on = !ground || static_cast<float>(truncated < 0 ? -truncated : truncated) > 0.01f;
+            // `abs` = int abs(int) there (D21); PGV_JUMPER_FLOAT_ABS: the float overload (oracle/pgo_chaser.cpp qabs)
+            const int truncated = static_cast<int>(avx);
+            const float mag = s.float_abs ? fabsf(avx) : static_cast<float>(truncated < 0 ? -truncated : truncated);
+            puff_on = !ground || mag > 0.01f;
         }
         // --- System_Particles::update (common_systems.cpp:255-283)
         {
@@ -874,6 +878,10 @@ class JumperGame final : public Game {
         return l;
     }
     size_t state_bytes(int n) const override { return layout(n).total; }
+    bool set_game_flags(uint32_t flags) override {  // include/procgen2_vec.h PGV_JUMPER_FLOAT_ABS
+        s_.float_abs = (flags & PGV_JUMPER_FLOAT_ABS) ? 1 : 0;
+        return (flags & ~PGV_JUMPER_FLOAT_ABS) == 0;
+    }
     void bind(void* d_state, int n, AtlasView atlas) override {
         uint8_t* p = static_cast<uint8_t*>(d_state);
         const Layout l = layout(n);

@@ -38,6 +38,7 @@ def mode_id(mode):
 
 # include/procgen2_vec.h PGV_COINRUN_NO_*
 COINRUN_NO_PIT, COINRUN_NO_CRATE, COINRUN_NO_DY, COINRUN_NO_MOBS = 1, 2, 4, 8
+CHASER_FLOAT_ABS = JUMPER_FLOAT_ABS = 1  # include/procgen2_vec.h PGV_*_FLOAT_ABS
 
 
 def make(lib, game, num_envs, device=0, seed_base=1, env_offset=0, stream=None, num_levels=0, start_level=0, mode=None,

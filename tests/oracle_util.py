@@ -50,6 +50,16 @@ def oracle():
     L.pgo_dump_tiles.argtypes = [c_void_p, POINTER(c_uint8), c_int]
     L.pgo_trace.argtypes = [c_char_p, c_uint32, c_int, POINTER(c_uint32), POINTER(c_int), POINTER(c_double),
                             POINTER(c_int), c_int]
+    L.pgo_trace_flags.argtypes = [c_char_p, c_uint32, c_int, c_uint32, POINTER(c_uint32), POINTER(c_int), POINTER(c_double),
+                                  POINTER(c_int), c_int]
+    for name, args in (("pgo_hook_mt", [c_int, c_void_p, c_int, c_void_p]),
+                       ("pgo_hook_draws", [c_uint32, c_int] + [c_void_p] * 7),
+                       ("pgo_hook_bulk", [c_uint32, c_int, c_int, c_void_p, c_void_p]),
+                       ("pgo_hook_hash_script", [c_int, c_void_p, c_void_p, c_void_p]),
+                       ("pgo_hook_set_rounds", [c_int, c_void_p, c_void_p, c_void_p]),
+                       ("pgo_hook_sort_equal", [c_int, c_void_p])):
+        getattr(L, name).argtypes = args
+        getattr(L, name).restype = None
     L.pgo_synthetic_action.argtypes = [c_uint32, c_uint32, c_uint32]
     L.pgo_vec_make.restype = c_void_p
     L.pgo_vec_make.argtypes = [c_char_p, c_int, c_uint32, c_int, c_int]

@@ -32,6 +32,21 @@ def test_reference_reward_done_trace(oracle_lib, trace):
     assert list(lens)[:len(want)] == want
 
 
+@pytest.mark.parametrize("trace", APPENDIX_C["traces_float_abs"], ids=lambda t: "%s-%d-float-abs" % (t["game"], t["seed"]))
+def test_reference_reward_done_trace_float_abs(oracle_lib, trace):
+    """The other reading of the same unmodified sources (appendix_c.json `_more_source`): game_flags bit 0."""
+    crc, episodes, total = ctypes.c_uint32(), ctypes.c_int(), ctypes.c_double()
+    lens = (ctypes.c_int * 6)()
+    rc = oracle_lib.pgo_trace_flags(trace["game"].encode(), trace["seed"], APPENDIX_C["steps"], trace["flags"], crc, episodes,
+                                    total, lens, 6)
+    assert rc == 0
+    assert "%08x" % crc.value == trace["crc"]
+    assert episodes.value == trace["episodes"]
+    assert abs(total.value - trace["reward_sum"]) < 1e-3
+    want = trace["first_lengths"]
+    assert list(lens)[:len(want)] == want
+
+
 def _frame_crcs(game, seed, steps, mode=0):
     oracle_util.register_textures(game)
     L = oracle_util.oracle()

@@ -24,16 +24,16 @@ def _actions(L, run_seed, step, n, offset=0):
     return np.array([L.pgo_synthetic_action(run_seed, step, offset + e) for e in range(n)], np.int32)
 
 
-def _lockstep(game, n, steps, seed_base=1, run_seed=0, check_state_every=0):
-    eng = EngineVec(game, n, seed_base=seed_base)
-    ora = OracleVec(game, n, seed_base=seed_base)
+def _lockstep(game, n, steps, seed_base=1, run_seed=0, check_state_every=0, game_flags=0, threads=1):
+    eng = EngineVec(game, n, seed_base=seed_base, game_flags=game_flags)
+    ora = OracleVec(game, n, seed_base=seed_base, game_flags=game_flags)
     L = ora.L
     assert np.array_equal(eng.reset(), ora.reset_obs()), "reset frame"
     resets = 0
     for s in range(steps):
         a = _actions(L, run_seed, s, n)
         oe, re_, de = eng.step(a)
-        oo, ro, do = ora.step(a)
+        oo, ro, do = ora.step(a, threads=threads)
         assert np.array_equal(de, do), "done, step %d" % s
         assert np.array_equal(re_.view(np.uint32), ro.view(np.uint32)), "reward bits, step %d" % s
         if not np.array_equal(oe, oo):
@@ -518,7 +518,8 @@ def _appendix_c():
         return json.load(f)
 
 
-@pytest.mark.parametrize("trace", _appendix_c()["traces"], ids=lambda t: "%s-%d" % (t["game"], t["seed"]))
+@pytest.mark.parametrize("trace", _appendix_c()["traces"] + _appendix_c()["traces_float_abs"],
+                         ids=lambda t: "%s-%d%s" % (t["game"], t["seed"], "-float-abs" if t.get("flags") else ""))
 def test_engine_reproduces_the_reference_reward_done_traces(trace):
     """The HIP engine against the reference itself, without the oracle in between: SURVEY.md Appendix C recorded the
     CRC-32 of the (reward f32, terminated u8) stream of the UNMODIFIED reference sources for make(seed) → reset →
@@ -527,7 +528,7 @@ def test_engine_reproduces_the_reference_reward_done_traces(trace):
     import struct
     import zlib
     steps = _appendix_c()["steps"]
-    eng = EngineVec(trace["game"], 1, seed_base=trace["seed"])
+    eng = EngineVec(trace["game"], 1, seed_base=trace["seed"], game_flags=trace.get("flags", 0))  # flags: appendix_c.json
     eng.reset()
     s, crc, episodes, total, length, lengths = 1, 0, 0, 0.0, 0, []
     one = np.ones(1, np.uint8)
@@ -580,3 +581,125 @@ def test_long_rollout_at_full_size_stays_on_the_oracle(game, steps):
         assert np.array_equal(obs[g], np.ctypeslib.as_array(L.pgo_obs(h), shape=(12288,))), g
         assert np.float32(r) == rew[g] and d == done[g], g
         L.pgo_close(h)
+
+
+def _host_threads():
+    import bench
+    return bench.usable_cores()
+
+
+def test_coinrun_4096_envs_256_steps_every_byte():
+    """BASELINE.json configs[1] at its stated size: coinrun, 4 096 envs, every observation byte, reward bit pattern and
+    done flag of every env for 256 steps against the oracle (all host threads)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    resets = _lockstep("coinrun", 4096, 256, check_state_every=64, threads=_host_threads())
+    assert resets > 0
+
+
+def test_chaser_float_abs_variant_lockstep():
+    """PGV_CHASER_FLOAT_ABS (include/procgen2_vec.h): the other reading of chaser's abs(<float>) calls — every byte
+    against the oracle's same variant, steering-heavy actions so that cell-centre alignment matters."""
+    n = 192
+    eng = EngineVec("chaser", n, seed_base=51, game_flags=pglib.CHASER_FLOAT_ABS)
+    ora = OracleVec("chaser", n, seed_base=51, game_flags=pglib.CHASER_FLOAT_ABS)
+    plain = OracleVec("chaser", n, seed_base=51, render=False)
+    assert np.array_equal(eng.reset(), ora.reset_obs())
+    rng = np.random.default_rng(12)
+    ends, differs = 0, False
+    hold = rng.choice([1, 3, 5, 7], n)
+    for s in range(700):
+        hold = np.where(rng.random(n) < 0.15, rng.choice([1, 3, 5, 7], n), hold)
+        a = np.where(rng.random(n) < 0.1, rng.integers(0, 15, n), hold).astype(np.int32)
+        oe, re_, de = eng.step(a)
+        oo, ro, do = ora.step(a)
+        _, rp, dp = plain.step(a)
+        assert np.array_equal(de, do) and np.array_equal(re_.view(np.uint32), ro.view(np.uint32)), s
+        assert np.array_equal(oe, oo), s
+        differs = differs or not (np.array_equal(do, dp) and np.array_equal(ro, rp))
+        ends += int(do.sum())
+        if s % 100 == 0:
+            for e in range(0, n, 24):
+                assert np.array_equal(eng.state(e, 1024).view(np.uint32), ora.state(e, 1024).view(np.uint32)), (s, e)
+    assert ends > 20 and differs, "the variant must actually change the game"
+    for v in (eng, ora, plain):
+        v.close()
+
+
+def test_jumper_float_abs_variant_lockstep():
+    """PGV_JUMPER_FLOAT_ABS: jumper/common_systems.cpp:198 decides when dust particles are emitted — pixels only."""
+    resets = _lockstep("jumper", 128, 400, seed_base=61, run_seed=5, check_state_every=80, game_flags=pglib.JUMPER_FLOAT_ABS)
+    assert resets >= 0
+
+
+def test_engine_refuses_unknown_game_flags():
+    for game, flags in (("maze", 1), ("chaser", 2), ("jumper", 4), ("coinrun", 16)):
+        with pytest.raises(pglib.EngineError):
+            EngineVec(game, 4, game_flags=flags)
+
+
+def test_mixed_seven_game_slice_of_configs4():
+    """BASELINE.json configs[4], one GPU's share: seven vector envs (65 536 envs split seven ways, the last game takes
+    the remainder) on seven HIP streams of one device, stepped 200 times side by side with device-generated actions and
+    no ordering between them; then a strided sample of every game's envs must be exactly where the oracle is.  The
+    envs sit at the global indices rank 3 of 8 would own (env_offset), as bench.py --workload mixed lays them out."""
+    import torch
+    from oracle_util import register_textures
+    from procgen2_amd.vec_env import GAMES, ProcgenVecEnv
+    per_gpu, rank, steps = 65536, 3, 200
+    base = per_gpu // len(GAMES)
+    counts = [base] * (len(GAMES) - 1) + [per_gpu - base * (len(GAMES) - 1)]
+    assert counts == [9362] * 6 + [9364]
+    envs = [ProcgenVecEnv(g, c, seed_base=1, env_offset=rank * c) for g, c in zip(GAMES, counts)]
+    for e in envs:
+        e.reset()
+    for s in range(steps):
+        for e in envs:
+            e.step_synthetic(0, ordered=False)  # each on its own stream, nothing waits for anything
+    for e in envs:
+        e.sync()
+    L = oracle()
+    for e, game, count in zip(envs, GAMES, counts):
+        obs = e.obs.cpu().numpy().reshape(count, -1)
+        rew, done = e.reward.cpu().numpy(), e.done.cpu().numpy()
+        register_textures(game)
+        for i in list(range(0, count, count // 6 + 1)) + [count - 1]:
+            g = rank * count + i  # global env index: seed 1 + g, action hash over g
+            h = L.pgo_make(game.encode(), (1 + g) & 0xFFFFFFFF, 1)
+            L.pgo_reset(h, 0, 0)
+            pending, r, d = False, 0.0, 0
+            for s in range(steps):
+                if pending:
+                    L.pgo_reset(h, 0, 0)
+                    pending, r, d = False, 0.0, 0
+                else:
+                    L.pgo_step(h, L.pgo_synthetic_action(0, s, g))
+                    r, d = L.pgo_reward(h), int(L.pgo_terminated(h))
+                    pending = bool(d)
+            assert np.array_equal(obs[i], np.ctypeslib.as_array(L.pgo_obs(h), shape=(12288,))), (game, i)
+            assert np.float32(r) == rew[i] and d == done[i], (game, i)
+            L.pgo_close(h)
+        e.close()
+    torch.cuda.synchronize()
+
+
+def test_cenv_abi_batched_maze_64_envs_through_the_timeout():
+    """BASELINE.json configs[0]'s shape on the engine: libMaze.so with num_envs = 64 through the reference wrapper's
+    call shapes for 520 steps — every env runs into maze's 500-step cap (D5) and is auto-reset."""
+    n = 64
+    env = pgcenv.CEnv(os.path.join(pglib.LIB_DIR, "libMaze.so"), options={"seed": 1, "num_envs": n})
+    ora = OracleVec("maze", n, seed_base=1)
+    obs, _ = env.reset()
+    assert np.array_equal(obs["screen"].reshape(n, 12288), ora.reset_obs())
+    ends = 0
+    for s in range(520):
+        a = _actions(ora.L, 0, s, n)
+        obs, rew, term, trunc, _ = env.step({"action": a})
+        oo, ro, do = ora.step(a)
+        assert np.array_equal(obs["screen"].reshape(n, 12288), oo), s
+        assert np.array_equal(obs["reward"], ro) and np.array_equal(obs["terminated"], do), s
+        assert trunc is False and term == bool(do.all())
+        ends += int(do.sum())
+    assert ends >= n
+    env.close()
+    ora.close()

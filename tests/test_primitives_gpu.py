@@ -1,0 +1,256 @@
+"""Device-side sweep of the bit-exact primitives (SURVEY.md rows T1–T4, H1/H2, the libm twins, raster arithmetic).
+
+tests/cpp/test_primitives.cpp checks the HOST compilation of procgen2_amd/csrc/pg_*.h; here the same functions run in
+small gfx950 kernels (tests/hip/selftest.hip → procgen2_amd/lib/libpg_selftest.so) — including their
+__HIP_DEVICE_COMPILE__ branches and the wave-cooperative forms that exist only on the device — and the raw results are
+compared on the host with glibc (ctypes → libm) and the genuine libstdc++ (oracle/pgo_hooks.cpp)."""
+import ctypes
+import os
+from ctypes import POINTER, c_float, c_int, c_int16, c_uint8, c_uint32, c_void_p
+
+import numpy as np
+import pytest
+
+import oracle_util
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def st():
+    try:
+        import torch  # noqa: F401  (one HIP runtime per process: torch's first, see procgen2_amd/lib.py)
+    except Exception:
+        pass
+    lib = ctypes.CDLL(os.path.join(ROOT, "procgen2_amd", "lib", "libpg_selftest.so"))
+    V = c_void_p
+    for name, args in (("pgst_sincos", [c_int, V, V, V]), ("pgst_atan2", [c_int, V, V, V, V]), ("pgst_div", [c_int, V, V, V, V]),
+                       ("pgst_blend", [c_int, V, V, V, V, V]), ("pgst_box", [c_int, V, V, V, V]),
+                       ("pgst_mt", [c_int, V, c_int, c_int, V]), ("pgst_draws", [c_uint32, c_int, V, V, V, V, V, c_int, V, V]),
+                       ("pgst_bulk", [c_uint32, c_int, c_int, V, V]), ("pgst_hash_script", [c_int, V, V, V]),
+                       ("pgst_set_rounds", [c_int, V, V, V]), ("pgst_sort_equal", [c_int, V])):
+        getattr(lib, name).argtypes = args
+        getattr(lib, name).restype = c_int
+    assert lib.pgst_device_count() > 0
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(c_void_p)
+
+
+def _libm():
+    m = ctypes.CDLL("libm.so.6")
+    for name in ("sinf", "cosf", "atanf"):
+        getattr(m, name).restype = c_float
+        getattr(m, name).argtypes = [c_float]
+    m.atan2f.restype = c_float
+    m.atan2f.argtypes = [c_float, c_float]
+    return m
+
+
+def _host_map(fn, *arrays):
+    return np.array([fn(*[float(v) for v in vals]) for vals in zip(*arrays)], np.float32)
+
+
+def test_sinf_cosf_match_glibc(st):
+    rng = np.random.default_rng(1)
+    parts = [
+        rng.uniform(-7.0, 7.0, 3_000_000).astype(np.float32),                       # the games' angles
+        rng.uniform(-1000.0, 1000.0, 1_000_000).astype(np.float32),                 # accumulated rotations
+        np.arange(0x39000000, 0x41000000, 41, dtype=np.uint32).view(np.float32),    # every binade up to 8.0, strided
+        np.arange(0, 0x7f800000, 4099, dtype=np.uint32).view(np.float32),           # all magnitudes incl. huge
+        -np.arange(0, 0x7f800000, 8191, dtype=np.uint32).view(np.float32),
+        np.array([0.0, -0.0, np.inf, -np.inf, np.nan, np.pi, np.pi / 2, np.pi / 4, 1e-40, -1e-40], np.float32),
+    ]
+    x = np.ascontiguousarray(np.concatenate(parts))
+    assert x.size > 8_000_000
+    s, c = np.zeros_like(x), np.zeros_like(x)
+    assert st.pgst_sincos(x.size, _p(x), _p(s), _p(c)) == 0
+    # host: glibc through numpy's float32 ufuncs is NOT glibc's sinf; call libm itself on a strided sample + all specials
+    m = _libm()
+    idx = np.concatenate([np.arange(0, x.size, 23), np.arange(x.size - 10, x.size)])
+    want_s = _host_map(m.sinf, x[idx])
+    want_c = _host_map(m.cosf, x[idx])
+    assert np.array_equal(s[idx].view(np.uint32)[~np.isnan(want_s)], want_s.view(np.uint32)[~np.isnan(want_s)])
+    assert np.array_equal(c[idx].view(np.uint32)[~np.isnan(want_c)], want_c.view(np.uint32)[~np.isnan(want_c)])
+    assert np.array_equal(np.isnan(s[idx]), np.isnan(want_s)) and np.array_equal(np.isnan(c[idx]), np.isnan(want_c))
+
+
+def test_sinf_cosf_full_sweep_against_host_twin(st, tmp_path):
+    """All 8 M+ arguments, every bit: device results against the HOST compilation of the same header, which
+    tests/cpp/test_primitives.cpp pins to glibc; (the libm ctypes loop above is too slow for all of them)."""
+    import subprocess
+    src = tmp_path / "twin.cpp"
+    src.write_text('#include "pg_sincos.h"\n#include "pg_atan2.h"\nextern "C" void twin_sincos(int n, const float* x, float* s, float* c)'
+                   '{ for (int i = 0; i < n; i++) { s[i] = pg::sc_sinf(x[i]); c[i] = pg::sc_cosf(x[i]); } }\n'
+                   'extern "C" void twin_atan2(int n, const float* y, const float* x, float* o, float* o1)'
+                   '{ for (int i = 0; i < n; i++) { o[i] = pg::at_atan2f(y[i], x[i]); o1[i] = pg::at_atanf(y[i]); } }\n')
+    so = tmp_path / "twin.so"
+    subprocess.run(["g++", "-std=gnu++17", "-O2", "-mfma", "-ffp-contract=off", "-shared", "-fPIC",
+                    "-I" + os.path.join(ROOT, "procgen2_amd", "csrc"), str(src), "-o", str(so)], check=True)
+    twin = ctypes.CDLL(str(so))
+    rng = np.random.default_rng(2)
+    x = np.concatenate([rng.uniform(-10, 10, 4_000_000).astype(np.float32),
+                        rng.integers(0, 1 << 32, 4_400_000, dtype=np.uint64).astype(np.uint32).view(np.float32)])
+    x = np.ascontiguousarray(x)
+    s, c, hs, hc = (np.zeros_like(x) for _ in range(4))
+    assert st.pgst_sincos(x.size, _p(x), _p(s), _p(c)) == 0
+    twin.twin_sincos(x.size, _p(x), _p(hs), _p(hc))
+    ok = ~np.isnan(hs)
+    assert np.array_equal(s.view(np.uint32)[ok], hs.view(np.uint32)[ok]) and np.array_equal(np.isnan(s), np.isnan(hs))
+    ok = ~np.isnan(hc)
+    assert np.array_equal(c.view(np.uint32)[ok], hc.view(np.uint32)[ok]) and np.array_equal(np.isnan(c), np.isnan(hc))
+    # atan2f / atanf the same way: level-sized vectors and arbitrary bit patterns
+    y = np.concatenate([rng.uniform(-40, 40, 4_000_000).astype(np.float32),
+                        rng.integers(0, 1 << 32, 4_000_000, dtype=np.uint64).astype(np.uint32).view(np.float32)])
+    xx = np.concatenate([rng.uniform(-40, 40, 4_000_000).astype(np.float32),
+                         rng.integers(0, 1 << 32, 4_000_000, dtype=np.uint64).astype(np.uint32).view(np.float32)])
+    y, xx = np.ascontiguousarray(y), np.ascontiguousarray(xx)
+    a2, a1, h2, h1 = (np.zeros_like(y) for _ in range(4))
+    assert st.pgst_atan2(y.size, _p(y), _p(xx), _p(a2), _p(a1)) == 0
+    twin.twin_atan2(y.size, _p(y), _p(xx), _p(h2), _p(h1))
+    for got, want in ((a2, h2), (a1, h1)):
+        ok = ~np.isnan(want)
+        assert np.array_equal(got.view(np.uint32)[ok], want.view(np.uint32)[ok])
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+
+
+def test_atan2f_matches_glibc(st):
+    rng = np.random.default_rng(3)
+    y = rng.uniform(-40, 40, 400_000).astype(np.float32)
+    x = rng.uniform(-40, 40, 400_000).astype(np.float32)
+    specials = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, 1e-40, -1e-40, 3e38, 0.5], np.float32)
+    sy, sx = np.meshgrid(specials, specials)
+    y = np.ascontiguousarray(np.concatenate([y, sy.ravel()]))
+    x = np.ascontiguousarray(np.concatenate([x, sx.ravel()]))
+    a2, a1 = np.zeros_like(y), np.zeros_like(y)
+    assert st.pgst_atan2(y.size, _p(y), _p(x), _p(a2), _p(a1)) == 0
+    m = _libm()
+    assert np.array_equal(a2.view(np.uint32), _host_map(m.atan2f, y, x).view(np.uint32))
+    assert np.array_equal(a1.view(np.uint32), _host_map(m.atanf, y).view(np.uint32))
+
+
+def test_mt19937_lane_and_wave_forms_match_libstdcxx(st):
+    L = oracle_util.oracle()
+    seeds = np.array([0, 1, 7, 123, 4294967291, 0xDEADBEEF, 5489, 65535], np.uint32)
+    n = 1300  # crosses two regenerations of the 624 words
+    want = np.zeros((seeds.size, n), np.uint32)
+    L.pgo_hook_mt(seeds.size, _p(seeds), n, _p(want))
+    assert want[3, :3].tolist() == [2991312382, 3062119789, 1228959102]  # SURVEY.md T1 known answers (seed 123)
+    assert want[1, 623] == 2006116153 and want[1, 624] == 1104314680 and want[4, 0] == 1844333030
+    for wave in (0, 1):
+        got = np.zeros_like(want)
+        assert st.pgst_mt(seeds.size, _p(seeds), n, wave, _p(got)) == 0
+        assert np.array_equal(got, want), "wave form" if wave else "lane form"
+
+
+def test_distributions_match_libstdcxx(st):
+    L = oracle_util.oracle()
+    rng = np.random.default_rng(4)
+    n = 4000
+    kind = (rng.random(n) < 0.4).astype(np.uint8)
+    lo = rng.integers(-50, 50, n).astype(np.int32)
+    span = rng.choice([0, 1, 2, 3, 9, 19, 48, 100, 1599, 65535, 1 << 20, (1 << 31) - 60], n)
+    hi = (lo.astype(np.int64) + span).astype(np.int32)
+    fa = rng.choice(np.array([0.0, -1.0, 0.7, -2.0], np.float32), n)
+    fb = (fa + rng.choice(np.array([1.0, 2.0, 0.5, 4.0], np.float32), n)).astype(np.float32)
+    for seed in (123, 7, 4294967291):
+        wi, wf = np.zeros(n, np.int32), np.zeros(n, np.float32)
+        L.pgo_hook_draws(seed, n, _p(kind), _p(lo), _p(hi), _p(fa), _p(fb), _p(wi), _p(wf))
+        for wave in (0, 1):
+            gi, gf = np.zeros(n, np.int32), np.zeros(n, np.float32)
+            assert st.pgst_draws(seed, n, _p(kind), _p(lo), _p(hi), _p(fa), _p(fb), wave, _p(gi), _p(gf)) == 0
+            assert np.array_equal(gi, wi) and np.array_equal(gf.view(np.uint32), wf.view(np.uint32)), (seed, wave)
+    # SURVEY.md T2 known answers, seed 123, in this order
+    kind = np.array([0, 0, 0, 1, 1, 1], np.uint8)
+    lo, hi = np.array([1, 0, 0, 0, 0, 0], np.int32), np.array([3, 48, 19, 0, 0, 0], np.int32)
+    fa, fb = np.array([0, 0, 0, 0.0, -1.0, 0.7], np.float32), np.array([0, 0, 0, 1.0, 1.0, 1.2], np.float32)
+    gi, gf = np.zeros(6, np.int32), np.zeros(6, np.float32)
+    assert st.pgst_draws(123, 6, _p(kind), _p(lo), _p(hi), _p(fa), _p(fb), 1, _p(gi), _p(gf)) == 0
+    assert gi[:3].tolist() == [3, 34, 5] and gf[3:].view(np.uint32).tolist() == [0x3EDB608B, 0xBF0BDA20, 0x3F85D10F]
+    # bulk canonical draws (wave_draws): 1 600 cells starting mid-block, stream position afterwards
+    for seed, skip, count in ((9, 0, 1600), (10, 500, 1600), (11, 623, 2025), (12, 100, 64)):
+        want, nxt = np.zeros(count, np.float32), c_uint32()
+        L.pgo_hook_bulk(seed, skip, count, _p(want), ctypes.byref(nxt))
+        got, gn = np.zeros(count, np.float32), c_uint32()
+        assert st.pgst_bulk(seed, skip, count, _p(got), ctypes.byref(gn)) == 0
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) and gn.value == nxt.value
+
+
+def test_unordered_set_order_twins_match_libstdcxx(st):
+    L = oracle_util.oracle()
+    rng = np.random.default_rng(5)
+    # serial twin (pg_order.h HashOrder, device hash_mod): insert / erase / clear scripts over up to 1 000 ids
+    for n_ops, key_max in ((300, 40), (2000, 1000), (1500, 300), (4000, 1000)):
+        ops = rng.choice([0, 0, 0, 1, 2], n_ops, p=[0.25, 0.25, 0.25, 0.245, 0.005]).astype(np.int32)
+        keys = rng.integers(0, key_max, n_ops).astype(np.int32)
+        want, got = np.zeros(n_ops, np.uint32), np.zeros(n_ops, np.uint32)
+        L.pgo_hook_hash_script(n_ops, _p(ops), _p(keys), _p(want))
+        assert st.pgst_hash_script(n_ops, _p(ops), _p(keys), _p(got)) == 0
+        assert np.array_equal(got, want), (n_ops, key_max)
+    # T3 known answer: fresh set, insert 0..29
+    ops, keys = np.zeros(30, np.int32), np.arange(30, dtype=np.int32)
+    want = np.zeros(30, np.uint32)
+    L.pgo_hook_hash_script(30, _p(ops), _p(keys), _p(want))
+    got = np.zeros(30, np.uint32)
+    assert st.pgst_hash_script(30, _p(ops), _p(keys), _p(got)) == 0 and np.array_equal(got, want)
+    # closed form (pg_setorder.h wave_set_order): rounds of clear() + n distinct inserts, bucket array carried over
+    for rounds in ([30], [6, 40, 5], [1600, 900, 1600, 20, 1300], [13, 14, 29, 30, 59, 60, 127, 128, 257, 258, 541, 542, 1109, 1110],
+                   [int(v) for v in rng.integers(1, 1600, 12)]):
+        counts = np.array(rounds, np.int32)
+        keys_in = np.concatenate([rng.permutation(2025)[:c] for c in rounds]).astype(np.int16)
+        want, got = np.zeros_like(keys_in), np.zeros_like(keys_in)
+        L.pgo_hook_set_rounds(counts.size, _p(counts), _p(keys_in), _p(want))
+        assert st.pgst_set_rounds(counts.size, _p(counts), _p(keys_in), _p(got)) == 0
+        assert np.array_equal(got, want), rounds
+    first = np.arange(30, dtype=np.int16)  # 29 12 11 … 0 13 14 … 28
+    got = np.zeros(30, np.int16)
+    assert st.pgst_set_rounds(1, _p(np.array([30], np.int32)), _p(first), _p(got)) == 0
+    assert got.tolist() == [29] + list(range(12, -1, -1)) + list(range(13, 29))
+
+
+def test_equal_key_sort_permutation_matches_std_sort(st):
+    L = oracle_util.oracle()
+    for n in list(range(1, 72)) + [100, 128, 150, 198, 208]:
+        want, got = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        L.pgo_hook_sort_equal(n, _p(want))
+        assert st.pgst_sort_equal(n, _p(got)) == 0
+        assert np.array_equal(got, want), n
+    got = np.zeros(17, np.int32)
+    st.pgst_sort_equal(17, _p(got))
+    assert got.tolist() == [8, 16, 15, 14, 13, 12, 11, 10, 9, 0, 7, 6, 5, 4, 3, 2, 1]
+
+
+def test_integer_raster_arithmetic_and_aabb(st):
+    rng = np.random.default_rng(6)
+    n = 4_000_000
+    a = rng.integers(0, 1 << 22, n).astype(np.int32)
+    b = np.where(rng.random(n) < 0.5, rng.integers(1, 700, n), rng.integers(1, 1 << 22, n)).astype(np.int32)
+    q, hm = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    assert st.pgst_div(n, _p(a), _p(b), _p(q), _p(hm)) == 0
+    assert np.array_equal(q, a // b)
+    assert np.array_equal(hm, (a & 0x7FFF) % (1 + (b & 0xFFF) % 4095))
+    dst = rng.integers(0, 1 << 24, n, dtype=np.int64).astype(np.uint32)
+    src = rng.integers(0, 1 << 32, n, dtype=np.int64).astype(np.uint32)
+    al = rng.integers(0, 256, n).astype(np.int32)
+    out, d255 = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+    assert st.pgst_blend(n, _p(dst), _p(src), _p(al), _p(out), _p(d255)) == 0
+    assert np.array_equal(d255, (np.arange(n, dtype=np.uint32) & 0xFFFF) // 255)
+    want = np.zeros(n, np.uint32)
+    for sh in (0, 8, 16):
+        s8, d8 = (src >> sh) & 0xFF, (dst >> sh) & 0xFF
+        want |= ((s8 * al.astype(np.uint32)) // 255 + (d8 * (255 - al).astype(np.uint32)) // 255) << sh
+    assert np.array_equal(out, want)
+    # H1 / H2 on the device against the REFERENCE's helpers.cpp where oracle/_ref travelled with the snapshot, else
+    # against the oracle's restatement (itself pinned to helpers.cpp by tests/test_reference_pin.py)
+    import ref_util
+    from test_reference_pin import _rect_pairs
+    ra, rb = _rect_pairs(rng, 1_000_000)
+    side = ref_util.Side("ref") if os.path.exists(os.path.join(ref_util.REF_DIR, "libref_ecs.so")) else ref_util.Side("pgo")
+    h0, o0 = side.collisions(ra, rb)
+    hit, ov = np.zeros(ra.shape[0], np.uint8), np.zeros((ra.shape[0], 4), np.float32)
+    assert st.pgst_box(ra.shape[0], _p(ra), _p(rb), _p(hit), _p(ov)) == 0
+    assert np.array_equal(hit, h0) and np.array_equal(ov.view(np.uint32), o0.view(np.uint32))
