@@ -49,22 +49,18 @@ class Env {
     // include/procgen2_vec.h pgv_config.game_flags (coinrun: PGV_COINRUN_NO_*).  Set before make().
     void set_flags(uint32_t flags) { flags_ = flags; }
 
-    // cenv_render (coinrun.cpp:393-411): render_game(false) into a width×height target, packed RGB.  The reference
-    // leaves its global camera scale/size at the window's values afterwards (only bossfight's reset reads them, D15);
-    // this restatement puts them back, i.e. it models a caller that never mixes human frames into a rollout.
+    // cenv_render (coinrun.cpp:393-411): render_game(false) into a width×height target, packed RGB.  Like the
+    // reference it leaves the camera scale/size at the window's values afterwards: the next observation render sets
+    // them again, and before that only bossfight reads them (reset() and both update()s, D15).
     void render_frame(int width, int height, uint8_t* out_rgb) {
         Surface big(width, height);
         Surface* keep_target = painter_.target;
-        const V2 keep_size = painter_.cam_size;
-        const float keep_scale = painter_.cam_scale;
         painter_.target = &big;
         view_w_ = width;
         view_h_ = height;
         paint();
         pack_rgb(big, out_rgb);
         painter_.target = keep_target;
-        painter_.cam_size = keep_size;
-        painter_.cam_scale = keep_scale;
         view_w_ = kObsW;
         view_h_ = kObsH;
     }

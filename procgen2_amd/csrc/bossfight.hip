@@ -52,7 +52,9 @@ enum Tex {
 // per-env scalar floats
 enum {
     F_AX, F_AY, F_AVX, F_AVY, F_ATIMER, F_BX, F_BY, F_BVX, F_BVY, F_PHASE_T, F_ATTACK_T, F_EXPLO_T, F_DAMAGE_T,
-    F_MOVE_T, F_COUNT
+    F_MOVE_T,
+    F_CAMW, F_CAMH,  // gr.camera_size as the last render_game left it (D15): 64×64 after an observation render
+    F_COUNT
 };
 // per-env scalar ints
 enum {
@@ -84,13 +86,28 @@ PG_D float& BS(const State& s, int field, int k, int env) { return s.bshot[(size
 PG_D float& BM(const State& s, int field, int k, int env) { return s.boom[(size_t(field) * kBooms + k) * s.n + env]; }
 PG_D float& RK(const State& s, int field, int k, int env) { return s.rock[(size_t(field) * kRocks + k) * s.n + env]; }
 
-// Observation camera: size 64, scale 1 (bossfight.cpp:413-414).  reset() and both update()s read these from the
-// renderer; for observation-only use they never change (D15).
+// Observation camera: size 64, scale 1 (bossfight.cpp:412-413).
 constexpr float kCamSize = 64.0f, kCamScale = 1.0f;
 
-PG_D Box screen_box() {  // common_systems.cpp:224-226, 513-515
-    return Box{-kCamSize / kCamScale * kPxUnit * 0.5f, -kCamSize / kCamScale * kPxUnit * 0.5f,
-               kCamSize / kCamScale * kPxUnit, kCamSize / kCamScale * kPxUnit};
+// D15: reset() (bossfight.cpp:434,458) and both update()s (common_systems.cpp:227-228,513-514) read gr.camera_size and
+// gr.camera_scale as the LAST render_game left them: the observation's 64 / 1.0 — or, right after a human-size
+// cenv_render, the window's W×H and 1.0·W/64, which for a non-square window moves the spawn row, the barriers and the
+// screen rectangle of the next step or reset.  F_CAMW/F_CAMH hold that size per env: the frame kernel writes the
+// window's, whoever reads them (logic / level code, always followed by an observation render) puts 64 back.
+struct View {
+    float w, h, sc;
+};
+PG_D View take_view(const State& s, int env) {
+    const float w = SF(s, F_CAMW, env), h = SF(s, F_CAMH, env);
+    if (w != kCamSize || h != kCamSize) {
+        SF(s, F_CAMW, env) = kCamSize;
+        SF(s, F_CAMH, env) = kCamSize;
+    }
+    return View{w, h, 1.0f * w / 64.0f};
+}
+
+PG_D Box screen_box(const View& v) {  // common_systems.cpp:224-226, 513-515
+    return Box{-v.w / v.sc * kPxUnit * 0.5f, -v.h / v.sc * kPxUnit * 0.5f, v.w / v.sc * kPxUnit, v.h / v.sc * kPxUnit};
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -98,8 +115,9 @@ PG_D Box screen_box() {  // common_systems.cpp:224-226, 513-515
 // ------------------------------------------------------------------------------------------------
 PG_D void new_level(const State& s, int env) {
     uint32_t* mt = s.mt + size_t(env) * kMtWords;
-    SF(s, F_AX, env) = rng_real(mt, -1.0f, 1.0f) * kCamSize / kCamScale * kPxUnit * 0.5f;
-    SF(s, F_AY, env) = kCamSize / kCamScale * kPxUnit * 0.5f;
+    const View view = take_view(s, env);
+    SF(s, F_AX, env) = rng_real(mt, -1.0f, 1.0f) * view.w / view.sc * kPxUnit * 0.5f;
+    SF(s, F_AY, env) = view.h / view.sc * kPxUnit * 0.5f;
     SF(s, F_AVX, env) = 0.0f;
     SF(s, F_AVY, env) = 0.0f;
     SF(s, F_BX, env) = 0.0f;
@@ -116,8 +134,8 @@ PG_D void new_level(const State& s, int env) {
     Box placed[kRocks];
     int n_rocks = 0;
     for (int k = 0; k < want; k++) {
-        const float px = rng_real(mt, -1.0f, 1.0f) * kCamSize / kCamScale * kPxUnit * 0.5f * 0.9f;
-        const float py = kCamSize / kCamScale * kPxUnit * 0.5f - rng_real(mt, 0.7f, 1.2f);
+        const float px = rng_real(mt, -1.0f, 1.0f) * view.w / view.sc * kPxUnit * 0.5f * 0.9f;
+        const float py = view.h / view.sc * kPxUnit * 0.5f - rng_real(mt, 0.7f, 1.2f);
         const Box wc{px + -0.1f, py + -0.1f, 0.2f, 0.2f};
         bool clash = false;
         for (int j = 0; j < k; j++)
@@ -166,6 +184,7 @@ struct Live {  // the hot scalars of one env, kept in registers over the four su
     float bx, by, bvx, bvy, phase_t, attack_t, explo_t, damage_t, move_t;
     int a_next, a_count, phase, weapon, hp, b_next, b_count, x_next, x_count, n_rocks;
     bool a_alive;
+    Box scr;  // the screen rectangle both update()s clamp against (screen_box of the env's View, D15)
 };
 
 PG_D Box hazard_box(const State& s, int env, const Live& v, int h) {  // h: 0..n_rocks-1 barrier, n_rocks = boss
@@ -235,7 +254,7 @@ PG_D void fire_pattern(const State& s, int env, Live& v, uint32_t* mt, int patte
 PG_D bool agent_update(const State& s, int env, Live& v, uint32_t* mt, float dt, int action) {  // :494-683
     const float mixrate = 0.5f, speed = 0.1f, bullet_time = 5.0f, bullet_speed = 0.1f;
     const float bounce_speed = 0.05f, bounce_time = 10.0f, explosion_rate = 0.3f;
-    const Box scr = screen_box();
+    const Box scr = v.scr;
     const float mx = static_cast<float>((action == 6 || action == 7 || action == 8) -
                                         (action == 0 || action == 1 || action == 2));
     const float my = static_cast<float>((action == 2 || action == 5 || action == 8) -
@@ -355,7 +374,7 @@ PG_D bool boss_update(const State& s, int env, Live& v, uint32_t* mt, float dt) 
     const int boss_hp = 3;
     bool alive = true;
     const Box agent_rect{v.ax + -0.15f, v.ay + -0.1f, 0.3f, 0.2f};
-    const Box scr = screen_box();
+    const Box scr = v.scr;
 
     if (v.phase_t == 0.0f) {
         v.weapon = rng_int(mt, 0, 3);
@@ -495,6 +514,7 @@ PG_D void advance(const State& s, int env, int action, float& reward_out, bool& 
     v.x_count = SI(s, I_X_COUNT, env);
     v.n_rocks = SI(s, I_NROCKS, env);
     v.a_alive = (flags & kFlagAlive) != 0;
+    v.scr = screen_box(take_view(s, env));
 
     const float dt = 1.0f / 4;
     float reward = 0.0f;
@@ -540,6 +560,8 @@ PG_D void advance(const State& s, int env, int action, float& reward_out, bool& 
 // ------------------------------------------------------------------------------------------------
 // What cenv_make leaves in an env besides the seeded RNG: the three bullet pools, all "dead".
 PG_D void fresh_env(const State& s, int env) {
+    SF(s, F_CAMW, env) = kCamSize;  // Renderer gr: camera_size{64, 64}, camera_scale = 1 (renderer.h:18-20)
+    SF(s, F_CAMH, env) = kCamSize;
     for (int k = 0; k < kAgentShots; k++) {  // std::vector<Bullet>(32): frame = -1 ("dead"), rest zero
         for (int f = 0; f < S_COUNT; f++) AS(s, f, k, env) = (f == S_FRAME) ? -1.0f : 0.0f;
         AB(s, k, env) = 0;
@@ -616,7 +638,7 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
                                                     int flags) {
     const int env = blockIdx.x;
     if (mask && !mask[env]) return;
-    const int lane = threadIdx.x & 63, half = threadIdx.x >> 6;  // two wavefronts per env (pg_render.h)
+    const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // two wavefronts per env (pg_render.h)
     constexpr int halves = 2;
     __shared__ uint32_t fb[kFbWords];
 
@@ -761,6 +783,10 @@ __global__ void __launch_bounds__(kFrameThreads) frame_kernel(State s, AtlasView
     const float fw = static_cast<float>(t.w), fh = static_cast<float>(t.h);
     const float sc = 1.0f * fw / 64.0f;
     FramePainter P{t, atlas, Camera{0.0f, 0.0f, fw, fh, sc}, static_cast<int>(threadIdx.x), kFrameThreads};
+    if (threadIdx.x == 0) {  // render_game(false) leaves the window's size in gr (D15, see take_view)
+        SF(s, F_CAMW, env) = fw;
+        SF(s, F_CAMH, env) = fh;
+    }
     const int skins = SI(s, I_SKINS, env), sflags = SI(s, I_FLAGS, env);
     const int a_ship = skins & 15, a_laser = (skins >> 4) & 15, b_ship = (skins >> 8) & 15, b_laser = (skins >> 12) & 15;
     const int backdrop = (skins >> 16) & 255;

@@ -824,7 +824,7 @@ __global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, Atla
                                                                    StepIO io, int flags) {
     const int env = blockIdx.x;
     if (mask && !mask[env]) return;
-    const int lane = threadIdx.x & 63, half = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int halves = kRenderWaves;
     __shared__ uint32_t fb[kFbWords];
     constexpr int kGrid = 16;  // 64 px / 4.8 px per tile = 13.3 tiles → at most 15 columns/rows in view
@@ -919,7 +919,8 @@ __global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, Atla
 
     bool composed = false;
     if (!(flags & 1) && !PG_ABL(flags, 4) && cols <= kGrid && rows <= kGrid) {
-        compose_spans(fb, L, cam, x0, y0, cols, rows, tile_desc.y, tile_desc.z, kUnitPx / tile_desc.y, lane, 0, half, halves);
+        compose_spans(fb, L, cam, x0, y0, cols, rows, tile_desc.y, tile_desc.z, kUnitPx / tile_desc.y, lane, 0, half, halves,
+                      /*exact_soft=*/true);
         // Texel offset of each tile kind's texture, one per lane (0..7), looked up with a cross-lane read:
         // lanes 0-3 = wall_top, wall_mid, lava_top, lava_mid (tile id - 1), lanes 4-7 = the four crates.
         int kind_tex = kTexCrate + ((lane - 4) & 3);
@@ -929,7 +930,9 @@ __global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, Atla
         if (lane == 3) kind_tex = kTexLava;
         const int4 kind_d = descs.at(kind_tex);
         const int kind_base = kind_d.x;
-        bool blendy = threadIdx.x == 0 && bg_d.w != 0;  // a visible texture with translucent texels (descriptor .w)
+        // which grid rows show a texture with translucent texels (descriptor .w; crates and lava caps are the only
+        // soft-edged tiles, 9 of the 49 backdrops have some): only there does the composer look at alphas
+        uint32_t soft_rows = (threadIdx.x == 0 && bg_d.w != 0) ? 0x80000000u : 0u;
 #pragma unroll
         for (int k = half; k < kGrid * kGrid / 64; k += halves) {  // the whole kGrid×kGrid table, 64 cells per pass
             const int cell = k * 64 + lane;
@@ -942,14 +945,11 @@ __global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, Atla
             const int off = __shfl(kind_base, slot < 0 ? 0 : slot);
             const int soft = __shfl(kind_d.w, slot < 0 ? 0 : slot);
             L.base[cell] = (t == kEmpty) ? static_cast<int32_t>(kNoTexel) : off * 4;
-            blendy = blendy || (t != kEmpty && soft != 0);
+            if (t != kEmpty && soft != 0 && r < rows && c < cols) soft_rows |= 1u << r;
         }
-        if (blendy) L.blendy = 1;
+        if (soft_rows) atomicOr(&L.soft_rows, static_cast<int32_t>(soft_rows));
         __syncthreads();
-        // no translucent texel in the background nor in any tile texture in view (most frames: crates and lava caps are
-        // the only soft-edged tiles) → the composer skips its per-texel translucency scan
-        const bool may_blend = L.blendy != 0;
-        composed = compose_rows(fb, L, atlas, bg, has_bg, cols, rows, tile_desc.y, lane, flags, half, halves, may_blend);
+        composed = compose_rows(fb, L, atlas, bg, has_bg, cols, rows, tile_desc.y, lane, flags, half, halves);
     }
     if (PG_ABL(flags, 4)) composed = true;  // (bit 2: timing experiment — no background/tiles at all)
     if (!composed) {  // draw-list replay of background and tiles (tilemap.cpp:294-321)

@@ -69,6 +69,11 @@ bool Atlas::load(const std::string& root, const std::vector<std::string>& names,
         size_t base = texels_.size();
         texels_.resize(base + size_t(img.w) * img.h);
         std::memcpy(&texels_[base], img.rgba.data(), size_t(img.w) * img.h * 4);
+        // A texel with alpha 0 never reaches a pixel (raster spec S4), whatever colour the PNG left in it: store it as
+        // the word 0, so that "nothing here" is one value (pg_render.h compose_rows picks the last drawn candidate
+        // with an unsigned maximum).
+        for (size_t k = base; k < texels_.size(); k++)
+            if ((texels_[k] >> 24) == 0) texels_[k] = 0;
     }
     return true;
 }

@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
                                                     int flags) {
     const int env = blockIdx.x;
     if (mask && !mask[env]) return;
-    const int lane = threadIdx.x & 63, half = threadIdx.x >> 6;  // two wavefronts per env (pg_render.h)
+    const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // two wavefronts per env (pg_render.h)
     constexpr int halves = 2;
     __shared__ uint32_t fb[kFbWords];
     constexpr int kGrid = kVisible + 3 <= 20 ? 20 : 28;  // visible tiles + the border cells of the inclusive window; as small as it

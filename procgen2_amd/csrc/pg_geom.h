@@ -162,7 +162,7 @@ PG_HD int sample_index(int start, int len, int i, int n) { return start + udiv_s
 // floor(x / 255) for 0 <= x < 65536 (exhaustively checked in tests/cpp/test_primitives.cpp).
 PG_HD uint32_t div255(uint32_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __umul24(x, 0x8081u) >> 23;
+    return static_cast<uint32_t>(__umul24(x, 0x8081u)) >> 23;  // (the intrinsic's result is signed in this HIP: x ≥ 65280 needs the cast)
 #else
     return (x * 0x8081u) >> 23;
 #endif

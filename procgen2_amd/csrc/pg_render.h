@@ -51,9 +51,12 @@ struct __attribute__((packed, aligned(4))) Rgb4 {
 // written and live in the frame target's own memory until then (compose_rows puts a barrier between the two uses).
 template <int GRID>
 struct ComposeLds {
-    int32_t base[GRID * GRID];  // [row][col] byte offset of the cell's tile texture in the atlas, kNoTexel = no tile
+    int32_t base[GRID * GRID + 1];  // [row][col] byte offset of the cell's tile texture in the atlas, kNoTexel = no tile;
+                                    // the extra last word is always kNoTexel (the cell of a pixel row no grid row covers)
     int32_t too_wide;           // some span is wider than kMaxSpan pixels → fall back
-    int32_t blendy;             // set by the caller's staging pass when a visible texture has translucent texels
+    int32_t soft_rows;          // bit r: grid row r shows a tile texture with translucent texels; bit 31: the background
+                                // has some.  compose_spans leaves −1 ("assume all"); a staging pass that knows clears it
+                                // first (compose_spans exact_soft) and ORs the exact bits in.
 };
 template <int GRID>
 struct ComposeTmp {
@@ -124,6 +127,11 @@ PG_D Blit blit_from_lane(const Blit& mine, int src) {
 }
 
 PG_D void blend_into(uint32_t* fb, int idx, uint32_t texel, int mod);
+
+PG_D uint32_t max3_u32(uint32_t a, uint32_t b, uint32_t c) {  // v_max3_u32
+    const uint32_t m = a > b ? a : b;
+    return m > c ? m : c;
+}
 
 // A resolved, un-rotated draw as six words per lane ([word][lane], 1536 B for a wave): the two wavefronts of an env
 // need the same 64 resolved draws, and resolving them (≈ 180 vector instructions of exact float division) once and
@@ -472,14 +480,16 @@ PG_D void wave_clear(uint32_t* fb, int lane, int half = 0, int halves = 1) {
 // rows of a pixel stay the tall texture's; only the texel row differs per cell (compose_rows<GRID, true>).
 template <int GRID, int MAXSPAN = kMaxSpan>
 PG_D void compose_spans(uint32_t* fb, ComposeLds<GRID>& L, const Camera& cam, int x0, int y0, int cols, int rows, int tw,
-                        int th, float tile_scale, int lane, int th2 = 0, int half = 0, int halves = 1) {
+                        int th, float tile_scale, int lane, int th2 = 0, int half = 0, int halves = 1,
+                        bool exact_soft = false) {
     ComposeTmp<GRID>& T = compose_tmp<GRID>(fb);
     if (half == 0) {
         T.cover_n[0][lane] = 0;
         T.cover_n[1][lane] = 0;
         if (lane == 0) {
             L.too_wide = 0;
-            L.blendy = 0;
+            L.soft_rows = exact_soft ? 0 : -1;
+            L.base[GRID * GRID] = static_cast<int32_t>(0x40000000u);  // kNoTexel (declared below)
         }
     }
     __syncthreads();
@@ -606,8 +616,7 @@ PG_D void compose_background(uint32_t* fb, const AtlasView& atlas, const Blit& b
 
 template <int GRID, bool TWO = false>
 PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView& atlas, const Blit& bg, bool has_bg,
-                       int cols, int rows, int tw, int lane, int ablate = 0, int half = 0, int halves = 1,
-                       bool may_blend = true) {
+                       int cols, int rows, int tw, int lane, int ablate = 0, int half = 0, int halves = 1) {
 
     // lane as pixel column: covering grid columns; lane as pixel row: covering grid rows.
     int ca, cb, ua, ub, ra, rb, va, vb;
@@ -661,69 +670,96 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
             if (sp.w > 0 && i >= 0 && i < sp.y) row_b2 = static_cast<uint32_t>(sample_index(sp.z, sp.w, i, sp.y) * tw) * 4u;
         }
     }
-    // one tile texel: cell base (bit 0 = second texture) + column offset + the row offset of the cell's texture
-    auto tile_texel = [&](uint32_t base, uint32_t col, uint32_t row_first, uint32_t row_second) {
-        if (TWO) {
-            const uint32_t row = (base & 1u) ? row_second : row_first;
-            return __builtin_amdgcn_raw_buffer_load_b32(atlas_rsrc, (base & ~3u) + col + row, 0, 0);
-        }
-        return __builtin_amdgcn_raw_buffer_load_b32(atlas_rsrc, base + col, row_first, 0);
-    };
-    const unsigned long long second_row = __ballot(rb >= 0);  // bit py: pixel row py is covered by two grid rows
+    if (__ballot((ra >= 0 && row_a >= (1u << 20)) || (rb >= 0 && row_b >= (1u << 20)))) return false;  // (packing below)
+    // Per pixel row (lane = row), one word per covering grid row: the texel row's byte offset (low 20 bits) and the
+    // index of the grid row's first cell in L.base (above) — one cross-lane read per row brings both into scalar
+    // registers.  A row that no grid row covers points at the sentinel cell behind the table, which holds kNoTexel.
+    static_assert(GRID * GRID + 1 < (1 << 11), "cell index field of the packed row word");
+    const uint32_t pack_a = ra >= 0 ? (row_a | (static_cast<uint32_t>(ria) << 20)) : (static_cast<uint32_t>(GRID * GRID) << 20);
+    const uint32_t pack_b = rb >= 0 ? (row_b | (static_cast<uint32_t>(rib) << 20)) : (static_cast<uint32_t>(GRID * GRID) << 20);
+    const uint32_t cia4 = static_cast<uint32_t>(cia) * 4u, cib4 = static_cast<uint32_t>(cib) * 4u;
+    // Wave-uniform row classes as 64-bit masks (bit py = pixel row py; every lane holds row `lane`'s values):
+    //   second_row  two grid rows cover the row (the seam a tile's padding makes with the next tile);
+    //   soft        a grid row covering the row shows a texture that has translucent texels (L.soft_rows; bit 31: the
+    //               background does): only batches with such a row look at the alphas they fetched.
+    const unsigned long long second_row = __ballot(rb >= 0);
+    const uint32_t soft_bits = static_cast<uint32_t>(L.soft_rows);
+    const bool soft_here = (soft_bits >> 31) != 0 || (ra >= 0 && ((soft_bits >> (ra & 31)) & 1u)) ||
+                           (rb >= 0 && ((soft_bits >> (rb & 31)) & 1u));  // (grids beyond 31 rows alias: conservative)
+    const unsigned long long soft = __ballot(soft_here);
     __syncthreads();  // everybody has read the set-up tables out of the frame target's memory: it may be written now
 
-    // Rows in batches: every texel gather of a batch is issued before any blend, so a batch costs one memory
-    // round trip.  Candidates in draw order: background, (row a, col a), (row a, col b), (row b, col a), (row b, col b).
+    // Rows in batches: every texel gather of a batch is issued before any pixel is produced, so a batch costs one
+    // memory round trip.  Candidates in draw order: background, (row a, col a), (row a, col b), (row b, col a),
+    // (row b, col b).
 #ifndef PG_BATCH
 #define PG_BATCH 8
 #endif
     constexpr int kBatch = PG_BATCH;
+    static_assert(kBatch == 8, "the batch's slice of the row masks is taken as one byte");
     if (PG_ABL(ablate, 128)) {  // timing experiment: everything but the row loop
         __syncthreads();
         return true;
     }
+    const char* const cells = reinterpret_cast<const char*>(L.base);
+    // one tile texel: cell word (texture byte offset; with TWO bit 0 = second texture) + column offset, then the row
+    // offset of the cell's texture — wave-uniform unless TWO, where it depends on the cell
+    auto tile_texel = [&](uint32_t cell_at, uint32_t col, uint32_t row_first, uint32_t row_second) {
+        const uint32_t cell = *reinterpret_cast<const uint32_t*>(cells + cell_at);
+        if (TWO) {
+            const uint32_t row = (cell & 1u) ? row_second : row_first;
+            return __builtin_amdgcn_raw_buffer_load_b32(atlas_rsrc, (cell & ~3u) + col + row, 0, 0);
+        }
+        return __builtin_amdgcn_raw_buffer_load_b32(atlas_rsrc, cell + col, row_first, 0);
+    };
     const int py_begin = half * (kObsH / halves), py_end = py_begin + kObsH / halves;
     for (int py0 = py_begin; py0 < py_end; py0 += kBatch) {
         uint32_t t[kBatch][5];
+        const uint32_t seconds = static_cast<uint32_t>(second_row >> py0) & 0xffu;
 #pragma unroll
         for (int k = 0; k < kBatch; k++) {
             const int py = py0 + k;
             const uint32_t s_bg = __builtin_amdgcn_readlane(bg_row, py);
-            const uint32_t s_a = __builtin_amdgcn_readlane(row_a, py);
-            const int l_a = __builtin_amdgcn_readlane(ria, py);
+            const uint32_t pa = __builtin_amdgcn_readlane(pack_a, py);
+            const uint32_t s_a = pa & 0xfffffu, l_a4 = (pa >> 20) * 4u;
             t[k][0] = __builtin_amdgcn_raw_buffer_load_b32(bg_rsrc, bg_col, s_bg, 0);
             const uint32_t s_a2 = TWO ? __builtin_amdgcn_readlane(row_a2, py) : 0u;
-            t[k][1] = tile_texel(static_cast<uint32_t>(L.base[l_a + cia]), col_a, s_a, s_a2);
-            t[k][2] = tile_texel(static_cast<uint32_t>(L.base[l_a + cib]), col_b, s_a, s_a2);
-            if ((second_row >> py) & 1ull) {
-                const uint32_t s_b = __builtin_amdgcn_readlane(row_b, py);
-                const int l_b = __builtin_amdgcn_readlane(rib, py);
+            t[k][1] = tile_texel(l_a4 + cia4, col_a, s_a, s_a2);
+            t[k][2] = tile_texel(l_a4 + cib4, col_b, s_a, s_a2);
+            if (seconds & (1u << k)) {
+                const uint32_t pb = __builtin_amdgcn_readlane(pack_b, py);
+                const uint32_t s_b = pb & 0xfffffu, l_b4 = (pb >> 20) * 4u;
                 const uint32_t s_b2 = TWO ? __builtin_amdgcn_readlane(row_b2, py) : 0u;
-                t[k][3] = tile_texel(static_cast<uint32_t>(L.base[l_b + cia]), col_a, s_b, s_b2);
-                t[k][4] = tile_texel(static_cast<uint32_t>(L.base[l_b + cib]), col_b, s_b, s_b2);
-            } else {
-                t[k][3] = t[k][4] = 0u;
+                t[k][3] = tile_texel(l_b4 + cia4, col_a, s_b, s_b2);
+                t[k][4] = tile_texel(l_b4 + cib4, col_b, s_b, s_b2);
             }
         }
-        // Is any fetched texel translucent (alpha not in {0, 255})?  (a + 1) & 0xFE is zero exactly for 0 and 255.
-        // `may_blend` false = the caller vouches (descriptor flags, set when the atlas is loaded) that no texture of
-        // this layer has such a texel: the scan — a third of this loop's vector instructions — is skipped.
-        uint32_t translucent = 0;
-        if (may_blend) {
-#pragma unroll
-            for (int k = 0; k < kBatch; k++)
-#pragma unroll
-                for (int j = 0; j < 5; j++) translucent |= ((t[k][j] >> 24) + 1u) & 0xFEu;
-        }
-        if (PG_ABL(ablate, 512)) translucent = 0;  // timing experiment: never take the blending path
-        if (bg_mod == 255 && (!may_blend || __ballot(translucent != 0) == 0)) {
-            // Opaque-or-absent everywhere in the batch: OVER is "last drawn wins" (what S4 yields for a = 0 / 255).
+        // Does the batch hold a translucent texel (alpha not in {0, 255})?  Asked only when one of its rows shows a
+        // texture that has any ((a + 1) & 0xFE is zero exactly for 0 and 255).
+        bool blend = bg_mod != 255;
+        if (!blend && ((static_cast<uint32_t>(soft >> py0) & 0xffu) != 0u) && !PG_ABL(ablate, 512)) {
+            uint32_t translucent = 0;
 #pragma unroll
             for (int k = 0; k < kBatch; k++) {
-                uint32_t pix = 0;
+                translucent |= (((t[k][0] >> 24) + 1u) | ((t[k][1] >> 24) + 1u) | ((t[k][2] >> 24) + 1u)) & 0xFEu;
+                if (seconds & (1u << k)) translucent |= (((t[k][3] >> 24) + 1u) | ((t[k][4] >> 24) + 1u)) & 0xFEu;
+            }
+            blend = __ballot(translucent != 0) != 0;
+        }
+        if (!blend) {
+            // Opaque-or-absent everywhere in the batch: OVER is "last drawn wins" (what S4 yields for a = 0 / 255).
+            // An absent or fully transparent texel is the word 0 (the atlas loader clears the colour of alpha-0
+            // texels); an opaque one has 0xFF on top.  Masking the top byte down to the candidate's rank in draw
+            // order turns "last drawn non-empty" into a plain unsigned maximum.  The rank stays in the target's top
+            // byte, which nothing reads (blend_px, wave_store_obs).
 #pragma unroll
-                for (int j = 0; j < 5; j++) pix = (t[k][j] > 0x00ffffffu) ? t[k][j] : pix;  // alpha ≠ 0
-                fb[(py0 + k) * kObsW + lane] = pix & 0x00ffffffu;
+            for (int k = 0; k < kBatch; k++) {
+                uint32_t pix = max3_u32(t[k][0] & 0x00ffffffu, t[k][1] & 0x01ffffffu, t[k][2] & 0x02ffffffu);
+                if (seconds & (1u << k)) {  // wave-uniform: a real branch (the empty asm keeps it from becoming a select)
+                    pix = max3_u32(pix, t[k][3] & 0x03ffffffu, t[k][4] & 0x04ffffffu);
+                    asm volatile("" : "+v"(pix));
+                }
+                fb[(py0 + k) * kObsW + lane] = pix;
             }
         } else {
 #pragma unroll
@@ -732,8 +768,12 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
                 int a = static_cast<int>(t[k][0] >> 24);
                 if (bg_mod != 255) a = static_cast<int>(div255(static_cast<uint32_t>(a * bg_mod)));
                 pix = blend_px(pix, t[k][0], a);
-#pragma unroll
-                for (int j = 1; j < 5; j++) pix = blend_px(pix, t[k][j], static_cast<int>(t[k][j] >> 24));
+                pix = blend_px(pix, t[k][1], static_cast<int>(t[k][1] >> 24));
+                pix = blend_px(pix, t[k][2], static_cast<int>(t[k][2] >> 24));
+                if (seconds & (1u << k)) {
+                    pix = blend_px(pix, t[k][3], static_cast<int>(t[k][3] >> 24));
+                    pix = blend_px(pix, t[k][4], static_cast<int>(t[k][4] >> 24));
+                }
                 fb[(py0 + k) * kObsW + lane] = pix;
             }
         }
@@ -749,10 +789,10 @@ PG_D void wave_store_obs(const uint32_t* fb, uint8_t* obs_env, int lane, int hal
     const uint4* in = reinterpret_cast<const uint4*>(fb);
     for (int g = lane + 64 * half; g < kFbWords / 4; g += 64 * halves) {
         const uint4 p = in[g];
-        Rgb4 o;
-        o.a = p.x | (p.y << 24);
-        o.b = (p.y >> 8) | (p.z << 16);
-        o.c = (p.z >> 16) | (p.w << 8);
+        Rgb4 o;  // three byte permutes; the target's top bytes (the composer leaves draw ranks there) are dropped
+        o.a = __builtin_amdgcn_perm(p.y, p.x, 0x04020100u);  // x0 x1 x2 y0
+        o.b = __builtin_amdgcn_perm(p.z, p.y, 0x05040201u);  // y1 y2 z0 z1
+        o.c = __builtin_amdgcn_perm(p.w, p.z, 0x06050402u);  // z2 w0 w1 w2
         // Streaming stores (`global_store_dwordx3 … nt`): the 12 KB of an observation are written once and not read
         // again by this launch; keeping them out of the L2's way leaves it to the atlas and the state (measured:
         // render 0.728 → 0.681 ms, coinrun 66.5 → 70.6 M env-steps/s).

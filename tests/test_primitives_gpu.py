@@ -238,12 +238,17 @@ def test_integer_raster_arithmetic_and_aabb(st):
     al = rng.integers(0, 256, n).astype(np.int32)
     out, d255 = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
     assert st.pgst_blend(n, _p(dst), _p(src), _p(al), _p(out), _p(d255)) == 0
-    assert np.array_equal(d255, (np.arange(n, dtype=np.uint32) & 0xFFFF) // 255)
+    want255 = (np.arange(n, dtype=np.uint32) & 0xFFFF) // 255
+    bad = np.nonzero(d255 != want255)[0]
+    assert bad.size == 0, "div255: %d mismatches, first at x=%d: got %d want %d" % (
+        bad.size, bad[0] & 0xFFFF, d255[bad[0]], want255[bad[0]])
     want = np.zeros(n, np.uint32)
     for sh in (0, 8, 16):
         s8, d8 = (src >> sh) & 0xFF, (dst >> sh) & 0xFF
         want |= ((s8 * al.astype(np.uint32)) // 255 + (d8 * (255 - al).astype(np.uint32)) // 255) << sh
-    assert np.array_equal(out, want)
+    bad = np.nonzero(out != want)[0]
+    assert bad.size == 0, "blend_px: %d mismatches, first dst=%08x src=%08x a=%d: got %08x want %08x" % (
+        bad.size, dst[bad[0]], src[bad[0]], al[bad[0]], out[bad[0]], want[bad[0]])
     # H1 / H2 on the device against the REFERENCE's helpers.cpp where oracle/_ref travelled with the snapshot, else
     # against the oracle's restatement (itself pinned to helpers.cpp by tests/test_reference_pin.py)
     import ref_util
