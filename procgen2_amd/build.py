@@ -80,7 +80,7 @@ def build(force=False, verbose=True, ablate=False):
     lib/libprocgen2_hip_ablate.so with its objects in build_ablate/ — for tools/ablate_render.py, never the product."""
     common, aliases, obj_dir = COMMON, ALIASES, OBJ
     if ablate:
-        common = COMMON + ["-DPG_ABLATE"]
+        common = COMMON + ["-DPG_ABLATE"] + os.environ.get("PG_EXTRA_FLAGS", "").split()  # (experiments only)
         aliases = {"libprocgen2_hip_ablate.so": 0}
         obj_dir = OBJ + "_ablate"
     return _build(force, verbose, common, aliases, obj_dir)

@@ -641,10 +641,12 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
         shot_rot = SF(s, F_ROT, env);
     }
 
+    int bg_soft = 0;  // the backdrop has texels that are not opaque (descriptor .w)
     Blit bg;  // caveflyer.cpp:427-432
     bool has_bg;
     {
         const int4 d = descs.uniform(kTexSpace + SI(s, I_BACKDROP, env));
+        bg_soft = d.w;
         const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
         const float extra = aspect - 1.0f;
         has_bg = resolve_draw(cam, d.y, d.z, d.x, -SF(s, F_BGSHIFT, env) * extra, 0.0f, 64.0f * kUnitPx / d.z, 1.0f,
@@ -661,7 +663,8 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
 
     bool composed = false;
     if (!(flags & 1) && cols <= kGrid && rows <= kGrid) {
-        compose_spans<kGrid, 16>(fb, L, cam, x0, y0, cols, rows, wall_d.y, wall_d.z, kUnitPx / wall_d.y, lane, 0, half, halves);
+        compose_spans<kGrid, 16>(fb, L, cam, x0, y0, cols, rows, wall_d.y, wall_d.z, kUnitPx / wall_d.y, lane, 0, half, halves,
+                                 soft_rows_of(bg_soft, wall_d.w), hard_rows_of(bg_soft, wall_d.w));
 #pragma unroll
         for (int k = half; k < kGrid * kGrid / 64; k += halves) {
             const int cell = k * 64 + lane;
@@ -703,7 +706,7 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
             has = resolve_rotated(cam, d.y, d.z, d.x, (puff_x + puff_dx * shift) * kUnitPx - size * d.y * 0.5f,
                                   (puff_y + puff_dy * shift) * kUnitPx - size * d.z * 0.5f, puff_rot, size, alpha, mine);
         }
-        wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
+        wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
     }
     {  // positive-z sprites (common_systems.cpp:26-48): goal, meteors, targets, enemies
         const int4 d = descs.at(kTexKind + spr_kind);
@@ -713,7 +716,7 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
             has = resolve_draw(cam, d.y, d.z, d.x, (spr_x + -0.4f) * kUnitPx, (spr_y + -0.4f) * kUnitPx,
                                scale * kUnitPx / d.y, 1.0f, false, false, mine);
         }
-        wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
+        wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
         if (kMaxEnt > 64 && n_draw > 64) {  // memory_mode: up to 76 sprites, the rest in a second pass
             const int k = 64 + lane;
             int kind2 = 0;
@@ -731,7 +734,7 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
                 has2 = resolve_draw(cam, d2.y, d2.z, d2.x, (x2 + -0.4f) * kUnitPx, (y2 + -0.4f) * kUnitPx,
                                     scale * kUnitPx / d2.y, 1.0f, false, false, mine);
             }
-            wave_replay(fb, atlas, mine, __ballot(has2), lane, half, halves);
+            wave_replay_rows(fb, atlas, mine, __ballot(has2), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
         }
     }
     {  // System_Agent::render (common_systems.cpp:291-327): bullets newest first, then the ship
@@ -748,10 +751,10 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
             has = resolve_rotated(cam, d.y, d.z, d.x, shot_x * kUnitPx - size * d.y * 0.5f,
                                   shot_y * kUnitPx - size * d.z * 0.5f, static_cast<float>(shot_rot + kPi * 0.5f), size,
                                   1.0f, mine);
-        wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
+        wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
     }
-    __syncthreads();
-    wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane, half, halves);
+    // each wave stores the rows it owns (pg_render.h wave_replay_rows): no barrier
+    wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
 }
 
 // cenv_render's frame (render_game(false)) for one env: pg_frame.h; the draw list of render_kernel, one draw at a time.

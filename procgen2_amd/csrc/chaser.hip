@@ -675,10 +675,12 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
     const DescRegs descs = DescRegs::load(atlas, lane);
     Blit mine;
 
+    int bg_soft = 0;  // the backdrop has texels that are not opaque (descriptor .w)
     Blit bg;  // chaser.cpp:404-409
     bool has_bg;
     {
         const int4 d = descs.uniform(kTexFloor + SI(s, I_BG, env));
+        bg_soft = d.w;
         const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
         const float extra = aspect - 1.0f;
         has_bg = resolve_draw(cam, d.y, d.z, d.x, -SF(s, F_BGSHIFT, env) * extra, 0.0f, 64.0f * kUnitPx / d.z, 1.0f,
@@ -695,7 +697,8 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
 
     bool composed = false;
     if (!(flags & 1) && cols <= kGrid && rows <= kGrid) {
-        compose_spans<kGrid, 16>(fb, L, cam, x0, y0, cols, rows, wall_d.y, wall_d.z, kUnitPx / wall_d.y, lane, 0, half, halves);
+        compose_spans<kGrid, 16>(fb, L, cam, x0, y0, cols, rows, wall_d.y, wall_d.z, kUnitPx / wall_d.y, lane, 0, half, halves,
+                                 soft_rows_of(bg_soft, wall_d.w), hard_rows_of(bg_soft, wall_d.w));
 #pragma unroll
         for (int k = half; k < kGrid * kGrid / 64; k += halves) {
             const int cell = k * 64 + lane;
@@ -755,10 +758,10 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
             has = resolve_draw(cam, d.y, d.z, d.x, (x + -0.5f) * kUnitPx, (y + -0.5f) * kUnitPx, scale, 1.0f, false, false,
                                mine);
         }
-        wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
+        wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
     }
-    __syncthreads();
-    wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane, half, halves);
+    // each wave stores the rows it owns (pg_render.h wave_replay_rows): no barrier
+    wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
 }
 
 // cenv_render's frame (render_game(false)) for one env: pg_frame.h; the draw list of render_kernel, one draw at a time.

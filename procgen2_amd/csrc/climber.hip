@@ -537,10 +537,12 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
         spr_y = EF(s, EF_Y, e, env);
     }
 
+    int bg_soft = 0;  // the backdrop has texels that are not opaque (descriptor .w)
     Blit bg;  // climber.cpp:447-452
     bool has_bg;
     {
         const int4 d = descs.uniform(kTexBackdrop + backdrop);
+        bg_soft = d.w;
         const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
         const float extra = aspect - 1.0f;
         has_bg = resolve_draw(cam, d.y, d.z, d.x, -SF(s, F_BGSHIFT, env) * extra, 0.0f, 64.0f * kUnitPx / d.z, 1.0f,
@@ -560,7 +562,8 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
     // two-texture mode; a cap taller than the body, or of another width, would take the draw-list replay.
     const bool two = top_d.z != mid_d.z;
     if (!(flags & 1) && cols <= kGrid && rows <= kGrid && top_d.y == mid_d.y && top_d.z <= mid_d.z) {
-        compose_spans(fb, L, cam, x0, y0, cols, rows, mid_d.y, mid_d.z, kUnitPx / mid_d.y, lane, two ? top_d.z : 0, half, halves);
+        compose_spans(fb, L, cam, x0, y0, cols, rows, mid_d.y, mid_d.z, kUnitPx / mid_d.y, lane, two ? top_d.z : 0, half, halves,
+                      soft_rows_of(bg_soft, top_d.w | mid_d.w), hard_rows_of(bg_soft, mid_d.w));  // (cap tiles are few: always worth the attempt)
 #pragma unroll
         for (int k = half; k < kGrid * kGrid / 64; k += halves) {
             const int cell = k * 64 + lane;
@@ -633,10 +636,10 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
             go = true;
         }
         if (go) has = resolve_draw(cam, d.y, d.z, d.x, wx, wy, scale_num / d.y, 1.0f, flip, false, mine);
-        wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
+        wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
     }
-    __syncthreads();
-    wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane, half, halves);
+    // each wave stores the rows it owns (pg_render.h wave_replay_rows): no barrier
+    wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
 }
 
 // cenv_render's frame (render_game(false)) for one env: pg_frame.h; the draw list of render_kernel, one draw at a time.

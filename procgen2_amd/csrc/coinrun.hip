@@ -834,6 +834,14 @@ __global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, Atla
         uint32_t slots[kBlitWords * 64];
     } shared;
     ComposeLds<kGrid>& L = shared.compose;
+#if defined(PG_ABLATE) && defined(PG_LDS_PAD)  // occupancy experiment: fewer envs per CU
+    __shared__ uint32_t lds_pad[PG_LDS_PAD];
+    if (flags & 0x40000000) {
+        lds_pad[(threadIdx.x * 37) % PG_LDS_PAD] = env;
+        __syncthreads();
+        fb[lane] = lds_pad[(lane * 11) % PG_LDS_PAD];
+    }
+#endif
 
     const Camera cam{SF(s, F_CAMX, env), SF(s, F_CAMY, env), 64.0f, 64.0f, 0.3f * 64.0f / 64.0f};
     const int themes = SI(s, I_THEMES, env);
@@ -920,7 +928,7 @@ __global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, Atla
     bool composed = false;
     if (!(flags & 1) && !PG_ABL(flags, 4) && cols <= kGrid && rows <= kGrid) {
         compose_spans(fb, L, cam, x0, y0, cols, rows, tile_desc.y, tile_desc.z, kUnitPx / tile_desc.y, lane, 0, half, halves,
-                      /*exact_soft=*/true);
+                      /*soft_init=*/0, /*hard_init=*/0);  // exact bits are ORed in below
         // Texel offset of each tile kind's texture, one per lane (0..7), looked up with a cross-lane read:
         // lanes 0-3 = wall_top, wall_mid, lava_top, lava_mid (tile id - 1), lanes 4-7 = the four crates.
         int kind_tex = kTexCrate + ((lane - 4) & 3);
@@ -933,6 +941,8 @@ __global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, Atla
         // which grid rows show a texture with translucent texels (descriptor .w; crates and lava caps are the only
         // soft-edged tiles, 9 of the 49 backdrops have some): only there does the composer look at alphas
         uint32_t soft_rows = (threadIdx.x == 0 && bg_d.w != 0) ? 0x80000000u : 0u;
+        // (the one-texel-per-pixel attempt is made everywhere unless the backdrop is mostly cut-out: crates and lava are few)
+        const uint32_t hard_rows = (threadIdx.x == 0 && (bg_d.w & 2)) ? 0x80000000u : 0u;
 #pragma unroll
         for (int k = half; k < kGrid * kGrid / 64; k += halves) {  // the whole kGrid×kGrid table, 64 cells per pass
             const int cell = k * 64 + lane;
@@ -948,6 +958,7 @@ __global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, Atla
             if (t != kEmpty && soft != 0 && r < rows && c < cols) soft_rows |= 1u << r;
         }
         if (soft_rows) atomicOr(&L.soft_rows, static_cast<int32_t>(soft_rows));
+        if (hard_rows) atomicOr(&L.hard_rows, static_cast<int32_t>(hard_rows));
         __syncthreads();
         composed = compose_rows(fb, L, atlas, bg, has_bg, cols, rows, tile_desc.y, lane, flags, half, halves);
     }
@@ -1013,7 +1024,7 @@ __global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, Atla
                     const int e = EB(s, EB_SPARK_ORDER, m, env);
                     has = particle(SP(s, buf, 2, e, k, env), SP(s, buf, 0, e, k, env), SP(s, buf, 1, e, k, env), mine);
                 }
-                wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
+                wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
             }
         }
         // The composer's tables are dead by now (its last barrier is behind both waves): their LDS carries the resolved
@@ -1079,10 +1090,11 @@ __global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, Atla
         }
         __syncthreads();
         if (half != 0) has = blit_take(slots, lane, mine);
-        wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
+        wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
     }
-    __syncthreads();
-    if (!PG_ABL(flags, 8)) wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane, half, halves);
+    // each wave stores the rows it owns (pg_render.h wave_replay_rows): no barrier
+    if (!PG_ABL(flags, 8))
+        wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
 }
 
 // cenv_render's frame (coinrun.cpp:393-411 → render_game(false), :443-470) for one env: pg_frame.h.

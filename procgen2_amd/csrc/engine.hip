@@ -59,12 +59,14 @@ bool Atlas::load(const std::string& root, const std::vector<std::string>& names,
         d.x = static_cast<int>(texels_.size());
         d.y = img.w;
         d.z = img.h;
-        d.w = 0;  // 1 = some texel is translucent (alpha neither 0 nor 255): the row composer's blend path can be needed
-        for (size_t k = 3; k < img.rgba.size(); k += 4)
-            if (img.rgba[k] != 0 && img.rgba[k] != 255) {
-                d.w = 1;
-                break;
-            }
+        // .w bit 0: some texel is not opaque (alpha < 255) — under this texture something else can show, and the row
+        // composer may have to blend; bit 1: more than 3 % of them are not — a frame that shows this texture is unlikely
+        // to get away with its one-texel-per-pixel attempt (pg_render.h compose_rows), so it does not try.
+        d.w = 0;
+        size_t not_opaque = 0;
+        for (size_t k = 3; k < img.rgba.size(); k += 4) not_opaque += img.rgba[k] != 255;
+        if (not_opaque) d.w |= 1;
+        if (not_opaque * 100 > size_t(img.w) * img.h * 3) d.w |= 2;
         desc_.push_back(d);
         size_t base = texels_.size();
         texels_.resize(base + size_t(img.w) * img.h);

@@ -571,10 +571,12 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
         puff_y = PF(s, PF_Y, lane, env);
     }
 
+    int bg_soft = 0;  // the backdrop has texels that are not opaque (descriptor .w)
     Blit bg;  // jumper.cpp:459-464
     bool has_bg;
     {
         const int4 d = descs.uniform(kTexBackdrop + backdrop);
+        bg_soft = d.w;
         const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
         const float extra = aspect - 1.0f;
         has_bg = resolve_draw(cam, d.y, d.z, d.x, -SF(s, F_BGSHIFT, env) * extra, 0.0f, 64.0f * kUnitPx / d.z, 1.0f,
@@ -592,7 +594,8 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
     bool composed = false;
     const bool two = top_d.z != mid_d.z;  // the brown cap tile is 64×53 (see climber.hip)
     if (!(flags & 1) && cols <= kGrid && rows <= kGrid && top_d.y == mid_d.y && top_d.z <= mid_d.z) {
-        compose_spans(fb, L, cam, x0, y0, cols, rows, mid_d.y, mid_d.z, kUnitPx / mid_d.y, lane, two ? top_d.z : 0, half, halves);
+        compose_spans(fb, L, cam, x0, y0, cols, rows, mid_d.y, mid_d.z, kUnitPx / mid_d.y, lane, two ? top_d.z : 0, half, halves,
+                      soft_rows_of(bg_soft, top_d.w | mid_d.w), hard_rows_of(bg_soft, mid_d.w));  // (cap tiles are few: always worth the attempt)
 #pragma unroll
         for (int k = half; k < kGrid * kGrid / 64; k += halves) {
             const int cell = k * 64 + lane;
@@ -638,7 +641,7 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
                                (puff_y + offset_y) * kUnitPx - 0.5f * d.z * scale, scale * kUnitPx / d.y, alpha, false,
                                false, mine);
         }
-        wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
+        wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
     }
     // positive-z sprites (common_systems.cpp:26-48): carrot and spikes in draw order
     for (int first = 0; first < n_draw; first += 64) {
@@ -664,7 +667,7 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
             }
             has = resolve_draw(cam, d.y, d.z, d.x, wx, wy, scale * kUnitPx / d.y, 1.0f, false, false, mine);
         }
-        wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
+        wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
     }
     {  // lane 0: the bunny (common_systems.cpp:204-247); lanes 1-3: the compass (jumper.cpp:473-509)
         const float avx = SF(s, F_AVX, env), phase = SF(s, F_APHASE, env);
@@ -724,10 +727,10 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
             }
             has = resolve_screen(d.y, d.z, d.x, sx, sy, sw, sh, deg, mine);
         }
-        wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
+        wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
     }
-    __syncthreads();
-    wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane, half, halves);
+    // each wave stores the rows it owns (pg_render.h wave_replay_rows): no barrier
+    wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
 }
 
 // cenv_render's frame (render_game(false)) for one env: pg_frame.h; the draw list of render_kernel, one draw at a time.

@@ -227,10 +227,12 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
     const uint8_t* tiles = s.tiles + size_t(env) * kTileStride;
     Blit mine;
 
+    int bg_soft = 0;  // the backdrop has texels that are not opaque (descriptor .w)
     Blit bg;  // background (maze.cpp:402-408)
     bool has_bg;
     {
         const int4 d = atlas.desc[kTexFloor + SI(s, I_BG, env)];
+        bg_soft = d.w;
         const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
         const float extra = aspect - 1.0f;
         has_bg = resolve_draw(cam, d.y, d.z, d.x, -SF(s, F_BGSHIFT, env) * extra, 0.0f, 64.0f * kUnitPx / d.z, 1.0f,
@@ -248,7 +250,8 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
     bool composed = false;
     if (!(flags & 1) && cols <= kGrid && rows <= kGrid) {
         constexpr int kSpan = 64 / kVisible + 2 <= kMaxSpan ? kMaxSpan : 16;  // pixels a tile covers (+ seam padding)
-        compose_spans<kGrid, kSpan>(fb, L, cam, x0, y0, cols, rows, wall.y, wall.z, kUnitPx / wall.y, lane, 0, half, halves);
+        compose_spans<kGrid, kSpan>(fb, L, cam, x0, y0, cols, rows, wall.y, wall.z, kUnitPx / wall.y, lane, 0, half, halves,
+                                    soft_rows_of(bg_soft, wall.w), hard_rows_of(bg_soft, wall.w));
         for (int cell = lane + 64 * half; cell < cells; cell += 64 * halves) {
             const int r = cell / cols, c = cell - r * cols;
             L.base[r * kGrid + c] =
@@ -280,17 +283,17 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
         const bool ok = resolve_draw(cam, d.y, d.z, d.x, (SF(s, F_GX, env) + -0.48f) * kUnitPx,
                                      (SF(s, F_GY, env) + -0.5f) * kUnitPx, scale * kUnitPx / d.y, 1.0f, false, false,
                                      mine);
-        wave_replay(fb, atlas, mine, ok ? 1ull : 0ull, lane, half, halves);
+        wave_replay_rows(fb, atlas, mine, ok ? 1ull : 0ull, lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
     }
     {  // the mouse (common_systems.cpp:138-150); flip = face_forward
         const int4 d = atlas.desc[kTexMouse];
         const bool ok = resolve_draw(cam, d.y, d.z, d.x, (SF(s, F_AX, env) + -0.5f) * kUnitPx,
                                      (SF(s, F_AY, env) + -0.5f) * kUnitPx, kUnitPx / d.y * 1.0f, 1.0f,
                                      (sflags & kFlagForward) != 0, false, mine);
-        wave_replay(fb, atlas, mine, ok ? 1ull : 0ull, lane, half, halves);
+        wave_replay_rows(fb, atlas, mine, ok ? 1ull : 0ull, lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
     }
-    __syncthreads();
-    wave_store_obs(fb, io.obs + size_t(env) * kObsBytes, lane, half, halves);
+    // each wave stores the rows it owns (pg_render.h wave_replay_rows): no barrier
+    wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
 }
 
 // cenv_render's frame (render_game(false)) for one env: pg_frame.h; the draw list of render_kernel, one draw at a time.

@@ -51,12 +51,13 @@ struct __attribute__((packed, aligned(4))) Rgb4 {
 // written and live in the frame target's own memory until then (compose_rows puts a barrier between the two uses).
 template <int GRID>
 struct ComposeLds {
-    int32_t base[GRID * GRID + 1];  // [row][col] byte offset of the cell's tile texture in the atlas, kNoTexel = no tile;
-                                    // the extra last word is always kNoTexel (the cell of a pixel row no grid row covers)
+    int32_t base[GRID * GRID + 2];  // [row][col] byte offset of the cell's tile texture in the atlas, kNoTexel = no tile;
+                                    // the two extra words are always kNoTexel (the cells of a pixel row no grid row covers)
     int32_t too_wide;           // some span is wider than kMaxSpan pixels → fall back
-    int32_t soft_rows;          // bit r: grid row r shows a tile texture with translucent texels; bit 31: the background
-                                // has some.  compose_spans leaves −1 ("assume all"); a staging pass that knows clears it
-                                // first (compose_spans exact_soft) and ORs the exact bits in.
+    int32_t hard_rows;          // same layout: where compose_rows does not attempt its one-texel-per-pixel fast path
+    int32_t soft_rows;          // bit r: grid row r shows a tile texture with texels that are not opaque (descriptor .w);
+                                // bit 31: the background has some.  compose_spans sets it to its soft_init argument
+                                // (default −1, "assume all"); a staging pass that knows better ORs exact bits in.
 };
 template <int GRID>
 struct ComposeTmp {
@@ -305,10 +306,11 @@ PG_D void blend_into(uint32_t* fb, int idx, uint32_t texel, int mod) {
 }
 
 // All 64 lanes execute one (wave-uniform) blit into the LDS target.
-PG_D void wave_blit(uint32_t* fb, const AtlasView& atlas, const Blit& b, int lane, int half = 0, int halves = 1) {
-    const int x0 = b.dx > 0 ? b.dx : 0, y0 = b.dy > 0 ? b.dy : 0;
+PG_D void wave_blit(uint32_t* fb, const AtlasView& atlas, const Blit& b, int lane, int half = 0, int halves = 1,
+                    int row_lo = 0, int row_hi = kObsH) {
+    const int x0 = b.dx > 0 ? b.dx : 0, y0 = b.dy > row_lo ? b.dy : row_lo;
     const int x1 = (b.dx + b.dw) < kObsW ? (b.dx + b.dw) : kObsW;
-    const int y1 = (b.dy + b.dh) < kObsH ? (b.dy + b.dh) : kObsH;
+    const int y1 = (b.dy + b.dh) < row_hi ? (b.dy + b.dh) : row_hi;
     const int cw = x1 - x0, ch = y1 - y0;
     if (cw <= 0 || ch <= 0) return;
     const uint32_t* tex = atlas.texels + b.tex_off;
@@ -464,11 +466,118 @@ PG_D void wave_replay(uint32_t* fb, const AtlasView& atlas, const Blit& mine, un
     }
 }
 
+// The sprite passes of the two-wavefront kernels: wave h OWNS the pixel rows [row_lo, row_hi) = [32h, 32h + 32) of the
+// target — it composed them, it blends every draw that reaches into them (clipped to them), in draw order, and it
+// stores them.  Nothing one wave writes is read by the other, so there is no barrier between draws (wave_replay above
+// hands whole draws to the waves in turn and meets at a barrier after each one) and the waves drift apart freely; a
+// draw that straddles row 32 is simply done by both, each on its own rows.  Same grouping as wave_replay: small
+// draws (≤ 64 pixels on my rows) four at a time per memory round trip, rotated or larger ones alone.
+PG_D void wave_replay_rows(uint32_t* fb, const AtlasView& atlas, const Blit& mine, unsigned long long mask, int lane,
+                           int row_lo, int row_hi) {
+    constexpr int kGroup = 4;
+    bool lone = false, reaches = false;
+    if ((mask >> lane) & 1ull) {
+        if (mine.flip_mod & kRotated) {
+            const RotBox box = rot_box(mine);
+            reaches = box.bw > 0 && box.y_lo < row_hi && box.y_lo + box.bh > row_lo;
+            lone = true;
+        } else {
+            const int x0 = mine.dx > 0 ? mine.dx : 0, y0 = mine.dy > row_lo ? mine.dy : row_lo;
+            const int x1 = (mine.dx + mine.dw) < kObsW ? (mine.dx + mine.dw) : kObsW;
+            const int y1 = (mine.dy + mine.dh) < row_hi ? (mine.dy + mine.dh) : row_hi;
+            reaches = x1 > x0 && y1 > y0;
+            lone = reaches && (x1 - x0) * (y1 - y0) > 64;
+        }
+    }
+    mask = __ballot(reaches);
+    const unsigned long long lones = __ballot(lone);
+    while (mask) {
+        uint32_t texel[kGroup];
+        int idx[kGroup], mod[kGroup];
+        bool stop = false;
+#pragma unroll
+        for (int g = 0; g < kGroup; g++) {
+            idx[g] = -1;
+            texel[g] = 0;
+            mod[g] = 255;
+            if (mask == 0 || stop) continue;
+            const int src = __builtin_ctzll(mask);
+            if ((lones >> src) & 1ull) {
+                stop = true;  // a rotated or big one: alone, only at the head of a group
+                if (g == 0) {
+                    mask &= mask - 1;
+                    const Blit b = blit_from_lane(mine, src);
+                    if (b.flip_mod & kRotated) {
+                        RotBox box = rot_box(b);
+                        const int lo = box.y_lo > row_lo ? box.y_lo : row_lo;
+                        const int hi = (box.y_lo + box.bh) < row_hi ? (box.y_lo + box.bh) : row_hi;
+                        box.y_lo = lo;
+                        box.bh = hi - lo;
+                        wave_blit_rotated(fb, atlas, b, box, lane, 64);
+                    } else {
+                        wave_blit(fb, atlas, b, lane, 0, 1, row_lo, row_hi);
+                    }
+                }
+                continue;
+            }
+            mask &= mask - 1;
+            const Blit b = blit_from_lane(mine, src);
+            const int x0 = b.dx > 0 ? b.dx : 0, y0 = b.dy > row_lo ? b.dy : row_lo;
+            const int x1 = (b.dx + b.dw) < kObsW ? (b.dx + b.dw) : kObsW;
+            const int y1 = (b.dy + b.dh) < row_hi ? (b.dy + b.dh) : row_hi;
+            const int cw = x1 - x0, ch = y1 - y0;
+            if (lane >= cw * ch) continue;
+            const int ry = udiv_small(lane, cw);
+            const int rx = lane - ry * cw;
+            const int x = x0 + rx, y = y0 + ry;
+            int i = x - b.dx, j = y - b.dy;
+            if (b.flip_mod & kFlipH) i = b.dw - 1 - i;
+            if (b.flip_mod & kFlipV) j = b.dh - 1 - j;
+            const int u = sample_index(b.sx, b.sw, i, b.dw);
+            const int v = sample_index(b.sy, b.sh, j, b.dh);
+            idx[g] = y * kObsW + x;
+            texel[g] = atlas.texels[b.tex_off + v * b.tex_w + u];
+            mod[g] = b.flip_mod & 0xff;
+        }
+#pragma unroll
+        for (int g = 0; g < kGroup; g++)
+            if (idx[g] >= 0) blend_into(fb, idx[g], texel[g], mod[g]);  // same wave, program order: draws may overlap
+    }
+}
+
+// The rows wave `half` of `halves` owns, and their share of the finished frame on its way out (no barrier needed
+// between a wave's last blend and its own store).
+PG_D void wave_store_rows(const uint32_t* fb, uint8_t* obs_env, int lane, int row_lo, int row_hi) {
+    Rgb4* out = reinterpret_cast<Rgb4*>(obs_env);
+    const uint4* in = reinterpret_cast<const uint4*>(fb);
+    for (int g = row_lo * (kObsW / 4) + lane; g < row_hi * (kObsW / 4); g += 64) {
+        const uint4 p = in[g];
+        Rgb4 o;
+        o.a = __builtin_amdgcn_perm(p.y, p.x, 0x04020100u);
+        o.b = __builtin_amdgcn_perm(p.z, p.y, 0x05040201u);
+        o.c = __builtin_amdgcn_perm(p.w, p.z, 0x06050402u);
+        __builtin_nontemporal_store(o.a, &out[g].a);
+        __builtin_nontemporal_store(o.b, &out[g].b);
+        __builtin_nontemporal_store(o.c, &out[g].c);
+    }
+}
+
 // SDL_RenderClear with (0,0,0,255): coinrun.cpp:447-448.
 PG_D void wave_clear(uint32_t* fb, int lane, int half = 0, int halves = 1) {
     uint4* p = reinterpret_cast<uint4*>(fb);
     for (int k = lane + 64 * half; k < kFbWords / 4; k += 64 * halves) p[k] = make_uint4(0, 0, 0, 0);
     __syncthreads();
+}
+
+// What a game that knows its textures passes as compose_spans' soft_init: the background's bit, and every grid row's
+// if some tile texture of the layer has texels that are not opaque (descriptor .w, set when the atlas is loaded).
+PG_D int32_t soft_rows_of(int bg_w, int tiles_w) {
+    return static_cast<int32_t>((bg_w ? 0x80000000u : 0u) | ((tiles_w & 1) ? 0x7fffffffu : 0u));
+}
+// … and as hard_init: where the one-texel-per-pixel attempt is not worth making (descriptor .w bit 1: many texels of
+// the texture are not opaque).
+PG_D int32_t hard_rows_of(int bg_w, int tiles_w) {
+    return static_cast<int32_t>(((bg_w & 2) ? 0x80000000u : 0u) | ((tiles_w & 2) ? 0x7fffffffu : 0u));
 }
 
 // Step 1 of the composer: the per-column / per-row span tables of the tile grid (lane c → column x0+c and row
@@ -481,15 +590,16 @@ PG_D void wave_clear(uint32_t* fb, int lane, int half = 0, int halves = 1) {
 template <int GRID, int MAXSPAN = kMaxSpan>
 PG_D void compose_spans(uint32_t* fb, ComposeLds<GRID>& L, const Camera& cam, int x0, int y0, int cols, int rows, int tw,
                         int th, float tile_scale, int lane, int th2 = 0, int half = 0, int halves = 1,
-                        bool exact_soft = false) {
+                        int32_t soft_init = -1, int32_t hard_init = -1) {
     ComposeTmp<GRID>& T = compose_tmp<GRID>(fb);
     if (half == 0) {
         T.cover_n[0][lane] = 0;
         T.cover_n[1][lane] = 0;
         if (lane == 0) {
             L.too_wide = 0;
-            L.soft_rows = exact_soft ? 0 : -1;
-            L.base[GRID * GRID] = static_cast<int32_t>(0x40000000u);  // kNoTexel (declared below)
+            L.soft_rows = soft_init;
+            L.hard_rows = hard_init;
+            L.base[GRID * GRID] = L.base[GRID * GRID + 1] = static_cast<int32_t>(0x40000000u);  // kNoTexel (declared below)
         }
     }
     __syncthreads();
@@ -651,12 +761,17 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
     }
     const int bg_mod = has_bg ? (bg.flip_mod & 0xff) : 255;
     // tile layer: per-lane column byte offsets and LDS column indices; per-row row byte offsets and LDS row bases
-    const uint32_t col_a = ca >= 0 ? static_cast<uint32_t>(ua) * 4u : kNoTexel;
-    const uint32_t col_b = cb >= 0 ? static_cast<uint32_t>(ub) * 4u : kNoTexel;
-    const int cia = ca >= 0 ? ca : 0, cib = cb >= 0 ? cb : 0;
+    uint32_t col_a = ca >= 0 ? static_cast<uint32_t>(ua) * 4u : kNoTexel;
+    uint32_t col_b = cb >= 0 ? static_cast<uint32_t>(ub) * 4u : kNoTexel;
+    if (PG_ABL(ablate, 1024)) {  // timing experiment: every lane of a tile samples texel column 0 (one cache line)
+        col_a = ca >= 0 ? 0u : kNoTexel;
+        col_b = cb >= 0 ? 0u : kNoTexel;
+    }
+    if (PG_ABL(ablate, 2048)) bg_col = bg_col == kNoTexel ? kNoTexel : static_cast<uint32_t>(bg.tex_off) * 4u;  // same for the background
+    const int cia = ca >= 0 ? ca : 0;
     const uint32_t row_a = ra >= 0 ? static_cast<uint32_t>(va * tw) * 4u : kNoTexel;
     const uint32_t row_b = rb >= 0 ? static_cast<uint32_t>(vb * tw) * 4u : kNoTexel;
-    const int ria = (ra >= 0 ? ra : 0) * GRID, rib = (rb >= 0 ? rb : 0) * GRID;
+    const int ria = (ra >= 0 ? ra : 0) * GRID;
     uint32_t row_a2 = kNoTexel, row_b2 = kNoTexel;  // lane = pixel row: texel rows of the second texture
     if (TWO) {
         if (ra >= 0) {
@@ -670,14 +785,14 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
             if (sp.w > 0 && i >= 0 && i < sp.y) row_b2 = static_cast<uint32_t>(sample_index(sp.z, sp.w, i, sp.y) * tw) * 4u;
         }
     }
-    if (__ballot((ra >= 0 && row_a >= (1u << 20)) || (rb >= 0 && row_b >= (1u << 20)))) return false;  // (packing below)
-    // Per pixel row (lane = row), one word per covering grid row: the texel row's byte offset (low 20 bits) and the
-    // index of the grid row's first cell in L.base (above) — one cross-lane read per row brings both into scalar
-    // registers.  A row that no grid row covers points at the sentinel cell behind the table, which holds kNoTexel.
-    static_assert(GRID * GRID + 1 < (1 << 11), "cell index field of the packed row word");
-    const uint32_t pack_a = ra >= 0 ? (row_a | (static_cast<uint32_t>(ria) << 20)) : (static_cast<uint32_t>(GRID * GRID) << 20);
-    const uint32_t pack_b = rb >= 0 ? (row_b | (static_cast<uint32_t>(rib) << 20)) : (static_cast<uint32_t>(GRID * GRID) << 20);
-    const uint32_t cia4 = static_cast<uint32_t>(cia) * 4u, cib4 = static_cast<uint32_t>(cib) * 4u;
+    // The two covering columns / rows of a pixel are neighbours in the grid (tiles only overlap the next one), so the
+    // cells of candidates (·, b) and (b, ·) sit one word / one table row behind those of (a, a): one LDS address per
+    // pixel row serves all four.  Anything else takes the fallback.
+    if (__ballot((cb >= 0 && cb != ca + 1) || (rb >= 0 && rb != ra + 1))) return false;
+    // Per pixel row (lane = row): byte address, inside the cell table, of grid row a's cells; a row that no grid row
+    // covers points at the two sentinel words behind the table, which hold kNoTexel.
+    const uint32_t cells_a = static_cast<uint32_t>(ra >= 0 ? ria : GRID * GRID) * 4u;
+    const uint32_t cia4 = static_cast<uint32_t>(cia) * 4u;
     // Wave-uniform row classes as 64-bit masks (bit py = pixel row py; every lane holds row `lane`'s values):
     //   second_row  two grid rows cover the row (the seam a tile's padding makes with the next tile);
     //   soft        a grid row covering the row shows a texture that has translucent texels (L.soft_rows; bit 31: the
@@ -687,11 +802,17 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
     const bool soft_here = (soft_bits >> 31) != 0 || (ra >= 0 && ((soft_bits >> (ra & 31)) & 1u)) ||
                            (rb >= 0 && ((soft_bits >> (rb & 31)) & 1u));  // (grids beyond 31 rows alias: conservative)
     const unsigned long long soft = __ballot(soft_here);
+    const uint32_t hard_bits = static_cast<uint32_t>(L.hard_rows);
+    const unsigned long long hard = __ballot((hard_bits >> 31) != 0 || (ra >= 0 && ((hard_bits >> (ra & 31)) & 1u)) ||
+                                             (rb >= 0 && ((hard_bits >> (rb & 31)) & 1u)));
     __syncthreads();  // everybody has read the set-up tables out of the frame target's memory: it may be written now
 
     // Rows in batches: every texel gather of a batch is issued before any pixel is produced, so a batch costs one
-    // memory round trip.  Candidates in draw order: background, (row a, col a), (row a, col b), (row b, col a),
-    // (row b, col b).
+    // memory round trip.  Candidates in draw order: background, (row a, col a), (row a, col b), then — on the rows
+    // two grid rows cover — (row b, col a), (row b, col b).
+    // This loop is written for the fewest instructions of ANY kind: the kernel issues about one instruction per
+    // SIMD issue slot whatever the mix (measured: scalar and vector instructions cost the same here), so one
+    // cross-lane read per row value beats a packed word that scalar code has to take apart.
 #ifndef PG_BATCH
 #define PG_BATCH 8
 #endif
@@ -701,37 +822,40 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
         __syncthreads();
         return true;
     }
-    const char* const cells = reinterpret_cast<const char*>(L.base);
-    // one tile texel: cell word (texture byte offset; with TWO bit 0 = second texture) + column offset, then the row
-    // offset of the cell's texture — wave-uniform unless TWO, where it depends on the cell
-    auto tile_texel = [&](uint32_t cell_at, uint32_t col, uint32_t row_first, uint32_t row_second) {
-        const uint32_t cell = *reinterpret_cast<const uint32_t*>(cells + cell_at);
-        if (TWO) {
+    const char* const cells = reinterpret_cast<const char*>(L.base) + cia4;  // per lane: its column a (b = next word)
+    auto texel_of = [&](uint32_t cell, uint32_t col, uint32_t row_first, uint32_t row_second) {
+        if (TWO) {  // the cell says which of the layer's two textures it shows (bit 0): its row offset is per lane
             const uint32_t row = (cell & 1u) ? row_second : row_first;
             return __builtin_amdgcn_raw_buffer_load_b32(atlas_rsrc, (cell & ~3u) + col + row, 0, 0);
         }
         return __builtin_amdgcn_raw_buffer_load_b32(atlas_rsrc, cell + col, row_first, 0);
     };
-    const int py_begin = half * (kObsH / halves), py_end = py_begin + kObsH / halves;
-    for (int py0 = py_begin; py0 < py_end; py0 += kBatch) {
-        uint32_t t[kBatch][5];
+    // The general form of one batch of rows: every candidate of every pixel is fetched, then resolved.
+    auto general_batch = [&](int py0) {
+        uint32_t t[kBatch][3], u[kBatch][2];
         const uint32_t seconds = static_cast<uint32_t>(second_row >> py0) & 0xffu;
 #pragma unroll
         for (int k = 0; k < kBatch; k++) {
             const int py = py0 + k;
             const uint32_t s_bg = __builtin_amdgcn_readlane(bg_row, py);
-            const uint32_t pa = __builtin_amdgcn_readlane(pack_a, py);
-            const uint32_t s_a = pa & 0xfffffu, l_a4 = (pa >> 20) * 4u;
-            t[k][0] = __builtin_amdgcn_raw_buffer_load_b32(bg_rsrc, bg_col, s_bg, 0);
+            const uint32_t s_a = __builtin_amdgcn_readlane(row_a, py);
+            const uint32_t* cp = reinterpret_cast<const uint32_t*>(cells + __builtin_amdgcn_readlane(cells_a, py));
             const uint32_t s_a2 = TWO ? __builtin_amdgcn_readlane(row_a2, py) : 0u;
-            t[k][1] = tile_texel(l_a4 + cia4, col_a, s_a, s_a2);
-            t[k][2] = tile_texel(l_a4 + cib4, col_b, s_a, s_a2);
-            if (seconds & (1u << k)) {
-                const uint32_t pb = __builtin_amdgcn_readlane(pack_b, py);
-                const uint32_t s_b = pb & 0xfffffu, l_b4 = (pb >> 20) * 4u;
-                const uint32_t s_b2 = TWO ? __builtin_amdgcn_readlane(row_b2, py) : 0u;
-                t[k][3] = tile_texel(l_b4 + cia4, col_a, s_b, s_b2);
-                t[k][4] = tile_texel(l_b4 + cib4, col_b, s_b, s_b2);
+            t[k][0] = __builtin_amdgcn_raw_buffer_load_b32(bg_rsrc, bg_col, s_bg, 0);
+            t[k][1] = texel_of(cp[0], col_a, s_a, s_a2);
+            t[k][2] = texel_of(cp[1], col_b, s_a, s_a2);
+        }
+        if (seconds) {
+#pragma unroll
+            for (int k = 0; k < kBatch; k++) {
+                if (seconds & (1u << k)) {
+                    const int py = py0 + k;
+                    const uint32_t s_b = __builtin_amdgcn_readlane(row_b, py);
+                    const uint32_t* cp = reinterpret_cast<const uint32_t*>(cells + __builtin_amdgcn_readlane(cells_a, py));
+                    const uint32_t s_b2 = TWO ? __builtin_amdgcn_readlane(row_b2, py) : 0u;
+                    u[k][0] = texel_of(cp[GRID], col_a, s_b, s_b2);
+                    u[k][1] = texel_of(cp[GRID + 1], col_b, s_b, s_b2);
+                }
             }
         }
         // Does the batch hold a translucent texel (alpha not in {0, 255})?  Asked only when one of its rows shows a
@@ -742,7 +866,7 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
 #pragma unroll
             for (int k = 0; k < kBatch; k++) {
                 translucent |= (((t[k][0] >> 24) + 1u) | ((t[k][1] >> 24) + 1u) | ((t[k][2] >> 24) + 1u)) & 0xFEu;
-                if (seconds & (1u << k)) translucent |= (((t[k][3] >> 24) + 1u) | ((t[k][4] >> 24) + 1u)) & 0xFEu;
+                if (seconds & (1u << k)) translucent |= (((u[k][0] >> 24) + 1u) | ((u[k][1] >> 24) + 1u)) & 0xFEu;
             }
             blend = __ballot(translucent != 0) != 0;
         }
@@ -751,16 +875,20 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
             // An absent or fully transparent texel is the word 0 (the atlas loader clears the colour of alpha-0
             // texels); an opaque one has 0xFF on top.  Masking the top byte down to the candidate's rank in draw
             // order turns "last drawn non-empty" into a plain unsigned maximum.  The rank stays in the target's top
-            // byte, which nothing reads (blend_px, wave_store_obs).
+            // byte, which nothing reads (blend_px, wave_store_rows).
+            uint32_t pix[kBatch];
 #pragma unroll
-            for (int k = 0; k < kBatch; k++) {
-                uint32_t pix = max3_u32(t[k][0] & 0x00ffffffu, t[k][1] & 0x01ffffffu, t[k][2] & 0x02ffffffu);
-                if (seconds & (1u << k)) {  // wave-uniform: a real branch (the empty asm keeps it from becoming a select)
-                    pix = max3_u32(pix, t[k][3] & 0x03ffffffu, t[k][4] & 0x04ffffffu);
-                    asm volatile("" : "+v"(pix));
-                }
-                fb[(py0 + k) * kObsW + lane] = pix;
+            for (int k = 0; k < kBatch; k++) pix[k] = max3_u32(t[k][0] & 0x00ffffffu, t[k][1] & 0x01ffffffu, t[k][2] & 0x02ffffffu);
+            if (seconds) {
+#pragma unroll
+                for (int k = 0; k < kBatch; k++)
+                    if (seconds & (1u << k)) {  // wave-uniform: a real branch (the empty asm keeps it from becoming a select)
+                        pix[k] = max3_u32(pix[k], u[k][0] & 0x03ffffffu, u[k][1] & 0x04ffffffu);
+                        asm volatile("" : "+v"(pix[k]));
+                    }
             }
+#pragma unroll
+            for (int k = 0; k < kBatch; k++) fb[(py0 + k) * kObsW + lane] = pix[k];
         } else {
 #pragma unroll
             for (int k = 0; k < kBatch; k++) {
@@ -771,11 +899,64 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
                 pix = blend_px(pix, t[k][1], static_cast<int>(t[k][1] >> 24));
                 pix = blend_px(pix, t[k][2], static_cast<int>(t[k][2] >> 24));
                 if (seconds & (1u << k)) {
-                    pix = blend_px(pix, t[k][3], static_cast<int>(t[k][3] >> 24));
-                    pix = blend_px(pix, t[k][4], static_cast<int>(t[k][4] >> 24));
+                    pix = blend_px(pix, u[k][0], static_cast<int>(u[k][0] >> 24));
+                    pix = blend_px(pix, u[k][1], static_cast<int>(u[k][1] >> 24));
                 }
                 fb[(py0 + k) * kObsW + lane] = pix;
             }
+        }
+    };
+
+    // The vector memory pipe takes a wavefront's 64 scattered dwords four lanes a clock — 16 clocks a gather, whatever
+    // it hits — and at five gathers a row that pipe, not the ALUs, is what this kernel saturates.  So a batch first
+    // fetches ONE texel per pixel: the candidate drawn LAST among those that exist there (a cell that holds a tile,
+    // else the background).  If every texel it gets is opaque that is the picture — nothing below can show — and the
+    // common frame (solid ground, walls, opaque backdrops) needs one gather per row instead of three to five.  Any
+    // texel that is not opaque (a crate's rounded corner, lava's surface, a cut-out backdrop, no candidate at all)
+    // sends the whole batch through the general form above, which gives the same pixels by construction.
+    auto tile_at = [&](uint32_t cell, uint32_t col, uint32_t row_first, uint32_t row_second) {  // ≥ kNoTexel: none
+        if (TWO) return (cell & ~3u) + col + ((cell & 1u) ? row_second : row_first);
+        return cell + col + row_first;
+    };
+    const int py_begin = half * (kObsH / halves), py_end = py_begin + kObsH / halves;
+    for (int py0 = py_begin; py0 < py_end; py0 += kBatch) {
+        if (bg_mod != 255 || (static_cast<uint32_t>(hard >> py0) & 0xffu) != 0u) {  // too much that is not opaque in sight
+            general_batch(py0);
+            continue;
+        }
+        const uint32_t seconds = static_cast<uint32_t>(second_row >> py0) & 0xffu;
+        uint32_t top[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) {
+            const int py = py0 + k;
+            const uint32_t s_bg = __builtin_amdgcn_readlane(bg_row, py);
+            const uint32_t s_a = __builtin_amdgcn_readlane(row_a, py);
+            const uint32_t* cp = reinterpret_cast<const uint32_t*>(cells + __builtin_amdgcn_readlane(cells_a, py));
+            const uint32_t s_a2 = TWO ? __builtin_amdgcn_readlane(row_a2, py) : 0u;
+            uint32_t at = bg_col + s_bg;  // draw order: background, (a, a), (a, b), (b, a), (b, b) — the last one there wins
+            uint32_t x = tile_at(cp[0], col_a, s_a, s_a2);
+            at = x < kNoTexel ? x : at;
+            x = tile_at(cp[1], col_b, s_a, s_a2);
+            at = x < kNoTexel ? x : at;
+            if (seconds & (1u << k)) {  // wave-uniform
+                const uint32_t s_b = __builtin_amdgcn_readlane(row_b, py);
+                const uint32_t s_b2 = TWO ? __builtin_amdgcn_readlane(row_b2, py) : 0u;
+                x = tile_at(cp[GRID], col_a, s_b, s_b2);
+                at = x < kNoTexel ? x : at;
+                x = tile_at(cp[GRID + 1], col_b, s_b, s_b2);
+                at = x < kNoTexel ? x : at;
+                asm volatile("" : "+v"(at));  // keeps the branch a branch
+            }
+            top[k] = __builtin_amdgcn_raw_buffer_load_b32(atlas_rsrc, at, 0, 0);
+        }
+        uint32_t least = top[0];
+#pragma unroll
+        for (int k = 1; k < kBatch; k++) least = least < top[k] ? least : top[k];
+        if (__ballot(least < 0xff000000u) == 0 && !PG_ABL(ablate, 4096)) {
+#pragma unroll
+            for (int k = 0; k < kBatch; k++) fb[(py0 + k) * kObsW + lane] = top[k];
+        } else {
+            general_batch(py0);
         }
     }
     __syncthreads();

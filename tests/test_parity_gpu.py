@@ -703,3 +703,75 @@ def test_cenv_abi_batched_maze_64_envs_through_the_timeout():
     assert ends >= n
     env.close()
     ora.close()
+
+
+def test_bossfight_step_and_reset_after_a_non_square_human_frame():
+    """D15 (bossfight.cpp:434,458, common_systems.cpp:227-228,513-514): reset() and both update()s read the camera size
+    and scale the LAST render left in the global renderer.  After a human-size cenv_render of a non-square window the
+    next step clamps against another screen rectangle and the next reset spawns the agent and the barriers on another
+    row; the observation render that follows puts 64×64 back.  Vector path (pgv_render_frame of single envs) and the
+    drop-in cenv path, against the oracle doing the same calls."""
+    from oracle_util import register_textures
+    register_textures("bossfight")
+    L = oracle()
+    n, W, H = 8, 200, 120
+    eng = EngineVec("bossfight", n, seed_base=9)
+    hs = [L.pgo_make(b"bossfight", 9 + i, 1) for i in range(n)]
+    for h in hs:
+        L.pgo_reset(h, 0, 0)
+    assert np.array_equal(eng.reset(), np.stack([np.ctypeslib.as_array(L.pgo_obs(h), shape=(12288,)) for h in hs]))
+    want = np.zeros((H, W, 3), np.uint8)
+    pending = [False] * n
+    for s in range(140):
+        if s % 9 == 4:  # a human frame of two envs between steps; env 3 is also reset right after its frame
+            for env in (1, 3):
+                L.pgo_render_frame(hs[env], W, H, want.ctypes.data_as(ctypes.c_void_p))
+                assert np.array_equal(eng.frame(env, W, H), want), (s, env)
+            if s % 18 == 4:
+                mask = np.zeros(n, np.uint8)
+                mask[3] = 1
+                o = eng.reset(mask=mask)
+                L.pgo_reset(hs[3], 0, 0)
+                pending[3] = False
+                assert np.array_equal(o[3], np.ctypeslib.as_array(L.pgo_obs(hs[3]), shape=(12288,))), s
+                assert np.array_equal(eng.state(3, 400).view(np.uint32), _oracle_state(L, hs[3], 400).view(np.uint32)), s
+        a = np.where(np.arange(n) % 2 == 0, 9, _actions(L, 3, s, n)).astype(np.int32)
+        oe, re_, de = eng.step(a)
+        for i, h in enumerate(hs):
+            if pending[i]:
+                L.pgo_reset(h, 0, 0)
+                pending[i] = False
+                assert re_[i] == 0.0 and de[i] == 0
+            else:
+                L.pgo_step(h, int(a[i]))
+                pending[i] = bool(L.pgo_terminated(h))
+                assert re_[i] == np.float32(L.pgo_reward(h)) and de[i] == int(L.pgo_terminated(h)), (s, i)
+            assert np.array_equal(oe[i], np.ctypeslib.as_array(L.pgo_obs(h), shape=(12288,))), (s, i)
+    for h in hs:
+        L.pgo_close(h)
+    eng.close()
+    # the drop-in path: CEnv with a 200×120 window, render() then reset()
+    env = pgcenv.CEnv(os.path.join(pglib.LIB_DIR, "libBossFight.so"), options={"seed": 5, "width": W, "height": H})
+    h = L.pgo_make(b"bossfight", 5, 1)
+    L.pgo_reset(h, 0, 0)
+    obs, _ = env.reset()
+    assert np.array_equal(obs["screen"], np.ctypeslib.as_array(L.pgo_obs(h), shape=(12288,)))
+    for k in range(12):
+        obs, rew, term, _, _ = env.step(9 if k % 2 else 7)
+        L.pgo_step(h, 9 if k % 2 else 7)
+        if k % 4 == 1:
+            frame = env.render()
+            L.pgo_render_frame(h, W, H, want.ctypes.data_as(ctypes.c_void_p))
+            assert frame.shape == (H, W, 3) and np.array_equal(frame, want)
+        if k == 5:  # render() was the last thing that touched the camera: this reset sees the window's
+            obs, _ = env.reset()
+            L.pgo_reset(h, 0, 0)
+        assert np.array_equal(obs["screen"], np.ctypeslib.as_array(L.pgo_obs(h), shape=(12288,))), k
+    env.close()
+    L.pgo_close(h)
+
+
+def _oracle_state(L, h, cap):
+    buf = (ctypes.c_float * cap)()
+    m = L.pgo_dump_state(h, buf, cap)
+    return np.array(buf[:min(m, cap)], np.float32)

@@ -6,7 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from engine_util import EngineVec  # noqa: E402
 LIB = os.path.join(ROOT, "procgen2_amd", "lib", "libprocgen2_hip_ablate.so")
-for flags, name in ((0, "full"), (512, "rows never blend"), (128, "no row loop"), (128 + 2, "no rows/sprites"),
+for flags, name in ((0, "full"), (1024, "tile cols -> one line"), (2048, "bg cols -> one line"), (3072, "both -> one line"),
+                    (512, "rows never blend"), (128, "no row loop"), (128 + 2, "no rows/sprites"),
                     (128 + 2 + 8, "no rows/spr/store"), (4 + 2 + 8, "nothing")):
     e = EngineVec("coinrun", 65536, seed_base=1, lib_path=LIB)
     e.reset()

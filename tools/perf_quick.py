@@ -22,12 +22,13 @@ ap.add_argument("--settle", type=int, default=400)
 ap.add_argument("--steps", type=int, default=128)
 ap.add_argument("--check", default="128x160", help="ENVSxSTEPS of the lock-step, 0x0 to skip")
 ap.add_argument("--envs", type=int, default=65536)
+ap.add_argument("--lib", default=None, help="another build of the engine (e.g. lib/libprocgen2_hip_ablate.so)")
 a = ap.parse_args()
 cn, cs = (int(v) for v in a.check.split("x"))
 for game in a.games.split(","):
     status = "unchecked"
     if cn and cs:
-        eng, ora = EngineVec(game, cn, seed_base=3), OracleVec(game, cn, seed_base=3)
+        eng, ora = EngineVec(game, cn, seed_base=3, lib_path=a.lib), OracleVec(game, cn, seed_base=3)
         ok = np.array_equal(eng.reset(), ora.reset_obs())
         idx = np.arange(cn)
         for s in range(cs):
@@ -44,7 +45,7 @@ for game in a.games.split(","):
             status = "bit-exact %dx%d" % (cn, cs)
         eng.close()
         ora.close()
-    e = EngineVec(game, a.envs, seed_base=1)
+    e = EngineVec(game, a.envs, seed_base=1, lib_path=a.lib)
     e.reset()
     e.timed(a.settle)
     tot, ren = e.timed(a.steps)
