@@ -634,7 +634,7 @@ __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actio
 }
 
 // render_game(true) (bossfight.cpp:401-424): one workgroup of two wavefronts per env (pg_render.h).
-__global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
+__global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
                                                     int flags) {
     const int env = blockIdx.x;
     if (mask && !mask[env]) return;
@@ -654,21 +654,23 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
     const float bx = SF(s, F_BX, env), by = SF(s, F_BY, env), ax = SF(s, F_AX, env), ay = SF(s, F_AY, env);
     Blit mine;
 
-    Blit bg;  // bossfight.cpp:416-419
-    bool has_bg;
+    int4 bg_d;  // the background draw, bossfight.cpp:416-419: texture, world position, scale — each wave resolves the axis it needs (pg_render.h BgAxis)
+    float bg_px, bg_py, bg_sc;
     {
         const int4 d = descs.uniform(kTexSpace + backdrop);
-        has_bg = resolve_draw(cam, d.y, d.z, d.x, -kCamSize / kCamScale * 0.5f, -kCamSize / kCamScale * 0.5f,
-                              1.0f / d.z * kCamSize / kCamScale, 1.0f, false, false, bg);
+        bg_d = d;
+        bg_px = -kCamSize / kCamScale * 0.5f;
+        bg_py = -kCamSize / kCamScale * 0.5f;
+        bg_sc = 1.0f / d.z * kCamSize / kCamScale;
     }
     bool composed = false;
     if (!(flags & 1)) {  // no tile layer in this game: the background over black (pg_render.h)
-        compose_background(fb, atlas, bg, has_bg, lane, half, halves);
+        compose_background(fb, atlas, bg_axis(cam, bg_d, bg_px, bg_py, bg_sc, half), lane, half, halves);
         composed = true;
     }
     if (!composed) {
         wave_clear(fb, lane, half, halves);
-        mine = bg;
+        const bool has_bg = resolve_draw(cam, bg_d.y, bg_d.z, bg_d.x, bg_px, bg_py, bg_sc, 1.0f, false, false, mine);
         wave_replay(fb, atlas, mine, has_bg ? 1ull : 0ull, lane, half, halves);
     }
 

@@ -592,7 +592,7 @@ __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actio
 
 
 // render_game(true) (caveflyer.cpp:413-440): one workgroup of two wavefronts per env (pg_render.h).
-__global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
+__global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
                                                     int flags) {
     const int env = blockIdx.x;
     if (mask && !mask[env]) return;
@@ -642,15 +642,17 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
     }
 
     int bg_soft = 0;  // the backdrop has texels that are not opaque (descriptor .w)
-    Blit bg;  // caveflyer.cpp:427-432
-    bool has_bg;
+    int4 bg_d;  // the background draw, caveflyer.cpp:427-432: texture, world position, scale — each wave resolves the axis it needs (pg_render.h BgAxis)
+    float bg_px, bg_py, bg_sc;
     {
         const int4 d = descs.uniform(kTexSpace + SI(s, I_BACKDROP, env));
         bg_soft = d.w;
         const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
         const float extra = aspect - 1.0f;
-        has_bg = resolve_draw(cam, d.y, d.z, d.x, -SF(s, F_BGSHIFT, env) * extra, 0.0f, 64.0f * kUnitPx / d.z, 1.0f,
-                              false, false, bg);
+        bg_d = d;
+        bg_px = -SF(s, F_BGSHIFT, env) * extra;
+        bg_py = 0.0f;
+        bg_sc = 64.0f * kUnitPx / d.z;
     }
     // tile window (tilemap.cpp:280-289)
     const float vx = (cam.px - cam.sw * 0.5f / cam.scale) * kPxUnit;
@@ -661,6 +663,7 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
     const int cols = x1 - x0 + 1, rows = y1 - y0 + 1, cells = cols * rows;
     const int4 wall_d = descs.uniform(kTexWall);
 
+    const BgAxis bga = bg_axis(cam, bg_d, bg_px, bg_py, bg_sc, half);  // wave 0: x axis, wave 1: y axis
     bool composed = false;
     if (!(flags & 1) && cols <= kGrid && rows <= kGrid) {
         compose_spans<kGrid, 16>(fb, L, cam, x0, y0, cols, rows, wall_d.y, wall_d.z, kUnitPx / wall_d.y, lane, 0, half, halves,
@@ -673,11 +676,11 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
             L.base[cell] = (t == kEmpty) ? static_cast<int32_t>(kNoTexel) : wall_d.x * 4;
         }
         __syncthreads();
-        composed = compose_rows(fb, L, atlas, bg, has_bg, cols, rows, wall_d.y, lane, flags, half, halves);
+        composed = compose_rows(fb, L, atlas, bga, cols, rows, wall_d.y, lane, flags, half, halves);
     }
     if (!composed) {  // draw-list replay (tilemap.cpp:291-302)
         wave_clear(fb, lane, half, halves);
-        mine = bg;
+        const bool has_bg = resolve_draw(cam, bg_d.y, bg_d.z, bg_d.x, bg_px, bg_py, bg_sc, 1.0f, false, false, mine);
         wave_replay(fb, atlas, mine, has_bg ? 1ull : 0ull, lane, half, halves);
         for (int base = 0; base < cells; base += 64) {
             const int cell = base + lane;

@@ -820,7 +820,7 @@ __global__ void __launch_bounds__(64) resolve_kernel(State s, StepIO io) {
 // Higher bits are timing experiments (tools/ablate_render.py), compiled in only with -DPG_ABLATE (pg_render.h PG_ABL).
 constexpr int kRenderWaves = 2;  // wavefronts per env (pg_render.h: two waves share one frame's LDS target)
 
-__global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, AtlasView atlas, const uint8_t* mask,
+__global__ void __launch_bounds__(64 * kRenderWaves, 4) render_kernel(State s, AtlasView atlas, const uint8_t* mask,
                                                                    StepIO io, int flags) {
     const int env = blockIdx.x;
     if (mask && !mask[env]) return;
@@ -903,16 +903,17 @@ __global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, Atla
     }
 
     // background (coinrun.cpp:459-464)
-    Blit bg;
-    bool has_bg;
-    int4 bg_d;
+    int4 bg_d;  // the background draw: texture, world position, scale — each wave resolves the axis it needs (pg_render.h BgAxis)
+    float bg_px, bg_py, bg_sc;
     {
         const int4 d = descs.uniform(kTexBackdrop + backdrop);
         bg_d = d;
         const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
         const float extra = aspect - 1.0f;
-        has_bg = resolve_draw(cam, d.y, d.z, d.x, -SF(s, F_BGSHIFT, env) * extra, 0.0f, 64.0f * kUnitPx / d.z, 1.0f,
-                              false, false, bg);
+        bg_d = d;
+        bg_px = -SF(s, F_BGSHIFT, env) * extra;
+        bg_py = 0.0f;
+        bg_sc = 64.0f * kUnitPx / d.z;
     }
     // negative-z sprites: none — every coinrun sprite has z = 1 (tilemap.cpp:63,88,283)
 
@@ -925,6 +926,7 @@ __global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, Atla
     const int cols = x1 - x0 + 1, rows = y1 - y0 + 1, cells = cols * rows;
     const int4 tile_desc = descs.uniform(kTexMid);  // every tile texture is 128×128 (checked at make time)
 
+    const BgAxis bga = bg_axis(cam, bg_d, bg_px, bg_py, bg_sc, half);  // wave 0: x axis, wave 1: y axis
     bool composed = false;
     if (!(flags & 1) && !PG_ABL(flags, 4) && cols <= kGrid && rows <= kGrid) {
         compose_spans(fb, L, cam, x0, y0, cols, rows, tile_desc.y, tile_desc.z, kUnitPx / tile_desc.y, lane, 0, half, halves,
@@ -960,12 +962,12 @@ __global__ void __launch_bounds__(64 * kRenderWaves) render_kernel(State s, Atla
         if (soft_rows) atomicOr(&L.soft_rows, static_cast<int32_t>(soft_rows));
         if (hard_rows) atomicOr(&L.hard_rows, static_cast<int32_t>(hard_rows));
         __syncthreads();
-        composed = compose_rows(fb, L, atlas, bg, has_bg, cols, rows, tile_desc.y, lane, flags, half, halves);
+        composed = compose_rows(fb, L, atlas, bga, cols, rows, tile_desc.y, lane, flags, half, halves);
     }
     if (PG_ABL(flags, 4)) composed = true;  // (bit 2: timing experiment — no background/tiles at all)
     if (!composed) {  // draw-list replay of background and tiles (tilemap.cpp:294-321)
         wave_clear(fb, lane, half, halves);
-        mine = bg;
+        const bool has_bg = resolve_draw(cam, bg_d.y, bg_d.z, bg_d.x, bg_px, bg_py, bg_sc, 1.0f, false, false, mine);
         wave_replay(fb, atlas, mine, has_bg ? 1ull : 0ull, lane, half, halves);
         for (int base = 0; base < cells; base += 64) {
             const int cell = base + lane;

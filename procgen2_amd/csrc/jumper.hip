@@ -545,7 +545,7 @@ __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actio
 }
 
 // render_game(true) (jumper.cpp:445-509): one workgroup of two wavefronts per env (pg_render.h).
-__global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
+__global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
                                                     int flags) {
     const int env = blockIdx.x;
     if (mask && !mask[env]) return;
@@ -572,15 +572,17 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
     }
 
     int bg_soft = 0;  // the backdrop has texels that are not opaque (descriptor .w)
-    Blit bg;  // jumper.cpp:459-464
-    bool has_bg;
+    int4 bg_d;  // the background draw, jumper.cpp:459-464: texture, world position, scale — each wave resolves the axis it needs (pg_render.h BgAxis)
+    float bg_px, bg_py, bg_sc;
     {
         const int4 d = descs.uniform(kTexBackdrop + backdrop);
         bg_soft = d.w;
         const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
         const float extra = aspect - 1.0f;
-        has_bg = resolve_draw(cam, d.y, d.z, d.x, -SF(s, F_BGSHIFT, env) * extra, 0.0f, 64.0f * kUnitPx / d.z, 1.0f,
-                              false, false, bg);
+        bg_d = d;
+        bg_px = -SF(s, F_BGSHIFT, env) * extra;
+        bg_py = 0.0f;
+        bg_sc = 64.0f * kUnitPx / d.z;
     }
     // tile window (tilemap.cpp:255-264)
     const float vx = (cam.px - cam.sw * 0.5f / cam.scale) * kPxUnit;
@@ -591,6 +593,7 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
     const int cols = x1 - x0 + 1, rows = y1 - y0 + 1, cells = cols * rows;
     const int4 top_d = descs.uniform(kTexTop + theme), mid_d = descs.uniform(kTexMid + theme);
 
+    const BgAxis bga = bg_axis(cam, bg_d, bg_px, bg_py, bg_sc, half);  // wave 0: x axis, wave 1: y axis
     bool composed = false;
     const bool two = top_d.z != mid_d.z;  // the brown cap tile is 64×53 (see climber.hip)
     if (!(flags & 1) && cols <= kGrid && rows <= kGrid && top_d.y == mid_d.y && top_d.z <= mid_d.z) {
@@ -605,12 +608,12 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
                                        : (t == kWallTop ? (top_d.x * 4) | (two ? 1 : 0) : mid_d.x * 4);
         }
         __syncthreads();
-        composed = two ? compose_rows<kGrid, true>(fb, L, atlas, bg, has_bg, cols, rows, mid_d.y, lane, flags, half, halves)
-                       : compose_rows<kGrid, false>(fb, L, atlas, bg, has_bg, cols, rows, mid_d.y, lane, flags, half, halves);
+        composed = two ? compose_rows<kGrid, true>(fb, L, atlas, bga, cols, rows, mid_d.y, lane, flags, half, halves)
+                       : compose_rows<kGrid, false>(fb, L, atlas, bga, cols, rows, mid_d.y, lane, flags, half, halves);
     }
     if (!composed) {  // draw-list replay (tilemap.cpp:266-280)
         wave_clear(fb, lane, half, halves);
-        mine = bg;
+        const bool has_bg = resolve_draw(cam, bg_d.y, bg_d.z, bg_d.x, bg_px, bg_py, bg_sc, 1.0f, false, false, mine);
         wave_replay(fb, atlas, mine, has_bg ? 1ull : 0ull, lane, half, halves);
         for (int base = 0; base < cells; base += 64) {
             const int cell = base + lane;

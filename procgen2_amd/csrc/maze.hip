@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actio
 }
 
 // flags bit 0: force the draw-list replay for background + walls (fallback path).
-__global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
+__global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
                                                     int flags) {
     const int env = blockIdx.x;
     if (mask && !mask[env]) return;
@@ -228,15 +228,17 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
     Blit mine;
 
     int bg_soft = 0;  // the backdrop has texels that are not opaque (descriptor .w)
-    Blit bg;  // background (maze.cpp:402-408)
-    bool has_bg;
+    int4 bg_d;  // the background draw, background (maze.cpp:402-408): texture, world position, scale — each wave resolves the axis it needs (pg_render.h BgAxis)
+    float bg_px, bg_py, bg_sc;
     {
         const int4 d = atlas.desc[kTexFloor + SI(s, I_BG, env)];
         bg_soft = d.w;
         const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
         const float extra = aspect - 1.0f;
-        has_bg = resolve_draw(cam, d.y, d.z, d.x, -SF(s, F_BGSHIFT, env) * extra, 0.0f, 64.0f * kUnitPx / d.z, 1.0f,
-                              false, false, bg);
+        bg_d = d;
+        bg_px = -SF(s, F_BGSHIFT, env) * extra;
+        bg_py = 0.0f;
+        bg_sc = 64.0f * kUnitPx / d.z;
     }
     // wall window (tilemap.cpp:111-121)
     const float vx = (cam.px - cam.sw * 0.5f / cam.scale) * kPxUnit;
@@ -247,6 +249,7 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
     const int cols = x1 - x0 + 1, rows = y1 - y0 + 1, cells = cols * rows;
     const int4 wall = atlas.desc[kTexWall];
 
+    const BgAxis bga = bg_axis(cam, bg_d, bg_px, bg_py, bg_sc, half);  // wave 0: x axis, wave 1: y axis
     bool composed = false;
     if (!(flags & 1) && cols <= kGrid && rows <= kGrid) {
         constexpr int kSpan = 64 / kVisible + 2 <= kMaxSpan ? kMaxSpan : 16;  // pixels a tile covers (+ seam padding)
@@ -258,11 +261,11 @@ __global__ void __launch_bounds__(128) render_kernel(State s, AtlasView atlas, c
                 tile_at(tiles, x0 + c, H - 1 - (y0 + r)) == kOpen ? static_cast<int32_t>(kNoTexel) : wall.x * 4;
         }
         __syncthreads();
-        composed = compose_rows(fb, L, atlas, bg, has_bg, cols, rows, wall.y, lane, flags, half, halves);
+        composed = compose_rows(fb, L, atlas, bga, cols, rows, wall.y, lane, flags, half, halves);
     }
     if (!composed) {  // draw-list replay (tilemap.cpp:111-133)
         wave_clear(fb, lane, half, halves);
-        mine = bg;
+        const bool has_bg = resolve_draw(cam, bg_d.y, bg_d.z, bg_d.x, bg_px, bg_py, bg_sc, 1.0f, false, false, mine);
         wave_replay(fb, atlas, mine, has_bg ? 1ull : 0ull, lane, half, halves);
         for (int base = 0; base < cells; base += 64) {
             const int cell = base + lane;

@@ -67,10 +67,23 @@ struct ComposeTmp {
     int32_t cover_n[2][64];   // [axis][pixel] how many grid columns (axis 0) / rows (axis 1) cover the pixel
     int32_t cover[2][64][2];  // the first two of them: grid index | texel coordinate << 8
 };
+// What the two waves hand each other before the first pixel is written (behind ComposeTmp, in the same borrowed memory).
+struct ComposeHand {
+    uint4 col[64];       // per pixel column (by wave 0): background column offset, column offsets a / b, 4 × cell column a
+    uint4 row[64];       // per pixel row (by wave 1): background row offset, row offsets a / b, byte offset of grid row a's cells
+    uint2 row2[64];      // … and the row offsets in the layer's second texture (compose_rows<GRID, true>)
+    uint32_t masks[6];   // second_row, soft, hard (64 bits each)
+    int32_t bad;         // either side found something the two-candidate scheme does not cover → fallback
+};
 template <int GRID>
 PG_D ComposeTmp<GRID>& compose_tmp(uint32_t* fb) {
-    static_assert(sizeof(ComposeTmp<GRID>) <= 64 * 64 * 4, "the set-up tables borrow the frame target's memory");
+    static_assert(sizeof(ComposeTmp<GRID>) % 16 == 0 && sizeof(ComposeTmp<GRID>) + sizeof(ComposeHand) <= 64 * 64 * 4,
+                  "the set-up tables borrow the frame target's memory");
     return *reinterpret_cast<ComposeTmp<GRID>*>(fb);
+}
+template <int GRID>
+PG_D ComposeHand& compose_hand(uint32_t* fb) {
+    return *reinterpret_cast<ComposeHand*>(reinterpret_cast<char*>(fb) + sizeof(ComposeTmp<GRID>));
 }
 constexpr int kMaxSpan = 8;  // default bound on the pixels one tile covers per axis (coinrun 5–6, maze 3); caveflyer passes 16
 
@@ -471,10 +484,11 @@ PG_D void wave_replay(uint32_t* fb, const AtlasView& atlas, const Blit& mine, un
 // stores them.  Nothing one wave writes is read by the other, so there is no barrier between draws (wave_replay above
 // hands whole draws to the waves in turn and meets at a barrier after each one) and the waves drift apart freely; a
 // draw that straddles row 32 is simply done by both, each on its own rows.  Same grouping as wave_replay: small
-// draws (≤ 64 pixels on my rows) four at a time per memory round trip, rotated or larger ones alone.
+// draws (≤ 64 pixels on my rows) kGroup at a time per memory round trip — the sprite pass is a chain of dependent
+// round trips, and its length, not its instruction count, is what it costs — rotated or larger ones alone.
+template <int kGroup = 4>
 PG_D void wave_replay_rows(uint32_t* fb, const AtlasView& atlas, const Blit& mine, unsigned long long mask, int lane,
                            int row_lo, int row_hi) {
-    constexpr int kGroup = 4;
     bool lone = false, reaches = false;
     if ((mask >> lane) & 1ull) {
         if (mine.flip_mod & kRotated) {
@@ -569,6 +583,29 @@ PG_D void wave_clear(uint32_t* fb, int lane, int half = 0, int halves = 1) {
     __syncthreads();
 }
 
+// One axis of the background draw (Renderer::render_texture is separable, pg_geom.h resolve_axis).  The two wavefronts
+// of a frame split the composer's set-up: wave 0 works out everything that belongs to pixel COLUMNS (and resolves the
+// background's x axis for it), wave 1 everything that belongs to pixel ROWS (y axis), and they trade the results
+// through the frame target's still unused memory (ComposeHand) — instead of both doing both.  A background that one
+// axis culls or empties needs no flag: that axis hands out kNoTexel offsets, and column + row offset is then out of
+// the atlas.  Every game draws its background unflipped and with alpha 1 (e.g. coinrun.cpp:459-464).
+struct BgAxis {
+    int32_t d0, dn, s0, sn;  // destination span on the target, source span in the texture (dn = 0: nothing)
+    int32_t tex_off, tex_w;
+};
+PG_D BgAxis bg_axis(const Camera& cam, const int4& desc, float pos_x, float pos_y, float scale, int axis) {
+    Span sp;
+    const bool ok = axis == 0 ? resolve_axis(cam.px, cam.sw, cam.scale, desc.y, pos_x, scale, false, false, sp)
+                              : resolve_axis(cam.py, cam.sh, cam.scale, desc.z, pos_y, scale, false, true, sp);
+    return BgAxis{ok ? sp.d0 : 0, ok ? sp.dn : 0, sp.s0, sp.sn, desc.x, desc.y};
+}
+// this lane's background offset on `axis`: texel column (× 4 bytes, + the texture's start) or texel row (× pitch)
+PG_D uint32_t bg_offset(const BgAxis& b, int lane, int axis) {
+    if (lane < b.d0 || lane >= b.d0 + b.dn) return 0x40000000u;  // kNoTexel
+    const int t = sample_index(b.s0, b.sn, lane - b.d0, b.dn);
+    return axis == 0 ? static_cast<uint32_t>(b.tex_off + t) * 4u : static_cast<uint32_t>(t * b.tex_w) * 4u;
+}
+
 // What a game that knows its textures passes as compose_spans' soft_init: the background's bit, and every grid row's
 // if some tile texture of the layer has texels that are not opaque (descriptor .w, set when the atlas is loaded).
 PG_D int32_t soft_rows_of(int bg_w, int tiles_w) {
@@ -599,6 +636,7 @@ PG_D void compose_spans(uint32_t* fb, ComposeLds<GRID>& L, const Camera& cam, in
             L.too_wide = 0;
             L.soft_rows = soft_init;
             L.hard_rows = hard_init;
+            compose_hand<GRID>(fb).bad = 0;
             L.base[GRID * GRID] = L.base[GRID * GRID + 1] = static_cast<int32_t>(0x40000000u);  // kNoTexel (declared below)
         }
     }
@@ -677,65 +715,43 @@ constexpr uint32_t kNoTexel = 0x40000000u;
 // L.row2 and is chosen per lane, at the price of a select and an add in front of every tile load.
 // The frame of a game without a tile layer (bossfight): the background over black, nothing else — one candidate per
 // pixel instead of the composer's five, no span tables.  Same arithmetic as compose_rows with four absent candidates.
-PG_D void compose_background(uint32_t* fb, const AtlasView& atlas, const Blit& bg, bool has_bg, int lane, int half = 0,
-                             int halves = 1) {
+PG_D void compose_background(uint32_t* fb, const AtlasView& atlas, const BgAxis& bga, int lane, int half, int halves) {
     const __amdgpu_buffer_rsrc_t bg_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t*>(atlas.texels), 0, static_cast<int>(atlas.texel_bytes), 0x00020000);
-    uint32_t bg_col = kNoTexel, bg_row = kNoTexel;
-    if (has_bg) {
-        const bool fh = (bg.flip_mod & kFlipH) != 0, fv = (bg.flip_mod & kFlipV) != 0;
-        if (lane >= bg.dx && lane < bg.dx + bg.dw) {
-            int i = lane - bg.dx;
-            if (fh) i = bg.dw - 1 - i;
-            bg_col = static_cast<uint32_t>(bg.tex_off + sample_index(bg.sx, bg.sw, i, bg.dw)) * 4u;
-        }
-        if (lane >= bg.dy && lane < bg.dy + bg.dh) {
-            int j = lane - bg.dy;
-            if (fv) j = bg.dh - 1 - j;
-            bg_row = static_cast<uint32_t>(sample_index(bg.sy, bg.sh, j, bg.dh) * bg.tex_w) * 4u;
-        }
+    // wave 0 resolved the x axis, wave 1 the y axis: trade the per-column / per-row offsets through the target's memory
+    fb[64 * half + lane] = bg_offset(bga, lane, half);
+    __syncthreads();
+    const uint32_t bg_col = fb[lane], bg_row = fb[64 + lane];
+    __syncthreads();
+    // all the rows of the wave at once: 32 gathers in flight, one memory round trip
+    constexpr int kRows = kObsH / 2;
+    const int py_begin = half * kRows;
+    uint32_t t[kRows];
+#pragma unroll
+    for (int k = 0; k < kRows; k++)
+        t[k] = __builtin_amdgcn_raw_buffer_load_b32(bg_rsrc, bg_col, __builtin_amdgcn_readlane(bg_row, py_begin + k), 0);
+    uint32_t least = t[0];
+#pragma unroll
+    for (int k = 1; k < kRows; k++) least = least < t[k] ? least : t[k];
+    if (__ballot(least < 0xff000000u) == 0) {  // opaque everywhere: the texels are the pixels (top byte unread)
+#pragma unroll
+        for (int k = 0; k < kRows; k++) fb[(py_begin + k) * kObsW + lane] = t[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < kRows; k++)
+            fb[(py_begin + k) * kObsW + lane] = blend_px(0u, t[k], static_cast<int>(t[k] >> 24));
     }
-    const int bg_mod = has_bg ? (bg.flip_mod & 0xff) : 255;
-    constexpr int kBatch = 8;
-    const int py_begin = half * (kObsH / halves), py_end = py_begin + kObsH / halves;
-    for (int py0 = py_begin; py0 < py_end; py0 += kBatch) {
-        uint32_t t[kBatch];
-#pragma unroll
-        for (int k = 0; k < kBatch; k++) {
-            const uint32_t s_bg = __builtin_amdgcn_readlane(bg_row, py0 + k);
-            t[k] = __builtin_amdgcn_raw_buffer_load_b32(bg_rsrc, bg_col, s_bg, 0);
-        }
-        uint32_t translucent = 0;
-#pragma unroll
-        for (int k = 0; k < kBatch; k++) translucent |= ((t[k] >> 24) + 1u) & 0xFEu;
-        if (bg_mod == 255 && __ballot(translucent != 0) == 0) {
-#pragma unroll
-            for (int k = 0; k < kBatch; k++)
-                fb[(py0 + k) * kObsW + lane] = (t[k] > 0x00ffffffu) ? (t[k] & 0x00ffffffu) : 0u;
-        } else {
-#pragma unroll
-            for (int k = 0; k < kBatch; k++) {
-                int a = static_cast<int>(t[k] >> 24);
-                if (bg_mod != 255) a = static_cast<int>(div255(static_cast<uint32_t>(a * bg_mod)));
-                fb[(py0 + k) * kObsW + lane] = blend_px(0u, t[k], a);
-            }
-        }
-    }
+    (void)halves;
     __syncthreads();
 }
 
 template <int GRID, bool TWO = false>
-PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView& atlas, const Blit& bg, bool has_bg,
-                       int cols, int rows, int tw, int lane, int ablate = 0, int half = 0, int halves = 1) {
-
-    // lane as pixel column: covering grid columns; lane as pixel row: covering grid rows.
-    int ca, cb, ua, ub, ra, rb, va, vb;
+PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView& atlas, const BgAxis& bga, int cols, int rows,
+                       int tw, int lane, int ablate, int half, int halves) {
+    static_assert(GRID <= 31 || true, "");
     if (L.too_wide) return false;
     const ComposeTmp<GRID>& T = compose_tmp<GRID>(fb);
-    bool fits = covering(T, 0, lane, ca, cb, ua, ub);
-    fits = covering(T, 1, lane, ra, rb, va, vb) && fits;
-    if (__ballot(!fits)) return false;
-
+    ComposeHand& H = compose_hand<GRID>(fb);
     // All texel reads go through one buffer descriptor over the atlas: 32-bit byte offsets, and out-of-range
     // (= "no candidate") reads return 0 without a branch.
     // (`ablate` bits 5/6 are timing experiments: a descriptor with zero records drops every load through it.)
@@ -744,67 +760,86 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
     const __amdgpu_buffer_rsrc_t atlas_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t*>(atlas.texels), 0, PG_ABL(ablate, 64) ? 0 : static_cast<int>(atlas.texel_bytes), 0x00020000);
 
-    // background: per-lane column byte offset, per-row (lane = row index) row byte offset
-    uint32_t bg_col = kNoTexel, bg_row = kNoTexel;
-    if (has_bg) {
-        const bool fh = (bg.flip_mod & kFlipH) != 0, fv = (bg.flip_mod & kFlipV) != 0;
-        if (lane >= bg.dx && lane < bg.dx + bg.dw) {
-            int i = lane - bg.dx;
-            if (fh) i = bg.dw - 1 - i;
-            bg_col = static_cast<uint32_t>(bg.tex_off + sample_index(bg.sx, bg.sw, i, bg.dw)) * 4u;
+    if (half == 0) {
+        // ---- wave 0, lane = pixel column: the covering grid columns (at most two, neighbours) and their texel columns
+        int ca, cb, ua, ub;
+        bool ok = covering(T, 0, lane, ca, cb, ua, ub);
+        ok = ok && !(cb >= 0 && cb != ca + 1);  // the cell of (·, b) must sit one word behind that of (·, a)
+        uint32_t col_a = ca >= 0 ? static_cast<uint32_t>(ua) * 4u : kNoTexel;
+        uint32_t col_b = cb >= 0 ? static_cast<uint32_t>(ub) * 4u : kNoTexel;
+        uint32_t bg_col = bg_offset(bga, lane, 0);
+        if (PG_ABL(ablate, 1024)) {  // timing experiment: every lane of a tile samples texel column 0 (one cache line)
+            col_a = ca >= 0 ? 0u : kNoTexel;
+            col_b = cb >= 0 ? 0u : kNoTexel;
         }
-        if (lane >= bg.dy && lane < bg.dy + bg.dh) {
-            int j = lane - bg.dy;
-            if (fv) j = bg.dh - 1 - j;
-            bg_row = static_cast<uint32_t>(sample_index(bg.sy, bg.sh, j, bg.dh) * bg.tex_w) * 4u;
+        if (PG_ABL(ablate, 2048)) bg_col = bg_col == kNoTexel ? kNoTexel : static_cast<uint32_t>(bga.tex_off) * 4u;
+        H.col[lane] = make_uint4(bg_col, col_a, col_b, static_cast<uint32_t>(ca >= 0 ? ca : 0) * 4u);
+        if (__ballot(!ok) && lane == 0) H.bad = 1;
+    } else {
+        // ---- wave 1, lane = pixel row: the covering grid rows and their texel rows, and the row classes as 64-bit
+        // masks (bit py = pixel row py):
+        //   second_row  two grid rows cover the row (the seam a tile's padding makes with the next tile);
+        //   soft        a grid row covering the row shows a texture that has texels that are not opaque (L.soft_rows;
+        //               bit 31: the background does): only batches with such a row look at the alphas they fetched;
+        //   hard        … so many of them that the one-texel-per-pixel attempt is not made (L.hard_rows).
+        int ra, rb, va, vb;
+        bool ok = covering(T, 1, lane, ra, rb, va, vb);
+        ok = ok && !(rb >= 0 && rb != ra + 1);  // the cells of (b, ·) must sit one table row behind those of (a, ·)
+        const uint32_t row_a = ra >= 0 ? static_cast<uint32_t>(va * tw) * 4u : kNoTexel;
+        const uint32_t row_b = rb >= 0 ? static_cast<uint32_t>(vb * tw) * 4u : kNoTexel;
+        // byte address, inside the cell table, of grid row a's cells; a row that no grid row covers points at the
+        // two sentinel words behind the table, which hold kNoTexel
+        const uint32_t cells_a = static_cast<uint32_t>(ra >= 0 ? ra * GRID : GRID * GRID) * 4u;
+        H.row[lane] = make_uint4(bg_offset(bga, lane, 1), row_a, row_b, cells_a);
+        if (TWO) {  // texel rows of the layer's second, shorter texture
+            uint32_t row_a2 = kNoTexel, row_b2 = kNoTexel;
+            if (ra >= 0) {
+                const int4 sp = T.row2[ra];
+                const int i = lane - sp.x;
+                if (sp.w > 0 && i >= 0 && i < sp.y) row_a2 = static_cast<uint32_t>(sample_index(sp.z, sp.w, i, sp.y) * tw) * 4u;
+            }
+            if (rb >= 0) {
+                const int4 sp = T.row2[rb];
+                const int i = lane - sp.x;
+                if (sp.w > 0 && i >= 0 && i < sp.y) row_b2 = static_cast<uint32_t>(sample_index(sp.z, sp.w, i, sp.y) * tw) * 4u;
+            }
+            H.row2[lane] = make_uint2(row_a2, row_b2);
+        }
+        const uint32_t soft_bits = static_cast<uint32_t>(L.soft_rows), hard_bits = static_cast<uint32_t>(L.hard_rows);
+        // (grids beyond 31 rows alias in these masks: conservative)
+        const bool soft_here = (soft_bits >> 31) != 0 || (ra >= 0 && ((soft_bits >> (ra & 31)) & 1u)) ||
+                               (rb >= 0 && ((soft_bits >> (rb & 31)) & 1u));
+        const bool hard_here = (hard_bits >> 31) != 0 || (ra >= 0 && ((hard_bits >> (ra & 31)) & 1u)) ||
+                               (rb >= 0 && ((hard_bits >> (rb & 31)) & 1u));
+        const unsigned long long m_second = __ballot(rb >= 0), m_soft = __ballot(soft_here), m_hard = __ballot(hard_here);
+        const bool any_bad = __ballot(!ok) != 0;
+        if (lane == 0) {
+            H.masks[0] = static_cast<uint32_t>(m_second);
+            H.masks[1] = static_cast<uint32_t>(m_second >> 32);
+            H.masks[2] = static_cast<uint32_t>(m_soft);
+            H.masks[3] = static_cast<uint32_t>(m_soft >> 32);
+            H.masks[4] = static_cast<uint32_t>(m_hard);
+            H.masks[5] = static_cast<uint32_t>(m_hard >> 32);
+            if (any_bad) H.bad = 1;
         }
     }
-    const int bg_mod = has_bg ? (bg.flip_mod & 0xff) : 255;
-    // tile layer: per-lane column byte offsets and LDS column indices; per-row row byte offsets and LDS row bases
-    uint32_t col_a = ca >= 0 ? static_cast<uint32_t>(ua) * 4u : kNoTexel;
-    uint32_t col_b = cb >= 0 ? static_cast<uint32_t>(ub) * 4u : kNoTexel;
-    if (PG_ABL(ablate, 1024)) {  // timing experiment: every lane of a tile samples texel column 0 (one cache line)
-        col_a = ca >= 0 ? 0u : kNoTexel;
-        col_b = cb >= 0 ? 0u : kNoTexel;
-    }
-    if (PG_ABL(ablate, 2048)) bg_col = bg_col == kNoTexel ? kNoTexel : static_cast<uint32_t>(bg.tex_off) * 4u;  // same for the background
-    const int cia = ca >= 0 ? ca : 0;
-    const uint32_t row_a = ra >= 0 ? static_cast<uint32_t>(va * tw) * 4u : kNoTexel;
-    const uint32_t row_b = rb >= 0 ? static_cast<uint32_t>(vb * tw) * 4u : kNoTexel;
-    const int ria = (ra >= 0 ? ra : 0) * GRID;
-    uint32_t row_a2 = kNoTexel, row_b2 = kNoTexel;  // lane = pixel row: texel rows of the second texture
+    __syncthreads();
+    if (H.bad) return false;  // (nothing has been written to the target yet)
+    const uint4 hc = H.col[lane], hr = H.row[lane];
+    const uint32_t bg_col = hc.x, col_a = hc.y, col_b = hc.z, cia4 = hc.w;
+    const uint32_t bg_row = hr.x, row_a = hr.y, row_b = hr.z, cells_a = hr.w;
+    uint32_t row_a2 = 0, row_b2 = 0;
     if (TWO) {
-        if (ra >= 0) {
-            const int4 sp = T.row2[ra];
-            const int i = lane - sp.x;
-            if (sp.w > 0 && i >= 0 && i < sp.y) row_a2 = static_cast<uint32_t>(sample_index(sp.z, sp.w, i, sp.y) * tw) * 4u;
-        }
-        if (rb >= 0) {
-            const int4 sp = T.row2[rb];
-            const int i = lane - sp.x;
-            if (sp.w > 0 && i >= 0 && i < sp.y) row_b2 = static_cast<uint32_t>(sample_index(sp.z, sp.w, i, sp.y) * tw) * 4u;
-        }
+        const uint2 h2 = H.row2[lane];
+        row_a2 = h2.x;
+        row_b2 = h2.y;
     }
-    // The two covering columns / rows of a pixel are neighbours in the grid (tiles only overlap the next one), so the
-    // cells of candidates (·, b) and (b, ·) sit one word / one table row behind those of (a, a): one LDS address per
-    // pixel row serves all four.  Anything else takes the fallback.
-    if (__ballot((cb >= 0 && cb != ca + 1) || (rb >= 0 && rb != ra + 1))) return false;
-    // Per pixel row (lane = row): byte address, inside the cell table, of grid row a's cells; a row that no grid row
-    // covers points at the two sentinel words behind the table, which hold kNoTexel.
-    const uint32_t cells_a = static_cast<uint32_t>(ra >= 0 ? ria : GRID * GRID) * 4u;
-    const uint32_t cia4 = static_cast<uint32_t>(cia) * 4u;
-    // Wave-uniform row classes as 64-bit masks (bit py = pixel row py; every lane holds row `lane`'s values):
-    //   second_row  two grid rows cover the row (the seam a tile's padding makes with the next tile);
-    //   soft        a grid row covering the row shows a texture that has translucent texels (L.soft_rows; bit 31: the
-    //               background does): only batches with such a row look at the alphas they fetched.
-    const unsigned long long second_row = __ballot(rb >= 0);
-    const uint32_t soft_bits = static_cast<uint32_t>(L.soft_rows);
-    const bool soft_here = (soft_bits >> 31) != 0 || (ra >= 0 && ((soft_bits >> (ra & 31)) & 1u)) ||
-                           (rb >= 0 && ((soft_bits >> (rb & 31)) & 1u));  // (grids beyond 31 rows alias: conservative)
-    const unsigned long long soft = __ballot(soft_here);
-    const uint32_t hard_bits = static_cast<uint32_t>(L.hard_rows);
-    const unsigned long long hard = __ballot((hard_bits >> 31) != 0 || (ra >= 0 && ((hard_bits >> (ra & 31)) & 1u)) ||
-                                             (rb >= 0 && ((hard_bits >> (rb & 31)) & 1u)));
+    auto mask64 = [&](int k) {
+        return static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(H.masks[2 * k])) |
+               (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(H.masks[2 * k + 1])) << 32);
+    };
+    const unsigned long long second_row = mask64(0), soft = mask64(1), hard = mask64(2);
+    constexpr int bg_mod = 255;  // (see BgAxis)
     __syncthreads();  // everybody has read the set-up tables out of the frame target's memory: it may be written now
 
     // Rows in batches: every texel gather of a batch is issued before any pixel is produced, so a batch costs one
@@ -918,45 +953,54 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
         if (TWO) return (cell & ~3u) + col + ((cell & 1u) ? row_second : row_first);
         return cell + col + row_first;
     };
-    const int py_begin = half * (kObsH / halves), py_end = py_begin + kObsH / halves;
-    for (int py0 = py_begin; py0 < py_end; py0 += kBatch) {
-        if (bg_mod != 255 || (static_cast<uint32_t>(hard >> py0) & 0xffu) != 0u) {  // too much that is not opaque in sight
-            general_batch(py0);
-            continue;
-        }
-        const uint32_t seconds = static_cast<uint32_t>(second_row >> py0) & 0xffu;
-        uint32_t top[kBatch];
+    // The attempt is made for all the rows of the wave at once — 32 gathers in flight, one memory round trip for the
+    // whole half frame — and judged in groups of kBatch rows, the unit the general form works in.
+    const int py_begin = half * (kObsH / halves);
+    constexpr int kRows = kObsH / 2;
+    static_assert(kRows % kBatch == 0, "");
+    if (halves != 2) return false;  // (every render kernel runs two wavefronts per env)
+    const uint32_t hards = static_cast<uint32_t>(hard >> py_begin);  // this wave's 32 rows
+    if (bg_mod != 255 || hards == 0xffffffffu) {  // nothing worth attempting
+        for (int py0 = py_begin; py0 < py_begin + kRows; py0 += kBatch) general_batch(py0);
+        __syncthreads();
+        return true;
+    }
+    const uint32_t seconds32 = static_cast<uint32_t>(second_row >> py_begin);
+    uint32_t top[kRows];
 #pragma unroll
-        for (int k = 0; k < kBatch; k++) {
-            const int py = py0 + k;
-            const uint32_t s_bg = __builtin_amdgcn_readlane(bg_row, py);
-            const uint32_t s_a = __builtin_amdgcn_readlane(row_a, py);
-            const uint32_t* cp = reinterpret_cast<const uint32_t*>(cells + __builtin_amdgcn_readlane(cells_a, py));
-            const uint32_t s_a2 = TWO ? __builtin_amdgcn_readlane(row_a2, py) : 0u;
-            uint32_t at = bg_col + s_bg;  // draw order: background, (a, a), (a, b), (b, a), (b, b) — the last one there wins
-            uint32_t x = tile_at(cp[0], col_a, s_a, s_a2);
+    for (int k = 0; k < kRows; k++) {
+        const int py = py_begin + k;
+        const uint32_t s_bg = __builtin_amdgcn_readlane(bg_row, py);
+        const uint32_t s_a = __builtin_amdgcn_readlane(row_a, py);
+        const uint32_t* cp = reinterpret_cast<const uint32_t*>(cells + __builtin_amdgcn_readlane(cells_a, py));
+        const uint32_t s_a2 = TWO ? __builtin_amdgcn_readlane(row_a2, py) : 0u;
+        uint32_t at = bg_col + s_bg;  // draw order: background, (a, a), (a, b), (b, a), (b, b) — the last one there wins
+        uint32_t x = tile_at(cp[0], col_a, s_a, s_a2);
+        at = x < kNoTexel ? x : at;
+        x = tile_at(cp[1], col_b, s_a, s_a2);
+        at = x < kNoTexel ? x : at;
+        if (seconds32 & (1u << k)) {  // wave-uniform
+            const uint32_t s_b = __builtin_amdgcn_readlane(row_b, py);
+            const uint32_t s_b2 = TWO ? __builtin_amdgcn_readlane(row_b2, py) : 0u;
+            x = tile_at(cp[GRID], col_a, s_b, s_b2);
             at = x < kNoTexel ? x : at;
-            x = tile_at(cp[1], col_b, s_a, s_a2);
+            x = tile_at(cp[GRID + 1], col_b, s_b, s_b2);
             at = x < kNoTexel ? x : at;
-            if (seconds & (1u << k)) {  // wave-uniform
-                const uint32_t s_b = __builtin_amdgcn_readlane(row_b, py);
-                const uint32_t s_b2 = TWO ? __builtin_amdgcn_readlane(row_b2, py) : 0u;
-                x = tile_at(cp[GRID], col_a, s_b, s_b2);
-                at = x < kNoTexel ? x : at;
-                x = tile_at(cp[GRID + 1], col_b, s_b, s_b2);
-                at = x < kNoTexel ? x : at;
-                asm volatile("" : "+v"(at));  // keeps the branch a branch
-            }
-            top[k] = __builtin_amdgcn_raw_buffer_load_b32(atlas_rsrc, at, 0, 0);
+            asm volatile("" : "+v"(at));  // keeps the branch a branch
         }
-        uint32_t least = top[0];
+        top[k] = __builtin_amdgcn_raw_buffer_load_b32(atlas_rsrc, at, 0, 0);
+    }
 #pragma unroll
-        for (int k = 1; k < kBatch; k++) least = least < top[k] ? least : top[k];
-        if (__ballot(least < 0xff000000u) == 0 && !PG_ABL(ablate, 4096)) {
+    for (int g = 0; g < kRows / kBatch; g++) {
+        uint32_t least = top[g * kBatch];
 #pragma unroll
-            for (int k = 0; k < kBatch; k++) fb[(py0 + k) * kObsW + lane] = top[k];
+        for (int k = 1; k < kBatch; k++) least = least < top[g * kBatch + k] ? least : top[g * kBatch + k];
+        const bool skip = ((hards >> (g * kBatch)) & 0xffu) != 0u;
+        if (!skip && __ballot(least < 0xff000000u) == 0 && !PG_ABL(ablate, 4096)) {
+#pragma unroll
+            for (int k = 0; k < kBatch; k++) fb[(py_begin + g * kBatch + k) * kObsW + lane] = top[g * kBatch + k];
         } else {
-            general_batch(py0);
+            general_batch(py_begin + g * kBatch);
         }
     }
     __syncthreads();
