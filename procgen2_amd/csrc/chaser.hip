@@ -695,19 +695,40 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
     const int x0 = static_cast<int>(floorf(vx)), y0 = static_cast<int>(floorf(vy));
     const int x1 = static_cast<int>(ceilf(vx + vw)), y1 = static_cast<int>(ceilf(vy + vh));
     const int cols = x1 - x0 + 1, rows = y1 - y0 + 1, cells = cols * rows;
-    const int4 wall_d = descs.uniform(kTexWall);
+    const int4 wall_d = descs.uniform(kTexWall), point_d = descs.uniform(kTexPoint);
+    // Needs: the wall's texture size (check_atlas), texels all opaque or all clear, a clear rim (descriptor .w bits 2, 3).
+    const bool points_in_layer = !(flags & 1) && (point_d.w & 12) == 8;
 
     const BgAxis bga = bg_axis(cam, bg_d, bg_px, bg_py, bg_sc, half);  // wave 0: x axis, wave 1: y axis
     bool composed = false;
     if (!(flags & 1) && cols <= kGrid && rows <= kGrid) {
         compose_spans<kGrid, 16>(fb, L, cam, x0, y0, cols, rows, wall_d.y, wall_d.z, kUnitPx / wall_d.y, lane, 0, half, halves,
-                                 soft_rows_of(bg_soft, wall_d.w), hard_rows_of(bg_soft, wall_d.w));
+                                 soft_rows_of(bg_soft, wall_d.w | (points_in_layer ? point_d.w : 0)),
+                                 hard_rows_of(bg_soft, wall_d.w | (points_in_layer ? point_d.w : 0)));
 #pragma unroll
         for (int k = half; k < kGrid * kGrid / 64; k += halves) {
             const int cell = k * 64 + lane;
             const int r = cell / kGrid, c = cell % kGrid;
             const bool wall = c < cols && r < rows && tile_at(tiles, x0 + c, H - 1 - (y0 + r)) == kWall;
             L.base[cell] = wall ? wall_d.x * 4 : static_cast<int32_t>(kNoTexel);
+        }
+        if (points_in_layer) {
+            // The points of the draw list join the tile layer: a point is drawn with exactly a tile's arithmetic
+            // (world position = its cell's corner, scale 16 / texture width — common_systems.cpp:41-63 vs
+            // tilemap.cpp:256-266), its texture is the wall's size, and the only texels of it that are not fully
+            // transparent are the opaque 4×4 in the middle — nowhere near the one-pixel seam it shares with its
+            // neighbours.  So where a point lands in the picture does not depend on when it is drawn relative to
+            // walls and other points; relative to the sprites that are not points it does, and the sprite pass below
+            // re-draws (idempotently: opaque texels) the points that follow such a sprite in the list and touch it.
+            __syncthreads();  // the wall pass has written every cell
+            for (int k = lane + 64 * half; k < n_draw; k += 64 * halves) {
+                const int e = EB(s, EB_DRAW, k, env);
+                if ((EB(s, EB_INFO, e, env) & kKindMask) == kPoint) {
+                    const int cell = ent_cell(s, e, env);
+                    const int c = cell / H - x0, r = (H - 1 - cell % H) - y0;
+                    if (c >= 0 && r >= 0 && c < cols && r < rows) L.base[r * kGrid + c] = point_d.x * 4;
+                }
+            }
         }
         __syncthreads();
         composed = compose_rows(fb, L, atlas, bga, cols, rows, wall_d.y, lane, flags, half, halves);
@@ -730,11 +751,19 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
         }
     }
     // every sprite has z = 0: the positive pass (common_systems.cpp:41-63), then the agent (:446-460)
+    // Points that the composer has already put into the picture are drawn again only if an earlier draw of the list
+    // that is not a point (orb, egg, enemy) touches them: those would otherwise end up on top of the point instead of
+    // under it.  The rectangles of the non-point draws seen so far live in the dead cell table, one region per wave
+    // (the waves run this pass independently, each on the rows it owns).
+    int4* const seen = reinterpret_cast<int4*>(L.base) + half * (kOrbs + kMobs + 2);
+    static_assert(2 * (kOrbs + kMobs + 2) * 4 <= kGrid * kGrid, "scratch inside the cell table");
+    int n_seen = 0;
+    const bool skip_points = composed && points_in_layer;
     for (int first = 0; first < n_draw + 1; first += 64) {
         const int k = first + lane;
         int want_tex = kTexAgent;
         float x = 0.0f, y = 0.0f;
-        bool has = false;
+        bool has = false, is_point = false;
         if (k < n_draw) {
             const int e = EB(s, EB_DRAW, k, env);
             const int kind = EB(s, EB_INFO, e, env) & kKindMask;
@@ -747,6 +776,7 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
             } else {
                 const int cell = ent_cell(s, e, env);
                 want_tex = kind == kOrb ? kTexOrb : kTexPoint;
+                is_point = kind == kPoint;
                 x = cell_x(cell);
                 y = cell_y(cell);
             }
@@ -760,6 +790,33 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
             const float scale = (k == n_draw) ? kUnitPx / d.y * 1.0f : (1.0f * 1.0f) * kUnitPx / d.y;
             has = resolve_draw(cam, d.y, d.z, d.x, (x + -0.5f) * kUnitPx, (y + -0.5f) * kUnitPx, scale, 1.0f, false, false,
                                mine);
+        }
+        if (skip_points) {
+            const unsigned long long others = __ballot(has && !is_point);
+            if (has && !is_point) {  // append in draw order
+                const int slot = n_seen + __popcll(others & ((1ull << lane) - 1ull));
+                seen[slot] = make_int4(mine.dx, mine.dy, mine.dx + mine.dw, mine.dy + mine.dh);
+            }
+            // a point is kept if a non-point draw EARLIER in the list touches it: those of earlier passes (all of
+            // them precede it), and those of this pass at lower lanes
+            bool keep = !is_point;
+            if (is_point && has) {
+                for (int q = 0; q < n_seen; q++) {
+                    const int4 r = seen[q];
+                    keep = keep || (mine.dx < r.z && mine.dx + mine.dw > r.x && mine.dy < r.w && mine.dy + mine.dh > r.y);
+                }
+            }
+            unsigned long long m = others;
+            while (m) {  // wave-uniform loop over this pass's non-point draws
+                const int q = __builtin_ctzll(m);
+                m &= m - 1;
+                const int rx0 = __builtin_amdgcn_readlane(mine.dx, q), ry0 = __builtin_amdgcn_readlane(mine.dy, q);
+                const int rx1 = rx0 + __builtin_amdgcn_readlane(mine.dw, q), ry1 = ry0 + __builtin_amdgcn_readlane(mine.dh, q);
+                if (is_point && lane > q)
+                    keep = keep || (mine.dx < rx1 && mine.dx + mine.dw > rx0 && mine.dy < ry1 && mine.dy + mine.dh > ry0);
+            }
+            n_seen += __popcll(others);
+            has = has && keep;
         }
         wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
     }
@@ -824,7 +881,9 @@ class ChaserGame final : public Game {
         return v;
     }
     std::string check_atlas(const std::vector<std::pair<int, int>>& sizes) const override {
-        return static_cast<int>(sizes.size()) == kTexCount ? "" : "chaser: unexpected texture count";
+        if (static_cast<int>(sizes.size()) != kTexCount) return "chaser: unexpected texture count";
+        if (sizes[kTexPoint] != sizes[kTexWall]) return "chaser: the point texture must have the wall tile's size (row composer)";
+        return "";
     }
     static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
     struct Layout {

@@ -67,6 +67,18 @@ bool Atlas::load(const std::string& root, const std::vector<std::string>& names,
         for (size_t k = 3; k < img.rgba.size(); k += 4) not_opaque += img.rgba[k] != 255;
         if (not_opaque) d.w |= 1;
         if (not_opaque * 100 > size_t(img.w) * img.h * 3) d.w |= 2;
+        // bit 2: some texel is translucent (alpha neither 0 nor 255); bit 3: every texel outside the central half of
+        // the texture (rows and columns [size/4, 3·size/4)) is fully transparent — what chaser.hip asks of its point
+        // sprite before it lets the points join the tile layer.
+        bool clear_rim = true;
+        for (int y = 0; y < img.h; y++)
+            for (int x = 0; x < img.w; x++) {
+                const uint8_t a = img.rgba[(size_t(y) * img.w + x) * 4 + 3];
+                if (a != 0 && a != 255) d.w |= 4;
+                const bool inner = y >= img.h / 4 && y < img.h - img.h / 4 && x >= img.w / 4 && x < img.w - img.w / 4;
+                if (!inner && a != 0) clear_rim = false;
+            }
+        if (clear_rim) d.w |= 8;
         desc_.push_back(d);
         size_t base = texels_.size();
         texels_.resize(base + size_t(img.w) * img.h);
