@@ -323,6 +323,7 @@ int32_t pgv_make_config(const pgv_config* cfg, pgv_env** out) {
     if (!e->atlas.load(pg::asset_root(), e->game->texture_names(), err)) return fail("pgv_make: " + err);
     err = e->game->check_atlas(e->atlas.sizes());
     if (!err.empty()) return fail("pgv_make: " + err);
+    e->game->extend_atlas(e->atlas);
     if (!e->atlas.upload(err)) return fail("pgv_make: " + err);
     const size_t sb = state_blob_bytes(e.get());
     PG_HIP(hipMalloc(&e->d_state, sb));

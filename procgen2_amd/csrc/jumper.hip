@@ -104,6 +104,9 @@ struct State {
     uint16_t* spike_cell;  // [kMaxSpikes][n]
     uint8_t* draw;         // [kMaxSprites][n]
     int float_abs;         // game_flags PGV_JUMPER_FLOAT_ABS (D21)
+    // the compass ring as it lands on the observation (extend_atlas; word offsets into the atlas, 0 = not prepared)
+    uint32_t hud_image, hud_list;
+    int hud_n;
 };
 
 PG_D float& SF(const State& s, int field, int env) { return s.f[size_t(field) * s.n + env]; }
@@ -730,7 +733,17 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
             }
             has = resolve_screen(d.y, d.z, d.x, sx, sy, sw, sh, deg, mine);
         }
-        wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
+        const int row_lo = half * (kObsH / halves), row_hi = (half + 1) * (kObsH / halves);
+        if (s.hud_image != 0u) {
+            // the ring is the same 60×60 pixels in every frame: prepared once (pg_render.h overlay_rows), in its place in
+            // the draw order — after the bunny, before the needle and the bar
+            wave_replay_rows(fb, atlas, mine, __ballot(has && lane == 0), lane, row_lo, row_hi);
+            overlay_rows(fb, atlas.texels + s.hud_image, reinterpret_cast<const uint2*>(atlas.texels + s.hud_list), s.hud_n,
+                         lane, row_lo, row_hi);
+            wave_replay_rows(fb, atlas, mine, __ballot(has && lane >= 2), lane, row_lo, row_hi);
+        } else {
+            wave_replay_rows(fb, atlas, mine, __ballot(has), lane, row_lo, row_hi);
+        }
     }
     // each wave stores the rows it owns (pg_render.h wave_replay_rows): no barrier
     wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
@@ -884,6 +897,41 @@ class JumperGame final : public Game {
         return l;
     }
     size_t state_bytes(int n) const override { return layout(n).total; }
+    // The compass ring (jumper.cpp:485-489: SDL_RenderTextureRotated(circle, NULL, &dst, 0°) at a fixed screen rectangle,
+    // drawn for the observation too, D17) lands on the same pixels with the same texels in every frame: sample it once
+    // here, under raster spec S1-S3, for the 64×64 observation (the human-size frame keeps the general path).
+    void extend_atlas(Atlas& atlas) override {
+        const int4 d = atlas.desc_host(kTexCircle);
+        const uint32_t* tex = atlas.texels_host(kTexCircle);
+        const float game_zoom = 0.3f, width = 64.0f, compass_size = 200.0f, offset_x = -32.0f, offset_y = 32.0f;
+        const float fx = width - compass_size * game_zoom + offset_x * game_zoom, fy = offset_y * game_zoom;
+        const float fw = compass_size * game_zoom, fh = compass_size * game_zoom;
+        if (!(fw >= 1.0f && fh >= 1.0f && fw < 32768.0f && fh < 32768.0f)) return;  // resolve_screen's S1
+        if (!(fx > -32768.0f && fx < 32768.0f && fy > -32768.0f && fy < 32768.0f)) return;
+        const int dx = static_cast<int>(fx), dy = static_cast<int>(fy), dw = static_cast<int>(fw), dh = static_cast<int>(fh);
+        std::vector<uint32_t> image(size_t(kObsW) * kObsH, 0u), list;
+        for (int y = 0; y < kObsH; y++)
+            for (int x = 0; x < kObsW; x++) {
+                const int i = x - dx, j = y - dy;
+                if (i < 0 || j < 0 || i >= dw || j >= dh) continue;
+                const uint32_t t = tex[sample_index(0, d.z, j, dh) * d.y + sample_index(0, d.y, i, dw)];
+                const uint32_t a = t >> 24;
+                if (a == 255u) {
+                    image[size_t(y) * kObsW + x] = t;
+                } else if (a != 0u) {
+                    list.push_back(static_cast<uint32_t>(y * kObsW + x));
+                    list.push_back(t);
+                }
+            }
+        while ((list.size() / 2) % 64 != 0) {
+            list.push_back(0xffffffffu);
+            list.push_back(0u);
+        }
+        if ((atlas.texel_bytes() / 4) % 2 != 0) atlas.append_words({0u});  // the list is read as 8-byte pairs
+        s_.hud_image = atlas.append_words(image);
+        s_.hud_n = static_cast<int>(list.size() / 2);
+        s_.hud_list = atlas.append_words(list.empty() ? std::vector<uint32_t>{0xffffffffu, 0u} : list);
+    }
     bool set_game_flags(uint32_t flags) override {  // include/procgen2_vec.h PGV_JUMPER_FLOAT_ABS
         s_.float_abs = (flags & PGV_JUMPER_FLOAT_ABS) ? 1 : 0;
         return (flags & ~PGV_JUMPER_FLOAT_ABS) == 0;

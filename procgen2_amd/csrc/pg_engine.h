@@ -33,6 +33,15 @@ class Atlas {
         return {d_texels_, d_desc_, static_cast<int>(desc_.size()), static_cast<uint32_t>(texels_.size() * 4), d_ranks_};
     }
     size_t texel_bytes() const { return texels_.size() * 4; }
+    // Host-side access for Game::extend_atlas: the decoded textures, and room for derived data behind them (returns
+    // the word offset of the appended block; the atlas is one flat array of 32-bit words on the device).
+    const uint32_t* texels_host(int tex) const { return texels_.data() + desc_[tex].x; }
+    int4 desc_host(int tex) const { return desc_[tex]; }
+    uint32_t append_words(const std::vector<uint32_t>& words) {
+        const uint32_t at = static_cast<uint32_t>(texels_.size());
+        texels_.insert(texels_.end(), words.begin(), words.end());
+        return at;
+    }
     std::vector<std::pair<int, int>> sizes() const {
         std::vector<std::pair<int, int>> v;
         for (const auto& d : desc_) v.emplace_back(d.y, d.z);
@@ -95,6 +104,9 @@ class Game {
     virtual int dump_tiles(hipStream_t s, int env, uint8_t* out, int cap) = 0;
     // pgv_config.game_flags (include/procgen2_vec.h); false = this game does not know these switches.
     virtual bool set_game_flags(uint32_t flags) { return flags == 0; }
+    // Called once between loading and uploading the atlas: a game may append data derived from its textures (jumper:
+    // its compass ring as it lands on the 64×64 observation — the same pixels in every frame of every env).
+    virtual void extend_atlas(Atlas& atlas) { (void)atlas; }
     // Host-side sanity check of the loaded atlas (sizes[i] = {w, h} of texture i); empty string = fine.
     virtual std::string check_atlas(const std::vector<std::pair<int, int>>& sizes) const { return ""; }
 

@@ -559,6 +559,29 @@ PG_D void wave_replay_rows(uint32_t* fb, const AtlasView& atlas, const Blit& min
     }
 }
 
+// A draw that is the same in every frame of every env (a HUD element at a fixed place on the observation), prepared
+// on the host when the atlas is loaded (Game::extend_atlas): `image` = 64×64 words, the texel that lands on each pixel
+// where it is opaque, 0 elsewhere; `list` = (pixel index, texel) pairs for the texels that are translucent, `list_n`
+// entries padded to a multiple of 64 with index 0xffffffff.  Opaque pixels are coalesced loads and masked stores —
+// all rows of the wave in one round trip — translucent ones one blend per pixel, instead of a 60×60 blit that samples,
+// tests and blends every pixel it covers.  Same pixels as wave_replay_rows of the draw (raster spec S1–S4).
+PG_D void overlay_rows(uint32_t* fb, const uint32_t* image, const uint2* list, int list_n, int lane, int row_lo,
+                       int row_hi) {
+    constexpr int kRows = kObsH / 2;
+    uint32_t t[kRows];
+#pragma unroll
+    for (int k = 0; k < kRows; k++) t[k] = image[(row_lo + k) * kObsW + lane];
+#pragma unroll
+    for (int k = 0; k < kRows; k++)
+        if (t[k] >= 0xff000000u) fb[(row_lo + k) * kObsW + lane] = t[k];
+    for (int e = lane; e < list_n; e += 64) {
+        const uint2 item = list[e];
+        const int row = static_cast<int>(item.x >> 6);
+        if (item.x != 0xffffffffu && row >= row_lo && row < row_hi) blend_into(fb, static_cast<int>(item.x), item.y, 255);
+    }
+    (void)row_hi;
+}
+
 // The rows wave `half` of `halves` owns, and their share of the finished frame on its way out (no barrier needed
 // between a wave's last blend and its own store).
 PG_D void wave_store_rows(const uint32_t* fb, uint8_t* obs_env, int lane, int row_lo, int row_hi) {
