@@ -696,7 +696,7 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
             has = resolve_rotated(cam, d.y, d.z, d.x, px * kUnitPx - size * d.y * 0.5f, py * kUnitPx - size * d.z * 0.5f,
                                   static_cast<float>(rot + kPi * 0.5f), size, 1.0f, mine);
         }
-        wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
+        wave_replay_rows<4, true>(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
     }
     // second list, one draw per lane: boss ship, shield, explosions, barriers (positive-z sprites), agent bullets, agent
     {
@@ -771,7 +771,7 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
             }
             has = resolve_draw(cam, d.y, d.z, d.x, wx, wy, sc, al, false, false, mine);
         }
-        wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
+        wave_replay_rows<4, true>(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
     }
     // each wave stores the rows it owns (pg_render.h wave_replay_rows): no barrier
     wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));

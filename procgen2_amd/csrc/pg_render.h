@@ -179,6 +179,20 @@ PG_D bool blit_take(const uint32_t* slots, int lane, Blit& b) {
     return w1 != 0u;
 }
 
+// The same hand-over for draws that may be rotated: two more words (16.16 sine and cosine), the flag in word 5.
+constexpr int kRotBlitWords = 8;
+PG_D void blit_share_rot(uint32_t* slots, int lane, const Blit& b, bool has) {
+    blit_share(slots, lane, b, has);
+    slots[6 * 64 + lane] = static_cast<uint32_t>(b.rot_sn);
+    slots[7 * 64 + lane] = static_cast<uint32_t>(b.rot_cs);
+}
+PG_D bool blit_take_rot(const uint32_t* slots, int lane, Blit& b) {
+    const bool has = blit_take(slots, lane, b);
+    b.rot_sn = static_cast<int32_t>(slots[6 * 64 + lane]);
+    b.rot_cs = static_cast<int32_t>(slots[7 * 64 + lane]);
+    return has;
+}
+
 // Renderer::render_texture_rotated (games/*/renderer.cpp:84-101) followed by raster-spec S1 and S6: no cull, no
 // crop, whole texture as source, rotation about the centre of the destination rectangle.  `rotation` is the
 // float the reference passes; the angle handed to SDL is rotation * 180.0f / M_PI in double.  An angle of exactly
@@ -486,15 +500,47 @@ PG_D void wave_replay(uint32_t* fb, const AtlasView& atlas, const Blit& mine, un
 // draw that straddles row 32 is simply done by both, each on its own rows.  Same grouping as wave_replay: small
 // draws (≤ 64 pixels on my rows) kGroup at a time per memory round trip — the sprite pass is a chain of dependent
 // round trips, and its length, not its instruction count, is what it costs — rotated or larger ones alone.
-template <int kGroup = 4>
+// One target pixel of a rotated draw (raster spec S6): pixel p of `box` (row-major) maps back into the un-rotated
+// destination rectangle or misses it.  Same arithmetic as wave_blit_rotated.
+PG_D bool rotated_pixel(const Blit& b, const RotBox& box, int p, int& idx, int& texel_at) {
+    if (p >= box.bw * box.bh) return false;
+    const int ry = udiv_small(p, box.bw);
+    const int X = box.x_lo + (p - ry * box.bw), Y = box.y_lo + ry;
+    const int px = 2 * (X - b.dx) + 1 - b.dw, py = 2 * (Y - b.dy) + 1 - b.dh;
+    // Callers pass draws of at most kRotSmall pixels a side only: a pixel of the bounding box is within
+    // (dw + dh) / 2 + 1 of the rectangle's centre, so |px|, |py| ≤ dw + dh + 2 < 2^10, the 16.16 sine and cosine are
+    // at most 2^16 in magnitude, and every sum below stays under 2^28 — the products are exact 24-bit × 24-bit
+    // multiplies, a quarter of the cost of the 64-bit form wave_blit_rotated needs for draws of any size.
+    const int lx = __mul24(px, b.rot_cs) + __mul24(py, b.rot_sn) + (b.dw << 16);
+    const int ly = __mul24(py, b.rot_cs) - __mul24(px, b.rot_sn) + (b.dh << 16);
+    if (lx < 0 || ly < 0 || lx >= (b.dw << 17) || ly >= (b.dh << 17)) return false;
+    const int i = lx >> 17, j = ly >> 17;
+    idx = Y * kObsW + X;
+    texel_at = b.tex_off + sample_index(0, b.sh, j, b.dh) * b.tex_w + sample_index(0, b.sw, i, b.dw);
+    return true;
+}
+constexpr int kRotSmall = 256;
+PG_D RotBox rot_box_rows(const Blit& b, int row_lo, int row_hi) {  // rot_box clipped to the rows [row_lo, row_hi)
+    RotBox box = rot_box(b);
+    const int lo = box.y_lo > row_lo ? box.y_lo : row_lo;
+    const int hi = (box.y_lo + box.bh) < row_hi ? (box.y_lo + box.bh) : row_hi;
+    box.y_lo = lo;
+    box.bh = hi - lo;
+    return box;
+}
+
+// kRotInGroups: small rotated draws (a bullet, a puff: ≤ 64 pixels of bounding box on my rows) share a memory round
+// trip with their neighbours in the list like the plain small ones, instead of paying one each (bossfight: dozens of
+// bullets a frame).  Costs registers and code in the group loop, so only kernels with room to spare turn it on.
+template <int kGroup = 4, bool kRotInGroups = false>
 PG_D void wave_replay_rows(uint32_t* fb, const AtlasView& atlas, const Blit& mine, unsigned long long mask, int lane,
                            int row_lo, int row_hi) {
     bool lone = false, reaches = false;
     if ((mask >> lane) & 1ull) {
         if (mine.flip_mod & kRotated) {
-            const RotBox box = rot_box(mine);
-            reaches = box.bw > 0 && box.y_lo < row_hi && box.y_lo + box.bh > row_lo;
-            lone = true;
+            const RotBox box = rot_box_rows(mine, row_lo, row_hi);
+            reaches = box.bw > 0 && box.bh > 0;
+            lone = !kRotInGroups || box.bw * box.bh > 64 || mine.dw > kRotSmall || mine.dh > kRotSmall;
         } else {
             const int x0 = mine.dx > 0 ? mine.dx : 0, y0 = mine.dy > row_lo ? mine.dy : row_lo;
             const int x1 = (mine.dx + mine.dw) < kObsW ? (mine.dx + mine.dw) : kObsW;
@@ -504,7 +550,7 @@ PG_D void wave_replay_rows(uint32_t* fb, const AtlasView& atlas, const Blit& min
         }
     }
     mask = __ballot(reaches);
-    const unsigned long long lones = __ballot(lone);
+    const unsigned long long lones = __ballot(lone && reaches);
     while (mask) {
         uint32_t texel[kGroup];
         int idx[kGroup], mod[kGroup];
@@ -517,25 +563,28 @@ PG_D void wave_replay_rows(uint32_t* fb, const AtlasView& atlas, const Blit& min
             if (mask == 0 || stop) continue;
             const int src = __builtin_ctzll(mask);
             if ((lones >> src) & 1ull) {
-                stop = true;  // a rotated or big one: alone, only at the head of a group
+                stop = true;  // a big one: alone, only at the head of a group
                 if (g == 0) {
                     mask &= mask - 1;
                     const Blit b = blit_from_lane(mine, src);
-                    if (b.flip_mod & kRotated) {
-                        RotBox box = rot_box(b);
-                        const int lo = box.y_lo > row_lo ? box.y_lo : row_lo;
-                        const int hi = (box.y_lo + box.bh) < row_hi ? (box.y_lo + box.bh) : row_hi;
-                        box.y_lo = lo;
-                        box.bh = hi - lo;
-                        wave_blit_rotated(fb, atlas, b, box, lane, 64);
-                    } else {
+                    if (b.flip_mod & kRotated)
+                        wave_blit_rotated(fb, atlas, b, rot_box_rows(b, row_lo, row_hi), lane, 64);
+                    else
                         wave_blit(fb, atlas, b, lane, 0, 1, row_lo, row_hi);
-                    }
                 }
                 continue;
             }
             mask &= mask - 1;
             const Blit b = blit_from_lane(mine, src);
+            if (kRotInGroups && (b.flip_mod & kRotated)) {
+                int at = 0, where = -1;
+                if (rotated_pixel(b, rot_box_rows(b, row_lo, row_hi), lane, where, at)) {
+                    idx[g] = where;
+                    texel[g] = atlas.texels[at];
+                    mod[g] = b.flip_mod & 0xff;
+                }
+                continue;
+            }
             const int x0 = b.dx > 0 ? b.dx : 0, y0 = b.dy > row_lo ? b.dy : row_lo;
             const int x1 = (b.dx + b.dw) < kObsW ? (b.dx + b.dw) : kObsW;
             const int y1 = (b.dy + b.dh) < row_hi ? (b.dy + b.dh) : row_hi;
