@@ -828,12 +828,8 @@ __global__ void __launch_bounds__(64 * kRenderWaves, 4) render_kernel(State s, A
     constexpr int halves = kRenderWaves;
     __shared__ uint32_t fb[kFbWords];
     constexpr int kGrid = 16;  // 64 px / 4.8 px per tile = 13.3 tiles → at most 15 columns/rows in view
-    // the composer's cell table, and — once it is dead — the 64 resolved draws wave 0 hands to wave 1
-    __shared__ union {
-        ComposeLds<kGrid> compose;
-        uint32_t slots[kBlitWords * 64];
-    } shared;
-    ComposeLds<kGrid>& L = shared.compose;
+    __shared__ ComposeLds<kGrid> L;                 // the composer's cell table
+    __shared__ uint32_t slots[kBlitWords * 64];     // the 64 resolved draws of the sprite pass, from wave 1 to wave 0
 #if defined(PG_ABLATE) && defined(PG_LDS_PAD)  // occupancy experiment: fewer envs per CU
     __shared__ uint32_t lds_pad[PG_LDS_PAD];
     if (flags & 0x40000000) {
@@ -886,8 +882,9 @@ __global__ void __launch_bounds__(64 * kRenderWaves, 4) render_kernel(State s, A
     const bool is_agent = lane == first_sprite + n_sprites;
     int spr_e = 0, spr_dyn = 0, spr_tex = 0;
     float spr_x = 0.0f, spr_y = 0.0f, part_life = 0.0f, part_x = 0.0f, part_y = 0.0f;
-    if (half != 0) {
-        // wave 0 resolves the 64 draws of the sprite pass and hands them over (pg_render.h blit_share)
+    if (half != 1) {
+        // wave 1 resolves the 64 draws of the sprite pass — before the frame is composed, while wave 0 sets up the
+        // column side of the composer — and hands them over (pg_render.h blit_share)
     } else if (is_sprite) {
         spr_e = EB(s, EB_DRAW_ORDER, lane - first_sprite, env);
         spr_dyn = DB(s, buf, spr_e, env);
@@ -926,6 +923,67 @@ __global__ void __launch_bounds__(64 * kRenderWaves, 4) render_kernel(State s, A
     const int cols = x1 - x0 + 1, rows = y1 - y0 + 1, cells = cols * rows;
     const int4 tile_desc = descs.uniform(kTexMid);  // every tile texture is 128×128 (checked at make time)
 
+    if (half == 1 && !PG_ABL(flags, 2)) {  // the sprite pass's draws, resolved ahead of the frame (see above)
+        {
+            bool has = false;
+            const int4 spark_d = descs.uniform(kTexSpark);
+            // every lane asks for the descriptor it needs with a cross-lane read, so do that outside the branches
+            int want_tex = 0;
+            if (is_sprite) {
+                want_tex = spr_tex + ((spr_dyn & kDynFrame) ? 1 : 0);
+            } else if (is_agent) {
+                const bool ground = (sflags & kFlagGround) != 0;
+                if (fabsf(SF(s, F_AVX, env)) < 0.01f && ground)
+                    want_tex = kTexStand + alien;
+                else if (!ground)
+                    want_tex = kTexJump + alien;
+                else if (SF(s, F_APHASE, env) > 0.5f)
+                    want_tex = kTexWalk2 + alien;
+                else
+                    want_tex = kTexWalk1 + alien;
+            }
+            const int4 d = descs.at(want_tex);
+            // The three kinds of draw differ only in their parameters: pick them per lane, then resolve once.  (One
+            // resolve_draw per kind in its own branch made every wave run its ~180 vector instructions three times.)
+            bool go = false, flip = false;
+            int tw = d.y, th = d.z, tex_at = d.x;
+            float wx = 0.0f, wy = 0.0f, scale_num = kUnitPx, alpha = 1.0f;
+            if (is_part) {  // System_Particles::render (common_systems.cpp:315-337), as `particle` above
+                if (part_life > 0.0f) {
+                    const float lr = (5.0f - part_life) / 5.0f;
+                    alpha = 0.5f * (1.0f - lr);
+                    const float scale = 0.45f * (0.4f * lr + 0.6f);
+                    const float oy = -lr * 0.17f;
+                    tw = spark_d.y;
+                    th = spark_d.z;
+                    tex_at = spark_d.x;
+                    wx = part_x * kUnitPx - 0.5f * spark_d.y * scale;
+                    wy = (part_y + oy) * kUnitPx - 0.5f * spark_d.z * scale;
+                    scale_num = scale * kUnitPx;
+                    go = true;
+                }
+            } else if (is_sprite) {
+                if (spr_dyn & kDynTexSet) {
+                    const float scale = 1.0f * 1.0f;
+                    wx = (spr_x + -0.5f) * kUnitPx;
+                    wy = (spr_y + -0.5f) * kUnitPx;
+                    scale_num = scale * kUnitPx;
+                    flip = (spr_dyn & kDynFlip) != 0;
+                    go = true;
+                }
+            } else if (is_agent) {
+                const float px = SF(s, F_AX, env) - 0.5f, py = SF(s, F_AY, env) - 2.0f;
+                wx = px * kUnitPx;
+                wy = py * kUnitPx;
+                flip = (sflags & kFlagForward) == 0;
+                go = true;
+            }
+            if (go)
+                has = resolve_draw(cam, tw, th, tex_at, wx, wy, scale_num / static_cast<float>(tw), alpha, flip, false,
+                                   mine);
+            blit_share(slots, lane, mine, has);
+        }
+    }
     const BgAxis bga = bg_axis(cam, bg_d, bg_px, bg_py, bg_sc, half);  // wave 0: x axis, wave 1: y axis
     bool composed = false;
     if (!(flags & 1) && !PG_ABL(flags, 4) && cols <= kGrid && rows <= kGrid) {
@@ -959,8 +1017,8 @@ __global__ void __launch_bounds__(64 * kRenderWaves, 4) render_kernel(State s, A
             L.base[cell] = (t == kEmpty) ? static_cast<int32_t>(kNoTexel) : off * 4;
             if (t != kEmpty && soft != 0 && r < rows && c < cols) soft_rows |= 1u << r;
         }
-        if (soft_rows) atomicOr(&L.soft_rows, static_cast<int32_t>(soft_rows));
-        if (hard_rows) atomicOr(&L.hard_rows, static_cast<int32_t>(hard_rows));
+        if (soft_rows) atomicOr(&L.soft_rows[half], static_cast<int32_t>(soft_rows));
+        if (hard_rows) atomicOr(&L.hard_rows[half], static_cast<int32_t>(hard_rows));
         __syncthreads();
         composed = compose_rows(fb, L, atlas, bga, cols, rows, tile_desc.y, lane, flags, half, halves);
     }
@@ -1029,69 +1087,8 @@ __global__ void __launch_bounds__(64 * kRenderWaves, 4) render_kernel(State s, A
                 wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
             }
         }
-        // The composer's tables are dead by now (its last barrier is behind both waves): their LDS carries the resolved
-        // draws from wave 0 to wave 1.
-        uint32_t* slots = shared.slots;
-        bool has = false;
-        if (half == 0) {
-            // every lane asks for the descriptor it needs with a cross-lane read, so do that outside the branches
-            int want_tex = 0;
-            if (is_sprite) {
-                want_tex = spr_tex + ((spr_dyn & kDynFrame) ? 1 : 0);
-            } else if (is_agent) {
-                const bool ground = (sflags & kFlagGround) != 0;
-                if (fabsf(SF(s, F_AVX, env)) < 0.01f && ground)
-                    want_tex = kTexStand + alien;
-                else if (!ground)
-                    want_tex = kTexJump + alien;
-                else if (SF(s, F_APHASE, env) > 0.5f)
-                    want_tex = kTexWalk2 + alien;
-                else
-                    want_tex = kTexWalk1 + alien;
-            }
-            const int4 d = descs.at(want_tex);
-            // The three kinds of draw differ only in their parameters: pick them per lane, then resolve once.  (One
-            // resolve_draw per kind in its own branch made every wave run its ~180 vector instructions three times.)
-            bool go = false, flip = false;
-            int tw = d.y, th = d.z, tex_at = d.x;
-            float wx = 0.0f, wy = 0.0f, scale_num = kUnitPx, alpha = 1.0f;
-            if (is_part) {  // System_Particles::render (common_systems.cpp:315-337), as `particle` above
-                if (part_life > 0.0f) {
-                    const float lr = (5.0f - part_life) / 5.0f;
-                    alpha = 0.5f * (1.0f - lr);
-                    const float scale = 0.45f * (0.4f * lr + 0.6f);
-                    const float oy = -lr * 0.17f;
-                    tw = spark_d.y;
-                    th = spark_d.z;
-                    tex_at = spark_d.x;
-                    wx = part_x * kUnitPx - 0.5f * spark_d.y * scale;
-                    wy = (part_y + oy) * kUnitPx - 0.5f * spark_d.z * scale;
-                    scale_num = scale * kUnitPx;
-                    go = true;
-                }
-            } else if (is_sprite) {
-                if (spr_dyn & kDynTexSet) {
-                    const float scale = 1.0f * 1.0f;
-                    wx = (spr_x + -0.5f) * kUnitPx;
-                    wy = (spr_y + -0.5f) * kUnitPx;
-                    scale_num = scale * kUnitPx;
-                    flip = (spr_dyn & kDynFlip) != 0;
-                    go = true;
-                }
-            } else if (is_agent) {
-                const float px = SF(s, F_AX, env) - 0.5f, py = SF(s, F_AY, env) - 2.0f;
-                wx = px * kUnitPx;
-                wy = py * kUnitPx;
-                flip = (sflags & kFlagForward) == 0;
-                go = true;
-            }
-            if (go)
-                has = resolve_draw(cam, tw, th, tex_at, wx, wy, scale_num / static_cast<float>(tw), alpha, flip, false,
-                                   mine);
-            blit_share(slots, lane, mine, has);
-        }
-        __syncthreads();
-        if (half != 0) has = blit_take(slots, lane, mine);
+        // the draws wave 1 resolved before the frame was composed (several barriers ago)
+        const bool has = blit_take(slots, lane, mine);
         wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
     }
     // each wave stores the rows it owns (pg_render.h wave_replay_rows): no barrier

@@ -53,9 +53,10 @@ template <int GRID>
 struct ComposeLds {
     int32_t base[GRID * GRID + 2];  // [row][col] byte offset of the cell's tile texture in the atlas, kNoTexel = no tile;
                                     // the two extra words are always kNoTexel (the cells of a pixel row no grid row covers)
-    int32_t too_wide;           // some span is wider than kMaxSpan pixels → fall back
-    int32_t hard_rows;          // same layout: where compose_rows does not attempt its one-texel-per-pixel fast path
-    int32_t soft_rows;          // bit r: grid row r shows a tile texture with texels that are not opaque (descriptor .w);
+    // flags in pairs, one word per wavefront (each wave initialises and sets its own; readers OR the two):
+    int32_t too_wide[2];        // some span is wider than kMaxSpan pixels → fall back
+    int32_t hard_rows[2];       // same layout as soft_rows: where compose_rows does not attempt its one-texel-per-pixel fast path
+    int32_t soft_rows[2];       // bit r: grid row r shows a tile texture with texels that are not opaque (descriptor .w);
                                 // bit 31: the background has some.  compose_spans sets it to its soft_init argument
                                 // (default −1, "assume all"); a staging pass that knows better ORs exact bits in.
 };
@@ -700,32 +701,36 @@ template <int GRID, int MAXSPAN = kMaxSpan>
 PG_D void compose_spans(uint32_t* fb, ComposeLds<GRID>& L, const Camera& cam, int x0, int y0, int cols, int rows, int tw,
                         int th, float tile_scale, int lane, int th2 = 0, int half = 0, int halves = 1,
                         int32_t soft_init = -1, int32_t hard_init = -1) {
+    // Two wavefronts, one axis each (wave 0: columns, wave 1: rows), and nothing of one axis is read by the other
+    // wave before the barrier that follows the caller's staging of L.base — so there is no barrier in here: every
+    // table below is written and read by the same wave (LDS operations of a wave complete in order), and the flags
+    // come in pairs, one word per wave.
+    (void)halves;
     ComposeTmp<GRID>& T = compose_tmp<GRID>(fb);
-    if (half == 0) {
-        T.cover_n[0][lane] = 0;
-        T.cover_n[1][lane] = 0;
-        if (lane == 0) {
-            L.too_wide = 0;
-            L.soft_rows = soft_init;
-            L.hard_rows = hard_init;
+    const int axis = half;
+    T.cover_n[axis][lane] = 0;
+    if (lane == 0) {
+        L.too_wide[half] = 0;
+        L.soft_rows[half] = soft_init;
+        L.hard_rows[half] = hard_init;
+        if (half == 0) {
             compose_hand<GRID>(fb).bad = 0;
             L.base[GRID * GRID] = L.base[GRID * GRID + 1] = static_cast<int32_t>(0x40000000u);  // kNoTexel (declared below)
         }
     }
-    __syncthreads();
     bool wide = false;
-    const bool do_cols = halves == 1 || half == 0, do_rows = halves == 1 || half == 1;  // one axis per wave
-    if (do_cols && lane < cols) {
-        Span sp;
-        const bool ok = resolve_axis(cam.px, cam.sw, cam.scale, tw, (x0 + lane) * kUnitPx, tile_scale, false, false, sp);
-        T.col[lane] = ok ? make_int4(sp.d0, sp.dn, sp.s0, sp.sn) : make_int4(0, 0, 0, 0);
-        wide = ok && sp.dn > MAXSPAN;
-    }
-    if (do_rows && lane < rows) {
+    if (axis == 0) {
+        if (lane < cols) {
+            Span sp;
+            const bool ok = resolve_axis(cam.px, cam.sw, cam.scale, tw, (x0 + lane) * kUnitPx, tile_scale, false, false, sp);
+            T.col[lane] = ok ? make_int4(sp.d0, sp.dn, sp.s0, sp.sn) : make_int4(0, 0, 0, 0);
+            wide = ok && sp.dn > MAXSPAN;
+        }
+    } else if (lane < rows) {
         Span sp;
         const bool ok = resolve_axis(cam.py, cam.sh, cam.scale, th, (y0 + lane) * kUnitPx, tile_scale, false, true, sp);
         T.row[lane] = ok ? make_int4(sp.d0, sp.dn, sp.s0, sp.sn) : make_int4(0, 0, 0, 0);
-        wide = wide || (ok && sp.dn > MAXSPAN);
+        wide = ok && sp.dn > MAXSPAN;
         if (th2 > 0) {
             Span s2;
             const bool ok2 =
@@ -734,22 +739,19 @@ PG_D void compose_spans(uint32_t* fb, ComposeLds<GRID>& L, const Camera& cam, in
             wide = wide || (ok2 && (!ok || s2.d0 != sp.d0 || s2.dn > sp.dn));  // not nested: take the fallback
         }
     }
-    if (wide) L.too_wide = 1;
-    __syncthreads();
-    if (L.too_wide) return;
-#pragma unroll
-    for (int axis = 0; axis < 2; axis++) {
-        if (halves >= 2 && axis != half) continue;
-        const int4* spans = axis == 0 ? T.col : T.row;
-        const int count = axis == 0 ? cols : rows;
-        for (int q = lane; q < count * MAXSPAN; q += 64) {
-            const int g = q / MAXSPAN, i = q % MAXSPAN;
-            const int4 sp = spans[g];
-            const int p = sp.x + i;
-            if (sp.w > 0 && i < sp.y && p >= 0 && p < 64) {
-                const int slot = atomicAdd(&T.cover_n[axis][p], 1);
-                if (slot < 2) T.cover[axis][p][slot] = g | (sample_index(sp.z, sp.w, i, sp.y) << 8);
-            }
+    if (__ballot(wide)) {  // some span is wider than MAXSPAN pixels: the caller's compose_rows will decline
+        if (lane == 0) L.too_wide[half] = 1;
+        return;
+    }
+    const int4* spans = axis == 0 ? T.col : T.row;
+    const int count = axis == 0 ? cols : rows;
+    for (int q = lane; q < count * MAXSPAN; q += 64) {
+        const int g = q / MAXSPAN, i = q % MAXSPAN;
+        const int4 sp = spans[g];
+        const int p = sp.x + i;
+        if (sp.w > 0 && i < sp.y && p >= 0 && p < 64) {
+            const int slot = atomicAdd(&T.cover_n[axis][p], 1);
+            if (slot < 2) T.cover[axis][p][slot] = g | (sample_index(sp.z, sp.w, i, sp.y) << 8);
         }
     }
 }
@@ -821,7 +823,7 @@ template <int GRID, bool TWO = false>
 PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView& atlas, const BgAxis& bga, int cols, int rows,
                        int tw, int lane, int ablate, int half, int halves) {
     static_assert(GRID <= 31 || true, "");
-    if (L.too_wide) return false;
+    if (L.too_wide[0] | L.too_wide[1]) return false;
     const ComposeTmp<GRID>& T = compose_tmp<GRID>(fb);
     ComposeHand& H = compose_hand<GRID>(fb);
     // All texel reads go through one buffer descriptor over the atlas: 32-bit byte offsets, and out-of-range
@@ -877,7 +879,8 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
             }
             H.row2[lane] = make_uint2(row_a2, row_b2);
         }
-        const uint32_t soft_bits = static_cast<uint32_t>(L.soft_rows), hard_bits = static_cast<uint32_t>(L.hard_rows);
+        const uint32_t soft_bits = static_cast<uint32_t>(L.soft_rows[0] | L.soft_rows[1]);
+        const uint32_t hard_bits = static_cast<uint32_t>(L.hard_rows[0] | L.hard_rows[1]);
         // (grids beyond 31 rows alias in these masks: conservative)
         const bool soft_here = (soft_bits >> 31) != 0 || (ra >= 0 && ((soft_bits >> (ra & 31)) & 1u)) ||
                                (rb >= 0 && ((soft_bits >> (rb & 31)) & 1u));

@@ -85,17 +85,36 @@ def test_oracle_frame_checksums_in_every_distribution_mode():
         assert _frame_crcs(game, int(seed), int(steps), int(mode)) == want, key
 
 
-def test_oracle_reset_frame_has_no_sprites_and_reseed_repeats():
-    """D2 (reset frame drawn before the first sprite update) and the reset "seed" option (coinrun.cpp:313-317)."""
+def test_oracle_reseeded_reset_repeats_the_level_and_keeps_the_old_camera():
+    """The reset "seed" option (coinrun.cpp:313-317) rebuilds the same level, and D3: the reset frame is drawn with the
+    camera the previous episode's last step left (coinrun/common_systems.cpp:238-239 is the only writer), so the two
+    reset frames of the same level differ exactly by that camera."""
     oracle_util.register_textures("coinrun")
     L = oracle_util.oracle()
+
+    def state(h):
+        buf = (ctypes.c_float * 512)()
+        n = L.pgo_dump_state(h, buf, 512)
+        return np.array(buf[:min(n, 512)], np.float32)
+
+    def tiles(h):
+        buf = (ctypes.c_uint8 * 4096)()
+        n = L.pgo_dump_tiles(h, buf, 4096)
+        return np.array(buf[:n], np.uint8)
+
     h = L.pgo_make(b"coinrun", 5, 1)
     L.pgo_reset(h, 1, 77)
-    a = np.ctypeslib.as_array(L.pgo_obs(h), shape=(12288,)).copy()
+    a, sa, ta = np.ctypeslib.as_array(L.pgo_obs(h), shape=(12288,)).copy(), state(h), tiles(h)
+    assert sa[7] == 0.0 and sa[8] == 0.0  # camera {0, 0}: nothing has stepped since make (renderer.h:17)
     for _ in range(10):
-        L.pgo_step(h, 7)
+        L.pgo_step(h, 7)  # walk right: the camera follows the agent
+    cam = state(h)[7:9].copy()
+    assert cam[0] > 0.0
     L.pgo_reset(h, 1, 77)
-    b = np.ctypeslib.as_array(L.pgo_obs(h), shape=(12288,)).copy()
+    b, sb, tb = np.ctypeslib.as_array(L.pgo_obs(h), shape=(12288,)).copy(), state(h), tiles(h)
     L.pgo_close(h)
-    # same seed → same level and backdrop; only the camera differs (D3: reset frame uses the last camera)
-    assert a.shape == b.shape and a.any() and b.any()
+    assert np.array_equal(ta, tb)                      # same seed → same level
+    assert np.array_equal(sa[9:], sb[9:])              # … same themes, backdrop, entities
+    assert np.array_equal(sb[7:9], cam)                # the camera is the one the last step left (D3)
+    assert not np.array_equal(a, b)                    # so the two reset frames of one level differ
+    assert np.array_equal(sa[:7], sb[:7])              # agent spawn state identical

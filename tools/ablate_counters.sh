@@ -5,7 +5,7 @@ TAG=${1:-r02}
 mkdir -p $(dirname $R/gpurun_out/${TAG}_x)
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/abl_$TAG
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d /tmp/abl_$TAG -- python3 $R/tools/ablate_counters.py run > $R/gpurun_out/${TAG}_ablate.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d /tmp/abl_$TAG -- python3 $R/tools/ablate_counters.py run > $R/gpurun_out/${TAG}_ablate.log 2>&1
 python3 - <<PY
 import csv, glob, json, collections
 plan = json.loads([l for l in open("$R/gpurun_out/${TAG}_ablate.log") if l.startswith('{"settle"')][-1])

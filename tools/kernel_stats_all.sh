@@ -2,11 +2,11 @@
 # rocprofv3 --kernel-trace --stats of bench.py for every game (default modes): per-kernel average durations.
 # Output: gpurun_out/<tag>_<game>_kernel_stats.csv
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r01_k}
+TAG=${1:-r02_k}
 cd /tmp && export TMPDIR=/tmp
 for G in coinrun maze bossfight climber caveflyer chaser jumper; do
   rm -rf /tmp/ks_$G
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$G -- python3 $R/bench.py --game $G --steps 128 --warmup 32 --no-cpu-baseline > $R/gpurun_out/${TAG}_$G.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$G -- python3 $R/bench.py --game $G --steps 128 --warmup 32 --no-cpu-baseline > $R/gpurun_out/${TAG}_$G.log 2>&1
   f=$(ls /tmp/ks_$G/*/*kernel_stats.csv 2>/dev/null | head -1)
   [ -n "$f" ] && cp "$f" $R/gpurun_out/${TAG}_${G}_kernel_stats.csv
 done

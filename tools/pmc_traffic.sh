@@ -2,17 +2,17 @@
 # HBM traffic of the step kernels from PMC counters: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (TCC slots:
 # MI355X_MICROARCH.md §rocprofv3 PMC slots), each with --kernel-trace only.  Output: gpurun_out/<tag>_traffic.json
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r01}
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/${TAG}_pmc_$C -- python3 $R/bench.py --steps 16 --warmup 4 --no-cpu-baseline > $R/gpurun_out/${TAG}_pmc_$C.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/${TAG//\//_}_pmc_$C -- python3 $R/bench.py --steps 16 --warmup 4 --no-cpu-baseline > $R/gpurun_out/${TAG}_pmc_$C.log 2>&1
 done
 python3 - <<PY
 import csv,glob,collections,json
 out={}
 for c in ("FETCH_SIZE","WRITE_SIZE"):
     agg=collections.defaultdict(float); cnt=collections.Counter()
-    for fn in glob.glob("$R/gpurun_out/${TAG}_pmc_%s/*/*counter_collection.csv"%c):
+    for fn in glob.glob("/tmp/${TAG//\//_}_pmc_%s/*/*counter_collection.csv"%c):
         for r in csv.DictReader(open(fn)):
             if r["Counter_Name"]!=c: continue
             k=r["Kernel_Name"].split("(")[0]
