@@ -23,7 +23,7 @@ LIB = os.path.join(HERE, "lib")
 OBJ = os.path.join(HERE, "build")
 ARCH = "gfx950"
 
-COMMON = ["--offload-arch=" + ARCH, "-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
+COMMON = os.environ.get("PG_MORE_FLAGS", "").split() + ["--offload-arch=" + ARCH, "-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
           "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-I" + CSRC]
 
 KERNEL_SOURCES = ["coinrun.hip", "maze.hip", "bossfight.hip", "climber.hip", "caveflyer.hip", "chaser.hip", "jumper.hip"]

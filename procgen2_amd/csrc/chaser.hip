@@ -797,6 +797,7 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
                 const int slot = n_seen + __popcll(others & ((1ull << lane) - 1ull));
                 seen[slot] = make_int4(mine.dx, mine.dy, mine.dx + mine.dw, mine.dy + mine.dh);
             }
+            wave_order();  // (the rectangles of earlier passes are read by other lanes than wrote them)
             // a point is kept if a non-point draw EARLIER in the list touches it: those of earlier passes (all of
             // them precede it), and those of this pass at lower lanes
             bool keep = !is_point;

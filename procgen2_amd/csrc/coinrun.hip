@@ -985,7 +985,8 @@ __global__ void __launch_bounds__(64 * kRenderWaves, 4) render_kernel(State s, A
         }
     }
     const BgAxis bga = bg_axis(cam, bg_d, bg_px, bg_py, bg_sc, half);  // wave 0: x axis, wave 1: y axis
-    bool composed = false;
+    bool composed = false, sprites_ready = false;
+    ReplayState<4> sprite_pass;
     if (!(flags & 1) && !PG_ABL(flags, 4) && cols <= kGrid && rows <= kGrid) {
         compose_spans(fb, L, cam, x0, y0, cols, rows, tile_desc.y, tile_desc.z, kUnitPx / tile_desc.y, lane, 0, half, halves,
                       /*soft_init=*/0, /*hard_init=*/0);  // exact bits are ORed in below
@@ -1020,6 +1021,12 @@ __global__ void __launch_bounds__(64 * kRenderWaves, 4) render_kernel(State s, A
         if (soft_rows) atomicOr(&L.soft_rows[half], static_cast<int32_t>(soft_rows));
         if (hard_rows) atomicOr(&L.hard_rows[half], static_cast<int32_t>(hard_rows));
         __syncthreads();
+        // the draws wave 1 resolved: the texels of the first few are requested now and arrive while the frame is composed
+        sprites_ready = !PG_ABL(flags, 2);
+        if (sprites_ready) {
+            const bool has = blit_take(slots, lane, mine);
+            sprite_pass = replay_begin(atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
+        }
         composed = compose_rows(fb, L, atlas, bga, cols, rows, tile_desc.y, lane, flags, half, halves);
     }
     if (PG_ABL(flags, 4)) composed = true;  // (bit 2: timing experiment — no background/tiles at all)
@@ -1077,19 +1084,23 @@ __global__ void __launch_bounds__(64 * kRenderWaves, 4) render_kernel(State s, A
                                 false, false, out);
         };
         if (!one_pass) {  // many mobs: particles in rounds of 64 first
+            Blit spark;  // (`mine` holds the draws of the pass that is already under way)
             for (int base = 0; base < n_parts; base += 64) {
                 bool has = false;
                 if (base + lane < n_parts) {
                     const int idx = base + lane, m = idx / kSparks, k = idx - m * kSparks;
                     const int e = EB(s, EB_SPARK_ORDER, m, env);
-                    has = particle(SP(s, buf, 2, e, k, env), SP(s, buf, 0, e, k, env), SP(s, buf, 1, e, k, env), mine);
+                    has = particle(SP(s, buf, 2, e, k, env), SP(s, buf, 0, e, k, env), SP(s, buf, 1, e, k, env), spark);
                 }
-                wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
+                wave_replay_rows(fb, atlas, spark, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
             }
         }
         // the draws wave 1 resolved before the frame was composed (several barriers ago)
-        const bool has = blit_take(slots, lane, mine);
-        wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
+        if (!sprites_ready) {  // (the draw-list replay path did not get that far)
+            const bool has = blit_take(slots, lane, mine);
+            sprite_pass = replay_begin(atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
+        }
+        replay_finish(fb, atlas, mine, sprite_pass, lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
     }
     // each wave stores the rows it owns (pg_render.h wave_replay_rows): no barrier
     if (!PG_ABL(flags, 8))

@@ -143,6 +143,17 @@ PG_D Blit blit_from_lane(const Blit& mine, int src) {
 
 PG_D void blend_into(uint32_t* fb, int idx, uint32_t texel, int mod);
 
+// Consecutive draws of one wavefront may overlap, and a pixel is in general touched by a different LANE in each of
+// them.  The hardware keeps a wave's LDS accesses in instruction order, but the language only orders the accesses of
+// one thread: the compiler is free to let the lanes that sit out draw k (a branch on their own data) start on draw
+// k + 1 before the others have done k.  wave_order() is the line it may not move anything across nor split the wave
+// around: every lane's accesses above it happen before any lane's accesses below it.  No instructions.
+PG_D void wave_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 PG_D uint32_t max3_u32(uint32_t a, uint32_t b, uint32_t c) {  // v_max3_u32
     const uint32_t m = a > b ? a : b;
     return m > c ? m : c;
@@ -533,9 +544,75 @@ PG_D RotBox rot_box_rows(const Blit& b, int row_lo, int row_hi) {  // rot_box cl
 // kRotInGroups: small rotated draws (a bullet, a puff: ≤ 64 pixels of bounding box on my rows) share a memory round
 // trip with their neighbours in the list like the plain small ones, instead of paying one each (bossfight: dozens of
 // bullets a frame).  Costs registers and code in the group loop, so only kernels with room to spare turn it on.
-template <int kGroup = 4, bool kRotInGroups = false>
-PG_D void wave_replay_rows(uint32_t* fb, const AtlasView& atlas, const Blit& mine, unsigned long long mask, int lane,
-                           int row_lo, int row_hi) {
+// The pass in two halves, for kernels that have their draws resolved before the frame is composed: replay_begin
+// classifies the draws and requests the texels of the first group, the caller composes the frame — a memory round trip
+// of its own — and replay_finish blends that group and goes on.  wave_replay_rows is the two back to back.
+template <int kGroup>
+struct ReplayState {
+    unsigned long long mask, lones;  // draws still to do (those that reach my rows); which of them go alone
+    uint32_t texel[kGroup];
+    int idx[kGroup], mod[kGroup];
+};
+
+template <int kGroup, bool kRotInGroups>
+PG_D void replay_group(const AtlasView& atlas, const Blit& mine, ReplayState<kGroup>& st, int lane, int row_lo, int row_hi,
+                       uint32_t* fb_for_lone) {
+    // requests the texels of the next ≤ kGroup small draws; a big draw at the head of the group is executed on the spot
+    // (fb_for_lone; nullptr = stop in front of it instead)
+    bool stop = false;
+#pragma unroll
+    for (int g = 0; g < kGroup; g++) {
+        st.idx[g] = -1;
+        st.texel[g] = 0;
+        st.mod[g] = 255;
+        if (st.mask == 0 || stop) continue;
+        const int src = __builtin_ctzll(st.mask);
+        if ((st.lones >> src) & 1ull) {
+            stop = true;  // a big one: alone, only at the head of a group
+            if (g == 0 && fb_for_lone != nullptr) {
+                st.mask &= st.mask - 1;
+                const Blit b = blit_from_lane(mine, src);
+                wave_order();
+                if (b.flip_mod & kRotated)
+                    wave_blit_rotated(fb_for_lone, atlas, b, rot_box_rows(b, row_lo, row_hi), lane, 64);
+                else
+                    wave_blit(fb_for_lone, atlas, b, lane, 0, 1, row_lo, row_hi);
+                wave_order();
+            }
+            continue;
+        }
+        st.mask &= st.mask - 1;
+        const Blit b = blit_from_lane(mine, src);
+        if (kRotInGroups && (b.flip_mod & kRotated)) {
+            int at = 0, where = -1;
+            if (rotated_pixel(b, rot_box_rows(b, row_lo, row_hi), lane, where, at)) {
+                st.idx[g] = where;
+                st.texel[g] = atlas.texels[at];
+                st.mod[g] = b.flip_mod & 0xff;
+            }
+            continue;
+        }
+        const int x0 = b.dx > 0 ? b.dx : 0, y0 = b.dy > row_lo ? b.dy : row_lo;
+        const int x1 = (b.dx + b.dw) < kObsW ? (b.dx + b.dw) : kObsW;
+        const int y1 = (b.dy + b.dh) < row_hi ? (b.dy + b.dh) : row_hi;
+        const int cw = x1 - x0, ch = y1 - y0;
+        if (lane >= cw * ch) continue;
+        const int ry = udiv_small(lane, cw);
+        const int rx = lane - ry * cw;
+        const int x = x0 + rx, y = y0 + ry;
+        int i = x - b.dx, j = y - b.dy;
+        if (b.flip_mod & kFlipH) i = b.dw - 1 - i;
+        if (b.flip_mod & kFlipV) j = b.dh - 1 - j;
+        const int u = sample_index(b.sx, b.sw, i, b.dw);
+        const int v = sample_index(b.sy, b.sh, j, b.dh);
+        st.idx[g] = y * kObsW + x;
+        st.texel[g] = atlas.texels[b.tex_off + v * b.tex_w + u];
+        st.mod[g] = b.flip_mod & 0xff;
+    }
+}
+
+template <int kGroup, bool kRotInGroups>
+PG_D ReplayState<kGroup> replay_classify(const Blit& mine, unsigned long long mask, int lane, int row_lo, int row_hi) {
     bool lone = false, reaches = false;
     if ((mask >> lane) & 1ull) {
         if (mine.flip_mod & kRotated) {
@@ -550,63 +627,43 @@ PG_D void wave_replay_rows(uint32_t* fb, const AtlasView& atlas, const Blit& min
             lone = reaches && (x1 - x0) * (y1 - y0) > 64;
         }
     }
-    mask = __ballot(reaches);
-    const unsigned long long lones = __ballot(lone && reaches);
-    while (mask) {
-        uint32_t texel[kGroup];
-        int idx[kGroup], mod[kGroup];
-        bool stop = false;
+    ReplayState<kGroup> st;
+    st.mask = __ballot(reaches);
+    st.lones = __ballot(lone && reaches);
+    return st;
+}
+
+template <int kGroup = 4, bool kRotInGroups = false>
+PG_D ReplayState<kGroup> replay_begin(const AtlasView& atlas, const Blit& mine, unsigned long long mask, int lane,
+                                      int row_lo, int row_hi) {
+    ReplayState<kGroup> st = replay_classify<kGroup, kRotInGroups>(mine, mask, lane, row_lo, row_hi);
+    replay_group<kGroup, kRotInGroups>(atlas, mine, st, lane, row_lo, row_hi, nullptr);  // (a big draw first: nothing requested)
+    return st;
+}
+
+template <int kGroup = 4, bool kRotInGroups = false>
+PG_D void replay_finish(uint32_t* fb, const AtlasView& atlas, const Blit& mine, ReplayState<kGroup>& st, int lane,
+                        int row_lo, int row_hi) {
+    wave_order();  // what the caller put into these rows in the meantime
+    for (;;) {
 #pragma unroll
         for (int g = 0; g < kGroup; g++) {
-            idx[g] = -1;
-            texel[g] = 0;
-            mod[g] = 255;
-            if (mask == 0 || stop) continue;
-            const int src = __builtin_ctzll(mask);
-            if ((lones >> src) & 1ull) {
-                stop = true;  // a big one: alone, only at the head of a group
-                if (g == 0) {
-                    mask &= mask - 1;
-                    const Blit b = blit_from_lane(mine, src);
-                    if (b.flip_mod & kRotated)
-                        wave_blit_rotated(fb, atlas, b, rot_box_rows(b, row_lo, row_hi), lane, 64);
-                    else
-                        wave_blit(fb, atlas, b, lane, 0, 1, row_lo, row_hi);
-                }
-                continue;
-            }
-            mask &= mask - 1;
-            const Blit b = blit_from_lane(mine, src);
-            if (kRotInGroups && (b.flip_mod & kRotated)) {
-                int at = 0, where = -1;
-                if (rotated_pixel(b, rot_box_rows(b, row_lo, row_hi), lane, where, at)) {
-                    idx[g] = where;
-                    texel[g] = atlas.texels[at];
-                    mod[g] = b.flip_mod & 0xff;
-                }
-                continue;
-            }
-            const int x0 = b.dx > 0 ? b.dx : 0, y0 = b.dy > row_lo ? b.dy : row_lo;
-            const int x1 = (b.dx + b.dw) < kObsW ? (b.dx + b.dw) : kObsW;
-            const int y1 = (b.dy + b.dh) < row_hi ? (b.dy + b.dh) : row_hi;
-            const int cw = x1 - x0, ch = y1 - y0;
-            if (lane >= cw * ch) continue;
-            const int ry = udiv_small(lane, cw);
-            const int rx = lane - ry * cw;
-            const int x = x0 + rx, y = y0 + ry;
-            int i = x - b.dx, j = y - b.dy;
-            if (b.flip_mod & kFlipH) i = b.dw - 1 - i;
-            if (b.flip_mod & kFlipV) j = b.dh - 1 - j;
-            const int u = sample_index(b.sx, b.sw, i, b.dw);
-            const int v = sample_index(b.sy, b.sh, j, b.dh);
-            idx[g] = y * kObsW + x;
-            texel[g] = atlas.texels[b.tex_off + v * b.tex_w + u];
-            mod[g] = b.flip_mod & 0xff;
+            if (st.idx[g] >= 0) blend_into(fb, st.idx[g], st.texel[g], st.mod[g]);
+            wave_order();  // draws may overlap
         }
-#pragma unroll
-        for (int g = 0; g < kGroup; g++)
-            if (idx[g] >= 0) blend_into(fb, idx[g], texel[g], mod[g]);  // same wave, program order: draws may overlap
+        if (st.mask == 0) break;
+        replay_group<kGroup, kRotInGroups>(atlas, mine, st, lane, row_lo, row_hi, fb);
     }
+}
+
+// kRotInGroups: small rotated draws (a bullet, a puff: ≤ 64 pixels of bounding box on my rows) share a memory round
+// trip with their neighbours in the list like the plain small ones, instead of paying one each (bossfight: dozens of
+// bullets a frame).  Costs registers and code in the group loop, so only kernels with room to spare turn it on.
+template <int kGroup = 4, bool kRotInGroups = false>
+PG_D void wave_replay_rows(uint32_t* fb, const AtlasView& atlas, const Blit& mine, unsigned long long mask, int lane,
+                           int row_lo, int row_hi) {
+    ReplayState<kGroup> st = replay_begin<kGroup, kRotInGroups>(atlas, mine, mask, lane, row_lo, row_hi);
+    replay_finish<kGroup, kRotInGroups>(fb, atlas, mine, st, lane, row_lo, row_hi);
 }
 
 // A draw that is the same in every frame of every env (a HUD element at a fixed place on the observation), prepared
@@ -621,15 +678,17 @@ PG_D void overlay_rows(uint32_t* fb, const uint32_t* image, const uint2* list, i
     uint32_t t[kRows];
 #pragma unroll
     for (int k = 0; k < kRows; k++) t[k] = image[(row_lo + k) * kObsW + lane];
+    wave_order();
 #pragma unroll
     for (int k = 0; k < kRows; k++)
         if (t[k] >= 0xff000000u) fb[(row_lo + k) * kObsW + lane] = t[k];
+    wave_order();
     for (int e = lane; e < list_n; e += 64) {
         const uint2 item = list[e];
         const int row = static_cast<int>(item.x >> 6);
         if (item.x != 0xffffffffu && row >= row_lo && row < row_hi) blend_into(fb, static_cast<int>(item.x), item.y, 255);
     }
-    (void)row_hi;
+    wave_order();
 }
 
 // The rows wave `half` of `halves` owns, and their share of the finished frame on its way out (no barrier needed
@@ -637,6 +696,7 @@ PG_D void overlay_rows(uint32_t* fb, const uint32_t* image, const uint2* list, i
 PG_D void wave_store_rows(const uint32_t* fb, uint8_t* obs_env, int lane, int row_lo, int row_hi) {
     Rgb4* out = reinterpret_cast<Rgb4*>(obs_env);
     const uint4* in = reinterpret_cast<const uint4*>(fb);
+    wave_order();  // the wave's own blends, lane-to-pixel mapping of the draws
     for (int g = row_lo * (kObsW / 4) + lane; g < row_hi * (kObsW / 4); g += 64) {
         const uint4 p = in[g];
         Rgb4 o;
@@ -1041,7 +1101,10 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
         return true;
     }
     const uint32_t seconds32 = static_cast<uint32_t>(second_row >> py_begin);
-    uint32_t top[kRows];
+    // The gathers land straight in the target: `buffer_load … lds` writes lane l's dword to LDS at M0 + 4·l, which is
+    // exactly pixel (row, l) of a row-major target — no result registers (32 of them otherwise, the kernel's register
+    // peak), no stores.  Out-of-range lanes write 0 (checked on the hardware: tools/probe/lds_direct_load.hip).
+    using lds_ptr = __attribute__((address_space(3))) void*;
 #pragma unroll
     for (int k = 0; k < kRows; k++) {
         const int py = py_begin + k;
@@ -1063,20 +1126,23 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
             at = x < kNoTexel ? x : at;
             asm volatile("" : "+v"(at));  // keeps the branch a branch
         }
-        top[k] = __builtin_amdgcn_raw_buffer_load_b32(atlas_rsrc, at, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(atlas_rsrc, (lds_ptr)(fb + py * kObsW), 4, static_cast<int>(at), 0, 0, 0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler does not track LDS-direct loads: wait for them here
+    // judged in groups of kBatch rows: 8 rows = 128 × 16 bytes of the target, two reads per lane
+    const uint4* const landed = reinterpret_cast<const uint4*>(fb) + py_begin * (kObsW / 4);
 #pragma unroll
     for (int g = 0; g < kRows / kBatch; g++) {
-        uint32_t least = top[g * kBatch];
-#pragma unroll
-        for (int k = 1; k < kBatch; k++) least = least < top[g * kBatch + k] ? least : top[g * kBatch + k];
+        const uint4 p = landed[g * (kBatch * kObsW / 4) + lane], q = landed[g * (kBatch * kObsW / 4) + 64 + lane];
+        uint32_t least = p.x < p.y ? p.x : p.y;
+        least = least < p.z ? least : p.z;
+        least = least < p.w ? least : p.w;
+        least = least < q.x ? least : q.x;
+        least = least < q.y ? least : q.y;
+        least = least < q.z ? least : q.z;
+        least = least < q.w ? least : q.w;
         const bool skip = ((hards >> (g * kBatch)) & 0xffu) != 0u;
-        if (!skip && __ballot(least < 0xff000000u) == 0 && !PG_ABL(ablate, 4096)) {
-#pragma unroll
-            for (int k = 0; k < kBatch; k++) fb[(py_begin + g * kBatch + k) * kObsW + lane] = top[g * kBatch + k];
-        } else {
-            general_batch(py_begin + g * kBatch);
-        }
+        if (skip || __ballot(least < 0xff000000u) != 0 || PG_ABL(ablate, 4096)) general_batch(py_begin + g * kBatch);
     }
     __syncthreads();
     return true;
