@@ -850,6 +850,7 @@ __global__ void __launch_bounds__(64 * kRenderWaves, 4) render_kernel(State s, A
     const uint8_t* tiles = s.tiles + size_t(env) * (W * H);
     const DescRegs descs = DescRegs::load(atlas, lane);  // the whole descriptor table, two entries per lane
     Blit mine;
+    PG_MARK("a_state");
 
     {   // the step ended after fewer than four sub-steps (resolve_kernel): bring the entity table to that sub-step,
         // one lane per entity, from the half of the table the optimistic pass left untouched
@@ -898,6 +899,7 @@ __global__ void __launch_bounds__(64 * kRenderWaves, 4) render_kernel(State s, A
         part_x = SP(s, buf, 0, e, k, env);
         part_y = SP(s, buf, 1, e, k, env);
     }
+    PG_MARK("b_inputs");
 
     // background (coinrun.cpp:459-464)
     int4 bg_d;  // the background draw: texture, world position, scale — each wave resolves the axis it needs (pg_render.h BgAxis)
@@ -984,12 +986,14 @@ __global__ void __launch_bounds__(64 * kRenderWaves, 4) render_kernel(State s, A
             blit_share(slots, lane, mine, has);
         }
     }
+    PG_MARK("c_resolve");
     const BgAxis bga = bg_axis(cam, bg_d, bg_px, bg_py, bg_sc, half);  // wave 0: x axis, wave 1: y axis
     bool composed = false, sprites_ready = false;
     ReplayState<4> sprite_pass;
     if (!(flags & 1) && !PG_ABL(flags, 4) && cols <= kGrid && rows <= kGrid) {
         compose_spans(fb, L, cam, x0, y0, cols, rows, tile_desc.y, tile_desc.z, kUnitPx / tile_desc.y, lane, 0, half, halves,
                       /*soft_init=*/0, /*hard_init=*/0);  // exact bits are ORed in below
+    PG_MARK("d_spans");
         // Texel offset of each tile kind's texture, one per lane (0..7), looked up with a cross-lane read:
         // lanes 0-3 = wall_top, wall_mid, lava_top, lava_mid (tile id - 1), lanes 4-7 = the four crates.
         int kind_tex = kTexCrate + ((lane - 4) & 3);
@@ -1021,13 +1025,16 @@ __global__ void __launch_bounds__(64 * kRenderWaves, 4) render_kernel(State s, A
         if (soft_rows) atomicOr(&L.soft_rows[half], static_cast<int32_t>(soft_rows));
         if (hard_rows) atomicOr(&L.hard_rows[half], static_cast<int32_t>(hard_rows));
         __syncthreads();
+        PG_MARK("e_cells");
         // the draws wave 1 resolved: the texels of the first few are requested now and arrive while the frame is composed
         sprites_ready = !PG_ABL(flags, 2);
         if (sprites_ready) {
             const bool has = blit_take(slots, lane, mine);
             sprite_pass = replay_begin(atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
         }
+        PG_MARK("f_begin");
         composed = compose_rows(fb, L, atlas, bga, cols, rows, tile_desc.y, lane, flags, half, halves);
+        PG_MARK("k_composed");
     }
     if (PG_ABL(flags, 4)) composed = true;  // (bit 2: timing experiment — no background/tiles at all)
     if (!composed) {  // draw-list replay of background and tiles (tilemap.cpp:294-321)
@@ -1100,11 +1107,14 @@ __global__ void __launch_bounds__(64 * kRenderWaves, 4) render_kernel(State s, A
             const bool has = blit_take(slots, lane, mine);
             sprite_pass = replay_begin(atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
         }
+        PG_MARK("m_fallback_and_rounds");
         replay_finish(fb, atlas, mine, sprite_pass, lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
+        PG_MARK("n_sprites");
     }
     // each wave stores the rows it owns (pg_render.h wave_replay_rows): no barrier
     if (!PG_ABL(flags, 8))
         wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
+    PG_MARK("o_store");
 }
 
 // cenv_render's frame (coinrun.cpp:393-411 → render_game(false), :443-470) for one env: pg_frame.h.

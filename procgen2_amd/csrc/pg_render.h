@@ -36,6 +36,13 @@
 #else
 #define PG_ABL(flags, bits) 0
 #endif
+// Phase markers for the static instruction inventory (tools/isa_phases.py compiles with -DPG_MARKS and splits the
+// kernel's assembly at them); nothing in the product build.
+#ifdef PG_MARKS
+#define PG_MARK(name) asm volatile("; PGMARK " name)
+#else
+#define PG_MARK(name) ((void)0)
+#endif
 
 namespace pg {
 
@@ -958,6 +965,7 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
             if (any_bad) H.bad = 1;
         }
     }
+    PG_MARK("g_hand");
     __syncthreads();
     if (H.bad) return false;  // (nothing has been written to the target yet)
     const uint4 hc = H.col[lane], hr = H.row[lane];
@@ -976,6 +984,7 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
     const unsigned long long second_row = mask64(0), soft = mask64(1), hard = mask64(2);
     constexpr int bg_mod = 255;  // (see BgAxis)
     __syncthreads();  // everybody has read the set-up tables out of the frame target's memory: it may be written now
+    PG_MARK("h_handread");
 
     // Rows in batches: every texel gather of a batch is issued before any pixel is produced, so a batch costs one
     // memory round trip.  Candidates in draw order: background, (row a, col a), (row a, col b), then — on the rows
@@ -1003,7 +1012,10 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
     // The general form of one batch of rows: every candidate of every pixel is fetched, then resolved.
     auto general_batch = [&](int py0) {
         uint32_t t[kBatch][3], u[kBatch][2];
-        const uint32_t seconds = static_cast<uint32_t>(second_row >> py0) & 0xffu;
+        uint32_t seconds = static_cast<uint32_t>(second_row >> py0) & 0xffu;
+        // (opaque to the compiler: it would otherwise keep the 32 per-row tests of the attempt below alive in scalar
+        // registers for this rarely taken path, and spill them)
+        asm volatile("" : "+s"(seconds));
 #pragma unroll
         for (int k = 0; k < kBatch; k++) {
             const int py = py0 + k;
@@ -1105,29 +1117,44 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
     // exactly pixel (row, l) of a row-major target — no result registers (32 of them otherwise, the kernel's register
     // peak), no stores.  Out-of-range lanes write 0 (checked on the hardware: tools/probe/lds_direct_load.hip).
     using lds_ptr = __attribute__((address_space(3))) void*;
+    // Eight rows at a time: first every cell word the rows may need is requested from the table, then the addresses
+    // are worked out and the gathers leave.  One wait for the table per eight rows instead of one per row.
 #pragma unroll
-    for (int k = 0; k < kRows; k++) {
-        const int py = py_begin + k;
-        const uint32_t s_bg = __builtin_amdgcn_readlane(bg_row, py);
-        const uint32_t s_a = __builtin_amdgcn_readlane(row_a, py);
-        const uint32_t* cp = reinterpret_cast<const uint32_t*>(cells + __builtin_amdgcn_readlane(cells_a, py));
-        const uint32_t s_a2 = TWO ? __builtin_amdgcn_readlane(row_a2, py) : 0u;
-        uint32_t at = bg_col + s_bg;  // draw order: background, (a, a), (a, b), (b, a), (b, b) — the last one there wins
-        uint32_t x = tile_at(cp[0], col_a, s_a, s_a2);
-        at = x < kNoTexel ? x : at;
-        x = tile_at(cp[1], col_b, s_a, s_a2);
-        at = x < kNoTexel ? x : at;
-        if (seconds32 & (1u << k)) {  // wave-uniform
-            const uint32_t s_b = __builtin_amdgcn_readlane(row_b, py);
-            const uint32_t s_b2 = TWO ? __builtin_amdgcn_readlane(row_b2, py) : 0u;
-            x = tile_at(cp[GRID], col_a, s_b, s_b2);
-            at = x < kNoTexel ? x : at;
-            x = tile_at(cp[GRID + 1], col_b, s_b, s_b2);
-            at = x < kNoTexel ? x : at;
-            asm volatile("" : "+v"(at));  // keeps the branch a branch
+    for (int g = 0; g < kRows / kBatch; g++) {
+        uint32_t cell_aa[kBatch], cell_ab[kBatch], cell_ba[kBatch], cell_bb[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) {
+            const int py = py_begin + g * kBatch + k;
+            const uint32_t* cp = reinterpret_cast<const uint32_t*>(cells + __builtin_amdgcn_readlane(cells_a, py));
+            cell_aa[k] = cp[0];
+            cell_ab[k] = cp[1];
+            cell_ba[k] = cp[GRID];  // (used on the rows two grid rows cover; reading them anyway keeps this loop straight)
+            cell_bb[k] = cp[GRID + 1];
         }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(atlas_rsrc, (lds_ptr)(fb + py * kObsW), 4, static_cast<int>(at), 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) {
+            const int py = py_begin + g * kBatch + k;
+            const uint32_t s_bg = __builtin_amdgcn_readlane(bg_row, py);
+            const uint32_t s_a = __builtin_amdgcn_readlane(row_a, py);
+            const uint32_t s_a2 = TWO ? __builtin_amdgcn_readlane(row_a2, py) : 0u;
+            uint32_t at = bg_col + s_bg;  // draw order: background, (a, a), (a, b), (b, a), (b, b) — the last one there wins
+            uint32_t x = tile_at(cell_aa[k], col_a, s_a, s_a2);
+            at = x < kNoTexel ? x : at;
+            x = tile_at(cell_ab[k], col_b, s_a, s_a2);
+            at = x < kNoTexel ? x : at;
+            if (seconds32 & (1u << (g * kBatch + k))) {  // wave-uniform
+                const uint32_t s_b = __builtin_amdgcn_readlane(row_b, py);
+                const uint32_t s_b2 = TWO ? __builtin_amdgcn_readlane(row_b2, py) : 0u;
+                x = tile_at(cell_ba[k], col_a, s_b, s_b2);
+                at = x < kNoTexel ? x : at;
+                x = tile_at(cell_bb[k], col_b, s_b, s_b2);
+                at = x < kNoTexel ? x : at;
+                asm volatile("" : "+v"(at));  // keeps the branch a branch
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(atlas_rsrc, (lds_ptr)(fb + py * kObsW), 4, static_cast<int>(at), 0, 0, 0);
+        }
     }
+    PG_MARK("i_fast_issue");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler does not track LDS-direct loads: wait for them here
     // judged in groups of kBatch rows: 8 rows = 128 × 16 bytes of the target, two reads per lane
     const uint4* const landed = reinterpret_cast<const uint4*>(fb) + py_begin * (kObsW / 4);
@@ -1142,7 +1169,8 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
         least = least < q.z ? least : q.z;
         least = least < q.w ? least : q.w;
         const bool skip = ((hards >> (g * kBatch)) & 0xffu) != 0u;
-        if (skip || __ballot(least < 0xff000000u) != 0 || PG_ABL(ablate, 4096)) general_batch(py_begin + g * kBatch);
+        if ((skip || __ballot(least < 0xff000000u) != 0 || PG_ABL(ablate, 4096)) && !PG_ABL(ablate, 8192))  // (bit 13: never)
+            general_batch(py_begin + g * kBatch);
     }
     __syncthreads();
     return true;
