@@ -663,11 +663,12 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
     const int cols = x1 - x0 + 1, rows = y1 - y0 + 1, cells = cols * rows;
     const int4 wall_d = descs.uniform(kTexWall);
 
-    const BgAxis bga = bg_axis(cam, bg_d, bg_px, bg_py, bg_sc, half);  // wave 0: x axis, wave 1: y axis
+    const BgDraw bg_draw{bg_d, bg_px, bg_py, bg_sc};
+    BgAxis bga{};  // this wave's axis of it (wave 0: x, wave 1: y), resolved along with the tile spans
     bool composed = false;
     if (!(flags & 1) && cols <= kGrid && rows <= kGrid) {
         compose_spans<kGrid, 16>(fb, L, cam, x0, y0, cols, rows, wall_d.y, wall_d.z, kUnitPx / wall_d.y, lane, 0, half, halves,
-                                 soft_rows_of(bg_soft, wall_d.w), hard_rows_of(bg_soft, wall_d.w));
+                                 soft_rows_of(bg_soft, wall_d.w), hard_rows_of(bg_soft, wall_d.w), &bg_draw, &bga);
 #pragma unroll
         for (int k = half; k < kGrid * kGrid / 64; k += halves) {
             const int cell = k * 64 + lane;

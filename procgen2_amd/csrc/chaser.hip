@@ -699,12 +699,13 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
     // Needs: the wall's texture size (check_atlas), texels all opaque or all clear, a clear rim (descriptor .w bits 2, 3).
     const bool points_in_layer = !(flags & 1) && (point_d.w & 12) == 8;
 
-    const BgAxis bga = bg_axis(cam, bg_d, bg_px, bg_py, bg_sc, half);  // wave 0: x axis, wave 1: y axis
+    const BgDraw bg_draw{bg_d, bg_px, bg_py, bg_sc};
+    BgAxis bga{};  // this wave's axis of it (wave 0: x, wave 1: y), resolved along with the tile spans
     bool composed = false;
     if (!(flags & 1) && cols <= kGrid && rows <= kGrid) {
         compose_spans<kGrid, 16>(fb, L, cam, x0, y0, cols, rows, wall_d.y, wall_d.z, kUnitPx / wall_d.y, lane, 0, half, halves,
                                  soft_rows_of(bg_soft, wall_d.w | (points_in_layer ? point_d.w : 0)),
-                                 hard_rows_of(bg_soft, wall_d.w | (points_in_layer ? point_d.w : 0)));
+                                 hard_rows_of(bg_soft, wall_d.w | (points_in_layer ? point_d.w : 0)), &bg_draw, &bga);
 #pragma unroll
         for (int k = half; k < kGrid * kGrid / 64; k += halves) {
             const int cell = k * 64 + lane;

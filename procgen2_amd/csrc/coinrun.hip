@@ -987,12 +987,13 @@ __global__ void __launch_bounds__(64 * kRenderWaves, 4) render_kernel(State s, A
         }
     }
     PG_MARK("c_resolve");
-    const BgAxis bga = bg_axis(cam, bg_d, bg_px, bg_py, bg_sc, half);  // wave 0: x axis, wave 1: y axis
+    const BgDraw bg_draw{bg_d, bg_px, bg_py, bg_sc};
+    BgAxis bga{};  // this wave's axis of it (wave 0: x, wave 1: y), resolved along with the tile spans
     bool composed = false, sprites_ready = false;
     ReplayState<4> sprite_pass;
     if (!(flags & 1) && !PG_ABL(flags, 4) && cols <= kGrid && rows <= kGrid) {
         compose_spans(fb, L, cam, x0, y0, cols, rows, tile_desc.y, tile_desc.z, kUnitPx / tile_desc.y, lane, 0, half, halves,
-                      /*soft_init=*/0, /*hard_init=*/0);  // exact bits are ORed in below
+                      /*soft_init=*/0, /*hard_init=*/0, &bg_draw, &bga);  // exact bits are ORed in below
     PG_MARK("d_spans");
         // Texel offset of each tile kind's texture, one per lane (0..7), looked up with a cross-lane read:
         // lanes 0-3 = wall_top, wall_mid, lava_top, lava_mid (tile id - 1), lanes 4-7 = the four crates.

@@ -596,12 +596,13 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
     const int cols = x1 - x0 + 1, rows = y1 - y0 + 1, cells = cols * rows;
     const int4 top_d = descs.uniform(kTexTop + theme), mid_d = descs.uniform(kTexMid + theme);
 
-    const BgAxis bga = bg_axis(cam, bg_d, bg_px, bg_py, bg_sc, half);  // wave 0: x axis, wave 1: y axis
+    const BgDraw bg_draw{bg_d, bg_px, bg_py, bg_sc};
+    BgAxis bga{};  // this wave's axis of it (wave 0: x, wave 1: y), resolved along with the tile spans
     bool composed = false;
     const bool two = top_d.z != mid_d.z;  // the brown cap tile is 64×53 (see climber.hip)
     if (!(flags & 1) && cols <= kGrid && rows <= kGrid && top_d.y == mid_d.y && top_d.z <= mid_d.z) {
         compose_spans(fb, L, cam, x0, y0, cols, rows, mid_d.y, mid_d.z, kUnitPx / mid_d.y, lane, two ? top_d.z : 0, half, halves,
-                      soft_rows_of(bg_soft, top_d.w | mid_d.w), hard_rows_of(bg_soft, mid_d.w));  // (cap tiles are few: always worth the attempt)
+                      soft_rows_of(bg_soft, top_d.w | mid_d.w), hard_rows_of(bg_soft, mid_d.w), &bg_draw, &bga);  // (cap tiles are few: always worth the attempt)
 #pragma unroll
         for (int k = half; k < kGrid * kGrid / 64; k += halves) {
             const int cell = k * 64 + lane;

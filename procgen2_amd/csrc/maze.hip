@@ -249,12 +249,13 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
     const int cols = x1 - x0 + 1, rows = y1 - y0 + 1, cells = cols * rows;
     const int4 wall = atlas.desc[kTexWall];
 
-    const BgAxis bga = bg_axis(cam, bg_d, bg_px, bg_py, bg_sc, half);  // wave 0: x axis, wave 1: y axis
+    const BgDraw bg_draw{bg_d, bg_px, bg_py, bg_sc};
+    BgAxis bga{};  // this wave's axis of it (wave 0: x, wave 1: y), resolved along with the tile spans
     bool composed = false;
     if (!(flags & 1) && cols <= kGrid && rows <= kGrid) {
         constexpr int kSpan = 64 / kVisible + 2 <= kMaxSpan ? kMaxSpan : 16;  // pixels a tile covers (+ seam padding)
         compose_spans<kGrid, kSpan>(fb, L, cam, x0, y0, cols, rows, wall.y, wall.z, kUnitPx / wall.y, lane, 0, half, halves,
-                                    soft_rows_of(bg_soft, wall.w), hard_rows_of(bg_soft, wall.w));
+                                    soft_rows_of(bg_soft, wall.w), hard_rows_of(bg_soft, wall.w), &bg_draw, &bga);
         for (int cell = lane + 64 * half; cell < cells; cell += 64 * halves) {
             const int r = cell / cols, c = cell - r * cols;
             L.base[r * kGrid + c] =

@@ -733,6 +733,10 @@ struct BgAxis {
     int32_t d0, dn, s0, sn;  // destination span on the target, source span in the texture (dn = 0: nothing)
     int32_t tex_off, tex_w;
 };
+struct BgDraw {  // the background's draw call: texture descriptor, world position (pixels), scale
+    int4 desc;
+    float px, py, scale;
+};
 PG_D BgAxis bg_axis(const Camera& cam, const int4& desc, float pos_x, float pos_y, float scale, int axis) {
     Span sp;
     const bool ok = axis == 0 ? resolve_axis(cam.px, cam.sw, cam.scale, desc.y, pos_x, scale, false, false, sp)
@@ -767,7 +771,7 @@ PG_D int32_t hard_rows_of(int bg_w, int tiles_w) {
 template <int GRID, int MAXSPAN = kMaxSpan>
 PG_D void compose_spans(uint32_t* fb, ComposeLds<GRID>& L, const Camera& cam, int x0, int y0, int cols, int rows, int tw,
                         int th, float tile_scale, int lane, int th2 = 0, int half = 0, int halves = 1,
-                        int32_t soft_init = -1, int32_t hard_init = -1) {
+                        int32_t soft_init = -1, int32_t hard_init = -1, const BgDraw* bg = nullptr, BgAxis* bga = nullptr) {
     // Two wavefronts, one axis each (wave 0: columns, wave 1: rows), and nothing of one axis is read by the other
     // wave before the barrier that follows the caller's staging of L.base — so there is no barrier in here: every
     // table below is written and read by the same wave (LDS operations of a wave complete in order), and the flags
@@ -785,26 +789,44 @@ PG_D void compose_spans(uint32_t* fb, ComposeLds<GRID>& L, const Camera& cam, in
             L.base[GRID * GRID] = L.base[GRID * GRID + 1] = static_cast<int32_t>(0x40000000u);  // kNoTexel (declared below)
         }
     }
+    // The background's draw on this axis is one more span to resolve — the same arithmetic with other numbers — so it
+    // rides along in the last lane (no grid is 63 wide) instead of costing every lane a second pass through
+    // resolve_axis, and comes back with cross-lane reads.
+    static_assert(GRID < 63, "lane 63 resolves the background");
+    const bool bg_lane = bg != nullptr && lane == 63;
     bool wide = false;
+    Span sp;
+    sp.d0 = sp.dn = sp.s0 = sp.sn = 0;
+    bool ok = false;
     if (axis == 0) {
-        if (lane < cols) {
-            Span sp;
-            const bool ok = resolve_axis(cam.px, cam.sw, cam.scale, tw, (x0 + lane) * kUnitPx, tile_scale, false, false, sp);
-            T.col[lane] = ok ? make_int4(sp.d0, sp.dn, sp.s0, sp.sn) : make_int4(0, 0, 0, 0);
+        if (lane < cols || bg_lane) {
+            const int ts = bg_lane ? bg->desc.y : tw;
+            const float pos = bg_lane ? bg->px : (x0 + lane) * kUnitPx;
+            ok = resolve_axis(cam.px, cam.sw, cam.scale, ts, pos, bg_lane ? bg->scale : tile_scale, false, false, sp);
+            if (!bg_lane) {
+                T.col[lane] = ok ? make_int4(sp.d0, sp.dn, sp.s0, sp.sn) : make_int4(0, 0, 0, 0);
+                wide = ok && sp.dn > MAXSPAN;
+            }
+        }
+    } else if (lane < rows || bg_lane) {
+        const int ts = bg_lane ? bg->desc.z : th;
+        const float pos = bg_lane ? bg->py : (y0 + lane) * kUnitPx;
+        ok = resolve_axis(cam.py, cam.sh, cam.scale, ts, pos, bg_lane ? bg->scale : tile_scale, false, true, sp);
+        if (!bg_lane) {
+            T.row[lane] = ok ? make_int4(sp.d0, sp.dn, sp.s0, sp.sn) : make_int4(0, 0, 0, 0);
             wide = ok && sp.dn > MAXSPAN;
         }
-    } else if (lane < rows) {
-        Span sp;
-        const bool ok = resolve_axis(cam.py, cam.sh, cam.scale, th, (y0 + lane) * kUnitPx, tile_scale, false, true, sp);
-        T.row[lane] = ok ? make_int4(sp.d0, sp.dn, sp.s0, sp.sn) : make_int4(0, 0, 0, 0);
-        wide = ok && sp.dn > MAXSPAN;
-        if (th2 > 0) {
+        if (th2 > 0 && !bg_lane) {
             Span s2;
             const bool ok2 =
                 resolve_axis(cam.py, cam.sh, cam.scale, th2, (y0 + lane) * kUnitPx, tile_scale, false, true, s2);
             T.row2[lane] = ok2 ? make_int4(s2.d0, s2.dn, s2.s0, s2.sn) : make_int4(0, 0, 0, 0);
             wide = wide || (ok2 && (!ok || s2.d0 != sp.d0 || s2.dn > sp.dn));  // not nested: take the fallback
         }
+    }
+    if (bga != nullptr) {
+        *bga = BgAxis{__builtin_amdgcn_readlane(ok ? sp.d0 : 0, 63), __builtin_amdgcn_readlane(ok ? sp.dn : 0, 63),
+                      __builtin_amdgcn_readlane(sp.s0, 63), __builtin_amdgcn_readlane(sp.sn, 63), bg->desc.x, bg->desc.y};
     }
     if (__ballot(wide)) {  // some span is wider than MAXSPAN pixels: the caller's compose_rows will decline
         if (lane == 0) L.too_wide[half] = 1;
