@@ -620,22 +620,27 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
         puff_dy = PF(s, PF_DY, lane, env);
         puff_rot = PF(s, PF_ROT, lane, env);
     }
+    // When everything after the tile layer fits the wave's 64 lanes it is drawn as ONE pass, lanes in draw order:
+    // particles, then the sprites, then the bullets and the ship (see below); otherwise a pass per kind, from lane 0.
+    const bool one_pass = kPuffs + n_draw + s_count + 1 <= 64;
+    const int spr_lane0 = one_pass ? kPuffs : 0, shot_lane0 = one_pass ? kPuffs + n_draw : 0;
     int spr_kind = 0;
     float spr_x = 0.0f, spr_y = 0.0f;
-    if (lane < n_draw) {
-        const int e = EB(s, EB_DRAW, lane, env);
+    if (lane >= spr_lane0 && lane - spr_lane0 < n_draw) {
+        const int e = EB(s, EB_DRAW, lane - spr_lane0, env);
         spr_kind = EB(s, EB_INFO, e, env) & kKindMask;
         spr_x = EF(s, EF_X, e, env);
         spr_y = EF(s, EF_Y, e, env);
     }
     float shot_frame = -1.0f, shot_x = 0.0f, shot_y = 0.0f, shot_rot = 0.0f;
-    if (lane < s_count) {
-        const int k = (kShots + s_next - 1 - lane) % kShots;
+    const int shot_i = lane - shot_lane0;  // bullets newest first, then the ship
+    if (shot_i >= 0 && shot_i < s_count) {
+        const int k = (kShots + s_next - 1 - shot_i) % kShots;
         shot_frame = SH(s, SH_FRAME, k, env);
         shot_x = SH(s, SH_X, k, env);
         shot_y = SH(s, SH_Y, k, env);
         shot_rot = SH(s, SH_ROT, k, env);
-    } else if (lane == s_count) {
+    } else if (shot_i == s_count) {
         shot_x = SF(s, F_AX, env);
         shot_y = SF(s, F_AY, env);
         shot_rot = SF(s, F_ROT, env);
@@ -697,65 +702,111 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
         }
     }
 
-    {  // System_Particles::render (common_systems.cpp:374-397): rotated, fading
-        const int4 d = descs.uniform(kTexPuff);
-        bool has = false;
-        if (lane < kPuffs && puff_life > 0.0f) {
+    if (one_pass) {
+        // System_Particles::render (common_systems.cpp:374-397: rotated, fading), the positive-z sprites (:26-48: goal,
+        // meteors, targets, enemies), System_Agent::render (:291-327: bullets newest first, then the ship) — one draw
+        // per lane in that order.  The rotated kinds share one trip through resolve_rotated (its sine and cosine are
+        // the expensive part), the sprites take resolve_draw.
+        const bool is_puff = lane < kPuffs, is_spr = lane >= spr_lane0 && lane < shot_lane0;
+        int want_tex = kTexShip;
+        bool go = shot_i == s_count;  // the ship
+        float size = 0.15f, alpha = 1.0f, rx = 0.0f, ry = 0.0f, rot = 0.0f;
+        if (is_puff) {
+            want_tex = kTexPuff;
+            go = puff_life > 0.0f;
+        } else if (is_spr) {
+            want_tex = kTexKind + spr_kind;
+            go = false;
+        } else if (shot_i >= 0 && shot_i < s_count && shot_frame != -1.0f) {
+            go = true;
+            size = 0.1f;
+            want_tex = (shot_frame == 0.0f) ? kTexLaser : kTexBoom + static_cast<int>(shot_frame - 1.0f);
+        }
+        const int4 d = descs.at(want_tex);
+        if (is_puff) {
             const float lifespan = 3.0f;
             const float life_ratio = (lifespan - puff_life) / lifespan;
-            const float alpha = 0.5f * (1.0f - life_ratio);
+            alpha = 0.5f * (1.0f - life_ratio);
             const float scale = 1.0f * (0.4f * life_ratio + 0.6f);
             const float shift = life_ratio * 2.0f;
-            const float size = scale * kUnitPx / d.y;
-            has = resolve_rotated(cam, d.y, d.z, d.x, (puff_x + puff_dx * shift) * kUnitPx - size * d.y * 0.5f,
-                                  (puff_y + puff_dy * shift) * kUnitPx - size * d.z * 0.5f, puff_rot, size, alpha, mine);
+            size = scale * kUnitPx / d.y;
+            rx = (puff_x + puff_dx * shift) * kUnitPx - size * d.y * 0.5f;
+            ry = (puff_y + puff_dy * shift) * kUnitPx - size * d.z * 0.5f;
+            rot = puff_rot;
+        } else {
+            rx = shot_x * kUnitPx - size * d.y * 0.5f;
+            ry = shot_y * kUnitPx - size * d.z * 0.5f;
+            rot = static_cast<float>(shot_rot + kPi * 0.5f);
         }
-        wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
-    }
-    {  // positive-z sprites (common_systems.cpp:26-48): goal, meteors, targets, enemies
-        const int4 d = descs.at(kTexKind + spr_kind);
         bool has = false;
-        if (lane < n_draw) {
+        if (go) has = resolve_rotated(cam, d.y, d.z, d.x, rx, ry, rot, size, alpha, mine);
+        if (is_spr) {
             const float scale = 1.0f * 0.8f;
             has = resolve_draw(cam, d.y, d.z, d.x, (spr_x + -0.4f) * kUnitPx, (spr_y + -0.4f) * kUnitPx,
                                scale * kUnitPx / d.y, 1.0f, false, false, mine);
         }
         wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
-        if (kMaxEnt > 64 && n_draw > 64) {  // memory_mode: up to 76 sprites, the rest in a second pass
-            const int k = 64 + lane;
-            int kind2 = 0;
-            float x2 = 0.0f, y2 = 0.0f;
-            if (k < n_draw) {
-                const int e = EB(s, EB_DRAW, k, env);
-                kind2 = EB(s, EB_INFO, e, env) & kKindMask;
-                x2 = EF(s, EF_X, e, env);
-                y2 = EF(s, EF_Y, e, env);
+    } else {
+        {  // System_Particles::render (common_systems.cpp:374-397): rotated, fading
+            const int4 d = descs.uniform(kTexPuff);
+            bool has = false;
+            if (lane < kPuffs && puff_life > 0.0f) {
+                const float lifespan = 3.0f;
+                const float life_ratio = (lifespan - puff_life) / lifespan;
+                const float alpha = 0.5f * (1.0f - life_ratio);
+                const float scale = 1.0f * (0.4f * life_ratio + 0.6f);
+                const float shift = life_ratio * 2.0f;
+                const float size = scale * kUnitPx / d.y;
+                has = resolve_rotated(cam, d.y, d.z, d.x, (puff_x + puff_dx * shift) * kUnitPx - size * d.y * 0.5f,
+                                      (puff_y + puff_dy * shift) * kUnitPx - size * d.z * 0.5f, puff_rot, size, alpha, mine);
             }
-            const int4 d2 = descs.at(kTexKind + kind2);
-            bool has2 = false;
-            if (k < n_draw) {
+            wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
+        }
+        {  // positive-z sprites (common_systems.cpp:26-48): goal, meteors, targets, enemies
+            const int4 d = descs.at(kTexKind + spr_kind);
+            bool has = false;
+            if (lane < n_draw) {
                 const float scale = 1.0f * 0.8f;
-                has2 = resolve_draw(cam, d2.y, d2.z, d2.x, (x2 + -0.4f) * kUnitPx, (y2 + -0.4f) * kUnitPx,
-                                    scale * kUnitPx / d2.y, 1.0f, false, false, mine);
+                has = resolve_draw(cam, d.y, d.z, d.x, (spr_x + -0.4f) * kUnitPx, (spr_y + -0.4f) * kUnitPx,
+                                   scale * kUnitPx / d.y, 1.0f, false, false, mine);
             }
-            wave_replay_rows(fb, atlas, mine, __ballot(has2), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
+            wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
+            if (kMaxEnt > 64 && n_draw > 64) {  // memory_mode: up to 76 sprites, the rest in a second pass
+                const int k = 64 + lane;
+                int kind2 = 0;
+                float x2 = 0.0f, y2 = 0.0f;
+                if (k < n_draw) {
+                    const int e = EB(s, EB_DRAW, k, env);
+                    kind2 = EB(s, EB_INFO, e, env) & kKindMask;
+                    x2 = EF(s, EF_X, e, env);
+                    y2 = EF(s, EF_Y, e, env);
+                }
+                const int4 d2 = descs.at(kTexKind + kind2);
+                bool has2 = false;
+                if (k < n_draw) {
+                    const float scale = 1.0f * 0.8f;
+                    has2 = resolve_draw(cam, d2.y, d2.z, d2.x, (x2 + -0.4f) * kUnitPx, (y2 + -0.4f) * kUnitPx,
+                                        scale * kUnitPx / d2.y, 1.0f, false, false, mine);
+                }
+                wave_replay_rows(fb, atlas, mine, __ballot(has2), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
+            }
         }
-    }
-    {  // System_Agent::render (common_systems.cpp:291-327): bullets newest first, then the ship
-        int want_tex = kTexShip;
-        bool has = lane == s_count;
-        float size = 0.15f;
-        if (lane < s_count && shot_frame != -1.0f) {
-            has = true;
-            size = 0.1f;
-            want_tex = (shot_frame == 0.0f) ? kTexLaser : kTexBoom + static_cast<int>(shot_frame - 1.0f);
+        {  // System_Agent::render (common_systems.cpp:291-327): bullets newest first, then the ship
+            int want_tex = kTexShip;
+            bool has = lane == s_count;
+            float size = 0.15f;
+            if (lane < s_count && shot_frame != -1.0f) {
+                has = true;
+                size = 0.1f;
+                want_tex = (shot_frame == 0.0f) ? kTexLaser : kTexBoom + static_cast<int>(shot_frame - 1.0f);
+            }
+            const int4 d = descs.at(want_tex);
+            if (has)
+                has = resolve_rotated(cam, d.y, d.z, d.x, shot_x * kUnitPx - size * d.y * 0.5f,
+                                      shot_y * kUnitPx - size * d.z * 0.5f, static_cast<float>(shot_rot + kPi * 0.5f), size,
+                                      1.0f, mine);
+            wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
         }
-        const int4 d = descs.at(want_tex);
-        if (has)
-            has = resolve_rotated(cam, d.y, d.z, d.x, shot_x * kUnitPx - size * d.y * 0.5f,
-                                  shot_y * kUnitPx - size * d.z * 0.5f, static_cast<float>(shot_rot + kPi * 0.5f), size,
-                                  1.0f, mine);
-        wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
     }
     // each wave stores the rows it owns (pg_render.h wave_replay_rows): no barrier
     wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));

@@ -635,72 +635,76 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
             wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
         }
     }
-    {  // System_Particles::render (common_systems.cpp:285-308)
-        const int4 d = descs.uniform(kTexPuff);
-        bool has = false;
-        if (lane < kPuffs && puff_life > 0.0f) {
-            const float lifespan = 5.0f;
-            const float life_ratio = (lifespan - puff_life) / lifespan;
-            const float alpha = 0.5f * (1.0f - life_ratio);
-            const float scale = 0.45f * (0.4f * life_ratio + 0.6f);
-            const float offset_y = -life_ratio * 0.17f;
-            has = resolve_draw(cam, d.y, d.z, d.x, puff_x * kUnitPx - 0.5f * d.y * scale,
-                               (puff_y + offset_y) * kUnitPx - 0.5f * d.z * scale, scale * kUnitPx / d.y, alpha, false,
-                               false, mine);
-        }
-        wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
-    }
-    // positive-z sprites (common_systems.cpp:26-48): carrot and spikes in draw order
-    for (int first = 0; first < n_draw; first += 64) {
-        const int k = first + lane;
-        bool has = false;
+    // The frame's draws after the tile layer, in the reference's order: particles (common_systems.cpp:285-308), the
+    // positive-z sprites (carrot and spikes, :26-48), the bunny (:204-247), the compass (jumper.cpp:473-509).  They
+    // differ in their parameters only, so when they fit the wave's 64 lanes they are ONE pass: one trip through
+    // resolve_draw (≈ 180 vector instructions of exact float division, whatever the number of draws) instead of three.
+    const int bunny_lane = kPuffs + n_draw;
+    if (bunny_lane + 4 <= 64) {
+        const bool is_puff = lane < kPuffs, is_draw = lane >= kPuffs && lane < bunny_lane, is_bunny = lane == bunny_lane;
+        const int hud = lane - bunny_lane;  // 1, 2, 3: circle, needle, bar
+        const bool is_hud = hud >= 1 && hud <= 3;
         int id = 0;
-        if (k < n_draw) {
-            id = s.draw[size_t(k) * s.n + env];
-            has = true;
-        }
-        const int4 d = descs.at(id == 0 ? kTexCarrot : kTexSpike);
-        if (has) {  // carrot and spikes differ in their parameters only: pick per lane, resolve once
-            float wx, wy, scale;
-            if (id == 0) {
-                scale = 1.0f * 1.0f;
-                wx = (SF(s, F_GX, env) + -0.5f) * kUnitPx;
-                wy = (SF(s, F_GY, env) + -0.5f) * kUnitPx;
-            } else {
-                const int cell = s.spike_cell[size_t(id - 2) * s.n + env];
-                scale = 1.0f * 0.4f;
-                wx = (cell_x(cell) + -0.25f) * kUnitPx;
-                wy = (cell_y(cell) + -0.25f) * kUnitPx;
-            }
-            has = resolve_draw(cam, d.y, d.z, d.x, wx, wy, scale * kUnitPx / d.y, 1.0f, false, false, mine);
-        }
-        wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
-    }
-    {  // lane 0: the bunny (common_systems.cpp:204-247); lanes 1-3: the compass (jumper.cpp:473-509)
+        if (is_draw) id = s.draw[size_t(lane - kPuffs) * s.n + env];
         const float avx = SF(s, F_AVX, env), phase = SF(s, F_APHASE, env);
         const bool ground = (sflags & kFlagGround) != 0;
-        int want_tex;
+        int bunny_tex;
         float agent_scale = 0.5f, off_x = 0.0f, off_y = 0.2f;
         if (fabsf(avx) < 0.01f && ground) {
-            want_tex = kTexStand;
+            bunny_tex = kTexStand;
         } else if (!ground) {
-            want_tex = kTexJump;
+            bunny_tex = kTexJump;
             agent_scale = 0.6f;
             off_x = -0.05f;
             off_y = 0.25f;
         } else if (phase > 0.5f) {
-            want_tex = kTexWalk2;
+            bunny_tex = kTexWalk2;
         } else {
-            want_tex = kTexWalk1;
+            bunny_tex = kTexWalk1;
         }
-        if (lane >= 1 && lane <= 3) want_tex = kTexCircle + (lane - 1);
+        int want_tex = kTexPuff;
+        if (is_draw) want_tex = id == 0 ? kTexCarrot : kTexSpike;
+        if (is_bunny) want_tex = bunny_tex;
+        if (is_hud) want_tex = kTexCircle + (hud - 1);
         const int4 d = descs.at(want_tex);
-        bool has = false;
-        if (lane == 0) {
+        bool has = false, go = false, flip = false;
+        float wx = 0.0f, wy = 0.0f, scale = 1.0f, alpha = 1.0f;
+        if (is_puff) {
+            if (puff_life > 0.0f) {
+                const float lifespan = 5.0f;
+                const float life_ratio = (lifespan - puff_life) / lifespan;
+                alpha = 0.5f * (1.0f - life_ratio);
+                const float size = 0.45f * (0.4f * life_ratio + 0.6f);
+                const float offset_y = -life_ratio * 0.17f;
+                wx = puff_x * kUnitPx - 0.5f * d.y * size;
+                wy = (puff_y + offset_y) * kUnitPx - 0.5f * d.z * size;
+                scale = size * kUnitPx / d.y;
+                go = true;
+            }
+        } else if (is_draw) {
+            float sc;
+            if (id == 0) {
+                sc = 1.0f * 1.0f;
+                wx = (SF(s, F_GX, env) + -0.5f) * kUnitPx;
+                wy = (SF(s, F_GY, env) + -0.5f) * kUnitPx;
+            } else {
+                const int cell = s.spike_cell[size_t(id - 2) * s.n + env];
+                sc = 1.0f * 0.4f;
+                wx = (cell_x(cell) + -0.25f) * kUnitPx;
+                wy = (cell_y(cell) + -0.25f) * kUnitPx;
+            }
+            scale = sc * kUnitPx / d.y;
+            go = true;
+        } else if (is_bunny) {
             const float px = SF(s, F_AX, env) - 0.25f, py = SF(s, F_AY, env) - 1.0f;
-            has = resolve_draw(cam, d.y, d.z, d.x, (px + off_x) * kUnitPx, (py + off_y) * kUnitPx,
-                               kUnitPx / d.y * agent_scale, 1.0f, (sflags & kFlagForward) == 0, false, mine);
-        } else if (lane <= 3) {
+            wx = (px + off_x) * kUnitPx;
+            wy = (py + off_y) * kUnitPx;
+            scale = kUnitPx / d.y * agent_scale;
+            flip = (sflags & kFlagForward) == 0;
+            go = true;
+        }
+        if (go) has = resolve_draw(cam, d.y, d.z, d.x, wx, wy, scale, alpha, flip, false, mine);
+        if (is_hud) {
             const float width = 64.0f, compass_size = 200.0f, offset_x = -32.0f, offset_y = 32.0f;
             const float tx = SF(s, F_TOGX, env), ty = SF(s, F_TOGY, env);
             const float angle = static_cast<float>(at_atan2f(ty, tx) * 180.0f / 3.14159265358979323846);
@@ -708,15 +712,14 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
             const float dist_inv = 1.0f / fmaxf(0.0001f, dist);
             const float dir_x = tx * dist_inv, dir_y = ty * dist_inv;
             const float ratio = fminf(1.0f, dist / (W * 1.414f));
-            // circle, needle and bar differ in their parameters only: pick per lane, resolve once
             float sx, sy, sw, sh;
             double deg = 0.0;
-            if (lane == 1) {
+            if (hud == 1) {
                 sx = width - compass_size * game_zoom + offset_x * game_zoom;
                 sy = offset_y * game_zoom;
                 sw = compass_size * game_zoom;
                 sh = compass_size * game_zoom;
-            } else if (lane == 2) {
+            } else if (hud == 2) {
                 float dx = width - compass_size * 0.75f * game_zoom + offset_x * game_zoom;
                 float dy = compass_size * 0.5f * game_zoom + offset_y * game_zoom;
                 dx += compass_size * 0.25f * dir_x * game_zoom;
@@ -738,12 +741,124 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
         if (s.hud_image != 0u) {
             // the ring is the same 60×60 pixels in every frame: prepared once (pg_render.h overlay_rows), in its place in
             // the draw order — after the bunny, before the needle and the bar
-            wave_replay_rows(fb, atlas, mine, __ballot(has && lane == 0), lane, row_lo, row_hi);
+            wave_replay_rows(fb, atlas, mine, __ballot(has && lane <= bunny_lane), lane, row_lo, row_hi);
             overlay_rows(fb, atlas.texels + s.hud_image, reinterpret_cast<const uint2*>(atlas.texels + s.hud_list), s.hud_n,
                          lane, row_lo, row_hi);
-            wave_replay_rows(fb, atlas, mine, __ballot(has && lane >= 2), lane, row_lo, row_hi);
+            wave_replay_rows(fb, atlas, mine, __ballot(has && lane >= bunny_lane + 2), lane, row_lo, row_hi);
         } else {
             wave_replay_rows(fb, atlas, mine, __ballot(has), lane, row_lo, row_hi);
+        }
+    } else {  // (more spikes than a wave has lanes for: a pass per kind)
+        {  // System_Particles::render (common_systems.cpp:285-308)
+            const int4 d = descs.uniform(kTexPuff);
+            bool has = false;
+            if (lane < kPuffs && puff_life > 0.0f) {
+                const float lifespan = 5.0f;
+                const float life_ratio = (lifespan - puff_life) / lifespan;
+                const float alpha = 0.5f * (1.0f - life_ratio);
+                const float scale = 0.45f * (0.4f * life_ratio + 0.6f);
+                const float offset_y = -life_ratio * 0.17f;
+                has = resolve_draw(cam, d.y, d.z, d.x, puff_x * kUnitPx - 0.5f * d.y * scale,
+                                   (puff_y + offset_y) * kUnitPx - 0.5f * d.z * scale, scale * kUnitPx / d.y, alpha, false,
+                                   false, mine);
+            }
+            wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
+        }
+        // positive-z sprites (common_systems.cpp:26-48): carrot and spikes in draw order
+        for (int first = 0; first < n_draw; first += 64) {
+            const int k = first + lane;
+            bool has = false;
+            int id = 0;
+            if (k < n_draw) {
+                id = s.draw[size_t(k) * s.n + env];
+                has = true;
+            }
+            const int4 d = descs.at(id == 0 ? kTexCarrot : kTexSpike);
+            if (has) {  // carrot and spikes differ in their parameters only: pick per lane, resolve once
+                float wx, wy, scale;
+                if (id == 0) {
+                    scale = 1.0f * 1.0f;
+                    wx = (SF(s, F_GX, env) + -0.5f) * kUnitPx;
+                    wy = (SF(s, F_GY, env) + -0.5f) * kUnitPx;
+                } else {
+                    const int cell = s.spike_cell[size_t(id - 2) * s.n + env];
+                    scale = 1.0f * 0.4f;
+                    wx = (cell_x(cell) + -0.25f) * kUnitPx;
+                    wy = (cell_y(cell) + -0.25f) * kUnitPx;
+                }
+                has = resolve_draw(cam, d.y, d.z, d.x, wx, wy, scale * kUnitPx / d.y, 1.0f, false, false, mine);
+            }
+            wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
+        }
+        {  // lane 0: the bunny (common_systems.cpp:204-247); lanes 1-3: the compass (jumper.cpp:473-509)
+            const float avx = SF(s, F_AVX, env), phase = SF(s, F_APHASE, env);
+            const bool ground = (sflags & kFlagGround) != 0;
+            int want_tex;
+            float agent_scale = 0.5f, off_x = 0.0f, off_y = 0.2f;
+            if (fabsf(avx) < 0.01f && ground) {
+                want_tex = kTexStand;
+            } else if (!ground) {
+                want_tex = kTexJump;
+                agent_scale = 0.6f;
+                off_x = -0.05f;
+                off_y = 0.25f;
+            } else if (phase > 0.5f) {
+                want_tex = kTexWalk2;
+            } else {
+                want_tex = kTexWalk1;
+            }
+            if (lane >= 1 && lane <= 3) want_tex = kTexCircle + (lane - 1);
+            const int4 d = descs.at(want_tex);
+            bool has = false;
+            if (lane == 0) {
+                const float px = SF(s, F_AX, env) - 0.25f, py = SF(s, F_AY, env) - 1.0f;
+                has = resolve_draw(cam, d.y, d.z, d.x, (px + off_x) * kUnitPx, (py + off_y) * kUnitPx,
+                                   kUnitPx / d.y * agent_scale, 1.0f, (sflags & kFlagForward) == 0, false, mine);
+            } else if (lane <= 3) {
+                const float width = 64.0f, compass_size = 200.0f, offset_x = -32.0f, offset_y = 32.0f;
+                const float tx = SF(s, F_TOGX, env), ty = SF(s, F_TOGY, env);
+                const float angle = static_cast<float>(at_atan2f(ty, tx) * 180.0f / 3.14159265358979323846);
+                const float dist = __fsqrt_rn(tx * tx + ty * ty);
+                const float dist_inv = 1.0f / fmaxf(0.0001f, dist);
+                const float dir_x = tx * dist_inv, dir_y = ty * dist_inv;
+                const float ratio = fminf(1.0f, dist / (W * 1.414f));
+                // circle, needle and bar differ in their parameters only: pick per lane, resolve once
+                float sx, sy, sw, sh;
+                double deg = 0.0;
+                if (lane == 1) {
+                    sx = width - compass_size * game_zoom + offset_x * game_zoom;
+                    sy = offset_y * game_zoom;
+                    sw = compass_size * game_zoom;
+                    sh = compass_size * game_zoom;
+                } else if (lane == 2) {
+                    float dx = width - compass_size * 0.75f * game_zoom + offset_x * game_zoom;
+                    float dy = compass_size * 0.5f * game_zoom + offset_y * game_zoom;
+                    dx += compass_size * 0.25f * dir_x * game_zoom;
+                    dy += compass_size * 0.25f * dir_y * game_zoom;
+                    sx = dx;
+                    sy = dy;
+                    sw = compass_size * 0.5f * game_zoom;
+                    sh = compass_size * 0.1f * game_zoom;
+                    deg = static_cast<double>(angle);
+                } else {
+                    sx = width - compass_size * game_zoom + offset_x * game_zoom;
+                    sy = compass_size * game_zoom + offset_y * game_zoom;
+                    sw = compass_size * game_zoom * ratio;
+                    sh = compass_size * 0.15f * game_zoom;
+                }
+                has = resolve_screen(d.y, d.z, d.x, sx, sy, sw, sh, deg, mine);
+            }
+            const int row_lo = half * (kObsH / halves), row_hi = (half + 1) * (kObsH / halves);
+            if (s.hud_image != 0u) {
+                // the ring is the same 60×60 pixels in every frame: prepared once (pg_render.h overlay_rows), in its place in
+                // the draw order — after the bunny, before the needle and the bar
+                wave_replay_rows(fb, atlas, mine, __ballot(has && lane == 0), lane, row_lo, row_hi);
+                overlay_rows(fb, atlas.texels + s.hud_image, reinterpret_cast<const uint2*>(atlas.texels + s.hud_list), s.hud_n,
+                             lane, row_lo, row_hi);
+                wave_replay_rows(fb, atlas, mine, __ballot(has && lane >= 2), lane, row_lo, row_hi);
+            } else {
+                wave_replay_rows(fb, atlas, mine, __ballot(has), lane, row_lo, row_hi);
+            }
         }
     }
     // each wave stores the rows it owns (pg_render.h wave_replay_rows): no barrier

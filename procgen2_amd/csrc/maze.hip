@@ -281,20 +281,18 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
             wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
         }
     }
-    if (sflags & kFlagListed) {  // the cheese sprite (tilemap.cpp:88): offset (-0.48,-0.5), scale 0.95, z = 1
-        const int4 d = atlas.desc[kTexCheese];
-        const float scale = 1.0f * 0.95f;
-        const bool ok = resolve_draw(cam, d.y, d.z, d.x, (SF(s, F_GX, env) + -0.48f) * kUnitPx,
-                                     (SF(s, F_GY, env) + -0.5f) * kUnitPx, scale * kUnitPx / d.y, 1.0f, false, false,
-                                     mine);
-        wave_replay_rows(fb, atlas, mine, ok ? 1ull : 0ull, lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
-    }
-    {  // the mouse (common_systems.cpp:138-150); flip = face_forward
-        const int4 d = atlas.desc[kTexMouse];
-        const bool ok = resolve_draw(cam, d.y, d.z, d.x, (SF(s, F_AX, env) + -0.5f) * kUnitPx,
-                                     (SF(s, F_AY, env) + -0.5f) * kUnitPx, kUnitPx / d.y * 1.0f, 1.0f,
-                                     (sflags & kFlagForward) != 0, false, mine);
-        wave_replay_rows(fb, atlas, mine, ok ? 1ull : 0ull, lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
+    {   // lane 0: the cheese sprite (tilemap.cpp:88): offset (-0.48,-0.5), scale 0.95, z = 1, once it is listed;
+        // lane 1: the mouse (common_systems.cpp:138-150); flip = face_forward.  The two differ in their parameters
+        // only: one pass through resolve_draw, one replay, in this order.
+        const bool cheese = lane == 0;
+        const int4 d = atlas.desc[cheese ? kTexCheese : kTexMouse];
+        const float wx = cheese ? (SF(s, F_GX, env) + -0.48f) * kUnitPx : (SF(s, F_AX, env) + -0.5f) * kUnitPx;
+        const float wy = cheese ? (SF(s, F_GY, env) + -0.5f) * kUnitPx : (SF(s, F_AY, env) + -0.5f) * kUnitPx;
+        const float scale = cheese ? (1.0f * 0.95f) * kUnitPx / d.y : kUnitPx / d.y * 1.0f;
+        bool has = cheese ? (sflags & kFlagListed) != 0 : lane == 1;
+        if (has)
+            has = resolve_draw(cam, d.y, d.z, d.x, wx, wy, scale, 1.0f, !cheese && (sflags & kFlagForward) != 0, false, mine);
+        wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
     }
     // each wave stores the rows it owns (pg_render.h wave_replay_rows): no barrier
     wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
