@@ -69,9 +69,10 @@ enum Tex {
 
 enum {
     F_AX, F_AY, F_AVX, F_AVY, F_APHASE, F_JUMP_T, F_CAMX, F_CAMY, F_TOGX, F_TOGY, F_GX, F_GY, F_BGSHIFT, F_PTIMER,
+    F_NEEDLE_X, F_NEEDLE_Y, F_BAR_W,  // the compass as it lands on the 64×64 observation (store_compass)
     F_COUNT
 };
-enum { I_FLAGS, I_THEMES, I_NSPIKES, I_JUMPS, I_HASH_SPRITE, I_COUNT };
+enum { I_FLAGS, I_THEMES, I_NSPIKES, I_JUMPS, I_HASH_SPRITE, I_NEEDLE_SN, I_NEEDLE_CS, I_COUNT };
 constexpr int kFlagGround = 1, kFlagForward = 2, kFlagListed = 4, kFlagPuffOn = 8;
 enum { PF_X, PF_Y, PF_LIFE, PF_COUNT };
 
@@ -397,11 +398,39 @@ PG_D void install(const State& s, int env, const Level& lv, int lane) {
 PG_D void fresh_chain(const State& s, int env) {
     SI(s, I_HASH_SPRITE, env) = 1;  // empty unordered_set: one bucket, next_resize 0
 }
+// The compass of the observation (jumper.cpp:473-509 at the 64×64 target: game_zoom 0.3) is a function of to_goal
+// alone: where the needle sits, its angle as the 16.16 sine and cosine of raster spec S6, how long the bar is.  Worked
+// out here, by the lane that owns the env in the logic kernel — 64 envs per pass through atan2f / sinf / cosf —
+// instead of by every lane of both render wavefronts of the env for the sake of one.  sn = 0, cs = 0 stands for an
+// angle of exactly zero (drawn un-rotated, like the oracle).
+constexpr float kObsZoom = 0.3f;
+PG_D void store_compass(const State& s, int env, float tx, float ty) {
+    SF(s, F_TOGX, env) = tx;
+    SF(s, F_TOGY, env) = ty;
+    const float game_zoom = kObsZoom;
+    const float width = 64.0f, compass_size = 200.0f, offset_x = -32.0f, offset_y = 32.0f;
+    const float angle = static_cast<float>(at_atan2f(ty, tx) * 180.0f / 3.14159265358979323846);
+    const float dist = __fsqrt_rn(tx * tx + ty * ty);
+    const float dist_inv = 1.0f / fmaxf(0.0001f, dist);
+    const float dir_x = tx * dist_inv, dir_y = ty * dist_inv;
+    const float ratio = fminf(1.0f, dist / (W * 1.414f));
+    float dx = width - compass_size * 0.75f * game_zoom + offset_x * game_zoom;
+    float dy = compass_size * 0.5f * game_zoom + offset_y * game_zoom;
+    dx += compass_size * 0.25f * dir_x * game_zoom;
+    dy += compass_size * 0.25f * dir_y * game_zoom;
+    SF(s, F_NEEDLE_X, env) = dx;
+    SF(s, F_NEEDLE_Y, env) = dy;
+    SF(s, F_BAR_W, env) = compass_size * game_zoom * ratio;
+    const double deg = static_cast<double>(angle);
+    int sn = 0, cs = 0;
+    if (deg != 0.0) rotation_16_16(deg, sn, cs);
+    SI(s, I_NEEDLE_SN, env) = sn;
+    SI(s, I_NEEDLE_CS, env) = cs;
+}
 PG_D void fresh_live(const State& s, int env) {
     SF(s, F_CAMX, env) = 0.0f;  // Renderer::camera_position{0} (renderer.h:18)
     SF(s, F_CAMY, env) = 0.0f;
-    SF(s, F_TOGX, env) = 0.0f;  // Agent_Info::to_goal{0, 0} (common_systems.h:57-59)
-    SF(s, F_TOGY, env) = 0.0f;
+    store_compass(s, env, 0.0f, 0.0f);  // Agent_Info::to_goal{0, 0} (common_systems.h:57-59)
 }
 
 struct Gen {  // pg_prefetch.h level_kernel<Gen>
@@ -513,8 +542,7 @@ PG_D void advance(const State& s, int env, int action, float& reward_out, bool& 
     SF(s, F_PTIMER, env) = p_timer;
     SF(s, F_CAMX, env) = ax * kUnitPx;  // common_systems.cpp:179-180
     SF(s, F_CAMY, env) = (ay - 0.5f) * kUnitPx;
-    SF(s, F_TOGX, env) = gx - ax;
-    SF(s, F_TOGY, env) = gy - ay;
+    store_compass(s, env, gx - ax, gy - ay);
     SI(s, I_JUMPS, env) = jumps;
     SI(s, I_FLAGS, env) = kFlagListed | (ground ? kFlagGround : 0) | (forward ? kFlagForward : 0) |
                           (puff_on ? kFlagPuffOn : 0);
@@ -704,38 +732,29 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
             go = true;
         }
         if (go) has = resolve_draw(cam, d.y, d.z, d.x, wx, wy, scale, alpha, flip, false, mine);
-        if (is_hud) {
+        if (is_hud) {  // circle, needle and bar differ in their parameters only (store_compass worked them out)
             const float width = 64.0f, compass_size = 200.0f, offset_x = -32.0f, offset_y = 32.0f;
-            const float tx = SF(s, F_TOGX, env), ty = SF(s, F_TOGY, env);
-            const float angle = static_cast<float>(at_atan2f(ty, tx) * 180.0f / 3.14159265358979323846);
-            const float dist = __fsqrt_rn(tx * tx + ty * ty);
-            const float dist_inv = 1.0f / fmaxf(0.0001f, dist);
-            const float dir_x = tx * dist_inv, dir_y = ty * dist_inv;
-            const float ratio = fminf(1.0f, dist / (W * 1.414f));
             float sx, sy, sw, sh;
-            double deg = 0.0;
+            int sn = 0, cs = 0;
             if (hud == 1) {
                 sx = width - compass_size * game_zoom + offset_x * game_zoom;
                 sy = offset_y * game_zoom;
                 sw = compass_size * game_zoom;
                 sh = compass_size * game_zoom;
             } else if (hud == 2) {
-                float dx = width - compass_size * 0.75f * game_zoom + offset_x * game_zoom;
-                float dy = compass_size * 0.5f * game_zoom + offset_y * game_zoom;
-                dx += compass_size * 0.25f * dir_x * game_zoom;
-                dy += compass_size * 0.25f * dir_y * game_zoom;
-                sx = dx;
-                sy = dy;
+                sx = SF(s, F_NEEDLE_X, env);
+                sy = SF(s, F_NEEDLE_Y, env);
                 sw = compass_size * 0.5f * game_zoom;
                 sh = compass_size * 0.1f * game_zoom;
-                deg = static_cast<double>(angle);
+                sn = SI(s, I_NEEDLE_SN, env);
+                cs = SI(s, I_NEEDLE_CS, env);
             } else {
                 sx = width - compass_size * game_zoom + offset_x * game_zoom;
                 sy = compass_size * game_zoom + offset_y * game_zoom;
-                sw = compass_size * game_zoom * ratio;
+                sw = SF(s, F_BAR_W, env);
                 sh = compass_size * 0.15f * game_zoom;
             }
-            has = resolve_screen(d.y, d.z, d.x, sx, sy, sw, sh, deg, mine);
+            has = resolve_screen_at(d.y, d.z, d.x, sx, sy, sw, sh, sn, cs, mine);
         }
         const int row_lo = half * (kObsH / halves), row_hi = (half + 1) * (kObsH / halves);
         if (s.hud_image != 0u) {

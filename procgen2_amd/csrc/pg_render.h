@@ -212,6 +212,13 @@ PG_D bool blit_take_rot(const uint32_t* slots, int lane, Blit& b) {
     return has;
 }
 
+// The angle of a rotated draw as raster spec S6 uses it: 16.16 sine and cosine of deg degrees (deg != 0).
+PG_D void rotation_16_16(double deg, int& sn, int& cs) {
+    const float theta = static_cast<float>(deg * (3.14159265358979323846 / 180.0));
+    sn = static_cast<int>(floor(static_cast<double>(sc_sinf(theta)) * 65536.0 + 0.5));
+    cs = static_cast<int>(floor(static_cast<double>(sc_cosf(theta)) * 65536.0 + 0.5));
+}
+
 // Renderer::render_texture_rotated (games/*/renderer.cpp:84-101) followed by raster-spec S1 and S6: no cull, no
 // crop, whole texture as source, rotation about the centre of the destination rectangle.  `rotation` is the
 // float the reference passes; the angle handed to SDL is rotation * 180.0f / M_PI in double.  An angle of exactly
@@ -241,9 +248,7 @@ PG_D bool resolve_rotated(const Camera& cam, int tw, int th, int tex_off, float 
     out.rot_sn = 0;
     out.rot_cs = 65536;
     if (deg != 0.0) {
-        const float theta = static_cast<float>(deg * (3.14159265358979323846 / 180.0));
-        out.rot_sn = static_cast<int>(floor(static_cast<double>(sc_sinf(theta)) * 65536.0 + 0.5));
-        out.rot_cs = static_cast<int>(floor(static_cast<double>(sc_cosf(theta)) * 65536.0 + 0.5));
+        rotation_16_16(deg, out.rot_sn, out.rot_cs);
         out.flip_mod |= kRotated;
     }
     return true;
@@ -268,11 +273,29 @@ PG_D bool resolve_screen(int tw, int th, int tex_off, float dx, float dy, float 
     out.rot_sn = 0;
     out.rot_cs = 65536;
     if (deg != 0.0) {
-        const float theta = static_cast<float>(deg * (3.14159265358979323846 / 180.0));
-        out.rot_sn = static_cast<int>(floor(static_cast<double>(sc_sinf(theta)) * 65536.0 + 0.5));
-        out.rot_cs = static_cast<int>(floor(static_cast<double>(sc_cosf(theta)) * 65536.0 + 0.5));
+        rotation_16_16(deg, out.rot_sn, out.rot_cs);
         out.flip_mod |= kRotated;
     }
+    return true;
+}
+// resolve_screen with the angle already in that form; sn = cs = 0: not rotated (an angle of exactly zero).
+PG_D bool resolve_screen_at(int tw, int th, int tex_off, float dx, float dy, float dw, float dh, int sn, int cs, Blit& out) {
+    if (!(dw >= 1.0f && dh >= 1.0f && dw < 32768.0f && dh < 32768.0f)) return false;
+    if (!(dx > -32768.0f && dx < 32768.0f && dy > -32768.0f && dy < 32768.0f)) return false;
+    out.dx = static_cast<int>(dx);
+    out.dy = static_cast<int>(dy);
+    out.dw = static_cast<int>(dw);
+    out.dh = static_cast<int>(dh);
+    out.sx = 0;
+    out.sy = 0;
+    out.sw = tw;
+    out.sh = th;
+    out.tex_off = tex_off;
+    out.tex_w = tw;
+    const bool rotated = sn != 0 || cs != 0;  // (sine and cosine are never both zero)
+    out.flip_mod = rotated ? (255 | kRotated) : 255;
+    out.rot_sn = rotated ? sn : 0;
+    out.rot_cs = rotated ? cs : 65536;
     return true;
 }
 
