@@ -64,7 +64,7 @@ enum {
 constexpr int kFlagAlive = 1, kFlagListed = 2;
 // I_SKINS: a_ship | a_laser<<4 | b_ship<<8 | b_laser<<12 | backdrop<<16
 // shot fields (floats); agent shots also have a "bouncing" byte
-enum { S_X, S_Y, S_VX, S_VY, S_ROT, S_FRAME, S_BOUNCE_T, S_COUNT };
+enum { S_X, S_Y, S_VX, S_VY, S_ROT, S_FRAME, S_BOUNCE_T, S_SN, S_CS, S_COUNT };  // S_SN/S_CS (boss bullets): the drawing angle as raster spec S6 takes it, int bits, fixed when fired
 
 struct State {
     int n;
@@ -196,6 +196,13 @@ PG_D void boss_fire(const State& s, int env, Live& v, float rotation, float spee
     if (v.b_count < kBossShots) {
         const int k = v.b_next;
         BS(s, S_ROT, k, env) = rotation;
+        {   // what System_Mob_AI::render's angle (rotation + π/2) comes to in the raster (pg_render.h rotation_of): once
+            // per bullet here, instead of sinf and cosf in every lane of both render wavefronts every frame
+            int sn, cs;
+            rotation_of(static_cast<float>(rotation + kPi * 0.5f), sn, cs);
+            BS(s, S_SN, k, env) = __int_as_float(sn);
+            BS(s, S_CS, k, env) = __int_as_float(cs);
+        }
         BS(s, S_VX, k, env) = sc_cosf(rotation) * speed;
         BS(s, S_VY, k, env) = -sc_sinf(rotation) * speed;
         BS(s, S_X, k, env) = v.bx;
@@ -678,7 +685,8 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
     {
         bool has = false;
         int want_tex = kTexLaser + b_laser;
-        float px = 0.0f, py = 0.0f, rot = 0.0f;
+        float px = 0.0f, py = 0.0f;
+        int rot_sn = 0, rot_cs = 0;  // (boss_fire worked them out)
         if (lane < b_count) {
             const int k = (kBossShots + b_next - 1 - lane) % kBossShots;
             const float frame = BS(s, S_FRAME, k, env);
@@ -687,14 +695,15 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
                 if (frame != 0.0f) want_tex = kTexBoom + static_cast<int>(frame - 1.0f);
                 px = BS(s, S_X, k, env);
                 py = BS(s, S_Y, k, env);
-                rot = BS(s, S_ROT, k, env);
+                rot_sn = __float_as_int(BS(s, S_SN, k, env));
+                rot_cs = __float_as_int(BS(s, S_CS, k, env));
             }
         }
         const int4 d = descs.at(want_tex);
         if (has) {
             const float size = 0.1f;
-            has = resolve_rotated(cam, d.y, d.z, d.x, px * kUnitPx - size * d.y * 0.5f, py * kUnitPx - size * d.z * 0.5f,
-                                  static_cast<float>(rot + kPi * 0.5f), size, 1.0f, mine);
+            has = resolve_rotated_at(cam, d.y, d.z, d.x, px * kUnitPx - size * d.y * 0.5f, py * kUnitPx - size * d.z * 0.5f,
+                                     rot_sn, rot_cs, size, 1.0f, mine);
         }
         wave_replay_rows<4, true>(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
     }

@@ -68,14 +68,18 @@ enum Tex {
     kTexCount = 26
 };
 
-enum { F_AX, F_AY, F_AVX, F_AVY, F_ROT, F_CAMX, F_CAMY, F_BGSHIFT, F_STIMER, F_PTIMER, F_COUNT };
+enum {
+    F_AX, F_AY, F_AVX, F_AVY, F_ROT, F_CAMX, F_CAMY, F_BGSHIFT, F_STIMER, F_PTIMER,
+    F_SHIP_SN, F_SHIP_CS,  // the ship's drawing angle as raster spec S6 takes it (pg_render.h rotation_of), int bits
+    F_COUNT
+};
 enum { I_FLAGS, I_BACKDROP, I_NENT, I_NDRAW, I_SNEXT, I_SCOUNT, I_HASH_SPRITE, I_HASH_HAZARD, I_COUNT };
 constexpr int kFlagListed = 1, kFlagPuffOn = 2;
 enum { EF_X, EF_Y, EF_VX, EF_VY, EF_COUNT };
 enum { EB_INFO, EB_ORDER_S, EB_ORDER_H, EB_DRAW, EB_COUNT };
 constexpr int kKindMask = 3, kAlive = 4;
-enum { SH_X, SH_Y, SH_VX, SH_VY, SH_ROT, SH_FRAME, SH_COUNT };
-enum { PF_X, PF_Y, PF_DX, PF_DY, PF_ROT, PF_LIFE, PF_COUNT };
+enum { SH_X, SH_Y, SH_VX, SH_VY, SH_ROT, SH_FRAME, SH_SN, SH_CS, SH_COUNT };  // SH_SN/CS: rotation_of the drawing angle, fixed when fired
+enum { PF_X, PF_Y, PF_DX, PF_DY, PF_ROT, PF_LIFE, PF_SN, PF_CS, PF_COUNT };  // likewise
 
 // One generated level, as the generator leaves it in LDS and as it waits in the shadow slot.
 struct Level {
@@ -107,6 +111,14 @@ PG_D float& SF(const State& s, int field, int env) { return s.f[size_t(field) * 
 PG_D int32_t& SI(const State& s, int field, int env) { return s.i[size_t(field) * s.n + env]; }
 PG_D float& EF(const State& s, int field, int e, int env) { return s.ef[(size_t(field) * kMaxEnt + e) * s.n + env]; }
 PG_D uint8_t& EB(const State& s, int field, int e, int env) { return s.eb[(size_t(field) * kMaxEnt + e) * s.n + env]; }
+// rotation_of(angle) into a pair of float slots (as int bits): where the angle is set, so the render kernel reads two
+// words instead of evaluating sinf and cosf in every lane of both wavefronts, every frame.
+PG_D void store_rotation(float& sn_slot, float& cs_slot, float angle) {
+    int sn, cs;
+    rotation_of(angle, sn, cs);
+    sn_slot = __int_as_float(sn);
+    cs_slot = __int_as_float(cs);
+}
 PG_D float& SH(const State& s, int field, int k, int env) { return s.sh[(size_t(field) * kShots + k) * s.n + env]; }
 PG_D float& PF(const State& s, int field, int k, int env) { return s.pf[(size_t(field) * kPuffs + k) * s.n + env]; }
 
@@ -280,6 +292,7 @@ PG_D void install(const State& s, int env, const Level& lv, int lane) {
         SF(s, F_AVX, env) = 0.0f;
         SF(s, F_AVY, env) = 0.0f;
         SF(s, F_ROT, env) = 0.0f;
+        store_rotation(SF(s, F_SHIP_SN, env), SF(s, F_SHIP_CS, env), static_cast<float>(0.0f + kPi * 0.5f));
         SF(s, F_BGSHIFT, env) = lv.bgshift;
         SF(s, F_STIMER, env) = 0.0f;
         SF(s, F_PTIMER, env) = 0.0f;
@@ -383,6 +396,7 @@ PG_D void advance(const State& s, StepLds& L, int lane, bool active, int env, in
             if (s_timer == 0.0f && s_count < kShots) {
                 s_timer = bullet_time;
                 SH(s, SH_ROT, s_next, env) = rot;
+                store_rotation(SH(s, SH_SN, s_next, env), SH(s, SH_CS, s_next, env), static_cast<float>(rot + kPi * 0.5f));
                 SH(s, SH_VX, s_next, env) = dir_x * bullet_speed;
                 SH(s, SH_VY, s_next, env) = dir_y * bullet_speed;
                 SH(s, SH_X, s_next, env) = ax;
@@ -502,6 +516,7 @@ PG_D void advance(const State& s, StepLds& L, int lane, bool active, int env, in
                 const float c = sc_cosf(prot), sn = sc_sinf(prot);
                 PF(s, PF_LIFE, dead_index, env) = lifespan;
                 PF(s, PF_ROT, dead_index, env) = prot;
+                store_rotation(PF(s, PF_SN, dead_index, env), PF(s, PF_CS, dead_index, env), prot);
                 PF(s, PF_DX, dead_index, env) = -sc_cosf(rot);
                 PF(s, PF_DY, dead_index, env) = -sc_sinf(rot);
                 PF(s, PF_X, dead_index, env) = ax + (c * off_x - sn * off_y);
@@ -520,6 +535,7 @@ PG_D void advance(const State& s, StepLds& L, int lane, bool active, int env, in
     SF(s, F_AVX, env) = avx;
     SF(s, F_AVY, env) = avy;
     SF(s, F_ROT, env) = rot;
+    store_rotation(SF(s, F_SHIP_SN, env), SF(s, F_SHIP_CS, env), static_cast<float>(rot + kPi * 0.5f));
     SF(s, F_STIMER, env) = s_timer;
     SF(s, F_PTIMER, env) = p_timer;
     SI(s, I_SNEXT, env) = s_next;
@@ -611,14 +627,16 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
     Blit mine;
 
     // inputs of the sprite passes, requested early
-    float puff_life = 0.0f, puff_x = 0.0f, puff_y = 0.0f, puff_dx = 0.0f, puff_dy = 0.0f, puff_rot = 0.0f;
+    float puff_life = 0.0f, puff_x = 0.0f, puff_y = 0.0f, puff_dx = 0.0f, puff_dy = 0.0f;
+    int puff_sn = 0, puff_cs = 0;  // the angles arrive as 16.16 sine and cosine (store_rotation)
     if (lane < kPuffs) {
         puff_life = PF(s, PF_LIFE, lane, env);
         puff_x = PF(s, PF_X, lane, env);
         puff_y = PF(s, PF_Y, lane, env);
         puff_dx = PF(s, PF_DX, lane, env);
         puff_dy = PF(s, PF_DY, lane, env);
-        puff_rot = PF(s, PF_ROT, lane, env);
+        puff_sn = __float_as_int(PF(s, PF_SN, lane, env));
+        puff_cs = __float_as_int(PF(s, PF_CS, lane, env));
     }
     // When everything after the tile layer fits the wave's 64 lanes it is drawn as ONE pass, lanes in draw order:
     // particles, then the sprites, then the bullets and the ship (see below); otherwise a pass per kind, from lane 0.
@@ -632,18 +650,21 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
         spr_x = EF(s, EF_X, e, env);
         spr_y = EF(s, EF_Y, e, env);
     }
-    float shot_frame = -1.0f, shot_x = 0.0f, shot_y = 0.0f, shot_rot = 0.0f;
+    float shot_frame = -1.0f, shot_x = 0.0f, shot_y = 0.0f;
+    int shot_sn = 0, shot_cs = 0;
     const int shot_i = lane - shot_lane0;  // bullets newest first, then the ship
     if (shot_i >= 0 && shot_i < s_count) {
         const int k = (kShots + s_next - 1 - shot_i) % kShots;
         shot_frame = SH(s, SH_FRAME, k, env);
         shot_x = SH(s, SH_X, k, env);
         shot_y = SH(s, SH_Y, k, env);
-        shot_rot = SH(s, SH_ROT, k, env);
+        shot_sn = __float_as_int(SH(s, SH_SN, k, env));
+        shot_cs = __float_as_int(SH(s, SH_CS, k, env));
     } else if (shot_i == s_count) {
         shot_x = SF(s, F_AX, env);
         shot_y = SF(s, F_AY, env);
-        shot_rot = SF(s, F_ROT, env);
+        shot_sn = __float_as_int(SF(s, F_SHIP_SN, env));
+        shot_cs = __float_as_int(SF(s, F_SHIP_CS, env));
     }
 
     int bg_soft = 0;  // the backdrop has texels that are not opaque (descriptor .w)
@@ -710,7 +731,7 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
         const bool is_puff = lane < kPuffs, is_spr = lane >= spr_lane0 && lane < shot_lane0;
         int want_tex = kTexShip;
         bool go = shot_i == s_count;  // the ship
-        float size = 0.15f, alpha = 1.0f, rx = 0.0f, ry = 0.0f, rot = 0.0f;
+        float size = 0.15f, alpha = 1.0f, rx = 0.0f, ry = 0.0f;
         if (is_puff) {
             want_tex = kTexPuff;
             go = puff_life > 0.0f;
@@ -732,14 +753,14 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
             size = scale * kUnitPx / d.y;
             rx = (puff_x + puff_dx * shift) * kUnitPx - size * d.y * 0.5f;
             ry = (puff_y + puff_dy * shift) * kUnitPx - size * d.z * 0.5f;
-            rot = puff_rot;
         } else {
             rx = shot_x * kUnitPx - size * d.y * 0.5f;
             ry = shot_y * kUnitPx - size * d.z * 0.5f;
-            rot = static_cast<float>(shot_rot + kPi * 0.5f);
         }
         bool has = false;
-        if (go) has = resolve_rotated(cam, d.y, d.z, d.x, rx, ry, rot, size, alpha, mine);
+        if (go)
+            has = resolve_rotated_at(cam, d.y, d.z, d.x, rx, ry, is_puff ? puff_sn : shot_sn, is_puff ? puff_cs : shot_cs, size,
+                                     alpha, mine);
         if (is_spr) {
             const float scale = 1.0f * 0.8f;
             has = resolve_draw(cam, d.y, d.z, d.x, (spr_x + -0.4f) * kUnitPx, (spr_y + -0.4f) * kUnitPx,
@@ -757,8 +778,9 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
                 const float scale = 1.0f * (0.4f * life_ratio + 0.6f);
                 const float shift = life_ratio * 2.0f;
                 const float size = scale * kUnitPx / d.y;
-                has = resolve_rotated(cam, d.y, d.z, d.x, (puff_x + puff_dx * shift) * kUnitPx - size * d.y * 0.5f,
-                                      (puff_y + puff_dy * shift) * kUnitPx - size * d.z * 0.5f, puff_rot, size, alpha, mine);
+                has = resolve_rotated_at(cam, d.y, d.z, d.x, (puff_x + puff_dx * shift) * kUnitPx - size * d.y * 0.5f,
+                                         (puff_y + puff_dy * shift) * kUnitPx - size * d.z * 0.5f, puff_sn, puff_cs, size, alpha,
+                                         mine);
             }
             wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
         }
@@ -802,9 +824,8 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
             }
             const int4 d = descs.at(want_tex);
             if (has)
-                has = resolve_rotated(cam, d.y, d.z, d.x, shot_x * kUnitPx - size * d.y * 0.5f,
-                                      shot_y * kUnitPx - size * d.z * 0.5f, static_cast<float>(shot_rot + kPi * 0.5f), size,
-                                      1.0f, mine);
+                has = resolve_rotated_at(cam, d.y, d.z, d.x, shot_x * kUnitPx - size * d.y * 0.5f,
+                                         shot_y * kUnitPx - size * d.z * 0.5f, shot_sn, shot_cs, size, 1.0f, mine);
             wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
         }
     }

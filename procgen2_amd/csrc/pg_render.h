@@ -254,6 +254,43 @@ PG_D bool resolve_rotated(const Camera& cam, int tw, int th, int tex_off, float 
     return true;
 }
 
+// The same with the angle in the form the raster uses, for games that know it before the frame: a bullet's rotation is
+// fixed when it is fired, a ship's changes once a step — the logic kernel's lane for the env works out the sine and
+// cosine once (rotation_of: exactly what resolve_rotated makes of its `rotation`) instead of every lane of both render
+// wavefronts doing it every frame.  sn = cs = 0 stands for an angle of exactly zero (drawn un-rotated).
+PG_D void rotation_of(float rotation, int& sn, int& cs) {
+    const double deg = rotation * 180.0f / 3.14159265358979323846;
+    sn = 0;
+    cs = 0;
+    if (deg != 0.0) rotation_16_16(deg, sn, cs);
+}
+PG_D bool resolve_rotated_at(const Camera& cam, int tw, int th, int tex_off, float pos_x, float pos_y, int sn, int cs,
+                             float scale, float alpha, Blit& out) {
+    const float dx = (pos_x - cam.px) * cam.scale + cam.sw * 0.5f;
+    const float dy = (pos_y - cam.py) * cam.scale + cam.sh * 0.5f;
+    const float dw = tw * scale * cam.scale;
+    const float dh = th * scale * cam.scale;
+    int mod = 255;
+    if (alpha != 1.0f) mod = static_cast<int>(255 * alpha) & 0xff;
+    if (!(dw >= 1.0f && dh >= 1.0f && dw < 32768.0f && dh < 32768.0f)) return false;
+    if (!(dx > -32768.0f && dx < 32768.0f && dy > -32768.0f && dy < 32768.0f)) return false;
+    out.dx = static_cast<int>(dx);
+    out.dy = static_cast<int>(dy);
+    out.dw = static_cast<int>(dw);
+    out.dh = static_cast<int>(dh);
+    out.sx = 0;
+    out.sy = 0;
+    out.sw = tw;
+    out.sh = th;
+    out.tex_off = tex_off;
+    out.tex_w = tw;
+    const bool rotated = sn != 0 || cs != 0;  // (sine and cosine are never both zero)
+    out.flip_mod = rotated ? (mod | kRotated) : mod;
+    out.rot_sn = rotated ? sn : 0;
+    out.rot_cs = rotated ? cs : 65536;
+    return true;
+}
+
 // A raw SDL_RenderTextureRotated(renderer, texture, NULL, &dst, angle, NULL, SDL_FLIP_NONE) in screen space (jumper's
 // compass, jumper.cpp:485-508): whole texture as source, float destination rectangle, `deg` degrees about its centre.
 PG_D bool resolve_screen(int tw, int th, int tex_off, float dx, float dy, float dw, float dh, double deg, Blit& out) {
