@@ -3,6 +3,7 @@
 # Output: gpurun_out/<tag>_<game>_kernel_stats.csv
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r02_k}
+mkdir -p $(dirname $R/gpurun_out/${TAG}_x)
 cd /tmp && export TMPDIR=/tmp
 for G in coinrun maze bossfight climber caveflyer chaser jumper; do
   rm -rf /tmp/ks_$G
