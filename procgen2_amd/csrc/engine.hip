@@ -93,8 +93,8 @@ bool Atlas::load(const std::string& root, const std::vector<std::string>& names,
 }
 
 bool Atlas::upload(std::string& err) {
-    if (texels_.size() * 4 >= 0x40000000ull) {
-        err = "atlas exceeds 1 GiB (pg_render.h kNoTexel)";
+    if (texels_.size() * 4 >= 0x10000000ull) {  // byte offsets share their word with two rank bits (pg_render.h kRank)
+        err = "atlas exceeds 256 MiB (pg_render.h kRank, kNoTexel)";
         return false;
     }
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_texels_), texels_.size() * 4);

@@ -19,7 +19,7 @@ struct AtlasView {
     const uint32_t* texels;
     const int4* desc;
     int count;
-    uint32_t texel_bytes;  // size of `texels` in bytes (< 1 GiB: pg_render.h kNoTexel)
+    uint32_t texel_bytes;  // size of `texels` in bytes (< 256 MiB: pg_render.h kRank, kNoTexel)
     const uint8_t* sort_ranks;  // pg_order.h equal_key_ranks table (kRankTableBytes), uploaded with the atlas
 };
 

@@ -924,7 +924,7 @@ PG_D bool covering(const ComposeTmp<GRID>& T, int axis, int p, int& ia, int& ib,
 }
 
 // "No texel here" marker for the composer's byte offsets: adding it to any valid offset lands beyond the
-// atlas (which must stay below kNoTexel bytes — checked at make time), so the buffer load's hardware range
+// atlas (which stays below 2^28 bytes — checked at make time), so the buffer load's hardware range
 // check returns 0 = alpha 0 = pixel untouched.  Two markers added together still do not wrap 32 bits.
 constexpr uint32_t kNoTexel = 0x40000000u;
 
@@ -1201,6 +1201,20 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
     using lds_ptr = __attribute__((address_space(3))) void*;
     // Eight rows at a time: first every cell word the rows may need is requested from the table, then the addresses
     // are worked out and the gathers leave.  One wait for the table per eight rows instead of one per row.
+    //
+    // "The candidate drawn last among those that exist" without a compare and a select per candidate: a candidate that
+    // exists has a byte offset below 2^28 (the atlas is smaller: checked at make time), one that does not is at least
+    // 2^30 (kNoTexel, from whichever of its three terms is missing).  Add the candidate's rank from the END of the draw
+    // order, times 2^28, and the unsigned MINIMUM is the existing candidate drawn last — or, when none exists, a word
+    // of at least 2^30.  The ranks sit in the per-lane column terms (loop-invariant) and in the scalar row terms.
+    // Clearing bits 28-29 leaves the offset, or something beyond the atlas that reads as 0.  On rows two grid rows
+    // cover the three candidates of the upper grid row are settled first and their winner enters the second minimum.
+    constexpr uint32_t kRank = 1u << 28, kOffsetBits = 0xcfffffffu;  // (several missing terms may carry into bit 31)
+    const uint32_t bg_col_r = bg_col + 2u * kRank, col_a_r = col_a + kRank;  // (·, b) is drawn after (·, a): rank 0
+    auto min3_u32 = [](uint32_t a, uint32_t b, uint32_t c) {  // v_min3_u32
+        const uint32_t m = a < b ? a : b;
+        return m < c ? m : c;
+    };
 #pragma unroll
     for (int g = 0; g < kRows / kBatch; g++) {
         uint32_t cell_aa[kBatch], cell_ab[kBatch], cell_ba[kBatch], cell_bb[kBatch];
@@ -1219,18 +1233,14 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
             const uint32_t s_bg = __builtin_amdgcn_readlane(bg_row, py);
             const uint32_t s_a = __builtin_amdgcn_readlane(row_a, py);
             const uint32_t s_a2 = TWO ? __builtin_amdgcn_readlane(row_a2, py) : 0u;
-            uint32_t at = bg_col + s_bg;  // draw order: background, (a, a), (a, b), (b, a), (b, b) — the last one there wins
-            uint32_t x = tile_at(cell_aa[k], col_a, s_a, s_a2);
-            at = x < kNoTexel ? x : at;
-            x = tile_at(cell_ab[k], col_b, s_a, s_a2);
-            at = x < kNoTexel ? x : at;
+            // draw order: background, (a, a), (a, b), (b, a), (b, b) — the last one there wins
+            uint32_t at = min3_u32(bg_col_r + s_bg, tile_at(cell_aa[k], col_a_r, s_a, s_a2), tile_at(cell_ab[k], col_b, s_a, s_a2)) &
+                          kOffsetBits;
             if (seconds32 & (1u << (g * kBatch + k))) {  // wave-uniform
                 const uint32_t s_b = __builtin_amdgcn_readlane(row_b, py);
                 const uint32_t s_b2 = TWO ? __builtin_amdgcn_readlane(row_b2, py) : 0u;
-                x = tile_at(cell_ba[k], col_a, s_b, s_b2);
-                at = x < kNoTexel ? x : at;
-                x = tile_at(cell_bb[k], col_b, s_b, s_b2);
-                at = x < kNoTexel ? x : at;
+                at = min3_u32(at + 2u * kRank, tile_at(cell_ba[k], col_a_r, s_b, s_b2), tile_at(cell_bb[k], col_b, s_b, s_b2)) &
+                     kOffsetBits;
                 asm volatile("" : "+v"(at));  // keeps the branch a branch
             }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(atlas_rsrc, (lds_ptr)(fb + py * kObsW), 4, static_cast<int>(at), 0, 0, 0);
