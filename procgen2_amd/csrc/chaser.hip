@@ -820,7 +820,7 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
             n_seen += __popcll(others);
             has = has && keep;
         }
-        wave_replay_rows(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
+        wave_replay_rows<4, false, false>(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
     }
     // each wave stores the rows it owns (pg_render.h wave_replay_rows): no barrier
     wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
