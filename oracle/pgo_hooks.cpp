@@ -245,3 +245,34 @@ HOOK void pgo_hook_sort_equal(int n, int* out) {
     std::sort(v.begin(), v.end(), [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.first < b.first; });
     for (int i = 0; i < n; i++) out[i] = v[i].second;
 }
+
+// A list of integer draw calls through the raster spec (pgo_raster.cpp spec_blit), for the device-side test of the
+// engine's sprite replay (tests/hip/selftest.hip pgst_replay): textures are RGBA8 blobs one after the other, `bg` the
+// 64×64 target to start from (0x00BBGGRR words), a draw is 12 ints {texture, dx, dy, dw, dh, sx, sy, sw, sh,
+// flip (1 = horizontal, 2 = vertical), alpha modulation, rotated} plus its angle in degrees; out = 64×64 RGB.
+#include "pgo_raster.h"
+HOOK void pgo_hook_raster(int n_tex, const int* tex_w, const int* tex_h, const uint8_t* rgba, const uint32_t* bg,
+                          int n_draws, const int32_t* draws, const double* deg, uint8_t* out_rgb) {
+    std::vector<pgo::Texture> tex(n_tex);
+    size_t at = 0;
+    for (int t = 0; t < n_tex; t++) {
+        tex[t].w = tex_w[t];
+        tex[t].h = tex_h[t];
+        tex[t].rgba.assign(rgba + at, rgba + at + size_t(tex_w[t]) * tex_h[t] * 4);
+        at += size_t(tex_w[t]) * tex_h[t] * 4;
+    }
+    pgo::Surface target(64, 64);
+    for (int k = 0; k < 64 * 64; k++) {
+        target.px[4 * k + 0] = static_cast<uint8_t>(bg[k]);
+        target.px[4 * k + 1] = static_cast<uint8_t>(bg[k] >> 8);
+        target.px[4 * k + 2] = static_cast<uint8_t>(bg[k] >> 16);
+        target.px[4 * k + 3] = 255;
+    }
+    for (int k = 0; k < n_draws; k++) {
+        const int32_t* d = draws + 12 * k;
+        pgo::spec_blit(target, tex[d[0]], static_cast<float>(d[5]), static_cast<float>(d[6]), static_cast<float>(d[7]),
+                       static_cast<float>(d[8]), static_cast<float>(d[1]), static_cast<float>(d[2]),
+                       static_cast<float>(d[3]), static_cast<float>(d[4]), d[11] ? deg[k] : 0.0, d[9], d[10]);
+    }
+    pgo::pack_rgb(target, out_rgb);
+}

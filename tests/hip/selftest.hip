@@ -17,6 +17,8 @@
 #include "pg_rng.h"
 #include "pg_setorder.h"
 #include "pg_sincos.h"
+#include "pg_engine.h"
+#include "pg_render.h"
 
 #define ST_API extern "C" __attribute__((visibility("default")))
 
@@ -190,7 +192,64 @@ __global__ void k_sort_equal(int n, int* out) {
     for (int k = 0; k < n; k++) out[k] = items[k].id;
 }
 
+// The sprite replay of the two-wavefront render kernels (pg_render.h wave_replay_rows) on a synthetic draw list: one
+// draw per lane, in lane order, over a given 64×64 target; each wave blends and stores the 32 rows it owns.
+template <bool kRotInGroups>
+__global__ void __launch_bounds__(128) k_replay(pg::AtlasView atlas, const uint32_t* bg, int n_draws, const int32_t* draws,
+                                                const double* deg, uint8_t* out_rgb) {
+    __shared__ uint32_t fb[pg::kFbWords];
+    const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int k = threadIdx.x; k < pg::kFbWords; k += 128) fb[k] = bg[k] | 0x5a000000u;  // (the top byte is nobody's)
+    __syncthreads();
+    pg::Blit mine;
+    mine.dx = mine.dy = mine.sx = mine.sy = mine.tex_off = 0;
+    mine.dw = mine.dh = mine.sw = mine.sh = mine.tex_w = 1;
+    mine.flip_mod = 255;
+    mine.rot_sn = 0;
+    mine.rot_cs = 65536;
+    const bool has = lane < n_draws;
+    if (has) {
+        const int32_t* d = draws + 12 * lane;
+        const int4 t = atlas.desc[d[0]];
+        mine.dx = d[1];
+        mine.dy = d[2];
+        mine.dw = d[3];
+        mine.dh = d[4];
+        mine.sx = d[5];
+        mine.sy = d[6];
+        mine.sw = d[7];
+        mine.sh = d[8];
+        mine.tex_off = t.x;
+        mine.tex_w = t.y;
+        mine.flip_mod = d[10] | ((d[9] & 1) ? pg::kFlipH : 0) | ((d[9] & 2) ? pg::kFlipV : 0);
+        if (d[11] && deg[lane] != 0.0) {
+            pg::rotation_16_16(deg[lane], mine.rot_sn, mine.rot_cs);
+            mine.flip_mod = d[10] | pg::kRotated;
+        }
+    }
+    pg::wave_replay_rows<4, kRotInGroups>(fb, atlas, mine, __ballot(has), lane, 32 * half, 32 * half + 32);
+    pg::wave_store_rows(fb, out_rgb, lane, 32 * half, 32 * half + 32);
+}
+
 }  // namespace
+
+// atlas: `words` RGBA texels of all textures one after the other, desc[t] = {first texel, w, h, 0}.
+ST_API int pgst_replay(int rot_in_groups, int n_tex, const int32_t* desc, int n_words, const uint32_t* words,
+                       const uint32_t* bg, int n_draws, const int32_t* draws, const double* deg, uint8_t* out_rgb) {
+    if (n_draws > 64) return 1;
+    Dev<int4> d_desc(reinterpret_cast<const int4*>(desc), n_tex);
+    Dev<uint32_t> d_words(words, n_words), d_bg(bg, 64 * 64);
+    Dev<int32_t> d_draws(draws, size_t(12) * (n_draws ? n_draws : 1));
+    Dev<double> d_deg(deg, n_draws ? n_draws : 1);
+    Dev<uint8_t> d_out(64 * 64 * 3);
+    const pg::AtlasView atlas{d_words.p, d_desc.p, n_tex, static_cast<uint32_t>(n_words) * 4u, nullptr};
+    if (rot_in_groups)
+        hipLaunchKernelGGL(k_replay<true>, dim3(1), dim3(128), 0, 0, atlas, d_bg.p, n_draws, d_draws.p, d_deg.p, d_out.p);
+    else
+        hipLaunchKernelGGL(k_replay<false>, dim3(1), dim3(128), 0, 0, atlas, d_bg.p, n_draws, d_draws.p, d_deg.p, d_out.p);
+    if (finish()) return 1;
+    return d_out.down(out_rgb) ? 0 : 1;
+}
 
 ST_API int pgst_device_count(void) {
     int n = 0;

@@ -30,7 +30,8 @@ def st():
                        ("pgst_blend", [c_int, V, V, V, V, V]), ("pgst_box", [c_int, V, V, V, V]),
                        ("pgst_mt", [c_int, V, c_int, c_int, V]), ("pgst_draws", [c_uint32, c_int, V, V, V, V, V, c_int, V, V]),
                        ("pgst_bulk", [c_uint32, c_int, c_int, V, V]), ("pgst_hash_script", [c_int, V, V, V]),
-                       ("pgst_set_rounds", [c_int, V, V, V]), ("pgst_sort_equal", [c_int, V])):
+                       ("pgst_set_rounds", [c_int, V, V, V]), ("pgst_sort_equal", [c_int, V]),
+                       ("pgst_replay", [c_int, c_int, V, c_int, V, V, c_int, V, V, V])):
         getattr(lib, name).argtypes = args
         getattr(lib, name).restype = c_int
     assert lib.pgst_device_count() > 0
@@ -259,3 +260,65 @@ def test_integer_raster_arithmetic_and_aabb(st):
     hit, ov = np.zeros(ra.shape[0], np.uint8), np.zeros((ra.shape[0], 4), np.float32)
     assert st.pgst_box(ra.shape[0], _p(ra), _p(rb), _p(hit), _p(ov)) == 0
     assert np.array_equal(hit, h0) and np.array_equal(ov.view(np.uint32), o0.view(np.uint32))
+
+
+def _sprite_scene(rng, n_draws, crowded):
+    """Random textures (alpha 0 / 255 / in between), a random opaque target and a list of integer draw calls: small
+    and large, clipped by the target's edges, flipped, alpha-modulated, some rotated; `crowded` keeps the small ones
+    in one corner so that consecutive draws overlap pixel for pixel (what wave_order() in pg_render.h is about)."""
+    n_tex = 6
+    tw = rng.integers(3, 40, n_tex).astype(np.int32)
+    th = rng.integers(3, 40, n_tex).astype(np.int32)
+    texels, desc, at = [], [], 0
+    for t in range(n_tex):
+        px = rng.integers(0, 256, (th[t], tw[t], 4)).astype(np.uint8)
+        kind = rng.random((th[t], tw[t]))
+        px[..., 3] = np.where(kind < 0.3, 0, np.where(kind < 0.7, 255, px[..., 3]))
+        texels.append(px.reshape(-1, 4))
+        desc.append((at, tw[t], th[t], 0))
+        at += int(tw[t]) * int(th[t])
+    rgba = np.concatenate(texels).astype(np.uint8)
+    words = (rgba[:, 0].astype(np.uint32) | (rgba[:, 1].astype(np.uint32) << 8) | (rgba[:, 2].astype(np.uint32) << 16)
+             | (rgba[:, 3].astype(np.uint32) << 24))
+    bg = rng.integers(0, 1 << 24, 64 * 64, dtype=np.int64).astype(np.uint32)
+    draws, deg = np.zeros((n_draws, 12), np.int32), np.zeros(n_draws, np.float64)
+    for k in range(n_draws):
+        t = int(rng.integers(0, n_tex))
+        small = rng.random() < 0.75
+        dw, dh = (int(rng.integers(1, 9)), int(rng.integers(1, 9))) if small else (int(rng.integers(9, 70)), int(rng.integers(9, 50)))
+        if crowded and small:
+            dx, dy = int(rng.integers(20, 30)), int(rng.integers(26, 38))  # across the row the two waves split at
+        else:
+            dx, dy = int(rng.integers(-12, 64)), int(rng.integers(-12, 64))
+        rotated = rng.random() < 0.3
+        if rotated:
+            sx, sy, sw, sh, flip = 0, 0, int(tw[t]), int(th[t]), 0
+            deg[k] = float(rng.uniform(-400.0, 400.0)) if rng.random() < 0.9 else 0.0
+        else:
+            sx, sy = int(rng.integers(0, tw[t])), int(rng.integers(0, th[t]))
+            sw, sh = int(rng.integers(1, tw[t] - sx + 1)), int(rng.integers(1, th[t] - sy + 1))
+            flip = int(rng.integers(0, 3))
+        mod = 255 if rng.random() < 0.5 else int(rng.integers(0, 256))
+        draws[k] = (t, dx, dy, dw, dh, sx, sy, sw, sh, flip, mod, 1 if rotated else 0)
+    return tw, th, rgba, words, np.array(desc, np.int32), bg, draws, deg
+
+
+@pytest.mark.parametrize("rot_in_groups", [0, 1])
+def test_sprite_replay_matches_the_raster_spec(st, rot_in_groups):
+    """pg_render.h wave_replay_rows — groups of small draws, large ones alone, rotated ones either way, each wave on
+    the rows it owns — against oracle/pgo_raster.cpp's spec_blit on the same integer draw calls."""
+    hooks = oracle_util.oracle()
+    hooks.pgo_hook_raster.argtypes = [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]
+    hooks.pgo_hook_raster.restype = None
+    for seed in range(60):
+        rng = np.random.default_rng(1000 + seed)
+        n_draws = int(rng.integers(0, 65))
+        tw, th, rgba, words, desc, bg, draws, deg = _sprite_scene(rng, n_draws, crowded=seed % 2 == 0)
+        want = np.zeros(64 * 64 * 3, np.uint8)
+        hooks.pgo_hook_raster(len(tw), _p(tw), _p(th), _p(rgba), _p(bg), n_draws, _p(draws), _p(deg), _p(want))
+        got = np.zeros(64 * 64 * 3, np.uint8)
+        assert st.pgst_replay(rot_in_groups, len(tw), _p(desc), len(words), _p(words), _p(bg), n_draws, _p(draws), _p(deg),
+                              _p(got)) == 0
+        bad = np.nonzero((got != want).reshape(-1, 3).any(axis=1))[0]
+        assert bad.size == 0, "seed %d: %d pixels differ, first (y=%d, x=%d): got %s want %s" % (
+            seed, bad.size, bad[0] // 64, bad[0] % 64, got.reshape(-1, 3)[bad[0]], want.reshape(-1, 3)[bad[0]])
