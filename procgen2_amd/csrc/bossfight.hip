@@ -62,6 +62,7 @@ enum {
     I_COUNT
 };
 constexpr int kFlagAlive = 1, kFlagListed = 2;
+constexpr int kShotBatch = 8;  // bullets whose state is fetched together (agent_update / boss_update)
 // I_SKINS: a_ship | a_laser<<4 | b_ship<<8 | b_laser<<12 | backdrop<<16
 // shot fields (floats); agent shots also have a "bouncing" byte
 enum { S_X, S_Y, S_VX, S_VY, S_ROT, S_FRAME, S_BOUNCE_T, S_SN, S_CS, S_COUNT };  // S_SN/S_CS (boss bullets): the drawing angle as raster spec S6 takes it, int bits, fixed when fired
@@ -185,11 +186,18 @@ struct Live {  // the hot scalars of one env, kept in registers over the four su
     int a_next, a_count, phase, weapon, hp, b_next, b_count, x_next, x_count, n_rocks;
     bool a_alive;
     Box scr;  // the screen rectangle both update()s clamp against (screen_box of the env's View, D15)
+    float rock_x[kRocks], rock_y[kRocks];  // the barriers (fixed for the episode): read once a step, not once per bullet
 };
 
 PG_D Box hazard_box(const State& s, int env, const Live& v, int h) {  // h: 0..n_rocks-1 barrier, n_rocks = boss
     if (h == v.n_rocks) return Box{v.bx + -0.6f, v.by + -0.4f, 1.2f, 0.8f};
-    return Box{RK(s, 0, h, env) + -0.1f, RK(s, 1, h, env) + -0.1f, 0.2f, 0.2f};
+    float x = v.rock_x[0], y = v.rock_y[0];  // (selects, not an indexed array: the table stays in registers)
+#pragma unroll
+    for (int q = 1; q < kRocks; q++) {
+        x = h == q ? v.rock_x[q] : x;
+        y = h == q ? v.rock_y[q] : y;
+    }
+    return Box{x + -0.1f, y + -0.1f, 0.2f, 0.2f};
 }
 
 PG_D void boss_fire(const State& s, int env, Live& v, float rotation, float speed) {  // common_systems.cpp:75-88
@@ -310,14 +318,34 @@ PG_D bool agent_update(const State& s, int env, Live& v, uint32_t* mt, float dt,
             v.a_alive = false;
             break;
         }
-    for (int i = 0; i < v.a_count; i++) {  // a_count shrinks inside the loop, as in the reference
+    // The bullets are visited one after the other (hits draw random numbers, count down the boss and shorten the very
+    // loop they are found in), but their state is fetched kShotBatch bullets at a time — the slots of the ring are known
+    // beforehand — so a batch costs one memory round trip instead of one per bullet.
+    for (int i0 = 0; i0 < v.a_count; i0 += kShotBatch) {
+    float f_frame[kShotBatch], f_x[kShotBatch], f_y[kShotBatch], f_vx[kShotBatch], f_vy[kShotBatch], f_bt[kShotBatch];
+    uint8_t f_bn[kShotBatch];
+#pragma unroll
+    for (int j = 0; j < kShotBatch; j++) {
+        const int k = (kAgentShots + v.a_next - 1 - (i0 + j)) & (kAgentShots - 1);  // (slots beyond the count: read, unused)
+        f_frame[j] = AS(s, S_FRAME, k, env);
+        f_x[j] = AS(s, S_X, k, env);
+        f_y[j] = AS(s, S_Y, k, env);
+        f_vx[j] = AS(s, S_VX, k, env);
+        f_vy[j] = AS(s, S_VY, k, env);
+        f_bt[j] = AS(s, S_BOUNCE_T, k, env);
+        f_bn[j] = AB(s, k, env);
+    }
+#pragma unroll
+    for (int j = 0; j < kShotBatch; j++) {
+        const int i = i0 + j;
+        if (i >= v.a_count) break;  // a_count shrinks inside the loop, as in the reference
         const int k = (kAgentShots + v.a_next - 1 - i) % kAgentShots;
-        float frame = AS(s, S_FRAME, k, env);
+        float frame = f_frame[j];
         if (frame == -1.0f) continue;
-        float px = AS(s, S_X, k, env), py = AS(s, S_Y, k, env);
-        float vx = AS(s, S_VX, k, env), vy = AS(s, S_VY, k, env);
-        float btimer = AS(s, S_BOUNCE_T, k, env);
-        bool bouncing = AB(s, k, env) != 0;
+        float px = f_x[j], py = f_y[j];
+        float vx = f_vx[j], vy = f_vy[j];
+        float btimer = f_bt[j];
+        bool bouncing = f_bn[j] != 0;
         if (frame == 0.0f) {
             const Box sb{px - 0.01f, py - 0.01f, 0.02f, 0.02f};
             if (!box_hit(sb, scr)) {
@@ -371,6 +399,7 @@ PG_D bool agent_update(const State& s, int env, Live& v, uint32_t* mt, float dt,
         AS(s, S_FRAME, k, env) = frame;
         AS(s, S_BOUNCE_T, k, env) = btimer;
         AB(s, k, env) = bouncing ? 1 : 0;
+    }
     }
     return v.a_alive;
 }
@@ -435,12 +464,27 @@ PG_D bool boss_update(const State& s, int env, Live& v, uint32_t* mt, float dt) 
     v.bx += v.bvx * dt;
     v.by += v.bvy * dt;
 
-    for (int i = 0; i < v.b_count; i++) {
+    bool hit_agent = false;
+    for (int i0 = 0; i0 < v.b_count && !hit_agent; i0 += kShotBatch) {  // fetched in batches like the agent's
+    float f_frame[kShotBatch], f_x[kShotBatch], f_y[kShotBatch], f_vx[kShotBatch], f_vy[kShotBatch];
+#pragma unroll
+    for (int j = 0; j < kShotBatch; j++) {
+        const int k = (kBossShots + v.b_next - 1 - (i0 + j)) & (kBossShots - 1);
+        f_frame[j] = BS(s, S_FRAME, k, env);
+        f_x[j] = BS(s, S_X, k, env);
+        f_y[j] = BS(s, S_Y, k, env);
+        f_vx[j] = BS(s, S_VX, k, env);
+        f_vy[j] = BS(s, S_VY, k, env);
+    }
+#pragma unroll
+    for (int j = 0; j < kShotBatch; j++) {
+        const int i = i0 + j;
+        if (i >= v.b_count) break;
         const int k = (kBossShots + v.b_next - 1 - i) % kBossShots;
-        float frame = BS(s, S_FRAME, k, env);
+        float frame = f_frame[j];
         if (frame == -1.0f) continue;
-        float px = BS(s, S_X, k, env), py = BS(s, S_Y, k, env);
-        float vx = BS(s, S_VX, k, env), vy = BS(s, S_VY, k, env);
+        float px = f_x[j], py = f_y[j];
+        float vx = f_vx[j], vy = f_vy[j];
         if (frame == 0.0f) {
             const Box sb{px - 0.01f, py - 0.01f, 0.02f, 0.02f};
             if (!box_hit(sb, scr)) {
@@ -452,6 +496,7 @@ PG_D bool boss_update(const State& s, int env, Live& v, uint32_t* mt, float dt) 
                     BS(s, S_VY, k, env) = 0.0f;
                     BS(s, S_FRAME, k, env) = 1.0f;
                     v.a_alive = false;
+                    hit_agent = true;
                     break;  // later bullets skip this sub-step (D14)
                 }
                 for (int step = 0; step < v.n_rocks; step++) {  // barriers, newest first (the boss skips itself)
@@ -476,6 +521,7 @@ PG_D bool boss_update(const State& s, int env, Live& v, uint32_t* mt, float dt) 
         BS(s, S_VX, k, env) = vx;
         BS(s, S_VY, k, env) = vy;
         BS(s, S_FRAME, k, env) = frame;
+    }
     }
     for (int i = 0; i < v.x_count; i++) {
         const int k = (kBooms + v.x_next - 1 - i) % kBooms;
@@ -522,6 +568,11 @@ PG_D void advance(const State& s, int env, int action, float& reward_out, bool& 
     v.n_rocks = SI(s, I_NROCKS, env);
     v.a_alive = (flags & kFlagAlive) != 0;
     v.scr = screen_box(take_view(s, env));
+#pragma unroll
+    for (int q = 0; q < kRocks; q++) {
+        v.rock_x[q] = RK(s, 0, q, env);
+        v.rock_y[q] = RK(s, 1, q, env);
+    }
 
     const float dt = 1.0f / 4;
     float reward = 0.0f;

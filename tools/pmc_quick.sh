@@ -21,7 +21,7 @@ for d in sorted(glob.glob("/tmp/pq_[0-9]*/")):
     rows = collections.defaultdict(dict)
     for fn in glob.glob(d + "*/*counter_collection.csv"):
         for r in csv.DictReader(open(fn)):
-            if "render_kernel" not in r["Kernel_Name"]: continue
+            if "${PG_KERNEL:-render_kernel}" not in r["Kernel_Name"]: continue
             rows[int(r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
     order = sorted(rows)[-8:]
     for c in sorted({k for d_ in order for k in rows[d_]}):
