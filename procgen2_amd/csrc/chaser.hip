@@ -639,10 +639,7 @@ __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actio
     const int lane = threadIdx.x;
     const int env = blockIdx.x * 64 + lane;
     bool active = env < s.n;
-    if (active && io.pending[env] == 2) {  // reset by the level kernel in this step
-        io.pending[env] = 0;
-        active = false;
-    }
+    if (active && io.pending[env] != 0) active = false;  // reset by the level kernel in this step, maybe right now (pg_engine.h StepIO)
     const int action = !active ? 0
                        : actions ? actions[env]
                                  : synthetic_action(run_seed, step_index, static_cast<uint32_t>(env_offset + env));
@@ -652,7 +649,7 @@ __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actio
     if (!active) return;
     io.reward[env] = reward;
     io.done[env] = terminated ? 1 : 0;
-    io.pending[env] = terminated ? 1 : 0;
+    io.pending[env] = terminated ? 3 : 0;  // (3, not 1: the level kernel may be running beside this one — pg_engine.h StepIO)
 }
 
 // render_game(true) (chaser.cpp:390-416): one workgroup of two wavefronts per env (pg_render.h).
@@ -660,6 +657,10 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
                                                     int flags) {
     const int env = blockIdx.x;
     if (mask && !mask[env]) return;
+    if (threadIdx.x == 0) {  // the step's level and logic kernels are both done: settle the flag (pg_engine.h StepIO)
+        const int p = io.pending[env];
+        if (p >= 2) io.pending[env] = p == 3 ? 1 : 0;
+    }
     const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // two wavefronts per env (pg_render.h)
     constexpr int halves = 2;
     __shared__ uint32_t fb[kFbWords];
@@ -940,9 +941,10 @@ class ChaserGame final : public Game {
     void launch_reset(hipStream_t st, const uint8_t* mask, const int32_t* seeds, StepIO io) override {
         LevelLaunch<Gen>::reset(st, s_, 0, mask, seeds, io, plan);
     }
+    bool resets_beside_logic() const override { return true; }
     void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
                       StepIO io) override {
-        LevelLaunch<Gen>::auto_reset(st, s_, 0, io, plan, kResetSpan);
+        LevelLaunch<Gen>::auto_reset(reset_stream ? reset_stream : st, s_, 0, io, plan, kResetSpan);
         hipLaunchKernelGGL(logic_kernel, dim3((s_.n + 63) / 64), dim3(64), 0, st, s_, actions, run_seed, step_index,
                            env_offset, io);
     }

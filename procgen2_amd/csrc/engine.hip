@@ -179,6 +179,9 @@ struct pgv_env {
     hipStream_t side = nullptr;
     hipEvent_t side_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int side_ev_next = 0, since_pregen = 0;
+    // auto-resets beside the logic kernels (pg_engine.h Game::reset_stream)
+    hipStream_t reset_stream = nullptr;
+    hipEvent_t reset_fork = nullptr, reset_join = nullptr;
 
     pg::StepIO io() const { return {d_obs, d_reward, d_done, d_pending}; }
 };
@@ -230,6 +233,12 @@ void pgv_close(pgv_env* e) {
         if (ev) hipEventDestroy(ev);
     for (auto& ev : e->ev)
         if (ev) hipEventDestroy(ev);
+    if (e->reset_stream) {
+        hipStreamSynchronize(e->reset_stream);
+        hipStreamDestroy(e->reset_stream);
+    }
+    if (e->reset_fork) hipEventDestroy(e->reset_fork);
+    if (e->reset_join) hipEventDestroy(e->reset_join);
     if (e->d_state) hipFree(e->d_state);
     if (e->own_obs && e->d_obs) hipFree(e->d_obs);
     if (e->own_reward && e->d_reward) hipFree(e->d_reward);
@@ -318,6 +327,12 @@ int32_t pgv_make_config(const pgv_config* cfg, pgv_env** out) {
     for (auto& ev : e->ev) PG_HIP(hipEventCreate(&ev));
     PG_HIP(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
     for (auto& ev : e->side_ev) PG_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    if (e->game->resets_beside_logic() && !std::getenv("PG_SERIAL_RESETS")) {  // (the variable: A/B measurements only)
+        PG_HIP(hipStreamCreateWithFlags(&e->reset_stream, hipStreamNonBlocking));
+        PG_HIP(hipEventCreateWithFlags(&e->reset_fork, hipEventDisableTiming));
+        PG_HIP(hipEventCreateWithFlags(&e->reset_join, hipEventDisableTiming));
+        e->game->reset_stream = e->reset_stream;
+    }
 
     std::string err;
     if (!e->atlas.load(pg::asset_root(), e->game->texture_names(), err)) return fail("pgv_make: " + err);
@@ -365,8 +380,16 @@ int32_t pgv_reset(pgv_env* e, const uint8_t* d_mask, const int32_t* d_seeds) {
 // only the most recent error, and pregen's hipStreamQuery legitimately leaves hipErrorNotReady behind.
 static int32_t step_impl(pgv_env* e, const int32_t* d_actions, uint32_t run_seed, hipEvent_t before_render = nullptr,
                          hipEvent_t after_render = nullptr) {
+    if (e->reset_stream) {  // fork: the auto-resets of this step go beside its logic kernels
+        PG_HIP(hipEventRecord(e->reset_fork, e->stream));
+        PG_HIP(hipStreamWaitEvent(e->reset_stream, e->reset_fork, 0));
+    }
     e->game->launch_logic(e->stream, d_actions, run_seed, e->step_index, e->env_offset, e->io());
     PG_HIP(hipGetLastError());
+    if (e->reset_stream) {  // join: the render kernel (and the level generator) see both
+        PG_HIP(hipEventRecord(e->reset_join, e->reset_stream));
+        PG_HIP(hipStreamWaitEvent(e->stream, e->reset_join, 0));
+    }
     pregen(e, false, false);  // before the render launch: the generator overlaps it
     (void)hipGetLastError();  // hipErrorNotReady of the stream query is not an error
     if (before_render) PG_HIP(hipEventRecord(before_render, e->stream));

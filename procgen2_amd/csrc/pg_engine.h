@@ -61,7 +61,13 @@ struct StepIO {
     uint8_t* obs;      // [n][64][64][3]
     float* reward;     // [n]
     uint8_t* done;     // [n]  terminated (truncated is always false in the reference: coinrun.cpp:367)
-    uint8_t* pending;  // [n]  env terminated last step → next step performs the reset instead
+    // [n]  1: the env terminated last step → the next step performs the reset instead: the level kernel serves it and
+    // leaves 2, the logic kernel skips it and puts 0 back.  A game whose logic kernel runs BESIDE the level kernel
+    // (Game::resets_beside_logic) cannot hand the flag over like that: there the logic kernel skips every env that is
+    // not 0 and writes 3 — not 1, which the level kernel running next to it would take for last step's — for an env that
+    // terminates now, and the step's render kernel, which runs after both, turns 2 into 0 and 3 into 1.
+    // Between steps: 0 or 1 either way.
+    uint8_t* pending;
 };
 
 // Level-seed mode (absent from the reference, modelled on the original procgen's
@@ -109,6 +115,13 @@ class Game {
     virtual void extend_atlas(Atlas& atlas) { (void)atlas; }
     // Host-side sanity check of the loaded atlas (sizes[i] = {w, h} of texture i); empty string = fine.
     virtual std::string check_atlas(const std::vector<std::pair<int, int>>& sizes) const { return ""; }
+
+    // A game that generates its levels inside the step (chaser: 0.2 ms a step) can have the level kernel's auto-reset
+    // (pg_prefetch.h mode 2) run beside its logic kernel — the envs being reset sit the logic out — on `reset_stream`,
+    // which the engine forks off its main stream before launch_logic and joins before the render launch.  The hand-over
+    // between the streams costs about 25 µs, so games whose auto-reset only installs a prefetched level do not ask.
+    virtual bool resets_beside_logic() const { return false; }
+    hipStream_t reset_stream = nullptr;
 
     // Bit 0: render background + tiles by draw-list replay instead of the row composer (fallback path).
     // Bit 8: no level prefetch — every reset generates its level synchronously inside the step.
