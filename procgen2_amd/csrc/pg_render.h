@@ -661,6 +661,7 @@ template <int kGroup>
 struct ReplayState {
     unsigned long long mask, lones;  // draws still to do (those that reach my rows); which of them go alone
     BlitWords packed;                // this lane's draw, packed for the cross-lane reads
+    uint32_t box[2];                 // kRotInGroups: a rotated draw's box on my rows (x_lo | y_lo << 16, bw | bh << 16)
     uint32_t texel[kGroup];
     int idx[kGroup], mod[kGroup];
 };
@@ -696,7 +697,10 @@ PG_D void replay_group(const AtlasView& atlas, const Blit& mine, ReplayState<kGr
         const Blit b = kPacked ? blit_from_lane(st.packed, mine, src) : blit_from_lane(mine, src);
         if (kRotInGroups && (b.flip_mod & kRotated)) {
             int at = 0, where = -1;
-            if (rotated_pixel(b, rot_box_rows(b, row_lo, row_hi), lane, where, at)) {
+            const uint32_t b0 = __builtin_amdgcn_readlane(st.box[0], src), b1 = __builtin_amdgcn_readlane(st.box[1], src);
+            const RotBox box{static_cast<int>(b0 & 0xffffu), static_cast<int>(b0 >> 16), static_cast<int>(b1 & 0xffffu),
+                             static_cast<int>(b1 >> 16)};  // (in a group: 1 ≤ bw, bh ≤ 64; x_lo, y_lo ≥ 0)
+            if (rotated_pixel(b, box, lane, where, at)) {
                 st.idx[g] = where;
                 st.texel[g] = atlas.texels[at];
                 st.mod[g] = b.flip_mod & 0xff;
@@ -725,11 +729,15 @@ PG_D void replay_group(const AtlasView& atlas, const Blit& mine, ReplayState<kGr
 template <int kGroup, bool kRotInGroups, bool kPacked>
 PG_D ReplayState<kGroup> replay_classify(const Blit& mine, unsigned long long mask, int lane, int row_lo, int row_hi) {
     bool lone = false, reaches = false;
+    uint32_t box0 = 0, box1 = 0;
     if ((mask >> lane) & 1ull) {
         if (mine.flip_mod & kRotated) {
             const RotBox box = rot_box_rows(mine, row_lo, row_hi);
             reaches = box.bw > 0 && box.bh > 0;
             lone = !kRotInGroups || box.bw * box.bh > 64 || mine.dw > kRotSmall || mine.dh > kRotSmall;
+            // (the box of a draw that goes into a group travels with it: no second pass through rot_box's 64-bit products)
+            box0 = static_cast<uint32_t>(box.x_lo) | (static_cast<uint32_t>(box.y_lo) << 16);
+            box1 = static_cast<uint32_t>(box.bw & 0xffff) | (static_cast<uint32_t>(box.bh) << 16);
         } else {
             const int x0 = mine.dx > 0 ? mine.dx : 0, y0 = mine.dy > row_lo ? mine.dy : row_lo;
             const int x1 = (mine.dx + mine.dw) < kObsW ? (mine.dx + mine.dw) : kObsW;
@@ -742,6 +750,8 @@ PG_D ReplayState<kGroup> replay_classify(const Blit& mine, unsigned long long ma
     st.mask = __ballot(reaches);
     st.lones = __ballot(lone && reaches);
     if (kPacked) st.packed = blit_pack(mine);
+    st.box[0] = box0;
+    st.box[1] = box1;
     return st;
 }
 
