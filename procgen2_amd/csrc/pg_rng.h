@@ -31,11 +31,39 @@ PG_HD uint32_t mt_mix(uint32_t hi, uint32_t lo) {
 }
 
 // In-place regeneration of all 624 words (one lane; amortised over 624 draws).
+#if defined(__HIP_DEVICE_COMPILE__)
+// On the device the state lives in global memory and the lane that runs out holds its whole wavefront up — in a logic
+// kernel that is one wavefront per 64 envs, so nearly every step of bossfight or chaser has some wavefront here, and
+// the step waits for it.  Written as a plain loop this is ~90 dependent memory round trips (the compiler forms groups
+// of six or eight words); taking kChunk words at a time — every load of a chunk issued before any of its stores: a
+// chunk reads only words no earlier store of the SAME chunk writes, `from` lies 227 or 397 words away — makes it 20.
+// Same words as the loop below.
+template <int kCount>
+PG_D void mt_twist_chunk(uint32_t* x, int i0, int from) {
+    uint32_t own[kCount + 1], far[kCount];
+#pragma unroll
+    for (int k = 0; k <= kCount; k++) own[k] = x[i0 + k];
+#pragma unroll
+    for (int k = 0; k < kCount; k++) far[k] = x[i0 + from + k];
+#pragma unroll
+    for (int k = 0; k < kCount; k++) x[i0 + k] = far[k] ^ mt_mix(own[k], own[k + 1]);
+}
+PG_D void mt_twist(uint32_t* x) {
+    constexpr int kChunk = 32, kFirst = kMtN - kMtM;  // 227 = 7·32 + 3;  623 − 227 = 396 = 12·32 + 12
+    for (int i = 0; i + kChunk <= kFirst; i += kChunk) mt_twist_chunk<kChunk>(x, i, kMtM);
+    mt_twist_chunk<kFirst % kChunk>(x, kFirst - kFirst % kChunk, kMtM);
+    constexpr int kSecond = kMtN - 1 - kFirst;
+    for (int i = kFirst; i + kChunk <= kMtN - 1; i += kChunk) mt_twist_chunk<kChunk>(x, i, kMtM - kMtN);
+    mt_twist_chunk<kSecond % kChunk>(x, kMtN - 1 - kSecond % kChunk, kMtM - kMtN);
+    x[kMtN - 1] = x[kMtM - 1] ^ mt_mix(x[kMtN - 1], x[0]);
+}
+#else
 PG_HD void mt_twist(uint32_t* x) {
     for (int i = 0; i < kMtN - kMtM; i++) x[i] = x[i + kMtM] ^ mt_mix(x[i], x[i + 1]);
     for (int i = kMtN - kMtM; i < kMtN - 1; i++) x[i] = x[i + kMtM - kMtN] ^ mt_mix(x[i], x[i + 1]);
     x[kMtN - 1] = x[kMtM - 1] ^ mt_mix(x[kMtN - 1], x[0]);
 }
+#endif
 
 PG_HD uint32_t mt_temper(uint32_t y) {
     y ^= y >> 11;
