@@ -394,7 +394,7 @@ PG_D void advance(const State& s, StepLds& L, int lane, bool active, int env, in
             ay += avy * dt;
             const Box body{ax + -0.5f, ay + -1.0f, 1.0f, 1.0f};
             if (ss == 0 || !awin.holds(body)) awin = Win::around(tiles, body, avx, avy);
-            const TileHit h = collide_plain(awin, body, is_wall);
+            const TileHit h = collide_plain<true>(awin, body, is_wall);
             const float moved_x = h.x - body.x, moved_y = h.y - body.y;
             ground = moved_y < 0.0f && h.any;
             ax = h.x - -0.5f;
@@ -419,7 +419,7 @@ PG_D void advance(const State& s, StepLds& L, int lane, bool active, int env, in
             x += vx * dt;
             const Box probe{x - 0.5f, y - 0.6f, 1.0f, 0.5f};
             const Win win{tiles, L.m_ax[m][lane], L.m_ay[m][lane], L.m_win[m][lane]};
-            const TileHit w = collide_plain(win, probe, is_wall);
+            const TileHit w = collide_plain<true>(win, probe, is_wall);
             x = w.x + 0.5f;
             if (box_hit(agent, Box{x + -0.4f, y + -0.4f, 0.8f, 0.8f})) dead = true;
             const int spawn_x = L.m_spawn[m][lane];

@@ -65,13 +65,62 @@ struct TileHit {
     bool any;
 };
 
-template <class Win, class Pred>
+// get_collision_overlap (pg_geom.h box_overlap) without its early return: the same values through selects.
+PG_D Box box_overlap_flat(const Box& a, const Box& b) {
+    const bool hit = (a.x < b.x + b.w) & (a.x + a.w > b.x) & (a.y < b.y + b.h) & (a.y + a.h > b.y);
+    const float ddx = fabsf(a.x - b.x), ddy = fabsf(a.y - b.y);
+    const bool left = a.x <= b.x, top = a.y <= b.y;
+    float w = (left ? a.w : b.w) - ddx, h = (top ? a.h : b.h) - ddy;
+    const float wcap = a.w > b.w ? b.w : a.w, hcap = a.h > b.h ? b.h : a.h;
+    w = w >= wcap ? wcap : w;
+    h = h >= hcap ? hcap : h;
+    return Box{hit ? (left ? b.x : a.x) : 0.0f, hit ? (top ? b.y : a.y) : 0.0f, hit ? w : 0.0f, hit ? h : 0.0f};
+}
+
+// kFlat: see below — pays where boxes are a tile in size (climber −2 %), not where they are bullets (caveflyer +2 %).
+template <bool kFlat = false, class Win, class Pred>
 PG_D TileHit collide_plain(const Win& win, Box r, Pred solid) {
     bool any = false;
     const int x0 = static_cast<int>(floorf(r.x)), y0 = static_cast<int>(floorf(r.y));
     const int x1 = static_cast<int>(ceilf(r.x + r.w)), y1 = static_cast<int>(ceilf(r.y + r.h));
     const float mid_x = r.x + r.w * 0.5f, mid_y = r.y + r.h * 0.5f;
     Box cell{0.0f, 0.0f, 1.0f, 1.0f};
+    if (kFlat && ((x1 - x0 <= 2) & (y1 - y0 <= 2) & (x0 >= win.ax) & (y0 >= win.ay) & (x1 < win.ax + 4) & (y1 < win.ay + 4))) {
+        // At most three by three cells, all inside the window: nine fixed steps with every decision a select (bitwise,
+        // so that nothing short-circuits into a branch) — same cells, same order, same arithmetic as the loops below.
+        // In a logic kernel (one wavefront per 64 envs, its SIMD to itself) the loops' taken branches cost more than
+        // the arithmetic of the cells they skip.
+        const int wx = x0 - win.ax, wy = y0 - win.ay;
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++) {
+                const bool in = (x0 + dx <= x1) & (y0 + dy <= y1);
+                const int ox_ = in ? dx : 0, oy_ = in ? dy : 0;  // (a cell past the box: look at the first one, ignore it)
+                const bool is_solid = solid(static_cast<int>((win.bits >> (3 * ((wx + ox_) + 4 * (wy + oy_)))) & 7u));
+                cell.x = static_cast<float>(x0 + ox_);
+                cell.y = static_cast<float>(y0 + oy_);
+                const Box o = box_overlap_flat(r, cell);
+                const bool take = in & is_solid & !((o.w == 0.0f) & (o.h == 0.0f)) & (o.w > o.h);
+                r.y = take ? (o.y + o.h * 0.5f > mid_y ? cell.y - r.h : cell.y + cell.h) : r.y;
+                any = any | take;
+            }
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++) {
+                const bool in = (x0 + dx <= x1) & (y0 + dy <= y1);
+                const int ox_ = in ? dx : 0, oy_ = in ? dy : 0;
+                const bool is_solid = solid(static_cast<int>((win.bits >> (3 * ((wx + ox_) + 4 * (wy + oy_)))) & 7u));
+                cell.x = static_cast<float>(x0 + ox_);
+                cell.y = static_cast<float>(y0 + oy_);
+                const Box o = box_overlap_flat(r, cell);
+                const bool take = in & is_solid & !((o.w == 0.0f) & (o.h == 0.0f)) & (o.w <= o.h);
+                r.x = take ? (o.x + o.w * 0.5f > mid_x ? cell.x - r.w : cell.x + cell.w) : r.x;
+                any = any | take;
+            }
+        return {r.x, r.y, any};
+    }
     for (int y = y0; y <= y1; y++)
         for (int x = x0; x <= x1; x++) {
             if (!solid(win.at(x, y))) continue;
