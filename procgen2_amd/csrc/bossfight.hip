@@ -335,70 +335,58 @@ PG_D bool agent_update(const State& s, int env, Live& v, uint32_t* mt, float dt,
         f_bt[j] = AS(s, S_BOUNCE_T, k, env);
         f_bn[j] = AB(s, k, env);
     }
+    // (one bullet = one straight run of selects, like the boss's below; the only branch left is the bounce off the
+    // shield, which draws a random number)
+    auto hit = [](const Box& a, const Box& b) {
+        return (a.x < b.x + b.w) & (a.x + a.w > b.x) & (a.y < b.y + b.h) & (a.y + a.h > b.y);
+    };
 #pragma unroll
     for (int j = 0; j < kShotBatch; j++) {
         const int i = i0 + j;
-        if (i >= v.a_count) break;  // a_count shrinks inside the loop, as in the reference
-        const int k = (kAgentShots + v.a_next - 1 - i) % kAgentShots;
-        float frame = f_frame[j];
-        if (frame == -1.0f) continue;
-        float px = f_x[j], py = f_y[j];
-        float vx = f_vx[j], vy = f_vy[j];
-        float btimer = f_bt[j];
+        const int k = (kAgentShots + v.a_next - 1 - i) & (kAgentShots - 1);
+        const float frame0 = f_frame[j];
+        const bool act = (i < v.a_count) & (frame0 != -1.0f);  // a_count shrinks inside the loop, as in the reference
+        float px = f_x[j], py = f_y[j], vx = f_vx[j], vy = f_vy[j], btimer = f_bt[j];
         bool bouncing = f_bn[j] != 0;
-        if (frame == 0.0f) {
-            const Box sb{px - 0.01f, py - 0.01f, 0.02f, 0.02f};
-            if (!box_hit(sb, scr)) {
-                vx = vy = 0.0f;
-                frame = 5.0f;
-            } else {
-                // hazard set order: barriers newest-first, then the boss
-                for (int step = 0; step <= v.n_rocks; step++) {
-                    const int h = step < v.n_rocks ? v.n_rocks - 1 - step : v.n_rocks;
-                    if (!box_hit(sb, hazard_box(s, env, v, h))) continue;
-                    if (h == v.n_rocks) {
-                        if (v.phase % 2 == 0) {  // shielded: bounce off
-                            vx = rng_real(mt, -1.0f, 1.0f) * bounce_speed;
-                            vy = bounce_speed;
-                            btimer = bounce_time;
-                            bouncing = true;
-                        } else {
-                            vx = vy = 0.0f;
-                            frame = 1.0f;
-                            if (v.hp > 0) v.hp--;
-                        }
-                    } else {
-                        vx = vy = 0.0f;
-                        frame = 1.0f;
-                    }
-                    break;
-                }
-            }
+        const Box sb{px - 0.01f, py - 0.01f, 0.02f, 0.02f};
+        const bool fly = act & (frame0 == 0.0f);
+        const bool off = fly & !hit(sb, scr);
+        // hazard set order: barriers newest-first, then the boss — the first one hit decides, and every barrier does the same
+        bool rock = false;
+#pragma unroll
+        for (int q = 0; q < kRocks; q++)
+            rock = rock | ((q < v.n_rocks) & hit(sb, Box{v.rock_x[q] + -0.1f, v.rock_y[q] + -0.1f, 0.2f, 0.2f}));
+        const bool at_boss = fly & !off & !rock & hit(sb, Box{v.bx + -0.6f, v.by + -0.4f, 1.2f, 0.8f});
+        const bool shielded = v.phase % 2 == 0;
+        if (at_boss & shielded) {  // bounce off
+            vx = rng_real(mt, -1.0f, 1.0f) * bounce_speed;
+            vy = bounce_speed;
+            btimer = bounce_time;
+            bouncing = true;
         }
-        px += vx * dt;
-        py += vy * dt;
-        bool destroy = false;
-        if (frame >= 5.0f)
-            destroy = true;
-        else if (frame >= 1.0f)
-            frame += explosion_rate * dt;
-        if (bouncing) {
-            if (btimer > 0.0f)
-                btimer = fmaxf(0.0f, btimer - dt);
-            else
-                destroy = true;
+        const bool bursts = (fly & !off & rock) | (at_boss & !shielded);
+        v.hp -= (at_boss & !shielded & (v.hp > 0)) ? 1 : 0;
+        vx = (off | bursts) ? 0.0f : vx;
+        vy = (off | bursts) ? 0.0f : vy;
+        float frame = off ? 5.0f : (bursts ? 1.0f : frame0);
+        px = act ? px + vx * dt : px;
+        py = act ? py + vy * dt : py;
+        bool destroy = act & (frame >= 5.0f);
+        frame = (act & !destroy & (frame >= 1.0f)) ? frame + explosion_rate * dt : frame;
+        const bool ticking = btimer > 0.0f;
+        destroy = destroy | (act & bouncing & !ticking);
+        btimer = (act & bouncing & ticking) ? fmaxf(0.0f, btimer - dt) : btimer;
+        v.a_count -= destroy ? 1 : 0;
+        frame = destroy ? -1.0f : frame;
+        if (act) {
+            AS(s, S_X, k, env) = px;
+            AS(s, S_Y, k, env) = py;
+            AS(s, S_VX, k, env) = vx;
+            AS(s, S_VY, k, env) = vy;
+            AS(s, S_FRAME, k, env) = frame;
+            AS(s, S_BOUNCE_T, k, env) = btimer;
+            AB(s, k, env) = bouncing ? 1 : 0;
         }
-        if (destroy) {
-            v.a_count--;
-            frame = -1.0f;
-        }
-        AS(s, S_X, k, env) = px;
-        AS(s, S_Y, k, env) = py;
-        AS(s, S_VX, k, env) = vx;
-        AS(s, S_VY, k, env) = vy;
-        AS(s, S_FRAME, k, env) = frame;
-        AS(s, S_BOUNCE_T, k, env) = btimer;
-        AB(s, k, env) = bouncing ? 1 : 0;
     }
     }
     return v.a_alive;
@@ -476,51 +464,48 @@ PG_D bool boss_update(const State& s, int env, Live& v, uint32_t* mt, float dt) 
         f_vx[j] = BS(s, S_VX, k, env);
         f_vy[j] = BS(s, S_VY, k, env);
     }
+    // One bullet = one straight run of selects (bitwise tests: nothing short-circuits into a branch).  The kernel is one
+    // wavefront per 64 envs with its SIMD to itself and walks max-over-its-envs many bullets: as nested ifs every bullet
+    // cost a dozen taken branches, which is where the time went — not into the arithmetic they skipped.  Same outcome
+    // per bullet as the reference's loop: a bullet that meets the agent explodes in place and ends the loop (D14).
+    auto hit = [](const Box& a, const Box& b) {
+        return (a.x < b.x + b.w) & (a.x + a.w > b.x) & (a.y < b.y + b.h) & (a.y + a.h > b.y);
+    };
 #pragma unroll
     for (int j = 0; j < kShotBatch; j++) {
         const int i = i0 + j;
-        if (i >= v.b_count) break;
-        const int k = (kBossShots + v.b_next - 1 - i) % kBossShots;
-        float frame = f_frame[j];
-        if (frame == -1.0f) continue;
-        float px = f_x[j], py = f_y[j];
-        float vx = f_vx[j], vy = f_vy[j];
-        if (frame == 0.0f) {
-            const Box sb{px - 0.01f, py - 0.01f, 0.02f, 0.02f};
-            if (!box_hit(sb, scr)) {
-                vx = vy = 0.0f;
-                frame = 5.0f;
-            } else {
-                if (box_hit(sb, agent_rect)) {
-                    BS(s, S_VX, k, env) = 0.0f;
-                    BS(s, S_VY, k, env) = 0.0f;
-                    BS(s, S_FRAME, k, env) = 1.0f;
-                    v.a_alive = false;
-                    hit_agent = true;
-                    break;  // later bullets skip this sub-step (D14)
-                }
-                for (int step = 0; step < v.n_rocks; step++) {  // barriers, newest first (the boss skips itself)
-                    const int h = v.n_rocks - 1 - step;
-                    if (box_hit(sb, hazard_box(s, env, v, h))) {
-                        vx = vy = 0.0f;
-                        frame = 1.0f;
-                        break;
-                    }
-                }
-            }
+        const int k = (kBossShots + v.b_next - 1 - i) & (kBossShots - 1);
+        const float frame0 = f_frame[j];
+        const bool act = (i < v.b_count) & !hit_agent & (frame0 != -1.0f);
+        float px = f_x[j], py = f_y[j], vx = f_vx[j], vy = f_vy[j];
+        const Box sb{px - 0.01f, py - 0.01f, 0.02f, 0.02f};
+        const bool fly = act & (frame0 == 0.0f);
+        const bool off = fly & !hit(sb, scr);
+        const bool strikes = fly & !off & hit(sb, agent_rect);
+        bool rock = false;  // barriers (the boss skips itself); which one is first does not matter
+#pragma unroll
+        for (int q = 0; q < kRocks; q++)
+            rock = rock | ((q < v.n_rocks) & hit(sb, Box{v.rock_x[q] + -0.1f, v.rock_y[q] + -0.1f, 0.2f, 0.2f}));
+        const bool bursts = strikes | (fly & !off & rock);
+        vx = (off | bursts) ? 0.0f : vx;
+        vy = (off | bursts) ? 0.0f : vy;
+        float frame = off ? 5.0f : (bursts ? 1.0f : frame0);
+        const bool moves = act & !strikes;  // (the one that met the agent stays where it is, at frame 1)
+        px = moves ? px + vx * dt : px;
+        py = moves ? py + vy * dt : py;
+        const bool gone = moves & (frame >= 5.0f);
+        const bool burns = moves & !gone & (frame >= 1.0f);
+        v.b_count -= gone ? 1 : 0;
+        frame = gone ? -1.0f : (burns ? frame + explosion_rate * dt : frame);
+        if (act) {
+            BS(s, S_X, k, env) = px;
+            BS(s, S_Y, k, env) = py;
+            BS(s, S_VX, k, env) = vx;
+            BS(s, S_VY, k, env) = vy;
+            BS(s, S_FRAME, k, env) = frame;
         }
-        px += vx * dt;
-        py += vy * dt;
-        if (frame >= 5.0f) {
-            v.b_count--;
-            frame = -1.0f;
-        } else if (frame >= 1.0f)
-            frame += explosion_rate * dt;
-        BS(s, S_X, k, env) = px;
-        BS(s, S_Y, k, env) = py;
-        BS(s, S_VX, k, env) = vx;
-        BS(s, S_VY, k, env) = vy;
-        BS(s, S_FRAME, k, env) = frame;
+        hit_agent = hit_agent | strikes;  // later bullets skip this sub-step (D14)
+        v.a_alive = v.a_alive & !strikes;
     }
     }
     for (int i = 0; i < v.x_count; i++) {
