@@ -8,8 +8,8 @@
 //   reset  games/bossfight/bossfight.cpp:426-504, common_systems.cpp:452-470, :724-737
 // Config = the reference's compile-time default, hard_mode (common_systems.h:63-65).
 //
-// Same machine mapping as coinrun.hip: logic one lane per env over struct-of-arrays state, render one wavefront
-// per env with the target in LDS.  std::cos/std::sin(float) are pg_sincos.h (bit-identical to the glibc the
+// Machine mapping: logic = a gang of kGang adjacent lanes per env (pg_gang.h): the env's scalars uniformly in all of
+// them, the three bullet rings walked kGang slots at a time; render = two wavefronts per env with the target in LDS.  std::cos/std::sin(float) are pg_sincos.h (bit-identical to the glibc the
 // reference links); every `M_PI` expression keeps the reference's float/double promotion points.
 //
 // Entity ids are fixed by creation order (player 0, boss 1, barriers 2..): the hazard set therefore iterates
@@ -17,6 +17,7 @@
 // goes to the list head — SURVEY.md T3), which is the order first-hit tests below use.
 #include "pg_engine.h"
 #include "pg_frame.h"
+#include "pg_gang.h"
 #include "pg_geom.h"
 #include "pg_render.h"
 #include "pg_rng.h"
@@ -62,29 +63,30 @@ enum {
     I_COUNT
 };
 constexpr int kFlagAlive = 1, kFlagListed = 2;
-constexpr int kShotBatch = 8;  // bullets whose state is fetched together (agent_update / boss_update)
 // I_SKINS: a_ship | a_laser<<4 | b_ship<<8 | b_laser<<12 | backdrop<<16
 // shot fields (floats); agent shots also have a "bouncing" byte
 enum { S_X, S_Y, S_VX, S_VY, S_ROT, S_FRAME, S_BOUNCE_T, S_SN, S_CS, S_COUNT };  // S_SN/S_CS (boss bullets): the drawing angle as raster spec S6 takes it, int bits, fixed when fired
 
+// The rings are per-env contiguous ([env][field][slot]): a gang's lanes and the render wavefront's lanes both index
+// them by slot, so one field of one env is one coalesced request.  Scalars are [field][env].
 struct State {
     int n;
     uint32_t* mt;   // [n][625]
     float* f;       // [F_COUNT][n]
     int32_t* i;     // [I_COUNT][n]
-    float* ashot;   // [S_COUNT][32][n]
-    uint8_t* abnc;  // [32][n]  bouncing flag
-    float* bshot;   // [S_COUNT][64][n]   (S_BOUNCE_T unused)
-    float* boom;    // [3][8][n]  x, y, frame
+    float* ashot;   // [n][S_COUNT][32]
+    uint8_t* abnc;  // [n][32]  bouncing flag
+    float* bshot;   // [n][S_COUNT][64]   (S_BOUNCE_T unused)
+    float* boom;    // [n][3][8]  x, y, frame
     float* rock;    // [3][4][n]  x, y, texture index
 };
 
 PG_D float& SF(const State& s, int field, int env) { return s.f[size_t(field) * s.n + env]; }
 PG_D int32_t& SI(const State& s, int field, int env) { return s.i[size_t(field) * s.n + env]; }
-PG_D float& AS(const State& s, int field, int k, int env) { return s.ashot[(size_t(field) * kAgentShots + k) * s.n + env]; }
-PG_D uint8_t& AB(const State& s, int k, int env) { return s.abnc[size_t(k) * s.n + env]; }
-PG_D float& BS(const State& s, int field, int k, int env) { return s.bshot[(size_t(field) * kBossShots + k) * s.n + env]; }
-PG_D float& BM(const State& s, int field, int k, int env) { return s.boom[(size_t(field) * kBooms + k) * s.n + env]; }
+PG_D float& AS(const State& s, int field, int k, int env) { return s.ashot[(size_t(env) * S_COUNT + field) * kAgentShots + k]; }
+PG_D uint8_t& AB(const State& s, int k, int env) { return s.abnc[size_t(env) * kAgentShots + k]; }
+PG_D float& BS(const State& s, int field, int k, int env) { return s.bshot[(size_t(env) * S_COUNT + field) * kBossShots + k]; }
+PG_D float& BM(const State& s, int field, int k, int env) { return s.boom[(size_t(env) * 3 + field) * kBooms + k]; }
 PG_D float& RK(const State& s, int field, int k, int env) { return s.rock[(size_t(field) * kRocks + k) * s.n + env]; }
 
 // Observation camera: size 64, scale 1 (bossfight.cpp:412-413).
@@ -95,18 +97,9 @@ constexpr float kCamSize = 64.0f, kCamScale = 1.0f;
 // cenv_render, the window's W×H and 1.0·W/64, which for a non-square window moves the spawn row, the barriers and the
 // screen rectangle of the next step or reset.  F_CAMW/F_CAMH hold that size per env: the frame kernel writes the
 // window's, whoever reads them (logic / level code, always followed by an observation render) puts 64 back.
-struct View {
+struct View {  // (reading: View{w, h, 1·w/64}; whoever reads a size other than 64 puts 64 back)
     float w, h, sc;
 };
-PG_D View take_view(const State& s, int env) {
-    const float w = SF(s, F_CAMW, env), h = SF(s, F_CAMH, env);
-    if (w != kCamSize || h != kCamSize) {
-        SF(s, F_CAMW, env) = kCamSize;
-        SF(s, F_CAMH, env) = kCamSize;
-    }
-    return View{w, h, 1.0f * w / 64.0f};
-}
-
 PG_D Box screen_box(const View& v) {  // common_systems.cpp:224-226, 513-515
     return Box{-v.w / v.sc * kPxUnit * 0.5f, -v.h / v.sc * kPxUnit * 0.5f, v.w / v.sc * kPxUnit, v.h / v.sc * kPxUnit};
 }
@@ -114,10 +107,62 @@ PG_D Box screen_box(const View& v) {  // common_systems.cpp:224-226, 513-515
 // ------------------------------------------------------------------------------------------------
 // reset (bossfight.cpp:426-504)
 // ------------------------------------------------------------------------------------------------
-PG_D void new_level(const State& s, int env) {
-    uint32_t* mt = s.mt + size_t(env) * kMtWords;
-    const View view = take_view(s, env);
-    SF(s, F_AX, env) = rng_real(mt, -1.0f, 1.0f) * view.w / view.sc * kPxUnit * 0.5f;
+// R: the env's stream, by one lane (LaneRng: make / reset kernels) or by a gang whose lanes all run this and draw the
+// same numbers (pg_gang.h GangRng: the auto-reset inside the logic kernel); `lead` = this lane does the writing.
+struct LaneRng {
+    uint32_t* mt;
+    PG_D float real(float a, float b) { return rng_real(mt, a, b); }
+    PG_D int integer(int lo, int hi) { return rng_int(mt, lo, hi); }
+};
+template <class R>
+PG_D void new_level(const State& s, int env, R& rng, bool lead) {
+    const float cam_w = SF(s, F_CAMW, env), cam_h = SF(s, F_CAMH, env);  // take_view: every lane reads, the lead puts 64 back
+    const View view{cam_w, cam_h, 1.0f * cam_w / 64.0f};
+    const float ax = rng.real(-1.0f, 1.0f) * view.w / view.sc * kPxUnit * 0.5f;
+    const int want = rng.integer(1, 4);
+    Box placed[kRocks];
+    float rock_x[kRocks], rock_y[kRocks], rock_t[kRocks];
+    int n_rocks = 0;
+#pragma unroll
+    for (int k = 0; k < kRocks; k++) {
+        if (k < want) {
+            const float px = rng.real(-1.0f, 1.0f) * view.w / view.sc * kPxUnit * 0.5f * 0.9f;
+            const float py = view.h / view.sc * kPxUnit * 0.5f - rng.real(0.7f, 1.2f);
+            const Box wc{px + -0.1f, py + -0.1f, 0.2f, 0.2f};
+            bool clash = false;
+#pragma unroll
+            for (int j = 0; j < kRocks; j++)
+                if (j < k && box_hit(wc, placed[j])) clash = true;
+            if (!clash) {
+                const float t = static_cast<float>(rng.integer(0, 7));
+#pragma unroll
+                for (int j = 0; j < kRocks; j++)  // (selects: the table stays in registers)
+                    if (j == n_rocks) {
+                        rock_x[j] = px;
+                        rock_y[j] = py;
+                        rock_t[j] = t;
+                    }
+                n_rocks++;
+                placed[k] = wc;
+            } else {
+                placed[k] = Box{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+        }
+    }
+    const int backdrop = rng.integer(0, 12);
+    rng.real(0.0f, 1.0f);  // current_background_offset_x / _y: drawn, never used
+    rng.real(0.0f, 1.0f);
+    // System_Agent::reset, then System_Mob_AI::reset
+    const int a_ship = rng.integer(0, 3);
+    const int a_laser = rng.integer(0, 2);
+    const int b_ship = rng.integer(0, 3);
+    const int b_laser = rng.integer(0, 2);
+    if (!lead) return;
+    if (cam_w != kCamSize || cam_h != kCamSize) {
+        SF(s, F_CAMW, env) = kCamSize;
+        SF(s, F_CAMH, env) = kCamSize;
+    }
+    SF(s, F_AX, env) = ax;
     SF(s, F_AY, env) = view.h / view.sc * kPxUnit * 0.5f;
     SF(s, F_AVX, env) = 0.0f;
     SF(s, F_AVY, env) = 0.0f;
@@ -130,40 +175,17 @@ PG_D void new_level(const State& s, int env) {
     SI(s, I_PHASE, env) = 0;
     SI(s, I_WEAPON, env) = 0;
     SI(s, I_HP, env) = 0;
-
-    const int want = rng_int(mt, 1, 4);
-    Box placed[kRocks];
-    int n_rocks = 0;
-    for (int k = 0; k < want; k++) {
-        const float px = rng_real(mt, -1.0f, 1.0f) * view.w / view.sc * kPxUnit * 0.5f * 0.9f;
-        const float py = view.h / view.sc * kPxUnit * 0.5f - rng_real(mt, 0.7f, 1.2f);
-        const Box wc{px + -0.1f, py + -0.1f, 0.2f, 0.2f};
-        bool clash = false;
-        for (int j = 0; j < k; j++)
-            if (box_hit(wc, placed[j])) {
-                clash = true;
-                break;
-            }
-        if (!clash) {
-            RK(s, 0, n_rocks, env) = px;
-            RK(s, 1, n_rocks, env) = py;
-            RK(s, 2, n_rocks, env) = static_cast<float>(rng_int(mt, 0, 7));
-            n_rocks++;
-            placed[k] = wc;
-        } else {
-            placed[k] = Box{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < kRocks; j++)
+        if (j < n_rocks) {
+            RK(s, 0, j, env) = rock_x[j];
+            RK(s, 1, j, env) = rock_y[j];
+            RK(s, 2, j, env) = rock_t[j];
         }
-    }
     SI(s, I_NROCKS, env) = n_rocks;
-    const int backdrop = rng_int(mt, 0, 12);
-    rng_real(mt, 0.0f, 1.0f);  // current_background_offset_x / _y: drawn, never used
-    rng_real(mt, 0.0f, 1.0f);
-    // System_Agent::reset, then System_Mob_AI::reset
     SI(s, I_A_NEXT, env) = 0;
     SI(s, I_A_COUNT, env) = 0;
     SF(s, F_ATIMER, env) = 0.0f;
-    const int a_ship = rng_int(mt, 0, 3);
-    const int a_laser = rng_int(mt, 0, 2);
     SI(s, I_B_NEXT, env) = 0;
     SI(s, I_X_NEXT, env) = 0;
     SI(s, I_B_COUNT, env) = 0;
@@ -171,8 +193,6 @@ PG_D void new_level(const State& s, int env) {
     SF(s, F_EXPLO_T, env) = 0.0f;
     SF(s, F_DAMAGE_T, env) = 0.0f;
     SF(s, F_MOVE_T, env) = 0.0f;
-    const int b_ship = rng_int(mt, 0, 3);
-    const int b_laser = rng_int(mt, 0, 2);
     SI(s, I_SKINS, env) = a_ship | (a_laser << 4) | (b_ship << 8) | (b_laser << 12) | (backdrop << 16);
     SI(s, I_FLAGS, env) = kFlagAlive;  // agent alive; sprite draw list cleared (D2)
 }
@@ -180,6 +200,16 @@ PG_D void new_level(const State& s, int env) {
 // ------------------------------------------------------------------------------------------------
 // step (bossfight.cpp:308-325)
 // ------------------------------------------------------------------------------------------------
+// One env = one gang (pg_gang.h).  Everything in Live is uniform over the gang; `q.g` only decides which ring slots a
+// lane owns (slot mod width) — it writes the bullets fired into them and is the one that moves them.
+#ifndef PG_BOSSFIGHT_GANG
+#define PG_BOSSFIGHT_GANG 8
+#endif
+constexpr int kGang = PG_BOSSFIGHT_GANG;
+constexpr int kBoomGang = kGang < kBooms ? kGang : kBooms;  // lanes of a trip over the explosions
+using Q = Gang<kGang>;
+using Rng = GangRng<kGang>;
+
 struct Live {  // the hot scalars of one env, kept in registers over the four sub-steps
     float ax, ay, avx, avy, atimer;
     float bx, by, bvx, bvy, phase_t, attack_t, explo_t, damage_t, move_t;
@@ -189,20 +219,26 @@ struct Live {  // the hot scalars of one env, kept in registers over the four su
     float rock_x[kRocks], rock_y[kRocks];  // the barriers (fixed for the episode): read once a step, not once per bullet
 };
 
-PG_D Box hazard_box(const State& s, int env, const Live& v, int h) {  // h: 0..n_rocks-1 barrier, n_rocks = boss
-    if (h == v.n_rocks) return Box{v.bx + -0.6f, v.by + -0.4f, 1.2f, 0.8f};
-    float x = v.rock_x[0], y = v.rock_y[0];  // (selects, not an indexed array: the table stays in registers)
+PG_D bool hit(const Box& a, const Box& b) {  // box_hit without short circuits (no branches)
+    return (a.x < b.x + b.w) & (a.x + a.w > b.x) & (a.y < b.y + b.h) & (a.y + a.h > b.y);
+}
+PG_D bool hits_a_rock(const Live& v, const Box& sb) {
+    bool rock = false;
 #pragma unroll
-    for (int q = 1; q < kRocks; q++) {
-        x = h == q ? v.rock_x[q] : x;
-        y = h == q ? v.rock_y[q] : y;
-    }
-    return Box{x + -0.1f, y + -0.1f, 0.2f, 0.2f};
+    for (int k = 0; k < kRocks; k++)
+        rock = rock | ((k < v.n_rocks) & hit(sb, Box{v.rock_x[k] + -0.1f, v.rock_y[k] + -0.1f, 0.2f, 0.2f}));
+    return rock;
 }
 
-PG_D void boss_fire(const State& s, int env, Live& v, float rotation, float speed) {  // common_systems.cpp:75-88
-    if (v.b_count < kBossShots) {
-        const int k = v.b_next;
+// `shots` calls of fire_bullet one after the other (common_systems.cpp:75-88; each fires only while fewer than 64 are
+// in flight): shot j goes into ring slot b_next + j, written by the lane that owns the slot.
+template <class Rot>
+PG_D void boss_volley(const State& s, int env, Live& v, Q q, int shots, float speed, Rot rotation_of_shot) {
+    const int room = kBossShots - v.b_count;
+    const int fired = shots < room ? shots : room;
+    for (int j = (q.g - v.b_next) & (kGang - 1); j < fired; j += kGang) {
+        const int k = (v.b_next + j) & (kBossShots - 1);
+        const float rotation = rotation_of_shot(j);
         BS(s, S_ROT, k, env) = rotation;
         {   // what System_Mob_AI::render's angle (rotation + π/2) comes to in the raster (pg_render.h rotation_of): once
             // per bullet here, instead of sinf and cosf in every lane of both render wavefronts every frame
@@ -216,57 +252,60 @@ PG_D void boss_fire(const State& s, int env, Live& v, float rotation, float spee
         BS(s, S_X, k, env) = v.bx;
         BS(s, S_Y, k, env) = v.by;
         BS(s, S_FRAME, k, env) = 0.0f;
-        v.b_next = (v.b_next + 1) % kBossShots;
-        v.b_count++;
     }
+    v.b_next = (v.b_next + fired) & (kBossShots - 1);
+    v.b_count += fired;
 }
 
-PG_D void fire_pattern(const State& s, int env, Live& v, uint32_t* mt, int pattern, float dt) {  // :103-185
+PG_D void fire_pattern(const State& s, int env, Live& v, Rng& rng, Q q, int pattern, float dt) {  // :103-185
     const float bullet_speed = kBossBulletSpeed;
     float& timer = v.attack_t;
     switch (pattern) {
         case -1:
-            if (rng_real(mt, 0.0f, 1.0f) < 0.1f * dt)
-                boss_fire(s, env, v, static_cast<float>(kPi * (1.0f + rng_real(mt, 0.0f, 1.0f))), bullet_speed);
+            if (rng.real(0.0f, 1.0f) < 0.1f * dt) {
+                const float rot = static_cast<float>(kPi * (1.0f + rng.real(0.0f, 1.0f)));
+                boss_volley(s, env, v, q, 1, bullet_speed, [&](int) { return rot; });
+            }
             break;
         case 0:
             if (timer >= 8.0f) {
                 timer = 0.0f;
-                for (int k = 0; k < 5; k++)
-                    boss_fire(s, env, v, static_cast<float>(kPi * 1.5f + (k - 2) * kPi * 0.125f), bullet_speed);
+                boss_volley(s, env, v, q, 5, bullet_speed,
+                            [](int k) { return static_cast<float>(kPi * 1.5f + (k - 2) * kPi * 0.125f); });
             } else
                 timer += dt;
             break;
         case 1:
             if (timer >= 5.0f) {
                 timer = 0.0f;
-                int q = static_cast<int>(timer / 5.0f);
-                q = abs(8 - (q % 16));
-                for (int k = 0; k < 4; k++)
-                    boss_fire(s, env, v, static_cast<float>(kPi * (1.25f + q * 0.0625f) + k * kPi * 0.5f), bullet_speed);
+                int w = static_cast<int>(timer / 5.0f);
+                w = abs(8 - (w % 16));
+                boss_volley(s, env, v, q, 4, bullet_speed,
+                            [w](int k) { return static_cast<float>(kPi * (1.25f + w * 0.0625f) + k * kPi * 0.5f); });
             } else
                 timer += dt;
             break;
         case 2:
             if (timer >= 10.0f) {
                 timer = 0.0f;
-                const float offset = static_cast<float>(rng_real(mt, 0.0f, 1.0f) * 2.0f * kPi);
-                for (int k = 0; k < 8; k++)
-                    boss_fire(s, env, v, static_cast<float>(kPi * 0.25f * k + offset), bullet_speed);
+                const float offset = static_cast<float>(rng.real(0.0f, 1.0f) * 2.0f * kPi);
+                boss_volley(s, env, v, q, 8, bullet_speed,
+                            [offset](int k) { return static_cast<float>(kPi * 0.25f * k + offset); });
             } else
                 timer += dt;
             break;
         case 3:
             if (timer >= 4.0f) {
                 timer = 0.0f;
-                boss_fire(s, env, v, static_cast<float>(kPi * (1.0f + rng_real(mt, 0.0f, 1.0f))), bullet_speed);
+                const float rot = static_cast<float>(kPi * (1.0f + rng.real(0.0f, 1.0f)));
+                boss_volley(s, env, v, q, 1, bullet_speed, [&](int) { return rot; });
             } else
                 timer += dt;
             break;
     }
 }
 
-PG_D bool agent_update(const State& s, int env, Live& v, uint32_t* mt, float dt, int action) {  // :494-683
+PG_D bool agent_update(const State& s, int env, Live& v, Rng& rng, Q q, float dt, int action) {  // :494-683
     const float mixrate = 0.5f, speed = 0.1f, bullet_time = 5.0f, bullet_speed = 0.1f;
     const float bounce_speed = 0.05f, bounce_time = 10.0f, explosion_rate = 0.3f;
     const Box scr = v.scr;
@@ -299,85 +338,78 @@ PG_D bool agent_update(const State& s, int env, Live& v, uint32_t* mt, float dt,
         if (v.atimer == 0.0f && v.a_count < kAgentShots) {
             v.atimer = bullet_time;
             const int k = v.a_next;
-            AS(s, S_ROT, k, env) = 0.0f;
-            AS(s, S_VX, k, env) = 0.0f;
-            AS(s, S_VY, k, env) = -bullet_speed;
-            AS(s, S_X, k, env) = v.ax;
-            AS(s, S_Y, k, env) = v.ay;
-            AS(s, S_FRAME, k, env) = 0.0f;
-            AS(s, S_BOUNCE_T, k, env) = 0.0f;
-            AB(s, k, env) = 0;
+            if ((k & (kGang - 1)) == q.g) {
+                AS(s, S_ROT, k, env) = 0.0f;
+                AS(s, S_VX, k, env) = 0.0f;
+                AS(s, S_VY, k, env) = -bullet_speed;
+                AS(s, S_X, k, env) = v.ax;
+                AS(s, S_Y, k, env) = v.ay;
+                AS(s, S_FRAME, k, env) = 0.0f;
+                AS(s, S_BOUNCE_T, k, env) = 0.0f;
+                AB(s, k, env) = 0;
+            }
             v.a_next = (v.a_next + 1) % kAgentShots;
             v.a_count++;
         } else {
             v.atimer = fmaxf(0.0f, v.atimer - dt);
         }
     }
-    for (int h = 0; h <= v.n_rocks; h++)  // any hazard: a boolean, order-free
-        if (box_hit(wc, hazard_box(s, env, v, h))) {
-            v.a_alive = false;
-            break;
+    // any hazard: a boolean, order-free
+    const bool crashed = hits_a_rock(v, wc) || hit(wc, Box{v.bx + -0.6f, v.by + -0.4f, 1.2f, 0.8f});
+    v.a_alive = v.a_alive && !crashed;
+    // The reference visits the bullets newest first, one after the other, while `count` shrinks under the loop's feet
+    // (positions beyond it are never reached), and a bounce off the shield draws a random number.  A trip does kGang
+    // positions at once: every lane works out what its bullet would do if it is reached; positions are reached as long
+    // as i < count − (bullets destroyed before i) — a prefix of the list, because i + destroyed(i) only grows — and the
+    // k-th bounce in visiting order takes the k-th next output of the stream.
+    const bool shielded = v.phase % 2 == 0;
+    const Box boss{v.bx + -0.6f, v.by + -0.4f, 1.2f, 0.8f};
+    int count = v.a_count;
+    for (int i0 = 0; i0 < count; i0 += kGang) {
+        const Q::Trip t = q.trip<kAgentShots>(v.a_next, i0);
+        const int k = t.slot;
+        const bool mine = t.i < count;
+        float frame0 = -1.0f, px = 0.0f, py = 0.0f, vx = 0.0f, vy = 0.0f, btimer = 0.0f;
+        bool bouncing = false;
+        if (mine) {
+            frame0 = AS(s, S_FRAME, k, env);
+            px = AS(s, S_X, k, env);
+            py = AS(s, S_Y, k, env);
+            vx = AS(s, S_VX, k, env);
+            vy = AS(s, S_VY, k, env);
+            btimer = AS(s, S_BOUNCE_T, k, env);
+            bouncing = AB(s, k, env) != 0;
         }
-    // The bullets are visited one after the other (hits draw random numbers, count down the boss and shorten the very
-    // loop they are found in), but their state is fetched kShotBatch bullets at a time — the slots of the ring are known
-    // beforehand — so a batch costs one memory round trip instead of one per bullet.
-    for (int i0 = 0; i0 < v.a_count; i0 += kShotBatch) {
-    float f_frame[kShotBatch], f_x[kShotBatch], f_y[kShotBatch], f_vx[kShotBatch], f_vy[kShotBatch], f_bt[kShotBatch];
-    uint8_t f_bn[kShotBatch];
-#pragma unroll
-    for (int j = 0; j < kShotBatch; j++) {
-        const int k = (kAgentShots + v.a_next - 1 - (i0 + j)) & (kAgentShots - 1);  // (slots beyond the count: read, unused)
-        f_frame[j] = AS(s, S_FRAME, k, env);
-        f_x[j] = AS(s, S_X, k, env);
-        f_y[j] = AS(s, S_Y, k, env);
-        f_vx[j] = AS(s, S_VX, k, env);
-        f_vy[j] = AS(s, S_VY, k, env);
-        f_bt[j] = AS(s, S_BOUNCE_T, k, env);
-        f_bn[j] = AB(s, k, env);
-    }
-    // (one bullet = one straight run of selects, like the boss's below; the only branch left is the bounce off the
-    // shield, which draws a random number)
-    auto hit = [](const Box& a, const Box& b) {
-        return (a.x < b.x + b.w) & (a.x + a.w > b.x) & (a.y < b.y + b.h) & (a.y + a.h > b.y);
-    };
-#pragma unroll
-    for (int j = 0; j < kShotBatch; j++) {
-        const int i = i0 + j;
-        const int k = (kAgentShots + v.a_next - 1 - i) & (kAgentShots - 1);
-        const float frame0 = f_frame[j];
-        const bool act = (i < v.a_count) & (frame0 != -1.0f);  // a_count shrinks inside the loop, as in the reference
-        float px = f_x[j], py = f_y[j], vx = f_vx[j], vy = f_vy[j], btimer = f_bt[j];
-        bool bouncing = f_bn[j] != 0;
+        const bool live = mine & (frame0 != -1.0f);
         const Box sb{px - 0.01f, py - 0.01f, 0.02f, 0.02f};
-        const bool fly = act & (frame0 == 0.0f);
+        const bool fly = live & (frame0 == 0.0f);
         const bool off = fly & !hit(sb, scr);
         // hazard set order: barriers newest-first, then the boss — the first one hit decides, and every barrier does the same
-        bool rock = false;
-#pragma unroll
-        for (int q = 0; q < kRocks; q++)
-            rock = rock | ((q < v.n_rocks) & hit(sb, Box{v.rock_x[q] + -0.1f, v.rock_y[q] + -0.1f, 0.2f, 0.2f}));
-        const bool at_boss = fly & !off & !rock & hit(sb, Box{v.bx + -0.6f, v.by + -0.4f, 1.2f, 0.8f});
-        const bool shielded = v.phase % 2 == 0;
-        if (at_boss & shielded) {  // bounce off
-            vx = rng_real(mt, -1.0f, 1.0f) * bounce_speed;
-            vy = bounce_speed;
-            btimer = bounce_time;
-            bouncing = true;
-        }
+        const bool rock = hits_a_rock(v, sb);
+        const bool at_boss = fly & !off & !rock & hit(sb, boss);
+        const bool bounces = at_boss & shielded;
         const bool bursts = (fly & !off & rock) | (at_boss & !shielded);
-        v.hp -= (at_boss & !shielded & (v.hp > 0)) ? 1 : 0;
+        btimer = bounces ? bounce_time : btimer;
+        bouncing = bouncing | bounces;
+        float frame = off ? 5.0f : (bursts ? 1.0f : frame0);
+        const bool ticking = btimer > 0.0f;
+        const bool destroyed = live & ((frame >= 5.0f) | (bouncing & !ticking));
+        const bool act = live & (t.i < count - Q::before(q.ranked(t, destroyed), t.rank));
+        const uint32_t bounce_list = q.ranked(t, bounces & act);
+        if (bounce_list) {  // bounce off the shield
+            const uint32_t word = rng.next_in_order(bounces & act, Q::before(bounce_list, t.rank), __popc(bounce_list));
+            vx = bounces ? (canonical_of(word) * (1.0f - -1.0f) + -1.0f) * bounce_speed : vx;
+            vy = bounces ? bounce_speed : vy;
+        }
+        const int wounds = __popc(q.ballot(at_boss & !shielded & act));
+        v.hp = v.hp - wounds < 0 ? 0 : v.hp - wounds;
         vx = (off | bursts) ? 0.0f : vx;
         vy = (off | bursts) ? 0.0f : vy;
-        float frame = off ? 5.0f : (bursts ? 1.0f : frame0);
-        px = act ? px + vx * dt : px;
-        py = act ? py + vy * dt : py;
-        bool destroy = act & (frame >= 5.0f);
-        frame = (act & !destroy & (frame >= 1.0f)) ? frame + explosion_rate * dt : frame;
-        const bool ticking = btimer > 0.0f;
-        destroy = destroy | (act & bouncing & !ticking);
-        btimer = (act & bouncing & ticking) ? fmaxf(0.0f, btimer - dt) : btimer;
-        v.a_count -= destroy ? 1 : 0;
-        frame = destroy ? -1.0f : frame;
+        px = px + vx * dt;
+        py = py + vy * dt;
+        frame = (!destroyed & (frame >= 1.0f)) ? frame + explosion_rate * dt : frame;
+        btimer = (bouncing & ticking) ? fmaxf(0.0f, btimer - dt) : btimer;
+        frame = destroyed ? -1.0f : frame;
         if (act) {
             AS(s, S_X, k, env) = px;
             AS(s, S_Y, k, env) = py;
@@ -387,13 +419,14 @@ PG_D bool agent_update(const State& s, int env, Live& v, uint32_t* mt, float dt,
             AS(s, S_BOUNCE_T, k, env) = btimer;
             AB(s, k, env) = bouncing ? 1 : 0;
         }
+        count -= __popc(q.ballot(destroyed & act));
     }
-    }
+    v.a_count = count;
     return v.a_alive;
 }
 
-PG_D bool boss_update(const State& s, int env, Live& v, uint32_t* mt, float dt) {  // :199-390
-    const float shielded_time = 180.0f + rng_real(mt, 0.0f, 1.0f) * kShieldedSpread;  // drawn every sub-step (D14)
+PG_D bool boss_update(const State& s, int env, Live& v, Rng& rng, Q q, float dt) {  // :199-390
+    const float shielded_time = 180.0f + rng.real(0.0f, 1.0f) * kShieldedSpread;  // drawn every sub-step (D14)
     const float unshielded_time = 300.0f, explosion_rate = 0.3f, move_time = 70.0f, damage_time = 80.0f;
     const int boss_hp = 3;
     bool alive = true;
@@ -401,7 +434,7 @@ PG_D bool boss_update(const State& s, int env, Live& v, uint32_t* mt, float dt) 
     const Box scr = v.scr;
 
     if (v.phase_t == 0.0f) {
-        v.weapon = rng_int(mt, 0, 3);
+        v.weapon = rng.integer(0, 3);
         v.attack_t = 0.0f;
         v.hp = boss_hp;
     }
@@ -411,23 +444,25 @@ PG_D bool boss_update(const State& s, int env, Live& v, uint32_t* mt, float dt) 
             v.phase++;
         } else
             v.phase_t += dt;
-        fire_pattern(s, env, v, mt, v.weapon, dt);
+        fire_pattern(s, env, v, rng, q, v.weapon, dt);
     } else {
         if (v.phase_t >= unshielded_time) {
             v.phase_t = 0.0f;
             v.phase++;
         } else
             v.phase_t += dt;
-        fire_pattern(s, env, v, mt, -1, dt);
+        fire_pattern(s, env, v, rng, q, -1, dt);
         if (v.hp == 0) {
             if (v.explo_t >= 8.0f) {  // show_damage → explode (:187-197, :91-101)
                 v.explo_t = 0.0f;
-                const float ox = rng_real(mt, -0.5f, 0.5f) + v.bx;
-                const float oy = rng_real(mt, -0.5f, 0.5f) + v.by;
+                const float ox = rng.real(-0.5f, 0.5f) + v.bx;
+                const float oy = rng.real(-0.5f, 0.5f) + v.by;
                 if (v.x_count < kBooms) {
-                    BM(s, 0, v.x_next, env) = ox;
-                    BM(s, 1, v.x_next, env) = oy;
-                    BM(s, 2, v.x_next, env) = 0.0f;
+                    if ((v.x_next & (kBoomGang - 1)) == q.g) {
+                        BM(s, 0, v.x_next, env) = ox;
+                        BM(s, 1, v.x_next, env) = oy;
+                        BM(s, 2, v.x_next, env) = 0.0f;
+                    }
                     v.x_next = (v.x_next + 1) % kBooms;
                     v.x_count++;
                 }
@@ -443,8 +478,8 @@ PG_D bool boss_update(const State& s, int env, Live& v, uint32_t* mt, float dt) 
     }
     if (v.move_t >= move_time) {
         v.move_t = 0.0f;
-        const float tx = (rng_real(mt, 0.0f, 1.0f) * 2.0f - 1.0f) * 0.5f * scr.w * 0.7f;
-        const float ty = ((rng_real(mt, 0.0f, 1.0f) * 2.0f - 1.0f) * 0.5f - 0.3f) * scr.h * 0.5f;
+        const float tx = (rng.real(0.0f, 1.0f) * 2.0f - 1.0f) * 0.5f * scr.w * 0.7f;
+        const float ty = ((rng.real(0.0f, 1.0f) * 2.0f - 1.0f) * 0.5f - 0.3f) * scr.h * 0.5f;
         v.bvx = (tx - v.bx) / move_time;
         v.bvy = (ty - v.by) / move_time;
     } else
@@ -452,79 +487,77 @@ PG_D bool boss_update(const State& s, int env, Live& v, uint32_t* mt, float dt) 
     v.bx += v.bvx * dt;
     v.by += v.bvy * dt;
 
-    bool hit_agent = false;
-    for (int i0 = 0; i0 < v.b_count && !hit_agent; i0 += kShotBatch) {  // fetched in batches like the agent's
-    float f_frame[kShotBatch], f_x[kShotBatch], f_y[kShotBatch], f_vx[kShotBatch], f_vy[kShotBatch];
-#pragma unroll
-    for (int j = 0; j < kShotBatch; j++) {
-        const int k = (kBossShots + v.b_next - 1 - (i0 + j)) & (kBossShots - 1);
-        f_frame[j] = BS(s, S_FRAME, k, env);
-        f_x[j] = BS(s, S_X, k, env);
-        f_y[j] = BS(s, S_Y, k, env);
-        f_vx[j] = BS(s, S_VX, k, env);
-        f_vy[j] = BS(s, S_VY, k, env);
-    }
-    // One bullet = one straight run of selects (bitwise tests: nothing short-circuits into a branch).  The kernel is one
-    // wavefront per 64 envs with its SIMD to itself and walks max-over-its-envs many bullets: as nested ifs every bullet
-    // cost a dozen taken branches, which is where the time went — not into the arithmetic they skipped.  Same outcome
-    // per bullet as the reference's loop: a bullet that meets the agent explodes in place and ends the loop (D14).
-    auto hit = [](const Box& a, const Box& b) {
-        return (a.x < b.x + b.w) & (a.x + a.w > b.x) & (a.y < b.y + b.h) & (a.y + a.h > b.y);
-    };
-#pragma unroll
-    for (int j = 0; j < kShotBatch; j++) {
-        const int i = i0 + j;
-        const int k = (kBossShots + v.b_next - 1 - i) & (kBossShots - 1);
-        const float frame0 = f_frame[j];
-        const bool act = (i < v.b_count) & !hit_agent & (frame0 != -1.0f);
-        float px = f_x[j], py = f_y[j], vx = f_vx[j], vy = f_vy[j];
-        const Box sb{px - 0.01f, py - 0.01f, 0.02f, 0.02f};
-        const bool fly = act & (frame0 == 0.0f);
-        const bool off = fly & !hit(sb, scr);
-        const bool strikes = fly & !off & hit(sb, agent_rect);
-        bool rock = false;  // barriers (the boss skips itself); which one is first does not matter
-#pragma unroll
-        for (int q = 0; q < kRocks; q++)
-            rock = rock | ((q < v.n_rocks) & hit(sb, Box{v.rock_x[q] + -0.1f, v.rock_y[q] + -0.1f, 0.2f, 0.2f}));
-        const bool bursts = strikes | (fly & !off & rock);
-        vx = (off | bursts) ? 0.0f : vx;
-        vy = (off | bursts) ? 0.0f : vy;
-        float frame = off ? 5.0f : (bursts ? 1.0f : frame0);
-        const bool moves = act & !strikes;  // (the one that met the agent stays where it is, at frame 1)
-        px = moves ? px + vx * dt : px;
-        py = moves ? py + vy * dt : py;
-        const bool gone = moves & (frame >= 5.0f);
-        const bool burns = moves & !gone & (frame >= 1.0f);
-        v.b_count -= gone ? 1 : 0;
-        frame = gone ? -1.0f : (burns ? frame + explosion_rate * dt : frame);
-        if (act) {
-            BS(s, S_X, k, env) = px;
-            BS(s, S_Y, k, env) = py;
-            BS(s, S_VX, k, env) = vx;
-            BS(s, S_VY, k, env) = vy;
-            BS(s, S_FRAME, k, env) = frame;
+    // The boss's bullets, as the agent's above; in addition a bullet that meets the agent explodes where it is and ends
+    // the loop (D14: the bullets behind it skip this sub-step): only the positions up to the first such one are reached.
+    {
+        int count = v.b_count;
+        bool struck = false;
+        for (int i0 = 0; i0 < count && !struck; i0 += kGang) {
+            const Q::Trip t = q.trip<kBossShots>(v.b_next, i0);
+            const int k = t.slot;
+            const bool mine = t.i < count;
+            float frame0 = -1.0f, px = 0.0f, py = 0.0f, vx = 0.0f, vy = 0.0f;
+            if (mine) {
+                frame0 = BS(s, S_FRAME, k, env);
+                px = BS(s, S_X, k, env);
+                py = BS(s, S_Y, k, env);
+                vx = BS(s, S_VX, k, env);
+                vy = BS(s, S_VY, k, env);
+            }
+            const bool live = mine & (frame0 != -1.0f);
+            const Box sb{px - 0.01f, py - 0.01f, 0.02f, 0.02f};
+            const bool fly = live & (frame0 == 0.0f);
+            const bool off = fly & !hit(sb, scr);
+            const bool strikes = fly & !off & hit(sb, agent_rect);
+            const bool rock = hits_a_rock(v, sb);  // barriers (the boss skips itself); which one is first does not matter
+            const bool bursts = strikes | (fly & !off & rock);
+            vx = (off | bursts) ? 0.0f : vx;
+            vy = (off | bursts) ? 0.0f : vy;
+            float frame = off ? 5.0f : (bursts ? 1.0f : frame0);
+            const bool moves = live & !strikes;  // (the one that met the agent stays where it is, at frame 1)
+            const bool gone = moves & (frame >= 5.0f);
+            const bool reached = t.i < count - Q::before(q.ranked(t, gone), t.rank);
+            const uint32_t strike_list = q.ranked(t, strikes & reached);
+            const int first = strike_list ? __ffs(strike_list) - 1 : kGang;
+            const bool act = live & reached & (t.rank <= first);
+            px = moves ? px + vx * dt : px;
+            py = moves ? py + vy * dt : py;
+            const bool burns = moves & !gone & (frame >= 1.0f);
+            frame = gone ? -1.0f : (burns ? frame + explosion_rate * dt : frame);
+            if (act) {
+                BS(s, S_X, k, env) = px;
+                BS(s, S_Y, k, env) = py;
+                BS(s, S_VX, k, env) = vx;
+                BS(s, S_VY, k, env) = vy;
+                BS(s, S_FRAME, k, env) = frame;
+            }
+            count -= __popc(q.ballot(gone & act));
+            struck = strike_list != 0;  // later bullets skip this sub-step (D14)
         }
-        hit_agent = hit_agent | strikes;  // later bullets skip this sub-step (D14)
-        v.a_alive = v.a_alive & !strikes;
+        v.b_count = count;
+        v.a_alive = v.a_alive & !struck;
     }
-    }
-    for (int i = 0; i < v.x_count; i++) {
-        const int k = (kBooms + v.x_next - 1 - i) % kBooms;
-        float frame = BM(s, 2, k, env);
-        if (frame == -1.0f) continue;
-        if (frame >= 4.0f) {
-            v.x_count--;
-            frame = -1.0f;
-        } else if (frame >= 0.0f)
-            frame += explosion_rate * dt;
-        BM(s, 2, k, env) = frame;
+    {
+        int count = v.x_count;
+        for (int i0 = 0; i0 < count; i0 += kBoomGang) {
+            const Q::Trip t = q.trip<kBooms, kBoomGang>(v.x_next, i0);
+            const bool mine = (q.g < kBoomGang) & (t.i < count);
+            float frame = mine ? BM(s, 2, t.slot, env) : -1.0f;
+            const bool live = mine & (frame != -1.0f);
+            const bool gone = live & (frame >= 4.0f);
+            const bool act = live & (t.i < count - Q::before(q.ranked<kBoomGang>(t, gone), t.rank));
+            frame = gone ? -1.0f : (frame >= 0.0f ? frame + explosion_rate * dt : frame);
+            if (act) BM(s, 2, t.slot, env) = frame;
+            count -= __popc(q.ballot(gone & act));
+        }
+        v.x_count = count;
     }
     if (v.phase >= 6) alive = false;
     return alive;
 }
 
-PG_D void advance(const State& s, int env, int action, float& reward_out, bool& terminated_out) {
-    uint32_t* mt = s.mt + size_t(env) * kMtWords;
+PG_D void advance(const State& s, Q q, int env, int action, float& reward_out, bool& terminated_out) {
+    Rng rng = Rng::open(s.mt + size_t(env) * kMtWords, q);
     const int flags = SI(s, I_FLAGS, env);
     Live v;
     v.ax = SF(s, F_AX, env);
@@ -552,48 +585,55 @@ PG_D void advance(const State& s, int env, int action, float& reward_out, bool& 
     v.x_count = SI(s, I_X_COUNT, env);
     v.n_rocks = SI(s, I_NROCKS, env);
     v.a_alive = (flags & kFlagAlive) != 0;
-    v.scr = screen_box(take_view(s, env));
+    const float cam_w = SF(s, F_CAMW, env), cam_h = SF(s, F_CAMH, env);  // take_view by a gang: all read, lane 0 puts 64 back below
+    v.scr = screen_box(View{cam_w, cam_h, 1.0f * cam_w / 64.0f});
 #pragma unroll
-    for (int q = 0; q < kRocks; q++) {
-        v.rock_x[q] = RK(s, 0, q, env);
-        v.rock_y[q] = RK(s, 1, q, env);
+    for (int k = 0; k < kRocks; k++) {
+        v.rock_x[k] = RK(s, 0, k, env);
+        v.rock_y[k] = RK(s, 1, k, env);
     }
 
     const float dt = 1.0f / 4;
     float reward = 0.0f;
     bool terminated = false;
     for (int ss = 0; ss < 4; ss++) {
-        const bool agent_alive = agent_update(s, env, v, mt, dt, action);
-        const bool boss_alive = boss_update(s, env, v, mt, dt);
+        const bool agent_alive = agent_update(s, env, v, rng, q, dt, action);
+        const bool boss_alive = boss_update(s, env, v, rng, q, dt);
         reward = (!agent_alive) * -10.0f + (!boss_alive) * 10.0f;
         terminated = !agent_alive || !boss_alive;
         if (terminated) break;
     }
-
-    SF(s, F_AX, env) = v.ax;
-    SF(s, F_AY, env) = v.ay;
-    SF(s, F_AVX, env) = v.avx;
-    SF(s, F_AVY, env) = v.avy;
-    SF(s, F_ATIMER, env) = v.atimer;
-    SF(s, F_BX, env) = v.bx;
-    SF(s, F_BY, env) = v.by;
-    SF(s, F_BVX, env) = v.bvx;
-    SF(s, F_BVY, env) = v.bvy;
-    SF(s, F_PHASE_T, env) = v.phase_t;
-    SF(s, F_ATTACK_T, env) = v.attack_t;
-    SF(s, F_EXPLO_T, env) = v.explo_t;
-    SF(s, F_DAMAGE_T, env) = v.damage_t;
-    SF(s, F_MOVE_T, env) = v.move_t;
-    SI(s, I_A_NEXT, env) = v.a_next;
-    SI(s, I_A_COUNT, env) = v.a_count;
-    SI(s, I_PHASE, env) = v.phase;
-    SI(s, I_WEAPON, env) = v.weapon;
-    SI(s, I_HP, env) = v.hp;
-    SI(s, I_B_NEXT, env) = v.b_next;
-    SI(s, I_B_COUNT, env) = v.b_count;
-    SI(s, I_X_NEXT, env) = v.x_next;
-    SI(s, I_X_COUNT, env) = v.x_count;
-    SI(s, I_FLAGS, env) = (v.a_alive ? kFlagAlive : 0) | kFlagListed;  // sprite list built by the first update
+    rng.close();
+    if (q.g == 0) {
+        if (cam_w != kCamSize || cam_h != kCamSize) {
+            SF(s, F_CAMW, env) = kCamSize;
+            SF(s, F_CAMH, env) = kCamSize;
+        }
+        SF(s, F_AX, env) = v.ax;
+        SF(s, F_AY, env) = v.ay;
+        SF(s, F_AVX, env) = v.avx;
+        SF(s, F_AVY, env) = v.avy;
+        SF(s, F_ATIMER, env) = v.atimer;
+        SF(s, F_BX, env) = v.bx;
+        SF(s, F_BY, env) = v.by;
+        SF(s, F_BVX, env) = v.bvx;
+        SF(s, F_BVY, env) = v.bvy;
+        SF(s, F_PHASE_T, env) = v.phase_t;
+        SF(s, F_ATTACK_T, env) = v.attack_t;
+        SF(s, F_EXPLO_T, env) = v.explo_t;
+        SF(s, F_DAMAGE_T, env) = v.damage_t;
+        SF(s, F_MOVE_T, env) = v.move_t;
+        SI(s, I_A_NEXT, env) = v.a_next;
+        SI(s, I_A_COUNT, env) = v.a_count;
+        SI(s, I_PHASE, env) = v.phase;
+        SI(s, I_WEAPON, env) = v.weapon;
+        SI(s, I_HP, env) = v.hp;
+        SI(s, I_B_NEXT, env) = v.b_next;
+        SI(s, I_B_COUNT, env) = v.b_count;
+        SI(s, I_X_NEXT, env) = v.x_next;
+        SI(s, I_X_COUNT, env) = v.x_count;
+        SI(s, I_FLAGS, env) = (v.a_alive ? kFlagAlive : 0) | kFlagListed;  // sprite list built by the first update
+    }
     reward_out = reward;
     terminated_out = terminated;
 }
@@ -634,7 +674,8 @@ PG_D void begin_level(const State& s, const LevelPlan& plan, int env, bool resta
     } else if (restart) {
         mt_seed(mt, chain_seed);
     }
-    new_level(s, env);
+    LaneRng rng{mt};
+    new_level(s, env, rng, true);
 }
 
 __global__ void __launch_bounds__(64) make_kernel(State s, uint32_t seed_base, int env_offset, LevelPlan plan) {
@@ -655,25 +696,36 @@ __global__ void __launch_bounds__(64) reset_kernel(State s, const uint8_t* mask,
     io.pending[env] = 0;
 }
 
-__global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actions, uint32_t run_seed,
-                                                   uint32_t step_index, int env_offset, StepIO io, LevelPlan plan) {
-    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(64, 4) logic_kernel(State s, const int32_t* actions, uint32_t run_seed,
+                                                      uint32_t step_index, int env_offset, StepIO io, LevelPlan plan) {
+    const int env = (blockIdx.x * 64 + threadIdx.x) / kGang;
     if (env >= s.n) return;
+    const Q q = Q::at(threadIdx.x);
     if (io.pending[env]) {
-        begin_level(s, plan, env, false, 0u);
-        io.reward[env] = 0.0f;
-        io.done[env] = 0;
-        io.pending[env] = 0;
+        if (plan.num_levels > 0) {  // level-seed mode rebuilds the env: one lane (begin_level)
+            if (q.g == 0) begin_level(s, plan, env, false, 0u);
+        } else {
+            Rng rng = Rng::open(s.mt + size_t(env) * kMtWords, q);
+            new_level(s, env, rng, q.g == 0);
+            rng.close();
+        }
+        if (q.g == 0) {
+            io.reward[env] = 0.0f;
+            io.done[env] = 0;
+            io.pending[env] = 0;
+        }
         return;
     }
     const int action =
         actions ? actions[env] : synthetic_action(run_seed, step_index, static_cast<uint32_t>(env_offset + env));
     float reward;
     bool terminated;
-    advance(s, env, action, reward, terminated);
-    io.reward[env] = reward;
-    io.done[env] = terminated ? 1 : 0;
-    io.pending[env] = terminated ? 1 : 0;
+    advance(s, q, env, action, reward, terminated);
+    if (q.g == 0) {
+        io.reward[env] = reward;
+        io.done[env] = terminated ? 1 : 0;
+        io.pending[env] = terminated ? 1 : 0;
+    }
 }
 
 // render_game(true) (bossfight.cpp:401-424): one workgroup of two wavefronts per env (pg_render.h).
@@ -970,7 +1022,7 @@ class BossfightGame final : public Game {
     }
     void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
                       StepIO io) override {
-        hipLaunchKernelGGL(logic_kernel, dim3(logic_blocks(s_.n)), dim3(logic_lanes()), 0, st, s_, actions, run_seed, step_index,
+        hipLaunchKernelGGL(logic_kernel, dim3((s_.n * kGang + 63) / 64), dim3(64), 0, st, s_, actions, run_seed, step_index,
                            env_offset, io, plan);
     }
     bool launch_frame(hipStream_t st, int env, uint32_t* d_px, int w, int h) override {
@@ -1002,9 +1054,9 @@ class BossfightGame final : public Game {
                                 iv(I_PHASE), iv(I_WEAPON), f(F_ATTACK_T), iv(I_HP), iv(I_B_NEXT), iv(I_B_COUNT),
                                 iv(I_X_NEXT), iv(I_X_COUNT), f(F_EXPLO_T), f(F_DAMAGE_T), f(F_MOVE_T), iv(I_NROCKS)};
         for (int k = 0; k < kAgentShots; k++)
-            for (int fld : {S_X, S_Y, S_FRAME}) v.push_back(rf(s_.ashot, (size_t(fld) * kAgentShots + k) * n + env));
+            for (int fld : {S_X, S_Y, S_FRAME}) v.push_back(rf(s_.ashot, (size_t(env) * S_COUNT + fld) * kAgentShots + k));
         for (int k = 0; k < kBossShots; k++)
-            for (int fld : {S_X, S_Y, S_FRAME}) v.push_back(rf(s_.bshot, (size_t(fld) * kBossShots + k) * n + env));
+            for (int fld : {S_X, S_Y, S_FRAME}) v.push_back(rf(s_.bshot, (size_t(env) * S_COUNT + fld) * kBossShots + k));
         const int m = cap < static_cast<int>(v.size()) ? cap : static_cast<int>(v.size());
         for (int k = 0; k < m; k++) out[k] = v[k];
         return static_cast<int>(v.size());
