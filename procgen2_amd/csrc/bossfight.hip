@@ -203,7 +203,10 @@ PG_D void new_level(const State& s, int env, R& rng, bool lead) {
 // One env = one gang (pg_gang.h).  Everything in Live is uniform over the gang; `q.g` only decides which ring slots a
 // lane owns (slot mod width) — it writes the bullets fired into them and is the one that moves them.
 #ifndef PG_BOSSFIGHT_GANG
-#define PG_BOSSFIGHT_GANG 8
+#define PG_BOSSFIGHT_GANG 16
+#endif
+#ifndef PG_BOSSFIGHT_WAVES
+#define PG_BOSSFIGHT_WAVES 4  // wavefronts per SIMD the logic kernel's registers are capped for
 #endif
 constexpr int kGang = PG_BOSSFIGHT_GANG;
 constexpr int kBoomGang = kGang < kBooms ? kGang : kBooms;  // lanes of a trip over the explosions
@@ -696,7 +699,7 @@ __global__ void __launch_bounds__(64) reset_kernel(State s, const uint8_t* mask,
     io.pending[env] = 0;
 }
 
-__global__ void __launch_bounds__(64, 4) logic_kernel(State s, const int32_t* actions, uint32_t run_seed,
+__global__ void __launch_bounds__(64, PG_BOSSFIGHT_WAVES) logic_kernel(State s, const int32_t* actions, uint32_t run_seed,
                                                       uint32_t step_index, int env_offset, StepIO io, LevelPlan plan) {
     const int env = (blockIdx.x * 64 + threadIdx.x) / kGang;
     if (env >= s.n) return;

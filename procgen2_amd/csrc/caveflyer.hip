@@ -9,7 +9,8 @@
 // Config = the reference's compile-time default, hard_mode (40×40, pruned; caveflyer/tilemap.h:43-45).
 //
 // Machine mapping:
-//   * logic  — one lane per env over struct-of-arrays state (agent, 32 bullets, ≤60 objects, 10 particles);
+//   * logic  — a gang of kGang adjacent lanes per env (pg_gang.h): the ship's scalars uniformly in all of them, the
+//              ≤60 objects dealt out over the lanes' registers, bullets and particles one slot per lane;
 //   * render — two wavefronts per env sharing an LDS target (pg_render.h), tiles through the row composer, the rotated sprites
 //              (particles, bullets, ship) as whole-wave rotated blits;
 //   * level generation — one wavefront per env with a 23 KiB LDS workspace.  The generator's result depends on
@@ -21,6 +22,7 @@
 //              ends (pg_prefetch.h); the synchronous path remains as the fallback and for reseeding resets.
 #include "pg_engine.h"
 #include "pg_frame.h"
+#include "pg_gang.h"
 #include "pg_geom.h"
 #include "pg_order.h"
 #include "pg_prefetch.h"
@@ -52,7 +54,7 @@ constexpr bool kPrune = PG_VARIANT != 2;              // tilemap.cpp:203 should_
 // ids: 0 goal, 1 ship, 2.. objects; 3·(free/80) objects (tilemap.cpp:232-233): ≤ 60 at 40×40, ≤ 75 at 45×45
 constexpr int kMaxEnt = 2 + 3 * ((kCells > 1600 ? kCells : 1600) / 80) + (kCells > 1600 ? 1 : 0);
 static_assert(kMaxEnt <= 128, "two wave passes cover the sprites");
-constexpr int kShots = 32, kPuffs = 10;
+constexpr int kShots = 32, kPuffs = 10, kPuffSlots = 16;
 constexpr double kPi = 3.14159265358979323846;  // M_PI
 enum Tile : uint8_t { kEmpty = 0, kWall = 1 };
 enum Kind { kMeteor = 0, kTarget = 1, kEnemy = 2, kGoal = 3 };
@@ -76,7 +78,8 @@ enum {
 enum { I_FLAGS, I_BACKDROP, I_NENT, I_NDRAW, I_SNEXT, I_SCOUNT, I_HASH_SPRITE, I_HASH_HAZARD, I_COUNT };
 constexpr int kFlagListed = 1, kFlagPuffOn = 2;
 enum { EF_X, EF_Y, EF_VX, EF_VY, EF_COUNT };
-enum { EB_INFO, EB_ORDER_S, EB_ORDER_H, EB_DRAW, EB_COUNT };
+enum { EB_INFO, EB_ORDER_S, EB_ORDER_H, EB_DRAW, EB_PLACE_H, EB_COUNT };  // EB_PLACE_H[e]: where e stands in EB_ORDER_H
+constexpr int kEntStride = (kMaxEnt + 15) / 16 * 16;
 constexpr int kKindMask = 3, kAlive = 4;
 enum { SH_X, SH_Y, SH_VX, SH_VY, SH_ROT, SH_FRAME, SH_SN, SH_CS, SH_COUNT };  // SH_SN/CS: rotation_of the drawing angle, fixed when fired
 enum { PF_X, PF_Y, PF_DX, PF_DY, PF_ROT, PF_LIFE, PF_SN, PF_CS, PF_COUNT };  // likewise
@@ -98,19 +101,21 @@ struct State {
     int32_t* slot;   // [n]  SlotState
     uint32_t* mt;    // [n][625]  generator chain: the stream position after the newest generated level
     uint8_t* tiles;  // [n][kCells]  column-major y + x*H
+    uint64_t* cols;  // [n][W]  the same map as wall bits, one word per column (pg_tiles.h BitWinT): what the logic kernel reads
     float* f;        // [F_COUNT][n]
     int32_t* i;      // [I_COUNT][n]
-    float* ef;       // [EF_COUNT][kMaxEnt][n]
-    uint8_t* eb;     // [EB_COUNT][kMaxEnt][n]
-    float* sh;       // [SH_COUNT][kShots][n]
-    float* pf;       // [PF_COUNT][kPuffs][n]
+    // per-env contiguous tables ([env][field][slot]): the lanes of a gang and of the render wavefronts index them by slot
+    float* ef;       // [n][EF_COUNT][kEntStride]
+    uint8_t* eb;     // [n][EB_COUNT][kEntStride]
+    float* sh;       // [n][SH_COUNT][kShots]
+    float* pf;       // [n][PF_COUNT][kPuffSlots]
     const uint8_t* ranks;  // pg_order.h equal-key sort ranks
 };
 
 PG_D float& SF(const State& s, int field, int env) { return s.f[size_t(field) * s.n + env]; }
 PG_D int32_t& SI(const State& s, int field, int env) { return s.i[size_t(field) * s.n + env]; }
-PG_D float& EF(const State& s, int field, int e, int env) { return s.ef[(size_t(field) * kMaxEnt + e) * s.n + env]; }
-PG_D uint8_t& EB(const State& s, int field, int e, int env) { return s.eb[(size_t(field) * kMaxEnt + e) * s.n + env]; }
+PG_D float& EF(const State& s, int field, int e, int env) { return s.ef[(size_t(env) * EF_COUNT + field) * kEntStride + e]; }
+PG_D uint8_t& EB(const State& s, int field, int e, int env) { return s.eb[(size_t(env) * EB_COUNT + field) * kEntStride + e]; }
 // rotation_of(angle) into a pair of float slots (as int bits): where the angle is set, so the render kernel reads two
 // words instead of evaluating sinf and cosf in every lane of both wavefronts, every frame.
 PG_D void store_rotation(float& sn_slot, float& cs_slot, float angle) {
@@ -119,10 +124,11 @@ PG_D void store_rotation(float& sn_slot, float& cs_slot, float angle) {
     sn_slot = __int_as_float(sn);
     cs_slot = __int_as_float(cs);
 }
-PG_D float& SH(const State& s, int field, int k, int env) { return s.sh[(size_t(field) * kShots + k) * s.n + env]; }
-PG_D float& PF(const State& s, int field, int k, int env) { return s.pf[(size_t(field) * kPuffs + k) * s.n + env]; }
+PG_D float& SH(const State& s, int field, int k, int env) { return s.sh[(size_t(env) * SH_COUNT + field) * kShots + k]; }
+PG_D float& PF(const State& s, int field, int k, int env) { return s.pf[(size_t(env) * PF_COUNT + field) * kPuffSlots + k]; }
 
 using Win = TileWinT<W, H, kWall>;  // out of bounds is a wall (tilemap.h:78-83)
+using BitWin = BitWinT<W, H, kWall, kEmpty>;
 PG_D bool is_wall(int t) { return t == kWall; }
 
 // ------------------------------------------------------------------------------------------------
@@ -274,6 +280,11 @@ PG_D void install(const State& s, int env, const Level& lv, int lane) {
     uint32_t* tiles = reinterpret_cast<uint32_t*>(s.tiles + size_t(env) * kTileStride);
     const uint32_t* src = reinterpret_cast<const uint32_t*>(lv.tiles);
     for (int k = lane; k < kTileStride / 4; k += 64) tiles[k] = src[k];
+    for (int x = lane; x < W; x += 64) {  // collide() looks at tile (x, H-1-y): bit y of the column word
+        uint64_t word = ~0ull << H;
+        for (int y = 0; y < H; y++) word |= static_cast<uint64_t>(lv.tiles[(H - 1 - y) + x * H] == kWall ? 1 : 0) << y;
+        s.cols[size_t(env) * W + x] = word;
+    }
     const int n_ent = lv.n_ent;
     for (int e = lane; e < n_ent; e += 64) {
         EF(s, EF_X, e, env) = lv.ex[e];
@@ -282,7 +293,10 @@ PG_D void install(const State& s, int env, const Level& lv, int lane) {
         EF(s, EF_VY, e, env) = lv.evy[e];
         EB(s, EB_INFO, e, env) = lv.info[e];
         if (e < n_ent - 1) EB(s, EB_ORDER_S, e, env) = lv.order_s[e];
-        if (e < n_ent - 2) EB(s, EB_ORDER_H, e, env) = lv.order_h[e];
+        if (e < n_ent - 2) {
+            EB(s, EB_ORDER_H, e, env) = lv.order_h[e];
+            EB(s, EB_PLACE_H, lv.order_h[e], env) = static_cast<uint8_t>(e);
+        }
     }
     if (lane < kPuffs)
         for (int f = 0; f < PF_COUNT; f++) PF(s, f, lane, env) = 0.0f;
@@ -310,19 +324,36 @@ PG_D void install(const State& s, int env, const Level& lv, int lane) {
 // ------------------------------------------------------------------------------------------------
 // step
 // ------------------------------------------------------------------------------------------------
-// The entity table of the 64 envs of a logic wavefront, staged in LDS for the step ([entity][lane]): a sub-step walks
-// the hazards for the ship and again, in the hazard set's order, for every flying bullet — from global memory three
-// dependent loads per visit on a wave with nothing to hide them behind.  Staged once (four entities at a time, all
-// loads in flight); enemy positions and destroyed targets are written through to global memory.
-struct StepLds {
-    float x[kMaxEnt][64], y[kMaxEnt][64];
-    uint8_t info[kMaxEnt][64], order_h[kMaxEnt][64];
-};
+// One env = one gang (pg_gang.h).  The ship's scalars are uniform over the gang.  Entity e is dealt to lane e mod kGang,
+// which keeps its position (and an enemy's velocity) in registers for the four sub-steps — the hazard test of the ship,
+// the first-hit search of a flying bullet and the enemies' own moves all run kGang entities at a time — and writes back
+// what changed.  Bullet ring slot k and particle k belong to lane k mod kGang.
+#ifndef PG_CAVEFLYER_GANG
+#define PG_CAVEFLYER_GANG 16
+#endif
+#ifndef PG_CAVEFLYER_WAVES
+#define PG_CAVEFLYER_WAVES 4  // wavefronts per SIMD the logic kernel's registers are capped for
+#endif
+constexpr int kGang = PG_CAVEFLYER_GANG;
+constexpr int kPerLane = (kMaxEnt + kGang - 1) / kGang;    // entities a lane holds
+constexpr int kPuffsPerLane = (kPuffs + kGang - 1) / kGang;
+using Q = Gang<kGang>;
+static_assert(kGang >= 8, "six lanes share a sub-step's trigonometry");
 
-PG_D Box thing_box(const StepLds& L, int lane, int e, int kind) {
-    const float x = L.x[e][lane], y = L.y[e][lane];
-    if (kind == kEnemy || kind == kGoal) return Box{x + -0.4f, y + -0.4f, 0.8f, 0.8f};
-    return Box{x + -0.25f, y + -0.25f, 0.5f, 0.5f};
+PG_D bool hit(const Box& a, const Box& b) {  // box_hit without short circuits
+    return (a.x < b.x + b.w) & (a.x + a.w > b.x) & (a.y < b.y + b.h) & (a.y + a.h > b.y);
+}
+template <class T, int N>
+PG_D T pick(const T (&table)[N], int t) {  // table[t] of a table that lives in registers
+    T v = table[0];
+#pragma unroll
+    for (int u = 1; u < N; u++) v = t == u ? table[u] : v;
+    return v;
+}
+PG_D Box thing_box(float x, float y, int kind) {
+    const bool big = (kind == kEnemy) | (kind == kGoal);
+    const float half = big ? -0.4f : -0.25f, size = big ? 0.8f : 0.5f;
+    return Box{x + half, y + half, size, size};
 }
 
 // System_Sprite_Render::update's list: the surviving sprites in set order, then std::sort on z (all 1.0).
@@ -338,35 +369,31 @@ PG_D void rebuild_draw_list(const State& s, int env, int n_ent) {
     SI(s, I_NDRAW, env) = n;
 }
 
-// Every lane of the wave goes in (the staging loop is wave-wide); `active` = this lane's env takes a step.
-PG_D void advance(const State& s, StepLds& L, int lane, bool active, int env, int action, float& reward_out,
-                  bool& terminated_out) {
-    const int n_ent = active ? SI(s, I_NENT, env) : 0;
-    for (int e0 = 0; __ballot(e0 < n_ent); e0 += 4) {
-        int info[4], order[4];
-        float x[4], y[4];
+PG_D void advance(const State& s, Q q, int env, const uint64_t* cols, int action, float& reward_out, bool& terminated_out) {
+    const int n_ent = SI(s, I_NENT, env);
+    // my entities: e = g + kGang·t
+    float ex[kPerLane], ey[kPerLane], evx[kPerLane], evy[kPerLane];
+    int einfo[kPerLane], eplace[kPerLane];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int e = e0 + k;
-            const bool ok = e < n_ent;
-            info[k] = ok ? EB(s, EB_INFO, e, env) : 0;
-            order[k] = (ok && e < n_ent - 2) ? EB(s, EB_ORDER_H, e, env) : 0;
-            x[k] = ok ? EF(s, EF_X, e, env) : 0.0f;
-            y[k] = ok ? EF(s, EF_Y, e, env) : 0.0f;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int e = e0 + k;
-            if (e < n_ent) {
-                L.info[e][lane] = static_cast<uint8_t>(info[k]);
-                L.order_h[e][lane] = static_cast<uint8_t>(order[k]);
-                L.x[e][lane] = x[k];
-                L.y[e][lane] = y[k];
-            }
-        }
+    for (int t = 0; t < kPerLane; t++) {
+        const int e = q.g + kGang * t;
+        const bool ok = e < n_ent;
+        einfo[t] = ok ? EB(s, EB_INFO, e, env) : 0;
+        eplace[t] = (ok && e >= 2) ? EB(s, EB_PLACE_H, e, env) : 0;
+        ex[t] = ok ? EF(s, EF_X, e, env) : 0.0f;
+        ey[t] = ok ? EF(s, EF_Y, e, env) : 0.0f;
+        evx[t] = ok ? EF(s, EF_VX, e, env) : 0.0f;
+        evy[t] = ok ? EF(s, EF_VY, e, env) : 0.0f;
+        if (e < 2) einfo[t] = 0;  // the goal and the ship are not in the hazard set
     }
-    if (!active) return;
-    const uint8_t* tiles = s.tiles + size_t(env) * kTileStride;
+    const float goal_x = EF(s, EF_X, 0, env), goal_y = EF(s, EF_Y, 0, env);
+    const int first_enemy = 2 + 2 * ((n_ent - 2) / 3);  // meteors, targets, enemies: a third of the objects each
+    float puff_life[kPuffsPerLane];
+#pragma unroll
+    for (int p = 0; p < kPuffsPerLane; p++) {
+        const int k = q.g + kGang * p;
+        puff_life[p] = k < kPuffs ? PF(s, PF_LIFE, k, env) : 1.0f;
+    }
     const int flags = SI(s, I_FLAGS, env);
     float ax = SF(s, F_AX, env), ay = SF(s, F_AY, env), avx = SF(s, F_AVX, env), avy = SF(s, F_AVY, env);
     float rot = SF(s, F_ROT, env), s_timer = SF(s, F_STIMER, env), p_timer = SF(s, F_PTIMER, env);
@@ -386,22 +413,46 @@ PG_D void advance(const State& s, StepLds& L, int lane, bool active, int env, in
 
     float reward = 0.0f;
     bool terminated = false;
+    int ship_sn = 0, ship_cs = 0;
     for (int ss = 0; ss < 4; ss++) {
         // --- System_Agent::update (common_systems.cpp:90-289)
         bool alive = true, achieved_goal = false;
         int targets_destroyed = 0;
         rot += movement_x * spin_rate * dt;
-        const float dir_x = sc_cosf(rot), dir_y = sc_sinf(rot);
+        // The sub-step's trigonometry, one value per lane instead of every value in every lane: cos / sin of the ship's
+        // rotation, cos / sin of rotation + π/2 (the exhaust puff), and that angle as the raster takes it (rotation_of: a
+        // fired bullet's, a puff's and — after the last sub-step — the ship's drawing angle are all this one).
+        const float prot = static_cast<float>(rot + kPi * 0.5f);
+        float dir_x, dir_y, puff_c, puff_s;
+        int prot_sn, prot_cs;
+        {
+            const double deg = prot * 180.0f / 3.14159265358979323846;  // rotation_of / rotation_16_16 (pg_render.h)
+            const float theta = static_cast<float>(deg * (3.14159265358979323846 / 180.0));
+            const int role = q.g >> 1;
+            const float mine = sc_trig(role == 0 ? rot : (role == 1 ? prot : theta), (q.g & 1) == 0);
+            dir_x = __shfl(mine, 0, kGang);
+            dir_y = __shfl(mine, 1, kGang);
+            puff_c = __shfl(mine, 2, kGang);
+            puff_s = __shfl(mine, 3, kGang);
+            const int fixed = static_cast<int>(floor(static_cast<double>(mine) * 65536.0 + 0.5));
+            prot_cs = deg != 0.0 ? __shfl(fixed, 4, kGang) : 0;
+            prot_sn = deg != 0.0 ? __shfl(fixed, 5, kGang) : 0;
+        }
+        ship_sn = prot_sn;
+        ship_cs = prot_cs;
         if (fire) {
             if (s_timer == 0.0f && s_count < kShots) {
                 s_timer = bullet_time;
-                SH(s, SH_ROT, s_next, env) = rot;
-                store_rotation(SH(s, SH_SN, s_next, env), SH(s, SH_CS, s_next, env), static_cast<float>(rot + kPi * 0.5f));
-                SH(s, SH_VX, s_next, env) = dir_x * bullet_speed;
-                SH(s, SH_VY, s_next, env) = dir_y * bullet_speed;
-                SH(s, SH_X, s_next, env) = ax;
-                SH(s, SH_Y, s_next, env) = ay;
-                SH(s, SH_FRAME, s_next, env) = 0.0f;
+                if ((s_next & (kGang - 1)) == q.g) {
+                    SH(s, SH_ROT, s_next, env) = rot;
+                    SH(s, SH_SN, s_next, env) = __int_as_float(prot_sn);
+                    SH(s, SH_CS, s_next, env) = __int_as_float(prot_cs);
+                    SH(s, SH_VX, s_next, env) = dir_x * bullet_speed;
+                    SH(s, SH_VY, s_next, env) = dir_y * bullet_speed;
+                    SH(s, SH_X, s_next, env) = ax;
+                    SH(s, SH_Y, s_next, env) = ay;
+                    SH(s, SH_FRAME, s_next, env) = 0.0f;
+                }
                 s_next = (s_next + 1) % kShots;
                 s_count++;
             } else {
@@ -415,7 +466,7 @@ PG_D void advance(const State& s, StepLds& L, int lane, bool active, int env, in
         ay += avy * dt;
         Box body{ax + -0.4f, ay + -0.4f, 0.8f, 0.8f};
         {
-            const Win win = Win::fetch(tiles, static_cast<int>(floorf(body.x)), static_cast<int>(floorf(body.y)));
+            const BitWin win = BitWin::fetch(cols, static_cast<int>(floorf(body.x)), static_cast<int>(floorf(body.y)));
             const TileHit h = collide_plain(win, body, is_wall);
             const float moved_x = h.x - body.x, moved_y = h.y - body.y;
             ax = h.x - -0.4f;
@@ -425,123 +476,196 @@ PG_D void advance(const State& s, StepLds& L, int lane, bool active, int env, in
             if (moved_x != 0.0f) avx = 0.0f;
             if (moved_y != 0.0f) avy = 0.0f;
         }
-        for (int e = 2; e < n_ent; e++) {  // hazards: any hit kills, order-free
-            const int info = L.info[e][lane];
-            if ((info & kAlive) && box_hit(body, thing_box(L, lane, e, info & kKindMask))) alive = false;
+        {   // hazards: any hit kills, order-free
+            bool crash = false;
+#pragma unroll
+            for (int t = 0; t < kPerLane; t++)
+                crash = crash | (((einfo[t] & kAlive) != 0) & hit(body, thing_box(ex[t], ey[t], einfo[t] & kKindMask)));
+            if (q.any(crash)) alive = false;
         }
-        if (box_hit(body, thing_box(L, lane, 0, kGoal))) achieved_goal = true;
-        const float cam_x = ax * kUnitPx, cam_y = ay * kUnitPx;
+        if (hit(body, thing_box(goal_x, goal_y, kGoal))) achieved_goal = true;
 
-        for (int i = 0; i < s_count; i++) {  // bullets, newest first
-            const int k = (kShots + s_next - 1 - i) % kShots;
-            float frame = SH(s, SH_FRAME, k, env);
-            if (frame == -1.0f) continue;
-            float bx = SH(s, SH_X, k, env), by = SH(s, SH_Y, k, env);
-            float bvx = SH(s, SH_VX, k, env), bvy = SH(s, SH_VY, k, env);
-            if (frame == 0.0f) {
-                const Box sb{bx - 0.01f, by - 0.01f, 0.02f, 0.02f};
-                const Win win = Win::fetch(tiles, static_cast<int>(floorf(sb.x)), static_cast<int>(floorf(sb.y)));
-                if (collide_plain(win, sb, is_wall).any) {
-                    bvx = 0.0f;
-                    bvy = 0.0f;
-                    frame = 1.0f;
+        // The bullets, newest first (see bossfight.hip agent_update for how a trip stands in for the reference's loop
+        // with its shrinking count).  Bullets in flight are few, and each of them looks for the FIRST hazard it touches in
+        // the hazard set's iteration order, destroying it if it is a target — so they are taken one after the other,
+        // each tested against all entities at once (the winner is the touched entity with the smallest place in the order).
+        {
+            int count = s_count;
+            for (int i0 = 0; i0 < count; i0 += kGang) {
+                const Q::Trip t = q.trip<kShots, (kGang < kShots ? kGang : kShots)>(s_next, i0);
+                const int k = t.slot;
+                const bool mine = (q.g < kShots) & (t.i < count);
+                float frame = -1.0f, bx = 0.0f, by = 0.0f, bvx = 0.0f, bvy = 0.0f;
+                if (mine) {
+                    frame = SH(s, SH_FRAME, k, env);
+                    bx = SH(s, SH_X, k, env);
+                    by = SH(s, SH_Y, k, env);
+                    bvx = SH(s, SH_VX, k, env);
+                    bvy = SH(s, SH_VY, k, env);
                 }
-                for (int q = 0; q < n_ent - 2; q++) {  // first hit in the hazard set's iteration order
-                    const int e = L.order_h[q][lane];
-                    const int info = L.info[e][lane];
-                    if (!(info & kAlive)) continue;
-                    if (box_hit(sb, thing_box(L, lane, e, info & kKindMask))) {
+                const bool live = mine & (frame != -1.0f);
+                const bool gone = live & (frame >= 5.0f);  // (a bullet that hits something this sub-step is at frame 1)
+                const bool act = live & (t.i < count - Q::before(q.ranked<(kGang < kShots ? kGang : kShots)>(t, gone), t.rank));
+                const bool flying = act & (frame == 0.0f);
+                uint32_t flying_list = q.ranked<(kGang < kShots ? kGang : kShots)>(t, flying);
+                if (flying_list) {
+                    const Box sb{bx - 0.01f, by - 0.01f, 0.02f, 0.02f};
+                    bool stops = false;
+                    if (flying) {
+                        const BitWin win = BitWin::fetch(cols, static_cast<int>(floorf(sb.x)), static_cast<int>(floorf(sb.y)));
+                        stops = collide_any(win, sb, is_wall);
+                    }
+                    while (flying_list) {
+                        const int rank = __ffs(flying_list) - 1;
+                        flying_list &= flying_list - 1;
+                        const int from = ((kGang < kShots ? kGang : kShots) - 1 - t.turn - rank) & ((kGang < kShots ? kGang : kShots) - 1);  // the lane of that rank
+                        const Box other{__shfl(sb.x, from, kGang), __shfl(sb.y, from, kGang), 0.02f, 0.02f};
+                        // key = place in the hazard order · 1024 + entity · 4 + kind; the smallest touched one wins
+                        int best = 0x7fffffff;
+#pragma unroll
+                        for (int u = 0; u < kPerLane; u++) {
+                            const int kind = einfo[u] & kKindMask;
+                            const bool touched = ((einfo[u] & kAlive) != 0) & hit(other, thing_box(ex[u], ey[u], kind));
+                            const int key = (eplace[u] << 10) | ((q.g + kGang * u) << 2) | kind;
+                            best = (touched & (key < best)) ? key : best;
+                        }
+#pragma unroll
+                        for (int w = 1; w < kGang; w <<= 1) {
+                            const int o = __shfl_xor(best, w, kGang);
+                            best = o < best ? o : best;
+                        }
+                        if (best != 0x7fffffff) {
+                            if (q.g == from) stops = true;
+                            if ((best & 3) == kTarget) {  // destroy_entity
+                                const int e = (best >> 2) & 255;
+#pragma unroll
+                                for (int u = 0; u < kPerLane; u++)
+                                    if (q.g + kGang * u == e) {
+                                        einfo[u] &= ~kAlive;
+                                        EB(s, EB_INFO, e, env) = static_cast<uint8_t>(einfo[u]);
+                                    }
+                                set_changed = true;
+                                targets_destroyed++;
+                            }
+                        }
+                    }
+                    if (stops) {
                         bvx = 0.0f;
                         bvy = 0.0f;
                         frame = 1.0f;
-                        if ((info & kKindMask) == kTarget) {
-                            L.info[e][lane] = static_cast<uint8_t>(info & ~kAlive);  // destroy_entity
-                            EB(s, EB_INFO, e, env) = static_cast<uint8_t>(info & ~kAlive);
-                            set_changed = true;
-                            targets_destroyed++;
-                        }
-                        break;
                     }
                 }
+                bx += bvx * dt;
+                by += bvy * dt;
+                frame = gone ? -1.0f : (frame >= 1.0f ? frame + explosion_rate * dt : frame);
+                if (act) {
+                    SH(s, SH_X, k, env) = bx;
+                    SH(s, SH_Y, k, env) = by;
+                    SH(s, SH_VX, k, env) = bvx;
+                    SH(s, SH_VY, k, env) = bvy;
+                    SH(s, SH_FRAME, k, env) = frame;
+                }
+                count -= __popc(q.ballot(gone & act));
             }
-            bx += bvx * dt;
-            by += bvy * dt;
-            if (frame >= 5.0f) {
-                s_count--;
-                frame = -1.0f;
-            } else if (frame >= 1.0f) {
-                frame += explosion_rate * dt;
-            }
-            SH(s, SH_X, k, env) = bx;
-            SH(s, SH_Y, k, env) = by;
-            SH(s, SH_VX, k, env) = bvx;
-            SH(s, SH_VY, k, env) = bvy;
-            SH(s, SH_FRAME, k, env) = frame;
+            s_count = count;
         }
         puff_on = movement_y > 0.0f;
 
-        // --- System_Mob_AI::update (common_systems.cpp:50-75)
-        for (int e = 2; e < n_ent; e++) {
-            const int info = L.info[e][lane];
-            if ((info & kKindMask) != kEnemy) continue;
-            float vx = EF(s, EF_VX, e, env), vy = EF(s, EF_VY, e, env);
-            const float x = L.x[e][lane] + vx * dt, y = L.y[e][lane] + vy * dt;
-            const Box box{x + -0.4f, y + -0.4f, 0.8f, 0.8f};
-            const Win win = Win::fetch(tiles, static_cast<int>(floorf(box.x)), static_cast<int>(floorf(box.y)));
-            if (collide_plain(win, box, is_wall).any) {
-                vx = -vx;
-                vy = -vy;
+        // --- System_Mob_AI::update (common_systems.cpp:50-75).  The enemies are the last third of the objects
+        // (tilemap.cpp:232-272: ids first_enemy .. n_ent-1), so consecutive lanes hold consecutive enemies: a pass moves
+        // kGang of them, each lane picking the one of its slots that holds its enemy.
+        for (int e0 = first_enemy; e0 < n_ent; e0 += kGang) {
+            const int e = e0 + ((q.g - e0) & (kGang - 1));  // the id in [e0, e0 + kGang) that is mine
+            const bool enemy = e < n_ent;
+            const int t = e / kGang;
+            float vx = pick(evx, t), vy = pick(evy, t);
+            const float x = pick(ex, t) + vx * dt, y = pick(ey, t) + vy * dt;
+            bool bump = false;
+            if (enemy) {
+                const Box box{x + -0.4f, y + -0.4f, 0.8f, 0.8f};
+                const BitWin win = BitWin::fetch(cols, static_cast<int>(floorf(box.x)), static_cast<int>(floorf(box.y)));
+                bump = collide_any(win, box, is_wall);
             }
-            L.x[e][lane] = x;
-            L.y[e][lane] = y;
-            EF(s, EF_X, e, env) = x;
-            EF(s, EF_Y, e, env) = y;
-            EF(s, EF_VX, e, env) = vx;
-            EF(s, EF_VY, e, env) = vy;
+            vx = bump ? -vx : vx;
+            vy = bump ? -vy : vy;
+#pragma unroll
+            for (int u = 0; u < kPerLane; u++) {
+                const bool here = enemy & (u == t);
+                ex[u] = here ? x : ex[u];
+                ey[u] = here ? y : ey[u];
+                evx[u] = here ? vx : evx[u];
+                evy[u] = here ? vy : evy[u];
+            }
         }
 
         // --- System_Particles::update (common_systems.cpp:333-372)
         {
             const float lifespan = 3.0f, spawn_time = 0.3f, off_x = 0.0f, off_y = 0.3f;
             int dead_index = -1;
-            for (int k = 0; k < kPuffs; k++) {
-                const float life = PF(s, PF_LIFE, k, env) - dt;
-                PF(s, PF_LIFE, k, env) = life;
-                if (life <= 0.0f) dead_index = k;
+#pragma unroll
+            for (int p = 0; p < kPuffsPerLane; p++) {
+                const int k = q.g + kGang * p;
+                puff_life[p] -= dt;
+                const uint32_t dead = q.ballot((k < kPuffs) & (puff_life[p] <= 0.0f));
+                if (dead) dead_index = kGang * p + 31 - __clz(dead);
             }
             p_timer += dt;
             if (dead_index != -1 && p_timer >= spawn_time && puff_on) {
                 p_timer = fmodf(p_timer, spawn_time);
-                const float prot = static_cast<float>(rot + kPi * 0.5f);
-                const float c = sc_cosf(prot), sn = sc_sinf(prot);
-                PF(s, PF_LIFE, dead_index, env) = lifespan;
-                PF(s, PF_ROT, dead_index, env) = prot;
-                store_rotation(PF(s, PF_SN, dead_index, env), PF(s, PF_CS, dead_index, env), prot);
-                PF(s, PF_DX, dead_index, env) = -sc_cosf(rot);
-                PF(s, PF_DY, dead_index, env) = -sc_sinf(rot);
-                PF(s, PF_X, dead_index, env) = ax + (c * off_x - sn * off_y);
-                PF(s, PF_Y, dead_index, env) = ay + (sn * off_x + c * off_y);
+                const float c = puff_c, sn = puff_s;
+#pragma unroll
+                for (int p = 0; p < kPuffsPerLane; p++)
+                    if (q.g + kGang * p == dead_index) {
+                        puff_life[p] = lifespan;
+                        PF(s, PF_ROT, dead_index, env) = prot;
+                        PF(s, PF_SN, dead_index, env) = __int_as_float(prot_sn);
+                        PF(s, PF_CS, dead_index, env) = __int_as_float(prot_cs);
+                        PF(s, PF_DX, dead_index, env) = -dir_x;
+                        PF(s, PF_DY, dead_index, env) = -dir_y;
+                        PF(s, PF_X, dead_index, env) = ax + (c * off_x - sn * off_y);
+                        PF(s, PF_Y, dead_index, env) = ay + (sn * off_x + c * off_y);
+                    }
             }
         }
-        SF(s, F_CAMX, env) = cam_x;
-        SF(s, F_CAMY, env) = cam_y;
 
         reward = achieved_goal * 10.0f + targets_destroyed * 3.0f;
         terminated = !alive || achieved_goal;
         if (terminated) break;
     }
-    SF(s, F_AX, env) = ax;
-    SF(s, F_AY, env) = ay;
-    SF(s, F_AVX, env) = avx;
-    SF(s, F_AVY, env) = avy;
-    SF(s, F_ROT, env) = rot;
-    store_rotation(SF(s, F_SHIP_SN, env), SF(s, F_SHIP_CS, env), static_cast<float>(rot + kPi * 0.5f));
-    SF(s, F_STIMER, env) = s_timer;
-    SF(s, F_PTIMER, env) = p_timer;
-    SI(s, I_SNEXT, env) = s_next;
-    SI(s, I_SCOUNT, env) = s_count;
-    SI(s, I_FLAGS, env) = kFlagListed | (puff_on ? kFlagPuffOn : 0);
-    if (set_changed) rebuild_draw_list(s, env, n_ent);
+    // what the sub-steps changed, back to memory: the enemies, the particles' lives, the scalars
+#pragma unroll
+    for (int t = 0; t < kPerLane; t++) {
+        const int e = q.g + kGang * t;
+        if ((einfo[t] & kKindMask) == kEnemy && e >= 2 && e < n_ent) {
+            EF(s, EF_X, e, env) = ex[t];
+            EF(s, EF_Y, e, env) = ey[t];
+            EF(s, EF_VX, e, env) = evx[t];
+            EF(s, EF_VY, e, env) = evy[t];
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < kPuffsPerLane; p++) {
+        const int k = q.g + kGang * p;
+        if (k < kPuffs) PF(s, PF_LIFE, k, env) = puff_life[p];
+    }
+    if (set_changed) gang_fence();  // the destroyed targets' info bytes, for the lane that rebuilds the list
+    if (q.g == 0) {
+        SF(s, F_CAMX, env) = ax * kUnitPx;
+        SF(s, F_CAMY, env) = ay * kUnitPx;
+        SF(s, F_AX, env) = ax;
+        SF(s, F_AY, env) = ay;
+        SF(s, F_AVX, env) = avx;
+        SF(s, F_AVY, env) = avy;
+        SF(s, F_ROT, env) = rot;
+        SF(s, F_SHIP_SN, env) = __int_as_float(ship_sn);
+        SF(s, F_SHIP_CS, env) = __int_as_float(ship_cs);
+        SF(s, F_STIMER, env) = s_timer;
+        SF(s, F_PTIMER, env) = p_timer;
+        SI(s, I_SNEXT, env) = s_next;
+        SI(s, I_SCOUNT, env) = s_count;
+        SI(s, I_FLAGS, env) = kFlagListed | (puff_on ? kFlagPuffOn : 0);
+        if (set_changed) rebuild_draw_list(s, env, n_ent);
+    }
     reward_out = reward;
     terminated_out = terminated;
 }
@@ -584,26 +708,29 @@ struct Gen {  // pg_prefetch.h level_kernel<Gen>
     PG_D static void fresh_live(const State& s, int env) { caveflyer::fresh_live(s, env); }
 };
 
-__global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actions, uint32_t run_seed,
-                                                   uint32_t step_index, int env_offset, StepIO io) {
-    __shared__ StepLds L;
-    const int lane = threadIdx.x;
-    const int env = blockIdx.x * 64 + lane;
-    bool active = env < s.n;
-    if (active && io.pending[env] == 2) {  // reset by the level kernel in this step
-        io.pending[env] = 0;
-        active = false;
+__global__ void __launch_bounds__(64, PG_CAVEFLYER_WAVES) logic_kernel(State s, const int32_t* actions, uint32_t run_seed,
+                                                                       uint32_t step_index, int env_offset, StepIO io) {
+    const int env = (blockIdx.x * 64 + threadIdx.x) / kGang;
+    if (env >= s.n) return;
+    const Q q = Q::at(threadIdx.x);
+    if (io.pending[env] == 2) {  // reset by the level kernel in this step
+        if (q.g == 0) io.pending[env] = 0;
+        return;
     }
-    const int action = !active ? 0
-                       : actions ? actions[env]
-                                 : synthetic_action(run_seed, step_index, static_cast<uint32_t>(env_offset + env));
+    __shared__ uint64_t wall_cols[64 / kGang][W];  // the env's map as wall bits (320 bytes): every tile window of the step comes from here
+    uint64_t* cols = wall_cols[(threadIdx.x & 63) / kGang];
+    for (int x = q.g; x < W; x += kGang) cols[x] = s.cols[size_t(env) * W + x];
+    wave_order();
+    const int action =
+        actions ? actions[env] : synthetic_action(run_seed, step_index, static_cast<uint32_t>(env_offset + env));
     float reward = 0.0f;
     bool terminated = false;
-    advance(s, L, lane, active, env, action, reward, terminated);
-    if (!active) return;
-    io.reward[env] = reward;
-    io.done[env] = terminated ? 1 : 0;
-    io.pending[env] = terminated ? 1 : 0;
+    advance(s, q, env, cols, action, reward, terminated);
+    if (q.g == 0) {
+        io.reward[env] = reward;
+        io.done[env] = terminated ? 1 : 0;
+        io.pending[env] = terminated ? 1 : 0;
+    }
 }
 
 
@@ -913,7 +1040,7 @@ class CaveflyerGame final : public Game {
     }
     static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
     struct Layout {
-        size_t shadow, slot, mt, tiles, f, i, ef, eb, sh, pf, total;
+        size_t shadow, slot, mt, tiles, cols, f, i, ef, eb, sh, pf, total;
     };
     static Layout layout(int n) {
         Layout l{};
@@ -927,12 +1054,13 @@ class CaveflyerGame final : public Game {
         l.slot = take(size_t(n) * 4);
         l.mt = take(size_t(n) * kMtWords * 4);
         l.tiles = take(size_t(n) * kTileStride);
+        l.cols = take(size_t(n) * W * 8);
         l.f = take(size_t(F_COUNT) * n * 4);
         l.i = take(size_t(I_COUNT) * n * 4);
-        l.ef = take(size_t(EF_COUNT) * kMaxEnt * n * 4);
-        l.eb = take(size_t(EB_COUNT) * kMaxEnt * n);
+        l.ef = take(size_t(EF_COUNT) * kEntStride * n * 4);
+        l.eb = take(size_t(EB_COUNT) * kEntStride * n);
         l.sh = take(size_t(SH_COUNT) * kShots * n * 4);
-        l.pf = take(size_t(PF_COUNT) * kPuffs * n * 4);
+        l.pf = take(size_t(PF_COUNT) * kPuffSlots * n * 4);
         l.total = off;
         return l;
     }
@@ -945,6 +1073,7 @@ class CaveflyerGame final : public Game {
         s_.slot = reinterpret_cast<int32_t*>(p + l.slot);
         s_.mt = reinterpret_cast<uint32_t*>(p + l.mt);
         s_.tiles = p + l.tiles;
+        s_.cols = reinterpret_cast<uint64_t*>(p + l.cols);
         s_.f = reinterpret_cast<float*>(p + l.f);
         s_.i = reinterpret_cast<int32_t*>(p + l.i);
         s_.ef = reinterpret_cast<float*>(p + l.ef);
@@ -971,7 +1100,7 @@ class CaveflyerGame final : public Game {
     void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
                       StepIO io) override {
         LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io, plan);
-        hipLaunchKernelGGL(logic_kernel, dim3((s_.n + 63) / 64), dim3(64), 0, st, s_, actions, run_seed, step_index,
+        hipLaunchKernelGGL(logic_kernel, dim3((s_.n * kGang + 63) / 64), dim3(64), 0, st, s_, actions, run_seed, step_index,
                            env_offset, io);
     }
     bool launch_frame(hipStream_t st, int env, uint32_t* d_px, int w, int h) override {
@@ -1002,14 +1131,14 @@ class CaveflyerGame final : public Game {
                                 static_cast<float>(ri(I_SCOUNT)), f(F_STIMER), f(F_PTIMER),
                                 (flags & kFlagPuffOn) ? 1.0f : 0.0f, static_cast<float>(n_ent)};
         for (int k = 0; k < kShots; k++)
-            for (int fld : {SH_X, SH_Y, SH_FRAME}) v.push_back(rf(s_.sh, (size_t(fld) * kShots + k) * n + env));
+            for (int fld : {SH_X, SH_Y, SH_FRAME}) v.push_back(rf(s_.sh, (size_t(env) * SH_COUNT + fld) * kShots + k));
         for (int k = 0; k < kPuffs; k++)
-            for (int fld : {PF_X, PF_Y, PF_LIFE}) v.push_back(rf(s_.pf, (size_t(fld) * kPuffs + k) * n + env));
+            for (int fld : {PF_X, PF_Y, PF_LIFE}) v.push_back(rf(s_.pf, (size_t(env) * PF_COUNT + fld) * kPuffSlots + k));
         for (int e = 0; e < n_ent; e++) {
             if (e == 1) continue;
             uint8_t info;
-            hipMemcpy(&info, s_.eb + (size_t(EB_INFO) * kMaxEnt + e) * n + env, 1, hipMemcpyDeviceToHost);
-            auto ef = [&](int field) { return rf(s_.ef, (size_t(field) * kMaxEnt + e) * n + env); };
+            hipMemcpy(&info, s_.eb + (size_t(env) * EB_COUNT + EB_INFO) * kEntStride + e, 1, hipMemcpyDeviceToHost);
+            auto ef = [&](int field) { return rf(s_.ef, (size_t(env) * EF_COUNT + field) * kEntStride + e); };
             v.push_back((info & kAlive) ? 1.0f : 0.0f);
             v.push_back(static_cast<float>(info & kKindMask));
             v.push_back(ef(EF_X));

@@ -78,8 +78,21 @@ struct GangRng {
     uint32_t* x;
     int idx;
     Gang<G> q;
+    // The next G words of the stream, one per lane (lane g: word win0 + g), fetched together: a step's handful of
+    // uniform draws are lane-to-lane reads instead of a dependent round trip to memory each.
+    uint32_t win;
+    int win0;
 
-    PG_D static GangRng open(uint32_t* words, Gang<G> gang) { return GangRng{words, static_cast<int>(words[kMtN]), gang}; }
+    PG_D void fetch_window() {
+        win0 = idx;
+        const int at = idx + q.g;
+        win = x[at < kMtN ? at : kMtN - 1];
+    }
+    PG_D static GangRng open(uint32_t* words, Gang<G> gang) {
+        GangRng r{words, static_cast<int>(words[kMtN]), gang, 0u, 0};
+        r.fetch_window();
+        return r;
+    }
     PG_D void close() const {
         if (q.g == 0) x[kMtN] = static_cast<uint32_t>(idx);
     }
@@ -114,8 +127,12 @@ struct GangRng {
         if (idx >= kMtN) {
             twist();
             idx = 0;
+            fetch_window();
         }
-        return mt_temper(x[idx++]);
+        if (idx - win0 >= G) fetch_window();
+        const uint32_t w = static_cast<uint32_t>(__shfl(static_cast<int>(win), idx - win0, G));
+        idx++;
+        return mt_temper(w);
     }
     PG_D float canonical() { return canonical_of(next()); }
     PG_D float real(float a, float b) { return canonical() * (b - a) + a; }  // = rng_real
@@ -142,6 +159,7 @@ struct GangRng {
             twist();
             if (want && at >= kMtN) w = x[at - kMtN];
             idx += total - kMtN;
+            fetch_window();
         } else {
             idx += total;
         }

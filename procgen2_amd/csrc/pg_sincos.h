@@ -131,4 +131,31 @@ PG_HD float sc_cosf(float y) {
     return sc_poly(r * s, r * r, (q & 2) != 0, n ^ 1);
 }
 
+// sc_cosf(y) or sc_sinf(y), picked per call: the same code as above with the one point where they differ (which
+// polynomial the parity selects) made an argument — so the lanes of a wavefront can evaluate different functions of
+// different angles side by side (pg_gang.h gangs deal the trigonometry of an env out over their lanes).
+PG_HD float sc_trig(float y, bool want_cos) {
+    const double x = y;
+    const uint32_t top = (sc_bits(y) >> 20) & 0x7ff;
+    const int flip = want_cos ? 1 : 0;
+    if (top < 0x3f4) {
+        if (top < 0x398) return want_cos ? 1.0f : y;
+        return sc_poly(x, x * x, false, flip);
+    }
+    int n, q;
+    double r;
+    if (top < 0x42f) {
+        r = sc_reduce_fast(x, n);
+        q = n;
+    } else if (top < 0x7f8) {
+        const uint32_t xi = sc_bits(y);
+        r = sc_reduce_large(xi, n);
+        q = n + static_cast<int>(xi >> 31);
+    } else {
+        return y - y;
+    }
+    const double s = ((q & 3) == 0 || (q & 3) == 3) ? 1.0 : -1.0;
+    return sc_poly(r * s, r * r, (q & 2) != 0, n ^ flip);
+}
+
 }  // namespace pg

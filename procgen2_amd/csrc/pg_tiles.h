@@ -42,9 +42,10 @@ struct TileWinT {
         for (int k = 0; k < 16; k++) w.bits |= static_cast<uint64_t>(inside[k] ? (t[k] & 7) : OOB) << (3 * k);
         return w;
     }
+    PG_D int cell(int dx, int dy) const { return static_cast<int>((bits >> (3 * (dx + 4 * dy))) & 7u); }  // inside the window
     PG_D int at(int x, int y) const {
         const unsigned dx = static_cast<unsigned>(x - ax), dy = static_cast<unsigned>(y - ay);
-        if (dx < 4u && dy < 4u) return static_cast<int>((bits >> (3 * (dx + 4 * dy))) & 7u);
+        if (dx < 4u && dy < 4u) return cell(static_cast<int>(dx), static_cast<int>(dy));
         return direct(tiles, x, y);
     }
     // Does the window hold every tile collide_plain() scans for box r (floor(x)..ceil(x+w) × floor(y)..ceil(y+h))?
@@ -57,6 +58,42 @@ struct TileWinT {
     PG_D static TileWinT around(const uint8_t* tiles, const Box& r, float dir_x, float dir_y) {
         const int x0 = static_cast<int>(floorf(r.x)), y0 = static_cast<int>(floorf(r.y));
         return fetch(tiles, x0 - (dir_x < 0.0f ? 1 : 0), y0 - (dir_y < 0.0f ? 1 : 0));
+    }
+};
+
+// The same window for a map that only has walls and empty cells, from one 64-bit word per map column: bit y (collide()
+// coordinates) = wall at (x, y), bits from H up set (above the map is wall), and out of the map sideways or below is wall
+// too (OOB).  Four words instead of sixteen bytes, and a logic kernel can hold the whole map of an env in 8·W bytes of LDS.
+template <int W, int H, int WALL, int EMPTY>
+struct BitWinT {
+    static_assert(H + 8 <= 60, "column words keep their top bits for the rows above the map");
+    const uint64_t* cols;  // [W]
+    int ax, ay;
+    uint32_t bits;  // bit 4·dx + dy
+
+    PG_D static uint32_t rows4(uint64_t word, int y) {  // the wall bits of rows y..y+3 of a column
+        const int at = y < -4 ? -4 : (y > 56 ? 56 : y);
+        return static_cast<uint32_t>((((word << 4) | 0xfull) >> (at + 4)) & 15ull);
+    }
+    PG_D static BitWinT fetch(const uint64_t* cols, int ax, int ay) {
+        BitWinT w{cols, ax, ay, 0u};
+        uint64_t word[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int x = ax + k;
+            word[k] = cols[(x < 0 || x >= W) ? 0 : x];
+            if (x < 0 || x >= W) word[k] = ~0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) w.bits |= rows4(word[k], ay) << (4 * k);
+        return w;
+    }
+    PG_D int cell(int dx, int dy) const { return ((bits >> (4 * dx + dy)) & 1u) ? WALL : EMPTY; }
+    PG_D int at(int x, int y) const {
+        const unsigned dx = static_cast<unsigned>(x - ax), dy = static_cast<unsigned>(y - ay);
+        if (dx < 4u && dy < 4u) return cell(static_cast<int>(dx), static_cast<int>(dy));
+        if (x < 0 || x >= W) return WALL;
+        return (rows4(cols[x], y) & 1u) ? WALL : EMPTY;
     }
 };
 
@@ -75,6 +112,49 @@ PG_D Box box_overlap_flat(const Box& a, const Box& b) {
     w = w >= wcap ? wcap : w;
     h = h >= hcap ? hcap : h;
     return Box{hit ? (left ? b.x : a.x) : 0.0f, hit ? (top ? b.y : a.y) : 0.0f, hit ? w : 0.0f, hit ? h : 0.0f};
+}
+
+// collide_plain(win, r, solid).any alone, for callers that only ask whether the box touches something (a bullet, an
+// enemy that turns round): `any` is set by the first solid cell whose overlap with the box is not 0×0, and until then
+// the box has not moved — so it is "some solid cell of the scan has a non-empty overlap with r", and get_collision_overlap
+// is separable: hit = hit_x ∧ hit_y, its width a function of the x axis and its height of the y axis alone.  Three
+// columns and three rows are evaluated with box_overlap's own arithmetic, the nine cells are bit tests.  The box must
+// be at most a cell wide and tall (scan of at most 3×3) and the window placed at (floor(r.x), floor(r.y)).
+struct AxisTouch {
+    uint32_t hit, zero;  // bit k: the box overlaps cell k of this axis; the overlap's extent is 0
+};
+PG_D AxisTouch axis_touch(float a, float aw, int c0, int c1) {  // cells c0..c1 (≤ c0+2), each [c, c+1)
+    AxisTouch t{0u, 0u};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float b = static_cast<float>(c0 + k), bw = 1.0f;
+        const bool in = c0 + k <= c1;
+        const bool hit = (a < b + bw) & (a + aw > b);
+        const float dd = fabsf(a - b);
+        float w = (a <= b ? aw : bw) - dd;
+        const float cap = aw > bw ? bw : aw;
+        w = w >= cap ? cap : w;
+        t.hit |= (in & hit) ? 1u << k : 0u;
+        t.zero |= (w == 0.0f) ? 1u << k : 0u;
+    }
+    return t;
+}
+template <class Win, class Pred>
+PG_D bool collide_any(const Win& win, const Box& r, Pred solid) {
+    const int x0 = static_cast<int>(floorf(r.x)), y0 = static_cast<int>(floorf(r.y));
+    const int x1 = static_cast<int>(ceilf(r.x + r.w)), y1 = static_cast<int>(ceilf(r.y + r.h));
+    const AxisTouch tx = axis_touch(r.x, r.w, x0, x1), ty = axis_touch(r.y, r.h, y0, y1);
+    const int wx = x0 - win.ax, wy = y0 - win.ay;
+    bool any = false;
+#pragma unroll
+    for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++) {
+            const bool touch = ((tx.hit >> dx) & (ty.hit >> dy) & 1u) != 0;           // box_hit (and the cell is scanned)
+            const bool empty = ((tx.zero >> dx) & (ty.zero >> dy) & 1u) != 0;         // o.w == 0 && o.h == 0
+            any = any | (touch & !empty & solid(win.cell((wx + dx) & 3, (wy + dy) & 3)));
+        }
+    return any;
 }
 
 // kFlat: see below — pays where boxes are a tile in size (climber −2 %), not where they are bullets (caveflyer +2 %).
@@ -97,7 +177,7 @@ PG_D TileHit collide_plain(const Win& win, Box r, Pred solid) {
             for (int dx = 0; dx < 3; dx++) {
                 const bool in = (x0 + dx <= x1) & (y0 + dy <= y1);
                 const int ox_ = in ? dx : 0, oy_ = in ? dy : 0;  // (a cell past the box: look at the first one, ignore it)
-                const bool is_solid = solid(static_cast<int>((win.bits >> (3 * ((wx + ox_) + 4 * (wy + oy_)))) & 7u));
+                const bool is_solid = solid(win.cell(wx + ox_, wy + oy_));
                 cell.x = static_cast<float>(x0 + ox_);
                 cell.y = static_cast<float>(y0 + oy_);
                 const Box o = box_overlap_flat(r, cell);
@@ -111,7 +191,7 @@ PG_D TileHit collide_plain(const Win& win, Box r, Pred solid) {
             for (int dx = 0; dx < 3; dx++) {
                 const bool in = (x0 + dx <= x1) & (y0 + dy <= y1);
                 const int ox_ = in ? dx : 0, oy_ = in ? dy : 0;
-                const bool is_solid = solid(static_cast<int>((win.bits >> (3 * ((wx + ox_) + 4 * (wy + oy_)))) & 7u));
+                const bool is_solid = solid(win.cell(wx + ox_, wy + oy_));
                 cell.x = static_cast<float>(x0 + ox_);
                 cell.y = static_cast<float>(y0 + oy_);
                 const Box o = box_overlap_flat(r, cell);
