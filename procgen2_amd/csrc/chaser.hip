@@ -18,6 +18,7 @@
 #include "../../include/procgen2_vec.h"
 #include "pg_engine.h"
 #include "pg_frame.h"
+#include "pg_gang.h"
 #include "pg_geom.h"
 #include "pg_kruskal.h"
 #include "pg_order.h"
@@ -101,7 +102,7 @@ struct State {
     int32_t* i;      // [I_COUNT][n]
     float* mf;       // [MF_COUNT][kMobs][n]
     uint8_t* mb;     // [2][kMobs][n]   texture index (0 egg, 1-3 flying, 4 walking), iteration order of the enemy set
-    uint8_t* eb;     // [EB_COUNT][kMaxEnt][n]
+    uint8_t* eb;     // [n][EB_COUNT][kMaxEnt]  per-env contiguous: a gang's and the render wavefronts' lanes index it by entity
     const uint8_t* ranks;  // pg_order.h equal-key sort ranks
     int float_abs;         // game_flags PGV_CHASER_FLOAT_ABS: which `abs` the reference's abs(<float>) calls are (D21)
 };
@@ -110,7 +111,7 @@ PG_D float& SF(const State& s, int field, int env) { return s.f[size_t(field) * 
 PG_D int32_t& SI(const State& s, int field, int env) { return s.i[size_t(field) * s.n + env]; }
 PG_D float& MF(const State& s, int field, int m, int env) { return s.mf[(size_t(field) * kMobs + m) * s.n + env]; }
 PG_D uint8_t& MB(const State& s, int field, int m, int env) { return s.mb[(size_t(field) * kMobs + m) * s.n + env]; }
-PG_D uint8_t& EB(const State& s, int field, int e, int env) { return s.eb[(size_t(field) * kMaxEnt + e) * s.n + env]; }
+PG_D uint8_t& EB(const State& s, int field, int e, int env) { return s.eb[(size_t(env) * EB_COUNT + field) * kMaxEnt + e]; }
 PG_D int ent_cell(const State& s, int e, int env) {
     int c = EB(s, EB_CELL, e, env);
     if (kWideCells) c |= EB(s, EB_CELL_HI, e, env) << 8;
@@ -340,62 +341,97 @@ struct Gen {  // pg_prefetch.h level_kernel<Gen>
     PG_D static void fresh_live(const State& s, int env) { chaser::fresh_live(s, env); }
 };
 
-// The entity table of the 64 envs of a logic wavefront, staged in LDS for the step ([entity][lane]).  A step visits
-// every orb and point four times (sub-steps) and the draw list is rebuilt whenever one is eaten — from global memory
-// ~950 dependent loads per wave (SQ_INSTS_VMEM_RD) on a wave with nothing to hide them behind: 0.35 ms.  Staged once
-// (eight entities at a time, all loads in flight) the loops run from LDS; the state in global memory is written through.
-struct StepLds {
-    uint8_t info[kMaxEnt][64];
-    uint16_t cell[kMaxEnt][64];
-    uint8_t order[kMaxEnt][64];
+// One env = one gang of kGang adjacent lanes (pg_gang.h).  The agent and the enemies — three to five of them, visited in
+// the enemy set's order because their junction choices draw from the env's stream one after the other — are uniform
+// over the gang; the orbs and points (up to 198 of them), each tested against the agent every sub-step, are dealt out
+// over the lanes: entity e belongs to lane e mod kGang.  The env's tiles and entity table are staged in LDS once a step.
+#ifndef PG_CHASER_GANG
+#define PG_CHASER_GANG 8
+#endif
+#ifndef PG_CHASER_WAVES
+#define PG_CHASER_WAVES 4  // wavefronts per SIMD the logic kernel's registers are capped for
+#endif
+constexpr int kGang = PG_CHASER_GANG;
+using Q = Gang<kGang>;
+using Rng = GangRng<kGang>;
+
+struct StepLds {  // one per gang
+    uint8_t tiles[kTileStride];
+    uint16_t cell[kMaxEnt];
+    uint8_t info[kMaxEnt];
+    uint8_t who[kTileStride];  // the orb or point that sits on a cell (each has its own), kNobody for none
 };
+constexpr int kNobody = 255;
+static_assert(kMaxEnt <= kNobody, "entity ids fit a byte");
 
 // System_Sprite_Render::update's list: the surviving sprites in set order, then std::sort on z (all 0.0).
-PG_D void rebuild_draw_list(const State& s, const StepLds& L, int lane, int env, int n_ent) {
+PG_D void rebuild_draw_list(const State& s, const StepLds& L, Q q, int env, int n_ent) {
     int n = 0;
-    for (int e = 0; e < n_ent; e++) n += (L.info[e][lane] & kAlive) ? 1 : 0;
+    for (int e0 = 0; e0 < n_ent; e0 += kGang) {
+        const int e = e0 + q.g;
+        n += __popc(q.ballot(e < n_ent && (L.info[e] & kAlive)));
+    }
     const uint8_t* rank = s.ranks + rank_offset(n);  // equal keys: the sort is a fixed permutation for each n
     int r = 0;
-    for (int k = 0; k < n_ent; k++) {
-        const int e = L.order[k][lane];
-        if (L.info[e][lane] & kAlive) EB(s, EB_DRAW, rank[r++], env) = static_cast<uint8_t>(e);
+    for (int k0 = 0; k0 < n_ent; k0 += kGang) {
+        const int k = k0 + q.g;
+        const int e = k < n_ent ? EB(s, EB_ORDER, k, env) : 0;
+        const bool alive = k < n_ent && (L.info[e] & kAlive);
+        const uint32_t m = q.ballot(alive);
+        if (alive) EB(s, EB_DRAW, rank[r + __popc(m & ((1u << q.g) - 1u))], env) = static_cast<uint8_t>(e);
+        r += __popc(m);
     }
-    SI(s, I_NDRAW, env) = n;
+    if (q.g == 0) SI(s, I_NDRAW, env) = n;
 }
 
-// Every lane of the wave goes in (the staging loop is wave-wide); `active` = this lane's env takes a step.
-PG_D void advance(const State& s, StepLds& L, int lane, bool active, int env, int action, float& reward_out,
-                  bool& terminated_out) {
-    const int n_ent = active ? SI(s, I_NENT, env) : 0;
-    for (int e0 = 0; __ballot(e0 < n_ent); e0 += 8) {
-        int info[8], cell[8], order[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int e = e0 + k;
+PG_D int tile_at(const StepLds& L, int x, int y) { return tile_at(L.tiles, x, y); }
+
+PG_D void advance(const State& s, StepLds& L, Q q, int env, int action, float& reward_out, bool& terminated_out) {
+    const int n_ent = SI(s, I_NENT, env);
+    int left = 0;  // orbs and points still there
+    {   // stage: tiles as 32-bit words, the entity table, who sits where
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(s.tiles + size_t(env) * kTileStride);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(L.tiles);
+        for (int k = q.g; k < kTileStride / 4; k += kGang) dst[k] = src[k];
+        uint32_t* who = reinterpret_cast<uint32_t*>(L.who);
+        for (int k = q.g; k < kTileStride / 4; k += kGang) who[k] = 0xffffffffu;
+        wave_order();
+        for (int e0 = 0; e0 < n_ent; e0 += kGang) {
+            const int e = e0 + q.g;
             const bool ok = e < n_ent;
-            info[k] = ok ? EB(s, EB_INFO, e, env) : 0;
-            cell[k] = ok ? ent_cell(s, e, env) : 0;
-            order[k] = ok ? EB(s, EB_ORDER, e, env) : 0;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int e = e0 + k;
-            if (e < n_ent) {
-                L.info[e][lane] = static_cast<uint8_t>(info[k]);
-                L.cell[e][lane] = static_cast<uint16_t>(cell[k]);
-                L.order[e][lane] = static_cast<uint8_t>(order[k]);
+            const int info = ok ? EB(s, EB_INFO, e, env) : 0;
+            const int cell = ok ? ent_cell(s, e, env) : 0;
+            const bool edible = ok && !(e >= kOrbs && e < kFirstPoint);
+            if (ok) {
+                L.info[e] = static_cast<uint8_t>(info);
+                L.cell[e] = static_cast<uint16_t>(cell);
             }
+            if (edible) L.who[cell] = static_cast<uint8_t>(e);
+            left += __popc(q.ballot(edible && (info & kAlive)));
         }
     }
-    if (!active) return;
-    const uint8_t* tiles = s.tiles + size_t(env) * kTileStride;
-    uint32_t* mt = s.mt + size_t(env) * kMtWords;
+    wave_order();
+    Rng rng = Rng::open(s.mt + size_t(env) * kMtWords, q);
     float ax = SF(s, F_AX, env), ay = SF(s, F_AY, env), avx = SF(s, F_AVX, env), avy = SF(s, F_AVY, env);
     float nvx = SF(s, F_NVX, env), nvy = SF(s, F_NVY, env);
     float input_t = SF(s, F_INPUT_T, env), anim_t = SF(s, F_ANIM_T, env), eat_t = SF(s, F_EAT_T, env);
     int anim_i = SI(s, I_ANIM_I, env);
     bool set_changed = (SI(s, I_FLAGS, env) & kFlagListed) == 0;
     const float dt = 1.0f / 4;
+    // the enemies in the set's iteration order, in registers for the step
+    int mob_id[kMobs], mob_tex[kMobs];
+    float mob_x[kMobs], mob_y[kMobs], mob_vx[kMobs], mob_vy[kMobs], mob_hatch[kMobs];
+#pragma unroll
+    for (int k = 0; k < kMobs; k++) {
+        const int m = MB(s, 1, k, env) - kOrbs;
+        mob_id[k] = m;
+        mob_tex[k] = MB(s, 0, m, env);
+        mob_x[k] = MF(s, MF_X, m, env);
+        mob_y[k] = MF(s, MF_Y, m, env);
+        mob_vx[k] = MF(s, MF_VX, m, env);
+        mob_vy[k] = MF(s, MF_VY, m, env);
+        mob_hatch[k] = MF(s, MF_HATCH, m, env);
+    }
 
     float movement_x = static_cast<float>((action == 7) - (action == 1));
     float movement_y = static_cast<float>((action == 3) - (action == 5));
@@ -414,14 +450,14 @@ PG_D void advance(const State& s, StepLds& L, int lane, bool active, int env, in
             }
             if (nvx > 0.0f) {
                 if (qabs(s, ay - (static_cast<int>(ay) + 0.5f)) <= speed * dt &&
-                    tile_at(tiles, static_cast<int>(ax) + 1, H - 1 - static_cast<int>(ay)) == kEmpty) {
+                    tile_at(L, static_cast<int>(ax) + 1, H - 1 - static_cast<int>(ay)) == kEmpty) {
                     ay = static_cast<int>(ay) + 0.5f;
                     avx = nvx;
                     avy = nvy;
                 }
             } else if (nvx < 0.0f) {
                 if (qabs(s, ay - (static_cast<int>(ay) + 0.5f)) <= speed * dt &&
-                    tile_at(tiles, static_cast<int>(ax) - 1, H - 1 - static_cast<int>(ay)) == kEmpty) {
+                    tile_at(L, static_cast<int>(ax) - 1, H - 1 - static_cast<int>(ay)) == kEmpty) {
                     ay = static_cast<int>(ay) + 0.5f;
                     avx = nvx;
                     avy = nvy;
@@ -429,14 +465,14 @@ PG_D void advance(const State& s, StepLds& L, int lane, bool active, int env, in
             }
             if (nvy > 0.0f) {
                 if (qabs(s, ax - (static_cast<int>(ax) + 0.5f)) <= speed * dt &&
-                    tile_at(tiles, static_cast<int>(ax), H - 1 - (static_cast<int>(ay) + 1)) == kEmpty) {
+                    tile_at(L, static_cast<int>(ax), H - 1 - (static_cast<int>(ay) + 1)) == kEmpty) {
                     ax = static_cast<int>(ax) + 0.5f;
                     avx = nvx;
                     avy = nvy;
                 }
             } else if (nvy < 0.0f) {
                 if (qabs(s, ax - (static_cast<int>(ax) + 0.5f)) <= speed * dt &&
-                    tile_at(tiles, static_cast<int>(ax), H - 1 - (static_cast<int>(ay) - 1)) == kEmpty) {
+                    tile_at(L, static_cast<int>(ax), H - 1 - (static_cast<int>(ay) - 1)) == kEmpty) {
                     ax = static_cast<int>(ax) + 0.5f;
                     avx = nvx;
                     avy = nvy;
@@ -444,26 +480,26 @@ PG_D void advance(const State& s, StepLds& L, int lane, bool active, int env, in
             }
             if (avx < 0.0f) {
                 if (qabs(s, ax - (static_cast<int>(ax) + 0.5f)) <= speed * dt &&
-                    tile_at(tiles, static_cast<int>(ax) - 1, H - 1 - static_cast<int>(ay)) != kEmpty) {
+                    tile_at(L, static_cast<int>(ax) - 1, H - 1 - static_cast<int>(ay)) != kEmpty) {
                     ax = static_cast<int>(ax) + 0.5f;
                     avx = 0.0f;
                 }
             } else if (avx > 0.0f) {
                 if (qabs(s, ax - (static_cast<int>(ax) + 0.5f)) <= speed * dt &&
-                    tile_at(tiles, static_cast<int>(ax) + 1, H - 1 - static_cast<int>(ay)) != kEmpty) {
+                    tile_at(L, static_cast<int>(ax) + 1, H - 1 - static_cast<int>(ay)) != kEmpty) {
                     ax = static_cast<int>(ax) + 0.5f;
                     avx = 0.0f;
                 }
             }
             if (avy < 0.0f) {
                 if (qabs(s, ay - (static_cast<int>(ay) + 0.5f)) <= speed * dt &&
-                    tile_at(tiles, static_cast<int>(ax), H - 1 - (static_cast<int>(ay) - 1)) != kEmpty) {
+                    tile_at(L, static_cast<int>(ax), H - 1 - (static_cast<int>(ay) - 1)) != kEmpty) {
                     ay = static_cast<int>(ay) + 0.5f;
                     avy = 0.0f;
                 }
             } else if (avy > 0.0f) {
                 if (qabs(s, ay - (static_cast<int>(ay) + 0.5f)) <= speed * dt &&
-                    tile_at(tiles, static_cast<int>(ax), H - 1 - (static_cast<int>(ay) + 1)) != kEmpty) {
+                    tile_at(L, static_cast<int>(ax), H - 1 - (static_cast<int>(ay) + 1)) != kEmpty) {
                     ay = static_cast<int>(ay) + 0.5f;
                     avy = 0.0f;
                 }
@@ -483,12 +519,12 @@ PG_D void advance(const State& s, StepLds& L, int lane, bool active, int env, in
         bool player_hit = false;
         {
             const float hatch_time = 50.0f, anim_time = 1.0f, speed_low = 0.125f, speed_high = 0.25f;
-            for (int q = 0; q < kMobs; q++) {
-                const int m = MB(s, 1, q, env) - kOrbs;
-                float hatch = MF(s, MF_HATCH, m, env);
+#pragma unroll
+            for (int k = 0; k < kMobs; k++) {
+                float hatch = mob_hatch[k];
                 if (hatch >= hatch_time) {
-                    float px = MF(s, MF_X, m, env), py = MF(s, MF_Y, m, env);
-                    float vx = MF(s, MF_VX, m, env), vy = MF(s, MF_VY, m, env);
+                    float px = mob_x[k], py = mob_y[k];
+                    float vx = mob_vx[k], vy = mob_vy[k];
                     float speed;
                     int tex;
                     if (eat_t == 0.0f) {
@@ -504,44 +540,44 @@ PG_D void advance(const State& s, StepLds& L, int lane, bool active, int env, in
                         bool possible[4];
                         int n_possible = 0;
 #pragma unroll
-                        for (int k = 0; k < 2; k++) {
-                            const int dx = 2 * k - 1;
-                            const int id = tile_at(tiles, static_cast<int>(px) + dx, H - 1 - static_cast<int>(py));
-                            possible[k] = (id == kEmpty && dx != -sign_of(vx));
-                            n_possible += possible[k] ? 1 : 0;
+                        for (int j = 0; j < 2; j++) {
+                            const int dx = 2 * j - 1;
+                            const int id = tile_at(L, static_cast<int>(px) + dx, H - 1 - static_cast<int>(py));
+                            possible[j] = (id == kEmpty && dx != -sign_of(vx));
+                            n_possible += possible[j] ? 1 : 0;
                         }
 #pragma unroll
-                        for (int k = 0; k < 2; k++) {
-                            const int dy = 2 * k - 1;
-                            const int id = tile_at(tiles, static_cast<int>(px), H - 1 - (static_cast<int>(py) + dy));
-                            possible[2 + k] = (id == kEmpty && dy != -sign_of(vy));
-                            n_possible += possible[2 + k] ? 1 : 0;
+                        for (int j = 0; j < 2; j++) {
+                            const int dy = 2 * j - 1;
+                            const int id = tile_at(L, static_cast<int>(px), H - 1 - (static_cast<int>(py) + dy));
+                            possible[2 + j] = (id == kEmpty && dy != -sign_of(vy));
+                            n_possible += possible[2 + j] ? 1 : 0;
                         }
-                        const bool be_aggressive = rng_real(mt, 0.0f, 1.0f) < 0.5f;
+                        const bool be_aggressive = rng.real(0.0f, 1.0f) < 0.5f;
                         int select = 0;
                         if (be_aggressive) {
                             float min_dist = 999999.0f;
 #pragma unroll
-                            for (int k = 0; k < 4; k++)
-                                if (possible[k]) {
-                                    const float dir_x = k == 0 ? -1.0f : (k == 1 ? 1.0f : 0.0f);
-                                    const float dir_y = k == 2 ? -1.0f : (k == 3 ? 1.0f : 0.0f);
+                            for (int j = 0; j < 4; j++)
+                                if (possible[j]) {
+                                    const float dir_x = j == 0 ? -1.0f : (j == 1 ? 1.0f : 0.0f);
+                                    const float dir_y = j == 2 ? -1.0f : (j == 3 ? 1.0f : 0.0f);
                                     float d = qabs(s, px + dir_x - ax) + qabs(s, py + dir_y - ay);
                                     if (eat_t > 0.0f) d = -d;
                                     if (d < min_dist) {
                                         min_dist = d;
-                                        select = k;
+                                        select = j;
                                     }
                                 }
                         } else if (n_possible > 0) {
-                            const int cusp = rng_int(mt, 0, n_possible - 1);
+                            const int cusp = rng.integer(0, n_possible - 1);
                             int sum = 0;
                             bool found = false;
 #pragma unroll
-                            for (int k = 0; k < 4; k++) {
-                                sum += possible[k] ? 1 : 0;
+                            for (int j = 0; j < 4; j++) {
+                                sum += possible[j] ? 1 : 0;
                                 if (!found && sum > cusp) {
-                                    select = k;
+                                    select = j;
                                     found = true;
                                 }
                             }
@@ -561,20 +597,20 @@ PG_D void advance(const State& s, StepLds& L, int lane, bool active, int env, in
                         } else {  // back to an egg on a random point cell, without the world-y flip (D16)
                             hatch = 0.0f;
                             const int n_free = n_ent - kFirstPoint;
-                            const int cell = L.cell[kFirstPoint + rng_int(mt, 0, n_free - 1)][lane];
+                            const int cell = L.cell[kFirstPoint + rng.integer(0, n_free - 1)];
                             px = cell / H + 0.5f;
                             py = cell % H + 0.5f;
                             tex = 0;
                         }
                     }
-                    MF(s, MF_X, m, env) = px;
-                    MF(s, MF_Y, m, env) = py;
-                    MF(s, MF_VX, m, env) = vx;
-                    MF(s, MF_VY, m, env) = vy;
-                    MF(s, MF_HATCH, m, env) = hatch;
-                    MB(s, 0, m, env) = static_cast<uint8_t>(tex);
+                    mob_x[k] = px;
+                    mob_y[k] = py;
+                    mob_vx[k] = vx;
+                    mob_vy[k] = vy;
+                    mob_hatch[k] = hatch;
+                    mob_tex[k] = tex;
                 } else {
-                    MF(s, MF_HATCH, m, env) = hatch + dt;
+                    mob_hatch[k] = hatch + dt;
                 }
             }
             if (anim_t < anim_time) {
@@ -586,42 +622,70 @@ PG_D void advance(const State& s, StepLds& L, int lane, bool active, int env, in
             if (eat_t > 0.0f) eat_t = fmaxf(0.0f, eat_t - dt);
         }
 
-        // --- System_Point::update (common_systems.cpp:66-106): order-free
-        int delta = 0, available = 0;
-        for (int e = 0; e < n_ent; e++) {
-            if (e >= kOrbs && e < kFirstPoint) continue;
-            const int info = L.info[e][lane];
-            if (!(info & kAlive)) continue;
-            const int cell = L.cell[e][lane];
-            const float x = cell_x(cell), y = cell_y(cell);
-            const bool orb = e < kOrbs;
-            const Box rect = orb ? Box{-0.5f + x, -0.5f + y, 1.0f, 1.0f} : Box{-0.3f + x, -0.3f + y, 0.6f, 0.6f};
-            if (box_hit(agent_rect, rect)) {
-                if (orb) eat_t = 75.0f;
-                delta++;
-                L.info[e][lane] = static_cast<uint8_t>(info & ~kAlive);  // destroy_entity
-                EB(s, EB_INFO, e, env) = static_cast<uint8_t>(info & ~kAlive);
-                set_changed = true;
-            } else {
-                available++;
+        // --- System_Point::update (common_systems.cpp:66-106): order-free.  The reference tests every orb and point; the
+        // agent's 1×1 box can only reach those on the nine cells around its own (their boxes are at most 1×1 about a cell
+        // centre), so the lanes take one of those cells each and test — with the same box arithmetic — whoever sits there.
+        int delta = 0;
+        bool orb_eaten = false;
+        {
+            const int cx = static_cast<int>(ax), cy = H - 1 - static_cast<int>(ay);  // cell (x, tile row) under the agent's centre
+#pragma unroll
+            for (int n0 = 0; n0 < 9; n0 += kGang) {
+                const int nb = n0 + q.g;
+                const int x = cx + nb % 3 - 1, ty = cy + (nb / 3) % 3 - 1;
+                const bool inside = nb < 9 && x >= 0 && ty >= 0 && x < W && ty < H;
+                const int cell = inside ? ty + x * H : 0;
+                const int e = inside ? L.who[cell] : kNobody;
+                const int info = e != kNobody ? L.info[e] : 0;
+                const bool alive = (info & kAlive) != 0;
+                const float px = cell_x(cell), py = cell_y(cell);
+                const bool orb = e < kOrbs;
+                const Box rect = orb ? Box{-0.5f + px, -0.5f + py, 1.0f, 1.0f} : Box{-0.3f + px, -0.3f + py, 0.6f, 0.6f};
+                const bool eaten = alive && box_hit(agent_rect, rect);
+                if (eaten) {  // destroy_entity
+                    L.info[e] = static_cast<uint8_t>(info & ~kAlive);
+                    EB(s, EB_INFO, e, env) = static_cast<uint8_t>(info & ~kAlive);
+                }
+                delta += __popc(q.ballot(eaten));
+                orb_eaten = orb_eaten | q.any(eaten & orb);
             }
         }
+        left -= delta;
+        const int available = left;
+        if (orb_eaten) eat_t = 75.0f;
+        if (delta) set_changed = true;
         reward = delta * 0.04f + (available == 0) * 10.0f;
         terminated = player_hit || (available == 0);
         if (terminated) break;
     }
-    SF(s, F_AX, env) = ax;
-    SF(s, F_AY, env) = ay;
-    SF(s, F_AVX, env) = avx;
-    SF(s, F_AVY, env) = avy;
-    SF(s, F_NVX, env) = nvx;
-    SF(s, F_NVY, env) = nvy;
-    SF(s, F_INPUT_T, env) = input_t;
-    SF(s, F_ANIM_T, env) = anim_t;
-    SF(s, F_EAT_T, env) = eat_t;
-    SI(s, I_ANIM_I, env) = anim_i;
-    SI(s, I_FLAGS, env) = kFlagListed;
-    if (set_changed) rebuild_draw_list(s, L, lane, env, n_ent);
+    rng.close();
+    if (q.g == 0) {
+#pragma unroll
+        for (int k = 0; k < kMobs; k++) {
+            const int m = mob_id[k];
+            MF(s, MF_X, m, env) = mob_x[k];
+            MF(s, MF_Y, m, env) = mob_y[k];
+            MF(s, MF_VX, m, env) = mob_vx[k];
+            MF(s, MF_VY, m, env) = mob_vy[k];
+            MF(s, MF_HATCH, m, env) = mob_hatch[k];
+            MB(s, 0, m, env) = static_cast<uint8_t>(mob_tex[k]);
+        }
+        SF(s, F_AX, env) = ax;
+        SF(s, F_AY, env) = ay;
+        SF(s, F_AVX, env) = avx;
+        SF(s, F_AVY, env) = avy;
+        SF(s, F_NVX, env) = nvx;
+        SF(s, F_NVY, env) = nvy;
+        SF(s, F_INPUT_T, env) = input_t;
+        SF(s, F_ANIM_T, env) = anim_t;
+        SF(s, F_EAT_T, env) = eat_t;
+        SI(s, I_ANIM_I, env) = anim_i;
+        SI(s, I_FLAGS, env) = kFlagListed;
+    }
+    if (set_changed) {
+        wave_order();
+        rebuild_draw_list(s, L, q, env, n_ent);
+    }
     reward_out = reward;
     terminated_out = terminated;
 }
@@ -633,33 +697,42 @@ __global__ void __launch_bounds__(64) make_kernel(State s) {
     fresh_live(s, env);
 }
 
-__global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actions, uint32_t run_seed,
-                                                   uint32_t step_index, int env_offset, StepIO io) {
-    __shared__ StepLds L;
-    const int lane = threadIdx.x;
-    const int env = blockIdx.x * 64 + lane;
-    bool active = env < s.n;
-    if (active && io.pending[env] != 0) active = false;  // reset by the level kernel in this step, maybe right now (pg_engine.h StepIO)
-    const int action = !active ? 0
-                       : actions ? actions[env]
-                                 : synthetic_action(run_seed, step_index, static_cast<uint32_t>(env_offset + env));
+__global__ void __launch_bounds__(64, PG_CHASER_WAVES) logic_kernel(State s, const int32_t* actions, uint32_t run_seed,
+                                                                    uint32_t step_index, int env_offset, StepIO io) {
+    __shared__ StepLds lds[64 / kGang];
+    const int env = (blockIdx.x * 64 + threadIdx.x) / kGang;
+    if (env >= s.n) return;
+    if (io.pending[env] != 0) return;  // reset by the level kernel in this step, maybe right now (pg_engine.h StepIO)
+    const Q q = Q::at(threadIdx.x);
+    const int action =
+        actions ? actions[env] : synthetic_action(run_seed, step_index, static_cast<uint32_t>(env_offset + env));
     float reward = 0.0f;
     bool terminated = false;
-    advance(s, L, lane, active, env, action, reward, terminated);
-    if (!active) return;
-    io.reward[env] = reward;
-    io.done[env] = terminated ? 1 : 0;
-    io.pending[env] = terminated ? 3 : 0;  // (3, not 1: the level kernel may be running beside this one — pg_engine.h StepIO)
+    advance(s, lds[(threadIdx.x & 63) / kGang], q, env, action, reward, terminated);
+    if (q.g == 0) {
+        io.reward[env] = reward;
+        io.done[env] = terminated ? 1 : 0;
+        io.pending[env] = terminated ? 3 : 0;  // (3, not 1: the level kernel may be running beside this one — pg_engine.h StepIO)
+    }
 }
 
 // render_game(true) (chaser.cpp:390-416): one workgroup of two wavefronts per env (pg_render.h).
+// pass 0: every env (of the mask); the step's level and logic kernels are both done, the flag is settled here
+// (pg_engine.h StepIO: 3 → 1, 2 → 0).  A step whose resets run on their own stream (pg_engine.h launch_render_step /
+// _late) renders in two passes: 1 = beside the level kernel, every env that is NOT being reset (pending 1 or 2: the level
+// kernel may be anywhere) — and it leaves the flags alone: a 1 written now could still be picked up by a late wavefront of
+// the level kernel running beside it, which would reset the env a step early; 2 = after the level kernel, the envs it
+// reset (all 2 by then), and the flags are settled.
 __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
-                                                    int flags) {
+                                                    int flags, int pass) {
     const int env = blockIdx.x;
     if (mask && !mask[env]) return;
-    if (threadIdx.x == 0) {  // the step's level and logic kernels are both done: settle the flag (pg_engine.h StepIO)
+    {
         const int p = io.pending[env];
-        if (p >= 2) io.pending[env] = p == 3 ? 1 : 0;
+        __syncthreads();  // every thread has read the flag before thread 0 settles it
+        if (pass == 1 && (p == 1 || p == 2)) return;
+        if (pass != 1 && threadIdx.x == 0 && p >= 2) io.pending[env] = p == 3 ? 1 : 0;
+        if (pass == 2 && p != 2) return;
     }
     const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // two wavefronts per env (pg_render.h)
     constexpr int halves = 2;
@@ -908,7 +981,7 @@ class ChaserGame final : public Game {
         l.i = take(size_t(I_COUNT) * n * 4);
         l.mf = take(size_t(MF_COUNT) * kMobs * n * 4);
         l.mb = take(size_t(2) * kMobs * n);
-        l.eb = take(size_t(EB_COUNT) * kMaxEnt * n);
+        l.eb = take(size_t(EB_COUNT) * kMaxEnt * n);  // (same size either way round)
         l.total = off;
         return l;
     }
@@ -945,7 +1018,7 @@ class ChaserGame final : public Game {
     void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
                       StepIO io) override {
         LevelLaunch<Gen>::auto_reset(reset_stream ? reset_stream : st, s_, 0, io, plan, kResetSpan);
-        hipLaunchKernelGGL(logic_kernel, dim3((s_.n + 63) / 64), dim3(64), 0, st, s_, actions, run_seed, step_index,
+        hipLaunchKernelGGL(logic_kernel, dim3((s_.n * kGang + 63) / 64), dim3(64), 0, st, s_, actions, run_seed, step_index,
                            env_offset, io);
     }
     bool launch_frame(hipStream_t st, int env, uint32_t* d_px, int w, int h) override {
@@ -953,7 +1026,15 @@ class ChaserGame final : public Game {
         return true;
     }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
-        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags);
+        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags, 0);
+    }
+    void launch_render_step(hipStream_t st, StepIO io) override {
+        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, nullptr, io, debug_flags, reset_stream ? 1 : 0);
+    }
+    bool launch_render_late(hipStream_t st, StepIO io) override {
+        if (!reset_stream) return false;
+        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, nullptr, io, debug_flags, 2);
+        return true;
     }
     // Same layout as oracle/pgo_chaser.cpp Chaser::dump_state.
     int dump_state(hipStream_t st, int env, float* out, int cap) override {
@@ -980,9 +1061,9 @@ class ChaserGame final : public Game {
                                 static_cast<float>(ri(I_ANIM_I)), f(F_EAT_T), static_cast<float>(ri(I_BG)), f(F_BGSHIFT),
                                 static_cast<float>(n_ent)};
         for (int e = 0; e < n_ent; e++) {
-            const int info = rb(s_.eb, (size_t(EB_INFO) * kMaxEnt + e) * n + env);
-            const int cell = rb(s_.eb, (size_t(EB_CELL) * kMaxEnt + e) * n + env) |
-                             (kWideCells ? rb(s_.eb, (size_t(EB_CELL_HI) * kMaxEnt + e) * n + env) << 8 : 0);
+            const int info = rb(s_.eb, (size_t(env) * EB_COUNT + EB_INFO) * kMaxEnt + e);
+            const int cell = rb(s_.eb, (size_t(env) * EB_COUNT + EB_CELL) * kMaxEnt + e) |
+                             (kWideCells ? rb(s_.eb, (size_t(env) * EB_COUNT + EB_CELL_HI) * kMaxEnt + e) << 8 : 0);
             const int kind = info & kKindMask;
             v.push_back((info & kAlive) ? 1.0f : 0.0f);
             v.push_back(static_cast<float>(kind));

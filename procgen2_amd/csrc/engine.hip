@@ -328,7 +328,11 @@ int32_t pgv_make_config(const pgv_config* cfg, pgv_env** out) {
     PG_HIP(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
     for (auto& ev : e->side_ev) PG_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     if (e->game->resets_beside_logic() && !std::getenv("PG_SERIAL_RESETS")) {  // (the variable: A/B measurements only)
-        PG_HIP(hipStreamCreateWithFlags(&e->reset_stream, hipStreamNonBlocking));
+        {   // the few long wavefronts of the in-step level kernel go first; the logic kernel's many short ones fill in around them
+            int least = 0, greatest = 0;
+            PG_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            PG_HIP(hipStreamCreateWithPriority(&e->reset_stream, hipStreamNonBlocking, greatest));
+        }
         PG_HIP(hipEventCreateWithFlags(&e->reset_fork, hipEventDisableTiming));
         PG_HIP(hipEventCreateWithFlags(&e->reset_join, hipEventDisableTiming));
         e->game->reset_stream = e->reset_stream;
@@ -380,22 +384,24 @@ int32_t pgv_reset(pgv_env* e, const uint8_t* d_mask, const int32_t* d_seeds) {
 // only the most recent error, and pregen's hipStreamQuery legitimately leaves hipErrorNotReady behind.
 static int32_t step_impl(pgv_env* e, const int32_t* d_actions, uint32_t run_seed, hipEvent_t before_render = nullptr,
                          hipEvent_t after_render = nullptr) {
-    if (e->reset_stream) {  // fork: the auto-resets of this step go beside its logic kernels
+    if (e->reset_stream) {  // fork: the auto-resets of this step go beside its logic and render kernels
         PG_HIP(hipEventRecord(e->reset_fork, e->stream));
         PG_HIP(hipStreamWaitEvent(e->reset_stream, e->reset_fork, 0));
     }
     e->game->launch_logic(e->stream, d_actions, run_seed, e->step_index, e->env_offset, e->io());
     PG_HIP(hipGetLastError());
-    if (e->reset_stream) {  // join: the render kernel (and the level generator) see both
-        PG_HIP(hipEventRecord(e->reset_join, e->reset_stream));
-        PG_HIP(hipStreamWaitEvent(e->stream, e->reset_join, 0));
-    }
     pregen(e, false, false);  // before the render launch: the generator overlaps it
     (void)hipGetLastError();  // hipErrorNotReady of the stream query is not an error
     if (before_render) PG_HIP(hipEventRecord(before_render, e->stream));
-    e->game->launch_render(e->stream, nullptr, e->io());
+    e->game->launch_render_step(e->stream, e->io());
     PG_HIP(hipGetLastError());
     if (after_render) PG_HIP(hipEventRecord(after_render, e->stream));
+    if (e->reset_stream) {  // join: the envs that were reset beside all this get their frame now
+        PG_HIP(hipEventRecord(e->reset_join, e->reset_stream));
+        PG_HIP(hipStreamWaitEvent(e->stream, e->reset_join, 0));
+        e->game->launch_render_late(e->stream, e->io());
+        PG_HIP(hipGetLastError());
+    }
     e->step_index++;
     return 0;
 }

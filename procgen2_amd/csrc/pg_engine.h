@@ -122,6 +122,12 @@ class Game {
     // between the streams costs about 25 µs, so games whose auto-reset only installs a prefetched level do not ask.
     virtual bool resets_beside_logic() const { return false; }
     hipStream_t reset_stream = nullptr;
+    // Such a game may go further and keep the reset stream apart until AFTER the step's render launch: the envs being
+    // reset are a per cent of the batch, their levels one long chain per wavefront — beside the render kernel that
+    // chain is hidden altogether.  launch_render_step() then renders every env that is not being reset,
+    // launch_render_late() — called once the reset stream has joined — the few that were.  Default: one launch.
+    virtual void launch_render_step(hipStream_t s, StepIO io) { launch_render(s, nullptr, io); }
+    virtual bool launch_render_late(hipStream_t s, StepIO io) { return false; }
 
     // Bit 0: render background + tiles by draw-list replay instead of the row composer (fallback path).
     // Bit 8: no level prefetch — every reset generates its level synchronously inside the step.

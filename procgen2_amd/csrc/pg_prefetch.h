@@ -75,6 +75,9 @@ __global__ void __launch_bounds__(64) level_kernel(typename G::State s, int mode
                                                    uint32_t seed_base, int env_offset, const uint8_t* mask,
                                                    const int32_t* seeds, StepIO io, LevelPlan plan) {
     using Level = typename G::Level;
+    // A level is one long dependent chain per wavefront; whatever shares its SIMD (a logic kernel running beside an
+    // in-step reset, a render kernel beside the prefetcher) is many short ones: let the chain issue first.
+    __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x;
     const int base = blockIdx.x * span;
     bool want = false;

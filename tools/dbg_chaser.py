@@ -1,0 +1,24 @@
+import sys, os
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import numpy as np
+from engine_util import EngineVec
+from oracle_util import OracleVec
+n=256
+eng, ora = EngineVec("chaser", n, seed_base=3), OracleVec("chaser", n, seed_base=3)
+assert np.array_equal(eng.reset(), ora.reset_obs())
+for s in range(3000):
+    acts = np.array([ora.L.pgo_synthetic_action(1, s, e) for e in range(n)], np.int32)
+    acts = np.where(acts % 2 == 1, acts, (acts*7+s) % 15).astype(np.int32)
+    oe, re_, de = eng.step(acts)
+    oo, ro, do = ora.step(acts, threads=8)
+    if not (np.array_equal(re_, ro) and np.array_equal(de, do) and np.array_equal(oe, oo)):
+        bad = np.nonzero((re_ != ro) | (de != do) | (oe != oo).any(axis=1))[0]
+        e = bad[0]
+        print("step", s, "envs", bad[:8], "reward", re_[e], ro[e], "done", de[e], do[e])
+        a, b = eng.state(e, 400), ora.state(e, 400)
+        d = np.nonzero(a.view(np.uint32) != b.view(np.uint32))[0]
+        print("state diff idx", d[:20], a[d[:20]], b[d[:20]])
+        print(a[:16]); print(b[:16])
+        break
+else:
+    print("no mismatch")
