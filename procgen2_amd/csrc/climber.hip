@@ -15,6 +15,7 @@
 // survivors whenever the set changed.
 #include "pg_engine.h"
 #include "pg_frame.h"
+#include "pg_gang.h"
 #include "pg_geom.h"
 #include "pg_order.h"
 #include "pg_prefetch.h"
@@ -36,7 +37,7 @@ constexpr float kEnemyProb = 0.2f;
 #endif
 
 constexpr int W = 20, H = 64;
-constexpr int kMaxEnt = 34;  // ≤ 17 platforms (difficulty 3), each at most one mob and one crystal (tilemap.cpp:98-105)
+constexpr int kMaxEnt = 34, kEntStride = 48;  // ≤ 17 platforms (difficulty 3), each at most one mob and one crystal (tilemap.cpp:98-105)
 enum Tile : uint8_t { kEmpty = 0, kWallTop, kWallMid };  // tilemap.h:12-17
 
 enum Tex {
@@ -82,15 +83,15 @@ struct State {
     uint8_t* tiles;  // [n][1280]  column-major y + x*H
     float* f;        // [F_COUNT][n]
     int32_t* i;      // [I_COUNT][n]
-    float* ef;       // [EF_COUNT][kMaxEnt][n]
-    uint8_t* eb;     // [EB_COUNT][kMaxEnt][n]
+    float* ef;       // [n][EF_COUNT][kEntStride]  per-env contiguous: a gang's and the render wavefronts' lanes index them by entity
+    uint8_t* eb;     // [n][EB_COUNT][kEntStride]
     const uint8_t* ranks;  // pg_order.h equal-key sort ranks
 };
 
 PG_D float& SF(const State& s, int field, int env) { return s.f[size_t(field) * s.n + env]; }
 PG_D int32_t& SI(const State& s, int field, int env) { return s.i[size_t(field) * s.n + env]; }
-PG_D float& EF(const State& s, int field, int e, int env) { return s.ef[(size_t(field) * kMaxEnt + e) * s.n + env]; }
-PG_D uint8_t& EB(const State& s, int field, int e, int env) { return s.eb[(size_t(field) * kMaxEnt + e) * s.n + env]; }
+PG_D float& EF(const State& s, int field, int e, int env) { return s.ef[(size_t(env) * EF_COUNT + field) * kEntStride + e]; }
+PG_D uint8_t& EB(const State& s, int field, int e, int env) { return s.eb[(size_t(env) * EB_COUNT + field) * kEntStride + e]; }
 
 using Win = TileWinT<W, H, kWallMid>;  // out of bounds is a wall (tilemap.h:66-68)
 
@@ -131,19 +132,6 @@ PG_D void episode_order(int32_t& packed, int n, uint8_t* out) {
         p = next[p];
     }
     packed = h.buckets | (h.next_resize << 16);
-}
-
-// System_Sprite_Render::update's list: the surviving sprites in set order, then std::sort on z (all 1.0).
-PG_D void rebuild_draw_list(const State& s, int env, int n_ent) {
-    int n = 0;
-    for (int k = 0; k < n_ent; k++) n += (EB(s, EB_INFO, EB(s, EB_ORDER, k, env), env) & kAlive) ? 1 : 0;
-    const uint8_t* rank = s.ranks + rank_offset(n);  // equal keys: the sort is a fixed permutation for each n
-    int r = 0;
-    for (int k = 0; k < n_ent; k++) {
-        const int e = EB(s, EB_ORDER, k, env);
-        if (EB(s, EB_INFO, e, env) & kAlive) EB(s, EB_DRAW, rank[r++], env) = static_cast<uint8_t>(e);
-    }
-    SI(s, I_NDRAW, env) = n;
 }
 
 // reset() (climber.cpp:461-497 + tilemap.cpp:75-170) for one env by one wavefront: every lane walks the generator
@@ -283,95 +271,101 @@ PG_D bool is_wall(int t) { return t == kWallMid || t == kWallTop; }
 // crystal.
 constexpr int kMaxMobs = 17, kMaxGems = 17;
 
-// The entities of the 64 envs of a logic wavefront, staged in LDS for the step ([slot][lane], conflict-free).
-// One lane walks its env's entities four times per step (sub-steps); from global memory every visit was a dependent
-// memory round trip — and two for a mob, whose 4×4 tile window depends on its position — with a single wave per SIMD
-// to hide nothing behind: 0.58 ms a step.  Here the alive entities are loaded once (four at a time, all loads in
-// flight), the mobs' tile windows are fetched once per step (they drift 0.15 tiles a step; `at()` falls back to a
-// direct load outside the window, so this is a cache, not an assumption), and the sub-steps run from LDS.
-struct StepLds {
-    float m_x[kMaxMobs][64], m_vx[kMaxMobs][64], m_t[kMaxMobs][64];
-    unsigned long long m_win[kMaxMobs][64];
-    int8_t m_ax[kMaxMobs][64], m_ay[kMaxMobs][64];
-    uint8_t m_row[kMaxMobs][64], m_spawn[kMaxMobs][64], m_id[kMaxMobs][64], m_info[kMaxMobs][64];
-    uint8_t g_col[kMaxGems][64], g_row[kMaxGems][64], g_id[kMaxGems][64], g_info[kMaxGems][64];
+// One env = one gang of kGang adjacent lanes (pg_gang.h).  What costs in this game is get_collision — the agent's box
+// and one probe per mob, every sub-step — so those are the gang's parallel work: collider 0 is the agent, collider
+// 1 + m the m-th alive mob, kGang of them per pass through ONE copy of the collision code.  Everything else about the
+// agent is uniform over the gang; mobs and crystals (alive ones, compacted in id order) live in LDS for the step.
+#ifndef PG_CLIMBER_GANG
+#define PG_CLIMBER_GANG 8
+#endif
+#ifndef PG_CLIMBER_WAVES
+#define PG_CLIMBER_WAVES 4  // wavefronts per SIMD the logic kernel's registers are capped for
+#endif
+constexpr int kGang = PG_CLIMBER_GANG;
+using Q = Gang<kGang>;
+
+struct StepLds {  // one per gang
+    float m_x[kMaxMobs], m_vx[kMaxMobs], m_t[kMaxMobs];
+    unsigned long long m_win[kMaxMobs];
+    int8_t m_ax[kMaxMobs], m_ay[kMaxMobs];
+    uint8_t m_row[kMaxMobs], m_spawn[kMaxMobs], m_id[kMaxMobs], m_info[kMaxMobs];
+    uint8_t g_col[kMaxGems], g_row[kMaxGems], g_id[kMaxGems], g_info[kMaxGems];
 };
 
-PG_D void advance(const State& s, StepLds& L, int lane, bool active, int env, int action, float& reward_out,
-                  bool& terminated_out) {
-    const uint8_t* tiles = s.tiles + size_t(active ? env : 0) * (W * H);
-    const int n_ent = active ? SI(s, I_NENT, env) : 0;
+// System_Sprite_Render::update's list: the surviving sprites in set order, then std::sort on z (all 1.0).
+PG_D void rebuild_draw_list(const State& s, Q q, int env, int n_ent) {
+    int n = 0;
+    for (int k0 = 0; k0 < n_ent; k0 += kGang) {
+        const int k = k0 + q.g;
+        n += __popc(q.ballot(k < n_ent && (EB(s, EB_INFO, k, env) & kAlive)));
+    }
+    const uint8_t* rank = s.ranks + rank_offset(n);  // equal keys: the sort is a fixed permutation for each n
+    int r = 0;
+    for (int k0 = 0; k0 < n_ent; k0 += kGang) {
+        const int k = k0 + q.g;
+        const int e = k < n_ent ? EB(s, EB_ORDER, k, env) : 0;
+        const bool alive = k < n_ent && (EB(s, EB_INFO, e, env) & kAlive);
+        const uint32_t m = q.ballot(alive);
+        if (alive) EB(s, EB_DRAW, rank[r + __popc(m & ((1u << q.g) - 1u))], env) = static_cast<uint8_t>(e);
+        r += __popc(m);
+    }
+    if (q.g == 0) SI(s, I_NDRAW, env) = n;
+}
+
+PG_D void advance(const State& s, StepLds& L, Q q, int env, int action, float& reward_out, bool& terminated_out) {
+    const uint8_t* tiles = s.tiles + size_t(env) * (W * H);
+    const int n_ent = SI(s, I_NENT, env);
     const float dt = 1.0f / 4;
+    const uint32_t below = (1u << q.g) - 1u;
 
     // --- stage the alive entities (reference loop: `if (!alive) continue`): mobs and crystals in id order
     int n_mobs = 0, n_gems = 0;
-    for (int e0 = 0; __ballot(e0 < n_ent); e0 += 4) {
-        int info[4], spawn[4];
-        float x[4], y[4], vx[4], t[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int e = e0 + k;
-            const bool ok = e < n_ent;
-            info[k] = ok ? EB(s, EB_INFO, e, env) : 0;
-            spawn[k] = ok ? EB(s, EB_SPAWN_X, e, env) : 0;
-            x[k] = ok ? EF(s, EF_X, e, env) : 0.0f;
-            y[k] = ok ? EF(s, EF_Y, e, env) : 0.0f;
-            vx[k] = ok ? EF(s, EF_VX, e, env) : 0.0f;
-            t[k] = ok ? EF(s, EF_ANIM_T, e, env) : 0.0f;
+    for (int e0 = 0; e0 < n_ent; e0 += kGang) {
+        const int e = e0 + q.g;
+        const bool ok = e < n_ent;
+        const int info = ok ? EB(s, EB_INFO, e, env) : 0;
+        const int spawn = ok ? EB(s, EB_SPAWN_X, e, env) : 0;
+        const float x = ok ? EF(s, EF_X, e, env) : 0.0f, y = ok ? EF(s, EF_Y, e, env) : 0.0f;
+        const float vx = ok ? EF(s, EF_VX, e, env) : 0.0f, t = ok ? EF(s, EF_ANIM_T, e, env) : 0.0f;
+        const bool alive = (info & kAlive) != 0, mob = alive && (info & kMob), gem = alive && !(info & kMob);
+        const uint32_t mobs = q.ballot(mob), gems = q.ballot(gem);
+        const int row = H - 1 - static_cast<int>(y);  // y = (H-1-row) + 0.5 exactly (generate(): spawn)
+        if (mob) {
+            const int m = n_mobs + __popc(mobs & below);
+            if (m >= kMaxMobs) __builtin_trap();
+            L.m_x[m] = x;
+            L.m_vx[m] = vx;
+            L.m_t[m] = t;
+            L.m_row[m] = static_cast<uint8_t>(row);
+            L.m_spawn[m] = static_cast<uint8_t>(spawn);
+            L.m_id[m] = static_cast<uint8_t>(e);
+            L.m_info[m] = static_cast<uint8_t>(info);
+            // its tile window for the step, around the probe of the first sub-step, spare column on the side it is heading
+            // (mobs drift 0.15 tiles a step; `at()` falls back to a direct load outside the window: a cache, not an assumption)
+            const float my = static_cast<float>(H - 1 - row) + 0.5f;
+            const Box probe{x + vx * dt - 0.5f, my - 0.6f, 1.0f, 0.5f};
+            const Win w = Win::around(tiles, probe, vx, 0.0f);
+            L.m_win[m] = w.bits;
+            L.m_ax[m] = static_cast<int8_t>(w.ax);
+            L.m_ay[m] = static_cast<int8_t>(w.ay);
         }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (!(info[k] & kAlive)) continue;
-            const int row = H - 1 - static_cast<int>(y[k]);  // y = (H-1-row) + 0.5 exactly (generate(): spawn)
-            if (info[k] & kMob) {
-                if (n_mobs >= kMaxMobs) __builtin_trap();
-                L.m_x[n_mobs][lane] = x[k];
-                L.m_vx[n_mobs][lane] = vx[k];
-                L.m_t[n_mobs][lane] = t[k];
-                L.m_row[n_mobs][lane] = static_cast<uint8_t>(row);
-                L.m_spawn[n_mobs][lane] = static_cast<uint8_t>(spawn[k]);
-                L.m_id[n_mobs][lane] = static_cast<uint8_t>(e0 + k);
-                L.m_info[n_mobs][lane] = static_cast<uint8_t>(info[k]);
-                n_mobs++;
-            } else {
-                if (n_gems >= kMaxGems) __builtin_trap();
-                L.g_col[n_gems][lane] = static_cast<uint8_t>(static_cast<int>(x[k]));  // x = col + 0.5 exactly
-                L.g_row[n_gems][lane] = static_cast<uint8_t>(row);
-                L.g_id[n_gems][lane] = static_cast<uint8_t>(e0 + k);
-                L.g_info[n_gems][lane] = static_cast<uint8_t>(info[k]);
-                n_gems++;
-            }
+        if (gem) {
+            const int k = n_gems + __popc(gems & below);
+            if (k >= kMaxGems) __builtin_trap();
+            L.g_col[k] = static_cast<uint8_t>(static_cast<int>(x));  // x = col + 0.5 exactly
+            L.g_row[k] = static_cast<uint8_t>(row);
+            L.g_id[k] = static_cast<uint8_t>(e);
+            L.g_info[k] = static_cast<uint8_t>(info);
         }
+        n_mobs += __popc(mobs);
+        n_gems += __popc(gems);
     }
-    // --- one tile window per mob, around the probe of its first sub-step, spare column on the side it is heading
-    for (int m0 = 0; __ballot(m0 < n_mobs); m0 += 2) {
-        Win w[2];
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int m = m0 + k;
-            w[k] = Win{tiles, 0, 0, 0};
-            if (m < n_mobs) {
-                const float vx = L.m_vx[m][lane];
-                const float y = static_cast<float>(H - 1 - L.m_row[m][lane]) + 0.5f;
-                const Box probe{L.m_x[m][lane] + vx * dt - 0.5f, y - 0.6f, 1.0f, 0.5f};
-                w[k] = Win::around(tiles, probe, vx, 0.0f);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int m = m0 + k;
-            if (m < n_mobs) {
-                L.m_win[m][lane] = w[k].bits;
-                L.m_ax[m][lane] = static_cast<int8_t>(w[k].ax);
-                L.m_ay[m][lane] = static_cast<int8_t>(w[k].ay);
-            }
-        }
-    }
+    wave_order();
 
-    int flags = active ? SI(s, I_FLAGS, env) : 0;
-    float ax = active ? SF(s, F_AX, env) : 0.0f, ay = active ? SF(s, F_AY, env) : 0.0f;
-    float avx = active ? SF(s, F_AVX, env) : 0.0f, avy = active ? SF(s, F_AVY, env) : 0.0f;
-    float phase = active ? SF(s, F_APHASE, env) : 0.0f, camy = active ? SF(s, F_CAMY, env) : 0.0f;
+    int flags = SI(s, I_FLAGS, env);
+    float ax = SF(s, F_AX, env), ay = SF(s, F_AY, env);
+    float avx = SF(s, F_AVX, env), avy = SF(s, F_AVY, env);
+    float phase = SF(s, F_APHASE, env), camy = SF(s, F_CAMY, env);
     bool ground = (flags & kFlagGround) != 0, forward = (flags & kFlagForward) != 0;
     const float max_jump = 1.55f, gravity = 0.2f, max_speed = 0.5f, mix = 0.2f, air_control = 0.15f;
     const float move_x = static_cast<float>((action == 6 || action == 7 || action == 8) -
@@ -381,99 +375,125 @@ PG_D void advance(const State& s, StepLds& L, int lane, bool active, int env, in
     float reward = 0.0f;
     bool terminated = false, set_changed = (flags & kFlagListed) == 0;
     Win awin{tiles, 0, 0, 0};
-    for (int ss = 0; ss < 4 && active; ss++) {
-        // --- System_Agent::update (common_systems.cpp:184-270)
-        {
-            const float mix_x = ground ? mix : (mix * air_control);
-            avx += mix_x * (max_speed * move_x - avx) * dt;
-            if (fabsf(avx) < mix_x * max_speed * dt) avx = 0.0f;
-            if (jump && ground) avy = -max_jump;
-            avy += gravity * dt;
-            if (fabsf(avy) > max_jump) avy = (avy > 0.0f ? 1.0f : -1.0f) * max_jump;
-            ax += avx * dt;
-            ay += avy * dt;
-            const Box body{ax + -0.5f, ay + -1.0f, 1.0f, 1.0f};
-            if (ss == 0 || !awin.holds(body)) awin = Win::around(tiles, body, avx, avy);
-            const TileHit h = collide_plain<true>(awin, body, is_wall);
-            const float moved_x = h.x - body.x, moved_y = h.y - body.y;
-            ground = moved_y < 0.0f && h.any;
-            ax = h.x - -0.5f;
-            ay = h.y - -1.0f;
-            if (moved_x != 0.0f) avx = 0.0f;
-            if (ground) avy = 0.0f;
-            camy = (ay - 8 - 0.5f) * kUnitPx;
-            phase += 0.1f * dt;
-            phase = fmodf(phase, 1.0f);
-            if (move_x > 0.0f)
-                forward = true;
-            else if (move_x < 0.0f)
-                forward = false;
-        }
-        const Box agent{ax + -0.5f, ay + -1.0f, 1.0f, 1.0f};
-        // --- mobs (common_systems.cpp:109-168), points (:66-107), animation (:8-39); all order-free per entity
+    for (int ss = 0; ss < 4; ss++) {
+        // --- System_Agent::update (common_systems.cpp:184-270), up to its get_collision
+        const float mix_x = ground ? mix : (mix * air_control);
+        avx += mix_x * (max_speed * move_x - avx) * dt;
+        if (fabsf(avx) < mix_x * max_speed * dt) avx = 0.0f;
+        if (jump && ground) avy = -max_jump;
+        avy += gravity * dt;
+        if (fabsf(avy) > max_jump) avy = (avy > 0.0f ? 1.0f : -1.0f) * max_jump;
+        ax += avx * dt;
+        ay += avy * dt;
+        const Box body{ax + -0.5f, ay + -1.0f, 1.0f, 1.0f};
+        if (ss == 0 || !awin.holds(body)) awin = Win::around(tiles, body, avx, avy);
+
+        // --- the colliders, kGang per pass: the agent, then the mobs (common_systems.cpp:109-168; order-free per entity)
         bool dead = false;
-        for (int m = 0; m < n_mobs; m++) {
-            float x = L.m_x[m][lane], vx = L.m_vx[m][lane];
-            int info = L.m_info[m][lane];
-            const float y = static_cast<float>(H - 1 - L.m_row[m][lane]) + 0.5f;
-            x += vx * dt;
-            const Box probe{x - 0.5f, y - 0.6f, 1.0f, 0.5f};
-            const Win win{tiles, L.m_ax[m][lane], L.m_ay[m][lane], L.m_win[m][lane]};
-            const TileHit w = collide_plain<true>(win, probe, is_wall);
-            x = w.x + 0.5f;
-            if (box_hit(agent, Box{x + -0.4f, y + -0.4f, 0.8f, 0.8f})) dead = true;
-            const int spawn_x = L.m_spawn[m][lane];
-            const bool end_patrol = x > spawn_x + 4 || x < spawn_x - 4;
-            if (w.any || end_patrol) vx *= -1.0f;
-            info = (info & ~kFlip) | (vx < 0.0f ? kFlip : 0);
-            float t = L.m_t[m][lane] + dt;
-            const int adv = static_cast<int>(t * 0.2f);
-            t -= adv / 0.2f;
-            const int frame = (((info & kFrame) ? 1 : 0) + adv) % 2;
-            info = (info & ~kFrame) | (frame ? kFrame : 0) | kTexSet;
-            L.m_x[m][lane] = x;
-            L.m_vx[m][lane] = vx;
-            L.m_t[m][lane] = t;
-            L.m_info[m][lane] = static_cast<uint8_t>(info);
-        }
-        int delta = 0, available = 0;
-        for (int g = 0; g < n_gems; g++) {
-            const int info = L.g_info[g][lane];
-            if (!(info & kAlive)) continue;
-            const float x = static_cast<float>(L.g_col[g][lane]) + 0.5f;
-            const float y = static_cast<float>(H - 1 - L.g_row[g][lane]) + 0.5f;
-            if (box_hit(agent, Box{x + -0.5f, y + -0.5f, 1.0f, 1.0f})) {
-                delta++;
-                L.g_info[g][lane] = static_cast<uint8_t>(info & ~kAlive);  // destroy_entity
-                set_changed = true;
-            } else {
-                available++;
+        Box agent{0.0f, 0.0f, 1.0f, 1.0f};
+        for (int c0 = 0; c0 < 1 + n_mobs; c0 += kGang) {
+            const int c = c0 + q.g, m = c - 1;
+            const bool is_agent = c == 0, is_mob = c >= 1 && c <= n_mobs;
+            float x = 0.0f, vx = 0.0f, y = 0.0f;
+            Box probe = body;
+            Win win = awin;
+            if (is_mob) {
+                x = L.m_x[m];
+                vx = L.m_vx[m];
+                y = static_cast<float>(H - 1 - L.m_row[m]) + 0.5f;
+                x += vx * dt;
+                probe = Box{x - 0.5f, y - 0.6f, 1.0f, 0.5f};
+                win = Win{tiles, L.m_ax[m], L.m_ay[m], L.m_win[m]};
             }
+            TileHit h{probe.x, probe.y, false};
+            if (is_agent | is_mob) h = collide_plain<true>(win, probe, is_wall);
+            if (c0 == 0) {  // the rest of the agent's update, from lane 0's result
+                const float hx = __shfl(h.x, 0, kGang), hy = __shfl(h.y, 0, kGang);
+                const bool any = __shfl(h.any ? 1 : 0, 0, kGang) != 0;
+                const float moved_x = hx - body.x, moved_y = hy - body.y;
+                ground = moved_y < 0.0f && any;
+                ax = hx - -0.5f;
+                ay = hy - -1.0f;
+                if (moved_x != 0.0f) avx = 0.0f;
+                if (ground) avy = 0.0f;
+                camy = (ay - 8 - 0.5f) * kUnitPx;
+                phase += 0.1f * dt;
+                phase = fmodf(phase, 1.0f);
+                if (move_x > 0.0f)
+                    forward = true;
+                else if (move_x < 0.0f)
+                    forward = false;
+                agent = Box{ax + -0.5f, ay + -1.0f, 1.0f, 1.0f};
+            }
+            bool bitten = false;
+            if (is_mob) {
+                int info = L.m_info[m];
+                x = h.x + 0.5f;
+                bitten = box_hit(agent, Box{x + -0.4f, y + -0.4f, 0.8f, 0.8f});
+                const int spawn_x = L.m_spawn[m];
+                const bool end_patrol = x > spawn_x + 4 || x < spawn_x - 4;
+                if (h.any || end_patrol) vx *= -1.0f;
+                info = (info & ~kFlip) | (vx < 0.0f ? kFlip : 0);
+                float t = L.m_t[m] + dt;
+                const int adv = static_cast<int>(t * 0.2f);
+                t -= adv / 0.2f;
+                const int frame = (((info & kFrame) ? 1 : 0) + adv) % 2;
+                info = (info & ~kFrame) | (frame ? kFrame : 0) | kTexSet;
+                L.m_x[m] = x;
+                L.m_vx[m] = vx;
+                L.m_t[m] = t;
+                L.m_info[m] = static_cast<uint8_t>(info);
+            }
+            if (q.any(bitten)) dead = true;
         }
+        // --- points (:66-107)
+        int delta = 0, available = 0;
+        for (int k0 = 0; k0 < n_gems; k0 += kGang) {
+            const int k = k0 + q.g;
+            const int info = k < n_gems ? L.g_info[k] : 0;
+            const bool alive = (info & kAlive) != 0;
+            const float x = static_cast<float>(k < n_gems ? L.g_col[k] : 0) + 0.5f;
+            const float y = static_cast<float>(H - 1 - (k < n_gems ? L.g_row[k] : 0)) + 0.5f;
+            const bool taken = alive && box_hit(agent, Box{x + -0.5f, y + -0.5f, 1.0f, 1.0f});
+            if (taken) L.g_info[k] = static_cast<uint8_t>(info & ~kAlive);  // destroy_entity
+            delta += __popc(q.ballot(taken));
+            available += __popc(q.ballot(alive && !taken));
+        }
+        if (delta) set_changed = true;
         reward = delta + (available == 0) * 10.0f;
         terminated = dead || (available == 0);
         if (terminated) break;
     }
     // Note: in the reference the mob loop runs before the point loop within a sub-step; the two never read each
     // other's data, so two loops per sub-step yield the same state.
-    if (!active) return;
-    for (int m = 0; m < n_mobs; m++) {
-        const int e = L.m_id[m][lane];
-        EF(s, EF_X, e, env) = L.m_x[m][lane];
-        EF(s, EF_VX, e, env) = L.m_vx[m][lane];
-        EF(s, EF_ANIM_T, e, env) = L.m_t[m][lane];
-        EB(s, EB_INFO, e, env) = L.m_info[m][lane];
+    for (int m0 = 0; m0 < n_mobs; m0 += kGang) {
+        const int m = m0 + q.g;
+        if (m < n_mobs) {
+            const int e = L.m_id[m];
+            EF(s, EF_X, e, env) = L.m_x[m];
+            EF(s, EF_VX, e, env) = L.m_vx[m];
+            EF(s, EF_ANIM_T, e, env) = L.m_t[m];
+            EB(s, EB_INFO, e, env) = L.m_info[m];
+        }
     }
     if (set_changed)
-        for (int g = 0; g < n_gems; g++) EB(s, EB_INFO, L.g_id[g][lane], env) = L.g_info[g][lane];
-    SF(s, F_AX, env) = ax;
-    SF(s, F_AY, env) = ay;
-    SF(s, F_AVX, env) = avx;
-    SF(s, F_AVY, env) = avy;
-    SF(s, F_APHASE, env) = phase;
-    SF(s, F_CAMY, env) = camy;
-    SI(s, I_FLAGS, env) = kFlagListed | (ground ? kFlagGround : 0) | (forward ? kFlagForward : 0);
-    if (set_changed) rebuild_draw_list(s, env, n_ent);
+        for (int k0 = 0; k0 < n_gems; k0 += kGang) {
+            const int k = k0 + q.g;
+            if (k < n_gems) EB(s, EB_INFO, L.g_id[k], env) = L.g_info[k];
+        }
+    if (q.g == 0) {
+        SF(s, F_AX, env) = ax;
+        SF(s, F_AY, env) = ay;
+        SF(s, F_AVX, env) = avx;
+        SF(s, F_AVY, env) = avy;
+        SF(s, F_APHASE, env) = phase;
+        SF(s, F_CAMY, env) = camy;
+        SI(s, I_FLAGS, env) = kFlagListed | (ground ? kFlagGround : 0) | (forward ? kFlagForward : 0);
+    }
+    if (set_changed) {
+        gang_fence();  // the info bytes just written, for the lanes that read them below
+        rebuild_draw_list(s, q, env, n_ent);
+    }
     reward_out = reward;
     terminated_out = terminated;
 }
@@ -485,26 +505,26 @@ __global__ void __launch_bounds__(64) make_kernel(State s, uint32_t seed_base, i
     fresh_live(s, env);
 }
 
-__global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actions, uint32_t run_seed,
-                                                   uint32_t step_index, int env_offset, StepIO io) {
-    __shared__ StepLds L;
-    const int lane = threadIdx.x;
-    const int env = blockIdx.x * 64 + lane;
-    bool active = env < s.n;
-    if (active && io.pending[env] == 2) {  // reset by the level kernel in this step
-        io.pending[env] = 0;
-        active = false;
+__global__ void __launch_bounds__(64, PG_CLIMBER_WAVES) logic_kernel(State s, const int32_t* actions, uint32_t run_seed,
+                                                                     uint32_t step_index, int env_offset, StepIO io) {
+    __shared__ StepLds lds[64 / kGang];
+    const int env = (blockIdx.x * 64 + threadIdx.x) / kGang;
+    if (env >= s.n) return;
+    const Q q = Q::at(threadIdx.x);
+    if (io.pending[env] == 2) {  // reset by the level kernel in this step
+        if (q.g == 0) io.pending[env] = 0;
+        return;
     }
-    const int action = !active ? 0
-                       : actions ? actions[env]
-                                 : synthetic_action(run_seed, step_index, static_cast<uint32_t>(env_offset + env));
+    const int action =
+        actions ? actions[env] : synthetic_action(run_seed, step_index, static_cast<uint32_t>(env_offset + env));
     float reward = 0.0f;
     bool terminated = false;
-    advance(s, L, lane, active, env, action, reward, terminated);  // every lane goes in: the staging loops are wave-wide
-    if (!active) return;
-    io.reward[env] = reward;
-    io.done[env] = terminated ? 1 : 0;
-    io.pending[env] = terminated ? 1 : 0;
+    advance(s, lds[(threadIdx.x & 63) / kGang], q, env, action, reward, terminated);
+    if (q.g == 0) {
+        io.reward[env] = reward;
+        io.done[env] = terminated ? 1 : 0;
+        io.pending[env] = terminated ? 1 : 0;
+    }
 }
 
 // render_game(true) (climber.cpp:431-459): one workgroup of two wavefronts per env (pg_render.h).
@@ -740,8 +760,8 @@ class ClimberGame final : public Game {
         l.tiles = take(size_t(n) * W * H);
         l.f = take(size_t(F_COUNT) * n * 4);
         l.i = take(size_t(I_COUNT) * n * 4);
-        l.ef = take(size_t(EF_COUNT) * kMaxEnt * n * 4);
-        l.eb = take(size_t(EB_COUNT) * kMaxEnt * n);
+        l.ef = take(size_t(EF_COUNT) * kEntStride * n * 4);
+        l.eb = take(size_t(EB_COUNT) * kEntStride * n);
         l.total = off;
         return l;
     }
@@ -778,7 +798,7 @@ class ClimberGame final : public Game {
     void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
                       StepIO io) override {
         LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io, plan);
-        hipLaunchKernelGGL(logic_kernel, dim3((s_.n + 63) / 64), dim3(64), 0, st, s_, actions, run_seed, step_index,
+        hipLaunchKernelGGL(logic_kernel, dim3((s_.n * kGang + 63) / 64), dim3(64), 0, st, s_, actions, run_seed, step_index,
                            env_offset, io);
     }
     bool launch_frame(hipStream_t st, int env, uint32_t* d_px, int w, int h) override {
@@ -811,8 +831,8 @@ class ClimberGame final : public Game {
                                 static_cast<float>(n_ent)};
         for (int e = 0; e < n_ent; e++) {
             uint8_t info;
-            hipMemcpy(&info, s_.eb + (size_t(EB_INFO) * kMaxEnt + e) * n + env, 1, hipMemcpyDeviceToHost);
-            auto ef = [&](int field) { return rf(s_.ef, (size_t(field) * kMaxEnt + e) * n + env); };
+            hipMemcpy(&info, s_.eb + (size_t(env) * EB_COUNT + EB_INFO) * kEntStride + e, 1, hipMemcpyDeviceToHost);
+            auto ef = [&](int field) { return rf(s_.ef, (size_t(env) * EF_COUNT + field) * kEntStride + e); };
             v.push_back((info & kAlive) ? 1.0f : 0.0f);
             v.push_back(ef(EF_X));
             v.push_back(ef(EF_Y));
