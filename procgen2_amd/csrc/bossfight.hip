@@ -65,7 +65,7 @@ enum {
 constexpr int kFlagAlive = 1, kFlagListed = 2;
 // I_SKINS: a_ship | a_laser<<4 | b_ship<<8 | b_laser<<12 | backdrop<<16
 // shot fields (floats); agent shots also have a "bouncing" byte
-enum { S_X, S_Y, S_VX, S_VY, S_ROT, S_FRAME, S_BOUNCE_T, S_SN, S_CS, S_COUNT };  // S_SN/S_CS (boss bullets): the drawing angle as raster spec S6 takes it, int bits, fixed when fired
+enum { S_X, S_Y, S_VX, S_VY, S_FRAME, S_BOUNCE_T, S_ROT, S_SN, S_CS, S_COUNT };  // S_SN/S_CS (boss bullets): the drawing angle as raster spec S6 takes it, int bits, fixed when fired
 
 // The rings are per-env contiguous ([env][field][slot]): a gang's lanes and the render wavefront's lanes both index
 // them by slot, so one field of one env is one coalesced request.  Scalars are [field][env].
@@ -213,6 +213,20 @@ constexpr int kBoomGang = kGang < kBooms ? kGang : kBooms;  // lanes of a trip o
 using Q = Gang<kGang>;
 using Rng = GangRng<kGang>;
 
+// The three rings of an env while its gang steps it: the slots that hold something are read once, before the first
+// sub-step, into LDS — indexable registers: a slot is only ever touched by the lane that owns it — and the slots that
+// changed go back after the last, so the eight trips of a step wait for LDS instead of for a store and a load each.
+struct RingsLds {  // one per gang
+    float b[S_FRAME + 1][kBossShots];       // S_X .. S_FRAME of the boss's bullets
+    float a[S_BOUNCE_T + 1][kAgentShots];   // … and S_BOUNCE_T of the agent's
+    uint8_t a_bouncing[kAgentShots];
+    float boom[kBooms];                     // frame
+};
+static_assert(S_X == 0 && S_FRAME == 4 && S_BOUNCE_T == 5, "the ring fields staged in LDS come first");
+struct Rings {  // a lane's view: the gang's rings, and which of ITS slots it has written (bit j: slot g + width·j)
+    RingsLds* lds;
+    uint32_t dirty_a, dirty_b, dirty_x;
+};
 struct Live {  // the hot scalars of one env, kept in registers over the four sub-steps
     float ax, ay, avx, avy, atimer;
     float bx, by, bvx, bvy, phase_t, attack_t, explo_t, damage_t, move_t;
@@ -236,13 +250,13 @@ PG_D bool hits_a_rock(const Live& v, const Box& sb) {
 // `shots` calls of fire_bullet one after the other (common_systems.cpp:75-88; each fires only while fewer than 64 are
 // in flight): shot j goes into ring slot b_next + j, written by the lane that owns the slot.
 template <class Rot>
-PG_D void boss_volley(const State& s, int env, Live& v, Q q, int shots, float speed, Rot rotation_of_shot) {
+PG_D void boss_volley(const State& s, Rings& R, int env, Live& v, Q q, int shots, float speed, Rot rotation_of_shot) {
     const int room = kBossShots - v.b_count;
     const int fired = shots < room ? shots : room;
     for (int j = (q.g - v.b_next) & (kGang - 1); j < fired; j += kGang) {
         const int k = (v.b_next + j) & (kBossShots - 1);
         const float rotation = rotation_of_shot(j);
-        BS(s, S_ROT, k, env) = rotation;
+        BS(s, S_ROT, k, env) = rotation;  // (angle, sine and cosine: for the render kernels only, straight to memory)
         {   // what System_Mob_AI::render's angle (rotation + π/2) comes to in the raster (pg_render.h rotation_of): once
             // per bullet here, instead of sinf and cosf in every lane of both render wavefronts every frame
             int sn, cs;
@@ -250,30 +264,31 @@ PG_D void boss_volley(const State& s, int env, Live& v, Q q, int shots, float sp
             BS(s, S_SN, k, env) = __int_as_float(sn);
             BS(s, S_CS, k, env) = __int_as_float(cs);
         }
-        BS(s, S_VX, k, env) = sc_cosf(rotation) * speed;
-        BS(s, S_VY, k, env) = -sc_sinf(rotation) * speed;
-        BS(s, S_X, k, env) = v.bx;
-        BS(s, S_Y, k, env) = v.by;
-        BS(s, S_FRAME, k, env) = 0.0f;
+        R.lds->b[S_VX][k] = sc_cosf(rotation) * speed;
+        R.lds->b[S_VY][k] = -sc_sinf(rotation) * speed;
+        R.lds->b[S_X][k] = v.bx;
+        R.lds->b[S_Y][k] = v.by;
+        R.lds->b[S_FRAME][k] = 0.0f;
+        R.dirty_b |= 1u << (k / kGang);
     }
     v.b_next = (v.b_next + fired) & (kBossShots - 1);
     v.b_count += fired;
 }
 
-PG_D void fire_pattern(const State& s, int env, Live& v, Rng& rng, Q q, int pattern, float dt) {  // :103-185
+PG_D void fire_pattern(const State& s, Rings& R, int env, Live& v, Rng& rng, Q q, int pattern, float dt) {  // :103-185
     const float bullet_speed = kBossBulletSpeed;
     float& timer = v.attack_t;
     switch (pattern) {
         case -1:
             if (rng.real(0.0f, 1.0f) < 0.1f * dt) {
                 const float rot = static_cast<float>(kPi * (1.0f + rng.real(0.0f, 1.0f)));
-                boss_volley(s, env, v, q, 1, bullet_speed, [&](int) { return rot; });
+                boss_volley(s, R, env, v, q, 1, bullet_speed, [&](int) { return rot; });
             }
             break;
         case 0:
             if (timer >= 8.0f) {
                 timer = 0.0f;
-                boss_volley(s, env, v, q, 5, bullet_speed,
+                boss_volley(s, R, env, v, q, 5, bullet_speed,
                             [](int k) { return static_cast<float>(kPi * 1.5f + (k - 2) * kPi * 0.125f); });
             } else
                 timer += dt;
@@ -283,7 +298,7 @@ PG_D void fire_pattern(const State& s, int env, Live& v, Rng& rng, Q q, int patt
                 timer = 0.0f;
                 int w = static_cast<int>(timer / 5.0f);
                 w = abs(8 - (w % 16));
-                boss_volley(s, env, v, q, 4, bullet_speed,
+                boss_volley(s, R, env, v, q, 4, bullet_speed,
                             [w](int k) { return static_cast<float>(kPi * (1.25f + w * 0.0625f) + k * kPi * 0.5f); });
             } else
                 timer += dt;
@@ -292,7 +307,7 @@ PG_D void fire_pattern(const State& s, int env, Live& v, Rng& rng, Q q, int patt
             if (timer >= 10.0f) {
                 timer = 0.0f;
                 const float offset = static_cast<float>(rng.real(0.0f, 1.0f) * 2.0f * kPi);
-                boss_volley(s, env, v, q, 8, bullet_speed,
+                boss_volley(s, R, env, v, q, 8, bullet_speed,
                             [offset](int k) { return static_cast<float>(kPi * 0.25f * k + offset); });
             } else
                 timer += dt;
@@ -301,14 +316,14 @@ PG_D void fire_pattern(const State& s, int env, Live& v, Rng& rng, Q q, int patt
             if (timer >= 4.0f) {
                 timer = 0.0f;
                 const float rot = static_cast<float>(kPi * (1.0f + rng.real(0.0f, 1.0f)));
-                boss_volley(s, env, v, q, 1, bullet_speed, [&](int) { return rot; });
+                boss_volley(s, R, env, v, q, 1, bullet_speed, [&](int) { return rot; });
             } else
                 timer += dt;
             break;
     }
 }
 
-PG_D bool agent_update(const State& s, int env, Live& v, Rng& rng, Q q, float dt, int action) {  // :494-683
+PG_D bool agent_update(const State& s, Rings& R, int env, Live& v, Rng& rng, Q q, float dt, int action) {  // :494-683
     const float mixrate = 0.5f, speed = 0.1f, bullet_time = 5.0f, bullet_speed = 0.1f;
     const float bounce_speed = 0.05f, bounce_time = 10.0f, explosion_rate = 0.3f;
     const Box scr = v.scr;
@@ -343,13 +358,14 @@ PG_D bool agent_update(const State& s, int env, Live& v, Rng& rng, Q q, float dt
             const int k = v.a_next;
             if ((k & (kGang - 1)) == q.g) {
                 AS(s, S_ROT, k, env) = 0.0f;
-                AS(s, S_VX, k, env) = 0.0f;
-                AS(s, S_VY, k, env) = -bullet_speed;
-                AS(s, S_X, k, env) = v.ax;
-                AS(s, S_Y, k, env) = v.ay;
-                AS(s, S_FRAME, k, env) = 0.0f;
-                AS(s, S_BOUNCE_T, k, env) = 0.0f;
-                AB(s, k, env) = 0;
+                R.lds->a[S_VX][k] = 0.0f;
+                R.lds->a[S_VY][k] = -bullet_speed;
+                R.lds->a[S_X][k] = v.ax;
+                R.lds->a[S_Y][k] = v.ay;
+                R.lds->a[S_FRAME][k] = 0.0f;
+                R.lds->a[S_BOUNCE_T][k] = 0.0f;
+                R.lds->a_bouncing[k] = 0;
+                R.dirty_a |= 1u << (k / kGang);
             }
             v.a_next = (v.a_next + 1) % kAgentShots;
             v.a_count++;
@@ -375,13 +391,13 @@ PG_D bool agent_update(const State& s, int env, Live& v, Rng& rng, Q q, float dt
         float frame0 = -1.0f, px = 0.0f, py = 0.0f, vx = 0.0f, vy = 0.0f, btimer = 0.0f;
         bool bouncing = false;
         if (mine) {
-            frame0 = AS(s, S_FRAME, k, env);
-            px = AS(s, S_X, k, env);
-            py = AS(s, S_Y, k, env);
-            vx = AS(s, S_VX, k, env);
-            vy = AS(s, S_VY, k, env);
-            btimer = AS(s, S_BOUNCE_T, k, env);
-            bouncing = AB(s, k, env) != 0;
+            frame0 = R.lds->a[S_FRAME][k];
+            px = R.lds->a[S_X][k];
+            py = R.lds->a[S_Y][k];
+            vx = R.lds->a[S_VX][k];
+            vy = R.lds->a[S_VY][k];
+            btimer = R.lds->a[S_BOUNCE_T][k];
+            bouncing = R.lds->a_bouncing[k] != 0;
         }
         const bool live = mine & (frame0 != -1.0f);
         const Box sb{px - 0.01f, py - 0.01f, 0.02f, 0.02f};
@@ -414,13 +430,14 @@ PG_D bool agent_update(const State& s, int env, Live& v, Rng& rng, Q q, float dt
         btimer = (bouncing & ticking) ? fmaxf(0.0f, btimer - dt) : btimer;
         frame = destroyed ? -1.0f : frame;
         if (act) {
-            AS(s, S_X, k, env) = px;
-            AS(s, S_Y, k, env) = py;
-            AS(s, S_VX, k, env) = vx;
-            AS(s, S_VY, k, env) = vy;
-            AS(s, S_FRAME, k, env) = frame;
-            AS(s, S_BOUNCE_T, k, env) = btimer;
-            AB(s, k, env) = bouncing ? 1 : 0;
+            R.lds->a[S_X][k] = px;
+            R.lds->a[S_Y][k] = py;
+            R.lds->a[S_VX][k] = vx;
+            R.lds->a[S_VY][k] = vy;
+            R.lds->a[S_FRAME][k] = frame;
+            R.lds->a[S_BOUNCE_T][k] = btimer;
+            R.lds->a_bouncing[k] = bouncing ? 1 : 0;
+            R.dirty_a |= 1u << (k / kGang);
         }
         count -= __popc(q.ballot(destroyed & act));
     }
@@ -428,7 +445,7 @@ PG_D bool agent_update(const State& s, int env, Live& v, Rng& rng, Q q, float dt
     return v.a_alive;
 }
 
-PG_D bool boss_update(const State& s, int env, Live& v, Rng& rng, Q q, float dt) {  // :199-390
+PG_D bool boss_update(const State& s, Rings& R, int env, Live& v, Rng& rng, Q q, float dt) {  // :199-390
     const float shielded_time = 180.0f + rng.real(0.0f, 1.0f) * kShieldedSpread;  // drawn every sub-step (D14)
     const float unshielded_time = 300.0f, explosion_rate = 0.3f, move_time = 70.0f, damage_time = 80.0f;
     const int boss_hp = 3;
@@ -447,14 +464,14 @@ PG_D bool boss_update(const State& s, int env, Live& v, Rng& rng, Q q, float dt)
             v.phase++;
         } else
             v.phase_t += dt;
-        fire_pattern(s, env, v, rng, q, v.weapon, dt);
+        fire_pattern(s, R, env, v, rng, q, v.weapon, dt);
     } else {
         if (v.phase_t >= unshielded_time) {
             v.phase_t = 0.0f;
             v.phase++;
         } else
             v.phase_t += dt;
-        fire_pattern(s, env, v, rng, q, -1, dt);
+        fire_pattern(s, R, env, v, rng, q, -1, dt);
         if (v.hp == 0) {
             if (v.explo_t >= 8.0f) {  // show_damage → explode (:187-197, :91-101)
                 v.explo_t = 0.0f;
@@ -464,7 +481,8 @@ PG_D bool boss_update(const State& s, int env, Live& v, Rng& rng, Q q, float dt)
                     if ((v.x_next & (kBoomGang - 1)) == q.g) {
                         BM(s, 0, v.x_next, env) = ox;
                         BM(s, 1, v.x_next, env) = oy;
-                        BM(s, 2, v.x_next, env) = 0.0f;
+                        R.lds->boom[v.x_next] = 0.0f;
+                        R.dirty_x |= 1u << (v.x_next / kBoomGang);
                     }
                     v.x_next = (v.x_next + 1) % kBooms;
                     v.x_count++;
@@ -501,11 +519,11 @@ PG_D bool boss_update(const State& s, int env, Live& v, Rng& rng, Q q, float dt)
             const bool mine = t.i < count;
             float frame0 = -1.0f, px = 0.0f, py = 0.0f, vx = 0.0f, vy = 0.0f;
             if (mine) {
-                frame0 = BS(s, S_FRAME, k, env);
-                px = BS(s, S_X, k, env);
-                py = BS(s, S_Y, k, env);
-                vx = BS(s, S_VX, k, env);
-                vy = BS(s, S_VY, k, env);
+                frame0 = R.lds->b[S_FRAME][k];
+                px = R.lds->b[S_X][k];
+                py = R.lds->b[S_Y][k];
+                vx = R.lds->b[S_VX][k];
+                vy = R.lds->b[S_VY][k];
             }
             const bool live = mine & (frame0 != -1.0f);
             const Box sb{px - 0.01f, py - 0.01f, 0.02f, 0.02f};
@@ -528,11 +546,12 @@ PG_D bool boss_update(const State& s, int env, Live& v, Rng& rng, Q q, float dt)
             const bool burns = moves & !gone & (frame >= 1.0f);
             frame = gone ? -1.0f : (burns ? frame + explosion_rate * dt : frame);
             if (act) {
-                BS(s, S_X, k, env) = px;
-                BS(s, S_Y, k, env) = py;
-                BS(s, S_VX, k, env) = vx;
-                BS(s, S_VY, k, env) = vy;
-                BS(s, S_FRAME, k, env) = frame;
+                R.lds->b[S_X][k] = px;
+                R.lds->b[S_Y][k] = py;
+                R.lds->b[S_VX][k] = vx;
+                R.lds->b[S_VY][k] = vy;
+                R.lds->b[S_FRAME][k] = frame;
+                R.dirty_b |= 1u << (k / kGang);
             }
             count -= __popc(q.ballot(gone & act));
             struck = strike_list != 0;  // later bullets skip this sub-step (D14)
@@ -545,12 +564,15 @@ PG_D bool boss_update(const State& s, int env, Live& v, Rng& rng, Q q, float dt)
         for (int i0 = 0; i0 < count; i0 += kBoomGang) {
             const Q::Trip t = q.trip<kBooms, kBoomGang>(v.x_next, i0);
             const bool mine = (q.g < kBoomGang) & (t.i < count);
-            float frame = mine ? BM(s, 2, t.slot, env) : -1.0f;
+            float frame = mine ? R.lds->boom[t.slot] : -1.0f;
             const bool live = mine & (frame != -1.0f);
             const bool gone = live & (frame >= 4.0f);
             const bool act = live & (t.i < count - Q::before(q.ranked<kBoomGang>(t, gone), t.rank));
             frame = gone ? -1.0f : (frame >= 0.0f ? frame + explosion_rate * dt : frame);
-            if (act) BM(s, 2, t.slot, env) = frame;
+            if (act) {
+                R.lds->boom[t.slot] = frame;
+                R.dirty_x |= 1u << (t.slot / kBoomGang);
+            }
             count -= __popc(q.ballot(gone & act));
         }
         v.x_count = count;
@@ -559,7 +581,7 @@ PG_D bool boss_update(const State& s, int env, Live& v, Rng& rng, Q q, float dt)
     return alive;
 }
 
-PG_D void advance(const State& s, Q q, int env, int action, float& reward_out, bool& terminated_out) {
+PG_D void advance(const State& s, Rings& R, Q q, int env, int action, float& reward_out, bool& terminated_out) {
     Rng rng = Rng::open(s.mt + size_t(env) * kMtWords, q);
     const int flags = SI(s, I_FLAGS, env);
     Live v;
@@ -596,17 +618,61 @@ PG_D void advance(const State& s, Q q, int env, int action, float& reward_out, b
         v.rock_y[k] = RK(s, 1, k, env);
     }
 
+    // stage the slots that hold something (list positions below the counts), each by its owner
+    R.dirty_a = R.dirty_b = R.dirty_x = 0u;
+#pragma unroll
+    for (int j = 0; j < kBossShots / kGang; j++) {
+        const int k = q.g + kGang * j;
+        if (((v.b_next - 1 - k) & (kBossShots - 1)) < v.b_count) {
+#pragma unroll
+            for (int f = S_X; f <= S_FRAME; f++) R.lds->b[f][k] = BS(s, f, k, env);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < (kAgentShots + kGang - 1) / kGang; j++) {
+        const int k = q.g + kGang * j;
+        if (k < kAgentShots && ((v.a_next - 1 - k) & (kAgentShots - 1)) < v.a_count) {
+#pragma unroll
+            for (int f = S_X; f <= S_BOUNCE_T; f++) R.lds->a[f][k] = AS(s, f, k, env);
+            R.lds->a_bouncing[k] = AB(s, k, env);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kBooms / kBoomGang; j++) {
+        const int k = q.g + kBoomGang * j;
+        if (q.g < kBoomGang && ((v.x_next - 1 - k) & (kBooms - 1)) < v.x_count) R.lds->boom[k] = BM(s, 2, k, env);
+    }
+
     const float dt = 1.0f / 4;
     float reward = 0.0f;
     bool terminated = false;
     for (int ss = 0; ss < 4; ss++) {
-        const bool agent_alive = agent_update(s, env, v, rng, q, dt, action);
-        const bool boss_alive = boss_update(s, env, v, rng, q, dt);
+        const bool agent_alive = agent_update(s, R, env, v, rng, q, dt, action);
+        const bool boss_alive = boss_update(s, R, env, v, rng, q, dt);
         reward = (!agent_alive) * -10.0f + (!boss_alive) * 10.0f;
         terminated = !agent_alive || !boss_alive;
         if (terminated) break;
     }
     rng.close();
+    // the slots this lane wrote, back to memory
+#pragma unroll
+    for (int j = 0; j < kBossShots / kGang; j++)
+        if ((R.dirty_b >> j) & 1u) {
+            const int k = q.g + kGang * j;
+#pragma unroll
+            for (int f = S_X; f <= S_FRAME; f++) BS(s, f, k, env) = R.lds->b[f][k];
+        }
+#pragma unroll
+    for (int j = 0; j < (kAgentShots + kGang - 1) / kGang; j++)
+        if ((R.dirty_a >> j) & 1u) {
+            const int k = q.g + kGang * j;
+#pragma unroll
+            for (int f = S_X; f <= S_BOUNCE_T; f++) AS(s, f, k, env) = R.lds->a[f][k];
+            AB(s, k, env) = R.lds->a_bouncing[k];
+        }
+#pragma unroll
+    for (int j = 0; j < kBooms / kBoomGang; j++)
+        if ((R.dirty_x >> j) & 1u) BM(s, 2, q.g + kBoomGang * j, env) = R.lds->boom[q.g + kBoomGang * j];
     if (q.g == 0) {
         if (cam_w != kCamSize || cam_h != kCamSize) {
             SF(s, F_CAMW, env) = kCamSize;
@@ -721,9 +787,11 @@ __global__ void __launch_bounds__(64, PG_BOSSFIGHT_WAVES) logic_kernel(State s, 
     }
     const int action =
         actions ? actions[env] : synthetic_action(run_seed, step_index, static_cast<uint32_t>(env_offset + env));
+    __shared__ RingsLds rings[64 / kGang];
+    Rings R{&rings[(threadIdx.x & 63) / kGang], 0u, 0u, 0u};
     float reward;
     bool terminated;
-    advance(s, q, env, action, reward, terminated);
+    advance(s, R, q, env, action, reward, terminated);
     if (q.g == 0) {
         io.reward[env] = reward;
         io.done[env] = terminated ? 1 : 0;
