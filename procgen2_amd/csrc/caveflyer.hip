@@ -324,31 +324,31 @@ PG_D void install(const State& s, int env, const Level& lv, int lane) {
 // ------------------------------------------------------------------------------------------------
 // step
 // ------------------------------------------------------------------------------------------------
-// One env = one gang (pg_gang.h).  The ship's scalars are uniform over the gang.  Entity e is dealt to lane e mod kGang,
-// which keeps its position (and an enemy's velocity) in registers for the four sub-steps — the hazard test of the ship,
-// the first-hit search of a flying bullet and the enemies' own moves all run kGang entities at a time — and writes back
-// what changed.  Bullet ring slot k and particle k belong to lane k mod kGang.
+// One env = one gang (pg_gang.h).  The ship's scalars are uniform over the gang.  The env's entity table (positions, info,
+// place in the hazard order, the enemies' velocities) and its map (one word of wall bits per column) are staged in LDS
+// for the four sub-steps; the hazard test of the ship, the first-hit search of a flying bullet and the enemies' own
+// moves all run kGang entities at a time — entity e is always handled by lane e mod kGang — and what changed goes back
+// at the end.  Bullet ring slot k and particle k belong to lane k mod kGang.
 #ifndef PG_CAVEFLYER_GANG
-#define PG_CAVEFLYER_GANG 16
+#define PG_CAVEFLYER_GANG 8
 #endif
 #ifndef PG_CAVEFLYER_WAVES
 #define PG_CAVEFLYER_WAVES 4  // wavefronts per SIMD the logic kernel's registers are capped for
 #endif
 constexpr int kGang = PG_CAVEFLYER_GANG;
-constexpr int kPerLane = (kMaxEnt + kGang - 1) / kGang;    // entities a lane holds
+constexpr int kMaxEnemies = (kMaxEnt - 2) / 3 + 1;
+struct StepLds {  // one per gang
+    uint64_t cols[W];
+    float x[kEntStride], y[kEntStride];
+    float vx[kMaxEnemies], vy[kMaxEnemies];  // of enemy first_enemy + j
+    uint8_t info[kEntStride], place[kEntStride];
+};
 constexpr int kPuffsPerLane = (kPuffs + kGang - 1) / kGang;
 using Q = Gang<kGang>;
 static_assert(kGang >= 8, "six lanes share a sub-step's trigonometry");
 
 PG_D bool hit(const Box& a, const Box& b) {  // box_hit without short circuits
     return (a.x < b.x + b.w) & (a.x + a.w > b.x) & (a.y < b.y + b.h) & (a.y + a.h > b.y);
-}
-template <class T, int N>
-PG_D T pick(const T (&table)[N], int t) {  // table[t] of a table that lives in registers
-    T v = table[0];
-#pragma unroll
-    for (int u = 1; u < N; u++) v = t == u ? table[u] : v;
-    return v;
 }
 PG_D Box thing_box(float x, float y, int kind) {
     const bool big = (kind == kEnemy) | (kind == kGoal);
@@ -369,25 +369,23 @@ PG_D void rebuild_draw_list(const State& s, int env, int n_ent) {
     SI(s, I_NDRAW, env) = n;
 }
 
-PG_D void advance(const State& s, Q q, int env, const uint64_t* cols, int action, float& reward_out, bool& terminated_out) {
+PG_D void advance(const State& s, StepLds& L, Q q, int env, int action, float& reward_out, bool& terminated_out) {
     const int n_ent = SI(s, I_NENT, env);
-    // my entities: e = g + kGang·t
-    float ex[kPerLane], ey[kPerLane], evx[kPerLane], evy[kPerLane];
-    int einfo[kPerLane], eplace[kPerLane];
-#pragma unroll
-    for (int t = 0; t < kPerLane; t++) {
-        const int e = q.g + kGang * t;
-        const bool ok = e < n_ent;
-        einfo[t] = ok ? EB(s, EB_INFO, e, env) : 0;
-        eplace[t] = (ok && e >= 2) ? EB(s, EB_PLACE_H, e, env) : 0;
-        ex[t] = ok ? EF(s, EF_X, e, env) : 0.0f;
-        ey[t] = ok ? EF(s, EF_Y, e, env) : 0.0f;
-        evx[t] = ok ? EF(s, EF_VX, e, env) : 0.0f;
-        evy[t] = ok ? EF(s, EF_VY, e, env) : 0.0f;
-        if (e < 2) einfo[t] = 0;  // the goal and the ship are not in the hazard set
-    }
-    const float goal_x = EF(s, EF_X, 0, env), goal_y = EF(s, EF_Y, 0, env);
     const int first_enemy = 2 + 2 * ((n_ent - 2) / 3);  // meteors, targets, enemies: a third of the objects each
+    const uint64_t* cols = L.cols;
+    for (int x = q.g; x < W; x += kGang) L.cols[x] = s.cols[size_t(env) * W + x];
+    for (int e = q.g; e < n_ent; e += kGang) {  // (the goal and the ship are not in the hazard set: info 0)
+        L.info[e] = e >= 2 ? EB(s, EB_INFO, e, env) : 0;
+        L.place[e] = e >= 2 ? EB(s, EB_PLACE_H, e, env) : 0;
+        L.x[e] = EF(s, EF_X, e, env);
+        L.y[e] = EF(s, EF_Y, e, env);
+        if (e >= first_enemy) {
+            L.vx[e - first_enemy] = EF(s, EF_VX, e, env);
+            L.vy[e - first_enemy] = EF(s, EF_VY, e, env);
+        }
+    }
+    wave_order();
+    const float goal_x = L.x[0], goal_y = L.y[0];
     float puff_life[kPuffsPerLane];
 #pragma unroll
     for (int p = 0; p < kPuffsPerLane; p++) {
@@ -478,9 +476,12 @@ PG_D void advance(const State& s, Q q, int env, const uint64_t* cols, int action
         }
         {   // hazards: any hit kills, order-free
             bool crash = false;
-#pragma unroll
-            for (int t = 0; t < kPerLane; t++)
-                crash = crash | (((einfo[t] & kAlive) != 0) & hit(body, thing_box(ex[t], ey[t], einfo[t] & kKindMask)));
+            for (int e0 = 0; e0 < n_ent; e0 += kGang) {
+                const int e = e0 + q.g;
+                const int info = e < n_ent ? L.info[e] : 0;
+                const float x = e < n_ent ? L.x[e] : 0.0f, y = e < n_ent ? L.y[e] : 0.0f;
+                crash = crash | (((info & kAlive) != 0) & hit(body, thing_box(x, y, info & kKindMask)));
+            }
             if (q.any(crash)) alive = false;
         }
         if (hit(body, thing_box(goal_x, goal_y, kGoal))) achieved_goal = true;
@@ -522,11 +523,13 @@ PG_D void advance(const State& s, Q q, int env, const uint64_t* cols, int action
                         const Box other{__shfl(sb.x, from, kGang), __shfl(sb.y, from, kGang), 0.02f, 0.02f};
                         // key = place in the hazard order · 1024 + entity · 4 + kind; the smallest touched one wins
                         int best = 0x7fffffff;
-#pragma unroll
-                        for (int u = 0; u < kPerLane; u++) {
-                            const int kind = einfo[u] & kKindMask;
-                            const bool touched = ((einfo[u] & kAlive) != 0) & hit(other, thing_box(ex[u], ey[u], kind));
-                            const int key = (eplace[u] << 10) | ((q.g + kGang * u) << 2) | kind;
+                        for (int e0 = 0; e0 < n_ent; e0 += kGang) {
+                            const int e = e0 + q.g;
+                            const int info = e < n_ent ? L.info[e] : 0;
+                            const float x = e < n_ent ? L.x[e] : 0.0f, y = e < n_ent ? L.y[e] : 0.0f;
+                            const int kind = info & kKindMask;
+                            const bool touched = ((info & kAlive) != 0) & hit(other, thing_box(x, y, kind));
+                            const int key = ((e < n_ent ? L.place[e] : 0) << 10) | (e << 2) | kind;
                             best = (touched & (key < best)) ? key : best;
                         }
 #pragma unroll
@@ -538,12 +541,11 @@ PG_D void advance(const State& s, Q q, int env, const uint64_t* cols, int action
                             if (q.g == from) stops = true;
                             if ((best & 3) == kTarget) {  // destroy_entity
                                 const int e = (best >> 2) & 255;
-#pragma unroll
-                                for (int u = 0; u < kPerLane; u++)
-                                    if (q.g + kGang * u == e) {
-                                        einfo[u] &= ~kAlive;
-                                        EB(s, EB_INFO, e, env) = static_cast<uint8_t>(einfo[u]);
-                                    }
+                                if ((e & (kGang - 1)) == q.g) {
+                                    const int info = L.info[e] & ~kAlive;
+                                    L.info[e] = static_cast<uint8_t>(info);
+                                    EB(s, EB_INFO, e, env) = static_cast<uint8_t>(info);
+                                }
                                 set_changed = true;
                                 targets_destroyed++;
                             }
@@ -576,25 +578,18 @@ PG_D void advance(const State& s, Q q, int env, const uint64_t* cols, int action
         // kGang of them, each lane picking the one of its slots that holds its enemy.
         for (int e0 = first_enemy; e0 < n_ent; e0 += kGang) {
             const int e = e0 + ((q.g - e0) & (kGang - 1));  // the id in [e0, e0 + kGang) that is mine
-            const bool enemy = e < n_ent;
-            const int t = e / kGang;
-            float vx = pick(evx, t), vy = pick(evy, t);
-            const float x = pick(ex, t) + vx * dt, y = pick(ey, t) + vy * dt;
-            bool bump = false;
-            if (enemy) {
+            if (e < n_ent) {
+                const int j = e - first_enemy;
+                float vx = L.vx[j], vy = L.vy[j];
+                const float x = L.x[e] + vx * dt, y = L.y[e] + vy * dt;
                 const Box box{x + -0.4f, y + -0.4f, 0.8f, 0.8f};
                 const BitWin win = BitWin::fetch(cols, static_cast<int>(floorf(box.x)), static_cast<int>(floorf(box.y)));
-                bump = collide_any(win, box, is_wall);
-            }
-            vx = bump ? -vx : vx;
-            vy = bump ? -vy : vy;
-#pragma unroll
-            for (int u = 0; u < kPerLane; u++) {
-                const bool here = enemy & (u == t);
-                ex[u] = here ? x : ex[u];
-                ey[u] = here ? y : ey[u];
-                evx[u] = here ? vx : evx[u];
-                evy[u] = here ? vy : evy[u];
+                if (collide_any(win, box, is_wall)) {
+                    L.vx[j] = -vx;
+                    L.vy[j] = -vy;
+                }
+                L.x[e] = x;
+                L.y[e] = y;
             }
         }
 
@@ -633,14 +628,13 @@ PG_D void advance(const State& s, Q q, int env, const uint64_t* cols, int action
         if (terminated) break;
     }
     // what the sub-steps changed, back to memory: the enemies, the particles' lives, the scalars
-#pragma unroll
-    for (int t = 0; t < kPerLane; t++) {
-        const int e = q.g + kGang * t;
-        if ((einfo[t] & kKindMask) == kEnemy && e >= 2 && e < n_ent) {
-            EF(s, EF_X, e, env) = ex[t];
-            EF(s, EF_Y, e, env) = ey[t];
-            EF(s, EF_VX, e, env) = evx[t];
-            EF(s, EF_VY, e, env) = evy[t];
+    for (int e0 = first_enemy; e0 < n_ent; e0 += kGang) {
+        const int e = e0 + ((q.g - e0) & (kGang - 1));
+        if (e < n_ent) {
+            EF(s, EF_X, e, env) = L.x[e];
+            EF(s, EF_Y, e, env) = L.y[e];
+            EF(s, EF_VX, e, env) = L.vx[e - first_enemy];
+            EF(s, EF_VY, e, env) = L.vy[e - first_enemy];
         }
     }
 #pragma unroll
@@ -717,15 +711,12 @@ __global__ void __launch_bounds__(64, PG_CAVEFLYER_WAVES) logic_kernel(State s, 
         if (q.g == 0) io.pending[env] = 0;
         return;
     }
-    __shared__ uint64_t wall_cols[64 / kGang][W];  // the env's map as wall bits (320 bytes): every tile window of the step comes from here
-    uint64_t* cols = wall_cols[(threadIdx.x & 63) / kGang];
-    for (int x = q.g; x < W; x += kGang) cols[x] = s.cols[size_t(env) * W + x];
-    wave_order();
+    __shared__ StepLds lds[64 / kGang];
     const int action =
         actions ? actions[env] : synthetic_action(run_seed, step_index, static_cast<uint32_t>(env_offset + env));
     float reward = 0.0f;
     bool terminated = false;
-    advance(s, q, env, cols, action, reward, terminated);
+    advance(s, lds[(threadIdx.x & 63) / kGang], q, env, action, reward, terminated);
     if (q.g == 0) {
         io.reward[env] = reward;
         io.done[env] = terminated ? 1 : 0;
