@@ -31,8 +31,46 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_ENV_STEP = 12297  # 12288 obs write + 4 action read + 4 reward write + 1 done write
+# 12288 obs write + 4 action read + 4 reward write + 1 done write.  (The synthetic path hashes its actions
+# in the kernel instead of reading them: the 4 bytes of the action read are counted because the figure is the survey's,
+# 0.03 % of it.)
+ALGO_BYTES_PER_ENV_STEP = 12297
 HBM_PEAK_GBPS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def csrc_fingerprint():
+    """sha1 over the kernel sources (procgen2_amd/csrc, sorted by name): what a traffic profile was taken on."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "procgen2_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
+def measured_copy_bandwidth(torch, device, nbytes, repeats=5):
+    """Device-to-device copy of a slab of the observation slab's size (hipMemcpyDtoD through torch), outside every
+    timed region: bytes read + bytes written per second, the best of a few repeats.  What a pure streaming kernel
+    reaches on THIS box, to be read beside the 8 TB/s spec peak."""
+    src = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    dst = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    src.zero_()
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(repeats):
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+        dst.copy_(src)
+        t1.record()
+        t1.synchronize()
+        ms = t0.elapsed_time(t1)
+        best = ms if best is None or ms < best else best
+    del src, dst
+    return 2.0 * nbytes / (best * 1e-3) / 1e9
 
 
 def measured_traffic(game):
@@ -43,16 +81,22 @@ def measured_traffic(game):
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic_pmc.json")))
     if not files:
-        return None, None
+        return None, None, None
     with open(files[-1]) as f:
         data = json.load(f)
     entry = None
-    for name, value in data.items():  # "pg::variant0::<game>::render_kernel" (default distribution mode)
+    for name, value in data.items():
+        if name.startswith("_"):
+            continue
+        # "pg::variant0::<game>::render_kernel" (default distribution mode)
         if name.endswith("::%s::render_kernel" % game) and ("variant" not in name or "variant0::" in name):
             entry = value
     if not entry:
-        return None, None
-    return entry["bytes_corrected"], os.path.relpath(files[-1], ROOT)
+        return None, None, None
+    # Stale = taken on other kernel sources than the ones in the tree now (the profile carries their fingerprint; one
+    # without a fingerprint predates the stamp and counts as stale).
+    stale = data.get("_csrc_sha1") != csrc_fingerprint()
+    return entry["bytes_corrected"], os.path.relpath(files[-1], ROOT), stale
 
 
 def usable_cores():
@@ -186,21 +230,24 @@ def main():
 
     fence()
     t0 = time.perf_counter()
-    env.timed_steps(a.steps, run_seed)  # returns after the stream has drained
+    env.timed_steps(a.steps, run_seed, render_events=False)  # the steps and nothing else; returns after the stream has drained
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     elapsed = t1 - t0
     fence()
-    # Roofline leg: the dominant kernel's average launch duration over its own steady-state window (HIP events around
-    # every render launch, on the engine's stream), independent of how short the timed region was asked to be.
+    # Roofline leg and latency percentiles: the dominant kernel's launch durations and the per-step times over their own
+    # steady-state window (HIP events on the engine's stream), independent of how short the timed region was asked to be.
     window = max(256, a.steps)
-    _, render_ms = env.timed_steps(window, run_seed)
-    render_avg_ms = render_ms / window
+    step_ms, render_ms = env.step_times(window, run_seed)
+    render_avg_ms = float(render_ms.mean())
+    import numpy as np
+    p50_ms, mean_ms = float(np.median(step_ms)), float(step_ms.mean())
     if distributed:
-        t = torch.tensor([elapsed, render_avg_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, render_avg_ms, p50_ms, mean_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, render_avg_ms = float(t[0]), float(t[1])
+        elapsed, render_avg_ms, p50_ms, mean_ms = (float(x) for x in t)
     fence()
+    copy_gbps = measured_copy_bandwidth(torch, env.device, a.envs * 12288) if rank == 0 else None
 
     done_frac = float(env.done.float().mean().item())
     env.close()
@@ -209,7 +256,7 @@ def main():
         total_steps = float(n_gpus) * a.envs * a.steps
         value = total_steps / elapsed
         achieved = ALGO_BYTES_PER_ENV_STEP * a.envs / (render_avg_ms * 1e-3) / 1e9
-        traffic, traffic_src = measured_traffic(a.game) if a.envs == 65536 and not a.mode else (None, None)
+        traffic, traffic_src, traffic_stale = measured_traffic(a.game) if a.envs == 65536 and not a.mode else (None, None, None)
         line = {
             "metric": "env-steps/sec at 65536 envs, 64x64x3 obs",
             "value": value,
@@ -219,6 +266,8 @@ def main():
             "warmup": a.warmup,
             "settle_steps": a.settle,
             "ms_per_step": elapsed / a.steps * 1e3,
+            "p50_ms_per_step": p50_ms,
+            "mean_ms_per_step_window": mean_ms,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -230,7 +279,11 @@ def main():
             "obs_write_GBps": value * 12288 / 1e9,
             "roofline": {"bound": "hbm", "kernel": "%s::render_kernel" % a.game, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "traffic_source": traffic_src,
+                         "traffic_source": traffic_src, "traffic_stale": traffic_stale,
+                         "peak_measured": copy_gbps,
+                         "peak_measured_how": "device-to-device copy of %d bytes (read + written bytes per second, best "
+                                              "of 5), outside the timed region" % (a.envs * 12288),
+                         "frac_of_measured": (achieved / copy_gbps) if copy_gbps else None,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * a.envs,
                          "avg_launch_ms": render_avg_ms,
                          "window": "%d launches after the timed region (steps %d..%d since make), HIP events on the "
@@ -252,22 +305,39 @@ def mixed(a, torch, ProcgenVecEnv, distributed, world, rank, local_rank, n_gpus,
     from procgen2_amd.vec_env import GAMES
     if distributed:
         import torch.distributed as dist
+    from procgen2_amd.vec_env import RootGather
     base = a.envs // len(GAMES)
     counts = [base] * (len(GAMES) - 1) + [a.envs - base * (len(GAMES) - 1)]
-    envs = []
-    for game, count in zip(GAMES, counts):
-        envs.append(ProcgenVecEnv(game, count, device=local_rank, seed_base=1, env_offset=rank * count))  # own stream each
+    device = torch.device("cuda", local_rank)
+    # ONE slab per GPU whatever the game: every game's env writes its block of it.  On the root of a
+    # gathered run that slab is the root's slice of the gathered batch, so its own block is never copied.
+    gathering = a.gather and distributed
+    shapes = (((64, 64, 3), torch.uint8), ((), torch.float32), ((), torch.uint8))
+    whole = None
+    if gathering and rank == 0:
+        whole = tuple(torch.zeros((world * a.envs,) + sh, dtype=dt, device=device) for sh, dt in shapes)
+        local = tuple(t[rank * a.envs:(rank + 1) * a.envs] for t in whole)
+    else:
+        local = tuple(torch.zeros((a.envs,) + sh, dtype=dt, device=device) for sh, dt in shapes)
+    envs, at = [], 0
+    for game, count in zip(GAMES, counts):  # own stream each
+        envs.append(ProcgenVecEnv(game, count, device=local_rank, seed_base=1, env_offset=rank * count,
+                                  out=tuple(t[at:at + count] for t in local)))
+        at += count
     for e in envs:
         e.reset()
+    gather = RootGather(local, dst=0, slabs=whole) if gathering else None  # 3 transfers per peer and step
 
     def run(steps):
         for _ in range(steps):
             for e in envs:
                 e.step_synthetic(run_seed, ordered=False)
-            if a.gather and distributed:
+            if gather is not None:
                 for e in envs:
-                    e.publish()  # torch's current stream waits for the engine's stream: no host synchronisation
-                    e.gather(dst=0)
+                    e.publish()   # torch's current stream waits for the engines' streams: no host synchronisation
+                gather()          # one batch of point-to-point transfers: obs, reward, done slabs
+                for e in envs:
+                    e.consume()   # … and the next step does not overwrite the slab while it is being sent
         for e in envs:
             e.sync()
 

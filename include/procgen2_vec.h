@@ -155,6 +155,14 @@ PGV_API int32_t pgv_render_frame(pgv_env* env, int32_t index, int32_t width, int
  * kernel launches inside it. */
 PGV_API int32_t pgv_timed_steps(pgv_env* env, int32_t steps, uint32_t run_seed, double* total_ms,
                                 double* render_kernel_ms);
+/* render_kernel_ms == NULL: the region holds nothing but the steps between its two events (no per-launch events): the
+ * form `value` is measured with.
+ *
+ * Per-step detail for the same kind of run: h_step_ms[s] = time from the start of step s to the start of step s+1 (to
+ * the end of the run for the last), h_render_ms[s] = its render launch, both from HIP events on the env's stream (host
+ * arrays of `steps` floats, either may be NULL).  For latency percentiles and the roofline window — never for `value`:
+ * three events per step sit inside the region. */
+PGV_API int32_t pgv_step_times(pgv_env* env, int32_t steps, uint32_t run_seed, float* h_step_ms, float* h_render_ms);
 
 /* Debug switches (tests only); neither changes a result.  Bit 0: render the background and tile layer by replaying the
  * draw list one blit at a time instead of the fused row composer.  Bit 8: no level prefetch — every reset generates its

@@ -209,6 +209,46 @@ void* pgo_vec_make_flags(const char* game, int n, uint32_t seed_base, int env_of
     return v;
 }
 
+void pgo_vec_close(void* h);
+
+// The same with the envs made by `threads` threads (env objects are independent; the texture bank is only read): the
+// full-size parity tests make 65 536 of them.
+void* pgo_vec_make_threads(const char* game, int n, uint32_t seed_base, int env_offset, int render_enabled,
+                           int num_levels, int start_level, int mode, uint32_t flags, int threads) {
+    auto* v = new VecState();
+    v->game = game;
+    v->mode = mode;
+    v->flags = flags;
+    v->render = render_enabled;
+    v->num_levels = num_levels;
+    v->start_level = start_level;
+    v->chain_seed.assign(n, 0);
+    v->drawn.assign(n, 0);
+    v->envs.assign(n, nullptr);
+    v->pending_reset.assign(n, 0);
+    auto work = [&](int lo, int hi) {
+        for (int i = lo; i < hi; i++) {
+            const uint32_t seed = seed_base + static_cast<uint32_t>(env_offset + i);
+            v->envs[i] = static_cast<Env*>(pgo_make_config(game, seed, render_enabled, mode, flags));
+            if (!v->envs[i]) return;
+            v->chain_seed[i] = seed;
+            v->drawn[i] = num_levels > 0 ? 1 : 0;
+            vec_new_level(v, i, false, 0);
+        }
+    };
+    if (threads < 1) threads = 1;
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; t++)
+        pool.emplace_back(work, static_cast<int>(int64_t(n) * t / threads), static_cast<int>(int64_t(n) * (t + 1) / threads));
+    for (auto& th : pool) th.join();
+    for (Env* e : v->envs)
+        if (!e) {
+            pgo_vec_close(v);
+            return nullptr;
+        }
+    return v;
+}
+
 void* pgo_vec_make_config(const char* game, int n, uint32_t seed_base, int env_offset, int render_enabled,
                           int num_levels, int start_level, int mode) {
     return pgo_vec_make_flags(game, n, seed_base, env_offset, render_enabled, num_levels, start_level, mode, 0);
@@ -237,6 +277,24 @@ void pgo_vec_close(void* h) {
     auto* v = static_cast<VecState*>(h);
     for (Env* e : v->envs) delete e;
     delete v;
+}
+
+void pgo_vec_reset_threads(void* h, int threads) {  // pgo_vec_reset(h, nullptr, nullptr) by `threads` threads
+    auto* v = static_cast<VecState*>(h);
+    const int n = static_cast<int>(v->envs.size());
+    auto work = [&](int lo, int hi) {
+        for (int i = lo; i < hi; i++) {
+            vec_new_level(v, i, false, 0u);
+            v->envs[i]->reward = 0.0f;
+            v->envs[i]->terminated = false;
+            v->pending_reset[i] = 0;
+        }
+    };
+    if (threads < 1) threads = 1;
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; t++)
+        pool.emplace_back(work, static_cast<int>(int64_t(n) * t / threads), static_cast<int>(int64_t(n) * (t + 1) / threads));
+    for (auto& th : pool) th.join();
 }
 
 // One vector step over envs [lo, hi) with explicit actions (nullptr → synthetic hash with

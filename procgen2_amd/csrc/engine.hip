@@ -384,24 +384,39 @@ int32_t pgv_reset(pgv_env* e, const uint8_t* d_mask, const int32_t* d_seeds) {
 // only the most recent error, and pregen's hipStreamQuery legitimately leaves hipErrorNotReady behind.
 static int32_t step_impl(pgv_env* e, const int32_t* d_actions, uint32_t run_seed, hipEvent_t before_render = nullptr,
                          hipEvent_t after_render = nullptr) {
-    if (e->reset_stream) {  // fork: the auto-resets of this step go beside its logic and render kernels
+    // hipGetLastError is sticky and per thread: whatever the embedding application left behind (a stream query's
+    // NotReady, say) is not this step's; start clean.
+    (void)hipGetLastError();
+    const bool forked = e->reset_stream != nullptr;
+    if (forked) {  // fork: the auto-resets of this step go beside its logic and render kernels
         PG_HIP(hipEventRecord(e->reset_fork, e->stream));
         PG_HIP(hipStreamWaitEvent(e->reset_stream, e->reset_fork, 0));
     }
+    hipError_t status = hipSuccess;
+    auto launched = [&]() {  // the status of the launches since the last call
+        const hipError_t now = hipGetLastError();
+        if (status == hipSuccess && now != hipSuccess) status = now;
+    };
     e->game->launch_logic(e->stream, d_actions, run_seed, e->step_index, e->env_offset, e->io());
-    PG_HIP(hipGetLastError());
+    launched();
     pregen(e, false, false);  // before the render launch: the generator overlaps it
     (void)hipGetLastError();  // hipErrorNotReady of the stream query is not an error
-    if (before_render) PG_HIP(hipEventRecord(before_render, e->stream));
-    e->game->launch_render_step(e->stream, e->io());
-    PG_HIP(hipGetLastError());
-    if (after_render) PG_HIP(hipEventRecord(after_render, e->stream));
-    if (e->reset_stream) {  // join: the envs that were reset beside all this get their frame now
-        PG_HIP(hipEventRecord(e->reset_join, e->reset_stream));
-        PG_HIP(hipStreamWaitEvent(e->stream, e->reset_join, 0));
-        e->game->launch_render_late(e->stream, e->io());
-        PG_HIP(hipGetLastError());
+    if (before_render && status == hipSuccess) status = hipEventRecord(before_render, e->stream);
+    if (status == hipSuccess) {
+        e->game->launch_render_step(e->stream, e->io());
+        launched();
     }
+    if (after_render && status == hipSuccess) status = hipEventRecord(after_render, e->stream);
+    if (forked) {  // join — on every way out, so the two streams stay consistent — and the late frames of the reset envs
+        hipError_t j = hipEventRecord(e->reset_join, e->reset_stream);
+        if (j == hipSuccess) j = hipStreamWaitEvent(e->stream, e->reset_join, 0);
+        if (status == hipSuccess) status = j;
+        if (status == hipSuccess) {
+            e->game->launch_render_late(e->stream, e->io());
+            launched();
+        }
+    }
+    if (status != hipSuccess) return fail(std::string("step: ") + hipGetErrorString(status));
     e->step_index++;
     return 0;
 }
@@ -479,7 +494,11 @@ struct SnapshotHeader {
     int32_t num_levels, start_level, mode;
     uint32_t game_flags, reserved;
 };
-static constexpr uint32_t kSnapshotMagic = 0x50474e32u;  // "PGN2"
+// "PGN" + the version of the state-blob layouts: bump it whenever any game's State / Level / field enums change — equal
+// state_bytes does not mean equal layout (sizes are rounded to 256 bytes), and an old blob would load silently.
+// 2: round 2.  3: round 3 (per-env contiguous rings and entity tables in bossfight, caveflyer, chaser, climber; caveflyer's
+// wall-bit columns and hazard places).
+static constexpr uint32_t kSnapshotMagic = 0x50474e33u;
 
 static size_t snapshot_bytes(const pgv_env* e) {
     return sizeof(SnapshotHeader) + state_blob_bytes(e) + size_t(e->n) * (4 + 1 + 1) +
@@ -582,36 +601,74 @@ int32_t pgv_copy_out(pgv_env* e, uint8_t* h_obs, float* h_reward, uint8_t* h_don
     return 0;
 }
 
+// Per-step events of a run of synthetic steps, created before the region starts and destroyed on every way out; they are
+// read back after the region so the host never stalls the stream inside it.
+namespace {
+struct StepEvents {
+    std::vector<hipEvent_t> v;
+    ~StepEvents() {
+        for (hipEvent_t p : v)
+            if (p) hipEventDestroy(p);
+    }
+};
+}  // namespace
+
 int32_t pgv_timed_steps(pgv_env* e, int32_t steps, uint32_t run_seed, double* total_ms, double* render_kernel_ms) {
     if (!e) return fail("pgv_timed_steps: env is NULL");
     if (steps < 1 || steps > (1 << 20)) return fail("pgv_timed_steps: steps must be in 1..1048576");
     PG_HIP(hipSetDevice(e->device));
-    // One event pair per render launch, created before the region starts and destroyed on every way out; they are read
-    // back after the region so the host never stalls the stream inside it.
-    struct Events {
-        std::vector<hipEvent_t> v;
-        ~Events() {
-            for (hipEvent_t p : v)
-                if (p) hipEventDestroy(p);
-        }
-    } pairs;
-    pairs.v.assign(size_t(steps) * 2, nullptr);
-    for (auto& p : pairs.v) PG_HIP(hipEventCreate(&p));
+    // render_kernel_ms == NULL: nothing but the steps between the region's two events (the form bench.py's `value` uses).
+    StepEvents pairs;
+    if (render_kernel_ms) {
+        pairs.v.assign(size_t(steps) * 2, nullptr);
+        for (auto& p : pairs.v) PG_HIP(hipEventCreate(&p));
+    }
     PG_HIP(hipEventRecord(e->ev[0], e->stream));  // whole region on the env's stream
     for (int s = 0; s < steps; s++)
-        if (step_impl(e, nullptr, run_seed, pairs.v[2 * s], pairs.v[2 * s + 1])) return 1;
+        if (step_impl(e, nullptr, run_seed, render_kernel_ms ? pairs.v[2 * s] : nullptr,
+                      render_kernel_ms ? pairs.v[2 * s + 1] : nullptr))
+            return 1;
     PG_HIP(hipEventRecord(e->ev[1], e->stream));
     PG_HIP(hipEventSynchronize(e->ev[1]));
     float ms = 0.0f;
     PG_HIP(hipEventElapsedTime(&ms, e->ev[0], e->ev[1]));
     if (total_ms) *total_ms = ms;
-    double render_sum = 0.0;
-    for (int s = 0; s < steps; s++) {
-        float k = 0.0f;
-        PG_HIP(hipEventElapsedTime(&k, pairs.v[2 * s], pairs.v[2 * s + 1]));
-        render_sum += k;
+    if (render_kernel_ms) {
+        double render_sum = 0.0;
+        for (int s = 0; s < steps; s++) {
+            float k = 0.0f;
+            PG_HIP(hipEventElapsedTime(&k, pairs.v[2 * s], pairs.v[2 * s + 1]));
+            render_sum += k;
+        }
+        *render_kernel_ms = render_sum;
     }
-    if (render_kernel_ms) *render_kernel_ms = render_sum;
+    return 0;
+}
+
+int32_t pgv_step_times(pgv_env* e, int32_t steps, uint32_t run_seed, float* h_step_ms, float* h_render_ms) {
+    if (!e) return fail("pgv_step_times: env is NULL");
+    if (steps < 1 || steps > (1 << 20)) return fail("pgv_step_times: steps must be in 1..1048576");
+    PG_HIP(hipSetDevice(e->device));
+    StepEvents ev;  // per step: start, before render, after render; one more at the very end
+    ev.v.assign(size_t(steps) * 3 + 1, nullptr);
+    for (auto& p : ev.v) PG_HIP(hipEventCreate(&p));
+    for (int s = 0; s < steps; s++) {
+        PG_HIP(hipEventRecord(ev.v[3 * s], e->stream));
+        if (step_impl(e, nullptr, run_seed, ev.v[3 * s + 1], ev.v[3 * s + 2])) return 1;
+    }
+    PG_HIP(hipEventRecord(ev.v[size_t(steps) * 3], e->stream));
+    PG_HIP(hipEventSynchronize(ev.v[size_t(steps) * 3]));
+    for (int s = 0; s < steps; s++) {
+        float t = 0.0f;
+        if (h_step_ms) {
+            PG_HIP(hipEventElapsedTime(&t, ev.v[3 * s], ev.v[3 * s + 3]));
+            h_step_ms[s] = t;
+        }
+        if (h_render_ms) {
+            PG_HIP(hipEventElapsedTime(&t, ev.v[3 * s + 1], ev.v[3 * s + 2]));
+            h_render_ms[s] = t;
+        }
+    }
     return 0;
 }
 

@@ -28,7 +28,10 @@ def shard_range(total_envs, world_size, rank):
 
 class ProcgenVecEnv:
     def __init__(self, game, num_envs, device=0, seed_base=1, env_offset=0, lib_path=None, num_levels=0,
-                 start_level=0, distribution_mode=None, game_flags=0):
+                 start_level=0, distribution_mode=None, game_flags=0, out=None):
+        """out = (obs, reward, done): caller-owned result tensors on `device` — uint8 [N,64,64,3], float32 [N],
+        uint8 [N], contiguous — e.g. slices of one slab that several envs (the games of a mixed workload) fill side by
+        side ("one contiguous [N_local,64,64,3] slab regardless of game").  Default: own tensors."""
         if not torch.cuda.is_available():
             raise pglib.EngineError("ProcgenVecEnv needs a HIP device (torch.cuda.is_available() is False); "
                                     "there is no CPU fallback")
@@ -53,9 +56,19 @@ class ProcgenVecEnv:
         self.distribution_mode = {v: k for k, v in pglib.MODES.items()}[self.L.pgv_mode(h)]
         self._h = h
         # torch owns the result buffers; the engine writes straight into them.
-        self.obs = torch.zeros((self.num_envs, 64, 64, 3), dtype=torch.uint8, device=self.device)
-        self.reward = torch.zeros(self.num_envs, dtype=torch.float32, device=self.device)
-        self.done = torch.zeros(self.num_envs, dtype=torch.uint8, device=self.device)
+        if out is not None:
+            self.obs, self.reward, self.done = out
+            want = (((self.num_envs, 64, 64, 3), torch.uint8), ((self.num_envs,), torch.float32),
+                    ((self.num_envs,), torch.uint8))
+            for t, (shape, dtype) in zip(out, want):
+                if tuple(t.shape) != shape or t.dtype != dtype or t.device != self.device or not t.is_contiguous():
+                    self.L.pgv_close(h)
+                    self._h = None
+                    raise ValueError("out: expected a contiguous %s tensor of shape %s on %s" % (dtype, shape, self.device))
+        else:
+            self.obs = torch.zeros((self.num_envs, 64, 64, 3), dtype=torch.uint8, device=self.device)
+            self.reward = torch.zeros(self.num_envs, dtype=torch.float32, device=self.device)
+            self.done = torch.zeros(self.num_envs, dtype=torch.uint8, device=self.device)
         pglib.check(self.L, self.L.pgv_bind_outputs(self._h, c_void_p(self.obs.data_ptr()),
                                                     c_void_p(self.reward.data_ptr()), c_void_p(self.done.data_ptr())),
                     "pgv_bind_outputs")
@@ -107,12 +120,22 @@ class ProcgenVecEnv:
     def _after(self):
         torch.cuda.current_stream(self.device).wait_stream(self._stream)
 
-    def timed_steps(self, steps, run_seed=0):
-        """(total_ms, render_kernel_ms_sum) from HIP events on the engine's stream."""
+    def timed_steps(self, steps, run_seed=0, render_events=True):
+        """(total_ms, render_kernel_ms_sum) from HIP events on the engine's stream.  render_events=False: the region holds
+        the steps and nothing else (no event pair per render launch); the second value is then None."""
         total, render = ctypes.c_double(), ctypes.c_double()
         pglib.check(self.L, self.L.pgv_timed_steps(self._h, steps, run_seed, ctypes.byref(total),
-                                                   ctypes.byref(render)), "pgv_timed_steps")
-        return total.value, render.value
+                                                   ctypes.byref(render) if render_events else None), "pgv_timed_steps")
+        return total.value, (render.value if render_events else None)
+
+    def step_times(self, steps, run_seed=0):
+        """Per-step detail of `steps` synthetic steps (HIP events on the engine's stream): (step_ms[steps],
+        render_ms[steps]) as numpy float32 arrays — for latency percentiles and the roofline window."""
+        import numpy as np
+        step_ms, render_ms = np.zeros(steps, np.float32), np.zeros(steps, np.float32)
+        pglib.check(self.L, self.L.pgv_step_times(self._h, steps, run_seed, c_void_p(step_ms.ctypes.data),
+                                                  c_void_p(render_ms.ctypes.data)), "pgv_step_times")
+        return step_ms, render_ms
 
     def render_frame(self, index=0, width=512, height=512):
         """The human-size frame of env `index` (cenv_render, render_game(false)): uint8 [height, width, 3] on the host."""
@@ -140,8 +163,16 @@ class ProcgenVecEnv:
 
     def publish(self):
         """Order torch's current stream behind the engine's stream (after step_synthetic(ordered=False)), without
-        blocking the host: whatever is enqueued on the current stream next sees the step's outputs."""
+        blocking the host: whatever is enqueued on the current stream next sees the step's outputs.  This covers
+        read-after-write only: the NEXT unordered step would overwrite obs / reward / done while a reader enqueued here
+        (a gather, a copy) is still at them — call consume() after enqueueing the readers."""
         self._after()
+
+    def consume(self):
+        """The counterpart of publish(): order the engine's stream behind torch's current stream, so the next
+        step_synthetic(ordered=False) does not overwrite the outputs before what was enqueued on the current stream
+        (and on streams it has been made to wait for, like a collective's) has read them."""
+        self._before()
 
     def close(self):
         if self._h:
@@ -178,7 +209,9 @@ class RootGather:
     GPUs this is RCCL grouped send/recv, so the root's inbound xGMI links (one per peer, point to point) all run at
     once; the CPU tests run the same code over gloo.  The returned slabs are reused by the next call."""
 
-    def __init__(self, tensors, dst=0, group=None):
+    def __init__(self, tensors, dst=0, group=None, slabs=None):
+        """slabs: the root's preallocated `[sum n_r, ...]` tensors (one per input).  When the root's own input IS its
+        slice of the slab (the engine writes straight into it), its block is not copied."""
         import torch.distributed as dist
         self.dist = dist
         self.group = group
@@ -198,8 +231,14 @@ class RootGather:
         self.slabs = None
         if self.rank == dst:
             total = self.offsets[-1]
-            self.slabs = tuple(torch.empty((total,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-                               for t in self.tensors)
+            if slabs is not None:
+                self.slabs = tuple(slabs)
+                for t, slab in zip(self.tensors, self.slabs):
+                    if tuple(slab.shape) != (total,) + tuple(t.shape[1:]) or slab.dtype != t.dtype or not slab.is_contiguous():
+                        raise ValueError("RootGather: a slab does not match [%d, ...] of its tensor" % total)
+            else:
+                self.slabs = tuple(torch.empty((total,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+                                   for t in self.tensors)
 
     def __call__(self):
         dist = self.dist
@@ -209,7 +248,8 @@ class RootGather:
                 for r in range(self.world):
                     part = slab[self.offsets[r]:self.offsets[r + 1]]  # contiguous: a block of leading indices
                     if r == self.rank:
-                        part.copy_(t)
+                        if part.data_ptr() != t.data_ptr():  # (already in place when the input is the slab's slice)
+                            part.copy_(t)
                     elif self.counts[r]:
                         ops.append(dist.P2POp(dist.irecv, part, self.global_rank[r], group=self.group))
         elif self.counts[self.rank]:

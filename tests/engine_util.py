@@ -46,6 +46,16 @@ class EngineVec:
             pglib.check(self.L, self.L.pgv_step_host(self.h, a.ctypes.data_as(c_void_p)), "pgv_step_host")
         return self._fetch()
 
+    def step_quiet(self, run_seed=0):
+        """One synthetic step, nothing copied out."""
+        pglib.check(self.L, self.L.pgv_step_synthetic(self.h, run_seed), "pgv_step_synthetic")
+
+    def fetch_scalars(self):
+        """Rewards and dones only (the observation slab stays on the device)."""
+        pglib.check(self.L, self.L.pgv_copy_out(self.h, None, self.reward.ctypes.data_as(c_void_p),
+                                                self.done.ctypes.data_as(c_void_p)), "pgv_copy_out")
+        return self.reward, self.done
+
     def frame(self, env, width, height):
         out = np.zeros((height, width, 3), np.uint8)
         pglib.check(self.L, self.L.pgv_render_frame(self.h, env, width, height, out.ctypes.data_as(c_void_p)),

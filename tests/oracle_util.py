@@ -69,6 +69,9 @@ def oracle():
     L.pgo_vec_make_config.argtypes = [c_char_p, c_int, c_uint32, c_int, c_int, c_int, c_int, c_int]
     L.pgo_vec_make_flags.restype = c_void_p
     L.pgo_vec_make_flags.argtypes = [c_char_p, c_int, c_uint32, c_int, c_int, c_int, c_int, c_int, c_uint32]
+    L.pgo_vec_make_threads.restype = c_void_p
+    L.pgo_vec_make_threads.argtypes = [c_char_p, c_int, c_uint32, c_int, c_int, c_int, c_int, c_int, c_uint32, c_int]
+    L.pgo_vec_reset_threads.argtypes = [c_void_p, c_int]
     L.pgo_make_mode.restype = c_void_p
     L.pgo_make_mode.argtypes = [c_char_p, c_uint32, c_int, c_int]
     L.pgo_resolve_mode.argtypes = [c_char_p, c_int]
@@ -110,14 +113,20 @@ def register_textures(game):
 class OracleVec:
     """N oracle envs stepped in lock-step with the engine's auto-reset policy (oracle/pgo_api.cpp)."""
 
-    def __init__(self, game, n, seed_base=1, env_offset=0, render=True, num_levels=0, start_level=0, mode=0, game_flags=0):
+    def __init__(self, game, n, seed_base=1, env_offset=0, render=True, num_levels=0, start_level=0, mode=0, game_flags=0,
+                 threads=1):
         if render:
             register_textures(game)
         self.L = oracle()
         self.n = n
         self.env_offset = env_offset
-        self.h = self.L.pgo_vec_make_flags(game.encode(), n, seed_base, env_offset, 1 if render else 0, num_levels,
-                                           start_level, mode, game_flags)
+        self.threads = threads
+        if threads > 1:  # the envs made (and, in reset(), given their first level) by several threads: full-size tests
+            self.h = self.L.pgo_vec_make_threads(game.encode(), n, seed_base, env_offset, 1 if render else 0, num_levels,
+                                                 start_level, mode, game_flags, threads)
+        else:
+            self.h = self.L.pgo_vec_make_flags(game.encode(), n, seed_base, env_offset, 1 if render else 0, num_levels,
+                                               start_level, mode, game_flags)
         assert self.h, "oracle does not know game %r" % game
         self.obs = np.zeros((n, OBS_BYTES), np.uint8)
         self.reward = np.zeros(n, np.float32)
@@ -131,7 +140,10 @@ class OracleVec:
         if seeds is not None:
             seeds = np.ascontiguousarray(seeds, dtype=np.int32)
             s = seeds.ctypes.data_as(c_void_p)
-        self.L.pgo_vec_reset(self.h, m, s)
+        if m is None and s is None and self.threads > 1:
+            self.L.pgo_vec_reset_threads(self.h, self.threads)
+        else:
+            self.L.pgo_vec_reset(self.h, m, s)
         return self.reset_obs()
 
     def reset_obs(self):

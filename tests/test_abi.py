@@ -134,3 +134,16 @@ def test_bench_launches_n_ranks_itself_before_touching_the_gpu():
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd
     assert cmd[cmd.index("--nproc-per-node") + 1] == "2" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-6:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"] and "--dry-launch" not in cmd
+
+
+def test_bench_mixed_gather_launch_line():
+    """`bench.py --workload mixed --gather --gpus 8 --dry-launch`: BASELINE.json configs[4]'s command, launcher side."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "mixed", "--gather", "--gpus", "8",
+                          "--dry-launch"], env=env, capture_output=True, text=True, check=True).stdout
+    line = json.loads(out.strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and line["launch"][-5:] == ["--workload", "mixed", "--gather", "--gpus", "8"]

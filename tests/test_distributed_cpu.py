@@ -110,3 +110,50 @@ def _subgroup_worker(rank, world, port, out_dir):
 def test_gather_inside_a_subgroup_translates_ranks(tmp_path):
     mp.spawn(_subgroup_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
     assert (tmp_path / "ok").exists()
+
+
+def _mixed_worker(rank, world, port, per_rank, out_dir):
+    """bench.py --workload mixed --gather, without GPUs: every rank owns ONE slab per output, seven "games" fill their
+    blocks of it (here: a value that encodes rank, game and env), and a step is ONE RootGather of the three slabs — on
+    the root straight into its slice of the gathered batch, which is never copied."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from procgen2_amd.vec_env import GAMES, RootGather
+    base = per_rank // len(GAMES)
+    counts = [base] * (len(GAMES) - 1) + [per_rank - base * (len(GAMES) - 1)]
+    shapes = (((4, 4, 3), torch.uint8), ((), torch.float32), ((), torch.uint8))  # small frames: the plumbing is the same
+    whole = None
+    if rank == 0:
+        whole = tuple(torch.zeros((world * per_rank,) + sh, dtype=dt) for sh, dt in shapes)
+        local = tuple(t[:per_rank] for t in whole)
+    else:
+        local = tuple(torch.zeros((per_rank,) + sh, dtype=dt) for sh, dt in shapes)
+    plan = RootGather(local, dst=0, slabs=whole)
+    if rank == 0:
+        assert all(a.data_ptr() == b.data_ptr() for a, b in zip(local, plan.slabs)), "the root's block is in place"
+    for step in range(3):
+        at = 0
+        for g, count in enumerate(counts):  # what seven ProcgenVecEnv(out=slices) would do
+            for t in local:
+                t[at:at + count] = (rank * 16 + g * 2 + step) % 251
+            at += count
+        got = plan()
+        if rank == 0:
+            for t in got:
+                for r in range(world):
+                    at = r * per_rank
+                    for g, count in enumerate(counts):
+                        assert (t[at:at + count] == (r * 16 + g * 2 + step) % 251).all(), (step, r, g)
+                        at += count
+        else:
+            assert all(t is None for t in got)
+    if rank == 0:
+        open(os.path.join(out_dir, "ok"), "w").write("1")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_mixed_workload_one_slab_one_gather_four_ranks(tmp_path):
+    mp.spawn(_mixed_worker, args=(4, _free_port(), 23, str(tmp_path)), nprocs=4, join=True)  # 23 = 6·3 + 5: a remainder
+    assert (tmp_path / "ok").exists()

@@ -490,6 +490,52 @@ def test_shard_invariance_and_determinism_at_full_size(game, n, steps):
         L.pgo_close(h)
 
 
+def _every_env_against_the_oracle(game, n, steps, env_offset=0, chunk=16384, eng=None):
+    """Every env of an engine batch against the oracle: rewards and dones of every step, every observation byte of the
+    reset frame, of the middle step and of the last one.  The engine runs first (device-generated actions); the oracle
+    then replays the envs in chunks of `chunk` (seeds and the action hash depend on the global index only) with all
+    host threads, so its memory stays bounded whatever n is."""
+    own = eng is None
+    if own:
+        eng = EngineVec(game, n, seed_base=1, env_offset=env_offset)
+    checkpoints = {-1: eng.reset().copy()}
+    rewards, dones = np.zeros((steps, n), np.float32), np.zeros((steps, n), np.uint8)
+    for s in range(steps):
+        eng.step_quiet(run_seed=0)
+        if s in (steps // 2, steps - 1):
+            checkpoints[s] = eng._fetch()[0].copy()
+            rewards[s], dones[s] = eng.reward, eng.done
+        else:
+            rewards[s], dones[s] = eng.fetch_scalars()
+    if own:
+        eng.close()
+    threads = _host_threads()
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        ora = OracleVec(game, hi - lo, seed_base=1, env_offset=env_offset + lo, threads=threads)
+        assert np.array_equal(ora.reset_obs(), checkpoints[-1][lo:hi]), (game, "reset frame", lo)  # (made = reset once)
+        for s in range(steps):
+            oo, ro, do = ora.step(None, run_seed=0, threads=threads)
+            assert np.array_equal(do, dones[s, lo:hi]), (game, "done", s, lo)
+            assert np.array_equal(ro.view(np.uint32), rewards[s, lo:hi].view(np.uint32)), (game, "reward bits", s, lo)
+            if s in checkpoints and not np.array_equal(oo, checkpoints[s][lo:hi]):
+                bad = np.nonzero((oo != checkpoints[s][lo:hi]).any(axis=1))[0]
+                raise AssertionError("%s: obs differ at step %d in %d envs (first: global env %d)" %
+                                     (game, s, bad.size, env_offset + lo + bad[0]))
+        ora.close()
+    return int(dones.sum())
+
+
+@pytest.mark.parametrize("game,n,steps", [("coinrun", 65536, 48), ("bossfight", 65536, 100), ("caveflyer", 32768, 48)])
+def test_every_env_at_full_size_matches_the_oracle(game, n, steps):
+    """BASELINE.json configs[1..3] at their full sizes, EVERY env (a strided sample cannot see a bug that needs a
+    particular env index mod something, LDS slot or XCD to show): 65 536 coinrun, 65 536 bossfight (long enough for
+    thousands of episodes to end and draw their next level inside the step), 32 768 caveflyer envs."""
+    ends = _every_env_against_the_oracle(game, n, steps)
+    if game == "bossfight":
+        assert ends > 1000, ends
+
+
 def test_vec_env_torch_zero_copy_matches_c_abi():
     import torch
     from procgen2_amd.vec_env import ProcgenVecEnv
@@ -640,22 +686,51 @@ def test_engine_refuses_unknown_game_flags():
 
 def test_mixed_seven_game_slice_of_configs4():
     """BASELINE.json configs[4], one GPU's share: seven vector envs (65 536 envs split seven ways, the last game takes
-    the remainder) on seven HIP streams of one device, stepped 200 times side by side with device-generated actions and
-    no ordering between them; then a strided sample of every game's envs must be exactly where the oracle is.  The
-    envs sit at the global indices rank 3 of 8 would own (env_offset), as bench.py --workload mixed lays them out."""
+    the remainder) on seven HIP streams of one device, all writing their blocks of ONE [65 536, 64, 64, 3] slab
+    (bench.py --workload mixed lays them out like this), stepped side by side with device-generated
+    actions and no ordering between them.  After 48 steps EVERY env of every game must be where the oracle is (rewards
+    and dones of every step, every observation byte of the last); after 200, a strided sample still is.  The envs sit
+    at the global indices rank 3 of 8 would own (env_offset)."""
     import torch
     from oracle_util import register_textures
     from procgen2_amd.vec_env import GAMES, ProcgenVecEnv
-    per_gpu, rank, steps = 65536, 3, 200
+    per_gpu, rank, first, steps = 65536, 3, 48, 200
     base = per_gpu // len(GAMES)
     counts = [base] * (len(GAMES) - 1) + [per_gpu - base * (len(GAMES) - 1)]
     assert counts == [9362] * 6 + [9364]
-    envs = [ProcgenVecEnv(g, c, seed_base=1, env_offset=rank * c) for g, c in zip(GAMES, counts)]
+    slab = (torch.zeros((per_gpu, 64, 64, 3), dtype=torch.uint8, device="cuda"),
+            torch.zeros(per_gpu, dtype=torch.float32, device="cuda"), torch.zeros(per_gpu, dtype=torch.uint8, device="cuda"))
+    envs, at = [], 0
+    for g, c in zip(GAMES, counts):
+        envs.append(ProcgenVecEnv(g, c, seed_base=1, env_offset=rank * c, out=tuple(t[at:at + c] for t in slab)))
+        assert envs[-1].obs.data_ptr() == slab[0][at:at + c].data_ptr()
+        at += c
     for e in envs:
         e.reset()
-    for s in range(steps):
+    rewards, dones = np.zeros((first, per_gpu), np.float32), np.zeros((first, per_gpu), np.uint8)
+    for s in range(first):
         for e in envs:
             e.step_synthetic(0, ordered=False)  # each on its own stream, nothing waits for anything
+        for e in envs:
+            e.sync()
+        rewards[s], dones[s] = slab[1].cpu().numpy(), slab[2].cpu().numpy()
+    obs_first = slab[0].cpu().numpy().reshape(per_gpu, -1)
+    threads, at = _host_threads(), 0
+    for game, count in zip(GAMES, counts):
+        ora = OracleVec(game, count, seed_base=1, env_offset=rank * count, threads=threads)  # (made = reset once)
+        for s in range(first):
+            oo, ro, do = ora.step(None, run_seed=0, threads=threads)
+            assert np.array_equal(do, dones[s, at:at + count]), (game, "done", s)
+            assert np.array_equal(ro.view(np.uint32), rewards[s, at:at + count].view(np.uint32)), (game, "reward bits", s)
+        if not np.array_equal(oo, obs_first[at:at + count]):
+            bad = np.nonzero((oo != obs_first[at:at + count]).any(axis=1))[0]
+            raise AssertionError("%s: obs differ after %d steps in %d envs (first: env %d of the game)" % (game, first, bad.size, bad[0]))
+        ora.close()
+        at += count
+    del obs_first
+    for s in range(first, steps):
+        for e in envs:
+            e.step_synthetic(0, ordered=False)
     for e in envs:
         e.sync()
     L = oracle()
