@@ -119,12 +119,24 @@ def _build(force, verbose, COMMON, ALIASES, OBJ):
 
 
 def _build_selftest(force, verbose, cc, hdrs, common):
-    """tests/hip/selftest.hip → lib/libpg_selftest.so: the device-side sweep of the bit-exact primitives (test
-    infrastructure, loaded only by tests/test_primitives_gpu.py; in lib/ so that it travels to the GPU box)."""
-    src = os.path.join(HERE, "..", "tests", "hip", "selftest.hip")
+    """tests/hip/selftest.hip (+ selftest_rooms.hip once per world size) → lib/libpg_selftest.so: the device-side sweep of
+    the bit-exact primitives (test infrastructure, loaded only by tests/test_primitives_gpu.py; in lib/ so that it travels
+    to the GPU box)."""
+    hip_dir = os.path.join(HERE, "..", "tests", "hip")
+    src = os.path.join(hip_dir, "selftest.hip")
+    rooms = os.path.join(hip_dir, "selftest_rooms.hip")
     out = os.path.join(LIB, "libpg_selftest.so")
-    if os.path.exists(src) and (force or _stale(out, [src] + hdrs)):
-        _run([cc] + common + ["-shared", src, "-o", out], verbose)
+    if os.path.exists(src) and (force or _stale(out, [src, rooms] + hdrs)):
+        objs, jobs = [], []
+        obj = os.path.join(OBJ, "selftest.o")
+        jobs.append([cc] + common + ["-c", src, "-o", obj])
+        objs.append(obj)
+        for k in range(3):  # pg_rooms.h is a per-size header: variants 0 / 1 / 2 = 40 / 20 / 45 cells a side
+            obj = os.path.join(OBJ, "selftest_rooms_v%d.o" % k)
+            jobs.append([cc] + common + ["-DPG_VARIANT=%d" % k, "-c", rooms, "-o", obj])
+            objs.append(obj)
+        _parallel(jobs, verbose)
+        _run([cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out] + objs, verbose)
     return out
 
 

@@ -806,7 +806,7 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
     if (mask && !mask[env]) return;
     const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // two wavefronts per env (pg_render.h)
     constexpr int halves = 2;
-    __shared__ uint32_t fb[kFbWords];
+    __shared__ alignas(16) uint32_t fb[kFbWords];
 
     const Camera cam{0.0f, 0.0f, kCamSize, kCamSize, kCamScale};  // camera_position stays {0,0} (renderer.h:18)
     const DescRegs descs = DescRegs::load(atlas, lane);

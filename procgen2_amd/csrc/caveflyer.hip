@@ -732,7 +732,7 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
     if (mask && !mask[env]) return;
     const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // two wavefronts per env (pg_render.h)
     constexpr int halves = 2;
-    __shared__ uint32_t fb[kFbWords];
+    __shared__ alignas(16) uint32_t fb[kFbWords];
     constexpr int kGrid = 16;  // 64 px / 8 px per tile → at most 10 columns/rows in view
     __shared__ ComposeLds<kGrid> L;
 

@@ -736,7 +736,7 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
     }
     const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // two wavefronts per env (pg_render.h)
     constexpr int halves = 2;
-    __shared__ uint32_t fb[kFbWords];
+    __shared__ alignas(16) uint32_t fb[kFbWords];
     constexpr int kGrid = W + 2 <= 16 ? 16 : 24;  // W tiles + the border cells of the inclusive window
     static_assert(W + 2 <= kGrid && (kGrid * kGrid) % 64 == 0, "composer grid");
     __shared__ ComposeLds<kGrid> L;

@@ -534,7 +534,7 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
     if (mask && !mask[env]) return;
     const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // two wavefronts per env (pg_render.h)
     constexpr int halves = 2;
-    __shared__ uint32_t fb[kFbWords];
+    __shared__ alignas(16) uint32_t fb[kFbWords];
     constexpr int kGrid = 24;  // 64 px / 3.2 px per tile = 20 tiles → at most 22 columns/rows in view (24² = 9·64 cells; LDS: 7 envs per CU instead of 6)
     __shared__ ComposeLds<kGrid> L;
 

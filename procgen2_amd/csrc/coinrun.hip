@@ -889,7 +889,7 @@ __global__ void __launch_bounds__(64 * kRenderWaves, 4) render_kernel(State s, A
     if (mask && !mask[env]) return;
     const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int halves = kRenderWaves;
-    __shared__ uint32_t fb[kFbWords];
+    __shared__ alignas(16) uint32_t fb[kFbWords];
     constexpr int kGrid = 16;  // 64 px / 4.8 px per tile = 13.3 tiles → at most 15 columns/rows in view
     __shared__ ComposeLds<kGrid> L;                 // the composer's cell table
     __shared__ uint32_t slots[kBlitWords * 64];     // the 64 resolved draws of the sprite pass, from wave 1 to wave 0

@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
     if (mask && !mask[env]) return;
     const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // two wavefronts per env (pg_render.h)
     constexpr int halves = 2;
-    __shared__ uint32_t fb[kFbWords];
+    __shared__ alignas(16) uint32_t fb[kFbWords];
     constexpr int kGrid = kVisible + 3 <= 20 ? 20 : 28;  // visible tiles + the border cells of the inclusive window; as small as it
     // may be: the composer tables are LDS, and LDS decides how many envs a CU holds (28: 7 per CU, 32: 6)
     __shared__ ComposeLds<kGrid> L;

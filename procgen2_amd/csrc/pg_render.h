@@ -56,8 +56,9 @@ struct __attribute__((packed, aligned(4))) Rgb4 {
 // LDS decides how many envs a CU holds (measured: one workgroup less per CU costs 9 %), so only what the row loop
 // itself reads stays in ComposeLds; the set-up tables (ComposeTmp) are read into registers before the first pixel is
 // written and live in the frame target's own memory until then (compose_rows puts a barrier between the two uses).
+// (alignas(16): chaser reads `base` through int4, the set-up tables that borrow the frame target are uint4 / int4.)
 template <int GRID>
-struct ComposeLds {
+struct alignas(16) ComposeLds {
     int32_t base[GRID * GRID + 2];  // [row][col] byte offset of the cell's tile texture in the atlas, kNoTexel = no tile;
                                     // the two extra words are always kNoTexel (the cells of a pixel row no grid row covers)
     // flags in pairs, one word per wavefront (each wave initialises and sets its own; readers OR the two):

@@ -197,7 +197,7 @@ __global__ void k_sort_equal(int n, int* out) {
 template <bool kRotInGroups>
 __global__ void __launch_bounds__(128) k_replay(pg::AtlasView atlas, const uint32_t* bg, int n_draws, const int32_t* draws,
                                                 const double* deg, uint8_t* out_rgb) {
-    __shared__ uint32_t fb[pg::kFbWords];
+    __shared__ alignas(16) uint32_t fb[pg::kFbWords];
     const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int k = threadIdx.x; k < pg::kFbWords; k += 128) fb[k] = bg[k] | 0x5a000000u;  // (the top byte is nobody's)
     __syncthreads();

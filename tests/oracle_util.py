@@ -21,7 +21,15 @@ _registered = set()
 
 
 def build_oracle():
-    subprocess.run(["make", "-C", ORACLE_DIR, "-s"], check=True)
+    """`make -C oracle` under a file lock: several processes ask at once (pytest workers, the spawned ranks of the
+    distributed tests) and only one of them may be compiling; with everything up to date make does nothing."""
+    import fcntl
+    with open(os.path.join(ORACLE_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            subprocess.run(["make", "-C", ORACLE_DIR, "-s"], check=True)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 def oracle():

@@ -29,7 +29,8 @@ def have_reference_build():
     """oracle/_ref is built from /root/reference when that tree is present (this container); elsewhere a prebuilt copy
     that travelled with the snapshot is used if it is there."""
     if os.path.isdir(REFERENCE):
-        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s"], check=True)
+        import oracle_util
+        oracle_util.build_oracle()  # (under the build lock; a no-op when everything is up to date)
     return all(os.path.exists(os.path.join(REF_DIR, "libref_%s.so" % f)) for f in set(FAMILY.values()))
 
 
@@ -114,6 +115,23 @@ def random_cave(rng, gw, gh, p_wall=0.5):
     """A cave grid as caveflyer/tilemap.cpp seeds it (independent wall bits); numpy's own generator — this is test
     input, the same for both sides."""
     return (rng.random(gw * gh) < p_wall).astype(np.int32)
+
+
+def rect_pairs(rng, n):
+    """Rectangles as the games build them (positions on a 1/4 … 1/64 lattice so that exact touching is common, sizes from
+    the games' hit boxes) plus raw random ones."""
+    base = rng.integers(-64, 64 * 64, size=(n, 2)).astype(np.float32) / np.float32(64.0)
+    size = rng.choice(np.array([0.02, 0.1, 0.15, 0.25, 0.5, 0.8, 0.95, 1.0, 2.0], np.float32), size=(n, 2))
+    a = np.concatenate([base, size], axis=1)
+    off = rng.integers(-96, 97, size=(n, 2)).astype(np.float32) / np.float32(64.0)
+    size_b = rng.choice(np.array([0.02, 0.1, 0.25, 0.5, 1.0, 1.0, 1.0, 3.0], np.float32), size=(n, 2))
+    b = np.concatenate([base + off, size_b], axis=1)
+    k = n // 4
+    a[:k] = rng.normal(0, 10, size=(k, 4)).astype(np.float32)
+    b[:k] = rng.normal(0, 10, size=(k, 4)).astype(np.float32)
+    a[:k, 2:] = np.abs(a[:k, 2:])
+    b[:k, 2:] = np.abs(b[:k, 2:])
+    return a.astype(np.float32), b.astype(np.float32)
 
 
 def ecs_random_script(rng, n_ops):

@@ -118,3 +118,28 @@ def test_oracle_reseeded_reset_repeats_the_level_and_keeps_the_old_camera():
     assert np.array_equal(sb[7:9], cam)                # the camera is the one the last step left (D3)
     assert not np.array_equal(a, b)                    # so the two reset frames of one level differ
     assert np.array_equal(sa[:7], sb[:7])              # agent spawn state identical
+
+
+def test_oracle_aabb_and_ecs_match_the_recorded_reference_outputs():
+    """tests/golden/ref_aabb_ecs.npz (helpers.cpp / ecs.cpp of the reference, recorded by make_ref_fixtures.py) against
+    the oracle's own pieces — in a fresh process, because both sides' entity sets keep their bucket arrays across
+    clear(): the scripts only reproduce when run from the beginning, in order.  Travels to boxes without /root/reference."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+import ref_util
+z = np.load(os.path.join(%r, "golden", "ref_aabb_ecs.npz"))
+ora = ref_util.Side("pgo")
+hit, ov = ora.collisions(z["a"], z["b"])
+assert np.array_equal(hit, z["hit"]) and np.array_equal(ov.view(np.uint32), z["overlap"].view(np.uint32))
+for k in range(int(z["n_scripts"])):
+    ids, orders = ora.ecs_script(z["ops%%d" %% k], z["args%%d" %% k])
+    assert np.array_equal(ids, z["ids%%d" %% k]), k
+    assert np.array_equal(orders, z["orders%%d" %% k]), k
+print("ok")
+''' % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]

@@ -31,7 +31,10 @@ def st():
                        ("pgst_mt", [c_int, V, c_int, c_int, V]), ("pgst_draws", [c_uint32, c_int, V, V, V, V, V, c_int, V, V]),
                        ("pgst_bulk", [c_uint32, c_int, c_int, V, V]), ("pgst_hash_script", [c_int, V, V, V]),
                        ("pgst_set_rounds", [c_int, V, V, V]), ("pgst_sort_equal", [c_int, V]),
-                       ("pgst_replay", [c_int, c_int, V, c_int, V, V, c_int, V, V, V])):
+                       ("pgst_replay", [c_int, c_int, V, c_int, V, V, c_int, V, V, V]),
+                       ("pgst_rooms_40", [V, c_uint32, c_uint32, V, V, V, V, V]),
+                       ("pgst_rooms_20", [V, c_uint32, c_uint32, V, V, V, V, V]),
+                       ("pgst_rooms_45", [V, c_uint32, c_uint32, V, V, V, V, V])):
         getattr(lib, name).argtypes = args
         getattr(lib, name).restype = c_int
     assert lib.pgst_device_count() > 0
@@ -253,8 +256,8 @@ def test_integer_raster_arithmetic_and_aabb(st):
     # H1 / H2 on the device against the REFERENCE's helpers.cpp where oracle/_ref travelled with the snapshot, else
     # against the oracle's restatement (itself pinned to helpers.cpp by tests/test_reference_pin.py)
     import ref_util
-    from test_reference_pin import _rect_pairs
-    ra, rb = _rect_pairs(rng, 1_000_000)
+    import ref_util
+    ra, rb = ref_util.rect_pairs(rng, 1_000_000)
     side = ref_util.Side("ref") if os.path.exists(os.path.join(ref_util.REF_DIR, "libref_ecs.so")) else ref_util.Side("pgo")
     h0, o0 = side.collisions(ra, rb)
     hit, ov = np.zeros(ra.shape[0], np.uint8), np.zeros((ra.shape[0], 4), np.float32)
@@ -322,3 +325,114 @@ def test_sprite_replay_matches_the_raster_spec(st, rot_in_groups):
         bad = np.nonzero((got != want).reshape(-1, 3).any(axis=1))[0]
         assert bad.size == 0, "seed %d: %d pixels differ, first (y=%d, x=%d): got %s want %s" % (
             seed, bad.size, bad[0] // 64, bad[0] % 64, got.reshape(-1, 3)[bad[0]], want.reshape(-1, 3)[bad[0]])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The device held to outputs of the REFERENCE's own compiled sources (tests/golden/ref_fixtures.json, ref_aabb_ecs.npz:
+# recorded by tests/golden/make_ref_fixtures.py from oracle/_ref) — no oracle in between.
+# ------------------------------------------------------------------------------------------------------------------
+def _golden(name):
+    return os.path.join(ROOT, "tests", "golden", name)
+
+
+def test_room_pipeline_matches_the_reference_room_generator(st):
+    """caveflyer/room_generator.cpp:4-202 (= jumper's): two automaton updates, find_best_room's ITERATION ORDER (what
+    `for (int i : best_room)` hands the level), find_path, expand_room's result — pg_rooms.h on the device, for the three
+    world sizes the games' modes use."""
+    import json
+    with open(_golden("ref_fixtures.json")) as f:
+        rooms = json.load(f)["rooms"]
+    assert {r["gw"] for r in rooms} == {40, 20, 45}
+    for r in rooms:
+        side = r["gw"]
+        n = side * side
+        raw = np.array([int(c) for c in r["raw"]], np.uint8)
+        cave, wide = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+        best, path, counts = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(2, np.int32)
+        fn = getattr(st, "pgst_rooms_%d" % side)
+        assert fn(_p(raw), r["src_sel"], r["dst_sel"], _p(cave), _p(best), _p(path), _p(wide), _p(counts)) == 0
+        assert "".join(str(int(v)) for v in cave) == r["cave"], "automaton"
+        assert best[:counts[0]].tolist() == r["best_order"], "find_best_room iteration order (side %d)" % side
+        if r["path"] and r["path"][0] != r["path"][-1]:
+            assert path[:counts[1]].tolist() == r["path"], "find_path"
+            assert sorted(np.nonzero(wide)[0].tolist()) == sorted(r["wide_order"]), "expand_room membership"
+
+
+def test_aabb_helpers_match_the_reference_on_recorded_pairs(st):
+    """helpers.cpp:40-108 check_collision / get_collision_overlap, 12 000 recorded pairs, results as bit patterns."""
+    z = np.load(_golden("ref_aabb_ecs.npz"))
+    a, b = np.ascontiguousarray(z["a"]), np.ascontiguousarray(z["b"])
+    hit, ov = np.zeros(len(a), np.uint8), np.zeros((len(a), 4), np.float32)
+    assert st.pgst_box(len(a), _p(a), _p(b), _p(hit), _p(ov)) == 0
+    assert 0.05 < z["hit"].mean() < 0.95
+    assert np.array_equal(hit, z["hit"])
+    assert np.array_equal(ov.view(np.uint32), z["overlap"].view(np.uint32))
+
+
+def _fnv(values):
+    h = 2166136261
+    for v in values:
+        h = ((h ^ (int(v) & 0xFFFFFFFF)) * 16777619) & 0xFFFFFFFF
+    return h
+
+
+def test_set_orders_match_the_reference_coordinator_scripts(st):
+    """ecs.cpp:3-83: the iteration order of the reference's three systems' entity sets after every operation of 24
+    recorded create / destroy / remove-component / clear scripts (run back to back in one process: the sets keep their
+    bucket arrays across clear()).  Each system's set is replayed on the device twin of std::unordered_set<int>
+    (pg_order.h HashOrder) as the inserts / erases / clears the Coordinator performs, with the entity ids the reference
+    handed out, and must list the same ids in the same order after every operation."""
+    z = np.load(_golden("ref_aabb_ecs.npz"))
+    n_scripts = int(z["n_scripts"])
+    assert n_scripts >= 20
+    # per system: the primitive stream, and for every (script, op) where to look and what to see
+    prim = [([], []) for _ in range(3)]      # (ops, keys): 0 insert-if-absent, 1 erase-if-present, 2 clear
+    look = [[] for _ in range(3)]            # (index into the stream, expected FNV of (count, ids…))
+    for k in range(n_scripts):
+        ops, args, ids, orders = z["ops%d" % k], z["args%d" % k], z["ids%d" % k], z["orders%d" % k]
+        for sysn in range(3):                # ref_ecs_script starts with clear_entities()
+            prim[sysn][0].append(2)
+            prim[sysn][1].append(0)
+        has_a, has_b, at = {}, {}, 0
+        for op, arg, eid in zip(ops, args, ids):
+            eid = int(eid)
+
+            def put(sysn, code):
+                prim[sysn][0].append(code)
+                prim[sysn][1].append(eid)
+            if op == 0:                      # create, add A if arg & 1, then B if arg & 2 (each add: signature changed)
+                a = b = False
+                for bit in (1, 2):
+                    if arg & bit:
+                        a, b = a or bit == 1, b or bit == 2
+                        put(0, 0 if a else 1)            # SysA wants {A}
+                        put(1, 0 if (a and b) else 1)    # SysAB wants {A, B}
+                        put(2, 0)                        # the empty signature matches every entity
+                has_a[eid], has_b[eid] = a, b
+            elif op == 1 and eid >= 0:       # destroy: erased from every system
+                for sysn in range(3):
+                    put(sysn, 1)
+                has_a.pop(eid), has_b.pop(eid)
+            elif op == 2:                    # clear_entities
+                for sysn in range(3):
+                    prim[sysn][0].append(2)
+                    prim[sysn][1].append(0)
+                has_a.clear(), has_b.clear()
+            elif op == 3 and eid >= 0:       # remove component B: signature changed
+                has_b[eid] = False
+                put(0, 0 if has_a[eid] else 1)
+                put(1, 1)
+                put(2, 0)
+            for sysn in range(3):
+                count = int(orders[at])
+                look[sysn].append((len(prim[sysn][0]) - 1, _fnv([count] + orders[at + 1:at + 1 + count].tolist())))
+                at += 1 + count
+        assert at == len(orders)
+    for sysn in range(3):
+        ops = np.array(prim[sysn][0], np.int32)
+        keys = np.array(prim[sysn][1], np.int32)
+        assert keys.max() < 2048
+        got = np.zeros(len(ops), np.uint32)
+        assert st.pgst_hash_script(len(ops), _p(ops), _p(keys), _p(got)) == 0
+        bad = [i for i, (where, want) in enumerate(look[sysn]) if got[where] != want]
+        assert not bad, "system %d: order differs after operation %d of %d" % (sysn, bad[0], len(look[sysn]))

@@ -97,28 +97,11 @@ def test_room_pipeline_matches_reference(sides):
     assert n >= 1000
 
 
-def _rect_pairs(rng, n):
-    """Rectangles as the games build them (positions on a 1/4 … 1/64 lattice so that exact touching is common, sizes from
-    the games' hit boxes) plus raw random ones."""
-    base = rng.integers(-64, 64 * 64, size=(n, 2)).astype(np.float32) / np.float32(64.0)
-    size = rng.choice(np.array([0.02, 0.1, 0.15, 0.25, 0.5, 0.8, 0.95, 1.0, 2.0], np.float32), size=(n, 2))
-    a = np.concatenate([base, size], axis=1)
-    off = rng.integers(-96, 97, size=(n, 2)).astype(np.float32) / np.float32(64.0)
-    size_b = rng.choice(np.array([0.02, 0.1, 0.25, 0.5, 1.0, 1.0, 1.0, 3.0], np.float32), size=(n, 2))
-    b = np.concatenate([base + off, size_b], axis=1)
-    k = n // 4
-    a[:k] = rng.normal(0, 10, size=(k, 4)).astype(np.float32)
-    b[:k] = rng.normal(0, 10, size=(k, 4)).astype(np.float32)
-    a[:k, 2:] = np.abs(a[:k, 2:])
-    b[:k, 2:] = np.abs(b[:k, 2:])
-    return a.astype(np.float32), b.astype(np.float32)
-
-
 def test_aabb_helpers_match_reference_on_a_million_pairs(sides):
     """helpers.cpp:40-46 check_collision, :48-108 get_collision_overlap — 10⁶ pairs, results compared as bit patterns."""
     ref, ora = sides
     rng = np.random.default_rng(7)
-    a, b = _rect_pairs(rng, 1_000_000)
+    a, b = ref_util.rect_pairs(rng, 1_000_000)
     h0, o0 = ref.collisions(a, b)
     h1, o1 = ora.collisions(a, b)
     assert 0.05 < h0.mean() < 0.95  # the sample exercises both outcomes
