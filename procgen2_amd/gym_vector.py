@@ -10,8 +10,12 @@ Boxes; what RL code imports is a vector env with real spaces.  This class gives 
 * `single_observation_space = Box(0, 255, (64, 64, 3), uint8)`, `single_action_space = Discrete(15)` and their batched
   forms — real `gymnasium.spaces` objects when gymnasium is importable, otherwise light stand-ins with the same
   attributes (`shape`, `dtype`, `low`, `high`, `n`, `contains`, `sample`); nothing else of gymnasium is needed.
-* Autoreset is Gymnasium 1.x's NEXT_STEP mode, which is exactly the engine's policy: the step after a
-  terminal one ignores the action, returns the first observation of the new episode with reward 0, terminated False.
+* Autoreset is Gymnasium 1.x's NEXT_STEP mode by default, which is exactly the engine's policy: the step
+  after a terminal one ignores the action, returns the first observation of the new episode with reward 0, terminated
+  False.  `autoreset_mode="same_step"` gives Gymnasium's SAME_STEP mode instead: the terminal step itself returns the
+  first observation of the next episode, and the terminal observation travels in `info["final_obs"]` (see step()).  It
+  is the reference caller's own loop — `if terminated: obs, info = env.reset()` (`game_test.py:36-40`) — done for the
+  envs that ended, with their random streams continuing, so both modes walk through the same levels.
   `truncated` is always False (the reference never truncates: `coinrun.cpp:367`).
 * `reset(seed=s)` reseeds env i with `s + i` (a list/array gives one seed per env); `reset(options={"reset_mask": m})`
   resets only the envs where `m` is true, as Gymnasium's vector API allows.
@@ -120,9 +124,12 @@ class GymVectorAdapter(_VectorBase):
 
     metadata = {"render_modes": ["rgb_array"], "autoreset_mode": "next_step"}
 
-    def __init__(self, engine, output="torch", render_mode=None, render_size=(512, 512)):
+    def __init__(self, engine, output="torch", render_mode=None, render_size=(512, 512), autoreset_mode="next_step"):
         if output not in ("torch", "numpy"):
             raise ValueError("output must be 'torch' or 'numpy'")
+        if autoreset_mode not in ("next_step", "same_step"):
+            raise ValueError("autoreset_mode must be 'next_step' or 'same_step'")
+        self.autoreset_mode = autoreset_mode
         if render_mode not in (None, "rgb_array"):
             raise ValueError("render_mode must be None or 'rgb_array'")
         self.engine = engine
@@ -133,9 +140,11 @@ class GymVectorAdapter(_VectorBase):
          self.action_space) = make_spaces(self.num_envs)
         self.render_mode = render_mode
         self.closed = False
+        self.metadata = dict(self.metadata, autoreset_mode=autoreset_mode)
         if _gym is not None:
             try:
-                self.metadata = dict(self.metadata, autoreset_mode=_gym.vector.AutoresetMode.NEXT_STEP)
+                modes = _gym.vector.AutoresetMode
+                self.metadata["autoreset_mode"] = modes.SAME_STEP if autoreset_mode == "same_step" else modes.NEXT_STEP
             except Exception:
                 pass
 
@@ -180,7 +189,24 @@ class GymVectorAdapter(_VectorBase):
         obs, reward, done = self.engine.step(actions)
         terminated = done != 0
         truncated = np.zeros(self.num_envs, dtype=bool) if self.output == "numpy" else (done != done)
-        return self._out(obs), self._out(reward), self._out(terminated, bool), truncated, {}
+        info = {}
+        if self.autoreset_mode == "same_step" and bool(terminated.any()):
+            # SAME_STEP: keep the terminal frames, then reset exactly the envs that ended (streams continue), which
+            # also takes them off the engine's own next-step reset.  reward / terminated stay the terminal step's.
+            # info["final_obs"]: the terminal observations of the envs that ended, [k, 64, 64, 3] in env order;
+            # info["final_obs_env"]: their indices; info["_final_obs"]: the mask over all envs (Gymnasium's key).
+            if hasattr(terminated, "nonzero") and not isinstance(terminated, np.ndarray):  # torch
+                mask, rew = terminated.clone(), reward.clone()
+                where = mask.nonzero().flatten()
+                final = obs[where].clone()
+            else:
+                mask, rew = np.array(terminated, dtype=bool), np.array(reward)
+                where = np.nonzero(mask)[0]
+                final = np.array(obs[where])
+            obs = self.engine.reset(mask=mask, seeds=None)  # (clears reward and done of those envs in the engine)
+            reward, terminated = rew, mask
+            info = {"final_obs": self._out(final), "final_obs_env": self._out(where), "_final_obs": self._out(mask, bool)}
+        return self._out(obs), self._out(reward), self._out(terminated, bool), truncated, info
 
     def render(self, index=0):
         """The human-size frame of one env (the reference's `cenv_render`, coinrun.cpp:393-411; default 512×512 as its
@@ -212,10 +238,10 @@ class ProcgenGymVectorEnv(GymVectorAdapter):
     """`GymVectorAdapter` over the HIP engine.  Raises if there is no HIP device (no CPU fallback)."""
 
     def __init__(self, game, num_envs, device=0, seed=1, env_offset=0, output="torch", num_levels=0, start_level=0,
-                 distribution_mode=None, render_mode=None, render_size=(512, 512)):
+                 distribution_mode=None, render_mode=None, render_size=(512, 512), autoreset_mode="next_step"):
         from .vec_env import ProcgenVecEnv
         super().__init__(ProcgenVecEnv(game, num_envs, device=device, seed_base=seed, env_offset=env_offset,
                                        num_levels=num_levels, start_level=start_level,
                                        distribution_mode=distribution_mode), output=output, render_mode=render_mode,
-                         render_size=render_size)
+                         render_size=render_size, autoreset_mode=autoreset_mode)
         self.game = game

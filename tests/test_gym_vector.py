@@ -111,6 +111,76 @@ def test_wrapper_over_the_oracle_engine_reset_step_autoreset():
     env.close()  # idempotent
 
 
+def test_same_step_autoreset_walks_the_same_episodes_as_next_step():
+    """SAME_STEP (SURVEY.md §8f-1 `final_observation`): the terminal step returns the next episode's first frame, the
+    terminal frame travels in info["final_obs"]; the frames an env shows are NEXT_STEP's with the reset step taken out."""
+    n, steps = 5, 520
+    rng = np.random.default_rng(4)
+    actions = rng.integers(0, NUM_ACTIONS, (steps, n))
+    same = GymVectorAdapter(OracleEngine("maze", n), output="numpy", autoreset_mode="same_step")
+    nxt = GymVectorAdapter(OracleEngine("maze", n), output="numpy")
+    o_s, _ = same.reset(seed=11)
+    o_n, _ = nxt.reset(seed=11)
+    assert np.array_equal(o_s, o_n)
+    ends = 0
+    for s in range(200):
+        obs, rew, term, trunc, info = same.step(actions[s])
+        if term.any():
+            assert set(info) == {"final_obs", "final_obs_env", "_final_obs"}
+            assert np.array_equal(info["final_obs_env"], np.nonzero(term)[0]) and np.array_equal(info["_final_obs"], term)
+            assert info["final_obs"].shape == (int(term.sum()), 64, 64, 3)
+            ends += int(term.sum())
+        else:
+            assert info == {}
+    assert ends > 0
+    same.close()
+    nxt.close()
+    # one env, exact comparison: SAME_STEP's stream == NEXT_STEP's with the reset steps (which take any action) removed
+    a = GymVectorAdapter(OracleEngine("maze", 1, seed_base=3), output="numpy", autoreset_mode="same_step")
+    b = GymVectorAdapter(OracleEngine("maze", 1, seed_base=3), output="numpy")
+    a.reset()
+    b.reset()
+    for s in range(steps):
+        oa, ra, ta, _, ia = a.step(actions[s, :1])
+        ob, rb, tb, _, _ = b.step(actions[s, :1])
+        assert ra[0] == rb[0] and ta[0] == tb[0]
+        if ta[0]:
+            assert np.array_equal(ia["final_obs"][0], ob[0])  # the terminal frame
+            ob, rb, tb, _, _ = b.step(np.zeros(1, np.int64))  # NEXT_STEP spends a step on the reset
+            assert rb[0] == 0.0 and not tb[0]
+        assert np.array_equal(oa, ob), s
+    a.close()
+    b.close()
+    with pytest.raises(ValueError):
+        GymVectorAdapter(OracleEngine("maze", 1), autoreset_mode="sometimes")
+
+
+@pytest.mark.gpu
+def test_same_step_autoreset_on_the_hip_engine_matches_the_oracle_engine():
+    import torch
+    from procgen2_amd.gym_vector import ProcgenGymVectorEnv
+    n = 16
+    gpu = ProcgenGymVectorEnv("bossfight", n, seed=1, autoreset_mode="same_step")  # short episodes, in-step random draws
+    cpu = GymVectorAdapter(OracleEngine("bossfight", n), output="numpy", autoreset_mode="same_step")
+    assert np.array_equal(gpu.reset(seed=5)[0].cpu().numpy(), cpu.reset(seed=5)[0])
+    rng = np.random.default_rng(9)
+    ends = 0
+    for s in range(300):
+        a = rng.integers(0, NUM_ACTIONS, n)
+        og, rg, tg, _, ig = gpu.step(torch.as_tensor(a, dtype=torch.int32, device="cuda"))
+        oc, rc, tc, _, ic = cpu.step(a)
+        assert np.array_equal(og.cpu().numpy(), oc), s
+        assert np.array_equal(rg.cpu().numpy(), rc) and np.array_equal(tg.cpu().numpy(), tc)
+        assert set(ig) == set(ic)
+        if ic:
+            assert np.array_equal(ig["final_obs"].cpu().numpy(), ic["final_obs"])
+            assert np.array_equal(ig["final_obs_env"].cpu().numpy(), ic["final_obs_env"])
+            ends += len(ic["final_obs_env"])
+    assert ends > 10
+    gpu.close()
+    cpu.close()
+
+
 @pytest.mark.gpu
 def test_wrapper_over_the_hip_engine_matches_the_oracle_engine():
     import torch

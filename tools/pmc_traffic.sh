@@ -23,6 +23,10 @@ for k,v in out.items():
     f=v.get("FETCH_SIZE_KB_per_launch",0.0); w=v.get("WRITE_SIZE_KB_per_launch",0.0)
     v["bytes_raw"]=(f+w)*1024
     v["bytes_corrected"]=(2*f+w)*1024   # gfx950: FETCH_SIZE tallies 128-B requests at 64 B (MI355X_MICROARCH.md §HBM)
+import sys
+sys.path.insert(0,"$R")
+import bench
+out["_csrc_sha1"]=bench.csrc_fingerprint()   # what the profile was taken on: bench.py reports traffic_stale when the tree has moved on
 json.dump(out,open("$R/gpurun_out/${TAG}_traffic.json","w"),indent=1)
 print(json.dumps(out,indent=1))
 PY
