@@ -189,6 +189,13 @@ static void test_sort() {
 
 static void test_blend() {
     for (uint32_t x = 0; x < 65536; x++) CHECK(pg::div255(x) == x / 255, "div255(%u)", x);
+    // the two-at-once form: every value a product of two bytes can take, in either half, beside an extreme in the other
+    for (uint32_t x = 0; x <= 65025; x++)
+        for (uint32_t other : {0u, 1u, 254u, 255u, 65024u, 65025u}) {
+            const uint32_t lo = pg::div255_pair(x | other << 16), hi = pg::div255_pair(other | x << 16);
+            CHECK((lo & 0xffffu) == x / 255 && (lo >> 16) == other / 255, "div255_pair low half %u beside %u", x, other);
+            CHECK((hi >> 16) == x / 255 && (hi & 0xffffu) == other / 255, "div255_pair high half %u beside %u", x, other);
+        }
     for (int b = 1; b < 700; b++)
         for (int a = 0; a < (1 << 22); a += (b < 140 ? 1 + a / 4096 : 997)) CHECK(pg::udiv_small(a, b) == a / b, "udiv_small(%d,%d)", a, b);
     for (int n = 1; n <= 70; n++)  // every (column, width) pair a blit can see
@@ -205,6 +212,17 @@ static void test_blend() {
                                                   uint32_t(s) | uint32_t(s) << 8 | uint32_t(s) << 16 | 0xab000000u, a);
                 CHECK(got == (uint32_t(want) | uint32_t(want) << 8 | uint32_t(want) << 16), "blend a=%d s=%d d=%d", a, s, d);
             }
+    {   // channels that differ from each other (red and blue share a word inside blend_px)
+        uint32_t seed = 12345u;
+        auto next = [&]() { return seed = seed * 1664525u + 1013904223u; };
+        for (int k = 0; k < 4000000; k++) {
+            const uint32_t d = next() >> 8, sc = next(), a = next() >> 24;
+            uint32_t want = 0;
+            for (int sh = 0; sh < 24; sh += 8)
+                want |= ((((sc >> sh) & 255u) * a) / 255u + (((d >> sh) & 255u) * (255u - a)) / 255u) << sh;
+            CHECK(pg::blend_px(d, sc, static_cast<int>(a)) == want, "blend_px(%08x, %08x, %u)", d, sc, a);
+        }
+    }
     // resolve_draw is the composition of its two axes and reproduces the known coinrun tile geometry:
     // a 128-px tile at zoom 0.3 is 4.8 px, padded source 155 texels → destination trunc(5.8125) = 5 px.
     pg::Camera cam{100.0f, 200.0f, 64.0f, 64.0f, 0.3f};

@@ -70,6 +70,10 @@ __global__ void k_blend(int n, const uint32_t* dst, const uint32_t* src, const i
     out[i] = pg::blend_px(dst[i], src[i], a[i]);
     d255[i] = pg::div255(static_cast<uint32_t>(i) & 0xffffu);
 }
+__global__ void k_div255_pair(int n, const uint32_t* x, uint32_t* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = pg::div255_pair(x[i]);
+}
 __global__ void k_box(int n, const float* a, const float* b, uint8_t* hit, float* ov) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -276,6 +280,11 @@ ST_API int pgst_blend(int n, const uint32_t* dst, const uint32_t* src, const int
     Dev<int> da(a, n);
     hipLaunchKernelGGL(k_blend, dim3((n + 255) / 256), dim3(256), 0, 0, n, dd.p, dsrc.p, da.p, dout.p, d255.p);
     return finish() || !dout.down(out) || !d255.down(div255);
+}
+ST_API int pgst_div255_pair(int n, const uint32_t* x, uint32_t* out) {
+    Dev<uint32_t> dx(x, n), dout(n);
+    hipLaunchKernelGGL(k_div255_pair, dim3((n + 255) / 256), dim3(256), 0, 0, n, dx.p, dout.p);
+    return finish() || !dout.down(out);
 }
 ST_API int pgst_box(int n, const float* a, const float* b, uint8_t* hit, float* overlap) {
     Dev<float> da(a, size_t(n) * 4), db(b, size_t(n) * 4), dov(size_t(n) * 4);

@@ -28,6 +28,7 @@ def st():
     V = c_void_p
     for name, args in (("pgst_sincos", [c_int, V, V, V]), ("pgst_atan2", [c_int, V, V, V, V]), ("pgst_div", [c_int, V, V, V, V]),
                        ("pgst_blend", [c_int, V, V, V, V, V]), ("pgst_box", [c_int, V, V, V, V]),
+                       ("pgst_div255_pair", [c_int, V, V]),
                        ("pgst_mt", [c_int, V, c_int, c_int, V]), ("pgst_draws", [c_uint32, c_int, V, V, V, V, V, c_int, V, V]),
                        ("pgst_bulk", [c_uint32, c_int, c_int, V, V]), ("pgst_hash_script", [c_int, V, V, V]),
                        ("pgst_set_rounds", [c_int, V, V, V]), ("pgst_sort_equal", [c_int, V]),
@@ -253,6 +254,14 @@ def test_integer_raster_arithmetic_and_aabb(st):
     bad = np.nonzero(out != want)[0]
     assert bad.size == 0, "blend_px: %d mismatches, first dst=%08x src=%08x a=%d: got %08x want %08x" % (
         bad.size, dst[bad[0]], src[bad[0]], al[bad[0]], out[bad[0]], want[bad[0]])
+    # floor(x / 255) two halves at once (pg_geom.h div255_pair, inside blend_px): every product of two bytes, in either
+    # half, beside the extremes in the other
+    xs = np.arange(65026, dtype=np.uint32)
+    pairs = np.concatenate([xs | np.uint32(o << 16) for o in (0, 1, 254, 255, 65024, 65025)] +
+                           [np.uint32(o) | (xs << 16) for o in (0, 1, 254, 255, 65024, 65025)]).astype(np.uint32)
+    got = np.zeros_like(pairs)
+    assert st.pgst_div255_pair(pairs.size, _p(pairs), _p(got)) == 0
+    assert np.array_equal(got, ((pairs & 0xFFFF) // 255) | (((pairs >> 16) // 255) << 16))
     # H1 / H2 on the device against the REFERENCE's helpers.cpp where oracle/_ref travelled with the snapshot, else
     # against the oracle's restatement (itself pinned to helpers.cpp by tests/test_reference_pin.py)
     import ref_util
