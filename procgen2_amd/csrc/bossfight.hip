@@ -830,7 +830,10 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
         bg_sc = 1.0f / d.z * kCamSize / kCamScale;
     }
     bool composed = false;
-    if (!(flags & 1)) {  // no tile layer in this game: the background over black (pg_render.h)
+    if (PG_ABL(flags, 0x10000)) {  // (timing experiment, -DPG_ABLATE builds only: no background)
+        wave_clear(fb, lane, half, halves);
+        composed = true;
+    } else if (!(flags & 1)) {  // no tile layer in this game: the background over black (pg_render.h)
         compose_background(fb, atlas, bg_axis(cam, bg_d, bg_px, bg_py, bg_sc, half), lane, half, halves);
         composed = true;
     }
@@ -864,6 +867,7 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
             has = resolve_rotated_at(cam, d.y, d.z, d.x, px * kUnitPx - size * d.y * 0.5f, py * kUnitPx - size * d.z * 0.5f,
                                      rot_sn, rot_cs, size, 1.0f, mine);
         }
+        if (PG_ABL(flags, 0x20000)) has = false;  // (timing experiment: no boss bullets)
         wave_replay_rows<4, true>(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
     }
     // second list, one draw per lane: boss ship, shield, explosions, barriers (positive-z sprites), agent bullets, agent
@@ -939,6 +943,8 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
             }
             has = resolve_draw(cam, d.y, d.z, d.x, wx, wy, sc, al, false, false, mine);
         }
+        if (PG_ABL(flags, 0x40000)) has = has && lane >= 2;    // (timing experiments: no boss ship and shield …
+        if (PG_ABL(flags, 0x80000)) has = has && lane < 2;     //  … nothing but them)
         wave_replay_rows<4, true>(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
     }
     // each wave stores the rows it owns (pg_render.h wave_replay_rows): no barrier

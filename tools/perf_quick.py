@@ -22,6 +22,7 @@ ap.add_argument("--settle", type=int, default=400)
 ap.add_argument("--steps", type=int, default=128)
 ap.add_argument("--check", default="128x160", help="ENVSxSTEPS of the lock-step, 0x0 to skip")
 ap.add_argument("--envs", type=int, default=65536)
+ap.add_argument("--debug", type=lambda v: int(v, 0), default=0, help="pgv_set_debug flags for the timed part (ablation bits: the -DPG_ABLATE library only)")
 ap.add_argument("--lib", default=None, help="another build of the engine (e.g. lib/libprocgen2_hip_ablate.so)")
 a = ap.parse_args()
 cn, cs = (int(v) for v in a.check.split("x"))
@@ -48,6 +49,8 @@ for game in a.games.split(","):
     e = EngineVec(game, a.envs, seed_base=1, lib_path=a.lib)
     e.reset()
     e.timed(a.settle)
+    if a.debug:
+        e.set_debug(a.debug)
     tot, ren = e.timed(a.steps)
     e.close()
     print("%-10s %-28s render %.4f ms  step %.4f ms  -> %.1f M env-steps/s" %
