@@ -47,7 +47,8 @@ constexpr bool kPrune = PG_VARIANT != 2;              // tilemap.cpp:176 should_
 constexpr float kSpikeProb = PG_VARIANT == 2 ? 0.0f : 0.2f;  // tilemap.cpp:205
 constexpr int kMaxSpikes = 126;             // entity ids: 0 carrot, 1 bunny, 2.. spikes
 constexpr int kMaxSprites = kMaxSpikes + 1;  // carrot + spikes
-constexpr int kPuffs = 10;
+constexpr int kPuffs = 10, kPuffSlots = 16, kSpikeSlots = 128;
+static_assert(kMaxSprites + 1 <= kSpikeSlots, "draw list row");
 enum Tile : uint8_t { kEmpty = 0, kWallTop = 1, kWallMid = 2, kSpike = 3 };  // tilemap.h:19-26
 
 enum Tex {
@@ -101,9 +102,11 @@ struct State {
     uint8_t* tiles;  // [n][kTileStride]  column-major y + x*H
     float* f;        // [F_COUNT][n]
     int32_t* i;      // [I_COUNT][n]
-    float* pf;       // [PF_COUNT][kPuffs][n]
-    uint16_t* spike_cell;  // [kMaxSpikes][n]
-    uint8_t* draw;         // [kMaxSprites][n]
+    // per-env contiguous tables: the render wavefronts' lanes index them by slot, so a table of one env is a coalesced
+    // request instead of one cache line per lane
+    float* pf;       // [n][PF_COUNT][kPuffSlots]
+    uint16_t* spike_cell;  // [n][kSpikeSlots]
+    uint8_t* draw;         // [n][kSpikeSlots]
     int float_abs;         // game_flags PGV_JUMPER_FLOAT_ABS (D21)
     // the compass ring as it lands on the observation (extend_atlas; word offsets into the atlas, 0 = not prepared)
     uint32_t hud_image, hud_list;
@@ -112,7 +115,9 @@ struct State {
 
 PG_D float& SF(const State& s, int field, int env) { return s.f[size_t(field) * s.n + env]; }
 PG_D int32_t& SI(const State& s, int field, int env) { return s.i[size_t(field) * s.n + env]; }
-PG_D float& PF(const State& s, int field, int k, int env) { return s.pf[(size_t(field) * kPuffs + k) * s.n + env]; }
+PG_D float& PF(const State& s, int field, int k, int env) { return s.pf[(size_t(env) * PF_COUNT + field) * kPuffSlots + k]; }
+PG_D uint16_t& SPK(const State& s, int k, int env) { return s.spike_cell[size_t(env) * kSpikeSlots + k]; }
+PG_D uint8_t& DRW(const State& s, int k, int env) { return s.draw[size_t(env) * kSpikeSlots + k]; }
 
 using Win = TileWinT<W, H, kWallMid>;  // out of bounds is a wall (tilemap.h:84-89)
 PG_D bool is_wall(int t) { return t == kWallMid || t == kWallTop; }
@@ -368,8 +373,8 @@ PG_D void install(const State& s, int env, const Level& lv, int lane) {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(lv.tiles);
     for (int k = lane; k < kTileStride / 4; k += 64) tiles[k] = src[k];
     const int n_spikes = lv.n_spikes;
-    for (int k = lane; k < n_spikes; k += 64) s.spike_cell[size_t(k) * s.n + env] = lv.spike_cell[k];
-    for (int k = lane; k < n_spikes + 1; k += 64) s.draw[size_t(k) * s.n + env] = lv.draw[k];
+    for (int k = lane; k < n_spikes; k += 64) SPK(s, k, env) = lv.spike_cell[k];
+    for (int k = lane; k < n_spikes + 1; k += 64) DRW(s, k, env) = lv.draw[k];
     if (lane < kPuffs)
         for (int f = 0; f < PF_COUNT; f++) PF(s, f, lane, env) = 0.0f;
     if (lane == 0) {
@@ -496,7 +501,7 @@ PG_D void advance(const State& s, int env, int action, float& reward_out, bool& 
             if (ground) avy = 0.0f;
         }
         for (int k = 0; k < n_spikes; k++) {  // hazards: any hit kills, order-free
-            const int cell = s.spike_cell[size_t(k) * s.n + env];
+            const int cell = SPK(s, k, env);
             if (box_hit(body, Box{cell_x(cell) + -0.25f, cell_y(cell) + -0.25f, 0.5f, 0.5f})) alive = false;
         }
         if (box_hit(body, Box{gx + -0.5f, gy + -0.5f, 1.0f, 1.0f})) achieved_goal = true;
@@ -673,7 +678,7 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
         const int hud = lane - bunny_lane;  // 1, 2, 3: circle, needle, bar
         const bool is_hud = hud >= 1 && hud <= 3;
         int id = 0;
-        if (is_draw) id = s.draw[size_t(lane - kPuffs) * s.n + env];
+        if (is_draw) id = DRW(s, lane - kPuffs, env);
         const float avx = SF(s, F_AVX, env), phase = SF(s, F_APHASE, env);
         const bool ground = (sflags & kFlagGround) != 0;
         int bunny_tex;
@@ -716,7 +721,7 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
                 wx = (SF(s, F_GX, env) + -0.5f) * kUnitPx;
                 wy = (SF(s, F_GY, env) + -0.5f) * kUnitPx;
             } else {
-                const int cell = s.spike_cell[size_t(id - 2) * s.n + env];
+                const int cell = SPK(s, id - 2, env);
                 sc = 1.0f * 0.4f;
                 wx = (cell_x(cell) + -0.25f) * kUnitPx;
                 wy = (cell_y(cell) + -0.25f) * kUnitPx;
@@ -789,7 +794,7 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
             bool has = false;
             int id = 0;
             if (k < n_draw) {
-                id = s.draw[size_t(k) * s.n + env];
+                id = DRW(s, k, env);
                 has = true;
             }
             const int4 d = descs.at(id == 0 ? kTexCarrot : kTexSpike);
@@ -800,7 +805,7 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
                     wx = (SF(s, F_GX, env) + -0.5f) * kUnitPx;
                     wy = (SF(s, F_GY, env) + -0.5f) * kUnitPx;
                 } else {
-                    const int cell = s.spike_cell[size_t(id - 2) * s.n + env];
+                    const int cell = SPK(s, id - 2, env);
                     scale = 1.0f * 0.4f;
                     wx = (cell_x(cell) + -0.25f) * kUnitPx;
                     wy = (cell_y(cell) + -0.25f) * kUnitPx;
@@ -923,13 +928,13 @@ __global__ void __launch_bounds__(kFrameThreads) frame_kernel(State s, AtlasView
                (PF(s, PF_Y, k, env) + offset_y) * kUnitPx - 0.5f * d.z * scale, scale * kUnitPx / d.y, alpha);
     }
     for (int k = 0; k < n_draw; k++) {
-        const int id = s.draw[size_t(k) * s.n + env];
+        const int id = DRW(s, k, env);
         if (id == 0) {
             const float scale = 1.0f * 1.0f;
             P.draw(kTexCarrot, (SF(s, F_GX, env) + -0.5f) * kUnitPx, (SF(s, F_GY, env) + -0.5f) * kUnitPx,
                    scale * kUnitPx / P.desc(kTexCarrot).y);
         } else {
-            const int cell = s.spike_cell[size_t(id - 2) * s.n + env];
+            const int cell = SPK(s, id - 2, env);
             const float scale = 1.0f * 0.4f;
             P.draw(kTexSpike, (cell_x(cell) + -0.25f) * kUnitPx, (cell_y(cell) + -0.25f) * kUnitPx,
                    scale * kUnitPx / P.desc(kTexSpike).y);
@@ -1025,9 +1030,9 @@ class JumperGame final : public Game {
         l.tiles = take(size_t(n) * kTileStride);
         l.f = take(size_t(F_COUNT) * n * 4);
         l.i = take(size_t(I_COUNT) * n * 4);
-        l.pf = take(size_t(PF_COUNT) * kPuffs * n * 4);
-        l.spike = take(size_t(kMaxSpikes) * n * 2);
-        l.draw = take(size_t(kMaxSprites) * n);
+        l.pf = take(size_t(PF_COUNT) * kPuffSlots * n * 4);
+        l.spike = take(size_t(kSpikeSlots) * n * 2);
+        l.draw = take(size_t(kSpikeSlots) * n);
         l.total = off;
         return l;
     }
@@ -1136,10 +1141,10 @@ class JumperGame final : public Game {
                                 f(F_PTIMER), (flags & kFlagPuffOn) ? 1.0f : 0.0f, f(F_GX), f(F_GY),
                                 static_cast<float>(n_spikes)};
         for (int k = 0; k < kPuffs; k++)
-            for (int fld : {PF_X, PF_Y, PF_LIFE}) v.push_back(rf(s_.pf, (size_t(fld) * kPuffs + k) * n + env));
+            for (int fld : {PF_X, PF_Y, PF_LIFE}) v.push_back(rf(s_.pf, (size_t(env) * PF_COUNT + fld) * kPuffSlots + k));
         for (int k = 0; k < n_spikes; k++) {
             uint16_t cell;
-            hipMemcpy(&cell, s_.spike_cell + size_t(k) * n + env, 2, hipMemcpyDeviceToHost);
+            hipMemcpy(&cell, s_.spike_cell + size_t(env) * kSpikeSlots + k, 2, hipMemcpyDeviceToHost);
             v.push_back(static_cast<float>(cell / H) + 0.5f);
             v.push_back(static_cast<float>(H - 1 - cell % H) + 0.5f);
         }
