@@ -328,7 +328,14 @@ def mixed(a, torch, ProcgenVecEnv, distributed, world, rank, local_rank, n_gpus,
         e.reset()
     gather = RootGather(local, dst=0, slabs=whole) if gathering else None  # 3 transfers per peer and step
 
+    from procgen2_amd.vec_env import step_many_synthetic
+
     def run(steps):
+        if gather is None:  # no per-step work on the host: the whole launch loop in C
+            step_many_synthetic(envs, steps, run_seed)
+            for e in envs:
+                e.sync()
+            return
         for _ in range(steps):
             for e in envs:
                 e.step_synthetic(run_seed, ordered=False)

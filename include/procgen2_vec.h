@@ -111,6 +111,11 @@ PGV_API int32_t pgv_synthetic_action(uint32_t run_seed, uint32_t step_index, uin
 
 /* Host-pointer conveniences (synchronous upload, then the calls above): for callers without device
  * memory of their own, e.g. the cenv shim and the parity tests.  h_mask / h_seeds may be NULL. */
+/* `steps` synthetic steps of `count` envs side by side — step s of every env is enqueued (each on its own stream) before
+ * step s+1 of any: the launch loop of a mixed workload (several games on one device) without a host round trip through
+ * the caller's language per env and step.  Nothing is synchronised; pgv_sync the envs afterwards. */
+PGV_API int32_t pgv_step_synthetic_many(pgv_env* const* envs, int32_t count, int32_t steps, uint32_t run_seed);
+
 PGV_API int32_t pgv_step_host(pgv_env* env, const int32_t* h_actions);
 PGV_API int32_t pgv_reset_host(pgv_env* env, const uint8_t* h_mask, const int32_t* h_seeds);
 

@@ -434,6 +434,18 @@ int32_t pgv_step_synthetic(pgv_env* e, uint32_t run_seed) {
     return step_impl(e, nullptr, run_seed);
 }
 
+int32_t pgv_step_synthetic_many(pgv_env* const* envs, int32_t count, int32_t steps, uint32_t run_seed) {
+    if (!envs || count < 1 || steps < 1) return fail("pgv_step_synthetic_many: bad arguments");
+    for (int32_t k = 0; k < count; k++)
+        if (!envs[k]) return fail("pgv_step_synthetic_many: env is NULL");
+    for (int32_t s = 0; s < steps; s++)
+        for (int32_t k = 0; k < count; k++) {
+            PG_HIP(hipSetDevice(envs[k]->device));
+            if (step_impl(envs[k], nullptr, run_seed)) return 1;
+        }
+    return 0;
+}
+
 static int32_t ensure_staging(pgv_env* e) {
     if (!e->d_host_i32) PG_HIP(hipMalloc(reinterpret_cast<void**>(&e->d_host_i32), size_t(e->n) * 4));
     if (!e->d_host_u8) PG_HIP(hipMalloc(reinterpret_cast<void**>(&e->d_host_u8), size_t(e->n)));

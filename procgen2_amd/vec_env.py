@@ -199,6 +199,15 @@ class ProcgenVecEnv:
         return plan()
 
 
+def step_many_synthetic(envs, steps, run_seed=0):
+    """`steps` synthetic steps of several ProcgenVecEnv on one device side by side, each on its own stream, with no
+    ordering against the caller's stream and no host work between the launches (include/procgen2_vec.h
+    pgv_step_synthetic_many).  Call sync() on the envs before reading their outputs."""
+    handles = (c_void_p * len(envs))(*[e._h for e in envs])
+    pglib.check(envs[0].L, envs[0].L.pgv_step_synthetic_many(handles, len(envs), int(steps), int(run_seed)),
+                "pgv_step_synthetic_many")
+
+
 class RootGather:
     """Rooted gather of a tuple of per-rank tensors `[n_r, ...]` into `[sum n_r, ...]` slabs on rank `dst` of `group`
     (SURVEY.md §8e).  Ranks may hold different env counts.

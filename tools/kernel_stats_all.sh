@@ -2,7 +2,7 @@
 # rocprofv3 --kernel-trace --stats of bench.py for every game (default modes): per-kernel average durations.
 # Output: gpurun_out/<tag>_<game>_kernel_stats.csv
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r02_k}
+TAG=${1:-r03_k}
 mkdir -p $(dirname $R/gpurun_out/${TAG}_x)
 cd /tmp && export TMPDIR=/tmp
 for G in coinrun maze bossfight climber caveflyer chaser jumper; do

@@ -2,7 +2,7 @@
 # SQ instruction counters and HBM traffic of every game's render kernel (default modes, 65 536 envs): three PMC passes
 # per game (SQ set, FETCH_SIZE, WRITE_SIZE — separate passes as the TCC counters require).  Output: gpurun_out/<tag>.json
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r02_s}
+TAG=${1:-r03_s}
 cd /tmp && export TMPDIR=/tmp
 for G in coinrun maze bossfight climber caveflyer chaser jumper; do
   for SET in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD" "SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_ANY" "FETCH_SIZE" "WRITE_SIZE"; do

@@ -2,7 +2,7 @@
 # HBM traffic of the step kernels from PMC counters: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (TCC slots:
 # MI355X_MICROARCH.md §rocprofv3 PMC slots), each with --kernel-trace only.  Output: gpurun_out/<tag>_traffic.json
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/${TAG//\//_}_pmc_$C -- python3 $R/bench.py --steps 16 --warmup 4 --no-cpu-baseline > $R/gpurun_out/${TAG}_pmc_$C.log 2>&1

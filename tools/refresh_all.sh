@@ -2,7 +2,7 @@
 # Round-end refresh on the GPU box: bench lines of every game + mixed, rocprof kernel stats and PMC traffic of the
 # headline run.  Everything lands in gpurun_out/<tag>_*.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r02_final}
+TAG=${1:-r03_final}
 cd $R
 mkdir -p $(dirname gpurun_out/${TAG}_x)
 python bench.py --game coinrun 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_coinrun.json
