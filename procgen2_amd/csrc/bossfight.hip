@@ -206,7 +206,7 @@ PG_D void new_level(const State& s, int env, R& rng, bool lead) {
 #define PG_BOSSFIGHT_GANG 16
 #endif
 #ifndef PG_BOSSFIGHT_WAVES
-#define PG_BOSSFIGHT_WAVES 4  // wavefronts per SIMD the logic kernel's registers are capped for
+#define PG_BOSSFIGHT_WAVES 3  // wavefronts per SIMD the logic kernel's registers are capped for
 #endif
 constexpr int kGang = PG_BOSSFIGHT_GANG;
 constexpr int kBoomGang = kGang < kBooms ? kGang : kBooms;  // lanes of a trip over the explosions
@@ -216,13 +216,25 @@ using Rng = GangRng<kGang>;
 // The three rings of an env while its gang steps it: the slots that hold something are read once, before the first
 // sub-step, into LDS — indexable registers: a slot is only ever touched by the lane that owns it — and the slots that
 // changed go back after the last, so the eight trips of a step wait for LDS instead of for a store and a load each.
+#ifndef PG_BOSSFIGHT_AGENT_RING_LDS
+#define PG_BOSSFIGHT_AGENT_RING_LDS 0  // 1: the agent's ring is staged in LDS too (896 bytes a gang more)
+#endif
 struct RingsLds {  // one per gang
     float b[S_FRAME + 1][kBossShots];       // S_X .. S_FRAME of the boss's bullets
+#if PG_BOSSFIGHT_AGENT_RING_LDS
     float a[S_BOUNCE_T + 1][kAgentShots];   // … and S_BOUNCE_T of the agent's
     uint8_t a_bouncing[kAgentShots];
+#endif
     float boom[kBooms];                     // frame
 };
 static_assert(S_X == 0 && S_FRAME == 4 && S_BOUNCE_T == 5, "the ring fields staged in LDS come first");
+#if PG_BOSSFIGHT_AGENT_RING_LDS
+#define PG_AS(R, s, f, k, env) (R).lds->a[f][k]
+#define PG_AB(R, s, k, env) (R).lds->a_bouncing[k]
+#else  // straight from memory: few of them are in flight, and a slot is only ever touched by the lane that owns it
+#define PG_AS(R, s, f, k, env) AS(s, f, k, env)
+#define PG_AB(R, s, k, env) AB(s, k, env)
+#endif
 struct Rings {  // a lane's view: the gang's rings, and which of ITS slots it has written (bit j: slot g + width·j)
     RingsLds* lds;
     uint32_t dirty_a, dirty_b, dirty_x;
@@ -358,13 +370,13 @@ PG_D bool agent_update(const State& s, Rings& R, int env, Live& v, Rng& rng, Q q
             const int k = v.a_next;
             if ((k & (kGang - 1)) == q.g) {
                 AS(s, S_ROT, k, env) = 0.0f;
-                R.lds->a[S_VX][k] = 0.0f;
-                R.lds->a[S_VY][k] = -bullet_speed;
-                R.lds->a[S_X][k] = v.ax;
-                R.lds->a[S_Y][k] = v.ay;
-                R.lds->a[S_FRAME][k] = 0.0f;
-                R.lds->a[S_BOUNCE_T][k] = 0.0f;
-                R.lds->a_bouncing[k] = 0;
+                PG_AS(R, s, S_VX, k, env) = 0.0f;
+                PG_AS(R, s, S_VY, k, env) = -bullet_speed;
+                PG_AS(R, s, S_X, k, env) = v.ax;
+                PG_AS(R, s, S_Y, k, env) = v.ay;
+                PG_AS(R, s, S_FRAME, k, env) = 0.0f;
+                PG_AS(R, s, S_BOUNCE_T, k, env) = 0.0f;
+                PG_AB(R, s, k, env) = 0;
                 R.dirty_a |= 1u << (k / kGang);
             }
             v.a_next = (v.a_next + 1) % kAgentShots;
@@ -391,13 +403,13 @@ PG_D bool agent_update(const State& s, Rings& R, int env, Live& v, Rng& rng, Q q
         float frame0 = -1.0f, px = 0.0f, py = 0.0f, vx = 0.0f, vy = 0.0f, btimer = 0.0f;
         bool bouncing = false;
         if (mine) {
-            frame0 = R.lds->a[S_FRAME][k];
-            px = R.lds->a[S_X][k];
-            py = R.lds->a[S_Y][k];
-            vx = R.lds->a[S_VX][k];
-            vy = R.lds->a[S_VY][k];
-            btimer = R.lds->a[S_BOUNCE_T][k];
-            bouncing = R.lds->a_bouncing[k] != 0;
+            frame0 = PG_AS(R, s, S_FRAME, k, env);
+            px = PG_AS(R, s, S_X, k, env);
+            py = PG_AS(R, s, S_Y, k, env);
+            vx = PG_AS(R, s, S_VX, k, env);
+            vy = PG_AS(R, s, S_VY, k, env);
+            btimer = PG_AS(R, s, S_BOUNCE_T, k, env);
+            bouncing = PG_AB(R, s, k, env) != 0;
         }
         const bool live = mine & (frame0 != -1.0f);
         const Box sb{px - 0.01f, py - 0.01f, 0.02f, 0.02f};
@@ -430,13 +442,13 @@ PG_D bool agent_update(const State& s, Rings& R, int env, Live& v, Rng& rng, Q q
         btimer = (bouncing & ticking) ? fmaxf(0.0f, btimer - dt) : btimer;
         frame = destroyed ? -1.0f : frame;
         if (act) {
-            R.lds->a[S_X][k] = px;
-            R.lds->a[S_Y][k] = py;
-            R.lds->a[S_VX][k] = vx;
-            R.lds->a[S_VY][k] = vy;
-            R.lds->a[S_FRAME][k] = frame;
-            R.lds->a[S_BOUNCE_T][k] = btimer;
-            R.lds->a_bouncing[k] = bouncing ? 1 : 0;
+            PG_AS(R, s, S_X, k, env) = px;
+            PG_AS(R, s, S_Y, k, env) = py;
+            PG_AS(R, s, S_VX, k, env) = vx;
+            PG_AS(R, s, S_VY, k, env) = vy;
+            PG_AS(R, s, S_FRAME, k, env) = frame;
+            PG_AS(R, s, S_BOUNCE_T, k, env) = btimer;
+            PG_AB(R, s, k, env) = bouncing ? 1 : 0;
             R.dirty_a |= 1u << (k / kGang);
         }
         count -= __popc(q.ballot(destroyed & act));
@@ -628,6 +640,7 @@ PG_D void advance(const State& s, Rings& R, Q q, int env, int action, float& rew
             for (int f = S_X; f <= S_FRAME; f++) R.lds->b[f][k] = BS(s, f, k, env);
         }
     }
+#if PG_BOSSFIGHT_AGENT_RING_LDS
 #pragma unroll
     for (int j = 0; j < (kAgentShots + kGang - 1) / kGang; j++) {
         const int k = q.g + kGang * j;
@@ -637,6 +650,7 @@ PG_D void advance(const State& s, Rings& R, Q q, int env, int action, float& rew
             R.lds->a_bouncing[k] = AB(s, k, env);
         }
     }
+#endif
 #pragma unroll
     for (int j = 0; j < kBooms / kBoomGang; j++) {
         const int k = q.g + kBoomGang * j;
@@ -662,6 +676,7 @@ PG_D void advance(const State& s, Rings& R, Q q, int env, int action, float& rew
 #pragma unroll
             for (int f = S_X; f <= S_FRAME; f++) BS(s, f, k, env) = R.lds->b[f][k];
         }
+#if PG_BOSSFIGHT_AGENT_RING_LDS
 #pragma unroll
     for (int j = 0; j < (kAgentShots + kGang - 1) / kGang; j++)
         if ((R.dirty_a >> j) & 1u) {
@@ -670,6 +685,7 @@ PG_D void advance(const State& s, Rings& R, Q q, int env, int action, float& rew
             for (int f = S_X; f <= S_BOUNCE_T; f++) AS(s, f, k, env) = R.lds->a[f][k];
             AB(s, k, env) = R.lds->a_bouncing[k];
         }
+#endif
 #pragma unroll
     for (int j = 0; j < kBooms / kBoomGang; j++)
         if ((R.dirty_x >> j) & 1u) BM(s, 2, q.g + kBoomGang * j, env) = R.lds->boom[q.g + kBoomGang * j];

@@ -766,8 +766,9 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
             // the ring is the same 60×60 pixels in every frame: prepared once (pg_render.h overlay_rows), in its place in
             // the draw order — after the bunny, before the needle and the bar
             wave_replay_rows(fb, atlas, mine, __ballot(has && lane <= bunny_lane), lane, row_lo, row_hi);
-            overlay_rows(fb, atlas.texels + s.hud_image, reinterpret_cast<const uint2*>(atlas.texels + s.hud_list), s.hud_n,
-                         lane, row_lo, row_hi);
+            if (!PG_ABL(flags, 0x100000))  // (traffic experiment, -DPG_ABLATE builds only: no compass ring)
+                overlay_rows(fb, atlas.texels + s.hud_image, reinterpret_cast<const uint2*>(atlas.texels + s.hud_list), s.hud_n,
+                             lane, row_lo, row_hi);
             wave_replay_rows(fb, atlas, mine, __ballot(has && lane >= bunny_lane + 2), lane, row_lo, row_hi);
         } else {
             wave_replay_rows(fb, atlas, mine, __ballot(has), lane, row_lo, row_hi);

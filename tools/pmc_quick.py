@@ -9,6 +9,6 @@ e = EngineVec(os.environ.get("PG_GAME", "coinrun"), 65536, seed_base=1, lib_path
 e.reset()
 e.timed(int(os.environ.get("PG_SETTLE", "300")))
 if os.environ.get("PG_DEBUG"):  # ablation bits: the -DPG_ABLATE library only (PG_LIB)
-    e.set_debug(int(os.environ["PG_DEBUG"]))
+    e.set_debug(int(os.environ["PG_DEBUG"], 0))
 e.timed(8)
 e.close()
