@@ -42,6 +42,7 @@ namespace coinrun {
 constexpr int W = 64, H = 64;
 constexpr int kMaxEnt = 36;  // 5 sections × max 7-wide pit of saws/mobs + the coin (tilemap.cpp:126-131,176-186)
 constexpr int kSparks = 10;  // tilemap.cpp:91
+constexpr int kSparkRow = 12; // (a row of ten, padded to 48 bytes)
 
 enum Tile : uint8_t { kEmpty = 0, kWallTop, kWallMid, kLavaTop, kLavaMid, kCrate };  // tilemap.h:13-21
 enum Solid { kPass = 0, kFull, kOneWay };                                            // tilemap.h:23-27
@@ -99,7 +100,9 @@ struct State {
     uint8_t* eb;     // [EB_COUNT][kMaxEnt][n]
     float* df;       // [2][DF_COUNT][kMaxEnt][n]         double-buffered
     uint8_t* db;     // [2][kMaxEnt][n]
-    float* spark;    // [2][3][kMaxEnt][kSparks][n]       x, y, life
+    float* spark;    // [2][n][kMaxEnt][3][kSparkRow]     x, y, life — a mob's thirty values are 144 contiguous bytes: the entity
+                     //                                   kernel's (env, mob) lanes and the render wave's spark lanes both read a
+                     //                                   couple of cache lines instead of one per value
     float* scratch;  // [SC_COUNT][n]                     hand-off between the three logic kernels of a step
     uint32_t no;     // generator switches turned off (PGV_COINRUN_NO_*: coinrun/tilemap.h:42-45 allow_* = false)
 };
@@ -127,7 +130,7 @@ PG_D int32_t& SCI(const State& s, int row, int env) {
     return reinterpret_cast<int32_t*>(s.scratch)[size_t(row) * s.n + env];
 }
 PG_D float& SP(const State& s, int buf, int comp, int e, int k, int env) {
-    return s.spark[(((size_t(buf) * 3 + comp) * kMaxEnt + e) * kSparks + k) * s.n + env];
+    return s.spark[(((size_t(buf) * s.n + env) * kMaxEnt + e) * 3 + comp) * kSparkRow + k];
 }
 
 // The tile map under construction (in LDS), written by the whole wavefront: a rectangle fill is spread over the
@@ -1339,7 +1342,7 @@ class CoinrunGame final : public Game {
         l.eb = take(size_t(EB_COUNT) * kMaxEnt * n);
         l.df = take(size_t(2) * DF_COUNT * kMaxEnt * n * 4);
         l.db = take(size_t(2) * kMaxEnt * n);
-        l.spark = take(size_t(2) * 3 * kMaxEnt * kSparks * n * 4);
+        l.spark = take(size_t(2) * 3 * kMaxEnt * kSparkRow * n * 4);
         l.scratch = take(size_t(SC_COUNT) * n * 4);
         l.total = off;
         return l;

@@ -195,8 +195,11 @@ struct LevelLaunch {
     // span = envs per wavefront, served one after the other.  With prefetch a served env costs a copy, so 64 per wave
     // is right; a game that generates inside the step (chaser) wants few, or the step waits for the unluckiest wave:
     // (number of its envs that reset in this step) × (one generation).
+#ifndef PG_RESET_SPAN
+#define PG_RESET_SPAN 64
+#endif
     static void auto_reset(hipStream_t st, const typename G::State& s, int prefetch, StepIO io, LevelPlan plan,
-                           int span = 64) {
+                           int span = PG_RESET_SPAN) {
         hipLaunchKernelGGL(level_kernel<G>, dim3((s.n + span - 1) / span), dim3(64), 0, st, s, 2, span, prefetch, 0u, 0,
                            nullptr, nullptr, io, plan);
     }
