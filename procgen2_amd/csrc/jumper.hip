@@ -769,6 +769,9 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
             if (!PG_ABL(flags, 0x100000))  // (traffic experiment, -DPG_ABLATE builds only: no compass ring)
                 overlay_rows(fb, atlas.texels + s.hud_image, reinterpret_cast<const uint2*>(atlas.texels + s.hud_list), s.hud_n,
                              lane, row_lo, row_hi);
+            // (timing experiments, -DPG_ABLATE builds only: 0x200000 no needle, 0x400000 no bar)
+            if (PG_ABL(flags, 0x200000)) has = has && lane != bunny_lane + 2;
+            if (PG_ABL(flags, 0x400000)) has = has && lane != bunny_lane + 3;
             wave_replay_rows(fb, atlas, mine, __ballot(has && lane >= bunny_lane + 2), lane, row_lo, row_hi);
         } else {
             wave_replay_rows(fb, atlas, mine, __ballot(has), lane, row_lo, row_hi);
