@@ -1,3 +1,5 @@
+"""Lock-step of the engine against the oracle with a mixed action stream; on the first mismatch prints the env, the step and
+the differing entries of the two state dumps.  Usage: python tools/lockstep_debug.py  (edit game / sizes below)."""
 import sys, os
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import numpy as np
