@@ -106,6 +106,11 @@ struct State {
     uint8_t* eb;     // [n][EB_COUNT][kMaxEnt]  per-env contiguous: a gang's and the render wavefronts' lanes index it by entity
     const uint8_t* ranks;  // pg_order.h equal-key sort ranks
     int float_abs;         // game_flags PGV_CHASER_FLOAT_ABS: which `abs` the reference's abs(<float>) calls are (D21)
+    // The envs the level kernel has reset in this step, for the late render pass (render_list_kernel): a list and, per
+    // step parity, its length — the late pass of a step zeroes the other parity's, which the next step fills.
+    int32_t* reset_list;   // [n]
+    int32_t* reset_count;  // [2]
+    int parity, listing;   // host-set per launch: step & 1; whether the list is kept at all (resets on their own stream)
 };
 
 PG_D float& SF(const State& s, int field, int env) { return s.f[size_t(field) * s.n + env]; }
@@ -340,6 +345,9 @@ struct Gen {  // pg_prefetch.h level_kernel<Gen>
     PG_D static void install(const State& s, int env, const Level& lv, int lane) { chaser::install(s, env, lv, lane); }
     PG_D static void fresh_chain(const State& s, int env) { chaser::fresh_chain(s, env); }
     PG_D static void fresh_live(const State& s, int env) { chaser::fresh_live(s, env); }
+    PG_D static void served(const State& s, int env) {  // (lane 0, after an auto-reset)
+        if (s.listing) s.reset_list[atomicAdd(&s.reset_count[s.parity], 1)] = env;
+    }
 };
 
 // One env = one gang of kGang adjacent lanes (pg_gang.h).  The agent and the enemies — three to five of them, visited in
@@ -724,23 +732,14 @@ __global__ void __launch_bounds__(64, PG_CHASER_WAVES) logic_kernel(State s, con
 // kernel may be anywhere) — and it leaves the flags alone: a 1 written now could still be picked up by a late wavefront of
 // the level kernel running beside it, which would reset the env a step early; 2 = after the level kernel, the envs it
 // reset (all 2 by then), and the flags are settled.
-__global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
-                                                    int flags, int pass) {
-    const int env = blockIdx.x;
-    if (mask && !mask[env]) return;
-    {
-        const int p = io.pending[env];
-        __syncthreads();  // every thread has read the flag before thread 0 settles it
-        if (pass == 1 && (p == 1 || p == 2)) return;
-        if (pass != 1 && threadIdx.x == 0 && p >= 2) io.pending[env] = p == 3 ? 1 : 0;
-        if (pass == 2 && p != 2) return;
-    }
+constexpr int kGrid = W + 2 <= 16 ? 16 : 24;  // composer grid: W tiles + the border cells of the inclusive window
+static_assert(W + 2 <= kGrid && (kGrid * kGrid) % 64 == 0, "composer grid");
+
+// One env's frame by its workgroup (two wavefronts, pg_render.h); fb and L are the workgroup's LDS.
+PG_D void render_env(const State& s, const AtlasView& atlas, const StepIO& io, int flags, int env, uint32_t* fb,
+                     ComposeLds<kGrid>& L) {
     const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // two wavefronts per env (pg_render.h)
     constexpr int halves = 2;
-    __shared__ alignas(16) uint32_t fb[kFbWords];
-    constexpr int kGrid = W + 2 <= 16 ? 16 : 24;  // W tiles + the border cells of the inclusive window
-    static_assert(W + 2 <= kGrid && (kGrid * kGrid) % 64 == 0, "composer grid");
-    __shared__ ComposeLds<kGrid> L;
 
     const float zoom = 64.0f * kPxUnit / static_cast<float>(W);  // chaser.cpp:401
     const Camera cam{W * 0.5f * kUnitPx, H * 0.5f * kUnitPx, 64.0f, 64.0f, zoom};
@@ -901,6 +900,40 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
     wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
 }
 
+__global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
+                                                    int flags, int pass) {
+    const int env = blockIdx.x;
+    if (mask && !mask[env]) return;
+    {
+        const int p = io.pending[env];
+        __syncthreads();  // every thread has read the flag before thread 0 settles it
+        if (pass == 1 && (p == 1 || p == 2)) return;
+        if (pass != 1 && threadIdx.x == 0 && p >= 2) io.pending[env] = p == 3 ? 1 : 0;
+    }
+    __shared__ alignas(16) uint32_t fb[kFbWords];
+    __shared__ ComposeLds<kGrid> L;
+    render_env(s, atlas, io, flags, env, fb, L);
+}
+
+// The late pass of a step whose resets ran on their own stream: the frames of the envs on the level kernel's list (a
+// few hundred of 65 536: a workgroup takes every gridDim.x-th of them), and the flags of everyone settled (3 → 1 for the
+// envs that ended an episode in this step, 2 → 0 for the ones just reset).  A full-size launch that exits at once for
+// all but the listed envs costs 30 µs in dispatch alone.
+__global__ void __launch_bounds__(128, 4) render_list_kernel(State s, AtlasView atlas, StepIO io, int flags) {
+    for (int e = blockIdx.x * 128 + threadIdx.x; e < s.n; e += gridDim.x * 128)
+        if (io.pending[e] == 3) io.pending[e] = 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) s.reset_count[1 - s.parity] = 0;
+    __shared__ alignas(16) uint32_t fb[kFbWords];
+    __shared__ ComposeLds<kGrid> L;
+    const int count = s.reset_count[s.parity];
+    for (int item = blockIdx.x; item < count; item += gridDim.x) {
+        const int env = s.reset_list[item];
+        if (threadIdx.x == 0) io.pending[env] = 0;
+        render_env(s, atlas, io, flags, env, fb, L);
+        __syncthreads();  // the next env of this workgroup reuses the LDS
+    }
+}
+
 // cenv_render's frame (render_game(false)) for one env: pg_frame.h; the draw list of render_kernel, one draw at a time.
 __global__ void __launch_bounds__(kFrameThreads) frame_kernel(State s, AtlasView atlas, int env, FrameTarget t) {
     const float fw = static_cast<float>(t.w), fh = static_cast<float>(t.h);
@@ -964,7 +997,7 @@ class ChaserGame final : public Game {
     }
     static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
     struct Layout {
-        size_t shadow, slot, mt, tiles, f, i, mf, mb, eb, total;
+        size_t shadow, slot, mt, tiles, f, i, mf, mb, eb, reset_list, reset_count, total;
     };
     static Layout layout(int n) {
         Layout l{};
@@ -983,6 +1016,8 @@ class ChaserGame final : public Game {
         l.mf = take(size_t(MF_COUNT) * kMobs * n * 4);
         l.mb = take(size_t(2) * kMobs * n);
         l.eb = take(size_t(EB_COUNT) * kMaxEnt * n);  // (same size either way round)
+        l.reset_list = take(size_t(n) * 4);
+        l.reset_count = take(8);
         l.total = off;
         return l;
     }
@@ -1004,6 +1039,8 @@ class ChaserGame final : public Game {
         s_.mf = reinterpret_cast<float*>(p + l.mf);
         s_.mb = p + l.mb;
         s_.eb = p + l.eb;
+        s_.reset_list = reinterpret_cast<int32_t*>(p + l.reset_list);
+        s_.reset_count = reinterpret_cast<int32_t*>(p + l.reset_count);
         s_.ranks = atlas.sort_ranks;
         atlas_ = atlas;
     }
@@ -1018,6 +1055,8 @@ class ChaserGame final : public Game {
     bool resets_beside_logic() const override { return true; }
     void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
                       StepIO io) override {
+        s_.parity = static_cast<int>(step_index & 1u);
+        s_.listing = reset_stream ? 1 : 0;
         LevelLaunch<Gen>::auto_reset(reset_stream ? reset_stream : st, s_, 0, io, plan, kResetSpan);
         hipLaunchKernelGGL(logic_kernel, dim3((s_.n * kGang + 63) / 64), dim3(64), 0, st, s_, actions, run_seed, step_index,
                            env_offset, io);
@@ -1034,7 +1073,8 @@ class ChaserGame final : public Game {
     }
     bool launch_render_late(hipStream_t st, StepIO io) override {
         if (!reset_stream) return false;
-        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, nullptr, io, debug_flags, 2);
+        const int groups = s_.n < 1024 ? s_.n : 1024;
+        hipLaunchKernelGGL(render_list_kernel, dim3(groups), dim3(128), 0, st, s_, atlas_, io, debug_flags);
         return true;
     }
     // Same layout as oracle/pgo_chaser.cpp Chaser::dump_state.

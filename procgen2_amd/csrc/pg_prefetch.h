@@ -70,6 +70,16 @@ PG_D int32_t slot_acquire_for_install(int32_t* p) {
 //   mode 2  auto-reset of the envs whose previous step terminated (StepIO::pending 1 → 2 tells the logic kernel);
 //   mode 3  side stream: fill the shadow slots that are kSlotQueued.
 // `prefetch` = whether a served env queues its next level.
+// Optional hook: G::served(s, env) — called by lane 0 after an auto-reset (mode 2) has given env its level.
+template <class G, class = void>
+struct HasServed {
+    static constexpr bool value = false;
+};
+template <class G>
+struct HasServed<G, decltype(static_cast<void>(&G::served))> {
+    static constexpr bool value = true;
+};
+
 template <class G>
 __global__ void __launch_bounds__(64) level_kernel(typename G::State s, int mode, int span, int prefetch,
                                                    uint32_t seed_base, int env_offset, const uint8_t* mask,
@@ -173,6 +183,9 @@ __global__ void __launch_bounds__(64) level_kernel(typename G::State s, int mode
                 io.reward[env] = 0.0f;
                 io.done[env] = 0;
                 io.pending[env] = mode == 2 ? 2 : 0;
+                if constexpr (HasServed<G>::value) {
+                    if (mode == 2) G::served(s, env);
+                }
             }
         }
         __syncthreads();
