@@ -111,6 +111,13 @@ struct State {
     int32_t* reset_list;   // [n]
     int32_t* reset_count;  // [2]
     int parity, listing;   // host-set per launch: step & 1; whether the list is kept at all (resets on their own stream)
+    // The point sprite's texels that are not fully transparent lie in columns point_box.x..y and rows .z..w (found when
+    // the atlas is loaded); point_solid: every texel in that box is opaque.
+    int4 point_box;
+    int point_solid;
+    // The row composer's span and hand-over tables: the camera shows the whole world, always, so they are worked out
+    // once (prepare_kernel, when the envs are made) and every frame reads them from here (pg_render.h compose_prepare).
+    ComposeHand* prepared;
 };
 
 PG_D float& SF(const State& s, int field, int env) { return s.f[size_t(field) * s.n + env]; }
@@ -732,22 +739,75 @@ __global__ void __launch_bounds__(64, PG_CHASER_WAVES) logic_kernel(State s, con
 // kernel may be anywhere) — and it leaves the flags alone: a 1 written now could still be picked up by a late wavefront of
 // the level kernel running beside it, which would reset the env a step early; 2 = after the level kernel, the envs it
 // reset (all 2 by then), and the flags are settled.
+// The wall tile's corners are translucent (16 of its 256 texels, enough for the atlas loader's "hard" mark), but a frame
+// samples at most two or three of them per wall, all in one pixel row of the tile: the composer's one-texel attempt
+// settles the other rows, so it is made regardless.
+#ifndef PG_CHASER_HARD_WALLS
+#define PG_CHASER_HARD_WALLS 0
+#endif
 constexpr int kGrid = W + 2 <= 16 ? 16 : 24;  // composer grid: W tiles + the border cells of the inclusive window
 static_assert(W + 2 <= kGrid && (kGrid * kGrid) % 64 == 0, "composer grid");
 
-// One env's frame by its workgroup (two wavefronts, pg_render.h); fb and L are the workgroup's LDS.
+// What the sprite pass needs of the entity tables, fetched when the kernel starts — the draw list's entities and the
+// enemies' places are two and three dependent global loads deep, and a wavefront that goes for them only when it gets
+// to its sprites waits that long with nothing else to do (the composer's work is behind it by then).
+struct SpriteLds {
+    uint32_t ent[kMaxEnt];   // per draw-list place: entity | kind << 8 | cell << 16
+    float mob[kMobs + 1][4];  // per enemy: x, y, texture
+    int4 seen[2][kOrbs + kMobs + 2];  // per wavefront: the rectangles of the draws so far that are not points
+};
+
+// What every frame shows: the whole world (chaser.cpp:401), and the wall window of it (tilemap.cpp:245-254).
+struct View {
+    Camera cam;
+    int x0, y0, cols, rows;
+};
+PG_D View view_of_world() {
+    const float zoom = 64.0f * kPxUnit / static_cast<float>(W);  // chaser.cpp:401
+    View v{Camera{W * 0.5f * kUnitPx, H * 0.5f * kUnitPx, 64.0f, 64.0f, zoom}, 0, 0, 0, 0};
+    const Camera& cam = v.cam;
+    const float vx = (cam.px - cam.sw * 0.5f / cam.scale) * kPxUnit;
+    const float vy = (cam.py - cam.sh * 0.5f / cam.scale) * kPxUnit;
+    const float vw = cam.sw * kPxUnit / cam.scale, vh = cam.sh * kPxUnit / cam.scale;
+    v.x0 = static_cast<int>(floorf(vx));
+    v.y0 = static_cast<int>(floorf(vy));
+    v.cols = static_cast<int>(ceilf(vx + vw)) - v.x0 + 1;
+    v.rows = static_cast<int>(ceilf(vy + vh)) - v.y0 + 1;
+    return v;
+}
+// descriptor .w of what the tile layer shows, as the composer's row classes want it (a point is a candidate only
+// inside its box: if the box is solid it brings nothing that is not opaque)
+PG_D int layer_flags(const State& s, const int4& wall_d, const int4& point_d, bool points_in_layer) {
+    return wall_d.w | (points_in_layer && !s.point_solid ? point_d.w : 0);
+}
+// Needs: the wall's texture size (check_atlas), texels all opaque or all clear, a clear rim (descriptor .w bits 2, 3).
+PG_D bool points_join_layer(const int4& point_d, int flags) { return !(flags & 1) && (point_d.w & 12) == 8; }
+
+// One env's frame by its workgroup (two wavefronts, pg_render.h); fb, LB and S are the workgroup's LDS.
 PG_D void render_env(const State& s, const AtlasView& atlas, const StepIO& io, int flags, int env, uint32_t* fb,
-                     ComposeLds<kGrid>& L) {
+                     ComposeLdsBoxed<kGrid>& LB, SpriteLds& S) {
+    ComposeLds<kGrid>& L = LB.plain;
     const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // two wavefronts per env (pg_render.h)
     constexpr int halves = 2;
 
-    const float zoom = 64.0f * kPxUnit / static_cast<float>(W);  // chaser.cpp:401
-    const Camera cam{W * 0.5f * kUnitPx, H * 0.5f * kUnitPx, 64.0f, 64.0f, zoom};
+    const View view = view_of_world();
+    const Camera& cam = view.cam;
     const int sflags = SI(s, I_FLAGS, env);
     const int n_draw = (sflags & kFlagListed) ? SI(s, I_NDRAW, env) : 0;  // empty right after a reset
     const uint8_t* tiles = s.tiles + size_t(env) * kTileStride;
     const DescRegs descs = DescRegs::load(atlas, lane);
     Blit mine;
+    for (int k = lane + 64 * half; k < n_draw; k += 64 * halves) {
+        const int e = EB(s, EB_DRAW, k, env);
+        S.ent[k] = static_cast<uint32_t>(e | (EB(s, EB_INFO, e, env) & kKindMask) << 8 | ent_cell(s, e, env) << 16);
+    }
+    if (half == 1 && lane < kMobs) {
+        S.mob[lane][0] = MF(s, MF_X, lane, env);
+        S.mob[lane][1] = MF(s, MF_Y, lane, env);
+        S.mob[lane][2] = static_cast<float>(MB(s, 0, lane, env));
+    }
+    const float agent_x = SF(s, F_AX, env), agent_y = SF(s, F_AY, env);
+    // (the barriers of the composer, or of the replay that stands in for it, come between these writes and their readers)
 
     int bg_soft = 0;  // the backdrop has texels that are not opaque (descriptor .w)
     int4 bg_d;  // the background draw, chaser.cpp:404-409: texture, world position, scale — each wave resolves the axis it needs (pg_render.h BgAxis)
@@ -762,31 +822,24 @@ PG_D void render_env(const State& s, const AtlasView& atlas, const StepIO& io, i
         bg_py = 0.0f;
         bg_sc = 64.0f * kUnitPx / d.z;
     }
-    // wall window (tilemap.cpp:245-254)
-    const float vx = (cam.px - cam.sw * 0.5f / cam.scale) * kPxUnit;
-    const float vy = (cam.py - cam.sh * 0.5f / cam.scale) * kPxUnit;
-    const float vw = cam.sw * kPxUnit / cam.scale, vh = cam.sh * kPxUnit / cam.scale;
-    const int x0 = static_cast<int>(floorf(vx)), y0 = static_cast<int>(floorf(vy));
-    const int x1 = static_cast<int>(ceilf(vx + vw)), y1 = static_cast<int>(ceilf(vy + vh));
-    const int cols = x1 - x0 + 1, rows = y1 - y0 + 1, cells = cols * rows;
+    const int x0 = view.x0, y0 = view.y0, cols = view.cols, rows = view.rows, cells = cols * rows;
     const int4 wall_d = descs.uniform(kTexWall), point_d = descs.uniform(kTexPoint);
-    // Needs: the wall's texture size (check_atlas), texels all opaque or all clear, a clear rim (descriptor .w bits 2, 3).
-    const bool points_in_layer = !(flags & 1) && (point_d.w & 12) == 8;
+    const bool points_in_layer = points_join_layer(point_d, flags);
 
-    const BgDraw bg_draw{bg_d, bg_px, bg_py, bg_sc};
-    BgAxis bga{};  // this wave's axis of it (wave 0: x, wave 1: y), resolved along with the tile spans
     bool composed = false;
     if (!(flags & 1) && cols <= kGrid && rows <= kGrid) {
-        compose_spans<kGrid, 16>(fb, L, cam, x0, y0, cols, rows, wall_d.y, wall_d.z, kUnitPx / wall_d.y, lane, 0, half, halves,
-                                 soft_rows_of(bg_soft, wall_d.w | (points_in_layer ? point_d.w : 0)),
-                                 hard_rows_of(bg_soft, wall_d.w | (points_in_layer ? point_d.w : 0)), &bg_draw, &bga);
+        // this wave's axis of the background (wave 0: x, wave 1: y); the tile spans are the prepared ones
+        const BgAxis bga = bg_axis(cam, bg_d, bg_px, bg_py, bg_sc, half);
+        if (half == 0 && lane < 2) L.base[kGrid * kGrid + lane] = static_cast<int32_t>(kNoTexel);
 #pragma unroll
         for (int k = half; k < kGrid * kGrid / 64; k += halves) {
             const int cell = k * 64 + lane;
             const int r = cell / kGrid, c = cell % kGrid;
             const bool wall = c < cols && r < rows && tile_at(tiles, x0 + c, H - 1 - (y0 + r)) == kWall;
             L.base[cell] = wall ? wall_d.x * 4 : static_cast<int32_t>(kNoTexel);
+            LB.boxed[cell] = static_cast<int32_t>(kNoTexel);
         }
+        if (half == 1 && lane < 2) LB.boxed[kGrid * kGrid + lane] = static_cast<int32_t>(kNoTexel);
         if (points_in_layer) {
             // The points of the draw list join the tile layer: a point is drawn with exactly a tile's arithmetic
             // (world position = its cell's corner, scale 16 / texture width — common_systems.cpp:41-63 vs
@@ -797,16 +850,17 @@ PG_D void render_env(const State& s, const AtlasView& atlas, const StepIO& io, i
             // re-draws (idempotently: opaque texels) the points that follow such a sprite in the list and touch it.
             __syncthreads();  // the wall pass has written every cell
             for (int k = lane + 64 * half; k < n_draw; k += 64 * halves) {
-                const int e = EB(s, EB_DRAW, k, env);
-                if ((EB(s, EB_INFO, e, env) & kKindMask) == kPoint) {
-                    const int cell = ent_cell(s, e, env);
+                const uint32_t v = S.ent[k];
+                if (((v >> 8) & kKindMask) == kPoint) {
+                    const int cell = static_cast<int>(v >> 16);
                     const int c = cell / H - x0, r = (H - 1 - cell % H) - y0;
-                    if (c >= 0 && r >= 0 && c < cols && r < rows) L.base[r * kGrid + c] = point_d.x * 4;
+                    if (c >= 0 && r >= 0 && c < cols && r < rows) LB.boxed[r * kGrid + c] = point_d.x * 4;
                 }
             }
         }
         __syncthreads();
-        composed = compose_rows(fb, L, atlas, bga, cols, rows, wall_d.y, lane, flags, half, halves);
+        composed = compose_rows<kGrid, false, true, true>(fb, L, atlas, bga, cols, rows, wall_d.y, lane, flags, half, halves,
+                                                          s.point_box, s.prepared, bg_soft);
     }
     if (!composed) {  // draw-list replay (tilemap.cpp:256-266)
         wave_clear(fb, lane, half, halves);
@@ -830,26 +884,26 @@ PG_D void render_env(const State& s, const AtlasView& atlas, const StepIO& io, i
     // that is not a point (orb, egg, enemy) touches them: those would otherwise end up on top of the point instead of
     // under it.  The rectangles of the non-point draws seen so far live in the dead cell table, one region per wave
     // (the waves run this pass independently, each on the rows it owns).
-    int4* const seen = reinterpret_cast<int4*>(L.base) + half * (kOrbs + kMobs + 2);
-    static_assert(2 * (kOrbs + kMobs + 2) * 4 <= kGrid * kGrid, "scratch inside the cell table");
+    int4* const seen = S.seen[half];
     int n_seen = 0;
+    PG_MARK("s_sprites");
     const bool skip_points = composed && points_in_layer;
-    for (int first = 0; first < n_draw + 1; first += 64) {
+    for (int first = 0; first < n_draw + 1 && !PG_ABL(flags, 0x10000); first += 64) {  // (bit 16: timing experiment — no sprite pass)
         const int k = first + lane;
         int want_tex = kTexAgent;
         float x = 0.0f, y = 0.0f;
         bool has = false, is_point = false;
         if (k < n_draw) {
-            const int e = EB(s, EB_DRAW, k, env);
-            const int kind = EB(s, EB_INFO, e, env) & kKindMask;
+            const uint32_t v = S.ent[k];
+            const int e = static_cast<int>(v & 0xffu), kind = static_cast<int>((v >> 8) & kKindMask);
             has = true;
             if (kind == kEgg) {
                 const int m = e - kOrbs;
-                want_tex = kTexEnemy + MB(s, 0, m, env);
-                x = MF(s, MF_X, m, env);
-                y = MF(s, MF_Y, m, env);
+                want_tex = kTexEnemy + static_cast<int>(S.mob[m][2]);
+                x = S.mob[m][0];
+                y = S.mob[m][1];
             } else {
-                const int cell = ent_cell(s, e, env);
+                const int cell = static_cast<int>(v >> 16);
                 want_tex = kind == kOrb ? kTexOrb : kTexPoint;
                 is_point = kind == kPoint;
                 x = cell_x(cell);
@@ -857,8 +911,8 @@ PG_D void render_env(const State& s, const AtlasView& atlas, const StepIO& io, i
             }
         } else if (k == n_draw) {
             has = true;
-            x = SF(s, F_AX, env);
-            y = SF(s, F_AY, env);
+            x = agent_x;
+            y = agent_y;
         }
         const int4 d = descs.at(want_tex);
         if (has) {
@@ -866,6 +920,7 @@ PG_D void render_env(const State& s, const AtlasView& atlas, const StepIO& io, i
             has = resolve_draw(cam, d.y, d.z, d.x, (x + -0.5f) * kUnitPx, (y + -0.5f) * kUnitPx, scale, 1.0f, false, false,
                                mine);
         }
+        PG_MARK("t_resolved");
         if (skip_points) {
             const unsigned long long others = __ballot(has && !is_point);
             if (has && !is_point) {  // append in draw order
@@ -894,10 +949,28 @@ PG_D void render_env(const State& s, const AtlasView& atlas, const StepIO& io, i
             n_seen += __popcll(others);
             has = has && keep;
         }
+        PG_MARK("u_kept");
+        if (PG_ABL(flags, 0x20000)) has = false;  // (bit 17: timing experiment — the pass without its draws)
         wave_replay_rows<4, false, false>(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
     }
+    PG_MARK("v_drawn");
     // each wave stores the rows it owns (pg_render.h wave_replay_rows): no barrier
     wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
+}
+
+// Once per engine: the composer's tables for the one view there is (State::prepared).
+__global__ void __launch_bounds__(128) prepare_kernel(State s, AtlasView atlas) {
+    __shared__ alignas(16) uint32_t fb[kFbWords];
+    __shared__ ComposeLdsBoxed<kGrid> LB;
+    const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const View view = view_of_world();
+    const int4 wall_d = atlas.desc[kTexWall], point_d = atlas.desc[kTexPoint];
+    const int layer_w = layer_flags(s, wall_d, point_d, points_join_layer(point_d, 0));
+    compose_spans<kGrid, 16>(fb, LB.plain, view.cam, view.x0, view.y0, view.cols, view.rows, wall_d.y, wall_d.z, kUnitPx / wall_d.y,
+                             lane, 0, half, 2, soft_rows_of(0, layer_w), hard_rows_of(0, PG_CHASER_HARD_WALLS ? layer_w : 0));
+    __syncthreads();
+    compose_hand_build<kGrid, false, true>(fb, LB.plain, BgAxis{}, wall_d.y, lane, 0, half, s.point_box);
+    compose_prepare<kGrid>(fb, LB.plain, s.prepared, lane, half);
 }
 
 __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
@@ -911,8 +984,9 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
         if (pass != 1 && threadIdx.x == 0 && p >= 2) io.pending[env] = p == 3 ? 1 : 0;
     }
     __shared__ alignas(16) uint32_t fb[kFbWords];
-    __shared__ ComposeLds<kGrid> L;
-    render_env(s, atlas, io, flags, env, fb, L);
+    __shared__ ComposeLdsBoxed<kGrid> L;
+    __shared__ SpriteLds S;
+    render_env(s, atlas, io, flags, env, fb, L, S);
 }
 
 // The late pass of a step whose resets ran on their own stream: the frames of the envs on the level kernel's list (a
@@ -924,12 +998,13 @@ __global__ void __launch_bounds__(128, 4) render_list_kernel(State s, AtlasView 
         if (io.pending[e] == 3) io.pending[e] = 1;
     if (blockIdx.x == 0 && threadIdx.x == 0) s.reset_count[1 - s.parity] = 0;
     __shared__ alignas(16) uint32_t fb[kFbWords];
-    __shared__ ComposeLds<kGrid> L;
+    __shared__ ComposeLdsBoxed<kGrid> L;
+    __shared__ SpriteLds S;
     const int count = s.reset_count[s.parity];
     for (int item = blockIdx.x; item < count; item += gridDim.x) {
         const int env = s.reset_list[item];
         if (threadIdx.x == 0) io.pending[env] = 0;
-        render_env(s, atlas, io, flags, env, fb, L);
+        render_env(s, atlas, io, flags, env, fb, L, S);
         __syncthreads();  // the next env of this workgroup reuses the LDS
     }
 }
@@ -995,9 +1070,29 @@ class ChaserGame final : public Game {
         if (sizes[kTexPoint] != sizes[kTexWall]) return "chaser: the point texture must have the wall tile's size (row composer)";
         return "";
     }
+    // The box of the point sprite's texels that are not fully transparent (atlas texels with alpha 0 are the word 0):
+    // inside it the sprite is a candidate of the row composer's tile layer, outside it is not there at all.
+    void extend_atlas(Atlas& atlas) override {
+        const int4 d = atlas.desc_host(kTexPoint);
+        const uint32_t* tex = atlas.texels_host(kTexPoint);
+        int4 box = make_int4(d.y, -1, d.z, -1);
+        for (int y = 0; y < d.z; y++)
+            for (int x = 0; x < d.y; x++)
+                if (tex[size_t(y) * d.y + x] != 0u) {
+                    box.x = std::min(box.x, x);
+                    box.y = std::max(box.y, x);
+                    box.z = std::min(box.z, y);
+                    box.w = std::max(box.w, y);
+                }
+        bool solid = true;
+        for (int y = box.z; y <= box.w; y++)
+            for (int x = box.x; x <= box.y; x++) solid = solid && (tex[size_t(y) * d.y + x] >> 24) == 255u;
+        s_.point_box = box;
+        s_.point_solid = solid ? 1 : 0;
+    }
     static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
     struct Layout {
-        size_t shadow, slot, mt, tiles, f, i, mf, mb, eb, reset_list, reset_count, total;
+        size_t shadow, slot, mt, tiles, f, i, mf, mb, eb, reset_list, reset_count, prepared, total;
     };
     static Layout layout(int n) {
         Layout l{};
@@ -1018,6 +1113,7 @@ class ChaserGame final : public Game {
         l.eb = take(size_t(EB_COUNT) * kMaxEnt * n);  // (same size either way round)
         l.reset_list = take(size_t(n) * 4);
         l.reset_count = take(8);
+        l.prepared = take(sizeof(ComposeHand));
         l.total = off;
         return l;
     }
@@ -1041,12 +1137,14 @@ class ChaserGame final : public Game {
         s_.eb = p + l.eb;
         s_.reset_list = reinterpret_cast<int32_t*>(p + l.reset_list);
         s_.reset_count = reinterpret_cast<int32_t*>(p + l.reset_count);
+        s_.prepared = reinterpret_cast<ComposeHand*>(p + l.prepared);
         s_.ranks = atlas.sort_ranks;
         atlas_ = atlas;
     }
     int blocks() const { return (s_.n + 63) / 64; }
     void launch_make(hipStream_t st, uint32_t seed_base, int env_offset) override {
         hipLaunchKernelGGL(make_kernel, dim3(blocks()), dim3(64), 0, st, s_);
+        hipLaunchKernelGGL(prepare_kernel, dim3(1), dim3(128), 0, st, s_, atlas_);
         LevelLaunch<Gen>::make(st, s_, 0, seed_base, env_offset, plan);
     }
     void launch_reset(hipStream_t st, const uint8_t* mask, const int32_t* seeds, StepIO io) override {

@@ -68,6 +68,14 @@ struct alignas(16) ComposeLds {
                                 // bit 31: the background has some.  compose_spans sets it to its soft_init argument
                                 // (default −1, "assume all"); a staging pass that knows better ORs exact bits in.
 };
+// … plus a second cell table for compose_rows<GRID, false, true>: the cells that show the layer's BOXED texture — one
+// whose texels are transparent outside a box of texel columns and rows, so that it is a candidate only for the pixels
+// that sample inside the box (chaser's points).  Same layout and sentinels as `base`; a cell is in one table or neither.
+template <int GRID>
+struct alignas(16) ComposeLdsBoxed {
+    ComposeLds<GRID> plain;
+    int32_t boxed[GRID * GRID + 2];
+};
 template <int GRID>
 struct ComposeTmp {
     int4 col[GRID];           // per grid column: {d0, dn, s0, sn}; sn == 0 ⇒ nothing drawn
@@ -80,7 +88,8 @@ struct ComposeTmp {
 struct ComposeHand {
     uint4 col[64];       // per pixel column (by wave 0): background column offset, column offsets a / b, 4 × cell column a
     uint4 row[64];       // per pixel row (by wave 1): background row offset, row offsets a / b, byte offset of grid row a's cells
-    uint2 row2[64];      // … and the row offsets in the layer's second texture (compose_rows<GRID, true>)
+    uint2 row2[64];      // … and the row offsets in the layer's second texture (compose_rows<GRID, true>) / boxed texture
+    uint2 col2[64];      // the column offsets a / b in the boxed texture (compose_rows<GRID, false, true>)
     uint32_t masks[6];   // second_row, soft, hard (64 bits each)
     int32_t bad;         // either side found something the two-candidate scheme does not cover → fallback
 };
@@ -1024,21 +1033,17 @@ PG_D void compose_background(uint32_t* fb, const AtlasView& atlas, const BgAxis&
     __syncthreads();
 }
 
-template <int GRID, bool TWO = false>
-PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView& atlas, const BgAxis& bga, int cols, int rows,
-                       int tw, int lane, int ablate, int half, int halves) {
-    static_assert(GRID <= 31 || true, "");
-    if (L.too_wide[0] | L.too_wide[1]) return false;
+// BOX: L is the `plain` part of a ComposeLdsBoxed; the cells of its `boxed` table show a texture (same size as the layer's) that exists
+// only where the sampled texel lies in columns box.x..box.y and rows box.z..box.w — outside, the cell is no candidate at
+// all instead of one that turns out transparent, and the pixel's one-texel attempt goes straight to what is under it.
+// Exact whenever every texel outside the box is fully transparent (the word 0 in the atlas), which the caller checks.
+// The composer's hand-over tables (ComposeHand, in the frame target's still unused memory) from the span tables
+// compose_spans left there: wave 0 the pixel columns, wave 1 the pixel rows.  Leaves the barrier to the caller.
+template <int GRID, bool TWO, bool BOX>
+PG_D void compose_hand_build(uint32_t* fb, const ComposeLds<GRID>& L, const BgAxis& bga, int tw, int lane, int ablate, int half,
+                             int4 box) {
     const ComposeTmp<GRID>& T = compose_tmp<GRID>(fb);
     ComposeHand& H = compose_hand<GRID>(fb);
-    // All texel reads go through one buffer descriptor over the atlas: 32-bit byte offsets, and out-of-range
-    // (= "no candidate") reads return 0 without a branch.
-    // (`ablate` bits 5/6 are timing experiments: a descriptor with zero records drops every load through it.)
-    const __amdgpu_buffer_rsrc_t bg_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint32_t*>(atlas.texels), 0, PG_ABL(ablate, 32) ? 0 : static_cast<int>(atlas.texel_bytes), 0x00020000);
-    const __amdgpu_buffer_rsrc_t atlas_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint32_t*>(atlas.texels), 0, PG_ABL(ablate, 64) ? 0 : static_cast<int>(atlas.texel_bytes), 0x00020000);
-
     if (half == 0) {
         // ---- wave 0, lane = pixel column: the covering grid columns (at most two, neighbours) and their texel columns
         int ca, cb, ua, ub;
@@ -1053,6 +1058,9 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
         }
         if (PG_ABL(ablate, 2048)) bg_col = bg_col == kNoTexel ? kNoTexel : static_cast<uint32_t>(bga.tex_off) * 4u;
         H.col[lane] = make_uint4(bg_col, col_a, col_b, static_cast<uint32_t>(ca >= 0 ? ca : 0) * 4u);
+        if (BOX)
+            H.col2[lane] = make_uint2(ca >= 0 && ua >= box.x && ua <= box.y ? col_a : kNoTexel,
+                                      cb >= 0 && ub >= box.x && ub <= box.y ? col_b : kNoTexel);
         if (__ballot(!ok) && lane == 0) H.bad = 1;
     } else {
         // ---- wave 1, lane = pixel row: the covering grid rows and their texel rows, and the row classes as 64-bit
@@ -1084,6 +1092,9 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
             }
             H.row2[lane] = make_uint2(row_a2, row_b2);
         }
+        if (BOX)
+            H.row2[lane] = make_uint2(ra >= 0 && va >= box.z && va <= box.w ? row_a : kNoTexel,
+                                      rb >= 0 && vb >= box.z && vb <= box.w ? row_b : kNoTexel);
         const uint32_t soft_bits = static_cast<uint32_t>(L.soft_rows[0] | L.soft_rows[1]);
         const uint32_t hard_bits = static_cast<uint32_t>(L.hard_rows[0] | L.hard_rows[1]);
         // (grids beyond 31 rows alias in these masks: conservative)
@@ -1103,23 +1114,80 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
             if (any_bad) H.bad = 1;
         }
     }
+}
+
+// A game whose camera never moves (chaser: the whole world, always) has the same span and hand-over tables in every
+// frame of every env: it runs compose_spans and compose_hand_build once, when the envs are made, keeps the result in
+// device memory (compose_prepare, from a two-wavefront kernel of its own) and passes it to compose_rows<…, true>, which
+// then only works out the background's offsets — the one thing that differs per env (texture, horizontal shift).
+// The row classes of the kept tables are those of the tile layer alone; compose_rows adds the background's (bg_w: its
+// descriptor's .w).
+template <int GRID>
+PG_D void compose_prepare(uint32_t* fb, const ComposeLds<GRID>& L, ComposeHand* out, int lane, int half) {
+    ComposeHand& H = compose_hand<GRID>(fb);
+    __syncthreads();
+    if (half == 0 && lane == 0 && (L.too_wide[0] | L.too_wide[1])) H.bad = 1;
+    __syncthreads();
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&H);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(out);
+    for (int k = lane + 64 * half; k < static_cast<int>(sizeof(ComposeHand) / 4); k += 128) dst[k] = src[k];
+}
+
+template <int GRID, bool TWO = false, bool BOX = false, bool PREP = false>
+PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView& atlas, const BgAxis& bga, int cols, int rows,
+                       int tw, int lane, int ablate, int half, int halves, int4 box = make_int4(0, -1, 0, -1),
+                       const ComposeHand* prepared = nullptr, int bg_w = 0) {
+    static_assert(!(TWO && BOX), "the two per-cell row tables share their hand-over slot");
+    if (!PREP && (L.too_wide[0] | L.too_wide[1])) return false;
+    ComposeHand& H = compose_hand<GRID>(fb);
+    // All texel reads go through one buffer descriptor over the atlas: 32-bit byte offsets, and out-of-range
+    // (= "no candidate") reads return 0 without a branch.
+    // (`ablate` bits 5/6 are timing experiments: a descriptor with zero records drops every load through it.)
+    const __amdgpu_buffer_rsrc_t bg_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t*>(atlas.texels), 0, PG_ABL(ablate, 32) ? 0 : static_cast<int>(atlas.texel_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t atlas_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t*>(atlas.texels), 0, PG_ABL(ablate, 64) ? 0 : static_cast<int>(atlas.texel_bytes), 0x00020000);
+
+    if (PREP) {  // the tables are there (prepared): only the background's share is worked out, and traded as usual
+        if (half == 0)
+            H.col[lane].x = bg_offset(bga, lane, 0);
+        else
+            H.row[lane].x = bg_offset(bga, lane, 1);
+    } else {
+        compose_hand_build<GRID, TWO, BOX>(fb, L, bga, tw, lane, ablate, half, box);
+    }
     PG_MARK("g_hand");
     __syncthreads();
-    if (H.bad) return false;  // (nothing has been written to the target yet)
-    const uint4 hc = H.col[lane], hr = H.row[lane];
+    const ComposeHand& K = PREP ? *prepared : H;  // (the kept tables are read from device memory: 48 bytes a lane, in the L2)
+    if (K.bad) return false;  // (nothing has been written to the target yet)
+    uint4 hc = K.col[lane], hr = K.row[lane];
+    if (PREP) {
+        hc.x = H.col[lane].x;
+        hr.x = H.row[lane].x;
+    }
     const uint32_t bg_col = hc.x, col_a = hc.y, col_b = hc.z, cia4 = hc.w;
     const uint32_t bg_row = hr.x, row_a = hr.y, row_b = hr.z, cells_a = hr.w;
     uint32_t row_a2 = 0, row_b2 = 0;
-    if (TWO) {
-        const uint2 h2 = H.row2[lane];
+    uint32_t col_pa = 0, col_pb = 0;
+    if (TWO || BOX) {
+        const uint2 h2 = K.row2[lane];
         row_a2 = h2.x;
         row_b2 = h2.y;
     }
+    if (BOX) {
+        const uint2 h2 = K.col2[lane];
+        col_pa = h2.x;
+        col_pb = h2.y;
+    }
+    // byte distance from a cell of L.base to the same cell of the boxed table
+    constexpr uint32_t kBoxed = BOX ? static_cast<uint32_t>(sizeof(ComposeLds<GRID>)) : 0u;
+    static_assert(!BOX || __builtin_offsetof(ComposeLdsBoxed<GRID>, boxed) == sizeof(ComposeLds<GRID>), "boxed table right behind");
     auto mask64 = [&](int k) {
-        return static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(H.masks[2 * k])) |
-               (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(H.masks[2 * k + 1])) << 32);
+        return static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(K.masks[2 * k])) |
+               (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(K.masks[2 * k + 1])) << 32);
     };
-    const unsigned long long second_row = mask64(0), soft = mask64(1), hard = mask64(2);
+    const unsigned long long second_row = mask64(0);
+    const unsigned long long soft = PREP && bg_w != 0 ? ~0ull : mask64(1), hard = PREP && (bg_w & 2) ? ~0ull : mask64(2);
     constexpr int bg_mod = 255;  // (see BgAxis)
     __syncthreads();  // everybody has read the set-up tables out of the frame target's memory: it may be written now
     PG_MARK("h_handread");
@@ -1147,21 +1215,32 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
         }
         return __builtin_amdgcn_raw_buffer_load_b32(atlas_rsrc, cell + col, row_first, 0);
     };
-    // The general form of one batch of rows: every candidate of every pixel is fetched, then resolved.
-    auto general_batch = [&](int py0) {
+    auto boxed_texel = [&](uint32_t plain, uint32_t boxed) {
+        return __builtin_amdgcn_raw_buffer_load_b32(atlas_rsrc, plain < boxed ? plain : boxed, 0, 0);
+    };
+    // The general form of one batch of rows: every candidate of every pixel is fetched, then resolved.  `todo`: the rows
+    // of the batch it is wanted for (bit k = row py0 + k, wave-uniform); the others are left as they are.
+    auto general_batch = [&](int py0, uint32_t todo) {
         uint32_t t[kBatch][3], u[kBatch][2];
-        uint32_t seconds = static_cast<uint32_t>(second_row >> py0) & 0xffu;
+        uint32_t seconds = static_cast<uint32_t>(second_row >> py0) & todo;
         // (opaque to the compiler: it would otherwise keep the 32 per-row tests of the attempt below alive in scalar
         // registers for this rarely taken path, and spill them)
         asm volatile("" : "+s"(seconds));
 #pragma unroll
         for (int k = 0; k < kBatch; k++) {
+            if (!(todo & (1u << k))) continue;
             const int py = py0 + k;
             const uint32_t s_bg = __builtin_amdgcn_readlane(bg_row, py);
             const uint32_t s_a = __builtin_amdgcn_readlane(row_a, py);
             const uint32_t* cp = reinterpret_cast<const uint32_t*>(cells + __builtin_amdgcn_readlane(cells_a, py));
-            const uint32_t s_a2 = TWO ? __builtin_amdgcn_readlane(row_a2, py) : 0u;
+            const uint32_t s_a2 = (TWO || BOX) ? __builtin_amdgcn_readlane(row_a2, py) : 0u;
             t[k][0] = __builtin_amdgcn_raw_buffer_load_b32(bg_rsrc, bg_col, s_bg, 0);
+            if (BOX) {  // a cell sits in one table at most: the smaller of the two offsets is the one that exists, if any
+                const uint32_t* bp = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(cp) + kBoxed);
+                t[k][1] = boxed_texel(cp[0] + col_a + s_a, bp[0] + col_pa + s_a2);
+                t[k][2] = boxed_texel(cp[1] + col_b + s_a, bp[1] + col_pb + s_a2);
+                continue;
+            }
             t[k][1] = texel_of(cp[0], col_a, s_a, s_a2);
             t[k][2] = texel_of(cp[1], col_b, s_a, s_a2);
         }
@@ -1172,7 +1251,13 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
                     const int py = py0 + k;
                     const uint32_t s_b = __builtin_amdgcn_readlane(row_b, py);
                     const uint32_t* cp = reinterpret_cast<const uint32_t*>(cells + __builtin_amdgcn_readlane(cells_a, py));
-                    const uint32_t s_b2 = TWO ? __builtin_amdgcn_readlane(row_b2, py) : 0u;
+                    const uint32_t s_b2 = (TWO || BOX) ? __builtin_amdgcn_readlane(row_b2, py) : 0u;
+                    if (BOX) {
+                        const uint32_t* bp = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(cp) + kBoxed);
+                        u[k][0] = boxed_texel(cp[GRID] + col_a + s_b, bp[GRID] + col_pa + s_b2);
+                        u[k][1] = boxed_texel(cp[GRID + 1] + col_b + s_b, bp[GRID + 1] + col_pb + s_b2);
+                        continue;
+                    }
                     u[k][0] = texel_of(cp[GRID], col_a, s_b, s_b2);
                     u[k][1] = texel_of(cp[GRID + 1], col_b, s_b, s_b2);
                 }
@@ -1181,10 +1266,11 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
         // Does the batch hold a translucent texel (alpha not in {0, 255})?  Asked only when one of its rows shows a
         // texture that has any ((a + 1) & 0xFE is zero exactly for 0 and 255).
         bool blend = bg_mod != 255;
-        if (!blend && ((static_cast<uint32_t>(soft >> py0) & 0xffu) != 0u) && !PG_ABL(ablate, 512)) {
+        if (!blend && ((static_cast<uint32_t>(soft >> py0) & todo) != 0u) && !PG_ABL(ablate, 512)) {
             uint32_t translucent = 0;
 #pragma unroll
             for (int k = 0; k < kBatch; k++) {
+                if (!(todo & (1u << k))) continue;
                 translucent |= (((t[k][0] >> 24) + 1u) | ((t[k][1] >> 24) + 1u) | ((t[k][2] >> 24) + 1u)) & 0xFEu;
                 if (seconds & (1u << k)) translucent |= (((u[k][0] >> 24) + 1u) | ((u[k][1] >> 24) + 1u)) & 0xFEu;
             }
@@ -1198,7 +1284,8 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
             // byte, which nothing reads (blend_px, wave_store_rows).
             uint32_t pix[kBatch];
 #pragma unroll
-            for (int k = 0; k < kBatch; k++) pix[k] = max3_u32(t[k][0] & 0x00ffffffu, t[k][1] & 0x01ffffffu, t[k][2] & 0x02ffffffu);
+            for (int k = 0; k < kBatch; k++)
+                if (todo & (1u << k)) pix[k] = max3_u32(t[k][0] & 0x00ffffffu, t[k][1] & 0x01ffffffu, t[k][2] & 0x02ffffffu);
             if (seconds) {
 #pragma unroll
                 for (int k = 0; k < kBatch; k++)
@@ -1208,10 +1295,12 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
                     }
             }
 #pragma unroll
-            for (int k = 0; k < kBatch; k++) fb[(py0 + k) * kObsW + lane] = pix[k];
+            for (int k = 0; k < kBatch; k++)
+                if (todo & (1u << k)) fb[(py0 + k) * kObsW + lane] = pix[k];
         } else {
 #pragma unroll
             for (int k = 0; k < kBatch; k++) {
+                if (!(todo & (1u << k))) continue;
                 uint32_t pix = 0;
                 int a = static_cast<int>(t[k][0] >> 24);
                 if (bg_mod != 255) a = static_cast<int>(div255(static_cast<uint32_t>(a * bg_mod)));
@@ -1244,9 +1333,9 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
     constexpr int kRows = kObsH / 2;
     static_assert(kRows % kBatch == 0, "");
     if (halves != 2) return false;  // (every render kernel runs two wavefronts per env)
-    const uint32_t hards = static_cast<uint32_t>(hard >> py_begin);  // this wave's 32 rows
+    const uint32_t hards = PG_ABL(ablate, 16384) ? 0u : static_cast<uint32_t>(hard >> py_begin);  // this wave's 32 rows
     if (bg_mod != 255 || hards == 0xffffffffu) {  // nothing worth attempting
-        for (int py0 = py_begin; py0 < py_begin + kRows; py0 += kBatch) general_batch(py0);
+        for (int py0 = py_begin; py0 < py_begin + kRows; py0 += kBatch) general_batch(py0, 0xffu);
         __syncthreads();
         return true;
     }
@@ -1267,6 +1356,7 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
     // cover the three candidates of the upper grid row are settled first and their winner enters the second minimum.
     constexpr uint32_t kRank = 1u << 28, kOffsetBits = 0xcfffffffu;  // (several missing terms may carry into bit 31)
     const uint32_t bg_col_r = bg_col + 2u * kRank, col_a_r = col_a + kRank;  // (·, b) is drawn after (·, a): rank 0
+    const uint32_t col_pa_r = col_pa + kRank;  // (BOX: a boxed cell has the rank of its place, like a plain one)
     auto min3_u32 = [](uint32_t a, uint32_t b, uint32_t c) {  // v_min3_u32
         const uint32_t m = a < b ? a : b;
         return m < c ? m : c;
@@ -1274,6 +1364,7 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
 #pragma unroll
     for (int g = 0; g < kRows / kBatch; g++) {
         uint32_t cell_aa[kBatch], cell_ab[kBatch], cell_ba[kBatch], cell_bb[kBatch];
+        uint32_t box_aa[BOX ? kBatch : 1], box_ab[BOX ? kBatch : 1];
 #pragma unroll
         for (int k = 0; k < kBatch; k++) {
             const int py = py_begin + g * kBatch + k;
@@ -1282,21 +1373,31 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
             cell_ab[k] = cp[1];
             cell_ba[k] = cp[GRID];  // (used on the rows two grid rows cover; reading them anyway keeps this loop straight)
             cell_bb[k] = cp[GRID + 1];
+            if (BOX) {
+                const uint32_t* bp = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(cp) + kBoxed);
+                box_aa[k] = bp[0];
+                box_ab[k] = bp[1];
+            }
         }
 #pragma unroll
         for (int k = 0; k < kBatch; k++) {
             const int py = py_begin + g * kBatch + k;
             const uint32_t s_bg = __builtin_amdgcn_readlane(bg_row, py);
             const uint32_t s_a = __builtin_amdgcn_readlane(row_a, py);
-            const uint32_t s_a2 = TWO ? __builtin_amdgcn_readlane(row_a2, py) : 0u;
+            const uint32_t s_a2 = (TWO || BOX) ? __builtin_amdgcn_readlane(row_a2, py) : 0u;
             // draw order: background, (a, a), (a, b), (b, a), (b, b) — the last one there wins
-            uint32_t at = min3_u32(bg_col_r + s_bg, tile_at(cell_aa[k], col_a_r, s_a, s_a2), tile_at(cell_ab[k], col_b, s_a, s_a2)) &
-                          kOffsetBits;
+            uint32_t at = min3_u32(bg_col_r + s_bg, tile_at(cell_aa[k], col_a_r, s_a, s_a2), tile_at(cell_ab[k], col_b, s_a, s_a2));
+            if (BOX) at = min3_u32(at, box_aa[k] + col_pa_r + s_a2, box_ab[k] + col_pb + s_a2);
+            at &= kOffsetBits;
             if (seconds32 & (1u << (g * kBatch + k))) {  // wave-uniform
                 const uint32_t s_b = __builtin_amdgcn_readlane(row_b, py);
-                const uint32_t s_b2 = TWO ? __builtin_amdgcn_readlane(row_b2, py) : 0u;
-                at = min3_u32(at + 2u * kRank, tile_at(cell_ba[k], col_a_r, s_b, s_b2), tile_at(cell_bb[k], col_b, s_b, s_b2)) &
-                     kOffsetBits;
+                const uint32_t s_b2 = (TWO || BOX) ? __builtin_amdgcn_readlane(row_b2, py) : 0u;
+                at = min3_u32(at + 2u * kRank, tile_at(cell_ba[k], col_a_r, s_b, s_b2), tile_at(cell_bb[k], col_b, s_b, s_b2));
+                if (BOX) {  // (the boxed cells of the second grid row are read here: one pixel row in five or six has one)
+                    const uint32_t* bp = reinterpret_cast<const uint32_t*>(cells + __builtin_amdgcn_readlane(cells_a, py) + kBoxed);
+                    at = min3_u32(at, bp[GRID] + col_pa_r + s_b2, bp[GRID + 1] + col_pb + s_b2);
+                }
+                at &= kOffsetBits;
                 asm volatile("" : "+v"(at));  // keeps the branch a branch
             }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(atlas_rsrc, (lds_ptr)(fb + py * kObsW), 4, static_cast<int>(at), 0, 0, 0);
@@ -1309,16 +1410,25 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
 #pragma unroll
     for (int g = 0; g < kRows / kBatch; g++) {
         const uint4 p = landed[g * (kBatch * kObsW / 4) + lane], q = landed[g * (kBatch * kObsW / 4) + 64 + lane];
-        uint32_t least = p.x < p.y ? p.x : p.y;
-        least = least < p.z ? least : p.z;
-        least = least < p.w ? least : p.w;
-        least = least < q.x ? least : q.x;
-        least = least < q.y ? least : q.y;
-        least = least < q.z ? least : q.z;
-        least = least < q.w ? least : q.w;
-        const bool skip = ((hards >> (g * kBatch)) & 0xffu) != 0u;
-        if ((skip || __ballot(least < 0xff000000u) != 0 || PG_ABL(ablate, 4096)) && !PG_ABL(ablate, 8192))  // (bit 13: never)
-            general_batch(py_begin + g * kBatch);
+        // lane l has rows l / 16 (p) and 4 + l / 16 (q) of the batch: the rows that hold a texel that is not opaque, and
+        // those the attempt was not meant for, go through the general form; the others are done
+        static_assert(kObsW == 64 && kBatch == 8, "sixteen lanes a row");
+        uint32_t least_p = p.x < p.y ? p.x : p.y, least_q = q.x < q.y ? q.x : q.y;
+        least_p = least_p < p.z ? least_p : p.z;
+        least_p = least_p < p.w ? least_p : p.w;
+        least_q = least_q < q.z ? least_q : q.z;
+        least_q = least_q < q.w ? least_q : q.w;
+        uint32_t todo = (hards >> (g * kBatch)) & 0xffu;
+        const unsigned long long open_p = __ballot(least_p < 0xff000000u), open_q = __ballot(least_q < 0xff000000u);
+        if ((open_p | open_q) != 0) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                if ((open_p >> (16 * r)) & 0xffffull) todo |= 1u << r;
+                if ((open_q >> (16 * r)) & 0xffffull) todo |= 16u << r;
+            }
+        }
+        if (PG_ABL(ablate, 4096)) todo = 0xffu;
+        if (todo != 0 && !PG_ABL(ablate, 8192)) general_batch(py_begin + g * kBatch, todo);  // (bit 13: never)
     }
     __syncthreads();
     return true;
