@@ -16,7 +16,9 @@
 // wavefront per env.  Because of the in-step draws the next level cannot be generated ahead of time (pg_prefetch.h
 // is used with prefetch off: every reset carves its maze inside the step).
 #include "../../include/procgen2_vec.h"
+#ifndef PG_CHASER_BLEND_PAIRS
 #define PG_BLEND_CHANNELWISE 1  // pg_geom.h blend_px
+#endif
 #include "pg_engine.h"
 #include "pg_frame.h"
 #include "pg_gang.h"
