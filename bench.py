@@ -30,6 +30,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Before torch or the engine touch HIP: the runtime reads this at its first call (see procgen2_amd/__init__.py — the
+# mixed workload runs fourteen streams, and on the default four hardware queues they queue up behind each other).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 # 12288 obs write + 4 action read + 4 reward write + 1 done write.  (The synthetic path hashes its actions
 # in the kernel instead of reading them: the 4 bytes of the action read are counted because the figure is the survey's,
