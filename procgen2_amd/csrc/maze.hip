@@ -60,6 +60,9 @@ struct State {
     int32_t* slot;   // [n]  SlotState
     uint32_t* mt;    // [n][625]  generator chain: the stream position after the newest generated level
     uint8_t* tiles;  // [n][kTileStride], column-major y + x*H
+    // !kCentred: the camera rests on the world centre and shows all of it, so the row composer's span and hand-over
+    // tables are the same in every frame: worked out once (prepare_kernel), read from here (pg_render.h compose_prepare)
+    ComposeHand* prepared;
     float* f;        // [F_COUNT][n]
     int32_t* i;      // [I_COUNT][n]
 };
@@ -208,6 +211,39 @@ __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actio
     io.pending[env] = terminated ? 1 : 0;
 }
 
+constexpr int kGrid = kVisible + 3 <= 20 ? 20 : 28;  // visible tiles + the border cells of the inclusive window; as small as it
+// may be: the composer tables are LDS, and LDS decides how many envs a CU holds (28: 7 per CU, 32: 6)
+constexpr int kSpan = 64 / kVisible + 2 <= kMaxSpan ? kMaxSpan : 16;  // pixels a tile covers (+ seam padding)
+
+// the wall window of a camera (tilemap.cpp:111-121)
+struct Window {
+    int x0, y0, cols, rows;
+};
+PG_D Window window_of(const Camera& cam) {
+    const float vx = (cam.px - cam.sw * 0.5f / cam.scale) * kPxUnit;
+    const float vy = (cam.py - cam.sh * 0.5f / cam.scale) * kPxUnit;
+    const float vw = cam.sw * kPxUnit / cam.scale, vh = cam.sh * kPxUnit / cam.scale;
+    const int x0 = static_cast<int>(floorf(vx)), y0 = static_cast<int>(floorf(vy));
+    const int x1 = static_cast<int>(ceilf(vx + vw)), y1 = static_cast<int>(ceilf(vy + vh));
+    return Window{x0, y0, x1 - x0 + 1, y1 - y0 + 1};
+}
+PG_D float zoom_of_obs() { return 64.0f / (kUnitPx * static_cast<float>(kVisible)); }  // maze.cpp:397-400
+
+// Once per engine (!kCentred): the composer's tables for the camera on the world centre (State::prepared).
+__global__ void __launch_bounds__(128) prepare_kernel(State s, AtlasView atlas) {
+    __shared__ alignas(16) uint32_t fb[kFbWords];
+    __shared__ ComposeLds<kGrid> L;
+    const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const Camera cam{W * 0.5f * kUnitPx, H * 0.5f * kUnitPx, 64.0f, 64.0f, zoom_of_obs()};  // maze.cpp:436-437
+    const Window w = window_of(cam);
+    const int4 wall = atlas.desc[kTexWall];
+    compose_spans<kGrid, kSpan>(fb, L, cam, w.x0, w.y0, w.cols, w.rows, wall.y, wall.z, kUnitPx / wall.y, lane, 0, half, 2,
+                                soft_rows_of(0, wall.w), hard_rows_of(0, wall.w));
+    __syncthreads();
+    compose_hand_build<kGrid, false, false>(fb, L, BgAxis{}, wall.y, lane, 0, half, make_int4(0, -1, 0, -1));
+    compose_prepare<kGrid>(fb, L, s.prepared, lane, half);
+}
+
 // flags bit 0: force the draw-list replay for background + walls (fallback path).
 __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
                                                     int flags) {
@@ -216,13 +252,12 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
     const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // two wavefronts per env (pg_render.h)
     constexpr int halves = 2;
     __shared__ alignas(16) uint32_t fb[kFbWords];
-    constexpr int kGrid = kVisible + 3 <= 20 ? 20 : 28;  // visible tiles + the border cells of the inclusive window; as small as it
-    // may be: the composer tables are LDS, and LDS decides how many envs a CU holds (28: 7 per CU, 32: 6)
     __shared__ ComposeLds<kGrid> L;
 
     // maze.cpp:397-400, 436-437: zoom = 64 / (16 * visible_width); camera at the world centre, or on the agent
-    const float zoom = 64.0f / (kUnitPx * static_cast<float>(kVisible));
-    const Camera cam{SF(s, F_CAMX, env), SF(s, F_CAMY, env), 64.0f, 64.0f, zoom};
+    const float zoom = zoom_of_obs();
+    const Camera cam{kCentred ? SF(s, F_CAMX, env) : W * 0.5f * kUnitPx, kCentred ? SF(s, F_CAMY, env) : H * 0.5f * kUnitPx,
+                     64.0f, 64.0f, zoom};
     const int sflags = SI(s, I_FLAGS, env);
     const uint8_t* tiles = s.tiles + size_t(env) * kTileStride;
     Blit mine;
@@ -240,29 +275,30 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
         bg_py = 0.0f;
         bg_sc = 64.0f * kUnitPx / d.z;
     }
-    // wall window (tilemap.cpp:111-121)
-    const float vx = (cam.px - cam.sw * 0.5f / cam.scale) * kPxUnit;
-    const float vy = (cam.py - cam.sh * 0.5f / cam.scale) * kPxUnit;
-    const float vw = cam.sw * kPxUnit / cam.scale, vh = cam.sh * kPxUnit / cam.scale;
-    const int x0 = static_cast<int>(floorf(vx)), y0 = static_cast<int>(floorf(vy));
-    const int x1 = static_cast<int>(ceilf(vx + vw)), y1 = static_cast<int>(ceilf(vy + vh));
-    const int cols = x1 - x0 + 1, rows = y1 - y0 + 1, cells = cols * rows;
+    const Window win = window_of(cam);
+    const int x0 = win.x0, y0 = win.y0, cols = win.cols, rows = win.rows, cells = cols * rows;
     const int4 wall = atlas.desc[kTexWall];
 
     const BgDraw bg_draw{bg_d, bg_px, bg_py, bg_sc};
     BgAxis bga{};  // this wave's axis of it (wave 0: x, wave 1: y), resolved along with the tile spans
     bool composed = false;
     if (!(flags & 1) && cols <= kGrid && rows <= kGrid) {
-        constexpr int kSpan = 64 / kVisible + 2 <= kMaxSpan ? kMaxSpan : 16;  // pixels a tile covers (+ seam padding)
-        compose_spans<kGrid, kSpan>(fb, L, cam, x0, y0, cols, rows, wall.y, wall.z, kUnitPx / wall.y, lane, 0, half, halves,
-                                    soft_rows_of(bg_soft, wall.w), hard_rows_of(bg_soft, wall.w), &bg_draw, &bga);
+        if (kCentred) {
+            compose_spans<kGrid, kSpan>(fb, L, cam, x0, y0, cols, rows, wall.y, wall.z, kUnitPx / wall.y, lane, 0, half, halves,
+                                        soft_rows_of(bg_soft, wall.w), hard_rows_of(bg_soft, wall.w), &bg_draw, &bga);
+        } else {  // the tile spans are the prepared ones: only this wave's axis of the background is resolved
+            bga = bg_axis(cam, bg_d, bg_px, bg_py, bg_sc, half);
+            if (half == 0 && lane < 2) L.base[kGrid * kGrid + lane] = static_cast<int32_t>(kNoTexel);
+        }
         for (int cell = lane + 64 * half; cell < cells; cell += 64 * halves) {
             const int r = cell / cols, c = cell - r * cols;
             L.base[r * kGrid + c] =
                 tile_at(tiles, x0 + c, H - 1 - (y0 + r)) == kOpen ? static_cast<int32_t>(kNoTexel) : wall.x * 4;
         }
         __syncthreads();
-        composed = compose_rows(fb, L, atlas, bga, cols, rows, wall.y, lane, flags, half, halves);
+        composed = kCentred ? compose_rows<kGrid>(fb, L, atlas, bga, cols, rows, wall.y, lane, flags, half, halves)
+                            : compose_rows<kGrid, false, false, true>(fb, L, atlas, bga, cols, rows, wall.y, lane, flags, half, halves,
+                                                                      make_int4(0, -1, 0, -1), s.prepared, bg_soft);
     }
     if (!composed) {  // draw-list replay (tilemap.cpp:111-133)
         wave_clear(fb, lane, half, halves);
@@ -340,7 +376,7 @@ class MazeGame final : public Game {
     size_t state_bytes(int n) const override {
         return align256(size_t(n) * sizeof(Level)) + align256(size_t(n) * 4) + align256(size_t(n) * kMtWords * 4) +
                align256(size_t(n) * kTileStride) +
-               align256(size_t(F_COUNT) * n * 4) + align256(size_t(I_COUNT) * n * 4);
+               align256(size_t(F_COUNT) * n * 4) + align256(size_t(I_COUNT) * n * 4) + align256(sizeof(ComposeHand));
     }
     void bind(void* d_state, int n, AtlasView atlas) override {
         uint8_t* p = static_cast<uint8_t*>(d_state);
@@ -356,11 +392,13 @@ class MazeGame final : public Game {
         s_.tiles = take(size_t(n) * kTileStride);
         s_.f = reinterpret_cast<float*>(take(size_t(F_COUNT) * n * 4));
         s_.i = reinterpret_cast<int32_t*>(take(size_t(I_COUNT) * n * 4));
+        s_.prepared = reinterpret_cast<ComposeHand*>(take(sizeof(ComposeHand)));
         atlas_ = atlas;
     }
     int blocks() const { return (s_.n + 63) / 64; }
     void launch_make(hipStream_t st, uint32_t seed_base, int env_offset) override {
         LevelLaunch<Gen>::make(st, s_, prefetch(), seed_base, env_offset, plan);
+        if (!kCentred) hipLaunchKernelGGL(prepare_kernel, dim3(1), dim3(128), 0, st, s_, atlas_);
     }
     void launch_reset(hipStream_t st, const uint8_t* mask, const int32_t* seeds, StepIO io) override {
         LevelLaunch<Gen>::reset(st, s_, prefetch(), mask, seeds, io, plan);
