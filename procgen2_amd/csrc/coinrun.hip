@@ -1075,8 +1075,11 @@ __global__ void __launch_bounds__(64 * kRenderWaves, 4) render_kernel(State s, A
         uint32_t soft_rows = (threadIdx.x == 0 && bg_d.w != 0) ? 0x80000000u : 0u;
         // (the one-texel-per-pixel attempt is made everywhere unless the backdrop is mostly cut-out: crates and lava are few)
         const uint32_t hard_rows = (threadIdx.x == 0 && (bg_d.w & 2)) ? 0x80000000u : 0u;
+        // the whole kGrid×kGrid table, 64 cells per pass — all by wave 0: wave 1 has resolved the sprite pass's draws above,
+        // and an env's frame is done when its slower wave is (measured: render 0.456 -> 0.440 ms against an even split)
 #pragma unroll
-        for (int k = half; k < kGrid * kGrid / 64; k += halves) {  // the whole kGrid×kGrid table, 64 cells per pass
+        for (int k = 0; k < kGrid * kGrid / 64; k++) {
+            if (half != 0) break;
             const int cell = k * 64 + lane;
             const int r = cell / kGrid, c = cell % kGrid;
             const int x = x0 + c, ty = H - 1 - (y0 + r);
