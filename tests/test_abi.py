@@ -147,3 +147,27 @@ def test_bench_mixed_gather_launch_line():
                           "--dry-launch"], env=env, capture_output=True, text=True, check=True).stdout
     line = json.loads(out.strip().splitlines()[-1])
     assert line["n_gpus"] == 8 and line["launch"][-5:] == ["--workload", "mixed", "--gather", "--gpus", "8"]
+
+
+def test_hardware_queue_default_is_set_by_library_and_package_unless_chosen():
+    """Several engines per GPU need more than the HIP runtime's four hardware queues: loading the
+    shared library (a load-time constructor) and importing the package both default GPU_MAX_HW_QUEUES to 16, and
+    neither touches a value the caller has chosen."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = ("import ctypes, os, sys\n"
+            "sys.path.insert(0, %r)\n"
+            "mode = sys.argv[1]\n"
+            "if mode == 'lib': ctypes.CDLL(%r)\n"
+            "else: import procgen2_amd\n"
+            "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p\n"
+            "print((libc.getenv(b'GPU_MAX_HW_QUEUES') or b'').decode())\n") % (root, pglib.DEFAULT_LIB)
+    for mode in ("lib", "package"):
+        for chosen, want in ((None, "16"), ("6", "6")):
+            env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+            if chosen is not None:
+                env["GPU_MAX_HW_QUEUES"] = chosen
+            out = subprocess.run([sys.executable, "-c", prog, mode], env=env, capture_output=True, text=True, timeout=120)
+            assert out.returncode == 0, out.stderr
+            assert out.stdout.strip() == want, (mode, chosen, out.stdout, out.stderr)
