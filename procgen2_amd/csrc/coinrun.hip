@@ -886,7 +886,12 @@ __global__ void __launch_bounds__(64) resolve_kernel(State s, StepIO io) {
 // Higher bits are timing experiments (tools/ablate_render.py), compiled in only with -DPG_ABLATE (pg_render.h PG_ABL).
 constexpr int kRenderWaves = 2;  // wavefronts per env (pg_render.h: two waves share one frame's LDS target)
 
-__global__ void __launch_bounds__(64 * kRenderWaves, 4) render_kernel(State s, AtlasView atlas, const uint8_t* mask,
+#ifndef PG_COINRUN_RENDER_WAVES
+// Wavefronts per SIMD the registers are capped for.  Five (96 registers: nine envs a CU, which the LDS now allows) spills
+// 77 of the 119 this kernel wants and is 7 % slower; at four the kernel holds eight envs a CU.
+#define PG_COINRUN_RENDER_WAVES 4
+#endif
+__global__ void __launch_bounds__(64 * kRenderWaves, PG_COINRUN_RENDER_WAVES) render_kernel(State s, AtlasView atlas, const uint8_t* mask,
                                                                    StepIO io, int flags) {
     const int env = blockIdx.x;
     if (mask && !mask[env]) return;
@@ -895,7 +900,11 @@ __global__ void __launch_bounds__(64 * kRenderWaves, 4) render_kernel(State s, A
     __shared__ alignas(16) uint32_t fb[kFbWords];
     constexpr int kGrid = 16;  // 64 px / 4.8 px per tile = 13.3 tiles → at most 15 columns/rows in view
     __shared__ ComposeLds<kGrid> L;                 // the composer's cell table
-    __shared__ uint32_t slots[kBlitWords * 64];     // the 64 resolved draws of the sprite pass, from wave 1 to wave 0
+    // The 64 resolved draws of the sprite pass, from wave 1 to wave 0, travel through the END of the frame target's
+    // memory (the composer's set-up tables borrow its start): they are written before the frame is composed and taken
+    // before its first pixel is (render 0.440 -> 0.435 ms against an array of their own: 1.5 KB less LDS per env).
+    uint32_t* const slots = fb + kFbWords - kBlitWords * 64;
+    static_assert(sizeof(ComposeTmp<kGrid>) + sizeof(ComposeHand) + kBlitWords * 64 * 4 <= kFbWords * 4, "room behind the set-up tables");
 #if defined(PG_ABLATE) && defined(PG_LDS_PAD)  // occupancy experiment: fewer envs per CU
     __shared__ uint32_t lds_pad[PG_LDS_PAD];
     if (flags & 0x40000000) {
@@ -1107,10 +1116,17 @@ __global__ void __launch_bounds__(64 * kRenderWaves, 4) render_kernel(State s, A
         PG_MARK("k_composed");
     }
     if (PG_ABL(flags, 4)) composed = true;  // (bit 2: timing experiment — no background/tiles at all)
+    bool taken = false;
     if (!composed) {  // draw-list replay of background and tiles (tilemap.cpp:294-321)
+        if (!sprites_ready) {  // the draws wave 1 resolved leave the target's memory before it is written
+            __syncthreads();
+            taken = blit_take(slots, lane, mine);
+            __syncthreads();
+        }
+        Blit tile;  // (`mine` holds the sprite pass's draws)
         wave_clear(fb, lane, half, halves);
-        const bool has_bg = resolve_draw(cam, bg_d.y, bg_d.z, bg_d.x, bg_px, bg_py, bg_sc, 1.0f, false, false, mine);
-        wave_replay(fb, atlas, mine, has_bg ? 1ull : 0ull, lane, half, halves);
+        const bool has_bg = resolve_draw(cam, bg_d.y, bg_d.z, bg_d.x, bg_px, bg_py, bg_sc, 1.0f, false, false, tile);
+        wave_replay(fb, atlas, tile, has_bg ? 1ull : 0ull, lane, half, halves);
         for (int base = 0; base < cells; base += 64) {
             const int cell = base + lane;
             bool has = false;
@@ -1138,10 +1154,10 @@ __global__ void __launch_bounds__(64 * kRenderWaves, 4) render_kernel(State s, A
                         tex = kTexCrate + crate;
                     const int4 d = atlas.desc[tex];  // fallback path: plain global lookup
                     has = resolve_draw(cam, d.y, d.z, d.x, x * kUnitPx, y * kUnitPx, kUnitPx / d.y, 1.0f, false, false,
-                                       mine);
+                                       tile);
                 }
             }
-            wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
+            wave_replay(fb, atlas, tile, __ballot(has), lane, half, halves);
         }
     }
 
@@ -1173,10 +1189,8 @@ __global__ void __launch_bounds__(64 * kRenderWaves, 4) render_kernel(State s, A
             }
         }
         // the draws wave 1 resolved before the frame was composed (several barriers ago)
-        if (!sprites_ready) {  // (the draw-list replay path did not get that far)
-            const bool has = blit_take(slots, lane, mine);
-            sprite_pass = replay_begin(atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
-        }
+        if (!sprites_ready)  // (the draw-list replay path did not get that far)
+            sprite_pass = replay_begin(atlas, mine, __ballot(taken), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
         PG_MARK("m_fallback_and_rounds");
         replay_finish(fb, atlas, mine, sprite_pass, lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
         PG_MARK("n_sprites");

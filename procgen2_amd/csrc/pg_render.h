@@ -1203,6 +1203,13 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
 #endif
     constexpr int kBatch = PG_BATCH;
     static_assert(kBatch == 8, "the batch's slice of the row masks is taken as one byte");
+#ifndef PG_GEN_ROWS
+#define PG_GEN_ROWS 4
+#endif
+    // Rows the general form takes at a time.  Its 5 × kGen texels were the register peak of every kernel that composes
+    // (eight rows: caveflyer 106 registers, climber 100, chaser 96, maze 83; four: 82, 64, 78, 46), and it is the rare path.
+    constexpr int kGen = PG_GEN_ROWS;
+    static_assert(kBatch % kGen == 0, "");
     if (PG_ABL(ablate, 128)) {  // timing experiment: everything but the row loop
         __syncthreads();
         return true;
@@ -1220,14 +1227,14 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
     };
     // The general form of one batch of rows: every candidate of every pixel is fetched, then resolved.  `todo`: the rows
     // of the batch it is wanted for (bit k = row py0 + k, wave-uniform); the others are left as they are.
-    auto general_batch = [&](int py0, uint32_t todo) {
-        uint32_t t[kBatch][3], u[kBatch][2];
+    auto general_batch = [&](int py0, uint32_t todo) {  // kGen rows from py0; `todo` has kGen bits
+        uint32_t t[kGen][3], u[kGen][2];
         uint32_t seconds = static_cast<uint32_t>(second_row >> py0) & todo;
         // (opaque to the compiler: it would otherwise keep the 32 per-row tests of the attempt below alive in scalar
         // registers for this rarely taken path, and spill them)
         asm volatile("" : "+s"(seconds));
 #pragma unroll
-        for (int k = 0; k < kBatch; k++) {
+        for (int k = 0; k < kGen; k++) {
             if (!(todo & (1u << k))) continue;
             const int py = py0 + k;
             const uint32_t s_bg = __builtin_amdgcn_readlane(bg_row, py);
@@ -1246,7 +1253,7 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
         }
         if (seconds) {
 #pragma unroll
-            for (int k = 0; k < kBatch; k++) {
+            for (int k = 0; k < kGen; k++) {
                 if (seconds & (1u << k)) {
                     const int py = py0 + k;
                     const uint32_t s_b = __builtin_amdgcn_readlane(row_b, py);
@@ -1269,7 +1276,7 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
         if (!blend && ((static_cast<uint32_t>(soft >> py0) & todo) != 0u) && !PG_ABL(ablate, 512)) {
             uint32_t translucent = 0;
 #pragma unroll
-            for (int k = 0; k < kBatch; k++) {
+            for (int k = 0; k < kGen; k++) {
                 if (!(todo & (1u << k))) continue;
                 translucent |= (((t[k][0] >> 24) + 1u) | ((t[k][1] >> 24) + 1u) | ((t[k][2] >> 24) + 1u)) & 0xFEu;
                 if (seconds & (1u << k)) translucent |= (((u[k][0] >> 24) + 1u) | ((u[k][1] >> 24) + 1u)) & 0xFEu;
@@ -1282,24 +1289,24 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
             // texels); an opaque one has 0xFF on top.  Masking the top byte down to the candidate's rank in draw
             // order turns "last drawn non-empty" into a plain unsigned maximum.  The rank stays in the target's top
             // byte, which nothing reads (blend_px, wave_store_rows).
-            uint32_t pix[kBatch];
+            uint32_t pix[kGen];
 #pragma unroll
-            for (int k = 0; k < kBatch; k++)
+            for (int k = 0; k < kGen; k++)
                 if (todo & (1u << k)) pix[k] = max3_u32(t[k][0] & 0x00ffffffu, t[k][1] & 0x01ffffffu, t[k][2] & 0x02ffffffu);
             if (seconds) {
 #pragma unroll
-                for (int k = 0; k < kBatch; k++)
+                for (int k = 0; k < kGen; k++)
                     if (seconds & (1u << k)) {  // wave-uniform: a real branch (the empty asm keeps it from becoming a select)
                         pix[k] = max3_u32(pix[k], u[k][0] & 0x03ffffffu, u[k][1] & 0x04ffffffu);
                         asm volatile("" : "+v"(pix[k]));
                     }
             }
 #pragma unroll
-            for (int k = 0; k < kBatch; k++)
+            for (int k = 0; k < kGen; k++)
                 if (todo & (1u << k)) fb[(py0 + k) * kObsW + lane] = pix[k];
         } else {
 #pragma unroll
-            for (int k = 0; k < kBatch; k++) {
+            for (int k = 0; k < kGen; k++) {
                 if (!(todo & (1u << k))) continue;
                 uint32_t pix = 0;
                 int a = static_cast<int>(t[k][0] >> 24);
@@ -1335,7 +1342,7 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
     if (halves != 2) return false;  // (every render kernel runs two wavefronts per env)
     const uint32_t hards = PG_ABL(ablate, 16384) ? 0u : static_cast<uint32_t>(hard >> py_begin);  // this wave's 32 rows
     if (bg_mod != 255 || hards == 0xffffffffu) {  // nothing worth attempting
-        for (int py0 = py_begin; py0 < py_begin + kRows; py0 += kBatch) general_batch(py0, 0xffu);
+        for (int py0 = py_begin; py0 < py_begin + kRows; py0 += kGen) general_batch(py0, (1u << kGen) - 1u);
         __syncthreads();
         return true;
     }
@@ -1428,7 +1435,13 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
             }
         }
         if (PG_ABL(ablate, 4096)) todo = 0xffu;
-        if (todo != 0 && !PG_ABL(ablate, 8192)) general_batch(py_begin + g * kBatch, todo);  // (bit 13: never)
+        if (todo != 0 && !PG_ABL(ablate, 8192)) {  // (bit 13: never)
+#pragma unroll
+            for (int h = 0; h < kBatch / kGen; h++) {
+                const uint32_t part = (todo >> (h * kGen)) & ((1u << kGen) - 1u);
+                if (part) general_batch(py_begin + g * kBatch + h * kGen, part);
+            }
+        }
     }
     __syncthreads();
     return true;
