@@ -887,9 +887,10 @@ __global__ void __launch_bounds__(64) resolve_kernel(State s, StepIO io) {
 constexpr int kRenderWaves = 2;  // wavefronts per env (pg_render.h: two waves share one frame's LDS target)
 
 #ifndef PG_COINRUN_RENDER_WAVES
-// Wavefronts per SIMD the registers are capped for.  Five (96 registers: nine envs a CU, which the LDS now allows) spills
-// 77 of the 119 this kernel wants and is 7 % slower; at four the kernel holds eight envs a CU.
-#define PG_COINRUN_RENDER_WAVES 4
+// Wavefronts per SIMD the registers are capped for.  Five = 96 registers = nine envs a CU, which the LDS allows since the
+// shared draws left it: render 0.435 -> 0.414 ms.  (The kernel wants 121; the 57 it spills sit in the rare paths.  With the
+// general form of the row composer still eight rows at a time it spilled 77 and was 7 % slower than at four.)
+#define PG_COINRUN_RENDER_WAVES 5
 #endif
 __global__ void __launch_bounds__(64 * kRenderWaves, PG_COINRUN_RENDER_WAVES) render_kernel(State s, AtlasView atlas, const uint8_t* mask,
                                                                    StepIO io, int flags) {
