@@ -744,19 +744,29 @@ __global__ void __launch_bounds__(64, PG_CHASER_WAVES) logic_kernel(State s, con
 // The wall tile's corners are translucent (16 of its 256 texels, enough for the atlas loader's "hard" mark), but a frame
 // samples at most two or three of them per wall, all in one pixel row of the tile: the composer's one-texel attempt
 // settles the other rows, so it is made regardless.
+// Wavefronts per SIMD the render kernels' registers are capped for (five = 96 registers; they take 80).  Only the default
+// mode's env is small enough for the LDS to hold nine of them per CU; the larger worlds hold eight either way.
+#ifndef PG_CHASER_RENDER_WAVES
+#if PG_VARIANT == 0
+#define PG_CHASER_RENDER_WAVES 5
+#else
+#define PG_CHASER_RENDER_WAVES 4
+#endif
+#endif
 #ifndef PG_CHASER_HARD_WALLS
 #define PG_CHASER_HARD_WALLS 0
 #endif
-constexpr int kGrid = W + 2 <= 16 ? 16 : 24;  // composer grid: W tiles + the border cells of the inclusive window
-static_assert(W + 2 <= kGrid && (kGrid * kGrid) % 64 == 0, "composer grid");
+// Composer grid: W tiles + the border cells of the inclusive window, not a cell more — LDS decides how many envs a CU
+// holds, and with 13 × 13 cell tables (16 × 16: 700 bytes more) and the draw list in registers the default mode's env
+// takes 17.4 KB instead of 19.1: nine per CU instead of eight.
+constexpr int kGrid = W + 2;
+constexpr int kEntRegs = (kMaxEnt + 63) / 64;  // the draw list, entry lane + 64·j in register j of every wavefront
 
 // What the sprite pass needs of the entity tables, fetched when the kernel starts — the draw list's entities and the
 // enemies' places are two and three dependent global loads deep, and a wavefront that goes for them only when it gets
 // to its sprites waits that long with nothing else to do (the composer's work is behind it by then).
 struct SpriteLds {
-    uint32_t ent[kMaxEnt];   // per draw-list place: entity | kind << 8 | cell << 16
     float mob[kMobs + 1][4];  // per enemy: x, y, texture
-    int4 seen[2][kOrbs + kMobs + 2];  // per wavefront: the rectangles of the draws so far that are not points
 };
 
 // What every frame shows: the whole world (chaser.cpp:401), and the wall window of it (tilemap.cpp:245-254).
@@ -799,9 +809,15 @@ PG_D void render_env(const State& s, const AtlasView& atlas, const StepIO& io, i
     const uint8_t* tiles = s.tiles + size_t(env) * kTileStride;
     const DescRegs descs = DescRegs::load(atlas, lane);
     Blit mine;
-    for (int k = lane + 64 * half; k < n_draw; k += 64 * halves) {
-        const int e = EB(s, EB_DRAW, k, env);
-        S.ent[k] = static_cast<uint32_t>(e | (EB(s, EB_INFO, e, env) & kKindMask) << 8 | ent_cell(s, e, env) << 16);
+    uint32_t ent[kEntRegs];  // per draw-list place lane + 64·j: entity | kind << 8 | cell << 16
+#pragma unroll
+    for (int j = 0; j < kEntRegs; j++) {
+        const int k = lane + 64 * j;
+        ent[j] = 0u;
+        if (k < n_draw) {
+            const int e = EB(s, EB_DRAW, k, env);
+            ent[j] = static_cast<uint32_t>(e | (EB(s, EB_INFO, e, env) & kKindMask) << 8 | ent_cell(s, e, env) << 16);
+        }
     }
     if (half == 1 && lane < kMobs) {
         S.mob[lane][0] = MF(s, MF_X, lane, env);
@@ -833,9 +849,7 @@ PG_D void render_env(const State& s, const AtlasView& atlas, const StepIO& io, i
         // this wave's axis of the background (wave 0: x, wave 1: y); the tile spans are the prepared ones
         const BgAxis bga = bg_axis(cam, bg_d, bg_px, bg_py, bg_sc, half);
         if (half == 0 && lane < 2) L.base[kGrid * kGrid + lane] = static_cast<int32_t>(kNoTexel);
-#pragma unroll
-        for (int k = half; k < kGrid * kGrid / 64; k += halves) {
-            const int cell = k * 64 + lane;
+        for (int cell = lane + 64 * half; cell < kGrid * kGrid; cell += 64 * halves) {
             const int r = cell / kGrid, c = cell % kGrid;
             const bool wall = c < cols && r < rows && tile_at(tiles, x0 + c, H - 1 - (y0 + r)) == kWall;
             L.base[cell] = wall ? wall_d.x * 4 : static_cast<int32_t>(kNoTexel);
@@ -851,9 +865,10 @@ PG_D void render_env(const State& s, const AtlasView& atlas, const StepIO& io, i
             // walls and other points; relative to the sprites that are not points it does, and the sprite pass below
             // re-draws (idempotently: opaque texels) the points that follow such a sprite in the list and touch it.
             __syncthreads();  // the wall pass has written every cell
-            for (int k = lane + 64 * half; k < n_draw; k += 64 * halves) {
-                const uint32_t v = S.ent[k];
-                if (((v >> 8) & kKindMask) == kPoint) {
+#pragma unroll
+            for (int j = 0; j < kEntRegs; j++) {  // (wave j mod 2 takes register j's entries)
+                const uint32_t v = ent[j];
+                if ((j & 1) == half && lane + 64 * j < n_draw && ((v >> 8) & kKindMask) == kPoint) {
                     const int cell = static_cast<int>(v >> 16);
                     const int c = cell / H - x0, r = (H - 1 - cell % H) - y0;
                     if (c >= 0 && r >= 0 && c < cols && r < rows) LB.boxed[r * kGrid + c] = point_d.x * 4;
@@ -886,7 +901,8 @@ PG_D void render_env(const State& s, const AtlasView& atlas, const StepIO& io, i
     // that is not a point (orb, egg, enemy) touches them: those would otherwise end up on top of the point instead of
     // under it.  The rectangles of the non-point draws seen so far live in the dead cell table, one region per wave
     // (the waves run this pass independently, each on the rows it owns).
-    int4* const seen = S.seen[half];
+    int4* const seen = reinterpret_cast<int4*>(L.base) + half * (kOrbs + kMobs + 2);
+    static_assert(2 * (kOrbs + kMobs + 2) * 4 <= kGrid * kGrid, "scratch inside the cell table");
     int n_seen = 0;
     PG_MARK("s_sprites");
     const bool skip_points = composed && points_in_layer;
@@ -896,7 +912,9 @@ PG_D void render_env(const State& s, const AtlasView& atlas, const StepIO& io, i
         float x = 0.0f, y = 0.0f;
         bool has = false, is_point = false;
         if (k < n_draw) {
-            const uint32_t v = S.ent[k];
+            uint32_t v = ent[0];
+#pragma unroll
+            for (int j = 1; j < kEntRegs; j++) v = first == 64 * j ? ent[j] : v;
             const int e = static_cast<int>(v & 0xffu), kind = static_cast<int>((v >> 8) & kKindMask);
             has = true;
             if (kind == kEgg) {
@@ -975,7 +993,7 @@ __global__ void __launch_bounds__(128) prepare_kernel(State s, AtlasView atlas) 
     compose_prepare<kGrid>(fb, LB.plain, s.prepared, lane, half);
 }
 
-__global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
+__global__ void __launch_bounds__(128, PG_CHASER_RENDER_WAVES) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
                                                     int flags, int pass) {
     const int env = blockIdx.x;
     if (mask && !mask[env]) return;
@@ -995,7 +1013,7 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
 // few hundred of 65 536: a workgroup takes every gridDim.x-th of them), and the flags of everyone settled (3 → 1 for the
 // envs that ended an episode in this step, 2 → 0 for the ones just reset).  A full-size launch that exits at once for
 // all but the listed envs costs 30 µs in dispatch alone.
-__global__ void __launch_bounds__(128, 4) render_list_kernel(State s, AtlasView atlas, StepIO io, int flags) {
+__global__ void __launch_bounds__(128, PG_CHASER_RENDER_WAVES) render_list_kernel(State s, AtlasView atlas, StepIO io, int flags) {
     for (int e = blockIdx.x * 128 + threadIdx.x; e < s.n; e += gridDim.x * 128)
         if (io.pending[e] == 3) io.pending[e] = 1;
     if (blockIdx.x == 0 && threadIdx.x == 0) s.reset_count[1 - s.parity] = 0;
