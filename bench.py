@@ -205,7 +205,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # Under a launcher (WORLD_SIZE set) this is a rank of a process group even when it is the only one: the single-GPU
+    # box then runs the same init / barrier / all_reduce / gather code the 8-GPU node will (tests/test_a_nccl_single_rank.py).
+    distributed = "WORLD_SIZE" in os.environ
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

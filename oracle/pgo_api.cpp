@@ -209,6 +209,33 @@ void* pgo_vec_make_flags(const char* game, int n, uint32_t seed_base, int env_of
     return v;
 }
 
+// cenv_make alone — level 0 built and never observed (D1), NO first reset: what the cenv shim (pgo_cenv.cpp) needs, whose
+// caller's cenv_reset comes as a call of its own.  (pgo_vec_make = this + one reset of every env.)
+void* pgo_vec_make_only(const char* game, int n, uint32_t seed_base, int env_offset, int render_enabled) {
+    auto* v = new VecState();
+    v->game = game;
+    v->mode = 0;
+    v->flags = 0;
+    v->render = render_enabled;
+    v->num_levels = 0;
+    v->start_level = 0;
+    v->chain_seed.assign(n, 0);
+    v->drawn.assign(n, 0);
+    for (int i = 0; i < n; i++) {
+        const uint32_t seed = seed_base + static_cast<uint32_t>(env_offset + i);
+        Env* e = static_cast<Env*>(pgo_make_config(game, seed, render_enabled, 0, 0));
+        if (!e) {
+            for (Env* made : v->envs) delete made;
+            delete v;
+            return nullptr;
+        }
+        v->envs.push_back(e);
+        v->chain_seed[i] = seed;
+    }
+    v->pending_reset.assign(n, 0);
+    return v;
+}
+
 void pgo_vec_close(void* h);
 
 // The same with the envs made by `threads` threads (env objects are independent; the texture bank is only read): the
@@ -277,6 +304,21 @@ void pgo_vec_close(void* h) {
     auto* v = static_cast<VecState*>(h);
     for (Env* e : v->envs) delete e;
     delete v;
+}
+
+// The single-env cenv shim (pgo_cenv.cpp): the reference never resets on its own.
+void pgo_vec_clear_pending(void* h) {
+    auto* v = static_cast<VecState*>(h);
+    std::fill(v->pending_reset.begin(), v->pending_reset.end(), 0);
+}
+
+// Drawing on / off for every env of the batch from now on (Painter::enabled gates the pixel work only: game state, draw
+// lists and the camera evolve the same either way).  The full-size parity tests step with drawing off and switch it on
+// for the steps whose observations they compare.
+void pgo_vec_set_render(void* h, int on) {
+    auto* v = static_cast<VecState*>(h);
+    v->render = on;
+    for (Env* e : v->envs) e->set_render_enabled(on != 0);
 }
 
 void pgo_vec_reset_threads(void* h, int threads) {  // pgo_vec_reset(h, nullptr, nullptr) by `threads` threads

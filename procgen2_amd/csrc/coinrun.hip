@@ -32,6 +32,7 @@
 #include "pg_geom.h"
 #include "pg_order.h"
 #include "pg_prefetch.h"
+#include "pg_prepass.h"
 #include "pg_render.h"
 #include "pg_rng.h"
 
@@ -105,6 +106,7 @@ struct State {
                      //                                   couple of cache lines instead of one per value
     float* scratch;  // [SC_COUNT][n]                     hand-off between the three logic kernels of a step
     uint32_t no;     // generator switches turned off (PGV_COINRUN_NO_*: coinrun/tilemap.h:42-45 allow_* = false)
+    PrepOut prep;    // what setup_kernel leaves for render_kernel (pg_prepass.h); not part of the state blob
 };
 
 // scratch rows: the agent after each of the 4 sub-steps, then one word of flags
@@ -892,15 +894,14 @@ constexpr int kRenderWaves = 2;  // wavefronts per env (pg_render.h: two waves s
 // general form of the row composer still eight rows at a time it spilled 77 and was 7 % slower than at four.)
 #define PG_COINRUN_RENDER_WAVES 5
 #endif
-__global__ void __launch_bounds__(64 * kRenderWaves, PG_COINRUN_RENDER_WAVES) render_kernel(State s, AtlasView atlas, const uint8_t* mask,
-                                                                   StepIO io, int flags) {
-    const int env = blockIdx.x;
-    if (mask && !mask[env]) return;
+constexpr int kGrid = 16;  // 64 px / 4.8 px per tile = 13.3 tiles → at most 16 columns/rows in view
+
+// The complete frame of one env by its workgroup, set-up included: every frame before the pre-pass existed, and still
+// the frames the pre-pass marks fat, the draw-list replay (flags bit 0) and kDebugNoPrepass.
+PG_D void render_full(const State& s, const AtlasView& atlas, const StepIO& io, int flags, int env, uint32_t* fb,
+                      ComposeLds<kGrid>& L) {
     const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int halves = kRenderWaves;
-    __shared__ alignas(16) uint32_t fb[kFbWords];
-    constexpr int kGrid = 16;  // 64 px / 4.8 px per tile = 13.3 tiles → at most 15 columns/rows in view
-    __shared__ ComposeLds<kGrid> L;                 // the composer's cell table
     // The 64 resolved draws of the sprite pass, from wave 1 to wave 0, travel through the END of the frame target's
     // memory (the composer's set-up tables borrow its start): they are written before the frame is composed and taken
     // before its first pixel is (render 0.440 -> 0.435 ms against an array of their own: 1.5 KB less LDS per env).
@@ -1202,6 +1203,271 @@ __global__ void __launch_bounds__(64 * kRenderWaves, PG_COINRUN_RENDER_WAVES) re
     PG_MARK("o_store");
 }
 
+// ------------------------------------------------------------------------------------------------
+// The render pre-pass (pg_prepass.h): tile spans, per-pixel candidates, the cell table and the resolved, culled draws
+// of kPrepEnvs envs per workgroup, every phase with its lanes dealt densely over (env, thing).
+// Reference arithmetic moved here unchanged: renderer.cpp:5-82 (render_texture), tilemap.cpp:294-321 (the tile window),
+// common_systems.cpp:41-63,254-278,315-337 (sprites, agent, particles).
+// ------------------------------------------------------------------------------------------------
+constexpr int kPrepEnvs = 8, kPrepThreads = 256;
+constexpr int kSlotTop = 0, kSlotMid = 1, kSlotLavaTop = 2, kSlotLava = 3, kSlotCrate = 4;  // cell bytes: tile kinds
+
+struct PrepEnv {  // per env of the workgroup: what the draws' lanes need, loaded once
+    int32_t sflags, buf, n_ent, n_mob, n_sprites, alien;
+    float avx, aphase, ax, ay;
+};
+struct SetupLds {
+    PrepLds<kGrid, kPrepEnvs> P;
+    PrepEnv env[kPrepEnvs];
+    int32_t kind_soft[kPrepEnvs];  // bit k: tile kind k's texture has texels that are not opaque
+    int32_t counts[kPrepEnvs];
+};
+
+__global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView atlas, const uint8_t* mask) {
+    __shared__ SetupLds S;
+    PrepLds<kGrid, kPrepEnvs>& P = S.P;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int env0 = blockIdx.x * kPrepEnvs;
+    const PrepOut& out = s.prep;
+
+    // ---- per env: camera, tile window, background draw (render_full's preamble, one lane per env)
+    for (int q = tid; q < kPrepEnvs * 2 * 64; q += kPrepThreads) (&P.cover[0][0][0])[q] = 0u;
+    if (tid < kPrepEnvs) {
+        const int e = tid, env = env0 + e;
+        PrepView v{};
+        bool active = env < s.n && (!mask || mask[env]);
+        P.fat[e] = 0;
+        P.soft_rows[e] = P.hard_rows[e] = 0;
+        S.counts[e] = 0;
+        if (active && SCI(s, SC_REDO, env) != 0) {  // the step ended early: the entity table is not final (resolve_kernel)
+            P.fat[e] = 1;
+            active = false;
+        }
+        if (active) {
+            v.cam = Camera{SF(s, F_CAMX, env), SF(s, F_CAMY, env), 64.0f, 64.0f, 0.3f * 64.0f / 64.0f};
+            const Camera& cam = v.cam;
+            const int themes = SI(s, I_THEMES, env);
+            const int sflags = SI(s, I_FLAGS, env);
+            const int backdrop = themes & 0xff;
+            const int4 d = atlas.desc[kTexBackdrop + backdrop];
+            const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
+            const float extra = aspect - 1.0f;
+            v.bg = BgDraw{d, -SF(s, F_BGSHIFT, env) * extra, 0.0f, 64.0f * kUnitPx / d.z};  // coinrun.cpp:459-464
+            const float vx = (cam.px - cam.sw * 0.5f / cam.scale) * kPxUnit;               // tilemap.cpp:294-304
+            const float vy = (cam.py - cam.sh * 0.5f / cam.scale) * kPxUnit;
+            const float vw = cam.sw * kPxUnit / cam.scale, vh = cam.sh * kPxUnit / cam.scale;
+            v.x0 = static_cast<int>(floorf(vx));
+            v.y0 = static_cast<int>(floorf(vy));
+            v.cols = static_cast<int>(ceilf(vx + vw)) - v.x0 + 1;
+            v.rows = static_cast<int>(ceilf(vy + vh)) - v.y0 + 1;
+            const int4 tile_desc = atlas.desc[kTexMid];  // every tile texture is 128×128 (checked at make time)
+            v.tw = tile_desc.y;
+            v.th = tile_desc.z;
+            v.th2 = 0;
+            v.tile_scale = kUnitPx / tile_desc.y;
+            if (v.cols > kGrid || v.rows > kGrid) {
+                P.fat[e] = 1;
+                active = false;
+            }
+            P.soft_rows[e] = d.w != 0 ? 0x80000000u : 0u;   // 9 of the 49 backdrops have texels that are not opaque
+            P.hard_rows[e] = (d.w & 2) ? 0x80000000u : 0u;  // … mostly cut-out: no one-texel attempt
+            PrepEnv pe{};
+            pe.sflags = sflags;
+            pe.buf = (sflags & kFlagBuf) ? 1 : 0;
+            pe.n_ent = SI(s, I_NENT, env);
+            pe.n_mob = SI(s, I_NMOB, env);
+            pe.n_sprites = (sflags & kFlagListed) ? pe.n_ent : 0;  // the draw list is empty until the first update (D2)
+            pe.alien = (themes >> 8) & 0xff;
+            pe.avx = SF(s, F_AVX, env);
+            pe.aphase = SF(s, F_APHASE, env);
+            pe.ax = SF(s, F_AX, env);
+            pe.ay = SF(s, F_AY, env);
+            S.env[e] = pe;
+            S.kind_soft[e] = 0;
+        }
+        v.active = active ? 1 : 0;
+        P.view[e] = v;
+    }
+    __syncthreads();
+    // the tile kinds' textures: lane = (env, kind)
+    if (tid < kPrepEnvs * 8) {
+        const int e = tid >> 3, k = tid & 7;
+        if (P.view[e].active) {
+            const int ground_theme = (SI(s, I_THEMES, env0 + e) >> 16) & 0xff;
+            int tex = kTexCrate + (k - kSlotCrate);
+            if (k == kSlotTop) tex = kTexTop + ground_theme;
+            if (k == kSlotMid) tex = kTexMid + ground_theme;
+            if (k == kSlotLavaTop) tex = kTexLavaTop;
+            if (k == kSlotLava) tex = kTexLava;
+            const int4 d = atlas.desc[tex];
+            P.meta[e][PM_KINDS + k] = static_cast<uint32_t>(d.x) * 4u;
+            P.meta[e][PM_KINDS + 8 + k] = kNoTexel;
+            if (d.w != 0) atomicOr(&S.kind_soft[e], 1 << k);
+        }
+    }
+    prep_spans<kGrid, kMaxSpan, kPrepEnvs>(P, tid, kPrepThreads);
+    __syncthreads();
+
+    // ---- the cell table: lane = (env, grid row, four grid columns) → four kind bytes, one word
+    for (int q = tid; q < kPrepEnvs * kGrid * (kGrid / 4); q += kPrepThreads) {
+        const int e = q / (kGrid * kGrid / 4), w = q - e * (kGrid * kGrid / 4);
+        const PrepView& v = P.view[e];
+        if (!v.active) continue;
+        const int r = w / (kGrid / 4), c4 = (w - r * (kGrid / 4)) * 4;
+        const uint8_t* tiles = s.tiles + size_t(env0 + e) * (W * H);
+        const int ty = H - 1 - (v.y0 + r);
+        const int soft_kinds = S.kind_soft[e];
+        uint32_t word = 0;
+        bool soft = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int x = v.x0 + c4 + j;
+            int raw = kWallMid;  // out of bounds is a wall (tilemap.h:80-81)
+            if (x >= 0 && ty >= 0 && x < W && ty < H) raw = tiles[ty + x * H];
+            const int t = raw & 7;
+            const int slot = t < kCrate ? t - 1 : kSlotCrate + (raw >> 4);
+            word |= (t == kEmpty ? 0xffu : static_cast<uint32_t>(slot)) << (8 * j);
+            soft = soft || (t != kEmpty && ((soft_kinds >> slot) & 1) && r < v.rows && c4 + j < v.cols);
+        }
+        reinterpret_cast<uint32_t*>(out.cells)[size_t(env0 + e) * (kGrid * kGrid / 4) + w] = word;
+        if (soft) atomicOr(&P.soft_rows[e], 1u << r);
+    }
+    __syncthreads();
+    prep_axes<kGrid, kPrepEnvs>(P, out, env0, wave, kPrepThreads / 64, lane);
+
+    // ---- the draws, in the reference's order — particles (owners in the particle system's set order), the sprites of
+    // the draw list, the agent — resolved one per lane; those that survive the cull are numbered per env and stored.
+    // A wavefront takes two envs of the workgroup, their draws dealt densely over its passes.
+    static_assert(kPrepEnvs == 2 * (kPrepThreads / 64), "two envs per wavefront");
+    {
+        const int ea = 2 * wave, eb = 2 * wave + 1;
+        const bool on_a = P.view[ea].active != 0, on_b = P.view[eb].active != 0;
+        const int cnt_a = on_a ? S.env[ea].n_mob * kSparks + S.env[ea].n_sprites + 1 : 0;
+        const int cnt_b = on_b ? S.env[eb].n_mob * kSparks + S.env[eb].n_sprites + 1 : 0;
+        const int4 spark_d = atlas.desc[kTexSpark];
+        int done_a = 0, done_b = 0;
+        for (int base = 0; base < cnt_a + cnt_b; base += 64) {  // wave-uniform
+            const int q = base + lane;
+            const bool is_b = q >= cnt_a;
+            const int e = is_b ? eb : ea, env = env0 + e;
+            const int slot = is_b ? q - cnt_a : q;
+            const bool valid = q < cnt_a + cnt_b;
+            const PrepEnv& pe = S.env[e];
+            const Camera& cam = P.view[e].cam;
+            const int n_parts = pe.n_mob * kSparks;
+            bool go = false, flip = false;
+            int tw = 1, th = 1, tex_at = 0;
+            float wx = 0.0f, wy = 0.0f, scale_num = kUnitPx, alpha = 1.0f;
+            if (valid && slot < n_parts) {  // System_Particles::render (common_systems.cpp:315-337)
+                const int m = slot / kSparks, k = slot - m * kSparks;
+                const int ent = EB(s, EB_SPARK_ORDER, m, env);
+                const float life = SP(s, pe.buf, 2, ent, k, env);
+                if (life > 0.0f) {
+                    const float px = SP(s, pe.buf, 0, ent, k, env), py = SP(s, pe.buf, 1, ent, k, env);
+                    const float lr = (5.0f - life) / 5.0f;
+                    alpha = 0.5f * (1.0f - lr);
+                    const float scale = 0.45f * (0.4f * lr + 0.6f);
+                    const float oy = -lr * 0.17f;
+                    tw = spark_d.y;
+                    th = spark_d.z;
+                    tex_at = spark_d.x;
+                    wx = px * kUnitPx - 0.5f * spark_d.y * scale;
+                    wy = (py + oy) * kUnitPx - 0.5f * spark_d.z * scale;
+                    scale_num = scale * kUnitPx;
+                    go = true;
+                }
+            } else if (valid && slot < n_parts + pe.n_sprites) {  // System_Sprite_Render::render (:41-63)
+                const int ent = EB(s, EB_DRAW_ORDER, slot - n_parts, env);
+                const int dyn = DB(s, pe.buf, ent, env);
+                if (dyn & kDynTexSet) {
+                    const int4 d = atlas.desc[EB(s, EB_TEX, ent, env) + ((dyn & kDynFrame) ? 1 : 0)];
+                    tw = d.y;
+                    th = d.z;
+                    tex_at = d.x;
+                    const float scale = 1.0f * 1.0f;
+                    wx = (DF(s, pe.buf, DF_X, ent, env) + -0.5f) * kUnitPx;
+                    wy = (EY(s, ent, env) + -0.5f) * kUnitPx;
+                    scale_num = scale * kUnitPx;
+                    flip = (dyn & kDynFlip) != 0;
+                    go = true;
+                }
+            } else if (valid) {  // the agent (:254-278)
+                const bool ground = (pe.sflags & kFlagGround) != 0;
+                int tex;
+                if (fabsf(pe.avx) < 0.01f && ground)
+                    tex = kTexStand + pe.alien;
+                else if (!ground)
+                    tex = kTexJump + pe.alien;
+                else if (pe.aphase > 0.5f)
+                    tex = kTexWalk2 + pe.alien;
+                else
+                    tex = kTexWalk1 + pe.alien;
+                const int4 d = atlas.desc[tex];
+                tw = d.y;
+                th = d.z;
+                tex_at = d.x;
+                wx = (pe.ax - 0.5f) * kUnitPx;
+                wy = (pe.ay - 2.0f) * kUnitPx;
+                flip = (pe.sflags & kFlagForward) == 0;
+                go = true;
+            }
+            Blit mine;
+            const bool has = go && resolve_draw(cam, tw, th, tex_at, wx, wy, scale_num / static_cast<float>(tw), alpha, flip, false, mine);
+            const unsigned long long m_a = __ballot(has && !is_b), m_b = __ballot(has && is_b);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const int rank = is_b ? done_b + __popcll(m_b & below) : done_a + __popcll(m_a & below);
+            if (has && rank < kPrepDraws) prep_draw_store(out.draws + (size_t(env) * kPrepDraws + rank) * kBlitWords, mine);
+            done_a += __popcll(m_a);
+            done_b += __popcll(m_b);
+        }
+        if (lane == 0) {
+            S.counts[ea] = done_a;
+            S.counts[eb] = done_b;
+        }
+    }
+    __syncthreads();
+    prep_meta_out<kGrid, kPrepEnvs>(P, out, env0, S.counts, tid, kPrepThreads);
+}
+
+// render_game(true) (coinrun.cpp:443-470): one workgroup of two wavefronts per env.  A lean frame starts from what
+// setup_kernel left: one word per pixel column and row, the cell table as kind bytes, its visible draws resolved.
+__global__ void __launch_bounds__(64 * kRenderWaves, PG_COINRUN_RENDER_WAVES) render_kernel(State s, AtlasView atlas, const uint8_t* mask,
+                                                                   StepIO io, int flags) {
+    const int env = blockIdx.x;
+    if (mask && !mask[env]) return;
+    const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int halves = kRenderWaves;
+    __shared__ alignas(16) uint32_t fb[kFbWords];
+    __shared__ ComposeLds<kGrid> L;  // the composer's cell table
+    const PrepMeta M{s.prep.meta + size_t(env) * kPrepMetaWords};
+    if ((flags & (1 | kDebugNoPrepass)) || M.fat()) {  // (wave-uniform)
+        render_full(s, atlas, io, flags, env, fb, L);
+        return;
+    }
+    // one round trip: the packed axes, the kind offsets, this wave's half of the cell bytes, my draw
+    const uint32_t colw = s.prep.axes[size_t(env) * 128 + lane], roww = s.prep.axes[size_t(env) * 128 + 64 + lane];
+    const uint32_t kind_off = M.w[PM_KINDS + (lane & (kPrepKinds - 1))];
+    const uint32_t two = reinterpret_cast<const uint16_t*>(s.prep.cells)[size_t(env) * (kGrid * kGrid / 2) + half * 64 + lane];
+    const int n_draws = M.draws();
+    const bool has = lane < n_draws;
+    const Blit mine = prep_draw_load(s.prep.draws + (size_t(env) * kPrepDraws + lane) * kBlitWords, has);
+    {   // kind bytes → byte offsets of the kinds' textures (0xff: no tile)
+        const uint32_t k0 = two & 0xffu, k1 = two >> 8;
+        const uint32_t o0 = __shfl(kind_off, static_cast<int>(k0 & (kPrepKinds - 1)));
+        const uint32_t o1 = __shfl(kind_off, static_cast<int>(k1 & (kPrepKinds - 1)));
+        reinterpret_cast<uint2*>(L.base)[half * 64 + lane] = make_uint2(k0 == 0xffu ? kNoTexel : o0, k1 == 0xffu ? kNoTexel : o1);
+        if (threadIdx.x == 0) L.base[kGrid * kGrid] = L.base[kGrid * kGrid + 1] = static_cast<int32_t>(kNoTexel);
+    }
+    const ComposeRegs R = prep_regs<kGrid>(M, colw, roww, 0u, lane);
+    __syncthreads();  // the cell table is complete
+    const int row_lo = half * (kObsH / halves), row_hi = (half + 1) * (kObsH / halves);
+    // (the PG_ABL tests are timing experiments of the -DPG_ABLATE build: constants 0 in the product)
+    ReplayState<4> sprite_pass = replay_begin(atlas, mine, PG_ABL(flags, 2) ? 0ull : __ballot(has), lane, row_lo, row_hi);
+    if (!PG_ABL(flags, 4)) compose_rows_from<kGrid, false, false>(fb, L, atlas, R, lane, flags, half, halves);
+    replay_finish(fb, atlas, mine, sprite_pass, lane, row_lo, row_hi);
+    if (!PG_ABL(flags, 8)) wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, row_lo, row_hi);
+}
+
 // cenv_render's frame (coinrun.cpp:393-411 → render_game(false), :443-470) for one env: pg_frame.h.
 __global__ void __launch_bounds__(kFrameThreads) frame_kernel(State s, AtlasView atlas, int env, FrameTarget t) {
     FramePainter P{t, atlas,
@@ -1411,9 +1677,13 @@ class CoinrunGame final : public Game {
         return true;
     }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
+        if (!(debug_flags & (1 | kDebugNoPrepass)) && !PG_ABL(debug_flags, 1 << 22))  // (experiment: the last frame's pre-pass again)
+            hipLaunchKernelGGL(setup_kernel, dim3((s_.n + kPrepEnvs - 1) / kPrepEnvs), dim3(kPrepThreads), 0, st, s_, atlas_, mask);
         hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(64 * kRenderWaves), 0, st, s_, atlas_, mask, io,
                            debug_flags);
     }
+    size_t scratch_bytes(int n) const override { return prep_bytes(n, kGrid, kBlitWords, false); }
+    void bind_scratch(void* d_scratch, int n) override { s_.prep = prep_bind(d_scratch, n, kGrid, kBlitWords, false); }
 
     // Same layout as oracle/pgo_coinrun.cpp Coinrun::dump_state.
     int dump_state(hipStream_t st, int env, float* out, int cap) override {

@@ -173,6 +173,7 @@ struct pgv_env {
     std::unique_ptr<pg::Game> game;
     pg::Atlas atlas;
     void* d_state = nullptr;
+    void* d_scratch = nullptr;  // Game::scratch_bytes: per-frame hand-over between a game's kernels, not part of any snapshot
     uint8_t* d_obs = nullptr;
     float* d_reward = nullptr;
     uint8_t* d_done = nullptr;
@@ -246,6 +247,7 @@ void pgv_close(pgv_env* e) {
     if (e->reset_fork) hipEventDestroy(e->reset_fork);
     if (e->reset_join) hipEventDestroy(e->reset_join);
     if (e->d_state) hipFree(e->d_state);
+    if (e->d_scratch) hipFree(e->d_scratch);
     if (e->own_obs && e->d_obs) hipFree(e->d_obs);
     if (e->own_reward && e->d_reward) hipFree(e->d_reward);
     if (e->own_done && e->d_done) hipFree(e->d_done);
@@ -364,6 +366,11 @@ int32_t pgv_make_config(const pgv_config* cfg, pgv_env** out) {
     PG_HIP(hipMemsetAsync(e->d_pending, 0, size_t(num_envs), e->stream));
 
     e->game->bind(e->d_state, num_envs, e->atlas.view());
+    if (const size_t scratch = e->game->scratch_bytes(num_envs)) {
+        PG_HIP(hipMalloc(&e->d_scratch, scratch));
+        PG_HIP(hipMemsetAsync(e->d_scratch, 0, scratch, e->stream));
+        e->game->bind_scratch(e->d_scratch, num_envs);
+    }
     {
         uint32_t* words = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(e->d_state) + game_state_bytes(e.get()));
         e->game->plan = pg::LevelPlan{num_levels, start_level, words, words + num_envs};
@@ -720,8 +727,8 @@ int32_t pgv_render_frame(pgv_env* e, int32_t index, int32_t width, int32_t heigh
 int32_t pgv_set_debug(pgv_env* e, int32_t flags) {
     if (!e) return fail("pgv_set_debug: env is NULL");
 #ifndef PG_ABLATE
-    if (flags & ~(1 | pg::kDebugNoPrefetch))
-        return fail("pgv_set_debug: only bit 0 (draw-list replay) and bit 8 (no level prefetch) exist in this build");
+    if (flags & ~(1 | pg::kDebugNoPrefetch | pg::kDebugNoPrepass))
+        return fail("pgv_set_debug: only bit 0 (draw-list replay), bit 8 (no level prefetch) and bit 21 (no render pre-pass) exist in this build");
 #endif
     if (e->side) hipStreamSynchronize(e->side);
     e->game->debug_flags = flags;

@@ -129,13 +129,20 @@ class Game {
     virtual void launch_render_step(hipStream_t s, StepIO io) { launch_render(s, nullptr, io); }
     virtual bool launch_render_late(hipStream_t s, StepIO io) { return false; }
 
+    // Device memory a game's kernels hand results to each other through within one frame (the render pre-pass,
+    // pg_prepass.h): allocated by the engine beside the state, never part of a snapshot.
+    virtual size_t scratch_bytes(int n) const { (void)n; return 0; }
+    virtual void bind_scratch(void* d_scratch, int n) { (void)d_scratch; (void)n; }
+
     // Bit 0: render background + tiles by draw-list replay instead of the row composer (fallback path).
     // Bit 8: no level prefetch — every reset generates its level synchronously inside the step.
+    // Bit 21: no render pre-pass — every frame's workgroup does its own set-up (the complete path; pg_prepass.h).
     int debug_flags = 0;
     LevelPlan plan{0, 0, nullptr, nullptr};  // set by the engine after bind()
 };
 
 constexpr int kDebugNoPrefetch = 1 << 8;
+constexpr int kDebugNoPrepass = 1 << 21;  // (clear of the -DPG_ABLATE experiment bits the games use)
 
 // Lanes per workgroup of the lane-per-env logic kernels: fewer envs per wave = more waves.
 int logic_lanes();

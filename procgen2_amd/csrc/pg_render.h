@@ -1133,6 +1133,19 @@ PG_D void compose_prepare(uint32_t* fb, const ComposeLds<GRID>& L, ComposeHand* 
     for (int k = lane + 64 * half; k < static_cast<int>(sizeof(ComposeHand) / 4); k += 128) dst[k] = src[k];
 }
 
+// What the row loop works from: per lane (= pixel column, and — read across lanes — pixel row) the offsets of its
+// candidates, and the three row-class masks (bit py = pixel row py).
+struct ComposeRegs {
+    uint32_t bg_col, col_a, col_b, cia4;     // as pixel column: background column offset, column offsets a / b, 4 × cell column a
+    uint32_t bg_row, row_a, row_b, cells_a;  // as pixel row: background row offset, row offsets a / b, byte offset of grid row a's cells
+    uint32_t row_a2, row_b2;                 // TWO: row offsets in the layer's second texture; BOX: in the boxed texture
+    uint32_t col_pa, col_pb;                 // BOX: column offsets in the boxed texture
+    unsigned long long second_row, soft, hard;
+};
+template <int GRID, bool TWO, bool BOX>
+PG_D bool compose_rows_from(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView& atlas, const ComposeRegs& R, int lane,
+                            int ablate, int half, int halves);
+
 template <int GRID, bool TWO = false, bool BOX = false, bool PREP = false>
 PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView& atlas, const BgAxis& bga, int cols, int rows,
                        int tw, int lane, int ablate, int half, int halves, int4 box = make_int4(0, -1, 0, -1),
@@ -1140,14 +1153,6 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
     static_assert(!(TWO && BOX), "the two per-cell row tables share their hand-over slot");
     if (!PREP && (L.too_wide[0] | L.too_wide[1])) return false;
     ComposeHand& H = compose_hand<GRID>(fb);
-    // All texel reads go through one buffer descriptor over the atlas: 32-bit byte offsets, and out-of-range
-    // (= "no candidate") reads return 0 without a branch.
-    // (`ablate` bits 5/6 are timing experiments: a descriptor with zero records drops every load through it.)
-    const __amdgpu_buffer_rsrc_t bg_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint32_t*>(atlas.texels), 0, PG_ABL(ablate, 32) ? 0 : static_cast<int>(atlas.texel_bytes), 0x00020000);
-    const __amdgpu_buffer_rsrc_t atlas_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint32_t*>(atlas.texels), 0, PG_ABL(ablate, 64) ? 0 : static_cast<int>(atlas.texel_bytes), 0x00020000);
-
     if (PREP) {  // the tables are there (prepared): only the background's share is worked out, and traded as usual
         if (half == 0)
             H.col[lane].x = bg_offset(bga, lane, 0);
@@ -1165,32 +1170,54 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
         hc.x = H.col[lane].x;
         hr.x = H.row[lane].x;
     }
-    const uint32_t bg_col = hc.x, col_a = hc.y, col_b = hc.z, cia4 = hc.w;
-    const uint32_t bg_row = hr.x, row_a = hr.y, row_b = hr.z, cells_a = hr.w;
-    uint32_t row_a2 = 0, row_b2 = 0;
-    uint32_t col_pa = 0, col_pb = 0;
+    ComposeRegs R;
+    R.bg_col = hc.x, R.col_a = hc.y, R.col_b = hc.z, R.cia4 = hc.w;
+    R.bg_row = hr.x, R.row_a = hr.y, R.row_b = hr.z, R.cells_a = hr.w;
+    R.row_a2 = R.row_b2 = R.col_pa = R.col_pb = 0;
     if (TWO || BOX) {
         const uint2 h2 = K.row2[lane];
-        row_a2 = h2.x;
-        row_b2 = h2.y;
+        R.row_a2 = h2.x;
+        R.row_b2 = h2.y;
     }
     if (BOX) {
         const uint2 h2 = K.col2[lane];
-        col_pa = h2.x;
-        col_pb = h2.y;
+        R.col_pa = h2.x;
+        R.col_pb = h2.y;
     }
-    // byte distance from a cell of L.base to the same cell of the boxed table
-    constexpr uint32_t kBoxed = BOX ? static_cast<uint32_t>(sizeof(ComposeLds<GRID>)) : 0u;
-    static_assert(!BOX || __builtin_offsetof(ComposeLdsBoxed<GRID>, boxed) == sizeof(ComposeLds<GRID>), "boxed table right behind");
     auto mask64 = [&](int k) {
         return static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(K.masks[2 * k])) |
                (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(K.masks[2 * k + 1])) << 32);
     };
-    const unsigned long long second_row = mask64(0);
-    const unsigned long long soft = PREP && bg_w != 0 ? ~0ull : mask64(1), hard = PREP && (bg_w & 2) ? ~0ull : mask64(2);
-    constexpr int bg_mod = 255;  // (see BgAxis)
+    R.second_row = mask64(0);
+    R.soft = PREP && bg_w != 0 ? ~0ull : mask64(1);
+    R.hard = PREP && (bg_w & 2) ? ~0ull : mask64(2);
     __syncthreads();  // everybody has read the set-up tables out of the frame target's memory: it may be written now
     PG_MARK("h_handread");
+    return compose_rows_from<GRID, TWO, BOX>(fb, L, atlas, R, lane, ablate, half, halves);
+}
+
+// The row loop itself, from the per-lane values and row masks of ComposeRegs — however the caller came by them: out of the
+// hand-over tables the two waves have just built in the frame target's memory (compose_rows above), or unpacked from what
+// a pre-pass kernel left in device memory (pg_prepass.h).  The cell table L.base must be complete and visible (a barrier
+// behind its staging is the caller's); nothing else of L is read.
+template <int GRID, bool TWO, bool BOX>
+PG_D bool compose_rows_from(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView& atlas, const ComposeRegs& R, int lane,
+                            int ablate, int half, int halves) {
+    // All texel reads go through one buffer descriptor over the atlas: 32-bit byte offsets, and out-of-range
+    // (= "no candidate") reads return 0 without a branch.
+    // (`ablate` bits 5/6 are timing experiments: a descriptor with zero records drops every load through it.)
+    const __amdgpu_buffer_rsrc_t bg_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t*>(atlas.texels), 0, PG_ABL(ablate, 32) ? 0 : static_cast<int>(atlas.texel_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t atlas_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t*>(atlas.texels), 0, PG_ABL(ablate, 64) ? 0 : static_cast<int>(atlas.texel_bytes), 0x00020000);
+    const uint32_t bg_col = R.bg_col, col_a = R.col_a, col_b = R.col_b, cia4 = R.cia4;
+    const uint32_t bg_row = R.bg_row, row_a = R.row_a, row_b = R.row_b, cells_a = R.cells_a;
+    const uint32_t row_a2 = R.row_a2, row_b2 = R.row_b2, col_pa = R.col_pa, col_pb = R.col_pb;
+    // byte distance from a cell of L.base to the same cell of the boxed table
+    constexpr uint32_t kBoxed = BOX ? static_cast<uint32_t>(sizeof(ComposeLds<GRID>)) : 0u;
+    static_assert(!BOX || __builtin_offsetof(ComposeLdsBoxed<GRID>, boxed) == sizeof(ComposeLds<GRID>), "boxed table right behind");
+    const unsigned long long second_row = R.second_row, soft = R.soft, hard = R.hard;
+    constexpr int bg_mod = 255;  // (see BgAxis)
 
     // Rows in batches: every texel gather of a batch is issued before any pixel is produced, so a batch costs one
     // memory round trip.  Candidates in draw order: background, (row a, col a), (row a, col b), then — on the rows

@@ -140,6 +140,7 @@ class GymVectorAdapter(_VectorBase):
          self.action_space) = make_spaces(self.num_envs)
         self.render_mode = render_mode
         self.closed = False
+        self._final_buf = None  # SAME_STEP, torch output: the env-indexed terminal frames (see step)
         self.metadata = dict(self.metadata, autoreset_mode=autoreset_mode)
         if _gym is not None:
             try:
@@ -193,8 +194,14 @@ class GymVectorAdapter(_VectorBase):
         if self.autoreset_mode == "same_step" and bool(terminated.any()):
             # SAME_STEP: keep the terminal frames, then reset exactly the envs that ended (streams continue), which
             # also takes them off the engine's own next-step reset.  reward / terminated stay the terminal step's.
-            # info["final_obs"]: the terminal observations of the envs that ended, [k, 64, 64, 3] in env order;
-            # info["final_obs_env"]: their indices; info["_final_obs"]: the mask over all envs (Gymnasium's key).
+            # Gymnasium's layout — both keys are indexed by ENV:
+            #   info["_final_obs"]  bool [num_envs]: which envs ended;
+            #   info["final_obs"]   numpy output: object array [num_envs], the env's terminal frame or None;
+            #                       torch output: uint8 [num_envs, 64, 64, 3] on the device, valid where _final_obs is
+            #                       true (one persistent buffer: only the k ended rows are copied each step; the other
+            #                       rows hold whatever an earlier episode left there).
+            # Beside them, for callers that want the batch of terminal frames without the holes:
+            #   info["final_obs_compact"] [k, 64, 64, 3] in env order, info["final_obs_env"] [k] their indices.
             if hasattr(terminated, "nonzero") and not isinstance(terminated, np.ndarray):  # torch
                 mask, rew = terminated.clone(), reward.clone()
                 where = mask.nonzero().flatten()
@@ -203,9 +210,20 @@ class GymVectorAdapter(_VectorBase):
                 mask, rew = np.array(terminated, dtype=bool), np.array(reward)
                 where = np.nonzero(mask)[0]
                 final = np.array(obs[where])
+            if self.output == "numpy":
+                final_np, where_np = self._out(final), self._out(where)
+                by_env = np.full(self.num_envs, None, dtype=object)
+                for k, e in enumerate(where_np):
+                    by_env[int(e)] = final_np[k]
+            else:
+                if self._final_buf is None or self._final_buf.shape != obs.shape:
+                    self._final_buf = obs.new_zeros(obs.shape) if hasattr(obs, "new_zeros") else np.zeros_like(obs)
+                self._final_buf[where] = final
+                by_env = self._final_buf
             obs = self.engine.reset(mask=mask, seeds=None)  # (clears reward and done of those envs in the engine)
             reward, terminated = rew, mask
-            info = {"final_obs": self._out(final), "final_obs_env": self._out(where), "_final_obs": self._out(mask, bool)}
+            info = {"final_obs": by_env, "_final_obs": self._out(mask, bool), "final_obs_compact": self._out(final),
+                    "final_obs_env": self._out(where)}
         return self._out(obs), self._out(reward), self._out(terminated, bool), truncated, info
 
     def render(self, index=0):

@@ -243,8 +243,10 @@ class RootGather:
             if slabs is not None:
                 self.slabs = tuple(slabs)
                 for t, slab in zip(self.tensors, self.slabs):
-                    if tuple(slab.shape) != (total,) + tuple(t.shape[1:]) or slab.dtype != t.dtype or not slab.is_contiguous():
-                        raise ValueError("RootGather: a slab does not match [%d, ...] of its tensor" % total)
+                    if (tuple(slab.shape) != (total,) + tuple(t.shape[1:]) or slab.dtype != t.dtype or slab.device != t.device
+                            or not slab.is_contiguous()):
+                        raise ValueError("RootGather: a slab does not match [%d, ...] of its tensor (shape, dtype, device, "
+                                         "contiguity)" % total)
             else:
                 self.slabs = tuple(torch.empty((total,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
                                    for t in self.tensors)

@@ -86,6 +86,7 @@ def oracle():
     L.pgo_present.argtypes = [c_void_p]
     L.pgo_vec_reset.argtypes = [c_void_p, c_void_p, c_void_p]
     L.pgo_vec_close.argtypes = [c_void_p]
+    L.pgo_vec_set_render.argtypes = [c_void_p, c_int]
     L.pgo_vec_step.argtypes = [c_void_p, c_void_p, c_uint32, c_int, c_int, c_void_p, c_void_p, c_void_p]
     L.pgo_vec_obs.argtypes = [c_void_p, c_void_p]
     L.pgo_vec_dump_state.argtypes = [c_void_p, c_int, POINTER(c_float), c_int]
@@ -166,6 +167,10 @@ class OracleVec:
         self.L.pgo_vec_step(self.h, a, run_seed, self.env_offset, threads, self.obs.ctypes.data_as(c_void_p),
                             self.reward.ctypes.data_as(c_void_p), self.done.ctypes.data_as(c_void_p))
         return self.obs, self.reward, self.done
+
+    def set_render(self, on):
+        """Drawing on / off from the next step on (logic is unaffected; obs is only meaningful for steps drawn)."""
+        self.L.pgo_vec_set_render(self.h, 1 if on else 0)
 
     def state(self, env, cap=512):
         buf = (c_float * cap)()

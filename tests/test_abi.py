@@ -171,3 +171,53 @@ def test_hardware_queue_default_is_set_by_library_and_package_unless_chosen():
             out = subprocess.run([sys.executable, "-c", prog, mode], env=env, capture_output=True, text=True, timeout=120)
             assert out.returncode == 0, out.stderr
             assert out.stdout.strip() == want, (mode, chosen, out.stdout, out.stderr)
+
+
+def test_configs0_maze_64_envs_on_the_cpu_engine_through_the_cenv_abi(oracle_lib):
+    """BASELINE.json configs[0] to the letter: "maze, 64 envs, CPU reference engine via cenv (plumbing, no GPU)".
+    The CPU restatement behind the reference's own ABI (oracle/pgo_cenv.cpp → oracle/libpgoracle_cenv.so: cenv_make /
+    cenv_reset / cenv_step / cenv_render / cenv_close and the four data symbols, cenv/cenv.h:122-133), driven by the
+    same wrapper class that drives the HIP engine's libMaze.so (procgen2_amd/cenv.py ≙ cenv/cenv.py:152-380), for 520
+    steps: every env runs into maze's 500-step cap (maze.cpp:308-310, D5) and is reset on the next step.  What travels
+    through the ABI must be what the oracle's own vector API hands out for the same seeds and actions, and the first
+    levels are those of the reference's maze generator compiled as-is (tests/golden/ref_fixtures.json holds that pin
+    for the oracle; here only the plumbing is new)."""
+    from oracle_util import OracleVec, register_textures
+    path = os.path.join(ROOT, "oracle", "libpgoracle_cenv.so")
+    assert os.path.exists(path), "make -C oracle builds it"
+    register_textures("maze")  # (libpgoracle_cenv.so links libpgoracle.so: one texture bank in the process)
+    L = ctypes.CDLL(path)
+    for name in ("cenv_get_env_version", "cenv_make", "cenv_reset", "cenv_step", "cenv_render", "cenv_close"):
+        assert hasattr(L, name), name
+    for data, typ in (("make_data", pgcenv.MakeData), ("reset_data", pgcenv.ResetData), ("step_data", pgcenv.StepData),
+                      ("render_data", pgcenv.RenderData)):
+        typ.in_dll(L, data)
+    n = 64
+    env = pgcenv.CEnv(path, options={"seed": 1, "num_envs": n})
+    assert env.version() == 100
+    assert list(env.observation_space) == ["screen"] and list(env.action_space) == ["action"]
+    ora = OracleVec("maze", n, seed_base=1)
+    obs, info = env.reset()
+    assert info == {} and obs["screen"].dtype == np.uint8 and obs["screen"].size == n * 12288
+    assert np.array_equal(obs["screen"].reshape(n, 12288), ora.reset_obs())
+    ended = np.zeros(n, bool)
+    ends = 0
+    for s in range(520):
+        a = np.array([oracle_lib.pgo_synthetic_action(0, s, e) for e in range(n)], np.int32)
+        obs, rew, term, trunc, _ = env.step({"action": a})
+        oo, ro, do = ora.step(a)
+        assert np.array_equal(obs["screen"].reshape(n, 12288), oo), s
+        assert np.array_equal(obs["reward"], ro) and np.array_equal(obs["terminated"], do), s
+        assert trunc is False and term == bool(do.all()) and abs(rew - float(ro.mean())) < 1e-6
+        ended |= do.astype(bool)
+        ends += int(do.sum())
+    assert ended.all() and ends >= n, "every env reaches the 500-step cap"
+    frame = env.render()
+    assert frame.shape == (512, 512, 3) and np.array_equal(frame[::8, ::8].reshape(-1), oo[0])
+    env.close()
+    ora.close()
+    # one env: the reference's own semantics — no auto-reset, the caller resets (game_test.py:36-40)
+    one = pgcenv.CEnv(path, options={"seed": 5})
+    obs, _ = one.reset()
+    assert list(obs) == ["screen"] and obs["screen"].shape == (12288,)
+    one.close()

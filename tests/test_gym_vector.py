@@ -126,9 +126,18 @@ def test_same_step_autoreset_walks_the_same_episodes_as_next_step():
     for s in range(200):
         obs, rew, term, trunc, info = same.step(actions[s])
         if term.any():
-            assert set(info) == {"final_obs", "final_obs_env", "_final_obs"}
+            assert set(info) == {"final_obs", "_final_obs", "final_obs_compact", "final_obs_env"}
             assert np.array_equal(info["final_obs_env"], np.nonzero(term)[0]) and np.array_equal(info["_final_obs"], term)
-            assert info["final_obs"].shape == (int(term.sum()), 64, 64, 3)
+            assert info["final_obs_compact"].shape == (int(term.sum()), 64, 64, 3)
+            # Gymnasium's layout: indexed by ENV — an object array with None for the envs that go on
+            assert info["final_obs"].shape == (n,) and info["final_obs"].dtype == object
+            for e in range(n):
+                if info["_final_obs"][e]:
+                    k = int(np.searchsorted(info["final_obs_env"], e))
+                    assert info["final_obs"][e].shape == (64, 64, 3)
+                    assert np.array_equal(info["final_obs"][e], info["final_obs_compact"][k])
+                else:
+                    assert info["final_obs"][e] is None
             ends += int(term.sum())
         else:
             assert info == {}
@@ -173,8 +182,13 @@ def test_same_step_autoreset_on_the_hip_engine_matches_the_oracle_engine():
         assert np.array_equal(rg.cpu().numpy(), rc) and np.array_equal(tg.cpu().numpy(), tc)
         assert set(ig) == set(ic)
         if ic:
-            assert np.array_equal(ig["final_obs"].cpu().numpy(), ic["final_obs"])
+            assert np.array_equal(ig["final_obs_compact"].cpu().numpy(), ic["final_obs_compact"])
             assert np.array_equal(ig["final_obs_env"].cpu().numpy(), ic["final_obs_env"])
+            # indexed by env id, as code written against Gymnasium reads it: infos["final_obs"][i] where infos["_final_obs"][i]
+            assert tuple(ig["final_obs"].shape) == (n, 64, 64, 3) and ig["final_obs"].is_cuda
+            for e in np.nonzero(ic["_final_obs"])[0]:
+                assert bool(ig["_final_obs"][e])
+                assert np.array_equal(ig["final_obs"][e].cpu().numpy(), ic["final_obs"][e]), (s, e)
             ends += len(ic["final_obs_env"])
     assert ends > 10
     gpu.close()

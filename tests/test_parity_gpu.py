@@ -490,11 +490,13 @@ def test_shard_invariance_and_determinism_at_full_size(game, n, steps):
         L.pgo_close(h)
 
 
-def _every_env_against_the_oracle(game, n, steps, env_offset=0, chunk=16384, eng=None):
+def _every_env_against_the_oracle(game, n, steps, env_offset=0, chunk=16384, eng=None, return_dones=False):
     """Every env of an engine batch against the oracle: rewards and dones of every step, every observation byte of the
     reset frame, of the middle step and of the last one.  The engine runs first (device-generated actions); the oracle
     then replays the envs in chunks of `chunk` (seeds and the action hash depend on the global index only) with all
-    host threads, so its memory stays bounded whatever n is."""
+    host threads, so its memory stays bounded whatever n is.  The oracle draws only the frames that are compared
+    (OracleVec.set_render: drawing does not feed back into the game), which is what makes hundreds of steps of 65 536
+    envs affordable on the host."""
     own = eng is None
     if own:
         eng = EngineVec(game, n, seed_base=1, env_offset=env_offset)
@@ -515,6 +517,7 @@ def _every_env_against_the_oracle(game, n, steps, env_offset=0, chunk=16384, eng
         ora = OracleVec(game, hi - lo, seed_base=1, env_offset=env_offset + lo, threads=threads)
         assert np.array_equal(ora.reset_obs(), checkpoints[-1][lo:hi]), (game, "reset frame", lo)  # (made = reset once)
         for s in range(steps):
+            ora.set_render(s in checkpoints)
             oo, ro, do = ora.step(None, run_seed=0, threads=threads)
             assert np.array_equal(do, dones[s, lo:hi]), (game, "done", s, lo)
             assert np.array_equal(ro.view(np.uint32), rewards[s, lo:hi].view(np.uint32)), (game, "reward bits", s, lo)
@@ -523,17 +526,27 @@ def _every_env_against_the_oracle(game, n, steps, env_offset=0, chunk=16384, eng
                 raise AssertionError("%s: obs differ at step %d in %d envs (first: global env %d)" %
                                      (game, s, bad.size, env_offset + lo + bad[0]))
         ora.close()
-    return int(dones.sum())
+    return dones if return_dones else int(dones.sum())
 
 
-@pytest.mark.parametrize("game,n,steps", [("coinrun", 65536, 48), ("bossfight", 65536, 100), ("caveflyer", 32768, 48)])
+@pytest.mark.parametrize("game,n,steps", [("coinrun", 65536, 48), ("bossfight", 65536, 100), ("caveflyer", 32768, 48),
+                                          ("chaser", 65536, 400), ("jumper", 65536, 96), ("climber", 65536, 96),
+                                          ("maze", 65536, 520)])
 def test_every_env_at_full_size_matches_the_oracle(game, n, steps):
     """BASELINE.json configs[1..3] at their full sizes, EVERY env (a strided sample cannot see a bug that needs a
     particular env index mod something, LDS slot or XCD to show): 65 536 coinrun, 65 536 bossfight (long enough for
-    thousands of episodes to end and draw their next level inside the step), 32 768 caveflyer envs."""
-    ends = _every_env_against_the_oracle(game, n, steps)
+    thousands of episodes to end and draw their next level inside the step), 32 768 caveflyer envs — and the other four
+    games at 65 536: chaser long enough that tens of thousands of episodes end inside the window (its levels are
+    generated on a side stream beside the step's logic and render kernels, the reset envs drawn by a late pass behind a
+    flag protocol: the one place a race was found once), maze through its 500-step cap in every env."""
+    dones = _every_env_against_the_oracle(game, n, steps, return_dones=True)
+    ends = int(dones.sum())
     if game == "bossfight":
         assert ends > 1000, ends
+    if game == "chaser":
+        assert ends >= 10000, ends  # the side-stream generator and the late render pass were exercised
+    if game == "maze":
+        assert bool(dones.any(axis=0).all()), "every maze env ends by step 500 (maze.cpp:308-310)"
 
 
 def test_vec_env_torch_zero_copy_matches_c_abi():
@@ -850,3 +863,139 @@ def _oracle_state(L, h, cap):
     buf = (ctypes.c_float * cap)()
     m = L.pgo_dump_state(h, buf, cap)
     return np.array(buf[:min(m, cap)], np.float32)
+
+
+def _seven_game_slab(per_game, rank=0):
+    """Seven vector envs on their own streams writing their blocks of ONE slab triple, as bench.py --workload mixed lays
+    them out (and test_mixed_seven_game_slice_of_configs4 checks against the oracle)."""
+    import torch
+    from procgen2_amd.vec_env import GAMES, ProcgenVecEnv
+    total = per_game * len(GAMES)
+    slab = (torch.zeros((total, 64, 64, 3), dtype=torch.uint8, device="cuda"),
+            torch.zeros(total, dtype=torch.float32, device="cuda"), torch.zeros(total, dtype=torch.uint8, device="cuda"))
+    envs = [ProcgenVecEnv(g, per_game, seed_base=1, env_offset=rank * per_game,
+                          out=tuple(t[k * per_game:(k + 1) * per_game] for t in slab)) for k, g in enumerate(GAMES)]
+    for e in envs:
+        e.reset()
+    for e in envs:
+        e.sync()
+    return envs, slab
+
+
+def test_publish_and_consume_keep_unordered_steps_and_their_readers_apart():
+    """The stream-ordering contract of ProcgenVecEnv (vec_env.py publish / consume), on one GPU:
+    seven games step side by side with step_synthetic(ordered=False) — each on its own stream, nothing waits for
+    anything — and after every step a READER on torch's current stream (here: a deliberately late device-to-device copy
+    of the three slabs into a history ring, the stand-in for bench.py's rooted RCCL gather) must see that step's
+    outputs, whole: publish() orders the reader behind the step, consume() orders the NEXT step behind the reader.
+    160 steps with no host synchronisation inside; afterwards every copied step equals a synchronous run of the same
+    envs, and a handful of envs per game are where the oracle is.
+
+    The test has teeth: the same loop without consume() — the engines then run ahead of the late reader and overwrite
+    the slab under it — is run too and MUST come out torn (observed: every one of its copied steps differs)."""
+    import torch
+    from oracle_util import register_textures
+    from procgen2_amd.vec_env import GAMES
+    per_game, steps = 128, 160
+    total = per_game * len(GAMES)
+
+    def rollout(consume):
+        envs, slab = _seven_game_slab(per_game)
+        hist = tuple(torch.zeros((steps,) + tuple(t.shape), dtype=t.dtype, device="cuda") for t in slab)
+        torch.cuda.synchronize()
+        for s in range(steps):
+            for e in envs:
+                e.step_synthetic(0, ordered=False)
+            for e in envs:
+                e.publish()
+            torch.cuda._sleep(2_000_000)  # the reader is late: about a millisecond, several steps' worth
+            for t, h in zip(slab, hist):
+                h[s].copy_(t, non_blocking=True)
+            if consume:
+                for e in envs:
+                    e.consume()
+        for e in envs:
+            e.sync()
+        torch.cuda.synchronize()
+        out = tuple(h.cpu().numpy() for h in hist)
+        for e in envs:
+            e.close()
+        return out
+
+    # the reference rollout: the same envs, the host waiting for every step
+    envs, slab = _seven_game_slab(per_game)
+    want = (np.zeros((steps, total, 64, 64, 3), np.uint8), np.zeros((steps, total), np.float32), np.zeros((steps, total), np.uint8))
+    for s in range(steps):
+        for e in envs:
+            e.step_synthetic(0, ordered=False)
+        for e in envs:
+            e.sync()
+        for w, t in zip(want, slab):
+            w[s] = t.cpu().numpy()
+    for e in envs:
+        e.close()
+
+    got = rollout(consume=True)
+    for s in range(steps):
+        assert np.array_equal(got[2][s], want[2][s]), ("done", s)
+        assert np.array_equal(got[1][s].view(np.uint32), want[1][s].view(np.uint32)), ("reward", s)
+        assert np.array_equal(got[0][s], want[0][s]), ("obs", s)
+    torn = rollout(consume=False)
+    differing = sum(not np.array_equal(torn[0][s], want[0][s]) for s in range(steps))
+    assert differing > steps // 2, "without consume() the late reader must see later steps' frames (%d of %d differ)" % (differing, steps)
+
+    # … and the rollout itself is the oracle's: a few envs of every game after the last step
+    L = oracle()
+    last = want[0][steps - 1].reshape(total, -1)
+    for k, game in enumerate(GAMES):
+        register_textures(game)
+        for i in (0, per_game // 3, per_game - 1):
+            h = L.pgo_make(game.encode(), 1 + i, 1)
+            L.pgo_reset(h, 0, 0)
+            pending, r, d = False, 0.0, 0
+            for s in range(steps):
+                if pending:
+                    L.pgo_reset(h, 0, 0)
+                    pending, r, d = False, 0.0, 0
+                else:
+                    L.pgo_step(h, L.pgo_synthetic_action(0, s, i))
+                    r, d = L.pgo_reward(h), int(L.pgo_terminated(h))
+                    pending = bool(d)
+            assert np.array_equal(last[k * per_game + i], np.ctypeslib.as_array(L.pgo_obs(h), shape=(12288,))), (game, i)
+            assert np.float32(r) == want[1][steps - 1][k * per_game + i] and d == want[2][steps - 1][k * per_game + i], (game, i)
+            L.pgo_close(h)
+
+
+def test_step_many_synthetic_equals_stepping_the_envs_one_by_one():
+    """pgv_step_synthetic_many (the launch loop of bench.py --workload mixed, in C) against a per-env
+    pgv_step_synthetic loop from the same snapshot: identical observations, rewards and dones for every env of every
+    game, and the per-step timing entry point pgv_step_times is sane."""
+    import torch
+    from procgen2_amd.vec_env import GAMES, step_many_synthetic
+    per_game, steps = 192, 40
+    envs, slab = _seven_game_slab(per_game)
+    snaps = [e.save_state() for e in envs]
+    step_many_synthetic(envs, steps, 3)
+    for e in envs:
+        e.sync()
+    many = tuple(t.cpu().numpy().copy() for t in slab)
+    for e, snap in zip(envs, snaps):
+        e.load_state(snap)
+    for s in range(steps):
+        for e in envs:
+            e.step_synthetic(3, ordered=False)
+    for e in envs:
+        e.sync()
+    one = tuple(t.cpu().numpy() for t in slab)
+    assert np.array_equal(many[2], one[2]) and np.array_equal(many[1].view(np.uint32), one[1].view(np.uint32))
+    assert np.array_equal(many[0], one[0])
+    # pgv_step_times: one entry per step, all positive, render within the step, and the sum close to a timed run's total
+    e = envs[0]
+    step_ms, render_ms = e.step_times(32, 3)
+    assert step_ms.shape == (32,) and render_ms.shape == (32,)
+    assert (step_ms > 0).all() and (render_ms > 0).all() and (render_ms <= step_ms * 1.05).all()
+    total_ms, _ = e.timed_steps(32, 3)
+    assert 0.3 * total_ms < float(step_ms.sum()) < 3.0 * total_ms, (float(step_ms.sum()), total_ms)
+    for e in envs:
+        e.close()
+    torch.cuda.synchronize()
