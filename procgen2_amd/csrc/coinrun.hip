@@ -1217,50 +1217,84 @@ struct PrepEnv {  // per env of the workgroup: what the draws' lanes need, loade
     float avx, aphase, ax, ay;
 };
 struct SetupLds {
-    PrepLds<kGrid, kPrepEnvs> P;
+    PrepLds<kGrid, kPrepEnvs, kMaxSpan> P;
     PrepEnv env[kPrepEnvs];
-    int32_t kind_soft[kPrepEnvs];  // bit k: tile kind k's texture has texels that are not opaque
+    int4 desc[kTexCount];                    // the atlas descriptor table: every later lookup is an LDS read
+    uint8_t order[kPrepEnvs][2][kMaxEnt + 4];  // EB_SPARK_ORDER, EB_DRAW_ORDER of every env (fetched before anything needs them)
+    int32_t kind_soft[kPrepEnvs];            // bit k: tile kind k's texture has texels that are not opaque
     int32_t counts[kPrepEnvs];
+    PrepDrawQueue queue[kPrepThreads / 64];  // one worklist per wavefront
 };
 
-__global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView atlas, const uint8_t* mask) {
+__global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView atlas, const uint8_t* mask, int flags) {
     __shared__ SetupLds S;
-    PrepLds<kGrid, kPrepEnvs>& P = S.P;
+    PrepLds<kGrid, kPrepEnvs, kMaxSpan>& P = S.P;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int env0 = blockIdx.x * kPrepEnvs;
     const PrepOut& out = s.prep;
 
-    // ---- per env: camera, tile window, background draw (render_full's preamble, one lane per env)
+    // ---- everything whose address does not depend on another load is requested first: the descriptor table, the envs'
+    // scalars (lane = env), the two entity orders (lane = (env, slot)) — one memory round trip for all of it
     for (int q = tid; q < kPrepEnvs * 2 * 64; q += kPrepThreads) (&P.cover[0][0][0])[q] = 0u;
+    if (tid < kTexCount) S.desc[tid] = atlas.desc[tid];
+    static_assert(kTexCount <= kPrepThreads, "one descriptor per thread");
+    for (int q = tid; q < kPrepEnvs * 2 * kMaxEnt; q += kPrepThreads) {
+        const int e = q / (2 * kMaxEnt), r = q - e * (2 * kMaxEnt), which = r / kMaxEnt, j = r - which * kMaxEnt;
+        if (env0 + e < s.n) S.order[e][which][j] = EB(s, which ? EB_DRAW_ORDER : EB_SPARK_ORDER, j, env0 + e);
+    }
+    Camera cam{};
+    int themes = 0, redo = 0;
+    float bgshift = 0.0f;
+    bool active = false;
     if (tid < kPrepEnvs) {
         const int e = tid, env = env0 + e;
+        active = env < s.n && (!mask || mask[env]);
+        if (active) {
+            redo = SCI(s, SC_REDO, env);
+            cam = Camera{SF(s, F_CAMX, env), SF(s, F_CAMY, env), 64.0f, 64.0f, 0.3f * 64.0f / 64.0f};
+            themes = SI(s, I_THEMES, env);
+            bgshift = SF(s, F_BGSHIFT, env);
+            PrepEnv pe{};
+            pe.sflags = SI(s, I_FLAGS, env);
+            pe.buf = (pe.sflags & kFlagBuf) ? 1 : 0;
+            pe.n_ent = SI(s, I_NENT, env);
+            pe.n_mob = SI(s, I_NMOB, env);
+            pe.n_sprites = (pe.sflags & kFlagListed) ? pe.n_ent : 0;  // the draw list is empty until the first update (D2)
+            pe.alien = (themes >> 8) & 0xff;
+            pe.avx = SF(s, F_AVX, env);
+            pe.aphase = SF(s, F_APHASE, env);
+            pe.ax = SF(s, F_AX, env);
+            pe.ay = SF(s, F_AY, env);
+            S.env[e] = pe;
+        }
+    }
+    __syncthreads();
+    // ---- per env (lane = env): camera, tile window, background draw — render_full's preamble
+    if (tid < kPrepEnvs) {
+        const int e = tid;
         PrepView v{};
-        bool active = env < s.n && (!mask || mask[env]);
         P.fat[e] = 0;
         P.soft_rows[e] = P.hard_rows[e] = 0;
         S.counts[e] = 0;
-        if (active && SCI(s, SC_REDO, env) != 0) {  // the step ended early: the entity table is not final (resolve_kernel)
+        S.kind_soft[e] = 0;
+        if (active && redo != 0) {  // the step ended early: the entity table is not final (resolve_kernel)
             P.fat[e] = 1;
             active = false;
         }
         if (active) {
-            v.cam = Camera{SF(s, F_CAMX, env), SF(s, F_CAMY, env), 64.0f, 64.0f, 0.3f * 64.0f / 64.0f};
-            const Camera& cam = v.cam;
-            const int themes = SI(s, I_THEMES, env);
-            const int sflags = SI(s, I_FLAGS, env);
-            const int backdrop = themes & 0xff;
-            const int4 d = atlas.desc[kTexBackdrop + backdrop];
+            v.cam = cam;
+            const int4 d = S.desc[kTexBackdrop + (themes & 0xff)];
             const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
             const float extra = aspect - 1.0f;
-            v.bg = BgDraw{d, -SF(s, F_BGSHIFT, env) * extra, 0.0f, 64.0f * kUnitPx / d.z};  // coinrun.cpp:459-464
-            const float vx = (cam.px - cam.sw * 0.5f / cam.scale) * kPxUnit;               // tilemap.cpp:294-304
+            v.bg = BgDraw{d, -bgshift * extra, 0.0f, 64.0f * kUnitPx / d.z};  // coinrun.cpp:459-464
+            const float vx = (cam.px - cam.sw * 0.5f / cam.scale) * kPxUnit;  // tilemap.cpp:294-304
             const float vy = (cam.py - cam.sh * 0.5f / cam.scale) * kPxUnit;
             const float vw = cam.sw * kPxUnit / cam.scale, vh = cam.sh * kPxUnit / cam.scale;
             v.x0 = static_cast<int>(floorf(vx));
             v.y0 = static_cast<int>(floorf(vy));
             v.cols = static_cast<int>(ceilf(vx + vw)) - v.x0 + 1;
             v.rows = static_cast<int>(ceilf(vy + vh)) - v.y0 + 1;
-            const int4 tile_desc = atlas.desc[kTexMid];  // every tile texture is 128×128 (checked at make time)
+            const int4 tile_desc = S.desc[kTexMid];  // every tile texture is 128×128 (checked at make time)
             v.tw = tile_desc.y;
             v.th = tile_desc.z;
             v.th2 = 0;
@@ -1271,81 +1305,92 @@ __global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView 
             }
             P.soft_rows[e] = d.w != 0 ? 0x80000000u : 0u;   // 9 of the 49 backdrops have texels that are not opaque
             P.hard_rows[e] = (d.w & 2) ? 0x80000000u : 0u;  // … mostly cut-out: no one-texel attempt
-            PrepEnv pe{};
-            pe.sflags = sflags;
-            pe.buf = (sflags & kFlagBuf) ? 1 : 0;
-            pe.n_ent = SI(s, I_NENT, env);
-            pe.n_mob = SI(s, I_NMOB, env);
-            pe.n_sprites = (sflags & kFlagListed) ? pe.n_ent : 0;  // the draw list is empty until the first update (D2)
-            pe.alien = (themes >> 8) & 0xff;
-            pe.avx = SF(s, F_AVX, env);
-            pe.aphase = SF(s, F_APHASE, env);
-            pe.ax = SF(s, F_AX, env);
-            pe.ay = SF(s, F_AY, env);
-            S.env[e] = pe;
-            S.kind_soft[e] = 0;
+            // the tile kinds' textures
+            const int ground_theme = (themes >> 16) & 0xff;
+            int soft = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                int tex = kTexCrate + (k - kSlotCrate);
+                if (k == kSlotTop) tex = kTexTop + ground_theme;
+                if (k == kSlotMid) tex = kTexMid + ground_theme;
+                if (k == kSlotLavaTop) tex = kTexLavaTop;
+                if (k == kSlotLava) tex = kTexLava;
+                const int4 kd = S.desc[tex];
+                P.meta[e][PM_KINDS + k] = static_cast<uint32_t>(kd.x) * 4u;
+                P.meta[e][PM_KINDS + 8 + k] = kNoTexel;
+                if (kd.w != 0) soft |= 1 << k;
+            }
+            S.kind_soft[e] = soft;
         }
         v.active = active ? 1 : 0;
         P.view[e] = v;
     }
     __syncthreads();
-    // the tile kinds' textures: lane = (env, kind)
-    if (tid < kPrepEnvs * 8) {
-        const int e = tid >> 3, k = tid & 7;
-        if (P.view[e].active) {
-            const int ground_theme = (SI(s, I_THEMES, env0 + e) >> 16) & 0xff;
-            int tex = kTexCrate + (k - kSlotCrate);
-            if (k == kSlotTop) tex = kTexTop + ground_theme;
-            if (k == kSlotMid) tex = kTexMid + ground_theme;
-            if (k == kSlotLavaTop) tex = kTexLavaTop;
-            if (k == kSlotLava) tex = kTexLava;
-            const int4 d = atlas.desc[tex];
-            P.meta[e][PM_KINDS + k] = static_cast<uint32_t>(d.x) * 4u;
-            P.meta[e][PM_KINDS + 8 + k] = kNoTexel;
-            if (d.w != 0) atomicOr(&S.kind_soft[e], 1 << k);
-        }
-    }
-    prep_spans<kGrid, kMaxSpan, kPrepEnvs>(P, tid, kPrepThreads);
-    __syncthreads();
+    if (PG_ABL(flags, 0x1000000)) return;  // (instruction inventory, -DPG_ABLATE builds only: the views alone)
 
-    // ---- the cell table: lane = (env, grid row, four grid columns) → four kind bytes, one word
-    for (int q = tid; q < kPrepEnvs * kGrid * (kGrid / 4); q += kPrepThreads) {
-        const int e = q / (kGrid * kGrid / 4), w = q - e * (kGrid * kGrid / 4);
+    // ---- the cell table, first half: lane = (env, grid row, four grid columns) requests its four tile bytes …
+    constexpr int kCellWords = kGrid * kGrid / 4;
+    static_assert(kPrepEnvs * kCellWords == 2 * kPrepThreads, "two cell words per thread");
+    int raw_tile[2][4];
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const int q = tid + it * kPrepThreads;
+        const int e = q / kCellWords, w = q - e * kCellWords;
         const PrepView& v = P.view[e];
-        if (!v.active) continue;
         const int r = w / (kGrid / 4), c4 = (w - r * (kGrid / 4)) * 4;
         const uint8_t* tiles = s.tiles + size_t(env0 + e) * (W * H);
         const int ty = H - 1 - (v.y0 + r);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int x = v.x0 + c4 + j;
+            raw_tile[it][j] = kWallMid;  // out of bounds is a wall (tilemap.h:80-81)
+            if (v.active && x >= 0 && ty >= 0 && x < W && ty < H) raw_tile[it][j] = tiles[ty + x * H];
+        }
+    }
+    // … the spans are worked out while they travel …
+    if (!PG_ABL(flags, 0x2000000)) prep_spans<kGrid, kMaxSpan, kPrepEnvs>(P, tid, kPrepThreads);
+    // … second half: four kind bytes, one word
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const int q = tid + it * kPrepThreads;
+        const int e = q / kCellWords, w = q - e * kCellWords;
+        const PrepView& v = P.view[e];
+        if (!v.active) continue;
+        const int r = w / (kGrid / 4), c4 = (w - r * (kGrid / 4)) * 4;
         const int soft_kinds = S.kind_soft[e];
         uint32_t word = 0;
         bool soft = false;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int x = v.x0 + c4 + j;
-            int raw = kWallMid;  // out of bounds is a wall (tilemap.h:80-81)
-            if (x >= 0 && ty >= 0 && x < W && ty < H) raw = tiles[ty + x * H];
+            const int raw = raw_tile[it][j];
             const int t = raw & 7;
             const int slot = t < kCrate ? t - 1 : kSlotCrate + (raw >> 4);
             word |= (t == kEmpty ? 0xffu : static_cast<uint32_t>(slot)) << (8 * j);
             soft = soft || (t != kEmpty && ((soft_kinds >> slot) & 1) && r < v.rows && c4 + j < v.cols);
         }
-        reinterpret_cast<uint32_t*>(out.cells)[size_t(env0 + e) * (kGrid * kGrid / 4) + w] = word;
+        reinterpret_cast<uint32_t*>(out.cells)[size_t(env0 + e) * kCellWords + w] = word;
         if (soft) atomicOr(&P.soft_rows[e], 1u << r);
     }
     __syncthreads();
-    prep_axes<kGrid, kPrepEnvs>(P, out, env0, wave, kPrepThreads / 64, lane);
+    if (PG_ABL(flags, 0x4000000)) return;
+    if (!PG_ABL(flags, 0x8000000)) prep_axes<kGrid, kMaxSpan, kPrepEnvs>(P, out, env0, wave, kPrepThreads / 64, lane);
+    if (PG_ABL(flags, 0x10000000)) return;
 
     // ---- the draws, in the reference's order — particles (owners in the particle system's set order), the sprites of
-    // the draw list, the agent — resolved one per lane; those that survive the cull are numbered per env and stored.
-    // A wavefront takes two envs of the workgroup, their draws dealt densely over its passes.
+    // the draw list, the agent.  A wavefront takes two envs of the workgroup, their lists dealt densely over its passes;
+    // a draw that survives render_texture's cull waits in the wave's worklist for the rest of the arithmetic
+    // (pg_prepass.h prep_draws_pass).
     static_assert(kPrepEnvs == 2 * (kPrepThreads / 64), "two envs per wavefront");
     {
         const int ea = 2 * wave, eb = 2 * wave + 1;
         const bool on_a = P.view[ea].active != 0, on_b = P.view[eb].active != 0;
         const int cnt_a = on_a ? S.env[ea].n_mob * kSparks + S.env[ea].n_sprites + 1 : 0;
         const int cnt_b = on_b ? S.env[eb].n_mob * kSparks + S.env[eb].n_sprites + 1 : 0;
-        const int4 spark_d = atlas.desc[kTexSpark];
-        int done_a = 0, done_b = 0;
+        const Camera cam_a = P.view[ea].cam, cam_b = P.view[eb].cam;
+        uint32_t* const draws_a = out.draws + size_t(env0 + ea) * kPrepDraws * kBlitWords;
+        uint32_t* const draws_b = out.draws + size_t(env0 + eb) * kPrepDraws * kBlitWords;
+        PrepDrawPass st{0, {0, 0}};
+        PrepDrawQueue& Q = S.queue[wave];
         for (int base = 0; base < cnt_a + cnt_b; base += 64) {  // wave-uniform
             const int q = base + lane;
             const bool is_b = q >= cnt_a;
@@ -1353,80 +1398,64 @@ __global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView 
             const int slot = is_b ? q - cnt_a : q;
             const bool valid = q < cnt_a + cnt_b;
             const PrepEnv& pe = S.env[e];
-            const Camera& cam = P.view[e].cam;
             const int n_parts = pe.n_mob * kSparks;
-            bool go = false, flip = false;
-            int tw = 1, th = 1, tex_at = 0;
-            float wx = 0.0f, wy = 0.0f, scale_num = kUnitPx, alpha = 1.0f;
+            PrepDraw p{false, false, false, kTexSpark, 0.0f, 0.0f, 1.0f, 1.0f};
             if (valid && slot < n_parts) {  // System_Particles::render (common_systems.cpp:315-337)
                 const int m = slot / kSparks, k = slot - m * kSparks;
-                const int ent = EB(s, EB_SPARK_ORDER, m, env);
+                const int ent = S.order[e][0][m];
                 const float life = SP(s, pe.buf, 2, ent, k, env);
+                const float px = SP(s, pe.buf, 0, ent, k, env), py = SP(s, pe.buf, 1, ent, k, env);
                 if (life > 0.0f) {
-                    const float px = SP(s, pe.buf, 0, ent, k, env), py = SP(s, pe.buf, 1, ent, k, env);
+                    const int4 spark_d = S.desc[kTexSpark];
                     const float lr = (5.0f - life) / 5.0f;
-                    alpha = 0.5f * (1.0f - lr);
+                    p.alpha = 0.5f * (1.0f - lr);
                     const float scale = 0.45f * (0.4f * lr + 0.6f);
                     const float oy = -lr * 0.17f;
-                    tw = spark_d.y;
-                    th = spark_d.z;
-                    tex_at = spark_d.x;
-                    wx = px * kUnitPx - 0.5f * spark_d.y * scale;
-                    wy = (py + oy) * kUnitPx - 0.5f * spark_d.z * scale;
-                    scale_num = scale * kUnitPx;
-                    go = true;
+                    p.wx = px * kUnitPx - 0.5f * spark_d.y * scale;
+                    p.wy = (py + oy) * kUnitPx - 0.5f * spark_d.z * scale;
+                    p.scale = scale * kUnitPx / static_cast<float>(spark_d.y);
+                    p.go = true;
                 }
             } else if (valid && slot < n_parts + pe.n_sprites) {  // System_Sprite_Render::render (:41-63)
-                const int ent = EB(s, EB_DRAW_ORDER, slot - n_parts, env);
+                const int ent = S.order[e][1][slot - n_parts];
                 const int dyn = DB(s, pe.buf, ent, env);
+                const int tex0 = EB(s, EB_TEX, ent, env);
+                const float ex = DF(s, pe.buf, DF_X, ent, env), ey = EY(s, ent, env);
                 if (dyn & kDynTexSet) {
-                    const int4 d = atlas.desc[EB(s, EB_TEX, ent, env) + ((dyn & kDynFrame) ? 1 : 0)];
-                    tw = d.y;
-                    th = d.z;
-                    tex_at = d.x;
+                    p.tex = tex0 + ((dyn & kDynFrame) ? 1 : 0);
                     const float scale = 1.0f * 1.0f;
-                    wx = (DF(s, pe.buf, DF_X, ent, env) + -0.5f) * kUnitPx;
-                    wy = (EY(s, ent, env) + -0.5f) * kUnitPx;
-                    scale_num = scale * kUnitPx;
-                    flip = (dyn & kDynFlip) != 0;
-                    go = true;
+                    p.wx = (ex + -0.5f) * kUnitPx;
+                    p.wy = (ey + -0.5f) * kUnitPx;
+                    p.scale = scale * kUnitPx / static_cast<float>(S.desc[p.tex].y);
+                    p.flip_h = (dyn & kDynFlip) != 0;
+                    p.go = true;
                 }
             } else if (valid) {  // the agent (:254-278)
                 const bool ground = (pe.sflags & kFlagGround) != 0;
-                int tex;
                 if (fabsf(pe.avx) < 0.01f && ground)
-                    tex = kTexStand + pe.alien;
+                    p.tex = kTexStand + pe.alien;
                 else if (!ground)
-                    tex = kTexJump + pe.alien;
+                    p.tex = kTexJump + pe.alien;
                 else if (pe.aphase > 0.5f)
-                    tex = kTexWalk2 + pe.alien;
+                    p.tex = kTexWalk2 + pe.alien;
                 else
-                    tex = kTexWalk1 + pe.alien;
-                const int4 d = atlas.desc[tex];
-                tw = d.y;
-                th = d.z;
-                tex_at = d.x;
-                wx = (pe.ax - 0.5f) * kUnitPx;
-                wy = (pe.ay - 2.0f) * kUnitPx;
-                flip = (pe.sflags & kFlagForward) == 0;
-                go = true;
+                    p.tex = kTexWalk1 + pe.alien;
+                p.wx = (pe.ax - 0.5f) * kUnitPx;
+                p.wy = (pe.ay - 2.0f) * kUnitPx;
+                p.scale = kUnitPx / static_cast<float>(S.desc[p.tex].y);
+                p.flip_h = (pe.sflags & kFlagForward) == 0;
+                p.go = true;
             }
-            Blit mine;
-            const bool has = go && resolve_draw(cam, tw, th, tex_at, wx, wy, scale_num / static_cast<float>(tw), alpha, flip, false, mine);
-            const unsigned long long m_a = __ballot(has && !is_b), m_b = __ballot(has && is_b);
-            const unsigned long long below = (1ull << lane) - 1ull;
-            const int rank = is_b ? done_b + __popcll(m_b & below) : done_a + __popcll(m_a & below);
-            if (has && rank < kPrepDraws) prep_draw_store(out.draws + (size_t(env) * kPrepDraws + rank) * kBlitWords, mine);
-            done_a += __popcll(m_a);
-            done_b += __popcll(m_b);
+            prep_draws_pass(Q, st, S.desc, cam_a, cam_b, draws_a, draws_b, valid, is_b, p, lane);
         }
+        prep_draws_flush(Q, st, S.desc, cam_a, cam_b, draws_a, draws_b, lane);
         if (lane == 0) {
-            S.counts[ea] = done_a;
-            S.counts[eb] = done_b;
+            S.counts[ea] = st.done[0];
+            S.counts[eb] = st.done[1];
         }
     }
     __syncthreads();
-    prep_meta_out<kGrid, kPrepEnvs>(P, out, env0, S.counts, tid, kPrepThreads);
+    prep_meta_out<kGrid, kMaxSpan, kPrepEnvs>(P, out, env0, S.counts, tid, kPrepThreads);
 }
 
 // render_game(true) (coinrun.cpp:443-470): one workgroup of two wavefronts per env.  A lean frame starts from what
@@ -1439,12 +1468,11 @@ __global__ void __launch_bounds__(64 * kRenderWaves, PG_COINRUN_RENDER_WAVES) re
     constexpr int halves = kRenderWaves;
     __shared__ alignas(16) uint32_t fb[kFbWords];
     __shared__ ComposeLds<kGrid> L;  // the composer's cell table
+    // One round trip for everything the frame starts from: the packed axes, the kind offsets, this wave's half of the
+    // cell bytes (vector loads) and the meta line (scalar loads) leave together; only the draws wait for their count.
+    // Whether the frame is a fat one is asked AFTER the lean preamble (a few wasted instructions for the rare fat frame,
+    // no load waiting behind a branch for all the others).
     const PrepMeta M{s.prep.meta + size_t(env) * kPrepMetaWords};
-    if ((flags & (1 | kDebugNoPrepass)) || M.fat()) {  // (wave-uniform)
-        render_full(s, atlas, io, flags, env, fb, L);
-        return;
-    }
-    // one round trip: the packed axes, the kind offsets, this wave's half of the cell bytes, my draw
     const uint32_t colw = s.prep.axes[size_t(env) * 128 + lane], roww = s.prep.axes[size_t(env) * 128 + 64 + lane];
     const uint32_t kind_off = M.w[PM_KINDS + (lane & (kPrepKinds - 1))];
     const uint32_t two = reinterpret_cast<const uint16_t*>(s.prep.cells)[size_t(env) * (kGrid * kGrid / 2) + half * 64 + lane];
@@ -1460,6 +1488,10 @@ __global__ void __launch_bounds__(64 * kRenderWaves, PG_COINRUN_RENDER_WAVES) re
     }
     const ComposeRegs R = prep_regs<kGrid>(M, colw, roww, 0u, lane);
     __syncthreads();  // the cell table is complete
+    if ((flags & (1 | kDebugNoPrepass)) || M.fat()) {  // (wave-uniform)
+        render_full(s, atlas, io, flags, env, fb, L);
+        return;
+    }
     const int row_lo = half * (kObsH / halves), row_hi = (half + 1) * (kObsH / halves);
     // (the PG_ABL tests are timing experiments of the -DPG_ABLATE build: constants 0 in the product)
     ReplayState<4> sprite_pass = replay_begin(atlas, mine, PG_ABL(flags, 2) ? 0ull : __ballot(has), lane, row_lo, row_hi);
@@ -1678,7 +1710,7 @@ class CoinrunGame final : public Game {
     }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
         if (!(debug_flags & (1 | kDebugNoPrepass)) && !PG_ABL(debug_flags, 1 << 22))  // (experiment: the last frame's pre-pass again)
-            hipLaunchKernelGGL(setup_kernel, dim3((s_.n + kPrepEnvs - 1) / kPrepEnvs), dim3(kPrepThreads), 0, st, s_, atlas_, mask);
+            hipLaunchKernelGGL(setup_kernel, dim3((s_.n + kPrepEnvs - 1) / kPrepEnvs), dim3(kPrepThreads), 0, st, s_, atlas_, mask, debug_flags);
         hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(64 * kRenderWaves), 0, st, s_, atlas_, mask, io,
                            debug_flags);
     }

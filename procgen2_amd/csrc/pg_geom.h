@@ -71,14 +71,22 @@ struct Span {
 // the untouched values).  This is one axis of it, followed by raster-spec S1/S2 for that axis.
 //   cam_pos/cam_len: camera position and viewport size on this axis; tsize: texture extent on this axis;
 //   strict_far: the far-side cull is `>=` on y and `>` on x (renderer.cpp:14).
-PG_HD bool resolve_axis(float cam_pos, float cam_len, float cam_scale, int tsize, float pos, float scale, bool flip,
-                        bool strict_far, Span& out) {
+// … in two parts, for callers that cull many draws and finish few (the render pre-pass, pg_prepass.h): the head is the
+// destination before any cropping and the cull test (renderer.cpp:8-14), the tail everything after it.
+struct AxisHead {
+    float d, dl;
+};
+PG_HD bool axis_head(float cam_pos, float cam_len, float cam_scale, int tsize, float pos, float scale, bool strict_far,
+                     AxisHead& h) {
+    h.d = (pos - cam_pos) * cam_scale + cam_len * 0.5f;
+    h.dl = tsize * scale * cam_scale;
+    return !((strict_far ? h.d >= cam_len : h.d > cam_len) || h.d + h.dl < 0);  // renderer.cpp:14
+}
+PG_HD bool axis_tail(float cam_len, float cam_scale, int tsize, float scale, bool flip, const AxisHead& h, Span& out) {
     float s = 0.0f;
     float sl = static_cast<float>(tsize);
-    float d = (pos - cam_pos) * cam_scale + cam_len * 0.5f;
-    float dl = tsize * scale * cam_scale;
-
-    if ((strict_far ? d >= cam_len : d > cam_len) || d + dl < 0) return false;  // renderer.cpp:14
+    float d = h.d;
+    float dl = h.dl;
 
     if (d < 0.0f) {  // renderer.cpp:18-26 / 36-44
         float ratio = -d / dl;
@@ -114,6 +122,12 @@ PG_HD bool resolve_axis(float cam_pos, float cam_len, float cam_scale, int tsize
     out.s0 = a;
     out.sn = b - a;
     return out.sn > 0;
+}
+PG_HD bool resolve_axis(float cam_pos, float cam_len, float cam_scale, int tsize, float pos, float scale, bool flip,
+                        bool strict_far, Span& out) {
+    AxisHead h;
+    if (!axis_head(cam_pos, cam_len, cam_scale, tsize, pos, scale, strict_far, h)) return false;
+    return axis_tail(cam_len, cam_scale, tsize, scale, flip, h, out);
 }
 
 // The full draw call = both axes.  tex_off/tw/th describe the texture; pos in world pixels.

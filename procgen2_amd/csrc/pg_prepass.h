@@ -77,11 +77,25 @@ struct PrepView {
     int32_t active;       // 0: this env takes no part (masked out, beyond n, or already known to be fat)
 };
 
-template <int GRID, int E>
+// One tile column / row (or row of the layer's second texture) as the pixel lanes need it: destination start and
+// extent, and WHICH table holds its texel coordinates — d0 (signed 16 bits) | dn << 16 | table << 24; dn = 0: nothing
+// drawn, dn = kPrepInterior: filled in from the axis's template (below).
+constexpr uint32_t kPrepInterior = 0xffu;
+constexpr int kPrepList = 128;  // full tails a workgroup works out per frame (edge tiles, templates, backgrounds)
+struct PrepTail {               // one of them, waiting: the head of render_texture's arithmetic has been done
+    float d, dl;
+    uint32_t code;              // env | axis << 4 | grid index << 8 | kind << 16
+};
+enum { kTailEdge = 0, kTailTemplate = 1, kTailBackground = 2 };
+
+template <int GRID, int E, int MAXSPAN = kMaxSpan>
 struct PrepLds {
     PrepView view[E];
-    int4 span[E][2][GRID];   // [env][axis][grid index]: d0, dn, s0, sn (sn = 0: nothing)
-    int4 span2[E][GRID];     // rows of the second texture
+    uint32_t span[E][3][GRID];   // [env][axis: 0 columns, 1 rows, 2 rows of the second texture][grid index]
+    uint32_t tmpl[E][3];         // the axis's template: dn << 16 | table << 24 (0: no tile of the axis is drawn whole)
+    PrepTail list[kPrepList];
+    int32_t list_n;
+    uint8_t texel[kPrepList][MAXSPAN];  // texel coordinate of destination offset i, per worked-out tail
     uint32_t cover[E][2][64];
     uint32_t soft_rows[E], hard_rows[E];  // bit r: grid row r shows soft / hard texels; bit 31: the background does
     uint32_t fat[E];
@@ -90,62 +104,154 @@ struct PrepLds {
 
 PG_D uint32_t pack_halves(int lo, int hi) { return (static_cast<uint32_t>(lo) & 0xffffu) | (static_cast<uint32_t>(hi) << 16); }
 
-// Phase A — lane = (env, axis, grid index) and two more per env for the background's axes: render_texture's arithmetic
-// for one axis of one tile column / row (pg_geom.h resolve_axis), then every span marks the pixels it covers with its
-// grid index.  P.cover and P.fat must have been cleared (and a barrier passed); leaves a barrier to the caller.
-template <int GRID, int MAXSPAN, int E>
-PG_D void prep_spans(PrepLds<GRID, E>& P, int tid, int nthreads) {
+// Phase A — the spans of the tile grid and of the background.
+//
+// render_texture's arithmetic per axis is a head (destination before cropping, cull: three operations) and a tail (the
+// crops against the screen, five exact divisions, the source snap: ≈ 170 vector instructions).  For every tile that
+// lies wholly on the screen the tail's inputs are the same — it depends on the destination's START only through the
+// crops, which are not taken, and through `d -= off * (dl / sl)` with off = 0 — so all those tiles of an axis share
+// one result but for d0 = (int)d: the axis's TEMPLATE, worked out once from a head with d = 0.  Only the tiles the screen
+// edge cuts (two per axis) need a tail of their own.  So: step 1, lane = (env, axis, grid index): the head; whole tiles
+// note their d0, cut ones queue up.  Step 2: the queue — cut tiles, one template per axis, the background's two axes —
+// 64 full tails per wavefront pass, each also tabulating its texel coordinates.  Step 3: whole tiles take their
+// template's extent and table; every span marks the pixels it covers with its grid index.
+// P.cover must have been cleared; the caller has a barrier in front (views complete) and puts one behind.
+template <int GRID, int MAXSPAN, int E, bool TWO = false>
+PG_D void prep_spans(PrepLds<GRID, E, MAXSPAN>& P, int tid, int nthreads) {
     static_assert(GRID <= 30, "grid indices are bits of a word (bit 31: the background's class)");
-    constexpr int kPer = 2 * GRID + 2;
-    for (int q = tid; q < E * kPer; q += nthreads) {
-        const int e = q / kPer, k = q - e * kPer;
+    if (tid == 0) P.list_n = 0;
+    __syncthreads();
+    auto axis_params = [&](const PrepView& v, int axis, int kind, float& cam_pos, float& cam_len, int& tsize, float& scale) {
+        const bool x = axis == 0;
+        cam_pos = x ? v.cam.px : v.cam.py;
+        cam_len = x ? v.cam.sw : v.cam.sh;
+        if (kind == kTailBackground) {
+            tsize = x ? v.bg.desc.y : v.bg.desc.z;
+            scale = v.bg.scale;
+        } else {
+            tsize = x ? v.tw : (axis == 1 ? v.th : v.th2);
+            scale = v.tile_scale;
+        }
+    };
+    auto enqueue = [&](float d, float dl, uint32_t code) {
+        const int at = atomicAdd(&P.list_n, 1);
+        if (at < kPrepList)
+            P.list[at] = PrepTail{d, dl, code};
+        else
+            atomicOr(&P.fat[code & 15u], 1u);  // (never seen: a frame with that many cut tiles takes the complete path)
+    };
+    // ---- step 1: the tiles …
+    constexpr int kAxes = TWO ? 3 : 2, kTiles = kAxes * GRID;
+    for (int q = tid; q < E * kTiles; q += nthreads) {
+        const int e = q / kTiles, k = q - e * kTiles;
         const PrepView& v = P.view[e];
         if (!v.active) continue;
-        const bool is_bg = k >= 2 * GRID;
-        const int axis = is_bg ? k - 2 * GRID : k / GRID;
-        const int g = k - axis * GRID;
+        const int axis = k / GRID, g = k - axis * GRID;
         const int count = axis == 0 ? v.cols : v.rows;
+        uint32_t word = 0u;
+        if (g < count && !(axis == 2 && v.th2 <= 0)) {
+            float cam_pos, cam_len, scale;
+            int tsize;
+            axis_params(v, axis, kTailEdge, cam_pos, cam_len, tsize, scale);
+            AxisHead h;
+            if (axis_head(cam_pos, cam_len, v.cam.scale, tsize, ((axis == 0 ? v.x0 : v.y0) + g) * kUnitPx, scale, axis != 0, h)) {
+                if (!(h.d < 0.0f) && !(h.d + h.dl > cam_len)) {  // neither crop of axis_tail is taken: a whole tile
+                    const bool fits = h.d > -32768.0f && h.d < 32768.0f;   // (S1, as the tail would ask)
+                    word = fits ? pack_halves(static_cast<int>(h.d), static_cast<int>(kPrepInterior)) : 0u;
+                } else {
+                    enqueue(h.d, h.dl, static_cast<uint32_t>(e) | (axis << 4) | (g << 8) | (kTailEdge << 16));
+                }
+            }
+        }
+        P.span[e][axis][g] = word;  // (a cut tile's word is written in step 2)
+    }
+    // … and per env the templates of its axes and the background's two axes
+    for (int q = tid; q < E * (kAxes + 2); q += nthreads) {
+        const int e = q / (kAxes + 2), j = q - e * (kAxes + 2);
+        const PrepView& v = P.view[e];
+        if (!v.active) continue;
+        const int axis = j < kAxes ? j : j - kAxes, kind = j < kAxes ? kTailTemplate : kTailBackground;
+        if (kind == kTailTemplate && axis == 2 && v.th2 <= 0) continue;
+        float cam_pos, cam_len, scale;
+        int tsize;
+        axis_params(v, axis, kind, cam_pos, cam_len, tsize, scale);
+        AxisHead h{0.0f, 0.0f};
+        bool alive = true;
+        if (kind == kTailBackground) {
+            alive = axis_head(cam_pos, cam_len, v.cam.scale, tsize, axis == 0 ? v.bg.px : v.bg.py, scale, axis == 1, h);
+            if (!alive) {  // culled on this axis: as compose_spans hands it out
+                P.meta[e][PM_BGX + 2 * axis] = 0u;
+                P.meta[e][PM_BGX + 2 * axis + 1] = 0u;
+            }
+        } else {
+            h.dl = tsize * scale * v.cam.scale;  // (axis_head's expression; d = 0)
+            P.tmpl[e][axis] = 0u;
+            alive = !(h.d + h.dl > cam_len);  // (a tile larger than the screen is never whole: no template)
+        }
+        if (alive) enqueue(h.d, h.dl, static_cast<uint32_t>(e) | (axis << 4) | (kind << 16));
+    }
+    __syncthreads();
+    // ---- step 2
+    const int n_list = P.list_n < kPrepList ? P.list_n : kPrepList;
+    for (int q = tid; q < n_list; q += nthreads) {
+        const PrepTail t = P.list[q];
+        const int e = t.code & 15u, axis = (t.code >> 4) & 15u, g = (t.code >> 8) & 0xffu, kind = (t.code >> 16) & 3u;
+        const PrepView& v = P.view[e];
+        float cam_pos, cam_len, scale;
+        int tsize;
+        axis_params(v, axis, kind, cam_pos, cam_len, tsize, scale);
         Span sp;
         sp.d0 = sp.dn = sp.s0 = sp.sn = 0;
-        bool ok = false;
-        if (is_bg || g < count) {
-            const int ts = is_bg ? (axis == 0 ? v.bg.desc.y : v.bg.desc.z) : (axis == 0 ? v.tw : v.th);
-            const float pos = is_bg ? (axis == 0 ? v.bg.px : v.bg.py) : ((axis == 0 ? v.x0 : v.y0) + g) * kUnitPx;
-            ok = resolve_axis(axis == 0 ? v.cam.px : v.cam.py, axis == 0 ? v.cam.sw : v.cam.sh, v.cam.scale, ts, pos,
-                              is_bg ? v.bg.scale : v.tile_scale, false, axis == 1, sp);
-        }
-        if (is_bg) {  // as compose_spans hands it out: destination emptied when the axis draws nothing, source as computed
+        const bool ok = axis_tail(cam_len, v.cam.scale, tsize, scale, false, AxisHead{t.d, t.dl}, sp);
+        if (kind == kTailBackground) {
             P.meta[e][PM_BGX + 2 * axis] = pack_halves(ok ? sp.d0 : 0, ok ? sp.dn : 0);
             P.meta[e][PM_BGX + 2 * axis + 1] = pack_halves(sp.s0, sp.sn);
             continue;
         }
-        P.span[e][axis][g] = ok ? make_int4(sp.d0, sp.dn, sp.s0, sp.sn) : make_int4(0, 0, 0, 0);
-        bool wide = ok && sp.dn > MAXSPAN;
-        if (axis == 1 && v.th2 > 0) {
-            Span s2;
-            s2.d0 = s2.dn = s2.s0 = s2.sn = 0;
-            const bool ok2 = g < count && resolve_axis(v.cam.py, v.cam.sh, v.cam.scale, v.th2, (v.y0 + g) * kUnitPx,
-                                                       v.tile_scale, false, true, s2);
-            P.span2[e][g] = ok2 ? make_int4(s2.d0, s2.dn, s2.s0, s2.sn) : make_int4(0, 0, 0, 0);
-            wide = wide || (ok2 && (!ok || s2.d0 != sp.d0 || s2.dn > sp.dn));  // not nested: the complete path
-        }
-        if (wide) {
-            atomicOr(&P.fat[e], 1u);
-            continue;
-        }
-        if (ok)
+        uint32_t word = 0u;
+        if (ok) {
+            bool bad = sp.dn > MAXSPAN || sp.d0 < -32768 || sp.d0 > 32767;
             for (int i = 0; i < MAXSPAN; i++) {
-                const int p = sp.d0 + i;
-                if (i < sp.dn && p >= 0 && p < 64) atomicOr(&P.cover[e][axis][p], 1u << g);
+                const int u = i < sp.dn ? sample_index(sp.s0, sp.sn, i, sp.dn) : 0;
+                bad = bad || u > 255;
+                P.texel[q][i] = static_cast<uint8_t>(u);
             }
+            if (bad) atomicOr(&P.fat[e], 1u);
+            word = bad ? 0u : (pack_halves(sp.d0, sp.dn) | (static_cast<uint32_t>(q) << 24));
+        }
+        if (kind == kTailTemplate)
+            P.tmpl[e][axis] = word & 0xffff0000u;
+        else
+            P.span[e][axis][g] = word;
+    }
+    __syncthreads();
+    // ---- step 3
+    for (int q = tid; q < E * kTiles; q += nthreads) {
+        const int e = q / kTiles, k = q - e * kTiles;
+        const PrepView& v = P.view[e];
+        if (!v.active) continue;
+        const int axis = k / GRID, g = k - axis * GRID;
+        uint32_t w = P.span[e][axis][g];
+        if (((w >> 16) & 0xffu) == kPrepInterior) {
+            const uint32_t t = P.tmpl[e][axis];
+            w = t ? ((w & 0xffffu) | t) : 0u;
+            P.span[e][axis][g] = w;
+        }
+        const int d0 = static_cast<int32_t>(w << 16) >> 16, dn = (w >> 16) & 0xffu;
+        if (axis == 2) continue;  // (the second texture's rows are nested in the first's: checked by prep_axes)
+        for (int i = 0; i < MAXSPAN; i++) {
+            if (__ballot(i < dn) == 0) break;  // (no span of this wave's is that long)
+            const int p = d0 + i;
+            if (i < dn && p >= 0 && p < 64) atomicOr(&P.cover[e][axis][p], 1u << g);
+        }
     }
 }
 
 // Phase B — one wavefront pass = the 64 pixel columns or the 64 pixel rows of one env: the (at most two, adjacent)
 // covering grid indices and their texel coordinates as one word, and, from the row pass, the three row-class masks
 // (pg_render.h compose_hand_build: same rules).  P.soft_rows / P.hard_rows must be complete (the game's cell phase).
-template <int GRID, int E>
-PG_D void prep_axes(PrepLds<GRID, E>& P, const PrepOut& out, int env0, int wave, int nwaves, int lane) {
+template <int GRID, int MAXSPAN, int E>
+PG_D void prep_axes(PrepLds<GRID, E, MAXSPAN>& P, const PrepOut& out, int env0, int wave, int nwaves, int lane) {
     for (int blk = wave; blk < 2 * E; blk += nwaves) {  // wave-uniform
         const int e = blk >> 1, axis = blk & 1;
         const PrepView& v = P.view[e];
@@ -155,32 +261,28 @@ PG_D void prep_axes(PrepLds<GRID, E>& P, const PrepOut& out, int env0, int wave,
         const int ia = n >= 1 ? __builtin_ctz(m) : -1;
         const uint32_t m2 = m & (m - 1u);
         const int ib = n >= 2 ? __builtin_ctz(m2) : -1;
-        const bool ok = n <= 2 && !(ib >= 0 && ib != ia + 1);
-        int ta = 0, tb = 0;
-        if (ia >= 0) {
-            const int4 sp = P.span[e][axis][ia];
-            ta = sample_index(sp.z, sp.w, lane - sp.x, sp.y);
-        }
-        if (ib >= 0) {
-            const int4 sp = P.span[e][axis][ib];
-            tb = sample_index(sp.z, sp.w, lane - sp.x, sp.y);
-        }
-        const uint32_t word = static_cast<uint32_t>(ta & 0xff) | (static_cast<uint32_t>(tb & 0xff) << 8) |
+        bool ok = n <= 2 && !(ib >= 0 && ib != ia + 1);
+        const uint32_t wa = ia >= 0 ? P.span[e][axis][ia] : 0u, wb = ib >= 0 ? P.span[e][axis][ib] : 0u;
+        const int da = static_cast<int32_t>(wa << 16) >> 16, db = static_cast<int32_t>(wb << 16) >> 16;
+        const int ta = ia >= 0 ? P.texel[wa >> 24][lane - da] : 0;
+        const int tb = ib >= 0 ? P.texel[wb >> 24][lane - db] : 0;
+        const uint32_t word = static_cast<uint32_t>(ta) | (static_cast<uint32_t>(tb) << 8) |
                               (static_cast<uint32_t>(ia >= 0 ? ia : 0) << 16) | (ia >= 0 ? 1u << 24 : 0u) | (ib >= 0 ? 1u << 25 : 0u);
         out.axes[size_t(env0 + e) * 128 + axis * 64 + lane] = word;
-        const bool any_bad = __ballot(!ok || ta > 255 || tb > 255) != 0;
         if (axis == 1) {
-            if (v.th2 > 0) {  // texel rows in the layer's second, shorter texture
+            if (v.th2 > 0) {  // texel rows in the layer's second, shorter texture: nested in the first's span, or the complete path
                 uint32_t w2 = 0;
                 if (ia >= 0) {
-                    const int4 sp = P.span2[e][ia];
-                    const int i = lane - sp.x;
-                    if (sp.w > 0 && i >= 0 && i < sp.y) w2 |= static_cast<uint32_t>(sample_index(sp.z, sp.w, i, sp.y) & 0xff) | (1u << 24);
+                    const uint32_t s2 = P.span[e][2][ia];
+                    const int d2 = static_cast<int32_t>(s2 << 16) >> 16, n2 = (s2 >> 16) & 0xffu, i = lane - d2;
+                    ok = ok && !(n2 > 0 && (d2 != da || n2 > static_cast<int>((wa >> 16) & 0xffu)));
+                    if (n2 > 0 && i >= 0 && i < n2) w2 |= static_cast<uint32_t>(P.texel[s2 >> 24][i]) | (1u << 24);
                 }
                 if (ib >= 0) {
-                    const int4 sp = P.span2[e][ib];
-                    const int i = lane - sp.x;
-                    if (sp.w > 0 && i >= 0 && i < sp.y) w2 |= (static_cast<uint32_t>(sample_index(sp.z, sp.w, i, sp.y) & 0xff) << 8) | (1u << 25);
+                    const uint32_t s2 = P.span[e][2][ib];
+                    const int d2 = static_cast<int32_t>(s2 << 16) >> 16, n2 = (s2 >> 16) & 0xffu, i = lane - d2;
+                    ok = ok && !(n2 > 0 && (d2 != db || n2 > static_cast<int>((wb >> 16) & 0xffu)));
+                    if (n2 > 0 && i >= 0 && i < n2) w2 |= (static_cast<uint32_t>(P.texel[s2 >> 24][i]) << 8) | (1u << 25);
                 }
                 out.axes2[size_t(env0 + e) * 64 + lane] = w2;
             }
@@ -199,14 +301,14 @@ PG_D void prep_axes(PrepLds<GRID, E>& P, const PrepOut& out, int env0, int wave,
                 P.meta[e][PM_HARD + 1] = static_cast<uint32_t>(m_hard >> 32);
             }
         }
-        if (any_bad && lane == 0) atomicOr(&P.fat[e], 1u);
+        if (__ballot(!ok) != 0 && lane == 0) atomicOr(&P.fat[e], 1u);
     }
 }
 
 // The last phase: the envs' meta lines, coalesced.  `counts[e]` = draws of env e (> kPrepDraws: fat).  Needs a barrier
 // in front (every phase has written its part of P.meta / P.fat).
-template <int GRID, int E>
-PG_D void prep_meta_out(PrepLds<GRID, E>& P, const PrepOut& out, int env0, const int32_t* counts, int tid, int nthreads) {
+template <int GRID, int MAXSPAN, int E>
+PG_D void prep_meta_out(PrepLds<GRID, E, MAXSPAN>& P, const PrepOut& out, int env0, const int32_t* counts, int tid, int nthreads) {
     for (int q = tid; q < E * kPrepMetaWords; q += nthreads) {
         const int e = q / kPrepMetaWords, w = q - e * kPrepMetaWords;
         if (!P.view[e].active && !P.fat[e]) continue;  // (an env the kernel sits out writes nothing; a fat one its flag)
@@ -259,6 +361,98 @@ PG_D ComposeRegs prep_regs(const PrepMeta& M, uint32_t colw, uint32_t roww, uint
     R.soft = M.mask(PM_SOFT);
     R.hard = M.mask(PM_HARD);
     return R;
+}
+
+PG_D void prep_draw_store(uint32_t* at, const Blit& b);
+
+// ---- draws: cull first, finish the survivors densely ---------------------------------------------------------------
+// One lane = one draw of the env's list.  Most draws of a level are off the screen (coinrun shows 13 of 64 tile columns)
+// or dead particles, and render_texture's arithmetic behind its cull test is ten times that in front of it; so a lane
+// first does the head of both axes (pg_geom.h axis_head: the reference's own cull, on the reference's own numbers) and
+// the survivors queue up — in list order, the two envs of a wavefront one behind the other — in a small worklist, from
+// which the tails are done 64 at a time.
+constexpr int kPrepQueue = 64;
+struct PrepDrawEntry {  // 24 bytes
+    float dx, dlx, dy, dly;  // destination before cropping, both axes
+    float scale;
+    uint32_t misc;           // texture | flip_h << 8 | flip_v << 9 | alpha modulation << 16 | second env of the wave << 31
+};
+struct PrepDrawQueue {
+    PrepDrawEntry e[kPrepQueue];
+};
+// What a game's lane knows about its draw before render_texture starts (renderer.cpp:5-7: texture, position, scale,
+// alpha, flips); `go` false = no draw call at all.
+struct PrepDraw {
+    bool go, flip_h, flip_v;
+    int tex;
+    float wx, wy, scale, alpha;
+};
+// State of a wavefront's pass over the draw lists of its two envs.
+struct PrepDrawPass {
+    int queued;          // entries waiting in the worklist
+    int done[2];         // draws stored so far, per env of the wave
+};
+// The tails of everything queued, ranks, stores.  desc: the atlas descriptor table (in LDS); cam: the two envs' cameras.
+PG_D void prep_draws_flush(PrepDrawQueue& Q, PrepDrawPass& st, const int4* desc, const Camera& cam_a, const Camera& cam_b,
+                           uint32_t* draws_a, uint32_t* draws_b, int lane) {
+    if (st.queued == 0) return;  // wave-uniform
+    wave_order();  // the entries were written by other lanes of this wave
+    const bool mine = lane < st.queued;
+    const PrepDrawEntry en = Q.e[mine ? lane : 0];
+    const bool is_b = (en.misc >> 31) != 0;
+    const Camera& cam = is_b ? cam_b : cam_a;
+    const int4 d = desc[en.misc & 0xffu];
+    Span x, y;
+    bool has = mine;
+    has = has && axis_tail(cam.sw, cam.scale, d.y, en.scale, (en.misc >> 8) & 1u, AxisHead{en.dx, en.dlx}, x);
+    has = has && axis_tail(cam.sh, cam.scale, d.z, en.scale, false, AxisHead{en.dy, en.dly}, y);
+    const unsigned long long m_a = __ballot(has && !is_b), m_b = __ballot(has && is_b);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int rank = is_b ? st.done[1] + __popcll(m_b & below) : st.done[0] + __popcll(m_a & below);
+    if (has && rank < kPrepDraws) {
+        Blit b;
+        b.dx = x.d0, b.dw = x.dn, b.sx = x.s0, b.sw = x.sn;
+        b.dy = y.d0, b.dh = y.dn, b.sy = y.s0, b.sh = y.sn;
+        b.tex_off = d.x;
+        b.tex_w = d.y;
+        const uint32_t flips = (en.misc >> 8) & 3u;
+        b.flip_mod = static_cast<int32_t>((en.misc >> 16) & 0xffu) | ((flips & 1u) ? kFlipH : ((flips & 2u) ? kFlipV : 0));  // (resolve_draw)
+        b.rot_sn = 0;
+        b.rot_cs = 65536;
+        prep_draw_store((is_b ? draws_b : draws_a) + size_t(rank) * kBlitWords, b);
+    }
+    st.done[0] += __popcll(m_a);
+    st.done[1] += __popcll(m_b);
+    st.queued = 0;
+    wave_order();  // … and may be overwritten from here on
+}
+// One pass: this lane's draw (of env a or b of the wave) through the heads; survivors appended to the worklist in lane
+// order (= list order).  Every lane of the wave calls this, with valid = false where there is no draw.
+PG_D void prep_draws_pass(PrepDrawQueue& Q, PrepDrawPass& st, const int4* desc, const Camera& cam_a, const Camera& cam_b,
+                          uint32_t* draws_a, uint32_t* draws_b, bool valid, bool is_b, const PrepDraw& p, int lane) {
+    const Camera& cam = is_b ? cam_b : cam_a;
+    AxisHead hx{0.0f, 0.0f}, hy{0.0f, 0.0f};
+    bool alive = valid && p.go;
+    if (alive) {
+        const int4 d = desc[p.tex];
+        alive = axis_head(cam.px, cam.sw, cam.scale, d.y, p.wx, p.scale, false, hx);
+        alive = axis_head(cam.py, cam.sh, cam.scale, d.z, p.wy, p.scale, true, hy) && alive;
+    }
+    const unsigned long long m = __ballot(alive);
+    const int n = __popcll(m);
+    if (n == 0) return;  // wave-uniform
+    if (st.queued + n > kPrepQueue) prep_draws_flush(Q, st, desc, cam_a, cam_b, draws_a, draws_b, lane);
+    if (alive) {
+        int mod = 255;
+        if (p.alpha != 1.0f) mod = static_cast<int>(255 * p.alpha) & 0xff;  // Uint8 parameter (renderer.cpp:56-57)
+        PrepDrawEntry en;
+        en.dx = hx.d, en.dlx = hx.dl, en.dy = hy.d, en.dly = hy.dl;
+        en.scale = p.scale;
+        en.misc = static_cast<uint32_t>(p.tex) | (p.flip_h ? 1u << 8 : 0u) | (p.flip_v ? 1u << 9 : 0u) |
+                  (static_cast<uint32_t>(mod) << 16) | (is_b ? 1u << 31 : 0u);
+        Q.e[st.queued + __popcll(m & ((1ull << lane) - 1ull))] = en;
+    }
+    st.queued += n;
 }
 
 // A resolved draw as the pre-pass stores it: pg_render.h BlitWords, kBlitWords per draw, draws of an env back to back.

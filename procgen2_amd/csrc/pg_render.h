@@ -773,10 +773,16 @@ PG_D ReplayState<kGroup> replay_begin(const AtlasView& atlas, const Blit& mine, 
     return st;
 }
 
+// (Measured and rejected, round 4: software-pipelining the groups — the texels of group k + 1 requested BEFORE group k is
+// blended, -DPG_REPLAY_PIPELINED below.  Bit-exact in all seven games, and slower: bossfight's render 0.779 -> 0.809 ms,
+// jumper's 0.843 -> 0.853.  These kernels are bound by vector instructions at four clocks apiece (SQ_ACTIVE_INST_VALU:
+// 4.6 clocks per SQ_INSTS_VALU), not by the length of the pass's chain of round trips; the copies that free the state for
+// the next request are more instructions.)
 template <int kGroup = 4, bool kRotInGroups = false, bool kPacked = true>
 PG_D void replay_finish(uint32_t* fb, const AtlasView& atlas, const Blit& mine, ReplayState<kGroup>& st, int lane,
                         int row_lo, int row_hi) {
     wave_order();  // what the caller put into these rows in the meantime
+#ifndef PG_REPLAY_PIPELINED
     for (;;) {
 #pragma unroll
         for (int g = 0; g < kGroup; g++) {
@@ -786,6 +792,29 @@ PG_D void replay_finish(uint32_t* fb, const AtlasView& atlas, const Blit& mine, 
         if (st.mask == 0) break;
         replay_group<kGroup, kRotInGroups, kPacked>(atlas, mine, st, lane, row_lo, row_hi, fb);
     }
+#else
+    for (;;) {
+        uint32_t texel[kGroup];
+        int idx[kGroup], mod[kGroup];
+#pragma unroll
+        for (int g = 0; g < kGroup; g++) {
+            texel[g] = st.texel[g];
+            idx[g] = st.idx[g];
+            mod[g] = st.mod[g];
+        }
+        const bool more = st.mask != 0;
+        const bool lone_next = more && ((st.lones >> __builtin_ctzll(st.mask)) & 1ull) != 0;
+        if (more && !lone_next)  // the next group's texels leave now (st.texel / idx / mod are overwritten: copied above)
+            replay_group<kGroup, kRotInGroups, kPacked>(atlas, mine, st, lane, row_lo, row_hi, nullptr);
+#pragma unroll
+        for (int g = 0; g < kGroup; g++) {
+            if (idx[g] >= 0) blend_into(fb, idx[g], texel[g], mod[g]);
+            wave_order();  // draws may overlap
+        }
+        if (!more) break;
+        if (lone_next) replay_group<kGroup, kRotInGroups, kPacked>(atlas, mine, st, lane, row_lo, row_hi, fb);  // the big draw, then a group
+    }
+#endif
 }
 
 // kRotInGroups: small rotated draws (a bullet, a puff: ≤ 64 pixels of bounding box on my rows) share a memory round

@@ -16,16 +16,23 @@ for SET in "$@"; do
 done
 python3 - <<PY
 import csv, glob, json, collections
-out = collections.OrderedDict()
-for d in sorted(glob.glob("/tmp/pq_[0-9]*/")):
-    rows = collections.defaultdict(dict)
-    for fn in glob.glob(d + "*/*counter_collection.csv"):
-        for r in csv.DictReader(open(fn)):
-            if "${PG_KERNEL:-render_kernel}" not in r["Kernel_Name"]: continue
-            rows[int(r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
-    order = sorted(rows)[-8:]
-    for c in sorted({k for d_ in order for k in rows[d_]}):
-        out[c] = sum(rows[d_].get(c, 0.0) for d_ in order) / max(1, len(order))
-for k, v in out.items(): print("%-36s %.6g" % (k, v))
-json.dump(out, open("$R/gpurun_out/${TAG}_pmc.json", "w"), indent=1)
+result = collections.OrderedDict()
+for kernel in "${PG_KERNEL:-render_kernel}".split(","):   # (several kernels: comma-separated)
+    out = collections.OrderedDict()
+    for d in sorted(glob.glob("/tmp/pq_[0-9]*/")):
+        rows = collections.defaultdict(dict)
+        for fn in glob.glob(d + "*/*counter_collection.csv"):
+            for r in csv.DictReader(open(fn)):
+                if kernel not in r["Kernel_Name"]: continue
+                rows[int(r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
+        order = sorted(rows)[-8:]
+        for c in sorted({k for d_ in order for k in rows[d_]}):
+            out[c] = sum(rows[d_].get(c, 0.0) for d_ in order) / max(1, len(order))
+    print("== " + kernel)
+    for k, v in out.items(): print("%-36s %.6g" % (k, v))
+    if "SQ_WAVES" in out:
+        for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM"):
+            if k in out: print("  %-34s %.1f per wave" % (k, out[k] / out["SQ_WAVES"]))
+    result[kernel] = out
+json.dump(result if len(result) > 1 else list(result.values())[0], open("$R/gpurun_out/${TAG}_pmc.json", "w"), indent=1)
 PY
