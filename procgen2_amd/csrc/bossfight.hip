@@ -19,6 +19,9 @@
 #include "pg_frame.h"
 #include "pg_gang.h"
 #include "pg_geom.h"
+#ifndef PG_REPLAY_SHARE_AREA
+#define PG_REPLAY_SHARE_AREA 1024  // pg_render.h: a plain draw of that many pixels (the boss, its shield) is done by both waves
+#endif
 #include "pg_render.h"
 #include "pg_rng.h"
 #include "pg_sincos.h"

@@ -41,6 +41,7 @@
 #error "caveflyer: unknown PG_VARIANT"
 #endif
 #include "pg_rooms.h"
+#include "pg_prepass.h"
 #include "pg_sincos.h"
 #include "pg_tiles.h"
 
@@ -110,6 +111,7 @@ struct State {
     float* sh;       // [n][SH_COUNT][kShots]
     float* pf;       // [n][PF_COUNT][kPuffSlots]
     const uint8_t* ranks;  // pg_order.h equal-key sort ranks
+    PrepOut prep;          // what setup_kernel leaves for render_kernel (pg_prepass.h); not part of the state blob
 };
 
 PG_D float& SF(const State& s, int field, int env) { return s.f[size_t(field) * s.n + env]; }
@@ -726,15 +728,15 @@ __global__ void __launch_bounds__(64, PG_CAVEFLYER_WAVES) logic_kernel(State s, 
 
 
 // render_game(true) (caveflyer.cpp:413-440): one workgroup of two wavefronts per env (pg_render.h).
-__global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
-                                                    int flags) {
-    const int env = blockIdx.x;
-    if (mask && !mask[env]) return;
+constexpr int kGrid = 16;  // 64 px / 8 px per tile → at most 10 columns/rows in view
+constexpr int kSpan = 16;  // a tile covers up to ten pixels per axis (pg_render.h compose_spans MAXSPAN)
+
+// The complete frame of one env by its workgroup, set-up included: the frames the pre-pass marks fat, the draw-list
+// replay (flags bit 0) and kDebugNoPrepass.
+PG_D void render_full(const State& s, const AtlasView& atlas, const StepIO& io, int flags, int env, uint32_t* fb,
+                      ComposeLds<kGrid>& L) {
     const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // two wavefronts per env (pg_render.h)
     constexpr int halves = 2;
-    __shared__ alignas(16) uint32_t fb[kFbWords];
-    constexpr int kGrid = 16;  // 64 px / 8 px per tile → at most 10 columns/rows in view
-    __shared__ ComposeLds<kGrid> L;
 
     const Camera cam{SF(s, F_CAMX, env), SF(s, F_CAMY, env), 64.0f, 64.0f, 0.5f * 64.0f / 64.0f};
     const int sflags = SI(s, I_FLAGS, env);
@@ -811,7 +813,7 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
     BgAxis bga{};  // this wave's axis of it (wave 0: x, wave 1: y), resolved along with the tile spans
     bool composed = false;
     if (!(flags & 1) && cols <= kGrid && rows <= kGrid) {
-        compose_spans<kGrid, 16>(fb, L, cam, x0, y0, cols, rows, wall_d.y, wall_d.z, kUnitPx / wall_d.y, lane, 0, half, halves,
+        compose_spans<kGrid, kSpan>(fb, L, cam, x0, y0, cols, rows, wall_d.y, wall_d.z, kUnitPx / wall_d.y, lane, 0, half, halves,
                                  soft_rows_of(bg_soft, wall_d.w), hard_rows_of(bg_soft, wall_d.w), &bg_draw, &bga);
 #pragma unroll
         for (int k = half; k < kGrid * kGrid / 64; k += halves) {
@@ -949,6 +951,278 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
     }
     // each wave stores the rows it owns (pg_render.h wave_replay_rows): no barrier
     wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
+}
+
+// ------------------------------------------------------------------------------------------------
+// The render pre-pass (pg_prepass.h; coinrun.hip's setup_kernel is the commented model): tile spans, per-pixel
+// candidates, the cell table and the resolved, culled SPRITES of kPrepEnvs envs per workgroup.  The rotated draws —
+// particles, bullets, the ship — stay with the render wave: resolve_rotated_at has no division and no cull, and their
+// sines and cosines come from the logic kernel.  Reference arithmetic moved here unchanged: renderer.cpp:5-82,
+// tilemap.cpp:280-289 (the window), common_systems.cpp:26-48 (sprites).
+// ------------------------------------------------------------------------------------------------
+constexpr int kPrepEnvs = 8, kPrepThreads = 256;
+enum { GW_SHOTS = 0, GW_SHIP_X, GW_SHIP_Y, GW_SHIP_SN, GW_SHIP_CS, GW_CAM_X, GW_CAM_Y };  // PM_GAME words: s_next | s_count << 16, the ship, the camera
+
+struct PrepEnv {
+    int32_t n_draw, s_count;
+};
+struct SetupLds {
+    PrepLds<kGrid, kPrepEnvs, kSpan> P;
+    PrepEnv env[kPrepEnvs];
+    int4 desc[kTexCount];
+    uint32_t draw_order[kPrepEnvs][kEntStride / 4];  // EB_DRAW of every env: fetched before anything needs it
+    uint32_t row_valid[kPrepEnvs][kGrid / 4];
+    int32_t counts[kPrepEnvs];
+    PrepDrawQueue queue[kPrepThreads / 64];
+};
+
+__global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView atlas, const uint8_t* mask) {
+    __shared__ SetupLds S;
+    PrepLds<kGrid, kPrepEnvs, kSpan>& P = S.P;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int env0 = blockIdx.x * kPrepEnvs;
+    const PrepOut& out = s.prep;
+
+    // ---- one memory round trip: descriptor table, the envs' scalars (lane = env), their draw orders
+    for (int q = tid; q < kPrepEnvs * 2 * 64; q += kPrepThreads) (&P.cover[0][0][0])[q] = 0u;
+    if (tid < kTexCount) S.desc[tid] = atlas.desc[tid];
+    static_assert(kTexCount <= kPrepThreads && kPrepEnvs * (kEntStride / 4) <= kPrepThreads, "one word per thread");
+    if (tid < kPrepEnvs * (kEntStride / 4)) {
+        const int e = tid / (kEntStride / 4), w = tid - e * (kEntStride / 4);
+        if (env0 + e < s.n) S.draw_order[e][w] = reinterpret_cast<const uint32_t*>(&EB(s, EB_DRAW, 0, env0 + e))[w];
+    }
+    Camera cam{};
+    int backdrop = 0;
+    float bgshift = 0.0f;
+    bool active = false;
+    uint32_t game_words[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    if (tid < kPrepEnvs) {
+        const int e = tid, env = env0 + e;
+        active = env < s.n && (!mask || mask[env]);
+        if (active) {
+            cam = Camera{SF(s, F_CAMX, env), SF(s, F_CAMY, env), 64.0f, 64.0f, 0.5f * 64.0f / 64.0f};
+            game_words[GW_CAM_X] = __float_as_uint(cam.px);
+            game_words[GW_CAM_Y] = __float_as_uint(cam.py);
+            backdrop = SI(s, I_BACKDROP, env);
+            bgshift = SF(s, F_BGSHIFT, env);
+            const int sflags = SI(s, I_FLAGS, env);
+            PrepEnv pe{};
+            pe.n_draw = (sflags & kFlagListed) ? SI(s, I_NDRAW, env) : 0;  // empty right after a reset
+            pe.s_count = SI(s, I_SCOUNT, env);
+            S.env[e] = pe;
+            game_words[GW_SHOTS] = pack_halves(SI(s, I_SNEXT, env), pe.s_count);
+            game_words[GW_SHIP_X] = __float_as_uint(SF(s, F_AX, env));
+            game_words[GW_SHIP_Y] = __float_as_uint(SF(s, F_AY, env));
+            game_words[GW_SHIP_SN] = __float_as_uint(SF(s, F_SHIP_SN, env));
+            game_words[GW_SHIP_CS] = __float_as_uint(SF(s, F_SHIP_CS, env));
+        }
+    }
+    __syncthreads();
+    // ---- per env (lane = env): camera, tile window, background draw — render_full's preamble
+    if (tid < kPrepEnvs) {
+        const int e = tid;
+        PrepView v{};
+        P.fat[e] = 0;
+        P.soft_rows[e] = P.hard_rows[e] = 0;
+        S.counts[e] = 0;
+        if (active) {
+            v.cam = cam;
+            const int4 d = S.desc[kTexSpace + backdrop];
+            const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
+            const float extra = aspect - 1.0f;
+            v.bg = BgDraw{d, -bgshift * extra, 0.0f, 64.0f * kUnitPx / d.z};  // caveflyer.cpp:427-432
+            const float vx = (cam.px - cam.sw * 0.5f / cam.scale) * kPxUnit;  // tilemap.cpp:280-289
+            const float vy = (cam.py - cam.sh * 0.5f / cam.scale) * kPxUnit;
+            const float vw = cam.sw * kPxUnit / cam.scale, vh = cam.sh * kPxUnit / cam.scale;
+            v.x0 = static_cast<int>(floorf(vx));
+            v.y0 = static_cast<int>(floorf(vy));
+            v.cols = static_cast<int>(ceilf(vx + vw)) - v.x0 + 1;
+            v.rows = static_cast<int>(ceilf(vy + vh)) - v.y0 + 1;
+            const int4 wall_d = S.desc[kTexWall];
+            v.tw = wall_d.y;
+            v.th = wall_d.z;
+            v.th2 = 0;
+            v.tile_scale = kUnitPx / wall_d.y;
+            if (v.cols > kGrid || v.rows > kGrid) {
+                P.fat[e] = 1;
+                active = false;
+            }
+            P.soft_rows[e] = static_cast<uint32_t>(soft_rows_of(d.w, wall_d.w));
+            P.hard_rows[e] = static_cast<uint32_t>(hard_rows_of(d.w, wall_d.w));
+#pragma unroll
+            for (int k = 0; k < kPrepKinds; k++) P.meta[e][PM_KINDS + k] = kNoTexel;
+            P.meta[e][PM_KINDS + 0] = static_cast<uint32_t>(wall_d.x) * 4u;  // the one tile kind
+#pragma unroll
+            for (int k = 0; k < 7; k++) P.meta[e][PM_GAME + k] = game_words[k];
+            prep_row_valid<kGrid, H>(v.y0, S.row_valid[e]);
+        }
+        v.active = active ? 1 : 0;
+        P.view[e] = v;
+    }
+    __syncthreads();
+
+    // ---- the cell table: lane = (env, grid column), one 16-byte load of the column-major map (pg_prepass.h) …
+    const int cell_e = tid / kGrid, cell_c = tid - cell_e * kGrid;
+    bool cell_lane = false, cell_x_ok = false;
+    uint32_t column[kGrid / 4] = {};
+    if (tid < kPrepEnvs * kGrid && P.view[cell_e].active) {
+        cell_lane = true;
+        prep_column_fetch<kGrid, W, H>(s.tiles + size_t(env0 + cell_e) * kTileStride, P.view[cell_e].x0 + cell_c, P.view[cell_e].y0, cell_x_ok, column);
+    }
+    // … the spans are worked out while it travels …
+    prep_spans<kGrid, kSpan, kPrepEnvs>(P, tid, kPrepThreads);
+    // … then the kind bytes: wall → 0, empty → none
+    if (cell_lane) {
+        uint32_t in_rows[kGrid / 4], kinds[kGrid / 4];
+        prep_column_rows<kGrid>(column, S.row_valid[cell_e], cell_x_ok, kWall, in_rows);  // out of bounds is a wall (tilemap.h:78-83)
+#pragma unroll
+        for (int w = 0; w < kGrid / 4; w++) {
+            const uint32_t t = in_rows[w] & 0x07070707u;
+            const uint32_t any = (t | (t >> 1) | (t >> 2)) & 0x01010101u;  // 1 where the cell is not empty
+            kinds[w] = ~(any * 0xffu);                                    // kind 0 for walls; 0xff: no tile
+        }
+        prep_column_store<kGrid>(out.cells + size_t(env0 + cell_e) * (kGrid * kGrid), cell_c, kinds);
+    }
+    __syncthreads();
+    prep_axes<kGrid, kSpan, kPrepEnvs>(P, out, env0, wave, kPrepThreads / 64, lane);
+
+    // ---- the positive-z sprites (common_systems.cpp:26-48: goal, meteors, targets, enemies) in draw order.  Two envs per
+    // wavefront, cull first (pg_prepass.h prep_draws_pass).
+    static_assert(kPrepEnvs == 2 * (kPrepThreads / 64), "two envs per wavefront");
+    {
+        const int ea = 2 * wave, eb = 2 * wave + 1;
+        const bool on_a = P.view[ea].active != 0, on_b = P.view[eb].active != 0;
+        const Camera cam_a = P.view[ea].cam, cam_b = P.view[eb].cam;
+        const int cnt_a = on_a ? S.env[ea].n_draw : 0, cnt_b = on_b ? S.env[eb].n_draw : 0;
+        uint32_t* const draws_a = out.draws + size_t(env0 + ea) * kPrepDraws * kBlitWords;
+        uint32_t* const draws_b = out.draws + size_t(env0 + eb) * kPrepDraws * kBlitWords;
+        PrepDrawPass st{0, {0, 0}};
+        PrepDrawQueue& Q = S.queue[wave];
+        for (int base = 0; base < cnt_a + cnt_b; base += 64) {  // wave-uniform
+            const int q = base + lane;
+            const bool is_b = q >= cnt_a;
+            const int e = is_b ? eb : ea, env = env0 + e;
+            const int slot = is_b ? q - cnt_a : q;
+            const bool valid = q < cnt_a + cnt_b;
+            PrepDraw p{false, false, false, kTexKind, 0.0f, 0.0f, 1.0f, 1.0f};
+            if (valid) {
+                const int ent = (S.draw_order[e][slot >> 2] >> (8 * (slot & 3))) & 0xffu;
+                const int kind = EB(s, EB_INFO, ent, env) & kKindMask;
+                const float ex = EF(s, EF_X, ent, env), ey = EF(s, EF_Y, ent, env);
+                const float scale = 1.0f * 0.8f;
+                p.tex = kTexKind + kind;
+                p.wx = (ex + -0.4f) * kUnitPx;
+                p.wy = (ey + -0.4f) * kUnitPx;
+                p.scale = scale * kUnitPx / S.desc[p.tex].y;
+                p.go = true;
+            }
+            prep_draws_pass(Q, st, S.desc, cam_a, cam_b, draws_a, draws_b, valid, is_b, p, lane);
+        }
+        prep_draws_flush(Q, st, S.desc, cam_a, cam_b, draws_a, draws_b, lane);
+        if (lane == 0) {  // (the render wave's one pass: particles, these sprites, the bullets, the ship — 64 lanes)
+            const int room_a = 64 - kPuffs - 1 - (on_a ? S.env[ea].s_count : 0), room_b = 64 - kPuffs - 1 - (on_b ? S.env[eb].s_count : 0);
+            S.counts[ea] = st.done[0] > room_a ? kPrepDraws + 1 : st.done[0];
+            S.counts[eb] = st.done[1] > room_b ? kPrepDraws + 1 : st.done[1];
+        }
+    }
+    __syncthreads();
+    prep_meta_out<kGrid, kSpan, kPrepEnvs>(P, out, env0, S.counts, tid, kPrepThreads);
+}
+
+// render_game(true) (caveflyer.cpp:413-440): one workgroup of two wavefronts per env; a lean frame starts from what
+// setup_kernel left (coinrun.hip's render_kernel is the commented model).
+__global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
+                                                    int flags) {
+    const int env = blockIdx.x;
+    if (mask && !mask[env]) return;
+    const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int halves = 2;
+    __shared__ alignas(16) uint32_t fb[kFbWords];
+    __shared__ ComposeLds<kGrid> L;
+    const PrepMeta M{s.prep.meta + size_t(env) * kPrepMetaWords};
+    const uint32_t colw = s.prep.axes[size_t(env) * 128 + lane], roww = s.prep.axes[size_t(env) * 128 + 64 + lane];
+    const uint32_t kind_off = M.w[PM_KINDS + (lane & (kPrepKinds - 1))];
+    const uint32_t two16 = reinterpret_cast<const uint16_t*>(s.prep.cells)[size_t(env) * (kGrid * kGrid / 2) + half * 64 + lane];
+    const DescRegs descs = DescRegs::load(atlas, lane);
+    // the rotated draws' inputs (per-env contiguous tables): particles in lanes 0-9; bullets and the ship behind the sprites
+    float puff_life = 0.0f, puff_x = 0.0f, puff_y = 0.0f, puff_dx = 0.0f, puff_dy = 0.0f;
+    int puff_sn = 0, puff_cs = 0;
+    if (lane < kPuffs) {
+        puff_life = PF(s, PF_LIFE, lane, env);
+        puff_x = PF(s, PF_X, lane, env);
+        puff_y = PF(s, PF_Y, lane, env);
+        puff_dx = PF(s, PF_DX, lane, env);
+        puff_dy = PF(s, PF_DY, lane, env);
+        puff_sn = __float_as_int(PF(s, PF_SN, lane, env));
+        puff_cs = __float_as_int(PF(s, PF_CS, lane, env));
+    }
+    const int n_vis = M.draws();
+    const int s_next = static_cast<int>(M.w[PM_GAME + GW_SHOTS] & 0xffffu), s_count = static_cast<int>(M.w[PM_GAME + GW_SHOTS] >> 16);
+    const int spr_lane0 = kPuffs, shot_lane0 = kPuffs + n_vis;
+    const bool is_puff = lane < kPuffs, is_spr = lane >= spr_lane0 && lane < shot_lane0;
+    Blit mine = prep_draw_load(s.prep.draws + (size_t(env) * kPrepDraws + (lane - spr_lane0)) * kBlitWords, is_spr);
+    float shot_frame = -1.0f, shot_x = 0.0f, shot_y = 0.0f;
+    int shot_sn = 0, shot_cs = 0;
+    const int shot_i = lane - shot_lane0;  // bullets newest first, then the ship
+    if (shot_i >= 0 && shot_i < s_count) {
+        const int k = (kShots + s_next - 1 - shot_i) % kShots;
+        shot_frame = SH(s, SH_FRAME, k, env);
+        shot_x = SH(s, SH_X, k, env);
+        shot_y = SH(s, SH_Y, k, env);
+        shot_sn = __float_as_int(SH(s, SH_SN, k, env));
+        shot_cs = __float_as_int(SH(s, SH_CS, k, env));
+    } else if (shot_i == s_count) {
+        shot_x = __uint_as_float(M.w[PM_GAME + GW_SHIP_X]);
+        shot_y = __uint_as_float(M.w[PM_GAME + GW_SHIP_Y]);
+        shot_sn = static_cast<int>(M.w[PM_GAME + GW_SHIP_SN]);
+        shot_cs = static_cast<int>(M.w[PM_GAME + GW_SHIP_CS]);
+    }
+    prep_cells_expand<kGrid>(L, two16, kind_off, half, lane);
+    const ComposeRegs R = prep_regs<kGrid>(M, colw, roww, 0u, lane);
+    __syncthreads();  // the cell table is complete
+    if ((flags & (1 | kDebugNoPrepass)) || M.fat()) {  // (wave-uniform)
+        render_full(s, atlas, io, flags, env, fb, L);
+        return;
+    }
+    const int row_lo = half * (kObsH / halves), row_hi = (half + 1) * (kObsH / halves);
+    compose_rows_from<kGrid, false, false>(fb, L, atlas, R, lane, flags, half, halves);
+    // one draw per lane in the reference's order: particles (common_systems.cpp:374-397: rotated, fading), the sprites the
+    // pre-pass resolved, System_Agent::render (:291-327: bullets newest first, then the ship)
+    const Camera cam{0.0f, 0.0f, 64.0f, 64.0f, 0.5f * 64.0f / 64.0f};  // (position: see below)
+    int want_tex = kTexShip;
+    bool go = shot_i == s_count;  // the ship
+    float size = 0.15f, alpha = 1.0f, rx = 0.0f, ry = 0.0f;
+    if (is_puff) {
+        want_tex = kTexPuff;
+        go = puff_life > 0.0f;
+    } else if (is_spr) {
+        go = false;
+    } else if (shot_i >= 0 && shot_i < s_count && shot_frame != -1.0f) {
+        go = true;
+        size = 0.1f;
+        want_tex = (shot_frame == 0.0f) ? kTexLaser : kTexBoom + static_cast<int>(shot_frame - 1.0f);
+    }
+    const int4 d = descs.at(want_tex);
+    if (is_puff) {
+        const float lifespan = 3.0f;
+        const float life_ratio = (lifespan - puff_life) / lifespan;
+        alpha = 0.5f * (1.0f - life_ratio);
+        const float scale = 1.0f * (0.4f * life_ratio + 0.6f);
+        const float shift = life_ratio * 2.0f;
+        size = scale * kUnitPx / d.y;
+        rx = (puff_x + puff_dx * shift) * kUnitPx - size * d.y * 0.5f;
+        ry = (puff_y + puff_dy * shift) * kUnitPx - size * d.z * 0.5f;
+    } else {
+        rx = shot_x * kUnitPx - size * d.y * 0.5f;
+        ry = shot_y * kUnitPx - size * d.z * 0.5f;
+    }
+    bool has = is_spr;
+    if (go) {
+        const Camera at{__uint_as_float(M.w[PM_GAME + GW_CAM_X]), __uint_as_float(M.w[PM_GAME + GW_CAM_Y]), cam.sw, cam.sh, cam.scale};
+        has = resolve_rotated_at(at, d.y, d.z, d.x, rx, ry, is_puff ? puff_sn : shot_sn, is_puff ? puff_cs : shot_cs, size, alpha, mine);
+    }
+    wave_replay_rows(fb, atlas, mine, __ballot(has), lane, row_lo, row_hi);
+    wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, row_lo, row_hi);
 }
 
 // cenv_render's frame (render_game(false)) for one env: pg_frame.h; the draw list of render_kernel, one draw at a time.
@@ -1098,7 +1372,11 @@ class CaveflyerGame final : public Game {
         hipLaunchKernelGGL(frame_kernel, dim3(1), dim3(kFrameThreads), 0, st, s_, atlas_, env, FrameTarget{d_px, w, h});
         return true;
     }
+    size_t scratch_bytes(int n) const override { return prep_bytes(n, kGrid, kBlitWords, false); }
+    void bind_scratch(void* d_scratch, int n) override { s_.prep = prep_bind(d_scratch, n, kGrid, kBlitWords, false); }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
+        if (!(debug_flags & (1 | kDebugNoPrepass)))
+            hipLaunchKernelGGL(setup_kernel, dim3((s_.n + kPrepEnvs - 1) / kPrepEnvs), dim3(kPrepThreads), 0, st, s_, atlas_, mask);
         hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags);
     }
     // Same layout as oracle/pgo_caveflyer.cpp Caveflyer::dump_state.

@@ -19,6 +19,7 @@
 #include "pg_geom.h"
 #include "pg_order.h"
 #include "pg_prefetch.h"
+#include "pg_prepass.h"
 #include "pg_render.h"
 #include "pg_rng.h"
 #include "pg_tiles.h"
@@ -86,6 +87,7 @@ struct State {
     float* ef;       // [n][EF_COUNT][kEntStride]  per-env contiguous: a gang's and the render wavefronts' lanes index them by entity
     uint8_t* eb;     // [n][EB_COUNT][kEntStride]
     const uint8_t* ranks;  // pg_order.h equal-key sort ranks
+    PrepOut prep;          // what setup_kernel leaves for render_kernel (pg_prepass.h); not part of the state blob
 };
 
 PG_D float& SF(const State& s, int field, int env) { return s.f[size_t(field) * s.n + env]; }
@@ -528,15 +530,14 @@ __global__ void __launch_bounds__(64, PG_CLIMBER_WAVES) logic_kernel(State s, co
 }
 
 // render_game(true) (climber.cpp:431-459): one workgroup of two wavefronts per env (pg_render.h).
-__global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
-                                                    int flags) {
-    const int env = blockIdx.x;
-    if (mask && !mask[env]) return;
+constexpr int kGrid = 24;  // 64 px / 3.2 px per tile = 20 tiles → at most 22 columns/rows in view (24² = 9·64 cells; LDS: 7 envs per CU instead of 6)
+
+// The complete frame of one env by its workgroup, set-up included: the frames the pre-pass marks fat, the draw-list
+// replay (flags bit 0) and kDebugNoPrepass.
+PG_D void render_full(const State& s, const AtlasView& atlas, const StepIO& io, int flags, int env, uint32_t* fb,
+                      ComposeLds<kGrid>& L) {
     const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // two wavefronts per env (pg_render.h)
     constexpr int halves = 2;
-    __shared__ alignas(16) uint32_t fb[kFbWords];
-    constexpr int kGrid = 24;  // 64 px / 3.2 px per tile = 20 tiles → at most 22 columns/rows in view (24² = 9·64 cells; LDS: 7 envs per CU instead of 6)
-    __shared__ ComposeLds<kGrid> L;
 
     const Camera cam{W / 2.0f * kUnitPx, SF(s, F_CAMY, env), 64.0f, 64.0f, 0.2f * 64.0f / 64.0f};
     const int themes = SI(s, I_THEMES, env), sflags = SI(s, I_FLAGS, env);
@@ -664,6 +665,236 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
     }
     // each wave stores the rows it owns (pg_render.h wave_replay_rows): no barrier
     wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
+}
+
+// ------------------------------------------------------------------------------------------------
+// The render pre-pass (pg_prepass.h; coinrun.hip's setup_kernel is the commented model): tile spans, per-pixel
+// candidates, the cell table and the resolved, culled draws of kPrepEnvs envs per workgroup.
+// Reference arithmetic moved here unchanged: renderer.cpp:5-82, tilemap.cpp:172-198 (the window),
+// common_systems.cpp:41-63,272-298 (sprites, agent).
+// ------------------------------------------------------------------------------------------------
+constexpr int kPrepEnvs = 8, kPrepThreads = 256;
+
+struct PrepEnv {
+    int32_t sflags, n_draw, suit;
+    float avx, aphase, ax, ay;
+};
+struct SetupLds {
+    PrepLds<kGrid, kPrepEnvs, kMaxSpan> P;
+    PrepEnv env[kPrepEnvs];
+    int4 desc[kTexCount];
+    uint32_t draw_order[kPrepEnvs][kEntStride / 4];  // EB_DRAW of every env: fetched before anything needs it
+    uint32_t row_valid[kPrepEnvs][kGrid / 4];
+    int32_t counts[kPrepEnvs];
+    PrepDrawQueue queue[kPrepThreads / 64];
+};
+
+__global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView atlas, const uint8_t* mask) {
+    __shared__ SetupLds S;
+    PrepLds<kGrid, kPrepEnvs, kMaxSpan>& P = S.P;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int env0 = blockIdx.x * kPrepEnvs;
+    const PrepOut& out = s.prep;
+
+    // ---- one memory round trip: descriptor table, the envs' scalars (lane = env), their draw orders
+    for (int q = tid; q < kPrepEnvs * 2 * 64; q += kPrepThreads) (&P.cover[0][0][0])[q] = 0u;
+    if (tid < kTexCount) S.desc[tid] = atlas.desc[tid];
+    static_assert(kTexCount <= kPrepThreads, "one descriptor per thread");
+    if (tid < kPrepEnvs * (kEntStride / 4)) {
+        const int e = tid / (kEntStride / 4), w = tid - e * (kEntStride / 4);
+        if (env0 + e < s.n) S.draw_order[e][w] = reinterpret_cast<const uint32_t*>(&EB(s, EB_DRAW, 0, env0 + e))[w];
+    }
+    Camera cam{};
+    int themes = 0;
+    float bgshift = 0.0f;
+    bool active = false;
+    if (tid < kPrepEnvs) {
+        const int e = tid, env = env0 + e;
+        active = env < s.n && (!mask || mask[env]);
+        if (active) {
+            cam = Camera{W / 2.0f * kUnitPx, SF(s, F_CAMY, env), 64.0f, 64.0f, 0.2f * 64.0f / 64.0f};
+            themes = SI(s, I_THEMES, env);
+            bgshift = SF(s, F_BGSHIFT, env);
+            PrepEnv pe{};
+            pe.sflags = SI(s, I_FLAGS, env);
+            pe.n_draw = (pe.sflags & kFlagListed) ? SI(s, I_NDRAW, env) : 0;  // empty right after a reset (D2)
+            pe.suit = (themes >> 8) & 0xff;
+            pe.avx = SF(s, F_AVX, env);
+            pe.aphase = SF(s, F_APHASE, env);
+            pe.ax = SF(s, F_AX, env);
+            pe.ay = SF(s, F_AY, env);
+            S.env[e] = pe;
+        }
+    }
+    __syncthreads();
+    // ---- per env (lane = env): camera, tile window, background draw — render_full's preamble
+    if (tid < kPrepEnvs) {
+        const int e = tid;
+        PrepView v{};
+        P.fat[e] = 0;
+        P.soft_rows[e] = P.hard_rows[e] = 0;
+        S.counts[e] = 0;
+        if (active) {
+            v.cam = cam;
+            const int backdrop = themes & 0xff, theme = (themes >> 16) & 0xff;
+            const int4 d = S.desc[kTexBackdrop + backdrop];
+            const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
+            const float extra = aspect - 1.0f;
+            v.bg = BgDraw{d, -bgshift * extra, 0.0f, 64.0f * kUnitPx / d.z};  // climber.cpp:447-452
+            const float vx = (cam.px - cam.sw * 0.5f / cam.scale) * kPxUnit;  // tilemap.cpp:172-181
+            const float vy = (cam.py - cam.sh * 0.5f / cam.scale) * kPxUnit;
+            const float vw = cam.sw * kPxUnit / cam.scale, vh = cam.sh * kPxUnit / cam.scale;
+            v.x0 = static_cast<int>(floorf(vx));
+            v.y0 = static_cast<int>(floorf(vy));
+            v.cols = static_cast<int>(ceilf(vx + vw)) - v.x0 + 1;
+            v.rows = static_cast<int>(ceilf(vy + vh)) - v.y0 + 1;
+            const int4 top_d = S.desc[kTexTop + theme], mid_d = S.desc[kTexMid + theme];
+            const bool two = top_d.z != mid_d.z;  // the brown theme's cap tile is 64×53 next to 64×64 bodies
+            v.tw = mid_d.y;
+            v.th = mid_d.z;
+            v.th2 = two ? top_d.z : 0;
+            v.tile_scale = kUnitPx / mid_d.y;
+            if (v.cols > kGrid || v.rows > kGrid || top_d.y != mid_d.y || top_d.z > mid_d.z) {
+                P.fat[e] = 1;
+                active = false;
+            }
+            P.soft_rows[e] = static_cast<uint32_t>(soft_rows_of(d.w, top_d.w | mid_d.w));
+            P.hard_rows[e] = static_cast<uint32_t>(hard_rows_of(d.w, mid_d.w));  // (cap tiles are few: always worth the attempt)
+            // tile kinds: 0 = cap (bit 0 of its offset: the layer's second texture), 1 = body
+#pragma unroll
+            for (int k = 0; k < kPrepKinds; k++) P.meta[e][PM_KINDS + k] = kNoTexel;
+            P.meta[e][PM_KINDS + 0] = (static_cast<uint32_t>(top_d.x) * 4u) | (two ? 1u : 0u);
+            P.meta[e][PM_KINDS + 1] = static_cast<uint32_t>(mid_d.x) * 4u;
+            prep_row_valid<kGrid, H>(v.y0, S.row_valid[e]);
+        }
+        v.active = active ? 1 : 0;
+        P.view[e] = v;
+    }
+    __syncthreads();
+
+    // ---- the cell table: lane = (env, grid column), the column's 24 bytes of the column-major map (pg_prepass.h) …
+    static_assert(kPrepEnvs * kGrid <= kPrepThreads, "one window column per thread");
+    const int cell_e = tid / kGrid, cell_c = tid - cell_e * kGrid;
+    bool cell_lane = false, cell_x_ok = false;
+    uint32_t column[kGrid / 4] = {};
+    if (tid < kPrepEnvs * kGrid && P.view[cell_e].active) {
+        cell_lane = true;
+        prep_column_fetch<kGrid, W, H>(s.tiles + size_t(env0 + cell_e) * (W * H), P.view[cell_e].x0 + cell_c, P.view[cell_e].y0, cell_x_ok, column);
+    }
+    // … the spans are worked out while it travels …
+    prep_spans<kGrid, kMaxSpan, kPrepEnvs, true>(P, tid, kPrepThreads);
+    // … then the kind bytes: wall_top → 0, wall_mid → 1, empty → none
+    if (cell_lane) {
+        uint32_t in_rows[kGrid / 4], kinds[kGrid / 4];
+        prep_column_rows<kGrid>(column, S.row_valid[cell_e], cell_x_ok, kWallMid, in_rows);  // out of bounds is a wall (tilemap.h:66-68)
+#pragma unroll
+        for (int w = 0; w < kGrid / 4; w++) {
+            const uint32_t t = in_rows[w] & 0x07070707u;  // kEmpty 0, kWallTop 1, kWallMid 2
+            const uint32_t lo = t & 0x01010101u, hi = (t >> 1) & 0x01010101u;
+            const uint32_t wall = (lo ^ hi) * 0xffu;  // 0xff where t is 1 or 2
+            kinds[w] = (hi & wall) | ~wall;           // kind = t - 1 for walls; 0xff: no tile
+        }
+        prep_column_store<kGrid>(out.cells + size_t(env0 + cell_e) * (kGrid * kGrid), cell_c, kinds);
+    }
+    __syncthreads();
+    prep_axes<kGrid, kMaxSpan, kPrepEnvs>(P, out, env0, wave, kPrepThreads / 64, lane);
+
+    // ---- the draws in the reference's order: the positive-z sprites (common_systems.cpp:41-63), then the agent
+    // (:272-298).  Two envs per wavefront, cull first (pg_prepass.h prep_draws_pass).
+    static_assert(kPrepEnvs == 2 * (kPrepThreads / 64), "two envs per wavefront");
+    {
+        const int ea = 2 * wave, eb = 2 * wave + 1;
+        const bool on_a = P.view[ea].active != 0, on_b = P.view[eb].active != 0;
+        const Camera cam_a = P.view[ea].cam, cam_b = P.view[eb].cam;
+        const int cnt_a = on_a ? S.env[ea].n_draw + 1 : 0, cnt_b = on_b ? S.env[eb].n_draw + 1 : 0;
+        uint32_t* const draws_a = out.draws + size_t(env0 + ea) * kPrepDraws * kBlitWords;
+        uint32_t* const draws_b = out.draws + size_t(env0 + eb) * kPrepDraws * kBlitWords;
+        PrepDrawPass st{0, {0, 0}};
+        PrepDrawQueue& Q = S.queue[wave];
+        for (int base = 0; base < cnt_a + cnt_b; base += 64) {  // wave-uniform
+            const int q = base + lane;
+            const bool is_b = q >= cnt_a;
+            const int e = is_b ? eb : ea, env = env0 + e;
+            const int slot = is_b ? q - cnt_a : q;
+            const bool valid = q < cnt_a + cnt_b;
+            const PrepEnv& pe = S.env[e];
+            PrepDraw p{false, false, false, kTexGem, 0.0f, 0.0f, 1.0f, 1.0f};
+            float num = kUnitPx;
+            if (valid && slot < pe.n_draw) {
+                const int ent = (S.draw_order[e][slot >> 2] >> (8 * (slot & 3))) & 0xffu;
+                const int info = EB(s, EB_INFO, ent, env);
+                const float ex = EF(s, EF_X, ent, env), ey = EF(s, EF_Y, ent, env);
+                if (info & kTexSet) {
+                    p.tex = (info & kMob) ? kTexFish + ((info & kFrame) ? 1 : 0) : kTexGem;
+                    const float off = (info & kMob) ? -0.4f : -0.5f;  // tilemap.cpp:53,66
+                    const float scale = 1.0f * 1.0f;
+                    p.wx = (ex + off) * kUnitPx;
+                    p.wy = (ey + off) * kUnitPx;
+                    num = scale * kUnitPx;
+                    p.flip_h = (info & kFlip) != 0;
+                    p.go = true;
+                }
+            } else if (valid) {
+                const bool ground = (pe.sflags & kFlagGround) != 0;
+                if (fabsf(pe.avx) < 0.01f && ground)
+                    p.tex = kTexStand + pe.suit;
+                else if (!ground)
+                    p.tex = kTexJump + pe.suit;
+                else if (pe.aphase > 0.5f)
+                    p.tex = kTexWalk2 + pe.suit;
+                else
+                    p.tex = kTexWalk1 + pe.suit;
+                const float px = pe.ax - 0.5f, py = pe.ay - 1.0f;
+                p.wx = px * kUnitPx;
+                p.wy = py * kUnitPx;
+                num = 0.8f * kUnitPx;
+                p.flip_h = (pe.sflags & kFlagForward) == 0;
+                p.go = true;
+            }
+            p.scale = num / S.desc[p.tex].y;
+            prep_draws_pass(Q, st, S.desc, cam_a, cam_b, draws_a, draws_b, valid, is_b, p, lane);
+        }
+        prep_draws_flush(Q, st, S.desc, cam_a, cam_b, draws_a, draws_b, lane);
+        if (lane == 0) {
+            S.counts[ea] = st.done[0];
+            S.counts[eb] = st.done[1];
+        }
+    }
+    __syncthreads();
+    prep_meta_out<kGrid, kMaxSpan, kPrepEnvs>(P, out, env0, S.counts, tid, kPrepThreads);
+}
+
+// render_game(true) (climber.cpp:431-459): one workgroup of two wavefronts per env; a lean frame starts from what
+// setup_kernel left (coinrun.hip's render_kernel is the commented model).
+__global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
+                                                    int flags) {
+    const int env = blockIdx.x;
+    if (mask && !mask[env]) return;
+    const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int halves = 2;
+    __shared__ alignas(16) uint32_t fb[kFbWords];
+    __shared__ ComposeLds<kGrid> L;
+    const PrepMeta M{s.prep.meta + size_t(env) * kPrepMetaWords};
+    const uint32_t colw = s.prep.axes[size_t(env) * 128 + lane], roww = s.prep.axes[size_t(env) * 128 + 64 + lane];
+    const uint32_t roww2 = s.prep.axes2[size_t(env) * 64 + lane];
+    const uint32_t kind_off = M.w[PM_KINDS + (lane & (kPrepKinds - 1))];
+    const int n_draws = M.draws();
+    const bool has = lane < n_draws;
+    const Blit mine = prep_draw_load(s.prep.draws + (size_t(env) * kPrepDraws + lane) * kBlitWords, has);
+    prep_cells_expand_any<kGrid>(L, s.prep.cells + size_t(env) * (kGrid * kGrid), kind_off, half, lane);
+    const ComposeRegs R = prep_regs<kGrid>(M, colw, roww, roww2, lane);
+    __syncthreads();  // the cell table is complete
+    if ((flags & (1 | kDebugNoPrepass)) || M.fat()) {  // (wave-uniform)
+        render_full(s, atlas, io, flags, env, fb, L);
+        return;
+    }
+    const int row_lo = half * (kObsH / halves), row_hi = (half + 1) * (kObsH / halves);
+    if (M.flags() & 2u)
+        compose_rows_from<kGrid, true, false>(fb, L, atlas, R, lane, flags, half, halves);
+    else
+        compose_rows_from<kGrid, false, false>(fb, L, atlas, R, lane, flags, half, halves);
+    wave_replay_rows(fb, atlas, mine, __ballot(has), lane, row_lo, row_hi);
+    wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, row_lo, row_hi);
 }
 
 // cenv_render's frame (render_game(false)) for one env: pg_frame.h; the draw list of render_kernel, one draw at a time.
@@ -805,7 +1036,11 @@ class ClimberGame final : public Game {
         hipLaunchKernelGGL(frame_kernel, dim3(1), dim3(kFrameThreads), 0, st, s_, atlas_, env, FrameTarget{d_px, w, h});
         return true;
     }
+    size_t scratch_bytes(int n) const override { return prep_bytes(n, kGrid, kBlitWords, true); }
+    void bind_scratch(void* d_scratch, int n) override { s_.prep = prep_bind(d_scratch, n, kGrid, kBlitWords, true); }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
+        if (!(debug_flags & (1 | kDebugNoPrepass)))
+            hipLaunchKernelGGL(setup_kernel, dim3((s_.n + kPrepEnvs - 1) / kPrepEnvs), dim3(kPrepThreads), 0, st, s_, atlas_, mask);
         hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags);
     }
     // Same layout as oracle/pgo_climber.cpp Climber::dump_state.

@@ -1222,6 +1222,9 @@ struct SetupLds {
     int4 desc[kTexCount];                    // the atlas descriptor table: every later lookup is an LDS read
     uint8_t order[kPrepEnvs][2][kMaxEnt + 4];  // EB_SPARK_ORDER, EB_DRAW_ORDER of every env (fetched before anything needs them)
     int32_t kind_soft[kPrepEnvs];            // bit k: tile kind k's texture has texels that are not opaque
+    uint32_t row_valid[kPrepEnvs][kGrid / 4];              // byte i: 0xff if map row ty_lo + i of the env's window exists (cells below)
+    uint8_t near_mob[kPrepEnvs][kMaxEnt];    // the mobs whose sparks can be on the screen, in the particle system's order
+    int32_t near_n[kPrepEnvs];
     int32_t counts[kPrepEnvs];
     PrepDrawQueue queue[kPrepThreads / 64];  // one worklist per wavefront
 };
@@ -1317,10 +1320,10 @@ __global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView 
                 if (k == kSlotLava) tex = kTexLava;
                 const int4 kd = S.desc[tex];
                 P.meta[e][PM_KINDS + k] = static_cast<uint32_t>(kd.x) * 4u;
-                P.meta[e][PM_KINDS + 8 + k] = kNoTexel;
-                if (kd.w != 0) soft |= 1 << k;
+                    if (kd.w != 0) soft |= 1 << k;
             }
             S.kind_soft[e] = soft;
+            prep_row_valid<kGrid, H>(v.y0, S.row_valid[e]);  // which of the 16 map rows under the window exist
         }
         v.active = active ? 1 : 0;
         P.view[e] = v;
@@ -1328,48 +1331,50 @@ __global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView 
     __syncthreads();
     if (PG_ABL(flags, 0x1000000)) return;  // (instruction inventory, -DPG_ABLATE builds only: the views alone)
 
-    // ---- the cell table, first half: lane = (env, grid row, four grid columns) requests its four tile bytes …
-    constexpr int kCellWords = kGrid * kGrid / 4;
-    static_assert(kPrepEnvs * kCellWords == 2 * kPrepThreads, "two cell words per thread");
-    int raw_tile[2][4];
-#pragma unroll
-    for (int it = 0; it < 2; it++) {
-        const int q = tid + it * kPrepThreads;
-        const int e = q / kCellWords, w = q - e * kCellWords;
-        const PrepView& v = P.view[e];
-        const int r = w / (kGrid / 4), c4 = (w - r * (kGrid / 4)) * 4;
-        const uint8_t* tiles = s.tiles + size_t(env0 + e) * (W * H);
-        const int ty = H - 1 - (v.y0 + r);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int x = v.x0 + c4 + j;
-            raw_tile[it][j] = kWallMid;  // out of bounds is a wall (tilemap.h:80-81)
-            if (v.active && x >= 0 && ty >= 0 && x < W && ty < H) raw_tile[it][j] = tiles[ty + x * H];
-        }
+    // ---- the cell table, first half: lane = (env, grid column).  The map is column-major (tilemap.h:62-85), so the sixteen
+    // cells of a window column are sixteen consecutive bytes — one 16-byte load (unaligned; rows beyond the map's edge
+    // read the neighbouring column or the neighbouring env's map and are replaced below) …
+    static_assert(kGrid == 16 && H == 64, "a window column is one 16-byte load");
+    const int cell_e = tid / kGrid, cell_c = tid - cell_e * kGrid;
+    bool cell_lane = false, cell_x_ok = false;
+    uint32_t column[kGrid / 4] = {};
+    if (tid < kPrepEnvs * kGrid && P.view[cell_e].active) {
+        cell_lane = true;
+        prep_column_fetch<kGrid, W, H>(s.tiles + size_t(env0 + cell_e) * (W * H), P.view[cell_e].x0 + cell_c, P.view[cell_e].y0, cell_x_ok, column);
     }
-    // … the spans are worked out while they travel …
+    // … the spans are worked out while it travels …
     if (!PG_ABL(flags, 0x2000000)) prep_spans<kGrid, kMaxSpan, kPrepEnvs>(P, tid, kPrepThreads);
-    // … second half: four kind bytes, one word
+    // … second half: sixteen kind bytes, four cells at a time
+    if (cell_lane) {
+        const PrepView& v = P.view[cell_e];
+        uint32_t in_rows[4];
+        prep_column_rows<kGrid>(column, S.row_valid[cell_e], cell_x_ok, kWallMid, in_rows);  // out of bounds is a wall (tilemap.h:80-81)
+        // soft kinds as a byte table for v_perm: byte k = 0xff if kind k's texture has texels that are not opaque
+        const uint32_t soft_kinds = static_cast<uint32_t>(S.kind_soft[cell_e]);
+        uint32_t soft_lo = 0u, soft_hi = 0u;
 #pragma unroll
-    for (int it = 0; it < 2; it++) {
-        const int q = tid + it * kPrepThreads;
-        const int e = q / kCellWords, w = q - e * kCellWords;
-        const PrepView& v = P.view[e];
-        if (!v.active) continue;
-        const int r = w / (kGrid / 4), c4 = (w - r * (kGrid / 4)) * 4;
-        const int soft_kinds = S.kind_soft[e];
-        uint32_t word = 0;
-        bool soft = false;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int raw = raw_tile[it][j];
-            const int t = raw & 7;
-            const int slot = t < kCrate ? t - 1 : kSlotCrate + (raw >> 4);
-            word |= (t == kEmpty ? 0xffu : static_cast<uint32_t>(slot)) << (8 * j);
-            soft = soft || (t != kEmpty && ((soft_kinds >> slot) & 1) && r < v.rows && c4 + j < v.cols);
+        for (int k = 0; k < 4; k++) {
+            soft_lo |= ((soft_kinds >> k) & 1u) ? 0xffu << (8 * k) : 0u;
+            soft_hi |= ((soft_kinds >> (4 + k)) & 1u) ? 0xffu << (8 * k) : 0u;
         }
-        reinterpret_cast<uint32_t*>(out.cells)[size_t(env0 + e) * kCellWords + w] = word;
-        if (soft) atomicOr(&P.soft_rows[e], 1u << r);
+        uint32_t kinds[4], soft_rows = 0u;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {  // window rows 4w .. 4w + 3: raw byte = tile id | crate kind << 4 (crates only)
+            const uint32_t raw = in_rows[w];
+            const uint32_t t = raw & 0x07070707u, crate = (raw >> 4) & 0x03030303u;
+            const uint32_t y = (t | 0x80808080u) - 0x01010101u;          // per byte: 0x7f if empty, else 0x80 + t - 1
+            const uint32_t there = ((y & 0x80808080u) >> 7) * 0xffu;      // 0xff where there is a tile
+            const uint32_t slots = (y & 0x07070707u) + crate;            // kSlotTop .. kSlotLava = t - 1, crates 4 + kind
+            kinds[w] = (slots & there) | ~there;                         // 0xff: no tile
+            // the rows that show a soft texture (only the window's own rows and columns count)
+            const uint32_t sel = (slots & there) | (0x0c0c0c0cu & ~there);  // v_perm selector 0x0c: the constant 0x00
+            const uint32_t soft = __builtin_amdgcn_perm(soft_hi, soft_lo, sel) & 0x01010101u;
+            soft_rows |= ((soft * 0x00204081u >> 21) & 0xfu) << (4 * w);
+        }
+        if (cell_c >= v.cols) soft_rows = 0u;
+        soft_rows &= (v.rows >= 32 ? ~0u : (1u << v.rows) - 1u);
+        prep_column_store<kGrid>(out.cells + size_t(env0 + cell_e) * (kGrid * kGrid), cell_c, kinds);
+        if (soft_rows) atomicOr(&P.soft_rows[cell_e], soft_rows);
     }
     __syncthreads();
     if (PG_ABL(flags, 0x4000000)) return;
@@ -1384,9 +1389,35 @@ __global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView 
     {
         const int ea = 2 * wave, eb = 2 * wave + 1;
         const bool on_a = P.view[ea].active != 0, on_b = P.view[eb].active != 0;
-        const int cnt_a = on_a ? S.env[ea].n_mob * kSparks + S.env[ea].n_sprites + 1 : 0;
-        const int cnt_b = on_b ? S.env[eb].n_mob * kSparks + S.env[eb].n_sprites + 1 : 0;
         const Camera cam_a = P.view[ea].cam, cam_b = P.view[eb].cam;
+        // Which mobs' sparks can be on the screen at all.  A spark stays where its mob was when it was emitted, lives 20
+        // sub-steps, and a mob moves 0.15 a step (tilemap.cpp:194 of this file's generator, common_systems.cpp:65-105):
+        // it is within 0.75 units of its mob in x and 0.34 in y, and render_texture culls it unless its corner is within
+        // half a screen (+ its own few pixels) of the camera.  Mobs further than that — generously: 140 world pixels +
+        // a quarter of the spark texture — are left out of the list; the others' sparks go through the exact cull.
+        {
+            const int4 spark_d = S.desc[kTexSpark];
+            const float reach_x = 140.0f + 0.25f * spark_d.y, reach_y = 140.0f + 0.25f * spark_d.z;
+#pragma unroll
+            for (int side = 0; side < 2; side++) {
+                const int e = side ? eb : ea;
+                const bool on = side ? on_b : on_a;
+                const Camera& cam = side ? cam_b : cam_a;
+                const int n_mob = on ? S.env[e].n_mob : 0;
+                bool near = false;
+                if (lane < n_mob) {
+                    const int ent = S.order[e][0][lane];
+                    const float mx = DF(s, S.env[e].buf, DF_X, ent, env0 + e) * kUnitPx, my = EY(s, ent, env0 + e) * kUnitPx;
+                    near = fabsf(mx - cam.px) <= reach_x && fabsf(my - cam.py) <= reach_y;
+                }
+                const unsigned long long m = __ballot(near);
+                if (near) S.near_mob[e][__popcll(m & ((1ull << lane) - 1ull))] = static_cast<uint8_t>(lane);
+                if (lane == 0) S.near_n[e] = __popcll(m);
+            }
+            wave_order();
+        }
+        const int cnt_a = on_a ? S.near_n[ea] * kSparks + S.env[ea].n_sprites + 1 : 0;
+        const int cnt_b = on_b ? S.near_n[eb] * kSparks + S.env[eb].n_sprites + 1 : 0;
         uint32_t* const draws_a = out.draws + size_t(env0 + ea) * kPrepDraws * kBlitWords;
         uint32_t* const draws_b = out.draws + size_t(env0 + eb) * kPrepDraws * kBlitWords;
         PrepDrawPass st{0, {0, 0}};
@@ -1398,11 +1429,11 @@ __global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView 
             const int slot = is_b ? q - cnt_a : q;
             const bool valid = q < cnt_a + cnt_b;
             const PrepEnv& pe = S.env[e];
-            const int n_parts = pe.n_mob * kSparks;
+            const int n_parts = S.near_n[e] * kSparks;
             PrepDraw p{false, false, false, kTexSpark, 0.0f, 0.0f, 1.0f, 1.0f};
             if (valid && slot < n_parts) {  // System_Particles::render (common_systems.cpp:315-337)
                 const int m = slot / kSparks, k = slot - m * kSparks;
-                const int ent = S.order[e][0][m];
+                const int ent = S.order[e][0][S.near_mob[e][m]];
                 const float life = SP(s, pe.buf, 2, ent, k, env);
                 const float px = SP(s, pe.buf, 0, ent, k, env), py = SP(s, pe.buf, 1, ent, k, env);
                 if (life > 0.0f) {
@@ -1479,13 +1510,7 @@ __global__ void __launch_bounds__(64 * kRenderWaves, PG_COINRUN_RENDER_WAVES) re
     const int n_draws = M.draws();
     const bool has = lane < n_draws;
     const Blit mine = prep_draw_load(s.prep.draws + (size_t(env) * kPrepDraws + lane) * kBlitWords, has);
-    {   // kind bytes → byte offsets of the kinds' textures (0xff: no tile)
-        const uint32_t k0 = two & 0xffu, k1 = two >> 8;
-        const uint32_t o0 = __shfl(kind_off, static_cast<int>(k0 & (kPrepKinds - 1)));
-        const uint32_t o1 = __shfl(kind_off, static_cast<int>(k1 & (kPrepKinds - 1)));
-        reinterpret_cast<uint2*>(L.base)[half * 64 + lane] = make_uint2(k0 == 0xffu ? kNoTexel : o0, k1 == 0xffu ? kNoTexel : o1);
-        if (threadIdx.x == 0) L.base[kGrid * kGrid] = L.base[kGrid * kGrid + 1] = static_cast<int32_t>(kNoTexel);
-    }
+    prep_cells_expand<kGrid>(L, two, kind_off, half, lane);  // kind bytes → byte offsets of the kinds' textures
     const ComposeRegs R = prep_regs<kGrid>(M, colw, roww, 0u, lane);
     __syncthreads();  // the cell table is complete
     if ((flags & (1 | kDebugNoPrepass)) || M.fat()) {  // (wave-uniform)

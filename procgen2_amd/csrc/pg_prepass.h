@@ -20,18 +20,20 @@
 namespace pg {
 
 constexpr int kPrepMetaWords = 32;  // one 128-byte line per env
-constexpr int kPrepKinds = 16;      // tile kinds a game may have (cell byte → byte offset of the kind's texture)
+constexpr int kPrepKinds = 8;       // tile kinds a game may have (cell byte → byte offset of the kind's texture)
 constexpr int kPrepDraws = 64;      // visible draws a lean frame may have (one per lane of the render wave)
 enum PrepMetaWord {
     PM_SECOND = 0,  // 64-bit row masks (lo, hi): two grid rows cover the pixel row
     PM_SOFT = 2,    //   … a covering grid row (or the background) shows texels that are not opaque
     PM_HARD = 4,    //   … so many that the one-texel attempt is not made
-    PM_FLAGS = 6,   // bit 0: fat (take the complete path); bits 8-15: number of draws
+    PM_FLAGS = 6,   // bit 0: fat (take the complete path); bit 1: the layer has a second, shorter texture (kind 0 shows it);
+                    // bits 8-15: number of draws
     PM_BGX = 7,     // background, x axis: d0 | dn << 16 (signed halves), then s0 | sn << 16
     PM_BGY = 9,     // background, y axis
     PM_BGTEX = 11,  // background: first texel in the atlas
     PM_WIDTHS = 12, // background texture width | tile texture width << 16
     PM_KINDS = 16,  // kPrepKinds words: byte offset in the atlas of each tile kind's texture
+    PM_GAME = 24,   // eight words of the game's own (jumper: its compass as it lands on the observation)
 };
 
 // Where the pre-pass leaves its results (device memory, per env; not part of the state: nothing survives a frame).
@@ -305,6 +307,54 @@ PG_D void prep_axes(PrepLds<GRID, E, MAXSPAN>& P, const PrepOut& out, int env0, 
     }
 }
 
+// ---- the cell table of a column-major byte map (tiles[ty + x * H], map row ty = H - 1 - y: coinrun/tilemap.h:62-85 and
+// the other platformers alike).  The GRID = 16 cells of one window column are sixteen consecutive bytes: lane = (env, grid
+// column) fetches them with ONE 16-byte load (unaligned; rows beyond the map's edge read the neighbouring column or the
+// neighbouring env's map — inside the state's allocation either way — and are replaced afterwards).
+// (GRID = 24, climber: 16 + 8 bytes.)
+// Which of the GRID map rows ty_lo + i under a window exist (byte i = 0xff), ty_lo = H - GRID - y0: once per env.
+template <int GRID, int H>
+PG_D void prep_row_valid(int y0, uint32_t (&mw)[GRID / 4]) {
+    const int ty_lo = H - GRID - y0;
+#pragma unroll
+    for (int w = 0; w < GRID / 4; w++) {
+        mw[w] = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int ty = ty_lo + 4 * w + j;
+            if (ty >= 0 && ty < H) mw[w] |= 0xffu << (8 * j);
+        }
+    }
+}
+template <int GRID, int W, int H>
+PG_D void prep_column_fetch(const uint8_t* tiles, int x, int y0, bool& x_ok, uint32_t (&column)[GRID / 4]) {
+#pragma unroll
+    for (int w = 0; w < GRID / 4; w++) column[w] = 0u;
+    x_ok = x >= 0 && x < W;
+    if (x_ok) __builtin_memcpy(column, tiles + x * H + (H - GRID - y0), GRID);
+}
+// … the GRID raw bytes in window-row order (byte r of word r / 4 = window row r), `oob` where the map has no cell.
+template <int GRID>
+PG_D void prep_column_rows(const uint32_t (&column)[GRID / 4], const uint32_t* valid, bool x_ok, uint32_t oob, uint32_t (&rows)[GRID / 4]) {
+    const uint32_t fill = 0x01010101u * oob;
+    // byte i of the column is map row ty_lo + i = window row GRID - 1 - i: reverse
+#pragma unroll
+    for (int w = 0; w < GRID / 4; w++) {
+        const uint32_t raw = column[GRID / 4 - 1 - w], ok = valid[GRID / 4 - 1 - w];
+        rows[w] = __builtin_amdgcn_perm(0u, x_ok ? ((raw & ok) | (fill & ~ok)) : fill, 0x00010203u);
+    }
+}
+template <int GRID>
+PG_D void prep_column_store(uint8_t* cells_env, int c, const uint32_t (&kinds)[GRID / 4]) {
+    uint32_t* at = reinterpret_cast<uint32_t*>(cells_env + c * GRID);
+    if constexpr (GRID == 16) {
+        *reinterpret_cast<uint4*>(at) = make_uint4(kinds[0], kinds[1], kinds[2], kinds[3]);
+    } else {
+#pragma unroll
+        for (int w = 0; w < GRID / 4; w++) at[w] = kinds[w];
+    }
+}
+
 // The last phase: the envs' meta lines, coalesced.  `counts[e]` = draws of env e (> kPrepDraws: fat).  Needs a barrier
 // in front (every phase has written its part of P.meta / P.fat).
 template <int GRID, int MAXSPAN, int E>
@@ -316,7 +366,7 @@ PG_D void prep_meta_out(PrepLds<GRID, E, MAXSPAN>& P, const PrepOut& out, int en
         if (w == PM_FLAGS) {
             const int c = counts[e];
             const bool fat = P.fat[e] != 0 || c > kPrepDraws;
-            word = (fat ? 1u : 0u) | (static_cast<uint32_t>(fat ? 0 : c) << 8);
+            word = (fat ? 1u : 0u) | (P.view[e].th2 > 0 ? 2u : 0u) | (static_cast<uint32_t>(fat ? 0 : c) << 8);
         }
         if (w == PM_BGTEX) word = static_cast<uint32_t>(P.view[e].bg.desc.x);
         if (w == PM_WIDTHS) word = pack_halves(P.view[e].bg.desc.y, P.view[e].tw);
@@ -453,6 +503,37 @@ PG_D void prep_draws_pass(PrepDrawQueue& Q, PrepDrawPass& st, const int4* desc, 
         Q.e[st.queued + __popcll(m & ((1ull << lane) - 1ull))] = en;
     }
     st.queued += n;
+}
+
+// The cell table from the kind bytes the pre-pass stored column by column (16 × 16 tables: byte 2j, 2j + 1 = cells
+// (column j / 8, rows 2j % 16 and + 1)): each of the workgroup's 128 lanes expands two cells.  `two16` = this lane's two
+// bytes, kind_off = PM_KINDS word (lane & 7).  Leaves the barrier to the caller.
+// Any table size: four cells (one stored word) per lane and trip; `cells_env` = the env's kind bytes in device memory.
+template <int GRID>
+PG_D void prep_cells_expand_any(ComposeLds<GRID>& L, const uint8_t* cells_env, uint32_t kind_off, int half, int lane) {
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(cells_env);
+    for (int wq = half * 64 + lane; wq < GRID * GRID / 4; wq += 128) {
+        const uint32_t four = words[wq];
+        const int c = wq / (GRID / 4), r4 = (wq - c * (GRID / 4)) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t k = (four >> (8 * i)) & 0xffu;
+            const uint32_t off = __shfl(kind_off, static_cast<int>(k & (kPrepKinds - 1)));
+            L.base[(r4 + i) * GRID + c] = static_cast<int32_t>(k == 0xffu ? kNoTexel : off);
+        }
+    }
+    if (half == 0 && lane == 0) L.base[GRID * GRID] = L.base[GRID * GRID + 1] = static_cast<int32_t>(kNoTexel);
+}
+template <int GRID>
+PG_D void prep_cells_expand(ComposeLds<GRID>& L, uint32_t two16, uint32_t kind_off, int half, int lane) {
+    static_assert(GRID == 16, "two cells per lane of a 128-lane workgroup");
+    const uint32_t k0 = two16 & 0xffu, k1 = two16 >> 8;
+    const uint32_t o0 = __shfl(kind_off, static_cast<int>(k0 & (kPrepKinds - 1)));
+    const uint32_t o1 = __shfl(kind_off, static_cast<int>(k1 & (kPrepKinds - 1)));
+    const int j = half * 64 + lane, at = ((2 * j) & (GRID - 1)) * GRID + (j >> 3);
+    L.base[at] = static_cast<int32_t>(k0 == 0xffu ? kNoTexel : o0);
+    L.base[at + GRID] = static_cast<int32_t>(k1 == 0xffu ? kNoTexel : o1);
+    if (half == 0 && lane == 0) L.base[GRID * GRID] = L.base[GRID * GRID + 1] = static_cast<int32_t>(kNoTexel);
 }
 
 // A resolved draw as the pre-pass stores it: pg_render.h BlitWords, kBlitWords per draw, draws of an env back to back.
