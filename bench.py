@@ -292,8 +292,12 @@ def main():
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * a.envs,
                          "avg_launch_ms": render_avg_ms,
                          "window": "%d launches after the timed region (steps %d..%d since make), HIP events on the "
-                                   "engine's stream" % (window, a.settle + max(1, a.warmup) + a.steps,
-                                                        a.settle + max(1, a.warmup) + a.steps + window - 1)},
+                                   "engine's stream around the render kernel alone (a game's render pre-pass, "
+                                   "setup_kernel, is a launch of its own in front of it and inside the step%s)"
+                                   % (window, a.settle + max(1, a.warmup) + a.steps,
+                                      a.settle + max(1, a.warmup) + a.steps + window - 1,
+                                      "; chaser: the late pass over the envs that reset is a second, small launch "
+                                      "behind the events" if a.game == "chaser" else "")},
             "done_fraction_last_step": done_frac,
         }
         if n_gpus == 1 and not a.no_cpu_baseline and not a.mode:

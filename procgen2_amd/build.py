@@ -126,7 +126,7 @@ def _build_selftest(force, verbose, cc, hdrs, common):
     src = os.path.join(hip_dir, "selftest.hip")
     rooms = os.path.join(hip_dir, "selftest_rooms.hip")
     out = os.path.join(LIB, "libpg_selftest.so")
-    if os.path.exists(src) and (force or _stale(out, [src, rooms] + hdrs)):
+    if os.path.exists(src) and os.path.exists(rooms) and (force or _stale(out, [src, rooms] + hdrs)):
         objs, jobs = [], []
         obj = os.path.join(OBJ, "selftest.o")
         jobs.append([cc] + common + ["-c", src, "-o", obj])

@@ -1374,9 +1374,11 @@ class CaveflyerGame final : public Game {
     }
     size_t scratch_bytes(int n) const override { return prep_bytes(n, kGrid, kBlitWords, false); }
     void bind_scratch(void* d_scratch, int n) override { s_.prep = prep_bind(d_scratch, n, kGrid, kBlitWords, false); }
-    void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
+    void launch_prepass(hipStream_t st, const uint8_t* mask) override {
         if (!(debug_flags & (1 | kDebugNoPrepass)))
             hipLaunchKernelGGL(setup_kernel, dim3((s_.n + kPrepEnvs - 1) / kPrepEnvs), dim3(kPrepThreads), 0, st, s_, atlas_, mask);
+    }
+    void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
         hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags);
     }
     // Same layout as oracle/pgo_caveflyer.cpp Caveflyer::dump_state.

@@ -1038,9 +1038,11 @@ class ClimberGame final : public Game {
     }
     size_t scratch_bytes(int n) const override { return prep_bytes(n, kGrid, kBlitWords, true); }
     void bind_scratch(void* d_scratch, int n) override { s_.prep = prep_bind(d_scratch, n, kGrid, kBlitWords, true); }
-    void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
+    void launch_prepass(hipStream_t st, const uint8_t* mask) override {
         if (!(debug_flags & (1 | kDebugNoPrepass)))
             hipLaunchKernelGGL(setup_kernel, dim3((s_.n + kPrepEnvs - 1) / kPrepEnvs), dim3(kPrepThreads), 0, st, s_, atlas_, mask);
+    }
+    void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
         hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags);
     }
     // Same layout as oracle/pgo_climber.cpp Climber::dump_state.

@@ -1733,9 +1733,11 @@ class CoinrunGame final : public Game {
         hipLaunchKernelGGL(frame_kernel, dim3(1), dim3(kFrameThreads), 0, st, s_, atlas_, env, FrameTarget{d_px, w, h});
         return true;
     }
-    void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
+    void launch_prepass(hipStream_t st, const uint8_t* mask) override {
         if (!(debug_flags & (1 | kDebugNoPrepass)) && !PG_ABL(debug_flags, 1 << 22))  // (experiment: the last frame's pre-pass again)
             hipLaunchKernelGGL(setup_kernel, dim3((s_.n + kPrepEnvs - 1) / kPrepEnvs), dim3(kPrepThreads), 0, st, s_, atlas_, mask, debug_flags);
+    }
+    void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
         hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(64 * kRenderWaves), 0, st, s_, atlas_, mask, io,
                            debug_flags);
     }

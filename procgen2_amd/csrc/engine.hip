@@ -1,8 +1,11 @@
 // Vector env engine + the two C ABIs (include/procgen2_vec.h, include/procgen2_cenv.h).
+#include <dirent.h>
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <mutex>
 
@@ -116,7 +119,44 @@ bool Atlas::upload(std::string& err) {
 // queue run their kernels one after the other: the mixed seven-game workload, fourteen streams, gains 9.5 % with twelve
 // or more).  The runtime reads GPU_MAX_HW_QUEUES when it initialises, at the first HIP call of the process; loading this
 // library is usually earlier.  A value the caller has set is left alone.
-__attribute__((constructor)) static void runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", /*overwrite=*/0); }
+// When the runtime is up already (the embedding process made a HIP call first, or rocprofv3's preloaded tool did) the
+// default comes too late and is silently without effect: that is noticed here — an initialised ROCm runtime holds
+// /dev/kfd open — and said once, on stderr, by the first pgv_make that would have profited (the third engine on a
+// device: a single game's two streams are served by the runtime's own four queues).
+static bool g_queue_default_too_late = false;
+static bool rocm_runtime_is_up() {
+    DIR* d = opendir("/proc/self/fd");
+    if (!d) return false;
+    bool up = false;
+    while (dirent* ent = readdir(d)) {
+        char link[64], target[64];
+        std::snprintf(link, sizeof link, "/proc/self/fd/%s", ent->d_name);
+        const ssize_t n = readlink(link, target, sizeof target - 1);
+        if (n > 0) {
+            target[n] = 0;
+            if (!std::strcmp(target, "/dev/kfd")) up = true;
+        }
+    }
+    closedir(d);
+    return up;
+}
+__attribute__((constructor)) static void runtime_defaults() {
+    if (std::getenv("GPU_MAX_HW_QUEUES")) return;  // the caller's choice
+    g_queue_default_too_late = rocm_runtime_is_up();
+    setenv("GPU_MAX_HW_QUEUES", "16", /*overwrite=*/0);
+}
+static std::atomic<int> g_live_engines[16];
+static void note_engine_made(int device) {
+    if (device < 0 || device >= 16) return;
+    static std::atomic<bool> said{false};
+    if (++g_live_engines[device] >= 3 && g_queue_default_too_late && !said.exchange(true))
+        std::fprintf(stderr,
+                     "procgen2_hip: %d engines on device %d, but the HIP runtime was initialised before this library was "
+                     "loaded, so its default GPU_MAX_HW_QUEUES=16 came too late and the streams of these engines share the "
+                     "runtime's default hardware queues (kernels of different engines run in turn; measured: -9 %% on the "
+                     "seven-game workload).  Export GPU_MAX_HW_QUEUES=16 before the process starts.\n",
+                     g_live_engines[device].load(), device);
+}
 
 static std::string asset_root() {
     if (const char* env = std::getenv("PROCGEN2_ASSETS")) return env;
@@ -173,6 +213,7 @@ struct pgv_env {
     std::unique_ptr<pg::Game> game;
     pg::Atlas atlas;
     void* d_state = nullptr;
+    bool counted = false;       // among g_live_engines (note_engine_made)
     void* d_scratch = nullptr;  // Game::scratch_bytes: per-frame hand-over between a game's kernels, not part of any snapshot
     uint8_t* d_obs = nullptr;
     float* d_reward = nullptr;
@@ -230,6 +271,7 @@ int32_t pgv_synthetic_action(uint32_t run_seed, uint32_t step_index, uint32_t gl
 
 void pgv_close(pgv_env* e) {
     if (!e) return;
+    if (e->counted && e->device >= 0 && e->device < 16) --pg::g_live_engines[e->device];
     hipSetDevice(e->device);
     if (e->stream) hipStreamSynchronize(e->stream);
     if (e->side) {
@@ -379,6 +421,8 @@ int32_t pgv_make_config(const pgv_config* cfg, pgv_env** out) {
     PG_HIP(hipGetLastError());
     PG_HIP(hipStreamSynchronize(e->stream));
     pregen(e.get(), true, true);
+    pg::note_engine_made(device);
+    e->counted = true;
     *out = e.release();
     return 0;
 }
@@ -387,6 +431,7 @@ int32_t pgv_reset(pgv_env* e, const uint8_t* d_mask, const int32_t* d_seeds) {
     if (!e) return fail("pgv_reset: env is NULL");
     PG_HIP(hipSetDevice(e->device));
     e->game->launch_reset(e->stream, d_mask, d_seeds, e->io());
+    e->game->launch_prepass(e->stream, d_mask);
     e->game->launch_render(e->stream, d_mask, e->io());
     pregen(e, true, true);
     PG_HIP(hipGetLastError());
@@ -414,6 +459,10 @@ static int32_t step_impl(pgv_env* e, const int32_t* d_actions, uint32_t run_seed
     launched();
     pregen(e, false, false);  // before the render launch: the generator overlaps it
     (void)hipGetLastError();  // hipErrorNotReady of the stream query is not an error
+    if (status == hipSuccess) {
+        e->game->launch_prepass(e->stream, nullptr);
+        launched();
+    }
     if (before_render && status == hipSuccess) status = hipEventRecord(before_render, e->stream);
     if (status == hipSuccess) {
         e->game->launch_render_step(e->stream, e->io());
@@ -454,7 +503,9 @@ int32_t pgv_step_synthetic_many(pgv_env* const* envs, int32_t count, int32_t ste
     for (int32_t s = 0; s < steps; s++)
         for (int32_t k = 0; k < count; k++) {
             PG_HIP(hipSetDevice(envs[k]->device));
-            if (step_impl(envs[k], nullptr, run_seed)) return 1;
+            if (step_impl(envs[k], nullptr, run_seed))  // (the envs before k have taken step s, those from k on have not)
+                return fail(pg::g_error + " (pgv_step_synthetic_many: env " + std::to_string(k) + " of " + std::to_string(count) +
+                            ", step " + std::to_string(s) + " of " + std::to_string(steps) + ")");
         }
     return 0;
 }

@@ -97,8 +97,11 @@ class Game {
     // cenv_step with next-step auto-reset; actions nullptr = synthetic hash(run_seed, step, env).
     virtual void launch_logic(hipStream_t s, const int32_t* actions, uint32_t run_seed, uint32_t step_index,
                               int env_offset, StepIO io) = 0;
-    // render_game(true) + RGB pack into io.obs for envs where mask != 0 (nullptr = all).
+    // render_game(true) + RGB pack into io.obs for envs where mask != 0 (nullptr = all).  A game with a render pre-pass
+    // (pg_prepass.h) has it launched right before, by the engine: launch_prepass, same mask — a launch of its own so that
+    // the engine's render events (pgv_step_times, bench.py's roofline leg) bracket the render kernel alone.
     virtual void launch_render(hipStream_t s, const uint8_t* mask, StepIO io) = 0;
+    virtual void launch_prepass(hipStream_t s, const uint8_t* mask) { (void)s; (void)mask; }
     // Level prefetch (pg_prefetch.h): launch the generator that fills queued shadow slots on the side stream.
     // bulk = most envs are expected to be queued (after make / a full reset).  False = game has no prefetch.
     virtual bool launch_pregen(hipStream_t side, bool bulk) { return false; }

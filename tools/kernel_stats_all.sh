@@ -7,6 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r03_k}
 mkdir -p $(dirname $R/gpurun_out/${TAG}_x)
 cd /tmp && export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=16   # the profiler initialises HIP before the library can: same configuration as the bench line
 for G in coinrun maze bossfight climber caveflyer chaser jumper; do
   rm -rf /tmp/ks_$G
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$G -- python3 $R/bench.py --game $G --settle 3072 --steps 128 --warmup 32 --no-cpu-baseline > $R/gpurun_out/${TAG}_$G.log 2>&1

@@ -1,14 +1,24 @@
 """Lock-step of the engine against the oracle with a mixed action stream; on the first mismatch prints the env, the step and
-the differing entries of the two state dumps.  Usage: python tools/lockstep_debug.py  (edit game / sizes below)."""
-import sys, os
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
-import numpy as np
-from engine_util import EngineVec
-from oracle_util import OracleVec
-n=256
-eng, ora = EngineVec("chaser", n, seed_base=3), OracleVec("chaser", n, seed_base=3)
+the differing entries of the two state dumps.
+
+    python tools/lockstep_debug.py [GAME] [ENVS] [STEPS]        (default: chaser 256 3000)
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+from engine_util import EngineVec  # noqa: E402
+from oracle_util import OracleVec  # noqa: E402
+
+game = sys.argv[1] if len(sys.argv) > 1 else "chaser"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3000
+eng, ora = EngineVec(game, n, seed_base=3), OracleVec(game, n, seed_base=3)
 assert np.array_equal(eng.reset(), ora.reset_obs())
-for s in range(3000):
+for s in range(steps):
     acts = np.array([ora.L.pgo_synthetic_action(1, s, e) for e in range(n)], np.int32)
     acts = np.where(acts % 2 == 1, acts, (acts*7+s) % 15).astype(np.int32)
     oe, re_, de = eng.step(acts)

@@ -4,6 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r03_s}
 cd /tmp && export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=16   # the profiler initialises HIP before the library can: same configuration as the bench line
 for G in coinrun maze bossfight climber caveflyer chaser jumper; do
   for SET in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD" "SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
     D=/tmp/pmc_${G}_$(echo $SET | tr ' ' '_' | cut -c1-24)

@@ -6,6 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=$1; shift
 mkdir -p $(dirname $R/gpurun_out/${TAG}_x)
 cd /tmp && export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=16   # the profiler initialises HIP before the library can: same configuration as the bench line
 rm -rf /tmp/pq_[0-9]*
 i=0
 for SET in "$@"; do

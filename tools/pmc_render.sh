@@ -3,6 +3,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$1; shift
 cd /tmp && export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=16   # the profiler initialises HIP before the library can: same configuration as the bench line
 timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT -- python3 $R/bench.py --steps 16 --warmup 4 --no-cpu-baseline ${PG_BENCH_ARGS} > $OUT.log 2>&1
 python3 - <<PY
 import csv,glob,collections
