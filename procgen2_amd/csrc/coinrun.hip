@@ -1499,6 +1499,10 @@ __global__ void __launch_bounds__(64 * kRenderWaves, PG_COINRUN_RENDER_WAVES) re
     constexpr int halves = kRenderWaves;
     __shared__ alignas(16) uint32_t fb[kFbWords];
     __shared__ ComposeLds<kGrid> L;  // the composer's cell table
+#if defined(PG_LDS_PAD_LEAN)  // occupancy experiment (tools/build_exp.py): PG_LDS_PAD_LEAN more words of LDS per env → fewer envs per CU
+    __shared__ uint32_t lean_pad[PG_LDS_PAD_LEAN];
+    if (flags == 0x7fffffff) lean_pad[threadIdx.x % PG_LDS_PAD_LEAN] = env;  // (never true: keeps the array allocated)
+#endif
     // One round trip for everything the frame starts from: the packed axes, the kind offsets, this wave's half of the
     // cell bytes (vector loads) and the meta line (scalar loads) leave together; only the draws wait for their count.
     // Whether the frame is a fat one is asked AFTER the lean preamble (a few wasted instructions for the rare fat frame,

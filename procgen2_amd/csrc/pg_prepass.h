@@ -447,15 +447,36 @@ PG_D void prep_draws_flush(PrepDrawQueue& Q, PrepDrawPass& st, const int4* desc,
                            uint32_t* draws_a, uint32_t* draws_b, int lane) {
     if (st.queued == 0) return;  // wave-uniform
     wave_order();  // the entries were written by other lanes of this wave
-    const bool mine = lane < st.queued;
-    const PrepDrawEntry en = Q.e[mine ? lane : 0];
+    // Up to 32 draws (the usual case: a dozen or two per pair of envs): lane = (draw, axis) — both axes of every draw in
+    // ONE trip through axis_tail instead of two at half the lanes; the even lane of a pair then holds x, takes y from its
+    // neighbour and stores the draw.  More than 32: a lane per draw, the two axes one after the other.
+    const bool paired = st.queued <= 32;
+    const int j = paired ? lane >> 1 : lane, axis = paired ? lane & 1 : 0;
+    const bool mine = j < st.queued;
+    const PrepDrawEntry en = Q.e[mine ? j : 0];
     const bool is_b = (en.misc >> 31) != 0;
     const Camera& cam = is_b ? cam_b : cam_a;
     const int4 d = desc[en.misc & 0xffu];
     Span x, y;
+    x.d0 = x.dn = x.s0 = x.sn = 0;
+    y = x;
     bool has = mine;
-    has = has && axis_tail(cam.sw, cam.scale, d.y, en.scale, (en.misc >> 8) & 1u, AxisHead{en.dx, en.dlx}, x);
-    has = has && axis_tail(cam.sh, cam.scale, d.z, en.scale, false, AxisHead{en.dy, en.dly}, y);
+    if (paired) {
+        Span sp;
+        sp.d0 = sp.dn = sp.s0 = sp.sn = 0;
+        const bool ok = mine && axis_tail(axis ? cam.sh : cam.sw, cam.scale, axis ? d.z : d.y, en.scale, axis == 0 && ((en.misc >> 8) & 1u),
+                                          axis ? AxisHead{en.dy, en.dly} : AxisHead{en.dx, en.dlx}, sp);
+        x = sp;
+        y.d0 = __shfl_xor(sp.d0, 1);
+        y.dn = __shfl_xor(sp.dn, 1);
+        y.s0 = __shfl_xor(sp.s0, 1);
+        y.sn = __shfl_xor(sp.sn, 1);
+        const bool ok_other = __shfl_xor(ok ? 1 : 0, 1) != 0;
+        has = ok && ok_other && axis == 0;  // (the even lane of the pair speaks for the draw)
+    } else {
+        has = has && axis_tail(cam.sw, cam.scale, d.y, en.scale, (en.misc >> 8) & 1u, AxisHead{en.dx, en.dlx}, x);
+        has = has && axis_tail(cam.sh, cam.scale, d.z, en.scale, false, AxisHead{en.dy, en.dly}, y);
+    }
     const unsigned long long m_a = __ballot(has && !is_b), m_b = __ballot(has && is_b);
     const unsigned long long below = (1ull << lane) - 1ull;
     const int rank = is_b ? st.done[1] + __popcll(m_b & below) : st.done[0] + __popcll(m_a & below);

@@ -4,7 +4,7 @@
 # phase with each other); with 3 488 launches per kernel the averages are steady state to within a few per cent.
 # Output: gpurun_out/<tag>_<game>_kernel_stats.csv
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r03_k}
+TAG=${1:-r04_k}
 mkdir -p $(dirname $R/gpurun_out/${TAG}_x)
 cd /tmp && export TMPDIR=/tmp
 export GPU_MAX_HW_QUEUES=16   # the profiler initialises HIP before the library can: same configuration as the bench line

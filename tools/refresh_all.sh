@@ -2,7 +2,7 @@
 # Round-end refresh on the GPU box: bench lines of every game + mixed, rocprof kernel stats and PMC traffic of the
 # headline run.  Everything lands in gpurun_out/<tag>_*.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r03_final}
+TAG=${1:-r04_final}
 cd $R
 mkdir -p $(dirname gpurun_out/${TAG}_x)
 python bench.py --game coinrun 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_coinrun.json
@@ -12,7 +12,7 @@ done
 timeout 300 python bench.py --workload mixed 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_mixed.json
 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_coinrun_driver_args.json
 ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/ks_final && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_final -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/${TAG}_rocprof.log 2>&1; cp $(ls /tmp/ks_final/*/*kernel_stats.csv | head -1) $R/gpurun_out/${TAG}_coinrun_kernel_stats.csv )
-tools/pmc_traffic.sh ${TAG} > gpurun_out/${TAG}_pmc.log 2>&1
+tools/pmc_traffic.sh ${TAG} > gpurun_out/${TAG}_pmc.log 2>&1   # every game: bench.py takes roofline.traffic of any --game from it
 for f in gpurun_out/${TAG}_bench_*.json; do python - "$f" <<'PY'
 import json,sys
 d=json.load(open(sys.argv[1])); c=d["config"]
