@@ -19,9 +19,9 @@
 #include "pg_frame.h"
 #include "pg_gang.h"
 #include "pg_geom.h"
-// (Measured and rejected, round 4: -DPG_REPLAY_SHARE_AREA=1024 — the boss and its shield, 50×50 pixels that fall mostly
-// into the upper wave's rows, done by both waves with their rows dealt alternately, pg_render.h replay_group.  Bit-exact;
-// render 0.783 -> 0.806 ms: the two barriers per shared draw cost more than the idle lower wave.)
+// (Measured and rejected, round 4 — commit bd6a4f0 has it, PG_REPLAY_SHARE_AREA: the boss and its shield (35×29 and 23×21
+// pixels, mostly in the upper wave's rows) done by both waves with their rows dealt alternately.  Bit-exact; render
+// 0.783 -> 0.806 ms: the two barriers per shared draw cost more than the idle lower wave.)
 #include "pg_render.h"
 #include "pg_rng.h"
 #include "pg_sincos.h"

@@ -1223,8 +1223,6 @@ struct SetupLds {
     uint8_t order[kPrepEnvs][2][kMaxEnt + 4];  // EB_SPARK_ORDER, EB_DRAW_ORDER of every env (fetched before anything needs them)
     int32_t kind_soft[kPrepEnvs];            // bit k: tile kind k's texture has texels that are not opaque
     uint32_t row_valid[kPrepEnvs][kGrid / 4];              // byte i: 0xff if map row ty_lo + i of the env's window exists (cells below)
-    uint8_t near_mob[kPrepEnvs][kMaxEnt];    // the mobs whose sparks can be on the screen, in the particle system's order
-    int32_t near_n[kPrepEnvs];
     int32_t counts[kPrepEnvs];
     PrepDrawQueue queue[kPrepThreads / 64];  // one worklist per wavefront
 };
@@ -1390,34 +1388,8 @@ __global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView 
         const int ea = 2 * wave, eb = 2 * wave + 1;
         const bool on_a = P.view[ea].active != 0, on_b = P.view[eb].active != 0;
         const Camera cam_a = P.view[ea].cam, cam_b = P.view[eb].cam;
-        // Which mobs' sparks can be on the screen at all.  A spark stays where its mob was when it was emitted, lives 20
-        // sub-steps, and a mob moves 0.15 a step (tilemap.cpp:194 of this file's generator, common_systems.cpp:65-105):
-        // it is within 0.75 units of its mob in x and 0.34 in y, and render_texture culls it unless its corner is within
-        // half a screen (+ its own few pixels) of the camera.  Mobs further than that — generously: 140 world pixels +
-        // a quarter of the spark texture — are left out of the list; the others' sparks go through the exact cull.
-        {
-            const int4 spark_d = S.desc[kTexSpark];
-            const float reach_x = 140.0f + 0.25f * spark_d.y, reach_y = 140.0f + 0.25f * spark_d.z;
-#pragma unroll
-            for (int side = 0; side < 2; side++) {
-                const int e = side ? eb : ea;
-                const bool on = side ? on_b : on_a;
-                const Camera& cam = side ? cam_b : cam_a;
-                const int n_mob = on ? S.env[e].n_mob : 0;
-                bool near = false;
-                if (lane < n_mob) {
-                    const int ent = S.order[e][0][lane];
-                    const float mx = DF(s, S.env[e].buf, DF_X, ent, env0 + e) * kUnitPx, my = EY(s, ent, env0 + e) * kUnitPx;
-                    near = fabsf(mx - cam.px) <= reach_x && fabsf(my - cam.py) <= reach_y;
-                }
-                const unsigned long long m = __ballot(near);
-                if (near) S.near_mob[e][__popcll(m & ((1ull << lane) - 1ull))] = static_cast<uint8_t>(lane);
-                if (lane == 0) S.near_n[e] = __popcll(m);
-            }
-            wave_order();
-        }
-        const int cnt_a = on_a ? S.near_n[ea] * kSparks + S.env[ea].n_sprites + 1 : 0;
-        const int cnt_b = on_b ? S.near_n[eb] * kSparks + S.env[eb].n_sprites + 1 : 0;
+        const int cnt_a = on_a ? S.env[ea].n_mob * kSparks + S.env[ea].n_sprites + 1 : 0;
+        const int cnt_b = on_b ? S.env[eb].n_mob * kSparks + S.env[eb].n_sprites + 1 : 0;
         uint32_t* const draws_a = out.draws + size_t(env0 + ea) * kPrepDraws * kBlitWords;
         uint32_t* const draws_b = out.draws + size_t(env0 + eb) * kPrepDraws * kBlitWords;
         PrepDrawPass st{0, {0, 0}};
@@ -1429,11 +1401,11 @@ __global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView 
             const int slot = is_b ? q - cnt_a : q;
             const bool valid = q < cnt_a + cnt_b;
             const PrepEnv& pe = S.env[e];
-            const int n_parts = S.near_n[e] * kSparks;
+            const int n_parts = pe.n_mob * kSparks;
             PrepDraw p{false, false, false, kTexSpark, 0.0f, 0.0f, 1.0f, 1.0f};
             if (valid && slot < n_parts) {  // System_Particles::render (common_systems.cpp:315-337)
                 const int m = slot / kSparks, k = slot - m * kSparks;
-                const int ent = S.order[e][0][S.near_mob[e][m]];
+                const int ent = S.order[e][0][m];
                 const float life = SP(s, pe.buf, 2, ent, k, env);
                 const float px = SP(s, pe.buf, 0, ent, k, env), py = SP(s, pe.buf, 1, ent, k, env);
                 if (life > 0.0f) {

@@ -412,8 +412,8 @@ PG_D RotBox rot_box(const Blit& b) {
     return RotBox{x_lo, y_lo, x_hi - x_lo + 1, y_hi - y_lo + 1};
 }
 
-// kBatch: texel fetches in flight per lane — a batch costs one memory round trip, and a frame whose life is a chain of
-// such trips (jumper: its compass needle alone was four of about eighteen) wants few of them.
+// kBatch: texel fetches in flight per lane — a batch costs one memory round trip.  (Four everywhere: eight or sixteen for
+// jumper's needle and bunny — one trip instead of four and two — spill at its 96-register cap, render 0.94 -> 1.36 ms.)
 template <int kBatch = 4>
 PG_D void wave_blit_rotated(uint32_t* fb, const AtlasView& atlas, const Blit& b, const RotBox& box, int lane,
                             int stride = 64) {
@@ -672,7 +672,6 @@ PG_D RotBox rot_box_rows(const Blit& b, int row_lo, int row_hi) {  // rot_box cl
 template <int kGroup>
 struct ReplayState {
     unsigned long long mask, lones;  // draws still to do (those that reach my rows); which of them go alone
-    unsigned long long shared;       // PG_REPLAY_SHARE_AREA: … and which of those are done by BOTH waves, rows interleaved
     BlitWords packed;                // this lane's draw, packed for the cross-lane reads
     uint32_t box[2];                 // kRotInGroups: a rotated draw's box on my rows (x_lo | y_lo << 16, bw | bh << 16)
     uint32_t texel[kGroup];
@@ -700,15 +699,6 @@ PG_D void replay_group(const AtlasView& atlas, const Blit& mine, ReplayState<kGr
                 wave_order();
                 if (b.flip_mod & kRotated) {
                     wave_blit_rotated<kLone>(fb_for_lone, atlas, b, rot_box_rows(b, row_lo, row_hi), lane, 64);
-                } else if ((st.shared >> src) & 1ull) {
-                    // A draw that covers a good part of the frame (bossfight's 50×50 boss and its shield) falls mostly into
-                    // ONE wave's rows wherever it does not straddle row 32 evenly, and an env's LDS is held until its slower
-                    // wave is done.  Such a draw is done by both waves, its rows dealt alternately — the one place where a
-                    // wave writes rows it does not own, hence the barrier on either side.  Both waves classify it alike
-                    // (on the whole target) and reach it after the same draws of the list.
-                    __syncthreads();
-                    wave_blit<kLone>(fb_for_lone, atlas, b, lane, row_lo ? 1 : 0, 2, 0, kObsH);
-                    __syncthreads();
                 } else {
                     wave_blit<kLone>(fb_for_lone, atlas, b, lane, 0, 1, row_lo, row_hi);
                 }
@@ -751,7 +741,7 @@ PG_D void replay_group(const AtlasView& atlas, const Blit& mine, ReplayState<kGr
 
 template <int kGroup, bool kRotInGroups, bool kPacked>
 PG_D ReplayState<kGroup> replay_classify(const Blit& mine, unsigned long long mask, int lane, int row_lo, int row_hi) {
-    bool lone = false, reaches = false, shared = false;
+    bool lone = false, reaches = false;
     uint32_t box0 = 0, box1 = 0;
     if ((mask >> lane) & 1ull) {
         if (mine.flip_mod & kRotated) {
@@ -767,18 +757,11 @@ PG_D ReplayState<kGroup> replay_classify(const Blit& mine, unsigned long long ma
             const int y1 = (mine.dy + mine.dh) < row_hi ? (mine.dy + mine.dh) : row_hi;
             reaches = x1 > x0 && y1 > y0;
             lone = reaches && (x1 - x0) * (y1 - y0) > 64;
-#if defined(PG_REPLAY_SHARE_AREA)
-            const int wy0 = mine.dy > 0 ? mine.dy : 0, wy1 = (mine.dy + mine.dh) < kObsH ? (mine.dy + mine.dh) : kObsH;
-            shared = x1 > x0 && wy1 > wy0 && (x1 - x0) * (wy1 - wy0) >= PG_REPLAY_SHARE_AREA;  // (the same in both waves)
-            reaches = reaches || shared;
-            lone = lone || shared;
-#endif
         }
     }
     ReplayState<kGroup> st;
     st.mask = __ballot(reaches);
     st.lones = __ballot(lone && reaches);
-    st.shared = __ballot(shared);
     if (kPacked) st.packed = blit_pack(mine);
     st.box[0] = box0;
     st.box[1] = box1;
@@ -794,7 +777,7 @@ PG_D ReplayState<kGroup> replay_begin(const AtlasView& atlas, const Blit& mine, 
 }
 
 // (Measured and rejected, round 4: software-pipelining the groups — the texels of group k + 1 requested BEFORE group k is
-// blended, -DPG_REPLAY_PIPELINED below.  Bit-exact in all seven games, and slower: bossfight's render 0.779 -> 0.809 ms,
+// blended (commit 00e86ae has the loop).  Bit-exact in all seven games, and slower: bossfight's render 0.779 -> 0.809 ms,
 // jumper's 0.843 -> 0.853.  These kernels are bound by vector instructions at four clocks apiece (SQ_ACTIVE_INST_VALU:
 // 4.6 clocks per SQ_INSTS_VALU), not by the length of the pass's chain of round trips; the copies that free the state for
 // the next request are more instructions.)
@@ -802,7 +785,6 @@ template <int kGroup = 4, bool kRotInGroups = false, bool kPacked = true, int kL
 PG_D void replay_finish(uint32_t* fb, const AtlasView& atlas, const Blit& mine, ReplayState<kGroup>& st, int lane,
                         int row_lo, int row_hi) {
     wave_order();  // what the caller put into these rows in the meantime
-#ifndef PG_REPLAY_PIPELINED
     for (;;) {
 #pragma unroll
         for (int g = 0; g < kGroup; g++) {
@@ -812,29 +794,6 @@ PG_D void replay_finish(uint32_t* fb, const AtlasView& atlas, const Blit& mine, 
         if (st.mask == 0) break;
         replay_group<kGroup, kRotInGroups, kPacked, kLone>(atlas, mine, st, lane, row_lo, row_hi, fb);
     }
-#else
-    for (;;) {
-        uint32_t texel[kGroup];
-        int idx[kGroup], mod[kGroup];
-#pragma unroll
-        for (int g = 0; g < kGroup; g++) {
-            texel[g] = st.texel[g];
-            idx[g] = st.idx[g];
-            mod[g] = st.mod[g];
-        }
-        const bool more = st.mask != 0;
-        const bool lone_next = more && ((st.lones >> __builtin_ctzll(st.mask)) & 1ull) != 0;
-        if (more && !lone_next)  // the next group's texels leave now (st.texel / idx / mod are overwritten: copied above)
-            replay_group<kGroup, kRotInGroups, kPacked>(atlas, mine, st, lane, row_lo, row_hi, nullptr);
-#pragma unroll
-        for (int g = 0; g < kGroup; g++) {
-            if (idx[g] >= 0) blend_into(fb, idx[g], texel[g], mod[g]);
-            wave_order();  // draws may overlap
-        }
-        if (!more) break;
-        if (lone_next) replay_group<kGroup, kRotInGroups, kPacked, kLone>(atlas, mine, st, lane, row_lo, row_hi, fb);  // the big draw, then a group
-    }
-#endif
 }
 
 // kRotInGroups: small rotated draws (a bullet, a puff: ≤ 64 pixels of bounding box on my rows) share a memory round
@@ -1444,42 +1403,11 @@ PG_D bool compose_rows_from(uint32_t* fb, const ComposeLds<GRID>& L, const Atlas
         const uint32_t m = a < b ? a : b;
         return m < c ? m : c;
     };
-#if defined(PG_ROWS_BY_GRID_ROW)  // measured and rejected (round 4): bit-exact, fewer vector instructions, slower — coinrun's
-    // render + pre-pass 0.401 -> 0.408 ms, maze's render 0.345 -> 0.381, caveflyer's 0.540 -> 0.555: a loop of wave-uniform but
-    // dynamic length waits for its two cell words once per grid row where the flat form below has eight rows' worth in flight.
-    if constexpr (!TWO && !BOX) {
-        // By grid row: the pixel rows one grid row covers (4 or 5 of them in coinrun) see the same two cells, so
-        //     min3(background, cell a + column a + texel row, cell b + column b + texel row)
-        // = min(background, M + texel row) with M = min(cell a + column a, cell b + column b) worked out once per GRID row
-        // (no carries: every term is below 2^30 + 2^29), and the cell words are read once per grid row instead of once
-        // per pixel row: six vector instructions a row instead of eleven.  The rows of a segment are a loop of wave-uniform
-        // length; the gathers land in LDS by themselves, so nothing waits inside it.
-        const uint32_t above = static_cast<uint32_t>(__shfl_up(static_cast<int>(cells_a), 1));
-        const unsigned long long starts64 = __ballot(lane == 0 || cells_a != above) | (1ull << py_begin);
-        const uint32_t starts = static_cast<uint32_t>(starts64 >> py_begin);  // bit k: row py_begin + k begins a grid row (bit 0 set)
-        for (int k = 0; k < kRows;) {  // wave-uniform
-            const uint32_t rest = k + 1 < kRows ? starts >> (k + 1) : 0u;
-            const int len = rest ? __builtin_ctz(rest) + 1 : kRows - k;
-            const uint32_t* cp = reinterpret_cast<const uint32_t*>(cells + __builtin_amdgcn_readlane(cells_a, py_begin + k));
-            const uint32_t seams = (seconds32 >> k) & (len >= 32 ? ~0u : (1u << len) - 1u);
-            const uint32_t m_a = min3_u32(cp[0] + col_a_r, cp[1] + col_b, 0xffffffffu);
-            uint32_t m_b = 0u;
-            if (seams) m_b = min3_u32(cp[GRID] + col_a_r, cp[GRID + 1] + col_b, 0xffffffffu);
-            for (int j = 0; j < len; j++) {
-                const int py = py_begin + k + j;
-                const uint32_t s_bg = __builtin_amdgcn_readlane(bg_row, py);
-                const uint32_t s_a = __builtin_amdgcn_readlane(row_a, py);
-                uint32_t at = min3_u32(bg_col_r + s_bg, m_a + s_a, 0xffffffffu) & kOffsetBits;
-                if (seams & (1u << j)) {  // wave-uniform
-                    const uint32_t s_b = __builtin_amdgcn_readlane(row_b, py);
-                    at = min3_u32(at + 2u * kRank, m_b + s_b, 0xffffffffu) & kOffsetBits;
-                }
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(atlas_rsrc, (lds_ptr)(fb + py * kObsW), 4, static_cast<int>(at), 0, 0, 0);
-            }
-            k += len;
-        }
-    } else
-#endif
+    // (Measured and rejected, round 4 — commit bd6a4f0 has the loop: the rows walked by GRID row, min(cell a + column a,
+    // cell b + column b) worked out once per grid row and the cell words read once per grid row instead of once per pixel
+    // row: six vector instructions a row instead of eleven, bit-exact, and slower — coinrun's render 0.401 -> 0.408 ms,
+    // maze's 0.345 -> 0.381, caveflyer's 0.540 -> 0.555: a loop of wave-uniform but dynamic length waits for its two cell
+    // words once per grid row where the flat form below has eight rows' worth in flight.)
     {
 #pragma unroll
     for (int g = 0; g < kRows / kBatch; g++) {

@@ -12,7 +12,8 @@ done
 timeout 300 python bench.py --workload mixed 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_mixed.json
 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_coinrun_driver_args.json
 ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/ks_final && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_final -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/${TAG}_rocprof.log 2>&1; cp $(ls /tmp/ks_final/*/*kernel_stats.csv | head -1) $R/gpurun_out/${TAG}_coinrun_kernel_stats.csv )
-tools/pmc_traffic.sh ${TAG} > gpurun_out/${TAG}_pmc.log 2>&1   # every game: bench.py takes roofline.traffic of any --game from it
+# (tools/pmc_traffic.sh runs BEFORE this script, in a call of its own: its result, copied to profiles/*traffic_pmc.json, is
+# what the bench lines above quote as roofline.traffic — stamped with the fingerprint of the kernel sources it was taken on)
 for f in gpurun_out/${TAG}_bench_*.json; do python - "$f" <<'PY'
 import json,sys
 d=json.load(open(sys.argv[1])); c=d["config"]
@@ -20,4 +21,3 @@ print(c.get("game","mixed"), round(d["value"]/1e6,1), "M env-steps/s", round(d["
 PY
 done
 head -4 gpurun_out/${TAG}_coinrun_kernel_stats.csv | cut -c1-200
-cat gpurun_out/${TAG}_traffic.json | head -20
