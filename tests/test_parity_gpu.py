@@ -73,6 +73,31 @@ def test_row_composer_equals_draw_list_replay(game):
     slow.close()
 
 
+@pytest.mark.parametrize("game", ["coinrun", "climber", "caveflyer"])
+def test_render_pre_pass_equals_the_complete_path(game):
+    """The lean frames — composed from what the render pre-pass (pg_prepass.h setup_kernel) left in device memory — against
+    the same engine with the pre-pass switched off (pgv_set_debug bit 21: every frame's workgroup does its own set-up, the
+    path the pre-pass's `fat` frames take anyway): every byte of 1 024 envs over 300 steps, through episode ends (coinrun:
+    steps that end early and owe their entities a redo), explicit masked resets and the auto-resets in between."""
+    n = 1024
+    lean, full = EngineVec(game, n, seed_base=901), EngineVec(game, n, seed_base=901)
+    full.set_debug(1 << 21)
+    assert np.array_equal(lean.reset(), full.reset())
+    ends = 0
+    for s in range(300):
+        ol, rl, dl = lean.step(None, run_seed=6)
+        of, rf, df = full.step(None, run_seed=6)
+        assert np.array_equal(ol, of), "step %d" % s
+        assert np.array_equal(rl.view(np.uint32), rf.view(np.uint32)) and np.array_equal(dl, df)
+        ends += int(dl.sum())
+        if s % 97 == 50:  # an explicit reset of some envs (the pre-pass runs behind it with the same mask)
+            mask = (np.arange(n) % 5 == s % 5).astype(np.uint8)
+            assert np.array_equal(lean.reset(mask=mask), full.reset(mask=mask)), "masked reset at step %d" % s
+    assert ends > 0 or game == "caveflyer"
+    lean.close()
+    full.close()
+
+
 def test_coinrun_other_seeds_and_action_stream():
     _lockstep("coinrun", 64, 300, seed_base=4294967000, run_seed=9)  # seeds wrap through 2^32 like `unsigned long`→u32
 
