@@ -313,7 +313,104 @@ static void test_atan2() {
     std::printf("OK atan2 (%ld pairs)\n", checked);
 }
 
+// The axis arithmetic of Renderer::render_texture (games/*/renderer.cpp:5-82) + raster spec S1/S2 in one piece, as
+// pg_geom.h resolve_axis was written before round 4 split it into axis_head / axis_tail for the render pre-pass.
+static bool axis_in_one_piece(float cam_pos, float cam_len, float cam_scale, int tsize, float pos, float scale, bool flip,
+                              bool strict_far, pg::Span& out) {
+    float s = 0.0f;
+    float sl = static_cast<float>(tsize);
+    float d = (pos - cam_pos) * cam_scale + cam_len * 0.5f;
+    float dl = tsize * scale * cam_scale;
+    if ((strict_far ? d >= cam_len : d > cam_len) || d + dl < 0) return false;
+    if (d < 0.0f) {
+        float ratio = -d / dl;
+        s += sl * ratio;
+        sl -= s;
+        dl += d;
+        d = 0.0f;
+    }
+    if (d + dl > cam_len) {
+        float ratio = (d + dl - cam_len) / dl;
+        sl = sl * (1.0f - ratio);
+        dl = cam_len - d;
+    }
+    int padding = static_cast<int>(ceilf(1.0f / (scale * cam_scale)));
+    int r0 = static_cast<int>(floorf(s));
+    int rl = static_cast<int>(ceilf(sl)) + padding;
+    float off = s - r0;
+    float ratio = rl / sl;
+    dl *= ratio;
+    d -= off * (dl / sl);
+    if (flip) r0 = tsize - rl - r0;
+    if (!(dl >= 1.0f && dl < 32768.0f)) return false;
+    if (!(d > -32768.0f && d < 32768.0f)) return false;
+    out.d0 = static_cast<int>(d);
+    out.dn = static_cast<int>(dl);
+    int a = r0, b = r0 + rl;
+    if (a < 0) a = 0;
+    if (b > tsize) b = tsize;
+    out.s0 = a;
+    out.sn = b - a;
+    return out.sn > 0;
+}
+
+// What the render pre-pass (pg_prepass.h prep_spans) rests on: (1) head + tail IS the one-piece arithmetic, bit for bit;
+// (2) a tile that neither crop touches has the tail of its axis's TEMPLATE (the same texture, scale and camera scale, d = 0)
+// in everything but d0, and its d0 is (int)d.  Swept over the games' own parameter families (tile textures of 64, 53 and
+// 128 texels at 16 / size pixels per texel, the zooms of all seven games and their modes, cameras at arbitrary float
+// positions, tile positions on the 16-pixel grid) and over random floats.
+static void test_axis_template() {
+    uint32_t seed = 2024u;
+    auto next = [&]() { return seed = seed * 1664525u + 1013904223u; };
+    auto unit = [&]() { return static_cast<float>(next() >> 8) / 16777216.0f; };
+    const int sizes[] = {64, 53, 128, 70, 99};
+    const float zooms[] = {0.2f, 0.3f, 0.5f, 0.16f, 64.0f / 16.0f / 11.0f, 64.0f / 16.0f / 13.0f, 64.0f / 16.0f / 19.0f, 1.0f,
+                           64.0f / (16.0f * 15.0f), 64.0f / (16.0f * 8.0f)};
+    long whole = 0, cut = 0, culled = 0;
+    for (int k = 0; k < 3000000; k++) {
+        const bool on_grid = k % 4 != 0;
+        const int tsize = sizes[next() % 5];
+        const float cam_scale = on_grid ? zooms[next() % 10] : 0.05f + 2.0f * unit();
+        const float scale = on_grid ? 16.0f / tsize : 0.01f + unit();
+        const float cam_len = 64.0f;
+        const float cam_pos = 1100.0f * unit() - 20.0f;
+        // (positions around the camera: two thirds of a screen either side, so that whole, cut and culled tiles all occur)
+        const float near = cam_pos + (2.0f * unit() - 1.0f) * (0.67f * cam_len / cam_scale);
+        const float pos = on_grid ? 16.0f * floorf(near / 16.0f) : near;
+        const bool flip = !on_grid && (next() & 1u), strict = (next() & 1u) != 0;
+        pg::Span want{0, 0, 0, 0}, got{0, 0, 0, 0};
+        const bool ok_want = axis_in_one_piece(cam_pos, cam_len, cam_scale, tsize, pos, scale, flip, strict, want);
+        const bool ok_got = pg::resolve_axis(cam_pos, cam_len, cam_scale, tsize, pos, scale, flip, strict, got);
+        CHECK(ok_want == ok_got && (!ok_want || (want.d0 == got.d0 && want.dn == got.dn && want.s0 == got.s0 && want.sn == got.sn)),
+              "head + tail differs from the one-piece arithmetic (case %d)", k);
+        pg::AxisHead h;
+        if (!pg::axis_head(cam_pos, cam_len, cam_scale, tsize, pos, scale, strict, h)) {
+            culled++;
+            CHECK(!ok_want, "culled by the head, drawn by the arithmetic (case %d)", k);
+            continue;
+        }
+        if (!(h.d < 0.0f) && !(h.d + h.dl > cam_len)) {  // prep_spans' test for "a whole tile"
+            whole++;
+            pg::Span tmpl{0, 0, 0, 0};
+            pg::AxisHead t{0.0f, tsize * scale * cam_scale};  // the template's head: d = 0, the same dl
+            const bool usable = !(t.d + t.dl > cam_len);
+            CHECK(usable, "a whole tile whose template would be cropped (case %d)", k);
+            const bool ok_tmpl = pg::axis_tail(cam_len, cam_scale, tsize, scale, flip, t, tmpl);
+            CHECK(ok_tmpl == ok_want, "template and tile disagree on whether anything is drawn (case %d)", k);
+            if (ok_want)
+                CHECK(want.d0 == static_cast<int>(h.d) && want.dn == tmpl.dn && want.s0 == tmpl.s0 && want.sn == tmpl.sn,
+                      "a whole tile is not its template shifted: d0 %d vs %d, dn %d vs %d, s0 %d vs %d, sn %d vs %d (case %d)", want.d0,
+                      static_cast<int>(h.d), want.dn, tmpl.dn, want.s0, tmpl.s0, want.sn, tmpl.sn, k);
+        } else {
+            cut++;
+        }
+    }
+    CHECK(whole > 300000 && cut > 100000 && culled > 100000, "the sweep must reach all three kinds (%ld whole, %ld cut, %ld culled)", whole, cut, culled);
+    std::printf("OK axis template (%ld whole tiles, %ld cut, %ld culled)\n", whole, cut, culled);
+}
+
 int main() {
+    test_axis_template();
     test_sincos();
     test_atan2();
     test_blend();
