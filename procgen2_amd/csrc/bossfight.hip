@@ -23,6 +23,7 @@
 // pixels, mostly in the upper wave's rows) done by both waves with their rows dealt alternately.  Bit-exact; render
 // 0.783 -> 0.806 ms: the two barriers per shared draw cost more than the idle lower wave.)
 #include "pg_render.h"
+#include "pg_prepass.h"
 #include "pg_rng.h"
 #include "pg_sincos.h"
 
@@ -82,7 +83,15 @@ struct State {
     float* bshot;   // [n][S_COUNT][64]   (S_BOUNCE_T unused)
     float* boom;    // [n][3][8]  x, y, frame
     float* rock;    // [3][4][n]  x, y, texture index
+    struct Prep {   // the render pre-pass's hand-over (setup_kernel → render_kernel; scratch memory, not state)
+        uint32_t* backdrops;  // [13][128]  per backdrop: bg_offset of pixel columns 0-63, of pixel rows 0-63 (backdrop_kernel, once)
+        uint32_t* meta;       // [n]        boss bullets | other draws << 8 | backdrop << 16
+        uint32_t* bullets;    // [n][64][kBulletWords]  visible boss bullets in drawing order
+        uint32_t* draws;      // [n][64][kBlitWords]    the visible draws of the second list in drawing order
+    } prep;
 };
+constexpr int kBulletWords = 10;  // pg_render.h BlitWords, sine, cosine (16.16), bounding box on the target (x, y, w, h: a byte each), one spare
+constexpr int kBackdrops = 13;
 
 PG_D float& SF(const State& s, int field, int env) { return s.f[size_t(field) * s.n + env]; }
 PG_D int32_t& SI(const State& s, int field, int env) { return s.i[size_t(field) * s.n + env]; }
@@ -818,9 +827,11 @@ __global__ void __launch_bounds__(64, PG_BOSSFIGHT_WAVES) logic_kernel(State s, 
     }
 }
 
-// render_game(true) (bossfight.cpp:401-424): one workgroup of two wavefronts per env (pg_render.h).
-__global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
-                                                    int flags) {
+// render_game(true) (bossfight.cpp:401-424): one workgroup of two wavefronts per env (pg_render.h).  The complete frame,
+// set-up included: every frame before the pre-pass existed; still the draw-list replay (flags bit 0), kDebugNoPrepass and
+// the timing experiments.
+__global__ void __launch_bounds__(128, 4) render_full_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
+                                                         int flags) {
     const int env = blockIdx.x;
     if (mask && !mask[env]) return;
     const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // two wavefronts per env (pg_render.h)
@@ -970,6 +981,240 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
     wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
 }
 
+// ---- the render pre-pass ---------------------------------------------------------------------------------------------
+// Everything the frame needs that does not depend on the pixel: which draws there are, each one's rectangle on the target
+// and in its texture, a rotated bullet's bounding box.  Both wavefronts of an env's render workgroup used to work all of
+// it out, one draw per lane, most lanes idle (a frame has some dozens of draws for 128 lanes); here a wavefront takes the
+// lists of two envs, dealt densely over its lanes, once.  The background's 64 column and 64 row offsets depend on the
+// backdrop only (the camera never moves): a table per backdrop, made once.
+
+// bg_axis + bg_offset of compose_background for each of the 13 backdrops (bossfight.cpp:416-419).
+__global__ void __launch_bounds__(128) backdrop_kernel(State s, AtlasView atlas) {
+    const int backdrop = blockIdx.x, lane = threadIdx.x & 63, axis = threadIdx.x >> 6;
+    const Camera cam{0.0f, 0.0f, kCamSize, kCamSize, kCamScale};
+    const int4 d = atlas.desc[kTexSpace + backdrop];
+    const float pos = -kCamSize / kCamScale * 0.5f, scale = 1.0f / d.z * kCamSize / kCamScale;
+    s.prep.backdrops[backdrop * 128 + axis * 64 + lane] = bg_offset(bg_axis(cam, d, pos, pos, scale, axis), lane, axis);
+}
+
+constexpr int kPrepEnvs = 8, kPrepThreads = 256;
+enum { PE_SKINS, PE_FLAGS, PE_A_NEXT, PE_A_COUNT, PE_B_NEXT, PE_B_COUNT, PE_X_NEXT, PE_X_COUNT, PE_NROCKS, PE_PHASE,
+       PE_BX, PE_BY, PE_AX, PE_AY, PE_COUNT };
+struct SetupLds {
+    int4 desc[kTexCount];
+    uint32_t env[kPrepEnvs][PE_COUNT];       // the scalars of the envs of this workgroup (float bits where floats)
+    PrepDrawQueue queue[kPrepThreads / 64];  // one worklist per wavefront (pg_prepass.h)
+};
+__global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView atlas, const uint8_t* mask) {
+    __shared__ SetupLds S;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int env0 = blockIdx.x * kPrepEnvs;
+    if (tid < kTexCount) S.desc[tid] = atlas.desc[tid];
+    if (tid >= 64 && tid < 64 + kPrepEnvs * PE_COUNT) {
+        const int q = tid - 64, f = q / kPrepEnvs, e = q - f * kPrepEnvs, env = env0 + e;  // (the envs of a field side by side)
+        constexpr int kInts[10] = {I_SKINS, I_FLAGS, I_A_NEXT, I_A_COUNT, I_B_NEXT, I_B_COUNT, I_X_NEXT, I_X_COUNT, I_NROCKS, I_PHASE};
+        constexpr int kFloats[4] = {F_BX, F_BY, F_AX, F_AY};
+        uint32_t v = 0;
+        if (env < s.n) v = f < 10 ? static_cast<uint32_t>(SI(s, kInts[f], env)) : __float_as_uint(SF(s, kFloats[f - 10], env));
+        S.env[e][f] = v;
+    }
+    __syncthreads();
+    static_assert(kPrepEnvs == 2 * (kPrepThreads / 64), "two envs per wavefront");
+    const Camera cam{0.0f, 0.0f, kCamSize, kCamSize, kCamScale};  // camera_position stays {0,0} (renderer.h:18)
+    const int ea = 2 * wave, eb = 2 * wave + 1;
+    const bool on_a = env0 + ea < s.n && !(mask && !mask[env0 + ea]), on_b = env0 + eb < s.n && !(mask && !mask[env0 + eb]);
+    int done_bullets[2];
+    // System_Mob_AI::render (common_systems.cpp:392-450): the boss's bullets, newest first, rotated
+    {
+        const int cnt_a = on_a ? static_cast<int>(S.env[ea][PE_B_COUNT]) : 0, cnt_b = on_b ? static_cast<int>(S.env[eb][PE_B_COUNT]) : 0;
+        int done[2] = {0, 0};
+        for (int base = 0; base < cnt_a + cnt_b; base += 64) {  // wave-uniform
+            const int q = base + lane;
+            const bool is_b = q >= cnt_a, valid = q < cnt_a + cnt_b;
+            const int e = is_b ? eb : ea, env = env0 + e, slot = is_b ? q - cnt_a : q;
+            const uint32_t* pe = S.env[e];
+            bool has = false;
+            int want_tex = kTexLaser + static_cast<int>((pe[PE_SKINS] >> 12) & 15u);
+            float px = 0.0f, py = 0.0f;
+            int rot_sn = 0, rot_cs = 0;  // (boss_fire worked them out)
+            if (valid) {
+                const int k = (kBossShots + static_cast<int>(pe[PE_B_NEXT]) - 1 - slot) % kBossShots;
+                const float frame = BS(s, S_FRAME, k, env);
+                if (frame != -1.0f) {
+                    has = true;
+                    if (frame != 0.0f) want_tex = kTexBoom + static_cast<int>(frame - 1.0f);
+                    px = BS(s, S_X, k, env);
+                    py = BS(s, S_Y, k, env);
+                    rot_sn = __float_as_int(BS(s, S_SN, k, env));
+                    rot_cs = __float_as_int(BS(s, S_CS, k, env));
+                }
+            }
+            Blit b;
+            RotBox box{0, 0, 0, 0};
+            if (has) {
+                const int4 d = S.desc[want_tex];
+                const float size = 0.1f;
+                has = resolve_rotated_at(cam, d.y, d.z, d.x, px * kUnitPx - size * d.y * 0.5f, py * kUnitPx - size * d.z * 0.5f,
+                                         rot_sn, rot_cs, size, 1.0f, b);
+                if (has && (b.flip_mod & kRotated)) {  // neither wave of the render workgroup would find a pixel of it: not listed
+                    box = rot_box(b);
+                    has = box.bw > 0 && box.bh > 0;
+                }
+            }
+            const unsigned long long m_a = __ballot(has && !is_b), m_b = __ballot(has && is_b);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (has) {
+                const int rank = is_b ? done[1] + __popcll(m_b & below) : done[0] + __popcll(m_a & below);
+                const BlitWords w = blit_pack(b);
+                uint2* at = reinterpret_cast<uint2*>(s.prep.bullets + (size_t(env) * kBossShots + rank) * kBulletWords);
+                at[0] = make_uint2(w.w[0], w.w[1]);
+                at[1] = make_uint2(w.w[2], w.w[3]);
+                at[2] = make_uint2(w.w[4], w.w[5]);
+                at[3] = make_uint2(static_cast<uint32_t>(b.rot_sn), static_cast<uint32_t>(b.rot_cs));
+                at[4] = make_uint2(static_cast<uint32_t>(box.x_lo) | static_cast<uint32_t>(box.y_lo) << 8 |
+                                       static_cast<uint32_t>(box.bw) << 16 | static_cast<uint32_t>(box.bh) << 24, 0u);
+            }
+            done[0] += __popcll(m_a);
+            done[1] += __popcll(m_b);
+        }
+        done_bullets[0] = done[0];
+        done_bullets[1] = done[1];
+    }
+    // second list: boss ship, shield, explosions, barriers (positive-z sprites), agent bullets, agent — culled first,
+    // the survivors finished densely (pg_prepass.h prep_draws_pass)
+    {
+        auto slots_of = [&](int e) {
+            const uint32_t* pe = S.env[e];
+            const int n_listed = (pe[PE_FLAGS] & kFlagListed) ? static_cast<int>(pe[PE_NROCKS]) : 0;  // empty draw list right after a reset (D2)
+            return 2 + static_cast<int>(pe[PE_X_COUNT]) + n_listed + static_cast<int>(pe[PE_A_COUNT]) + 1;
+        };
+        const int cnt_a = on_a ? slots_of(ea) : 0, cnt_b = on_b ? slots_of(eb) : 0;
+        uint32_t* const draws_a = s.prep.draws + size_t(env0 + ea) * kPrepDraws * kBlitWords;
+        uint32_t* const draws_b = s.prep.draws + size_t(env0 + eb) * kPrepDraws * kBlitWords;
+        PrepDrawPass st{0, {0, 0}};
+        PrepDrawQueue& Q = S.queue[wave];
+        for (int base = 0; base < cnt_a + cnt_b; base += 64) {  // wave-uniform
+            const int q = base + lane;
+            const bool is_b = q >= cnt_a, valid = q < cnt_a + cnt_b;
+            const int e = is_b ? eb : ea, env = env0 + e, slot = is_b ? q - cnt_a : q;
+            const uint32_t* pe = S.env[e];
+            const int skins = static_cast<int>(pe[PE_SKINS]);
+            const int a_ship = skins & 15, a_laser = (skins >> 4) & 15, b_ship = (skins >> 8) & 15;
+            const int x_count = static_cast<int>(pe[PE_X_COUNT]), n_rocks = static_cast<int>(pe[PE_NROCKS]);
+            const int first_boom = 2, first_rock = first_boom + x_count;
+            const int n_listed = (pe[PE_FLAGS] & kFlagListed) ? n_rocks : 0;
+            const int first_shot = first_rock + n_listed, agent_slot = first_shot + static_cast<int>(pe[PE_A_COUNT]);
+            const float bx = __uint_as_float(pe[PE_BX]), by = __uint_as_float(pe[PE_BY]);
+            bool has = false, sprite = false;
+            int want_tex = 0;
+            float px = 0.0f, py = 0.0f, size = 0.0f, alpha = 1.0f;
+            if (!valid) {
+            } else if (slot == 0) {
+                has = true;
+                want_tex = kTexBoss + b_ship;
+                px = bx;
+                py = by;
+                size = 0.25f;
+            } else if (slot == 1) {
+                has = (static_cast<int>(pe[PE_PHASE]) % 2 == 0);
+                want_tex = kTexShield;
+                px = bx;
+                py = by;
+                size = 0.25f;
+                alpha = 0.7f;
+            } else if (slot < first_rock) {
+                const int k = (kBooms + static_cast<int>(pe[PE_X_NEXT]) - 1 - (slot - first_boom)) % kBooms;
+                const float frame = BM(s, 2, k, env);
+                if (frame != -1.0f) {
+                    has = true;
+                    want_tex = kTexBoom + static_cast<int>(frame);
+                    px = BM(s, 0, k, env);
+                    py = BM(s, 1, k, env);
+                    size = 0.3f;
+                }
+            } else if (slot < first_shot) {
+                const int r = n_rocks - 1 - (slot - first_rock);  // sprite set order: newest barrier first
+                has = true;
+                sprite = true;
+                want_tex = kTexRock + static_cast<int>(RK(s, 2, r, env));
+                px = RK(s, 0, r, env);
+                py = RK(s, 1, r, env);
+            } else if (slot < agent_slot) {
+                const int k = (kAgentShots + static_cast<int>(pe[PE_A_NEXT]) - 1 - (slot - first_shot)) % kAgentShots;
+                const float frame = AS(s, S_FRAME, k, env);
+                if (frame != -1.0f) {
+                    has = true;
+                    want_tex = (frame == 0.0f) ? kTexLaser + a_laser : kTexBoom + static_cast<int>(frame - 1.0f);
+                    px = AS(s, S_X, k, env);
+                    py = AS(s, S_Y, k, env);
+                    size = 0.05f;
+                }
+            } else {
+                has = true;
+                want_tex = kTexPlayer + a_ship;
+                px = __uint_as_float(pe[PE_AX]);
+                py = __uint_as_float(pe[PE_AY]);
+                size = 0.05f;
+            }
+            PrepDraw p{has, false, false, want_tex, 0.0f, 0.0f, 1.0f, 1.0f};
+            if (has) {  // the two kinds of draw differ in their parameters only
+                const int4 d = S.desc[want_tex];
+                if (sprite) {  // common_systems.cpp:22-48: offset (-0.15,-0.15), scale 0.3 (bossfight.cpp:479)
+                    const float scale = 1.0f * 0.3f;
+                    p.wx = (px + -0.15f) * kUnitPx;
+                    p.wy = (py + -0.15f) * kUnitPx;
+                    p.scale = scale * kUnitPx / d.y;
+                } else {
+                    p.wx = px * kUnitPx - size * d.y * 0.5f;
+                    p.wy = py * kUnitPx - size * d.z * 0.5f;
+                    p.scale = size;
+                    p.alpha = alpha;
+                }
+            }
+            prep_draws_pass(Q, st, S.desc, cam, cam, draws_a, draws_b, valid, is_b, p, lane);
+        }
+        prep_draws_flush(Q, st, S.desc, cam, cam, draws_a, draws_b, lane);
+        if (lane < 2) {
+            const int e = lane ? eb : ea;
+            const bool on = lane ? on_b : on_a;
+            const uint32_t word = static_cast<uint32_t>(lane ? done_bullets[1] : done_bullets[0]) |
+                                  static_cast<uint32_t>(lane ? st.done[1] : st.done[0]) << 8 | ((S.env[e][PE_SKINS] >> 16) & 255u) << 16;
+            if (on) s.prep.meta[env0 + e] = word;
+        }
+    }
+}
+
+// The frame from what setup_kernel left.  Nothing here is shared between the two wavefronts of the env: no barrier.
+__global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io) {
+    const int env = blockIdx.x;
+    if (mask && !mask[env]) return;
+    const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // two wavefronts per env (pg_render.h)
+    constexpr int halves = 2;
+    __shared__ alignas(16) uint32_t fb[kFbWords];
+    const uint32_t meta = __builtin_amdgcn_readfirstlane(s.prep.meta[env]);
+    const int n_bullets = meta & 0xffu, n_draws = (meta >> 8) & 0xffu, backdrop = meta >> 16;
+    const int row_lo = half * (kObsH / halves), row_hi = (half + 1) * (kObsH / halves);
+    const uint32_t* tab = s.prep.backdrops + backdrop * 128;
+    const uint32_t bg_col = tab[lane], bg_row = tab[64 + lane];
+    const bool has_bullet = lane < n_bullets, has_draw = lane < n_draws;
+    uint2 b3 = make_uint2(0u, 65536u), b4 = make_uint2(0u, 0u);
+    const uint32_t* mine_at = s.prep.bullets + (size_t(env) * kBossShots + lane) * kBulletWords;
+    Blit bullet = prep_draw_load(mine_at, has_bullet);
+    if (has_bullet) {
+        b3 = reinterpret_cast<const uint2*>(mine_at)[3];
+        b4 = reinterpret_cast<const uint2*>(mine_at)[4];
+    }
+    bullet.rot_sn = static_cast<int32_t>(b3.x);
+    bullet.rot_cs = static_cast<int32_t>(b3.y);
+    const RotBox box{static_cast<int>(b4.x & 0xffu), static_cast<int>((b4.x >> 8) & 0xffu), static_cast<int>((b4.x >> 16) & 0xffu),
+                     static_cast<int>(b4.x >> 24)};
+    const Blit draw = prep_draw_load(s.prep.draws + (size_t(env) * kPrepDraws + lane) * kBlitWords, has_draw);
+    compose_background_from(fb, atlas, bg_col, bg_row, lane, half);
+    wave_replay_rows<4, true>(fb, atlas, bullet, __ballot(has_bullet), lane, row_lo, row_hi, &box);
+    wave_replay_rows<4, true>(fb, atlas, draw, __ballot(has_draw), lane, row_lo, row_hi);
+    wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, row_lo, row_hi);
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -1112,6 +1357,7 @@ class BossfightGame final : public Game {
     int blocks() const { return (s_.n + 63) / 64; }
     void launch_make(hipStream_t st, uint32_t seed_base, int env_offset) override {
         hipLaunchKernelGGL(make_kernel, dim3(blocks()), dim3(64), 0, st, s_, seed_base, env_offset, plan);
+        hipLaunchKernelGGL(backdrop_kernel, dim3(kBackdrops), dim3(128), 0, st, s_, atlas_);  // (the engine binds the scratch memory first)
     }
     void launch_reset(hipStream_t st, const uint8_t* mask, const int32_t* seeds, StepIO io) override {
         hipLaunchKernelGGL(reset_kernel, dim3(blocks()), dim3(64), 0, st, s_, mask, seeds, io, plan);
@@ -1125,8 +1371,31 @@ class BossfightGame final : public Game {
         hipLaunchKernelGGL(frame_kernel, dim3(1), dim3(kFrameThreads), 0, st, s_, atlas_, env, FrameTarget{d_px, w, h});
         return true;
     }
+    // (every flag that changes the frame's path — the draw-list replay, kDebugNoPrepass, the timing experiments — takes the complete kernel)
+    bool lean() const { return (debug_flags & ~kDebugNoPrefetch) == 0; }
+    void launch_prepass(hipStream_t st, const uint8_t* mask) override {
+        if (lean()) hipLaunchKernelGGL(setup_kernel, dim3((s_.n + kPrepEnvs - 1) / kPrepEnvs), dim3(kPrepThreads), 0, st, s_, atlas_, mask);
+    }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
-        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags);
+        if (lean())
+            hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io);
+        else
+            hipLaunchKernelGGL(render_full_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags);
+    }
+    static size_t up256(size_t b) { return (b + 255) & ~size_t(255); }
+    size_t scratch_bytes(int n) const override {
+        return up256(size_t(kBackdrops) * 128 * 4) + up256(size_t(n) * 4) + up256(size_t(n) * kBossShots * kBulletWords * 4) +
+               up256(size_t(n) * kPrepDraws * kBlitWords * 4);
+    }
+    void bind_scratch(void* d_scratch, int n) override {
+        uint8_t* p = static_cast<uint8_t*>(d_scratch);
+        s_.prep.backdrops = reinterpret_cast<uint32_t*>(p);
+        p += up256(size_t(kBackdrops) * 128 * 4);
+        s_.prep.meta = reinterpret_cast<uint32_t*>(p);
+        p += up256(size_t(n) * 4);
+        s_.prep.bullets = reinterpret_cast<uint32_t*>(p);
+        p += up256(size_t(n) * kBossShots * kBulletWords * 4);
+        s_.prep.draws = reinterpret_cast<uint32_t*>(p);
     }
     // Same layout as oracle/pgo_bossfight.cpp Bossfight::dump_state.
     int dump_state(hipStream_t st, int env, float* out, int cap) override {

@@ -739,13 +739,23 @@ PG_D void replay_group(const AtlasView& atlas, const Blit& mine, ReplayState<kGr
     }
 }
 
+// `whole`: this lane's rotated draw's bounding box on the whole target, where somebody has worked it out already (the
+// render pre-pass: rot_box is two 64-bit products per axis) — it is clipped to the wave's rows here; nullptr: rot_box now.
+PG_D RotBox rot_box_clip(RotBox box, int row_lo, int row_hi) {
+    const int lo = box.y_lo > row_lo ? box.y_lo : row_lo;
+    const int hi = (box.y_lo + box.bh) < row_hi ? (box.y_lo + box.bh) : row_hi;
+    box.y_lo = lo;
+    box.bh = hi - lo;
+    return box;
+}
 template <int kGroup, bool kRotInGroups, bool kPacked>
-PG_D ReplayState<kGroup> replay_classify(const Blit& mine, unsigned long long mask, int lane, int row_lo, int row_hi) {
+PG_D ReplayState<kGroup> replay_classify(const Blit& mine, unsigned long long mask, int lane, int row_lo, int row_hi,
+                                         const RotBox* whole = nullptr) {
     bool lone = false, reaches = false;
     uint32_t box0 = 0, box1 = 0;
     if ((mask >> lane) & 1ull) {
         if (mine.flip_mod & kRotated) {
-            const RotBox box = rot_box_rows(mine, row_lo, row_hi);
+            const RotBox box = whole ? rot_box_clip(*whole, row_lo, row_hi) : rot_box_rows(mine, row_lo, row_hi);
             reaches = box.bw > 0 && box.bh > 0;
             lone = !kRotInGroups || box.bw * box.bh > 64 || mine.dw > kRotSmall || mine.dh > kRotSmall;
             // (the box of a draw that goes into a group travels with it: no second pass through rot_box's 64-bit products)
@@ -770,8 +780,8 @@ PG_D ReplayState<kGroup> replay_classify(const Blit& mine, unsigned long long ma
 
 template <int kGroup = 4, bool kRotInGroups = false, bool kPacked = true>
 PG_D ReplayState<kGroup> replay_begin(const AtlasView& atlas, const Blit& mine, unsigned long long mask, int lane,
-                                      int row_lo, int row_hi) {
-    ReplayState<kGroup> st = replay_classify<kGroup, kRotInGroups, kPacked>(mine, mask, lane, row_lo, row_hi);
+                                      int row_lo, int row_hi, const RotBox* whole = nullptr) {
+    ReplayState<kGroup> st = replay_classify<kGroup, kRotInGroups, kPacked>(mine, mask, lane, row_lo, row_hi, whole);
     replay_group<kGroup, kRotInGroups, kPacked>(atlas, mine, st, lane, row_lo, row_hi, nullptr);  // (a big draw first: nothing requested)
     return st;
 }
@@ -801,8 +811,8 @@ PG_D void replay_finish(uint32_t* fb, const AtlasView& atlas, const Blit& mine, 
 // bullets a frame).  Costs registers and code in the group loop, so only kernels with room to spare turn it on.
 template <int kGroup = 4, bool kRotInGroups = false, bool kPacked = true, int kLone = 4>
 PG_D void wave_replay_rows(uint32_t* fb, const AtlasView& atlas, const Blit& mine, unsigned long long mask, int lane,
-                           int row_lo, int row_hi) {
-    ReplayState<kGroup> st = replay_begin<kGroup, kRotInGroups, kPacked>(atlas, mine, mask, lane, row_lo, row_hi);
+                           int row_lo, int row_hi, const RotBox* whole = nullptr) {
+    ReplayState<kGroup> st = replay_begin<kGroup, kRotInGroups, kPacked>(atlas, mine, mask, lane, row_lo, row_hi, whole);
     replay_finish<kGroup, kRotInGroups, kPacked, kLone>(fb, atlas, mine, st, lane, row_lo, row_hi);
 }
 
@@ -1011,14 +1021,11 @@ constexpr uint32_t kNoTexel = 0x40000000u;
 // L.row2 and is chosen per lane, at the price of a select and an add in front of every tile load.
 // The frame of a game without a tile layer (bossfight): the background over black, nothing else — one candidate per
 // pixel instead of the composer's five, no span tables.  Same arithmetic as compose_rows with four absent candidates.
-PG_D void compose_background(uint32_t* fb, const AtlasView& atlas, const BgAxis& bga, int lane, int half, int halves) {
+// The background over black from this lane's two offsets (bg_offset of pixel column `lane` and of pixel row `lane`):
+// the wave's own rows, nothing shared with the other wave — no barrier.
+PG_D void compose_background_from(uint32_t* fb, const AtlasView& atlas, uint32_t bg_col, uint32_t bg_row, int lane, int half) {
     const __amdgpu_buffer_rsrc_t bg_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t*>(atlas.texels), 0, static_cast<int>(atlas.texel_bytes), 0x00020000);
-    // wave 0 resolved the x axis, wave 1 the y axis: trade the per-column / per-row offsets through the target's memory
-    fb[64 * half + lane] = bg_offset(bga, lane, half);
-    __syncthreads();
-    const uint32_t bg_col = fb[lane], bg_row = fb[64 + lane];
-    __syncthreads();
     // all the rows of the wave at once: 32 gathers in flight, one memory round trip
     constexpr int kRows = kObsH / 2;
     const int py_begin = half * kRows;
@@ -1037,6 +1044,14 @@ PG_D void compose_background(uint32_t* fb, const AtlasView& atlas, const BgAxis&
         for (int k = 0; k < kRows; k++)
             fb[(py_begin + k) * kObsW + lane] = blend_px(0u, t[k], static_cast<int>(t[k] >> 24));
     }
+}
+PG_D void compose_background(uint32_t* fb, const AtlasView& atlas, const BgAxis& bga, int lane, int half, int halves) {
+    // wave 0 resolved the x axis, wave 1 the y axis: trade the per-column / per-row offsets through the target's memory
+    fb[64 * half + lane] = bg_offset(bga, lane, half);
+    __syncthreads();
+    const uint32_t bg_col = fb[lane], bg_row = fb[64 + lane];
+    __syncthreads();
+    compose_background_from(fb, atlas, bg_col, bg_row, lane, half);
     (void)halves;
     __syncthreads();
 }

@@ -73,11 +73,12 @@ def test_row_composer_equals_draw_list_replay(game):
     slow.close()
 
 
-@pytest.mark.parametrize("game", ["coinrun", "climber", "caveflyer"])
+@pytest.mark.parametrize("game", ["coinrun", "climber", "caveflyer", "bossfight"])
 def test_render_pre_pass_equals_the_complete_path(game):
     """The lean frames — composed from what the render pre-pass (pg_prepass.h setup_kernel) left in device memory — against
     the same engine with the pre-pass switched off (pgv_set_debug bit 21: every frame's workgroup does its own set-up, the
-    path the pre-pass's `fat` frames take anyway): every byte of 1 024 envs over 300 steps, through episode ends (coinrun:
+    path the pre-pass's `fat` frames take anyway; bossfight has no such frames — its complete kernel is a second kernel, chosen
+    by the host): every byte of 1 024 envs over 300 steps, through episode ends (coinrun:
     steps that end early and owe their entities a redo), explicit masked resets and the auto-resets in between."""
     n = 1024
     lean, full = EngineVec(game, n, seed_base=901), EngineVec(game, n, seed_base=901)
