@@ -155,6 +155,22 @@ PG_HD bool resolve_draw(const Camera& cam, int tw, int th, int tex_off, float po
     return true;
 }
 
+// Raster spec S6, the bounding box of a rotated draw on the target (pg_render.h rot_box).  How tight it may be:
+// a pixel with doubled offsets (px, py) from the rectangle's centre is drawn iff a = px·cs + py·sn lies in [−dw·2^16, dw·2^16)
+// and b = py·cs − px·sn in [−dh·2^16, dh·2^16).  Then px·N = a·cs − b·sn with N = cs² + sn², so |px| ≤ 2^16·(dw·|cs| +
+// dh·|sn|) / N.  sn and cs are 2^16·sin and 2^16·cos rounded to integers, each within 0.51 of the real product, so N =
+// 2^32·(1 + e) with |e| < 1.5 / 2^16, and with v = (dw·|cs| + dh·|sn|) / 2^16 ≤ dw + dh:  |px| ≤ v·(1 + 1.5/2^16) ≤ v +
+// 2(dw + dh)/2^16 — px being an integer, |px| ≤ rot_extent(dw, dh, |cs|, |sn|); likewise |py| ≤ rot_extent(dh, dw, …).
+// px = 2(X − dx) + 1 − dw, so X − dx runs from ceil((dw − 1 − ex) / 2) = rot_first to floor((dw − 1 + ex) / 2) = rot_last.
+// (Until round 4 the box had one more unit in ex and one more pixel on every side on top of that: 10 × 10 pixels around a
+// 4 × 4 bullet at 45° instead of 6 × 6 — more than a wave's 64 lanes, so every bullet went alone, with a memory round trip
+// of its own.  Any superset of the drawn pixels gives the same frame; tests/cpp/test_primitives.cpp sweeps this one.)
+PG_HD int rot_extent(int along, int across, int acs, int asn) {
+    return static_cast<int>((static_cast<long long>(along) * acs + static_cast<long long>(across) * asn + 2ll * (along + across)) >> 16);
+}
+PG_HD int rot_first(int dn, int extent) { return (dn - extent) >> 1; }
+PG_HD int rot_last(int dn, int extent) { return (dn - 1 + extent) >> 1; }
+
 // Raster spec S3: nearest texel for destination column/row `i` of `n`, over `len` texels from `start`.
 // floor(a / b) for 0 <= a < 2^22, 1 <= b < 2^22.  On the device: one reciprocal estimate and a ±1 fix-up
 // instead of the ~30-instruction generic 32-bit division (a and b are exact in float, the estimate is off

@@ -400,11 +400,9 @@ struct RotBox {
 };
 PG_D RotBox rot_box(const Blit& b) {
     const int acs = b.rot_cs < 0 ? -b.rot_cs : b.rot_cs, asn = b.rot_sn < 0 ? -b.rot_sn : b.rot_sn;
-    const int ex = static_cast<int>((static_cast<long long>(b.dw) * acs + static_cast<long long>(b.dh) * asn) >> 16) + 1;
-    const int ey = static_cast<int>((static_cast<long long>(b.dw) * asn + static_cast<long long>(b.dh) * acs) >> 16) + 1;
-    // pixel X has doubled offset px = 2(X − dx) + 1 − dw; |px| ≤ ex  ⇐  X within the bounds below (floor/ceil + 1)
-    int x_lo = b.dx + ((b.dw - 1 - ex) >> 1) - 1, x_hi = b.dx + ((b.dw - 1 + ex + 1) >> 1) + 1;
-    int y_lo = b.dy + ((b.dh - 1 - ey) >> 1) - 1, y_hi = b.dy + ((b.dh - 1 + ey + 1) >> 1) + 1;
+    const int ex = rot_extent(b.dw, b.dh, acs, asn), ey = rot_extent(b.dh, b.dw, acs, asn);  // (pg_geom.h: why this is enough)
+    int x_lo = b.dx + rot_first(b.dw, ex), x_hi = b.dx + rot_last(b.dw, ex);
+    int y_lo = b.dy + rot_first(b.dh, ey), y_hi = b.dy + rot_last(b.dh, ey);
     x_lo = x_lo < 0 ? 0 : x_lo;
     y_lo = y_lo < 0 ? 0 : y_lo;
     x_hi = x_hi > kObsW - 1 ? kObsW - 1 : x_hi;
@@ -1023,11 +1021,11 @@ constexpr uint32_t kNoTexel = 0x40000000u;
 // pixel instead of the composer's five, no span tables.  Same arithmetic as compose_rows with four absent candidates.
 // The background over black from this lane's two offsets (bg_offset of pixel column `lane` and of pixel row `lane`):
 // the wave's own rows, nothing shared with the other wave — no barrier.
+template <int kRows = kObsH / 2>
 PG_D void compose_background_from(uint32_t* fb, const AtlasView& atlas, uint32_t bg_col, uint32_t bg_row, int lane, int half) {
     const __amdgpu_buffer_rsrc_t bg_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t*>(atlas.texels), 0, static_cast<int>(atlas.texel_bytes), 0x00020000);
     // all the rows of the wave at once: 32 gathers in flight, one memory round trip
-    constexpr int kRows = kObsH / 2;
     const int py_begin = half * kRows;
     uint32_t t[kRows];
 #pragma unroll

@@ -2,6 +2,7 @@
 // against the genuine libstdc++ behaviour the reference depends on (SURVEY.md rows T1–T4).
 // Built and run by tests/test_primitives.py; prints "OK <name>" per section, exits non-zero on failure.
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -409,8 +410,56 @@ static void test_axis_template() {
     std::printf("OK axis template (%ld whole tiles, %ld cut, %ld culled)\n", whole, cut, culled);
 }
 
+// pg_geom.h rot_extent / rot_first / rot_last: every pixel raster spec S6 draws of a rotated rectangle lies inside the box
+// they give.  Brute force in doubled pixel coordinates: all offsets within twice the rectangle's diagonal, the inside test
+// exactly as pg_render.h wave_blit_rotated makes it (64-bit), over sizes 1..48 squared plus a few large ones, and the
+// 16.16 sine / cosine of 3 000 angles (rounded the way rotation_16_16 rounds them, and off by one unit either way).
+static void test_rot_box() {
+    long drawn = 0, cases = 0, tight = 0;
+    auto sweep = [&](int dw, int dh, int sn, int cs) {
+        const int acs = cs < 0 ? -cs : cs, asn = sn < 0 ? -sn : sn;
+        const int ex = pg::rot_extent(dw, dh, acs, asn), ey = pg::rot_extent(dh, dw, acs, asn);
+        const int first_x = pg::rot_first(dw, ex), last_x = pg::rot_last(dw, ex), first_y = pg::rot_first(dh, ey), last_y = pg::rot_last(dh, ey);
+        const int reach = dw + dh + 4;
+        int seen_lo = 1 << 30, seen_hi = -(1 << 30);
+        for (int Y = -reach; Y <= reach + dh; Y++)
+            for (int X = -reach; X <= reach + dw; X++) {  // X, Y relative to the rectangle's corner (dx, dy)
+                const long long px = 2 * X + 1 - dw, py = 2 * Y + 1 - dh;
+                const long long lx = px * cs + py * sn + static_cast<long long>(dw) * 65536;
+                const long long ly = -px * sn + py * cs + static_cast<long long>(dh) * 65536;
+                if (lx < 0 || ly < 0 || lx >= static_cast<long long>(2 * dw) * 65536 || ly >= static_cast<long long>(2 * dh) * 65536) continue;
+                drawn++;
+                seen_lo = X < seen_lo ? X : seen_lo;
+                seen_hi = X > seen_hi ? X : seen_hi;
+                CHECK(X >= first_x && X <= last_x && Y >= first_y && Y <= last_y,
+                      "a drawn pixel outside the box: %dx%d sn %d cs %d pixel (%d,%d) box x %d..%d y %d..%d", dw, dh, sn, cs, X, Y, first_x, last_x, first_y, last_y);
+            }
+        cases++;
+        if (seen_lo <= seen_hi && last_x - first_x <= seen_hi - seen_lo + 2) tight++;
+    };
+    for (int k = 0; k < 3000; k++) {
+        const double deg = k < 360 ? k : (k * 0.1234567 - 180.0);
+        const float theta = static_cast<float>(deg * (3.14159265358979323846 / 180.0));
+        const int sn = static_cast<int>(std::floor(static_cast<double>(std::sin(theta)) * 65536.0 + 0.5));
+        const int cs = static_cast<int>(std::floor(static_cast<double>(std::cos(theta)) * 65536.0 + 0.5));
+        const int dw = 1 + (k * 7) % 48, dh = 1 + (k * 13) % 48;
+        sweep(dw, dh, sn, cs);
+        sweep(dh, dw, sn + (k % 3) - 1, cs + ((k / 3) % 3) - 1);
+        if (k % 100 == 0) sweep(200 + k / 20, 3 + k / 100, sn, cs);
+    }
+    for (int d = 1; d <= 12; d++)
+        for (int deg = 0; deg < 360; deg++) {  // bullets and puffs: small squares at every whole degree
+            const float theta = static_cast<float>(deg * (3.14159265358979323846 / 180.0));
+            sweep(d, d, static_cast<int>(std::floor(static_cast<double>(std::sin(theta)) * 65536.0 + 0.5)),
+                  static_cast<int>(std::floor(static_cast<double>(std::cos(theta)) * 65536.0 + 0.5)));
+        }
+    CHECK(drawn > 1000000 && tight * 10 > cases * 9, "the sweep must draw something and the box must be tight (%ld pixels, %ld of %ld cases within a pixel a side)", drawn, tight, cases);
+    std::printf("OK rot box (%ld cases, %ld drawn pixels, all inside; %ld within a pixel a side of what is drawn)\n", cases, drawn, tight);
+}
+
 int main() {
     test_axis_template();
+    test_rot_box();
     test_sincos();
     test_atan2();
     test_blend();
