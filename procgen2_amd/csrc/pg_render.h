@@ -465,6 +465,38 @@ PG_D void blend_into(uint32_t* fb, int idx, uint32_t texel, int mod) {
 }
 
 // All 64 lanes execute one (wave-uniform) blit into the LDS target.
+// Columns [xa, xa + cwa) of the clipped rectangle (x0.., y0.., ch rows), cwa ≤ 32: the wave is 64 / W rows of W = 8, 16 or
+// 32 lanes.  A lane's texel column never changes; lane r holds the texel row of target row y0 + r (`row_at`, × the
+// texture's pitch), fetched across lanes.
+template <int kBatch>
+PG_D void wave_blit_columns(uint32_t* fb, const uint32_t* tex, const Blit& b, int xa, int cwa, int y0, int ch, int row_at, int lane,
+                            int half, int halves) {
+    const int mod = b.flip_mod & 0xff;
+    const int wshift = cwa <= 8 ? 3 : (cwa <= 16 ? 4 : 5);  // wave-uniform
+    const int rows = 64 >> wshift;
+    const int rx = lane & ((1 << wshift) - 1), rsub = lane >> wshift;
+    const bool on = rx < cwa;
+    const int x = xa + rx;
+    int i = x - b.dx;
+    if (b.flip_mod & kFlipH) i = b.dw - 1 - i;
+    const int u = on ? sample_index(b.sx, b.sw, i, b.dw) : b.sx;
+    for (int t0 = half; t0 * rows < ch; t0 += halves * kBatch) {
+        uint32_t texel[kBatch];
+        int idx[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) {
+            const int r = (t0 + k * halves) * rows + rsub;
+            const int v_tw = __shfl(row_at, r & 63);
+            const bool ok = on && r < ch;
+            idx[k] = ok ? (y0 + r) * kObsW + x : -1;
+            texel[k] = 0;
+            if (ok) texel[k] = tex[v_tw + u];
+        }
+#pragma unroll
+        for (int k = 0; k < kBatch; k++)
+            if (idx[k] >= 0) blend_into(fb, idx[k], texel[k], mod);
+    }
+}
 template <int kBatch = 4>
 PG_D void wave_blit(uint32_t* fb, const AtlasView& atlas, const Blit& b, int lane, int half = 0, int halves = 1,
                     int row_lo = 0, int row_hi = kObsH) {
@@ -477,23 +509,23 @@ PG_D void wave_blit(uint32_t* fb, const AtlasView& atlas, const Blit& b, int lan
     const int tw = b.tex_w;
     const int mod = b.flip_mod & 0xff;
     const bool fh = (b.flip_mod & kFlipH) != 0, fv = (b.flip_mod & kFlipV) != 0;
-
-    if (cw > 32) {
+    // The texel row of target row y0 + r is the same for every lane: lane r works it out once for all of them (the
+    // target has 64 rows) and the loops below pick it up with a cross-lane read — one division per lane and draw for the
+    // rows, one for the lane's column, instead of three per pixel (one pixel per lane in row-major order, the narrow
+    // draws' form until round 4).
+    int row_at = 0;
+    if (y0 + lane < y1) {
+        int j = y0 + lane - b.dy;
+        if (fv) j = b.dh - 1 - j;
+        row_at = sample_index(b.sy, b.sh, j, b.dh) * tw;
+    }
+    if (cw > 48) {
         // Wide blit (backgrounds on the fallback path, jumper's compass): lane = column, kBatch rows per iteration.
-        // The texel row of target row y0 + r is the same for every lane: lane r works it out once for all of them
-        // (the target has 64 rows) and the row loop picks it up with a cross-lane read instead of every lane redoing
-        // the division for every row.
         const int x = x0 + lane;
         const bool on = lane < cw;
         int i = x - b.dx;
         if (fh) i = b.dw - 1 - i;
         const int u = on ? sample_index(b.sx, b.sw, i, b.dw) : b.sx;
-        int row_at = 0;
-        if (y0 + lane < y1) {
-            int j = y0 + lane - b.dy;
-            if (fv) j = b.dh - 1 - j;
-            row_at = sample_index(b.sy, b.sh, j, b.dh) * tw;
-        }
         for (int yb = y0 + half; yb < y1; yb += halves * kBatch) {
             uint32_t texel[kBatch];
 #pragma unroll
@@ -510,33 +542,13 @@ PG_D void wave_blit(uint32_t* fb, const AtlasView& atlas, const Blit& b, int lan
                 if (on && y < y1) blend_into(fb, y * kObsW + x, texel[k], mod);
             }
         }
+    } else if (cw > 32) {
+        // 33 to 48 columns (bossfight's shield, 35 × 29 at 0.7 alpha — every pixel a full blend): a lane per column would
+        // leave up to half the wave idle in each of `ch` trips; the first 32 columns two rows a trip, the rest apart.
+        wave_blit_columns<kBatch>(fb, tex, b, x0, 32, y0, ch, row_at, lane, half, halves);
+        wave_blit_columns<kBatch>(fb, tex, b, x0 + 32, cw - 32, y0, ch, row_at, lane, half, halves);
     } else {
-        const int total = cw * ch;
-        const int step = 64 * halves;
-        for (int p0 = lane + 64 * half; p0 < total; p0 += step * kBatch) {
-            uint32_t texel[kBatch];
-            int idx[kBatch];
-#pragma unroll
-            for (int k = 0; k < kBatch; k++) {
-                const int p = p0 + k * step;
-                idx[k] = -1;
-                texel[k] = 0;
-                if (p >= total) continue;
-                const int ry = udiv_small(p, cw);
-                const int rx = p - ry * cw;
-                const int x = x0 + rx, y = y0 + ry;
-                int i = x - b.dx, j = y - b.dy;
-                if (fh) i = b.dw - 1 - i;
-                if (fv) j = b.dh - 1 - j;
-                const int u = sample_index(b.sx, b.sw, i, b.dw);
-                const int v = sample_index(b.sy, b.sh, j, b.dh);
-                idx[k] = y * kObsW + x;
-                texel[k] = tex[v * tw + u];
-            }
-#pragma unroll
-            for (int k = 0; k < kBatch; k++)
-                if (idx[k] >= 0) blend_into(fb, idx[k], texel[k], mod);
-        }
+        wave_blit_columns<kBatch>(fb, tex, b, x0, cw, y0, ch, row_at, lane, half, halves);
     }
 }
 
