@@ -169,10 +169,11 @@ PGV_API int32_t pgv_timed_steps(pgv_env* env, int32_t steps, uint32_t run_seed, 
  * three events per step sit inside the region. */
 PGV_API int32_t pgv_step_times(pgv_env* env, int32_t steps, uint32_t run_seed, float* h_step_ms, float* h_render_ms);
 
-/* Debug switches (tests only); neither changes a result.  Bit 0: render the background and tile layer by replaying the
+/* Debug switches (tests only); none changes a result.  Bit 0: render the background and tile layer by replaying the
  * draw list one blit at a time instead of the fused row composer.  Bit 8: no level prefetch — every reset generates its
  * level inside the step.  Bit 21: no render pre-pass — every frame's workgroup does its own set-up, as the frames the
- * pre-pass hands back do anyway.  Any other bit is refused. */
+ * pre-pass hands back do anyway.  Bit 23: the pre-pass hands back every third env's frame (the way for tests to the
+ * hand-back path of games that never take it in a normal run).  Any other bit is refused. */
 PGV_API int32_t pgv_set_debug(pgv_env* env, int32_t flags);
 
 /* Parity taps (host pointers): game-defined state vector / tile ids of one env; return the full

@@ -976,7 +976,7 @@ struct SetupLds {
     PrepDrawQueue queue[kPrepThreads / 64];
 };
 
-__global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView atlas, const uint8_t* mask) {
+__global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView atlas, const uint8_t* mask, int flags) {
     __shared__ SetupLds S;
     PrepLds<kGrid, kPrepEnvs, kSpan>& P = S.P;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1043,7 +1043,7 @@ __global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView 
             v.th = wall_d.z;
             v.th2 = 0;
             v.tile_scale = kUnitPx / wall_d.y;
-            if (v.cols > kGrid || v.rows > kGrid) {
+            if (v.cols > kGrid || v.rows > kGrid || ((flags & kDebugFatThirds) && (env0 + e) % 3 == 0)) {
                 P.fat[e] = 1;
                 active = false;
             }
@@ -1376,7 +1376,7 @@ class CaveflyerGame final : public Game {
     void bind_scratch(void* d_scratch, int n) override { s_.prep = prep_bind(d_scratch, n, kGrid, kBlitWords, false); }
     void launch_prepass(hipStream_t st, const uint8_t* mask) override {
         if (!(debug_flags & (1 | kDebugNoPrepass)))
-            hipLaunchKernelGGL(setup_kernel, dim3((s_.n + kPrepEnvs - 1) / kPrepEnvs), dim3(kPrepThreads), 0, st, s_, atlas_, mask);
+            hipLaunchKernelGGL(setup_kernel, dim3((s_.n + kPrepEnvs - 1) / kPrepEnvs), dim3(kPrepThreads), 0, st, s_, atlas_, mask, debug_flags);
     }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
         hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags);

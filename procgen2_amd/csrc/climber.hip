@@ -689,7 +689,7 @@ struct SetupLds {
     PrepDrawQueue queue[kPrepThreads / 64];
 };
 
-__global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView atlas, const uint8_t* mask) {
+__global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView atlas, const uint8_t* mask, int flags) {
     __shared__ SetupLds S;
     PrepLds<kGrid, kPrepEnvs, kMaxSpan>& P = S.P;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -754,7 +754,7 @@ __global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView 
             v.th = mid_d.z;
             v.th2 = two ? top_d.z : 0;
             v.tile_scale = kUnitPx / mid_d.y;
-            if (v.cols > kGrid || v.rows > kGrid || top_d.y != mid_d.y || top_d.z > mid_d.z) {
+            if (v.cols > kGrid || v.rows > kGrid || top_d.y != mid_d.y || top_d.z > mid_d.z || ((flags & kDebugFatThirds) && (env0 + e) % 3 == 0)) {
                 P.fat[e] = 1;
                 active = false;
             }
@@ -1040,7 +1040,7 @@ class ClimberGame final : public Game {
     void bind_scratch(void* d_scratch, int n) override { s_.prep = prep_bind(d_scratch, n, kGrid, kBlitWords, true); }
     void launch_prepass(hipStream_t st, const uint8_t* mask) override {
         if (!(debug_flags & (1 | kDebugNoPrepass)))
-            hipLaunchKernelGGL(setup_kernel, dim3((s_.n + kPrepEnvs - 1) / kPrepEnvs), dim3(kPrepThreads), 0, st, s_, atlas_, mask);
+            hipLaunchKernelGGL(setup_kernel, dim3((s_.n + kPrepEnvs - 1) / kPrepEnvs), dim3(kPrepThreads), 0, st, s_, atlas_, mask, debug_flags);
     }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
         hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags);

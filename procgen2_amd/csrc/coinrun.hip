@@ -1300,7 +1300,7 @@ __global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView 
             v.th = tile_desc.z;
             v.th2 = 0;
             v.tile_scale = kUnitPx / tile_desc.y;
-            if (v.cols > kGrid || v.rows > kGrid) {
+            if (v.cols > kGrid || v.rows > kGrid || ((flags & kDebugFatThirds) && (env0 + e) % 3 == 0)) {
                 P.fat[e] = 1;
                 active = false;
             }

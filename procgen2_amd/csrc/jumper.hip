@@ -20,6 +20,7 @@
 #include "pg_kruskal.h"
 #include "pg_order.h"
 #include "pg_prefetch.h"
+#include "pg_prepass.h"
 #include "pg_render.h"
 #include "pg_rng.h"
 #include "pg_defs.h"
@@ -116,6 +117,8 @@ struct State {
     // the compass ring as it lands on the observation (extend_atlas; word offsets into the atlas, 0 = not prepared)
     uint32_t hud_image, hud_list;
     int hud_n;
+    PrepOut prep;  // what setup_kernel leaves for render_kernel (pg_prepass.h); not part of the state blob
+    uint32_t* fat;  // [1 + n]  number of frames the pre-pass left to the complete path, then their envs (render_full_kernel)
 };
 
 PG_D float& SF(const State& s, int field, int env) { return s.f[size_t(field) * s.n + env]; }
@@ -586,15 +589,14 @@ __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actio
 }
 
 // render_game(true) (jumper.cpp:445-509): one workgroup of two wavefronts per env (pg_render.h).
-__global__ void __launch_bounds__(128, PG_RENDER_WAVES) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
-                                                    int flags) {
-    const int env = blockIdx.x;
-    if (mask && !mask[env]) return;
+constexpr int kGrid = 16;  // 64 px / 4.8 px per tile → at most 16 columns/rows in view
+
+// The complete frame of one env by its workgroup, set-up included: the frames the pre-pass marks fat, the draw-list
+// replay (flags bit 0) and kDebugNoPrepass.
+PG_D void render_full(const State& s, const AtlasView& atlas, const StepIO& io, int flags, int env, uint32_t* fb,
+                      ComposeLds<kGrid>& L) {
     const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // two wavefronts per env (pg_render.h)
     constexpr int halves = 2;
-    __shared__ alignas(16) uint32_t fb[kFbWords];
-    constexpr int kGrid = 16;  // 64 px / 4.8 px per tile → at most 16 columns/rows in view
-    __shared__ ComposeLds<kGrid> L;
 
     const float game_zoom = 0.3f;
     const Camera cam{SF(s, F_CAMX, env), SF(s, F_CAMY, env), 64.0f, 64.0f, game_zoom * 64.0f / 64.0f};
@@ -771,12 +773,12 @@ __global__ void __launch_bounds__(128, PG_RENDER_WAVES) render_kernel(State s, A
             // the ring is the same 60×60 pixels in every frame: prepared once (pg_render.h overlay_rows), in its place in
             // the draw order — after the bunny, before the needle and the bar
             wave_replay_rows(fb, atlas, mine, __ballot(has && lane <= bunny_lane), lane, row_lo, row_hi);
-            if (!PG_ABL(flags, 0x100000))  // (traffic experiment, -DPG_ABLATE builds only: no compass ring)
+            if (!PG_ABL(flags, 0x10000))  // (traffic experiment, -DPG_ABLATE builds only: no compass ring)
                 overlay_rows(fb, atlas.texels + s.hud_image, reinterpret_cast<const uint2*>(atlas.texels + s.hud_list), s.hud_n,
                              lane, row_lo, row_hi);
-            // (timing experiments, -DPG_ABLATE builds only: 0x200000 no needle, 0x400000 no bar)
-            if (PG_ABL(flags, 0x200000)) has = has && lane != bunny_lane + 2;
-            if (PG_ABL(flags, 0x400000)) has = has && lane != bunny_lane + 3;
+            // (timing experiments, -DPG_ABLATE builds only: 0x20000 no needle, 0x40000 no bar)
+            if (PG_ABL(flags, 0x20000)) has = has && lane != bunny_lane + 2;
+            if (PG_ABL(flags, 0x40000)) has = has && lane != bunny_lane + 3;
             wave_replay_rows(fb, atlas, mine, __ballot(has && lane >= bunny_lane + 2), lane, row_lo, row_hi);
         } else {
             wave_replay_rows(fb, atlas, mine, __ballot(has), lane, row_lo, row_hi);
@@ -896,6 +898,353 @@ __global__ void __launch_bounds__(128, PG_RENDER_WAVES) render_kernel(State s, A
     }
     // each wave stores the rows it owns (pg_render.h wave_replay_rows): no barrier
     wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
+}
+
+// ------------------------------------------------------------------------------------------------
+// The render pre-pass (pg_prepass.h; coinrun.hip's setup_kernel is the commented model): tile spans, per-pixel
+// candidates, the cell table and the resolved, culled draws of kPrepEnvs envs per workgroup.
+// Reference arithmetic moved here unchanged: renderer.cpp:5-82, tilemap.cpp:255-280 (the window),
+// common_systems.cpp:26-48,204-247,285-308 (sprites, bunny, particles).  The compass stays with the render wave: its
+// ring is a prepared overlay, needle and bar are raw screen-space draws without a division (jumper.cpp:473-509).
+// ------------------------------------------------------------------------------------------------
+constexpr int kPrepEnvs = 8, kPrepThreads = 256;
+enum { GW_NEEDLE_X = 0, GW_NEEDLE_Y, GW_BAR_W, GW_NEEDLE_SN, GW_NEEDLE_CS };  // PM_GAME words
+
+struct PrepEnv {
+    int32_t sflags, n_draw;
+    float avx, aphase, ax, ay, gx, gy;
+};
+struct SetupLds {
+    PrepLds<kGrid, kPrepEnvs, kMaxSpan> P;
+    PrepEnv env[kPrepEnvs];
+    int4 desc[kTexCount];
+    uint32_t draw_ids[kPrepEnvs][kSpikeSlots / 4];    // State::draw of every env …
+    uint32_t spike_cells[kPrepEnvs][kSpikeSlots / 2];  // … and State::spike_cell: fetched before anything needs them
+    uint32_t row_valid[kPrepEnvs][kGrid / 4];
+    int32_t counts[kPrepEnvs];
+    PrepDrawQueue queue[kPrepThreads / 64];
+};
+
+__global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView atlas, const uint8_t* mask, int flags) {
+    __shared__ SetupLds S;
+    PrepLds<kGrid, kPrepEnvs, kMaxSpan>& P = S.P;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int env0 = blockIdx.x * kPrepEnvs;
+    const PrepOut& out = s.prep;
+
+    // ---- one memory round trip: descriptor table, the envs' scalars (lane = env), their draw lists and spike cells
+    for (int q = tid; q < kPrepEnvs * 2 * 64; q += kPrepThreads) (&P.cover[0][0][0])[q] = 0u;
+    if (tid < kTexCount) S.desc[tid] = atlas.desc[tid];
+    static_assert(kTexCount <= kPrepThreads, "one descriptor per thread");
+    static_assert(kPrepEnvs * kSpikeSlots / 4 == kPrepThreads, "one word of the draw lists per thread");
+    {
+        const int e = tid / (kSpikeSlots / 4), w = tid - e * (kSpikeSlots / 4);
+        if (env0 + e < s.n) {
+            S.draw_ids[e][w] = reinterpret_cast<const uint32_t*>(s.draw + size_t(env0 + e) * kSpikeSlots)[w];
+            const uint32_t* cells = reinterpret_cast<const uint32_t*>(s.spike_cell + size_t(env0 + e) * kSpikeSlots);
+            S.spike_cells[e][2 * w] = cells[2 * w];
+            S.spike_cells[e][2 * w + 1] = cells[2 * w + 1];
+        }
+    }
+    Camera cam{};
+    int themes = 0;
+    float bgshift = 0.0f;
+    bool active = false;
+    uint32_t game_words[5] = {0u, 0u, 0u, 0u, 0u};
+    if (tid < kPrepEnvs) {
+        const int e = tid, env = env0 + e;
+        active = env < s.n && (!mask || mask[env]);
+        if (active) {
+            cam = Camera{SF(s, F_CAMX, env), SF(s, F_CAMY, env), 64.0f, 64.0f, kObsZoom * 64.0f / 64.0f};
+            themes = SI(s, I_THEMES, env);
+            bgshift = SF(s, F_BGSHIFT, env);
+            PrepEnv pe{};
+            pe.sflags = SI(s, I_FLAGS, env);
+            pe.n_draw = (pe.sflags & kFlagListed) ? SI(s, I_NSPIKES, env) + 1 : 0;  // empty right after a reset
+            pe.avx = SF(s, F_AVX, env);
+            pe.aphase = SF(s, F_APHASE, env);
+            pe.ax = SF(s, F_AX, env);
+            pe.ay = SF(s, F_AY, env);
+            pe.gx = SF(s, F_GX, env);
+            pe.gy = SF(s, F_GY, env);
+            S.env[e] = pe;
+            game_words[GW_NEEDLE_X] = __float_as_uint(SF(s, F_NEEDLE_X, env));
+            game_words[GW_NEEDLE_Y] = __float_as_uint(SF(s, F_NEEDLE_Y, env));
+            game_words[GW_BAR_W] = __float_as_uint(SF(s, F_BAR_W, env));
+            game_words[GW_NEEDLE_SN] = static_cast<uint32_t>(SI(s, I_NEEDLE_SN, env));
+            game_words[GW_NEEDLE_CS] = static_cast<uint32_t>(SI(s, I_NEEDLE_CS, env));
+        }
+    }
+    __syncthreads();
+    // ---- per env (lane = env): camera, tile window, background draw — render_full's preamble
+    if (tid < kPrepEnvs) {
+        const int e = tid;
+        PrepView v{};
+        P.fat[e] = 0;
+        P.soft_rows[e] = P.hard_rows[e] = 0;
+        S.counts[e] = 0;
+        if (active) {
+            v.cam = cam;
+            const int backdrop = themes & 0xff, theme = (themes >> 8) & 0xff;
+            const int4 d = S.desc[kTexBackdrop + backdrop];
+            const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
+            const float extra = aspect - 1.0f;
+            v.bg = BgDraw{d, -bgshift * extra, 0.0f, 64.0f * kUnitPx / d.z};  // jumper.cpp:459-464
+            const float vx = (cam.px - cam.sw * 0.5f / cam.scale) * kPxUnit;  // tilemap.cpp:255-264
+            const float vy = (cam.py - cam.sh * 0.5f / cam.scale) * kPxUnit;
+            const float vw = cam.sw * kPxUnit / cam.scale, vh = cam.sh * kPxUnit / cam.scale;
+            v.x0 = static_cast<int>(floorf(vx));
+            v.y0 = static_cast<int>(floorf(vy));
+            v.cols = static_cast<int>(ceilf(vx + vw)) - v.x0 + 1;
+            v.rows = static_cast<int>(ceilf(vy + vh)) - v.y0 + 1;
+            const int4 top_d = S.desc[kTexTop + theme], mid_d = S.desc[kTexMid + theme];
+            const bool two = top_d.z != mid_d.z;  // the brown cap tile is 64×53 (see climber.hip)
+            v.tw = mid_d.y;
+            v.th = mid_d.z;
+            v.th2 = two ? top_d.z : 0;
+            v.tile_scale = kUnitPx / mid_d.y;
+            if (v.cols > kGrid || v.rows > kGrid || top_d.y != mid_d.y || top_d.z > mid_d.z || ((flags & kDebugFatThirds) && (env0 + e) % 3 == 0)) {
+                P.fat[e] = 1;
+                active = false;
+            }
+            P.soft_rows[e] = static_cast<uint32_t>(soft_rows_of(d.w, top_d.w | mid_d.w));
+            P.hard_rows[e] = static_cast<uint32_t>(hard_rows_of(d.w, mid_d.w));  // (cap tiles are few: always worth the attempt)
+            // tile kinds: 0 = cap (bit 0 of its offset: the layer's second texture), 1 = body
+#pragma unroll
+            for (int k = 0; k < kPrepKinds; k++) P.meta[e][PM_KINDS + k] = kNoTexel;
+            P.meta[e][PM_KINDS + 0] = (static_cast<uint32_t>(top_d.x) * 4u) | (two ? 1u : 0u);
+            P.meta[e][PM_KINDS + 1] = static_cast<uint32_t>(mid_d.x) * 4u;
+#pragma unroll
+            for (int k = 0; k < 5; k++) P.meta[e][PM_GAME + k] = game_words[k];
+            prep_row_valid<kGrid, H>(v.y0, S.row_valid[e]);
+        }
+        v.active = active ? 1 : 0;
+        P.view[e] = v;
+    }
+    __syncthreads();
+
+    // ---- the cell table: lane = (env, grid column), one 16-byte load of the column-major map (pg_prepass.h) …
+    const int cell_e = tid / kGrid, cell_c = tid - cell_e * kGrid;
+    bool cell_lane = false, cell_x_ok = false;
+    uint32_t column[kGrid / 4] = {};
+    if (tid < kPrepEnvs * kGrid && P.view[cell_e].active) {
+        cell_lane = true;
+        prep_column_fetch<kGrid, W, H>(s.tiles + size_t(env0 + cell_e) * kTileStride, P.view[cell_e].x0 + cell_c, P.view[cell_e].y0, cell_x_ok, column);
+    }
+    // … the spans are worked out while it travels …
+    prep_spans<kGrid, kMaxSpan, kPrepEnvs, true>(P, tid, kPrepThreads);
+    // … then sixteen kind bytes: wall_top → 0, wall_mid → 1, everything else (empty, spike) no tile
+    if (cell_lane) {
+        uint32_t in_rows[4];
+        prep_column_rows<kGrid>(column, S.row_valid[cell_e], cell_x_ok, kWallMid, in_rows);  // out of bounds is a wall (tilemap.h:84-89)
+        uint32_t kinds[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const uint32_t t = in_rows[w] & 0x07070707u;                  // kEmpty 0, kWallTop 1, kWallMid 2, kSpike 3
+            const uint32_t lo = t & 0x01010101u, hi = (t >> 1) & 0x01010101u;
+            const uint32_t wall = (lo ^ hi) * 0xffu;                      // 0xff where t is 1 or 2
+            kinds[w] = (hi & wall) | ~wall;                               // kind = t - 1 for walls; 0xff: no tile
+        }
+        prep_column_store<kGrid>(out.cells + size_t(env0 + cell_e) * (kGrid * kGrid), cell_c, kinds);
+    }
+    __syncthreads();
+    prep_axes<kGrid, kMaxSpan, kPrepEnvs>(P, out, env0, wave, kPrepThreads / 64, lane);
+
+    // ---- the draws in the reference's order: particles (common_systems.cpp:285-308), the positive-z sprites (carrot and
+    // spikes, :26-48), the bunny (:204-247).  Two envs per wavefront, cull first (pg_prepass.h prep_draws_pass).
+    static_assert(kPrepEnvs == 2 * (kPrepThreads / 64), "two envs per wavefront");
+    {
+        const int ea = 2 * wave, eb = 2 * wave + 1;
+        const bool on_a = P.view[ea].active != 0, on_b = P.view[eb].active != 0;
+        const Camera cam_a = P.view[ea].cam, cam_b = P.view[eb].cam;
+        const int cnt_a = on_a ? kPuffs + S.env[ea].n_draw + 1 : 0, cnt_b = on_b ? kPuffs + S.env[eb].n_draw + 1 : 0;
+        uint32_t* const draws_a = out.draws + size_t(env0 + ea) * kPrepDraws * kBlitWords;
+        uint32_t* const draws_b = out.draws + size_t(env0 + eb) * kPrepDraws * kBlitWords;
+        PrepDrawPass st{0, {0, 0}};
+        PrepDrawQueue& Q = S.queue[wave];
+        for (int base = 0; base < cnt_a + cnt_b; base += 64) {  // wave-uniform
+            const int q = base + lane;
+            const bool is_b = q >= cnt_a;
+            const int e = is_b ? eb : ea, env = env0 + e;
+            const int slot = is_b ? q - cnt_a : q;
+            const bool valid = q < cnt_a + cnt_b;
+            const PrepEnv& pe = S.env[e];
+            PrepDraw p{false, false, false, kTexPuff, 0.0f, 0.0f, 1.0f, 1.0f};
+            float num = kUnitPx, post = 1.0f;  // scale = num / texture width * post (one division for every kind)
+            if (valid && slot < kPuffs) {
+                const float life = PF(s, PF_LIFE, slot, env), px = PF(s, PF_X, slot, env), py = PF(s, PF_Y, slot, env);
+                if (life > 0.0f) {
+                    const int4 d = S.desc[kTexPuff];
+                    const float lifespan = 5.0f;
+                    const float life_ratio = (lifespan - life) / lifespan;
+                    p.alpha = 0.5f * (1.0f - life_ratio);
+                    const float size = 0.45f * (0.4f * life_ratio + 0.6f);
+                    const float offset_y = -life_ratio * 0.17f;
+                    p.wx = px * kUnitPx - 0.5f * d.y * size;
+                    p.wy = (py + offset_y) * kUnitPx - 0.5f * d.z * size;
+                    num = size * kUnitPx;
+                    p.go = true;
+                }
+            } else if (valid && slot < kPuffs + pe.n_draw) {
+                const int k = slot - kPuffs;
+                const int id = (S.draw_ids[e][k >> 2] >> (8 * (k & 3))) & 0xffu;
+                float sc;
+                if (id == 0) {
+                    p.tex = kTexCarrot;
+                    sc = 1.0f * 1.0f;
+                    p.wx = (pe.gx + -0.5f) * kUnitPx;
+                    p.wy = (pe.gy + -0.5f) * kUnitPx;
+                } else {
+                    const int j = id - 2;
+                    const int cell = (S.spike_cells[e][j >> 1] >> (16 * (j & 1))) & 0xffffu;
+                    p.tex = kTexSpike;
+                    sc = 1.0f * 0.4f;
+                    p.wx = (cell_x(cell) + -0.25f) * kUnitPx;
+                    p.wy = (cell_y(cell) + -0.25f) * kUnitPx;
+                }
+                num = sc * kUnitPx;
+                p.go = true;
+            } else if (valid) {
+                const bool ground = (pe.sflags & kFlagGround) != 0;
+                float agent_scale = 0.5f, off_x = 0.0f, off_y = 0.2f;
+                if (fabsf(pe.avx) < 0.01f && ground) {
+                    p.tex = kTexStand;
+                } else if (!ground) {
+                    p.tex = kTexJump;
+                    agent_scale = 0.6f;
+                    off_x = -0.05f;
+                    off_y = 0.25f;
+                } else if (pe.aphase > 0.5f) {
+                    p.tex = kTexWalk2;
+                } else {
+                    p.tex = kTexWalk1;
+                }
+                const float px = pe.ax - 0.25f, py = pe.ay - 1.0f;
+                p.wx = (px + off_x) * kUnitPx;
+                p.wy = (py + off_y) * kUnitPx;
+                post = agent_scale;  // kUnitPx / d.y * agent_scale
+                p.flip_h = (pe.sflags & kFlagForward) == 0;
+                p.go = true;
+            }
+            p.scale = num / S.desc[p.tex].y * post;
+            prep_draws_pass(Q, st, S.desc, cam_a, cam_b, draws_a, draws_b, valid, is_b, p, lane);
+        }
+        prep_draws_flush(Q, st, S.desc, cam_a, cam_b, draws_a, draws_b, lane);
+        if (lane == 0) {  // (the compass's needle and bar take two more lanes of the render wave)
+            S.counts[ea] = st.done[0] > kPrepDraws - 3 ? kPrepDraws + 1 : st.done[0];
+            S.counts[eb] = st.done[1] > kPrepDraws - 3 ? kPrepDraws + 1 : st.done[1];
+        }
+    }
+    __syncthreads();
+    prep_meta_out<kGrid, kMaxSpan, kPrepEnvs>(P, out, env0, S.counts, tid, kPrepThreads);
+    if (tid < kPrepEnvs && (P.fat[tid] != 0 || S.counts[tid] > kPrepDraws) && env0 + tid < s.n)  // (prep_meta_out's own test)
+#if defined(PG_FAT_WHY)
+        s.fat[1 + atomicAdd(s.fat, 1u)] = static_cast<uint32_t>(env0 + tid) | (P.fat[tid] << 24) | (S.counts[tid] > kPrepDraws ? 16u << 24 : 0u);
+#else
+        s.fat[1 + atomicAdd(s.fat, 1u)] = static_cast<uint32_t>(env0 + tid);
+#endif
+}
+
+// The complete path as a kernel of its own: every env (`listed` = 0: the draw-list replay, kDebugNoPrepass), or the few
+// frames the pre-pass could not prepare (s.fat: more than 64 visible draws, a window or a span beyond the tables — none
+// in a run of the default mode), a handful of workgroups walking the list.  It is not a branch of render_kernel because
+// a kernel's registers and code are those of its largest path: with the complete path inside, the lean frames ran with
+// 95 registers and spills instead of 81 and none (render 0.72 -> 0.65 ms without it).
+constexpr int kFatBlocks = 64;
+__global__ void __launch_bounds__(128, PG_RENDER_WAVES) render_full_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
+                                                         int flags, int listed) {
+    __shared__ alignas(16) uint32_t fb[kFbWords];
+    __shared__ ComposeLds<kGrid> L;
+    if (!listed) {
+        const int env = blockIdx.x;
+        if (mask && !mask[env]) return;
+        render_full(s, atlas, io, flags, env, fb, L);
+        return;
+    }
+    const uint32_t count = s.fat[0];
+#if defined(PG_FAT_WHY)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && count) {
+        uint32_t why[5] = {0, 0, 0, 0, 0};
+        for (uint32_t k = 0; k < count; k++)
+            for (int b = 0; b < 5; b++) why[b] += (s.fat[1 + k] >> (24 + b)) & 1u;
+        printf("fat %u: view %u list %u span %u nest %u draws %u\n", count, why[0], why[1], why[2], why[3], why[4]);
+    }
+    return;
+#endif
+    for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {  // (workgroup-uniform)
+        render_full(s, atlas, io, flags, static_cast<int>(s.fat[1 + k]), fb, L);
+        __syncthreads();
+    }
+}
+
+// render_game(true) (jumper.cpp:445-509): one workgroup of two wavefronts per env; a frame starts from what setup_kernel
+// left (coinrun.hip's render_kernel is the commented model).
+__global__ void __launch_bounds__(128, PG_RENDER_WAVES) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
+                                                    int flags) {
+    const int env = blockIdx.x;
+    if (env == 0 && threadIdx.x == 0) s.fat[0] = 0u;  // (render_full_kernel, launched in front of this one, has read it)
+    if (mask && !mask[env]) return;
+    const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int halves = 2;
+    __shared__ alignas(16) uint32_t fb[kFbWords];
+    __shared__ ComposeLds<kGrid> L;
+    const PrepMeta M{s.prep.meta + size_t(env) * kPrepMetaWords};
+    const uint32_t colw = s.prep.axes[size_t(env) * 128 + lane], roww = s.prep.axes[size_t(env) * 128 + 64 + lane];
+    const uint32_t roww2 = s.prep.axes2[size_t(env) * 64 + lane];
+    const uint32_t kind_off = M.w[PM_KINDS + (lane & (kPrepKinds - 1))];
+    const uint32_t two16 = reinterpret_cast<const uint16_t*>(s.prep.cells)[size_t(env) * (kGrid * kGrid / 2) + half * 64 + lane];
+    const int n_draws = M.draws();
+    Blit mine = prep_draw_load(s.prep.draws + (size_t(env) * kPrepDraws + lane) * kBlitWords, lane < n_draws);
+    prep_cells_expand<kGrid>(L, two16, kind_off, half, lane);
+    const ComposeRegs R = prep_regs<kGrid>(M, colw, roww, roww2, lane);
+    __syncthreads();  // the cell table is complete
+    if (M.fat()) return;  // (wave-uniform; render_full_kernel has drawn it)
+    const int row_lo = half * (kObsH / halves), row_hi = (half + 1) * (kObsH / halves);
+    if (M.flags() & 2u)
+        compose_rows_from<kGrid, true, false>(fb, L, atlas, R, lane, flags, half, halves);
+    else
+        compose_rows_from<kGrid, false, false>(fb, L, atlas, R, lane, flags, half, halves);
+    // the compass (jumper.cpp:473-509) behind the resolved draws: lanes n_draws, + 1, + 2 = circle, needle, bar — raw
+    // screen-space draws whose parameters the logic kernel worked out (store_compass)
+    const int hud = lane - n_draws + 1;  // 1, 2, 3
+    bool has = lane < n_draws;
+    if (hud >= 1 && hud <= 3) {
+        const float game_zoom = kObsZoom;
+        const float width = 64.0f, compass_size = 200.0f, offset_x = -32.0f, offset_y = 32.0f;
+        const int4 d = atlas.desc[kTexCircle + (hud - 1)];
+        float sx, sy, sw, sh;
+        int sn = 0, cs = 0;
+        if (hud == 1) {
+            sx = width - compass_size * game_zoom + offset_x * game_zoom;
+            sy = offset_y * game_zoom;
+            sw = compass_size * game_zoom;
+            sh = compass_size * game_zoom;
+        } else if (hud == 2) {
+            sx = __uint_as_float(M.w[PM_GAME + GW_NEEDLE_X]);
+            sy = __uint_as_float(M.w[PM_GAME + GW_NEEDLE_Y]);
+            sw = compass_size * 0.5f * game_zoom;
+            sh = compass_size * 0.1f * game_zoom;
+            sn = static_cast<int>(M.w[PM_GAME + GW_NEEDLE_SN]);
+            cs = static_cast<int>(M.w[PM_GAME + GW_NEEDLE_CS]);
+        } else {
+            sx = width - compass_size * game_zoom + offset_x * game_zoom;
+            sy = compass_size * game_zoom + offset_y * game_zoom;
+            sw = __uint_as_float(M.w[PM_GAME + GW_BAR_W]);
+            sh = compass_size * 0.15f * game_zoom;
+        }
+        has = resolve_screen_at(d.y, d.z, d.x, sx, sy, sw, sh, sn, cs, mine);
+    }
+    if (s.hud_image != 0u) {
+        // the ring is the same 60×60 pixels in every frame: prepared once (pg_render.h overlay_rows), in its place in the
+        // draw order — after the bunny, before the needle and the bar
+        wave_replay_rows(fb, atlas, mine, __ballot(has && lane < n_draws), lane, row_lo, row_hi);
+        overlay_rows(fb, atlas.texels + s.hud_image, reinterpret_cast<const uint2*>(atlas.texels + s.hud_list), s.hud_n, lane,
+                     row_lo, row_hi);
+        wave_replay_rows(fb, atlas, mine, __ballot(has && lane > n_draws), lane, row_lo, row_hi);
+    } else {
+        wave_replay_rows(fb, atlas, mine, __ballot(has), lane, row_lo, row_hi);
+    }
+    wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, row_lo, row_hi);
 }
 
 // cenv_render's frame (render_game(false)) for one env: pg_frame.h; the draw list of render_kernel, one draw at a time.
@@ -1124,8 +1473,22 @@ class JumperGame final : public Game {
         hipLaunchKernelGGL(frame_kernel, dim3(1), dim3(kFrameThreads), 0, st, s_, atlas_, env, FrameTarget{d_px, w, h});
         return true;
     }
+    size_t scratch_bytes(int n) const override { return prep_bytes(n, kGrid, kBlitWords, true) + size_t(n + 1) * 4; }
+    void bind_scratch(void* d_scratch, int n) override {
+        s_.prep = prep_bind(d_scratch, n, kGrid, kBlitWords, true);
+        s_.fat = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(d_scratch) + prep_bytes(n, kGrid, kBlitWords, true));  // (zeroed by the engine)
+    }
+    bool lean() const { return !(debug_flags & (1 | kDebugNoPrepass)); }
+    void launch_prepass(hipStream_t st, const uint8_t* mask) override {
+        if (lean()) hipLaunchKernelGGL(setup_kernel, dim3((s_.n + kPrepEnvs - 1) / kPrepEnvs), dim3(kPrepThreads), 0, st, s_, atlas_, mask, debug_flags);
+    }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
-        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags);
+        if (lean()) {
+            hipLaunchKernelGGL(render_full_kernel, dim3(kFatBlocks), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags, 1);
+            hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags);
+        } else {
+            hipLaunchKernelGGL(render_full_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags, 0);
+        }
     }
     // Same layout as oracle/pgo_jumper.cpp Jumper::dump_state.
     int dump_state(hipStream_t st, int env, float* out, int cap) override {

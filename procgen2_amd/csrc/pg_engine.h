@@ -140,12 +140,15 @@ class Game {
     // Bit 0: render background + tiles by draw-list replay instead of the row composer (fallback path).
     // Bit 8: no level prefetch — every reset generates its level synchronously inside the step.
     // Bit 21: no render pre-pass — every frame's workgroup does its own set-up (the complete path; pg_prepass.h).
+    // Bit 23: the pre-pass leaves every third env's frame to the complete path (`fat`), as it does by itself for the frames
+    //         its tables do not hold — which some games never have in a normal run: the tests' way to that path.
     int debug_flags = 0;
     LevelPlan plan{0, 0, nullptr, nullptr};  // set by the engine after bind()
 };
 
 constexpr int kDebugNoPrefetch = 1 << 8;
 constexpr int kDebugNoPrepass = 1 << 21;  // (clear of the -DPG_ABLATE experiment bits the games use)
+constexpr int kDebugFatThirds = 1 << 23;
 
 // Lanes per workgroup of the lane-per-env logic kernels: fewer envs per wave = more waves.
 int logic_lanes();

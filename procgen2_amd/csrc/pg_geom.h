@@ -155,6 +155,19 @@ PG_HD bool resolve_draw(const Camera& cam, int tw, int th, int tex_off, float po
     return true;
 }
 
+// A tile layer with a second, shorter texture (the brown theme's 64×53 cap on 64×64 bodies): the pixel rows a grid row's
+// cap covers must be among those its body covers — the composer finds a pixel row's candidates from the bodies' spans
+// alone.  Only pixels ON the target count: cut by the target's top edge down to its last texel row or two, the cap's
+// rectangle comes out of render_texture's crop arithmetic at a negative row, and at the bottom edge it may reach one row
+// further beyond the target than the body's (until round 4 both made the frame take the draw-list replay: one
+// jumper frame in forty).
+PG_HD bool span_nested(int d_in, int n_in, int d_out, int n_out, int len) {
+    const int lo_in = d_in > 0 ? d_in : 0, hi_in = d_in + n_in < len ? d_in + n_in : len;
+    if (lo_in >= hi_in) return true;
+    const int lo_out = d_out > 0 ? d_out : 0, hi_out = d_out + n_out < len ? d_out + n_out : len;
+    return lo_in >= lo_out && hi_in <= hi_out;
+}
+
 // Raster spec S6, the bounding box of a rotated draw on the target (pg_render.h rot_box).  How tight it may be:
 // a pixel with doubled offsets (px, py) from the rectangle's centre is drawn iff a = px·cs + py·sn lies in [−dw·2^16, dw·2^16)
 // and b = py·cs − px·sn in [−dh·2^16, dh·2^16).  Then px·N = a·cs − b·sn with N = cs² + sn², so |px| ≤ 2^16·(dw·|cs| +

@@ -100,7 +100,7 @@ struct PrepLds {
     uint8_t texel[kPrepList][MAXSPAN];  // texel coordinate of destination offset i, per worked-out tail
     uint32_t cover[E][2][64];
     uint32_t soft_rows[E], hard_rows[E];  // bit r: grid row r shows soft / hard texels; bit 31: the background does
-    uint32_t fat[E];
+    uint32_t fat[E];  // why an env takes the complete path — 1: the game's view, 2: worklist full, 4: a span beyond the tables, 8: pixel candidates not adjacent
     uint32_t meta[E][kPrepMetaWords];
 };
 
@@ -140,7 +140,7 @@ PG_D void prep_spans(PrepLds<GRID, E, MAXSPAN>& P, int tid, int nthreads) {
         if (at < kPrepList)
             P.list[at] = PrepTail{d, dl, code};
         else
-            atomicOr(&P.fat[code & 15u], 1u);  // (never seen: a frame with that many cut tiles takes the complete path)
+            atomicOr(&P.fat[code & 15u], 2u);  // (never seen: a frame with that many cut tiles takes the complete path)
     };
     // ---- step 1: the tiles …
     constexpr int kAxes = TWO ? 3 : 2, kTiles = kAxes * GRID;
@@ -218,7 +218,7 @@ PG_D void prep_spans(PrepLds<GRID, E, MAXSPAN>& P, int tid, int nthreads) {
                 bad = bad || u > 255;
                 P.texel[q][i] = static_cast<uint8_t>(u);
             }
-            if (bad) atomicOr(&P.fat[e], 1u);
+            if (bad) atomicOr(&P.fat[e], 4u);
             word = bad ? 0u : (pack_halves(sp.d0, sp.dn) | (static_cast<uint32_t>(q) << 24));
         }
         if (kind == kTailTemplate)
@@ -277,13 +277,13 @@ PG_D void prep_axes(PrepLds<GRID, E, MAXSPAN>& P, const PrepOut& out, int env0, 
                 if (ia >= 0) {
                     const uint32_t s2 = P.span[e][2][ia];
                     const int d2 = static_cast<int32_t>(s2 << 16) >> 16, n2 = (s2 >> 16) & 0xffu, i = lane - d2;
-                    ok = ok && !(n2 > 0 && (d2 != da || n2 > static_cast<int>((wa >> 16) & 0xffu)));
+                    ok = ok && !(n2 > 0 && !span_nested(d2, n2, da, static_cast<int>((wa >> 16) & 0xffu), kObsH));
                     if (n2 > 0 && i >= 0 && i < n2) w2 |= static_cast<uint32_t>(P.texel[s2 >> 24][i]) | (1u << 24);
                 }
                 if (ib >= 0) {
                     const uint32_t s2 = P.span[e][2][ib];
                     const int d2 = static_cast<int32_t>(s2 << 16) >> 16, n2 = (s2 >> 16) & 0xffu, i = lane - d2;
-                    ok = ok && !(n2 > 0 && (d2 != db || n2 > static_cast<int>((wb >> 16) & 0xffu)));
+                    ok = ok && !(n2 > 0 && !span_nested(d2, n2, db, static_cast<int>((wb >> 16) & 0xffu), kObsH));
                     if (n2 > 0 && i >= 0 && i < n2) w2 |= (static_cast<uint32_t>(P.texel[s2 >> 24][i]) << 8) | (1u << 25);
                 }
                 out.axes2[size_t(env0 + e) * 64 + lane] = w2;
@@ -303,7 +303,7 @@ PG_D void prep_axes(PrepLds<GRID, E, MAXSPAN>& P, const PrepOut& out, int env0, 
                 P.meta[e][PM_HARD + 1] = static_cast<uint32_t>(m_hard >> 32);
             }
         }
-        if (__ballot(!ok) != 0 && lane == 0) atomicOr(&P.fat[e], 1u);
+        if (__ballot(!ok) != 0 && lane == 0) atomicOr(&P.fat[e], 8u);
     }
 }
 

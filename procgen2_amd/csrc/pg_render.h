@@ -974,7 +974,7 @@ PG_D void compose_spans(uint32_t* fb, ComposeLds<GRID>& L, const Camera& cam, in
             const bool ok2 =
                 resolve_axis(cam.py, cam.sh, cam.scale, th2, (y0 + lane) * kUnitPx, tile_scale, false, true, s2);
             T.row2[lane] = ok2 ? make_int4(s2.d0, s2.dn, s2.s0, s2.sn) : make_int4(0, 0, 0, 0);
-            wide = wide || (ok2 && (!ok || s2.d0 != sp.d0 || s2.dn > sp.dn));  // not nested: take the fallback
+            wide = wide || (ok2 && !span_nested(s2.d0, s2.dn, ok ? sp.d0 : 0, ok ? sp.dn : 0, kObsH));  // not nested (pg_geom.h): take the fallback
         }
     }
     if (bga != nullptr) {

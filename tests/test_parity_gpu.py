@@ -73,7 +73,7 @@ def test_row_composer_equals_draw_list_replay(game):
     slow.close()
 
 
-@pytest.mark.parametrize("game", ["coinrun", "climber", "caveflyer", "bossfight"])
+@pytest.mark.parametrize("game", ["coinrun", "climber", "caveflyer", "bossfight", "jumper"])
 def test_render_pre_pass_equals_the_complete_path(game):
     """The lean frames — composed from what the render pre-pass (pg_prepass.h setup_kernel) left in device memory — against
     the same engine with the pre-pass switched off (pgv_set_debug bit 21: every frame's workgroup does its own set-up, the
@@ -97,6 +97,29 @@ def test_render_pre_pass_equals_the_complete_path(game):
     assert ends > 0 or game == "caveflyer"
     lean.close()
     full.close()
+
+
+@pytest.mark.parametrize("game", ["coinrun", "climber", "caveflyer", "jumper"])
+def test_frames_the_pre_pass_hands_back_equal_the_prepared_ones(game):
+    """The pre-pass leaves a frame its tables do not hold (more visible draws than a wave has lanes, a window beyond the
+    cell table, …) to the complete path — inside the render kernel (coinrun, climber, caveflyer) or by a kernel of its own
+    walking a list (jumper).  Climber and jumper never have such a frame in a normal run, so pgv_set_debug bit 23 makes the
+    pre-pass hand back every third env's: those frames, their neighbours' and everything after them must be what the
+    engine without the switch produces, under masked resets too (the list is rebuilt by every pre-pass launch)."""
+    n = 768
+    plain, thirds = EngineVec(game, n, seed_base=77), EngineVec(game, n, seed_base=77)
+    thirds.set_debug(1 << 23)
+    assert np.array_equal(plain.reset(), thirds.reset())
+    for s in range(120):
+        op, rp, dp = plain.step(None, run_seed=8)
+        ot, rt, dt = thirds.step(None, run_seed=8)
+        assert np.array_equal(op, ot), "step %d" % s
+        assert np.array_equal(rp.view(np.uint32), rt.view(np.uint32)) and np.array_equal(dp, dt)
+        if s % 40 == 20:
+            mask = (np.arange(n) % 4 == 1).astype(np.uint8)  # (env 0, which the list's counter is reset by, sits this one out)
+            assert np.array_equal(plain.reset(mask=mask), thirds.reset(mask=mask)), "masked reset at step %d" % s
+    plain.close()
+    thirds.close()
 
 
 def test_coinrun_other_seeds_and_action_stream():
