@@ -1216,18 +1216,7 @@ __global__ void __launch_bounds__(64, 5) render_kernel(State s, AtlasView atlas,
                      static_cast<int>(b4.x >> 24)};
     const Blit draw = prep_draw_load(s.prep.draws + (size_t(env) * kPrepDraws + lane) * kBlitWords, has_draw);
     compose_background_from<kObsH / halves>(fb, atlas, bg_col, bg_row, lane, half);
-#if defined(PG_BOSS_NOB)
-    const unsigned long long mb = 0;
-#else
-    const unsigned long long mb = __ballot(has_bullet);
-#endif
-#if defined(PG_BOSS_NOD)
-    const unsigned long long md = 0;
-#elif defined(PG_BOSS_NOSHIP)
-    const unsigned long long md = __ballot(has_draw) & ~3ull;
-#else
-    const unsigned long long md = __ballot(has_draw);
-#endif
+    const unsigned long long mb = __ballot(has_bullet), md = __ballot(has_draw);
     wave_replay_rows<4, true>(fb, atlas, bullet, mb, lane, row_lo, row_hi, &box);
     wave_replay_rows<4, true>(fb, atlas, draw, md, lane, row_lo, row_hi);
     wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, row_lo, row_hi);

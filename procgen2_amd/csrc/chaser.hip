@@ -27,6 +27,7 @@
 #include "pg_order.h"
 #include "pg_prefetch.h"
 #include "pg_render.h"
+#include "pg_prepass.h"
 #include "pg_rng.h"
 #include "pg_setorder.h"
 
@@ -120,7 +121,17 @@ struct State {
     // The row composer's span and hand-over tables: the camera shows the whole world, always, so they are worked out
     // once (prepare_kernel, when the envs are made) and every frame reads them from here (pg_render.h compose_prepare).
     ComposeHand* prepared;
+    // The render pre-pass's tables (scratch memory, not state).  The camera never moves, so an orb's or a point's draw is a
+    // function of its cell: worked out once for every cell (prepare_kernel); what moves — the enemies and the agent — and
+    // the background's two axes once per frame and env by a dense kernel (setup_kernel) instead of by both wavefronts of
+    // the env's render workgroup, 64 lanes at a time whatever the number of draws.
+    struct Prep {
+        uint32_t* cell_blits;  // [2][kCells][kBlitWords]   orb, point at each cell (pg_render.h BlitWords; word 1 = 0: not drawn)
+        uint32_t* movers;      // [n][kMovers][kBlitWords]  enemy 0 … kMobs − 1, the agent
+        uint32_t* bg;          // [n][8]                    background, x axis then y axis: d0 | dn << 16, s0 | sn << 16, first texel, width
+    } prep;
 };
+constexpr int kMovers = kMobs + 1;
 
 PG_D float& SF(const State& s, int field, int env) { return s.f[size_t(field) * s.n + env]; }
 PG_D int32_t& SI(const State& s, int field, int env) { return s.i[size_t(field) * s.n + env]; }
@@ -796,18 +807,35 @@ PG_D int layer_flags(const State& s, const int4& wall_d, const int4& point_d, bo
 PG_D bool points_join_layer(const int4& point_d, int flags) { return !(flags & 1) && (point_d.w & 12) == 8; }
 
 // One env's frame by its workgroup (two wavefronts, pg_render.h); fb, LB and S are the workgroup's LDS.
+// kPrepped: the draws and the background's axes come from the pre-pass's tables (State::Prep) instead of being resolved
+// here — the frames of the step's main pass; the late pass (envs reset in this step: their level did not exist when the
+// pre-pass ran) and the debug paths resolve their own.
+template <bool kPrepped>
 PG_D void render_env(const State& s, const AtlasView& atlas, const StepIO& io, int flags, int env, uint32_t* fb,
                      ComposeLdsBoxed<kGrid>& LB, SpriteLds& S) {
     ComposeLds<kGrid>& L = LB.plain;
     const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // two wavefronts per env (pg_render.h)
     constexpr int halves = 2;
 
+#if defined(PG_TIMELINE)  // (latency experiment, tools/build_exp.py + tools/probe/wave_timeline.py: where a wave's life goes)
+    unsigned long long tl[7];
+#define PG_TL(k)                                \
+    do {                                        \
+        __builtin_amdgcn_s_waitcnt(0);          \
+        __builtin_amdgcn_wave_barrier();        \
+        tl[k] = __builtin_amdgcn_s_memtime();   \
+    } while (0)
+#else
+#define PG_TL(k) do {} while (0)
+#endif
+    PG_TL(0);
     const View view = view_of_world();
     const Camera& cam = view.cam;
     const int sflags = SI(s, I_FLAGS, env);
     const int n_draw = (sflags & kFlagListed) ? SI(s, I_NDRAW, env) : 0;  // empty right after a reset
     const uint8_t* tiles = s.tiles + size_t(env) * kTileStride;
-    const DescRegs descs = DescRegs::load(atlas, lane);
+    DescRegs descs{};
+    if (!kPrepped) descs = DescRegs::load(atlas, lane);
     Blit mine;
     uint32_t ent[kEntRegs];  // per draw-list place lane + 64·j: entity | kind << 8 | cell << 16
 #pragma unroll
@@ -819,19 +847,20 @@ PG_D void render_env(const State& s, const AtlasView& atlas, const StepIO& io, i
             ent[j] = static_cast<uint32_t>(e | (EB(s, EB_INFO, e, env) & kKindMask) << 8 | ent_cell(s, e, env) << 16);
         }
     }
-    if (half == 1 && lane < kMobs) {
+    if (!kPrepped && half == 1 && lane < kMobs) {
         S.mob[lane][0] = MF(s, MF_X, lane, env);
         S.mob[lane][1] = MF(s, MF_Y, lane, env);
         S.mob[lane][2] = static_cast<float>(MB(s, 0, lane, env));
     }
-    const float agent_x = SF(s, F_AX, env), agent_y = SF(s, F_AY, env);
+    float agent_x = 0.0f, agent_y = 0.0f;
+    if (!kPrepped) agent_x = SF(s, F_AX, env), agent_y = SF(s, F_AY, env);
     // (the barriers of the composer, or of the replay that stands in for it, come between these writes and their readers)
 
     int bg_soft = 0;  // the backdrop has texels that are not opaque (descriptor .w)
     int4 bg_d;  // the background draw, chaser.cpp:404-409: texture, world position, scale — each wave resolves the axis it needs (pg_render.h BgAxis)
     float bg_px, bg_py, bg_sc;
     {
-        const int4 d = descs.uniform(kTexFloor + SI(s, I_BG, env));
+        const int4 d = atlas.desc[kTexFloor + __builtin_amdgcn_readfirstlane(SI(s, I_BG, env))];  // (wave-uniform: scalar loads)
         bg_soft = d.w;
         const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
         const float extra = aspect - 1.0f;
@@ -841,13 +870,21 @@ PG_D void render_env(const State& s, const AtlasView& atlas, const StepIO& io, i
         bg_sc = 64.0f * kUnitPx / d.z;
     }
     const int x0 = view.x0, y0 = view.y0, cols = view.cols, rows = view.rows, cells = cols * rows;
-    const int4 wall_d = descs.uniform(kTexWall), point_d = descs.uniform(kTexPoint);
+    const int4 wall_d = atlas.desc[kTexWall], point_d = atlas.desc[kTexPoint];
     const bool points_in_layer = points_join_layer(point_d, flags);
 
     bool composed = false;
+    PG_TL(1);
     if (!(flags & 1) && cols <= kGrid && rows <= kGrid) {
         // this wave's axis of the background (wave 0: x, wave 1: y); the tile spans are the prepared ones
-        const BgAxis bga = bg_axis(cam, bg_d, bg_px, bg_py, bg_sc, half);
+        BgAxis bga;
+        if (kPrepped) {
+            const uint32_t* w = s.prep.bg + size_t(env) * 8 + half * 4;
+            bga = BgAxis{static_cast<int32_t>(w[0] << 16) >> 16, static_cast<int32_t>(w[0]) >> 16, static_cast<int32_t>(w[1] & 0xffffu),
+                         static_cast<int32_t>(w[1] >> 16), static_cast<int32_t>(w[2]), static_cast<int32_t>(w[3])};
+        } else {
+            bga = bg_axis(cam, bg_d, bg_px, bg_py, bg_sc, half);
+        }
         if (half == 0 && lane < 2) L.base[kGrid * kGrid + lane] = static_cast<int32_t>(kNoTexel);
         for (int cell = lane + 64 * half; cell < kGrid * kGrid; cell += 64 * halves) {
             const int r = cell / kGrid, c = cell % kGrid;
@@ -876,6 +913,7 @@ PG_D void render_env(const State& s, const AtlasView& atlas, const StepIO& io, i
             }
         }
         __syncthreads();
+        PG_TL(2);
         composed = compose_rows<kGrid, false, true, true>(fb, L, atlas, bga, cols, rows, wall_d.y, lane, flags, half, halves,
                                                           s.point_box, s.prepared, bg_soft);
     }
@@ -904,6 +942,7 @@ PG_D void render_env(const State& s, const AtlasView& atlas, const StepIO& io, i
     int4* const seen = reinterpret_cast<int4*>(L.base) + half * (kOrbs + kMobs + 2);
     static_assert(2 * (kOrbs + kMobs + 2) * 4 <= kGrid * kGrid, "scratch inside the cell table");
     int n_seen = 0;
+    PG_TL(3);
     PG_MARK("s_sprites");
     const bool skip_points = composed && points_in_layer;
     for (int first = 0; first < n_draw + 1 && !PG_ABL(flags, 0x10000); first += 64) {  // (bit 16: timing experiment — no sprite pass)
@@ -911,7 +950,22 @@ PG_D void render_env(const State& s, const AtlasView& atlas, const StepIO& io, i
         int want_tex = kTexAgent;
         float x = 0.0f, y = 0.0f;
         bool has = false, is_point = false;
-        if (k < n_draw) {
+        if (kPrepped) {  // the lane's draw as the pre-pass left it: by cell for what stays put, by env for what moves
+            const uint32_t* at = nullptr;
+            if (k < n_draw) {
+                uint32_t v = ent[0];
+#pragma unroll
+                for (int j = 1; j < kEntRegs; j++) v = first == 64 * j ? ent[j] : v;
+                const int e = static_cast<int>(v & 0xffu), kind = static_cast<int>((v >> 8) & kKindMask);
+                is_point = kind == kPoint;
+                at = kind == kEgg ? s.prep.movers + (size_t(env) * kMovers + (e - kOrbs)) * kBlitWords
+                                  : s.prep.cell_blits + (size_t(is_point ? kCells : 0) + (v >> 16)) * kBlitWords;
+            } else if (k == n_draw) {
+                at = s.prep.movers + (size_t(env) * kMovers + kMobs) * kBlitWords;
+            }
+            mine = prep_draw_load(at, at != nullptr);
+            has = mine.dw > 0;  // (a draw that render_texture culls is stored as zeros)
+        } else if (k < n_draw) {
             uint32_t v = ent[0];
 #pragma unroll
             for (int j = 1; j < kEntRegs; j++) v = first == 64 * j ? ent[j] : v;
@@ -934,11 +988,13 @@ PG_D void render_env(const State& s, const AtlasView& atlas, const StepIO& io, i
             x = agent_x;
             y = agent_y;
         }
-        const int4 d = descs.at(want_tex);
-        if (has) {
-            const float scale = (k == n_draw) ? kUnitPx / d.y * 1.0f : (1.0f * 1.0f) * kUnitPx / d.y;
-            has = resolve_draw(cam, d.y, d.z, d.x, (x + -0.5f) * kUnitPx, (y + -0.5f) * kUnitPx, scale, 1.0f, false, false,
-                               mine);
+        if (!kPrepped) {
+            const int4 d = descs.at(want_tex);
+            if (has) {
+                const float scale = (k == n_draw) ? kUnitPx / d.y * 1.0f : (1.0f * 1.0f) * kUnitPx / d.y;
+                has = resolve_draw(cam, d.y, d.z, d.x, (x + -0.5f) * kUnitPx, (y + -0.5f) * kUnitPx, scale, 1.0f, false, false,
+                                   mine);
+            }
         }
         PG_MARK("t_resolved");
         if (skip_points) {
@@ -971,11 +1027,20 @@ PG_D void render_env(const State& s, const AtlasView& atlas, const StepIO& io, i
         }
         PG_MARK("u_kept");
         if (PG_ABL(flags, 0x20000)) has = false;  // (bit 17: timing experiment — the pass without its draws)
+        if (first == 0) PG_TL(4);
         wave_replay_rows<4, false, false>(fb, atlas, mine, __ballot(has), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
     }
+    PG_TL(5);
     PG_MARK("v_drawn");
     // each wave stores the rows it owns (pg_render.h wave_replay_rows): no barrier
     wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
+#if defined(PG_TIMELINE)
+    PG_TL(6);
+    if (lane == 0 && composed) {
+        unsigned long long* out = reinterpret_cast<unsigned long long*>(io.obs + size_t(env) * kObsBytes + half * (kObsBytes / 2));
+        for (int k = 0; k < 7; k++) out[k] = tl[k];
+    }
+#endif
 }
 
 // Once per engine: the composer's tables for the one view there is (State::prepared).
@@ -991,8 +1056,55 @@ __global__ void __launch_bounds__(128) prepare_kernel(State s, AtlasView atlas) 
     __syncthreads();
     compose_hand_build<kGrid, false, true>(fb, LB.plain, BgAxis{}, wall_d.y, lane, 0, half, s.point_box);
     compose_prepare<kGrid>(fb, LB.plain, s.prepared, lane, half);
+    // an orb's and a point's draw at every cell (common_systems.cpp:41-63 as render_env's sprite pass states it)
+    for (int q = threadIdx.x; q < 2 * kCells; q += blockDim.x) {
+        const int is_point = q / kCells, cell = q - is_point * kCells;
+        const int4 d = atlas.desc[is_point ? kTexPoint : kTexOrb];
+        const float scale = (1.0f * 1.0f) * kUnitPx / d.y;
+        Blit b;
+        const bool has = resolve_draw(view.cam, d.y, d.z, d.x, (cell_x(cell) + -0.5f) * kUnitPx, (cell_y(cell) + -0.5f) * kUnitPx, scale,
+                                      1.0f, false, false, b);
+        BlitWords w = blit_pack(b);
+        if (!has) w.w[0] = w.w[1] = w.w[2] = w.w[3] = w.w[4] = w.w[5] = 0u;
+        for (int k = 0; k < kBlitWords; k++) s.prep.cell_blits[size_t(q) * kBlitWords + k] = w.w[k];
+    }
 }
 
+// The render pre-pass: eight lanes an env — its enemies (at most five) and the agent resolved (their positions are
+// floats: nothing to tabulate), and the two axes of the background's draw (chaser.cpp:404-409; pg_render.h bg_axis).
+constexpr int kPrepLanes = 8;
+static_assert(kMovers + 2 <= kPrepLanes, "enemies, agent, two background axes");
+__global__ void __launch_bounds__(256) setup_kernel(State s, AtlasView atlas) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int env = gid / kPrepLanes, item = gid - env * kPrepLanes;
+    if (env >= s.n) return;
+    const View view = view_of_world();
+    if (item < kMovers) {
+        const bool agent = item == kMobs;
+        const int tex = agent ? kTexAgent : kTexEnemy + MB(s, 0, item, env);
+        const float x = agent ? SF(s, F_AX, env) : MF(s, MF_X, item, env), y = agent ? SF(s, F_AY, env) : MF(s, MF_Y, item, env);
+        const int4 d = atlas.desc[tex];
+        const float scale = agent ? kUnitPx / d.y * 1.0f : (1.0f * 1.0f) * kUnitPx / d.y;
+        Blit b;
+        const bool has = resolve_draw(view.cam, d.y, d.z, d.x, (x + -0.5f) * kUnitPx, (y + -0.5f) * kUnitPx, scale, 1.0f, false, false, b);
+        BlitWords w = blit_pack(b);
+        if (!has) w.w[0] = w.w[1] = w.w[2] = w.w[3] = w.w[4] = w.w[5] = 0u;
+        uint2* at = reinterpret_cast<uint2*>(s.prep.movers + (size_t(env) * kMovers + item) * kBlitWords);
+        at[0] = make_uint2(w.w[0], w.w[1]);
+        at[1] = make_uint2(w.w[2], w.w[3]);
+        at[2] = make_uint2(w.w[4], w.w[5]);
+    } else if (item < kMovers + 2) {
+        const int axis = item - kMovers;
+        const int4 d = atlas.desc[kTexFloor + SI(s, I_BG, env)];
+        const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
+        const float extra = aspect - 1.0f;
+        const BgAxis a = bg_axis(view.cam, d, -SF(s, F_BGSHIFT, env) * extra, 0.0f, 64.0f * kUnitPx / d.z, axis);
+        uint4* at = reinterpret_cast<uint4*>(s.prep.bg + size_t(env) * 8 + axis * 4);
+        *at = make_uint4(pack_halves(a.d0, a.dn), pack_halves(a.s0, a.sn), static_cast<uint32_t>(a.tex_off), static_cast<uint32_t>(a.tex_w));
+    }
+}
+
+template <bool kPrepped>
 __global__ void __launch_bounds__(128, PG_CHASER_RENDER_WAVES) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
                                                     int flags, int pass) {
     const int env = blockIdx.x;
@@ -1006,7 +1118,7 @@ __global__ void __launch_bounds__(128, PG_CHASER_RENDER_WAVES) render_kernel(Sta
     __shared__ alignas(16) uint32_t fb[kFbWords];
     __shared__ ComposeLdsBoxed<kGrid> L;
     __shared__ SpriteLds S;
-    render_env(s, atlas, io, flags, env, fb, L, S);
+    render_env<kPrepped>(s, atlas, io, flags, env, fb, L, S);
 }
 
 // The late pass of a step whose resets ran on their own stream: the frames of the envs on the level kernel's list (a
@@ -1024,7 +1136,7 @@ __global__ void __launch_bounds__(128, PG_CHASER_RENDER_WAVES) render_list_kerne
     for (int item = blockIdx.x; item < count; item += gridDim.x) {
         const int env = s.reset_list[item];
         if (threadIdx.x == 0) io.pending[env] = 0;
-        render_env(s, atlas, io, flags, env, fb, L, S);
+        render_env<false>(s, atlas, io, flags, env, fb, L, S);
         __syncthreads();  // the next env of this workgroup reuses the LDS
     }
 }
@@ -1183,11 +1295,35 @@ class ChaserGame final : public Game {
         hipLaunchKernelGGL(frame_kernel, dim3(1), dim3(kFrameThreads), 0, st, s_, atlas_, env, FrameTarget{d_px, w, h});
         return true;
     }
+    // (the draw-list replay and kDebugNoPrepass take the kernel that resolves its own draws)
+    bool lean() const { return !(debug_flags & (1 | kDebugNoPrepass)); }
+    void launch_prepass(hipStream_t st, const uint8_t* mask) override {
+        (void)mask;  // (every env: a lane's work, and the frames of the others are not drawn)
+        if (lean()) hipLaunchKernelGGL(setup_kernel, dim3((s_.n * kPrepLanes + 255) / 256), dim3(256), 0, st, s_, atlas_);
+    }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
-        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags, 0);
+        if (lean())
+            hipLaunchKernelGGL(render_kernel<true>, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags, 0);
+        else
+            hipLaunchKernelGGL(render_kernel<false>, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags, 0);
     }
     void launch_render_step(hipStream_t st, StepIO io) override {
-        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, nullptr, io, debug_flags, reset_stream ? 1 : 0);
+        if (lean())
+            hipLaunchKernelGGL(render_kernel<true>, dim3(s_.n), dim3(128), 0, st, s_, atlas_, nullptr, io, debug_flags, reset_stream ? 1 : 0);
+        else
+            hipLaunchKernelGGL(render_kernel<false>, dim3(s_.n), dim3(128), 0, st, s_, atlas_, nullptr, io, debug_flags, reset_stream ? 1 : 0);
+    }
+    static size_t up256(size_t b) { return (b + 255) & ~size_t(255); }
+    size_t scratch_bytes(int n) const override {
+        return up256(size_t(2) * kCells * kBlitWords * 4) + up256(size_t(n) * kMovers * kBlitWords * 4) + up256(size_t(n) * 8 * 4);
+    }
+    void bind_scratch(void* d_scratch, int n) override {
+        uint8_t* p = static_cast<uint8_t*>(d_scratch);
+        s_.prep.cell_blits = reinterpret_cast<uint32_t*>(p);
+        p += up256(size_t(2) * kCells * kBlitWords * 4);
+        s_.prep.movers = reinterpret_cast<uint32_t*>(p);
+        p += up256(size_t(n) * kMovers * kBlitWords * 4);
+        s_.prep.bg = reinterpret_cast<uint32_t*>(p);
     }
     bool launch_render_late(hipStream_t st, StepIO io) override {
         if (!reset_stream) return false;

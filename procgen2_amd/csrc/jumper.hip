@@ -1188,6 +1188,18 @@ __global__ void __launch_bounds__(128, PG_RENDER_WAVES) render_kernel(State s, A
     constexpr int halves = 2;
     __shared__ alignas(16) uint32_t fb[kFbWords];
     __shared__ ComposeLds<kGrid> L;
+#if defined(PG_TIMELINE)  // (latency experiment, tools/build_exp.py + tools/probe/wave_timeline.py: where a wave's life goes)
+    unsigned long long tl[8];
+#define PG_TL(k)                                \
+    do {                                        \
+        __builtin_amdgcn_s_waitcnt(0);          \
+        __builtin_amdgcn_wave_barrier();        \
+        tl[k] = __builtin_amdgcn_s_memtime();   \
+    } while (0)
+#else
+#define PG_TL(k) do {} while (0)
+#endif
+    PG_TL(0);
     const PrepMeta M{s.prep.meta + size_t(env) * kPrepMetaWords};
     const uint32_t colw = s.prep.axes[size_t(env) * 128 + lane], roww = s.prep.axes[size_t(env) * 128 + 64 + lane];
     const uint32_t roww2 = s.prep.axes2[size_t(env) * 64 + lane];
@@ -1198,12 +1210,14 @@ __global__ void __launch_bounds__(128, PG_RENDER_WAVES) render_kernel(State s, A
     prep_cells_expand<kGrid>(L, two16, kind_off, half, lane);
     const ComposeRegs R = prep_regs<kGrid>(M, colw, roww, roww2, lane);
     __syncthreads();  // the cell table is complete
+    PG_TL(1);
     if (M.fat()) return;  // (wave-uniform; render_full_kernel has drawn it)
     const int row_lo = half * (kObsH / halves), row_hi = (half + 1) * (kObsH / halves);
     if (M.flags() & 2u)
         compose_rows_from<kGrid, true, false>(fb, L, atlas, R, lane, flags, half, halves);
     else
         compose_rows_from<kGrid, false, false>(fb, L, atlas, R, lane, flags, half, halves);
+    PG_TL(2);
     // the compass (jumper.cpp:473-509) behind the resolved draws: lanes n_draws, + 1, + 2 = circle, needle, bar — raw
     // screen-space draws whose parameters the logic kernel worked out (store_compass)
     const int hud = lane - n_draws + 1;  // 1, 2, 3
@@ -1234,17 +1248,28 @@ __global__ void __launch_bounds__(128, PG_RENDER_WAVES) render_kernel(State s, A
         }
         has = resolve_screen_at(d.y, d.z, d.x, sx, sy, sw, sh, sn, cs, mine);
     }
+    PG_TL(3);
     if (s.hud_image != 0u) {
         // the ring is the same 60×60 pixels in every frame: prepared once (pg_render.h overlay_rows), in its place in the
         // draw order — after the bunny, before the needle and the bar
         wave_replay_rows(fb, atlas, mine, __ballot(has && lane < n_draws), lane, row_lo, row_hi);
+        PG_TL(4);
         overlay_rows(fb, atlas.texels + s.hud_image, reinterpret_cast<const uint2*>(atlas.texels + s.hud_list), s.hud_n, lane,
                      row_lo, row_hi);
+        PG_TL(5);
         wave_replay_rows(fb, atlas, mine, __ballot(has && lane > n_draws), lane, row_lo, row_hi);
+        PG_TL(6);
     } else {
         wave_replay_rows(fb, atlas, mine, __ballot(has), lane, row_lo, row_hi);
     }
     wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, row_lo, row_hi);
+#if defined(PG_TIMELINE)
+    PG_TL(7);
+    if (lane == 0 && s.hud_image != 0u) {
+        unsigned long long* out = reinterpret_cast<unsigned long long*>(io.obs + size_t(env) * kObsBytes + half * (kObsBytes / 2));
+        for (int k = 0; k < 8; k++) out[k] = tl[k];
+    }
+#endif
 }
 
 // cenv_render's frame (render_game(false)) for one env: pg_frame.h; the draw list of render_kernel, one draw at a time.

@@ -412,6 +412,10 @@ PG_D RotBox rot_box(const Blit& b) {
 
 // kBatch: texel fetches in flight per lane — a batch costs one memory round trip.  (Four everywhere: eight or sixteen for
 // jumper's needle and bunny — one trip instead of four and two — spill at its 96-register cap, render 0.94 -> 1.36 ms.)
+// (Measured and rejected, round 4: for rectangles of at most 64 × 64 pixels, the two texel coordinates from per-lane tables
+// read across lanes instead of two divisions a pixel, and the rotation as four 24-bit multiplies (rotated_pixel below) —
+// 85 -> 45 vector instructions a pixel, bit-exact; jumper's render unchanged (0.651 ms), caveflyer's 0.429 -> 0.486: two
+// more LDS round trips in front of every texel fetch cost more than the instructions they replace.)
 template <int kBatch = 4>
 PG_D void wave_blit_rotated(uint32_t* fb, const AtlasView& atlas, const Blit& b, const RotBox& box, int lane,
                             int stride = 64) {

@@ -73,7 +73,7 @@ def test_row_composer_equals_draw_list_replay(game):
     slow.close()
 
 
-@pytest.mark.parametrize("game", ["coinrun", "climber", "caveflyer", "bossfight", "jumper"])
+@pytest.mark.parametrize("game", ["coinrun", "climber", "caveflyer", "bossfight", "jumper", "chaser"])
 def test_render_pre_pass_equals_the_complete_path(game):
     """The lean frames — composed from what the render pre-pass (pg_prepass.h setup_kernel) left in device memory — against
     the same engine with the pre-pass switched off (pgv_set_debug bit 21: every frame's workgroup does its own set-up, the
