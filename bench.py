@@ -92,7 +92,8 @@ def measured_traffic(game):
         if name.startswith("_"):
             continue
         # "pg::variant0::<game>::render_kernel" (default distribution mode)
-        if name.endswith("::%s::render_kernel" % game) and ("variant" not in name or "variant0::" in name):
+        # (chaser's is a template: "void pg::variant0::chaser::render_kernel<true>")
+        if name.split("<")[0].endswith("::%s::render_kernel" % game) and ("variant" not in name or "variant0::" in name):
             entry = value
     if not entry:
         return None, None, None
@@ -297,7 +298,9 @@ def main():
                                    % (window, a.settle + max(1, a.warmup) + a.steps,
                                       a.settle + max(1, a.warmup) + a.steps + window - 1,
                                       "; chaser: the late pass over the envs that reset is a second, small launch "
-                                      "behind the events" if a.game == "chaser" else "")},
+                                      "behind the events" if a.game == "chaser" else
+                                      "; jumper: the kernel that walks the list of frames the pre-pass hands back — "
+                                      "empty in this run, 5 us — is inside the events too" if a.game == "jumper" else "")},
             "done_fraction_last_step": done_frac,
         }
         if n_gpus == 1 and not a.no_cpu_baseline and not a.mode:
