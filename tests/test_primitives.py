@@ -12,5 +12,5 @@ def test_primitives_match_libstdcxx(tmp_path):
                     os.path.join(ROOT, "tests", "cpp", "test_primitives.cpp"), "-o", exe], check=True)
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
-    for section in ("OK axis template", "OK rot box", "OK sincos", "OK blend", "OK mt19937", "OK distributions", "OK hash_order", "OK sort", "ALL OK"):
+    for section in ("OK axis template", "OK rot box", "OK span nested", "OK sincos", "OK blend", "OK mt19937", "OK distributions", "OK hash_order", "OK sort", "ALL OK"):
         assert section in out.stdout
