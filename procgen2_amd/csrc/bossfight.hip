@@ -1195,8 +1195,7 @@ __global__ void __launch_bounds__(64, 5) render_kernel(State s, AtlasView atlas,
     const int env = blockIdx.x / halves;
     if (mask && !mask[env]) return;
     const int lane = threadIdx.x & 63, half = blockIdx.x % halves;
-    __shared__ alignas(16) uint32_t fb_rows[kFbWords / halves];
-    uint32_t* const fb = fb_rows - half * (kFbWords / halves);  // (everything below addresses the target by absolute row)
+    __shared__ alignas(16) uint32_t fb[kFbWords / halves];  // this wave's rows only: frame row row_lo is its row 0
     const uint32_t meta = __builtin_amdgcn_readfirstlane(s.prep.meta[env]);
     const int n_bullets = meta & 0xffu, n_draws = (meta >> 8) & 0xffu, backdrop = meta >> 16;
     const int row_lo = half * (kObsH / halves), row_hi = (half + 1) * (kObsH / halves);
@@ -1212,14 +1211,19 @@ __global__ void __launch_bounds__(64, 5) render_kernel(State s, AtlasView atlas,
     }
     bullet.rot_sn = static_cast<int32_t>(b3.x);
     bullet.rot_cs = static_cast<int32_t>(b3.y);
-    const RotBox box{static_cast<int>(b4.x & 0xffu), static_cast<int>((b4.x >> 8) & 0xffu), static_cast<int>((b4.x >> 16) & 0xffu),
+    // The draws in the coordinates of the wave's own target: everything moved up by row_lo.  A draw's pixels are found from
+    // their offsets to its corner (pg_render.h wave_blit, rotated_pixel), so moving the corner moves them and nothing else.
+    bullet.dy -= row_lo;
+    const RotBox box{static_cast<int>(b4.x & 0xffu), static_cast<int>((b4.x >> 8) & 0xffu) - row_lo, static_cast<int>((b4.x >> 16) & 0xffu),
                      static_cast<int>(b4.x >> 24)};
-    const Blit draw = prep_draw_load(s.prep.draws + (size_t(env) * kPrepDraws + lane) * kBlitWords, has_draw);
-    compose_background_from<kObsH / halves>(fb, atlas, bg_col, bg_row, lane, half);
+    Blit draw = prep_draw_load(s.prep.draws + (size_t(env) * kPrepDraws + lane) * kBlitWords, has_draw);
+    draw.dy -= row_lo;
+    constexpr int kOwnRows = kObsH / halves;
+    compose_background_from<kOwnRows, true>(fb, atlas, bg_col, bg_row, lane, half);
     const unsigned long long mb = __ballot(has_bullet), md = __ballot(has_draw);
-    wave_replay_rows<4, true>(fb, atlas, bullet, mb, lane, row_lo, row_hi, &box);
-    wave_replay_rows<4, true>(fb, atlas, draw, md, lane, row_lo, row_hi);
-    wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, row_lo, row_hi);
+    wave_replay_rows<4, true>(fb, atlas, bullet, mb, lane, 0, kOwnRows, &box);
+    wave_replay_rows<4, true>(fb, atlas, draw, md, lane, 0, kOwnRows);
+    wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, row_lo, row_hi, 0);
 }
 
 // ------------------------------------------------------------------------------------------------

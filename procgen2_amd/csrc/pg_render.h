@@ -857,12 +857,14 @@ PG_D void overlay_rows(uint32_t* fb, const uint32_t* image, const uint2* list, i
 
 // The rows wave `half` of `halves` owns, and their share of the finished frame on its way out (no barrier needed
 // between a wave's last blend and its own store).
-PG_D void wave_store_rows(const uint32_t* fb, uint8_t* obs_env, int lane, int row_lo, int row_hi) {
+// fb_row0: the row of `fb` that holds frame row row_lo (row_lo itself for a whole-frame target, 0 for a wave's own).
+PG_D void wave_store_rows(const uint32_t* fb, uint8_t* obs_env, int lane, int row_lo, int row_hi, int fb_row0 = -1) {
     Rgb4* out = reinterpret_cast<Rgb4*>(obs_env);
     const uint4* in = reinterpret_cast<const uint4*>(fb);
+    const int shift = fb_row0 < 0 ? 0 : (row_lo - fb_row0) * (kObsW / 4);
     wave_order();  // the wave's own blends, lane-to-pixel mapping of the draws
     for (int g = row_lo * (kObsW / 4) + lane; g < row_hi * (kObsW / 4); g += 64) {
-        const uint4 p = in[g];
+        const uint4 p = in[g - shift];
         Rgb4 o;
         o.a = __builtin_amdgcn_perm(p.y, p.x, 0x04020100u);
         o.b = __builtin_amdgcn_perm(p.z, p.y, 0x05040201u);
@@ -1037,12 +1039,13 @@ constexpr uint32_t kNoTexel = 0x40000000u;
 // pixel instead of the composer's five, no span tables.  Same arithmetic as compose_rows with four absent candidates.
 // The background over black from this lane's two offsets (bg_offset of pixel column `lane` and of pixel row `lane`):
 // the wave's own rows, nothing shared with the other wave — no barrier.
-template <int kRows = kObsH / 2>
+// kOwnTarget: `fb` holds this wave's rows only (row py_begin of the frame is row 0 of fb).
+template <int kRows = kObsH / 2, bool kOwnTarget = false>
 PG_D void compose_background_from(uint32_t* fb, const AtlasView& atlas, uint32_t bg_col, uint32_t bg_row, int lane, int half) {
     const __amdgpu_buffer_rsrc_t bg_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t*>(atlas.texels), 0, static_cast<int>(atlas.texel_bytes), 0x00020000);
     // all the rows of the wave at once: 32 gathers in flight, one memory round trip
-    const int py_begin = half * kRows;
+    const int py_begin = half * kRows, at_begin = kOwnTarget ? 0 : py_begin;
     uint32_t t[kRows];
 #pragma unroll
     for (int k = 0; k < kRows; k++)
@@ -1052,11 +1055,11 @@ PG_D void compose_background_from(uint32_t* fb, const AtlasView& atlas, uint32_t
     for (int k = 1; k < kRows; k++) least = least < t[k] ? least : t[k];
     if (__ballot(least < 0xff000000u) == 0) {  // opaque everywhere: the texels are the pixels (top byte unread)
 #pragma unroll
-        for (int k = 0; k < kRows; k++) fb[(py_begin + k) * kObsW + lane] = t[k];
+        for (int k = 0; k < kRows; k++) fb[(at_begin + k) * kObsW + lane] = t[k];
     } else {
 #pragma unroll
         for (int k = 0; k < kRows; k++)
-            fb[(py_begin + k) * kObsW + lane] = blend_px(0u, t[k], static_cast<int>(t[k] >> 24));
+            fb[(at_begin + k) * kObsW + lane] = blend_px(0u, t[k], static_cast<int>(t[k] >> 24));
     }
 }
 PG_D void compose_background(uint32_t* fb, const AtlasView& atlas, const BgAxis& bga, int lane, int half, int halves) {
