@@ -355,6 +355,9 @@ PG_D void prep_column_store(uint8_t* cells_env, int c, const uint32_t (&kinds)[G
     }
 }
 
+#if defined(PG_FAT_WHY)
+__device__ unsigned g_fat_why[6];
+#endif
 // The last phase: the envs' meta lines, coalesced.  `counts[e]` = draws of env e (> kPrepDraws: fat).  Needs a barrier
 // in front (every phase has written its part of P.meta / P.fat).
 template <int GRID, int MAXSPAN, int E>
@@ -366,6 +369,19 @@ PG_D void prep_meta_out(PrepLds<GRID, E, MAXSPAN>& P, const PrepOut& out, int en
         if (w == PM_FLAGS) {
             const int c = counts[e];
             const bool fat = P.fat[e] != 0 || c > kPrepDraws;
+#if defined(PG_FAT_WHY)  // (diagnostic build, tools/build_exp.py GAME fatwhy -DPG_FAT_WHY: why frames are handed back, counted per launch)
+            if (fat) {
+                for (int b = 0; b < 4; b++)
+                    if (P.fat[e] & (1u << b)) atomicAdd(&g_fat_why[b], 1u);
+                if (c > kPrepDraws) atomicAdd(&g_fat_why[4], 1u);
+                atomicAdd(&g_fat_why[5], 1u);
+            }
+            if (env0 == 0 && e == 0) {
+                printf("handed back last launch: %u frames (view %u, worklist %u, span %u, candidates %u, draws %u)\n", g_fat_why[5], g_fat_why[0],
+                       g_fat_why[1], g_fat_why[2], g_fat_why[3], g_fat_why[4]);
+                for (int b = 0; b < 6; b++) g_fat_why[b] = 0u;
+            }
+#endif
             word = (fat ? 1u : 0u) | (P.view[e].th2 > 0 ? 2u : 0u) | (static_cast<uint32_t>(fat ? 0 : c) << 8);
         }
         if (w == PM_BGTEX) word = static_cast<uint32_t>(P.view[e].bg.desc.x);
