@@ -17,6 +17,7 @@
 #include "pg_kruskal.h"
 #include "pg_prefetch.h"
 #include "pg_render.h"
+#include "pg_prepass.h"
 #include "pg_rng.h"
 
 namespace pg {
@@ -65,6 +66,13 @@ struct State {
     ComposeHand* prepared;
     float* f;        // [F_COUNT][n]
     int32_t* i;      // [I_COUNT][n]
+    // The render pre-pass's hand-over (scratch memory, not state): the frame's two draws and the background's two axes, worked
+    // out by four lanes an env of a dense kernel (setup_kernel) instead of by 2 + 1 lanes of each of the env's two render
+    // wavefronts — a quarter of what those executed.
+    struct Prep {
+        uint32_t* draws;  // [n][2][kBlitWords]  cheese, mouse (pg_render.h BlitWords; word 1 = 0: not drawn)
+        uint32_t* bg;     // [n][8]              background, x axis then y axis: d0 | dn << 16, s0 | sn << 16, first texel, width
+    } prep;
 };
 
 PG_D float& SF(const State& s, int field, int env) { return s.f[size_t(field) * s.n + env]; }
@@ -245,6 +253,43 @@ __global__ void __launch_bounds__(128) prepare_kernel(State s, AtlasView atlas) 
 }
 
 // flags bit 0: force the draw-list replay for background + walls (fallback path).
+// The render pre-pass: four lanes an env — cheese, mouse (tilemap.cpp:88, common_systems.cpp:138-150 as render_kernel states
+// them), the background's x and y axis (maze.cpp:402-408; pg_render.h bg_axis).
+__global__ void __launch_bounds__(256) setup_kernel(State s, AtlasView atlas) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int env = gid >> 2, item = gid & 3;
+    if (env >= s.n) return;
+    const Camera cam{kCentred ? SF(s, F_CAMX, env) : W * 0.5f * kUnitPx, kCentred ? SF(s, F_CAMY, env) : H * 0.5f * kUnitPx,
+                     64.0f, 64.0f, zoom_of_obs()};
+    if (item < 2) {
+        const bool cheese = item == 0;
+        const int sflags = SI(s, I_FLAGS, env);
+        const int4 d = atlas.desc[cheese ? kTexCheese : kTexMouse];
+        const float wx = cheese ? (SF(s, F_GX, env) + -0.48f) * kUnitPx : (SF(s, F_AX, env) + -0.5f) * kUnitPx;
+        const float wy = cheese ? (SF(s, F_GY, env) + -0.5f) * kUnitPx : (SF(s, F_AY, env) + -0.5f) * kUnitPx;
+        const float scale = cheese ? (1.0f * 0.95f) * kUnitPx / d.y : kUnitPx / d.y * 1.0f;
+        bool has = cheese ? (sflags & kFlagListed) != 0 : true;
+        Blit b;
+        if (has) has = resolve_draw(cam, d.y, d.z, d.x, wx, wy, scale, 1.0f, !cheese && (sflags & kFlagForward) != 0, false, b);
+        BlitWords w{};
+        if (has) w = blit_pack(b);
+        uint2* at = reinterpret_cast<uint2*>(s.prep.draws + (size_t(env) * 2 + item) * kBlitWords);
+        at[0] = make_uint2(w.w[0], w.w[1]);
+        at[1] = make_uint2(w.w[2], w.w[3]);
+        at[2] = make_uint2(w.w[4], w.w[5]);
+    } else {
+        const int axis = item - 2;
+        const int4 d = atlas.desc[kTexFloor + SI(s, I_BG, env)];
+        const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
+        const float extra = aspect - 1.0f;
+        const BgAxis a = bg_axis(cam, d, -SF(s, F_BGSHIFT, env) * extra, 0.0f, 64.0f * kUnitPx / d.z, axis);
+        uint4* at = reinterpret_cast<uint4*>(s.prep.bg + size_t(env) * 8 + axis * 4);
+        *at = make_uint4(pack_halves(a.d0, a.dn), pack_halves(a.s0, a.sn), static_cast<uint32_t>(a.tex_off), static_cast<uint32_t>(a.tex_w));
+    }
+}
+
+// kPrepped: the two draws and (camera at rest) the background's axes come from the pre-pass; false: the debug paths.
+template <bool kPrepped>
 __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io,
                                                     int flags) {
     const int env = blockIdx.x;
@@ -287,7 +332,13 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
             compose_spans<kGrid, kSpan>(fb, L, cam, x0, y0, cols, rows, wall.y, wall.z, kUnitPx / wall.y, lane, 0, half, halves,
                                         soft_rows_of(bg_soft, wall.w), hard_rows_of(bg_soft, wall.w), &bg_draw, &bga);
         } else {  // the tile spans are the prepared ones: only this wave's axis of the background is resolved
-            bga = bg_axis(cam, bg_d, bg_px, bg_py, bg_sc, half);
+            if (kPrepped) {
+                const uint32_t* w = s.prep.bg + size_t(env) * 8 + half * 4;
+                bga = BgAxis{static_cast<int32_t>(w[0] << 16) >> 16, static_cast<int32_t>(w[0]) >> 16, static_cast<int32_t>(w[1] & 0xffffu),
+                             static_cast<int32_t>(w[1] >> 16), static_cast<int32_t>(w[2]), static_cast<int32_t>(w[3])};
+            } else {
+                bga = bg_axis(cam, bg_d, bg_px, bg_py, bg_sc, half);
+            }
             if (half == 0 && lane < 2) L.base[kGrid * kGrid + lane] = static_cast<int32_t>(kNoTexel);
         }
         for (int cell = lane + 64 * half; cell < cells; cell += 64 * halves) {
@@ -317,7 +368,11 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
             wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
         }
     }
-    {   // lane 0: the cheese sprite (tilemap.cpp:88): offset (-0.48,-0.5), scale 0.95, z = 1, once it is listed;
+    if (kPrepped) {  // lane 0: the cheese, lane 1: the mouse, as the pre-pass resolved them
+        mine = prep_draw_load(s.prep.draws + (size_t(env) * 2 + (lane & 1)) * kBlitWords, lane < 2);
+        wave_replay_rows(fb, atlas, mine, __ballot(lane < 2 && mine.dw > 0), lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
+    } else {
+        // lane 0: the cheese sprite (tilemap.cpp:88): offset (-0.48,-0.5), scale 0.95, z = 1, once it is listed;
         // lane 1: the mouse (common_systems.cpp:138-150); flip = face_forward.  The two differ in their parameters
         // only: one pass through resolve_draw, one replay, in this order.
         const bool cheese = lane == 0;
@@ -419,8 +474,24 @@ class MazeGame final : public Game {
         hipLaunchKernelGGL(frame_kernel, dim3(1), dim3(kFrameThreads), 0, st, s_, atlas_, env, FrameTarget{d_px, w, h});
         return true;
     }
+    // (the draw-list replay and kDebugNoPrepass take the kernel that resolves its own draws)
+    bool lean() const { return !(debug_flags & (1 | kDebugNoPrepass)); }
+    void launch_prepass(hipStream_t st, const uint8_t* mask) override {
+        (void)mask;  // (every env: a lane's work, and the frames of the others are not drawn)
+        if (lean()) hipLaunchKernelGGL(setup_kernel, dim3((s_.n * 4 + 255) / 256), dim3(256), 0, st, s_, atlas_);
+    }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
-        hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags);
+        if (lean())
+            hipLaunchKernelGGL(render_kernel<true>, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags);
+        else
+            hipLaunchKernelGGL(render_kernel<false>, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags);
+    }
+    static size_t up256(size_t b) { return (b + 255) & ~size_t(255); }
+    size_t scratch_bytes(int n) const override { return up256(size_t(n) * 2 * kBlitWords * 4) + up256(size_t(n) * 8 * 4); }
+    void bind_scratch(void* d_scratch, int n) override {
+        uint8_t* p = static_cast<uint8_t*>(d_scratch);
+        s_.prep.draws = reinterpret_cast<uint32_t*>(p);
+        s_.prep.bg = reinterpret_cast<uint32_t*>(p + up256(size_t(n) * 2 * kBlitWords * 4));
     }
     // Same layout as oracle/pgo_maze.cpp Maze::dump_state.
     int dump_state(hipStream_t st, int env, float* out, int cap) override {

@@ -73,7 +73,7 @@ def test_row_composer_equals_draw_list_replay(game):
     slow.close()
 
 
-@pytest.mark.parametrize("game", ["coinrun", "climber", "caveflyer", "bossfight", "jumper", "chaser"])
+@pytest.mark.parametrize("game", ["coinrun", "climber", "caveflyer", "bossfight", "jumper", "chaser", "maze"])
 def test_render_pre_pass_equals_the_complete_path(game):
     """The lean frames — composed from what the render pre-pass (pg_prepass.h setup_kernel) left in device memory — against
     the same engine with the pre-pass switched off (pgv_set_debug bit 21: every frame's workgroup does its own set-up, the
@@ -94,7 +94,7 @@ def test_render_pre_pass_equals_the_complete_path(game):
         if s % 97 == 50:  # an explicit reset of some envs (the pre-pass runs behind it with the same mask)
             mask = (np.arange(n) % 5 == s % 5).astype(np.uint8)
             assert np.array_equal(lean.reset(mask=mask), full.reset(mask=mask)), "masked reset at step %d" % s
-    assert ends > 0 or game == "caveflyer"
+    assert ends > 0 or game in ("caveflyer", "maze")
     lean.close()
     full.close()
 
