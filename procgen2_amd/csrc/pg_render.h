@@ -1294,16 +1294,26 @@ PG_D bool compose_rows_from(uint32_t* fb, const ComposeLds<GRID>& L, const Atlas
     };
     // The general form of one batch of rows: every candidate of every pixel is fetched, then resolved.  `todo`: the rows
     // of the batch it is wanted for (bit k = row py0 + k, wave-uniform); the others are left as they are.
-    auto general_batch = [&](int py0, uint32_t todo) {  // kGen rows from py0; `todo` has kGen bits
+    // The rows are named one by one (py_of[k], wave-uniform; bit k of `todo`: wanted): the rows of a wave's 32 that need this form
+    // are few and scattered — one in five or six in chaser, where a wall tile's translucent edge is sampled — and taking
+    // them kGen at a time wherever they lie, instead of by aligned groups of kGen, is fewer trips through memory.
+    auto general_batch = [&](const int (&py_of)[kGen], uint32_t todo) {
         uint32_t t[kGen][3], u[kGen][2];
-        uint32_t seconds = static_cast<uint32_t>(second_row >> py0) & todo;
+        uint32_t seconds = 0, softs = 0;
+#pragma unroll
+        for (int k = 0; k < kGen; k++) {
+            seconds |= static_cast<uint32_t>((second_row >> py_of[k]) & 1ull) << k;
+            softs |= static_cast<uint32_t>((soft >> py_of[k]) & 1ull) << k;
+        }
+        seconds &= todo;
+        softs &= todo;
         // (opaque to the compiler: it would otherwise keep the 32 per-row tests of the attempt below alive in scalar
         // registers for this rarely taken path, and spill them)
         asm volatile("" : "+s"(seconds));
 #pragma unroll
         for (int k = 0; k < kGen; k++) {
             if (!(todo & (1u << k))) continue;
-            const int py = py0 + k;
+            const int py = py_of[k];
             const uint32_t s_bg = __builtin_amdgcn_readlane(bg_row, py);
             const uint32_t s_a = __builtin_amdgcn_readlane(row_a, py);
             const uint32_t* cp = reinterpret_cast<const uint32_t*>(cells + __builtin_amdgcn_readlane(cells_a, py));
@@ -1322,7 +1332,7 @@ PG_D bool compose_rows_from(uint32_t* fb, const ComposeLds<GRID>& L, const Atlas
 #pragma unroll
             for (int k = 0; k < kGen; k++) {
                 if (seconds & (1u << k)) {
-                    const int py = py0 + k;
+                    const int py = py_of[k];
                     const uint32_t s_b = __builtin_amdgcn_readlane(row_b, py);
                     const uint32_t* cp = reinterpret_cast<const uint32_t*>(cells + __builtin_amdgcn_readlane(cells_a, py));
                     const uint32_t s_b2 = (TWO || BOX) ? __builtin_amdgcn_readlane(row_b2, py) : 0u;
@@ -1340,7 +1350,7 @@ PG_D bool compose_rows_from(uint32_t* fb, const ComposeLds<GRID>& L, const Atlas
         // Does the batch hold a translucent texel (alpha not in {0, 255})?  Asked only when one of its rows shows a
         // texture that has any ((a + 1) & 0xFE is zero exactly for 0 and 255).
         bool blend = bg_mod != 255;
-        if (!blend && ((static_cast<uint32_t>(soft >> py0) & todo) != 0u) && !PG_ABL(ablate, 512)) {
+        if (!blend && softs != 0u && !PG_ABL(ablate, 512)) {
             uint32_t translucent = 0;
 #pragma unroll
             for (int k = 0; k < kGen; k++) {
@@ -1370,7 +1380,7 @@ PG_D bool compose_rows_from(uint32_t* fb, const ComposeLds<GRID>& L, const Atlas
             }
 #pragma unroll
             for (int k = 0; k < kGen; k++)
-                if (todo & (1u << k)) fb[(py0 + k) * kObsW + lane] = pix[k];
+                if (todo & (1u << k)) fb[py_of[k] * kObsW + lane] = pix[k];
         } else {
 #pragma unroll
             for (int k = 0; k < kGen; k++) {
@@ -1385,7 +1395,7 @@ PG_D bool compose_rows_from(uint32_t* fb, const ComposeLds<GRID>& L, const Atlas
                     pix = blend_px(pix, u[k][0], static_cast<int>(u[k][0] >> 24));
                     pix = blend_px(pix, u[k][1], static_cast<int>(u[k][1] >> 24));
                 }
-                fb[(py0 + k) * kObsW + lane] = pix;
+                fb[py_of[k] * kObsW + lane] = pix;
             }
         }
     };
@@ -1409,7 +1419,12 @@ PG_D bool compose_rows_from(uint32_t* fb, const ComposeLds<GRID>& L, const Atlas
     if (halves != 2) return false;  // (every render kernel runs two wavefronts per env)
     const uint32_t hards = PG_ABL(ablate, 16384) ? 0u : static_cast<uint32_t>(hard >> py_begin);  // this wave's 32 rows
     if (bg_mod != 255 || hards == 0xffffffffu) {  // nothing worth attempting
-        for (int py0 = py_begin; py0 < py_begin + kRows; py0 += kGen) general_batch(py0, (1u << kGen) - 1u);
+        for (int py0 = py_begin; py0 < py_begin + kRows; py0 += kGen) {
+            int py_of[kGen];
+#pragma unroll
+            for (int k = 0; k < kGen; k++) py_of[k] = py0 + k;
+            general_batch(py_of, (1u << kGen) - 1u);
+        }
         __syncthreads();
         return true;
     }
@@ -1488,6 +1503,7 @@ PG_D bool compose_rows_from(uint32_t* fb, const ComposeLds<GRID>& L, const Atlas
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler does not track LDS-direct loads: wait for them here
     // judged in groups of kBatch rows: 8 rows = 128 × 16 bytes of the target, two reads per lane
     const uint4* const landed = reinterpret_cast<const uint4*>(fb) + py_begin * (kObsW / 4);
+    uint32_t todo32 = 0;
 #pragma unroll
     for (int g = 0; g < kRows / kBatch; g++) {
         const uint4 p = landed[g * (kBatch * kObsW / 4) + lane], q = landed[g * (kBatch * kObsW / 4) + 64 + lane];
@@ -1509,13 +1525,21 @@ PG_D bool compose_rows_from(uint32_t* fb, const ComposeLds<GRID>& L, const Atlas
             }
         }
         if (PG_ABL(ablate, 4096)) todo = 0xffu;
-        if (todo != 0 && !PG_ABL(ablate, 8192)) {  // (bit 13: never)
+        if (!PG_ABL(ablate, 8192)) todo32 |= todo << (g * kBatch);  // (bit 13: never)
+    }
+    while (todo32 != 0u) {  // wave-uniform: the rows that go through the general form, kGen at a time
+        int py_of[kGen];
+        uint32_t bits = 0;
 #pragma unroll
-            for (int h = 0; h < kBatch / kGen; h++) {
-                const uint32_t part = (todo >> (h * kGen)) & ((1u << kGen) - 1u);
-                if (part) general_batch(py_begin + g * kBatch + h * kGen, part);
+        for (int k = 0; k < kGen; k++) {
+            py_of[k] = py_begin;
+            if (todo32 != 0u) {
+                py_of[k] = py_begin + __builtin_ctz(todo32);
+                todo32 &= todo32 - 1u;
+                bits |= 1u << k;
             }
         }
+        general_batch(py_of, bits);
     }
     __syncthreads();
     return true;
