@@ -1356,6 +1356,7 @@ class CaveflyerGame final : public Game {
     void launch_reset(hipStream_t st, const uint8_t* mask, const int32_t* seeds, StepIO io) override {
         LevelLaunch<Gen>::reset(st, s_, prefetch(), mask, seeds, io, plan);
     }
+    int pregen_every() const override { return 2; }  // (pg_engine.h)
     bool launch_pregen(hipStream_t side, bool bulk) override {
         if (!prefetch()) return false;
         LevelLaunch<Gen>::pregen(side, s_, bulk, plan);

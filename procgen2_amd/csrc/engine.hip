@@ -240,7 +240,9 @@ struct pgv_env {
 static void pregen(pgv_env* e, bool bulk, bool force) {
     if (!e->side) return;
     e->since_pregen++;
-    if (!force && e->since_pregen < 4 && hipStreamQuery(e->side) != hipSuccess) return;
+    // (The query is the HOST's view: with the host hundreds of steps ahead of the device the side stream always has work
+    // queued, so this is "every pregen_every()-th step" in a long run — the game says how long it can wait.)
+    if (!force && e->since_pregen < e->game->pregen_every() && hipStreamQuery(e->side) != hipSuccess) return;
     hipEvent_t ev = e->side_ev[e->side_ev_next];
     e->side_ev_next = (e->side_ev_next + 1) % 8;
     if (hipEventRecord(ev, e->stream) != hipSuccess || hipStreamWaitEvent(e->side, ev, 0) != hipSuccess) return;

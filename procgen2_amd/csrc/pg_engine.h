@@ -105,6 +105,12 @@ class Game {
     // Level prefetch (pg_prefetch.h): launch the generator that fills queued shadow slots on the side stream.
     // bulk = most envs are expected to be queued (after make / a full reset).  False = game has no prefetch.
     virtual bool launch_pregen(hipStream_t side, bool bulk) { return false; }
+    // While the side stream is busy the engine launches the generator again only every this-many steps: an env whose
+    // episode ends before its slot is refilled generates its level inside the step, on the main stream, and one such env
+    // costs the step a whole level's latency.  Four suits the games whose episodes last hundreds of steps; maze's
+    // smallest mazes are solved in a few (two: 160 -> 195 M env-steps/s; one: 191), caveflyer gains 4 % at two,
+    // coinrun, climber and jumper lose 1-2 %.
+    virtual int pregen_every() const { return 4; }
     // cenv_render's human-size frame (render_game(false)) of one env into a w×h target of 0x00BBGGRR words in device
     // memory (pg_frame.h).  False = not implemented for this game.
     virtual bool launch_frame(hipStream_t s, int env, uint32_t* d_px, int w, int h) { return false; }
