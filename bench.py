@@ -149,6 +149,21 @@ def cpu_baseline(game, run_seed, budget_s=20.0):
                       "render on, %d threads" % (game, envs, envs, steps, cores)}
 
 
+def cpu_baseline_mixed(games, counts, run_seed, budget_s=21.0):
+    """The mixed workload on the CPU oracle: each game timed like cpu_baseline on its own bounded sample (budget split
+    seven ways), combined as the workload combines them — a mixed step is counts[g] env-steps of every game g, so the
+    rate is sum(counts) / sum(counts[g] / rate[g])."""
+    per_game, cores, samples = {}, usable_cores(), []
+    for game in games:
+        b = cpu_baseline(game, run_seed, budget_s / len(games))
+        per_game[game] = b["value"]
+        samples.append(b["sample"])
+    seconds_per_mixed_step = sum(c / per_game[g] for g, c in zip(games, counts))
+    return {"value": sum(counts) / seconds_per_mixed_step, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "per_game": per_game,
+            "sample": "each game on its own: " + "; ".join(samples) + " — combined in the workload's proportions %s" % (counts,)}
+
+
 def launch_ranks(a):
     """--gpus N > 1 without a launcher: start the N ranks as children (one per GPU, RCCL rendezvous on 127.0.0.1).
     Nothing in this process has touched the GPU — torch is not even imported — so no initialised HIP runtime is ever
@@ -197,7 +212,7 @@ def main():
     if a.gpus < 1:
         ap.error("--gpus must be >= 1")
 
-    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if a.gpus > 1 and not (all(k in os.environ for k in ("WORLD_SIZE", "RANK", "MASTER_PORT")) or "TORCHELASTIC_RUN_ID" in os.environ):
         return launch_ranks(a)
 
     import torch
@@ -208,7 +223,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # Under a launcher (WORLD_SIZE set) this is a rank of a process group even when it is the only one: the single-GPU
     # box then runs the same init / barrier / all_reduce / gather code the 8-GPU node will (tests/test_a_nccl_single_rank.py).
-    distributed = "WORLD_SIZE" in os.environ
+    # "Under a launcher" = its whole variable set is there: a scheduler or container image that merely exports WORLD_SIZE=1
+    # leaves a plain single-GPU run a plain run (no rendezvous to fail at).
+    distributed = all(k in os.environ for k in ("WORLD_SIZE", "RANK", "MASTER_PORT")) or "TORCHELASTIC_RUN_ID" in os.environ
+    if not distributed:
+        world, rank, local_rank = 1, 0, 0
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -244,14 +263,21 @@ def main():
     # Roofline leg and latency percentiles: the dominant kernel's launch durations and the per-step times over their own
     # steady-state window (HIP events on the engine's stream), independent of how short the timed region was asked to be.
     window = max(256, a.steps)
-    step_ms, render_ms = env.step_times(window, run_seed)
-    render_avg_ms = float(render_ms.mean())
+    ph = env.step_phases(window, run_seed)
     import numpy as np
+    step_ms = ph["step"]
+    render_avg_ms = float(ph["render"].mean())
+    prepass_avg_ms, logic_avg_ms, late_avg_ms = float(ph["prepass"].mean()), float(ph["logic"].mean()), float(ph["late"].mean())
     p50_ms, mean_ms = float(np.median(step_ms)), float(step_ms.mean())
+    per_rank_ms = [elapsed / a.steps * 1e3]
     if distributed:
-        t = torch.tensor([elapsed, render_avg_ms, p50_ms, mean_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, render_avg_ms, p50_ms, mean_ms, prepass_avg_ms, logic_avg_ms, late_avg_ms], dtype=torch.float64, device="cuda")
+        mine = torch.tensor([elapsed / a.steps * 1e3], dtype=torch.float64, device="cuda")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)  # a straggler rank shows in the first SCALE record
+        per_rank_ms = [float(x[0]) for x in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, render_avg_ms, p50_ms, mean_ms = (float(x) for x in t)
+        elapsed, render_avg_ms, p50_ms, mean_ms, prepass_avg_ms, logic_avg_ms, late_avg_ms = (float(x) for x in t)
     fence()
     copy_gbps = measured_copy_bandwidth(torch, env.device, a.envs * 12288) if rank == 0 else None
 
@@ -261,7 +287,13 @@ def main():
     if rank == 0:
         total_steps = float(n_gpus) * a.envs * a.steps
         value = total_steps / elapsed
-        achieved = ALGO_BYTES_PER_ENV_STEP * a.envs / (render_avg_ms * 1e-3) / 1e9
+        algo = ALGO_BYTES_PER_ENV_STEP * a.envs
+        achieved = algo / (render_avg_ms * 1e-3) / 1e9
+        # The path, not a launch: everything that turns the step's state into the frame (pre-pass + render kernel + late /
+        # list kernels), and the whole step as `value` times it — a fraction that cannot rise by moving work across a
+        # launch boundary.
+        path_ms = prepass_avg_ms + render_avg_ms + late_avg_ms
+        ms_per_step = elapsed / a.steps * 1e3
         traffic, traffic_src, traffic_stale = measured_traffic(a.game) if a.envs == 65536 and not a.mode else (None, None, None)
         line = {
             "metric": "env-steps/sec at 65536 envs, 64x64x3 obs",
@@ -271,7 +303,8 @@ def main():
             "steps": a.steps,
             "warmup": a.warmup,
             "settle_steps": a.settle,
-            "ms_per_step": elapsed / a.steps * 1e3,
+            "ms_per_step": ms_per_step,
+            "per_rank_ms": per_rank_ms,
             "p50_ms_per_step": p50_ms,
             "mean_ms_per_step_window": mean_ms,
             "higher_is_better": True,
@@ -286,21 +319,25 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "%s::render_kernel" % a.game, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "traffic_source": traffic_src, "traffic_stale": traffic_stale,
+                         "whole_step_frac": algo / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         "render_path": {"achieved": algo / (path_ms * 1e-3) / 1e9, "frac": algo / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                         "avg_ms": path_ms, "what": "render pre-pass + render kernel + late / list kernels"},
+                         "kernels": [{"name": "logic kernels (auto-reset install, agent / entities / resolve or the game's logic kernel)", "avg_us": logic_avg_ms * 1e3},
+                                     {"name": "%s::setup_kernel (render pre-pass)" % a.game, "avg_us": prepass_avg_ms * 1e3},
+                                     {"name": "%s::render_kernel" % a.game, "avg_us": render_avg_ms * 1e3},
+                                     {"name": "late pass / list kernels behind the render launch", "avg_us": late_avg_ms * 1e3}],
                          "peak_measured": copy_gbps,
                          "peak_measured_how": "device-to-device copy of %d bytes (read + written bytes per second, best "
                                               "of 5), outside the timed region" % (a.envs * 12288),
                          "frac_of_measured": (achieved / copy_gbps) if copy_gbps else None,
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * a.envs,
+                         "algorithmic_bytes_per_launch": algo,
                          "avg_launch_ms": render_avg_ms,
-                         "window": "%d launches after the timed region (steps %d..%d since make), HIP events on the "
-                                   "engine's stream around the render kernel alone (a game's render pre-pass, "
-                                   "setup_kernel, is a launch of its own in front of it and inside the step%s)"
+                         "window": "%d steps after the timed region (steps %d..%d since make), HIP events on the engine's "
+                                   "stream between the phases of every step (pgv_step_phases): `frac` is the render kernel "
+                                   "alone, `render_path` adds the pre-pass in front of it and what follows it inside the "
+                                   "step, `whole_step_frac` is the same bytes over ms_per_step of the timed region"
                                    % (window, a.settle + max(1, a.warmup) + a.steps,
-                                      a.settle + max(1, a.warmup) + a.steps + window - 1,
-                                      "; chaser: the late pass over the envs that reset is a second, small launch "
-                                      "behind the events" if a.game == "chaser" else
-                                      "; jumper: the kernel that walks the list of frames the pre-pass hands back — "
-                                      "empty in this run, 5 us — is inside the events too" if a.game == "jumper" else "")},
+                                      a.settle + max(1, a.warmup) + a.steps + window - 1)},
             "done_fraction_last_step": done_frac,
         }
         if n_gpus == 1 and not a.no_cpu_baseline and not a.mode:
@@ -379,16 +416,37 @@ def mixed(a, torch, ProcgenVecEnv, distributed, world, rank, local_rank, n_gpus,
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
     fence()
+    # Per-game phases over a window of their own, all seven stepping side by side as in the timed region (events on each
+    # game's stream; the streams overlap, so a game's numbers are what its stream saw, not a share of the wall clock).
+    from procgen2_amd.vec_env import step_phases_many
+    import numpy as np
+    window = 128
+    ph = step_phases_many(envs, window, run_seed).mean(axis=2)  # [game][step, logic, prepass, render, late]
+    per_rank_ms = [elapsed / a.steps * 1e3]
+    if distributed:
+        mine = torch.tensor([elapsed / a.steps * 1e3], dtype=torch.float64, device="cuda")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_ms = [float(x[0]) for x in every]
+    fence()
     for e in envs:
         e.close()
     if rank == 0:
         value = float(n_gpus) * a.envs * a.steps / elapsed
-        achieved = ALGO_BYTES_PER_ENV_STEP * a.envs / (elapsed / a.steps) / 1e9
-        print(json.dumps({
+        algo = ALGO_BYTES_PER_ENV_STEP * a.envs
+        achieved = algo / (elapsed / a.steps) / 1e9
+        kernels, paths = [], {}
+        for g, (game, count) in enumerate(zip(GAMES, counts)):
+            for j, what in ((1, "logic kernels"), (2, "setup_kernel (render pre-pass)"), (3, "render_kernel"), (4, "late pass / list kernels")):
+                kernels.append({"name": "%s: %s" % (game, what), "avg_us": float(ph[g][j]) * 1e3})
+            path_ms = float(ph[g][2] + ph[g][3] + ph[g][4])
+            paths[game] = {"envs": count, "avg_ms": path_ms, "achieved": ALGO_BYTES_PER_ENV_STEP * count / (path_ms * 1e-3) / 1e9,
+                           "step_ms": float(ph[g][0])}
+        line = {
             "metric": "env-steps/sec, all 7 games mixed, 64x64x3 obs",
             "value": value, "unit": "env-steps/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
             "settle_steps": a.settle,
-            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / a.steps * 1e3, "per_rank_ms": per_rank_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/f32", "data": "synthetic",
             "config": {"workload": "all seven games, %d envs per GPU split %s, one stream per game, uniform random "
                                    "actions from a device counter hash, next-step auto-reset" % (a.envs, counts),
@@ -398,8 +456,19 @@ def mixed(a, torch, ProcgenVecEnv, distributed, world, rank, local_rank, n_gpus,
             "obs_write_GBps": value * 12288 / 1e9,
             "roofline": {"bound": "hbm", "kernel": "whole step, all games (wall clock, not one kernel)",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "whole_step_frac": achieved / HBM_PEAK_GBPS,
+                         "render_path": {"per_game": paths,
+                                         "what": "per game, on its own stream while the other six run beside it: render pre-pass + "
+                                                 "render kernel + late / list kernels of its share of the slab (the streams "
+                                                 "overlap: these do not add up to the wall clock)"},
+                         "kernels": kernels,
+                         "window": "%d steps after the timed region, all seven games side by side, HIP events on each game's "
+                                   "stream (pgv_step_phases_many)" % window,
                          "traffic": None},
-        }), flush=True)
+        }
+        if n_gpus == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_mixed(list(GAMES), counts, run_seed)
+        print(json.dumps(line), flush=True)
     if distributed:
         dist.destroy_process_group()
 

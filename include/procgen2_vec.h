@@ -125,6 +125,11 @@ PGV_API int32_t pgv_decode_png(const char* path, int32_t* w, int32_t* h, uint8_t
 
 PGV_API int32_t pgv_sync(pgv_env* env);
 
+/* How many times the level generator has been launched on the env's side stream since make (pg_prefetch.h).  The cadence
+ * is a function of the step count alone — every Game::pregen_every()-th step, plus one launch per make / reset — whatever
+ * the caller's synchronisation pattern: a measurement / test tap, -1 for a NULL env. */
+PGV_API int64_t pgv_generator_launches(pgv_env* env);
+
 /* Result buffers (device pointers, valid until pgv_close or the next pgv_bind_outputs):
  *   obs    u8 [N][64][64][3]   row-major HWC, one contiguous slab
  *   reward f32[N]
@@ -161,13 +166,30 @@ PGV_API int32_t pgv_render_frame(pgv_env* env, int32_t index, int32_t width, int
 PGV_API int32_t pgv_timed_steps(pgv_env* env, int32_t steps, uint32_t run_seed, double* total_ms,
                                 double* render_kernel_ms);
 /* render_kernel_ms == NULL: the region holds nothing but the steps between its two events (no per-launch events): the
- * form `value` is measured with.
+ * form `value` is measured with.  render_kernel_ms is the render KERNEL's launches alone: a game's render pre-pass
+ * (setup_kernel, since round 4 a launch of its own in front of the render kernel) is NOT in it — pgv_step_phases
+ * reports that one beside it.
  *
  * Per-step detail for the same kind of run: h_step_ms[s] = time from the start of step s to the start of step s+1 (to
- * the end of the run for the last), h_render_ms[s] = its render launch, both from HIP events on the env's stream (host
- * arrays of `steps` floats, either may be NULL).  For latency percentiles and the roofline window — never for `value`:
- * three events per step sit inside the region. */
+ * the end of the run for the last), h_render_ms[s] = its render launch (again without the pre-pass), both from HIP events
+ * on the env's stream (host arrays of `steps` floats, either may be NULL).  For latency percentiles and the roofline
+ * window — never for `value`: events sit inside the region. */
 PGV_API int32_t pgv_step_times(pgv_env* env, int32_t steps, uint32_t run_seed, float* h_step_ms, float* h_render_ms);
+/* The same run with a step cut into its four phases by events on the env's stream (any pointer may be NULL):
+ *   h_logic_ms    the logic kernels (level install / auto-reset, agent, entities, resolve — whatever the game launches
+ *                 in front of its frame), including the side-stream launch of the level generator;
+ *   h_prepass_ms  the render pre-pass (setup_kernel; 0 for a game or debug mode without one);
+ *   h_render_ms   the render kernel (jumper: + the list kernel that walks the frames the pre-pass handed back);
+ *   h_late_ms     what follows the render launch inside the step (chaser: the join with its reset stream and the late
+ *                 pass over the envs that were reset).
+ * logic + prepass + render + late = step.  bench.py's roofline.render_path is prepass + render + late. */
+PGV_API int32_t pgv_step_phases(pgv_env* env, int32_t steps, uint32_t run_seed, float* h_step_ms, float* h_logic_ms,
+                                float* h_prepass_ms, float* h_render_ms, float* h_late_ms);
+/* … of `count` envs stepping side by side, each on its own stream (the mixed workload: step s of every env is enqueued
+ * before step s+1 of any, as pgv_step_synthetic_many does).  h_ms: host floats [count][5][steps] — per env: step, logic,
+ * prepass, render, late.  The streams overlap on the device, so an env's phases are what ITS stream saw, not a share of
+ * the wall clock. */
+PGV_API int32_t pgv_step_phases_many(pgv_env* const* envs, int32_t count, int32_t steps, uint32_t run_seed, float* h_ms);
 
 /* Debug switches (tests only); none changes a result.  Bit 0: render the background and tile layer by replaying the
  * draw list one blit at a time instead of the fused row composer.  Bit 8: no level prefetch — every reset generates its

@@ -781,13 +781,21 @@ __global__ void __launch_bounds__(64) make_kernel(State s, uint32_t seed_base, i
     fresh_live(s, env);
 }
 
-// A — lane = env: the agent's sub-steps into the scratch table (envs that reset in this step sit it out).
+// A — lane = env: the agent's sub-steps into the scratch table (envs that reset in this step sit it out) — blockIdx.y == 0;
+// blockIdx.y == 1: the auto-reset of those envs whose next level lies ready in its shadow slot (pg_prefetch.h
+// install_prefetched: a copy), beside the agents instead of in a launch in front of them.  An env is looked at by one
+// lane of each row; the rows share nothing but its pending byte, which row 0 only reads and row 1 only ever turns from 1
+// into 2 — "not 0" either way.  resolve_kernel puts the 2 back to 0.
 __global__ void __launch_bounds__(64) agent_kernel(State s, const int32_t* actions, uint32_t run_seed,
-                                                   uint32_t step_index, int env_offset, StepIO io) {
+                                                   uint32_t step_index, int env_offset, StepIO io, int prefetch, LevelPlan plan) {
+    if (blockIdx.y == 1) {  // (block-uniform)
+        __shared__ Level lv;
+        install_prefetched<Gen>(s, blockIdx.x * blockDim.x, blockDim.x, prefetch, io, plan, lv, threadIdx.x);
+        return;
+    }
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= s.n) return;
-    if (io.pending[env] == 2) {  // the caller's `if term: env.reset()` (game_test.py:38-40): done by the level kernel
-        io.pending[env] = 0;
+    if (io.pending[env] != 0) {  // the caller's `if term: env.reset()` (game_test.py:38-40): this step is the env's reset
         SCI(s, SC_BITS, env) = 0;  // did not step: B and C leave this env alone
         return;
     }
@@ -803,6 +811,10 @@ __global__ void __launch_bounds__(64) agent_kernel(State s, const int32_t* actio
 //     that path max-over-the-block times with mostly idle lanes (SQ counters: 78 M wave instructions per launch, the
 //     kernel is issue-bound).  Instead the (env, mob) pairs of the block are numbered densely — a wave prefix sum over
 //     the 64 mob counts — and row y takes pairs [64y, 64y + 64): full waves, about mean-instead-of-max many of them.
+// (Measured and rejected, round 5: a grid of 8 + 12 rows whose waves loop on to their next share of the pairs / entity
+// slots instead of 2 × 36 rows of which nine in ten find nothing to do — 20 480 wavefronts instead of 73 728.  Bit-exact and
+// slower: 45.5 -> 79.0 µs.  The kernel is the length of its longest wave, a wave that exits early costs the dispatcher
+// 0.2 ns, and a second share is a second chain of round trips behind the first.)
 __global__ void __launch_bounds__(64) entity_kernel(State s) {
     const int lane = threadIdx.x;
     int env = blockIdx.x * 64 + lane;
@@ -854,7 +866,10 @@ __global__ void __launch_bounds__(64) resolve_kernel(State s, StepIO io) {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= s.n) return;
     const int bits = SCI(s, SC_BITS, env);
-    if (bits >= 0) return;  // reset this step; agent_kernel already wrote reward/done/pending
+    if (bits >= 0) {  // reset this step (reward / done are written with the install): the flag goes back to "nothing pending"
+        io.pending[env] = 0;
+        return;
+    }
     const int flags = SI(s, I_FLAGS, env);
     const int src = (flags & kFlagBuf) ? 1 : 0;
     const int hazard = SCI(s, SC_HAZARD, env);
@@ -1699,9 +1714,11 @@ class CoinrunGame final : public Game {
     int prefetch() const { return (debug_flags & kDebugNoPrefetch) ? 0 : 1; }
     void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
                       StepIO io) override {
+        // the auto-resets: a prefetched level is installed beside the agents (agent_kernel's second row of blocks); the
+        // level kernel behind it generates, synchronously, the levels that were not ready — none in steady state
+        hipLaunchKernelGGL(agent_kernel, dim3(logic_blocks(s_.n), prefetch() ? 2 : 1), dim3(logic_lanes()), 0, st, s_, actions, run_seed,
+                           step_index, env_offset, io, prefetch(), plan);
         LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io, plan);
-        hipLaunchKernelGGL(agent_kernel, dim3(logic_blocks(s_.n)), dim3(logic_lanes()), 0, st, s_, actions, run_seed, step_index,
-                           env_offset, io);
         hipLaunchKernelGGL(entity_kernel, dim3((s_.n + 63) / 64, 2 * kMaxEnt), dim3(64), 0, st, s_);
         hipLaunchKernelGGL(resolve_kernel, dim3(logic_blocks(s_.n)), dim3(logic_lanes()), 0, st, s_, io);
     }

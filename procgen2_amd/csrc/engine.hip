@@ -227,6 +227,7 @@ struct pgv_env {
     hipStream_t side = nullptr;
     hipEvent_t side_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int side_ev_next = 0, since_pregen = 0;
+    int64_t generator_launches = 0;  // pgv_generator_launches
     // auto-resets beside the logic kernels (pg_engine.h Game::reset_stream)
     hipStream_t reset_stream = nullptr;
     hipEvent_t reset_fork = nullptr, reset_join = nullptr;
@@ -234,22 +235,26 @@ struct pgv_env {
     pg::StepIO io() const { return {d_obs, d_reward, d_done, d_pending}; }
 };
 
-// Queue one generator launch behind everything the main stream holds so far.  In the step loop: whenever the side
-// stream is idle, otherwise every 4th step — one launch serves every slot queued by then, and a launch costs its
-// single-env latency (ms) even for one env, so launching per step would only pile launches up.
+// Queue one generator launch behind everything the main stream holds so far.  In the step loop: every
+// pregen_every()-th step (pg_engine.h: the game says how long a queued slot may wait) — one launch serves every slot
+// queued by then, and a launch costs its single-env latency (ms) even for one env, so launching per step would only pile
+// launches up.  The cadence is a count of steps and nothing else: until round 5 a launch was also made whenever the
+// HOST saw the side stream idle (hipStreamQuery), which a benchmark loop that runs hundreds of steps ahead of the device
+// never does and a caller that synchronises every step always does — two callers, two cadences, and the second one
+// the slower for coinrun, climber and jumper (tests/test_levels.py::test_generator_cadence_…).
 static void pregen(pgv_env* e, bool bulk, bool force) {
     if (!e->side) return;
     e->since_pregen++;
-    // (The query is the HOST's view: with the host hundreds of steps ahead of the device the side stream always has work
-    // queued, so this is "every pregen_every()-th step" in a long run — the game says how long it can wait.)
-    if (!force && e->since_pregen < e->game->pregen_every() && hipStreamQuery(e->side) != hipSuccess) return;
+    if (!force && e->since_pregen < e->game->pregen_every()) return;
     hipEvent_t ev = e->side_ev[e->side_ev_next];
     e->side_ev_next = (e->side_ev_next + 1) % 8;
     if (hipEventRecord(ev, e->stream) != hipSuccess || hipStreamWaitEvent(e->side, ev, 0) != hipSuccess) return;
     if (!e->game->launch_pregen(e->side, bulk)) {
         hipStreamDestroy(e->side);  // this game generates its levels inside the step
         e->side = nullptr;
+        return;
     }
+    e->generator_launches++;
     e->since_pregen = 0;
 }
 
@@ -441,9 +446,13 @@ int32_t pgv_reset(pgv_env* e, const uint8_t* d_mask, const int32_t* d_seeds) {
 }
 
 // One step's launches.  The launch status is read after each group of launches: hipGetLastError reports (and clears)
-// only the most recent error, and pregen's hipStreamQuery legitimately leaves hipErrorNotReady behind.
+// only the most recent error.
+// `after_logic` / `before_render` / `after_render`: optional events (measurement only) — behind the logic kernels (and the
+// level generator's launch on the side stream), behind the render pre-pass = in front of the render kernel, behind the
+// render launch (jumper: its list kernel included).  What follows after_render inside a step is the late pass of a game
+// that resets beside its render kernel (chaser).
 static int32_t step_impl(pgv_env* e, const int32_t* d_actions, uint32_t run_seed, hipEvent_t before_render = nullptr,
-                         hipEvent_t after_render = nullptr) {
+                         hipEvent_t after_render = nullptr, hipEvent_t after_logic = nullptr) {
     // hipGetLastError is sticky and per thread: whatever the embedding application left behind (a stream query's
     // NotReady, say) is not this step's; start clean.
     (void)hipGetLastError();
@@ -460,7 +469,8 @@ static int32_t step_impl(pgv_env* e, const int32_t* d_actions, uint32_t run_seed
     e->game->launch_logic(e->stream, d_actions, run_seed, e->step_index, e->env_offset, e->io());
     launched();
     pregen(e, false, false);  // before the render launch: the generator overlaps it
-    (void)hipGetLastError();  // hipErrorNotReady of the stream query is not an error
+    launched();
+    if (after_logic && status == hipSuccess) status = hipEventRecord(after_logic, e->stream);
     if (status == hipSuccess) {
         e->game->launch_prepass(e->stream, nullptr);
         launched();
@@ -553,6 +563,8 @@ int32_t pgv_decode_png(const char* path, int32_t* w, int32_t* h, uint8_t* h_rgba
     }
     return 0;
 }
+
+int64_t pgv_generator_launches(pgv_env* e) { return e ? e->generator_launches : -1; }
 
 int32_t pgv_sync(pgv_env* e) {
     if (!e) return fail("pgv_sync: env is NULL");
@@ -691,6 +703,43 @@ struct StepEvents {
 };
 }  // namespace
 
+namespace pg {
+// `steps` synthetic steps of `count` envs side by side (step s of every env enqueued before step s + 1 of any, each on
+// its own stream, as pgv_step_synthetic_many), every step cut into its phases by events on the env's stream.
+// out[5 * k + j]: `steps` floats of env k — j = 0 the whole step, 1 logic, 2 pre-pass, 3 render, 4 late — or NULL.
+static int32_t step_phases_many(pgv_env* const* envs, int count, int steps, uint32_t run_seed, float* const* out) {
+    if (steps < 1 || steps > (1 << 20)) return fail("pgv_step_phases: steps must be in 1..1048576");
+    std::vector<StepEvents> ev(static_cast<size_t>(count));  // per step: start, after logic, before render, after render; one more at the end
+    for (int k = 0; k < count; k++) {
+        PG_HIP(hipSetDevice(envs[k]->device));
+        ev[k].v.assign(size_t(steps) * 4 + 1, nullptr);
+        for (auto& p : ev[k].v) PG_HIP(hipEventCreate(&p));
+    }
+    for (int s = 0; s < steps; s++)
+        for (int k = 0; k < count; k++) {
+            pgv_env* e = envs[k];
+            PG_HIP(hipSetDevice(e->device));
+            PG_HIP(hipEventRecord(ev[k].v[4 * s], e->stream));
+            if (step_impl(e, nullptr, run_seed, ev[k].v[4 * s + 2], ev[k].v[4 * s + 3], ev[k].v[4 * s + 1])) return 1;
+        }
+    for (int k = 0; k < count; k++) {
+        PG_HIP(hipSetDevice(envs[k]->device));
+        PG_HIP(hipEventRecord(ev[k].v[size_t(steps) * 4], envs[k]->stream));
+    }
+    static const int kFrom[5] = {0, 0, 1, 2, 3}, kTo[5] = {4, 1, 2, 3, 4};
+    for (int k = 0; k < count; k++) {
+        PG_HIP(hipSetDevice(envs[k]->device));
+        PG_HIP(hipEventSynchronize(ev[k].v[size_t(steps) * 4]));
+        for (int j = 0; j < 5; j++) {
+            float* to = out[5 * k + j];
+            if (!to) continue;
+            for (int s = 0; s < steps; s++) PG_HIP(hipEventElapsedTime(&to[s], ev[k].v[4 * s + kFrom[j]], ev[k].v[4 * s + kTo[j]]));
+        }
+    }
+    return 0;
+}
+}  // namespace pg
+
 int32_t pgv_timed_steps(pgv_env* e, int32_t steps, uint32_t run_seed, double* total_ms, double* render_kernel_ms) {
     if (!e) return fail("pgv_timed_steps: env is NULL");
     if (steps < 1 || steps > (1 << 20)) return fail("pgv_timed_steps: steps must be in 1..1048576");
@@ -724,30 +773,23 @@ int32_t pgv_timed_steps(pgv_env* e, int32_t steps, uint32_t run_seed, double* to
 }
 
 int32_t pgv_step_times(pgv_env* e, int32_t steps, uint32_t run_seed, float* h_step_ms, float* h_render_ms) {
-    if (!e) return fail("pgv_step_times: env is NULL");
-    if (steps < 1 || steps > (1 << 20)) return fail("pgv_step_times: steps must be in 1..1048576");
-    PG_HIP(hipSetDevice(e->device));
-    StepEvents ev;  // per step: start, before render, after render; one more at the very end
-    ev.v.assign(size_t(steps) * 3 + 1, nullptr);
-    for (auto& p : ev.v) PG_HIP(hipEventCreate(&p));
-    for (int s = 0; s < steps; s++) {
-        PG_HIP(hipEventRecord(ev.v[3 * s], e->stream));
-        if (step_impl(e, nullptr, run_seed, ev.v[3 * s + 1], ev.v[3 * s + 2])) return 1;
-    }
-    PG_HIP(hipEventRecord(ev.v[size_t(steps) * 3], e->stream));
-    PG_HIP(hipEventSynchronize(ev.v[size_t(steps) * 3]));
-    for (int s = 0; s < steps; s++) {
-        float t = 0.0f;
-        if (h_step_ms) {
-            PG_HIP(hipEventElapsedTime(&t, ev.v[3 * s], ev.v[3 * s + 3]));
-            h_step_ms[s] = t;
-        }
-        if (h_render_ms) {
-            PG_HIP(hipEventElapsedTime(&t, ev.v[3 * s + 1], ev.v[3 * s + 2]));
-            h_render_ms[s] = t;
-        }
-    }
-    return 0;
+    return pgv_step_phases(e, steps, run_seed, h_step_ms, nullptr, nullptr, h_render_ms, nullptr);
+}
+
+int32_t pgv_step_phases(pgv_env* e, int32_t steps, uint32_t run_seed, float* h_step_ms, float* h_logic_ms, float* h_prepass_ms,
+                        float* h_render_ms, float* h_late_ms) {
+    if (!e) return fail("pgv_step_phases: env is NULL");
+    float* out[5] = {h_step_ms, h_logic_ms, h_prepass_ms, h_render_ms, h_late_ms};
+    return pg::step_phases_many(&e, 1, steps, run_seed, out);
+}
+
+int32_t pgv_step_phases_many(pgv_env* const* envs, int32_t count, int32_t steps, uint32_t run_seed, float* h_ms) {
+    if (!envs || count < 1 || !h_ms) return fail("pgv_step_phases_many: bad arguments");
+    for (int32_t k = 0; k < count; k++)
+        if (!envs[k]) return fail("pgv_step_phases_many: env is NULL");
+    std::vector<float*> out(size_t(count) * 5);
+    for (size_t k = 0; k < out.size(); k++) out[k] = h_ms + k * size_t(steps > 0 ? steps : 0);
+    return pg::step_phases_many(envs, count, steps, run_seed, out.data());
 }
 
 int32_t pgv_render_frame(pgv_env* e, int32_t index, int32_t width, int32_t height, uint8_t* h_rgb) {

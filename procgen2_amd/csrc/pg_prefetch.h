@@ -192,6 +192,50 @@ __global__ void __launch_bounds__(64) level_kernel(typename G::State s, int mode
     }
 }
 
+// The copy-only part of an auto-reset (mode 2 above, slot kSlotReady) as a device function, for a game that runs it
+// INSIDE the grid of its first logic kernel instead of as a launch in front of it (round 5, coinrun: blockIdx.y == 1 of
+// agent_kernel).  An env that resets does not step, so its install and the other envs' agents have nothing to wait for
+// in each other; as a launch of its own the install was 26 µs of latency chain — pending byte, slot word, shadow level,
+// flags, the stores, a fence — in front of every step, for the sixty-odd envs of 65 536 that reset in it.  What is left
+// to the level kernel, launched behind (mode 2, unchanged): the envs whose slot is NOT ready (an episode shorter than the
+// generator's latency) — they keep pending == 1 and are generated synchronously there, as before; in steady state that
+// launch finds nothing (one load per lane).  The generator's 256 registers stay out of the logic kernel this way
+// (the fused kernel WITH the generator ran at one wave per SIMD and took the sum of the two chains).
+// One wavefront (blockDim ≤ 64); `lv` is a Level in LDS.  Served envs are left at pending == 2 like mode 2 leaves them.
+template <class G>
+PG_D void install_prefetched(const typename G::State& s, int base, int span, int prefetch, StepIO io, LevelPlan plan,
+                             typename G::Level& lv, int lane) {
+    using Level = typename G::Level;
+    constexpr int kWords = static_cast<int>(sizeof(Level) / 4);
+    const bool want = lane < span && base + lane < s.n && io.pending[base + lane] == 1;
+    unsigned long long todo = __ballot(want);
+    const bool levels = plan.num_levels > 0;
+    while (todo) {  // wave-uniform
+        const int env = base + __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int32_t st = __builtin_amdgcn_readfirstlane(slot_load(&s.slot[env]));  // acquire, agent scope
+        if (st != kSlotReady) continue;  // queued, busy or idle: the level kernel behind this launch takes it
+        __threadfence();
+        const uint32_t* shadow = reinterpret_cast<const uint32_t*>(&s.shadow[env]);
+        uint32_t* local = reinterpret_cast<uint32_t*>(&lv);
+        for (int k = lane; k < kWords; k += 64) local[k] = shadow[k];
+        __syncthreads();
+        if (levels && lane == 0) G::fresh_live(s, env);
+        __syncthreads();
+        G::install(s, env, lv, lane);
+        __threadfence();
+        __syncthreads();
+        if (lane == 0) {
+            slot_store(&s.slot[env], prefetch ? kSlotQueued : kSlotIdle);
+            io.reward[env] = 0.0f;
+            io.done[env] = 0;
+            io.pending[env] = 2;
+            if constexpr (HasServed<G>::value) G::served(s, env);
+        }
+        __syncthreads();
+    }
+}
+
 // Host side of the same: the four launches a prefetching game needs.
 template <class G>
 struct LevelLaunch {

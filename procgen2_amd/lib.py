@@ -94,6 +94,7 @@ def load(path=None):
         "pgv_reset_host": (c_int32, [P, P, P]),
         "pgv_decode_png": (c_int32, [c_char_p, POINTER(c_int32), POINTER(c_int32), P, ctypes.c_int64]),
         "pgv_sync": (c_int32, [P]),
+        "pgv_generator_launches": (c_int64, [P]),
         "pgv_obs": (P, [P]),
         "pgv_reward": (P, [P]),
         "pgv_done": (P, [P]),
@@ -109,6 +110,8 @@ def load(path=None):
         "pgv_step_synthetic_many": (c_int32, [P, c_int32, c_int32, c_uint32]),
         "pgv_timed_steps": (c_int32, [P, c_int32, c_uint32, POINTER(c_double), POINTER(c_double)]),
         "pgv_step_times": (c_int32, [P, c_int32, c_uint32, c_void_p, c_void_p]),
+        "pgv_step_phases": (c_int32, [P, c_int32, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+        "pgv_step_phases_many": (c_int32, [P, c_int32, c_int32, c_uint32, c_void_p]),
         "pgv_set_debug": (c_int32, [P, c_int32]),
         "pgv_dump_state": (c_int32, [P, c_int32, POINTER(c_float), c_int32]),
         "pgv_dump_tiles": (c_int32, [P, c_int32, POINTER(c_uint8), c_int32]),
@@ -130,8 +133,8 @@ def check(lib, rc, what):
 
 EXPORTED_VEC_SYMBOLS = [
     "pgv_game_name", "pgv_game_id", "pgv_make", "pgv_make_levels", "pgv_make_config", "pgv_game_modes", "pgv_mode", "pgv_close", "pgv_reset", "pgv_step", "pgv_step_synthetic", "pgv_step_synthetic_many",
-    "pgv_synthetic_action", "pgv_step_host", "pgv_reset_host", "pgv_decode_png", "pgv_sync", "pgv_obs", "pgv_reward", "pgv_done", "pgv_bind_outputs", "pgv_num_envs",
-    "pgv_device", "pgv_stream", "pgv_copy_out", "pgv_render_frame", "pgv_snapshot_bytes", "pgv_save_state", "pgv_load_state", "pgv_timed_steps", "pgv_step_times", "pgv_set_debug", "pgv_dump_state", "pgv_dump_tiles",
+    "pgv_synthetic_action", "pgv_step_host", "pgv_reset_host", "pgv_decode_png", "pgv_sync", "pgv_generator_launches", "pgv_obs", "pgv_reward", "pgv_done", "pgv_bind_outputs", "pgv_num_envs",
+    "pgv_device", "pgv_stream", "pgv_copy_out", "pgv_render_frame", "pgv_snapshot_bytes", "pgv_save_state", "pgv_load_state", "pgv_timed_steps", "pgv_step_times", "pgv_step_phases", "pgv_step_phases_many", "pgv_set_debug", "pgv_dump_state", "pgv_dump_tiles",
     "pgv_last_error",
 ]
 EXPORTED_CENV_SYMBOLS = [

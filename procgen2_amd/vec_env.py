@@ -137,6 +137,17 @@ class ProcgenVecEnv:
                                                   c_void_p(render_ms.ctypes.data)), "pgv_step_times")
         return step_ms, render_ms
 
+    def step_phases(self, steps, run_seed=0):
+        """`steps` synthetic steps cut into their phases by HIP events on the engine's stream (include/procgen2_vec.h
+        pgv_step_phases): a dict of numpy float32 arrays step / logic / prepass / render / late, milliseconds per step;
+        logic + prepass + render + late = step."""
+        import numpy as np
+        names = ("step", "logic", "prepass", "render", "late")
+        out = {k: np.zeros(steps, np.float32) for k in names}
+        pglib.check(self.L, self.L.pgv_step_phases(self._h, steps, run_seed, *(c_void_p(out[k].ctypes.data) for k in names)),
+                    "pgv_step_phases")
+        return out
+
     def render_frame(self, index=0, width=512, height=512):
         """The human-size frame of env `index` (cenv_render, render_game(false)): uint8 [height, width, 3] on the host."""
         import numpy as np
@@ -206,6 +217,18 @@ def step_many_synthetic(envs, steps, run_seed=0):
     handles = (c_void_p * len(envs))(*[e._h for e in envs])
     pglib.check(envs[0].L, envs[0].L.pgv_step_synthetic_many(handles, len(envs), int(steps), int(run_seed)),
                 "pgv_step_synthetic_many")
+
+
+def step_phases_many(envs, steps, run_seed=0):
+    """`steps` synthetic steps of several ProcgenVecEnv side by side (as step_many_synthetic), every step of every env cut
+    into its phases by HIP events on that env's stream (pgv_step_phases_many): numpy float32 [len(envs), 5, steps] —
+    step, logic, prepass, render, late, milliseconds."""
+    import numpy as np
+    out = np.zeros((len(envs), 5, int(steps)), np.float32)
+    handles = (c_void_p * len(envs))(*[e._h for e in envs])
+    pglib.check(envs[0].L, envs[0].L.pgv_step_phases_many(handles, len(envs), int(steps), int(run_seed), c_void_p(out.ctypes.data)),
+                "pgv_step_phases_many")
+    return out
 
 
 class RootGather:

@@ -190,3 +190,28 @@ def test_engine_snapshot_carries_the_level_sequence():
         other.load_state(snap)
     other.close()
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("game,every", [("coinrun", 4), ("maze", 2)])
+def test_generator_cadence_does_not_depend_on_how_the_caller_synchronises(game, every):
+    """the level generator is launched every Game::pregen_every()-th step — a count of steps, not
+    the host's view of the side stream.  A caller that drains the stream after every step (any policy loop) and one that
+    enqueues all its steps ahead (bench.py) get the same number of generator launches, and the same frames."""
+    from engine_util import EngineVec
+    from procgen2_amd import lib as pglib
+    steps, n = 64, 256
+    counts, frames = [], []
+    for drain in (True, False):
+        e = EngineVec(game, n, seed_base=5)
+        e.reset()
+        before = e.L.pgv_generator_launches(e.h)
+        for s in range(steps):
+            e.step_quiet(run_seed=9)
+            if drain:
+                pglib.check(e.L, e.L.pgv_sync(e.h), "pgv_sync")
+        counts.append(e.L.pgv_generator_launches(e.h) - before)
+        frames.append(e._fetch()[0].copy())
+        e.close()
+    assert counts[0] == counts[1] == steps // every, counts
+    assert np.array_equal(frames[0], frames[1])
