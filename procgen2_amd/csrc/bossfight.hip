@@ -41,6 +41,12 @@ constexpr float kBossBulletSpeed = 0.05f, kShieldedSpread = 30.0f;
 #endif
 
 constexpr int kAgentShots = 32, kBossShots = 64, kBooms = 8, kRocks = 4;
+// What the render pre-pass's tables hold (setup_kernel → render_kernel, no complete-path fallback in the lean kernel): the
+// second list — the boss, its shield, explosions, barriers, the agent's bullets, the agent — as draws of rank < kPrepDraws
+// (prep_draws_flush drops any beyond), and the boss's bullets one per lane of a wavefront with their count in a byte of
+// the meta word.  True of these constants; a change to them has to give the lean kernel a fallback first.
+static_assert(2 + kBooms + kRocks + kAgentShots + 1 <= 64 /* pg_prepass.h kPrepDraws */ && kBossShots <= 64,
+              "bossfight's lean render kernel has no path for draws beyond its tables");
 constexpr double kPi = 3.14159265358979323846;  // M_PI
 
 enum Tex {

@@ -1242,11 +1242,18 @@ struct SetupLds {
     PrepDrawQueue queue[kPrepThreads / 64];  // one worklist per wavefront
 };
 
+// (Measured and rejected, round 5: the pre-pass in two halves — views / cells / spans / axes, which need the step only
+// through the camera, i.e. through the agent, as further workgroups of the ENTITY launch (camera taken optimistically from
+// the agent's scratch row of sub-step 3), the draws in a kernel behind resolve_kernel as now.  Bit-exact in the 24 coinrun
+// tests, and slower: the fused launch 146 µs, the draws' kernel 57, against 46 + 93 one after the other.  A kernel has one
+// register allocation: with the entity path's 132 registers three wavefronts fit a SIMD, the mobs' 3 600 long chains take
+// every one of those slots for their whole 40 µs, and the pre-pass workgroups, dealt behind them, start when they end; and
+// the draws alone are a chain of round trips that the other phases of the same kernel used to hide.)
 __global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView atlas, const uint8_t* mask, int flags) {
     __shared__ SetupLds S;
     PrepLds<kGrid, kPrepEnvs, kMaxSpan>& P = S.P;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int env0 = blockIdx.x * kPrepEnvs;
+    const int env0 = prep_block(blockIdx.x, gridDim.x) * kPrepEnvs;
     const PrepOut& out = s.prep;
 
     // ---- everything whose address does not depend on another load is requested first: the descriptor table, the envs'
@@ -1299,7 +1306,10 @@ __global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView 
         }
         if (active) {
             v.cam = cam;
-            const int4 d = S.desc[kTexBackdrop + (themes & 0xff)];
+            // (bit 4: timing experiment of the -DPG_ABLATE build — every env shows backdrop 9, the bound on what keeping
+            // the backdrops' texels closer to the workgroups that sample them could buy: render FETCH_SIZE 309 -> 45 MB,
+            // render 0.350 -> 0.333 ms)
+            const int4 d = S.desc[kTexBackdrop + (PG_ABL(flags, 16) ? 9 : (themes & 0xff))];
             const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
             const float extra = aspect - 1.0f;
             v.bg = BgDraw{d, -bgshift * extra, 0.0f, 64.0f * kUnitPx / d.z};  // coinrun.cpp:459-464

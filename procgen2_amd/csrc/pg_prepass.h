@@ -104,6 +104,34 @@ struct PrepLds {
     uint32_t meta[E][kPrepMetaWords];
 };
 
+// The pre-pass's results are PLAIN stores.  (Measured and rejected, round 5: as streaming `nt` stores — the thought was
+// that the 145 MB a launch leaves dirty in the L2s are written back at the kernel's end, in front of the render launch,
+// which rocprofv3 shows 19 µs longer behind a pre-pass than behind none — coinrun's render kernel went from 0.333 to
+// 0.398 ms, climber's 0.334 -> 0.395: what the render workgroups read a few microseconds later then comes from HBM
+// instead of the Infinity Cache the write-back leaves it in.  -DPG_PREP_NT_STORES keeps the experiment.)
+#ifdef PG_PREP_NT_STORES
+#define PG_PREP_STORE(value, ptr) __builtin_nontemporal_store((value), (ptr))
+#else
+#define PG_PREP_STORE(value, ptr) (*(ptr) = (value))
+#endif
+typedef uint32_t prep_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t prep_u32x2 __attribute__((ext_vector_type(2)));
+
+// Which group of envs a workgroup of the pre-pass takes.  The hardware deals workgroups to the eight XCDs in turn
+// (workgroup b → XCD b mod 8, each with an L2 of its own), and the pre-pass reads struct-of-arrays state — a group's eight
+// envs are 32 bytes of a 128-byte line of every float field, 8 bytes of every byte field — so with group = b the
+// workgroups that share a line sit on different XCDs and every one of those L2s fetches the whole line.  Dealt this way the
+// groups of ONE XCD are consecutive: the line is fetched once.  (Any mapping gives the same frames; n_groups not a
+// multiple of 8: the tail keeps its place.)
+PG_D int prep_block(int b, int n_groups) {
+#ifdef PG_NO_XCD_MAP  // (A/B only)
+    return b;
+#else
+    const int per = n_groups >> 3, body = per << 3;
+    return b < body ? (b & 7) * per + (b >> 3) : b;
+#endif
+}
+
 PG_D uint32_t pack_halves(int lo, int hi) { return (static_cast<uint32_t>(lo) & 0xffffu) | (static_cast<uint32_t>(hi) << 16); }
 
 // Phase A — the spans of the tile grid and of the background.
@@ -270,7 +298,7 @@ PG_D void prep_axes(PrepLds<GRID, E, MAXSPAN>& P, const PrepOut& out, int env0, 
         const int tb = ib >= 0 ? P.texel[wb >> 24][lane - db] : 0;
         const uint32_t word = static_cast<uint32_t>(ta) | (static_cast<uint32_t>(tb) << 8) |
                               (static_cast<uint32_t>(ia >= 0 ? ia : 0) << 16) | (ia >= 0 ? 1u << 24 : 0u) | (ib >= 0 ? 1u << 25 : 0u);
-        out.axes[size_t(env0 + e) * 128 + axis * 64 + lane] = word;
+        PG_PREP_STORE(word, &out.axes[size_t(env0 + e) * 128 + axis * 64 + lane]);
         if (axis == 1) {
             if (v.th2 > 0) {  // texel rows in the layer's second, shorter texture: nested in the first's span, or the complete path
                 uint32_t w2 = 0;
@@ -286,7 +314,7 @@ PG_D void prep_axes(PrepLds<GRID, E, MAXSPAN>& P, const PrepOut& out, int env0, 
                     ok = ok && !(n2 > 0 && !span_nested(d2, n2, db, static_cast<int>((wb >> 16) & 0xffu), kObsH));
                     if (n2 > 0 && i >= 0 && i < n2) w2 |= (static_cast<uint32_t>(P.texel[s2 >> 24][i]) << 8) | (1u << 25);
                 }
-                out.axes2[size_t(env0 + e) * 64 + lane] = w2;
+                PG_PREP_STORE(w2, &out.axes2[size_t(env0 + e) * 64 + lane]);
             }
             const uint32_t soft_bits = P.soft_rows[e], hard_bits = P.hard_rows[e];
             const bool soft_here = (soft_bits >> 31) != 0 || (ia >= 0 && ((soft_bits >> (ia & 31)) & 1u)) ||
@@ -348,10 +376,12 @@ template <int GRID>
 PG_D void prep_column_store(uint8_t* cells_env, int c, const uint32_t (&kinds)[GRID / 4]) {
     uint32_t* at = reinterpret_cast<uint32_t*>(cells_env + c * GRID);
     if constexpr (GRID == 16) {
-        *reinterpret_cast<uint4*>(at) = make_uint4(kinds[0], kinds[1], kinds[2], kinds[3]);
+        prep_u32x4 v;
+        v.x = kinds[0], v.y = kinds[1], v.z = kinds[2], v.w = kinds[3];
+        PG_PREP_STORE(v, reinterpret_cast<prep_u32x4*>(at));
     } else {
 #pragma unroll
-        for (int w = 0; w < GRID / 4; w++) at[w] = kinds[w];
+        for (int w = 0; w < GRID / 4; w++) PG_PREP_STORE(kinds[w], &at[w]);
     }
 }
 
@@ -365,7 +395,9 @@ PG_D void prep_meta_out(PrepLds<GRID, E, MAXSPAN>& P, const PrepOut& out, int en
     for (int q = tid; q < E * kPrepMetaWords; q += nthreads) {
         const int e = q / kPrepMetaWords, w = q - e * kPrepMetaWords;
         if (!P.view[e].active && !P.fat[e]) continue;  // (an env the kernel sits out writes nothing; a fat one its flag)
-        uint32_t word = P.meta[e][w];
+        // An env flagged fat before its view was built never had P.meta written: its line is zeros but for the words set
+        // below (the render workgroup runs its lean preamble on the line before it asks whether the frame is fat).
+        uint32_t word = P.view[e].active ? P.meta[e][w] : 0u;
         if (w == PM_FLAGS) {
             const int c = counts[e];
             const bool fat = P.fat[e] != 0 || c > kPrepDraws;
@@ -386,7 +418,7 @@ PG_D void prep_meta_out(PrepLds<GRID, E, MAXSPAN>& P, const PrepOut& out, int en
         }
         if (w == PM_BGTEX) word = static_cast<uint32_t>(P.view[e].bg.desc.x);
         if (w == PM_WIDTHS) word = pack_halves(P.view[e].bg.desc.y, P.view[e].tw);
-        out.meta[size_t(env0 + e) * kPrepMetaWords + w] = word;
+        PG_PREP_STORE(word, &out.meta[size_t(env0 + e) * kPrepMetaWords + w]);
     }
 }
 
@@ -576,10 +608,12 @@ PG_D void prep_cells_expand(ComposeLds<GRID>& L, uint32_t two16, uint32_t kind_o
 // A resolved draw as the pre-pass stores it: pg_render.h BlitWords, kBlitWords per draw, draws of an env back to back.
 PG_D void prep_draw_store(uint32_t* at, const Blit& b) {
     const BlitWords p = blit_pack(b);
-    uint2* q = reinterpret_cast<uint2*>(at);  // (24-byte records: 8-byte aligned)
-    q[0] = make_uint2(p.w[0], p.w[1]);
-    q[1] = make_uint2(p.w[2], p.w[3]);
-    q[2] = make_uint2(p.w[4], p.w[5]);
+    prep_u32x2* q = reinterpret_cast<prep_u32x2*>(at);  // (24-byte records: 8-byte aligned)
+    prep_u32x2 w01, w23, w45;
+    w01.x = p.w[0], w01.y = p.w[1], w23.x = p.w[2], w23.y = p.w[3], w45.x = p.w[4], w45.y = p.w[5];
+    PG_PREP_STORE(w01, &q[0]);
+    PG_PREP_STORE(w23, &q[1]);
+    PG_PREP_STORE(w45, &q[2]);
 }
 PG_D Blit prep_draw_load(const uint32_t* at, bool has) {
     uint2 a = make_uint2(0, 0), b = make_uint2(0, 0), c = make_uint2(0, 0);

@@ -1495,6 +1495,17 @@ PG_D bool compose_rows_from(uint32_t* fb, const ComposeLds<GRID>& L, const Atlas
                 at &= kOffsetBits;
                 asm volatile("" : "+v"(at));  // keeps the branch a branch
             }
+            if (PG_ABL(ablate, 32768)) {
+                // Timing experiment (what a tile mini-atlas in LDS could buy AT MOST): the row's
+                // texels come out of LDS — one ds_read_b32 at an address that scatters like a mini-atlas's would, one
+                // ds_write_b32 — instead of through the gather; wrong pixels (opaque, so no row takes the general form), the
+                // cost structure of a row served entirely by LDS.  Bit 16 on top: every second row only (a frame
+                // half tiles, half backdrop).
+                if (!PG_ABL(ablate, 65536) || (k & 1)) {
+                    fb[py * kObsW + lane] = 0xff000000u | static_cast<uint32_t>(L.base[(at >> 2) % (GRID * GRID)]);
+                    continue;
+                }
+            }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(atlas_rsrc, (lds_ptr)(fb + py * kObsW), 4, static_cast<int>(at), 0, 0, 0);
         }
     }

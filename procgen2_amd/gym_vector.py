@@ -140,7 +140,6 @@ class GymVectorAdapter(_VectorBase):
          self.action_space) = make_spaces(self.num_envs)
         self.render_mode = render_mode
         self.closed = False
-        self._final_buf = None  # SAME_STEP, torch output: the env-indexed terminal frames (see step)
         self.metadata = dict(self.metadata, autoreset_mode=autoreset_mode)
         if _gym is not None:
             try:
@@ -198,8 +197,8 @@ class GymVectorAdapter(_VectorBase):
             #   info["_final_obs"]  bool [num_envs]: which envs ended;
             #   info["final_obs"]   numpy output: object array [num_envs], the env's terminal frame or None;
             #                       torch output: uint8 [num_envs, 64, 64, 3] on the device, valid where _final_obs is
-            #                       true (one persistent buffer: only the k ended rows are copied each step; the other
-            #                       rows hold whatever an earlier episode left there).
+            #                       true, zero elsewhere — a FRESH tensor every step (Gymnasium hands out fresh data: an
+            #                       info kept from step t is not touched by step t + 1, so a replay buffer may keep it).
             # Beside them, for callers that want the batch of terminal frames without the holes:
             #   info["final_obs_compact"] [k, 64, 64, 3] in env order, info["final_obs_env"] [k] their indices.
             if hasattr(terminated, "nonzero") and not isinstance(terminated, np.ndarray):  # torch
@@ -216,10 +215,8 @@ class GymVectorAdapter(_VectorBase):
                 for k, e in enumerate(where_np):
                     by_env[int(e)] = final_np[k]
             else:
-                if self._final_buf is None or self._final_buf.shape != obs.shape:
-                    self._final_buf = obs.new_zeros(obs.shape) if hasattr(obs, "new_zeros") else np.zeros_like(obs)
-                self._final_buf[where] = final
-                by_env = self._final_buf
+                by_env = obs.new_zeros(obs.shape) if hasattr(obs, "new_zeros") else np.zeros_like(obs)
+                by_env[where] = final
             obs = self.engine.reset(mask=mask, seeds=None)  # (clears reward and done of those envs in the engine)
             reward, terminated = rew, mask
             info = {"final_obs": by_env, "_final_obs": self._out(mask, bool), "final_obs_compact": self._out(final),

@@ -60,7 +60,7 @@ class EngineError(RuntimeError):
 
 def load(path=None):
     """Load libprocgen2_hip.so (building is `python -m procgen2_amd.build` / __graft_entry__.build())."""
-    path = os.path.abspath(path or DEFAULT_LIB)
+    path = os.path.abspath(path or os.environ.get("PROCGEN2_HIP_LIB") or DEFAULT_LIB)  # (the variable: experiment builds, tools/build_exp.py)
     if path in _cached:
         return _cached[path]
     if not os.path.exists(path):

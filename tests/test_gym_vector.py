@@ -174,6 +174,7 @@ def test_same_step_autoreset_on_the_hip_engine_matches_the_oracle_engine():
     assert np.array_equal(gpu.reset(seed=5)[0].cpu().numpy(), cpu.reset(seed=5)[0])
     rng = np.random.default_rng(9)
     ends = 0
+    kept = []  # (the info's tensor as handed out, a copy of what it held then): ownership passes to the caller
     for s in range(300):
         a = rng.integers(0, NUM_ACTIONS, n)
         og, rg, tg, _, ig = gpu.step(torch.as_tensor(a, dtype=torch.int32, device="cuda"))
@@ -182,6 +183,9 @@ def test_same_step_autoreset_on_the_hip_engine_matches_the_oracle_engine():
         assert np.array_equal(rg.cpu().numpy(), rc) and np.array_equal(tg.cpu().numpy(), tc)
         assert set(ig) == set(ic)
         if ic:
+            kept.append((ig["final_obs"], ig["final_obs"].cpu().numpy().copy(), ic["_final_obs"].copy()))
+            # rows of envs that did not end this step are zero, not an older episode's frame
+            assert not ig["final_obs"][torch.as_tensor(~ic["_final_obs"], device="cuda")].any()
             assert np.array_equal(ig["final_obs_compact"].cpu().numpy(), ic["final_obs_compact"])
             assert np.array_equal(ig["final_obs_env"].cpu().numpy(), ic["final_obs_env"])
             # indexed by env id, as code written against Gymnasium reads it: infos["final_obs"][i] where infos["_final_obs"][i]
@@ -191,6 +195,11 @@ def test_same_step_autoreset_on_the_hip_engine_matches_the_oracle_engine():
                 assert np.array_equal(ig["final_obs"][e].cpu().numpy(), ic["final_obs"][e]), (s, e)
             ends += len(ic["final_obs_env"])
     assert ends > 10
+    # an info kept from step t still holds step t's terminal frames after all the later steps (r04 advisor finding: one
+    # persistent buffer was handed out again and again)
+    assert len(kept) > 5
+    for tensor, then, _ in kept:
+        assert np.array_equal(tensor.cpu().numpy(), then)
     gpu.close()
     cpu.close()
 

@@ -11,8 +11,7 @@ GAME = sys.argv[1] if len(sys.argv) > 1 else "coinrun"
 K = 1 << 22
 for flags, name in ((0, "pre-pass + render"), (1 << 21, "complete path (no pre-pass)"), (K, "render alone"), (K | 2, "  no sprites"),
                     (K | 128, "  no row loop"), (K | 8, "  no store"), (K | 8192, "  never general"),
-                    (K | 32, "  no backdrop texels (loads dropped)"), (K | 64, "  no tile texels"), (K | 32 | 64, "  no row-loop texels"),
-                    (K | 32 | 64 | 8, "  no row-loop texels, no store"), (K | 2 | 128, "  no rows/sprites"),
+                    (K | 32768, "  every row's texels from LDS (mini-atlas bound)"), (K | 32768 | 65536, "  every second row's texels from LDS"), (K | 2 | 128, "  no rows/sprites"),
                     (K | 2 | 128 | 8, "  preamble only"), (K | 2 | 4 | 8, "  nothing")):
     e = EngineVec(GAME, 65536, seed_base=1, lib_path=LIB)
     e.reset()
