@@ -347,6 +347,23 @@ def main():
         dist.destroy_process_group()
 
 
+def gathered_steps(envs, gather, steps, run_seed):
+    """The step loop of the gathered mixed workload: every engine steps on its own stream, then ONE rooted gather of the
+    rank's three slabs — publish() orders the gather behind the engines' streams, consume() orders the engines' next step
+    behind the gather, so a slab is neither sent before it is written nor overwritten while it is being sent.  No host
+    synchronisation inside the loop.  (tests/test_distributed_cpu.py drives exactly this function over gloo.)"""
+    for _ in range(steps):
+        for e in envs:
+            e.step_synthetic(run_seed, ordered=False)
+        for e in envs:
+            e.publish()   # torch's current stream waits for the engines' streams: no host synchronisation
+        gather()          # one batch of point-to-point transfers: obs, reward, done slabs
+        for e in envs:
+            e.consume()   # … and the next step does not overwrite the slab while it is being sent
+    for e in envs:
+        e.sync()
+
+
 def mixed(a, torch, ProcgenVecEnv, distributed, world, rank, local_rank, n_gpus, run_seed):
     """BASELINE.json configs[4]: the seven games side by side on every GPU.  Each game is its own vector env on its own
     HIP stream (they overlap on the device); the envs of a game are sharded over the ranks by global index like the
@@ -385,17 +402,7 @@ def mixed(a, torch, ProcgenVecEnv, distributed, world, rank, local_rank, n_gpus,
             for e in envs:
                 e.sync()
             return
-        for _ in range(steps):
-            for e in envs:
-                e.step_synthetic(run_seed, ordered=False)
-            if gather is not None:
-                for e in envs:
-                    e.publish()   # torch's current stream waits for the engines' streams: no host synchronisation
-                gather()          # one batch of point-to-point transfers: obs, reward, done slabs
-                for e in envs:
-                    e.consume()   # … and the next step does not overwrite the slab while it is being sent
-        for e in envs:
-            e.sync()
+        gathered_steps(envs, gather, steps, run_seed)
 
     def fence():
         torch.cuda.synchronize()

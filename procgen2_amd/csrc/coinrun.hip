@@ -1726,9 +1726,11 @@ class CoinrunGame final : public Game {
                       StepIO io) override {
         // the auto-resets: a prefetched level is installed beside the agents (agent_kernel's second row of blocks); the
         // level kernel behind it generates, synchronously, the levels that were not ready — none in steady state
-        hipLaunchKernelGGL(agent_kernel, dim3(logic_blocks(s_.n), prefetch() ? 2 : 1), dim3(logic_lanes()), 0, st, s_, actions, run_seed,
+        const bool fused = prefetch() && install_in_logic();
+        if (!fused) LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io, plan);
+        hipLaunchKernelGGL(agent_kernel, dim3(logic_blocks(s_.n), fused ? 2 : 1), dim3(logic_lanes()), 0, st, s_, actions, run_seed,
                            step_index, env_offset, io, prefetch(), plan);
-        LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io, plan);
+        if (fused) LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io, plan);
         hipLaunchKernelGGL(entity_kernel, dim3((s_.n + 63) / 64, 2 * kMaxEnt), dim3(64), 0, st, s_);
         hipLaunchKernelGGL(resolve_kernel, dim3(logic_blocks(s_.n)), dim3(logic_lanes()), 0, st, s_, io);
     }

@@ -43,6 +43,14 @@ int logic_lanes() {
     return lanes;
 }
 
+bool install_in_logic() {
+    static const bool on = [] {
+        const char* e = std::getenv("PG_SEPARATE_INSTALL");
+        return !(e && e[0] == '1');
+    }();
+    return on;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Atlas
 // ------------------------------------------------------------------------------------------------
@@ -382,7 +390,17 @@ int32_t pgv_make_config(const pgv_config* cfg, pgv_env** out) {
         e->own_stream = true;
     }
     for (auto& ev : e->ev) PG_HIP(hipEventCreate(&ev));
-    PG_HIP(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+    {   // The level generator's stream.  PG_SIDE_PRIORITY=low (A/B only) asks the runtime for its lowest
+        // stream priority: measured on the seven-game slab, round 5 — see DESIGN.md.
+        const char* pr = std::getenv("PG_SIDE_PRIORITY");
+        if (pr && !std::strcmp(pr, "low")) {
+            int least = 0, greatest = 0;
+            PG_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            PG_HIP(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, least));
+        } else {
+            PG_HIP(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+        }
+    }
     for (auto& ev : e->side_ev) PG_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     if (e->game->resets_beside_logic() && !std::getenv("PG_SERIAL_RESETS")) {  // (the variable: A/B measurements only)
         {   // the few long wavefronts of the in-step level kernel go first; the logic kernel's many short ones fill in around them

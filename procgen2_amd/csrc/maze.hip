@@ -202,13 +202,15 @@ PG_D void advance(const State& s, int env, int action, float& reward_out, bool& 
 }
 
 __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actions, uint32_t run_seed,
-                                                   uint32_t step_index, int env_offset, StepIO io) {
-    const int env = blockIdx.x * blockDim.x + threadIdx.x;
-    if (env >= s.n) return;
-    if (io.pending[env] == 2) {  // reset by the level kernel in this step
-        io.pending[env] = 0;
+                                                   uint32_t step_index, int env_offset, StepIO io, int prefetch, LevelPlan plan) {
+    if (blockIdx.y == 1) {  // (block-uniform) the auto-resets whose level lies ready: a copy, beside the envs that step (pg_prefetch.h)
+        __shared__ Level lv;
+        install_prefetched<Gen>(s, blockIdx.x * blockDim.x, blockDim.x, prefetch, io, plan, lv, threadIdx.x, reset_served_mark(step_index), reset_due_mark(step_index));
         return;
     }
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= s.n) return;
+    if (resets_in_step(io.pending[env], step_index)) return;  // this step is the env's reset (pg_prefetch.h: who serves it, and the byte)
     const int action =
         actions ? actions[env] : synthetic_action(run_seed, step_index, static_cast<uint32_t>(env_offset + env));
     float reward;
@@ -216,7 +218,7 @@ __global__ void __launch_bounds__(64) logic_kernel(State s, const int32_t* actio
     advance(s, env, action, reward, terminated);
     io.reward[env] = reward;
     io.done[env] = terminated ? 1 : 0;
-    io.pending[env] = terminated ? 1 : 0;
+    io.pending[env] = terminated ? static_cast<uint8_t>(reset_due_mark(step_index + 1u)) : 0;  // (pg_prefetch.h: the byte)
 }
 
 constexpr int kGrid = kVisible + 3 <= 20 ? 20 : 28;  // visible tiles + the border cells of the inclusive window; as small as it
@@ -467,9 +469,13 @@ class MazeGame final : public Game {
     int prefetch() const { return (debug_flags & kDebugNoPrefetch) ? 0 : 1; }
     void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
                       StepIO io) override {
-        LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io, plan);
-        hipLaunchKernelGGL(logic_kernel, dim3(logic_blocks(s_.n)), dim3(logic_lanes()), 0, st, s_, actions, run_seed, step_index,
-                           env_offset, io);
+        // prefetched levels are installed beside the logic (its second row of blocks); the level kernel behind it
+        // generates, synchronously, the levels that were not ready — none in steady state (pg_prefetch.h install_prefetched)
+        const bool fused = prefetch() && install_in_logic();
+        if (!fused) LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io, plan, PG_RESET_SPAN, reset_served_mark(step_index), reset_due_mark(step_index));
+        hipLaunchKernelGGL(logic_kernel, dim3(logic_blocks(s_.n), fused ? 2 : 1), dim3(logic_lanes()), 0, st, s_, actions, run_seed, step_index,
+                           env_offset, io, prefetch(), plan);
+        if (fused) LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io, plan, PG_RESET_SPAN, reset_served_mark(step_index), reset_due_mark(step_index));
     }
     bool launch_frame(hipStream_t st, int env, uint32_t* d_px, int w, int h) override {
         hipLaunchKernelGGL(frame_kernel, dim3(1), dim3(kFrameThreads), 0, st, s_, atlas_, env, FrameTarget{d_px, w, h});

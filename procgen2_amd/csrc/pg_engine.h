@@ -66,7 +66,9 @@ struct StepIO {
     // (Game::resets_beside_logic) cannot hand the flag over like that: there the logic kernel skips every env that is
     // not 0 and writes 3 — not 1, which the level kernel running next to it would take for last step's — for an env that
     // terminates now, and the step's render kernel, which runs after both, turns 2 into 0 and 3 into 1.
-    // Between steps: 0 or 1 either way.
+    // Between steps: 0 or 1 either way.  The games that install prefetched levels inside their one logic launch
+    // (pg_prefetch.h install_prefetched: maze, jumper, climber, caveflyer) keep the step's parity in the byte instead:
+    // 4 | t mod 2 = reset due in step t, 2 | t mod 2 = reset served in step t, anything else = step.
     uint8_t* pending;
 };
 
@@ -158,6 +160,9 @@ constexpr int kDebugFatThirds = 1 << 23;
 
 // Lanes per workgroup of the lane-per-env logic kernels: fewer envs per wave = more waves.
 int logic_lanes();
+// Whether a game's prefetched levels are installed inside its first logic launch (pg_prefetch.h install_prefetched; the
+// default) or by the level kernel in a launch of its own in front of it (PG_SEPARATE_INSTALL=1: same-box A/B only).
+bool install_in_logic();
 inline int logic_blocks(int n) { return (n + logic_lanes() - 1) / logic_lanes(); }
 
 // Factories, one per compiled variant of a game (pg_defs.h PG_VARIANT; v0 = the reference's compile-time default).

@@ -80,10 +80,13 @@ struct HasServed<G, decltype(static_cast<void>(&G::served))> {
     static constexpr bool value = true;
 };
 
+// `due_mark` / `served_mark`: what mode 2 looks for in StepIO::pending and what it leaves there for an env it has served —
+// 1 and 2, or reset_due_mark(step) / reset_served_mark(step) for the games whose logic kernel runs the prefetched installs
+// in its own grid (install_prefetched below).
 template <class G>
 __global__ void __launch_bounds__(64) level_kernel(typename G::State s, int mode, int span, int prefetch,
                                                    uint32_t seed_base, int env_offset, const uint8_t* mask,
-                                                   const int32_t* seeds, StepIO io, LevelPlan plan) {
+                                                   const int32_t* seeds, StepIO io, LevelPlan plan, int served_mark, int due_mark) {
     using Level = typename G::Level;
     // A level is one long dependent chain per wavefront; whatever shares its SIMD (a logic kernel running beside an
     // in-step reset, a render kernel beside the prefetcher) is many short ones: let the chain issue first.
@@ -98,7 +101,7 @@ __global__ void __launch_bounds__(64) level_kernel(typename G::State s, int mode
         else if (mode == 1)
             want = !mask || mask[e];
         else if (mode == 2)
-            want = io.pending[e] == 1;
+            want = io.pending[e] == due_mark;
         else
             want = __hip_atomic_load(&s.slot[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kSlotQueued;
     }
@@ -182,7 +185,7 @@ __global__ void __launch_bounds__(64) level_kernel(typename G::State s, int mode
             if (mode != 0) {
                 io.reward[env] = 0.0f;
                 io.done[env] = 0;
-                io.pending[env] = mode == 2 ? 2 : 0;
+                io.pending[env] = mode == 2 ? static_cast<uint8_t>(served_mark) : 0;
                 if constexpr (HasServed<G>::value) {
                     if (mode == 2) G::served(s, env);
                 }
@@ -201,13 +204,31 @@ __global__ void __launch_bounds__(64) level_kernel(typename G::State s, int mode
 // generator's latency) — they keep pending == 1 and are generated synchronously there, as before; in steady state that
 // launch finds nothing (one load per lane).  The generator's 256 registers stay out of the logic kernel this way
 // (the fused kernel WITH the generator ran at one wave per SIMD and took the sum of the two chains).
-// One wavefront (blockDim ≤ 64); `lv` is a Level in LDS.  Served envs are left at pending == 2 like mode 2 leaves them.
+// One wavefront (blockDim ≤ 64); `lv` is a Level in LDS.  Served envs are left at pending == served_mark, as mode 2 leaves them.
+//
+// The pending byte when install and logic share a launch — a game whose ONE logic kernel both reads the byte (is this
+// step the env's reset?) and writes it (the env terminated: reset it next step).  Two races to keep out:
+//   * a logic lane may look at its env's byte before, while or after the install row serves it: "due in step t" and
+//     "served in step t" must both mean "this step is the env's reset";
+//   * the install row scans the bytes while logic lanes of the same launch write them: an env that terminates NOW must not
+//     look due NOW (it was, with a plain 1: four of 128 mazes were reset in the step that ended them).
+// So the marks carry the parity of the step they are about: reset_due_mark(t) = 4 | t mod 2, written by the logic lane of
+// step t − 1; reset_served_mark(t) = 2 | t mod 2, written by whoever serves the env in step t.  In step t, due(t) and
+// served(t) mean reset; anything else — 0, served(t − 1) — means step, and the logic lane overwrites it with its verdict.
+// Nothing has to clear a mark.  (coinrun's byte is written by resolve_kernel, two launches behind the install row: plain 1
+// and 2 there, and resolve_kernel clears the 2.)
+PG_HD int reset_due_mark(uint32_t step_index) { return 4 | static_cast<int>(step_index & 1u); }
+PG_HD int reset_served_mark(uint32_t step_index) { return 2 | static_cast<int>(step_index & 1u); }
+PG_HD bool resets_in_step(int pending, uint32_t step_index) {
+    return pending == reset_due_mark(step_index) || pending == reset_served_mark(step_index);
+}
+
 template <class G>
 PG_D void install_prefetched(const typename G::State& s, int base, int span, int prefetch, StepIO io, LevelPlan plan,
-                             typename G::Level& lv, int lane) {
+                             typename G::Level& lv, int lane, int served_mark = 2, int due_mark = 1) {
     using Level = typename G::Level;
     constexpr int kWords = static_cast<int>(sizeof(Level) / 4);
-    const bool want = lane < span && base + lane < s.n && io.pending[base + lane] == 1;
+    const bool want = lane < span && base + lane < s.n && io.pending[base + lane] == due_mark;
     unsigned long long todo = __ballot(want);
     const bool levels = plan.num_levels > 0;
     while (todo) {  // wave-uniform
@@ -229,7 +250,7 @@ PG_D void install_prefetched(const typename G::State& s, int base, int span, int
             slot_store(&s.slot[env], prefetch ? kSlotQueued : kSlotIdle);
             io.reward[env] = 0.0f;
             io.done[env] = 0;
-            io.pending[env] = 2;
+            io.pending[env] = static_cast<uint8_t>(served_mark);
             if constexpr (HasServed<G>::value) G::served(s, env);
         }
         __syncthreads();
@@ -242,12 +263,12 @@ struct LevelLaunch {
     static void make(hipStream_t st, const typename G::State& s, int prefetch, uint32_t seed_base, int env_offset,
                      LevelPlan plan) {
         hipLaunchKernelGGL(level_kernel<G>, dim3(s.n), dim3(64), 0, st, s, 0, 1, prefetch, seed_base, env_offset,
-                           nullptr, nullptr, StepIO{}, plan);
+                           nullptr, nullptr, StepIO{}, plan, 2, 1);
     }
     static void reset(hipStream_t st, const typename G::State& s, int prefetch, const uint8_t* mask,
                       const int32_t* seeds, StepIO io, LevelPlan plan) {
         hipLaunchKernelGGL(level_kernel<G>, dim3(s.n), dim3(64), 0, st, s, 1, 1, prefetch, 0u, 0, mask, seeds, io,
-                           plan);
+                           plan, 2, 1);
     }
     // span = envs per wavefront, served one after the other.  With prefetch a served env costs a copy, so 64 per wave
     // is right; a game that generates inside the step (chaser) wants few, or the step waits for the unluckiest wave:
@@ -256,16 +277,16 @@ struct LevelLaunch {
 #define PG_RESET_SPAN 64
 #endif
     static void auto_reset(hipStream_t st, const typename G::State& s, int prefetch, StepIO io, LevelPlan plan,
-                           int span = PG_RESET_SPAN) {
+                           int span = PG_RESET_SPAN, int served_mark = 2, int due_mark = 1) {
         hipLaunchKernelGGL(level_kernel<G>, dim3((s.n + span - 1) / span), dim3(64), 0, st, s, 2, span, prefetch, 0u, 0,
-                           nullptr, nullptr, io, plan);
+                           nullptr, nullptr, io, plan, served_mark, due_mark);
     }
     // bulk: most slots are queued (after make / a full reset) → a wavefront per env; otherwise few envs per wave,
     // because the queued envs of one wave are served one after the other.
     static void pregen(hipStream_t side, const typename G::State& s, bool bulk, LevelPlan plan) {
         const int span = bulk ? 1 : 8;
         hipLaunchKernelGGL(level_kernel<G>, dim3((s.n + span - 1) / span), dim3(64), 0, side, s, 3, span, 1, 0u, 0,
-                           nullptr, nullptr, StepIO{}, plan);
+                           nullptr, nullptr, StepIO{}, plan, 2, 1);
     }
 };
 #endif

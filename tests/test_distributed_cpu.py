@@ -157,3 +157,82 @@ def _mixed_worker(rank, world, port, per_rank, out_dir):
 def test_mixed_workload_one_slab_one_gather_four_ranks(tmp_path):
     mp.spawn(_mixed_worker, args=(4, _free_port(), 23, str(tmp_path)), nprocs=4, join=True)  # 23 = 6·3 + 5: a remainder
     assert (tmp_path / "ok").exists()
+
+
+class _SlabWriter:
+    """What bench.py's gathered_steps() needs of a ProcgenVecEnv, on CPU tensors: step_synthetic(ordered=False) fills this
+    engine's block of the rank's three slabs, publish() / consume() / sync() are recorded — the loop under test is
+    bench.py's own, the collective a real RootGather over gloo."""
+
+    def __init__(self, log, rank, game, blocks):
+        self.log, self.rank, self.game, self.blocks, self.step = log, rank, game, blocks, 0
+
+    def step_synthetic(self, run_seed, ordered=True):
+        assert ordered is False
+        for t in self.blocks:
+            t.fill_((self.rank * 32 + self.game * 3 + self.step + run_seed) % 251)
+        self.step += 1
+        self.log.append(("step", self.game))
+
+    def publish(self):
+        self.log.append(("publish", self.game))
+
+    def consume(self):
+        self.log.append(("consume", self.game))
+
+    def sync(self):
+        self.log.append(("sync", self.game))
+
+
+def _bench_loop_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from procgen2_amd.vec_env import GAMES, RootGather
+    per_rank = 23 if rank == 0 else 31  # rank-dependent counts: the plan exchanges them once
+    base = per_rank // len(GAMES)
+    counts = [base] * (len(GAMES) - 1) + [per_rank - base * (len(GAMES) - 1)]
+    shapes = (((4, 4, 3), torch.uint8), ((), torch.float32), ((), torch.uint8))
+    local = tuple(torch.zeros((per_rank,) + sh, dtype=dt) for sh, dt in shapes)
+    log, envs, at = [], [], 0
+    for g, count in enumerate(counts):
+        envs.append(_SlabWriter(log, rank, g, tuple(t[at:at + count] for t in local)))
+        at += count
+    plan = RootGather(local, dst=0)
+    seen = []
+
+    def gather():
+        log.append(("gather", -1))
+        got = plan()
+        if rank == 0:
+            seen.append(tuple(t.clone() for t in got))
+
+    steps, run_seed = 4, 7
+    bench.gathered_steps(envs, gather, steps, run_seed)
+    # the order of one step: every engine steps, every engine publishes, ONE gather, every engine consumes
+    n = len(GAMES)
+    per_step = [("step", g) for g in range(n)] + [("publish", g) for g in range(n)] + [("gather", -1)] + [("consume", g) for g in range(n)]
+    assert log == per_step * steps + [("sync", g) for g in range(n)]
+    if rank == 0:
+        sizes = [23, 31]
+        assert plan.slabs[0].shape[0] == sum(sizes)
+        for step, got in enumerate(seen):
+            for t in got:
+                at = 0
+                for r, size in enumerate(sizes):
+                    b = size // n
+                    cs = [b] * (n - 1) + [size - b * (n - 1)]
+                    for g, c in enumerate(cs):
+                        assert (t[at:at + c] == (r * 32 + g * 3 + step + run_seed) % 251).all(), (step, r, g)
+                        at += c
+        open(os.path.join(out_dir, "ok"), "w").write("1")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_gathered_step_loop_two_ranks_with_different_counts(tmp_path):
+    """bench.py's own publish -> RootGather -> consume loop (bench.gathered_steps), two gloo ranks
+    holding 23 and 31 envs."""
+    mp.spawn(_bench_loop_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").exists()
