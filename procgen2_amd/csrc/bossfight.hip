@@ -1014,7 +1014,7 @@ struct SetupLds {
 __global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView atlas, const uint8_t* mask) {
     __shared__ SetupLds S;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int env0 = blockIdx.x * kPrepEnvs;
+    const int env0 = prep_block(blockIdx.x, gridDim.x) * kPrepEnvs;  // (pg_prepass.h: the groups of one XCD are consecutive)
     if (tid < kTexCount) S.desc[tid] = atlas.desc[tid];
     if (tid >= 64 && tid < 64 + kPrepEnvs * PE_COUNT) {
         const int q = tid - 64, f = q / kPrepEnvs, e = q - f * kPrepEnvs, env = env0 + e;  // (the envs of a field side by side)

@@ -982,7 +982,7 @@ __global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView 
     __shared__ SetupLds S;
     PrepLds<kGrid, kPrepEnvs, kSpan>& P = S.P;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int env0 = blockIdx.x * kPrepEnvs;
+    const int env0 = prep_block(blockIdx.x, gridDim.x) * kPrepEnvs;  // (pg_prepass.h: the groups of one XCD are consecutive)
     const PrepOut& out = s.prep;
 
     // ---- one memory round trip: descriptor table, the envs' scalars (lane = env), their draw orders

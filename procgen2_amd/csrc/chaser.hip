@@ -469,7 +469,10 @@ PG_D void advance(const State& s, StepLds& L, Q q, int env, int action, float& r
     float reward = 0.0f;
     bool terminated = false;
     for (int ss = 0; ss < 4; ss++) {
-        {  // --- System_Agent::update (common_systems.cpp:305-444)
+#ifndef PG_CHASER_SKIP  // (instruction inventory of the logic kernel, tools/probe/chaser_logic_phases.sh: experiment builds leave parts out)
+#define PG_CHASER_SKIP 0
+#endif
+        if (!(PG_CHASER_SKIP & 1)) {  // --- System_Agent::update (common_systems.cpp:305-444)
             const float speed = 0.2f;
             const float input_reset_time = 1.0f / speed * 0.5f;
             if (movement_x != 0.0f || movement_y != 0.0f) {
@@ -549,7 +552,7 @@ PG_D void advance(const State& s, StepLds& L, Q q, int env, int action, float& r
         {
             const float hatch_time = 50.0f, anim_time = 1.0f, speed_low = 0.125f, speed_high = 0.25f;
 #pragma unroll
-            for (int k = 0; k < kMobs; k++) {
+            for (int k = 0; k < ((PG_CHASER_SKIP & 2) ? 0 : kMobs); k++) {
                 float hatch = mob_hatch[k];
                 if (hatch >= hatch_time) {
                     float px = mob_x[k], py = mob_y[k];
@@ -659,7 +662,7 @@ PG_D void advance(const State& s, StepLds& L, Q q, int env, int action, float& r
         {
             const int cx = static_cast<int>(ax), cy = H - 1 - static_cast<int>(ay);  // cell (x, tile row) under the agent's centre
 #pragma unroll
-            for (int n0 = 0; n0 < 9; n0 += kGang) {
+            for (int n0 = 0; n0 < ((PG_CHASER_SKIP & 4) ? 0 : 9); n0 += kGang) {
                 const int nb = n0 + q.g;
                 const int x = cx + nb % 3 - 1, ty = cy + (nb / 3) % 3 - 1;
                 const bool inside = nb < 9 && x >= 0 && ty >= 0 && x < W && ty < H;
@@ -711,7 +714,7 @@ PG_D void advance(const State& s, StepLds& L, Q q, int env, int action, float& r
         SI(s, I_ANIM_I, env) = anim_i;
         SI(s, I_FLAGS, env) = kFlagListed;
     }
-    if (set_changed) {
+    if (set_changed && !(PG_CHASER_SKIP & 8)) {
         wave_order();
         rebuild_draw_list(s, L, q, env, n_ent);
     }
