@@ -125,6 +125,20 @@ struct State {
     // function of its cell: worked out once for every cell (prepare_kernel); what moves — the enemies and the agent — and
     // the background's two axes once per frame and env by a dense kernel (setup_kernel) instead of by both wavefronts of
     // the env's render workgroup, 64 lanes at a time whatever the number of draws.
+    // The BASE LAYER of every env's frame (round 5): background + walls as they land on the 64 × 64 target, 0x00BBGGRR
+    // words, 16 KB an env.  The camera never moves, the walls and the backdrop are the level's: that layer is the same
+    // picture in every frame of an episode — it IS the episode's first frame (the draw list is empty then, D2) — and
+    // working it out again every frame was 55 % of the render kernel (the row loop's one-texel pass 510 vector instructions
+    // per wave, its general form, which the walls' translucent corners send one pixel row in five through, 443; 75 texel
+    // gathers).  Whoever renders a frame the complete way — the late pass over the envs reset in a step, pgv_reset's
+    // render, the debug paths — leaves the layer here; the step's frames start from a 16-KB copy of it and only stamp the
+    // points that are still there (overlay_points).  Scratch memory, not state: derived, rebuilt after pgv_load_state.
+    uint32_t* base;  // [n][64 * 64]
+    // A point's stamp at every cell: the pixels of the frame its draw leaves something on (at most kStampMax: the opaque
+    // middle of its texture as it lands there), as pairs {pixel = 64 · row + column, or kNoStamp; 0x00BBGGRR} — worked out
+    // once, on the host, when the atlas is loaded (ChaserGame::extend_atlas: Renderer::render_texture's arithmetic and
+    // raster rules S1–S3 through pg_geom.h, one call per cell) and kept behind the textures in the atlas array.
+    uint32_t stamps;  // word offset in AtlasView::texels of [kCells][kStampMax][2]
     struct Prep {
         uint32_t* cell_blits;  // [2][kCells][kBlitWords]   orb, point at each cell (pg_render.h BlitWords; word 1 = 0: not drawn)
         uint32_t* movers;      // [n][kMovers][kBlitWords]  enemy 0 … kMobs − 1, the agent
@@ -132,6 +146,8 @@ struct State {
     } prep;
 };
 constexpr int kMovers = kMobs + 1;
+constexpr int kStampMax = 16;
+constexpr uint32_t kNoStamp = 0xffffffffu;
 
 PG_D float& SF(const State& s, int field, int env) { return s.f[size_t(field) * s.n + env]; }
 PG_D int32_t& SI(const State& s, int field, int env) { return s.i[size_t(field) * s.n + env]; }
@@ -300,8 +316,8 @@ PG_D void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, u
     __syncthreads();
 }
 
-PG_D float cell_x(int cell) { return static_cast<float>(cell / H) + 0.5f; }
-PG_D float cell_y(int cell) { return static_cast<float>(H - 1 - cell % H) + 0.5f; }
+PG_HD float cell_x(int cell) { return static_cast<float>(cell / H) + 0.5f; }
+PG_HD float cell_y(int cell) { return static_cast<float>(H - 1 - cell % H) + 0.5f; }
 
 // The level becomes the env's live state (what reset() and the component constructors initialise).
 PG_D void install(const State& s, int env, const Level& lv, int lane) {
@@ -788,7 +804,7 @@ struct View {
     Camera cam;
     int x0, y0, cols, rows;
 };
-PG_D View view_of_world() {
+PG_HD View view_of_world() {
     const float zoom = 64.0f * kPxUnit / static_cast<float>(W);  // chaser.cpp:401
     View v{Camera{W * 0.5f * kUnitPx, H * 0.5f * kUnitPx, 64.0f, 64.0f, zoom}, 0, 0, 0, 0};
     const Camera& cam = v.cam;
@@ -813,9 +829,36 @@ PG_D bool points_join_layer(const int4& point_d, int flags) { return !(flags & 1
 // kPrepped: the draws and the background's axes come from the pre-pass's tables (State::Prep) instead of being resolved
 // here — the frames of the step's main pass; the late pass (envs reset in this step: their level did not exist when the
 // pre-pass ran) and the debug paths resolve their own.
+// The points of the draw list over a frame that already holds the base layer: lane = point.  A point is a stamp — a handful
+// of opaque pixels whose places and colours depend on its cell alone (State::stamps) — and no two points' stamps meet, nor a
+// wall's padded seam (they lie in the middle of free cells): written in any order, each wave the pixels of its own rows.
+// `ent`: the draw list as render_env holds it (entry lane + 64·j in register j: entity | kind << 8 | cell << 16).
+PG_D void stamp_points(uint32_t* fb, const State& s, const AtlasView& atlas, const uint32_t (&ent)[kEntRegs], int n_draw, int lane, int half) {
+    const uint4* table = reinterpret_cast<const uint4*>(atlas.texels + s.stamps);
+    const uint32_t row_lo = static_cast<uint32_t>(half) * (kObsH / 2) * kObsW, row_hi = row_lo + (kObsH / 2) * kObsW;
+#pragma unroll
+    for (int j = 0; j < kEntRegs; j++) {
+        const uint32_t v = ent[j];
+        const bool point = lane + 64 * j < n_draw && ((v >> 8) & kKindMask) == kPoint;
+        if (__ballot(point) == 0) continue;  // wave-uniform
+        const uint4* mine = table + size_t(point ? (v >> 16) : 0u) * (kStampMax / 2);
+        uint4 e[kStampMax / 2];
+#pragma unroll
+        for (int k = 0; k < kStampMax / 2; k++) e[k] = mine[k];  // (two stamps a load; the table is 15 KB for every env of the engine)
+#pragma unroll
+        for (int k = 0; k < kStampMax / 2; k++) {
+            if (point && e[k].x >= row_lo && e[k].x < row_hi) fb[e[k].x] = e[k].y;
+            if (point && e[k].z >= row_lo && e[k].z < row_hi) fb[e[k].z] = e[k].w;
+        }
+    }
+}
+
+// kBase (kPrepped frames only): the frame starts from the env's base layer (State::base) and stamps its points, instead of
+// composing background and walls.  write_base (the other frames): background and walls are composed WITHOUT the points
+// (the sprite pass draws those), and the layer is left in State::base on the way.
 template <bool kPrepped>
 PG_D void render_env(const State& s, const AtlasView& atlas, const StepIO& io, int flags, int env, uint32_t* fb,
-                     ComposeLdsBoxed<kGrid>& LB, SpriteLds& S) {
+                     ComposeLdsBoxed<kGrid>& LB, SpriteLds& S, bool from_base = false, bool write_base = false) {
     ComposeLds<kGrid>& L = LB.plain;
     const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // two wavefronts per env (pg_render.h)
     constexpr int halves = 2;
@@ -874,11 +917,29 @@ PG_D void render_env(const State& s, const AtlasView& atlas, const StepIO& io, i
     }
     const int x0 = view.x0, y0 = view.y0, cols = view.cols, rows = view.rows, cells = cols * rows;
     const int4 wall_d = atlas.desc[kTexWall], point_d = atlas.desc[kTexPoint];
-    const bool points_in_layer = points_join_layer(point_d, flags);
+    const bool points_in_layer = points_join_layer(point_d, flags) && !write_base;
 
     bool composed = false;
     PG_TL(1);
-    if (!(flags & 1) && cols <= kGrid && rows <= kGrid) {
+    if (kPrepped && from_base) {
+        // the base layer: a straight copy of this wave's 32 rows (8 KB), memory to LDS without passing through registers —
+        // `buffer_load_dwordx4 … lds`: lane l's 16 bytes land at M0 + 16·l, 1 KB an instruction
+        {
+            using lds_ptr = __attribute__((address_space(3))) void*;
+            const __amdgpu_buffer_rsrc_t base_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<uint32_t*>(s.base + size_t(env) * kFbWords + half * (kFbWords / 2)), 0, kFbWords / 2 * 4, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < kFbWords / 8 / 64; k++)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(base_rsrc, (lds_ptr)(fb + half * (kFbWords / 2) + k * 256), 16, lane * 16, k * 1024, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the compiler does not track LDS-direct loads: the copy has landed)
+        wave_order();  // the copy, lane by lane, before the stamps of other lanes on the same words
+        PG_TL(2);
+        // … and the points that are still there, stamped over it (each wave its own rows: no barrier)
+        stamp_points(fb, s, atlas, ent, n_draw, lane, half);
+        wave_order();
+        composed = true;
+    } else if (!(flags & 1) && cols <= kGrid && rows <= kGrid) {
         // this wave's axis of the background (wave 0: x, wave 1: y); the tile spans are the prepared ones
         BgAxis bga;
         if (kPrepped) {
@@ -936,6 +997,13 @@ PG_D void render_env(const State& s, const AtlasView& atlas, const StepIO& io, i
             }
             wave_replay(fb, atlas, mine, __ballot(has), lane, half, halves);
         }
+    }
+    if (write_base) {  // background + walls are in the target, nothing else yet: the env's base layer (State::base)
+        wave_order();
+        const uint4* src = reinterpret_cast<const uint4*>(fb) + half * (kFbWords / 8);
+        uint4* dst = reinterpret_cast<uint4*>(s.base + size_t(env) * kFbWords) + half * (kFbWords / 8);
+#pragma unroll
+        for (int k = 0; k < kFbWords / 8 / 64; k++) dst[k * 64 + lane] = src[k * 64 + lane];
     }
     // every sprite has z = 0: the positive pass (common_systems.cpp:41-63), then the agent (:446-460)
     // Points that the composer has already put into the picture are drawn again only if an earlier draw of the list
@@ -1121,7 +1189,12 @@ __global__ void __launch_bounds__(128, PG_CHASER_RENDER_WAVES) render_kernel(Sta
     __shared__ alignas(16) uint32_t fb[kFbWords];
     __shared__ ComposeLdsBoxed<kGrid> L;
     __shared__ SpriteLds S;
-    render_env<kPrepped>(s, atlas, io, flags, env, fb, L, S);
+    // kPrepped: from the env's base layer (the host launches this form only when every env that is drawn here has one:
+    // ChaserGame::from_base).  Otherwise the complete frame, which leaves the base layer behind.
+    if (kPrepped)
+        render_env<true>(s, atlas, io, flags, env, fb, L, S, true, false);
+    else
+        render_env<false>(s, atlas, io, flags, env, fb, L, S, false, true);
 }
 
 // The late pass of a step whose resets ran on their own stream: the frames of the envs on the level kernel's list (a
@@ -1139,7 +1212,7 @@ __global__ void __launch_bounds__(128, PG_CHASER_RENDER_WAVES) render_list_kerne
     for (int item = blockIdx.x; item < count; item += gridDim.x) {
         const int env = s.reset_list[item];
         if (threadIdx.x == 0) io.pending[env] = 0;
-        render_env<false>(s, atlas, io, flags, env, fb, L, S);
+        render_env<false>(s, atlas, io, flags, env, fb, L, S, false, true);  // (… and leaves the new level's base layer)
         __syncthreads();  // the next env of this workgroup reuses the LDS
     }
 }
@@ -1224,6 +1297,37 @@ class ChaserGame final : public Game {
             for (int x = box.x; x <= box.y; x++) solid = solid && (tex[size_t(y) * d.y + x] >> 24) == 255u;
         s_.point_box = box;
         s_.point_solid = solid ? 1 : 0;
+        stamp_ok_ = solid && (d.w & 12) == 8;  // (points_join_layer: a clear rim around an opaque box)
+        // A point's stamp at every cell (State::stamps): its draw call through render_texture's arithmetic and raster rules
+        // S1–S3 (pg_geom.h resolve_draw / sample_index — the very functions the kernels run, compiled for the host with the
+        // same -ffp-contract=off), the pixels whose texel is not clear.  More than kStampMax of them, or one that is not
+        // opaque: no stamps — every frame is then composed the complete way (from_base() false).
+        std::vector<uint32_t> words(size_t(kCells) * kStampMax * 2, kNoStamp);
+        const View view = view_of_world();
+        for (int cell = 0; cell < kCells; cell++) {
+            Blit b;
+            const float scale = (1.0f * 1.0f) * kUnitPx / d.y;
+            if (!resolve_draw(view.cam, d.y, d.z, 0, (cell_x(cell) + -0.5f) * kUnitPx, (cell_y(cell) + -0.5f) * kUnitPx, scale, 1.0f, false,
+                              false, b))
+                continue;
+            int count = 0;
+            for (int j = 0; j < b.dh; j++)
+                for (int i = 0; i < b.dw; i++) {
+                    const int X = b.dx + i, Y = b.dy + j;
+                    if (X < 0 || Y < 0 || X >= kObsW || Y >= kObsH) continue;  // S5
+                    const uint32_t texel = tex[size_t(sample_index(b.sy, b.sh, j, b.dh)) * d.y + sample_index(b.sx, b.sw, i, b.dw)];
+                    if ((texel >> 24) == 0u) continue;
+                    if ((texel >> 24) != 255u || count == kStampMax) {
+                        stamp_ok_ = false;
+                        continue;
+                    }
+                    words[(size_t(cell) * kStampMax + count) * 2] = static_cast<uint32_t>(Y * kObsW + X);
+                    words[(size_t(cell) * kStampMax + count) * 2 + 1] = texel & 0x00ffffffu;
+                    count++;
+                }
+        }
+        while (atlas.texel_bytes() % 16) atlas.append_words({0u});  // (the kernels read the table 16 bytes at a time)
+        s_.stamps = atlas.append_words(words);
     }
     static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
     struct Layout {
@@ -1304,22 +1408,28 @@ class ChaserGame final : public Game {
         (void)mask;  // (every env: a lane's work, and the frames of the others are not drawn)
         if (lean()) hipLaunchKernelGGL(setup_kernel, dim3((s_.n * kPrepLanes + 255) / 256), dim3(256), 0, st, s_, atlas_);
     }
+    // pgv_reset's frames: the complete way (new levels: their base layers are made on the way).
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
-        if (lean())
-            hipLaunchKernelGGL(render_kernel<true>, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags, 0);
-        else
-            hipLaunchKernelGGL(render_kernel<false>, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags, 0);
+        hipLaunchKernelGGL(render_kernel<false>, dim3(s_.n), dim3(128), 0, st, s_, atlas_, mask, io, debug_flags, 0);
+        if (!mask) base_valid_ = true;  // (every env has been rendered the complete way)
     }
+    // A step's frames start from the base layers when every env drawn by this launch has a current one: the layers are
+    // valid (not right after make / pgv_load_state), the envs reset in this step are left to the late pass (resets on their
+    // own stream: the default), the point sprite is a stamp (an opaque box in a clear rim: true of the reference's asset).
+    bool from_base() const { return lean() && base_valid_ && reset_stream != nullptr && stamp_ok_; }
     void launch_render_step(hipStream_t st, StepIO io) override {
-        if (lean())
-            hipLaunchKernelGGL(render_kernel<true>, dim3(s_.n), dim3(128), 0, st, s_, atlas_, nullptr, io, debug_flags, reset_stream ? 1 : 0);
+        if (from_base())
+            hipLaunchKernelGGL(render_kernel<true>, dim3(s_.n), dim3(128), 0, st, s_, atlas_, nullptr, io, debug_flags, 1);
         else
             hipLaunchKernelGGL(render_kernel<false>, dim3(s_.n), dim3(128), 0, st, s_, atlas_, nullptr, io, debug_flags, reset_stream ? 1 : 0);
+        base_valid_ = true;  // (either way every env's layer has been written by now, or is by this launch and the late pass)
     }
     static size_t up256(size_t b) { return (b + 255) & ~size_t(255); }
     size_t scratch_bytes(int n) const override {
-        return up256(size_t(2) * kCells * kBlitWords * 4) + up256(size_t(n) * kMovers * kBlitWords * 4) + up256(size_t(n) * 8 * 4);
+        return up256(size_t(2) * kCells * kBlitWords * 4) + up256(size_t(n) * kMovers * kBlitWords * 4) + up256(size_t(n) * 8 * 4) +
+               up256(size_t(n) * kFbWords * 4);
     }
+    void state_loaded() override { base_valid_ = false; }
     void bind_scratch(void* d_scratch, int n) override {
         uint8_t* p = static_cast<uint8_t*>(d_scratch);
         s_.prep.cell_blits = reinterpret_cast<uint32_t*>(p);
@@ -1327,6 +1437,9 @@ class ChaserGame final : public Game {
         s_.prep.movers = reinterpret_cast<uint32_t*>(p);
         p += up256(size_t(n) * kMovers * kBlitWords * 4);
         s_.prep.bg = reinterpret_cast<uint32_t*>(p);
+        p += up256(size_t(n) * 8 * 4);
+        s_.base = reinterpret_cast<uint32_t*>(p);
+        base_valid_ = false;
     }
     bool launch_render_late(hipStream_t st, StepIO io) override {
         if (!reset_stream) return false;
@@ -1397,6 +1510,8 @@ class ChaserGame final : public Game {
    private:
     State s_{};
     AtlasView atlas_{};
+    bool base_valid_ = false;  // every env's base layer (State::base) is its current level's
+    bool stamp_ok_ = false;    // the point sprite is an opaque box in a clear rim (extend_atlas)
 };
 
 }  // namespace chaser

@@ -1730,6 +1730,9 @@ class CoinrunGame final : public Game {
         if (!fused) LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io, plan);
         hipLaunchKernelGGL(agent_kernel, dim3(logic_blocks(s_.n), fused ? 2 : 1), dim3(logic_lanes()), 0, st, s_, actions, run_seed,
                            step_index, env_offset, io, prefetch(), plan);
+        // (Measured and rejected, round 5: that level kernel on a stream of its own beside the entities — forked behind
+        // agent_kernel, joined in front of resolve_kernel — so that its 6 µs and its kernel boundary leave the main stream:
+        // 123.6 against 126.7 M env-steps/s, three same-box pairs; the two event hand-overs cost more than they hide.)
         if (fused) LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io, plan);
         hipLaunchKernelGGL(entity_kernel, dim3((s_.n + 63) / 64, 2 * kMaxEnt), dim3(64), 0, st, s_);
         hipLaunchKernelGGL(resolve_kernel, dim3(logic_blocks(s_.n)), dim3(logic_lanes()), 0, st, s_, io);

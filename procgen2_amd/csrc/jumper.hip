@@ -987,7 +987,9 @@ __global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView 
         S.counts[e] = 0;
         if (active) {
             v.cam = cam;
-            const int backdrop = themes & 0xff, theme = (themes >> 8) & 0xff;
+            // (bit 4: traffic experiment of the -DPG_ABLATE build — every env shows backdrop 9: what the backdrops' share of
+            // the render kernel's FETCH_SIZE is, and what the kernel would gain if it were not there)
+            const int backdrop = PG_ABL(flags, 16) ? 9 : (themes & 0xff), theme = (themes >> 8) & 0xff;
             const int4 d = S.desc[kTexBackdrop + backdrop];
             const float aspect = static_cast<float>(d.y) / static_cast<float>(d.z);
             const float extra = aspect - 1.0f;

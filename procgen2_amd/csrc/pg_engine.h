@@ -140,6 +140,10 @@ class Game {
     virtual void launch_render_step(hipStream_t s, StepIO io) { launch_render(s, nullptr, io); }
     virtual bool launch_render_late(hipStream_t s, StepIO io) { return false; }
 
+    // Called after pgv_load_state has replaced the state blob: whatever a game derives from its state and keeps OUTSIDE the
+    // blob (chaser: the base layer of every env's frame, pg chaser.hip) is stale from here on.
+    virtual void state_loaded() {}
+
     // Device memory a game's kernels hand results to each other through within one frame (the render pre-pass,
     // pg_prepass.h): allocated by the engine beside the state, never part of a snapshot.
     virtual size_t scratch_bytes(int n) const { (void)n; return 0; }

@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-bash tools/probe/chaser_logic_phases.sh run r05m/chl 2>&1 | tee gpurun_out/r05m_chaser_logic_phases.txt
-python tools/perf_quick.py --games bossfight,caveflyer,climber,jumper,chaser --check 128x150 2>&1 | tail -5
+timeout 1500 python -m pytest tests -m gpu -x -q -k "chaser or snapshot or mixed or modes or levels or gym or human_frame" 2>&1 | tail -4
+for rep in 1 2; do python tools/perf_quick.py --games chaser --check 0x0 --settle 600 --steps 256 2>&1 | tail -1; done
