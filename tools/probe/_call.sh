@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
-python tools/perf_quick.py --games chaser --check 256x400 --settle 600 --steps 256 2>&1 | tail -1
-python tools/perf_quick.py --games chaser --check 0x0 --settle 600 --steps 256 2>&1 | tail -1
-timeout 1500 python -m pytest tests -m gpu -x -q -k "chaser or snapshot or mixed or modes or levels" 2>&1 | tail -3
+bash tools/bound_table.sh r05 2>&1 | tail -5
+python tools/bound_table.py gpurun_out/r05_bounds_raw.json > gpurun_out/r05_bounds.md
+tail -5 gpurun_out/r05_bounds.md
