@@ -10,6 +10,7 @@ index, so results do not depend on the GPU count).  There is no collective in re
 `gather()` is the optional rooted gather of obs/reward/done to rank 0 over RCCL.
 """
 import ctypes
+import os
 from ctypes import c_void_p
 
 import torch
@@ -45,7 +46,9 @@ class ProcgenVecEnv:
         # has handle 0, which the C ABI reads as "create one", and work on an unrelated stream would race with the
         # caller's.  Every call below makes the engine's stream wait for the caller's current stream (actions, masks)
         # and the caller's current stream wait for the engine's (obs, reward, done).
-        self._stream = torch.cuda.Stream(device=self.device)
+        # (PG_STREAM_PRIORITY_<GAME>=-1: a high-priority stream for that game's engine — an A/B switch for several engines on
+        # one GPU, bench.py --workload mixed; default 0)
+        self._stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("PG_STREAM_PRIORITY_" + game.upper(), "0")))
         # num_levels > 0: a finite level set (include/procgen2_vec.h pgv_make_levels); 0 = every level is new.
         # distribution_mode: None / "default" = the reference's compile-time config, or "easy" | "hard" | "memory" |
         # "extreme" where the game has it (pgv_game_modes).
