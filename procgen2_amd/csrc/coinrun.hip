@@ -862,6 +862,10 @@ __global__ void __launch_bounds__(64) entity_kernel(State s) {
 }
 
 // C — lane = env: which sub-step ended the step, rare redo, commit (coinrun.cpp:356-371).
+// (Measured and rejected, round 5: no launch of its own — every wavefront of entity_kernel counts itself off in its block's
+// word and the last one resolves the block's 64 envs.  Bit-exact; with relaxed agent-scope atomics and a workgroup-scope
+// release 125.6 against 128.3 M env-steps/s — 73 728 atomics cost more than a 6-µs kernel and its boundary; with
+// __threadfence() and an acq_rel count, an L2 write-back per wavefront, the step took 2.86 ms.)
 __global__ void __launch_bounds__(64) resolve_kernel(State s, StepIO io) {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= s.n) return;
