@@ -1504,6 +1504,18 @@ __global__ void __launch_bounds__(64 * kRenderWaves, PG_COINRUN_RENDER_WAVES) re
     __shared__ uint32_t lean_pad[PG_LDS_PAD_LEAN];
     if (flags == 0x7fffffff) lean_pad[threadIdx.x % PG_LDS_PAD_LEAN] = env;  // (never true: keeps the array allocated)
 #endif
+#if defined(PG_TIMELINE)  // (latency experiment, tools/build_exp.py + tools/probe/wave_timeline.py: where a wave's life goes)
+    unsigned long long tl[6];
+#define PG_TL(k)                                \
+    do {                                        \
+        __builtin_amdgcn_s_waitcnt(0);          \
+        __builtin_amdgcn_wave_barrier();        \
+        tl[k] = __builtin_amdgcn_s_memtime();   \
+    } while (0)
+#else
+#define PG_TL(k) do {} while (0)
+#endif
+    PG_TL(0);
     // One round trip for everything the frame starts from: the packed axes, the kind offsets, this wave's half of the
     // cell bytes (vector loads) and the meta line (scalar loads) leave together; only the draws wait for their count.
     // Whether the frame is a fat one is asked AFTER the lean preamble (a few wasted instructions for the rare fat frame,
@@ -1518,6 +1530,7 @@ __global__ void __launch_bounds__(64 * kRenderWaves, PG_COINRUN_RENDER_WAVES) re
     prep_cells_expand<kGrid>(L, two, kind_off, half, lane);  // kind bytes → byte offsets of the kinds' textures
     const ComposeRegs R = prep_regs<kGrid>(M, colw, roww, 0u, lane);
     __syncthreads();  // the cell table is complete
+    PG_TL(1);
     if ((flags & (1 | kDebugNoPrepass)) || M.fat()) {  // (wave-uniform)
         render_full(s, atlas, io, flags, env, fb, L);
         return;
@@ -1525,9 +1538,19 @@ __global__ void __launch_bounds__(64 * kRenderWaves, PG_COINRUN_RENDER_WAVES) re
     const int row_lo = half * (kObsH / halves), row_hi = (half + 1) * (kObsH / halves);
     // (the PG_ABL tests are timing experiments of the -DPG_ABLATE build: constants 0 in the product)
     ReplayState<4> sprite_pass = replay_begin(atlas, mine, PG_ABL(flags, 2) ? 0ull : __ballot(has), lane, row_lo, row_hi);
+    PG_TL(2);
     if (!PG_ABL(flags, 4)) compose_rows_from<kGrid, false, false>(fb, L, atlas, R, lane, flags, half, halves);
+    PG_TL(3);
     replay_finish(fb, atlas, mine, sprite_pass, lane, row_lo, row_hi);
+    PG_TL(4);
     if (!PG_ABL(flags, 8)) wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, row_lo, row_hi);
+#if defined(PG_TIMELINE)
+    PG_TL(5);
+    if (lane == 0) {
+        unsigned long long* out = reinterpret_cast<unsigned long long*>(io.obs + size_t(env) * kObsBytes + half * (kObsBytes / 2));
+        for (int k = 0; k < 6; k++) out[k] = tl[k];
+    }
+#endif
 }
 
 // cenv_render's frame (coinrun.cpp:393-411 → render_game(false), :443-470) for one env: pg_frame.h.

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where a wavefront of a render kernel spends its life.  A -DPG_TIMELINE build of the game (tools/build_exp.py GAME tl
--DPG_TIMELINE; chaser.hip and jumper.hip carry the stamps) reads s_memtime at the ends of its phases — after waiting for
+-DPG_TIMELINE; chaser.hip, jumper.hip, coinrun.hip and bossfight.hip carry the stamps) reads s_memtime at the ends of its phases — after waiting for
 everything outstanding — and leaves the stamps in the first bytes of the rows it stored.  Prints the mean length of each
 phase per wave (upper / lower rows) in shader clocks and as a share of the wave's life.
 
@@ -18,7 +18,9 @@ from engine_util import EngineVec  # noqa: E402
 
 PHASES = {
     "jumper": ["pre-pass loads, cell table", "row loop", "compass resolve", "sprites + bunny", "ring overlay", "needle + bar", "store"],
-    "chaser": ["list + state loads", "cell table, points", "row loop", "first pass: fetch + keep", "draws", "store"],
+    "chaser": ["list + state loads", "base layer copy", "point stamps", "first pass: fetch + keep", "draws", "store"],
+    "coinrun": ["hand-off loads, cell table", "first sprite texels requested", "row loop", "sprite replay", "store"],
+    "bossfight": ["hand-off loads", "background", "boss bullets", "second list (ship, shield, shots, agent)", "store"],
 }
 game, lib = sys.argv[1], sys.argv[2]
 names = PHASES[game]
