@@ -1492,6 +1492,15 @@ __global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView 
 
 // render_game(true) (coinrun.cpp:443-470): one workgroup of two wavefronts per env.  A lean frame starts from what
 // setup_kernel left: one word per pixel column and row, the cell table as kind bytes, its visible draws resolved.
+// (Measured and rejected, round 5 — the frame's wavefront waits 6 600 of its 22 000 clocks for its hand-off,
+// profiles/r05_wave_timelines.txt, and two ways of hiding that were built, both bit-exact:
+//  * a PERSISTENT form — as many workgroups as the device holds, each drawing env after env and asking for the next env's
+//    hand-off while it draws this one; handed-back frames drawn first, from a list: 0.41 ms against 0.33 at any register
+//    budget.  A wavefront's vector-memory counter retires in issue order, stores included, so the next frame's first wait
+//    for a texel also waits for this frame's 24 streaming stores to be acknowledged — what a workgroup that ends never does;
+//  * the draws fetched before their count is known (the first 16 / 24 / 64 lanes unconditionally, the rest in a second trip
+//    when there are more): 0.352 / 0.368 / 0.400 ms against 0.335 — most frames have more than 24 draws, sparks mostly, and
+//    then make both trips.)
 __global__ void __launch_bounds__(64 * kRenderWaves, PG_COINRUN_RENDER_WAVES) render_kernel(State s, AtlasView atlas, const uint8_t* mask,
                                                                    StepIO io, int flags) {
     const int env = blockIdx.x;
