@@ -1,6 +1,7 @@
 cd $GRAFT_REPO_ROOT
-python tools/perf_quick.py --games coinrun --check 256x300 2>&1 | tail -1
+python tools/perf_quick.py --games chaser --check 256x400 2>&1 | tail -1
 for rep in 1 2; do
-python tools/perf_quick.py --games coinrun --check 0x0 --settle 600 --steps 256 2>&1 | tail -1 | sed "s/^/sure 24: /"
-for v in sure0 sure16 sure64; do python tools/perf_quick.py --games coinrun --check 0x0 --settle 600 --steps 256 --lib procgen2_amd/lib/libpg_exp_$v.so 2>&1 | tail -1 | sed "s/^/$v: /"; done
+python tools/perf_quick.py --games chaser --check 0x0 --settle 600 --steps 256 2>&1 | tail -1 | sed "s/^/rgb base: /"
+python tools/perf_quick.py --games chaser --check 0x0 --settle 600 --steps 256 --lib procgen2_amd/lib/libpg_exp_words.so 2>&1 | tail -1 | sed "s/^/word base: /"
 done
+timeout 1500 python -m pytest tests -m gpu -x -q -k "chaser or snapshot or mixed or modes" 2>&1 | tail -3
