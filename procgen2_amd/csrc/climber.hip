@@ -509,10 +509,14 @@ __global__ void __launch_bounds__(64) make_kernel(State s, uint32_t seed_base, i
 
 __global__ void __launch_bounds__(64, PG_CLIMBER_WAVES) logic_kernel(State s, const int32_t* actions, uint32_t run_seed,
                                                                      uint32_t step_index, int env_offset, StepIO io, int prefetch, LevelPlan plan) {
-    __shared__ StepLds lds[64 / kGang];
+    // One block is EITHER a row of gangs stepping their envs (StepLds each) OR the install row (a Level staged on its way from
+    // the shadow slot to the live state): the same LDS serves both — as two arrays the logic blocks carried the Level's
+    // 2–3 KB for nothing and fewer of them fitted a CU (caveflyer: 11.8 KB a block, 13 blocks instead of 16).
+    constexpr size_t kLdsBytes = sizeof(StepLds) * (64 / kGang) > sizeof(Level) ? sizeof(StepLds) * (64 / kGang) : sizeof(Level);
+    __shared__ alignas(16) unsigned char lds_bytes[kLdsBytes];
+    StepLds* const lds = reinterpret_cast<StepLds*>(lds_bytes);
     if (blockIdx.y == 1) {  // (block-uniform) the auto-resets whose level lies ready: a copy, beside the envs that step (pg_prefetch.h)
-        __shared__ Level lv;
-        install_prefetched<Gen>(s, blockIdx.x * (64 / kGang), 64 / kGang, prefetch, io, plan, lv, threadIdx.x, reset_served_mark(step_index), reset_due_mark(step_index));
+        install_prefetched<Gen>(s, blockIdx.x * (64 / kGang), 64 / kGang, prefetch, io, plan, *reinterpret_cast<Level*>(lds_bytes), threadIdx.x, reset_served_mark(step_index), reset_due_mark(step_index));
         return;
     }
     const int env = (blockIdx.x * 64 + threadIdx.x) / kGang;
