@@ -1045,6 +1045,28 @@ def test_step_many_synthetic_equals_stepping_the_envs_one_by_one():
     assert (step_ms > 0).all() and (render_ms > 0).all() and (render_ms <= step_ms * 1.05).all()
     total_ms, _ = e.timed_steps(32, 3)
     assert 0.3 * total_ms < float(step_ms.sum()) < 3.0 * total_ms, (float(step_ms.sum()), total_ms)
+    # pgv_step_phases: the same step cut in four by events on the stream — the parts are non-negative and add up to the step
+    ph = e.step_phases(16, 3)
+    assert set(ph) == {"step", "logic", "prepass", "render", "late"} and all(v.shape == (16,) for v in ph.values())
+    parts = ph["logic"] + ph["prepass"] + ph["render"] + ph["late"]
+    assert (ph["logic"] > 0).all() and (ph["render"] > 0).all() and (ph["prepass"] >= 0).all() and (ph["late"] >= 0).all()
+    assert np.allclose(parts, ph["step"], rtol=0.02, atol=0.005), (parts, ph["step"])
+    # … and of all seven games side by side (the mixed bench line's window); the rollout it makes is the one
+    # step_many_synthetic makes
+    from procgen2_amd.vec_env import step_phases_many
+    snaps = [x.save_state() for x in envs]
+    many_ms = step_phases_many(envs, 8, 3)
+    for x in envs:
+        x.sync()
+    assert many_ms.shape == (len(envs), 5, 8) and (many_ms[:, 0] > 0).all() and (many_ms[:, 3] > 0).all()
+    assert np.allclose(many_ms[:, 1:].sum(axis=1), many_ms[:, 0], rtol=0.02, atol=0.005)
+    after_phases = tuple(t.cpu().numpy().copy() for t in slab)
+    for x, snap in zip(envs, snaps):
+        x.load_state(snap)
+    step_many_synthetic(envs, 8, 3)
+    for x in envs:
+        x.sync()
+    assert all(np.array_equal(a, t.cpu().numpy()) for a, t in zip(after_phases, slab))
     for e in envs:
         e.close()
     torch.cuda.synchronize()
