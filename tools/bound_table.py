@@ -15,6 +15,14 @@ Units (MI355X: 256 CUs, 1 024 SIMDs, 8 XCDs):
   TD          TD_TD_BUSY_sum / (256 x cycles)
   memory      (2 x FETCH_SIZE + WRITE_SIZE) KB, the gfx950 correction of MI355X_MICROARCH.md, / duration / the box's measured copy rate
   wait        SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES: share of a wave's life spent waiting to issue
+
+A second table prices the kernel's own counts with measured unit costs, as if each unit worked alone (µs):
+  t_valu      SQ_INSTS_VALU x 4.5 clocks / (1 024 SIMDs x clock)        (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 4.4–4.6 in every kernel here)
+  t_gather    SQ_INSTS_VMEM_RD x 17 clocks / (256 CUs x clock)          (tools/probe/gather_rate.hip: 13–17 clocks a wave-level load over <= 8 lines,
+                                                                         21 with few lanes active, 45 over 64 L1-resident lines: 17 is the floor of a gather)
+  t_lds       SQ_INSTS_LDS x 6 clocks / (256 CUs x clock)               (gather_rate.hip: ds_read_b32 4.3–5.9; wider reads more)
+  t_bytes     corrected bytes / the box's copy rate
+and names the largest beside the measured time: where measured >> every t_*, the kernel is a chain of waits, not a throughput.
 """
 import json
 import sys
@@ -82,6 +90,32 @@ def main():
             print("| %s | %s | %.1f | %.0f | %s | %s | %s | %s | %s | %s | %s | %s | %s |" % (
                 game, short, dur / 1e3, waves, per_wave, cell("VALU"), cell("scalar"), cell("LDS", conflict), cell("TA"), cell("TD"),
                 cell("memory"), tr, wait))
+    print()
+    print("## The same kernels priced by their own counts (µs, each unit as if alone; clock from GRBM_GUI_ACTIVE)\n")
+    print("Caveats.  t_bytes takes FETCH_SIZE doubled, the guide's correction for wide coalesced loads; for scattered dword gathers it may "
+          "count twice — with one backdrop for every env coinrun's render kernel loses 37 % of these bytes and 5 % of its time "
+          "(DESIGN.md §3), so `bytes` as the largest entry is an upper bound, not a verdict.  t_gather prices every vector-memory read at "
+          "the 17-clock floor; a gather over many lines costs more (gather_rate.hip), a coalesced load less.  measured ÷ largest near 1.2–1.5 "
+          "with three entries within a factor of two of each other is what a balanced kernel looks like; 2.5 and more is a chain of "
+          "round trips on too few wavefronts (the logic kernels, the level kernels).\n")
+    print("| game | kernel | measured µs | t_valu | t_gather (17 clk) | t_lds (6 clk) | t_bytes | largest | measured ÷ largest |")
+    print("|---|---|---|---|---|---|---|---|---|")
+    for game, kernels in raw.items():
+        for name, c in sorted(kernels.items(), key=lambda kv: -kv[1].get("duration_ns", 0)):
+            dur = c.get("duration_ns", 0.0)
+            if dur < 4000 or not c.get("GRBM_GUI_ACTIVE") or not c.get("SQ_WAVES"):
+                continue
+            short = name.split("::")[-1] if "level_kernel" not in name else "level_kernel (install / generator)"
+            clock = c["GRBM_GUI_ACTIVE"] / 8.0 / dur  # cycles per ns = GHz
+            t = {"valu": c.get("SQ_INSTS_VALU", 0) * 4.5 / (SIMDS * clock) / 1e3,
+                 "gather": c.get("SQ_INSTS_VMEM_RD", 0) * 17.0 / (CUS * clock) / 1e3,
+                 "lds": c.get("SQ_INSTS_LDS", 0) * 6.0 / (CUS * clock) / 1e3}
+            if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                t["bytes"] = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 / (copy_gbps * 1e9) * 1e6
+            top = max(t, key=t.get)
+            print("| %s | %s | %.1f | %.1f | %.1f | %.1f | %s | %s | %.2f |" % (
+                game, short, dur / 1e3, t["valu"], t["gather"], t["lds"], ("%.1f" % t["bytes"]) if "bytes" in t else "–", top,
+                dur / 1e3 / t[top] if t[top] else 0.0))
     print()
 
 
