@@ -784,18 +784,19 @@ __global__ void __launch_bounds__(64) make_kernel(State s, uint32_t seed_base, i
 // A — lane = env: the agent's sub-steps into the scratch table (envs that reset in this step sit it out) — blockIdx.y == 0;
 // blockIdx.y == 1: the auto-reset of those envs whose next level lies ready in its shadow slot (pg_prefetch.h
 // install_prefetched: a copy), beside the agents instead of in a launch in front of them.  An env is looked at by one
-// lane of each row; the rows share nothing but its pending byte, which row 0 only reads and row 1 only ever turns from 1
-// into 2 — "not 0" either way.  resolve_kernel puts the 2 back to 0.
+// lane of each row; the rows share nothing but its pending byte, which row 0 only reads and row 1 only ever turns from
+// "due in this step" into "served in this step" — a reset either way (pg_prefetch.h resets_in_step).
 __global__ void __launch_bounds__(64) agent_kernel(State s, const int32_t* actions, uint32_t run_seed,
                                                    uint32_t step_index, int env_offset, StepIO io, int prefetch, LevelPlan plan) {
     if (blockIdx.y == 1) {  // (block-uniform)
         __shared__ Level lv;
-        install_prefetched<Gen>(s, blockIdx.x * blockDim.x, blockDim.x, prefetch, io, plan, lv, threadIdx.x);
+        install_prefetched<Gen>(s, blockIdx.x * blockDim.x, blockDim.x, prefetch, io, plan, lv, threadIdx.x,
+                                reset_served_mark(step_index), reset_due_mark(step_index));
         return;
     }
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= s.n) return;
-    if (io.pending[env] != 0) {  // the caller's `if term: env.reset()` (game_test.py:38-40): this step is the env's reset
+    if (resets_in_step(io.pending[env], step_index)) {  // the caller's `if term: env.reset()` (game_test.py:38-40): this step is the env's reset
         SCI(s, SC_BITS, env) = 0;  // did not step: B and C leave this env alone
         return;
     }
@@ -866,14 +867,23 @@ __global__ void __launch_bounds__(64) entity_kernel(State s) {
 // word and the last one resolves the block's 64 envs.  Bit-exact; with relaxed agent-scope atomics and a workgroup-scope
 // release 125.6 against 128.3 M env-steps/s — 73 728 atomics cost more than a 6-µs kernel and its boundary; with
 // __threadfence() and an acq_rel count, an L2 write-back per wavefront, the step took 2.86 ms.)
-__global__ void __launch_bounds__(64) resolve_kernel(State s, StepIO io) {
+// blockIdx.y == 1 (64 lanes): the auto-resets that agent_kernel's install row could not serve — no level lay ready, an
+// episode shorter than the generator's latency — generated here, synchronously (pg_prefetch.h level_serve, mode 2), in this
+// launch instead of in one of its own between agent_kernel and entity_kernel: in steady state that launch found nothing
+// and cost the step its 6 µs and a kernel boundary.  Nothing in between needs those envs' new levels (agent_kernel has
+// zeroed their SC_BITS: entity_kernel and row 0 here leave them alone); the pre-pass behind this launch does.  The byte
+// carries the step's parity (pg_prefetch.h reset_due_mark): row 0 writes "due in step t + 1" for an env that terminates
+// now, which row 1, looking for "due in step t" in the same launch, does not take for its own.
+__global__ void __launch_bounds__(64) resolve_kernel(State s, StepIO io, uint32_t step_index, int prefetch, LevelPlan plan) {
+    if (blockIdx.y == 1) {  // (block-uniform)
+        level_serve<Gen>(s, 2, 64, prefetch, 0u, 0, nullptr, nullptr, io, plan, reset_served_mark(step_index),
+                         reset_due_mark(step_index), static_cast<int>(blockIdx.x) * 64, static_cast<int>(threadIdx.x));
+        return;
+    }
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= s.n) return;
     const int bits = SCI(s, SC_BITS, env);
-    if (bits >= 0) {  // reset this step (reward / done are written with the install): the flag goes back to "nothing pending"
-        io.pending[env] = 0;
-        return;
-    }
+    if (bits >= 0) return;  // reset this step: reward / done are written with the install, the byte's mark expires by itself
     const int flags = SI(s, I_FLAGS, env);
     const int src = (flags & kFlagBuf) ? 1 : 0;
     const int hazard = SCI(s, SC_HAZARD, env);
@@ -899,7 +909,7 @@ __global__ void __launch_bounds__(64) resolve_kernel(State s, StepIO io) {
     const bool terminated = !alive || got_coin;  // coinrun.cpp:366
     io.reward[env] = got_coin * 10.0f;           // coinrun.cpp:364, last executed sub-step only (D4)
     io.done[env] = terminated ? 1 : 0;
-    io.pending[env] = terminated ? 1 : 0;
+    io.pending[env] = terminated ? reset_due_mark(step_index + 1u) : 0;
 }
 
 // render_game(true) (coinrun.cpp:443-470): one workgroup of two wavefronts per env (pg_render.h).
@@ -1763,15 +1773,21 @@ class CoinrunGame final : public Game {
         // the auto-resets: a prefetched level is installed beside the agents (agent_kernel's second row of blocks); the
         // level kernel behind it generates, synchronously, the levels that were not ready — none in steady state
         const bool fused = prefetch() && install_in_logic();
-        if (!fused) LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io, plan);
+        const int served = reset_served_mark(step_index), due = reset_due_mark(step_index);
+        if (!fused) LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io, plan, PG_RESET_SPAN, served, due);
         hipLaunchKernelGGL(agent_kernel, dim3(logic_blocks(s_.n), fused ? 2 : 1), dim3(logic_lanes()), 0, st, s_, actions, run_seed,
                            step_index, env_offset, io, prefetch(), plan);
         // (Measured and rejected, round 5: that level kernel on a stream of its own beside the entities — forked behind
         // agent_kernel, joined in front of resolve_kernel — so that its 6 µs and its kernel boundary leave the main stream:
         // 123.6 against 126.7 M env-steps/s, three same-box pairs; the two event hand-overs cost more than they hide.)
-        if (fused) LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io, plan);
+        // The unprepared ones ride in resolve_kernel's second row (see there); with fewer than 64 lanes per logic block
+        // (PG_LOGIC_LANES, experiments) or PG_LATE_LAUNCH=1 (the A/B) they keep the launch of their own.
+        static const bool late_launch = [] { const char* e = std::getenv("PG_LATE_LAUNCH"); return e && e[0] == '1'; }();
+        const bool late_row = fused && logic_lanes() == 64 && !late_launch;
+        if (fused && !late_row) LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io, plan, PG_RESET_SPAN, served, due);
         hipLaunchKernelGGL(entity_kernel, dim3((s_.n + 63) / 64, 2 * kMaxEnt), dim3(64), 0, st, s_);
-        hipLaunchKernelGGL(resolve_kernel, dim3(logic_blocks(s_.n)), dim3(logic_lanes()), 0, st, s_, io);
+        hipLaunchKernelGGL(resolve_kernel, dim3(logic_blocks(s_.n), late_row ? 2 : 1), dim3(logic_lanes()), 0, st, s_, io,
+                           step_index, prefetch(), plan);
     }
     bool launch_frame(hipStream_t st, int env, uint32_t* d_px, int w, int h) override {
         hipLaunchKernelGGL(frame_kernel, dim3(1), dim3(kFrameThreads), 0, st, s_, atlas_, env, FrameTarget{d_px, w, h});

@@ -83,16 +83,13 @@ struct HasServed<G, decltype(static_cast<void>(&G::served))> {
 // `due_mark` / `served_mark`: what mode 2 looks for in StepIO::pending and what it leaves there for an env it has served —
 // 1 and 2, or reset_due_mark(step) / reset_served_mark(step) for the games whose logic kernel runs the prefetched installs
 // in its own grid (install_prefetched below).
+// The body is a device function (one wavefront of 64 lanes serving the envs [base, base + span)) so that a game can also
+// run mode 2 as a row of blocks of one of its own kernels (coinrun: resolve_kernel's blockIdx.y == 1).
 template <class G>
-__global__ void __launch_bounds__(64) level_kernel(typename G::State s, int mode, int span, int prefetch,
-                                                   uint32_t seed_base, int env_offset, const uint8_t* mask,
-                                                   const int32_t* seeds, StepIO io, LevelPlan plan, int served_mark, int due_mark) {
+PG_D void level_serve(const typename G::State& s, int mode, int span, int prefetch, uint32_t seed_base, int env_offset,
+                      const uint8_t* mask, const int32_t* seeds, StepIO io, LevelPlan plan, int served_mark, int due_mark,
+                      int base, int lane) {
     using Level = typename G::Level;
-    // A level is one long dependent chain per wavefront; whatever shares its SIMD (a logic kernel running beside an
-    // in-step reset, a render kernel beside the prefetcher) is many short ones: let the chain issue first.
-    __builtin_amdgcn_s_setprio(3);
-    const int lane = threadIdx.x;
-    const int base = blockIdx.x * span;
     bool want = false;
     if (lane < span && base + lane < s.n) {
         const int e = base + lane;
@@ -195,6 +192,17 @@ __global__ void __launch_bounds__(64) level_kernel(typename G::State s, int mode
     }
 }
 
+template <class G>
+__global__ void __launch_bounds__(64) level_kernel(typename G::State s, int mode, int span, int prefetch,
+                                                   uint32_t seed_base, int env_offset, const uint8_t* mask,
+                                                   const int32_t* seeds, StepIO io, LevelPlan plan, int served_mark, int due_mark) {
+    // A level is one long dependent chain per wavefront; whatever shares its SIMD (a logic kernel running beside an
+    // in-step reset, a render kernel beside the prefetcher) is many short ones: let the chain issue first.
+    __builtin_amdgcn_s_setprio(3);
+    level_serve<G>(s, mode, span, prefetch, seed_base, env_offset, mask, seeds, io, plan, served_mark, due_mark,
+                   static_cast<int>(blockIdx.x) * span, static_cast<int>(threadIdx.x));
+}
+
 // The copy-only part of an auto-reset (mode 2 above, slot kSlotReady) as a device function, for a game that runs it
 // INSIDE the grid of its first logic kernel instead of as a launch in front of it (round 5, coinrun: blockIdx.y == 1 of
 // agent_kernel).  An env that resets does not step, so its install and the other envs' agents have nothing to wait for
@@ -215,8 +223,8 @@ __global__ void __launch_bounds__(64) level_kernel(typename G::State s, int mode
 // So the marks carry the parity of the step they are about: reset_due_mark(t) = 4 | t mod 2, written by the logic lane of
 // step t − 1; reset_served_mark(t) = 2 | t mod 2, written by whoever serves the env in step t.  In step t, due(t) and
 // served(t) mean reset; anything else — 0, served(t − 1) — means step, and the logic lane overwrites it with its verdict.
-// Nothing has to clear a mark.  (coinrun's byte is written by resolve_kernel, two launches behind the install row: plain 1
-// and 2 there, and resolve_kernel clears the 2.)
+// Nothing has to clear a mark.  (coinrun writes the byte in resolve_kernel, whose second row of blocks generates the
+// levels that were not ready — level_serve, mode 2 — beside the lanes that write it: the same two races, the same marks.)
 PG_HD int reset_due_mark(uint32_t step_index) { return 4 | static_cast<int>(step_index & 1u); }
 PG_HD int reset_served_mark(uint32_t step_index) { return 2 | static_cast<int>(step_index & 1u); }
 PG_HD bool resets_in_step(int pending, uint32_t step_index) {
