@@ -14,18 +14,18 @@
 // reference's std::unordered_set-based systems is recomputed at reset with pg_order.h and stored as two
 // small permutations (sprite draw order, particle-owner order).
 //
-// One lane per env gives only 1 024 waves at 65 536 envs (one per SIMD), so the step is cut into three launches
-// that expose more parallelism and few dependent memory round trips, while producing the reference's sub-step
-// interleaving exactly:
-//   A. agent_kernel (lane = env): the auto-reset, or the agent's four sub-steps — they depend on tiles only —
-//      leaving a snapshot per sub-step in a scratch table;
-//   B. entity_kernel (lane = env, blockIdx.y = entity slot): every entity simulates all its sub-steps (mob walk +
-//      particles + animation) with its state in registers and tests its box against the agent's box of the
-//      same sub-step; tile lookups of a whole collide() come from a 4×4 window fetched in one go and packed
-//      3 bits per cell into a 64-bit word; results go to the *other* half of a double-buffered entity table;
-//   C. resolve_kernel (lane = env): the first sub-step that terminates (hazard, lava, coin) decides how many
-//      sub-steps really happened; in the rare case that is fewer than four, that env's entities are redone from
-//      the untouched half with that limit.  Writes reward / done and commits the agent.
+// One lane per env gives only 1 024 waves at 65 536 envs (one per SIMD), so the step is cut into parts that expose more
+// parallelism and few dependent memory round trips, while producing the reference's sub-step interleaving exactly:
+//   A. the agents (logic_kernel row 0, lane = env): the agent's four sub-steps — they depend on tiles only — leaving a
+//      snapshot per sub-step in a scratch table;
+//   B. the entities (logic_kernel rows 2…, lane = env, row = entity slot — the SAME launch: they do not react to the
+//      agent): every entity simulates all its sub-steps (mob walk + particles + animation) with its state in registers;
+//      tile lookups of a whole collide() come from a 4×4 window fetched in one go and packed 3 bits per cell into a
+//      64-bit word; results go to the *other* half of a double-buffered entity table, a mob's x per sub-step to scratch;
+//   C. resolve_kernel (lane = env): holds the hazards' boxes against the agent's, sub-step by sub-step; the first sub-step
+//      that terminates (hazard, lava, coin) decides how many sub-steps really happened; in the rare case that is fewer
+//      than four, that env's entities are redone from the untouched half with that limit.  Writes reward / done and
+//      commits the agent.
 #include "../../include/procgen2_vec.h"
 #include "pg_engine.h"
 #include "pg_frame.h"
@@ -104,18 +104,21 @@ struct State {
     float* spark;    // [2][n][kMaxEnt][3][kSparkRow]     x, y, life — a mob's thirty values are 144 contiguous bytes: the entity
                      //                                   kernel's (env, mob) lanes and the render wave's spark lanes both read a
                      //                                   couple of cache lines instead of one per value
-    float* scratch;  // [SC_COUNT][n]                     hand-off between the three logic kernels of a step
+    float* scratch;  // [SC_COUNT][n]                     hand-off between the logic kernels of a step
+    float4* hazx;    // [kMaxEnt][n]                      a hazard's box after each of the four sub-steps: its left edges;
+    float2* hazy;    // [kMaxEnt][n]                      top edge and height.  Left by the entity lanes that come near the
+                     //                                   agent (hazard_near) for resolve_kernel
     uint32_t no;     // generator switches turned off (PGV_COINRUN_NO_*: coinrun/tilemap.h:42-45 allow_* = false)
     PrepOut prep;    // what setup_kernel leaves for render_kernel (pg_prepass.h); not part of the state blob
 };
 
 // scratch rows: the agent after each of the 4 sub-steps, then one word of flags
 enum {
-    SC_AX = 0, SC_AY = 4, SC_AVX = 8, SC_AVY = 12, SC_PHASE = 16, SC_BITS = 20, SC_HAZARD = 21, SC_REDO = 22, SC_COUNT = 23
+    SC_AX = 0, SC_AY = 4, SC_AVX = 8, SC_AVY = 12, SC_PHASE = 16, SC_BITS = 20, SC_REDO = 21, SC_CAND = 22, SC_COUNT = 24
 };
 // SC_BITS (int): per sub-step ss: ground 1<<ss, forward 1<<(4+ss), lava 1<<(8+ss), coin 1<<(12+ss); bit 31: this env
-// stepped (as opposed to: performed its auto-reset) in the current vector step.
-// SC_HAZARD (int): bit ss set by entity_kernel when a hazard overlaps the agent in sub-step ss.
+// stepped (as opposed to: performed its auto-reset) in the current vector step; bit 30 (kBitsFar): see hazard_near.
+// SC_CAND, SC_CAND + 1 (int): bit e — entity slot e left its hazard boxes for resolve_kernel, which clears the words.
 // SC_REDO (int): n > 0 — the step ended after n < 4 sub-steps; the entities (advanced by four, optimistically) are
 // recomputed for n sub-steps from the untouched half of the table by the env's render wavefront, one lane per entity.
 
@@ -596,41 +599,49 @@ struct AgentSnap {  // agent + camera after one sub-step
     bool ground, forward;
 };
 
-// One entity, `limit` sub-steps, reading half `src` and writing half `1 - src` of the dynamic table.
-// body_x/body_y[ss] = the agent's box origin after its sub-step ss.  Returns a bit per sub-step in which this
-// entity, a hazard, overlaps the agent (the reference ORs over its hazard set, so set order is irrelevant — App. B).
-PG_D int entity_step(const State& s, int env, int e, int src, int limit, const float (&body_x)[4],
-                     const float (&body_y)[4]) {
+// One entity, `limit` sub-steps, reading half `src` and writing half `1 - src` of the dynamic table.  Nothing here looks
+// at the agent: the entities of coinrun do not react to it, and whether one of them, a hazard, overlaps it in a sub-step is
+// decided by resolve_kernel (hazard_bits below) from hb: the left edge of the entity's hazard box after sub-step ss
+// (ss < limit), [4] its top edge — 1e30 for the coin, no hazard — and [5] its height.  kStore = false: the boxes only,
+// nothing written (resolve_kernel's fallback).
+template <bool kStore = true>
+PG_D void entity_step(const State& s, int env, int e, int src, int limit, float (&hb)[6]) {
     const uint8_t* tiles = s.tiles + size_t(env) * (W * H);
     const int dst = 1 - src;
     const float dt = 1.0f / 4;
-    int hits = 0;
     const int kind = EB(s, EB_KIND, e, env);
     if (kind == kCoin) {  // no dynamic state beyond the texture flag
-        DF(s, dst, DF_X, e, env) = DF(s, src, DF_X, e, env);
-        DB(s, dst, e, env) = DB(s, src, e, env);
-        return 0;
+        if constexpr (kStore) {
+            DF(s, dst, DF_X, e, env) = DF(s, src, DF_X, e, env);
+            DB(s, dst, e, env) = DB(s, src, e, env);
+        }
+        hb[0] = hb[1] = hb[2] = hb[3] = hb[5] = 0.0f;
+        hb[4] = 1e30f;
+        return;
     }
     float x = DF(s, src, DF_X, e, env);
     const float y = EY(s, e, env);
     float anim_t = DF(s, src, DF_ANIM_T, e, env);
     int dyn = DB(s, src, e, env);
     if (kind == kSaw) {
-        const Box hb{x + -0.5f, y + -0.5f, 1.0f, 1.0f};  // tilemap.cpp:66
+        hb[0] = hb[1] = hb[2] = hb[3] = x + -0.5f;  // tilemap.cpp:66: Box{x - 0.5, y - 0.5, 1, 1}
+        hb[4] = y + -0.5f;
+        hb[5] = 1.0f;
 #pragma unroll
         for (int ss = 0; ss < 4; ss++) {
             if (ss >= limit) break;
-            if (box_hit(Box{body_x[ss], body_y[ss], 1.0f, 1.0f}, hb)) hits |= 1 << ss;
             // System_Sprite_Render::update (common_systems.cpp:14-29), rate 1.0 (tilemap.cpp:60)
             anim_t += dt;
             const int adv = static_cast<int>(anim_t * 1.0f);
             anim_t -= adv / 1.0f;
             dyn = ((dyn & ~kDynFrame) | ((((dyn & kDynFrame) ? 1 : 0) + adv) % 2 ? kDynFrame : 0)) | kDynTexSet;
         }
-        DF(s, dst, DF_X, e, env) = x;
-        DF(s, dst, DF_ANIM_T, e, env) = anim_t;
-        DB(s, dst, e, env) = static_cast<uint8_t>(dyn);
-        return hits;
+        if constexpr (kStore) {
+            DF(s, dst, DF_X, e, env) = x;
+            DF(s, dst, DF_ANIM_T, e, env) = anim_t;
+            DB(s, dst, e, env) = static_cast<uint8_t>(dyn);
+        }
+        return;
     }
     // --- mob: System_Mob_AI (common_systems.cpp:65-105) + System_Particles (:284-313) + animation, rate 0.2
     float vx = DF(s, src, DF_VX, e, env);
@@ -638,9 +649,9 @@ PG_D int entity_step(const State& s, int env, int e, int src, int limit, const f
     float sx[kSparks], sy[kSparks], sl[kSparks];
 #pragma unroll
     for (int k = 0; k < kSparks; k++) {
-        sx[k] = SP(s, src, 0, e, k, env);
-        sy[k] = SP(s, src, 1, e, k, env);
-        sl[k] = SP(s, src, 2, e, k, env);
+        sx[k] = kStore ? SP(s, src, 0, e, k, env) : 0.0f;
+        sy[k] = kStore ? SP(s, src, 1, e, k, env) : 0.0f;
+        sl[k] = kStore ? SP(s, src, 2, e, k, env) : 0.0f;
     }
     // both sensors of all sub-steps live inside this window (x drifts by at most 0.15 per step)
     const TileWin win = TileWin::fetch(tiles, static_cast<int>(floorf(x - 0.66f)), static_cast<int>(floorf(y - 0.6f)));
@@ -660,8 +671,7 @@ PG_D int entity_step(const State& s, int env, int e, int src, int limit, const f
         if (wall.any || gap.any) vx *= -1.0f;
         dyn = (dyn & ~kDynFlip) | (vx > 0.0f ? kDynFlip : 0);
 
-        const Box hb{x + -0.5f, y + -0.48f, 1.0f, 0.98f};  // tilemap.cpp:89
-        if (box_hit(Box{body_x[ss], body_y[ss], 1.0f, 1.0f}, hb)) hits |= 1 << ss;
+        hb[ss] = x + -0.5f;  // tilemap.cpp:89: Box{x - 0.5, y - 0.48, 1, 0.98}
 
         int dead = -1;
 #pragma unroll
@@ -685,27 +695,65 @@ PG_D int entity_step(const State& s, int env, int e, int src, int limit, const f
         anim_t -= adv / 0.2f;
         dyn = ((dyn & ~kDynFrame) | ((((dyn & kDynFrame) ? 1 : 0) + adv) % 2 ? kDynFrame : 0)) | kDynTexSet;
     }
-    DF(s, dst, DF_X, e, env) = x;
-    DF(s, dst, DF_VX, e, env) = vx;
-    DF(s, dst, DF_ANIM_T, e, env) = anim_t;
-    DF(s, dst, DF_SPAWN_T, e, env) = timer;
-    DB(s, dst, e, env) = static_cast<uint8_t>(dyn);
+    if constexpr (kStore) {
+        DF(s, dst, DF_X, e, env) = x;
+        DF(s, dst, DF_VX, e, env) = vx;
+        DF(s, dst, DF_ANIM_T, e, env) = anim_t;
+        DF(s, dst, DF_SPAWN_T, e, env) = timer;
+        DB(s, dst, e, env) = static_cast<uint8_t>(dyn);
 #pragma unroll
-    for (int k = 0; k < kSparks; k++) {
-        SP(s, dst, 0, e, k, env) = sx[k];
-        SP(s, dst, 1, e, k, env) = sy[k];
-        SP(s, dst, 2, e, k, env) = sl[k];
+        for (int k = 0; k < kSparks; k++) {
+            SP(s, dst, 0, e, k, env) = sx[k];
+            SP(s, dst, 1, e, k, env) = sy[k];
+            SP(s, dst, 2, e, k, env) = sl[k];
+        }
     }
+    hb[4] = y + -0.48f;
+    hb[5] = 0.98f;
+}
+
+// Which hazards can touch the agent at all is decided before anyone knows where the agent goes: an entity lane compares
+// its boxes with the agent's box at the START of the step, grown by kReachX / kReachY to every side, and only an entity
+// that comes near leaves its boxes (hazx / hazy) and its bit in the env's candidate words (SC_CAND) for resolve_kernel —
+// a few in a hundred.  The agent's lane checks the other half of the argument: that none of its four sub-steps took it
+// further than that from where it started (a sub-step moves it by at most 0.125 × 0.3875 — but a collision sets it against
+// a cell's edge, which no line of the code bounds by less than two cells).  Where that fails — it has not in any run —
+// SC_BITS says so (kBitsFar) and resolve_kernel works every box of the env out again, from the half of the table the
+// entity lanes read.  Either way the bits are the reference's.  kReachSlack: the comparisons are made in different float
+// expressions on the two sides (a rounding error is 1e-6 of it).
+constexpr float kReachX = 1.0f, kReachY = 2.0f, kReachSlack = 0.01f;
+constexpr int kBitsFar = 1 << 30;
+
+PG_D bool hazard_near(const float (&hb)[6], float ax0, float ay0, float reach_x, float reach_y) {
+    // the agent's box: Box{ax - 0.5, ay - 1, 1, 1} (common_systems.cpp:171)
+    const float x0 = ax0 - 0.5f - reach_x - kReachSlack, x1 = ax0 + 0.5f + reach_x + kReachSlack;
+    const float y0 = ay0 - 1.0f - reach_y - kReachSlack, y1 = ay0 + reach_y + kReachSlack;
+    if (!(hb[4] < y1 && hb[4] + hb[5] > y0)) return false;  // (the coin's 1e30 ends here)
+    bool near = false;
+#pragma unroll
+    for (int ss = 0; ss < 4; ss++) near = near || (hb[ss] < x1 && hb[ss] + 1.0f > x0);
+    return near;
+}
+
+// Bit ss: the hazard box hb overlaps the agent after sub-step ss (common_systems.cpp:241-251: the reference ORs over its
+// hazard set, so set order is irrelevant — App. B).
+PG_D int hazard_hits(const float (&hb)[6], const float (&bx)[4], const float (&by)[4]) {
+    int hits = 0;
+#pragma unroll
+    for (int ss = 0; ss < 4; ss++)
+        if (box_hit(Box{bx[ss], by[ss], 1.0f, 1.0f}, Box{hb[ss], hb[4], 1.0f, hb[5]})) hits |= 1 << ss;
     return hits;
 }
 
 // A: System_Agent::update ×4 (common_systems.cpp:121-252) minus the hazard loop, which needs the mobs.
-PG_D void agent_substeps(const State& s, int env, int action) {
+PG_D void agent_substeps(const State& s, int env, int action, float reach_x, float reach_y) {
     const uint8_t* tiles = s.tiles + size_t(env) * (W * H);
     const int n_ent = SI(s, I_NENT, env);
     const int flags = SI(s, I_FLAGS, env);
     const int src = (flags & kFlagBuf) ? 1 : 0;
     float ax = SF(s, F_AX, env), ay = SF(s, F_AY, env);
+    const float ax0 = ax, ay0 = ay;
+    bool stayed = true;  // within reach of where the step began (hazard_near)
     float avx = SF(s, F_AVX, env), avy = SF(s, F_AVY, env);
     float phase = SF(s, F_APHASE, env);
     bool ground = (flags & kFlagGround) != 0, forward = (flags & kFlagForward) != 0;
@@ -759,6 +807,7 @@ PG_D void agent_substeps(const State& s, int env, int action) {
         else if (move_x < 0.0f)
             forward = false;
 
+        stayed = stayed && fabsf(ax - ax0) <= reach_x && fabsf(ay - ay0) <= reach_y;
         SC(s, SC_AX + ss, env) = ax;
         SC(s, SC_AY + ss, env) = ay;
         SC(s, SC_AVX + ss, env) = avx;
@@ -767,8 +816,7 @@ PG_D void agent_substeps(const State& s, int env, int action) {
         bits |= (ground ? 1 << ss : 0) | (forward ? 1 << (4 + ss) : 0) | (lv.any ? 1 << (8 + ss) : 0) |
                 (box_hit(b, coin_box) ? 1 << (12 + ss) : 0);
     }
-    SCI(s, SC_BITS, env) = bits;
-    SCI(s, SC_HAZARD, env) = 0;
+    SCI(s, SC_BITS, env) = bits | (stayed ? 0 : kBitsFar);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -781,47 +829,60 @@ __global__ void __launch_bounds__(64) make_kernel(State s, uint32_t seed_base, i
     fresh_live(s, env);
 }
 
-// A — lane = env: the agent's sub-steps into the scratch table (envs that reset in this step sit it out) — blockIdx.y == 0;
-// blockIdx.y == 1: the auto-reset of those envs whose next level lies ready in its shadow slot (pg_prefetch.h
-// install_prefetched: a copy), beside the agents instead of in a launch in front of them.  An env is looked at by one
-// lane of each row; the rows share nothing but its pending byte, which row 0 only reads and row 1 only ever turns from
-// "due in this step" into "served in this step" — a reset either way (pg_prefetch.h resets_in_step).
-__global__ void __launch_bounds__(64) agent_kernel(State s, const int32_t* actions, uint32_t run_seed,
-                                                   uint32_t step_index, int env_offset, StepIO io, int prefetch, LevelPlan plan) {
-    if (blockIdx.y == 1) {  // (block-uniform)
-        __shared__ Level lv;
-        install_prefetched<Gen>(s, blockIdx.x * blockDim.x, blockDim.x, prefetch, io, plan, lv, threadIdx.x,
-                                reset_served_mark(step_index), reset_due_mark(step_index));
-        return;
-    }
-    const int env = blockIdx.x * blockDim.x + threadIdx.x;
-    if (env >= s.n) return;
-    if (resets_in_step(io.pending[env], step_index)) {  // the caller's `if term: env.reset()` (game_test.py:38-40): this step is the env's reset
-        SCI(s, SC_BITS, env) = 0;  // did not step: B and C leave this env alone
-        return;
-    }
-    const int action =
-        actions ? actions[env] : synthetic_action(run_seed, step_index, static_cast<uint32_t>(env_offset + env));
-    agent_substeps(s, env, action);
-}
-
-// B — the entities of a step.  One workgroup = one wavefront = a block of 64 envs.
-//   blockIdx.y ≥ kMaxEnt: lane = env, entity id y − kMaxEnt unless it is a mob (saws and coins: cheap, coalesced).
-//   blockIdx.y < kMaxEnt: the mobs.  Their path is ~5 000 instructions (tile window, two collision probes per
+// A + B — the agent's sub-steps and the entities' in ONE launch (round 5): neither needs the other.  The agent depends on
+// tiles, the entities on tiles and their own state; what joins them — does a hazard's box overlap the agent's after
+// sub-step ss — is held by resolve_kernel, behind both.  As two launches they were two latency chains end to end (34 and
+// 46 µs) and a kernel boundary; side by side the step pays for the longer one.  Rows of blocks (row = blockIdx.y + row_base;
+// row_base: the two-launch form, PG_SPLIT_LOGIC=1, for the A/B):
+//   row 0 — lane = env: the agent's sub-steps into the scratch table (envs that reset in this step sit it out);
+//   row 1 — the auto-reset of those envs whose next level lies ready in its shadow slot (pg_prefetch.h install_prefetched:
+//     a copy), beside the agents instead of in a launch in front of them.  The rows share nothing of a resetting env but
+//     its pending byte, which the others only read and row 1 only ever turns from "due in this step" into "served in this
+//     step" — a reset either way (pg_prefetch.h resets_in_step);
+//   rows 2 + y — the entities.  One workgroup = one wavefront = a block of 64 envs.
+//     y ≥ kMaxEnt: lane = env, entity id y − kMaxEnt unless it is a mob (saws and coins: cheap, coalesced).
+//     y < kMaxEnt: the mobs.  Their path is ~5 000 instructions (tile window, two collision probes per
 //     sub-step, sparks) and a level has between none and a dozen of them, so "row y = the y-th mob of every env" ran
 //     that path max-over-the-block times with mostly idle lanes (SQ counters: 78 M wave instructions per launch, the
 //     kernel is issue-bound).  Instead the (env, mob) pairs of the block are numbered densely — a wave prefix sum over
 //     the 64 mob counts — and row y takes pairs [64y, 64y + 64): full waves, about mean-instead-of-max many of them.
-// (Measured and rejected, round 5: a grid of 8 + 12 rows whose waves loop on to their next share of the pairs / entity
-// slots instead of 2 × 36 rows of which nine in ten find nothing to do — 20 480 wavefronts instead of 73 728.  Bit-exact and
-// slower: 45.5 -> 79.0 µs.  The kernel is the length of its longest wave, a wave that exits early costs the dispatcher
-// 0.2 ns, and a second share is a second chain of round trips behind the first.)
-__global__ void __launch_bounds__(64) entity_kernel(State s) {
+// (Measured and rejected, round 5: a grid of 8 + 12 entity rows whose waves loop on to their next share of the pairs /
+// entity slots instead of 2 × 36 rows of which nine in ten find nothing to do — 20 480 wavefronts instead of 73 728.
+// Bit-exact and slower: 45.5 -> 79.0 µs.  The kernel is the length of its longest wave, a wave that exits early costs the
+// dispatcher 0.2 ns, and a second share is a second chain of round trips behind the first.)
+// (Wavefronts per SIMD the registers are capped for: the kernel wants 131, which is three; at 128 it is four — 66 -> ? µs.)
+#ifndef PG_COINRUN_LOGIC_WAVES
+#define PG_COINRUN_LOGIC_WAVES 4
+#endif
+__global__ void __launch_bounds__(64, PG_COINRUN_LOGIC_WAVES) logic_kernel(State s, const int32_t* actions, uint32_t run_seed, uint32_t step_index,
+                                                   int env_offset, StepIO io, int prefetch, LevelPlan plan, int install_row,
+                                                   int row_base, float reach_x, float reach_y) {
+    const int row = static_cast<int>(blockIdx.y) + row_base;
     const int lane = threadIdx.x;
     int env = blockIdx.x * 64 + lane;
+    if (row == 1) {  // (block-uniform)
+        __shared__ Level lv;
+        if (install_row)
+            install_prefetched<Gen>(s, blockIdx.x * 64, 64, prefetch, io, plan, lv, lane, reset_served_mark(step_index),
+                                    reset_due_mark(step_index));
+        return;
+    }
+    // the caller's `if term: env.reset()` (game_test.py:38-40): for such an env this step is its reset
+    const bool stepping = env < s.n && !resets_in_step(io.pending[env], step_index);
+    if (row == 0) {
+        if (env >= s.n) return;
+        if (!stepping) {
+            SCI(s, SC_BITS, env) = 0;  // did not step: resolve_kernel leaves this env alone
+            return;
+        }
+        const int action =
+            actions ? actions[env] : synthetic_action(run_seed, step_index, static_cast<uint32_t>(env_offset + env));
+        agent_substeps(s, env, action, reach_x, reach_y);
+        return;
+    }
+    const int y = row - 2;
     int e;
-    if (blockIdx.y < kMaxEnt) {
-        const bool stepping = env < s.n && SCI(s, SC_BITS, env) < 0;  // bit 31 clear: the env reset instead
+    if (y < kMaxEnt) {
         const int count = stepping ? SI(s, I_NMOB, env) : 0;
         int upto = count;  // inclusive prefix sum over the block
 #pragma unroll
@@ -830,8 +891,8 @@ __global__ void __launch_bounds__(64) entity_kernel(State s) {
             if (lane >= off) upto += t;
         }
         const int total = __shfl(upto, 63);
-        const int pair = static_cast<int>(blockIdx.y) * 64 + lane;
-        if (static_cast<int>(blockIdx.y) * 64 >= total) return;  // wave-uniform
+        const int pair = y * 64 + lane;
+        if (y * 64 >= total) return;  // wave-uniform
         int lo = 0, hi = 63;  // owner of `pair`: the first lane whose inclusive sum exceeds it
 #pragma unroll
         for (int it = 0; it < 6; it++) {
@@ -845,21 +906,38 @@ __global__ void __launch_bounds__(64) entity_kernel(State s) {
         env = blockIdx.x * 64 + lo;
         e = EB(s, EB_SPARK_ORDER, pair - before, env);
     } else {
-        if (env >= s.n) return;
-        e = blockIdx.y - kMaxEnt;
+        if (!stepping) return;
+        e = y - kMaxEnt;
         if (e >= SI(s, I_NENT, env)) return;
         if (EB(s, EB_KIND, e, env) == kMob) return;
-        if (SCI(s, SC_BITS, env) >= 0) return;  // bit 31 clear: this env performed its reset instead
     }
-    float bx[4], by[4];
-#pragma unroll
-    for (int ss = 0; ss < 4; ss++) {
-        bx[ss] = SC(s, SC_AX + ss, env) + -0.5f;
-        by[ss] = SC(s, SC_AY + ss, env) + -1.0f;
-    }
+    // (the agent's start, for hazard_near: asked for with the flags and pinned there — left to itself the compiler loads the
+    // two where they are used, a round trip at the END of the longest chain of the launch: 57 -> 66 µs)
+    float ax0 = SF(s, F_AX, env), ay0 = SF(s, F_AY, env);  // (row 0 writes neither: resolve_kernel does)
     const int src = (SI(s, I_FLAGS, env) & kFlagBuf) ? 1 : 0;
-    const int hits = entity_step(s, env, e, src, 4, bx, by);
-    if (hits) atomicOr(&SCI(s, SC_HAZARD, env), hits);
+    asm volatile("" : "+v"(ax0), "+v"(ay0));
+    float hb[6];
+    entity_step(s, env, e, src, 4, hb);
+#if defined(PG_EXP_F)
+    if (hazard_near(hb, ax0, ay0, reach_x, reach_y)) atomicOr(&SCI(s, SC_CAND + (e >> 5), env), 1 << (e & 31));
+#elif defined(PG_EXP_G)
+    if (y < kMaxEnt) {
+        s.hazx[size_t(e) * s.n + env] = float4{hb[0], hb[1], hb[2], hb[3]};
+        s.hazy[size_t(e) * s.n + env] = float2{hb[4], hb[5]};
+    }
+#elif defined(PG_EXP_H)
+    if (y < kMaxEnt && hazard_near(hb, ax0, ay0, reach_x, reach_y)) {
+        s.hazx[size_t(e) * s.n + env] = float4{hb[0], hb[1], hb[2], hb[3]};
+        s.hazy[size_t(e) * s.n + env] = float2{hb[4], hb[5]};
+        atomicOr(&SCI(s, SC_CAND + (e >> 5), env), 1 << (e & 31));
+    }
+#else
+    if (hazard_near(hb, ax0, ay0, reach_x, reach_y)) {
+        s.hazx[size_t(e) * s.n + env] = float4{hb[0], hb[1], hb[2], hb[3]};
+        s.hazy[size_t(e) * s.n + env] = float2{hb[4], hb[5]};
+        atomicOr(&SCI(s, SC_CAND + (e >> 5), env), 1 << (e & 31));
+    }
+#endif
 }
 
 // C — lane = env: which sub-step ended the step, rare redo, commit (coinrun.cpp:356-371).
@@ -867,13 +945,13 @@ __global__ void __launch_bounds__(64) entity_kernel(State s) {
 // word and the last one resolves the block's 64 envs.  Bit-exact; with relaxed agent-scope atomics and a workgroup-scope
 // release 125.6 against 128.3 M env-steps/s — 73 728 atomics cost more than a 6-µs kernel and its boundary; with
 // __threadfence() and an acq_rel count, an L2 write-back per wavefront, the step took 2.86 ms.)
-// blockIdx.y == 1 (64 lanes): the auto-resets that agent_kernel's install row could not serve — no level lay ready, an
+// blockIdx.y == 1 (64 lanes): the auto-resets that logic_kernel's install row could not serve — no level lay ready, an
 // episode shorter than the generator's latency — generated here, synchronously (pg_prefetch.h level_serve, mode 2), in this
-// launch instead of in one of its own between agent_kernel and entity_kernel: in steady state that launch found nothing
-// and cost the step its 6 µs and a kernel boundary.  Nothing in between needs those envs' new levels (agent_kernel has
-// zeroed their SC_BITS: entity_kernel and row 0 here leave them alone); the pre-pass behind this launch does.  The byte
-// carries the step's parity (pg_prefetch.h reset_due_mark): row 0 writes "due in step t + 1" for an env that terminates
-// now, which row 1, looking for "due in step t" in the same launch, does not take for its own.
+// launch instead of in one of its own in front of it: in steady state that launch found nothing and cost the step its 6 µs
+// and a kernel boundary.  Nothing in between needs those envs' new levels (their agents and entities sit the step out, row 0
+// here leaves them alone); the pre-pass behind this launch does.  The byte carries the step's parity (pg_prefetch.h
+// reset_due_mark): row 0 writes "due in step t + 1" for an env that terminates now, which row 1, looking for "due in
+// step t" in the same launch, does not take for its own.
 __global__ void __launch_bounds__(64) resolve_kernel(State s, StepIO io, uint32_t step_index, int prefetch, LevelPlan plan) {
     if (blockIdx.y == 1) {  // (block-uniform)
         level_serve<Gen>(s, 2, 64, prefetch, 0u, 0, nullptr, nullptr, io, plan, reset_served_mark(step_index),
@@ -886,7 +964,37 @@ __global__ void __launch_bounds__(64) resolve_kernel(State s, StepIO io, uint32_
     if (bits >= 0) return;  // reset this step: reward / done are written with the install, the byte's mark expires by itself
     const int flags = SI(s, I_FLAGS, env);
     const int src = (flags & kFlagBuf) ? 1 : 0;
-    const int hazard = SCI(s, SC_HAZARD, env);
+    // the hazards: the few boxes that came near (hazard_near), each against the agent's four
+    uint32_t cand0 = static_cast<uint32_t>(SCI(s, SC_CAND, env)), cand1 = static_cast<uint32_t>(SCI(s, SC_CAND + 1, env));
+    float bx[4], by[4];
+#pragma unroll
+    for (int ss = 0; ss < 4; ss++) {
+        bx[ss] = SC(s, SC_AX + ss, env) + -0.5f;
+        by[ss] = SC(s, SC_AY + ss, env) + -1.0f;
+    }
+    int hazard = 0;
+    if (cand0 | cand1) {
+        SCI(s, SC_CAND, env) = 0;
+        SCI(s, SC_CAND + 1, env) = 0;
+    }
+    if (bits & kBitsFar) {  // the agent left the region the entity lanes looked at: every box again, from the table
+        const int n_ent = SI(s, I_NENT, env);
+        for (int e = 0; e < n_ent; e++) {
+            float hb[6];
+            entity_step<false>(s, env, e, src, 4, hb);
+            hazard |= hazard_hits(hb, bx, by);
+        }
+    } else {
+        unsigned long long cand = cand0 | (static_cast<unsigned long long>(cand1) << 32);
+        while (cand) {
+            const int e = __builtin_ctzll(cand);
+            cand &= cand - 1;
+            const float4 x = s.hazx[size_t(e) * s.n + env];
+            const float2 y = s.hazy[size_t(e) * s.n + env];
+            const float hb[6] = {x.x, x.y, x.z, x.w, y.x, y.y};
+            hazard |= hazard_hits(hb, bx, by);
+        }
+    }
     const int lava = (bits >> 8) & 15, coin = (bits >> 12) & 15;
     const int ending = hazard | lava | coin;
     const int last = ending ? __builtin_ctz(ending) : 3;  // first terminating sub-step, or all four took place
@@ -964,13 +1072,8 @@ PG_D void render_full(const State& s, const AtlasView& atlas, const StepIO& io, 
         __syncthreads();  // every wave has read the flag before it is cleared
         if (redo) {
             if (half == 0 && lane < n_ent) {
-                float bx[4], by[4];
-#pragma unroll
-                for (int ss = 0; ss < 4; ss++) {
-                    bx[ss] = SC(s, SC_AX + ss, env) + -0.5f;
-                    by[ss] = SC(s, SC_AY + ss, env) + -1.0f;
-                }
-                entity_step(s, env, lane, 1 - buf, redo, bx, by);
+                float hb[6];
+                entity_step(s, env, lane, 1 - buf, redo, hb);
             }
             if (threadIdx.x == 0) SCI(s, SC_REDO, env) = 0;
             __threadfence();
@@ -1710,7 +1813,7 @@ class CoinrunGame final : public Game {
 
     static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
     struct Layout {
-        size_t shadow, slot, mt, tiles, f, i, ey, eb, df, db, spark, scratch, total;
+        size_t shadow, slot, mt, tiles, f, i, ey, eb, df, db, spark, scratch, hazx, hazy, total;
     };
     static Layout layout(int n) {
         Layout l{};
@@ -1732,6 +1835,8 @@ class CoinrunGame final : public Game {
         l.db = take(size_t(2) * kMaxEnt * n);
         l.spark = take(size_t(2) * 3 * kMaxEnt * kSparkRow * n * 4);
         l.scratch = take(size_t(SC_COUNT) * n * 4);
+        l.hazx = take(size_t(kMaxEnt) * n * sizeof(float4));
+        l.hazy = take(size_t(kMaxEnt) * n * sizeof(float2));
         l.total = off;
         return l;
     }
@@ -1752,6 +1857,8 @@ class CoinrunGame final : public Game {
         s_.db = p + l.db;
         s_.spark = reinterpret_cast<float*>(p + l.spark);
         s_.scratch = reinterpret_cast<float*>(p + l.scratch);
+        s_.hazx = reinterpret_cast<float4*>(p + l.hazx);
+        s_.hazy = reinterpret_cast<float2*>(p + l.hazy);
         atlas_ = atlas;
     }
     int blocks() const { return (s_.n + 63) / 64; }
@@ -1770,22 +1877,31 @@ class CoinrunGame final : public Game {
     int prefetch() const { return (debug_flags & kDebugNoPrefetch) ? 0 : 1; }
     void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
                       StepIO io) override {
-        // the auto-resets: a prefetched level is installed beside the agents (agent_kernel's second row of blocks); the
-        // level kernel behind it generates, synchronously, the levels that were not ready — none in steady state
+        // the auto-resets: a prefetched level is installed beside the agents (logic_kernel's row 1); the levels that were
+        // not ready — none in steady state — are generated synchronously behind it
         const bool fused = prefetch() && install_in_logic();
         const int served = reset_served_mark(step_index), due = reset_due_mark(step_index);
         if (!fused) LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io, plan, PG_RESET_SPAN, served, due);
-        hipLaunchKernelGGL(agent_kernel, dim3(logic_blocks(s_.n), fused ? 2 : 1), dim3(logic_lanes()), 0, st, s_, actions, run_seed,
-                           step_index, env_offset, io, prefetch(), plan);
-        // (Measured and rejected, round 5: that level kernel on a stream of its own beside the entities — forked behind
-        // agent_kernel, joined in front of resolve_kernel — so that its 6 µs and its kernel boundary leave the main stream:
-        // 123.6 against 126.7 M env-steps/s, three same-box pairs; the two event hand-overs cost more than they hide.)
-        // The unprepared ones ride in resolve_kernel's second row (see there); with fewer than 64 lanes per logic block
-        // (PG_LOGIC_LANES, experiments) or PG_LATE_LAUNCH=1 (the A/B) they keep the launch of their own.
+        // agents, prefetched installs and entities side by side (logic_kernel); PG_SPLIT_LOGIC=1: the entities in a launch
+        // of their own behind the agents, as until round 5 (the A/B)
+        static const bool split = [] { const char* e = std::getenv("PG_SPLIT_LOGIC"); return e && e[0] == '1'; }();
+        const dim3 blocks((s_.n + 63) / 64, split ? 2 : 2 + 2 * kMaxEnt);
+        // (bit 24: no reach — the tests' way to resolve_kernel's fallback, see hazard_near)
+        const float reach_x = (debug_flags & kDebugCoinrunNoReach) ? 0.0f : kReachX;
+        const float reach_y = (debug_flags & kDebugCoinrunNoReach) ? 0.0f : kReachY;
+        hipLaunchKernelGGL(logic_kernel, blocks, dim3(64), 0, st, s_, actions, run_seed, step_index, env_offset, io,
+                           prefetch(), plan, fused ? 1 : 0, 0, reach_x, reach_y);
+        // (Measured and rejected, round 5, when agents and entities were two launches: that level kernel on a stream of
+        // its own beside the entities — forked behind the agents, joined in front of resolve_kernel: 123.6 against 126.7 M
+        // env-steps/s, three same-box pairs; the two event hand-overs cost more than they hide.)
+        // They ride in resolve_kernel's second row (see there: +0.6 to 1 %); with fewer than 64 lanes per logic block
+        // (PG_LOGIC_LANES, experiments) or PG_LATE_LAUNCH=1 (the A/B) they keep a launch of their own.
         static const bool late_launch = [] { const char* e = std::getenv("PG_LATE_LAUNCH"); return e && e[0] == '1'; }();
         const bool late_row = fused && logic_lanes() == 64 && !late_launch;
         if (fused && !late_row) LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io, plan, PG_RESET_SPAN, served, due);
-        hipLaunchKernelGGL(entity_kernel, dim3((s_.n + 63) / 64, 2 * kMaxEnt), dim3(64), 0, st, s_);
+        if (split)
+            hipLaunchKernelGGL(logic_kernel, dim3((s_.n + 63) / 64, 2 * kMaxEnt), dim3(64), 0, st, s_, actions, run_seed,
+                               step_index, env_offset, io, prefetch(), plan, 0, 2, reach_x, reach_y);
         hipLaunchKernelGGL(resolve_kernel, dim3(logic_blocks(s_.n), late_row ? 2 : 1), dim3(logic_lanes()), 0, st, s_, io,
                            step_index, prefetch(), plan);
     }

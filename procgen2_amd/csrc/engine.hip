@@ -841,8 +841,8 @@ int32_t pgv_render_frame(pgv_env* e, int32_t index, int32_t width, int32_t heigh
 int32_t pgv_set_debug(pgv_env* e, int32_t flags) {
     if (!e) return fail("pgv_set_debug: env is NULL");
 #ifndef PG_ABLATE
-    if (flags & ~(1 | pg::kDebugNoPrefetch | pg::kDebugNoPrepass | pg::kDebugFatThirds))
-        return fail("pgv_set_debug: only bit 0 (draw-list replay), bit 8 (no level prefetch), bit 21 (no render pre-pass) and bit 23 (every third frame by the complete path) exist in this build");
+    if (flags & ~(1 | pg::kDebugNoPrefetch | pg::kDebugNoPrepass | pg::kDebugFatThirds | pg::kDebugCoinrunNoReach))
+        return fail("pgv_set_debug: only bit 0 (draw-list replay), bit 8 (no level prefetch), bit 21 (no render pre-pass), bit 23 (every third frame by the complete path) and bit 24 (coinrun: hazards the long way) exist in this build");
 #endif
     if (e->side) hipStreamSynchronize(e->side);
     e->game->debug_flags = flags;

@@ -154,6 +154,8 @@ class Game {
     // Bit 21: no render pre-pass — every frame's workgroup does its own set-up (the complete path; pg_prepass.h).
     // Bit 23: the pre-pass leaves every third env's frame to the complete path (`fat`), as it does by itself for the frames
     //         its tables do not hold — which some games never have in a normal run: the tests' way to that path.
+    // Bit 24: coinrun — the entity lanes' hazard pre-selection assumes an agent that does not move (coinrun.hip hazard_near):
+    //         the agent's own check of that assumption fails and resolve_kernel works the hazards out the long way.
     int debug_flags = 0;
     LevelPlan plan{0, 0, nullptr, nullptr};  // set by the engine after bind()
 };
@@ -161,6 +163,7 @@ class Game {
 constexpr int kDebugNoPrefetch = 1 << 8;
 constexpr int kDebugNoPrepass = 1 << 21;  // (clear of the -DPG_ABLATE experiment bits the games use)
 constexpr int kDebugFatThirds = 1 << 23;
+constexpr int kDebugCoinrunNoReach = 1 << 24;
 
 // Lanes per workgroup of the lane-per-env logic kernels: fewer envs per wave = more waves.
 int logic_lanes();

@@ -24,8 +24,10 @@ def _actions(L, run_seed, step, n, offset=0):
     return np.array([L.pgo_synthetic_action(run_seed, step, offset + e) for e in range(n)], np.int32)
 
 
-def _lockstep(game, n, steps, seed_base=1, run_seed=0, check_state_every=0, game_flags=0, threads=1):
+def _lockstep(game, n, steps, seed_base=1, run_seed=0, check_state_every=0, game_flags=0, threads=1, debug=0):
     eng = EngineVec(game, n, seed_base=seed_base, game_flags=game_flags)
+    if debug:
+        eng.set_debug(debug)
     ora = OracleVec(game, n, seed_base=seed_base, game_flags=game_flags)
     L = ora.L
     assert np.array_equal(eng.reset(), ora.reset_obs()), "reset frame"
@@ -54,6 +56,16 @@ def test_coinrun_lockstep_256_envs():
     # configs[1] scaled to what the scalar oracle renders in seconds; 400 steps cross several episode ends
     resets = _lockstep("coinrun", 256, 400, check_state_every=50)
     assert resets > 0, "no episode ended: the auto-reset path was not exercised"
+
+
+def test_coinrun_hazards_the_long_way():
+    """coinrun's entity lanes hand resolve_kernel only the hazards that come near where the agent STARTED the step, and the
+    agent's lane checks that it stayed within that reach (coinrun.hip hazard_near); where it did not — never, in a normal
+    run — resolve_kernel works every hazard's boxes out again.  pgv_set_debug bit 24 sets the reach to nothing, so that
+    every agent that moves fails the check: the same rewards, dones and frames as the oracle through episode ends (deaths
+    by saw and by mob are most of them)."""
+    resets = _lockstep("coinrun", 192, 300, seed_base=5, run_seed=3, check_state_every=60, debug=1 << 24)
+    assert resets > 0
 
 
 @pytest.mark.parametrize("game", ["coinrun", "maze", "bossfight", "climber", "caveflyer", "chaser", "jumper"])
