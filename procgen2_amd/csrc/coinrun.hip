@@ -452,20 +452,36 @@ struct TileWin {
     }
     PG_D static TileWin fetch(const uint8_t* tiles, int ax, int ay) {
         TileWin w{tiles, ax, ay, 0};
-        // Sixteen UNCONDITIONAL loads — a cell outside the map reads cell 0 and is replaced afterwards — so that they are
-        // all in flight together.  (A load behind the bounds test is a load in a branch of its own, and the compiler
-        // waits for each before it enters the next: sixteen memory round trips instead of one.)
-        int t[16];
-        bool inside[16];
+        // A column of the window is four consecutive bytes of the map (index ty + x·H, ty = H − 1 − y): four loads of a
+        // word — at any byte address, which global memory allows — instead of sixteen of a byte.  UNCONDITIONAL loads, so
+        // that they are all in flight together (a load behind the bounds test is a load in a branch of its own, and the
+        // compiler waits for each before it enters the next): a column beyond the map reads column 0, a word that would
+        // stick out above or below is read from the nearest place inside and shifted, and a cell outside the map is
+        // replaced afterwards.
+        const int ty_lo = H - 4 - ay;  // the window's row ay + 3; row ay + j sits in byte 3 − j of the column's word
+        const int ty_at = ty_lo < 0 ? 0 : (ty_lo > H - 4 ? H - 4 : ty_lo);
+        const int delta = ty_at - ty_lo;  // ∈ [−3, 3] where any cell is inside
+        uint32_t col[4];
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int x = ax + (k & 3), ty = H - 1 - (ay + (k >> 2));
-            inside[k] = !(x < 0 || ty < 0 || x >= W || ty >= H);
-            t[k] = tiles[inside[k] ? ty + x * H : 0];
+        for (int c = 0; c < 4; c++) {
+            const int x = ax + c;
+            uint32_t word;
+            __builtin_memcpy(&word, tiles + ty_at + ((x < 0 || x >= W) ? 0 : x) * H, 4);
+            col[c] = word;
         }
 #pragma unroll
-        for (int k = 0; k < 16; k++)
-            w.bits |= static_cast<uint64_t>(inside[k] ? (t[k] & 7) : kWallMid) << (3 * k);  // out of bounds is a wall (tilemap.h:80-81)
+        for (int c = 0; c < 4; c++) {
+            const int x = ax + c;
+            const uint32_t sh = 8u * static_cast<uint32_t>(delta < 0 ? -delta : delta);
+            const uint32_t word = sh >= 32u ? 0u : (delta >= 0 ? col[c] << sh : col[c] >> sh);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int ty = H - 1 - (ay + j);
+                const bool inside = !(x < 0 || ty < 0 || x >= W || ty >= H);
+                const int tile = inside ? static_cast<int>((word >> (8 * (3 - j))) & 7u) : kWallMid;  // tilemap.h:80-81
+                w.bits |= static_cast<uint64_t>(tile) << (3 * (c + 4 * j));
+            }
+        }
         return w;
     }
     PG_D int at(int x, int y) const {
@@ -850,7 +866,7 @@ __global__ void __launch_bounds__(64) make_kernel(State s, uint32_t seed_base, i
 // entity slots instead of 2 × 36 rows of which nine in ten find nothing to do — 20 480 wavefronts instead of 73 728.
 // Bit-exact and slower: 45.5 -> 79.0 µs.  The kernel is the length of its longest wave, a wave that exits early costs the
 // dispatcher 0.2 ns, and a second share is a second chain of round trips behind the first.)
-// (Wavefronts per SIMD the registers are capped for: the kernel wants 131, which is three; at 128 it is four — 66 -> ? µs.)
+// (Wavefronts per SIMD the registers are capped for: the kernel wants 131, which is three; at 128 (three spilled) it is four — 66 -> 61 µs; five, at 96: 70 µs.)
 #ifndef PG_COINRUN_LOGIC_WAVES
 #define PG_COINRUN_LOGIC_WAVES 4
 #endif
@@ -877,6 +893,8 @@ __global__ void __launch_bounds__(64, PG_COINRUN_LOGIC_WAVES) logic_kernel(State
         }
         const int action =
             actions ? actions[env] : synthetic_action(run_seed, step_index, static_cast<uint32_t>(env_offset + env));
+        // (Measured, round 5: s_setprio(3) for this row — one long chain beside the entities' many shorter ones — changes
+        // nothing: 59.5 against 59.4 µs.)
         agent_substeps(s, env, action, reach_x, reach_y);
         return;
     }
@@ -911,33 +929,16 @@ __global__ void __launch_bounds__(64, PG_COINRUN_LOGIC_WAVES) logic_kernel(State
         if (e >= SI(s, I_NENT, env)) return;
         if (EB(s, EB_KIND, e, env) == kMob) return;
     }
-    // (the agent's start, for hazard_near: asked for with the flags and pinned there — left to itself the compiler loads the
-    // two where they are used, a round trip at the END of the longest chain of the launch: 57 -> 66 µs)
-    float ax0 = SF(s, F_AX, env), ay0 = SF(s, F_AY, env);  // (row 0 writes neither: resolve_kernel does)
+    // the agent's start, for hazard_near (row 0 writes neither: resolve_kernel does)
+    const float ax0 = SF(s, F_AX, env), ay0 = SF(s, F_AY, env);
     const int src = (SI(s, I_FLAGS, env) & kFlagBuf) ? 1 : 0;
-    asm volatile("" : "+v"(ax0), "+v"(ay0));
     float hb[6];
     entity_step(s, env, e, src, 4, hb);
-#if defined(PG_EXP_F)
-    if (hazard_near(hb, ax0, ay0, reach_x, reach_y)) atomicOr(&SCI(s, SC_CAND + (e >> 5), env), 1 << (e & 31));
-#elif defined(PG_EXP_G)
-    if (y < kMaxEnt) {
-        s.hazx[size_t(e) * s.n + env] = float4{hb[0], hb[1], hb[2], hb[3]};
-        s.hazy[size_t(e) * s.n + env] = float2{hb[4], hb[5]};
-    }
-#elif defined(PG_EXP_H)
-    if (y < kMaxEnt && hazard_near(hb, ax0, ay0, reach_x, reach_y)) {
-        s.hazx[size_t(e) * s.n + env] = float4{hb[0], hb[1], hb[2], hb[3]};
-        s.hazy[size_t(e) * s.n + env] = float2{hb[4], hb[5]};
-        atomicOr(&SCI(s, SC_CAND + (e >> 5), env), 1 << (e & 31));
-    }
-#else
     if (hazard_near(hb, ax0, ay0, reach_x, reach_y)) {
         s.hazx[size_t(e) * s.n + env] = float4{hb[0], hb[1], hb[2], hb[3]};
         s.hazy[size_t(e) * s.n + env] = float2{hb[4], hb[5]};
         atomicOr(&SCI(s, SC_CAND + (e >> 5), env), 1 << (e & 31));
     }
-#endif
 }
 
 // C — lane = env: which sub-step ended the step, rare redo, commit (coinrun.cpp:356-371).
