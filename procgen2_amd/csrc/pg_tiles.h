@@ -27,19 +27,35 @@ struct TileWinT {
     }
     PG_D static TileWinT fetch(const uint8_t* tiles, int ax, int ay) {
         TileWinT w{tiles, ax, ay, 0};
-        // Sixteen UNCONDITIONAL loads — a cell outside the map reads cell 0 and is replaced afterwards — so that they are
-        // all in flight together.  (A load behind the bounds test is a load in a branch of its own, and the compiler
-        // waits for each before it enters the next: sixteen memory round trips instead of one.)
-        int t[16];
-        bool inside[16];
+        // A column of the window is four consecutive bytes of the map (index ty + x·H, ty = H − 1 − y): four loads of a
+        // word — at any byte address, which global memory allows — instead of sixteen of a byte.  UNCONDITIONAL loads, so
+        // that they are all in flight together (a load behind the bounds test is a load in a branch of its own, and the
+        // compiler waits for each before it enters the next): a column beyond the map reads column 0, a word that would
+        // stick out above or below is read from the nearest place inside and shifted, and a cell outside the map is
+        // replaced afterwards.
+        static_assert(H >= 4, "a column holds a word");
+        const int ty_lo = H - 4 - ay;  // the window's row ay + 3; row ay + j sits in byte 3 − j of the column's word
+        const int ty_at = ty_lo < 0 ? 0 : (ty_lo > H - 4 ? H - 4 : ty_lo);
+        const int delta = ty_at - ty_lo;  // ∈ [−3, 3] where any cell is inside
+        const uint32_t sh = 8u * static_cast<uint32_t>(delta < 0 ? -delta : delta);
+        uint32_t col[4];
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int x = ax + (k & 3), ty = H - 1 - (ay + (k >> 2));
-            inside[k] = !(x < 0 || ty < 0 || x >= W || ty >= H);
-            t[k] = tiles[inside[k] ? ty + x * H : 0];
+        for (int c = 0; c < 4; c++) {
+            const int x = ax + c;
+            __builtin_memcpy(&col[c], tiles + ty_at + ((x < 0 || x >= W) ? 0 : x) * H, 4);
         }
 #pragma unroll
-        for (int k = 0; k < 16; k++) w.bits |= static_cast<uint64_t>(inside[k] ? (t[k] & 7) : OOB) << (3 * k);
+        for (int c = 0; c < 4; c++) {
+            const int x = ax + c;
+            const uint32_t word = sh >= 32u ? 0u : (delta >= 0 ? col[c] << sh : col[c] >> sh);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int ty = H - 1 - (ay + j);
+                const bool inside = !(x < 0 || ty < 0 || x >= W || ty >= H);
+                const int tile = inside ? static_cast<int>((word >> (8 * (3 - j))) & 7u) : OOB;
+                w.bits |= static_cast<uint64_t>(tile) << (3 * (c + 4 * j));
+            }
+        }
         return w;
     }
     PG_D int cell(int dx, int dy) const { return static_cast<int>((bits >> (3 * (dx + 4 * dy))) & 7u); }  // inside the window
