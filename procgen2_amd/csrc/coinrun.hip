@@ -1017,6 +1017,9 @@ __global__ void __launch_bounds__(64) resolve_kernel(State s, StepIO io, uint32_
                           (((bits >> (4 + last)) & 1) ? kFlagForward : 0) | (src ? 0 : kFlagBuf);
     const bool terminated = !alive || got_coin;  // coinrun.cpp:366
     io.reward[env] = got_coin * 10.0f;           // coinrun.cpp:364, last executed sub-step only (D4)
+#ifdef PG_EXP_COUNT_FAR
+    if (bits & kBitsFar) io.reward[env] = 12345.0f;  // (experiment build: how often does the agent leave its reach?)
+#endif
     io.done[env] = terminated ? 1 : 0;
     io.pending[env] = terminated ? reset_due_mark(step_index + 1u) : 0;
 }
