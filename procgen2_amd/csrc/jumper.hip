@@ -117,6 +117,7 @@ struct State {
     // the compass ring as it lands on the observation (extend_atlas; word offsets into the atlas, 0 = not prepared)
     uint32_t hud_image, hud_list;
     int hud_n;
+    uint32_t hud_cover;  // 64 words: the columns of each pixel row the ring's opaque texels overwrite (pg_prepass.h `cover`)
     PrepOut prep;  // what setup_kernel leaves for render_kernel (pg_prepass.h); not part of the state blob
     uint32_t* fat;  // [1 + n]  number of frames the pre-pass left to the complete path, then their envs (render_full_kernel)
 };
@@ -1066,6 +1067,9 @@ __global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView 
         uint32_t* const draws_b = out.draws + size_t(env0 + eb) * kPrepDraws * kBlitWords;
         PrepDrawPass st{0, {0, 0}};
         PrepDrawQueue& Q = S.queue[wave];
+        // everything drawn here lies beneath the compass ring, which is opaque over two thirds of the frame: what lands
+        // wholly under it — the bunny, nearly always — is not handed to the render wave at all
+        const uint32_t* const cover = (s.hud_cover != 0u && !PG_ABL(flags, 0x10000)) ? atlas.texels + s.hud_cover : nullptr;
         for (int base = 0; base < cnt_a + cnt_b; base += 64) {  // wave-uniform
             const int q = base + lane;
             const bool is_b = q >= cnt_a;
@@ -1131,9 +1135,9 @@ __global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView 
                 p.go = true;
             }
             p.scale = num / S.desc[p.tex].y * post;
-            prep_draws_pass(Q, st, S.desc, cam_a, cam_b, draws_a, draws_b, valid, is_b, p, lane);
+            prep_draws_pass(Q, st, S.desc, cam_a, cam_b, draws_a, draws_b, valid, is_b, p, lane, cover);
         }
-        prep_draws_flush(Q, st, S.desc, cam_a, cam_b, draws_a, draws_b, lane);
+        prep_draws_flush(Q, st, S.desc, cam_a, cam_b, draws_a, draws_b, lane, cover);
         if (lane == 0) {  // (the compass's needle and bar take two more lanes of the render wave)
             S.counts[ea] = st.done[0] > kPrepDraws - 3 ? kPrepDraws + 1 : st.done[0];
             S.counts[eb] = st.done[1] > kPrepDraws - 3 ? kPrepDraws + 1 : st.done[1];
@@ -1454,7 +1458,35 @@ class JumperGame final : public Game {
             list.push_back(0xffffffffu);
             list.push_back(0u);
         }
+        // the columns each row's OPAQUE texels cover, for the pre-pass to drop what lies wholly beneath (pg_prepass.h
+        // `cover`): one run per row, starts valley-shaped and ends hill-shaped over the rows — else no table
+        std::vector<uint32_t> cover(kObsH, 0x00ffu);
+        bool shaped = true;
+        int falling_lo = 1, rising_hi = 1, prev_lo = 256, prev_hi = -1, seen = 0, ended = 0;
+        for (int y = 0; y < kObsH; y++) {
+            int lo = -1, hi = -1, runs = 0;
+            for (int x = 0; x < kObsW; x++) {
+                const bool op = image[size_t(y) * kObsW + x] != 0u;
+                if (op && (x == 0 || image[size_t(y) * kObsW + x - 1] == 0u)) runs++, lo = lo < 0 ? x : lo;
+                if (op) hi = x;
+            }
+            if (runs == 0) {
+                ended = seen;
+                continue;
+            }
+            if (runs > 1 || ended) shaped = false;
+            if (seen) {
+                if (lo > prev_lo) falling_lo = 0;
+                else if (lo < prev_lo && !falling_lo) shaped = false;
+                if (hi < prev_hi) rising_hi = 0;
+                else if (hi > prev_hi && !rising_hi) shaped = false;
+            }
+            seen = 1, prev_lo = lo, prev_hi = hi;
+            cover[y] = static_cast<uint32_t>(lo) | (static_cast<uint32_t>(hi) << 8);
+        }
         if ((atlas.texel_bytes() / 4) % 2 != 0) atlas.append_words({0u});  // the list is read as 8-byte pairs
+        s_.hud_cover = shaped && seen ? atlas.append_words(cover) : 0u;
+        if ((atlas.texel_bytes() / 4) % 2 != 0) atlas.append_words({0u});
         s_.hud_image = atlas.append_words(image);
         s_.hud_n = static_cast<int>(list.size() / 2);
         s_.hud_list = atlas.append_words(list.empty() ? std::vector<uint32_t>{0xffffffffu, 0u} : list);

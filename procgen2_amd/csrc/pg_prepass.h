@@ -491,8 +491,12 @@ struct PrepDrawPass {
     int done[2];         // draws stored so far, per env of the wave
 };
 // The tails of everything queued, ranks, stores.  desc: the atlas descriptor table (in LDS); cam: the two envs' cameras.
+// `cover` (optional): what a later, OPAQUE part of every frame hides — per pixel row y a word lo | hi << 8, the columns
+// [lo, hi] that part overwrites (lo > hi: none), valley- / hill-shaped over the rows, so that a rectangle whose first and
+// last row lie inside lies inside altogether.  A draw that lands wholly under it is dropped here: nobody sees it.
+// (jumper's compass disc covers two thirds of the 64×64 frame, the bunny at its centre included.)
 PG_D void prep_draws_flush(PrepDrawQueue& Q, PrepDrawPass& st, const int4* desc, const Camera& cam_a, const Camera& cam_b,
-                           uint32_t* draws_a, uint32_t* draws_b, int lane) {
+                           uint32_t* draws_a, uint32_t* draws_b, int lane, const uint32_t* cover = nullptr) {
     if (st.queued == 0) return;  // wave-uniform
     wave_order();  // the entries were written by other lanes of this wave
     // Up to 32 draws (the usual case: a dozen or two per pair of envs): lane = (draw, axis) — both axes of every draw in
@@ -525,6 +529,16 @@ PG_D void prep_draws_flush(PrepDrawQueue& Q, PrepDrawPass& st, const int4* desc,
         has = has && axis_tail(cam.sw, cam.scale, d.y, en.scale, (en.misc >> 8) & 1u, AxisHead{en.dx, en.dlx}, x);
         has = has && axis_tail(cam.sh, cam.scale, d.z, en.scale, false, AxisHead{en.dy, en.dly}, y);
     }
+    if (cover != nullptr && has) {  // (the part of the destination on the target: the rest is dropped anyway, raster spec S5)
+        const int x0 = x.d0 < 0 ? 0 : x.d0, x1 = x.d0 + x.dn - 1 > kObsW - 1 ? kObsW - 1 : x.d0 + x.dn - 1;
+        const int y0 = y.d0 < 0 ? 0 : y.d0, y1 = y.d0 + y.dn - 1 > kObsH - 1 ? kObsH - 1 : y.d0 + y.dn - 1;
+        if (x0 <= x1 && y0 <= y1) {
+            const uint32_t top = cover[y0], bottom = cover[y1];
+            const int lo_t = static_cast<int>(top & 0xffu), lo_b = static_cast<int>(bottom & 0xffu);
+            const int hi_t = static_cast<int>((top >> 8) & 0xffu), hi_b = static_cast<int>((bottom >> 8) & 0xffu);
+            if (x0 >= (lo_t > lo_b ? lo_t : lo_b) && x1 <= (hi_t < hi_b ? hi_t : hi_b)) has = false;
+        }
+    }
     const unsigned long long m_a = __ballot(has && !is_b), m_b = __ballot(has && is_b);
     const unsigned long long below = (1ull << lane) - 1ull;
     const int rank = is_b ? st.done[1] + __popcll(m_b & below) : st.done[0] + __popcll(m_a & below);
@@ -548,7 +562,8 @@ PG_D void prep_draws_flush(PrepDrawQueue& Q, PrepDrawPass& st, const int4* desc,
 // One pass: this lane's draw (of env a or b of the wave) through the heads; survivors appended to the worklist in lane
 // order (= list order).  Every lane of the wave calls this, with valid = false where there is no draw.
 PG_D void prep_draws_pass(PrepDrawQueue& Q, PrepDrawPass& st, const int4* desc, const Camera& cam_a, const Camera& cam_b,
-                          uint32_t* draws_a, uint32_t* draws_b, bool valid, bool is_b, const PrepDraw& p, int lane) {
+                          uint32_t* draws_a, uint32_t* draws_b, bool valid, bool is_b, const PrepDraw& p, int lane,
+                          const uint32_t* cover = nullptr) {
     const Camera& cam = is_b ? cam_b : cam_a;
     AxisHead hx{0.0f, 0.0f}, hy{0.0f, 0.0f};
     bool alive = valid && p.go;
@@ -560,7 +575,7 @@ PG_D void prep_draws_pass(PrepDrawQueue& Q, PrepDrawPass& st, const int4* desc, 
     const unsigned long long m = __ballot(alive);
     const int n = __popcll(m);
     if (n == 0) return;  // wave-uniform
-    if (st.queued + n > kPrepQueue) prep_draws_flush(Q, st, desc, cam_a, cam_b, draws_a, draws_b, lane);
+    if (st.queued + n > kPrepQueue) prep_draws_flush(Q, st, desc, cam_a, cam_b, draws_a, draws_b, lane, cover);
     if (alive) {
         int mod = 255;
         if (p.alpha != 1.0f) mod = static_cast<int>(255 * p.alpha) & 0xff;  // Uint8 parameter (renderer.cpp:56-57)
