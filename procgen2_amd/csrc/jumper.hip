@@ -116,7 +116,6 @@ struct State {
     int float_abs;         // game_flags PGV_JUMPER_FLOAT_ABS (D21)
     // the compass ring as it lands on the observation (extend_atlas; word offsets into the atlas, 0 = not prepared)
     uint32_t hud_image, hud_list;
-    int hud_n;
     uint32_t hud_cover;  // 64 words: the columns of each pixel row the ring's opaque texels overwrite (pg_prepass.h `cover`)
     PrepOut prep;  // what setup_kernel leaves for render_kernel (pg_prepass.h); not part of the state blob
     uint32_t* fat;  // [1 + n]  number of frames the pre-pass left to the complete path, then their envs (render_full_kernel)
@@ -777,8 +776,7 @@ PG_D void render_full(const State& s, const AtlasView& atlas, const StepIO& io, 
             // the draw order — after the bunny, before the needle and the bar
             wave_replay_rows(fb, atlas, mine, __ballot(has && lane <= bunny_lane), lane, row_lo, row_hi);
             if (!PG_ABL(flags, 0x10000))  // (traffic experiment, -DPG_ABLATE builds only: no compass ring)
-                overlay_rows(fb, atlas.texels + s.hud_image, reinterpret_cast<const uint2*>(atlas.texels + s.hud_list), s.hud_n,
-                             lane, row_lo, row_hi);
+                overlay_rows(fb, atlas.texels + s.hud_image, reinterpret_cast<const uint2*>(atlas.texels + s.hud_list), lane, row_lo);
             // (timing experiments, -DPG_ABLATE builds only: 0x20000 no needle, 0x40000 no bar)
             if (PG_ABL(flags, 0x20000)) has = has && lane != bunny_lane + 2;
             if (PG_ABL(flags, 0x40000)) has = has && lane != bunny_lane + 3;
@@ -891,8 +889,7 @@ PG_D void render_full(const State& s, const AtlasView& atlas, const StepIO& io, 
                 // the ring is the same 60×60 pixels in every frame: prepared once (pg_render.h overlay_rows), in its place in
                 // the draw order — after the bunny, before the needle and the bar
                 wave_replay_rows(fb, atlas, mine, __ballot(has && lane == 0), lane, row_lo, row_hi);
-                overlay_rows(fb, atlas.texels + s.hud_image, reinterpret_cast<const uint2*>(atlas.texels + s.hud_list), s.hud_n,
-                             lane, row_lo, row_hi);
+                overlay_rows(fb, atlas.texels + s.hud_image, reinterpret_cast<const uint2*>(atlas.texels + s.hud_list), lane, row_lo);
                 wave_replay_rows(fb, atlas, mine, __ballot(has && lane >= 2), lane, row_lo, row_hi);
             } else {
                 wave_replay_rows(fb, atlas, mine, __ballot(has), lane, row_lo, row_hi);
@@ -1262,8 +1259,7 @@ __global__ void __launch_bounds__(128, PG_RENDER_WAVES) render_kernel(State s, A
         // draw order — after the bunny, before the needle and the bar
         wave_replay_rows(fb, atlas, mine, __ballot(has && lane < n_draws), lane, row_lo, row_hi);
         PG_TL(4);
-        overlay_rows(fb, atlas.texels + s.hud_image, reinterpret_cast<const uint2*>(atlas.texels + s.hud_list), s.hud_n, lane,
-                     row_lo, row_hi);
+        overlay_rows(fb, atlas.texels + s.hud_image, reinterpret_cast<const uint2*>(atlas.texels + s.hud_list), lane, row_lo);
         PG_TL(5);
         wave_replay_rows(fb, atlas, mine, __ballot(has && lane > n_draws), lane, row_lo, row_hi);
         PG_TL(6);
@@ -1441,22 +1437,26 @@ class JumperGame final : public Game {
         if (!(fx > -32768.0f && fx < 32768.0f && fy > -32768.0f && fy < 32768.0f)) return;
         const int dx = static_cast<int>(fx), dy = static_cast<int>(fy), dw = static_cast<int>(fw), dh = static_cast<int>(fh);
         std::vector<uint32_t> image(size_t(kObsW) * kObsH, 0u), list;
-        for (int y = 0; y < kObsH; y++)
-            for (int x = 0; x < kObsW; x++) {
-                const int i = x - dx, j = y - dy;
-                if (i < 0 || j < 0 || i >= dw || j >= dh) continue;
-                const uint32_t t = tex[sample_index(0, d.z, j, dh) * d.y + sample_index(0, d.y, i, dw)];
-                const uint32_t a = t >> 24;
-                if (a == 255u) {
-                    image[size_t(y) * kObsW + x] = t;
-                } else if (a != 0u) {
-                    list.push_back(static_cast<uint32_t>(y * kObsW + x));
-                    list.push_back(t);
+        const size_t half_words = size_t(kOverlayPerLane) * 64 * 2;  // (pg_render.h overlay_rows: a half's share of the list)
+        for (int half = 0; half < 2; half++) {
+            for (int y = half * (kObsH / 2); y < (half + 1) * (kObsH / 2); y++)
+                for (int x = 0; x < kObsW; x++) {
+                    const int i = x - dx, j = y - dy;
+                    if (i < 0 || j < 0 || i >= dw || j >= dh) continue;
+                    const uint32_t t = tex[sample_index(0, d.z, j, dh) * d.y + sample_index(0, d.y, i, dw)];
+                    const uint32_t a = t >> 24;
+                    if (a == 255u) {
+                        image[size_t(y) * kObsW + x] = t;
+                    } else if (a != 0u) {
+                        list.push_back(static_cast<uint32_t>(y * kObsW + x));
+                        list.push_back(t);
+                    }
                 }
+            if (list.size() > (half + 1) * half_words) return;  // more translucent texels than the overlay's lanes take: the blit stays
+            while (list.size() < (half + 1) * half_words) {
+                list.push_back(0xffffffffu);
+                list.push_back(0u);
             }
-        while ((list.size() / 2) % 64 != 0) {
-            list.push_back(0xffffffffu);
-            list.push_back(0u);
         }
         // the columns each row's OPAQUE texels cover, for the pre-pass to drop what lies wholly beneath (pg_prepass.h
         // `cover`): one run per row, starts valley-shaped and ends hill-shaped over the rows — else no table
@@ -1488,8 +1488,7 @@ class JumperGame final : public Game {
         s_.hud_cover = shaped && seen ? atlas.append_words(cover) : 0u;
         if ((atlas.texel_bytes() / 4) % 2 != 0) atlas.append_words({0u});
         s_.hud_image = atlas.append_words(image);
-        s_.hud_n = static_cast<int>(list.size() / 2);
-        s_.hud_list = atlas.append_words(list.empty() ? std::vector<uint32_t>{0xffffffffu, 0u} : list);
+        s_.hud_list = atlas.append_words(list);
     }
     bool set_game_flags(uint32_t flags) override {  // include/procgen2_vec.h PGV_JUMPER_FLOAT_ABS
         s_.float_abs = (flags & PGV_JUMPER_FLOAT_ABS) ? 1 : 0;

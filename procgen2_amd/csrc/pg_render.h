@@ -832,26 +832,28 @@ PG_D void wave_replay_rows(uint32_t* fb, const AtlasView& atlas, const Blit& min
 
 // A draw that is the same in every frame of every env (a HUD element at a fixed place on the observation), prepared
 // on the host when the atlas is loaded (Game::extend_atlas): `image` = 64×64 words, the texel that lands on each pixel
-// where it is opaque, 0 elsewhere; `list` = (pixel index, texel) pairs for the texels that are translucent, `list_n`
-// entries padded to a multiple of 64 with index 0xffffffff.  Opaque pixels are coalesced loads and masked stores —
-// all rows of the wave in one round trip — translucent ones one blend per pixel, instead of a 60×60 blit that samples,
-// tests and blends every pixel it covers.  Same pixels as wave_replay_rows of the draw (raster spec S1–S4).
-PG_D void overlay_rows(uint32_t* fb, const uint32_t* image, const uint2* list, int list_n, int lane, int row_lo,
-                       int row_hi) {
+// where it is opaque, 0 elsewhere; `list` = (pixel index, texel) pairs for the texels that are translucent — the upper
+// 32 rows' first, then the lower rows', each half padded to kOverlayPerLane × 64 entries with index 0xffffffff.  Opaque
+// pixels are coalesced loads and masked stores, translucent ones one blend per pixel — instead of a 60×60 blit that
+// samples, tests and blends every pixel it covers — and every load of the wave, the list's too, is in one round trip
+// (the list walked in a loop was a round trip per 64 entries, both halves' entries by both waves: 5 000 -> ? clocks).
+// Same pixels as wave_replay_rows of the draw (raster spec S1–S4).  row_lo: 0 or 32.
+constexpr int kOverlayPerLane = 2;
+PG_D void overlay_rows(uint32_t* fb, const uint32_t* image, const uint2* list, int lane, int row_lo) {
     constexpr int kRows = kObsH / 2;
     uint32_t t[kRows];
+    uint2 item[kOverlayPerLane];
 #pragma unroll
     for (int k = 0; k < kRows; k++) t[k] = image[(row_lo + k) * kObsW + lane];
+#pragma unroll
+    for (int k = 0; k < kOverlayPerLane; k++) item[k] = list[(row_lo ? kOverlayPerLane * 64 : 0) + k * 64 + lane];
     wave_order();
 #pragma unroll
     for (int k = 0; k < kRows; k++)
         if (t[k] >= 0xff000000u) fb[(row_lo + k) * kObsW + lane] = t[k];
-    wave_order();
-    for (int e = lane; e < list_n; e += 64) {
-        const uint2 item = list[e];
-        const int row = static_cast<int>(item.x >> 6);
-        if (item.x != 0xffffffffu && row >= row_lo && row < row_hi) blend_into(fb, static_cast<int>(item.x), item.y, 255);
-    }
+#pragma unroll
+    for (int k = 0; k < kOverlayPerLane; k++)
+        if (item[k].x != 0xffffffffu) blend_into(fb, static_cast<int>(item[k].x), item[k].y, 255);
     wave_order();
 }
 
