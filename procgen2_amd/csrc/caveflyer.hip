@@ -1227,10 +1227,10 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
         const Camera at{__uint_as_float(M.w[PM_GAME + GW_CAM_X]), __uint_as_float(M.w[PM_GAME + GW_CAM_Y]), cam.sw, cam.sh, cam.scale};
         has = resolve_rotated_at(at, d.y, d.z, d.x, rx, ry, is_puff ? puff_sn : shot_sn, is_puff ? puff_cs : shot_cs, size, alpha, mine);
     }
-#ifndef PG_CAVE_ROT_GROUPS
-#define PG_CAVE_ROT_GROUPS 1
-#endif
-    wave_replay_rows<4, PG_CAVE_ROT_GROUPS != 0>(fb, atlas, mine, __ballot(has), lane, row_lo, row_hi);
+    // The small rotated draws — exhaust particles, bullets — share their memory round trips in groups of four like the plain
+    // ones (pg_render.h kRotInGroups) instead of going alone, a round trip each: 107.8 -> 118.9 M env-steps/s same-box.  (Groups of
+    // two: the same; of six or eight: the kernel spills, 85.6 and 78.4 M.)  The ship, more than 64 pixels, still goes alone.
+    wave_replay_rows<4, true>(fb, atlas, mine, __ballot(has), lane, row_lo, row_hi);
     wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, row_lo, row_hi);
 }
 
