@@ -186,6 +186,51 @@ def launch_ranks(a):
     return subprocess.run(cmd, env=env).returncode
 
 
+def first_contact_report(stage, rank, local_rank, world, error=None):
+    """What a maintainer needs when the first multi-GPU run fails: which rank, on which device, at which stage, under
+    which RCCL / HSA / rendezvous environment — as one JSON line on stderr instead of a bare traceback."""
+    info = {"bench_error": "first contact failed at: " + stage, "rank": rank, "local_rank": local_rank, "world_size": world,
+            "error": repr(error) if error is not None else "timed out",
+            "env": {k: v for k, v in sorted(os.environ.items())
+                    if k.startswith(("NCCL_", "RCCL_", "HSA_", "HIP_", "ROCR_", "GPU_", "MASTER_", "TORCHELASTIC_", "OMP_"))
+                    or k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK")}}
+    try:
+        import torch
+        info["visible_devices"] = torch.cuda.device_count()
+        if torch.cuda.is_available() and local_rank < torch.cuda.device_count():
+            info["device"] = torch.cuda.get_device_name(local_rank)
+    except Exception as exc:  # the report must come out whatever state torch is in
+        info["device_query_error"] = repr(exc)
+    print(json.dumps(info), file=sys.stderr, flush=True)
+
+
+class FirstContact:
+    """Guards the stages of a rank's first contact with the others (rendezvous, first barrier, first all_reduce, first
+    gather): a stage that raises OR hangs past the timeout (BENCH_FIRST_CONTACT_TIMEOUT seconds, default 180; a collective
+    over a broken link blocks rather than raises) ends the process non-zero behind a first_contact_report."""
+
+    def __init__(self, rank, local_rank, world):
+        self.rank, self.local_rank, self.world = rank, local_rank, world
+        self.timeout = float(os.environ.get("BENCH_FIRST_CONTACT_TIMEOUT", "180"))
+
+    def stage(self, name, fn):
+        import threading
+
+        def expired():
+            first_contact_report(name, self.rank, self.local_rank, self.world)
+            os._exit(3)  # (a blocked collective cannot be interrupted from Python)
+        timer = threading.Timer(self.timeout, expired)
+        timer.daemon = True
+        timer.start()
+        try:
+            return fn()
+        except BaseException as exc:
+            first_contact_report(name, self.rank, self.local_rank, self.world, exc)
+            raise SystemExit(3)
+        finally:
+            timer.cancel()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -230,9 +275,20 @@ def main():
         world, rank, local_rank = 1, 0, 0
     if distributed:
         import torch.distributed as dist
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        contact = FirstContact(rank, local_rank, world)
+        contact.stage("torch.cuda.set_device(LOCAL_RANK)", lambda: torch.cuda.set_device(local_rank))
+        contact.stage("init_process_group(nccl)", lambda: dist.init_process_group(
+            "nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+            timeout=datetime.timedelta(seconds=contact.timeout)))
+
+        def first_collectives():
+            dist.barrier()
+            probe = torch.ones(1, dtype=torch.float64, device="cuda")
+            dist.all_reduce(probe, op=dist.ReduceOp.MAX)
+            torch.cuda.synchronize()
+        contact.stage("first barrier + all_reduce", first_collectives)
     n_gpus = world if distributed else 1
     if a.gpus != n_gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d" % (a.gpus, n_gpus))
@@ -392,7 +448,20 @@ def mixed(a, torch, ProcgenVecEnv, distributed, world, rank, local_rank, n_gpus,
         at += count
     for e in envs:
         e.reset()
-    gather = RootGather(local, dst=0, slabs=whole) if gathering else None  # 3 transfers per peer and step
+    gather = None
+    if gathering:  # 3 transfers per peer and step; the plan is one all_gather of the per-rank counts
+        gather = FirstContact(rank, local_rank, world).stage("RootGather plan (all_gather of the counts)",
+                                                             lambda: RootGather(local, dst=0, slabs=whole))
+    if gather is not None:  # the first point-to-point transfers this node has ever made: guarded like the rendezvous
+
+        def first_gather():
+            for e in envs:
+                e.publish()
+            gather()
+            for e in envs:
+                e.consume()
+            torch.cuda.synchronize()
+        FirstContact(rank, local_rank, world).stage("first RootGather (batch_isend_irecv)", first_gather)
 
     from procgen2_amd.vec_env import step_many_synthetic
 

@@ -1202,17 +1202,7 @@ __global__ void __launch_bounds__(64, 5) render_kernel(State s, AtlasView atlas,
     if (mask && !mask[env]) return;
     const int lane = threadIdx.x & 63, half = blockIdx.x % halves;
     __shared__ alignas(16) uint32_t fb[kFbWords / halves];  // this wave's rows only: frame row row_lo is its row 0
-#if defined(PG_TIMELINE)  // (latency experiment, tools/build_exp.py + tools/probe/wave_timeline.py: where a wave's life goes)
-    unsigned long long tl[6];
-#define PG_TL(k)                                \
-    do {                                        \
-        __builtin_amdgcn_s_waitcnt(0);          \
-        __builtin_amdgcn_wave_barrier();        \
-        tl[k] = __builtin_amdgcn_s_memtime();   \
-    } while (0)
-#else
-#define PG_TL(k) do {} while (0)
-#endif
+    PG_TL_BEGIN(6);
     PG_TL(0);
     const uint32_t meta = __builtin_amdgcn_readfirstlane(s.prep.meta[env]);
     const int n_bullets = meta & 0xffu, n_draws = (meta >> 8) & 0xffu, backdrop = meta >> 16;
@@ -1246,13 +1236,7 @@ __global__ void __launch_bounds__(64, 5) render_kernel(State s, AtlasView atlas,
     wave_replay_rows<4, true>(fb, atlas, draw, md, lane, 0, kOwnRows);
     PG_TL(4);
     wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, row_lo, row_hi, 0);
-#if defined(PG_TIMELINE)
-    PG_TL(5);
-    if (lane == 0) {
-        unsigned long long* out = reinterpret_cast<unsigned long long*>(io.obs + size_t(env) * kObsBytes + half * (kObsBytes / 2));
-        for (int k = 0; k < 6; k++) out[k] = tl[k];
-    }
-#endif
+    PG_TL_END(6, true, io.obs + size_t(env) * kObsBytes + half * (kObsBytes / 2));
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -863,17 +863,7 @@ PG_D void render_env(const State& s, const AtlasView& atlas, const StepIO& io, i
     const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // two wavefronts per env (pg_render.h)
     constexpr int halves = 2;
 
-#if defined(PG_TIMELINE)  // (latency experiment, tools/build_exp.py + tools/probe/wave_timeline.py: where a wave's life goes)
-    unsigned long long tl[7];
-#define PG_TL(k)                                \
-    do {                                        \
-        __builtin_amdgcn_s_waitcnt(0);          \
-        __builtin_amdgcn_wave_barrier();        \
-        tl[k] = __builtin_amdgcn_s_memtime();   \
-    } while (0)
-#else
-#define PG_TL(k) do {} while (0)
-#endif
+    PG_TL_BEGIN(7);
     PG_TL(0);
     const View view = view_of_world();
     const Camera& cam = view.cam;
@@ -1110,13 +1100,7 @@ PG_D void render_env(const State& s, const AtlasView& atlas, const StepIO& io, i
     PG_MARK("v_drawn");
     // each wave stores the rows it owns (pg_render.h wave_replay_rows): no barrier
     wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, half * (kObsH / halves), (half + 1) * (kObsH / halves));
-#if defined(PG_TIMELINE)
-    PG_TL(6);
-    if (lane == 0 && composed) {
-        unsigned long long* out = reinterpret_cast<unsigned long long*>(io.obs + size_t(env) * kObsBytes + half * (kObsBytes / 2));
-        for (int k = 0; k < 7; k++) out[k] = tl[k];
-    }
-#endif
+    PG_TL_END(7, composed, io.obs + size_t(env) * kObsBytes + half * (kObsBytes / 2));
 }
 
 // Once per engine: the composer's tables for the one view there is (State::prepared).
@@ -1398,8 +1382,8 @@ class ChaserGame final : public Game {
     void launch_logic(hipStream_t st, const int32_t* actions, uint32_t run_seed, uint32_t step_index, int env_offset,
                       StepIO io) override {
         s_.parity = static_cast<int>(step_index & 1u);
-        s_.listing = reset_stream ? 1 : 0;
-        LevelLaunch<Gen>::auto_reset(reset_stream ? reset_stream : st, s_, 0, io, plan, kResetSpan);
+        s_.listing = 1;  // (the envs reset in this step are listed for the late pass)
+        LevelLaunch<Gen>::auto_reset(reset_stream, s_, 0, io, plan, kResetSpan);  // engine.hip: always there for a game that resets beside its logic
         hipLaunchKernelGGL(logic_kernel, dim3((s_.n * kGang + 63) / 64), dim3(64), 0, st, s_, actions, run_seed, step_index,
                            env_offset, io);
     }
@@ -1420,13 +1404,13 @@ class ChaserGame final : public Game {
     }
     // A step's frames start from the base layers when every env drawn by this launch has a current one: the layers are
     // valid (not right after make / pgv_load_state), the envs reset in this step are left to the late pass (resets on their
-    // own stream: the default), the point sprite is a stamp (an opaque box in a clear rim: true of the reference's asset).
-    bool from_base() const { return lean() && base_valid_ && reset_stream != nullptr && stamp_ok_; }
+    // own stream), the point sprite is a stamp (an opaque box in a clear rim: true of the reference's asset).
+    bool from_base() const { return lean() && base_valid_ && stamp_ok_; }
     void launch_render_step(hipStream_t st, StepIO io) override {
         if (from_base())
             hipLaunchKernelGGL(render_kernel<true>, dim3(s_.n), dim3(128), 0, st, s_, atlas_, nullptr, io, debug_flags, 1);
         else
-            hipLaunchKernelGGL(render_kernel<false>, dim3(s_.n), dim3(128), 0, st, s_, atlas_, nullptr, io, debug_flags, reset_stream ? 1 : 0);
+            hipLaunchKernelGGL(render_kernel<false>, dim3(s_.n), dim3(128), 0, st, s_, atlas_, nullptr, io, debug_flags, 1);
         base_valid_ = true;  // (either way every env's layer has been written by now, or is by this launch and the late pass)
     }
     static size_t up256(size_t b) { return (b + 255) & ~size_t(255); }
@@ -1447,7 +1431,6 @@ class ChaserGame final : public Game {
         base_valid_ = false;
     }
     bool launch_render_late(hipStream_t st, StepIO io) override {
-        if (!reset_stream) return false;
         const int groups = s_.n < 1024 ? s_.n : 1024;
         hipLaunchKernelGGL(render_list_kernel, dim3(groups), dim3(128), 0, st, s_, atlas_, io, debug_flags);
         return true;

@@ -1036,7 +1036,7 @@ class ClimberGame final : public Game {
                       StepIO io) override {
         // prefetched levels are installed beside the logic (its second row of blocks); the level kernel behind it
         // generates, synchronously, the levels that were not ready — none in steady state (pg_prefetch.h install_prefetched)
-        const bool fused = prefetch() && install_in_logic();
+        const bool fused = prefetch() != 0;
         if (!fused) LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io, plan, PG_RESET_SPAN, reset_served_mark(step_index), reset_due_mark(step_index));
         hipLaunchKernelGGL(logic_kernel, dim3((s_.n * kGang + 63) / 64, fused ? 2 : 1), dim3(64), 0, st, s_, actions, run_seed, step_index,
                            env_offset, io, prefetch(), plan);

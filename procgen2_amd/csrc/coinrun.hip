@@ -848,8 +848,7 @@ __global__ void __launch_bounds__(64) make_kernel(State s, uint32_t seed_base, i
 // A + B — the agent's sub-steps and the entities' in ONE launch (round 5): neither needs the other.  The agent depends on
 // tiles, the entities on tiles and their own state; what joins them — does a hazard's box overlap the agent's after
 // sub-step ss — is held by resolve_kernel, behind both.  As two launches they were two latency chains end to end (34 and
-// 46 µs) and a kernel boundary; side by side the step pays for the longer one.  Rows of blocks (row = blockIdx.y + row_base;
-// row_base: the two-launch form, PG_SPLIT_LOGIC=1, for the A/B):
+// 46 µs) and a kernel boundary; side by side the step pays for the longer one.  Rows of blocks (row = blockIdx.y):
 //   row 0 — lane = env: the agent's sub-steps into the scratch table (envs that reset in this step sit it out);
 //   row 1 — the auto-reset of those envs whose next level lies ready in its shadow slot (pg_prefetch.h install_prefetched:
 //     a copy), beside the agents instead of in a launch in front of them.  The rows share nothing of a resetting env but
@@ -872,8 +871,8 @@ __global__ void __launch_bounds__(64) make_kernel(State s, uint32_t seed_base, i
 #endif
 __global__ void __launch_bounds__(64, PG_COINRUN_LOGIC_WAVES) logic_kernel(State s, const int32_t* actions, uint32_t run_seed, uint32_t step_index,
                                                    int env_offset, StepIO io, int prefetch, LevelPlan plan, int install_row,
-                                                   int row_base, float reach_x, float reach_y) {
-    const int row = static_cast<int>(blockIdx.y) + row_base;
+                                                   float reach_x, float reach_y) {
+    const int row = static_cast<int>(blockIdx.y);
     const int lane = threadIdx.x;
     int env = blockIdx.x * 64 + lane;
     if (row == 1) {  // (block-uniform)
@@ -1017,9 +1016,6 @@ __global__ void __launch_bounds__(64) resolve_kernel(State s, StepIO io, uint32_
                           (((bits >> (4 + last)) & 1) ? kFlagForward : 0) | (src ? 0 : kFlagBuf);
     const bool terminated = !alive || got_coin;  // coinrun.cpp:366
     io.reward[env] = got_coin * 10.0f;           // coinrun.cpp:364, last executed sub-step only (D4)
-#ifdef PG_EXP_COUNT_FAR
-    if (bits & kBitsFar) io.reward[env] = 12345.0f;  // (experiment build: how often does the agent leave its reach?)
-#endif
     io.done[env] = terminated ? 1 : 0;
     io.pending[env] = terminated ? reset_due_mark(step_index + 1u) : 0;
 }
@@ -1048,14 +1044,6 @@ PG_D void render_full(const State& s, const AtlasView& atlas, const StepIO& io, 
     // before its first pixel is (render 0.440 -> 0.435 ms against an array of their own: 1.5 KB less LDS per env).
     uint32_t* const slots = fb + kFbWords - kBlitWords * 64;
     static_assert(sizeof(ComposeTmp<kGrid>) + sizeof(ComposeHand) + kBlitWords * 64 * 4 <= kFbWords * 4, "room behind the set-up tables");
-#if defined(PG_ABLATE) && defined(PG_LDS_PAD)  // occupancy experiment: fewer envs per CU
-    __shared__ uint32_t lds_pad[PG_LDS_PAD];
-    if (flags & 0x40000000) {
-        lds_pad[(threadIdx.x * 37) % PG_LDS_PAD] = env;
-        __syncthreads();
-        fb[lane] = lds_pad[(lane * 11) % PG_LDS_PAD];
-    }
-#endif
 
     const Camera cam{SF(s, F_CAMX, env), SF(s, F_CAMY, env), 64.0f, 64.0f, 0.3f * 64.0f / 64.0f};
     const int themes = SI(s, I_THEMES, env);
@@ -1626,21 +1614,7 @@ __global__ void __launch_bounds__(64 * kRenderWaves, PG_COINRUN_RENDER_WAVES) re
     constexpr int halves = kRenderWaves;
     __shared__ alignas(16) uint32_t fb[kFbWords];
     __shared__ ComposeLds<kGrid> L;  // the composer's cell table
-#if defined(PG_LDS_PAD_LEAN)  // occupancy experiment (tools/build_exp.py): PG_LDS_PAD_LEAN more words of LDS per env → fewer envs per CU
-    __shared__ uint32_t lean_pad[PG_LDS_PAD_LEAN];
-    if (flags == 0x7fffffff) lean_pad[threadIdx.x % PG_LDS_PAD_LEAN] = env;  // (never true: keeps the array allocated)
-#endif
-#if defined(PG_TIMELINE)  // (latency experiment, tools/build_exp.py + tools/probe/wave_timeline.py: where a wave's life goes)
-    unsigned long long tl[6];
-#define PG_TL(k)                                \
-    do {                                        \
-        __builtin_amdgcn_s_waitcnt(0);          \
-        __builtin_amdgcn_wave_barrier();        \
-        tl[k] = __builtin_amdgcn_s_memtime();   \
-    } while (0)
-#else
-#define PG_TL(k) do {} while (0)
-#endif
+    PG_TL_BEGIN(6);
     PG_TL(0);
     // One round trip for everything the frame starts from: the packed axes, the kind offsets, this wave's half of the
     // cell bytes (vector loads) and the meta line (scalar loads) leave together; only the draws wait for their count.
@@ -1670,13 +1644,7 @@ __global__ void __launch_bounds__(64 * kRenderWaves, PG_COINRUN_RENDER_WAVES) re
     replay_finish(fb, atlas, mine, sprite_pass, lane, row_lo, row_hi);
     PG_TL(4);
     if (!PG_ABL(flags, 8)) wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, row_lo, row_hi);
-#if defined(PG_TIMELINE)
-    PG_TL(5);
-    if (lane == 0) {
-        unsigned long long* out = reinterpret_cast<unsigned long long*>(io.obs + size_t(env) * kObsBytes + half * (kObsBytes / 2));
-        for (int k = 0; k < 6; k++) out[k] = tl[k];
-    }
-#endif
+    PG_TL_END(6, true, io.obs + size_t(env) * kObsBytes + half * (kObsBytes / 2));
 }
 
 // cenv_render's frame (coinrun.cpp:393-411 → render_game(false), :443-470) for one env: pg_frame.h.
@@ -1817,7 +1785,7 @@ class CoinrunGame final : public Game {
 
     static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
     struct Layout {
-        size_t shadow, slot, mt, tiles, f, i, ey, eb, df, db, spark, scratch, hazx, hazy, total;
+        size_t shadow, slot, mt, tiles, f, i, ey, eb, df, db, spark, scratch, total;
     };
     static Layout layout(int n) {
         Layout l{};
@@ -1839,8 +1807,6 @@ class CoinrunGame final : public Game {
         l.db = take(size_t(2) * kMaxEnt * n);
         l.spark = take(size_t(2) * 3 * kMaxEnt * kSparkRow * n * 4);
         l.scratch = take(size_t(SC_COUNT) * n * 4);
-        l.hazx = take(size_t(kMaxEnt) * n * sizeof(float4));
-        l.hazy = take(size_t(kMaxEnt) * n * sizeof(float2));
         l.total = off;
         return l;
     }
@@ -1861,8 +1827,6 @@ class CoinrunGame final : public Game {
         s_.db = p + l.db;
         s_.spark = reinterpret_cast<float*>(p + l.spark);
         s_.scratch = reinterpret_cast<float*>(p + l.scratch);
-        s_.hazx = reinterpret_cast<float4*>(p + l.hazx);
-        s_.hazy = reinterpret_cast<float2*>(p + l.hazy);
         atlas_ = atlas;
     }
     int blocks() const { return (s_.n + 63) / 64; }
@@ -1883,31 +1847,22 @@ class CoinrunGame final : public Game {
                       StepIO io) override {
         // the auto-resets: a prefetched level is installed beside the agents (logic_kernel's row 1); the levels that were
         // not ready — none in steady state — are generated synchronously behind it
-        const bool fused = prefetch() && install_in_logic();
+        const bool fused = prefetch() != 0;
         const int served = reset_served_mark(step_index), due = reset_due_mark(step_index);
         if (!fused) LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io, plan, PG_RESET_SPAN, served, due);
-        // agents, prefetched installs and entities side by side (logic_kernel); PG_SPLIT_LOGIC=1: the entities in a launch
-        // of their own behind the agents, as until round 5 (the A/B)
-        static const bool split = [] { const char* e = std::getenv("PG_SPLIT_LOGIC"); return e && e[0] == '1'; }();
-        const dim3 blocks((s_.n + 63) / 64, split ? 2 : 2 + 2 * kMaxEnt);
+        // agents, prefetched installs and entities side by side (logic_kernel)
+        const dim3 blocks((s_.n + 63) / 64, 2 + 2 * kMaxEnt);
         // (bit 24: no reach — the tests' way to resolve_kernel's fallback, see hazard_near)
         const float reach_x = (debug_flags & kDebugCoinrunNoReach) ? 0.0f : kReachX;
         const float reach_y = (debug_flags & kDebugCoinrunNoReach) ? 0.0f : kReachY;
         hipLaunchKernelGGL(logic_kernel, blocks, dim3(64), 0, st, s_, actions, run_seed, step_index, env_offset, io,
-                           prefetch(), plan, fused ? 1 : 0, 0, reach_x, reach_y);
+                           prefetch(), plan, fused ? 1 : 0, reach_x, reach_y);
         // (Measured and rejected, round 5, when agents and entities were two launches: that level kernel on a stream of
         // its own beside the entities — forked behind the agents, joined in front of resolve_kernel: 123.6 against 126.7 M
         // env-steps/s, three same-box pairs; the two event hand-overs cost more than they hide.)
-        // They ride in resolve_kernel's second row (see there: +0.6 to 1 %); with fewer than 64 lanes per logic block
-        // (PG_LOGIC_LANES, experiments) or PG_LATE_LAUNCH=1 (the A/B) they keep a launch of their own.
-        static const bool late_launch = [] { const char* e = std::getenv("PG_LATE_LAUNCH"); return e && e[0] == '1'; }();
-        const bool late_row = fused && logic_lanes() == 64 && !late_launch;
-        if (fused && !late_row) LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io, plan, PG_RESET_SPAN, served, due);
-        if (split)
-            hipLaunchKernelGGL(logic_kernel, dim3((s_.n + 63) / 64, 2 * kMaxEnt), dim3(64), 0, st, s_, actions, run_seed,
-                               step_index, env_offset, io, prefetch(), plan, 0, 2, reach_x, reach_y);
-        hipLaunchKernelGGL(resolve_kernel, dim3(logic_blocks(s_.n), late_row ? 2 : 1), dim3(logic_lanes()), 0, st, s_, io,
-                           step_index, prefetch(), plan);
+        // The resets no prefetched level lay ready for ride in resolve_kernel's second row (see there: +0.6 to 1 %).
+        hipLaunchKernelGGL(resolve_kernel, dim3((s_.n + 63) / 64, fused ? 2 : 1), dim3(64), 0, st, s_, io, step_index, prefetch(),
+                           plan);
     }
     bool launch_frame(hipStream_t st, int env, uint32_t* d_px, int w, int h) override {
         hipLaunchKernelGGL(frame_kernel, dim3(1), dim3(kFrameThreads), 0, st, s_, atlas_, env, FrameTarget{d_px, w, h});
@@ -1921,8 +1876,19 @@ class CoinrunGame final : public Game {
         hipLaunchKernelGGL(render_kernel, dim3(s_.n), dim3(64 * kRenderWaves), 0, st, s_, atlas_, mask, io,
                            debug_flags);
     }
-    size_t scratch_bytes(int n) const override { return prep_bytes(n, kGrid, kBlitWords, false); }
-    void bind_scratch(void* d_scratch, int n) override { s_.prep = prep_bind(d_scratch, n, kGrid, kBlitWords, false); }
+    // Scratch (not state, not in snapshots): the pre-pass's hand-over, then the hazards' boxes — written by logic_kernel's
+    // entity lanes and read by resolve_kernel of the same step, only where a candidate bit of that step says so.
+    static size_t up256(size_t b) { return (b + 255) & ~size_t(255); }
+    size_t scratch_bytes(int n) const override {
+        return up256(prep_bytes(n, kGrid, kBlitWords, false)) + up256(size_t(kMaxEnt) * n * sizeof(float4)) +
+               up256(size_t(kMaxEnt) * n * sizeof(float2));
+    }
+    void bind_scratch(void* d_scratch, int n) override {
+        s_.prep = prep_bind(d_scratch, n, kGrid, kBlitWords, false);
+        uint8_t* p = static_cast<uint8_t*>(d_scratch) + up256(prep_bytes(n, kGrid, kBlitWords, false));
+        s_.hazx = reinterpret_cast<float4*>(p);
+        s_.hazy = reinterpret_cast<float2*>(p + up256(size_t(kMaxEnt) * n * sizeof(float4)));
+    }
 
     // Same layout as oracle/pgo_coinrun.cpp Coinrun::dump_state.
     int dump_state(hipStream_t st, int env, float* out, int cap) override {

@@ -34,23 +34,6 @@ static int fail(const std::string& msg) {
         if (e_ != hipSuccess) return fail(std::string(#call) + ": " + hipGetErrorString(e_));    \
     } while (0)
 
-int logic_lanes() {
-    static const int lanes = [] {
-        const char* e = std::getenv("PG_LOGIC_LANES");
-        const int v = e ? std::atoi(e) : 64;
-        return (v == 8 || v == 16 || v == 32 || v == 64) ? v : 64;
-    }();
-    return lanes;
-}
-
-bool install_in_logic() {
-    static const bool on = [] {
-        const char* e = std::getenv("PG_SEPARATE_INSTALL");
-        return !(e && e[0] == '1');
-    }();
-    return on;
-}
-
 // ------------------------------------------------------------------------------------------------
 // Atlas
 // ------------------------------------------------------------------------------------------------
@@ -390,19 +373,9 @@ int32_t pgv_make_config(const pgv_config* cfg, pgv_env** out) {
         e->own_stream = true;
     }
     for (auto& ev : e->ev) PG_HIP(hipEventCreate(&ev));
-    {   // The level generator's stream.  PG_SIDE_PRIORITY=low (A/B only) asks the runtime for its lowest
-        // stream priority: measured on the seven-game slab, round 5 — see DESIGN.md.
-        const char* pr = std::getenv("PG_SIDE_PRIORITY");
-        if (pr && !std::strcmp(pr, "low")) {
-            int least = 0, greatest = 0;
-            PG_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            PG_HIP(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, least));
-        } else {
-            PG_HIP(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
-        }
-    }
+    PG_HIP(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));  // the level generator's stream
     for (auto& ev : e->side_ev) PG_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    if (e->game->resets_beside_logic() && !std::getenv("PG_SERIAL_RESETS")) {  // (the variable: A/B measurements only)
+    if (e->game->resets_beside_logic()) {
         {   // the few long wavefronts of the in-step level kernel go first; the logic kernel's many short ones fill in around them
             int least = 0, greatest = 0;
             PG_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -484,7 +457,11 @@ static int32_t step_impl(pgv_env* e, const int32_t* d_actions, uint32_t run_seed
         const hipError_t now = hipGetLastError();
         if (status == hipSuccess && now != hipSuccess) status = now;
     };
-    e->game->launch_logic(e->stream, d_actions, run_seed, e->step_index, e->env_offset, e->io());
+    // The step counter moves as soon as the logic launch has been issued, whatever becomes of the rest: the logic kernels
+    // write "reset due in step index + 1" into the pending bytes (pg_prefetch.h reset_due_mark), and a counter that stayed
+    // behind after a failed later launch would have the next call read those marks as another step's.
+    const uint32_t step_index = e->step_index++;
+    e->game->launch_logic(e->stream, d_actions, run_seed, step_index, e->env_offset, e->io());
     launched();
     pregen(e, false, false);  // before the render launch: the generator overlaps it
     launched();
@@ -509,7 +486,6 @@ static int32_t step_impl(pgv_env* e, const int32_t* d_actions, uint32_t run_seed
         }
     }
     if (status != hipSuccess) return fail(std::string("step: ") + hipGetErrorString(status));
-    e->step_index++;
     return 0;
 }
 
@@ -605,8 +581,9 @@ struct SnapshotHeader {
 // "PGN" + the version of the state-blob layouts: bump it whenever any game's State / Level / field enums change — equal
 // state_bytes does not mean equal layout (sizes are rounded to 256 bytes), and an old blob would load silently.
 // 2: round 2.  3: round 3 (per-env contiguous rings and entity tables in bossfight, caveflyer, chaser, climber; caveflyer's
-// wall-bit columns and hazard places).
-static constexpr uint32_t kSnapshotMagic = 0x50474e33u;
+// wall-bit columns and hazard places).  4: round 5/6 (the pending byte carries the parity of the step it is about —
+// pg_prefetch.h reset_due_mark / reset_served_mark — where it used to be 0 / 1; coinrun's hazard hand-off left the blob).
+static constexpr uint32_t kSnapshotMagic = 0x50474e34u;
 
 static size_t snapshot_bytes(const pgv_env* e) {
     return sizeof(SnapshotHeader) + state_blob_bytes(e) + size_t(e->n) * (4 + 1 + 1) +

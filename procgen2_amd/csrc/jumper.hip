@@ -1193,17 +1193,7 @@ __global__ void __launch_bounds__(128, PG_RENDER_WAVES) render_kernel(State s, A
     constexpr int halves = 2;
     __shared__ alignas(16) uint32_t fb[kFbWords];
     __shared__ ComposeLds<kGrid> L;
-#if defined(PG_TIMELINE)  // (latency experiment, tools/build_exp.py + tools/probe/wave_timeline.py: where a wave's life goes)
-    unsigned long long tl[8];
-#define PG_TL(k)                                \
-    do {                                        \
-        __builtin_amdgcn_s_waitcnt(0);          \
-        __builtin_amdgcn_wave_barrier();        \
-        tl[k] = __builtin_amdgcn_s_memtime();   \
-    } while (0)
-#else
-#define PG_TL(k) do {} while (0)
-#endif
+    PG_TL_BEGIN(8);
     PG_TL(0);
     const PrepMeta M{s.prep.meta + size_t(env) * kPrepMetaWords};
     const uint32_t colw = s.prep.axes[size_t(env) * 128 + lane], roww = s.prep.axes[size_t(env) * 128 + 64 + lane];
@@ -1267,13 +1257,7 @@ __global__ void __launch_bounds__(128, PG_RENDER_WAVES) render_kernel(State s, A
         wave_replay_rows(fb, atlas, mine, __ballot(has), lane, row_lo, row_hi);
     }
     wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, row_lo, row_hi);
-#if defined(PG_TIMELINE)
-    PG_TL(7);
-    if (lane == 0 && s.hud_image != 0u) {
-        unsigned long long* out = reinterpret_cast<unsigned long long*>(io.obs + size_t(env) * kObsBytes + half * (kObsBytes / 2));
-        for (int k = 0; k < 8; k++) out[k] = tl[k];
-    }
-#endif
+    PG_TL_END(8, s.hud_image != 0u, io.obs + size_t(env) * kObsBytes + half * (kObsBytes / 2));
 }
 
 // cenv_render's frame (render_game(false)) for one env: pg_frame.h; the draw list of render_kernel, one draw at a time.
@@ -1527,9 +1511,9 @@ class JumperGame final : public Game {
                       StepIO io) override {
         // prefetched levels are installed beside the logic (its second row of blocks); the level kernel behind it
         // generates, synchronously, the levels that were not ready — none in steady state (pg_prefetch.h install_prefetched)
-        const bool fused = prefetch() && install_in_logic();
+        const bool fused = prefetch() != 0;
         if (!fused) LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io, plan, PG_RESET_SPAN, reset_served_mark(step_index), reset_due_mark(step_index));
-        hipLaunchKernelGGL(logic_kernel, dim3(logic_blocks(s_.n), fused ? 2 : 1), dim3(logic_lanes()), 0, st, s_, actions, run_seed, step_index,
+        hipLaunchKernelGGL(logic_kernel, dim3((s_.n + 63) / 64, fused ? 2 : 1), dim3(64), 0, st, s_, actions, run_seed, step_index,
                            env_offset, io, prefetch(), plan);
         if (fused) LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io, plan, PG_RESET_SPAN, reset_served_mark(step_index), reset_due_mark(step_index));
     }

@@ -165,13 +165,6 @@ constexpr int kDebugNoPrepass = 1 << 21;  // (clear of the -DPG_ABLATE experimen
 constexpr int kDebugFatThirds = 1 << 23;
 constexpr int kDebugCoinrunNoReach = 1 << 24;
 
-// Lanes per workgroup of the lane-per-env logic kernels: fewer envs per wave = more waves.
-int logic_lanes();
-// Whether a game's prefetched levels are installed inside its first logic launch (pg_prefetch.h install_prefetched; the
-// default) or by the level kernel in a launch of its own in front of it (PG_SEPARATE_INSTALL=1: same-box A/B only).
-bool install_in_logic();
-inline int logic_blocks(int n) { return (n + logic_lanes() - 1) / logic_lanes(); }
-
 // Factories, one per compiled variant of a game (pg_defs.h PG_VARIANT; v0 = the reference's compile-time default).
 std::unique_ptr<Game> make_coinrun_v0();
 std::unique_ptr<Game> make_maze_v0();

@@ -231,9 +231,6 @@ PG_HD uint32_t mul_pair(uint32_t halves, uint32_t byte) {  // both bytes of 0x00
 // yields src — both fall out of the formula, no special cases needed.  Red and blue go through the arithmetic
 // together, as the two halves of one word (render kernels are bound by vector instructions: 25 instead of 32 a pixel).
 PG_HD uint32_t blend_px(uint32_t dst, uint32_t src, int a) {
-#ifdef PG_EXP_NOBLEND  // timing experiment only (tools/build_exp.py): what the blend arithmetic costs at most
-    return (src & 0x00ffffffu) ^ (dst & 1u) ^ static_cast<uint32_t>(a & 1);
-#endif
     const uint32_t ua = static_cast<uint32_t>(a), ia = 255u - ua;
 #ifdef PG_BLEND_CHANNELWISE  // the three channels one by one: same result; chaser's render kernel, whose scalar unit is as
                              // busy as its vector unit, measured 5 % slower with the paired form (every other game 0–2.5 % faster)

@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(64) level_kernel(typename G::State s, int mode
 // generator's latency) — they keep pending == 1 and are generated synchronously there, as before; in steady state that
 // launch finds nothing (one load per lane).  The generator's 256 registers stay out of the logic kernel this way
 // (the fused kernel WITH the generator ran at one wave per SIMD and took the sum of the two chains).
-// One wavefront (blockDim ≤ 64); `lv` is a Level in LDS.  Served envs are left at pending == served_mark, as mode 2 leaves them.
+// One wavefront of 64 lanes (the copies stride by 64); `lv` is a Level in LDS.  Served envs are left at pending == served_mark, as mode 2 leaves them.
 //
 // The pending byte when install and logic share a launch — a game whose ONE logic kernel both reads the byte (is this
 // step the env's reset?) and writes it (the env terminated: reset it next step).  Two races to keep out:

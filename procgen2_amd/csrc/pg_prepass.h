@@ -108,12 +108,8 @@ struct PrepLds {
 // that the 145 MB a launch leaves dirty in the L2s are written back at the kernel's end, in front of the render launch,
 // which rocprofv3 shows 19 µs longer behind a pre-pass than behind none — coinrun's render kernel went from 0.333 to
 // 0.398 ms, climber's 0.334 -> 0.395: what the render workgroups read a few microseconds later then comes from HBM
-// instead of the Infinity Cache the write-back leaves it in.  -DPG_PREP_NT_STORES keeps the experiment.)
-#ifdef PG_PREP_NT_STORES
-#define PG_PREP_STORE(value, ptr) __builtin_nontemporal_store((value), (ptr))
-#else
+// instead of the Infinity Cache the write-back leaves it in.)
 #define PG_PREP_STORE(value, ptr) (*(ptr) = (value))
-#endif
 typedef uint32_t prep_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t prep_u32x2 __attribute__((ext_vector_type(2)));
 
@@ -124,12 +120,8 @@ typedef uint32_t prep_u32x2 __attribute__((ext_vector_type(2)));
 // groups of ONE XCD are consecutive: the line is fetched once.  (Any mapping gives the same frames; n_groups not a
 // multiple of 8: the tail keeps its place.)
 PG_D int prep_block(int b, int n_groups) {
-#ifdef PG_NO_XCD_MAP  // (A/B only)
-    return b;
-#else
     const int per = n_groups >> 3, body = per << 3;
     return b < body ? (b & 7) * per + (b >> 3) : b;
-#endif
 }
 
 PG_D uint32_t pack_halves(int lo, int hi) { return (static_cast<uint32_t>(lo) & 0xffffu) | (static_cast<uint32_t>(hi) << 16); }

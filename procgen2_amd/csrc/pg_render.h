@@ -26,23 +26,8 @@
 
 #include "pg_engine.h"
 #include "pg_geom.h"
+#include "pg_probe.h"  // PG_ABL / PG_MARK / PG_TL: nothing in the product build
 #include "pg_sincos.h"
-
-// Timing experiments (tools/ablate_render.py) change the picture; they exist only in the -DPG_ABLATE build
-// (`python -m procgen2_amd.build --ablate` → lib/libprocgen2_hip_ablate.so).  In the product build every test on an
-// ablation bit is the constant 0 and the compiler drops the branch.
-#ifdef PG_ABLATE
-#define PG_ABL(flags, bits) ((flags) & (bits))
-#else
-#define PG_ABL(flags, bits) 0
-#endif
-// Phase markers for the static instruction inventory (tools/isa_phases.py compiles with -DPG_MARKS and splits the
-// kernel's assembly at them); nothing in the product build.
-#ifdef PG_MARKS
-#define PG_MARK(name) asm volatile("; PGMARK " name)
-#else
-#define PG_MARK(name) ((void)0)
-#endif
 
 namespace pg {
 

@@ -21,3 +21,9 @@ print(c.get("game","mixed"), round(d["value"]/1e6,1), "M env-steps/s", round(d["
 PY
 done
 head -4 gpurun_out/${TAG}_coinrun_kernel_stats.csv | cut -c1-200
+# the regression gate: every line against the committed line of the same workload of the round before (tools/check_bench.py)
+AGAINST=${CHECK_AGAINST:-profiles/bench_r05}
+for f in gpurun_out/${TAG}_bench_*.json; do
+  case $f in *driver_args*) continue;; esac
+  python tools/check_bench.py "$f" --against $AGAINST || echo "check_bench: $f: exit $?"
+done
