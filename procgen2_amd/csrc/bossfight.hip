@@ -24,6 +24,7 @@
 // 0.783 -> 0.806 ms: the two barriers per shared draw cost more than the idle lower wave.)
 #include "pg_render.h"
 #include "pg_prepass.h"
+#include "pg_stamps.h"
 #include "pg_rng.h"
 #include "pg_sincos.h"
 
@@ -95,6 +96,7 @@ struct State {
         uint32_t* bullets;    // [n][64][kBulletWords]  visible boss bullets in drawing order
         uint32_t* draws;      // [n][64][kBlitWords]    the visible draws of the second list in drawing order
     } prep;
+    uint32_t stamps;  // word offset of the stamp table in the atlas (pg_stamps.h; BossfightGame::extend_atlas), 0 = none
 };
 constexpr int kBulletWords = 10;  // pg_render.h BlitWords, sine, cosine (16.16), bounding box on the target (x, y, w, h: a byte each), one spare
 constexpr int kBackdrops = 13;
@@ -1010,12 +1012,16 @@ struct SetupLds {
     int4 desc[kTexCount];
     uint32_t env[kPrepEnvs][PE_COUNT];       // the scalars of the envs of this workgroup (float bits where floats)
     PrepDrawQueue queue[kPrepThreads / 64];  // one worklist per wavefront (pg_prepass.h)
+    uint4 stamp[kTexCount * kStampsPerTex];  // pg_stamps.h: the sizes each texture is drawn at, pre-scaled
 };
 __global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView atlas, const uint8_t* mask) {
     __shared__ SetupLds S;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int env0 = prep_block(blockIdx.x, gridDim.x) * kPrepEnvs;  // (pg_prepass.h: the groups of one XCD are consecutive)
     if (tid < kTexCount) S.desc[tid] = atlas.desc[tid];
+    if (tid < kTexCount * kStampsPerTex)
+        S.stamp[tid] = s.stamps ? reinterpret_cast<const uint4*>(atlas.texels + s.stamps)[tid] : make_uint4(0u, 0u, 0u, 0u);
+    static_assert(kTexCount * kStampsPerTex <= kPrepThreads, "one entry per thread");
     if (tid >= 64 && tid < 64 + kPrepEnvs * PE_COUNT) {
         const int q = tid - 64, f = q / kPrepEnvs, e = q - f * kPrepEnvs, env = env0 + e;  // (the envs of a field side by side)
         constexpr int kInts[10] = {I_SKINS, I_FLAGS, I_A_NEXT, I_A_COUNT, I_B_NEXT, I_B_COUNT, I_X_NEXT, I_X_COUNT, I_NROCKS, I_PHASE};
@@ -1066,6 +1072,7 @@ __global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView 
                     box = rot_box(b);
                     has = box.bw > 0 && box.bh > 0;
                 }
+                if (has) stamp_substitute(&S.stamp[want_tex * kStampsPerTex], d.y, d.z, b);
             }
             const unsigned long long m_a = __ballot(has && !is_b), m_b = __ballot(has && is_b);
             const unsigned long long below = (1ull << lane) - 1ull;
@@ -1177,9 +1184,9 @@ __global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView 
                     p.alpha = alpha;
                 }
             }
-            prep_draws_pass(Q, st, S.desc, cam, cam, draws_a, draws_b, valid, is_b, p, lane);
+            prep_draws_pass(Q, st, S.desc, cam, cam, draws_a, draws_b, valid, is_b, p, lane, nullptr, S.stamp);
         }
-        prep_draws_flush(Q, st, S.desc, cam, cam, draws_a, draws_b, lane);
+        prep_draws_flush(Q, st, S.desc, cam, cam, draws_a, draws_b, lane, nullptr, S.stamp);
         if (lane < 2) {
             const int e = lane ? eb : ea;
             const bool on = lane ? on_b : on_a;
@@ -1231,9 +1238,9 @@ __global__ void __launch_bounds__(64, 5) render_kernel(State s, AtlasView atlas,
     compose_background_from<kOwnRows, true>(fb, atlas, bg_col, bg_row, lane, half);
     PG_TL(2);
     const unsigned long long mb = __ballot(has_bullet), md = __ballot(has_draw);
-    wave_replay_rows<4, true>(fb, atlas, bullet, mb, lane, 0, kOwnRows, &box);
+    wave_replay_rows<4, true, true, 4, true>(fb, atlas, bullet, mb, lane, 0, kOwnRows, &box);  // (…, stamps: setup_kernel substitutes them)
     PG_TL(3);
-    wave_replay_rows<4, true>(fb, atlas, draw, md, lane, 0, kOwnRows);
+    wave_replay_rows<4, true, true, 4, true>(fb, atlas, draw, md, lane, 0, kOwnRows);
     PG_TL(4);
     wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, row_lo, row_hi, 0);
     PG_TL_END(6, true, io.obs + size_t(env) * kObsBytes + half * (kObsBytes / 2));
@@ -1340,6 +1347,30 @@ class BossfightGame final : public Game {
     std::string check_atlas(const std::vector<std::pair<int, int>>& sizes) const override {
         return static_cast<int>(sizes.size()) == kTexCount ? "" : "bossfight: unexpected texture count";
     }
+    // The observation camera never moves or zooms (kCamSize, kCamScale), so every sprite lands at one size per texture
+    // and scale: pre-scaled stamps (pg_stamps.h) for every draw of setup_kernel's two lists — the sizes are what the
+    // kernels' own arithmetic gives (a size predicted wrongly would only never match).
+    void extend_atlas(Atlas& atlas) override {
+        std::vector<StampSpec> specs;
+        auto plain = [&](int tex, float scale, float alpha) {
+            const int4 d = atlas.desc_host(tex);
+            specs.push_back({tex, stamp_len_plain(kCamSize, kCamScale, d.y, scale), stamp_len_plain(kCamSize, kCamScale, d.z, scale), stamp_mod(alpha)});
+        };
+        auto rotated = [&](int tex, float scale) {
+            const int4 d = atlas.desc_host(tex);
+            specs.push_back({tex, stamp_len_rotated(kCamScale, d.y, scale), stamp_len_rotated(kCamScale, d.z, scale), 255});
+        };
+        for (int k = 0; k < 3; k++) rotated(kTexLaser + k, 0.1f);   // the boss's bullets …
+        for (int k = 0; k < 5; k++) rotated(kTexBoom + k, 0.1f);    // … and their explosion frames
+        for (int k = 0; k < 4; k++) plain(kTexBoss + k, 0.25f, 1.0f);
+        plain(kTexShield, 0.25f, 0.7f);
+        for (int k = 0; k < 5; k++) plain(kTexBoom + k, 0.3f, 1.0f);
+        for (int k = 0; k < 8; k++) plain(kTexRock + k, 1.0f * 0.3f * kUnitPx / atlas.desc_host(kTexRock + k).y, 1.0f);
+        for (int k = 0; k < 3; k++) plain(kTexLaser + k, 0.05f, 1.0f);  // the agent's bullets, their explosion frames, the agent
+        for (int k = 0; k < 5; k++) plain(kTexBoom + k, 0.05f, 1.0f);
+        for (int k = 0; k < 4; k++) plain(kTexPlayer + k, 0.05f, 1.0f);
+        stamps_at_ = append_stamps(atlas, kTexCount, specs);
+    }
     static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
     struct Layout {
         size_t mt, f, i, ashot, abnc, bshot, boom, rock, total;
@@ -1376,6 +1407,7 @@ class BossfightGame final : public Game {
         s_.bshot = reinterpret_cast<float*>(p + l.bshot);
         s_.boom = reinterpret_cast<float*>(p + l.boom);
         s_.rock = reinterpret_cast<float*>(p + l.rock);
+        s_.stamps = stamps_at_;
         atlas_ = atlas;
     }
     int blocks() const { return (s_.n + 63) / 64; }
@@ -1455,6 +1487,7 @@ class BossfightGame final : public Game {
    private:
     State s_{};
     AtlasView atlas_{};
+    uint32_t stamps_at_ = 0;  // extend_atlas → bind
 };
 
 }  // namespace bossfight

@@ -52,10 +52,7 @@ constexpr int kOrbs = 4 + kExtraOrbSign, kFirstPoint = kOrbs + kMobs;
 constexpr int kOpenCells = 2 * ((W + 1) / 2) * ((W + 1) / 2) - 1;
 constexpr int kMaxEnt = (kOpenCells - 1 + 7) / 8 * 8;
 constexpr bool kWideCells = kCells > 256;  // cell indices need a second byte
-#ifndef PG_CHASER_SPAN
-#define PG_CHASER_SPAN 1
-#endif
-constexpr int kResetSpan = PG_CHASER_SPAN;  // envs per wavefront of the in-step level kernel (pg_prefetch.h auto_reset)
+constexpr int kDueBlocks = 1024;            // wavefronts of the in-step level kernel (due_level_kernel): one each for the envs that are due, usually
 static_assert(kMaxEnt <= 255 && kMaxEnt <= kRankMax, "entity ids are bytes; draw lists use the equal-key rank table");
 enum Tile : uint8_t { kEmpty = 0, kWall = 1, kMarker = 2 };
 enum Kind { kOrb = 0, kPoint = 1, kEgg = 2 };
@@ -113,6 +110,17 @@ struct State {
     // step parity, its length — the late pass of a step zeroes the other parity's, which the next step fills.
     int32_t* reset_list;   // [n]
     int32_t* reset_count;  // [2]
+    // … and the envs whose episode ended in the step before (pending 3 → 1, settled by that step's late pass), per step
+    // parity: what the in-step level kernel walks (due_level_kernel) instead of looking at every env's byte.
+    int32_t* due_list;     // [2][n]
+    int32_t* due_count;    // [2]
+    // A second buffer for every env's random stream and its selector (pg_gang.h GangRng): the stream's next 624 words are
+    // worked out ahead of the step that needs them (the step's late pass, render_list_kernel → pg_rng.h
+    // mt_next_block_wave) into whichever buffer is not current, and the gang that runs out of numbers changes buffers.
+    // Scratch memory, not state: whoever takes the stream out of the engine (snapshots: prepare_save) or hands it to a
+    // level generator (generate) first makes mt[env] the current block again.
+    uint32_t* mt_other;    // [n][kMtN]
+    uint8_t* mt_sel;       // [n]  bit 1: the current words are in mt_other[env]; bit 0: the other buffer holds the next block
     int parity, listing;   // host-set per launch: step & 1; whether the list is kept at all (resets on their own stream)
     // The point sprite's texels that are not fully transparent lie in columns point_box.x..y and rows .z..w (found when
     // the atlas is loaded); point_solid: every texel in that box is opaque.
@@ -187,7 +195,10 @@ PG_D void generate(const State& s, int env, GenLds& L, Level& lv, bool reseed, u
     if (reseed) {
         if (lane == 0) mt_seed(L.mt, seed);
     } else {
-        for (int k = lane; k < kMtWords; k += 64) L.mt[k] = gmt[k];
+        // (the stream's current words are wherever its gang left them: State::mt_sel; they go back into mt[env] below)
+        const uint32_t* cur = (s.mt_sel[env] & 2) ? s.mt_other + size_t(env) * kMtN : gmt;
+        for (int k = lane; k < kMtN; k += 64) L.mt[k] = cur[k];
+        if (lane == 0) L.mt[kMtN] = gmt[kMtN];
     }
     __syncthreads();
     uint32_t* mt = L.mt;
@@ -321,6 +332,7 @@ PG_HD float cell_y(int cell) { return static_cast<float>(H - 1 - cell % H) + 0.5
 
 // The level becomes the env's live state (what reset() and the component constructors initialise).
 PG_D void install(const State& s, int env, const Level& lv, int lane) {
+    if (lane == 0) s.mt_sel[env] = 0;  // the generator has left the stream in mt[env]; what was made ahead of it is stale
     uint32_t* tiles = reinterpret_cast<uint32_t*>(s.tiles + size_t(env) * kTileStride);
     const uint32_t* src = reinterpret_cast<const uint32_t*>(lv.tiles);
     for (int k = lane; k < kTileStride / 4; k += 64) tiles[k] = src[k];
@@ -386,6 +398,21 @@ struct Gen {  // pg_prefetch.h level_kernel<Gen>
     }
 };
 
+// The in-step auto-reset (pg_prefetch.h level_serve, mode 2) for the envs on the step's due list — two or three in a
+// thousand — by a fixed, small grid: workgroup b takes entries b, b + gridDim.x, …  (Until round 6 a wavefront per env
+// looked at its env's pending byte: 65 536 workgroups a step beside the logic kernel, 0.2 ms of dispatch for two hundred
+// levels, and a fourteenth of the machine's launch slots in the seven-game slab.)  An entry whose env is no longer due —
+// an explicit pgv_reset came in between — is skipped by level_serve's own test of the byte.
+__global__ void __launch_bounds__(64) due_level_kernel(State s, StepIO io, LevelPlan plan) {
+    __builtin_amdgcn_s_setprio(3);  // (pg_prefetch.h level_kernel: one long chain beside many short ones)
+    const int count = s.due_count[s.parity];
+    for (int item = blockIdx.x; item < count; item += gridDim.x) {  // (workgroup-uniform)
+        const int env = s.due_list[size_t(s.parity) * s.n + item];
+        level_serve<Gen>(s, 2, 1, 0, 0u, 0, nullptr, nullptr, io, plan, 2, 1, env, static_cast<int>(threadIdx.x));
+        __syncthreads();
+    }
+}
+
 // One env = one gang of kGang adjacent lanes (pg_gang.h).  The agent and the enemies — three to five of them, visited in
 // the enemy set's order because their junction choices draw from the env's stream one after the other — are uniform
 // over the gang; the orbs and points (up to 198 of them), each tested against the agent every sub-step, are dealt out
@@ -431,7 +458,158 @@ PG_D void rebuild_draw_list(const State& s, const StepLds& L, Q q, int env, int 
 
 PG_D int tile_at(const StepLds& L, int x, int y) { return tile_at(L.tiles, x, y); }
 
-PG_D void advance(const State& s, StepLds& L, Q q, int env, int action, float& reward_out, bool& terminated_out) {
+// One enemy's turn of System_Mob_AI::update (common_systems.cpp:117-295) past its hatch test, in two parts (mob_head,
+// mob_tail).  `draw`: where its random numbers come from — the env's stream itself (SerialDraws: every lane of the gang runs the same enemy) or three outputs
+// peeked at the place in the stream this enemy is thought to start at (PeekDraws: one enemy per lane, see advance).
+// Returns true when it caught the agent.
+struct Mob {
+    float px, py, vx, vy, hatch;
+    int tex;
+};
+template <class Draw>
+PG_D uint32_t draw_range(Draw& draw, uint32_t range) {  // = rng_int(0, range − 1): Lemire's nearly divisionless form (pg_rng.h)
+    uint64_t product = static_cast<uint64_t>(draw.next()) * range;
+    uint32_t low = static_cast<uint32_t>(product);
+    if (low < range) {
+        const uint32_t threshold = (0u - range) % range;
+        while (low < threshold) {
+            product = static_cast<uint64_t>(draw.next()) * range;
+            low = static_cast<uint32_t>(product);
+            if (draw.over()) break;  // (PeekDraws only: more outputs than were peeked — the caller takes the long way)
+        }
+    }
+    return static_cast<uint32_t>(product >> 32);
+}
+// The part of a turn that draws nothing, done once: is the enemy at a junction (or standing), which ways are open, which
+// of them an aggressive enemy would take.
+struct MobHead {
+    bool junction;
+    int open, n_open, toward;  // bit j of `open`: direction j (−x, +x, −y, +y) is possible; toward: the aggressive choice
+    float speed;
+    int tex;
+};
+PG_D MobHead mob_head(const State& s, const StepLds& L, const Mob& m, float ax, float ay, float eat_t, int anim_i, float dt) {
+    const float speed_low = 0.125f, speed_high = 0.25f;
+    MobHead h;
+    const float px = m.px, py = m.py, vx = m.vx, vy = m.vy;
+    if (eat_t == 0.0f) {
+        h.tex = anim_i < 3 ? 1 + anim_i : 1 + (5 - anim_i);
+        h.speed = speed_high;
+    } else {
+        h.tex = 4;
+        h.speed = speed_low;
+    }
+    const float fx = qabs(s, px - (static_cast<int>(px) + 0.5f)), fy = qabs(s, py - (static_cast<int>(py) + 0.5f));
+    const bool at_junction = (fx < fy ? fy : fx) < h.speed * dt;  // std::max
+    h.junction = (vx == 0.0f && vy == 0.0f) || at_junction;
+    h.open = 0;
+    h.n_open = 0;
+    h.toward = 0;
+    if (h.junction) {
+        bool possible[4];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int dx = 2 * j - 1;
+            const int id = tile_at(L, static_cast<int>(px) + dx, H - 1 - static_cast<int>(py));
+            possible[j] = (id == kEmpty && dx != -sign_of(vx));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int dy = 2 * j - 1;
+            const int id = tile_at(L, static_cast<int>(px), H - 1 - (static_cast<int>(py) + dy));
+            possible[2 + j] = (id == kEmpty && dy != -sign_of(vy));
+        }
+        float min_dist = 999999.0f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            h.open |= possible[j] ? 1 << j : 0;
+            h.n_open += possible[j] ? 1 : 0;
+            if (possible[j]) {
+                const float dir_x = j == 0 ? -1.0f : (j == 1 ? 1.0f : 0.0f);
+                const float dir_y = j == 2 ? -1.0f : (j == 3 ? 1.0f : 0.0f);
+                float d = qabs(s, px + dir_x - ax) + qabs(s, py + dir_y - ay);
+                if (eat_t > 0.0f) d = -d;
+                if (d < min_dist) {
+                    min_dist = d;
+                    h.toward = j;
+                }
+            }
+        }
+    }
+    return h;
+}
+// … and the part that does: which way (one number: aggressive or not; a second if not: the cusp-th open direction), the
+// move, the agent met (a third: where the egg goes).  Returns true when the enemy caught the agent.
+template <class Draw>
+PG_D bool mob_tail(const StepLds& L, Mob& m, const MobHead& h, Draw& draw, const Box& agent_rect, float eat_t, int n_ent, float dt) {
+    bool player_hit = false;
+    float px = m.px, py = m.py;
+    float vx = m.vx, vy = m.vy;
+    int tex = h.tex;
+    if (h.junction) {
+        const bool be_aggressive = canonical_of(draw.next()) * (1.0f - 0.0f) + 0.0f < 0.5f;  // rng_real(0, 1)
+        int select = 0;
+        if (be_aggressive) {
+            select = h.toward;
+        } else if (h.n_open > 0) {
+            const int cusp = static_cast<int>(draw_range(draw, static_cast<uint32_t>(h.n_open)));
+            int sum = 0;
+            bool found = false;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                sum += (h.open >> j) & 1;
+                if (!found && sum > cusp) {
+                    select = j;
+                    found = true;
+                }
+            }
+        }
+        const float dir_x = select == 0 ? -1.0f : (select == 1 ? 1.0f : 0.0f);
+        const float dir_y = select == 2 ? -1.0f : (select == 3 ? 1.0f : 0.0f);
+        vx = dir_x * h.speed;
+        vy = dir_y * h.speed;
+        if (dir_x == 0.0f) px = static_cast<int>(px) + 0.5f;
+        if (dir_y == 0.0f) py = static_cast<int>(py) + 0.5f;
+    }
+    px += vx * dt;
+    py += vy * dt;
+    if (box_hit(agent_rect, Box{-0.5f + px, -0.5f + py, 1.0f, 1.0f})) {
+        if (eat_t == 0.0f) {
+            player_hit = true;
+        } else {  // back to an egg on a random point cell, without the world-y flip (D16)
+            m.hatch = 0.0f;
+            const int n_free = n_ent - kFirstPoint;
+            const int cell = L.cell[kFirstPoint + static_cast<int>(draw_range(draw, static_cast<uint32_t>(n_free)))];
+            px = cell / H + 0.5f;
+            py = cell % H + 0.5f;
+            tex = 0;
+        }
+    }
+    m.px = px;
+    m.py = py;
+    m.vx = vx;
+    m.vy = vy;
+    m.tex = tex;
+    return player_hit;
+}
+struct SerialDraws {  // the env's stream, one output after the other (all lanes of the gang call, with the same enemy)
+    Rng& rng;
+    PG_D uint32_t next() { return rng.next(); }
+    PG_D bool over() const { return false; }
+};
+constexpr int kPeek = 3;  // an enemy's turn takes at most three outputs unless a range draw is rejected (≈ range / 2^32)
+struct PeekDraws {        // kPeek outputs from a place in the stream, already tempered; asked for more, it says so (over)
+    uint32_t w[kPeek];
+    int taken;
+    PG_D uint32_t next() {
+        const uint32_t v = taken == 0 ? w[0] : (taken == 1 ? w[1] : w[2]);
+        taken++;
+        return v;
+    }
+    PG_D bool over() const { return taken > kPeek; }
+};
+
+PG_D void advance(const State& s, StepLds& L, Q q, int env, int action, bool serial_mobs, float& reward_out, bool& terminated_out) {
     const int n_ent = SI(s, I_NENT, env);
     int left = 0;  // orbs and points still there
     {   // stage: tiles as 32-bit words, the entity table, who sits where
@@ -456,27 +634,19 @@ PG_D void advance(const State& s, StepLds& L, Q q, int env, int action, float& r
         }
     }
     wave_order();
-    Rng rng = Rng::open(s.mt + size_t(env) * kMtWords, q);
+    Rng rng = Rng::open(s.mt + size_t(env) * kMtWords, q, s.mt_other + size_t(env) * kMtN, s.mt_sel + env);
     float ax = SF(s, F_AX, env), ay = SF(s, F_AY, env), avx = SF(s, F_AVX, env), avy = SF(s, F_AVY, env);
     float nvx = SF(s, F_NVX, env), nvy = SF(s, F_NVY, env);
     float input_t = SF(s, F_INPUT_T, env), anim_t = SF(s, F_ANIM_T, env), eat_t = SF(s, F_EAT_T, env);
     int anim_i = SI(s, I_ANIM_I, env);
     bool set_changed = (SI(s, I_FLAGS, env) & kFlagListed) == 0;
     const float dt = 1.0f / 4;
-    // the enemies in the set's iteration order, in registers for the step
-    int mob_id[kMobs], mob_tex[kMobs];
-    float mob_x[kMobs], mob_y[kMobs], mob_vx[kMobs], mob_vy[kMobs], mob_hatch[kMobs];
-#pragma unroll
-    for (int k = 0; k < kMobs; k++) {
-        const int m = MB(s, 1, k, env) - kOrbs;
-        mob_id[k] = m;
-        mob_tex[k] = MB(s, 0, m, env);
-        mob_x[k] = MF(s, MF_X, m, env);
-        mob_y[k] = MF(s, MF_Y, m, env);
-        mob_vx[k] = MF(s, MF_VX, m, env);
-        mob_vy[k] = MF(s, MF_VY, m, env);
-        mob_hatch[k] = MF(s, MF_HATCH, m, env);
-    }
+    // The enemies: lane k of the gang (k < kMobs) holds the k-th of the enemy set's iteration order for the step.
+    static_assert(kMobs <= kGang, "one enemy per lane of the gang");
+    const bool has_mob = q.g < kMobs;
+    const int mob_id = MB(s, 1, has_mob ? q.g : 0, env) - kOrbs;
+    Mob mob{MF(s, MF_X, mob_id, env), MF(s, MF_Y, mob_id, env), MF(s, MF_VX, mob_id, env), MF(s, MF_VY, mob_id, env),
+            MF(s, MF_HATCH, mob_id, env), MB(s, 0, mob_id, env)};
 
     float movement_x = static_cast<float>((action == 7) - (action == 1));
     float movement_y = static_cast<float>((action == 3) - (action == 5));
@@ -564,103 +734,71 @@ PG_D void advance(const State& s, StepLds& L, Q q, int env, int action, float& r
         const Box agent_rect{-0.5f + ax, -0.5f + ay, 1.0f, 1.0f};
 
         // --- System_Mob_AI::update (common_systems.cpp:117-295), enemies in the set's iteration order
+        // The enemies do not see each other: all that joins them is the env's random stream, which they draw from one
+        // after the other — an enemy at a junction one number (aggressive or not), a second if it was not (which way), a
+        // third when the agent, having eaten an orb, catches it (where its egg goes).  So they take their turns side by
+        // side, one per lane (round 6; until then one after the other on every lane of the gang: 118 of the kernel's
+        // 157 µs), each on outputs peeked at the place in the stream where it is THOUGHT to start — the numbers taken by
+        // the enemies before it, as far as known — and the turns are taken again until every start is right: lane 0's is
+        // from the outset, lane k's after at most k rounds.  With the int reading of `abs` (D21, the default) every
+        // enemy counts as at a junction in every sub-step, so every one draws and it is kMobs rounds each time — which is why
+        // a round is only the part of the turn that draws (mob_tail: which way, the move, the agent met), a third of the
+        // turn's instructions; the part that does not (mob_head: the junction test, the open ways, the aggressive choice) is
+        // done once in front.  With the float reading a junction comes every sixteenth sub-step and one round settles it.  The long way — one enemy after the other on the stream
+        // itself, every lane running the same one (SerialDraws) — is taken where the peeked outputs do not reach:
+        // the stream's 624 words run out inside the window, or a range draw is rejected (probability ≈ range / 2^32);
+        // `serial_mobs` (pgv_set_debug bit 25) forces it for the tests.
         bool player_hit = false;
         {
-            const float hatch_time = 50.0f, anim_time = 1.0f, speed_low = 0.125f, speed_high = 0.25f;
+            const float hatch_time = 50.0f, anim_time = 1.0f;
+            const bool hatched = has_mob && mob.hatch >= hatch_time;
+            bool long_way = serial_mobs || rng.idx + kMobs * kPeek > kMtN;  // (gang-uniform)
+            MobHead head{false, 0, 0, 0, 0.0f, 0};
+            if (hatched && !(PG_CHASER_SKIP & 2) && !long_way) head = mob_head(s, L, mob, ax, ay, eat_t, anim_i, dt);
+            if (!(PG_CHASER_SKIP & 2) && !long_way) {
+                Mob after = mob;
+                bool hit = false, over = false;
+                int start = 0, taken = 0;
+                for (int round = 0; round < kMobs; round++) {
+                    after = mob;
+                    PeekDraws draw{{0u, 0u, 0u}, 0};
+                    if (hatched) {
 #pragma unroll
-            for (int k = 0; k < ((PG_CHASER_SKIP & 2) ? 0 : kMobs); k++) {
-                float hatch = mob_hatch[k];
-                if (hatch >= hatch_time) {
-                    float px = mob_x[k], py = mob_y[k];
-                    float vx = mob_vx[k], vy = mob_vy[k];
-                    float speed;
-                    int tex;
-                    if (eat_t == 0.0f) {
-                        tex = anim_i < 3 ? 1 + anim_i : 1 + (5 - anim_i);
-                        speed = speed_high;
-                    } else {
-                        tex = 4;
-                        speed = speed_low;
+                        for (int j = 0; j < kPeek; j++) draw.w[j] = mt_temper(rng.x[rng.idx + start + j]);
+                        hit = mob_tail(L, after, head, draw, agent_rect, eat_t, n_ent, dt);
                     }
-                    const float fx = qabs(s, px - (static_cast<int>(px) + 0.5f)), fy = qabs(s, py - (static_cast<int>(py) + 0.5f));
-                    const bool at_junction = (fx < fy ? fy : fx) < speed * dt;  // std::max
-                    if ((vx == 0.0f && vy == 0.0f) || at_junction) {
-                        bool possible[4];
-                        int n_possible = 0;
-#pragma unroll
-                        for (int j = 0; j < 2; j++) {
-                            const int dx = 2 * j - 1;
-                            const int id = tile_at(L, static_cast<int>(px) + dx, H - 1 - static_cast<int>(py));
-                            possible[j] = (id == kEmpty && dx != -sign_of(vx));
-                            n_possible += possible[j] ? 1 : 0;
-                        }
-#pragma unroll
-                        for (int j = 0; j < 2; j++) {
-                            const int dy = 2 * j - 1;
-                            const int id = tile_at(L, static_cast<int>(px), H - 1 - (static_cast<int>(py) + dy));
-                            possible[2 + j] = (id == kEmpty && dy != -sign_of(vy));
-                            n_possible += possible[2 + j] ? 1 : 0;
-                        }
-                        const bool be_aggressive = rng.real(0.0f, 1.0f) < 0.5f;
-                        int select = 0;
-                        if (be_aggressive) {
-                            float min_dist = 999999.0f;
-#pragma unroll
-                            for (int j = 0; j < 4; j++)
-                                if (possible[j]) {
-                                    const float dir_x = j == 0 ? -1.0f : (j == 1 ? 1.0f : 0.0f);
-                                    const float dir_y = j == 2 ? -1.0f : (j == 3 ? 1.0f : 0.0f);
-                                    float d = qabs(s, px + dir_x - ax) + qabs(s, py + dir_y - ay);
-                                    if (eat_t > 0.0f) d = -d;
-                                    if (d < min_dist) {
-                                        min_dist = d;
-                                        select = j;
-                                    }
-                                }
-                        } else if (n_possible > 0) {
-                            const int cusp = rng.integer(0, n_possible - 1);
-                            int sum = 0;
-                            bool found = false;
-#pragma unroll
-                            for (int j = 0; j < 4; j++) {
-                                sum += possible[j] ? 1 : 0;
-                                if (!found && sum > cusp) {
-                                    select = j;
-                                    found = true;
-                                }
-                            }
-                        }
-                        const float dir_x = select == 0 ? -1.0f : (select == 1 ? 1.0f : 0.0f);
-                        const float dir_y = select == 2 ? -1.0f : (select == 3 ? 1.0f : 0.0f);
-                        vx = dir_x * speed;
-                        vy = dir_y * speed;
-                        if (dir_x == 0.0f) px = static_cast<int>(px) + 0.5f;
-                        if (dir_y == 0.0f) py = static_cast<int>(py) + 0.5f;
-                    }
-                    px += vx * dt;
-                    py += vy * dt;
-                    if (box_hit(agent_rect, Box{-0.5f + px, -0.5f + py, 1.0f, 1.0f})) {
-                        if (eat_t == 0.0f) {
-                            player_hit = true;
-                        } else {  // back to an egg on a random point cell, without the world-y flip (D16)
-                            hatch = 0.0f;
-                            const int n_free = n_ent - kFirstPoint;
-                            const int cell = L.cell[kFirstPoint + rng.integer(0, n_free - 1)];
-                            px = cell / H + 0.5f;
-                            py = cell % H + 0.5f;
-                            tex = 0;
-                        }
-                    }
-                    mob_x[k] = px;
-                    mob_y[k] = py;
-                    mob_vx[k] = vx;
-                    mob_vy[k] = vy;
-                    mob_hatch[k] = hatch;
-                    mob_tex[k] = tex;
-                } else {
-                    mob_hatch[k] = hatch + dt;
+                    over = draw.over();
+                    taken = over ? kPeek : draw.taken;
+                    // where every lane's enemy starts, given what the ones before it took this round (0 to 3 each)
+                    const uint32_t below = (1u << q.g) - 1u;
+                    const int now = __popc(q.ballot((taken & 1) != 0) & below) + 2 * __popc(q.ballot((taken & 2) != 0) & below);
+                    // (an enemy that drew nothing this round never looked at its outputs: wherever it starts, its turn stands)
+                    const bool moved = taken != 0 && now != start;
+                    start = now;
+                    if (!q.any(moved)) break;
+                }
+                long_way = q.any(over);  // (a rejected range draw: never in practice)
+                if (!long_way) {
+                    player_hit = q.any(hit);
+                    if (hatched) mob = after;
+                    const int total = __popc(q.ballot((taken & 1) != 0)) + 2 * __popc(q.ballot((taken & 2) != 0));
+                    rng.idx += total;  // (next() refills its window by itself)
                 }
             }
+            if (!(PG_CHASER_SKIP & 2) && long_way) {
+                for (int k = 0; k < kMobs; k++) {  // enemy k on every lane of the gang, committed by lane k
+                    const int src = q.shift + k;
+                    if (__shfl(mob.hatch, src) >= hatch_time) {
+                        Mob one{__shfl(mob.px, src), __shfl(mob.py, src), __shfl(mob.vx, src), __shfl(mob.vy, src),
+                                __shfl(mob.hatch, src), __shfl(mob.tex, src)};
+                        SerialDraws draw{rng};
+                        const MobHead h = mob_head(s, L, one, ax, ay, eat_t, anim_i, dt);
+                        player_hit = mob_tail(L, one, h, draw, agent_rect, eat_t, n_ent, dt) || player_hit;
+                        if (q.g == k) mob = one;
+                    }
+                }
+            }
+            if (has_mob && !hatched && !(PG_CHASER_SKIP & 2)) mob.hatch += dt;
             if (anim_t < anim_time) {
                 anim_t += dt;
             } else {
@@ -707,17 +845,15 @@ PG_D void advance(const State& s, StepLds& L, Q q, int env, int action, float& r
         if (terminated) break;
     }
     rng.close();
+    if (has_mob) {
+        MF(s, MF_X, mob_id, env) = mob.px;
+        MF(s, MF_Y, mob_id, env) = mob.py;
+        MF(s, MF_VX, mob_id, env) = mob.vx;
+        MF(s, MF_VY, mob_id, env) = mob.vy;
+        MF(s, MF_HATCH, mob_id, env) = mob.hatch;
+        MB(s, 0, mob_id, env) = static_cast<uint8_t>(mob.tex);
+    }
     if (q.g == 0) {
-#pragma unroll
-        for (int k = 0; k < kMobs; k++) {
-            const int m = mob_id[k];
-            MF(s, MF_X, m, env) = mob_x[k];
-            MF(s, MF_Y, m, env) = mob_y[k];
-            MF(s, MF_VX, m, env) = mob_vx[k];
-            MF(s, MF_VY, m, env) = mob_vy[k];
-            MF(s, MF_HATCH, m, env) = mob_hatch[k];
-            MB(s, 0, m, env) = static_cast<uint8_t>(mob_tex[k]);
-        }
         SF(s, F_AX, env) = ax;
         SF(s, F_AY, env) = ay;
         SF(s, F_AVX, env) = avx;
@@ -746,7 +882,7 @@ __global__ void __launch_bounds__(64) make_kernel(State s) {
 }
 
 __global__ void __launch_bounds__(64, PG_CHASER_WAVES) logic_kernel(State s, const int32_t* actions, uint32_t run_seed,
-                                                                    uint32_t step_index, int env_offset, StepIO io) {
+                                                                    uint32_t step_index, int env_offset, StepIO io, int serial_mobs) {
     __shared__ StepLds lds[64 / kGang];
     const int env = (blockIdx.x * 64 + threadIdx.x) / kGang;
     if (env >= s.n) return;
@@ -756,7 +892,7 @@ __global__ void __launch_bounds__(64, PG_CHASER_WAVES) logic_kernel(State s, con
         actions ? actions[env] : synthetic_action(run_seed, step_index, static_cast<uint32_t>(env_offset + env));
     float reward = 0.0f;
     bool terminated = false;
-    advance(s, lds[(threadIdx.x & 63) / kGang], q, env, action, reward, terminated);
+    advance(s, lds[(threadIdx.x & 63) / kGang], q, env, action, serial_mobs != 0, reward, terminated);
     if (q.g == 0) {
         io.reward[env] = reward;
         io.done[env] = terminated ? 1 : 0;
@@ -1190,15 +1326,66 @@ __global__ void __launch_bounds__(128, PG_CHASER_RENDER_WAVES) render_kernel(Sta
 // few hundred of 65 536: a workgroup takes every gridDim.x-th of them), and the flags of everyone settled (3 → 1 for the
 // envs that ended an episode in this step, 2 → 0 for the ones just reset).  A full-size launch that exits at once for
 // all but the listed envs costs 30 µs in dispatch alone.
-__global__ void __launch_bounds__(128, PG_CHASER_RENDER_WAVES) render_list_kernel(State s, AtlasView atlas, StepIO io, int flags) {
-    for (int e = blockIdx.x * 128 + threadIdx.x; e < s.n; e += gridDim.x * 128)
-        if (io.pending[e] == 3) io.pending[e] = 1;
-    if (blockIdx.x == 0 && threadIdx.x == 0) s.reset_count[1 - s.parity] = 0;
+// Every stream whose current words are in the second buffer back into mt[env] (ChaserGame::prepare_save); a wavefront per
+// 64 envs.  The block made ahead, if any, is dropped: the late pass makes it again.
+__global__ void __launch_bounds__(64) streams_home_kernel(State s) {
+    const int lane = threadIdx.x, env0 = blockIdx.x * 64, e = env0 + lane;
+    unsigned long long todo = __ballot(e < s.n && (s.mt_sel[e] & 2));
+    while (todo) {  // (wave-uniform)
+        const int env = env0 + __builtin_ctzll(todo);
+        todo &= todo - 1;
+        uint32_t* home = s.mt + size_t(env) * kMtWords;
+        const uint32_t* other = s.mt_other + size_t(env) * kMtN;
+        for (int k = lane; k < kMtN; k += 64) home[k] = other[k];
+        if (lane == 0) s.mt_sel[env] = 0;
+    }
+}
+
+// Workgroups from `groups` on: the random streams' next blocks (State::mt_other, mt_sel) for the envs that have none — the two or
+// three in a hundred whose gang took its block in this step, and those given a level — a wavefront per 64 envs.  Nothing
+// else of this engine runs beside the late pass, so the streams stand still; an env whose byte is not 0 (it resets in the
+// next step, or is being settled right now) is left for a later step.
+__global__ void __launch_bounds__(128, PG_CHASER_RENDER_WAVES) render_list_kernel(State s, AtlasView atlas, StepIO io, int flags, int groups) {
+    if (static_cast<int>(blockIdx.x) >= groups) {  // (workgroup-uniform)
+        const int lane = threadIdx.x & 63;
+        const int env0 = ((static_cast<int>(blockIdx.x) - groups) * 2 + static_cast<int>(threadIdx.x >> 6)) * 64;
+        const int e = env0 + lane;
+        const int sel = e < s.n ? s.mt_sel[e] : 1;
+        unsigned long long todo = __ballot(e < s.n && !(sel & 1) && io.pending[e] == 0);
+        while (todo) {  // (wave-uniform)
+            const int k = __builtin_ctzll(todo), env = env0 + k;
+            todo &= todo - 1;
+            uint32_t* home = s.mt + size_t(env) * kMtWords;
+            uint32_t* other = s.mt_other + size_t(env) * kMtN;
+            const int sel_env = __shfl(sel, k);  // (every lane: a cross-lane read inside `if (lane == 0)` would read an idle lane)
+            const bool in_other = (sel_env & 2) != 0;
+            mt_next_block_wave(in_other ? other : home, in_other ? home : other, lane);
+            if (lane == 0) s.mt_sel[env] = static_cast<uint8_t>(sel_env | 1);
+        }
+        return;
+    }
+    // (the bytes four at a time: a word that holds no 3 — nearly every word — is left alone)
+    const int next = 1 - s.parity;
+    for (int e4 = blockIdx.x * 128 + threadIdx.x; e4 * 4 < s.n; e4 += groups * 128) {
+        if (e4 * 4 + 4 <= s.n) {
+            const uint32_t four = reinterpret_cast<const uint32_t*>(io.pending)[e4];
+            if (!(((four ^ 0x03030303u) - 0x01010101u) & ~(four ^ 0x03030303u) & 0x80808080u)) continue;  // no byte equals 3
+        }
+        for (int e = e4 * 4; e < e4 * 4 + 4 && e < s.n; e++)
+            if (io.pending[e] == 3) {
+                io.pending[e] = 1;
+                s.due_list[size_t(next) * s.n + atomicAdd(&s.due_count[next], 1)] = e;  // the next step's level kernel resets it
+            }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        s.reset_count[1 - s.parity] = 0;
+        s.due_count[s.parity] = 0;  // (this step's level kernel has walked it: the late pass runs behind the join)
+    }
     __shared__ alignas(16) uint32_t fb[kFbWords];
     __shared__ ComposeLdsBoxed<kGrid> L;
     __shared__ SpriteLds S;
     const int count = s.reset_count[s.parity];
-    for (int item = blockIdx.x; item < count; item += gridDim.x) {
+    for (int item = blockIdx.x; item < count; item += groups) {
         const int env = s.reset_list[item];
         if (threadIdx.x == 0) io.pending[env] = 0;
         render_env<false>(s, atlas, io, flags, env, fb, L, S, false, true);  // (… and leaves the new level's base layer)
@@ -1320,7 +1507,7 @@ class ChaserGame final : public Game {
     }
     static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
     struct Layout {
-        size_t shadow, slot, mt, tiles, f, i, mf, mb, eb, reset_list, reset_count, prepared, total;
+        size_t shadow, slot, mt, tiles, f, i, mf, mb, eb, reset_list, reset_count, due_list, due_count, prepared, total;
     };
     static Layout layout(int n) {
         Layout l{};
@@ -1341,6 +1528,8 @@ class ChaserGame final : public Game {
         l.eb = take(size_t(EB_COUNT) * kMaxEnt * n);  // (same size either way round)
         l.reset_list = take(size_t(n) * 4);
         l.reset_count = take(8);
+        l.due_list = take(size_t(2) * n * 4);
+        l.due_count = take(8);
         l.prepared = take(sizeof(ComposeHand));
         l.total = off;
         return l;
@@ -1365,6 +1554,8 @@ class ChaserGame final : public Game {
         s_.eb = p + l.eb;
         s_.reset_list = reinterpret_cast<int32_t*>(p + l.reset_list);
         s_.reset_count = reinterpret_cast<int32_t*>(p + l.reset_count);
+        s_.due_list = reinterpret_cast<int32_t*>(p + l.due_list);
+        s_.due_count = reinterpret_cast<int32_t*>(p + l.due_count);
         s_.prepared = reinterpret_cast<ComposeHand*>(p + l.prepared);
         s_.ranks = atlas.sort_ranks;
         atlas_ = atlas;
@@ -1383,9 +1574,10 @@ class ChaserGame final : public Game {
                       StepIO io) override {
         s_.parity = static_cast<int>(step_index & 1u);
         s_.listing = 1;  // (the envs reset in this step are listed for the late pass)
-        LevelLaunch<Gen>::auto_reset(reset_stream, s_, 0, io, plan, kResetSpan);  // engine.hip: always there for a game that resets beside its logic
+        // the auto-resets, beside the logic kernel (engine.hip: reset_stream is always there for a game that resets so)
+        hipLaunchKernelGGL(due_level_kernel, dim3(s_.n < kDueBlocks ? s_.n : kDueBlocks), dim3(64), 0, reset_stream, s_, io, plan);
         hipLaunchKernelGGL(logic_kernel, dim3((s_.n * kGang + 63) / 64), dim3(64), 0, st, s_, actions, run_seed, step_index,
-                           env_offset, io);
+                           env_offset, io, (debug_flags & kDebugChaserSerialMobs) ? 1 : 0);
     }
     bool launch_frame(hipStream_t st, int env, uint32_t* d_px, int w, int h) override {
         hipLaunchKernelGGL(frame_kernel, dim3(1), dim3(kFrameThreads), 0, st, s_, atlas_, env, FrameTarget{d_px, w, h});
@@ -1416,9 +1608,16 @@ class ChaserGame final : public Game {
     static size_t up256(size_t b) { return (b + 255) & ~size_t(255); }
     size_t scratch_bytes(int n) const override {
         return up256(size_t(2) * kCells * kBlitWords * 4) + up256(size_t(n) * kMovers * kBlitWords * 4) + up256(size_t(n) * 8 * 4) +
-               up256(size_t(n) * kFbWords * 4);
+               up256(size_t(n) * kFbWords * 4) + up256(size_t(n) * kMtN * 4) + up256(size_t(n));
     }
-    void state_loaded() override { base_valid_ = false; }
+    void state_loaded() override {
+        base_valid_ = false;
+        hipMemset(s_.mt_sel, 0, size_t(s_.n));  // the streams that were just loaded are in mt[env]; what was made ahead is not theirs
+    }
+    // A snapshot takes the streams from mt[env]: the ones whose gang has moved on to the second buffer come home first.
+    void prepare_save(hipStream_t st) override {
+        hipLaunchKernelGGL(streams_home_kernel, dim3((s_.n + 63) / 64), dim3(64), 0, st, s_);
+    }
     void bind_scratch(void* d_scratch, int n) override {
         uint8_t* p = static_cast<uint8_t*>(d_scratch);
         s_.prep.cell_blits = reinterpret_cast<uint32_t*>(p);
@@ -1428,11 +1627,15 @@ class ChaserGame final : public Game {
         s_.prep.bg = reinterpret_cast<uint32_t*>(p);
         p += up256(size_t(n) * 8 * 4);
         s_.base = reinterpret_cast<uint32_t*>(p);
+        p += up256(size_t(n) * kFbWords * 4);
+        s_.mt_other = reinterpret_cast<uint32_t*>(p);
+        p += up256(size_t(n) * kMtN * 4);
+        s_.mt_sel = p;  // (the engine zeroes the scratch block: every stream is at home, nothing is made ahead)
         base_valid_ = false;
     }
     bool launch_render_late(hipStream_t st, StepIO io) override {
         const int groups = s_.n < 1024 ? s_.n : 1024;
-        hipLaunchKernelGGL(render_list_kernel, dim3(groups), dim3(128), 0, st, s_, atlas_, io, debug_flags);
+        hipLaunchKernelGGL(render_list_kernel, dim3(groups + (s_.n + 127) / 128), dim3(128), 0, st, s_, atlas_, io, debug_flags, groups);
         return true;
     }
     // Same layout as oracle/pgo_chaser.cpp Chaser::dump_state.

@@ -596,6 +596,8 @@ int32_t pgv_save_state(pgv_env* e, void* h_buffer, int64_t capacity) {
     if (!e || !h_buffer) return fail("pgv_save_state: NULL argument");
     if (capacity < static_cast<int64_t>(snapshot_bytes(e))) return fail("pgv_save_state: buffer too small");
     PG_HIP(hipSetDevice(e->device));
+    e->game->prepare_save(e->stream);
+    PG_HIP(hipGetLastError());
     PG_HIP(hipStreamSynchronize(e->stream));
     if (e->side) PG_HIP(hipStreamSynchronize(e->side));
     uint8_t* out = static_cast<uint8_t*>(h_buffer);
@@ -818,8 +820,8 @@ int32_t pgv_render_frame(pgv_env* e, int32_t index, int32_t width, int32_t heigh
 int32_t pgv_set_debug(pgv_env* e, int32_t flags) {
     if (!e) return fail("pgv_set_debug: env is NULL");
 #ifndef PG_ABLATE
-    if (flags & ~(1 | pg::kDebugNoPrefetch | pg::kDebugNoPrepass | pg::kDebugFatThirds | pg::kDebugCoinrunNoReach))
-        return fail("pgv_set_debug: only bit 0 (draw-list replay), bit 8 (no level prefetch), bit 21 (no render pre-pass), bit 23 (every third frame by the complete path) and bit 24 (coinrun: hazards the long way) exist in this build");
+    if (flags & ~(1 | pg::kDebugNoPrefetch | pg::kDebugNoPrepass | pg::kDebugFatThirds | pg::kDebugCoinrunNoReach | pg::kDebugChaserSerialMobs))
+        return fail("pgv_set_debug: only bit 0 (draw-list replay), bit 8 (no level prefetch), bit 21 (no render pre-pass), bit 23 (every third frame by the complete path), bit 24 (coinrun: hazards the long way) and bit 25 (chaser: enemies the long way) exist in this build");
 #endif
     if (e->side) hipStreamSynchronize(e->side);
     e->game->debug_flags = flags;

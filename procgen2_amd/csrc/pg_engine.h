@@ -124,6 +124,10 @@ class Game {
     // Called once between loading and uploading the atlas: a game may append data derived from its textures (jumper:
     // its compass ring as it lands on the 64×64 observation — the same pixels in every frame of every env).
     virtual void extend_atlas(Atlas& atlas) { (void)atlas; }
+    // Called by pgv_save_state before it copies the state blob: a game that keeps part of what a rollout depends on
+    // outside the blob for speed (chaser: the random streams' second buffers) puts it back first.  The engine
+    // synchronises the stream afterwards.
+    virtual void prepare_save(hipStream_t st) { (void)st; }
     // Host-side sanity check of the loaded atlas (sizes[i] = {w, h} of texture i); empty string = fine.
     virtual std::string check_atlas(const std::vector<std::pair<int, int>>& sizes) const { return ""; }
 
@@ -164,6 +168,7 @@ constexpr int kDebugNoPrefetch = 1 << 8;
 constexpr int kDebugNoPrepass = 1 << 21;  // (clear of the -DPG_ABLATE experiment bits the games use)
 constexpr int kDebugFatThirds = 1 << 23;
 constexpr int kDebugCoinrunNoReach = 1 << 24;
+constexpr int kDebugChaserSerialMobs = 1 << 25;  // chaser: the enemies one after the other on the stream itself (chaser.hip advance)
 
 // Factories, one per compiled variant of a game (pg_defs.h PG_VARIANT; v0 = the reference's compile-time default).
 std::unique_ptr<Game> make_coinrun_v0();

@@ -82,19 +82,35 @@ struct GangRng {
     // uniform draws are lane-to-lane reads instead of a dependent round trip to memory each.
     uint32_t win;
     int win0;
+    // Optional (round 6): a second buffer of 624 words per env and a selector byte — bit 1: the stream's CURRENT words
+    // are in the second buffer (`other`) instead of the env's own (`home`); bit 0: whichever buffer is not current holds
+    // the NEXT 624 words already, worked out ahead of time by somebody else (pg_rng.h mt_next_block_wave, from a kernel
+    // that runs when no gang does).  A gang that runs out of numbers then just changes buffers (refill) instead of
+    // regenerating the block in six dependent memory round trips — chaser's logic kernel spent 80 of its 180 µs in
+    // wavefronts waiting for one of their eight gangs to do that; copying a block made ahead still cost 50.  The index
+    // stays in home[kMtN].  Anybody else who reads the stream looks at the selector first (GangRng users' level
+    // generators, snapshots).  No selector: regenerate in place, as before.
+    uint32_t* home = nullptr;
+    uint32_t* other = nullptr;
+    uint8_t* sel_at = nullptr;
+    int sel = 0;
 
     PG_D void fetch_window() {
         win0 = idx;
         const int at = idx + q.g;
         win = x[at < kMtN ? at : kMtN - 1];
     }
-    PG_D static GangRng open(uint32_t* words, Gang<G> gang) {
-        GangRng r{words, static_cast<int>(words[kMtN]), gang, 0u, 0};
+    PG_D static GangRng open(uint32_t* words, Gang<G> gang, uint32_t* second = nullptr, uint8_t* selector = nullptr) {
+        GangRng r{words, static_cast<int>(words[kMtN]), gang, 0u, 0, words, second, selector, 0};
+        if (selector != nullptr) {
+            r.sel = *selector;
+            if (r.sel & 2) r.x = second;
+        }
         r.fetch_window();
         return r;
     }
     PG_D void close() const {
-        if (q.g == 0) x[kMtN] = static_cast<uint32_t>(idx);
+        if (q.g == 0) home[kMtN] = static_cast<uint32_t>(idx);
     }
 
     template <int kPer>
@@ -122,10 +138,22 @@ struct GangRng {
         gang_fence();
     }
 
+    // The stream has run out: the next 624 words — in the other buffer if somebody has made them already, else regenerated
+    // in place (in whichever buffer is current).
+    PG_D void refill() {
+        if (sel & 1) {  // (gang-uniform)
+            x = (sel & 2) ? home : other;
+            sel = (sel ^ 2) & 2;
+            if (q.g == 0) *sel_at = static_cast<uint8_t>(sel);
+            return;
+        }
+        twist();
+    }
+
     // One engine output, the same for every lane of the gang (all of them call).
     PG_D uint32_t next() {
         if (idx >= kMtN) {
-            twist();
+            refill();
             idx = 0;
             fetch_window();
         }
@@ -156,7 +184,7 @@ struct GangRng {
         uint32_t w = (want && at < kMtN) ? x[at] : 0u;
         if (idx + total > kMtN) {  // the stream runs out in the middle: the rest comes from the next 624 words
             gang_fence();
-            twist();
+            refill();
             if (want && at >= kMtN) w = x[at - kMtN];
             idx += total - kMtN;
             fetch_window();

@@ -60,6 +60,7 @@ struct Camera {
 constexpr int32_t kFlipH = 1 << 8;
 constexpr int32_t kFlipV = 1 << 9;
 constexpr int32_t kRotated = 1 << 10;
+constexpr int32_t kStamped = 1 << 11;  // the texture is a pre-scaled stamp (pg_stamps.h): texel (i, j) lands on pixel (i, j), s | a << 24
 
 // One axis of a resolved draw: destination span [d0, d0+dn) and source span [s0, s0+sn).
 struct Span {
@@ -243,6 +244,25 @@ PG_HD uint32_t blend_px(uint32_t dst, uint32_t src, int a) {
     const uint32_t g = div255(((src >> 8) & 0xffu) * ua) + div255(((dst >> 8) & 0xffu) * ia);
     return rb | (g << 8);
 #endif
+}
+
+// A texel as a stamp holds it (pg_stamps.h): the first half of raster spec S4 applied — a = A·mod/255 (mod != 255), s =
+// a < 255 ? C·a/255 : C per channel — as s | a << 24; 0 when a = 0 (nothing lands).
+PG_HD uint32_t stamp_texel(uint32_t t, int mod) {
+    uint32_t a = t >> 24;
+    if (mod != 255) a = div255(a * static_cast<uint32_t>(mod));
+    if (a == 0u) return 0u;
+    if (a == 255u) return (t & 0x00ffffffu) | 0xff000000u;
+    const uint32_t r = div255((t & 0xffu) * a), g = div255(((t >> 8) & 0xffu) * a), b = div255(((t >> 16) & 0xffu) * a);
+    return r | g << 8 | b << 16 | a << 24;
+}
+// The second half of raster spec S4 for a texel whose first half is tabulated (pg_stamps.h: src = s | a << 24 with
+// s = C·a/255 per channel, 0 < a < 255): D' = s + (255 − a)·D/255.  s ≤ a, so no channel exceeds 255.
+PG_HD uint32_t blend_premul(uint32_t dst, uint32_t src, int a) {
+    const uint32_t ia = 255u - static_cast<uint32_t>(a);
+    const uint32_t rb = (src & 0x00ff00ffu) + div255_pair(mul_pair(dst & 0x00ff00ffu, ia));
+    const uint32_t g = ((src >> 8) & 0xffu) + div255(((dst >> 8) & 0xffu) * ia);
+    return rb | (g << 8);
 }
 
 }  // namespace pg

@@ -16,6 +16,7 @@
 #pragma once
 
 #include "pg_render.h"
+#include "pg_stamps.h"
 
 namespace pg {
 
@@ -487,8 +488,11 @@ struct PrepDrawPass {
 // [lo, hi] that part overwrites (lo > hi: none), valley- / hill-shaped over the rows, so that a rectangle whose first and
 // last row lie inside lies inside altogether.  A draw that lands wholly under it is dropped here: nobody sees it.
 // (jumper's compass disc covers two thirds of the 64×64 frame, the bunny at its centre included.)
+// `stamps` (optional): the game's stamp table, kStampsPerTex entries per texture (pg_stamps.h) — a draw that takes its whole
+// texture at a size a stamp exists for is stored with the stamp as its texture.
 PG_D void prep_draws_flush(PrepDrawQueue& Q, PrepDrawPass& st, const int4* desc, const Camera& cam_a, const Camera& cam_b,
-                           uint32_t* draws_a, uint32_t* draws_b, int lane, const uint32_t* cover = nullptr) {
+                           uint32_t* draws_a, uint32_t* draws_b, int lane, const uint32_t* cover = nullptr,
+                           const uint4* stamps = nullptr) {
     if (st.queued == 0) return;  // wave-uniform
     wave_order();  // the entries were written by other lanes of this wave
     // Up to 32 draws (the usual case: a dozen or two per pair of envs): lane = (draw, axis) — both axes of every draw in
@@ -544,6 +548,7 @@ PG_D void prep_draws_flush(PrepDrawQueue& Q, PrepDrawPass& st, const int4* desc,
         b.flip_mod = static_cast<int32_t>((en.misc >> 16) & 0xffu) | ((flips & 1u) ? kFlipH : ((flips & 2u) ? kFlipV : 0));  // (resolve_draw)
         b.rot_sn = 0;
         b.rot_cs = 65536;
+        if (stamps != nullptr) stamp_substitute(stamps + (en.misc & 0xffu) * kStampsPerTex, d.y, d.z, b);
         prep_draw_store((is_b ? draws_b : draws_a) + size_t(rank) * kBlitWords, b);
     }
     st.done[0] += __popcll(m_a);
@@ -555,7 +560,7 @@ PG_D void prep_draws_flush(PrepDrawQueue& Q, PrepDrawPass& st, const int4* desc,
 // order (= list order).  Every lane of the wave calls this, with valid = false where there is no draw.
 PG_D void prep_draws_pass(PrepDrawQueue& Q, PrepDrawPass& st, const int4* desc, const Camera& cam_a, const Camera& cam_b,
                           uint32_t* draws_a, uint32_t* draws_b, bool valid, bool is_b, const PrepDraw& p, int lane,
-                          const uint32_t* cover = nullptr) {
+                          const uint32_t* cover = nullptr, const uint4* stamps = nullptr) {
     const Camera& cam = is_b ? cam_b : cam_a;
     AxisHead hx{0.0f, 0.0f}, hy{0.0f, 0.0f};
     bool alive = valid && p.go;
@@ -567,7 +572,7 @@ PG_D void prep_draws_pass(PrepDrawQueue& Q, PrepDrawPass& st, const int4* desc, 
     const unsigned long long m = __ballot(alive);
     const int n = __popcll(m);
     if (n == 0) return;  // wave-uniform
-    if (st.queued + n > kPrepQueue) prep_draws_flush(Q, st, desc, cam_a, cam_b, draws_a, draws_b, lane, cover);
+    if (st.queued + n > kPrepQueue) prep_draws_flush(Q, st, desc, cam_a, cam_b, draws_a, draws_b, lane, cover, stamps);
     if (alive) {
         int mod = 255;
         if (p.alpha != 1.0f) mod = static_cast<int>(255 * p.alpha) & 0xff;  // Uint8 parameter (renderer.cpp:56-57)

@@ -186,7 +186,13 @@ PG_D Blit blit_from_lane(const BlitWords& p, const Blit& mine, int src) {
     return b;
 }
 
+// kStamps (template parameter of everything that samples or blends a draw): whether the draws may be stamps at all.
+// Only a kernel whose pre-pass substitutes stamps says true; for every other kernel the stamped forms compile to nothing.
+template <bool kStamps = false>
 PG_D void blend_into(uint32_t* fb, int idx, uint32_t texel, int mod);
+// blend_into's `mod`: the draw's alpha modulation, or kStamped | 255 for a stamp's texels (pg_stamps.h: the modulation
+// and the source half of the blend are in the texel already).
+PG_D int blend_key(int flip_mod) { return flip_mod & (0xff | kStamped); }
 
 // Consecutive draws of one wavefront may overlap, and a pixel is in general touched by a different LANE in each of
 // them.  The hardware keeps a wave's LDS accesses in instruction order, but the language only orders the accesses of
@@ -401,13 +407,14 @@ PG_D RotBox rot_box(const Blit& b) {
 // read across lanes instead of two divisions a pixel, and the rotation as four 24-bit multiplies (rotated_pixel below) —
 // 85 -> 45 vector instructions a pixel, bit-exact; jumper's render unchanged (0.651 ms), caveflyer's 0.429 -> 0.486: two
 // more LDS round trips in front of every texel fetch cost more than the instructions they replace.)
-template <int kBatch = 4>
+template <int kBatch = 4, bool kStamps = false>
 PG_D void wave_blit_rotated(uint32_t* fb, const AtlasView& atlas, const Blit& b, const RotBox& box, int lane,
                             int stride = 64) {
     const int x_lo = box.x_lo, y_lo = box.y_lo, bw = box.bw, bh = box.bh;
     if (bw <= 0 || bh <= 0) return;
     const uint32_t* tex = atlas.texels + b.tex_off;
-    const int mod = b.flip_mod & 0xff;
+    const int mod = blend_key(b.flip_mod);
+    const bool stamped = kStamps && (b.flip_mod & kStamped) != 0;  // (wave-uniform: texel (i, j) itself)
     const int total = bw * bh;
     for (int p0 = lane; p0 < total; p0 += stride * kBatch) {
         int idx[kBatch];
@@ -425,13 +432,13 @@ PG_D void wave_blit_rotated(uint32_t* fb, const AtlasView& atlas, const Blit& b,
             const long long ly = -(long long)px * b.rot_sn + (long long)py * b.rot_cs + (long long)b.dh * 65536;
             if (lx < 0 || ly < 0 || lx >= (long long)(2 * b.dw) * 65536 || ly >= (long long)(2 * b.dh) * 65536) continue;
             const int i = static_cast<int>(lx >> 17), j = static_cast<int>(ly >> 17);
-            const int u = sample_index(0, b.sw, i, b.dw), v = sample_index(0, b.sh, j, b.dh);
+            const int u = stamped ? i : sample_index(0, b.sw, i, b.dw), v = stamped ? j : sample_index(0, b.sh, j, b.dh);
             idx[k] = Y * kObsW + X;
             texel[k] = tex[v * b.tex_w + u];
         }
 #pragma unroll
         for (int k = 0; k < kBatch; k++)
-            if (idx[k] >= 0) blend_into(fb, idx[k], texel[k], mod);
+            if (idx[k] >= 0) blend_into<kStamps>(fb, idx[k], texel[k], mod);
     }
 }
 
@@ -442,8 +449,14 @@ PG_D uint32_t over(uint32_t dst, uint32_t texel, int a) {
     return blend_px(dst, texel, a);
 }
 
+template <bool kStamps>
 PG_D void blend_into(uint32_t* fb, int idx, uint32_t texel, int mod) {
     int a = static_cast<int>(texel >> 24);
+    if (kStamps && (mod & kStamped)) {
+        if (a == 0) return;
+        fb[idx] = a == 255 ? (texel & 0x00ffffffu) : blend_premul(fb[idx], texel, a);
+        return;
+    }
     if (mod != 255) a = static_cast<int>(div255(static_cast<uint32_t>(a * mod)));
     if (a == 0) return;
     if (a == 255) {  // what the blend yields for an opaque texel, without the read-modify-write
@@ -457,10 +470,10 @@ PG_D void blend_into(uint32_t* fb, int idx, uint32_t texel, int mod) {
 // Columns [xa, xa + cwa) of the clipped rectangle (x0.., y0.., ch rows), cwa ≤ 32: the wave is 64 / W rows of W = 8, 16 or
 // 32 lanes.  A lane's texel column never changes; lane r holds the texel row of target row y0 + r (`row_at`, × the
 // texture's pitch), fetched across lanes.
-template <int kBatch>
+template <int kBatch, bool kStamps = false>
 PG_D void wave_blit_columns(uint32_t* fb, const uint32_t* tex, const Blit& b, int xa, int cwa, int y0, int ch, int row_at, int lane,
                             int half, int halves) {
-    const int mod = b.flip_mod & 0xff;
+    const int mod = blend_key(b.flip_mod);
     const int wshift = cwa <= 8 ? 3 : (cwa <= 16 ? 4 : 5);  // wave-uniform
     const int rows = 64 >> wshift;
     const int rx = lane & ((1 << wshift) - 1), rsub = lane >> wshift;
@@ -468,7 +481,7 @@ PG_D void wave_blit_columns(uint32_t* fb, const uint32_t* tex, const Blit& b, in
     const int x = xa + rx;
     int i = x - b.dx;
     if (b.flip_mod & kFlipH) i = b.dw - 1 - i;
-    const int u = on ? sample_index(b.sx, b.sw, i, b.dw) : b.sx;
+    const int u = !on ? b.sx : ((kStamps && (b.flip_mod & kStamped)) ? i : sample_index(b.sx, b.sw, i, b.dw));
     for (int t0 = half; t0 * rows < ch; t0 += halves * kBatch) {
         uint32_t texel[kBatch];
         int idx[kBatch];
@@ -483,10 +496,10 @@ PG_D void wave_blit_columns(uint32_t* fb, const uint32_t* tex, const Blit& b, in
         }
 #pragma unroll
         for (int k = 0; k < kBatch; k++)
-            if (idx[k] >= 0) blend_into(fb, idx[k], texel[k], mod);
+            if (idx[k] >= 0) blend_into<kStamps>(fb, idx[k], texel[k], mod);
     }
 }
-template <int kBatch = 4>
+template <int kBatch = 4, bool kStamps = false>
 PG_D void wave_blit(uint32_t* fb, const AtlasView& atlas, const Blit& b, int lane, int half = 0, int halves = 1,
                     int row_lo = 0, int row_hi = kObsH) {
     const int x0 = b.dx > 0 ? b.dx : 0, y0 = b.dy > row_lo ? b.dy : row_lo;
@@ -496,8 +509,9 @@ PG_D void wave_blit(uint32_t* fb, const AtlasView& atlas, const Blit& b, int lan
     if (cw <= 0 || ch <= 0) return;
     const uint32_t* tex = atlas.texels + b.tex_off;
     const int tw = b.tex_w;
-    const int mod = b.flip_mod & 0xff;
+    const int mod = blend_key(b.flip_mod);
     const bool fh = (b.flip_mod & kFlipH) != 0, fv = (b.flip_mod & kFlipV) != 0;
+    const bool stamped = kStamps && (b.flip_mod & kStamped) != 0;
     // The texel row of target row y0 + r is the same for every lane: lane r works it out once for all of them (the
     // target has 64 rows) and the loops below pick it up with a cross-lane read — one division per lane and draw for the
     // rows, one for the lane's column, instead of three per pixel (one pixel per lane in row-major order, the narrow
@@ -506,7 +520,7 @@ PG_D void wave_blit(uint32_t* fb, const AtlasView& atlas, const Blit& b, int lan
     if (y0 + lane < y1) {
         int j = y0 + lane - b.dy;
         if (fv) j = b.dh - 1 - j;
-        row_at = sample_index(b.sy, b.sh, j, b.dh) * tw;
+        row_at = (stamped ? j : sample_index(b.sy, b.sh, j, b.dh)) * tw;
     }
     if (cw > 48) {
         // Wide blit (backgrounds on the fallback path, jumper's compass): lane = column, kBatch rows per iteration.
@@ -514,7 +528,7 @@ PG_D void wave_blit(uint32_t* fb, const AtlasView& atlas, const Blit& b, int lan
         const bool on = lane < cw;
         int i = x - b.dx;
         if (fh) i = b.dw - 1 - i;
-        const int u = on ? sample_index(b.sx, b.sw, i, b.dw) : b.sx;
+        const int u = !on ? b.sx : (stamped ? i : sample_index(b.sx, b.sw, i, b.dw));
         for (int yb = y0 + half; yb < y1; yb += halves * kBatch) {
             uint32_t texel[kBatch];
 #pragma unroll
@@ -528,16 +542,16 @@ PG_D void wave_blit(uint32_t* fb, const AtlasView& atlas, const Blit& b, int lan
 #pragma unroll
             for (int k = 0; k < kBatch; k++) {
                 const int y = yb + k * halves;
-                if (on && y < y1) blend_into(fb, y * kObsW + x, texel[k], mod);
+                if (on && y < y1) blend_into<kStamps>(fb, y * kObsW + x, texel[k], mod);
             }
         }
     } else if (cw > 32) {
         // 33 to 48 columns (bossfight's shield, 35 × 29 at 0.7 alpha — every pixel a full blend): a lane per column would
         // leave up to half the wave idle in each of `ch` trips; the first 32 columns two rows a trip, the rest apart.
-        wave_blit_columns<kBatch>(fb, tex, b, x0, 32, y0, ch, row_at, lane, half, halves);
-        wave_blit_columns<kBatch>(fb, tex, b, x0 + 32, cw - 32, y0, ch, row_at, lane, half, halves);
+        wave_blit_columns<kBatch, kStamps>(fb, tex, b, x0, 32, y0, ch, row_at, lane, half, halves);
+        wave_blit_columns<kBatch, kStamps>(fb, tex, b, x0 + 32, cw - 32, y0, ch, row_at, lane, half, halves);
     } else {
-        wave_blit_columns<kBatch>(fb, tex, b, x0, cw, y0, ch, row_at, lane, half, halves);
+        wave_blit_columns<kBatch, kStamps>(fb, tex, b, x0, cw, y0, ch, row_at, lane, half, halves);
     }
 }
 
@@ -635,6 +649,7 @@ PG_D void wave_replay(uint32_t* fb, const AtlasView& atlas, const Blit& mine, un
 // round trips, and its length, not its instruction count, is what it costs — rotated or larger ones alone.
 // One target pixel of a rotated draw (raster spec S6): pixel p of `box` (row-major) maps back into the un-rotated
 // destination rectangle or misses it.  Same arithmetic as wave_blit_rotated.
+template <bool kStamps = false>
 PG_D bool rotated_pixel(const Blit& b, const RotBox& box, int p, int& idx, int& texel_at) {
     if (p >= box.bw * box.bh) return false;
     const int ry = udiv_small(p, box.bw);
@@ -649,7 +664,8 @@ PG_D bool rotated_pixel(const Blit& b, const RotBox& box, int p, int& idx, int& 
     if (lx < 0 || ly < 0 || lx >= (b.dw << 17) || ly >= (b.dh << 17)) return false;
     const int i = lx >> 17, j = ly >> 17;
     idx = Y * kObsW + X;
-    texel_at = b.tex_off + sample_index(0, b.sh, j, b.dh) * b.tex_w + sample_index(0, b.sw, i, b.dw);
+    texel_at = (kStamps && (b.flip_mod & kStamped)) ? b.tex_off + j * b.tex_w + i
+                                       : b.tex_off + sample_index(0, b.sh, j, b.dh) * b.tex_w + sample_index(0, b.sw, i, b.dw);
     return true;
 }
 constexpr int kRotSmall = 256;
@@ -677,11 +693,27 @@ struct ReplayState {
     int idx[kGroup], mod[kGroup];
 };
 
-template <int kGroup, bool kRotInGroups, bool kPacked, int kLone = 4>
+template <int kGroup, bool kRotInGroups, bool kPacked, int kLone = 4, bool kStamps = false>
 PG_D void replay_group(const AtlasView& atlas, const Blit& mine, ReplayState<kGroup>& st, int lane, int row_lo, int row_hi,
                        uint32_t* fb_for_lone) {
-    // requests the texels of the next ≤ kGroup small draws; a big draw at the head of the group is executed on the spot
-    // (fb_for_lone; nullptr = stop in front of it instead)
+    // requests the texels of the next ≤ kGroup small draws; the big draws at the head of the list are executed on the spot
+    // first (fb_for_lone; nullptr = stop in front of them instead).  They have a loop of their own, in front of the
+    // unrolled one: wave_blit and wave_blit_rotated are most of this function's code, and inside the group loop that
+    // code counted four times against the unroller's budget — over it, the loop stays rolled and ReplayState's arrays
+    // land in scratch memory (bossfight's render kernel, round 6: 0.49 -> 0.72 ms).
+    while (fb_for_lone != nullptr && st.mask != 0) {  // (wave-uniform)
+        const int src = __builtin_ctzll(st.mask);
+        if (!((st.lones >> src) & 1ull)) break;
+        st.mask &= st.mask - 1;
+        const Blit b = kPacked ? blit_from_lane(st.packed, mine, src) : blit_from_lane(mine, src);
+        wave_order();
+        if (b.flip_mod & kRotated) {
+            wave_blit_rotated<kLone, kStamps>(fb_for_lone, atlas, b, rot_box_rows(b, row_lo, row_hi), lane, 64);
+        } else {
+            wave_blit<kLone, kStamps>(fb_for_lone, atlas, b, lane, 0, 1, row_lo, row_hi);
+        }
+        wave_order();
+    }
     bool stop = false;
 #pragma unroll
     for (int g = 0; g < kGroup; g++) {
@@ -691,31 +723,20 @@ PG_D void replay_group(const AtlasView& atlas, const Blit& mine, ReplayState<kGr
         if (st.mask == 0 || stop) continue;
         const int src = __builtin_ctzll(st.mask);
         if ((st.lones >> src) & 1ull) {
-            stop = true;  // a big one: alone, only at the head of a group
-            if (g == 0 && fb_for_lone != nullptr) {
-                st.mask &= st.mask - 1;
-                const Blit b = kPacked ? blit_from_lane(st.packed, mine, src) : blit_from_lane(mine, src);
-                wave_order();
-                if (b.flip_mod & kRotated) {
-                    wave_blit_rotated<kLone>(fb_for_lone, atlas, b, rot_box_rows(b, row_lo, row_hi), lane, 64);
-                } else {
-                    wave_blit<kLone>(fb_for_lone, atlas, b, lane, 0, 1, row_lo, row_hi);
-                }
-                wave_order();
-            }
+            stop = true;  // a big one: alone, in front of the next group
             continue;
         }
         st.mask &= st.mask - 1;
         const Blit b = kPacked ? blit_from_lane(st.packed, mine, src) : blit_from_lane(mine, src);
+        st.mod[g] = blend_key(b.flip_mod);  // (here, where control is still wave-uniform: the key stays a scalar)
         if (kRotInGroups && (b.flip_mod & kRotated)) {
             int at = 0, where = -1;
             const uint32_t b0 = __builtin_amdgcn_readlane(st.box[0], src), b1 = __builtin_amdgcn_readlane(st.box[1], src);
             const RotBox box{static_cast<int>(b0 & 0xffffu), static_cast<int>(b0 >> 16), static_cast<int>(b1 & 0xffffu),
                              static_cast<int>(b1 >> 16)};  // (in a group: 1 ≤ bw, bh ≤ 64; x_lo, y_lo ≥ 0)
-            if (rotated_pixel(b, box, lane, where, at)) {
+            if (rotated_pixel<kStamps>(b, box, lane, where, at)) {
                 st.idx[g] = where;
                 st.texel[g] = atlas.texels[at];
-                st.mod[g] = b.flip_mod & 0xff;
             }
             continue;
         }
@@ -730,11 +751,11 @@ PG_D void replay_group(const AtlasView& atlas, const Blit& mine, ReplayState<kGr
         int i = x - b.dx, j = y - b.dy;
         if (b.flip_mod & kFlipH) i = b.dw - 1 - i;
         if (b.flip_mod & kFlipV) j = b.dh - 1 - j;
-        const int u = sample_index(b.sx, b.sw, i, b.dw);
-        const int v = sample_index(b.sy, b.sh, j, b.dh);
+        const bool stamped = kStamps && (b.flip_mod & kStamped) != 0;
+        const int u = stamped ? i : sample_index(b.sx, b.sw, i, b.dw);
+        const int v = stamped ? j : sample_index(b.sy, b.sh, j, b.dh);
         st.idx[g] = y * kObsW + x;
         st.texel[g] = atlas.texels[b.tex_off + v * b.tex_w + u];
-        st.mod[g] = b.flip_mod & 0xff;
     }
 }
 
@@ -777,11 +798,11 @@ PG_D ReplayState<kGroup> replay_classify(const Blit& mine, unsigned long long ma
     return st;
 }
 
-template <int kGroup = 4, bool kRotInGroups = false, bool kPacked = true>
+template <int kGroup = 4, bool kRotInGroups = false, bool kPacked = true, bool kStamps = false>
 PG_D ReplayState<kGroup> replay_begin(const AtlasView& atlas, const Blit& mine, unsigned long long mask, int lane,
                                       int row_lo, int row_hi, const RotBox* whole = nullptr) {
     ReplayState<kGroup> st = replay_classify<kGroup, kRotInGroups, kPacked>(mine, mask, lane, row_lo, row_hi, whole);
-    replay_group<kGroup, kRotInGroups, kPacked>(atlas, mine, st, lane, row_lo, row_hi, nullptr);  // (a big draw first: nothing requested)
+    replay_group<kGroup, kRotInGroups, kPacked, 4, kStamps>(atlas, mine, st, lane, row_lo, row_hi, nullptr);  // (a big draw first: nothing requested)
     return st;
 }
 
@@ -790,29 +811,29 @@ PG_D ReplayState<kGroup> replay_begin(const AtlasView& atlas, const Blit& mine, 
 // jumper's 0.843 -> 0.853.  These kernels are bound by vector instructions at four clocks apiece (SQ_ACTIVE_INST_VALU:
 // 4.6 clocks per SQ_INSTS_VALU), not by the length of the pass's chain of round trips; the copies that free the state for
 // the next request are more instructions.)
-template <int kGroup = 4, bool kRotInGroups = false, bool kPacked = true, int kLone = 4>
+template <int kGroup = 4, bool kRotInGroups = false, bool kPacked = true, int kLone = 4, bool kStamps = false>
 PG_D void replay_finish(uint32_t* fb, const AtlasView& atlas, const Blit& mine, ReplayState<kGroup>& st, int lane,
                         int row_lo, int row_hi) {
     wave_order();  // what the caller put into these rows in the meantime
     for (;;) {
 #pragma unroll
         for (int g = 0; g < kGroup; g++) {
-            if (st.idx[g] >= 0) blend_into(fb, st.idx[g], st.texel[g], st.mod[g]);
+            if (st.idx[g] >= 0) blend_into<kStamps>(fb, st.idx[g], st.texel[g], st.mod[g]);
             wave_order();  // draws may overlap
         }
         if (st.mask == 0) break;
-        replay_group<kGroup, kRotInGroups, kPacked, kLone>(atlas, mine, st, lane, row_lo, row_hi, fb);
+        replay_group<kGroup, kRotInGroups, kPacked, kLone, kStamps>(atlas, mine, st, lane, row_lo, row_hi, fb);
     }
 }
 
 // kRotInGroups: small rotated draws (a bullet, a puff: ≤ 64 pixels of bounding box on my rows) share a memory round
 // trip with their neighbours in the list like the plain small ones, instead of paying one each (bossfight: dozens of
 // bullets a frame).  Costs registers and code in the group loop, so only kernels with room to spare turn it on.
-template <int kGroup = 4, bool kRotInGroups = false, bool kPacked = true, int kLone = 4>
+template <int kGroup = 4, bool kRotInGroups = false, bool kPacked = true, int kLone = 4, bool kStamps = false>
 PG_D void wave_replay_rows(uint32_t* fb, const AtlasView& atlas, const Blit& mine, unsigned long long mask, int lane,
                            int row_lo, int row_hi, const RotBox* whole = nullptr) {
-    ReplayState<kGroup> st = replay_begin<kGroup, kRotInGroups, kPacked>(atlas, mine, mask, lane, row_lo, row_hi, whole);
-    replay_finish<kGroup, kRotInGroups, kPacked, kLone>(fb, atlas, mine, st, lane, row_lo, row_hi);
+    ReplayState<kGroup> st = replay_begin<kGroup, kRotInGroups, kPacked, kStamps>(atlas, mine, mask, lane, row_lo, row_hi, whole);
+    replay_finish<kGroup, kRotInGroups, kPacked, kLone, kStamps>(fb, atlas, mine, st, lane, row_lo, row_hi);
 }
 
 // A draw that is the same in every frame of every env (a HUD element at a fixed place on the observation), prepared

@@ -136,6 +136,47 @@ __device__ inline void mt_twist_wave(uint32_t* x, int lane) {
     __syncthreads();
 }
 
+// The stream's NEXT 624 words from its current ones, OUT of place, by one wavefront (round 6).  What mt_twist makes of
+// x in place is a function of x alone, so it can be worked out into a second buffer at any time after x was (re)generated
+// — long before the stream runs out — by somebody who is not in a hurry (pg_gang.h GangRng::refill: the gang that runs out
+// then copies 624 words, one memory round trip, instead of regenerating them in six dependent ones).  Word i of the new
+// block, in three ranges: [0, 227): cur[i + 397] ^ mix(cur[i], cur[i + 1]); [227, 454) and [454, 623): NEW[i − 227] ^
+// mix(cur[i], cur[i + 1]) — lane l takes words l, l + 64, … of every range, so the new word it needs is one it has made
+// itself; 623: NEW[396] ^ mix(cur[623], NEW[0]).  Every load (of `cur` only) leaves before the first is waited for.
+// cur and next are in device memory; every lane of the wave calls.
+__device__ inline void mt_next_block_wave(const uint32_t* cur, uint32_t* next, int lane) {
+    constexpr int kA = kMtN - kMtM;  // 227
+    uint32_t own[3][4], up[3][4], far[4];
+#pragma unroll
+    for (int ph = 0; ph < 3; ph++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int j = lane + 64 * r, i = ph * kA + j;
+            const bool in = j < kA && i < kMtN - 1;
+            own[ph][r] = in ? cur[i] : 0u;
+            up[ph][r] = in ? cur[i + 1] : 0u;
+            if (ph == 0) far[r] = in ? cur[i + kMtM] : 0u;
+        }
+    const uint32_t last = cur[kMtN - 1];
+    uint32_t made[3][4];
+#pragma unroll
+    for (int ph = 0; ph < 3; ph++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) made[ph][r] = (ph == 0 ? far[r] : made[ph - 1][r]) ^ mt_mix(own[ph][r], up[ph][r]);
+#pragma unroll
+    for (int ph = 0; ph < 3; ph++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int j = lane + 64 * r, i = ph * kA + j;
+            if (j < kA && i < kMtN - 1) next[i] = made[ph][r];
+        }
+    // word 623: NEW[396] = range 1, j = 169 = 41 + 64·2 (lane 41, r = 2); NEW[0] = range 0, lane 0, r = 0
+    const uint32_t new396 = static_cast<uint32_t>(__shfl(static_cast<int>(made[1][2]), 41));
+    const uint32_t new0 = static_cast<uint32_t>(__shfl(static_cast<int>(made[0][0]), 0));
+    static_assert(kMtM - 1 - kA == 169 && 169 == 41 + 64 * 2, "where NEW[396] is made");
+    if (lane == 0) next[kMtN - 1] = new396 ^ mt_mix(last, new0);
+}
+
 // Wave-uniform draws from a stream held in LDS: every lane calls them together and gets the same value; the
 // regeneration of the 624 words, when due, is done by all lanes (mt_twist_wave) instead of by one.
 __device__ inline uint32_t wave_mt_next(uint32_t* x, int lane) {

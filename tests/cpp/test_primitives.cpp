@@ -213,6 +213,25 @@ static void test_blend() {
                                                   uint32_t(s) | uint32_t(s) << 8 | uint32_t(s) << 16 | 0xab000000u, a);
                 CHECK(got == (uint32_t(want) | uint32_t(want) << 8 | uint32_t(want) << 16), "blend a=%d s=%d d=%d", a, s, d);
             }
+    // … and through a stamp's texel (pg_stamps.h: stamp_texel on the host, blend_premul on the device): the same pixel as
+    // the naive S4 with the modulation applied first, for every texel alpha, modulation, colour and destination
+    for (int mod : {255, 178, 254, 100, 1, 0})
+        for (int A = 0; A < 256; A++)
+            for (int s = 0; s < 256; s += (A % 8 == 0 ? 1 : 7))
+                for (int d = 0; d < 256; d += (A % 16 == 0 ? 1 : 5)) {
+                    const int a = mod != 255 ? A * mod / 255 : A;
+                    int want = d;
+                    if (a != 0) {
+                        const int sc = (a < 255) ? s * a / 255 : s;
+                        want = sc + (255 - a) * d / 255;
+                    }
+                    const uint32_t st = pg::stamp_texel(uint32_t(s) | uint32_t(s) << 8 | uint32_t(s) << 16 | uint32_t(A) << 24, mod);
+                    const uint32_t dst = uint32_t(d) | uint32_t(d) << 8 | uint32_t(d) << 16;
+                    const int sa = int(st >> 24);
+                    const uint32_t got = sa == 0 ? dst : (sa == 255 ? (st & 0x00ffffffu) : pg::blend_premul(dst, st, sa));
+                    CHECK(sa == a, "stamp alpha A=%d mod=%d", A, mod);
+                    CHECK(got == (uint32_t(want) | uint32_t(want) << 8 | uint32_t(want) << 16), "stamp blend A=%d mod=%d s=%d d=%d", A, mod, s, d);
+                }
     {   // channels that differ from each other (red and blue share a word inside blend_px)
         uint32_t seed = 12345u;
         auto next = [&]() { return seed = seed * 1664525u + 1013904223u; };

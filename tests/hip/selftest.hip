@@ -19,6 +19,7 @@
 #include "pg_sincos.h"
 #include "pg_engine.h"
 #include "pg_render.h"
+#include "pg_stamps.h"
 
 #define ST_API extern "C" __attribute__((visibility("default")))
 
@@ -200,7 +201,7 @@ __global__ void k_sort_equal(int n, int* out) {
 // draw per lane, in lane order, over a given 64×64 target; each wave blends and stores the 32 rows it owns.
 template <bool kRotInGroups>
 __global__ void __launch_bounds__(128) k_replay(pg::AtlasView atlas, const uint32_t* bg, int n_draws, const int32_t* draws,
-                                                const double* deg, uint8_t* out_rgb) {
+                                                const double* deg, uint8_t* out_rgb, uint32_t stamps) {
     __shared__ alignas(16) uint32_t fb[pg::kFbWords];
     const int lane = threadIdx.x & 63, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int k = threadIdx.x; k < pg::kFbWords; k += 128) fb[k] = bg[k] | 0x5a000000u;  // (the top byte is nobody's)
@@ -230,17 +231,53 @@ __global__ void __launch_bounds__(128) k_replay(pg::AtlasView atlas, const uint3
             pg::rotation_16_16(deg[lane], mine.rot_sn, mine.rot_cs);
             mine.flip_mod = d[10] | pg::kRotated;
         }
+        // stamps != 0: the pre-pass's substitution (pg_stamps.h) where a stamp of this draw's size and modulation exists
+        if (stamps) pg::stamp_substitute(reinterpret_cast<const uint4*>(atlas.texels + stamps) + d[0] * pg::kStampsPerTex, t.y, t.z, mine);
     }
-    pg::wave_replay_rows<4, kRotInGroups>(fb, atlas, mine, __ballot(has), lane, 32 * half, 32 * half + 32);
+    pg::wave_replay_rows<4, kRotInGroups, true, 4, true>(fb, atlas, mine, __ballot(has), lane, 32 * half, 32 * half + 32);  // (stamps allowed)
     pg::wave_store_rows(fb, out_rgb, lane, 32 * half, 32 * half + 32);
 }
 
 }  // namespace
 
 // atlas: `words` RGBA texels of all textures one after the other, desc[t] = {first texel, w, h, 0}.
-ST_API int pgst_replay(int rot_in_groups, int n_tex, const int32_t* desc, int n_words, const uint32_t* words,
+namespace {
+struct MiniAtlas {  // what pg::append_stamps asks of an atlas (pg_engine.h Atlas has the same four members)
+    std::vector<uint32_t> words;
+    std::vector<int4> desc;
+    const uint32_t* texels_host(int tex) const { return words.data() + desc[tex].x; }
+    int4 desc_host(int tex) const { return desc[tex]; }
+    uint32_t append_words(const std::vector<uint32_t>& more) {
+        const uint32_t at = static_cast<uint32_t>(words.size());
+        words.insert(words.end(), more.begin(), more.end());
+        return at;
+    }
+    size_t texel_bytes() const { return words.size() * 4; }
+};
+}  // namespace
+
+// `stamped` (rot_in_groups bit 1): every draw that takes its whole texture gets a stamp of its size and modulation
+// (pg_stamps.h append_stamps, the first kStampsPerTex per texture) and the kernel substitutes it, as a pre-pass would.
+ST_API int pgst_replay(int rot_in_groups, int n_tex, const int32_t* desc, int n_words_in, const uint32_t* words_in,
                        const uint32_t* bg, int n_draws, const int32_t* draws, const double* deg, uint8_t* out_rgb) {
     if (n_draws > 64) return 1;
+    const bool stamped = (rot_in_groups & 2) != 0;
+    rot_in_groups &= 1;
+    MiniAtlas mini;
+    mini.words.assign(words_in, words_in + n_words_in);
+    mini.desc.assign(reinterpret_cast<const int4*>(desc), reinterpret_cast<const int4*>(desc) + n_tex);
+    uint32_t stamps = 0;
+    if (stamped) {
+        std::vector<pg::StampSpec> specs;
+        for (int k = 0; k < n_draws; k++) {
+            const int32_t* d = draws + 12 * k;
+            const int4 t = mini.desc[d[0]];
+            if (d[5] == 0 && d[6] == 0 && d[7] == t.y && d[8] == t.z) specs.push_back({d[0], d[3], d[4], d[10]});
+        }
+        stamps = pg::append_stamps(mini, n_tex, specs);
+    }
+    const int n_words = static_cast<int>(mini.words.size());
+    const uint32_t* words = mini.words.data();
     Dev<int4> d_desc(reinterpret_cast<const int4*>(desc), n_tex);
     Dev<uint32_t> d_words(words, n_words), d_bg(bg, 64 * 64);
     Dev<int32_t> d_draws(draws, size_t(12) * (n_draws ? n_draws : 1));
@@ -248,9 +285,9 @@ ST_API int pgst_replay(int rot_in_groups, int n_tex, const int32_t* desc, int n_
     Dev<uint8_t> d_out(64 * 64 * 3);
     const pg::AtlasView atlas{d_words.p, d_desc.p, n_tex, static_cast<uint32_t>(n_words) * 4u, nullptr};
     if (rot_in_groups)
-        hipLaunchKernelGGL(k_replay<true>, dim3(1), dim3(128), 0, 0, atlas, d_bg.p, n_draws, d_draws.p, d_deg.p, d_out.p);
+        hipLaunchKernelGGL(k_replay<true>, dim3(1), dim3(128), 0, 0, atlas, d_bg.p, n_draws, d_draws.p, d_deg.p, d_out.p, stamps);
     else
-        hipLaunchKernelGGL(k_replay<false>, dim3(1), dim3(128), 0, 0, atlas, d_bg.p, n_draws, d_draws.p, d_deg.p, d_out.p);
+        hipLaunchKernelGGL(k_replay<false>, dim3(1), dim3(128), 0, 0, atlas, d_bg.p, n_draws, d_draws.p, d_deg.p, d_out.p, stamps);
     if (finish()) return 1;
     return d_out.down(out_rgb) ? 0 : 1;
 }

@@ -68,6 +68,17 @@ def test_coinrun_hazards_the_long_way():
     assert resets > 0
 
 
+@pytest.mark.parametrize("game_flags", [0, 1])
+def test_chaser_enemies_the_long_way(game_flags):
+    """chaser's enemies take their turns side by side, one per lane, on outputs peeked from the env's stream where each is
+    thought to start (chaser.hip advance); where the peek does not reach — the last few of the stream's 624 words, a
+    rejected range draw — they go one after the other on the stream itself.  pgv_set_debug bit 25 sends every sub-step
+    that way: the same rewards, dones, frames and enemy states as the oracle through episode ends, for both `abs`
+    readings (D21).  (The default path is what every other chaser test runs.)"""
+    resets = _lockstep("chaser", 256, 400, seed_base=11, run_seed=5, check_state_every=50, debug=1 << 25, game_flags=game_flags)
+    assert resets > 0
+
+
 @pytest.mark.parametrize("game", ["coinrun", "maze", "bossfight", "climber", "caveflyer", "chaser", "jumper"])
 def test_row_composer_equals_draw_list_replay(game):
     """The fused background+tile row composer (pg_render.h compose_rows) against the one-blit-at-a-time replay of

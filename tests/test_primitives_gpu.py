@@ -309,16 +309,26 @@ def _sprite_scene(rng, n_draws, crowded):
         else:
             sx, sy = int(rng.integers(0, tw[t])), int(rng.integers(0, th[t]))
             sw, sh = int(rng.integers(1, tw[t] - sx + 1)), int(rng.integers(1, th[t] - sy + 1))
+            if rng.random() < 0.4:  # the whole texture: what a sprite wholly on the screen is, and what a stamp may replace
+                sx, sy, sw, sh = 0, 0, int(tw[t]), int(th[t])
             flip = int(rng.integers(0, 3))
-        mod = 255 if rng.random() < 0.5 else int(rng.integers(0, 256))
+        mod = 255 if rng.random() < 0.5 else int(rng.choice([178, int(rng.integers(0, 256))]))
+        if k and rng.random() < 0.25:  # the same sprite again elsewhere (same texture, size, modulation: shares a stamp)
+            t, dw, dh, sx, sy, sw, sh, mod = (int(draws[k - 1][j]) for j in (0, 3, 4, 5, 6, 7, 8, 10))
+            if draws[k - 1][11] and not rotated:
+                flip = 0
+            if rotated and (sx, sy, sw, sh) != (0, 0, int(tw[t]), int(th[t])):
+                sx, sy, sw, sh = 0, 0, int(tw[t]), int(th[t])
         draws[k] = (t, dx, dy, dw, dh, sx, sy, sw, sh, flip, mod, 1 if rotated else 0)
     return tw, th, rgba, words, np.array(desc, np.int32), bg, draws, deg
 
 
-@pytest.mark.parametrize("rot_in_groups", [0, 1])
+@pytest.mark.parametrize("rot_in_groups", [0, 1, 2, 3])
 def test_sprite_replay_matches_the_raster_spec(st, rot_in_groups):
     """pg_render.h wave_replay_rows — groups of small draws, large ones alone, rotated ones either way, each wave on
-    the rows it owns — against oracle/pgo_raster.cpp's spec_blit on the same integer draw calls."""
+    the rows it owns — against oracle/pgo_raster.cpp's spec_blit on the same integer draw calls.  Bit 1 of the parameter:
+    the draws that take their whole texture are replaced by pre-scaled, pre-multiplied stamps first (pg_stamps.h), as a
+    render pre-pass would; the oracle draws the original textures."""
     hooks = oracle_util.oracle()
     hooks.pgo_hook_raster.argtypes = [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]
     hooks.pgo_hook_raster.restype = None
