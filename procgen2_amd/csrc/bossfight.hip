@@ -96,6 +96,13 @@ struct State {
         uint32_t* bullets;    // [n][64][kBulletWords]  visible boss bullets in drawing order
         uint32_t* draws;      // [n][64][kBlitWords]    the visible draws of the second list in drawing order
     } prep;
+    // A second buffer for every env's random stream and its selector (pg_gang.h GangRng): the stream's next 624 words are
+    // worked out ahead of the step that needs them (a few extra workgroups of setup_kernel, pg_rng.h mt_next_block_wave)
+    // into whichever buffer is not current, and the gang that runs out of numbers changes buffers instead of regenerating
+    // the block (19 of the logic kernel's 126 µs were wavefronts waiting for one of their four gangs to do that).  Scratch
+    // memory, not state: begin_level and prepare_save make mt[env] the current block again.
+    uint32_t* mt_other;  // [n][kMtN]
+    uint8_t* mt_sel;     // [n]  bit 1: the current words are in mt_other[env]; bit 0: the other buffer holds the next block
     uint32_t stamps;  // word offset of the stamp table in the atlas (pg_stamps.h; BossfightGame::extend_atlas), 0 = none
 };
 constexpr int kBulletWords = 10;  // pg_render.h BlitWords, sine, cosine (16.16), bounding box on the target (x, y, w, h: a byte each), one spare
@@ -614,7 +621,7 @@ PG_D bool boss_update(const State& s, Rings& R, int env, Live& v, Rng& rng, Q q,
 }
 
 PG_D void advance(const State& s, Rings& R, Q q, int env, int action, float& reward_out, bool& terminated_out) {
-    Rng rng = Rng::open(s.mt + size_t(env) * kMtWords, q);
+    Rng rng = Rng::open(s.mt + size_t(env) * kMtWords, q, s.mt_other + size_t(env) * kMtN, s.mt_sel + env);
     const int flags = SI(s, I_FLAGS, env);
     Live v;
     v.ax = SF(s, F_AX, env);
@@ -767,6 +774,11 @@ PG_D void fresh_env(const State& s, int env) {
 // (pg_engine.h LevelPlan) instead rebuilds the env as a fresh cenv_make(seed = level number) would.
 PG_D void begin_level(const State& s, const LevelPlan& plan, int env, bool restart, uint32_t chain_seed) {
     uint32_t* mt = s.mt + size_t(env) * kMtWords;
+    if (s.mt_sel[env] & 2) {  // the stream's current words are where its gang left them (State::mt_sel): home first
+        const uint32_t* other = s.mt_other + size_t(env) * kMtN;
+        for (int k = 0; k < kMtN; k++) mt[k] = other[k];
+    }
+    s.mt_sel[env] = 0;  // (… and whatever was made ahead is dropped: this lane draws, or reseeds)
     if (restart) {
         plan.chain_seed[env] = chain_seed;
         plan.drawn[env] = 0;
@@ -810,7 +822,7 @@ __global__ void __launch_bounds__(64, PG_BOSSFIGHT_WAVES) logic_kernel(State s, 
         if (plan.num_levels > 0) {  // level-seed mode rebuilds the env: one lane (begin_level)
             if (q.g == 0) begin_level(s, plan, env, false, 0u);
         } else {
-            Rng rng = Rng::open(s.mt + size_t(env) * kMtWords, q);
+            Rng rng = Rng::open(s.mt + size_t(env) * kMtWords, q, s.mt_other + size_t(env) * kMtN, s.mt_sel + env);
             new_level(s, env, rng, q.g == 0);
             rng.close();
         }
@@ -996,6 +1008,21 @@ __global__ void __launch_bounds__(128, 4) render_full_kernel(State s, AtlasView 
 // lists of two envs, dealt densely over its lanes, once.  The background's 64 column and 64 row offsets depend on the
 // backdrop only (the camera never moves): a table per backdrop, made once.
 
+// Every stream whose current words are in the second buffer back into mt[env] (BossfightGame::prepare_save); a wavefront
+// per 64 envs.  The block made ahead, if any, is dropped: setup_kernel makes it again.
+__global__ void __launch_bounds__(64) streams_home_kernel(State s) {
+    const int lane = threadIdx.x, env0 = blockIdx.x * 64, e = env0 + lane;
+    unsigned long long todo = __ballot(e < s.n && (s.mt_sel[e] & 2));
+    while (todo) {  // (wave-uniform)
+        const int env = env0 + __builtin_ctzll(todo);
+        todo &= todo - 1;
+        uint32_t* home = s.mt + size_t(env) * kMtWords;
+        const uint32_t* other = s.mt_other + size_t(env) * kMtN;
+        for (int k = lane; k < kMtN; k += 64) home[k] = other[k];
+        if (lane == 0) s.mt_sel[env] = 0;
+    }
+}
+
 // bg_axis + bg_offset of compose_background for each of the 13 backdrops (bossfight.cpp:416-419).
 __global__ void __launch_bounds__(128) backdrop_kernel(State s, AtlasView atlas) {
     const int backdrop = blockIdx.x, lane = threadIdx.x & 63, axis = threadIdx.x >> 6;
@@ -1014,10 +1041,28 @@ struct SetupLds {
     PrepDrawQueue queue[kPrepThreads / 64];  // one worklist per wavefront (pg_prepass.h)
     uint4 stamp[kTexCount * kStampsPerTex];  // pg_stamps.h: the sizes each texture is drawn at, pre-scaled
 };
-__global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView atlas, const uint8_t* mask) {
+// Workgroups from n_groups on (a step's launch only): the random streams' next blocks for the envs that have none
+// (State::mt_other, mt_sel), a wavefront per 64 envs.  The logic kernel is done and nothing else draws: the streams stand still.
+__global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView atlas, const uint8_t* mask, int n_groups) {
     __shared__ SetupLds S;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int env0 = prep_block(blockIdx.x, gridDim.x) * kPrepEnvs;  // (pg_prepass.h: the groups of one XCD are consecutive)
+    if (static_cast<int>(blockIdx.x) >= n_groups) {  // (workgroup-uniform)
+        const int first = ((static_cast<int>(blockIdx.x) - n_groups) * (kPrepThreads / 64) + wave) * 64, e = first + lane;
+        const int sel = e < s.n ? s.mt_sel[e] : 1;
+        unsigned long long todo = __ballot(e < s.n && !(sel & 1));
+        while (todo) {  // (wave-uniform)
+            const int k = __builtin_ctzll(todo), env = first + k;
+            todo &= todo - 1;
+            const int sel_env = __shfl(sel, k);
+            uint32_t* home = s.mt + size_t(env) * kMtWords;
+            uint32_t* other = s.mt_other + size_t(env) * kMtN;
+            const bool in_other = (sel_env & 2) != 0;
+            mt_next_block_wave(in_other ? other : home, in_other ? home : other, lane);
+            if (lane == 0) s.mt_sel[env] = static_cast<uint8_t>(sel_env | 1);
+        }
+        return;
+    }
+    const int env0 = prep_block(blockIdx.x, n_groups) * kPrepEnvs;  // (pg_prepass.h: the groups of one XCD are consecutive)
     if (tid < kTexCount) S.desc[tid] = atlas.desc[tid];
     if (tid < kTexCount * kStampsPerTex)
         S.stamp[tid] = s.stamps ? reinterpret_cast<const uint4*>(atlas.texels + s.stamps)[tid] : make_uint4(0u, 0u, 0u, 0u);
@@ -1430,7 +1475,10 @@ class BossfightGame final : public Game {
     // (every flag that changes the frame's path — the draw-list replay, kDebugNoPrepass, the timing experiments — takes the complete kernel)
     bool lean() const { return (debug_flags & ~kDebugNoPrefetch) == 0; }
     void launch_prepass(hipStream_t st, const uint8_t* mask) override {
-        if (lean()) hipLaunchKernelGGL(setup_kernel, dim3((s_.n + kPrepEnvs - 1) / kPrepEnvs), dim3(kPrepThreads), 0, st, s_, atlas_, mask);
+        if (lean()) {
+            const int groups = (s_.n + kPrepEnvs - 1) / kPrepEnvs;  // … and a wavefront per 64 envs for the random streams' next blocks
+            hipLaunchKernelGGL(setup_kernel, dim3(groups + (s_.n + kPrepThreads - 1) / kPrepThreads), dim3(kPrepThreads), 0, st, s_, atlas_, mask, groups);
+        }
     }
     void launch_render(hipStream_t st, const uint8_t* mask, StepIO io) override {
         if (lean())
@@ -1441,7 +1489,14 @@ class BossfightGame final : public Game {
     static size_t up256(size_t b) { return (b + 255) & ~size_t(255); }
     size_t scratch_bytes(int n) const override {
         return up256(size_t(kBackdrops) * 128 * 4) + up256(size_t(n) * 4) + up256(size_t(n) * kBossShots * kBulletWords * 4) +
-               up256(size_t(n) * kPrepDraws * kBlitWords * 4);
+               up256(size_t(n) * kPrepDraws * kBlitWords * 4) + up256(size_t(n) * kMtN * 4) + up256(size_t(n));
+    }
+    void state_loaded() override {
+        hipMemset(s_.mt_sel, 0, size_t(s_.n));  // the streams that were just loaded are in mt[env]; what was made ahead is not theirs
+    }
+    // A snapshot takes the streams from mt[env]: the ones whose gang has moved on to the second buffer come home first.
+    void prepare_save(hipStream_t st) override {
+        hipLaunchKernelGGL(streams_home_kernel, dim3((s_.n + 63) / 64), dim3(64), 0, st, s_);
     }
     void bind_scratch(void* d_scratch, int n) override {
         uint8_t* p = static_cast<uint8_t*>(d_scratch);
@@ -1452,6 +1507,10 @@ class BossfightGame final : public Game {
         s_.prep.bullets = reinterpret_cast<uint32_t*>(p);
         p += up256(size_t(n) * kBossShots * kBulletWords * 4);
         s_.prep.draws = reinterpret_cast<uint32_t*>(p);
+        p += up256(size_t(n) * kPrepDraws * kBlitWords * 4);
+        s_.mt_other = reinterpret_cast<uint32_t*>(p);
+        p += up256(size_t(n) * kMtN * 4);
+        s_.mt_sel = p;  // (the engine zeroes the scratch block: every stream is at home, nothing is made ahead)
     }
     // Same layout as oracle/pgo_bossfight.cpp Bossfight::dump_state.
     int dump_state(hipStream_t st, int env, float* out, int cap) override {
