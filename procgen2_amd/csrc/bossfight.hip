@@ -1113,11 +1113,17 @@ __global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView 
                 const float size = 0.1f;
                 has = resolve_rotated_at(cam, d.y, d.z, d.x, px * kUnitPx - size * d.y * 0.5f, py * kUnitPx - size * d.z * 0.5f,
                                          rot_sn, rot_cs, size, 1.0f, b);
-                if (has && (b.flip_mod & kRotated)) {  // neither wave of the render workgroup would find a pixel of it: not listed
-                    box = rot_box(b);
-                    has = box.bw > 0 && box.bh > 0;
+                if (has) {
+                    // the bullet's stamp, and with it the part of the bullet that can show at all: a laser is a few opaque
+                    // texels in a transparent rim, and the box is that of the core (pg_stamps.h rot_box_core) — 3 × 3 or
+                    // 4 × 4 pixels instead of 6 × 6, four bullets to a render wavefront's slot (pg_render.h, tiny draws)
+                    int core_w, core_h;
+                    has = stamp_substitute(&S.stamp[want_tex * kStampsPerTex], d.y, d.z, b, core_w, core_h);
+                    if (has && (b.flip_mod & kRotated)) {  // no pixel of it on the target: not listed
+                        box = rot_box_core(b, core_w, core_h);
+                        has = box.bw > 0 && box.bh > 0;
+                    }
                 }
-                if (has) stamp_substitute(&S.stamp[want_tex * kStampsPerTex], d.y, d.z, b);
             }
             const unsigned long long m_a = __ballot(has && !is_b), m_b = __ballot(has && is_b);
             const unsigned long long below = (1ull << lane) - 1ull;
@@ -1248,6 +1254,14 @@ __global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView 
 // slot and memory back at once.  Four parts of 16 rows: 0.84 ms, what a wave does before its first pixel is a third of its
 // work; one wave for all 64 rows: 0.86 ms, 16 KB a wave leaves 2.5 waves per SIMD).
 constexpr int kRenderParts = 2;
+// Draws per memory round trip of the lean kernel's sprite passes (pg_render.h kGroup: small draws in flight together;
+// kLone: trips of a big draw in flight together).  A render wavefront's life is a chain of such round trips.
+#ifndef PG_BOSSFIGHT_GROUP
+#define PG_BOSSFIGHT_GROUP 4
+#endif
+#ifndef PG_BOSSFIGHT_LONE
+#define PG_BOSSFIGHT_LONE 4
+#endif
 __global__ void __launch_bounds__(64, 5) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io) {
     constexpr int halves = kRenderParts;
     const int env = blockIdx.x / halves;
@@ -1283,9 +1297,9 @@ __global__ void __launch_bounds__(64, 5) render_kernel(State s, AtlasView atlas,
     compose_background_from<kOwnRows, true>(fb, atlas, bg_col, bg_row, lane, half);
     PG_TL(2);
     const unsigned long long mb = __ballot(has_bullet), md = __ballot(has_draw);
-    wave_replay_rows<4, true, true, 4, true>(fb, atlas, bullet, mb, lane, 0, kOwnRows, &box);  // (…, stamps: setup_kernel substitutes them)
+    wave_replay_rows<PG_BOSSFIGHT_GROUP, true, true, PG_BOSSFIGHT_LONE, true, true>(fb, atlas, bullet, mb, lane, 0, kOwnRows, &box);  // (…, stamps: setup_kernel substitutes them; tiny draws four to a slot)
     PG_TL(3);
-    wave_replay_rows<4, true, true, 4, true>(fb, atlas, draw, md, lane, 0, kOwnRows);
+    wave_replay_rows<PG_BOSSFIGHT_GROUP, true, true, PG_BOSSFIGHT_LONE, true, true>(fb, atlas, draw, md, lane, 0, kOwnRows);
     PG_TL(4);
     wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, row_lo, row_hi, 0);
     PG_TL_END(6, true, io.obs + size_t(env) * kObsBytes + half * (kObsBytes / 2));

@@ -512,6 +512,31 @@ PG_D void wave_blit(uint32_t* fb, const AtlasView& atlas, const Blit& b, int lan
     const int mod = blend_key(b.flip_mod);
     const bool fh = (b.flip_mod & kFlipH) != 0, fv = (b.flip_mod & kFlipV) != 0;
     const bool stamped = kStamps && (b.flip_mod & kStamped) != 0;
+    if (stamped && !fh && !fv) {
+        // A stamp comes with the list of its texels that show (pg_stamps.h append_stamps, stamp_list_at): lanes are dealt
+        // over the entries of the stamp's rows that lie on my rows — no lane on a transparent texel (bossfight's shield is
+        // a ring: 279 texels of 1 015), no sampling arithmetic, 8-byte loads side by side.  Same pixels: every texel that
+        // shows is blended into its pixel once, the others never touched anything.
+        const uint32_t* rows = atlas.texels + (static_cast<uint32_t>(b.sx) | static_cast<uint32_t>(b.sy) << 16);
+        const uint2* entries = reinterpret_cast<const uint2*>(rows + ((b.dh + 2) & ~1));
+        const int r0 = y0 - b.dy, r1 = y1 - b.dy;
+        const int begin = static_cast<int>(__builtin_amdgcn_readfirstlane(rows[r0])), end = static_cast<int>(__builtin_amdgcn_readfirstlane(rows[r1]));
+        for (int k0 = begin + half * 64; k0 < end; k0 += 64 * halves * kBatch) {
+            uint2 e[kBatch];
+#pragma unroll
+            for (int k = 0; k < kBatch; k++) {
+                const int at = k0 + 64 * halves * k + lane;
+                e[k] = make_uint2(0xffffffffu, 0u);
+                if (at < end) e[k] = entries[at];
+            }
+#pragma unroll
+            for (int k = 0; k < kBatch; k++) {
+                const int x = b.dx + static_cast<int>(e[k].x & 0xffu), y = b.dy + static_cast<int>((e[k].x >> 8) & 0xffu);
+                if (e[k].x != 0xffffffffu && x >= 0 && x < kObsW) blend_into<kStamps>(fb, y * kObsW + x, e[k].y, mod);
+            }
+        }
+        return;
+    }
     // The texel row of target row y0 + r is the same for every lane: lane r works it out once for all of them (the
     // target has 64 rows) and the loops below pick it up with a cross-lane read — one division per lane and draw for the
     // rows, one for the lane's column, instead of three per pixel (one pixel per lane in row-major order, the narrow
@@ -651,9 +676,19 @@ PG_D void wave_replay(uint32_t* fb, const AtlasView& atlas, const Blit& mine, un
 // destination rectangle or misses it.  Same arithmetic as wave_blit_rotated.
 template <bool kStamps = false>
 PG_D bool rotated_pixel(const Blit& b, const RotBox& box, int p, int& idx, int& texel_at) {
-    if (p >= box.bw * box.bh) return false;
-    const int ry = udiv_small(p, box.bw);
-    const int X = box.x_lo + (p - ry * box.bw), Y = box.y_lo + ry;
+    // A box of at most 8 × 8 pixels (every bullet and puff that gets here) is laid over the wave as an 8 × 8 grid — pixel
+    // (p & 7, p >> 3), no division; a longer one row by row.  (Wave-uniform where the box is: the group path.)
+    int rx, ry;
+    if (box.bw <= 8 && box.bh <= 8) {
+        rx = p & 7;
+        ry = p >> 3;
+        if (rx >= box.bw || ry >= box.bh) return false;
+    } else {
+        if (p >= box.bw * box.bh) return false;
+        ry = udiv_small(p, box.bw);
+        rx = p - ry * box.bw;
+    }
+    const int X = box.x_lo + rx, Y = box.y_lo + ry;
     const int px = 2 * (X - b.dx) + 1 - b.dw, py = 2 * (Y - b.dy) + 1 - b.dh;
     // Callers pass draws of at most kRotSmall pixels a side only: a pixel of the bounding box is within
     // (dw + dh) / 2 + 1 of the rectangle's centre, so |px|, |py| ≤ dw + dh + 2 < 2^10, the 16.16 sine and cosine are
@@ -687,21 +722,81 @@ PG_D RotBox rot_box_rows(const Blit& b, int row_lo, int row_hi) {  // rot_box cl
 template <int kGroup>
 struct ReplayState {
     unsigned long long mask, lones;  // draws still to do (those that reach my rows); which of them go alone
+    // kQuarters: which draws are tiny (at most 4 × 4 pixels of my rows), and which of those touch the first, second, third
+    // draw before them in the list (replay_group packs up to four tiny draws that follow and do not touch each other)
+    unsigned long long tiny, near1, near2, near3;
     BlitWords packed;                // this lane's draw, packed for the cross-lane reads
-    uint32_t box[2];                 // kRotInGroups: a rotated draw's box on my rows (x_lo | y_lo << 16, bw | bh << 16)
+    uint32_t box[2];                 // kRotInGroups / kQuarters: the draw's box on my rows (x_lo | y_lo << 16, bw | bh << 16)
     uint32_t texel[kGroup];
     int idx[kGroup], mod[kGroup];
 };
 
-template <int kGroup, bool kRotInGroups, bool kPacked, int kLone = 4, bool kStamps = false>
+// Up to four tiny draws in one slot of a group (kQuarters): sixteen lanes each — quarter q of the wave takes draw
+// `src[q]`, lane l of it the pixel (l & 3, (l >> 2) & 3) of the draw's box on my rows (at most 4 × 4) —, the draws' words
+// fetched per lane across lanes instead of broadcast through scalar registers.  The per-draw work of a slot (unpacking,
+// the pixel's place in the texture, one gather, one blend) is then done once for four draws: a render kernel's time is its
+// instruction count, and a bullet or a spark is a dozen pixels that had a 64-lane slot to themselves.  The caller has made
+// sure the draws follow each other in the list and do not touch (replay_classify): one LDS write per pixel, any order.
+template <bool kRotInGroups, bool kStamps>
+PG_D void quarters_request(const AtlasView& atlas, const Blit& mine, const BlitWords& packed, const uint32_t (&box)[2], int lane,
+                           const int (&src)[4], int count, uint32_t& texel, int& idx, int& mod) {
+    const int q = lane >> 4;
+    const int from = (q == 0 ? src[0] : (q == 1 ? src[1] : (q == 2 ? src[2] : src[3]))) & 63;
+    const uint32_t w0 = static_cast<uint32_t>(__shfl(static_cast<int>(packed.w[0]), from));
+    const uint32_t w1 = static_cast<uint32_t>(__shfl(static_cast<int>(packed.w[1]), from));
+    const uint32_t w2 = static_cast<uint32_t>(__shfl(static_cast<int>(packed.w[2]), from));
+    const uint32_t w3 = static_cast<uint32_t>(__shfl(static_cast<int>(packed.w[3]), from));
+    const uint32_t w4 = static_cast<uint32_t>(__shfl(static_cast<int>(packed.w[4]), from));
+    const uint32_t w5 = static_cast<uint32_t>(__shfl(static_cast<int>(packed.w[5]), from));
+    const uint32_t b0 = static_cast<uint32_t>(__shfl(static_cast<int>(box[0]), from));
+    const uint32_t b1 = static_cast<uint32_t>(__shfl(static_cast<int>(box[1]), from));
+    const int dx = static_cast<int32_t>(w0 << 16) >> 16, dy = static_cast<int32_t>(w0) >> 16;
+    const int dw = static_cast<int>(w1 & 0xffffu), dh = static_cast<int>(w1 >> 16);
+    const int tex_off = static_cast<int>(w4), tex_w = static_cast<int>(w5 & 0xffffu), flip_mod = static_cast<int>(w5 >> 16);
+    const int rx = lane & 3, ry = (lane >> 2) & 3;
+    const int X = static_cast<int>(b0 & 0xffffu) + rx, Y = static_cast<int>(b0 >> 16) + ry;
+    bool in = q < count && rx < static_cast<int>(b1 & 0xffffu) && ry < static_cast<int>(b1 >> 16);
+    const bool stamped = kStamps && (flip_mod & kStamped) != 0;
+    int i = X - dx, j = Y - dy;
+    int sn = 0, cs = 65536;
+    if (kRotInGroups && __ballot((flip_mod & kRotated) != 0) != 0ull) {  // (wave-uniform: a cross-lane read wants every lane there)
+        sn = __shfl(mine.rot_sn, from);
+        cs = __shfl(mine.rot_cs, from);
+    }
+    if (kRotInGroups && (flip_mod & kRotated)) {  // (per lane: the draws of a slot may differ in kind)
+        const int px = 2 * i + 1 - dw, py = 2 * j + 1 - dh;  // rotated_pixel's arithmetic (tiny draws are far below kRotSmall)
+        const int lx = __mul24(px, cs) + __mul24(py, sn) + (dw << 16);
+        const int ly = __mul24(py, cs) - __mul24(px, sn) + (dh << 16);
+        in = in && !(lx < 0 || ly < 0 || lx >= (dw << 17) || ly >= (dh << 17));
+        i = lx >> 17;
+        j = ly >> 17;
+    } else {
+        if (flip_mod & kFlipH) i = dw - 1 - i;
+        if (flip_mod & kFlipV) j = dh - 1 - j;
+    }
+    int u = i, v = j;
+    if (!stamped && in) {
+        u = sample_index(static_cast<int>(w2 & 0xffffu), static_cast<int>(w3 & 0xffffu), i, dw);
+        v = sample_index(static_cast<int>(w2 >> 16), static_cast<int>(w3 >> 16), j, dh);
+    }
+    mod = blend_key(flip_mod);
+    idx = in ? Y * kObsW + X : -1;
+    texel = 0u;
+    if (in) texel = atlas.texels[tex_off + v * tex_w + u];
+}
+
+template <int kGroup, bool kRotInGroups, bool kPacked, int kLone = 4, bool kStamps = false, bool kQuarters = false>
 PG_D void replay_group(const AtlasView& atlas, const Blit& mine, ReplayState<kGroup>& st, int lane, int row_lo, int row_hi,
                        uint32_t* fb_for_lone) {
-    // requests the texels of the next ≤ kGroup small draws; the big draws at the head of the list are executed on the spot
-    // first (fb_for_lone; nullptr = stop in front of them instead).  They have a loop of their own, in front of the
-    // unrolled one: wave_blit and wave_blit_rotated are most of this function's code, and inside the group loop that
-    // code counted four times against the unroller's budget — over it, the loop stays rolled and ReplayState's arrays
-    // land in scratch memory (bossfight's render kernel, round 6: 0.49 -> 0.72 ms).
-    while (fb_for_lone != nullptr && st.mask != 0) {  // (wave-uniform)
+    // requests the texels of the next ≤ kGroup small draws; a big draw at the head of the list is executed on the spot
+    // (fb_for_lone; nullptr = stop in front of it instead).
+    // kStamps kernels (bossfight) take the big draws in a loop of their own, in front of the unrolled one: wave_blit and
+    // wave_blit_rotated are most of this function's code, and with the stamped forms on top that code, counted four times
+    // against the unroller's budget inside the group loop, went over it — the loop stayed rolled and ReplayState's arrays
+    // landed in scratch memory (bossfight's render kernel: 0.49 -> 0.72 ms).  The other kernels keep the round-5 form
+    // (the big draw as iteration 0 of the group loop): jumper measured 0.7 % faster with it.
+    constexpr bool kLonesFirst = kStamps;
+    while (kLonesFirst && fb_for_lone != nullptr && st.mask != 0) {  // (wave-uniform)
         const int src = __builtin_ctzll(st.mask);
         if (!((st.lones >> src) & 1ull)) break;
         st.mask &= st.mask - 1;
@@ -723,7 +818,40 @@ PG_D void replay_group(const AtlasView& atlas, const Blit& mine, ReplayState<kGr
         if (st.mask == 0 || stop) continue;
         const int src = __builtin_ctzll(st.mask);
         if ((st.lones >> src) & 1ull) {
-            stop = true;  // a big one: alone, in front of the next group
+            stop = true;  // a big one: alone, only at the head of a group
+            if (!kLonesFirst && g == 0 && fb_for_lone != nullptr) {
+                st.mask &= st.mask - 1;
+                const Blit b = kPacked ? blit_from_lane(st.packed, mine, src) : blit_from_lane(mine, src);
+                wave_order();
+                if (b.flip_mod & kRotated) {
+                    wave_blit_rotated<kLone, kStamps>(fb_for_lone, atlas, b, rot_box_rows(b, row_lo, row_hi), lane, 64);
+                } else {
+                    wave_blit<kLone, kStamps>(fb_for_lone, atlas, b, lane, 0, 1, row_lo, row_hi);
+                }
+                wave_order();
+            }
+            continue;
+        }
+        if (kQuarters && ((st.tiny >> src) & 1ull)) {
+            // this tiny draw and up to three that follow it in the list, tiny too and touching none of the ones taken
+            static_assert(!kQuarters || kPacked, "the quarters fetch the packed words");
+            int from[4] = {src, 64, 64, 64};
+            int count = 1;
+            unsigned long long rest = st.mask & (st.mask - 1);
+#pragma unroll
+            for (int k = 1; k < 4; k++) {
+                if (count != k || rest == 0ull) continue;  // (wave-uniform)
+                const int next = __builtin_ctzll(rest);
+                const unsigned long long bit = 1ull << next;
+                const bool apart = !(st.near1 & bit) && (k < 2 || !(st.near2 & bit)) && (k < 3 || !(st.near3 & bit));
+                if ((st.tiny & bit) && apart) {
+                    from[k] = next;
+                    count = k + 1;
+                    rest &= rest - 1;
+                }
+            }
+            st.mask = rest;
+            quarters_request<kRotInGroups, kStamps>(atlas, mine, st.packed, st.box, lane, from, count, st.texel[g], st.idx[g], st.mod[g]);
             continue;
         }
         st.mask &= st.mask - 1;
@@ -744,9 +872,16 @@ PG_D void replay_group(const AtlasView& atlas, const Blit& mine, ReplayState<kGr
         const int x1 = (b.dx + b.dw) < kObsW ? (b.dx + b.dw) : kObsW;
         const int y1 = (b.dy + b.dh) < row_hi ? (b.dy + b.dh) : row_hi;
         const int cw = x1 - x0, ch = y1 - y0;
-        if (lane >= cw * ch) continue;
-        const int ry = udiv_small(lane, cw);
-        const int rx = lane - ry * cw;
+        int rx, ry;
+        if (cw <= 8 && ch <= 8) {  // (wave-uniform) the wave as an 8 × 8 grid: no division
+            rx = lane & 7;
+            ry = lane >> 3;
+            if (rx >= cw || ry >= ch) continue;
+        } else {
+            if (lane >= cw * ch) continue;
+            ry = udiv_small(lane, cw);
+            rx = lane - ry * cw;
+        }
         const int x = x0 + rx, y = y0 + ry;
         int i = x - b.dx, j = y - b.dy;
         if (b.flip_mod & kFlipH) i = b.dw - 1 - i;
@@ -768,11 +903,11 @@ PG_D RotBox rot_box_clip(RotBox box, int row_lo, int row_hi) {
     box.bh = hi - lo;
     return box;
 }
-template <int kGroup, bool kRotInGroups, bool kPacked>
+template <int kGroup, bool kRotInGroups, bool kPacked, bool kQuarters = false>
 PG_D ReplayState<kGroup> replay_classify(const Blit& mine, unsigned long long mask, int lane, int row_lo, int row_hi,
                                          const RotBox* whole = nullptr) {
-    bool lone = false, reaches = false;
-    uint32_t box0 = 0, box1 = 0;
+    bool lone = false, reaches = false, tiny = false;
+    uint32_t box0 = 0, box1 = 0, edges = 0;
     if ((mask >> lane) & 1ull) {
         if (mine.flip_mod & kRotated) {
             const RotBox box = whole ? rot_box_clip(*whole, row_lo, row_hi) : rot_box_rows(mine, row_lo, row_hi);
@@ -781,28 +916,61 @@ PG_D ReplayState<kGroup> replay_classify(const Blit& mine, unsigned long long ma
             // (the box of a draw that goes into a group travels with it: no second pass through rot_box's 64-bit products)
             box0 = static_cast<uint32_t>(box.x_lo) | (static_cast<uint32_t>(box.y_lo) << 16);
             box1 = static_cast<uint32_t>(box.bw & 0xffff) | (static_cast<uint32_t>(box.bh) << 16);
+            tiny = kQuarters && reaches && !lone && box.bw <= 4 && box.bh <= 4;
+            edges = static_cast<uint32_t>(box.x_lo) | static_cast<uint32_t>(box.y_lo - row_lo) << 8 |
+                    static_cast<uint32_t>(box.x_lo + box.bw - 1) << 16 | static_cast<uint32_t>(box.y_lo - row_lo + box.bh - 1) << 24;
         } else {
             const int x0 = mine.dx > 0 ? mine.dx : 0, y0 = mine.dy > row_lo ? mine.dy : row_lo;
             const int x1 = (mine.dx + mine.dw) < kObsW ? (mine.dx + mine.dw) : kObsW;
             const int y1 = (mine.dy + mine.dh) < row_hi ? (mine.dy + mine.dh) : row_hi;
             reaches = x1 > x0 && y1 > y0;
             lone = reaches && (x1 - x0) * (y1 - y0) > 64;
+            if (kQuarters) {
+                tiny = reaches && x1 - x0 <= 4 && y1 - y0 <= 4;
+                box0 = static_cast<uint32_t>(x0) | (static_cast<uint32_t>(y0) << 16);
+                box1 = static_cast<uint32_t>(x1 - x0) | (static_cast<uint32_t>(y1 - y0) << 16);
+                edges = static_cast<uint32_t>(x0) | static_cast<uint32_t>(y0 - row_lo) << 8 | static_cast<uint32_t>(x1 - 1) << 16 |
+                        static_cast<uint32_t>(y1 - 1 - row_lo) << 24;
+            }
         }
     }
     ReplayState<kGroup> st;
     st.mask = __ballot(reaches);
     st.lones = __ballot(lone && reaches);
+    st.tiny = st.near1 = st.near2 = st.near3 = 0ull;
+    if (kQuarters) {
+        // A tiny draw's box as four bytes (x_lo, y_lo, x_hi, y_hi — rows counted from row_lo, all below 64), held against
+        // those of the three draws before it in the list: a = hi | 0x8080, b = lo of the other — every byte of a − b has
+        // bit 7 set exactly when hi ≥ lo (no borrow between the bytes: 0x80 + hi − lo ≥ 0x41), and two boxes touch when
+        // that holds both ways on both axes.
+        st.tiny = __ballot(tiny);
+        unsigned long long before = st.mask & ((1ull << lane) - 1ull);
+        const uint32_t my_hi = (edges >> 16) | 0x8080u, my_lo = edges & 0xffffu;
+        bool near[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const bool there = before != 0ull;
+            const int prev = there ? 63 - __builtin_clzll(before) : 0;
+            before &= ~(1ull << prev);
+            const uint32_t other = static_cast<uint32_t>(__shfl(static_cast<int>(edges), prev));
+            const uint32_t its_hi = (other >> 16) | 0x8080u, its_lo = other & 0xffffu;
+            near[k] = tiny && there && (((my_hi - its_lo) & (its_hi - my_lo) & 0x8080u) == 0x8080u);
+        }
+        st.near1 = __ballot(near[0]);
+        st.near2 = __ballot(near[1]);
+        st.near3 = __ballot(near[2]);
+    }
     if (kPacked) st.packed = blit_pack(mine);
     st.box[0] = box0;
     st.box[1] = box1;
     return st;
 }
 
-template <int kGroup = 4, bool kRotInGroups = false, bool kPacked = true, bool kStamps = false>
+template <int kGroup = 4, bool kRotInGroups = false, bool kPacked = true, bool kStamps = false, bool kQuarters = false>
 PG_D ReplayState<kGroup> replay_begin(const AtlasView& atlas, const Blit& mine, unsigned long long mask, int lane,
                                       int row_lo, int row_hi, const RotBox* whole = nullptr) {
-    ReplayState<kGroup> st = replay_classify<kGroup, kRotInGroups, kPacked>(mine, mask, lane, row_lo, row_hi, whole);
-    replay_group<kGroup, kRotInGroups, kPacked, 4, kStamps>(atlas, mine, st, lane, row_lo, row_hi, nullptr);  // (a big draw first: nothing requested)
+    ReplayState<kGroup> st = replay_classify<kGroup, kRotInGroups, kPacked, kQuarters>(mine, mask, lane, row_lo, row_hi, whole);
+    replay_group<kGroup, kRotInGroups, kPacked, 4, kStamps, kQuarters>(atlas, mine, st, lane, row_lo, row_hi, nullptr);  // (a big draw first: nothing requested)
     return st;
 }
 
@@ -811,7 +979,7 @@ PG_D ReplayState<kGroup> replay_begin(const AtlasView& atlas, const Blit& mine, 
 // jumper's 0.843 -> 0.853.  These kernels are bound by vector instructions at four clocks apiece (SQ_ACTIVE_INST_VALU:
 // 4.6 clocks per SQ_INSTS_VALU), not by the length of the pass's chain of round trips; the copies that free the state for
 // the next request are more instructions.)
-template <int kGroup = 4, bool kRotInGroups = false, bool kPacked = true, int kLone = 4, bool kStamps = false>
+template <int kGroup = 4, bool kRotInGroups = false, bool kPacked = true, int kLone = 4, bool kStamps = false, bool kQuarters = false>
 PG_D void replay_finish(uint32_t* fb, const AtlasView& atlas, const Blit& mine, ReplayState<kGroup>& st, int lane,
                         int row_lo, int row_hi) {
     wave_order();  // what the caller put into these rows in the meantime
@@ -822,18 +990,18 @@ PG_D void replay_finish(uint32_t* fb, const AtlasView& atlas, const Blit& mine, 
             wave_order();  // draws may overlap
         }
         if (st.mask == 0) break;
-        replay_group<kGroup, kRotInGroups, kPacked, kLone, kStamps>(atlas, mine, st, lane, row_lo, row_hi, fb);
+        replay_group<kGroup, kRotInGroups, kPacked, kLone, kStamps, kQuarters>(atlas, mine, st, lane, row_lo, row_hi, fb);
     }
 }
 
 // kRotInGroups: small rotated draws (a bullet, a puff: ≤ 64 pixels of bounding box on my rows) share a memory round
 // trip with their neighbours in the list like the plain small ones, instead of paying one each (bossfight: dozens of
 // bullets a frame).  Costs registers and code in the group loop, so only kernels with room to spare turn it on.
-template <int kGroup = 4, bool kRotInGroups = false, bool kPacked = true, int kLone = 4, bool kStamps = false>
+template <int kGroup = 4, bool kRotInGroups = false, bool kPacked = true, int kLone = 4, bool kStamps = false, bool kQuarters = false>
 PG_D void wave_replay_rows(uint32_t* fb, const AtlasView& atlas, const Blit& mine, unsigned long long mask, int lane,
                            int row_lo, int row_hi, const RotBox* whole = nullptr) {
-    ReplayState<kGroup> st = replay_begin<kGroup, kRotInGroups, kPacked, kStamps>(atlas, mine, mask, lane, row_lo, row_hi, whole);
-    replay_finish<kGroup, kRotInGroups, kPacked, kLone, kStamps>(fb, atlas, mine, st, lane, row_lo, row_hi);
+    ReplayState<kGroup> st = replay_begin<kGroup, kRotInGroups, kPacked, kStamps, kQuarters>(atlas, mine, mask, lane, row_lo, row_hi, whole);
+    replay_finish<kGroup, kRotInGroups, kPacked, kLone, kStamps, kQuarters>(fb, atlas, mine, st, lane, row_lo, row_hi);
 }
 
 // A draw that is the same in every frame of every env (a HUD element at a fixed place on the observation), prepared

@@ -212,7 +212,8 @@ __global__ void __launch_bounds__(128) k_replay(pg::AtlasView atlas, const uint3
     mine.flip_mod = 255;
     mine.rot_sn = 0;
     mine.rot_cs = 65536;
-    const bool has = lane < n_draws;
+    bool has = lane < n_draws;
+    pg::RotBox whole{0, 0, 0, 0};
     if (has) {
         const int32_t* d = draws + 12 * lane;
         const int4 t = atlas.desc[d[0]];
@@ -231,10 +232,19 @@ __global__ void __launch_bounds__(128) k_replay(pg::AtlasView atlas, const uint3
             pg::rotation_16_16(deg[lane], mine.rot_sn, mine.rot_cs);
             mine.flip_mod = d[10] | pg::kRotated;
         }
-        // stamps != 0: the pre-pass's substitution (pg_stamps.h) where a stamp of this draw's size and modulation exists
-        if (stamps) pg::stamp_substitute(reinterpret_cast<const uint4*>(atlas.texels + stamps) + d[0] * pg::kStampsPerTex, t.y, t.z, mine);
+        // stamps != 0: the pre-pass's substitution (pg_stamps.h) where a stamp of this draw's size and modulation exists —
+        // the draw cut down to the stamp's core, or (rotated) its box to the core's
+        if (stamps) {
+            int core_w, core_h;
+            has = pg::stamp_substitute(reinterpret_cast<const uint4*>(atlas.texels + stamps) + d[0] * pg::kStampsPerTex, t.y, t.z, mine,
+                                       core_w, core_h);
+            if (mine.flip_mod & pg::kRotated) whole = pg::rot_box_core(mine, core_w, core_h);
+        } else if (mine.flip_mod & pg::kRotated) {
+            whole = pg::rot_box(mine);
+        }
     }
-    pg::wave_replay_rows<4, kRotInGroups, true, 4, true>(fb, atlas, mine, __ballot(has), lane, 32 * half, 32 * half + 32);  // (stamps allowed)
+    // (stamps allowed; tiny draws four to a slot)
+    pg::wave_replay_rows<4, kRotInGroups, true, 4, true, true>(fb, atlas, mine, __ballot(has), lane, 32 * half, 32 * half + 32, &whole);
     pg::wave_store_rows(fb, out_rgb, lane, 32 * half, 32 * half + 32);
 }
 
