@@ -1262,6 +1262,9 @@ constexpr int kRenderParts = 2;
 #ifndef PG_BOSSFIGHT_LONE
 #define PG_BOSSFIGHT_LONE 4
 #endif
+#ifndef PG_BOSSFIGHT_QUARTERS
+#define PG_BOSSFIGHT_QUARTERS false  // (tiny draws four to a slot, pg_render.h: measured, 2 % slower here — a half frame holds five or six bullets)
+#endif
 __global__ void __launch_bounds__(64, 5) render_kernel(State s, AtlasView atlas, const uint8_t* mask, StepIO io) {
     constexpr int halves = kRenderParts;
     const int env = blockIdx.x / halves;
@@ -1297,9 +1300,9 @@ __global__ void __launch_bounds__(64, 5) render_kernel(State s, AtlasView atlas,
     compose_background_from<kOwnRows, true>(fb, atlas, bg_col, bg_row, lane, half);
     PG_TL(2);
     const unsigned long long mb = __ballot(has_bullet), md = __ballot(has_draw);
-    wave_replay_rows<PG_BOSSFIGHT_GROUP, true, true, PG_BOSSFIGHT_LONE, true, true>(fb, atlas, bullet, mb, lane, 0, kOwnRows, &box);  // (…, stamps: setup_kernel substitutes them; tiny draws four to a slot)
+    wave_replay_rows<PG_BOSSFIGHT_GROUP, true, true, PG_BOSSFIGHT_LONE, true, PG_BOSSFIGHT_QUARTERS>(fb, atlas, bullet, mb, lane, 0, kOwnRows, &box);  // (…, stamps: setup_kernel substitutes them; tiny draws four to a slot)
     PG_TL(3);
-    wave_replay_rows<PG_BOSSFIGHT_GROUP, true, true, PG_BOSSFIGHT_LONE, true, true>(fb, atlas, draw, md, lane, 0, kOwnRows);
+    wave_replay_rows<PG_BOSSFIGHT_GROUP, true, true, PG_BOSSFIGHT_LONE, true, PG_BOSSFIGHT_QUARTERS>(fb, atlas, draw, md, lane, 0, kOwnRows);
     PG_TL(4);
     wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, row_lo, row_hi, 0);
     PG_TL_END(6, true, io.obs + size_t(env) * kObsBytes + half * (kObsBytes / 2));

@@ -1230,7 +1230,10 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
     // The small rotated draws — exhaust particles, bullets — share their memory round trips in groups of four like the plain
     // ones (pg_render.h kRotInGroups) instead of going alone, a round trip each: 107.8 -> 118.9 M env-steps/s same-box.  (Groups of
     // two: the same; of six or eight: the kernel spills, 85.6 and 78.4 M.)  The ship, more than 64 pixels, still goes alone.
-    wave_replay_rows<4, true>(fb, atlas, mine, __ballot(has), lane, row_lo, row_hi);
+#ifndef PG_CAVEFLYER_QUARTERS
+#define PG_CAVEFLYER_QUARTERS false
+#endif
+    wave_replay_rows<4, true, true, 4, false, PG_CAVEFLYER_QUARTERS>(fb, atlas, mine, __ballot(has), lane, row_lo, row_hi);
     wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, row_lo, row_hi);
 }
 

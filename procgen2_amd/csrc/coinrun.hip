@@ -1024,6 +1024,10 @@ __global__ void __launch_bounds__(64) resolve_kernel(State s, StepIO io, uint32_
 // flags bit 0: force the draw-list replay for background + tiles (fallback path; parity tests run both).
 // Higher bits are timing experiments (tools/ablate_render.py), compiled in only with -DPG_ABLATE (pg_render.h PG_ABL).
 constexpr int kRenderWaves = 2;  // wavefronts per env (pg_render.h: two waves share one frame's LDS target)
+#ifndef PG_COINRUN_QUARTERS
+#define PG_COINRUN_QUARTERS false
+#endif
+constexpr bool kQuarters = PG_COINRUN_QUARTERS;  // the lean kernel's tiny draws (sparks) four to a slot (pg_render.h)
 
 #ifndef PG_COINRUN_RENDER_WAVES
 // Wavefronts per SIMD the registers are capped for.  Five = 96 registers = nine envs a CU, which the LDS allows since the
@@ -1637,11 +1641,11 @@ __global__ void __launch_bounds__(64 * kRenderWaves, PG_COINRUN_RENDER_WAVES) re
     }
     const int row_lo = half * (kObsH / halves), row_hi = (half + 1) * (kObsH / halves);
     // (the PG_ABL tests are timing experiments of the -DPG_ABLATE build: constants 0 in the product)
-    ReplayState<4> sprite_pass = replay_begin(atlas, mine, PG_ABL(flags, 2) ? 0ull : __ballot(has), lane, row_lo, row_hi);
+    ReplayState<4> sprite_pass = replay_begin<4, false, true, false, kQuarters>(atlas, mine, PG_ABL(flags, 2) ? 0ull : __ballot(has), lane, row_lo, row_hi);
     PG_TL(2);
     if (!PG_ABL(flags, 4)) compose_rows_from<kGrid, false, false>(fb, L, atlas, R, lane, flags, half, halves);
     PG_TL(3);
-    replay_finish(fb, atlas, mine, sprite_pass, lane, row_lo, row_hi);
+    replay_finish<4, false, true, 4, false, kQuarters>(fb, atlas, mine, sprite_pass, lane, row_lo, row_hi);
     PG_TL(4);
     if (!PG_ABL(flags, 8)) wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, row_lo, row_hi);
     PG_TL_END(6, true, io.obs + size_t(env) * kObsBytes + half * (kObsBytes / 2));
