@@ -230,7 +230,7 @@ PG_D void new_level(const State& s, int env, R& rng, bool lead) {
 // One env = one gang (pg_gang.h).  Everything in Live is uniform over the gang; `q.g` only decides which ring slots a
 // lane owns (slot mod width) — it writes the bullets fired into them and is the one that moves them.
 #ifndef PG_BOSSFIGHT_GANG
-#define PG_BOSSFIGHT_GANG 16
+#define PG_BOSSFIGHT_GANG 8  // (16 until the random streams changed buffers instead of regenerating, round 6: 8 then 126.5 -> 130.8 M; 4: 124.6; 32: 118.3)
 #endif
 #ifndef PG_BOSSFIGHT_WAVES
 #define PG_BOSSFIGHT_WAVES 3  // wavefronts per SIMD the logic kernel's registers are capped for

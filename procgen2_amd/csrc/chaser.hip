@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(64) due_level_kernel(State s, StepIO io, Level
 // over the gang; the orbs and points (up to 198 of them), each tested against the agent every sub-step, are dealt out
 // over the lanes: entity e belongs to lane e mod kGang.  The env's tiles and entity table are staged in LDS once a step.
 #ifndef PG_CHASER_GANG
-#define PG_CHASER_GANG 8
+#define PG_CHASER_GANG (kMobs <= 4 && W <= 11 ? 4 : 8)  // (the larger worlds' sixteen gangs a wavefront would not fit four wavefronts a SIMD in the LDS)  // (8 until round 6; with the streams changing buffers 4 lanes an env: 101.7 -> 104.8 M; 16: 95.2; an enemy needs a lane)
 #endif
 #ifndef PG_CHASER_WAVES
 #define PG_CHASER_WAVES 4  // wavefronts per SIMD the logic kernel's registers are capped for
