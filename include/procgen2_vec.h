@@ -196,8 +196,9 @@ PGV_API int32_t pgv_step_phases_many(pgv_env* const* envs, int32_t count, int32_
  * level inside the step.  Bit 21: no render pre-pass — every frame's workgroup does its own set-up, as the frames the
  * pre-pass hands back do anyway.  Bit 23: the pre-pass hands back every third env's frame (the way for tests to the
  * hand-back path of games that never take it in a normal run).  Bit 24: coinrun works every hazard's boxes out behind
- * the agent instead of the few its entity lanes pre-selected (the fallback a normal run never takes).  Any other bit
- * is refused. */
+ * the agent instead of the few its entity lanes pre-selected (the fallback a normal run never takes).  Bit 25: chaser's
+ * enemies take their turns one after the other on the env's random stream itself instead of side by side on outputs
+ * peeked from it (what the last few words of a 624-word block take in a normal run).  Any other bit is refused. */
 PGV_API int32_t pgv_set_debug(pgv_env* env, int32_t flags);
 
 /* Parity taps (host pointers): game-defined state vector / tile ids of one env; return the full

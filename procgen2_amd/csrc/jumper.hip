@@ -1417,8 +1417,13 @@ class JumperGame final : public Game {
         const float game_zoom = 0.3f, width = 64.0f, compass_size = 200.0f, offset_x = -32.0f, offset_y = 32.0f;
         const float fx = width - compass_size * game_zoom + offset_x * game_zoom, fy = offset_y * game_zoom;
         const float fw = compass_size * game_zoom, fh = compass_size * game_zoom;
-        if (!(fw >= 1.0f && fh >= 1.0f && fw < 32768.0f && fh < 32768.0f)) return;  // resolve_screen's S1
-        if (!(fx > -32768.0f && fx < 32768.0f && fy > -32768.0f && fy < 32768.0f)) return;
+        // Whenever the ring cannot be prepared the frames stay right — the kernels draw it as the 60 × 60 blit it is — but a
+        // quarter slower, and the draws it hides are no longer dropped: say so once instead of falling back in silence.
+        auto unprepared = [](const char* why) {
+            std::fprintf(stderr, "procgen2_amd: jumper: compass ring not prepared (%s): drawn as a plain blit, ≈ 25 %% slower\n", why);
+        };
+        if (!(fw >= 1.0f && fh >= 1.0f && fw < 32768.0f && fh < 32768.0f)) return unprepared("degenerate size");  // resolve_screen's S1
+        if (!(fx > -32768.0f && fx < 32768.0f && fy > -32768.0f && fy < 32768.0f)) return unprepared("degenerate place");
         const int dx = static_cast<int>(fx), dy = static_cast<int>(fy), dw = static_cast<int>(fw), dh = static_cast<int>(fh);
         std::vector<uint32_t> image(size_t(kObsW) * kObsH, 0u), list;
         const size_t half_words = size_t(kOverlayPerLane) * 64 * 2;  // (pg_render.h overlay_rows: a half's share of the list)
@@ -1436,7 +1441,8 @@ class JumperGame final : public Game {
                         list.push_back(t);
                     }
                 }
-            if (list.size() > (half + 1) * half_words) return;  // more translucent texels than the overlay's lanes take: the blit stays
+            if (list.size() > (half + 1) * half_words)  // more translucent texels than the overlay's lanes take: the blit stays
+                return unprepared("more translucent texels in a half frame than pg_render.h kOverlayPerLane allows");
             while (list.size() < (half + 1) * half_words) {
                 list.push_back(0xffffffffu);
                 list.push_back(0u);

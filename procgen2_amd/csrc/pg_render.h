@@ -1014,7 +1014,8 @@ PG_D void wave_replay_rows(uint32_t* fb, const AtlasView& atlas, const Blit& min
 // Same pixels as wave_replay_rows of the draw (raster spec S1–S4).  row_lo: 0 or 32.
 constexpr int kOverlayPerLane = 2;
 PG_D void overlay_rows(uint32_t* fb, const uint32_t* image, const uint2* list, int lane, int row_lo) {
-    constexpr int kRows = kObsH / 2;
+    constexpr int kRows = kObsH / 2;  // (the contract with the callers and with whoever made the list: a wave owns HALF the frame's rows)
+    static_assert(kObsH == 64 && kRows == 32, "overlay_rows: the list is split per half frame of 32 rows");
     uint32_t t[kRows];
     uint2 item[kOverlayPerLane];
 #pragma unroll
