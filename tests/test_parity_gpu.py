@@ -79,6 +79,30 @@ def test_chaser_enemies_the_long_way(game_flags):
     assert resets > 0
 
 
+@pytest.mark.parametrize("game", ["bossfight", "chaser"])
+def test_plain_masked_reset_after_the_streams_changed_buffers(game):
+    """bossfight's and chaser's random streams live in two buffers (pg_gang.h GangRng: a gang that runs out of numbers
+    changes buffers, the next block having been made ahead of time).  A reset WITHOUT a seed continues the env's stream:
+    whoever generates the level must read it from where the gang left it (chaser generate, bossfight begin_level).  Sixty
+    steps in, most streams have changed buffers at least once; a third of the envs — some of them due for an auto-reset —
+    are then reset by hand, without seeds, and the batch goes on: frames, rewards and dones as the oracle's throughout."""
+    n = 192
+    eng, ora = EngineVec(game, n, seed_base=21), OracleVec(game, n, seed_base=21)
+    L = ora.L
+    assert np.array_equal(eng.reset(), ora.reset_obs())
+    for s in range(160):
+        a = _actions(L, 9, s, n)
+        oe, re_, de = eng.step(a)
+        oo, ro, do = ora.step(a)
+        assert np.array_equal(de, do) and np.array_equal(re_.view(np.uint32), ro.view(np.uint32)), "step %d" % s
+        assert np.array_equal(oe, oo), "obs, step %d" % s
+        if s in (60, 61, 110):
+            mask = ((np.arange(n) + s) % 3 == 0).astype(np.uint8)
+            assert np.array_equal(eng.reset(mask=mask), ora.reset(mask=mask)), "masked reset at step %d" % s
+    eng.close()
+    ora.close()
+
+
 @pytest.mark.parametrize("game", ["coinrun", "maze", "bossfight", "climber", "caveflyer", "chaser", "jumper"])
 def test_row_composer_equals_draw_list_replay(game):
     """The fused background+tile row composer (pg_render.h compose_rows) against the one-blit-at-a-time replay of
