@@ -92,6 +92,7 @@ struct State {
     float* rock;    // [3][4][n]  x, y, texture index
     struct Prep {   // the render pre-pass's hand-over (setup_kernel → render_kernel; scratch memory, not state)
         uint32_t* backdrops;  // [13][128]  per backdrop: bg_offset of pixel columns 0-63, of pixel rows 0-63 (backdrop_kernel, once)
+        uint32_t* backdrop_px;  // [13][64 × 64]  … and the backdrop as it lands on the frame, composed once (backdrop_kernel): the camera never moves
         uint32_t* meta;       // [n]        boss bullets | other draws << 8 | backdrop << 16
         uint32_t* bullets;    // [n][64][kBulletWords]  visible boss bullets in drawing order
         uint32_t* draws;      // [n][64][kBlitWords]    the visible draws of the second list in drawing order
@@ -1024,12 +1025,24 @@ __global__ void __launch_bounds__(64) streams_home_kernel(State s) {
 }
 
 // bg_axis + bg_offset of compose_background for each of the 13 backdrops (bossfight.cpp:416-419).
+// … and, from those, the backdrop's 64 × 64 pixels as the frame target holds them (pg_render.h compose_background_from, the
+// words it leaves in LDS): thirteen pictures of 16 KB for every env of the batch, which a frame then starts from as a
+// straight copy (render_kernel) instead of 32 gathers and their offsets — the camera of this game never moves.
 __global__ void __launch_bounds__(128) backdrop_kernel(State s, AtlasView atlas) {
     const int backdrop = blockIdx.x, lane = threadIdx.x & 63, axis = threadIdx.x >> 6;
     const Camera cam{0.0f, 0.0f, kCamSize, kCamSize, kCamScale};
     const int4 d = atlas.desc[kTexSpace + backdrop];
     const float pos = -kCamSize / kCamScale * 0.5f, scale = 1.0f / d.z * kCamSize / kCamScale;
-    s.prep.backdrops[backdrop * 128 + axis * 64 + lane] = bg_offset(bg_axis(cam, d, pos, pos, scale, axis), lane, axis);
+    const uint32_t mine = bg_offset(bg_axis(cam, d, pos, pos, scale, axis), lane, axis);
+    s.prep.backdrops[backdrop * 128 + axis * 64 + lane] = mine;
+    __shared__ uint32_t offsets[128];
+    __shared__ alignas(16) uint32_t fb[kFbWords];
+    offsets[axis * 64 + lane] = mine;
+    __syncthreads();
+    const int half = axis;  // (wave h composes rows [32h, 32h + 32) of the picture)
+    compose_background_from<kObsH / 2, false>(fb, atlas, offsets[lane], offsets[64 + lane], lane, half);
+    __syncthreads();
+    for (int k = threadIdx.x; k < kFbWords; k += 128) s.prep.backdrop_px[size_t(backdrop) * kFbWords + k] = fb[k];
 }
 
 constexpr int kPrepEnvs = 8, kPrepThreads = 256;
@@ -1276,8 +1289,6 @@ __global__ void __launch_bounds__(64, 5) render_kernel(State s, AtlasView atlas,
     const uint32_t meta = __builtin_amdgcn_readfirstlane(s.prep.meta[env]);
     const int n_bullets = meta & 0xffu, n_draws = (meta >> 8) & 0xffu, backdrop = meta >> 16;
     const int row_lo = half * (kObsH / halves), row_hi = (half + 1) * (kObsH / halves);
-    const uint32_t* tab = s.prep.backdrops + backdrop * 128;
-    const uint32_t bg_col = tab[lane], bg_row = tab[64 + lane];
     const bool has_bullet = lane < n_bullets, has_draw = lane < n_draws;
     uint2 b3 = make_uint2(0u, 65536u), b4 = make_uint2(0u, 0u);
     const uint32_t* mine_at = s.prep.bullets + (size_t(env) * kBossShots + lane) * kBulletWords;
@@ -1297,7 +1308,18 @@ __global__ void __launch_bounds__(64, 5) render_kernel(State s, AtlasView atlas,
     draw.dy -= row_lo;
     constexpr int kOwnRows = kObsH / halves;
     PG_TL(1);
-    compose_background_from<kOwnRows, true>(fb, atlas, bg_col, bg_row, lane, half);
+    {   // the backdrop: a straight copy of this wave's 32 rows of its picture (8 KB, backdrop_kernel), memory to LDS without
+        // passing through registers — `buffer_load_dwordx4 … lds`: lane l's 16 bytes land at M0 + 16·l, 1 KB an instruction
+        using lds_ptr = __attribute__((address_space(3))) void*;
+        const __amdgpu_buffer_rsrc_t px_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint32_t*>(s.prep.backdrop_px + size_t(backdrop) * kFbWords + half * (kFbWords / halves)), 0,
+            kFbWords / halves * 4, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < kFbWords / halves / 4 / 64; k++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(px_rsrc, (lds_ptr)(fb + k * 256), 16, lane * 16, k * 1024, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the compiler does not track LDS-direct loads: the copy has landed)
+        wave_order();  // the copy, lane by lane, before the draws of other lanes on the same words
+    }
     PG_TL(2);
     const unsigned long long mb = __ballot(has_bullet), md = __ballot(has_draw);
     wave_replay_rows<PG_BOSSFIGHT_GROUP, true, true, PG_BOSSFIGHT_LONE, true, PG_BOSSFIGHT_QUARTERS>(fb, atlas, bullet, mb, lane, 0, kOwnRows, &box);  // (…, stamps: setup_kernel substitutes them; tiny draws four to a slot)
@@ -1506,7 +1528,8 @@ class BossfightGame final : public Game {
     static size_t up256(size_t b) { return (b + 255) & ~size_t(255); }
     size_t scratch_bytes(int n) const override {
         return up256(size_t(kBackdrops) * 128 * 4) + up256(size_t(n) * 4) + up256(size_t(n) * kBossShots * kBulletWords * 4) +
-               up256(size_t(n) * kPrepDraws * kBlitWords * 4) + up256(size_t(n) * kMtN * 4) + up256(size_t(n));
+               up256(size_t(n) * kPrepDraws * kBlitWords * 4) + up256(size_t(n) * kMtN * 4) + up256(size_t(n)) +
+               up256(size_t(kBackdrops) * kFbWords * 4);
     }
     void state_loaded() override {
         hipMemset(s_.mt_sel, 0, size_t(s_.n));  // the streams that were just loaded are in mt[env]; what was made ahead is not theirs
@@ -1528,6 +1551,8 @@ class BossfightGame final : public Game {
         s_.mt_other = reinterpret_cast<uint32_t*>(p);
         p += up256(size_t(n) * kMtN * 4);
         s_.mt_sel = p;  // (the engine zeroes the scratch block: every stream is at home, nothing is made ahead)
+        p += up256(size_t(n));
+        s_.prep.backdrop_px = reinterpret_cast<uint32_t*>(p);
     }
     // Same layout as oracle/pgo_bossfight.cpp Bossfight::dump_state.
     int dump_state(hipStream_t st, int env, float* out, int cap) override {
