@@ -1531,8 +1531,8 @@ class BossfightGame final : public Game {
                up256(size_t(n) * kPrepDraws * kBlitWords * 4) + up256(size_t(n) * kMtN * 4) + up256(size_t(n)) +
                up256(size_t(kBackdrops) * kFbWords * 4);
     }
-    void state_loaded() override {
-        hipMemset(s_.mt_sel, 0, size_t(s_.n));  // the streams that were just loaded are in mt[env]; what was made ahead is not theirs
+    void state_loaded(hipStream_t st) override {
+        hipMemsetAsync(s_.mt_sel, 0, size_t(s_.n), st);  // the streams that were just loaded are in mt[env]; what was made ahead is not theirs
     }
     // A snapshot takes the streams from mt[env]: the ones whose gang has moved on to the second buffer come home first.
     void prepare_save(hipStream_t st) override {

@@ -1610,9 +1610,9 @@ class ChaserGame final : public Game {
         return up256(size_t(2) * kCells * kBlitWords * 4) + up256(size_t(n) * kMovers * kBlitWords * 4) + up256(size_t(n) * 8 * 4) +
                up256(size_t(n) * kFbWords * 4) + up256(size_t(n) * kMtN * 4) + up256(size_t(n));
     }
-    void state_loaded() override {
+    void state_loaded(hipStream_t st) override {
         base_valid_ = false;
-        hipMemset(s_.mt_sel, 0, size_t(s_.n));  // the streams that were just loaded are in mt[env]; what was made ahead is not theirs
+        hipMemsetAsync(s_.mt_sel, 0, size_t(s_.n), st);  // the streams that were just loaded are in mt[env]; what was made ahead is not theirs
     }
     // A snapshot takes the streams from mt[env]: the ones whose gang has moved on to the second buffer come home first.
     void prepare_save(hipStream_t st) override {

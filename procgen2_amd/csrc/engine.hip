@@ -642,7 +642,7 @@ int32_t pgv_load_state(pgv_env* e, const void* h_buffer, int64_t size) {
     in += size_t(e->n);
     PG_HIP(hipMemcpy(e->d_obs, in, size_t(e->n) * pg::kObsBytes, hipMemcpyHostToDevice));
     e->step_index = hd.step_index;
-    e->game->state_loaded();
+    e->game->state_loaded(e->stream);  // (on the env's stream: ordered in front of the next step)
     pregen(e, true, true);  // queued shadow slots of the snapshot get their generator launch
     return 0;
 }

@@ -146,7 +146,7 @@ class Game {
 
     // Called after pgv_load_state has replaced the state blob: whatever a game derives from its state and keeps OUTSIDE the
     // blob (chaser: the base layer of every env's frame, pg chaser.hip) is stale from here on.
-    virtual void state_loaded() {}
+    virtual void state_loaded(hipStream_t st) { (void)st; }
 
     // Device memory a game's kernels hand results to each other through within one frame (the render pre-pass,
     // pg_prepass.h): allocated by the engine beside the state, never part of a snapshot.
