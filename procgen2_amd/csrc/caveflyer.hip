@@ -1147,6 +1147,8 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
     __shared__ ComposeLds<kGrid> L;
     const PrepMeta M{s.prep.meta + size_t(env) * kPrepMetaWords};
     const uint32_t colw = s.prep.axes[size_t(env) * 128 + lane], roww = s.prep.axes[size_t(env) * 128 + 64 + lane];
+    PG_TL_BEGIN(6);
+    PG_TL(0);
     const uint32_t kind_off = M.w[PM_KINDS + (lane & (kPrepKinds - 1))];
     const uint32_t two16 = reinterpret_cast<const uint16_t*>(s.prep.cells)[size_t(env) * (kGrid * kGrid / 2) + half * 64 + lane];
     const DescRegs descs = DescRegs::load(atlas, lane);
@@ -1191,7 +1193,9 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
         return;
     }
     const int row_lo = half * (kObsH / halves), row_hi = (half + 1) * (kObsH / halves);
+    PG_TL(1);
     compose_rows_from<kGrid, false, false>(fb, L, atlas, R, lane, flags, half, halves);
+    PG_TL(2);
     // one draw per lane in the reference's order: particles (common_systems.cpp:374-397: rotated, fading), the sprites the
     // pre-pass resolved, System_Agent::render (:291-327: bullets newest first, then the ship)
     const Camera cam{0.0f, 0.0f, 64.0f, 64.0f, 0.5f * 64.0f / 64.0f};  // (position: see below)
@@ -1233,8 +1237,11 @@ __global__ void __launch_bounds__(128, 4) render_kernel(State s, AtlasView atlas
 #ifndef PG_CAVEFLYER_QUARTERS
 #define PG_CAVEFLYER_QUARTERS false
 #endif
+    PG_TL(3);
     wave_replay_rows<4, true, true, 4, false, PG_CAVEFLYER_QUARTERS>(fb, atlas, mine, __ballot(has), lane, row_lo, row_hi);
+    PG_TL(4);
     wave_store_rows(fb, io.obs + size_t(env) * kObsBytes, lane, row_lo, row_hi);
+    PG_TL_END(6, true, io.obs + size_t(env) * kObsBytes + half * (kObsBytes / 2));
 }
 
 // cenv_render's frame (render_game(false)) for one env: pg_frame.h; the draw list of render_kernel, one draw at a time.

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where a wavefront of a render kernel spends its life.  A -DPG_TIMELINE build of the game (tools/build_exp.py GAME tl
--DPG_TIMELINE; chaser.hip, jumper.hip, coinrun.hip and bossfight.hip carry the stamps) reads s_memtime at the ends of its phases — after waiting for
+-DPG_TIMELINE; chaser.hip, jumper.hip, coinrun.hip, bossfight.hip and caveflyer.hip carry the stamps) reads s_memtime at the ends of its phases — after waiting for
 everything outstanding — and leaves the stamps in the first bytes of the rows it stored.  Prints the mean length of each
 phase per wave (upper / lower rows) in shader clocks and as a share of the wave's life.
 
@@ -21,6 +21,7 @@ PHASES = {
     "chaser": ["list + state loads", "base layer copy", "point stamps", "first pass: fetch + keep", "draws", "store"],
     "coinrun": ["hand-off loads, cell table", "first sprite texels requested", "row loop", "sprite replay", "store"],
     "bossfight": ["hand-off loads", "background", "boss bullets", "second list (ship, shield, shots, agent)", "store"],
+    "caveflyer": ["hand-off and state loads, cell table", "row loop", "draws resolved (one per lane)", "draw replay", "store"],
 }
 game, lib = sys.argv[1], sys.argv[2]
 names = PHASES[game]
