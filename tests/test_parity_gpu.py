@@ -79,6 +79,14 @@ def test_chaser_enemies_the_long_way(game_flags):
     assert resets > 0
 
 
+def test_bossfight_long_lockstep_over_many_changes_of_buffers():
+    """bossfight draws about six numbers a step, so an env's stream runs out every hundred steps or so and its gang
+    changes buffers (pg_gang.h GangRng::refill) — in both directions, with the next block made ahead by setup_kernel each
+    time, through in-step resets that draw from whichever buffer is current: 700 steps of 256 envs against the oracle."""
+    resets = _lockstep("bossfight", 256, 700, seed_base=31, run_seed=6, check_state_every=100)
+    assert resets > 0
+
+
 @pytest.mark.parametrize("game", ["bossfight", "chaser"])
 def test_plain_masked_reset_after_the_streams_changed_buffers(game):
     """bossfight's and chaser's random streams live in two buffers (pg_gang.h GangRng: a gang that runs out of numbers
