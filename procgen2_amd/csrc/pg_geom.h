@@ -61,6 +61,9 @@ constexpr int32_t kFlipH = 1 << 8;
 constexpr int32_t kFlipV = 1 << 9;
 constexpr int32_t kRotated = 1 << 10;
 constexpr int32_t kStamped = 1 << 11;  // the texture is a pre-scaled stamp (pg_stamps.h): texel (i, j) lands on pixel (i, j), s | a << 24
+// Where the list of a stamped, un-rotated, unflipped draw's visible texels is (word offset into the atlas): pg_stamps.h
+// stamp_substitute leaves it in the draw's source corner, which a stamp has no use for.
+PG_HD uint32_t stamp_list_at(const Blit& b) { return static_cast<uint32_t>(b.sx) | static_cast<uint32_t>(b.sy) << 16; }
 
 // One axis of a resolved draw: destination span [d0, d0+dn) and source span [s0, s0+sn).
 struct Span {

@@ -513,11 +513,11 @@ PG_D void wave_blit(uint32_t* fb, const AtlasView& atlas, const Blit& b, int lan
     const bool fh = (b.flip_mod & kFlipH) != 0, fv = (b.flip_mod & kFlipV) != 0;
     const bool stamped = kStamps && (b.flip_mod & kStamped) != 0;
     if (stamped && !fh && !fv) {
-        // A stamp comes with the list of its texels that show (pg_stamps.h append_stamps, stamp_list_at): lanes are dealt
+        // A stamp comes with the list of its texels that show (pg_stamps.h append_stamps, pg_geom.h stamp_list_at): lanes are dealt
         // over the entries of the stamp's rows that lie on my rows — no lane on a transparent texel (bossfight's shield is
         // a ring: 279 texels of 1 015), no sampling arithmetic, 8-byte loads side by side.  Same pixels: every texel that
         // shows is blended into its pixel once, the others never touched anything.
-        const uint32_t* rows = atlas.texels + (static_cast<uint32_t>(b.sx) | static_cast<uint32_t>(b.sy) << 16);
+        const uint32_t* rows = atlas.texels + stamp_list_at(b);
         const uint2* entries = reinterpret_cast<const uint2*>(rows + ((b.dh + 2) & ~1));
         const int r0 = y0 - b.dy, r1 = y1 - b.dy;
         const int begin = static_cast<int>(__builtin_amdgcn_readfirstlane(rows[r0])), end = static_cast<int>(__builtin_amdgcn_readfirstlane(rows[r1]));

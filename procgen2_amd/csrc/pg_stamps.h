@@ -86,7 +86,7 @@ inline uint32_t append_stamps(AtlasT& atlas, int n_tex, const std::vector<StampS
                     i1 = i + 1 > i1 ? i + 1 : i1, j1 = j + 1 > j1 ? j + 1 : j1;
                 }
         if (i1 == 0) i0 = j0 = j1 = 0;
-        // Behind the image (at the next even word: stamp_list_at), the stamp as a LIST of the texels that show, row by
+        // Behind the image (at the next even word), the stamp as a LIST of the texels that show, row by
         // row, for a big draw of it (pg_render.h wave_blit): core rows + 1 words — where each core row's entries start,
         // and where the last one's end —, padded to an even count, then {i − i0 | (j − j0) << 8, texel} per entry.  A ring
         // like bossfight's shield is 279 texels of 1 015.
@@ -155,7 +155,7 @@ PG_D bool stamp_substitute(const uint4* table, int tw, int th, Blit& b, int& cor
                     core_h = j1 - j0;
                 }
             } else if (!(b.flip_mod & (kFlipH | kFlipV))) {
-                // (… and where the stamp's list is, in the source rectangle's two free halves: stamp_list_at)
+                // (… and where the stamp's list is, in the source rectangle's two free halves: pg_geom.h stamp_list_at)
                 const uint32_t list = (e.x + static_cast<uint32_t>(b.dw * b.dh) + 1u) & ~1u;
                 b.sx = static_cast<int32_t>(list & 0xffffu);
                 b.sy = static_cast<int32_t>(list >> 16);
@@ -169,9 +169,6 @@ PG_D bool stamp_substitute(const uint4* table, int tw, int th, Blit& b, int& cor
     }
     return shows;
 }
-// Where the list of a stamped, un-rotated, unflipped draw is (word offset into the atlas; stamp_substitute left it in the
-// draw's source corner, which a stamp has no use for).
-PG_D uint32_t stamp_list_at(const Blit& b) { return static_cast<uint32_t>(b.sx) | static_cast<uint32_t>(b.sy) << 16; }
 PG_D bool stamp_substitute(const uint4* table, int tw, int th, Blit& b) {
     int cw, ch;
     return stamp_substitute(table, tw, th, b, cw, ch);
