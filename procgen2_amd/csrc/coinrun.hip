@@ -620,19 +620,49 @@ struct AgentSnap {  // agent + camera after one sub-step
 // decided by resolve_kernel (hazard_bits below) from hb: the left edge of the entity's hazard box after sub-step ss
 // (ss < limit), [4] its top edge — 1e30 for the coin, no hazard — and [5] its height.  kStore = false: the boxes only,
 // nothing written (resolve_kernel's fallback).
+// The entities that never move — saws and the coin — from their loaded inputs (x, y, anim_t, dyn of half 1 - dst): the
+// same writes and the same hazard box as ever; apart from entity_step so that logic_kernel's rows for them can ask memory
+// for several entities' inputs at once (static_rows below).
+template <bool kStore = true>
+PG_D void static_step(const State& s, int env, int e, int kind, int dst, int limit, float x, float y, float anim_t, int dyn,
+                      float (&hb)[6]) {
+    const float dt = 1.0f / 4;
+    if (kind == kCoin) {  // no dynamic state beyond the texture flag
+        if constexpr (kStore) {
+            DF(s, dst, DF_X, e, env) = x;
+            DB(s, dst, e, env) = static_cast<uint8_t>(dyn);
+        }
+        hb[0] = hb[1] = hb[2] = hb[3] = hb[5] = 0.0f;
+        hb[4] = 1e30f;
+        return;
+    }
+    hb[0] = hb[1] = hb[2] = hb[3] = x + -0.5f;  // tilemap.cpp:66: Box{x - 0.5, y - 0.5, 1, 1}
+    hb[4] = y + -0.5f;
+    hb[5] = 1.0f;
+#pragma unroll
+    for (int ss = 0; ss < 4; ss++) {
+        if (ss >= limit) break;
+        // System_Sprite_Render::update (common_systems.cpp:14-29), rate 1.0 (tilemap.cpp:60)
+        anim_t += dt;
+        const int adv = static_cast<int>(anim_t * 1.0f);
+        anim_t -= adv / 1.0f;
+        dyn = ((dyn & ~kDynFrame) | ((((dyn & kDynFrame) ? 1 : 0) + adv) % 2 ? kDynFrame : 0)) | kDynTexSet;
+    }
+    if constexpr (kStore) {
+        DF(s, dst, DF_X, e, env) = x;
+        DF(s, dst, DF_ANIM_T, e, env) = anim_t;
+        DB(s, dst, e, env) = static_cast<uint8_t>(dyn);
+    }
+}
+
 template <bool kStore = true>
 PG_D void entity_step(const State& s, int env, int e, int src, int limit, float (&hb)[6]) {
     const uint8_t* tiles = s.tiles + size_t(env) * (W * H);
     const int dst = 1 - src;
     const float dt = 1.0f / 4;
     const int kind = EB(s, EB_KIND, e, env);
-    if (kind == kCoin) {  // no dynamic state beyond the texture flag
-        if constexpr (kStore) {
-            DF(s, dst, DF_X, e, env) = DF(s, src, DF_X, e, env);
-            DB(s, dst, e, env) = DB(s, src, e, env);
-        }
-        hb[0] = hb[1] = hb[2] = hb[3] = hb[5] = 0.0f;
-        hb[4] = 1e30f;
+    if (kind == kCoin) {
+        static_step<kStore>(s, env, e, kind, dst, limit, DF(s, src, DF_X, e, env), 0.0f, 0.0f, DB(s, src, e, env), hb);
         return;
     }
     float x = DF(s, src, DF_X, e, env);
@@ -640,23 +670,7 @@ PG_D void entity_step(const State& s, int env, int e, int src, int limit, float 
     float anim_t = DF(s, src, DF_ANIM_T, e, env);
     int dyn = DB(s, src, e, env);
     if (kind == kSaw) {
-        hb[0] = hb[1] = hb[2] = hb[3] = x + -0.5f;  // tilemap.cpp:66: Box{x - 0.5, y - 0.5, 1, 1}
-        hb[4] = y + -0.5f;
-        hb[5] = 1.0f;
-#pragma unroll
-        for (int ss = 0; ss < 4; ss++) {
-            if (ss >= limit) break;
-            // System_Sprite_Render::update (common_systems.cpp:14-29), rate 1.0 (tilemap.cpp:60)
-            anim_t += dt;
-            const int adv = static_cast<int>(anim_t * 1.0f);
-            anim_t -= adv / 1.0f;
-            dyn = ((dyn & ~kDynFrame) | ((((dyn & kDynFrame) ? 1 : 0) + adv) % 2 ? kDynFrame : 0)) | kDynTexSet;
-        }
-        if constexpr (kStore) {
-            DF(s, dst, DF_X, e, env) = x;
-            DF(s, dst, DF_ANIM_T, e, env) = anim_t;
-            DB(s, dst, e, env) = static_cast<uint8_t>(dyn);
-        }
+        static_step<kStore>(s, env, e, kind, dst, limit, x, y, anim_t, dyn, hb);
         return;
     }
     // --- mob: System_Mob_AI (common_systems.cpp:65-105) + System_Particles (:284-313) + animation, rate 0.2
@@ -855,8 +869,9 @@ __global__ void __launch_bounds__(64) make_kernel(State s, uint32_t seed_base, i
 //     its pending byte, which the others only read and row 1 only ever turns from "due in this step" into "served in this
 //     step" — a reset either way (pg_prefetch.h resets_in_step);
 //   rows 2 + y — the entities.  One workgroup = one wavefront = a block of 64 envs.
-//     y ≥ kMaxEnt: lane = env, entity id y − kMaxEnt unless it is a mob (saws and coins: cheap, coalesced).
-//     y < kMaxEnt: the mobs.  Their path is ~5 000 instructions (tile window, two collision probes per
+//     y ≥ kMobRows: lane = env, entity ids kStaticPerLane · (y − kMobRows) … unless they are mobs (saws and coins: cheap,
+//     coalesced; four to a lane since round 6: the 36 rows of one were 36 864 wavefronts of three dependent round trips).
+//     y < kMobRows: the mobs.  Their path is ~5 000 instructions (tile window, two collision probes per
 //     sub-step, sparks) and a level has between none and a dozen of them, so "row y = the y-th mob of every env" ran
 //     that path max-over-the-block times with mostly idle lanes (SQ counters: 78 M wave instructions per launch, the
 //     kernel is issue-bound).  Instead the (env, mob) pairs of the block are numbered densely — a wave prefix sum over
@@ -869,6 +884,12 @@ __global__ void __launch_bounds__(64) make_kernel(State s, uint32_t seed_base, i
 #ifndef PG_COINRUN_LOGIC_WAVES
 #define PG_COINRUN_LOGIC_WAVES 4
 #endif
+#ifndef PG_COINRUN_STATIC_PER_LANE
+#define PG_COINRUN_STATIC_PER_LANE 4
+#endif
+constexpr int kStaticPerLane = PG_COINRUN_STATIC_PER_LANE;  // entity slots a lane of the saws' and coins' rows takes
+constexpr int kStaticRows = (kMaxEnt + kStaticPerLane - 1) / kStaticPerLane;
+constexpr int kMobRows = kMaxEnt;  // rows of 64 (env, mob) pairs a block of 64 envs is given: every entity of every env could be a mob
 __global__ void __launch_bounds__(64, PG_COINRUN_LOGIC_WAVES) logic_kernel(State s, const int32_t* actions, uint32_t run_seed, uint32_t step_index,
                                                    int env_offset, StepIO io, int prefetch, LevelPlan plan, int install_row,
                                                    float reach_x, float reach_y) {
@@ -898,8 +919,10 @@ __global__ void __launch_bounds__(64, PG_COINRUN_LOGIC_WAVES) logic_kernel(State
         return;
     }
     const int y = row - 2;
-    int e;
-    if (y < kMaxEnt) {
+    if (y < kMobRows) {
+        // (Measured and rejected, round 6: twelve rows that stride on over the pairs instead of 36 of which nine in ten find
+        // nothing — the loop around the mob's path alone, never taken twice, made the kernel 47.6 -> 52.0 µs with 36 rows,
+        // and sixteen rows instead of 36 were worth 0.7 µs: the empty rows cost next to nothing.)
         const int count = stepping ? SI(s, I_NMOB, env) : 0;
         int upto = count;  // inclusive prefix sum over the block
 #pragma unroll
@@ -921,22 +944,49 @@ __global__ void __launch_bounds__(64, PG_COINRUN_LOGIC_WAVES) logic_kernel(State
         const int before = __shfl(upto, lo) - __shfl(count, lo);
         if (pair >= total) return;
         env = blockIdx.x * 64 + lo;
-        e = EB(s, EB_SPARK_ORDER, pair - before, env);
+        const int e = EB(s, EB_SPARK_ORDER, pair - before, env);
+        // the agent's start, for hazard_near (row 0 writes neither: resolve_kernel does)
+        const float ax0 = SF(s, F_AX, env), ay0 = SF(s, F_AY, env);
+        const int src = (SI(s, I_FLAGS, env) & kFlagBuf) ? 1 : 0;
+        float hb[6];
+        entity_step(s, env, e, src, 4, hb);
+        if (hazard_near(hb, ax0, ay0, reach_x, reach_y)) {
+            s.hazx[size_t(e) * s.n + env] = float4{hb[0], hb[1], hb[2], hb[3]};
+            s.hazy[size_t(e) * s.n + env] = float2{hb[4], hb[5]};
+            atomicOr(&SCI(s, SC_CAND + (e >> 5), env), 1 << (e & 31));
+        }
     } else {
+        // saws and the coin: kStaticPerLane entity slots a lane, everything they need asked for at once (the slots beyond
+        // the env's count read slot kMaxEnt - 1 and write nothing) — a quarter of the wavefronts, one chain of round trips
         if (!stepping) return;
-        e = y - kMaxEnt;
-        if (e >= SI(s, I_NENT, env)) return;
-        if (EB(s, EB_KIND, e, env) == kMob) return;
-    }
-    // the agent's start, for hazard_near (row 0 writes neither: resolve_kernel does)
-    const float ax0 = SF(s, F_AX, env), ay0 = SF(s, F_AY, env);
-    const int src = (SI(s, I_FLAGS, env) & kFlagBuf) ? 1 : 0;
-    float hb[6];
-    entity_step(s, env, e, src, 4, hb);
-    if (hazard_near(hb, ax0, ay0, reach_x, reach_y)) {
-        s.hazx[size_t(e) * s.n + env] = float4{hb[0], hb[1], hb[2], hb[3]};
-        s.hazy[size_t(e) * s.n + env] = float2{hb[4], hb[5]};
-        atomicOr(&SCI(s, SC_CAND + (e >> 5), env), 1 << (e & 31));
+        const int n_ent = SI(s, I_NENT, env);
+        const int e0 = (y - kMobRows) * kStaticPerLane;
+        if (e0 >= n_ent) return;
+        const float ax0 = SF(s, F_AX, env), ay0 = SF(s, F_AY, env);
+        const int src = (SI(s, I_FLAGS, env) & kFlagBuf) ? 1 : 0;
+        int kind[kStaticPerLane], dyn[kStaticPerLane];
+        float x[kStaticPerLane], ey[kStaticPerLane], anim_t[kStaticPerLane];
+#pragma unroll
+        for (int k = 0; k < kStaticPerLane; k++) {
+            const int ek = e0 + k < kMaxEnt ? e0 + k : kMaxEnt - 1;
+            kind[k] = EB(s, EB_KIND, ek, env);
+            x[k] = DF(s, src, DF_X, ek, env);
+            ey[k] = EY(s, ek, env);
+            anim_t[k] = DF(s, src, DF_ANIM_T, ek, env);
+            dyn[k] = DB(s, src, ek, env);
+        }
+#pragma unroll
+        for (int k = 0; k < kStaticPerLane; k++) {
+            const int ek = e0 + k;
+            if (ek >= n_ent || kind[k] == kMob) continue;
+            float hb[6];
+            static_step(s, env, ek, kind[k], 1 - src, 4, x[k], ey[k], anim_t[k], dyn[k], hb);
+            if (hazard_near(hb, ax0, ay0, reach_x, reach_y)) {
+                s.hazx[size_t(ek) * s.n + env] = float4{hb[0], hb[1], hb[2], hb[3]};
+                s.hazy[size_t(ek) * s.n + env] = float2{hb[4], hb[5]};
+                atomicOr(&SCI(s, SC_CAND + (ek >> 5), env), 1 << (ek & 31));
+            }
+        }
     }
 }
 
@@ -1855,7 +1905,7 @@ class CoinrunGame final : public Game {
         const int served = reset_served_mark(step_index), due = reset_due_mark(step_index);
         if (!fused) LevelLaunch<Gen>::auto_reset(st, s_, prefetch(), io, plan, PG_RESET_SPAN, served, due);
         // agents, prefetched installs and entities side by side (logic_kernel)
-        const dim3 blocks((s_.n + 63) / 64, 2 + 2 * kMaxEnt);
+        const dim3 blocks((s_.n + 63) / 64, 2 + kMobRows + kStaticRows);
         // (bit 24: no reach — the tests' way to resolve_kernel's fallback, see hazard_near)
         const float reach_x = (debug_flags & kDebugCoinrunNoReach) ? 0.0f : kReachX;
         const float reach_y = (debug_flags & kDebugCoinrunNoReach) ? 0.0f : kReachY;
