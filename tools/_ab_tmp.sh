@@ -1,19 +1,19 @@
 cd /tmp && export TMPDIR=/tmp
 export GPU_MAX_HW_QUEUES=16
 R=$GRAFT_REPO_ROOT
-for rep in 1 2; do
-for L in now nosparks; do
-  if [ $L = now ]; then A=""; else A="--lib $R/procgen2_amd/lib/libpg_exp_$L.so"; fi
+G=${PG_GAME:-jumper}
+for L in $@; do
+  if [ $L = now ]; then A=""; elif [ $L = r05 ]; then A="--lib $R/procgen2_amd/lib_ref/libprocgen2_hip_r05.so"; else A="--lib $R/procgen2_amd/lib/libpg_exp_$L.so"; fi
   rm -rf /tmp/kq
-  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kq -- python3 $R/tools/perf_quick.py --games coinrun --check 0x0 --settle 300 --steps 200 $A > /tmp/kq.log 2>&1
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kq -- python3 $R/tools/perf_quick.py --games $G --check 0x0 --settle 300 --steps 200 $A > /tmp/kq.log 2>&1
   f=$(ls /tmp/kq/*/*kernel_stats.csv | head -1)
-  python3 - "$f" $L <<'PY'
+  python3 - "$f" $L $G <<'PY'
 import csv, sys
 out=[]
 for r in csv.DictReader(open(sys.argv[1])):
     n=r["Name"]
     for k in ("logic_kernel","resolve_kernel","setup_kernel","render_kernel"):
-        if k in n and "coinrun" in n: out.append("%s %.1f"%(k.split('_')[0], float(r["AverageNs"])/1e3))
+        if k in n and sys.argv[3] in n: out.append("%s %.1f"%(k.split('_')[0], float(r["AverageNs"])/1e3))
 print(sys.argv[2], " ".join(sorted(out)))
 PY
-done; done
+done
