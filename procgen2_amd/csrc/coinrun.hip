@@ -35,6 +35,7 @@
 #include "pg_prepass.h"
 #include "pg_render.h"
 #include "pg_rng.h"
+#include "pg_tiles.h"  // collide_any
 
 namespace pg {
 namespace PG_VARIANT_NS {
@@ -484,6 +485,7 @@ struct TileWin {
         }
         return w;
     }
+    PG_D int cell(int dx, int dy) const { return static_cast<int>((bits >> (3 * (dx + 4 * dy))) & 7u); }  // inside the window
     PG_D int at(int x, int y) const {
         const unsigned dx = static_cast<unsigned>(x - ax), dy = static_cast<unsigned>(y - ay);
         if (dx < 4u && dy < 4u) return static_cast<int>((bits >> (3 * (dx + 4 * dy))) & 7u);
@@ -507,18 +509,7 @@ struct Hit {
     bool any;
 };
 
-// get_collision_overlap (pg_geom.h box_overlap) without its early return: the same values through selects.
-PG_D Box box_overlap_flat(const Box& a, const Box& b) {
-    const bool hit = (a.x < b.x + b.w) & (a.x + a.w > b.x) & (a.y < b.y + b.h) & (a.y + a.h > b.y);
-    const float ddx = fabsf(a.x - b.x), ddy = fabsf(a.y - b.y);
-    const bool left = a.x <= b.x, top = a.y <= b.y;
-    float w = (left ? a.w : b.w) - ddx, h = (top ? a.h : b.h) - ddy;
-    const float wcap = a.w > b.w ? b.w : a.w, hcap = a.h > b.h ? b.h : a.h;
-    w = w >= wcap ? wcap : w;
-    h = h >= hcap ? hcap : h;
-    return Box{hit ? (left ? b.x : a.x) : 0.0f, hit ? (top ? b.y : a.y) : 0.0f, hit ? w : 0.0f, hit ? h : 0.0f};
-}
-
+// (box_overlap_flat — get_collision_overlap without its early return — is pg_tiles.h's)
 template <class Pred>
 PG_D Hit collide(const TileWin& win, Box r, Pred solid, bool fallthrough, float step_y) {
     bool any = false;
@@ -691,10 +682,21 @@ PG_D void entity_step(const State& s, int env, int e, int src, int limit, float 
         x += vx * dt;
         const Box wall_probe{x - 0.5f, y - 0.6f, 1.0f, 0.5f};
         const Box floor_probe{x - 0.5f, y + 0.6f, 1.0f, 0.5f};
-        const Hit wall = collide(
-            win, wall_probe, [](int t) { return (t == kWallMid || t == kWallTop) ? kFull : kPass; }, false, 0.0f);
-        const Hit gap = collide(
-            win, floor_probe, [](int t) { return t == kEmpty ? kFull : kPass; }, false, 0.0f);
+        // A probe that touches nothing comes back as it went (collide moves the box only where it takes a cell), and whether
+        // it touches anything is collide_any's question (see the agent's lava probe): the walk itself — two passes over nine
+        // cells — is made only in the sub-steps where some mob of the wavefront does turn round (round 6; a mob meets a
+        // wall or an edge once in a few hundred sub-steps).  A probe outside the window takes the walk, which looks cells up
+        // wherever they are.
+        const bool wall_maybe = !win.holds(wall_probe) ||
+                                pg::collide_any(win, wall_probe, [](int t) { return t == kWallMid || t == kWallTop; });
+        const bool gap_maybe = !win.holds(floor_probe) || pg::collide_any(win, floor_probe, [](int t) { return t == kEmpty; });
+        Hit wall{wall_probe.x, wall_probe.y, false}, gap{floor_probe.x, floor_probe.y, false};
+        if (__ballot(wall_maybe))  // (wave-uniform)
+            wall = collide(
+                win, wall_probe, [](int t) { return (t == kWallMid || t == kWallTop) ? kFull : kPass; }, false, 0.0f);
+        if (__ballot(gap_maybe))
+            gap = collide(
+                win, floor_probe, [](int t) { return t == kEmpty ? kFull : kPass; }, false, 0.0f);
         float nx = wall.x + 0.5f;
         if (gap.any) nx = gap.x + 0.5f;
         x = nx;
@@ -827,8 +829,11 @@ PG_D void agent_substeps(const State& s, int env, int action, float reach_x, flo
         if (ground) avy = 0.0f;
 
         if (!win.holds(b)) win = TileWin::around(tiles, b, avx, avy);
-        const Hit lv = collide(
-            win, b, [](int t) { return (t == kLavaMid || t == kLavaTop) ? kFull : kPass; }, false, 0.0f);
+        // the lava probe is only asked WHETHER (common_systems.cpp:221-229): `any` is "some scanned lava cell has a non-empty
+        // overlap with the box as it came" — the first cell taken is met by the box unmoved, and either pass takes every
+        // such cell — which pg_tiles.h collide_any works out per axis, without the walk (round 6: a quarter of this lane's
+        // instructions)
+        const bool in_lava = pg::collide_any(win, b, [](int t) { return t == kLavaMid || t == kLavaTop; });
 
         phase += 0.1f * dt;
         phase = fmodf(phase, 1.0f);
@@ -843,7 +848,7 @@ PG_D void agent_substeps(const State& s, int env, int action, float reach_x, flo
         SC(s, SC_AVX + ss, env) = avx;
         SC(s, SC_AVY + ss, env) = avy;
         SC(s, SC_PHASE + ss, env) = phase;
-        bits |= (ground ? 1 << ss : 0) | (forward ? 1 << (4 + ss) : 0) | (lv.any ? 1 << (8 + ss) : 0) |
+        bits |= (ground ? 1 << ss : 0) | (forward ? 1 << (4 + ss) : 0) | (in_lava ? 1 << (8 + ss) : 0) |
                 (box_hit(b, coin_box) ? 1 << (12 + ss) : 0);
     }
     SCI(s, SC_BITS, env) = bits | (stayed ? 0 : kBitsFar);
