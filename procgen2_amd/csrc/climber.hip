@@ -390,12 +390,34 @@ PG_D void advance(const State& s, StepLds& L, Q q, int env, int action, float& r
         const Box body{ax + -0.5f, ay + -1.0f, 1.0f, 1.0f};
         if (ss == 0 || !awin.holds(body)) awin = Win::around(tiles, body, avx, avy);
 
-        // --- the colliders, kGang per pass: the agent, then the mobs (common_systems.cpp:109-168; order-free per entity)
+        // --- the agent's get_collision: the same box in every lane of the gang, so the walk's nine cells go side by side
+        // (pg_tiles.h collide_plain_gang8; until round 6 the agent was lane 0 of the mobs' pass and every lane walked)
         bool dead = false;
         Box agent{0.0f, 0.0f, 1.0f, 1.0f};
-        for (int c0 = 0; c0 < 1 + n_mobs; c0 += kGang) {
-            const int c = c0 + q.g, m = c - 1;
-            const bool is_agent = c == 0, is_mob = c >= 1 && c <= n_mobs;
+        {
+            static_assert(kGang == 8, "collide_plain_gang8");
+            const TileHit h = collide_plain_gang8(q, awin, body, is_wall);
+            const float moved_x = h.x - body.x, moved_y = h.y - body.y;
+            ground = moved_y < 0.0f && h.any;
+            ax = h.x - -0.5f;
+            ay = h.y - -1.0f;
+            if (moved_x != 0.0f) avx = 0.0f;
+            if (ground) avy = 0.0f;
+            camy = (ay - 8 - 0.5f) * kUnitPx;
+            phase += 0.1f * dt;
+            phase = fmodf(phase, 1.0f);
+            if (move_x > 0.0f)
+                forward = true;
+            else if (move_x < 0.0f)
+                forward = false;
+            agent = Box{ax + -0.5f, ay + -1.0f, 1.0f, 1.0f};
+        }
+        // --- the mobs, kGang per pass (common_systems.cpp:109-168; order-free per entity).  A probe that touches nothing
+        // comes back as it went, and whether it touches anything is collide_any's question: the walk is made only in the
+        // passes where some mob of the wavefront meets a wall (as coinrun's mobs; a probe outside its window walks).
+        for (int m0 = 0; m0 < n_mobs; m0 += kGang) {
+            const int m = m0 + q.g;
+            const bool is_mob = m < n_mobs;
             float x = 0.0f, vx = 0.0f, y = 0.0f;
             Box probe = body;
             Win win = awin;
@@ -408,24 +430,9 @@ PG_D void advance(const State& s, StepLds& L, Q q, int env, int action, float& r
                 win = Win{tiles, L.m_ax[m], L.m_ay[m], L.m_win[m]};
             }
             TileHit h{probe.x, probe.y, false};
-            if (is_agent | is_mob) h = collide_plain<true>(win, probe, is_wall);
-            if (c0 == 0) {  // the rest of the agent's update, from lane 0's result
-                const float hx = __shfl(h.x, 0, kGang), hy = __shfl(h.y, 0, kGang);
-                const bool any = __shfl(h.any ? 1 : 0, 0, kGang) != 0;
-                const float moved_x = hx - body.x, moved_y = hy - body.y;
-                ground = moved_y < 0.0f && any;
-                ax = hx - -0.5f;
-                ay = hy - -1.0f;
-                if (moved_x != 0.0f) avx = 0.0f;
-                if (ground) avy = 0.0f;
-                camy = (ay - 8 - 0.5f) * kUnitPx;
-                phase += 0.1f * dt;
-                phase = fmodf(phase, 1.0f);
-                if (move_x > 0.0f)
-                    forward = true;
-                else if (move_x < 0.0f)
-                    forward = false;
-                agent = Box{ax + -0.5f, ay + -1.0f, 1.0f, 1.0f};
+            const bool maybe = is_mob && (!win.holds(probe) || collide_any(win, probe, is_wall));
+            if (__ballot(maybe)) {  // (wave-uniform; measured: never walking 56 µs, always 104, this way 96 — of the ≈ 60 mobs of a pass one usually does touch)
+                if (is_mob) h = collide_plain<true>(win, probe, is_wall);
             }
             bool bitten = false;
             if (is_mob) {

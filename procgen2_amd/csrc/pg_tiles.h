@@ -244,4 +244,65 @@ PG_D TileHit collide_plain(const Win& win, Box r, Pred solid) {
     return {r.x, r.y, any};
 }
 
+// collide_plain<true> for a box that every lane of a gang of eight holds alike (the env's own body, pg_gang.h): the nine
+// cells of a pass are looked at SIDE BY SIDE instead of one after the other.  The walk is sequential only through the
+// box — a cell that is taken moves it, and the cells behind are held against the moved box — so: lane k judges cell k
+// against the box as it stands; the first cell that takes (a ballot) is exactly the one the walk would take next, since
+// none before it did and the box has not moved since they were judged; it moves the box, and the cells behind it are
+// judged again.  A pass ends when nobody takes: one round more than it has takes — one or two for a body that rests on
+// a floor, against nine steps.  The ninth cell, the last of the walk, is judged by every lane once the eight are settled.
+// Same cells, same order, same arithmetic; `q`: Gang<8>.  (caveflyer's ship, round 6: the walk was 31 of its logic
+// kernel's 102 µs — every lane of the gang doing all of it.)
+template <class Q, class Win, class Pred>
+PG_D TileHit collide_plain_gang8(const Q& q, const Win& win, Box r, Pred solid) {
+    const int x0 = static_cast<int>(floorf(r.x)), y0 = static_cast<int>(floorf(r.y));
+    const int x1 = static_cast<int>(ceilf(r.x + r.w)), y1 = static_cast<int>(ceilf(r.y + r.h));
+    if (!((x1 - x0 <= 2) & (y1 - y0 <= 2) & (x0 >= win.ax) & (y0 >= win.ay) & (x1 < win.ax + 4) & (y1 < win.ay + 4)))
+        return collide_plain<true>(win, r, solid);  // (gang-uniform: the box is)
+    const float mid_x = r.x + r.w * 0.5f, mid_y = r.y + r.h * 0.5f;
+    const int wx = x0 - win.ax, wy = y0 - win.ay;
+    bool any = false;
+    // cell k of the walk against box `at`: does it take, and where does it put the box (y in the first pass, x in the second)
+    auto judge = [&](int k, const Box& at, bool second, float& put) {
+        const int dy = k / 3, dx = k - 3 * dy;
+        const bool in = (x0 + dx <= x1) & (y0 + dy <= y1);
+        const int ox_ = in ? dx : 0, oy_ = in ? dy : 0;  // (a cell past the box: look at the first one, ignore it)
+        const bool is_solid = solid(win.cell(wx + ox_, wy + oy_));
+        const Box cell{static_cast<float>(x0 + ox_), static_cast<float>(y0 + oy_), 1.0f, 1.0f};
+        const Box o = box_overlap_flat(at, cell);
+        const bool some = in & is_solid & !((o.w == 0.0f) & (o.h == 0.0f));
+        put = second ? (o.x + o.w * 0.5f > mid_x ? cell.x - at.w : cell.x + cell.w)
+                     : (o.y + o.h * 0.5f > mid_y ? cell.y - at.h : cell.y + cell.h);
+        return some & (second ? (o.w <= o.h) : (o.w > o.h));
+    };
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        const bool second = pass == 1;
+        int settled = 0;  // cells below this one have had their say
+        for (;;) {        // (gang-uniform)
+            float put;
+            const bool take = (q.g >= settled) & judge(q.g, r, second, put);
+            const uint32_t takers = q.ballot(take);
+            if (takers == 0u) break;
+            const int first = __ffs(takers) - 1;
+            const float moved = __shfl(put, first, 8);
+            if (second)
+                r.x = moved;
+            else
+                r.y = moved;
+            any = true;
+            settled = first + 1;
+        }
+        float put;
+        if (judge(8, r, second, put)) {
+            if (second)
+                r.x = put;
+            else
+                r.y = put;
+            any = true;
+        }
+    }
+    return {r.x, r.y, any};
+}
+
 }  // namespace pg
