@@ -1,3 +1,9 @@
+#!/bin/bash
+# usage: PG_GAME=jumper tools/kstats_libs.sh now r05 EXP_TAG ...      (GPU box)
+# Per-kernel average durations (rocprofv3 --kernel-trace --stats) of a short steady-state run of one game through
+# tools/perf_quick.py, once per named library, seconds apart on one box: `now` = the tree's own build, `r05` =
+# procgen2_amd/lib_ref/libprocgen2_hip_r05.so, anything else = procgen2_amd/lib/libpg_exp_<tag>.so (tools/build_exp.py).
+# The logic kernels' A/B of round 6's second half (static rows, jumper's sub-steps, the gang walk) were taken with it.
 cd /tmp && export TMPDIR=/tmp
 export GPU_MAX_HW_QUEUES=16
 R=$GRAFT_REPO_ROOT
