@@ -1302,6 +1302,9 @@ __global__ void __launch_bounds__(128, PG_RENDER_WAVES) render_kernel(State s, A
             sh = compass_size * 0.15f * game_zoom;
         }
         has = resolve_screen_at(d.y, d.z, d.x, sx, sy, sw, sh, sn, cs, mine);
+        // (the bar's rectangle starts at y = 69 of the 64-pixel observation, always: a draw that is not rotated and lies
+        // wholly beyond the target reaches no pixel — raster rule S5 — and need not be replayed to find that out)
+        if (!(mine.flip_mod & kRotated) && (mine.dy >= kObsH || mine.dx >= kObsW || mine.dy + mine.dh <= 0 || mine.dx + mine.dw <= 0)) has = false;
     }
     PG_TL(3);
     if (s.hud_image != 0u) {
@@ -1311,8 +1314,23 @@ __global__ void __launch_bounds__(128, PG_RENDER_WAVES) render_kernel(State s, A
         PG_TL(4);
         overlay_rows(fb, atlas.texels + s.hud_image, reinterpret_cast<const uint2*>(atlas.texels + s.hud_list), lane, row_lo);
         PG_TL(5);
-        // (the needle is 82 of this kernel's 514 µs, 74 of them its scan: five or more texels a lane in flight instead of four change nothing or spill)
-        wave_replay_rows(fb, atlas, mine, __ballot(has && lane > n_draws), lane, row_lo, row_hi);
+        // The needle (82 of this kernel's 514 µs, 74 of them its scan; five or more texels a lane in flight instead of four
+        // change nothing or spill) lies in the lower half of the frame nearly always, and a frame is done when its slower
+        // wavefront is: so it is the one draw the two wavefronts SHARE — every other 64 pixels of its scan each, on either
+        // half's rows, between two barriers (the ring under it complete, the bar over it not begun).
+        {
+            const unsigned long long drawn = __ballot(has);
+            __syncthreads();
+            if ((drawn >> (n_draws + 1)) & 1ull) {  // (workgroup-uniform: both wavefronts resolved the same draws)
+                const Blit needle = blit_from_lane(blit_pack(mine), mine, n_draws + 1);
+                if (needle.flip_mod & kRotated)
+                    wave_blit_rotated(fb, atlas, needle, rot_box(needle), lane + 64 * half, 64 * halves);
+                else
+                    wave_blit(fb, atlas, needle, lane, half, halves);
+            }
+            __syncthreads();
+            if (drawn & (1ull << (n_draws + 2))) wave_replay_rows(fb, atlas, mine, drawn & (1ull << (n_draws + 2)), lane, row_lo, row_hi);
+        }
         PG_TL(6);
     } else {
         wave_replay_rows(fb, atlas, mine, __ballot(has), lane, row_lo, row_hi);

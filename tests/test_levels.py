@@ -155,6 +155,7 @@ def test_engine_one_level_means_one_first_frame_at_scale():
     """4096 maze envs on one level: every env's every episode starts with the same frame (mazes time out at 500)."""
     from engine_util import EngineVec
     n = 4096
+    register_textures("maze")  # (_fresh_make_obs goes to the oracle directly: not only when an earlier test has done this)
     eng = EngineVec("maze", n, seed_base=1, num_levels=1, start_level=77)
     first = eng.reset().copy()
     assert (first == first[0]).all()
