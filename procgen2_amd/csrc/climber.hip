@@ -822,7 +822,7 @@ __global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView 
         const int cnt_a = on_a ? S.env[ea].n_draw + 1 : 0, cnt_b = on_b ? S.env[eb].n_draw + 1 : 0;
         uint32_t* const draws_a = out.draws + size_t(env0 + ea) * kPrepDraws * kBlitWords;
         uint32_t* const draws_b = out.draws + size_t(env0 + eb) * kPrepDraws * kBlitWords;
-        PrepDrawPass st{0, {0, 0}};
+        PrepDrawPass st{0, {0, 0}, {0, 0}};
         PrepDrawQueue& Q = S.queue[wave];
         for (int base = 0; base < cnt_a + cnt_b; base += 64) {  // wave-uniform
             const int q = base + lane;

@@ -116,6 +116,7 @@ struct State {
     int float_abs;         // game_flags PGV_JUMPER_FLOAT_ABS (D21)
     // the compass ring as it lands on the observation (extend_atlas; word offsets into the atlas, 0 = not prepared)
     uint32_t hud_image, hud_list;
+    uint32_t hud_under;  // 64 × 2 words: bit x of pair y = the ring's picture has an opaque texel at pixel (x, y) (pg_render.h compose_rows_from UNDER)
     uint32_t hud_cover;  // 64 words: the columns of each pixel row the ring's opaque texels overwrite (pg_prepass.h `cover`)
     PrepOut prep;  // what setup_kernel leaves for render_kernel (pg_prepass.h); not part of the state blob
     uint32_t* fat;  // [1 + n]  number of frames the pre-pass left to the complete path, then their envs (render_full_kernel)
@@ -968,7 +969,7 @@ PG_D void render_full(const State& s, const AtlasView& atlas, const StepIO& io, 
 // ring is a prepared overlay, needle and bar are raw screen-space draws without a division (jumper.cpp:473-509).
 // ------------------------------------------------------------------------------------------------
 constexpr int kPrepEnvs = 8, kPrepThreads = 256;
-enum { GW_NEEDLE_X = 0, GW_NEEDLE_Y, GW_BAR_W, GW_NEEDLE_SN, GW_NEEDLE_CS };  // PM_GAME words
+enum { GW_NEEDLE_X = 0, GW_NEEDLE_Y, GW_BAR_W, GW_NEEDLE_SN, GW_NEEDLE_CS, GW_TOUCH };  // PM_GAME words (GW_TOUCH: a kept draw reaches into the compass disc's box, pg_prepass.h PrepDrawPass::touch)
 
 struct PrepEnv {
     int32_t sflags, n_draw;
@@ -1122,7 +1123,7 @@ __global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView 
         const int cnt_a = on_a ? kPuffs + S.env[ea].n_draw + 1 : 0, cnt_b = on_b ? kPuffs + S.env[eb].n_draw + 1 : 0;
         uint32_t* const draws_a = out.draws + size_t(env0 + ea) * kPrepDraws * kBlitWords;
         uint32_t* const draws_b = out.draws + size_t(env0 + eb) * kPrepDraws * kBlitWords;
-        PrepDrawPass st{0, {0, 0}};
+        PrepDrawPass st{0, {0, 0}, {0, 0}};
         PrepDrawQueue& Q = S.queue[wave];
         // everything drawn here lies beneath the compass ring, which is opaque over two thirds of the frame: what lands
         // wholly under it — the bunny, nearly always — is not handed to the render wave at all
@@ -1198,6 +1199,8 @@ __global__ void __launch_bounds__(kPrepThreads) setup_kernel(State s, AtlasView 
         if (lane == 0) {  // (the compass's needle and bar take two more lanes of the render wave)
             S.counts[ea] = st.done[0] > kPrepDraws - 3 ? kPrepDraws + 1 : st.done[0];
             S.counts[eb] = st.done[1] > kPrepDraws - 3 ? kPrepDraws + 1 : st.done[1];
+            P.meta[ea][PM_GAME + GW_TOUCH] = (cover == nullptr || st.touch[0]) ? 1u : 0u;
+            P.meta[eb][PM_GAME + GW_TOUCH] = (cover == nullptr || st.touch[1]) ? 1u : 0u;
         }
     }
     __syncthreads();
@@ -1268,10 +1271,25 @@ __global__ void __launch_bounds__(128, PG_RENDER_WAVES) render_kernel(State s, A
     PG_TL(1);
     if (M.fat()) return;  // (wave-uniform; render_full_kernel has drawn it)
     const int row_lo = half * (kObsH / halves), row_hi = (half + 1) * (kObsH / halves);
-    if (M.flags() & 2u)
+    // (what the compass disc is going to cover is not fetched: pg_render.h compose_rows_from UNDER)
+#ifndef PG_JUMPER_UNDER
+#define PG_JUMPER_UNDER 2
+#endif
+    uint32_t ring_rows = 0xffffffffu;  // the rows of this wave's 32 whose covered pixels do not hold the ring's texels yet
+    if (PG_JUMPER_UNDER && s.hud_image != 0u && s.hud_under != 0u) {
+        const unsigned long long* under = reinterpret_cast<const unsigned long long*>(atlas.texels + s.hud_under);
+        uint32_t whole = 0xffffffffu;
+        if (M.flags() & 2u)
+            compose_rows_from<kGrid, true, false, true>(fb, L, atlas, R, lane, flags, half, halves, under, s.hud_image * 4u, &whole);
+        else
+            compose_rows_from<kGrid, false, false, true>(fb, L, atlas, R, lane, flags, half, halves, under, s.hud_image * 4u, &whole);
+        // … and none of the frame's draws has been near them (setup_kernel, GW_TOUCH): the ring's opaque part is there already
+        if (PG_JUMPER_UNDER > 1 && M.w[PM_GAME + GW_TOUCH] == 0u) ring_rows = whole;
+    } else if (M.flags() & 2u) {
         compose_rows_from<kGrid, true, false>(fb, L, atlas, R, lane, flags, half, halves);
-    else
+    } else {
         compose_rows_from<kGrid, false, false>(fb, L, atlas, R, lane, flags, half, halves);
+    }
     PG_TL(2);
     // the compass (jumper.cpp:473-509) behind the resolved draws: lanes n_draws, + 1, + 2 = circle, needle, bar — raw
     // screen-space draws whose parameters the logic kernel worked out (store_compass)
@@ -1312,7 +1330,7 @@ __global__ void __launch_bounds__(128, PG_RENDER_WAVES) render_kernel(State s, A
         // draw order — after the bunny, before the needle and the bar
         wave_replay_rows(fb, atlas, mine, __ballot(has && lane < n_draws), lane, row_lo, row_hi);
         PG_TL(4);
-        overlay_rows(fb, atlas.texels + s.hud_image, reinterpret_cast<const uint2*>(atlas.texels + s.hud_list), lane, row_lo);
+        overlay_rows(fb, atlas.texels + s.hud_image, reinterpret_cast<const uint2*>(atlas.texels + s.hud_list), lane, row_lo, ring_rows);
         PG_TL(5);
         // The needle (82 of this kernel's 514 µs, 74 of them its scan; five or more texels a lane in flight instead of four
         // change nothing or spill) lies in the lower half of the frame nearly always, and a frame is done when its slower
@@ -1553,11 +1571,28 @@ class JumperGame final : public Game {
             seen = 1, prev_lo = lo, prev_hi = hi;
             cover[y] = static_cast<uint32_t>(lo) | (static_cast<uint32_t>(hi) << 8);
         }
+        {   // word kObsH: the bounding box of everything opaque (pg_prepass.h PrepDrawPass::touch)
+            int bx0 = 255, bx1 = 0, by0 = 255, by1 = 0;
+            for (int y = 0; y < kObsH; y++)
+                for (int x = 0; x < kObsW; x++)
+                    if (image[size_t(y) * kObsW + x] != 0u) {
+                        bx0 = x < bx0 ? x : bx0, bx1 = x > bx1 ? x : bx1;
+                        by0 = y < by0 ? y : by0, by1 = y > by1 ? y : by1;
+                    }
+            cover.push_back(static_cast<uint32_t>(bx0) | static_cast<uint32_t>(bx1) << 8 | static_cast<uint32_t>(by0) << 16 | static_cast<uint32_t>(by1) << 24);
+        }
         if ((atlas.texel_bytes() / 4) % 2 != 0) atlas.append_words({0u});  // the list is read as 8-byte pairs
         s_.hud_cover = shaped && seen ? atlas.append_words(cover) : 0u;
         if ((atlas.texel_bytes() / 4) % 2 != 0) atlas.append_words({0u});
         s_.hud_image = atlas.append_words(image);
         s_.hud_list = atlas.append_words(list);
+        // … and the pixels its opaque texels cover, a 64-bit mask per pixel row (pg_render.h compose_rows_from UNDER)
+        std::vector<uint32_t> under(size_t(kObsH) * 2, 0u);
+        for (int y = 0; y < kObsH; y++)
+            for (int x = 0; x < kObsW; x++)
+                if ((image[size_t(y) * kObsW + x] >> 24) == 255u) under[size_t(y) * 2 + (x >> 5)] |= 1u << (x & 31);
+        if ((atlas.texel_bytes() / 4) % 2 != 0) atlas.append_words({0u});
+        s_.hud_under = atlas.append_words(under);
     }
     bool set_game_flags(uint32_t flags) override {  // include/procgen2_vec.h PGV_JUMPER_FLOAT_ABS
         s_.float_abs = (flags & PGV_JUMPER_FLOAT_ABS) ? 1 : 0;

@@ -482,12 +482,16 @@ struct PrepDraw {
 struct PrepDrawPass {
     int queued;          // entries waiting in the worklist
     int done[2];         // draws stored so far, per env of the wave
+    int touch[2];        // `cover` only: some draw that was kept reaches into the covered part's bounding box (cover[kObsH])
 };
 // The tails of everything queued, ranks, stores.  desc: the atlas descriptor table (in LDS); cam: the two envs' cameras.
 // `cover` (optional): what a later, OPAQUE part of every frame hides — per pixel row y a word lo | hi << 8, the columns
 // [lo, hi] that part overwrites (lo > hi: none), valley- / hill-shaped over the rows, so that a rectangle whose first and
 // last row lie inside lies inside altogether.  A draw that lands wholly under it is dropped here: nobody sees it.
-// (jumper's compass disc covers two thirds of the 64×64 frame, the bunny at its centre included.)
+// (jumper's compass disc covers two thirds of the 64×64 frame, the bunny at its centre included.)  Word kObsH of the table
+// is the covered part's bounding box, x_lo | x_hi << 8 | y_lo << 16 | y_hi << 24: whether any draw that is KEPT reaches into
+// it is noted in st.touch — a frame none of whose draws does has nothing between its tile layer and the covering part
+// that could have written on a covered pixel (pg_render.h compose_rows_from UNDER, overlay_rows).
 // `stamps` (optional): the game's stamp table, kStampsPerTex entries per texture (pg_stamps.h) — a draw that takes its whole
 // texture at a size a stamp exists for is stored with the stamp as its texture.
 PG_D void prep_draws_flush(PrepDrawQueue& Q, PrepDrawPass& st, const int4* desc, const Camera& cam_a, const Camera& cam_b,
@@ -525,6 +529,7 @@ PG_D void prep_draws_flush(PrepDrawQueue& Q, PrepDrawPass& st, const int4* desc,
         has = has && axis_tail(cam.sw, cam.scale, d.y, en.scale, (en.misc >> 8) & 1u, AxisHead{en.dx, en.dlx}, x);
         has = has && axis_tail(cam.sh, cam.scale, d.z, en.scale, false, AxisHead{en.dy, en.dly}, y);
     }
+    bool touches = false;
     if (cover != nullptr && has) {  // (the part of the destination on the target: the rest is dropped anyway, raster spec S5)
         const int x0 = x.d0 < 0 ? 0 : x.d0, x1 = x.d0 + x.dn - 1 > kObsW - 1 ? kObsW - 1 : x.d0 + x.dn - 1;
         const int y0 = y.d0 < 0 ? 0 : y.d0, y1 = y.d0 + y.dn - 1 > kObsH - 1 ? kObsH - 1 : y.d0 + y.dn - 1;
@@ -533,7 +538,14 @@ PG_D void prep_draws_flush(PrepDrawQueue& Q, PrepDrawPass& st, const int4* desc,
             const int lo_t = static_cast<int>(top & 0xffu), lo_b = static_cast<int>(bottom & 0xffu);
             const int hi_t = static_cast<int>((top >> 8) & 0xffu), hi_b = static_cast<int>((bottom >> 8) & 0xffu);
             if (x0 >= (lo_t > lo_b ? lo_t : lo_b) && x1 <= (hi_t < hi_b ? hi_t : hi_b)) has = false;
+            const uint32_t box = cover[kObsH];
+            touches = has && x0 <= static_cast<int>((box >> 8) & 0xffu) && x1 >= static_cast<int>(box & 0xffu) &&
+                      y0 <= static_cast<int>(box >> 24) && y1 >= static_cast<int>((box >> 16) & 0xffu);
         }
+    }
+    if (cover != nullptr) {  // (wave-uniform)
+        if (__ballot(touches && !is_b)) st.touch[0] = 1;
+        if (__ballot(touches && is_b)) st.touch[1] = 1;
     }
     const unsigned long long m_a = __ballot(has && !is_b), m_b = __ballot(has && is_b);
     const unsigned long long below = (1ull << lane) - 1ull;

@@ -1049,19 +1049,36 @@ PG_D void wave_replay_rows(uint32_t* fb, const AtlasView& atlas, const Blit& min
 // (the list walked in a loop was a round trip per 64 entries, both halves' entries by both waves: 5 000 -> ? clocks).
 // Same pixels as wave_replay_rows of the draw (raster spec S1–S4).  row_lo: 0 or 32.
 constexpr int kOverlayPerLane = 2;
-PG_D void overlay_rows(uint32_t* fb, const uint32_t* image, const uint2* list, int lane, int row_lo) {
+// `rows` (wave-uniform): bit r = the opaque texels of row row_lo + r are still to be written; a row whose covered pixels
+// hold them already (compose_rows_from UNDER put them there and no draw has been near since) is left out — all 32 of them
+// in most frames, and then the picture is not even loaded: only the translucent texels' list remains.  Eight rows a group.
+PG_D void overlay_rows(uint32_t* fb, const uint32_t* image, const uint2* list, int lane, int row_lo, uint32_t rows = 0xffffffffu) {
     constexpr int kRows = kObsH / 2;  // (the contract with the callers and with whoever made the list: a wave owns HALF the frame's rows)
     static_assert(kObsH == 64 && kRows == 32, "overlay_rows: the list is split per half frame of 32 rows");
-    uint32_t t[kRows];
     uint2 item[kOverlayPerLane];
 #pragma unroll
-    for (int k = 0; k < kRows; k++) t[k] = image[(row_lo + k) * kObsW + lane];
-#pragma unroll
     for (int k = 0; k < kOverlayPerLane; k++) item[k] = list[(row_lo ? kOverlayPerLane * 64 : 0) + k * 64 + lane];
-    wave_order();
+    if (rows == 0xffffffffu) {
+        uint32_t t[kRows];
 #pragma unroll
-    for (int k = 0; k < kRows; k++)
-        if (t[k] >= 0xff000000u) fb[(row_lo + k) * kObsW + lane] = t[k];
+        for (int k = 0; k < kRows; k++) t[k] = image[(row_lo + k) * kObsW + lane];
+        wave_order();
+#pragma unroll
+        for (int k = 0; k < kRows; k++)
+            if (t[k] >= 0xff000000u) fb[(row_lo + k) * kObsW + lane] = t[k];
+    } else {
+        wave_order();
+#pragma unroll
+        for (int g = 0; g < kRows / 8; g++) {
+            if (((rows >> (8 * g)) & 0xffu) == 0u) continue;  // (wave-uniform)
+            uint32_t t[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) t[k] = image[(row_lo + 8 * g + k) * kObsW + lane];
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (t[k] >= 0xff000000u) fb[(row_lo + 8 * g + k) * kObsW + lane] = t[k];
+        }
+    }
 #pragma unroll
     for (int k = 0; k < kOverlayPerLane; k++)
         if (item[k].x != 0xffffffffu) blend_into(fb, static_cast<int>(item[k].x), item[k].y, 255);
@@ -1395,9 +1412,10 @@ struct ComposeRegs {
     uint32_t col_pa, col_pb;                 // BOX: column offsets in the boxed texture
     unsigned long long second_row, soft, hard;
 };
-template <int GRID, bool TWO, bool BOX>
+template <int GRID, bool TWO, bool BOX, bool UNDER = false>
 PG_D bool compose_rows_from(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView& atlas, const ComposeRegs& R, int lane,
-                            int ablate, int half, int halves);
+                            int ablate, int half, int halves, const unsigned long long* under = nullptr, uint32_t under_image = 0u,
+                            uint32_t* whole_rows = nullptr);
 
 template <int GRID, bool TWO = false, bool BOX = false, bool PREP = false>
 PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView& atlas, const BgAxis& bga, int cols, int rows,
@@ -1438,8 +1456,10 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
         R.col_pb = h2.y;
     }
     auto mask64 = [&](int k) {
-        return static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(K.masks[2 * k])) |
-               (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(K.masks[2 * k + 1])) << 32);
+        // (through uint32_t: the builtin returns int, and a low word with bit 31 set would fill the high one with ones —
+        // which only ever made the complete path's masks too generous: more rows than need be judged soft or two-rowed)
+        return static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(K.masks[2 * k]))) |
+               (static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(K.masks[2 * k + 1]))) << 32);
     };
     R.second_row = mask64(0);
     R.soft = PREP && bg_w != 0 ? ~0ull : mask64(1);
@@ -1453,9 +1473,19 @@ PG_D bool compose_rows(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView&
 // hand-over tables the two waves have just built in the frame target's memory (compose_rows above), or unpacked from what
 // a pre-pass kernel left in device memory (pg_prepass.h).  The cell table L.base must be complete and visible (a barrier
 // behind its staging is the caller's); nothing else of L is read.
-template <int GRID, bool TWO, bool BOX>
+// UNDER (jumper's compass disc): `under[py]` = the pixels of row py that an opaque texel of a picture drawn over every
+// frame — 64 × 64 words at byte `under_image` of the atlas, the same for every env — is going to cover whatever lies
+// beneath.  The one-texel attempt fetches THAT texel for them instead of the layer's: the pixel ends up the same (the
+// overlay writes the same word again when its turn in the draw order comes, over whatever a sprite left there in
+// between), the row's other pixels are judged as ever (the stand-in is opaque), and what is not fetched is the backdrop
+// under two thirds of the frame — a scattered texel a pixel, 600 MB a launch of a kernel that runs at the memory's rate.
+// A row that takes the general form is composed whole, as ever.
+template <int GRID, bool TWO, bool BOX, bool UNDER>
 PG_D bool compose_rows_from(uint32_t* fb, const ComposeLds<GRID>& L, const AtlasView& atlas, const ComposeRegs& R, int lane,
-                            int ablate, int half, int halves) {
+                            int ablate, int half, int halves, const unsigned long long* under, uint32_t under_image,
+                            uint32_t* whole_rows) {
+    // (whole_rows, UNDER's companion: bit r = row r of this wave's 32 went through the general form, i.e. was composed
+    // whole — its covered pixels hold what lies beneath, not the stand-in — wave-uniform)
     // All texel reads go through one buffer descriptor over the atlas: 32-bit byte offsets, and out-of-range
     // (= "no candidate") reads return 0 without a branch.
     // (`ablate` bits 5/6 are timing experiments: a descriptor with zero records drops every load through it.)
@@ -1631,6 +1661,7 @@ PG_D bool compose_rows_from(uint32_t* fb, const ComposeLds<GRID>& L, const Atlas
     static_assert(kRows % kBatch == 0, "");
     if (halves != 2) return false;  // (every render kernel runs two wavefronts per env)
     const uint32_t hards = PG_ABL(ablate, 16384) ? 0u : static_cast<uint32_t>(hard >> py_begin);  // this wave's 32 rows
+    if (whole_rows != nullptr) *whole_rows = 0xffffffffu;
     if (bg_mod != 255 || hards == 0xffffffffu) {  // nothing worth attempting
         for (int py0 = py_begin; py0 < py_begin + kRows; py0 += kGen) {
             int py_of[kGen];
@@ -1642,6 +1673,12 @@ PG_D bool compose_rows_from(uint32_t* fb, const ComposeLds<GRID>& L, const Atlas
         return true;
     }
     const uint32_t seconds32 = static_cast<uint32_t>(second_row >> py_begin);
+    // (UNDER: the masks of this wave's 32 rows are read as CONSTANT memory — scalar loads, the mask straight into the scalar
+    // pair the select takes; as a vector load handed round with cross-lane reads they were four instructions a row, and
+    // the kernel lost what the fetches saved)
+    using under_ptr = const __attribute__((address_space(4))) unsigned long long*;
+    const under_ptr under_rows = UNDER ? (under_ptr)(reinterpret_cast<unsigned long long>(under + py_begin)) : (under_ptr)0;
+    const uint32_t under_lane = under_image + static_cast<uint32_t>(py_begin * kObsW * 4) + static_cast<uint32_t>(lane) * 4u;
     // The gathers land straight in the target: `buffer_load … lds` writes lane l's dword to LDS at M0 + 4·l, which is
     // exactly pixel (row, l) of a row-major target — no result registers (32 of them otherwise, the kernel's register
     // peak), no stores.  Out-of-range lanes write 0 (checked on the hardware: tools/probe/lds_direct_load.hip).
@@ -1673,6 +1710,11 @@ PG_D bool compose_rows_from(uint32_t* fb, const ComposeLds<GRID>& L, const Atlas
     for (int g = 0; g < kRows / kBatch; g++) {
         uint32_t cell_aa[kBatch], cell_ab[kBatch], cell_ba[kBatch], cell_bb[kBatch];
         uint32_t box_aa[BOX ? kBatch : 1], box_ab[BOX ? kBatch : 1];
+        unsigned long long covered[UNDER ? kBatch : 1];
+        if (UNDER) {  // (the batch's eight masks leave with its cell words)
+#pragma unroll
+            for (int k = 0; k < kBatch; k++) covered[k] = under_rows[g * kBatch + k];
+        }
 #pragma unroll
         for (int k = 0; k < kBatch; k++) {
             const int py = py_begin + g * kBatch + k;
@@ -1719,6 +1761,13 @@ PG_D bool compose_rows_from(uint32_t* fb, const ComposeLds<GRID>& L, const Atlas
                     continue;
                 }
             }
+            if (UNDER) {  // (the row's mask as a scalar pair: one select on it, one add for the stand-in's address)
+                const int r = g * kBatch + k;
+                const uint32_t stand_in = under_lane + static_cast<uint32_t>(r * kObsW * 4);
+                uint32_t chosen;
+                asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(chosen) : "v"(at), "v"(stand_in), "s"(covered[k]));
+                at = chosen;
+            }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(atlas_rsrc, (lds_ptr)(fb + py * kObsW), 4, static_cast<int>(at), 0, 0, 0);
         }
     }
@@ -1751,6 +1800,7 @@ PG_D bool compose_rows_from(uint32_t* fb, const ComposeLds<GRID>& L, const Atlas
         if (PG_ABL(ablate, 4096)) todo = 0xffu;
         if (!PG_ABL(ablate, 8192)) todo32 |= todo << (g * kBatch);  // (bit 13: never)
     }
+    if (whole_rows != nullptr) *whole_rows = todo32;
     while (todo32 != 0u) {  // wave-uniform: the rows that go through the general form, kGen at a time
         int py_of[kGen];
         uint32_t bits = 0;
