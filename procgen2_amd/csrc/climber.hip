@@ -412,9 +412,9 @@ PG_D void advance(const State& s, StepLds& L, Q q, int env, int action, float& r
                 forward = false;
             agent = Box{ax + -0.5f, ay + -1.0f, 1.0f, 1.0f};
         }
-        // --- the mobs, kGang per pass (common_systems.cpp:109-168; order-free per entity).  A probe that touches nothing
-        // comes back as it went, and whether it touches anything is collide_any's question: the walk is made only in the
-        // passes where some mob of the wavefront meets a wall (as coinrun's mobs; a probe outside its window walks).
+        // --- the mobs, kGang per pass (common_systems.cpp:109-168; order-free per entity).  Their walk skips the cells no
+        // mob of the wavefront meets (pg_tiles.h PG_WALK_SKIP: 96 -> 88 µs); a whether-test in front of it as in coinrun
+        // (collide_any) then buys nothing more here — of the ≈ 60 mobs of a pass one usually does touch — and is not made.
         for (int m0 = 0; m0 < n_mobs; m0 += kGang) {
             const int m = m0 + q.g;
             const bool is_mob = m < n_mobs;
@@ -430,10 +430,7 @@ PG_D void advance(const State& s, StepLds& L, Q q, int env, int action, float& r
                 win = Win{tiles, L.m_ax[m], L.m_ay[m], L.m_win[m]};
             }
             TileHit h{probe.x, probe.y, false};
-            const bool maybe = is_mob && (!win.holds(probe) || collide_any(win, probe, is_wall));
-            if (__ballot(maybe)) {  // (wave-uniform; measured: never walking 56 µs, always 104, this way 96 — of the ≈ 60 mobs of a pass one usually does touch)
-                if (is_mob) h = collide_plain<true>(win, probe, is_wall);
-            }
+            if (is_mob) h = collide_plain<true>(win, probe, is_wall);
             bool bitten = false;
             if (is_mob) {
                 int info = L.m_info[m];

@@ -533,6 +533,9 @@ PG_D Hit collide(const TileWin& win, Box r, Pred solid, bool fallthrough, float 
                 const int kind = solid(static_cast<int>((win.bits >> (3 * ((wx + ox_) + 4 * (wy + oy_)))) & 7u));
                 cell.x = static_cast<float>(x0 + ox_);
                 cell.y = static_cast<float>(y0 + oy_);
+#if PG_WALK_SKIP
+                if (__ballot(in & (kind != kPass) & box_hit(r, cell)) == 0) continue;  // (pg_tiles.h: a cell nobody's box meets takes nobody)
+#endif
                 const Box o = box_overlap_flat(r, cell);
                 const float oy = o.y + o.h * 0.5f;
                 const bool inside = (r.y + r.h - step_y > cell.y);
@@ -551,6 +554,9 @@ PG_D Hit collide(const TileWin& win, Box r, Pred solid, bool fallthrough, float 
                 const int kind = solid(static_cast<int>((win.bits >> (3 * ((wx + ox_) + 4 * (wy + oy_)))) & 7u));
                 cell.x = static_cast<float>(x0 + ox_);
                 cell.y = static_cast<float>(y0 + oy_);
+#if PG_WALK_SKIP
+                if (__ballot(in & (kind != kPass) & box_hit(r, cell)) == 0) continue;
+#endif
                 const Box o = box_overlap_flat(r, cell);
                 const float ox = o.x + o.w * 0.5f;
                 const bool take = in & (kind != kPass) & !((o.w == 0.0f) & (o.h == 0.0f)) & (o.w <= o.h) & (kind != kOneWay);

@@ -173,6 +173,14 @@ PG_D bool collide_any(const Win& win, const Box& r, Pred solid) {
     return any;
 }
 
+// PG_WALK_SKIP: a step of the flat walk is skipped — wave-uniformly — when no lane's box meets a solid cell there: whoever
+// takes a cell meets it (strictly: get_collision_overlap is all zeros otherwise), so the walk's results are the same, and
+// of the eighteen steps of a walk most find nobody: the row under a mob's probe is floor for every mob and met by none.
+// climber's logic kernel 96.2 -> 87.7 µs, coinrun's 43.8 -> 42.3 (its own variant A walk has the same line), jumper's and
+// caveflyer's unchanged (a lane per env / the gang walk).  0: every step, as before.
+#ifndef PG_WALK_SKIP
+#define PG_WALK_SKIP 1
+#endif
 // kFlat: see below — pays where boxes are a tile in size (climber −2 %), not where they are bullets (caveflyer +2 %).
 template <bool kFlat = false, class Win, class Pred>
 PG_D TileHit collide_plain(const Win& win, Box r, Pred solid) {
@@ -196,6 +204,9 @@ PG_D TileHit collide_plain(const Win& win, Box r, Pred solid) {
                 const bool is_solid = solid(win.cell(wx + ox_, wy + oy_));
                 cell.x = static_cast<float>(x0 + ox_);
                 cell.y = static_cast<float>(y0 + oy_);
+#if PG_WALK_SKIP
+                if (__ballot(in & is_solid & box_hit(r, cell)) == 0) continue;
+#endif
                 const Box o = box_overlap_flat(r, cell);
                 const bool take = in & is_solid & !((o.w == 0.0f) & (o.h == 0.0f)) & (o.w > o.h);
                 r.y = take ? (o.y + o.h * 0.5f > mid_y ? cell.y - r.h : cell.y + cell.h) : r.y;
@@ -210,6 +221,9 @@ PG_D TileHit collide_plain(const Win& win, Box r, Pred solid) {
                 const bool is_solid = solid(win.cell(wx + ox_, wy + oy_));
                 cell.x = static_cast<float>(x0 + ox_);
                 cell.y = static_cast<float>(y0 + oy_);
+#if PG_WALK_SKIP
+                if (__ballot(in & is_solid & box_hit(r, cell)) == 0) continue;
+#endif
                 const Box o = box_overlap_flat(r, cell);
                 const bool take = in & is_solid & !((o.w == 0.0f) & (o.h == 0.0f)) & (o.w <= o.h);
                 r.x = take ? (o.x + o.w * 0.5f > mid_x ? cell.x - r.w : cell.x + cell.w) : r.x;
