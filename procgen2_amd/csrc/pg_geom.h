@@ -188,6 +188,25 @@ PG_HD int rot_extent(int along, int across, int acs, int asn) {
 PG_HD int rot_first(int dn, int extent) { return (dn - extent) >> 1; }
 PG_HD int rot_last(int dn, int extent) { return (dn - 1 + extent) >> 1; }
 
+// Raster spec S6, THIN rectangles (dw ≥ 3·dh: jumper's needle, 30 × 6).  Of a pixel row Y of the target only a short run of
+// columns can map back between the rectangle's long edges: with px = 2(X − dx) + 1 − dw, py = 2(Y − dy) + 1 − dh the row
+// coordinate ly = −px·sn + (py·cs + dh·2^16) must lie in [0, 2·dh·2^16) — a linear condition on px with slope −sn, met over
+// L = dh·2^16 / |sn| pixels, (A, A + L] say.  thin_run_start gives a column at or left of floor(A) − 2 … floor(A): A in
+// floats — the quantities are integers below 2^25, the quotient below a few thousand for |sn| ≥ 4096, so the float result
+// is within 0.01 of A — rounded down, less one; thin_run_width gives floor(L) + 5 columns from there, which reach
+// floor(A) + floor(L) + 1 ≥ floor(A + L), the run's last column, from wherever the start landed.  Every pixel raster spec
+// S6 draws on row Y lies in [start, start + width): swept on the host against the exact 64-bit test
+// (tests/cpp/test_primitives.cpp test_thin_runs).  pg_render.h wave_blit_rotated scans those runs instead of the rows of
+// the bounding box.  (m = 2·dh·2^16 and inv = 1 / sn as floats, worked out once per draw.)
+PG_HD int thin_run_width(int dh, int asn) { return (dh * 65536) / asn + 5; }
+PG_HD int thin_run_start(int dx, int dy, int dw, int dh, int cs, float m, float inv, int Y) {
+    const int qy = 2 * (Y - dy) + 1 - dh;
+    const float c = static_cast<float>(qy * (cs >> 4)) * 16.0f + static_cast<float>(qy * (cs & 15)) +
+                    static_cast<float>(dh) * 65536.0f;  // qy·cs + dh·2^16 (|qy| < 2^9, |cs| ≤ 2^16: the parts are exact)
+    const float p_min = fminf((c - m) * inv, c * inv);
+    return dx + static_cast<int>(floorf((p_min + static_cast<float>(dw - 1)) * 0.5f)) - 1;  // X = dx + (px + dw − 1) / 2
+}
+
 // Raster spec S3: nearest texel for destination column/row `i` of `n`, over `len` texels from `start`.
 // floor(a / b) for 0 <= a < 2^22, 1 <= b < 2^22.  On the device: one reciprocal estimate and a ±1 fix-up
 // instead of the ~30-instruction generic 32-bit division (a and b are exact in float, the estimate is off

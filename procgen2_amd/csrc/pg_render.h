@@ -416,21 +416,17 @@ PG_D void wave_blit_rotated(uint32_t* fb, const AtlasView& atlas, const Blit& b,
     const int mod = blend_key(b.flip_mod);
     const bool stamped = kStamps && (b.flip_mod & kStamped) != 0;  // (wave-uniform: texel (i, j) itself)
     // A THIN rectangle (jumper's needle, 30 × 6) fills a fraction of its bounding box — a sixth at 45° — and every pixel of
-    // the box costs the whole inverse map before it is found outside.  Of a pixel row of the box only a short run can map
-    // back between the rectangle's long edges: ly = −px·sn + (py·cs + dh·2^16) must lie in [0, 2·dh·2^16), a linear
-    // condition on px with slope −sn, met over dh·2^16 / |sn| pixels.  So the box is scanned as bh rows of that width
-    // (+ 5: the run's ends rounded outwards and a whole pixel to spare on either side), each from its own start, which a
-    // lane works out for its row in floats: the quantities are integers below 2^24 and the quotient is below a few
-    // thousand, so the float result is within 0.001 of the exact bound, against the pixel to spare.  A superset of the
-    // row's drawn pixels, and any superset gives the same frame: every pixel scanned still takes the exact integer test
-    // below.  (Round 6; a flat needle, whose runs are as wide as the box, and every rectangle that is not thin take the
-    // plain scan.)
+    // the box costs the whole inverse map before it is found outside.  Of a pixel row only a short run of columns can map
+    // back between the rectangle's long edges (pg_geom.h thin_run_start / thin_run_width: a superset of the row's drawn
+    // pixels, swept on the host), so the box is scanned as bh rows of that width, each from its own start — and any
+    // superset gives the same frame: every pixel scanned still takes the exact integer test below.  (Round 6; a flat
+    // needle, whose runs are as wide as the box, and every rectangle that is not thin take the plain scan.)
     int row_w = bw;
     float run_inv = 0.0f, run_m = 0.0f;
     {
         const int asn = b.rot_sn < 0 ? -b.rot_sn : b.rot_sn;
         if (b.dw >= 3 * b.dh && asn >= 4096) {  // (wave-uniform)
-            const int w = (b.dh * 65536) / asn + 5;
+            const int w = thin_run_width(b.dh, asn);
             if (w < bw) {
                 row_w = w;
                 run_inv = 1.0f / static_cast<float>(b.rot_sn);
@@ -453,13 +449,8 @@ PG_D void wave_blit_rotated(uint32_t* fb, const AtlasView& atlas, const Blit& b,
             const int off = p - ry * row_w;
             const int Y = y_lo + ry;
             int X = x_lo + off;
-            if (runs) {  // the first column of this row's run (see above), not left of the box
-                const int qy = 2 * (Y - b.dy) + 1 - b.dh;
-                const float c = static_cast<float>(qy * (b.rot_cs >> 4)) * 16.0f + static_cast<float>(qy * (b.rot_cs & 15)) +
-                                static_cast<float>(b.dh) * 65536.0f;  // qy·cs + dh·2^16 (|qy| < 2^8, |cs| ≤ 2^16: the parts are exact)
-                const float p_min = fminf((c - run_m) * run_inv, c * run_inv);
-                // px = 2(X − dx) + 1 − dw  ⇒  X = dx + (px + dw − 1) / 2
-                const int xa = b.dx + static_cast<int>(floorf((p_min + static_cast<float>(b.dw - 1)) * 0.5f)) - 1;
+            if (runs) {  // the first column of this row's run, not left of the box
+                const int xa = thin_run_start(b.dx, b.dy, b.dw, b.dh, b.rot_cs, run_m, run_inv, Y);
                 X = (xa < x_lo ? x_lo : xa) + off;
                 if (X >= x_lo + bw) continue;
             }

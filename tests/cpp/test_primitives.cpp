@@ -476,6 +476,50 @@ static void test_rot_box() {
     std::printf("OK rot box (%ld cases, %ld drawn pixels, all inside; %ld within a pixel a side of what is drawn)\n", cases, drawn, tight);
 }
 
+// pg_geom.h thin_run_start / thin_run_width: every pixel raster spec S6 draws of a THIN rotated rectangle on target row Y
+// lies in [start, start + width) — the runs pg_render.h wave_blit_rotated scans instead of the rows of the bounding box.
+// The exact 64-bit inside test over every pixel within the rectangle's reach, rectangles 9..64 long and 1..dw/3 high
+// (jumper's needle is 30 × 6) at 1 500 angles and their 16.16 sines off by one unit either way, corners on and far off
+// the target.
+static void test_thin_runs() {
+    long drawn = 0, cases = 0, slack = 0, rows = 0;
+    for (int k = 0; k < 1500; k++) {
+        const double deg = k < 360 ? k : (k * 0.2345678 - 180.0);
+        const float theta = static_cast<float>(deg * (3.14159265358979323846 / 180.0));
+        const int sn0 = static_cast<int>(std::floor(static_cast<double>(std::sin(theta)) * 65536.0 + 0.5));
+        const int cs0 = static_cast<int>(std::floor(static_cast<double>(std::cos(theta)) * 65536.0 + 0.5));
+        for (int v = 0; v < 3; v++) {
+            const int sn = sn0 + (v == 1 ? 1 : (v == 2 ? -1 : 0)), cs = cs0 + (v == 2 ? 1 : 0);
+            const int asn = sn < 0 ? -sn : sn;
+            if (asn < 4096) continue;  // (wave_blit_rotated takes the plain scan)
+            const int dw = 9 + (k * 7 + v) % 56, dh = 1 + (k * 5 + v) % (dw / 3);
+            const int dx = -40 + (k * 11) % 120, dy = -40 + (k * 17) % 140;
+            const int width = pg::thin_run_width(dh, asn);
+            const float m = static_cast<float>(2 * dh) * 65536.0f, inv = 1.0f / static_cast<float>(sn);
+            const int reach = dw + dh + 4;
+            cases++;
+            for (int Y = dy - reach; Y <= dy + dh + reach; Y++) {
+                const int start = pg::thin_run_start(dx, dy, dw, dh, cs, m, inv, Y);
+                int lo = 1 << 30, hi = -(1 << 30);
+                for (int X = dx - reach; X <= dx + dw + reach; X++) {
+                    const long long px = 2 * (X - dx) + 1 - dw, py = 2 * (Y - dy) + 1 - dh;
+                    const long long lx = px * cs + py * sn + static_cast<long long>(dw) * 65536;
+                    const long long ly = -px * sn + py * cs + static_cast<long long>(dh) * 65536;
+                    if (lx < 0 || ly < 0 || lx >= static_cast<long long>(2 * dw) * 65536 || ly >= static_cast<long long>(2 * dh) * 65536) continue;
+                    drawn++;
+                    lo = X < lo ? X : lo, hi = X > hi ? X : hi;
+                    CHECK(X >= start && X < start + width, "a drawn pixel outside its row's run: %dx%d at (%d,%d) sn %d cs %d pixel (%d,%d) run %d..%d", dw, dh,
+                          dx, dy, sn, cs, X, Y, start, start + width - 1);
+                }
+                if (lo <= hi) rows++, slack += width - (hi - lo + 1);
+            }
+        }
+    }
+    CHECK(drawn > 500000 && cases > 3000, "the sweep must draw something (%ld pixels, %ld rectangles)", drawn, cases);
+    std::printf("OK thin runs (%ld rectangles, %ld drawn pixels, all inside their row's run; %.1f spare columns a row)\n", cases, drawn,
+                rows ? static_cast<double>(slack) / rows : 0.0);
+}
+
 // pg_geom.h span_nested — the rule by which a tile layer's second, shorter texture (the brown theme's 64×53 cap over 64×64
 // bodies: jumper at zoom 0.3, climber at 0.2) may share the composer's per-pixel-row candidates with the first.  Swept
 // over 400 000 camera heights per zoom with render_texture's own arithmetic (resolve_axis, y axis): whenever the rule
@@ -513,6 +557,7 @@ static void test_span_nested() {
 int main() {
     test_axis_template();
     test_rot_box();
+    test_thin_runs();
     test_span_nested();
     test_sincos();
     test_atan2();
